@@ -1,0 +1,198 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of the CPU oracle (oracle/vf_oracle.c).
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this package.  The product (``visfly_amd``) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvf_oracle.so")
+
+ROWS = 28
+POS, QUAT, VEL, OMG, MOT, THR, AACC, ACC, T = 0, 3, 7, 10, 13, 17, 21, 24, 27
+
+
+class Consts(C.Structure):
+    """mirror of vfo_consts (oracle/vf_oracle.h)"""
+    _fields_ = [
+        ("action_type", C.c_int32), ("integrator", C.c_int32),
+        ("interval_steps", C.c_int32), ("delay_steps", C.c_int32),
+        ("ctrl_delay", C.c_int32), ("pad0", C.c_int32),
+        ("dt", C.c_float), ("ctrl_dt", C.c_float),
+        ("m", C.c_float), ("g_z", C.c_float),
+        ("J", C.c_float * 9), ("Jinv", C.c_float * 9),
+        ("JP", C.c_float * 9), ("Dm", C.c_float * 9),
+        ("B", C.c_float * 16), ("Binv", C.c_float * 16),
+        ("c_motor", C.c_float), ("one_minus_c", C.c_float),
+        ("tm0", C.c_float), ("tm1", C.c_float), ("tm2", C.c_float),
+        ("rot_scale", C.c_float), ("rot_neg_tm1", C.c_float),
+        ("rot_tm1sq", C.c_float), ("rot_4tm0", C.c_float),
+        ("T_min", C.c_float), ("T_max", C.c_float),
+        ("acc_half", C.c_float), ("acc_mean", C.c_float),
+        ("rate_half", C.c_float), ("rate_mean", C.c_float),
+        ("k_lin", C.c_float * 3), ("k_quad", C.c_float * 3),
+        ("wind", C.c_float * 3),
+        ("pos_xy_lim", C.c_float), ("pos_z_lo", C.c_float), ("pos_z_hi", C.c_float),
+        ("vel_lim", C.c_float), ("omg_lim", C.c_float),
+        ("T_init", C.c_float), ("w_init", C.c_float),
+    ]
+
+
+class EnvConsts(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("is_collision_reset", C.c_int32), ("n_gates", C.c_int32),
+        ("bbox_lo", C.c_float * 3), ("bbox_hi", C.c_float * 3),
+        ("uav_radius", C.c_float), ("success_radius", C.c_float),
+        ("target", C.c_float * 3), ("gates", (C.c_float * 3) * 8),
+    ]
+
+
+class EnvState(C.Structure):
+    _fields_ = [
+        ("step_count", C.c_void_p), ("reward", C.c_void_p), ("rewards", C.c_void_p),
+        ("success", C.c_void_p), ("failure", C.c_void_p), ("episode_done", C.c_void_p),
+        ("done", C.c_void_p), ("is_collision", C.c_void_p), ("is_out_bounds", C.c_void_p),
+        ("once_collided", C.c_void_p), ("col_point", C.c_void_p), ("col_vec", C.c_void_p),
+        ("col_dis", C.c_void_p), ("next_gate", C.c_void_p), ("past_gates", C.c_void_p),
+        ("is_pass_next", C.c_void_p),
+    ]
+
+
+# name -> (ctypes field, is_array) ; constants are passed around as a dict of
+# float32 numpy scalars/arrays (bit patterns are the parity contract)
+CONST_FIELDS = [f[0] for f in Consts._fields_ if f[0] != "pad0"]
+
+
+def consts_from_dict(d):
+    c = Consts()
+    for name in CONST_FIELDS:
+        v = d[name]
+        cur = getattr(c, name)
+        if isinstance(cur, (int, float)):
+            setattr(c, name, v.item() if hasattr(v, "item") else v)
+        else:
+            arr = np.asarray(v, dtype=np.float32).reshape(-1)
+            assert arr.size == len(cur), name
+            for i, x in enumerate(arr):
+                cur[i] = float(x)
+    return c
+
+
+def build(force=False):
+    """compile oracle/libvf_oracle.so with gcc (checker only)"""
+    src = os.path.join(_HERE, "vf_oracle.c")
+    hdr = os.path.join(_HERE, "vf_oracle.h")
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libvf_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int32)
+        L.vfo_dyn_step.argtypes = [C.POINTER(Consts), C.c_int, fp, fp, ip, fp, fp, fp, fp]
+        L.vfo_dyn_step.restype = None
+        L.vfo_dyn_reset.argtypes = [C.POINTER(Consts), C.c_int, fp, fp, ip, ip, C.c_int,
+                                    fp, fp, fp, fp, fp, fp, fp, fp]
+        L.vfo_dyn_reset.restype = None
+        L.vfo_update_collision.argtypes = [C.POINTER(EnvConsts), C.c_int, fp,
+                                           C.POINTER(EnvState), ip, C.c_int]
+        L.vfo_update_collision.restype = None
+        L.vfo_env_post_step.argtypes = [C.POINTER(Consts), C.POINTER(EnvConsts), C.c_int, fp,
+                                        C.POINTER(EnvState)]
+        L.vfo_env_post_step.restype = None
+        L.vfo_env_reset_attr.argtypes = [C.c_int, C.POINTER(EnvState), ip, C.c_int]
+        L.vfo_env_reset_attr.restype = None
+        L.vfo_gae.argtypes = [fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.vfo_gae.restype = None
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    if a is None:
+        return None
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class OracleDynamics:
+    """Thin numpy wrapper: state slab S [ROWS][N], ring Q [D][4][N]."""
+
+    def __init__(self, consts, N, klin=None, kquad=None):
+        self.cd = dict(consts)
+        self.c = consts_from_dict(consts)
+        self.N = N
+        self.S = np.zeros((ROWS, N), np.float32)
+        D = int(self.c.delay_steps)
+        self.Q = np.zeros((max(D, 1), 4, N), np.float32)
+        self.tick = C.c_int32(0)
+        self.klin = klin
+        self.kquad = kquad
+        self.reset()
+
+    def reset(self, pos=None, quat=None, vel=None, omg=None, mot=None, thr=None, t=None,
+              idx=None, t_rand=None):
+        f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+        pos, quat, vel, omg, mot, thr, t, t_rand = map(f, (pos, quat, vel, omg, mot, thr, t, t_rand))
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, np.int32)
+        lib().vfo_dyn_reset(C.byref(self.c), self.N, _fp(self.S), _fp(self.Q), C.byref(self.tick),
+                            _ip(idx), 0 if idx is None else len(idx),
+                            _fp(pos), _fp(quat), _fp(vel), _fp(omg), _fp(mot), _fp(thr), _fp(t),
+                            _fp(t_rand))
+
+    def set_full_state(self, fs):
+        """fs (N,22) = [p q v w motor thrust t] (dynamics.py:793-803)"""
+        fs = np.asarray(fs, np.float32)
+        self.reset(pos=fs[:, 0:3], quat=fs[:, 3:7], vel=fs[:, 7:10], omg=fs[:, 10:13],
+                   mot=fs[:, 13:17], thr=fs[:, 17:21], t=fs[:, 21])
+
+    def step(self, action):
+        action = np.ascontiguousarray(action, np.float32)
+        obs = np.empty((self.N, 13), np.float32)
+        lib().vfo_dyn_step(C.byref(self.c), self.N, _fp(self.S), _fp(self.Q), C.byref(self.tick),
+                           _fp(self.klin), _fp(self.kquad), _fp(action), _fp(obs))
+        return obs
+
+    @property
+    def extend_state(self):
+        """(N,28) = [p q v(+wind) w acc ang_acc motor thrust t] (dynamics.py:806-819)"""
+        S = self.S
+        wind = np.asarray(self.cd["wind"], np.float32).reshape(3, 1)
+        return np.concatenate([S[POS:POS + 3], S[QUAT:QUAT + 4], S[VEL:VEL + 3] + wind,
+                               S[OMG:OMG + 3], S[ACC:ACC + 3], S[AACC:AACC + 3],
+                               S[MOT:MOT + 4], S[THR:THR + 4], S[T:T + 1]], 0).T.copy()
+
+
+def gae(rewards, values, episode_starts, last_values, dones, gamma, lam):
+    T, N = rewards.shape
+    adv = np.empty((T, N), np.float32)
+    ret = np.empty((T, N), np.float32)
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    r, v, e, lv, d = map(f, (rewards, values, episode_starts, last_values, dones))
+    lib().vfo_gae(_fp(r), _fp(v), _fp(e), _fp(lv), _fp(d), _fp(adv), _fp(ret), T, N,
+                  float(gamma), float(lam))
+    return adv, ret

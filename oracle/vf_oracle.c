@@ -1,0 +1,486 @@
+/*
+ * vf_oracle.c -- TEST INFRASTRUCTURE ONLY (see vf_oracle.h header).
+ *
+ * Plain-C fp32 restatement of the VisFly hot path.  Build with
+ *   gcc -O2 -ffp-contract=off -fno-fast-math -mfma -fopenmp
+ * Every elementwise torch op is one separately rounded fp32 operation; the
+ * only fused operations are the ones torch itself fuses on the oracle host
+ * (SURVEY App. B.4): BLAS matmuls with K in {3,4} are k-ordered FMA chains and
+ * torch.linalg.cross is fma(a_i, b_j, -(a_j*b_i)).  Those sites call fmaf()
+ * explicitly; everything else relies on -ffp-contract=off.
+ */
+#include "vf_oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+
+/* ---------- small helpers ---------- */
+
+/* (3x3) @ v as the k-ordered FMA chain torch's sgemm produces (App. B.4) */
+static inline void mat3_chain(const float* A, float x0, float x1, float x2, float* o)
+{
+    for (int i = 0; i < 3; ++i) {
+        float acc = A[3 * i + 0] * x0;
+        acc = fmaf(A[3 * i + 1], x1, acc);
+        acc = fmaf(A[3 * i + 2], x2, acc);
+        o[i] = acc;
+    }
+}
+
+/* (4x4) @ v, same chain */
+static inline void mat4_chain(const float* A, const float* x, float* o)
+{
+    for (int i = 0; i < 4; ++i) {
+        float acc = A[4 * i + 0] * x[0];
+        acc = fmaf(A[4 * i + 1], x[1], acc);
+        acc = fmaf(A[4 * i + 2], x[2], acc);
+        acc = fmaf(A[4 * i + 3], x[3], acc);
+        o[i] = acc;
+    }
+}
+
+/* Hamilton product, term order and rounding of utils/maths.py:168-174 */
+typedef struct { float w, x, y, z; } quat;
+
+static inline quat qmul(quat a, quat b)
+{
+    quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return r;
+}
+
+static inline quat qconj(quat a) /* utils/maths.py:232-233 */
+{
+    quat r = { a.w, -a.x, -a.y, -a.z };
+    return r;
+}
+
+static inline float clampf(float v, float lo, float hi) /* th.clamp semantics */
+{
+    /* torch clamp: min(max(v, lo), hi); NaN propagates */
+    float r = v < lo ? lo : v;
+    r = r > hi ? hi : r;
+    return r;
+}
+
+/* derivatives of (q, omega) used by both integrators (utils/maths.py:300-315) */
+static inline void derivs(const vfo_consts* c, quat q, const float* w, const float* tq,
+                          float* dq, float* dw)
+{
+    /* d_q = (ori * Quaternion(0, *ori_vel) * 0.5)          maths.py:311 */
+    quat wq = { 0.0f, w[0], w[1], w[2] };
+    quat p = qmul(q, wq);
+    dq[0] = p.w * 0.5f; dq[1] = p.x * 0.5f; dq[2] = p.y * 0.5f; dq[3] = p.z * 0.5f;
+    /* d_ori_vel = J_inv @ (tau - linalg.cross(w, J @ w))    maths.py:314 */
+    float Jw[3];
+    mat3_chain(c->J, w[0], w[1], w[2], Jw);
+    float cr[3];
+    cr[0] = fmaf(w[1], Jw[2], -(w[2] * Jw[1]));
+    cr[1] = fmaf(w[2], Jw[0], -(w[0] * Jw[2]));
+    cr[2] = fmaf(w[0], Jw[1], -(w[1] * Jw[0]));
+    float r0 = tq[0] - cr[0], r1 = tq[1] - cr[1], r2 = tq[2] - cr[2];
+    mat3_chain(c->Jinv, r0, r1, r2, dw);
+}
+
+/* ---------- Dynamics.step ---------- */
+
+void vfo_dyn_step(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
+                  const float* klin, const float* kquad,
+                  const float* action, float* obs)
+{
+    const int D = c->delay_steps;
+    const int slot = D > 0 ? (int)((*tick) % D) : 0;
+    const float dt = c->dt;
+
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+#define ROW(r) S[(size_t)(r) * N + i]
+        /* ---- delay queue: use oldest, store newest   dynamics.py:323-328 ---- */
+        float a[4];
+        if (D > 0) {
+            float* qs = Q + ((size_t)slot * 4) * N + i;
+            for (int k = 0; k < 4; ++k) {
+                a[k] = qs[(size_t)k * N];
+                qs[(size_t)k * N] = action[4 * (size_t)i + k];
+            }
+        } else {
+            for (int k = 0; k < 4; ++k) a[k] = action[4 * (size_t)i + k];
+        }
+
+        float p[3] = { ROW(VFO_POS), ROW(VFO_POS + 1), ROW(VFO_POS + 2) };
+        quat q = { ROW(VFO_QUAT), ROW(VFO_QUAT + 1), ROW(VFO_QUAT + 2), ROW(VFO_QUAT + 3) };
+        float v[3] = { ROW(VFO_VEL), ROW(VFO_VEL + 1), ROW(VFO_VEL + 2) };
+        float w[3] = { ROW(VFO_OMG), ROW(VFO_OMG + 1), ROW(VFO_OMG + 2) };
+        float wm[4] = { ROW(VFO_MOT), ROW(VFO_MOT + 1), ROW(VFO_MOT + 2), ROW(VFO_MOT + 3) };
+        float T[4] = { ROW(VFO_THR), ROW(VFO_THR + 1), ROW(VFO_THR + 2), ROW(VFO_THR + 3) };
+        float al[3] = { ROW(VFO_AACC), ROW(VFO_AACC + 1), ROW(VFO_AACC + 2) };
+        float acc[3] = { ROW(VFO_ACC), ROW(VFO_ACC + 1), ROW(VFO_ACC + 2) };
+        float kl[3], kq[3];
+        for (int k = 0; k < 3; ++k) {
+            kl[k] = klin ? klin[(size_t)k * N + i] : c->k_lin[k];
+            kq[k] = kquad ? kquad[(size_t)k * N + i] : c->k_quad[k];
+        }
+
+        /* ---- de-normalise + low-level controller (once per interval) ---- */
+        float Td[4];
+        if (c->action_type == VFO_ACT_BODYRATE) {
+            /* dynamics.py:704-710 */
+            float Fc = (a[0] * c->acc_half + c->acc_mean) * c->m;
+            float wc[3];
+            for (int k = 0; k < 3; ++k) wc[k] = a[k + 1] * c->rate_half + c->rate_mean;
+            /* dynamics.py:401-413 */
+            float e[3] = { wc[0] - w[0], wc[1] - w[1], wc[2] - w[2] };
+            float t1[3], Jw[3], t3[3];
+            mat3_chain(c->JP, e[0], e[1], e[2], t1);
+            float w0 = w[0] + 0.0f, w1 = w[1] + 0.0f, w2 = w[2] + 0.0f;
+            mat3_chain(c->J, w0, w1, w2, Jw);
+            /* cross(): utils/maths.py:392-394, separately rounded, "+ 0" */
+            float cr[3];
+            cr[0] = (w1 * Jw[2] - w2 * Jw[1]) + 0.0f;
+            cr[1] = (w2 * Jw[0] - w0 * Jw[2]) + 0.0f;
+            cr[2] = (w0 * Jw[1] - w1 * Jw[0]) + 0.0f;
+            mat3_chain(c->Dm, al[0], al[1], al[2], t3);
+            float u[4];
+            u[0] = Fc;
+            for (int k = 0; k < 3; ++k) u[k + 1] = (t1[k] + cr[k]) - t3[k];
+            mat4_chain(c->Binv, u, Td);
+        } else {
+            /* THRUST: dynamics.py:712-714,398-399 */
+            for (int k = 0; k < 4; ++k) Td[k] = c->m * (a[k] * c->acc_half + c->acc_mean);
+        }
+        for (int k = 0; k < 4; ++k) Td[k] = clampf(Td[k], c->T_min, c->T_max); /* :501 */
+
+        float aa[3] = { al[0], al[1], al[2] };
+        /* ---- sub-steps   dynamics.py:335-367 ---- */
+        for (int s = 0; s < c->interval_steps; ++s) {
+            if (c->ctrl_delay) {
+                for (int k = 0; k < 4; ++k) {
+                    /* _compute_rotor_omega :545-553 */
+                    float d1 = c->tm2 - Td[k];
+                    float d2 = c->rot_4tm0 * d1;
+                    float d3 = c->rot_tm1sq - d2;
+                    float sq = sqrtf(d3);
+                    float wd = c->rot_scale * (c->rot_neg_tm1 + sq);
+                    /* first-order motor :514 */
+                    wm[k] = c->c_motor * wm[k] + c->one_minus_c * wd;
+                    /* _compute_thrust :530-534 */
+                    float wp = wm[k] + 0.0f;
+                    T[k] = (c->tm0 * (wp * wp) + c->tm1 * wm[k]) + c->tm2;
+                }
+            } else {
+                for (int k = 0; k < 4; ++k) T[k] = Td[k]; /* :518 */
+            }
+            float ft[4];
+            mat4_chain(c->B, T, ft); /* :339 */
+
+            /* body-frame velocity :342, maths.py:49 */
+            quat vq = { 0.0f, v[0] + 0.0f, v[1] + 0.0f, v[2] + 0.0f };
+            quat vb = qmul(qmul(qconj(q), vq), q);
+            float vbv[3] = { vb.x, vb.y, vb.z };
+            float u[3];
+            for (int k = 0; k < 3; ++k) {
+                float lin = kl[k] * vbv[k];                 /* :343 */
+                float qd = (kq[k] * vbv[k]) * fabsf(vbv[k]); /* :344 */
+                float drag = lin + qd;                       /* :345 */
+                float zf = (k == 2 ? 1.0f : 0.0f) * ft[0];   /* z * F  :347 */
+                u[k] = zf - drag;
+            }
+            quat uq = { 0.0f, u[0], u[1], u[2] };
+            quat ra = qmul(qmul(q, uq), qconj(q));
+            acc[0] = ra.x / c->m + 0.0f;
+            acc[1] = ra.y / c->m + 0.0f;
+            acc[2] = ra.z / c->m + c->g_z;
+
+            const float* tq = ft + 1; /* :349 */
+            float dpos[3] = { v[0] + c->wind[0], v[1] + c->wind[1], v[2] + c->wind[2] }; /* maths.py:310 */
+
+            if (c->integrator == VFO_INT_EULER) {
+                float dq[4], dw[3];
+                derivs(c, q, w, tq, dq, dw);
+                /* maths.py:344-347 */
+                for (int k = 0; k < 3; ++k) p[k] = p[k] + dpos[k] * dt;
+                q.w = q.w + dq[0] * dt; q.x = q.x + dq[1] * dt;
+                q.y = q.y + dq[2] * dt; q.z = q.z + dq[3] * dt;
+                for (int k = 0; k < 3; ++k) v[k] = v[k] + acc[k] * dt;
+                for (int k = 0; k < 3; ++k) w[k] = w[k] + dw[k] * dt;
+                for (int k = 0; k < 3; ++k) aa[k] = dw[k]; /* :351 */
+            } else {
+                /* REPAIRED rk4: maths.py:353-386 with (i) the
+                 * caller's wind passed to every stage, (ii) the four `d_* @ ks`
+                 * contractions restated as explicit elementwise weighted sums
+                 * ((k1*w0 + k2*w1) + k3*w2) + k4*w3, (iii) the ks-weighted
+                 * d_ori_vel returned as the angular acceleration.  acc and tau
+                 * stay frozen across stages as in the reference. */
+                const float ks[4] = { 1.0f / 6.0f, 2.0f / 6.0f, 2.0f / 6.0f, 1.0f / 6.0f };
+                const float sl[3] = { 0.5f, 0.5f, 1.0f };
+                float kq4[4][4], kw[4][3], kv[4][3], kp[4][3];
+                quat qc = q;
+                float vc[3] = { v[0], v[1], v[2] };
+                float wc[3] = { w[0], w[1], w[2] };
+                for (int st = 0; st < 4; ++st) {
+                    if (st != 0) {
+                        /* maths.py:366-368: x + d[:, :, st-1] * slice_ts[st-1] * dt */
+                        float h = sl[st - 1];
+                        qc.w = q.w + kq4[st - 1][0] * h * dt;
+                        qc.x = q.x + kq4[st - 1][1] * h * dt;
+                        qc.y = q.y + kq4[st - 1][2] * h * dt;
+                        qc.z = q.z + kq4[st - 1][3] * h * dt;
+                        for (int k = 0; k < 3; ++k) vc[k] = v[k] + kv[st - 1][k] * h * dt;
+                        for (int k = 0; k < 3; ++k) wc[k] = w[k] + kw[st - 1][k] * h * dt;
+                    }
+                    for (int k = 0; k < 3; ++k) kp[st][k] = vc[k] + c->wind[k];
+                    derivs(c, qc, wc, tq, kq4[st], kw[st]);
+                    for (int k = 0; k < 3; ++k) kv[st][k] = acc[k];
+                }
+#define WSUM(arr, k) ((((arr)[0][k] * ks[0] + (arr)[1][k] * ks[1]) + (arr)[2][k] * ks[2]) + (arr)[3][k] * ks[3])
+                float dwk[3];
+                for (int k = 0; k < 3; ++k) p[k] = p[k] + WSUM(kp, k) * dt;
+                q.w = q.w + WSUM(kq4, 0) * dt; q.x = q.x + WSUM(kq4, 1) * dt;
+                q.y = q.y + WSUM(kq4, 2) * dt; q.z = q.z + WSUM(kq4, 3) * dt;
+                for (int k = 0; k < 3; ++k) v[k] = v[k] + WSUM(kv, k) * dt;
+                for (int k = 0; k < 3; ++k) { dwk[k] = WSUM(kw, k); w[k] = w[k] + dwk[k] * dt; }
+                for (int k = 0; k < 3; ++k) aa[k] = dwk[k];
+#undef WSUM
+            }
+            /* normalize :367, maths.py:226-230 */
+            float nn = sqrtf(((q.w * q.w + q.x * q.x) + q.y * q.y) + q.z * q.z);
+            q.w = q.w / nn; q.x = q.x / nn; q.y = q.y / nn; q.z = q.z / nn;
+        }
+        float t = ROW(VFO_T) + c->ctrl_dt; /* :368 */
+
+        /* _ugly_fix :374-382 */
+        p[0] = clampf(p[0], -c->pos_xy_lim, c->pos_xy_lim);
+        p[1] = clampf(p[1], -c->pos_xy_lim, c->pos_xy_lim);
+        p[2] = clampf(p[2], c->pos_z_lo, c->pos_z_hi);
+        for (int k = 0; k < 3; ++k) v[k] = clampf(v[k], -c->vel_lim, c->vel_lim);
+        for (int k = 0; k < 3; ++k) w[k] = clampf(w[k], -c->omg_lim, c->omg_lim);
+
+        for (int k = 0; k < 3; ++k) ROW(VFO_POS + k) = p[k];
+        ROW(VFO_QUAT) = q.w; ROW(VFO_QUAT + 1) = q.x; ROW(VFO_QUAT + 2) = q.y; ROW(VFO_QUAT + 3) = q.z;
+        for (int k = 0; k < 3; ++k) ROW(VFO_VEL + k) = v[k];
+        for (int k = 0; k < 3; ++k) ROW(VFO_OMG + k) = w[k];
+        for (int k = 0; k < 4; ++k) ROW(VFO_MOT + k) = wm[k];
+        for (int k = 0; k < 4; ++k) ROW(VFO_THR + k) = T[k];
+        for (int k = 0; k < 3; ++k) ROW(VFO_AACC + k) = aa[k];
+        for (int k = 0; k < 3; ++k) ROW(VFO_ACC + k) = acc[k];
+        ROW(VFO_T) = t;
+
+        if (obs) { /* state :779-786 */
+            float* o = obs + 13 * (size_t)i;
+            o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+            o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+            for (int k = 0; k < 3; ++k) o[7 + k] = v[k] + c->wind[k];
+            for (int k = 0; k < 3; ++k) o[10 + k] = w[k];
+        }
+#undef ROW
+    }
+    if (D > 0) *tick = (*tick + 1) % D;
+}
+
+/* ---------- Dynamics.reset ---------- */
+
+void vfo_dyn_reset(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
+                   const int32_t* idx, int k,
+                   const float* pos, const float* quat_, const float* vel, const float* omg,
+                   const float* mot, const float* thr, const float* t, const float* t_rand)
+{
+    const int full = (idx == NULL);
+    const int n = full ? N : k;
+    for (int j = 0; j < n; ++j) {
+        const int i = full ? j : idx[j];
+#define ROW(r) S[(size_t)(r) * N + i]
+        for (int d = 0; d < 3; ++d) ROW(VFO_POS + d) = pos ? pos[3 * j + d] : 0.0f;
+        for (int d = 0; d < 4; ++d) ROW(VFO_QUAT + d) = quat_ ? quat_[4 * j + d] : (d == 0 ? 1.0f : 0.0f);
+        for (int d = 0; d < 3; ++d) ROW(VFO_VEL + d) = vel ? vel[3 * j + d] : 0.0f;
+        for (int d = 0; d < 3; ++d) ROW(VFO_OMG + d) = omg ? omg[3 * j + d] : 0.0f;
+        for (int d = 0; d < 4; ++d) ROW(VFO_MOT + d) = mot ? mot[4 * j + d] : c->w_init;
+        for (int d = 0; d < 4; ++d) ROW(VFO_THR + d) = thr ? thr[4 * j + d] : c->T_init;
+        for (int d = 0; d < 3; ++d) ROW(VFO_AACC + d) = 0.0f;
+        for (int d = 0; d < 3; ++d) ROW(VFO_ACC + d) = 0.0f;
+        if (t) ROW(VFO_T) = t[j];
+        else if (full || !t_rand) ROW(VFO_T) = 0.0f;
+        else ROW(VFO_T) = 0.0f + t_rand[j] * 3.14f * 2.0f; /* dynamics.py:256 */
+#undef ROW
+        if (Q) /* dynamics.py:243,262-263 */
+            for (int s = 0; s < c->delay_steps * 4; ++s) Q[(size_t)s * N + i] = 0.0f;
+    }
+    if (full && tick) *tick = 0;
+}
+
+/* ---------- env layer ---------- */
+
+/* x.norm(dim=1) for 3 / 4 columns as torch's reduce kernel rounds it (App. B.4) */
+static inline float norm3(float x, float y, float z)
+{
+    return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+}
+static inline float norm4(float a, float b, float c_, float d)
+{
+    return sqrtf(((a * a + b * b) + c_ * c_) + d * d);
+}
+/* (a*b).sum(dim=1) over 3 columns: separately rounded products, fp32 adds in order */
+static inline float dot3_sum(const float* a, const float* b)
+{
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+void vfo_update_collision(const vfo_env_consts* e, int N, const float* S, vfo_env_state* es,
+                          const int32_t* idx, int k)
+{
+    /* NB the reference recomputes vector/dis/flags for ALL agents even for an
+     * indexed call (droneEnv.py:364-369); only collision_point is indexed. */
+    const int n = idx ? k : N;
+    for (int j = 0; j < n; ++j) {
+        const int i = idx ? idx[j] : j;
+        float p[3] = { S[(size_t)(VFO_POS)*N + i], S[(size_t)(VFO_POS + 1) * N + i], S[(size_t)(VFO_POS + 2) * N + i] };
+        /* hstack([p - lo, hi - p]).min(dim=1)   :347-350 ; first minimum wins */
+        float cand[6];
+        for (int d = 0; d < 3; ++d) { cand[d] = p[d] - e->bbox_lo[d]; cand[3 + d] = e->bbox_hi[d] - p[d]; }
+        int best = 0;
+        for (int d = 1; d < 6; ++d) if (cand[d] < cand[best]) best = d;
+        float cp[3] = { p[0], p[1], p[2] };
+        cp[best % 3] = best < 3 ? e->bbox_lo[best] : e->bbox_hi[best - 3]; /* :352 */
+        for (int d = 0; d < 3; ++d) es->col_point[3 * (size_t)i + d] = cp[d];
+    }
+    for (int i = 0; i < N; ++i) {
+        float p[3] = { S[(size_t)(VFO_POS)*N + i], S[(size_t)(VFO_POS + 1) * N + i], S[(size_t)(VFO_POS + 2) * N + i] };
+        uint8_t oob = 0;
+        for (int d = 0; d < 3; ++d) oob |= (p[d] < e->bbox_lo[d]) | (p[d] > e->bbox_hi[d]); /* :361-362 */
+        float vec[3];
+        for (int d = 0; d < 3; ++d) vec[d] = es->col_point[3 * (size_t)i + d] - p[d]; /* :365 */
+        float dis = norm3(vec[0] - 0.0f, vec[1] - 0.0f, vec[2] - 0.0f);             /* :366 */
+        for (int d = 0; d < 3; ++d) es->col_vec[3 * (size_t)i + d] = vec[d];
+        es->col_dis[i] = dis;
+        es->is_out_bounds[i] = oob;
+        es->is_collision[i] = dis < e->uav_radius;                                    /* :367 */
+        es->once_collided[i] = es->once_collided[i] | es->is_collision[i];            /* :369 */
+    }
+}
+
+static float hover_like_reward(const float* p, const float* tgt, const float* q, const float* v, const float* w)
+{
+    /* envs/HoverEnv.py:83-94 ; strict left-to-right, python-double coefficients
+     * cast to fp32 at the multiply */
+    const float c1 = (float)(-0.1 * 1 / 9), c2 = (float)-0.00001, c3 = (float)-0.002;
+    float r = 0.1f + norm3(p[0] - tgt[0], p[1] - tgt[1], p[2] - tgt[2]) * c1;
+    r = r + norm4(q[0] - 1.0f, q[1] - 0.0f, q[2] - 0.0f, q[3] - 0.0f) * c2;
+    r = r + norm3(v[0] - 0.0f, v[1] - 0.0f, v[2] - 0.0f) * c3;
+    r = r + norm3(w[0] - 0.0f, w[1] - 0.0f, w[2] - 0.0f) * c3;
+    return r;
+}
+
+void vfo_env_post_step(const vfo_consts* c, const vfo_env_consts* e, int N, const float* S,
+                       vfo_env_state* es)
+{
+    for (int i = 0; i < N; ++i) {
+#define ROW(r) S[(size_t)(r) * N + i]
+        float p[3] = { ROW(VFO_POS), ROW(VFO_POS + 1), ROW(VFO_POS + 2) };
+        float q[4] = { ROW(VFO_QUAT), ROW(VFO_QUAT + 1), ROW(VFO_QUAT + 2), ROW(VFO_QUAT + 3) };
+        float v[3] = { ROW(VFO_VEL) + c->wind[0], ROW(VFO_VEL + 1) + c->wind[1], ROW(VFO_VEL + 2) + c->wind[2] };
+        float w[3] = { ROW(VFO_OMG), ROW(VFO_OMG + 1), ROW(VFO_OMG + 2) };
+#undef ROW
+        es->step_count[i] += 1; /* droneGymEnv.py:163 */
+        uint8_t success = 0, failure = 0;
+        float r = 0.0f;
+        if (e->kind == VFO_ENV_HOVER) {
+            success = 0; /* HoverEnv.py:79-80 */
+            r = hover_like_reward(p, e->target, q, v, w);
+        } else if (e->kind == VFO_ENV_NAV) {
+            /* NavigationEnv.py:81-99 */
+            float dp[3] = { p[0] - e->target[0], p[1] - e->target[1], p[2] - e->target[2] };
+            success = norm3(dp[0], dp[1], dp[2]) <= e->success_radius;
+            float tp[3] = { e->target[0] - p[0], e->target[1] - p[1], e->target[2] - p[2] };
+            float t1 = dot3_sum(v, tp) / (1e-6f + norm3(tp[0], tp[1], tp[2]));
+            t1 = (t1 > 10.0f ? 10.0f : t1) * 0.01f;
+            /* direction = x_axis (maths.py:123-133) */
+            float dir[3];
+            dir[0] = 1.0f - 2.0f * (q[2] * q[2] + q[3] * q[3]);
+            dir[1] = 2.0f * (q[1] * q[2] + q[3] * q[0]);
+            dir[2] = 2.0f * (q[1] * q[3] - q[2] * q[0]);
+            const float thrd = (float)(3.14159265358979323846 / 18.0);
+            float cs = dot3_sum(dir, v) / (1e-6f + norm3(v[0], v[1], v[2])) / 1.0f;
+            cs = clampf(cs, -1.0f, 1.0f);
+            float ang = acosf(cs);
+            ang = ang < thrd ? thrd : ang;
+            float t2 = (ang - thrd) * -0.01f;
+            float t3 = norm4(q[0] - 1.0f, q[1] - 0.0f, q[2] - 0.0f, q[3] - 0.0f) * (float)-0.00001;
+            float t4 = norm3(v[0] - 0.0f, v[1] - 0.0f, v[2] - 0.0f) * -0.002f;
+            float t5 = norm3(w[0] - 0.0f, w[1] - 0.0f, w[2] - 0.0f) * -0.002f;
+            float cd = es->col_dis[i];
+            float t6 = 1.0f / (cd + 0.2f) * -0.01f;
+            float relu1 = 1.0f - cd; relu1 = relu1 > 0.0f ? relu1 : 0.0f;
+            float vv[3] = { v[0] - 0.0f, v[1] - 0.0f, v[2] - 0.0f };
+            float ap = dot3_sum(es->col_vec + 3 * (size_t)i, vv) / (1e-6f + cd);
+            ap = ap > 0.0f ? ap : 0.0f;
+            float t7 = relu1 * ap * -0.005f;
+            /* success(bool) * (max_steps - step_count)(int) * base_r * (0.2 + 0.8/(1 + 1*|v|)) */
+            float sterm = (float)((int)success * (e->max_episode_steps - es->step_count[i]));
+            float t8 = sterm * 0.1f * (0.2f + 0.8f / (1.0f + 1.0f * norm3(v[0], v[1], v[2])));
+            r = 0.1f * 0.0f + t1;
+            r = r + t2; r = r + t3; r = r + t4; r = r + t5; r = r + t6; r = r + t7; r = r + t8;
+        } else { /* RACING: RacingEnv.py:142-148,187-215 (is_pos_reward branch) */
+            int g = es->next_gate[i];
+            const float* gt = e->gates[g];
+            uint8_t pass = norm3(p[0] - gt[0], p[1] - gt[1], p[2] - gt[2]) <= e->success_radius;
+            es->is_pass_next[i] = pass;
+            g = (g + pass) % e->n_gates;
+            es->next_gate[i] = g;
+            es->past_gates[i] += pass;
+            success = 0;
+            gt = e->gates[g]; /* reward uses the UPDATED gate index */
+            r = hover_like_reward(p, gt, q, v, w);
+            r = r + (float)pass * 20.0f;
+        }
+        es->success[i] = success;
+        es->failure[i] = failure;
+        es->reward[i] = r;
+        es->rewards[i] = es->rewards[i] + r; /* :185 */
+        uint8_t ed = es->episode_done[i] | success | failure | es->is_out_bounds[i]; /* :188 */
+        if (e->is_collision_reset) ed |= es->is_collision[i];                           /* :189-190 */
+        es->episode_done[i] = ed;
+        es->done[i] = ed | (es->step_count[i] >= e->max_episode_steps);                /* :193 */
+    }
+}
+
+void vfo_env_reset_attr(int N, vfo_env_state* es, const int32_t* idx, int k)
+{
+    (void)N;
+    for (int j = 0; j < k; ++j) { /* droneGymEnv.py:387-392 */
+        int i = idx[j];
+        es->reward[i] = 0.0f;
+        es->rewards[i] = 0.0f;
+        es->done[i] = 0;
+        es->episode_done[i] = 0;
+        es->step_count[i] = 0;
+    }
+}
+
+/* ---------- GAE ---------- */
+
+void vfo_gae(const float* rewards, const float* values, const float* episode_starts,
+             const float* last_values, const float* dones,
+             float* adv, float* ret, int T, int N, double gamma_d, double lam_d)
+{
+    /* utils/algorithms/common.py:119-132.  SB3 holds gamma / gae_lambda as
+     * python floats: `gamma * next_values` rounds gamma to fp32 at the multiply,
+     * `gamma * gae_lambda` is a double product rounded once. */
+    const float gamma = (float)gamma_d;
+    const float gl = (float)(gamma_d * lam_d);
+    for (int i = 0; i < N; ++i) {
+        float last = 0.0f;
+        for (int t = T - 1; t >= 0; --t) {
+            float nnt, nv;
+            if (t == T - 1) { nnt = 1.0f - dones[i]; nv = last_values[i]; }
+            else { nnt = 1.0f - episode_starts[(size_t)(t + 1) * N + i]; nv = values[(size_t)(t + 1) * N + i]; }
+            float delta = rewards[(size_t)t * N + i] + gamma * nv * nnt - values[(size_t)t * N + i];
+            last = delta + gl * nnt * last;
+            adv[(size_t)t * N + i] = last;
+        }
+        for (int t = 0; t < T; ++t)
+            ret[(size_t)t * N + i] = adv[(size_t)t * N + i] + values[(size_t)t * N + i];
+    }
+}

@@ -1,0 +1,37 @@
+"""helpers shared by the parity tests: fixture loading + the int8 action decode"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def consts_of(fx):
+    return {k[2:]: fx[k] for k in fx if k.startswith("c_")}
+
+
+def decode_actions(fx):
+    """int8 fixture -> fp32 actions, identical to oracle/gen_golden.py::decode_actions"""
+    a = fx["actions_q"].astype(np.float32) * np.float32(float(fx["scale"]) / 127.0) + fx["hover"].astype(np.float32)
+    return np.clip(a, np.float32(-1), np.float32(1)).astype(np.float32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what=""):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ne = bits(a) != bits(b)
+    # +0 / -0 are distinct bit patterns; report them explicitly if that's the only difference
+    if ne.any():
+        idx = np.argwhere(ne)[0]
+        raise AssertionError(f"{what}: {int(ne.sum())} of {a.size} fp32 words differ; first at {tuple(idx)}: "
+                             f"{a[tuple(idx)]!r} vs {b[tuple(idx)]!r}; max|diff|={np.nanmax(np.abs(a - b)):.3e}")

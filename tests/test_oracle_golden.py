@@ -1,0 +1,26 @@
+"""Pins the CPU oracle (oracle/vf_oracle.c) bit-for-bit against golden vectors generated
+from the imported reference (oracle/gen_golden.py, CR-sqrt oracle)."""
+import numpy as np
+import pytest
+
+import oracle
+from _golden import assert_bits_equal, consts_of, decode_actions, load
+
+DYN = ["dyn_bodyrate_euler", "dyn_bodyrate_euler_wide", "dyn_thrust_euler", "dyn_bodyrate_nodelay",
+       "dyn_bodyrate_dt005", "dyn_bodyrate_rk4"]
+
+
+@pytest.mark.parametrize("name", DYN)
+def test_dyn_step_bit_exact(name):
+    fx = load(name)
+    acts = decode_actions(fx)
+    N = fx["fs0"].shape[0]
+    od = oracle.OracleDynamics(consts_of(fx), N)
+    od.set_full_state(fx["fs0"])
+    cps = list(fx["checkpoints"])
+    for k in range(acts.shape[0]):
+        obs = od.step(acts[k])
+        if (k + 1) in cps:
+            j = cps.index(k + 1)
+            assert_bits_equal(od.extend_state, fx["ext"][j], f"{name} extend_state @ step {k + 1}")
+            assert_bits_equal(obs, fx["obs"][j], f"{name} obs @ step {k + 1}")
