@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/s of the fused quadrotor step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one control interval (ctrl_dt = 8 sub-steps of dt) for every agent of the batch.
+Workload = BASELINE.json configs[1]: 65 536 agents per GPU, visual=False, bodyrate + Euler,
+dt=0.0025 / ctrl_dt=0.02, ctrl_delay on, 3-slot comm-delay ring.  Agents shard trivially:
+each rank owns its own 65 536 agents (weak scaling), no data-path collective.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+AGENTS_PER_GPU = 65536
+DYN_KW = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+BYTES_PER_AGENT_STEP = 244      # 116 B read + 128 B written per agent-step (Dynamics.step)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(consts, seconds_target=15.0):
+    """TEST/BENCH INFRASTRUCTURE: time the CPU oracle (C restatement, OpenMP over agents) on the
+    host cores of this box on a bounded sample of the same workload."""
+    import oracle
+    N = AGENTS_PER_GPU
+    od = oracle.OracleDynamics(consts, N)
+    rng = np.random.default_rng(0)
+    pos = (np.array([1, 0, 1.5]) + rng.uniform(-1, 1, (N, 3)) * np.array([1, 1, .5])).astype(np.float32)
+    od.reset(pos=pos)
+    a = np.clip(np.array([-1 / 3, 0, 0, 0]) + rng.uniform(-.02, .02, (N, 4)), -1, 1).astype(np.float32)
+    for _ in range(2):
+        od.step(a)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        for _ in range(8):
+            od.step(a)
+        steps += 8
+        el = time.perf_counter() - t0
+        if el > seconds_target or steps >= 4096:
+            break
+    cores = len(os.sched_getaffinity(0))
+    return {"value": N * steps / el, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/vf_oracle.c (OpenMP, {cores} threads), N={N}, {steps} control steps, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--agents", type=int, default=AGENTS_PER_GPU, help="agents per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from visfly_amd import Dynamics
+    N = args.agents
+    dyn = Dynamics(num=N, device=dev, seed=42 + rank, **DYN_KW)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    spawn = torch.tensor([1, 0, 1.5], device=dev) + \
+        (torch.rand((N, 3), device=dev, generator=g) * 2 - 1) * torch.tensor([1, 1, .5], device=dev)
+    dyn.reset(pos=spawn)
+    hover = torch.tensor([-1 / 3, 0, 0, 0], device=dev)
+    pool = [(hover + (torch.rand((N, 4), device=dev, generator=g) * 2 - 1) * 0.02).clamp(-1, 1).contiguous()
+            for _ in range(16)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        dyn.step(pool[k % 16])
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        dyn.step(pool[k % 16])
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # dominant kernel, HIP events on the launch stream
+    kern_us = dyn.time_steps(pool[0], iters=200)
+    assert torch.isfinite(dyn.state).all()
+
+    if rank == 0:
+        value = world * N * args.steps / el
+        achieved = BYTES_PER_AGENT_STEP * N / (kern_us * 1e-6) / 1e9
+        out = {
+            "metric": "agent-steps/sec (dynamics.step, visual=False)",
+            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"HoverEnv dynamics, {N} agents/GPU, visual=False, bodyrate+euler, "
+                                   "dt=0.0025/ctrl_dt=0.02, ctrl_delay, 3-slot delay ring (BASELINE configs[1])",
+                       "agents_per_gpu": N, "parallelism": f"agents sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_dyn_step<bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
+                         "bytes_per_agent_step": BYTES_PER_AGENT_STEP},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dyn.constants)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+"""Parity of the fused HIP control-interval kernel (through the C-ABI / Dynamics class)
+with (a) the golden vectors from the imported reference and (b) the CPU oracle on seeded
+inputs, bit-exact.  Tolerance stated by north_star: 1e-5 per component after 256 steps;
+the bar enforced here is 0 ulp."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _golden import assert_bits_equal, consts_of, decode_actions, load
+
+pytestmark = pytest.mark.gpu
+
+DYN = ["dyn_bodyrate_euler", "dyn_bodyrate_euler_wide", "dyn_thrust_euler", "dyn_bodyrate_nodelay",
+       "dyn_bodyrate_dt005", "dyn_bodyrate_rk4"]
+
+
+def make_dyn(consts, N, **kw):
+    from visfly_amd import Dynamics
+    names = {0: "thrust", 1: "bodyrate"}
+    return Dynamics(num=N, device="cuda:0", action_type=names[int(consts["action_type"])],
+                    integrator="rk4" if int(consts["integrator"]) else "euler",
+                    dt=float(consts["dt"]), ctrl_dt=float(consts["ctrl_dt"]), constants=consts, **kw)
+
+
+def set_full_state(dyn, fs):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    dyn.reset(pos=t(fs[:, 0:3]), ori=t(fs[:, 3:7]), vel=t(fs[:, 7:10]), ori_vel=t(fs[:, 10:13]),
+              motor_omega=t(fs[:, 13:17]), thrusts=t(fs[:, 17:21]), t=t(fs[:, 21]))
+
+
+@pytest.mark.parametrize("name", DYN)
+def test_golden_bit_exact(name):
+    fx = load(name)
+    consts = consts_of(fx)
+    acts = decode_actions(fx)
+    N = fx["fs0"].shape[0]
+    dyn = make_dyn(consts, N)
+    set_full_state(dyn, fx["fs0"])
+    cps = list(fx["checkpoints"])
+    acts_d = torch.from_numpy(acts).cuda()
+    for k in range(acts.shape[0]):
+        obs = dyn.step(acts_d[k])
+        if (k + 1) in cps:
+            j = cps.index(k + 1)
+            assert_bits_equal(dyn.extend_state.cpu().numpy(), fx["ext"][j], f"{name} extend_state @ {k + 1}")
+            assert_bits_equal(obs.cpu().numpy(), fx["obs"][j], f"{name} step() return @ {k + 1}")
+    # north_star tolerance, also against the un-patched reference (drift from its non-IEEE sqrt is reported)
+    drift = np.abs(dyn.extend_state.cpu().numpy()[:, :13] - fx["raw_ext_last"][:, :13]).max()
+    print(f"{name}: |HIP - unpatched reference| @ {acts.shape[0]} steps = {drift:.3e}")
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 257, 4099])
+@pytest.mark.parametrize("mode", ["bodyrate", "thrust"])
+def test_vs_oracle_ragged_sizes(N, mode):
+    """sizes that are not multiples of the wave / block, including a single agent"""
+    from visfly_amd import Dynamics
+    kw = dict(action_type=mode, dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+    dyn = Dynamics(num=N, device="cuda:0", **kw)
+    ref = oracle.OracleDynamics(dyn.constants, N)
+    rng = np.random.default_rng(N)
+    pos = (np.array([1, 0, 1.5]) + rng.uniform(-1, 1, (N, 3))).astype(np.float32)
+    vel = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+    dyn.reset(pos=torch.from_numpy(pos), vel=torch.from_numpy(vel))
+    ref.reset(pos=pos, vel=vel)
+    hover = np.array([-1 / 3, 0, 0, 0]) if mode == "bodyrate" else np.full(4, -0.8333)
+    for k in range(40):
+        a = np.clip(hover + rng.uniform(-1, 1, (N, 4)) * (1.0 if k % 2 else 0.1), -1, 1).astype(np.float32)
+        s = dyn.step(torch.from_numpy(a).cuda())
+        so = ref.step(a)
+        assert_bits_equal(s.cpu().numpy(), so, f"N={N} {mode} step {k}")
+    assert_bits_equal(dyn.extend_state.cpu().numpy(), ref.extend_state, "extend_state")
+
+
+def test_indexed_reset_and_queue():
+    """indexed reset scatters state, zeroes the agent's delay-ring rows, t <- U*6.28 (dynamics.py:248-263)"""
+    from visfly_amd import Dynamics
+    N = 300
+    dyn = Dynamics(num=N, device="cuda:0", action_type="bodyrate", dt=0.0025, ctrl_dt=0.02)
+    ref = oracle.OracleDynamics(dyn.constants, N)
+    rng = np.random.default_rng(7)
+    for k in range(30):
+        a = rng.uniform(-1, 1, (N, 4)).astype(np.float32)
+        dyn.step(torch.from_numpy(a).cuda()); ref.step(a)
+        if k % 4 == 3:
+            idx = np.sort(rng.choice(N, size=17, replace=False)).astype(np.int32)
+            pos = rng.uniform(0, 2, (17, 3)).astype(np.float32)
+            q = rng.normal(size=(17, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+            tr = rng.uniform(0, 1, 17).astype(np.float32)
+            dyn.reset(pos=torch.from_numpy(pos), ori=torch.from_numpy(q), indices=torch.from_numpy(idx),
+                      t_rand=torch.from_numpy(tr))
+            ref.reset(pos=pos, quat=q, idx=idx, t_rand=tr)
+    assert_bits_equal(dyn.extend_state.cpu().numpy(), ref.extend_state, "after indexed resets")
+    assert_bits_equal(dyn._queue.cpu().numpy(), ref.Q, "delay ring")
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (65 536 agents): invariants that need no oracle run --
+    unit quaternions, clamps respected, finite state, agents with identical inputs stay identical."""
+    from visfly_amd import Dynamics
+    N = 65536
+    dyn = Dynamics(num=N, device="cuda:0", action_type="bodyrate", dt=0.0025, ctrl_dt=0.02)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    pos = torch.tensor([1, 0, 1.5], device="cuda") + (torch.rand((N // 2, 3), device="cuda", generator=g) * 2 - 1)
+    pos = torch.cat([pos, pos])  # second half duplicates the first
+    dyn.reset(pos=pos)
+    for k in range(64):
+        a = torch.rand((N // 2, 4), device="cuda", generator=g) * 2 - 1
+        s = dyn.step(torch.cat([a, a]))
+    fs = dyn.extend_state
+    assert torch.isfinite(fs).all()
+    assert torch.equal(fs[:N // 2], fs[N // 2:])
+    qn = fs[:, 3:7].norm(dim=1)
+    assert (qn - 1).abs().max() < 1e-6
+    assert fs[:, 2].min() >= 0 and fs[:, 2].max() <= 20 and fs[:, 7:10].abs().max() <= 20 and fs[:, 10:13].abs().max() <= 10
+    assert torch.equal(s, dyn.state)
+    assert torch.allclose(dyn.t, torch.full((N,), 64 * 0.02, device="cuda"), atol=1e-5)
+
+
+def test_errors():
+    from visfly_amd import Dynamics
+    from visfly_amd._lib import VisflyError
+    with pytest.raises(ValueError):
+        Dynamics(num=8, device="cuda:0", dt=0.003, ctrl_dt=0.02)
+    d = Dynamics(num=8, device="cuda:0")
+    with pytest.raises(ValueError):
+        d.step(torch.zeros((7, 4), device="cuda"))

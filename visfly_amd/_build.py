@@ -1,0 +1,37 @@
+"""Builds libvisfly_amd.so (hand-written HIP for gfx950) in-tree with hipcc."""
+import glob
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(CSRC, "libvisfly_amd.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+# -ffp-contract=off: the kernels reproduce the reference's fp32 rounding sequence; FMAs are
+# written explicitly where the reference fuses.  Division/sqrt stay IEEE (hipcc default).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    return os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB

@@ -1,0 +1,130 @@
+"""ctypes binding of libvisfly_amd.so -- the C-ABI declared in include/visfly_amd.h.
+
+The product path has NO fallback: if the HIP library is missing or cannot be loaded,
+importing this module's ``lib()`` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # noqa: F401  -- must be imported first: it maps the one HIP runtime (libamdhip64.so.7) we share
+
+from ._build import LIB
+
+ROWS = 28
+POS, QUAT, VEL, OMG, MOT, THR, AACC, ACC, T = 0, 3, 7, 10, 13, 17, 21, 24, 27
+
+
+class DynCfg(C.Structure):
+    """mirror of vf_dyn_cfg"""
+    _fields_ = [
+        ("action_type", C.c_int32), ("integrator", C.c_int32),
+        ("interval_steps", C.c_int32), ("delay_steps", C.c_int32),
+        ("ctrl_delay", C.c_int32), ("pad0", C.c_int32),
+        ("dt", C.c_float), ("ctrl_dt", C.c_float),
+        ("m", C.c_float), ("g_z", C.c_float),
+        ("J", C.c_float * 9), ("Jinv", C.c_float * 9),
+        ("JP", C.c_float * 9), ("Dm", C.c_float * 9),
+        ("B", C.c_float * 16), ("Binv", C.c_float * 16),
+        ("c_motor", C.c_float), ("one_minus_c", C.c_float),
+        ("tm0", C.c_float), ("tm1", C.c_float), ("tm2", C.c_float),
+        ("rot_scale", C.c_float), ("rot_neg_tm1", C.c_float),
+        ("rot_tm1sq", C.c_float), ("rot_4tm0", C.c_float),
+        ("T_min", C.c_float), ("T_max", C.c_float),
+        ("acc_half", C.c_float), ("acc_mean", C.c_float),
+        ("rate_half", C.c_float), ("rate_mean", C.c_float),
+        ("k_lin", C.c_float * 3), ("k_quad", C.c_float * 3),
+        ("wind", C.c_float * 3),
+        ("pos_xy_lim", C.c_float), ("pos_z_lo", C.c_float), ("pos_z_hi", C.c_float),
+        ("vel_lim", C.c_float), ("omg_lim", C.c_float),
+        ("T_init", C.c_float), ("w_init", C.c_float),
+    ]
+
+    @classmethod
+    def from_dict(cls, d):
+        c = cls()
+        for name, _ in cls._fields_:
+            if name == "pad0":
+                continue
+            v = d[name]
+            cur = getattr(c, name)
+            if isinstance(cur, (int, float)):
+                setattr(c, name, np.asarray(v).item())
+            else:
+                arr = np.asarray(v, dtype=np.float32).reshape(-1)
+                if arr.size != len(cur):
+                    raise ValueError(f"constant '{name}': expected {len(cur)} values, got {arr.size}")
+                for i, x in enumerate(arr):
+                    cur[i] = float(x)
+        return c
+
+
+class VisflyError(RuntimeError):
+    pass
+
+
+_lib = None
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/visfly_amd.h declares
+SIGNATURES = {
+    "vf_last_error": (C.c_char_p, []),
+    "vf_abi_version": (C.c_int32, []),
+    "vf_dyn_create": (C.c_int, [C.POINTER(DynCfg), C.c_int32, C.POINTER(_vp)]),
+    "vf_dyn_destroy": (None, [_vp]),
+    "vf_dyn_bind": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "vf_dyn_step": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "vf_dyn_reset": (C.c_int, [_vp, _vp, C.c_int32] + [_vp] * 8 + [_vp]),
+    "vf_dyn_time_steps": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.POINTER(C.c_float)]),
+}
+
+
+def _single_hip_runtime():
+    """two HIP runtimes in one process cannot share streams/pointers: refuse loudly"""
+    seen = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                seen.add(line.split()[-1])
+    return seen
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise VisflyError(
+                f"{LIB} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  visfly_amd has no CPU/eager fallback.")
+        L = C.CDLL(LIB)
+        rts = _single_hip_runtime()
+        if len(rts) > 1:
+            raise VisflyError(f"more than one HIP runtime mapped into this process: {sorted(rts)}")
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.vf_abi_version() != 1:
+            raise VisflyError("libvisfly_amd.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise VisflyError(f"libvisfly_amd error {rc}: {lib().vf_last_error().decode()}")
+
+
+def ptr(t):
+    """device pointer of a contiguous CUDA(ROCm) tensor, or NULL"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VisflyError("visfly_amd kernels need device tensors (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise VisflyError("visfly_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def current_stream(device):
+    return torch.cuda.current_stream(device).cuda_stream

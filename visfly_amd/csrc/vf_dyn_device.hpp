@@ -1,0 +1,354 @@
+// Per-agent rigid-body arithmetic for the fused control-interval kernels (gfx950).
+//
+// One thread owns one agent; the whole state lives in VGPRs across all sub-steps.
+// The arithmetic reproduces the reference's fp32 rounding sequence exactly
+// (SURVEY.md App. A / B.4): every elementwise op is rounded separately (this file is
+// compiled with -ffp-contract=off), and fused multiply-adds appear only where the
+// reference's BLAS matmuls (k-ordered FMA chains, K in {3,4}) and torch.linalg.cross
+// fuse.  Division and sqrt are the IEEE correctly rounded forms (hipcc default).
+//
+// Reference: envs/base/dynamics.py:319-382,389-413,505-554,692-714; utils/maths.py:168-174,
+// 226-233,300-351.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "visfly_amd.h"
+
+#pragma clang fp contract(off)
+
+namespace vf {
+
+struct Quat {
+    float w, x, y, z;
+};
+
+struct Agent {
+    float p[3];
+    Quat q;
+    float v[3];
+    float w[3];
+    float wm[4];  // motor omega
+    float T[4];   // rotor thrusts
+    float aa[3];  // angular acceleration of the last sub-step
+    float acc[3]; // linear acceleration of the last sub-step
+    float t;
+};
+
+// Hamilton product; term order and rounding of utils/maths.py:168-174
+__device__ __forceinline__ Quat qmul(const Quat& a, const Quat& b)
+{
+    Quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return r;
+}
+
+__device__ __forceinline__ Quat qconj(const Quat& a) { return Quat{a.w, -a.x, -a.y, -a.z}; }
+
+// th.clamp: min(max(v, lo), hi) with NaN passing through
+__device__ __forceinline__ float clampf(float v, float lo, float hi)
+{
+    float r = v < lo ? lo : v;
+    return r > hi ? hi : r;
+}
+
+// (3x3) @ x as the k-ordered FMA chain of the reference's sgemm
+__device__ __forceinline__ void mat3(const float* __restrict__ A, float x0, float x1, float x2, float* o)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = A[3 * i] * x0;
+        acc = __builtin_fmaf(A[3 * i + 1], x1, acc);
+        acc = __builtin_fmaf(A[3 * i + 2], x2, acc);
+        o[i] = acc;
+    }
+}
+
+__device__ __forceinline__ void mat4(const float* __restrict__ A, const float* x, float* o)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float acc = A[4 * i] * x[0];
+        acc = __builtin_fmaf(A[4 * i + 1], x[1], acc);
+        acc = __builtin_fmaf(A[4 * i + 2], x[2], acc);
+        acc = __builtin_fmaf(A[4 * i + 3], x[3], acc);
+        o[i] = acc;
+    }
+}
+
+// Integrator._get_derivatives for (q, omega)  (utils/maths.py:311,314)
+__device__ __forceinline__ void derivs(const vf_dyn_cfg& c, const Quat& q, const float* w, const float* tq,
+                                       float* dq, float* dw)
+{
+    const Quat wq{0.0f, w[0], w[1], w[2]};
+    const Quat p = qmul(q, wq);
+    dq[0] = p.w * 0.5f;
+    dq[1] = p.x * 0.5f;
+    dq[2] = p.y * 0.5f;
+    dq[3] = p.z * 0.5f;
+    float Jw[3];
+    mat3(c.J, w[0], w[1], w[2], Jw);
+    // torch.linalg.cross contracts to fma(a_i, b_j, -(a_j*b_i))
+    const float c0 = __builtin_fmaf(w[1], Jw[2], -(w[2] * Jw[1]));
+    const float c1 = __builtin_fmaf(w[2], Jw[0], -(w[0] * Jw[2]));
+    const float c2 = __builtin_fmaf(w[0], Jw[1], -(w[1] * Jw[0]));
+    mat3(c.Jinv, tq[0] - c0, tq[1] - c1, tq[2] - c2, dw);
+}
+
+// De-normalise the (delayed) action and run the low-level controller once per control
+// interval -> clamped desired rotor thrusts (dynamics.py:692-714,389-413,501).
+template <int ACT>
+__device__ __forceinline__ void desired_thrusts(const vf_dyn_cfg& c, const Agent& s, const float* a, float* Td)
+{
+    if constexpr (ACT == VF_ACT_BODYRATE) {
+        const float Fc = (a[0] * c.acc_half + c.acc_mean) * c.m;
+        float e[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) e[k] = (a[k + 1] * c.rate_half + c.rate_mean) - s.w[k];
+        float t1[3], Jw[3], t3[3];
+        mat3(c.JP, e[0], e[1], e[2], t1);
+        const float w0 = s.w[0] + 0.0f, w1 = s.w[1] + 0.0f, w2 = s.w[2] + 0.0f;
+        mat3(c.J, w0, w1, w2, Jw);
+        // cross() helper of utils/maths.py:392-394: separately rounded, then "+ 0"
+        float cr[3];
+        cr[0] = (w1 * Jw[2] - w2 * Jw[1]) + 0.0f;
+        cr[1] = (w2 * Jw[0] - w0 * Jw[2]) + 0.0f;
+        cr[2] = (w0 * Jw[1] - w1 * Jw[0]) + 0.0f;
+        mat3(c.Dm, s.aa[0], s.aa[1], s.aa[2], t3);
+        float u[4];
+        u[0] = Fc;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k + 1] = (t1[k] + cr[k]) - t3[k];
+        mat4(c.Binv, u, Td);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Td[k] = c.m * (a[k] * c.acc_half + c.acc_mean);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Td[k] = clampf(Td[k], c.T_min, c.T_max);
+}
+
+// All sub-steps of one control interval, then t += ctrl_dt and the state clamps
+// (dynamics.py:335-382).  kl/kq: this agent's drag coefficients.
+template <int ACT, int INTEG, bool CTRL_DELAY>
+__device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, const float* a,
+                                                 const float* kl, const float* kq)
+{
+    float Td[4];
+    desired_thrusts<ACT>(c, s, a, Td);
+
+    // rotor set-point: loop invariant (thrust_des is fixed for the interval), so the
+    // quadratic root of dynamics.py:545-553 is taken once instead of once per sub-step.
+    float wd[4];
+    if constexpr (CTRL_DELAY) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d3 = c.rot_tm1sq - c.rot_4tm0 * (c.tm2 - Td[k]);
+            wd[k] = (c.one_minus_c) * (c.rot_scale * (c.rot_neg_tm1 + sqrtf(d3)));
+        }
+    }
+    const float dt = c.dt;
+
+    for (int sub = 0; sub < c.interval_steps; ++sub) {
+        if constexpr (CTRL_DELAY) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s.wm[k] = c.c_motor * s.wm[k] + wd[k];                        // :514
+                const float wp = s.wm[k] + 0.0f;
+                s.T[k] = (c.tm0 * (wp * wp) + c.tm1 * s.wm[k]) + c.tm2;       // :530-534
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s.T[k] = Td[k];                       // :518
+        }
+        float ft[4];
+        mat4(c.B, s.T, ft);                                                    // :339
+
+        // body-frame velocity and drag (:342-345)
+        const Quat vq{0.0f, s.v[0] + 0.0f, s.v[1] + 0.0f, s.v[2] + 0.0f};
+        const Quat vb = qmul(qmul(qconj(s.q), vq), s.q);
+        const float vbv[3] = {vb.x, vb.y, vb.z};
+        float u[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float drag = kl[k] * vbv[k] + (kq[k] * vbv[k]) * __builtin_fabsf(vbv[k]);
+            const float zf = (k == 2 ? 1.0f : 0.0f) * ft[0];
+            u[k] = zf - drag;
+        }
+        // acc = q (x) (z F - drag) (x) q* / m + g   (:347)
+        const Quat uq{0.0f, u[0], u[1], u[2]};
+        const Quat ra = qmul(qmul(s.q, uq), qconj(s.q));
+        s.acc[0] = ra.x / c.m + 0.0f;
+        s.acc[1] = ra.y / c.m + 0.0f;
+        s.acc[2] = ra.z / c.m + c.g_z;
+
+        const float* tq = ft + 1;
+        if constexpr (INTEG == VF_INT_EULER) {
+            float dq[4], dw[3];
+            derivs(c, s.q, s.w, tq, dq, dw);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s.p[k] = s.p[k] + (s.v[k] + c.wind[k]) * dt;   // maths.py:310,344
+            s.q.w = s.q.w + dq[0] * dt;
+            s.q.x = s.q.x + dq[1] * dt;
+            s.q.y = s.q.y + dq[2] * dt;
+            s.q.z = s.q.z + dq[3] * dt;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s.v[k] = s.v[k] + s.acc[k] * dt;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s.w[k] = s.w[k] + dw[k] * dt;
+                s.aa[k] = dw[k];                                                       // maths.py:351
+            }
+        } else {
+            // Repaired RK4 (utils/maths.py:353-386 is not executable in the
+            // reference): stages see the caller's wind, the ks-contractions are the explicit
+            // sums ((k1*w0 + k2*w1) + k3*w2) + k4*w3, acc/tau stay frozen, and the weighted
+            // d_ori_vel is the angular acceleration handed to the controller.
+            const float ks0 = 1.0f / 6.0f, ks1 = 2.0f / 6.0f;
+            Quat qc = s.q;
+            float vc[3] = {s.v[0], s.v[1], s.v[2]};
+            float wc[3] = {s.w[0], s.w[1], s.w[2]};
+            float sp[3], sq[4], sv[3], sw[3];
+            float dq[4], dw[3];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                if (st != 0) {
+                    const float h = st == 3 ? 1.0f : 0.5f;
+                    qc.w = s.q.w + dq[0] * h * dt;
+                    qc.x = s.q.x + dq[1] * h * dt;
+                    qc.y = s.q.y + dq[2] * h * dt;
+                    qc.z = s.q.z + dq[3] * h * dt;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) vc[k] = s.v[k] + s.acc[k] * h * dt;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wc[k] = s.w[k] + dw[k] * h * dt;
+                }
+                derivs(c, qc, wc, tq, dq, dw);
+                const float ks = (st == 0 || st == 3) ? ks0 : ks1;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float kp = (vc[k] + c.wind[k]) * ks, kv = s.acc[k] * ks, kw = dw[k] * ks;
+                    sp[k] = st == 0 ? kp : sp[k] + kp;
+                    sv[k] = st == 0 ? kv : sv[k] + kv;
+                    sw[k] = st == 0 ? kw : sw[k] + kw;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float kq4 = dq[k] * ks;
+                    sq[k] = st == 0 ? kq4 : sq[k] + kq4;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s.p[k] = s.p[k] + sp[k] * dt;
+            s.q.w = s.q.w + sq[0] * dt;
+            s.q.x = s.q.x + sq[1] * dt;
+            s.q.y = s.q.y + sq[2] * dt;
+            s.q.z = s.q.z + sq[3] * dt;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s.v[k] = s.v[k] + sv[k] * dt;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s.w[k] = s.w[k] + sw[k] * dt;
+                s.aa[k] = sw[k];
+            }
+        }
+        // normalize (:367, maths.py:226-230)
+        const float nn = sqrtf(((s.q.w * s.q.w + s.q.x * s.q.x) + s.q.y * s.q.y) + s.q.z * s.q.z);
+        s.q.w = s.q.w / nn;
+        s.q.x = s.q.x / nn;
+        s.q.y = s.q.y / nn;
+        s.q.z = s.q.z / nn;
+    }
+    s.t = s.t + c.ctrl_dt;                                                             // :368
+    // _ugly_fix (:374-382)
+    s.p[0] = clampf(s.p[0], -c.pos_xy_lim, c.pos_xy_lim);
+    s.p[1] = clampf(s.p[1], -c.pos_xy_lim, c.pos_xy_lim);
+    s.p[2] = clampf(s.p[2], c.pos_z_lo, c.pos_z_hi);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.v[k] = clampf(s.v[k], -c.vel_lim, c.vel_lim);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.w[k] = clampf(s.w[k], -c.omg_lim, c.omg_lim);
+}
+
+// ---- slab I/O: coalesced row loads/stores, lane i <-> agent i ----
+__device__ __forceinline__ void load_agent(const float* __restrict__ S, int N, int i, Agent& s)
+{
+    const float* b = S + i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.p[k] = b[(size_t)(VF_POS + k) * N];
+    s.q.w = b[(size_t)(VF_QUAT + 0) * N];
+    s.q.x = b[(size_t)(VF_QUAT + 1) * N];
+    s.q.y = b[(size_t)(VF_QUAT + 2) * N];
+    s.q.z = b[(size_t)(VF_QUAT + 3) * N];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.v[k] = b[(size_t)(VF_VEL + k) * N];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.w[k] = b[(size_t)(VF_OMG + k) * N];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.wm[k] = b[(size_t)(VF_MOT + k) * N];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.T[k] = b[(size_t)(VF_THR + k) * N];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.aa[k] = b[(size_t)(VF_AACC + k) * N];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.acc[k] = b[(size_t)(VF_ACC + k) * N];
+    s.t = b[(size_t)VF_T * N];
+}
+
+__device__ __forceinline__ void store_agent(float* __restrict__ S, int N, int i, const Agent& s)
+{
+    float* b = S + i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[(size_t)(VF_POS + k) * N] = s.p[k];
+    b[(size_t)(VF_QUAT + 0) * N] = s.q.w;
+    b[(size_t)(VF_QUAT + 1) * N] = s.q.x;
+    b[(size_t)(VF_QUAT + 2) * N] = s.q.y;
+    b[(size_t)(VF_QUAT + 3) * N] = s.q.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[(size_t)(VF_VEL + k) * N] = s.v[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[(size_t)(VF_OMG + k) * N] = s.w[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[(size_t)(VF_MOT + k) * N] = s.wm[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[(size_t)(VF_THR + k) * N] = s.T[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[(size_t)(VF_AACC + k) * N] = s.aa[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[(size_t)(VF_ACC + k) * N] = s.acc[k];
+    b[(size_t)VF_T * N] = s.t;
+}
+
+// state(N,13) row of one agent: [p, q wxyz, v + wind, w]  (dynamics.py:779-786)
+__device__ __forceinline__ void obs_row(const vf_dyn_cfg& c, const Agent& s, float* o)
+{
+    o[0] = s.p[0]; o[1] = s.p[1]; o[2] = s.p[2];
+    o[3] = s.q.w; o[4] = s.q.x; o[5] = s.q.y; o[6] = s.q.z;
+    o[7] = s.v[0] + c.wind[0]; o[8] = s.v[1] + c.wind[1]; o[9] = s.v[2] + c.wind[2];
+    o[10] = s.w[0]; o[11] = s.w[1]; o[12] = s.w[2];
+}
+
+// AoS (N,C) output through LDS so that the global stores are coalesced dwords:
+// thread t parks its C-float row at lds[t*C..] (C odd -> conflict-free), then the block
+// streams the tile out linearly.  `tile` must hold blockDim.x*C floats.
+template <int C>
+__device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, int N, int block_first,
+                                                     const float* row, float* tile)
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < C; ++k) tile[t * C + k] = row[k];
+    __syncthreads();
+    const int rows_here = min((int)blockDim.x, N - block_first);
+    const int total = rows_here * C;
+    float* dst = out + (size_t)block_first * C;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const int j = k * blockDim.x + t;
+        if (j < total) dst[j] = tile[j];
+    }
+}
+
+}  // namespace vf

@@ -1,0 +1,271 @@
+"""``Dynamics`` -- drop-in for the reference's batched quadrotor dynamics
+(envs/base/dynamics.py:19) whose ``step``/``reset`` run as single fused HIP launches.
+
+Same constructor kwargs (``dynamics_kwargs``), same ``reset``/``step`` signatures and
+return shapes, same properties.  State lives in ONE device slab ``[28][N]`` fp32 (SoA,
+component-major like the reference's internal ``(C, N)`` tensors); the public properties
+are transposed views of its rows, so nothing is copied to serve them.
+"""
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch as th
+
+from . import _lib
+from ._lib import ACC, AACC, MOT, OMG, POS, QUAT, ROWS, THR, VEL, VisflyError
+from ._lib import T as TROW
+from .constants import ACTION_TYPES, derive_constants
+
+
+class ACTION_TYPE:
+    """value-compatible with the reference enum (utils/type.py:14-18)"""
+    THRUST, BODYRATE, VELOCITY, POSITION = 0, 1, 2, 3
+
+
+def _as_device_f32(x, device, cols=None):
+    if x is None:
+        return None
+    t = th.as_tensor(x, dtype=th.float32).to(device, non_blocking=True)
+    if cols is not None:
+        t = t.reshape(-1, cols)
+    return t.contiguous()
+
+
+class Dynamics:
+    def __init__(
+            self,
+            num: int = 1,
+            action_type: str = "bodyrate",
+            ori_output_type: str = "quaternion",
+            seed: int = 42,
+            dt: float = 0.005,
+            ctrl_dt: float = 0.03,
+            ctrl_delay: bool = True,
+            comm_delay: float = 0.06,
+            action_space: Tuple[float, float] = (-1, 1),
+            device: Union[str, th.device] = "cuda",
+            integrator: str = "euler",
+            drag_random: float = 0,
+            cfg: Union[str, dict] = "drone_state",
+            wind_settings: Optional[List] = (0, 0, 0),
+            rotor_sim: bool = True,
+            constants: Optional[dict] = None,
+    ):
+        assert action_type in ["bodyrate", "thrust", "velocity", "position"]
+        assert ori_output_type in ["quaternion", "euler"]
+        self.device = th.device(device)
+        if self.device.type != "cuda":
+            raise VisflyError(
+                f"visfly_amd.Dynamics runs on an MI355X only (device='{device}'); there is no CPU fallback")
+        if self.device.index is None:
+            self.device = th.device("cuda", th.cuda.current_device())
+        self.num = int(num)
+        self.action_type = ACTION_TYPES[action_type]
+        self.angular_output_type = ori_output_type
+        self._is_quat_output = ori_output_type == "quaternion"
+        self.dt, self.ctrl_dt = dt, ctrl_dt
+        self._integrator = integrator
+        self._ctrl_delay = ctrl_delay
+        self._drag_random = drag_random
+        self._rotor_sim = rotor_sim
+        # `constants` lets parity tests inject the golden fixture's constant bits verbatim
+        self.constants = dict(constants) if constants is not None else derive_constants(
+            action_type=action_type, dt=dt, ctrl_dt=ctrl_dt, ctrl_delay=ctrl_delay, comm_delay=comm_delay,
+            action_space=action_space, integrator=integrator, cfg=cfg, wind_settings=wind_settings)
+        c = self.constants
+        self._interval_steps = int(c["interval_steps"])
+        self._comm_delay_steps = int(c["delay_steps"])
+        self.m = th.tensor(float(c["m"]))
+        self.name = cfg if isinstance(cfg, str) else cfg.get("name", "custom")
+
+        self.set_seed(seed)
+
+        N, D = self.num, self._comm_delay_steps
+        with th.cuda.device(self.device):
+            self._slab = th.zeros((ROWS, N), dtype=th.float32, device=self.device)
+            self._queue = th.zeros((D, 4, N), dtype=th.float32, device=self.device) if D > 0 else None
+            self._klin = self._kquad = None
+            if drag_random:
+                self._klin = th.empty((3, N), dtype=th.float32, device=self.device)
+                self._kquad = th.empty((3, N), dtype=th.float32, device=self.device)
+                self._set_drag(th.ones((3, 1)), th.ones((3, 1)))
+            self._wind = th.as_tensor(np.asarray(c["wind"], np.float32), device=self.device).reshape(3, 1)
+            self._cfg = _lib.DynCfg.from_dict(c)
+            h = _lib._vp()
+            _lib.check(_lib.lib().vf_dyn_create(self._cfg, N, h))
+            self._h = h
+            _lib.check(_lib.lib().vf_dyn_bind(self._h, _lib.ptr(self._slab), _lib.ptr(self._queue),
+                                              _lib.ptr(self._klin), _lib.ptr(self._kquad)))
+        self.reset()
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().vf_dyn_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_seed(self, seed=42):
+        """reference: th.manual_seed(seed) on the global CPU generator (dynamics.py:556-557);
+        here the stream lives in ``self.rng`` (shared with the env layer for replay parity)."""
+        self.rng = th.Generator(device="cpu")
+        self.rng.manual_seed(int(seed))
+
+    def detach(self):
+        """state tensors carry no autograd graph on the kernel path (dynamics.py:176-190)"""
+        return None
+
+    def _stream(self):
+        return _lib.current_stream(self.device)
+
+    def _set_drag(self, f_lin, f_quad):
+        """k = k_mean * factor, factor (3,1) shared or (3,N) per agent (dynamics.py:244-246)"""
+        c = self.constants
+        kl = th.as_tensor(np.asarray(c["k_lin"], np.float32)).reshape(3, 1) * f_lin
+        kq = th.as_tensor(np.asarray(c["k_quad"], np.float32)).reshape(3, 1) * f_quad
+        self._klin.copy_(kl.expand(3, self.num), non_blocking=True)
+        self._kquad.copy_(kq.expand(3, self.num), non_blocking=True)
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(
+            self,
+            pos=None, ori=None, vel=None, ori_vel=None, motor_omega=None, thrusts=None, t=None,
+            indices: Optional[List] = None,
+            t_rand=None,
+    ):
+        """Dynamics.reset (dynamics.py:218-269): full reset (indices None) or scatter into
+        ``indices``.  ``t_rand``: optional uniform draws for the indexed ``t <- U*6.28``; by
+        default they come from ``self.rng`` in the reference's order."""
+        dev = self.device
+        with th.cuda.device(dev):
+            idx = None
+            k = self.num
+            if indices is not None:
+                idx = th.as_tensor(indices, dtype=th.int32).reshape(-1).to(dev, non_blocking=True).contiguous()
+                k = idx.numel()
+                if t is None and t_rand is None:
+                    t_rand = th.rand((k,), generator=self.rng)
+            elif self._drag_random:
+                r = self._drag_random
+                fl = ((th.rand((3, 1), generator=self.rng) - 0.5) * 2 * r).clamp(-0.5, .5) + 1
+                fq = ((th.rand((3, 1), generator=self.rng) - 0.5) * 2 * r).clamp(-0.5, .5) + 1
+                self._set_drag(fl, fq)
+            args = [_as_device_f32(pos, dev, 3), _as_device_f32(ori, dev, 4), _as_device_f32(vel, dev, 3),
+                    _as_device_f32(ori_vel, dev, 3), _as_device_f32(motor_omega, dev, 4),
+                    _as_device_f32(thrusts, dev, 4), _as_device_f32(t, dev), _as_device_f32(t_rand, dev)]
+            for a in args:
+                if a is not None and a.shape[0] != k:
+                    raise ValueError(f"reset: expected {k} rows, got {tuple(a.shape)}")
+            _lib.check(_lib.lib().vf_dyn_reset(self._h, _lib.ptr(idx), k, *[_lib.ptr(a) for a in args],
+                                               self._stream()))
+            self._keepalive = (idx, args)  # until the stream has consumed them
+        return self.state
+
+    def step(self, action) -> th.Tensor:
+        """One control interval (dynamics.py:319-372) -> state (N,13)."""
+        with th.cuda.device(self.device):
+            a = _as_device_f32(action, self.device, 4)
+            if a.shape[0] != self.num:
+                raise ValueError(f"step: action must be ({self.num},4), got {tuple(a.shape)}")
+            out = th.empty((self.num, 13), dtype=th.float32, device=self.device)
+            _lib.check(_lib.lib().vf_dyn_step(self._h, _lib.ptr(a), _lib.ptr(out), self._stream()))
+            self._last_action = a
+        return out
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def position(self):
+        return self._slab[POS:POS + 3].T
+
+    @property
+    def orientation(self):
+        if self._is_quat_output:
+            return self._slab[QUAT:QUAT + 4].T
+        return self._euler().T
+
+    def _euler(self):
+        w, x, y, z = self._slab[QUAT:QUAT + 4]
+        roll = th.atan2(2 * (w * x + y * z), 1 - 2 * (x.pow(2) + y.pow(2)))       # maths.py:244-249
+        pitch = th.asin(2 * (w * y - z * x))
+        yaw = th.atan2(2 * (w * z + x * y), 1 - 2 * (y.pow(2) + z.pow(2)))
+        return th.stack([roll, pitch, yaw])
+
+    @property
+    def direction(self):
+        w, x, y, z = self._slab[QUAT:QUAT + 4]                                     # maths.py:123-133
+        return th.stack([1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w)]).T
+
+    @property
+    def R(self):
+        w, x, y, z = self._slab[QUAT:QUAT + 4]                                     # maths.py:110-120
+        return th.stack([
+            th.stack([1 - 2 * (y.pow(2) + z.pow(2)), 2 * (x * y - z * w), 2 * (x * z + y * w)]),
+            th.stack([2 * (x * y + z * w), 1 - 2 * (x.pow(2) + z.pow(2)), 2 * (y * z - x * w)]),
+            th.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x.pow(2) + y.pow(2))])])
+
+    @property
+    def velocity(self):
+        return (self._slab[VEL:VEL + 3] + self._wind).T
+
+    @property
+    def angular_velocity(self):
+        return self._slab[OMG:OMG + 3].T
+
+    @property
+    def acceleration(self):
+        return self._slab[ACC:ACC + 3].T
+
+    @property
+    def angular_acceleration(self):
+        return self._slab[AACC:AACC + 3].T
+
+    @property
+    def t(self):
+        return self._slab[TROW]
+
+    @property
+    def motor_omega(self):
+        return self._slab[MOT:MOT + 4].T
+
+    @property
+    def thrusts(self):
+        return self._slab[THR:THR + 4].T
+
+    @property
+    def wind_velocity(self):
+        return self._wind.expand(3, self.num)
+
+    @property
+    def is_quat_output(self):
+        return self._is_quat_output
+
+    @property
+    def state(self):
+        return th.hstack([self.position, self.orientation, self.velocity, self.angular_velocity])
+
+    @property
+    def full_state(self):
+        return th.hstack([self.position, self.orientation, self.velocity, self.angular_velocity,
+                          self.motor_omega, self.thrusts, self.t.unsqueeze(1)])
+
+    @property
+    def extend_state(self):
+        return th.hstack([self.position, self.orientation, self.velocity, self.angular_velocity,
+                          self.acceleration, self.angular_acceleration, self.motor_omega, self.thrusts,
+                          self.t.unsqueeze(1)])
+
+    # ------------------------------------------------------------------ measurement helper
+    def time_steps(self, action, iters=100):
+        """mean device microseconds per fused-step launch, HIP events on the current stream"""
+        import ctypes
+        a = _as_device_f32(action, self.device, 4)
+        out = th.empty((self.num, 13), dtype=th.float32, device=self.device)
+        us = ctypes.c_float(0)
+        _lib.check(_lib.lib().vf_dyn_time_steps(self._h, _lib.ptr(a), _lib.ptr(out), int(iters), self._stream(),
+                                                ctypes.byref(us)))
+        return float(us.value)
