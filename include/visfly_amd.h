@@ -30,18 +30,31 @@ typedef void* vf_stream_t;
 
 enum { VF_OK = 0, VF_EINVAL = -1, VF_EHIP = -2, VF_ESTATE = -3 };
 
-/* ---- state slab rows: SoA [VF_ROWS][N] (envs/base/dynamics.py:116-123,229-243) ---- */
+/* ---- state slab: wave-tile AoSoA with 16-byte granules -------------------------------
+ * The reference keeps component-major (C, N) tensors (envs/base/dynamics.py:116-123).  On
+ * MI355X a power-of-two row stride puts every row of an agent on the same L1/L2 set and HBM
+ * channel, so the slab is tiled per wavefront instead: 64 agents x G granules, a granule
+ * being 4 fp32 of ONE agent (one global_load_dwordx4 per lane, 1 KiB per wave-instruction,
+ * one contiguous G KiB chunk per wave):
+ *
+ *     float index of (agent i, granule g, component c) =
+ *         (((i / 64) * G + g) * 64 + (i % 64)) * 4 + c          G = vf_dyn_granules(cfg)
+ *
+ * 3-vectors sit in components 1..3 (the pure-quaternion embedding the rotation code uses);
+ * component 0 of those granules is a spare slot ("s") the env layer uses.              */
+#define VF_TILE 64
 enum {
-    VF_POS = 0,   /* 3: position                          */
-    VF_QUAT = 3,  /* 4: orientation w,x,y,z               */
-    VF_VEL = 7,   /* 3: velocity (without wind)           */
-    VF_OMG = 10,  /* 3: body rates                        */
-    VF_MOT = 13,  /* 4: motor omega                       */
-    VF_THR = 17,  /* 4: rotor thrusts                     */
-    VF_AACC = 21, /* 3: angular acceleration (last sub-step) */
-    VF_ACC = 24,  /* 3: linear acceleration (last sub-step)  */
-    VF_T = 27,    /* 1: time                              */
-    VF_ROWS = 28
+    VF_G_POS = 0,   /* t,  p.x, p.y, p.z                                 */
+    VF_G_QUAT = 1,  /* q.w, q.x, q.y, q.z                                */
+    VF_G_VEL = 2,   /* h,  v.x, v.y, v.z   (velocity without wind; h = delay-ring head, int bits) */
+    VF_G_OMG = 3,   /* s,  w.x, w.y, w.z   (body rates)                  */
+    VF_G_MOT = 4,   /* motor omega 0..3                                  */
+    VF_G_THR = 5,   /* rotor thrusts 0..3                                */
+    VF_G_AACC = 6,  /* s,  angular acceleration of the last sub-step     */
+    VF_G_ACC = 7,   /* s,  linear acceleration of the last sub-step      */
+    VF_G_RING = 8,  /* delay_steps granules: delayed actions (ring)      */
+    /* then, if per-agent drag is enabled: (s, k_lin xyz), (s, k_quad xyz) */
+    VF_G_FIXED = 8
 };
 
 enum { VF_ACT_THRUST = 0, VF_ACT_BODYRATE = 1 };   /* utils/type.py:14-18 */
@@ -84,15 +97,18 @@ typedef struct vf_dyn vf_dyn;
 const char* vf_last_error(void);
 int32_t vf_abi_version(void);
 
-/* Dynamics.__init__ (envs/base/dynamics.py:26-130): copies cfg, allocates the 8-byte
- * device control block (delay-ring head + arrival counter). */
-int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, vf_dyn** out);
+/* Dynamics.__init__ (envs/base/dynamics.py:26-130): copies cfg; no device allocation. */
+int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, int32_t per_agent_drag, vf_dyn** out);
 void vf_dyn_destroy(vf_dyn* h);
 
-/* Bind caller-owned device memory (the tensors a reference Dynamics holds as attributes,
- * dynamics.py:116-130):  slab [VF_ROWS][N]; queue [delay_steps][4][N] (NULL iff
- * delay_steps == 0); klin/kquad per-agent drag [3][N] or NULL -> cfg.k_lin/k_quad. */
-int vf_dyn_bind(vf_dyn* h, float* slab, float* queue, const float* klin, const float* kquad);
+/* Number of granules per agent / number of floats of the slab for N agents
+ * (N is padded up to a multiple of VF_TILE; pad lanes hold inert hover states). */
+int32_t vf_dyn_granules(const vf_dyn* h);
+int64_t vf_dyn_slab_floats(const vf_dyn* h);
+
+/* Bind the caller-owned device slab (what a reference Dynamics holds as its state
+ * attributes, dynamics.py:116-130), vf_dyn_slab_floats() fp32, 16-byte aligned. */
+int vf_dyn_bind(vf_dyn* h, float* slab);
 
 /* Dynamics.step (envs/base/dynamics.py:319-372): one control interval, all sub-steps fused.
  *   action  (N,4) AoS in [-1,1];  state_out (N,13) AoS [p, q wxyz, v+wind, w] or NULL. */
@@ -100,6 +116,7 @@ int vf_dyn_step(vf_dyn* h, const float* action, float* state_out, vf_stream_t st
 
 /* Dynamics.reset (envs/base/dynamics.py:218-269).
  *   idx == NULL: full reset, arrays hold N rows in agent order; else k indexed agents.
+ *   klin/kquad (k,3) AoS per-agent drag coefficients or NULL (kept / cfg values on full reset).
  *   pos (k,3) quat (k,4) vel (k,3) omg (k,3) mot (k,4) thr (k,4): AoS or NULL for the
  *   reference defaults (zeros / identity / hover).  t (k,) or NULL; when NULL an indexed
  *   reset sets t = t_rand[j]*3.14*2 (dynamics.py:256; t_rand = uniform [0,1) draws) or 0
@@ -107,7 +124,7 @@ int vf_dyn_step(vf_dyn* h, const float* action, float* state_out, vf_stream_t st
 int vf_dyn_reset(vf_dyn* h, const int32_t* idx, int32_t k,
                  const float* pos, const float* quat, const float* vel, const float* omg,
                  const float* mot, const float* thr, const float* t, const float* t_rand,
-                 vf_stream_t stream);
+                 const float* klin, const float* kquad, vf_stream_t stream);
 
 /* Time the dominant kernel with HIP events on `stream`: runs `iters` back-to-back
  * vf_dyn_step launches and returns the mean device time per launch in microseconds.

@@ -91,7 +91,7 @@ def test_indexed_reset_and_queue():
                       t_rand=torch.from_numpy(tr))
             ref.reset(pos=pos, quat=q, idx=idx, t_rand=tr)
     assert_bits_equal(dyn.extend_state.cpu().numpy(), ref.extend_state, "after indexed resets")
-    assert_bits_equal(dyn._queue.cpu().numpy(), ref.Q, "delay ring")
+    assert_bits_equal(dyn.delay_ring.permute(0, 2, 1).contiguous().cpu().numpy(), ref.Q, "delay ring")
 
 
 def test_full_size_properties():

@@ -1,0 +1,12 @@
+"""run the fused step kernel a few times at a given N (for rocprofv3 --pmc passes)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visfly_amd import Dynamics
+N = int(sys.argv[1]); iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+kw = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+d = Dynamics(num=N, device="cuda:0", **kw)
+a = (torch.rand((N, 4), device="cuda") * 2 - 1) * 0.02 + torch.tensor([-1 / 3, 0, 0, 0], device="cuda")
+for _ in range(iters):
+    d.step(a)
+torch.cuda.synchronize()

@@ -11,8 +11,9 @@ import torch  # noqa: F401  -- must be imported first: it maps the one HIP runti
 
 from ._build import LIB
 
-ROWS = 28
-POS, QUAT, VEL, OMG, MOT, THR, AACC, ACC, T = 0, 3, 7, 10, 13, 17, 21, 24, 27
+TILE = 64
+# granule indices (include/visfly_amd.h): vectors live in components 1..3
+G_POS, G_QUAT, G_VEL, G_OMG, G_MOT, G_THR, G_AACC, G_ACC, G_RING = range(9)
 
 
 class DynCfg(C.Structure):
@@ -70,11 +71,13 @@ _vp = C.c_void_p
 SIGNATURES = {
     "vf_last_error": (C.c_char_p, []),
     "vf_abi_version": (C.c_int32, []),
-    "vf_dyn_create": (C.c_int, [C.POINTER(DynCfg), C.c_int32, C.POINTER(_vp)]),
+    "vf_dyn_create": (C.c_int, [C.POINTER(DynCfg), C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "vf_dyn_destroy": (None, [_vp]),
-    "vf_dyn_bind": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "vf_dyn_granules": (C.c_int32, [_vp]),
+    "vf_dyn_slab_floats": (C.c_int64, [_vp]),
+    "vf_dyn_bind": (C.c_int, [_vp, _vp]),
     "vf_dyn_step": (C.c_int, [_vp, _vp, _vp, _vp]),
-    "vf_dyn_reset": (C.c_int, [_vp, _vp, C.c_int32] + [_vp] * 8 + [_vp]),
+    "vf_dyn_reset": (C.c_int, [_vp, _vp, C.c_int32] + [_vp] * 10 + [_vp]),
     "vf_dyn_time_steps": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.POINTER(C.c_float)]),
 }
 

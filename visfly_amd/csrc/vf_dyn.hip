@@ -3,8 +3,9 @@
 // Replaces Dynamics.step / Dynamics.reset (envs/base/dynamics.py:218-269,319-382) and the
 // Quaternion / Integrator helpers it drives (utils/maths.py).  The reference issues ~3.8k
 // aten ops per control step; here one launch does the whole interval: one thread per
-// agent, state in VGPRs for all sub-steps, coalesced SoA row loads/stores, the AoS
-// (N,13) observation staged through LDS for coalesced stores.
+// agent, state in VGPRs for all sub-steps, the slab tiled per wavefront (one contiguous
+// chunk of 16-byte granules per wave, include/visfly_amd.h), the AoS (N,13) observation
+// staged through LDS for coalesced stores.
 #include "vf_common.hpp"
 #include "vf_dyn_device.hpp"
 
@@ -19,127 +20,133 @@ char* err_buf()
 }
 
 struct DynArgs {
-    int N;
-    float* S;           // [VF_ROWS][N]
-    float* Q;           // [D][4][N] ring
-    int* ctl;           // ctl[0] = ring head, ctl[1] = arrived blocks
-    const float* klin;  // [3][N] or null
-    const float* kquad;
+    int N;      // live agents
+    int G;      // granules per agent
+    int g_drag; // first drag granule or -1
+    float* S;   // slab
     const float4* action;  // (N,4)
     float* obs;            // (N,13) or null
 };
 
-// Pops the oldest action of agent i from the ring slot and pushes the new one
-// (dynamics.py:323-328).  The ring head is a device word advanced by the last block to
-// finish, so the launch is replayable from a hipGraph without host-side arguments.
-__device__ __forceinline__ void ring_exchange(const vf_dyn_cfg& c, const DynArgs& g, int i, float* a)
+// Pops the oldest action of agent i from its ring slot and pushes the new one
+// (dynamics.py:323-328).  The ring head is per agent and lives in the spare component of
+// the velocity granule (bit pattern of a small int), so the launch needs no cross-block
+// state and replays from a hipGraph unchanged; a reset zeroes all slots, after which any
+// head position is equivalent.
+__device__ __forceinline__ void ring_exchange(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, float& head_bits,
+                                              float* a)
 {
-    const float4 an = g.action[i];
+    float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) an = g.action[i];
     if (c.delay_steps > 0) {
-        const int slot = g.ctl[0];
-        float* qs = g.Q + ((size_t)slot * 4) * g.N + i;
-        a[0] = qs[0];
-        a[1] = qs[(size_t)g.N];
-        a[2] = qs[(size_t)2 * g.N];
-        a[3] = qs[(size_t)3 * g.N];
-        qs[0] = an.x;
-        qs[(size_t)g.N] = an.y;
-        qs[(size_t)2 * g.N] = an.z;
-        qs[(size_t)3 * g.N] = an.w;
-    } else {
-        a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
+        int head = __float_as_int(head_bits);
+        head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
+        float4* slot = granule(g.S, g.G, i, VF_G_RING + head);
+        const float4 old = *slot;
+        *slot = an;
+        an = old;
+        head_bits = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
     }
+    a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
 }
 
-__device__ __forceinline__ void ring_advance(const vf_dyn_cfg& c, int* ctl)
+__device__ __forceinline__ void drag_of(const vf_dyn_cfg& c, const DynArgs& g, int i, float* kl, float* kq)
 {
-    // every wave of this block has read ctl[0] (callers place a __syncthreads() before)
-    if (c.delay_steps > 0 && threadIdx.x == 0) {
-        const int head = ctl[0];
-        const unsigned prev = atomicAdd(reinterpret_cast<unsigned*>(ctl + 1), 1u);
-        if (prev == gridDim.x - 1) {
-            ctl[1] = 0;
-            ctl[0] = head + 1 == c.delay_steps ? 0 : head + 1;
-        }
+    if (g.g_drag >= 0) {
+        const float4 a = *granule(g.S, g.G, i, g.g_drag), b = *granule(g.S, g.G, i, g.g_drag + 1);
+        kl[0] = a.y; kl[1] = a.z; kl[2] = a.w;
+        kq[0] = b.y; kq[1] = b.z; kq[2] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
     }
 }
 
+// grid covers the padded agent count (multiple of 64); pad lanes integrate an inert hover state
 template <int ACT, int INTEG, bool CTRL_DELAY>
 __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg c, const DynArgs g)
 {
     __shared__ float tile[kBlock * 13];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.N;
-    float o[13];
-    if (live) {
-        float a[4];
-        ring_exchange(c, g, i, a);
-        Agent s;
-        load_agent(g.S, g.N, i, s);
-        float kl[3], kq[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            kl[k] = g.klin ? g.klin[(size_t)k * g.N + i] : c.k_lin[k];
-            kq[k] = g.kquad ? g.kquad[(size_t)k * g.N + i] : c.k_quad[k];
-        }
-        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
-        store_agent(g.S, g.N, i, s);
+    Agent s;
+    Spares sp;
+    load_agent(g.S, g.G, i, s, sp);
+    float a[4];
+    ring_exchange(c, g, i, live, sp.vel, a);
+    float kl[3], kq[3];
+    drag_of(c, g, i, kl, kq);
+    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
+    store_agent(g.S, g.G, i, s, sp);
+    if (g.obs) {
+        float o[13];
         obs_row(c, s, o);
+        store_rows_coalesced<13>(g.obs, g.N, blockIdx.x * kBlock, o, tile);
     }
-    if (g.obs) store_rows_coalesced<13>(g.obs, g.N, blockIdx.x * kBlock, o, tile);
-    else __syncthreads();
-    ring_advance(c, g.ctl);
 }
 
 struct ResetArgs {
-    int N, k;
+    int N, Npad, k, G, g_drag;
     float* S;
-    float* Q;
     const int* idx;
-    const float *pos, *quat, *vel, *omg, *mot, *thr, *t, *t_rand;
+    const float *pos, *quat, *vel, *omg, *mot, *thr, *t, *t_rand, *klin, *kquad;
 };
 
+// One thread per reset entry; a full reset (idx == null) also initialises the pad lanes.
 __global__ __launch_bounds__(kBlock) void k_dyn_reset(const vf_dyn_cfg c, const ResetArgs r)
 {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= r.k) return;
     const int i = r.idx ? r.idx[j] : j;
-    float* b = r.S + i;
-    const size_t N = r.N;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b[(VF_POS + d) * N] = r.pos ? r.pos[3 * (size_t)j + d] : 0.0f;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) b[(VF_QUAT + d) * N] = r.quat ? r.quat[4 * (size_t)j + d] : (d == 0 ? 1.0f : 0.0f);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b[(VF_VEL + d) * N] = r.vel ? r.vel[3 * (size_t)j + d] : 0.0f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b[(VF_OMG + d) * N] = r.omg ? r.omg[3 * (size_t)j + d] : 0.0f;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) b[(VF_MOT + d) * N] = r.mot ? r.mot[4 * (size_t)j + d] : c.w_init;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) b[(VF_THR + d) * N] = r.thr ? r.thr[4 * (size_t)j + d] : c.T_init;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b[(VF_AACC + d) * N] = 0.0f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b[(VF_ACC + d) * N] = 0.0f;
-    float t = 0.0f;
-    if (r.t) t = r.t[j];
-    else if (r.idx && r.t_rand) t = 0.0f + r.t_rand[j] * 3.14f * 2.0f;  // dynamics.py:256
-    b[VF_T * N] = t;
-    if (r.Q)
-        for (int s = 0; s < c.delay_steps * 4; ++s) r.Q[(size_t)s * N + i] = 0.0f;  // :243,262-263
+    const bool given = j < r.N || r.idx;  // pad lanes of a full reset take defaults
+    const size_t j3 = 3 * (size_t)j, j4 = 4 * (size_t)j;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = make_float4(1.f, 0.f, 0.f, 0.f);
+    float4 g2 = *granule(r.S, r.G, i, VF_G_VEL), g3 = *granule(r.S, r.G, i, VF_G_OMG);
+    float4 g6 = *granule(r.S, r.G, i, VF_G_AACC), g7 = *granule(r.S, r.G, i, VF_G_ACC);
+    g2.y = g2.z = g2.w = 0.f;
+    if (!r.idx) g2.x = 0.f;  // ring head
+    g3.y = g3.z = g3.w = 0.f;
+    g6.y = g6.z = g6.w = 0.f;  // dynamics.py:239-240,258-259
+    g7.y = g7.z = g7.w = 0.f;
+    float4 g4 = make_float4(c.w_init, c.w_init, c.w_init, c.w_init);
+    float4 g5 = make_float4(c.T_init, c.T_init, c.T_init, c.T_init);
+    if (given) {
+        if (r.pos) { g0.y = r.pos[j3]; g0.z = r.pos[j3 + 1]; g0.w = r.pos[j3 + 2]; }
+        if (r.quat) g1 = make_float4(r.quat[j4], r.quat[j4 + 1], r.quat[j4 + 2], r.quat[j4 + 3]);
+        if (r.vel) { g2.y = r.vel[j3]; g2.z = r.vel[j3 + 1]; g2.w = r.vel[j3 + 2]; }
+        if (r.omg) { g3.y = r.omg[j3]; g3.z = r.omg[j3 + 1]; g3.w = r.omg[j3 + 2]; }
+        if (r.mot) g4 = make_float4(r.mot[j4], r.mot[j4 + 1], r.mot[j4 + 2], r.mot[j4 + 3]);
+        if (r.thr) g5 = make_float4(r.thr[j4], r.thr[j4 + 1], r.thr[j4 + 2], r.thr[j4 + 3]);
+        if (r.t) g0.x = r.t[j];
+        else if (r.idx && r.t_rand) g0.x = 0.0f + r.t_rand[j] * 3.14f * 2.0f;  // dynamics.py:256
+    }
+    *granule(r.S, r.G, i, VF_G_POS) = g0;
+    *granule(r.S, r.G, i, VF_G_QUAT) = g1;
+    *granule(r.S, r.G, i, VF_G_VEL) = g2;
+    *granule(r.S, r.G, i, VF_G_OMG) = g3;
+    *granule(r.S, r.G, i, VF_G_MOT) = g4;
+    *granule(r.S, r.G, i, VF_G_THR) = g5;
+    *granule(r.S, r.G, i, VF_G_AACC) = g6;
+    *granule(r.S, r.G, i, VF_G_ACC) = g7;
+    for (int s = 0; s < c.delay_steps; ++s)  // :243,262-263
+        *granule(r.S, r.G, i, VF_G_RING + s) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r.g_drag >= 0) {
+        if (given && r.klin) {
+            *granule(r.S, r.G, i, r.g_drag) = make_float4(0.f, r.klin[j3], r.klin[j3 + 1], r.klin[j3 + 2]);
+            *granule(r.S, r.G, i, r.g_drag + 1) = make_float4(0.f, r.kquad[j3], r.kquad[j3 + 1], r.kquad[j3 + 2]);
+        } else if (!r.idx) {
+            *granule(r.S, r.G, i, r.g_drag) = make_float4(0.f, c.k_lin[0], c.k_lin[1], c.k_lin[2]);
+            *granule(r.S, r.G, i, r.g_drag + 1) = make_float4(0.f, c.k_quad[0], c.k_quad[1], c.k_quad[2]);
+        }
+    }
 }
 
 }  // namespace vf
 
 struct vf_dyn {
     vf_dyn_cfg cfg;
-    int N;
+    int N, Npad, G, g_drag;
     float* S = nullptr;
-    float* Q = nullptr;
-    const float* klin = nullptr;
-    const float* kquad = nullptr;
-    int* ctl = nullptr;  // device: {ring head, arrival counter}
 };
 
 namespace {
@@ -164,8 +171,8 @@ StepKernel pick_step_kernel(const vf_dyn_cfg& c)
 
 int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st)
 {
-    vf::DynArgs g{h->N, h->S, h->Q, h->ctl, h->klin, h->kquad, reinterpret_cast<const float4*>(action), state_out};
-    hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(vf::blocks_for(h->N)), dim3(vf::kBlock), 0, st, h->cfg, g);
+    vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out};
+    hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->cfg, g);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
@@ -178,24 +185,22 @@ const char* vf_last_error(void) { return vf::err_buf(); }
 
 int32_t vf_abi_version(void) { return VF_ABI_VERSION; }
 
-int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, vf_dyn** out)
+int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, int32_t per_agent_drag, vf_dyn** out)
 {
     if (!cfg || !out || N <= 0) return vf::fail(VF_EINVAL, "vf_dyn_create: null argument or N <= 0");
     if (cfg->action_type != VF_ACT_THRUST && cfg->action_type != VF_ACT_BODYRATE)
         return vf::fail(VF_EINVAL, "vf_dyn_create: action_type %d not supported (thrust=0, bodyrate=1)", cfg->action_type);
     if (cfg->integrator != VF_INT_EULER && cfg->integrator != VF_INT_RK4)
         return vf::fail(VF_EINVAL, "vf_dyn_create: integrator %d not supported (euler=0, rk4=1)", cfg->integrator);
-    if (cfg->interval_steps <= 0 || cfg->delay_steps < 0)
+    if (cfg->interval_steps <= 0 || cfg->delay_steps < 0 || cfg->delay_steps > 64)
         return vf::fail(VF_EINVAL, "vf_dyn_create: bad interval_steps/delay_steps");
     vf_dyn* h = new vf_dyn;
     h->cfg = *cfg;
     h->N = N;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->ctl), 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(h->ctl, 0, 2 * sizeof(int));
-    if (e != hipSuccess) {
-        delete h;
-        return vf::fail(VF_EHIP, "vf_dyn_create: hipMalloc/hipMemset failed: %s", hipGetErrorString(e));
-    }
+    // pad to whole workgroups so that every lane of every wave owns a (possibly inert) agent
+    h->Npad = (N + vf::kBlock - 1) / vf::kBlock * vf::kBlock;
+    h->g_drag = per_agent_drag ? VF_G_FIXED + cfg->delay_steps : -1;
+    h->G = VF_G_FIXED + cfg->delay_steps + (per_agent_drag ? 2 : 0);
     *out = h;
     return VF_OK;
 }
@@ -203,21 +208,18 @@ int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, vf_dyn** out)
 void vf_dyn_destroy(vf_dyn* h)
 {
     if (!h) return;
-    if (h->ctl) (void)hipFree(h->ctl);
     delete h;
 }
 
-int vf_dyn_bind(vf_dyn* h, float* slab, float* queue, const float* klin, const float* kquad)
+int32_t vf_dyn_granules(const vf_dyn* h) { return h ? h->G : 0; }
+
+int64_t vf_dyn_slab_floats(const vf_dyn* h) { return h ? (int64_t)h->Npad * h->G * 4 : 0; }
+
+int vf_dyn_bind(vf_dyn* h, float* slab)
 {
     if (!h || !slab) return vf::fail(VF_EINVAL, "vf_dyn_bind: null handle or slab");
-    if ((h->cfg.delay_steps > 0) != (queue != nullptr))
-        return vf::fail(VF_EINVAL, "vf_dyn_bind: queue must be given iff delay_steps > 0 (delay_steps=%d)", h->cfg.delay_steps);
-    if ((klin == nullptr) != (kquad == nullptr))
-        return vf::fail(VF_EINVAL, "vf_dyn_bind: klin and kquad must be given together");
+    if (reinterpret_cast<uintptr_t>(slab) % 16) return vf::fail(VF_EINVAL, "vf_dyn_bind: slab must be 16-byte aligned");
     h->S = slab;
-    h->Q = queue;
-    h->klin = klin;
-    h->kquad = kquad;
     return VF_OK;
 }
 
@@ -230,16 +232,17 @@ int vf_dyn_step(vf_dyn* h, const float* action, float* state_out, vf_stream_t st
 
 int vf_dyn_reset(vf_dyn* h, const int32_t* idx, int32_t k, const float* pos, const float* quat, const float* vel,
                  const float* omg, const float* mot, const float* thr, const float* t, const float* t_rand,
-                 vf_stream_t stream)
+                 const float* klin, const float* kquad, vf_stream_t stream)
 {
     if (!h) return vf::fail(VF_EINVAL, "vf_dyn_reset: null handle");
     if (!h->S) return vf::fail(VF_ESTATE, "vf_dyn_reset: vf_dyn_bind has not been called");
-    const int n = idx ? k : h->N;
+    if ((klin == nullptr) != (kquad == nullptr)) return vf::fail(VF_EINVAL, "vf_dyn_reset: klin and kquad go together");
+    if (klin && h->g_drag < 0) return vf::fail(VF_EINVAL, "vf_dyn_reset: handle was created without per-agent drag");
+    const int n = idx ? k : h->Npad;
     if (n < 0) return vf::fail(VF_EINVAL, "vf_dyn_reset: k < 0");
     hipStream_t st = vf::as_stream(stream);
-    if (!idx) VF_HIP(hipMemsetAsync(h->ctl, 0, 2 * sizeof(int), st));
     if (n == 0) return VF_OK;
-    vf::ResetArgs r{h->N, n, h->S, h->Q, idx, pos, quat, vel, omg, mot, thr, t, t_rand};
+    vf::ResetArgs r{h->N, h->Npad, n, h->G, h->g_drag, h->S, idx, pos, quat, vel, omg, mot, thr, t, t_rand, klin, kquad};
     hipLaunchKernelGGL(vf::k_dyn_reset, dim3(vf::blocks_for(n)), dim3(vf::kBlock), 0, st, h->cfg, r);
     VF_HIP(hipGetLastError());
     return VF_OK;

@@ -272,53 +272,47 @@ __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, 
     for (int k = 0; k < 3; ++k) s.w[k] = clampf(s.w[k], -c.omg_lim, c.omg_lim);
 }
 
-// ---- slab I/O: coalesced row loads/stores, lane i <-> agent i ----
-__device__ __forceinline__ void load_agent(const float* __restrict__ S, int N, int i, Agent& s)
+// ---- slab I/O: wave-tile AoSoA, one 16-byte granule per lane per access ----
+// float4 address of (agent i, granule g): see include/visfly_amd.h
+__device__ __forceinline__ float4* granule(float* __restrict__ S, int G, int i, int g)
 {
-    const float* b = S + i;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s.p[k] = b[(size_t)(VF_POS + k) * N];
-    s.q.w = b[(size_t)(VF_QUAT + 0) * N];
-    s.q.x = b[(size_t)(VF_QUAT + 1) * N];
-    s.q.y = b[(size_t)(VF_QUAT + 2) * N];
-    s.q.z = b[(size_t)(VF_QUAT + 3) * N];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s.v[k] = b[(size_t)(VF_VEL + k) * N];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s.w[k] = b[(size_t)(VF_OMG + k) * N];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s.wm[k] = b[(size_t)(VF_MOT + k) * N];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s.T[k] = b[(size_t)(VF_THR + k) * N];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s.aa[k] = b[(size_t)(VF_AACC + k) * N];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s.acc[k] = b[(size_t)(VF_ACC + k) * N];
-    s.t = b[(size_t)VF_T * N];
+    return reinterpret_cast<float4*>(S) + ((size_t)(i >> 6) * G + g) * VF_TILE + (i & 63);
 }
 
-__device__ __forceinline__ void store_agent(float* __restrict__ S, int N, int i, const Agent& s)
+struct Spares {  // component 0 of the vector granules (env-layer slots), carried through untouched
+    float vel, omg, aacc, acc;
+};
+
+__device__ __forceinline__ void load_agent(float* __restrict__ S, int G, int i, Agent& s, Spares& sp)
 {
-    float* b = S + i;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) b[(size_t)(VF_POS + k) * N] = s.p[k];
-    b[(size_t)(VF_QUAT + 0) * N] = s.q.w;
-    b[(size_t)(VF_QUAT + 1) * N] = s.q.x;
-    b[(size_t)(VF_QUAT + 2) * N] = s.q.y;
-    b[(size_t)(VF_QUAT + 3) * N] = s.q.z;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) b[(size_t)(VF_VEL + k) * N] = s.v[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) b[(size_t)(VF_OMG + k) * N] = s.w[k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) b[(size_t)(VF_MOT + k) * N] = s.wm[k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) b[(size_t)(VF_THR + k) * N] = s.T[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) b[(size_t)(VF_AACC + k) * N] = s.aa[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) b[(size_t)(VF_ACC + k) * N] = s.acc[k];
-    b[(size_t)VF_T * N] = s.t;
+    const float4 g0 = *granule(S, G, i, VF_G_POS);
+    const float4 g1 = *granule(S, G, i, VF_G_QUAT);
+    const float4 g2 = *granule(S, G, i, VF_G_VEL);
+    const float4 g3 = *granule(S, G, i, VF_G_OMG);
+    const float4 g4 = *granule(S, G, i, VF_G_MOT);
+    const float4 g5 = *granule(S, G, i, VF_G_THR);
+    const float4 g6 = *granule(S, G, i, VF_G_AACC);
+    const float4 g7 = *granule(S, G, i, VF_G_ACC);
+    s.t = g0.x; s.p[0] = g0.y; s.p[1] = g0.z; s.p[2] = g0.w;
+    s.q = Quat{g1.x, g1.y, g1.z, g1.w};
+    sp.vel = g2.x; s.v[0] = g2.y; s.v[1] = g2.z; s.v[2] = g2.w;
+    sp.omg = g3.x; s.w[0] = g3.y; s.w[1] = g3.z; s.w[2] = g3.w;
+    s.wm[0] = g4.x; s.wm[1] = g4.y; s.wm[2] = g4.z; s.wm[3] = g4.w;
+    s.T[0] = g5.x; s.T[1] = g5.y; s.T[2] = g5.z; s.T[3] = g5.w;
+    sp.aacc = g6.x; s.aa[0] = g6.y; s.aa[1] = g6.z; s.aa[2] = g6.w;
+    sp.acc = g7.x; s.acc[0] = g7.y; s.acc[1] = g7.z; s.acc[2] = g7.w;
+}
+
+__device__ __forceinline__ void store_agent(float* __restrict__ S, int G, int i, const Agent& s, const Spares& sp)
+{
+    *granule(S, G, i, VF_G_POS) = make_float4(s.t, s.p[0], s.p[1], s.p[2]);
+    *granule(S, G, i, VF_G_QUAT) = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
+    *granule(S, G, i, VF_G_VEL) = make_float4(sp.vel, s.v[0], s.v[1], s.v[2]);
+    *granule(S, G, i, VF_G_OMG) = make_float4(sp.omg, s.w[0], s.w[1], s.w[2]);
+    *granule(S, G, i, VF_G_MOT) = make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]);
+    *granule(S, G, i, VF_G_THR) = make_float4(s.T[0], s.T[1], s.T[2], s.T[3]);
+    *granule(S, G, i, VF_G_AACC) = make_float4(sp.aacc, s.aa[0], s.aa[1], s.aa[2]);
+    *granule(S, G, i, VF_G_ACC) = make_float4(sp.acc, s.acc[0], s.acc[1], s.acc[2]);
 }
 
 // state(N,13) row of one agent: [p, q wxyz, v + wind, w]  (dynamics.py:779-786)
@@ -340,7 +334,9 @@ __device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, in
     const int t = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < C; ++k) tile[t * C + k] = row[k];
-    __syncthreads();
+    // raw barrier: only the LDS writes above must land; outstanding global stores keep flying
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
     const int rows_here = min((int)blockDim.x, N - block_first);
     const int total = rows_here * C;
     float* dst = out + (size_t)block_first * C;

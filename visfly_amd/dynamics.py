@@ -2,9 +2,9 @@
 (envs/base/dynamics.py:19) whose ``step``/``reset`` run as single fused HIP launches.
 
 Same constructor kwargs (``dynamics_kwargs``), same ``reset``/``step`` signatures and
-return shapes, same properties.  State lives in ONE device slab ``[28][N]`` fp32 (SoA,
-component-major like the reference's internal ``(C, N)`` tensors); the public properties
-are transposed views of its rows, so nothing is copied to serve them.
+return shapes, same properties.  State lives in ONE device slab ``[N/64][G][64][4]`` fp32 (AoSoA,
+tiled per wavefront in 16-byte granules, include/visfly_amd.h); the public properties
+gather the requested components out of it.
 """
 from typing import List, Optional, Tuple, Union
 
@@ -12,8 +12,7 @@ import numpy as np
 import torch as th
 
 from . import _lib
-from ._lib import ACC, AACC, MOT, OMG, POS, QUAT, ROWS, THR, VEL, VisflyError
-from ._lib import T as TROW
+from ._lib import G_ACC, G_AACC, G_MOT, G_OMG, G_POS, G_QUAT, G_THR, G_VEL, TILE, VisflyError
 from .constants import ACTION_TYPES, derive_constants
 
 
@@ -80,22 +79,18 @@ class Dynamics:
 
         self.set_seed(seed)
 
-        N, D = self.num, self._comm_delay_steps
+        N = self.num
         with th.cuda.device(self.device):
-            self._slab = th.zeros((ROWS, N), dtype=th.float32, device=self.device)
-            self._queue = th.zeros((D, 4, N), dtype=th.float32, device=self.device) if D > 0 else None
-            self._klin = self._kquad = None
-            if drag_random:
-                self._klin = th.empty((3, N), dtype=th.float32, device=self.device)
-                self._kquad = th.empty((3, N), dtype=th.float32, device=self.device)
-                self._set_drag(th.ones((3, 1)), th.ones((3, 1)))
-            self._wind = th.as_tensor(np.asarray(c["wind"], np.float32), device=self.device).reshape(3, 1)
+            self._wind = th.as_tensor(np.asarray(c["wind"], np.float32), device=self.device).reshape(1, 3)
             self._cfg = _lib.DynCfg.from_dict(c)
             h = _lib._vp()
-            _lib.check(_lib.lib().vf_dyn_create(self._cfg, N, h))
+            _lib.check(_lib.lib().vf_dyn_create(self._cfg, N, 1 if drag_random else 0, h))
             self._h = h
-            _lib.check(_lib.lib().vf_dyn_bind(self._h, _lib.ptr(self._slab), _lib.ptr(self._queue),
-                                              _lib.ptr(self._klin), _lib.ptr(self._kquad)))
+            self._G = int(_lib.lib().vf_dyn_granules(self._h))
+            floats = int(_lib.lib().vf_dyn_slab_floats(self._h))
+            self._slab = th.zeros((floats // (self._G * TILE * 4), self._G, TILE, 4), dtype=th.float32,
+                                  device=self.device)
+            _lib.check(_lib.lib().vf_dyn_bind(self._h, _lib.ptr(self._slab)))
         self.reset()
 
     # ------------------------------------------------------------------ lifecycle
@@ -123,13 +118,12 @@ class Dynamics:
     def _stream(self):
         return _lib.current_stream(self.device)
 
-    def _set_drag(self, f_lin, f_quad):
-        """k = k_mean * factor, factor (3,1) shared or (3,N) per agent (dynamics.py:244-246)"""
+    def _drag_rows(self, f_lin, f_quad, k):
+        """k = k_mean * factor with factor (3,) shared or (k,3) per agent (dynamics.py:244-246) -> (k,3) x2"""
         c = self.constants
-        kl = th.as_tensor(np.asarray(c["k_lin"], np.float32)).reshape(3, 1) * f_lin
-        kq = th.as_tensor(np.asarray(c["k_quad"], np.float32)).reshape(3, 1) * f_quad
-        self._klin.copy_(kl.expand(3, self.num), non_blocking=True)
-        self._kquad.copy_(kq.expand(3, self.num), non_blocking=True)
+        kl = th.as_tensor(np.asarray(c["k_lin"], np.float32)).reshape(1, 3) * f_lin
+        kq = th.as_tensor(np.asarray(c["k_quad"], np.float32)).reshape(1, 3) * f_quad
+        return kl.expand(k, 3).contiguous(), kq.expand(k, 3).contiguous()
 
     # ------------------------------------------------------------------ reset / step
     def reset(
@@ -145,19 +139,25 @@ class Dynamics:
         with th.cuda.device(dev):
             idx = None
             k = self.num
+            klin = kquad = None
+            r = self._drag_random
             if indices is not None:
                 idx = th.as_tensor(indices, dtype=th.int32).reshape(-1).to(dev, non_blocking=True).contiguous()
                 k = idx.numel()
                 if t is None and t_rand is None:
                     t_rand = th.rand((k,), generator=self.rng)
-            elif self._drag_random:
-                r = self._drag_random
+                if r:  # per-agent redraw (the reference raises IndexError here, SURVEY C-2)
+                    fl = ((th.rand((k, 3), generator=self.rng) - 0.5) * 2 * r).clamp(-0.5, .5) + 1
+                    fq = ((th.rand((k, 3), generator=self.rng) - 0.5) * 2 * r).clamp(-0.5, .5) + 1
+                    klin, kquad = self._drag_rows(fl, fq, k)
+            elif r:  # one (3,1) factor pair shared by all agents, like the reference's full reset
                 fl = ((th.rand((3, 1), generator=self.rng) - 0.5) * 2 * r).clamp(-0.5, .5) + 1
                 fq = ((th.rand((3, 1), generator=self.rng) - 0.5) * 2 * r).clamp(-0.5, .5) + 1
-                self._set_drag(fl, fq)
+                klin, kquad = self._drag_rows(fl.reshape(1, 3), fq.reshape(1, 3), k)
             args = [_as_device_f32(pos, dev, 3), _as_device_f32(ori, dev, 4), _as_device_f32(vel, dev, 3),
                     _as_device_f32(ori_vel, dev, 3), _as_device_f32(motor_omega, dev, 4),
-                    _as_device_f32(thrusts, dev, 4), _as_device_f32(t, dev), _as_device_f32(t_rand, dev)]
+                    _as_device_f32(thrusts, dev, 4), _as_device_f32(t, dev), _as_device_f32(t_rand, dev),
+                    _as_device_f32(klin, dev, 3), _as_device_f32(kquad, dev, 3)]
             for a in args:
                 if a is not None and a.shape[0] != k:
                     raise ValueError(f"reset: expected {k} rows, got {tuple(a.shape)}")
@@ -178,18 +178,30 @@ class Dynamics:
         return out
 
     # ------------------------------------------------------------------ properties
+    def _vec(self, g):
+        """(N,3) copy of the xyz components of granule g"""
+        return self._slab[:, g, :, 1:4].reshape(-1, 3)[:self.num]
+
+    def _gran(self, g):
+        """(N,4) copy of granule g"""
+        return self._slab[:, g].reshape(-1, 4)[:self.num]
+
     @property
     def position(self):
-        return self._slab[POS:POS + 3].T
+        return self._vec(G_POS)
+
+    @property
+    def quaternion(self):
+        return self._gran(G_QUAT)
 
     @property
     def orientation(self):
         if self._is_quat_output:
-            return self._slab[QUAT:QUAT + 4].T
+            return self._gran(G_QUAT)
         return self._euler().T
 
     def _euler(self):
-        w, x, y, z = self._slab[QUAT:QUAT + 4]
+        w, x, y, z = self._gran(G_QUAT).T
         roll = th.atan2(2 * (w * x + y * z), 1 - 2 * (x.pow(2) + y.pow(2)))       # maths.py:244-249
         pitch = th.asin(2 * (w * y - z * x))
         yaw = th.atan2(2 * (w * z + x * y), 1 - 2 * (y.pow(2) + z.pow(2)))
@@ -197,12 +209,12 @@ class Dynamics:
 
     @property
     def direction(self):
-        w, x, y, z = self._slab[QUAT:QUAT + 4]                                     # maths.py:123-133
+        w, x, y, z = self._gran(G_QUAT).T                                          # maths.py:123-133
         return th.stack([1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w)]).T
 
     @property
     def R(self):
-        w, x, y, z = self._slab[QUAT:QUAT + 4]                                     # maths.py:110-120
+        w, x, y, z = self._gran(G_QUAT).T                                          # maths.py:110-120
         return th.stack([
             th.stack([1 - 2 * (y.pow(2) + z.pow(2)), 2 * (x * y - z * w), 2 * (x * z + y * w)]),
             th.stack([2 * (x * y + z * w), 1 - 2 * (x.pow(2) + z.pow(2)), 2 * (y * z - x * w)]),
@@ -210,35 +222,41 @@ class Dynamics:
 
     @property
     def velocity(self):
-        return (self._slab[VEL:VEL + 3] + self._wind).T
+        return self._vec(G_VEL) + self._wind
 
     @property
     def angular_velocity(self):
-        return self._slab[OMG:OMG + 3].T
+        return self._vec(G_OMG)
 
     @property
     def acceleration(self):
-        return self._slab[ACC:ACC + 3].T
+        return self._vec(G_ACC)
 
     @property
     def angular_acceleration(self):
-        return self._slab[AACC:AACC + 3].T
+        return self._vec(G_AACC)
 
     @property
     def t(self):
-        return self._slab[TROW]
+        return self._slab[:, G_POS, :, 0].reshape(-1)[:self.num]
 
     @property
     def motor_omega(self):
-        return self._slab[MOT:MOT + 4].T
+        return self._gran(G_MOT)
 
     @property
     def thrusts(self):
-        return self._slab[THR:THR + 4].T
+        return self._gran(G_THR)
+
+    @property
+    def delay_ring(self):
+        """(D, N, 4) delayed actions in slot order (slot = ring head at the time of the push)"""
+        D = self._comm_delay_steps
+        return th.stack([self._gran(_lib.G_RING + s) for s in range(D)]) if D else None
 
     @property
     def wind_velocity(self):
-        return self._wind.expand(3, self.num)
+        return self._wind.T.expand(3, self.num)
 
     @property
     def is_quat_output(self):
