@@ -196,3 +196,71 @@ def gae(rewards, values, episode_starts, last_values, dones, gamma, lam):
     lib().vfo_gae(_fp(r), _fp(v), _fp(e), _fp(lv), _fp(d), _fp(adv), _fp(ret), T, N,
                   float(gamma), float(lam))
     return adv, ret
+
+
+class OracleEnv:
+    """CPU restatement of DroneGymEnvsBase.step with visual=False (droneGymEnv.py:141-218):
+    dynamics step -> bbox collision -> counters/masks/reward -> (scripted) auto-reset."""
+
+    KINDS = {"hover": 0, "nav": 1, "racing": 2}
+
+    def __init__(self, consts, N, kind, max_episode_steps, target=(1.0, 0.0, 1.5), success_radius=0.5,
+                 is_collision_reset=True, gates=None):
+        self.N = N
+        self.dyn = OracleDynamics(consts, N)
+        e = EnvConsts()
+        e.kind = self.KINDS[kind]
+        e.max_episode_steps = int(max_episode_steps)
+        e.is_collision_reset = int(is_collision_reset)
+        lo, hi = (-30.0, -30.0, 0.0), (30.0, 30.0, 8.0)  # droneEnv.py:129
+        for d in range(3):
+            e.bbox_lo[d], e.bbox_hi[d], e.target[d] = lo[d], hi[d], float(target[d])
+        e.uav_radius = 0.1
+        e.success_radius = float(success_radius)
+        gates = [] if gates is None else gates
+        e.n_gates = len(gates)
+        for gi, gt in enumerate(gates):
+            for d in range(3):
+                e.gates[gi][d] = float(gt[d])
+        self.e = e
+        z = lambda dt, *s: np.zeros(s, dt)
+        self.a = dict(step_count=z(np.int32, N), reward=z(np.float32, N), rewards=z(np.float32, N),
+                      success=z(np.uint8, N), failure=z(np.uint8, N), episode_done=z(np.uint8, N),
+                      done=z(np.uint8, N), is_collision=z(np.uint8, N), is_out_bounds=z(np.uint8, N),
+                      once_collided=z(np.uint8, N), col_point=z(np.float32, N, 3), col_vec=z(np.float32, N, 3),
+                      col_dis=z(np.float32, N), next_gate=z(np.int32, N), past_gates=z(np.int32, N),
+                      is_pass_next=z(np.uint8, N))
+        self.es = EnvState()
+        for name, _ in EnvState._fields_:
+            setattr(self.es, name, self.a[name].ctypes.data)
+
+    def update_collision(self, idx=None):
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, np.int32)
+        lib().vfo_update_collision(C.byref(self.e), self.N, _fp(self.dyn.S), C.byref(self.es), _ip(idx),
+                                   0 if idx is None else len(idx))
+
+    def reset_full_state(self, fs):
+        """env.reset() with the spawn states given (droneGymEnv.py:302-327)"""
+        self.dyn.set_full_state(fs)
+        self.a["once_collided"][:] = 0
+        self.update_collision()
+        for k in ("reward", "rewards", "done", "episode_done", "step_count"):
+            self.a[k][:] = 0
+
+    def step(self, action):
+        """-> (obs_pre_reset (N,13), reward, done) ; no auto reset here"""
+        obs = self.dyn.step(action)
+        self.update_collision()
+        lib().vfo_env_post_step(C.byref(self.dyn.c), C.byref(self.e), self.N, _fp(self.dyn.S), C.byref(self.es))
+        return obs, self.a["reward"].copy(), self.a["done"].copy()
+
+    def reset_agents(self, idx, fs):
+        """reset_agent_by_id with given full states (droneGymEnv.py:339-349, droneEnv.py:260-288)"""
+        idx = np.ascontiguousarray(idx, np.int32)
+        fs = np.asarray(fs, np.float32)
+        self.dyn.reset(pos=fs[:, 0:3], quat=fs[:, 3:7], vel=fs[:, 7:10], omg=fs[:, 10:13], mot=fs[:, 13:17],
+                       thr=fs[:, 17:21], t=fs[:, 21], idx=idx)
+        self.update_collision(idx)
+        self.a["once_collided"][idx] = 0
+        lib().vfo_env_reset_attr(self.N, C.byref(self.es), _ip(idx), len(idx))

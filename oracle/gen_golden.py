@@ -61,10 +61,9 @@ def extract_consts(d):
 
     Keys follow oracle/vf_oracle.h::vfo_consts; each is computed with the SAME torch ops
     the reference applies at run time so the bits are the reference's bits."""
-    import reference.envs.base.dynamics as RD
-    from reference.utils.type import ACTION_TYPE
+    RD = sys.modules[type(d).__module__]   # reference dynamics module (holds the global g)
     tm = d._thrust_map
-    is_bodyrate = d.action_type == ACTION_TYPE.BODYRATE
+    is_bodyrate = d.action_type.name == "BODYRATE"
     c = {
         "action_type": np.int32(1 if is_bodyrate else 0),
         "integrator": np.int32(1 if d._integrator == "rk4" else 0),

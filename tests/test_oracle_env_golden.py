@@ -1,0 +1,65 @@
+"""Pins the oracle's env layer (bbox collision, reward, counters, masks) bit-for-bit against
+per-step traces captured from the stub-imported reference HoverEnv / NavigationEnv
+(oracle/gen_golden.py; resets are scripted from the captured reset events)."""
+import numpy as np
+import pytest
+
+import oracle
+from _golden import assert_bits_equal, consts_of, decode_actions, load
+
+ENVS = ["env_hover", "env_hover_256", "env_nav", "env_nav_close"]
+
+
+def run_env_fixture(name, make_env, step_fn, reset_fn, state_fn):
+    """drives any env implementation through the fixture; shared with the GPU parity test"""
+    fx = load(name)
+    acts = decode_actions(fx)
+    env = make_env(fx)
+    steps = acts.shape[0]
+    keep = list(fx["keep_steps"])
+    for k in range(steps):
+        out = step_fn(env, acts[k])
+        if str(fx["kind"]) == "nav":
+            # NavigationEnv's reward goes through acos (NavigationEnv.py:88): torch's vectorised CPU acos
+            # (SLEEF, <=1 ulp, not correctly rounded -- SURVEY App. B.4) cannot be reproduced bit-for-bit
+            # by another libm.  1 ulp of acos (<=2.4e-7) * 0.01 -> 1e-8 absolute, plus one final-rounding
+            # ulp (2^-23 relative) when that perturbation crosses a rounding boundary of the summed reward;
+            # everything that feeds done / counters / state stays bit-exact below.
+            tol = 1e-8 + 1.2e-7 * np.abs(fx["reward"][k])
+            assert (np.abs(out["reward"] - fx["reward"][k]) <= tol).all(), f"{name} reward @ {k}"
+        else:
+            assert_bits_equal(out["reward"], fx["reward"][k], f"{name} reward @ {k}")
+        assert np.array_equal(out["done"].astype(np.uint8), fx["done"][k]), f"{name} done @ {k}"
+        assert np.array_equal(out["step_count"], fx["step_count"][k]), f"{name} step_count @ {k}"
+        assert np.array_equal(out["is_collision"].astype(np.uint8), fx["is_collision"][k]), f"{name} is_collision @ {k}"
+        assert np.array_equal(out["is_out_bounds"].astype(np.uint8), fx["is_out_bounds"][k]), f"{name} oob @ {k}"
+        assert np.array_equal(out["success"].astype(np.uint8), fx["success"][k]), f"{name} success @ {k}"
+        assert_bits_equal(out["col_dis"], fx["col_dis"][k], f"{name} collision_dis @ {k}")
+        if k in keep:
+            assert_bits_equal(out["ext"], fx["ext_pre_keep"][keep.index(k)], f"{name} extend_state(pre-reset) @ {k}")
+        sel = fx["ev_step"] == k
+        assert np.array_equal(np.nonzero(out["done"])[0], fx["ev_agent"][sel]), f"{name} reset set @ {k}"
+        if sel.any():
+            reset_fn(env, fx["ev_agent"][sel], fx["ev_fs"][sel])
+        if k in keep:
+            assert_bits_equal(state_fn(env), fx["obs_state_keep"][keep.index(k)], f"{name} obs(post-reset) @ {k}")
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_oracle_env_trace(name):
+    def make_env(fx):
+        env = oracle.OracleEnv(consts_of(fx), fx["fs_init"].shape[0], str(fx["kind"]),
+                               int(fx["max_episode_steps"]), target=fx["target"])
+        env.reset_full_state(fx["fs_init"])
+        return env
+
+    def step_fn(env, a):
+        env.step(a)
+        out = {k: v.copy() for k, v in env.a.items()}
+        out["ext"] = env.dyn.extend_state
+        return out
+
+    def state_fn(env):
+        return env.dyn.extend_state[:, :13]
+
+    run_env_fixture(name, make_env, step_fn, lambda env, idx, fs: env.reset_agents(idx, fs), state_fn)
