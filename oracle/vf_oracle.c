@@ -419,7 +419,8 @@ void vfo_env_post_step(const vfo_consts* c, const vfo_env_consts* e, int N, cons
             float t7 = relu1 * ap * -0.005f;
             /* success(bool) * (max_steps - step_count)(int) * base_r * (0.2 + 0.8/(1 + 1*|v|)) */
             float sterm = (float)((int)success * (e->max_episode_steps - es->step_count[i]));
-            float t8 = sterm * 0.1f * (0.2f + 0.8f / (1.0f + 1.0f * norm3(v[0], v[1], v[2])));
+            /* python_scalar / tensor is tensor.reciprocal() * scalar in torch (two roundings) */
+            float t8 = sterm * 0.1f * (0.2f + (1.0f / (1.0f + 1.0f * norm3(v[0], v[1], v[2]))) * 0.8f);
             r = 0.1f * 0.0f + t1;
             r = r + t2; r = r + t3; r = r + t4; r = r + t5; r = r + t6; r = r + t7; r = r + t8;
         } else { /* RACING: RacingEnv.py:142-148,187-215 (is_pos_reward branch) */
