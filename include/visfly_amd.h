@@ -132,6 +132,98 @@ int vf_dyn_reset(vf_dyn* h, const int32_t* idx, int32_t k,
 int vf_dyn_time_steps(vf_dyn* h, const float* action, float* state_out, int32_t iters,
                       vf_stream_t stream, float* mean_us);
 
+/* =====================================================================================
+ * Env layer, visual=False: DroneEnvsBase.step + DroneGymEnvsBase.step + task reward/success
+ * fused with the dynamics step into ONE launch (envs/base/droneEnv.py:114-125,345-379;
+ * envs/base/droneGymEnv.py:141-218,357-423; envs/HoverEnv.py:62-94; envs/NavigationEnv.py:63-99;
+ * envs/RacingEnv.py:142-215).
+ *
+ * Per-agent env state rides in the spare components of the dynamics granules:
+ *   VF_G_OMG.c0  = _step_count (int32 bits)            droneGymEnv.py:119
+ *   VF_G_AACC.c0 = _rewards running sum (fp32)         droneGymEnv.py:121
+ *   VF_G_ACC.c0  = flag word (int32 bits): VF_F_* | episode counter << 8
+ * RacingEnv adds one granule after the dynamics ones: (next gate, passed gates, is_pass_next, -).
+ * ===================================================================================== */
+enum { VF_ENV_HOVER = 0, VF_ENV_NAV = 1, VF_ENV_RACING = 2 };
+enum {
+    VF_F_EPISODE_DONE = 1, VF_F_ONCE_COLLIDED = 2, VF_F_COLLISION = 4, VF_F_OUT_BOUNDS = 8,
+    VF_F_SUCCESS = 16, VF_F_FAILURE = 32, VF_F_DONE = 64
+};
+enum { VF_EP_SUCCESS = 1, VF_EP_TRUNCATED = 2, VF_EP_COLLIDED = 4, VF_EP_EPISODE_DONE = 8 };
+#define VF_MAX_GATES 8
+#define VF_MAX_SPAWN 4
+
+/* one UniformStateRandomizer box (utils/randomization.py:108-170); orientation = euler r,p,y */
+typedef struct vf_spawn_box {
+    float pos_mean[3], pos_half[3];
+    float ori_mean[3], ori_half[3];
+    float vel_mean[3], vel_half[3];
+    float omg_mean[3], omg_half[3];
+} vf_spawn_box;
+
+typedef struct vf_env_cfg {
+    int32_t kind;                 /* VF_ENV_*                                            */
+    int32_t max_episode_steps;    /* droneGymEnv.py:134                                  */
+    int32_t is_collision_reset;   /* droneGymEnv.py:189                                  */
+    int32_t n_gates;              /* RacingEnv.py:87-93                                  */
+    float bbox_lo[3], bbox_hi[3]; /* droneEnv.py:129                                     */
+    float uav_radius;             /* droneEnv.py:31,367                                  */
+    float success_radius;         /* HoverEnv.py:60, NavigationEnv.py:61, RacingEnv.py:98 */
+    float target[3];              /* Hover / Navigation target                           */
+    float gates[VF_MAX_GATES][3];
+    int32_t n_spawn;              /* 1 = Uniform, >1 = Union of Uniform boxes (randomization.py:250-296) */
+    int32_t pad0;
+    vf_spawn_box spawn[VF_MAX_SPAWN];
+    uint64_t seed;                /* Philox key of the on-device spawner                 */
+} vf_env_cfg;
+
+/* Outputs of one env step; obs/reward/done are required, the rest may be NULL. */
+typedef struct vf_env_out {
+    float* obs;           /* (N,13) state observation AFTER auto-reset (droneGymEnv.py:209-218) */
+    float* reward;        /* (N,)   reward of this step, pre-reset                              */
+    uint8_t* done;        /* (N,)   done of this step, pre-reset                                */
+    float* ep_return;     /* (N,)   episode reward sum, written where done   (collect_info :251) */
+    int32_t* ep_length;   /* (N,)   episode length, written where done                     (:252) */
+    uint8_t* ep_flags;    /* (N,)   VF_EP_* bits, written where done                  (:241-269) */
+    float* terminal_obs;  /* (N,13) pre-reset observation rows, written where done        (:260) */
+    int32_t* gate;        /* (N,)   RacingEnv next-gate observation after auto-reset            */
+} vf_env_out;
+
+/* Dense per-agent view of the env state for the reference's properties (droneGymEnv.py:477-571,
+ * droneEnv.py:424-504); every pointer optional. */
+typedef struct vf_env_view {
+    int32_t* step_count; float* rewards; uint8_t* flags /* VF_F_* */;
+    float* col_point /* (N,3) */; float* col_vec /* (N,3) */; float* col_dis /* (N,) */;
+    int32_t* gate; int32_t* past_gates;
+} vf_env_view;
+
+typedef struct vf_env vf_env;
+
+int vf_env_create(const vf_dyn_cfg* dyn, const vf_env_cfg* env, int32_t N, int32_t per_agent_drag, vf_env** out);
+void vf_env_destroy(vf_env* h);
+int32_t vf_env_granules(const vf_env* h);
+int64_t vf_env_slab_floats(const vf_env* h);
+int vf_env_bind(vf_env* h, float* slab);
+vf_dyn* vf_env_dyn(vf_env* h);   /* embedded dynamics handle sharing the slab (DroneEnvsBase.dynamics) */
+
+/* DroneGymEnvsBase.reset / reset_agent_by_id (droneGymEnv.py:302-349, droneEnv.py:260-288).
+ *   idx NULL: all agents.  full_state (k,22) = [p q v w motor thrust t] (dynamics.py:793-803)
+ *   gives the spawn states (host-replayed randomizer, parity mode); NULL draws them on the
+ *   device from the cfg spawn boxes with Philox4x32-10 keyed by (seed, agent, episode#).
+ *   Clears counters/flags of the reset agents, recomputes their collision flags. */
+int vf_env_reset(vf_env* h, const int32_t* idx, int32_t k, const float* full_state, vf_stream_t stream);
+
+/* DroneGymEnvsBase.step (droneGymEnv.py:141-218): dynamics interval + bbox collision + counters +
+ * success/failure + reward + done masks, and, if auto_reset, the examine()/reset_agent_by_id of
+ * done agents with on-device spawning.  action (N,4) AoS in [-1,1]. */
+int vf_env_step(vf_env* h, const float* action, const vf_env_out* out, int32_t auto_reset, vf_stream_t stream);
+
+int vf_env_query(vf_env* h, const vf_env_view* view, vf_stream_t stream);
+
+/* mean device microseconds per vf_env_step launch over `iters` back-to-back launches (HIP events) */
+int vf_env_time_steps(vf_env* h, const float* action, const vf_env_out* out, int32_t auto_reset, int32_t iters,
+                      vf_stream_t stream, float* mean_us);
+
 #ifdef __cplusplus
 }
 #endif

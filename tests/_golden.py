@@ -35,3 +35,17 @@ def assert_bits_equal(a, b, what=""):
         idx = np.argwhere(ne)[0]
         raise AssertionError(f"{what}: {int(ne.sum())} of {a.size} fp32 words differ; first at {tuple(idx)}: "
                              f"{a[tuple(idx)]!r} vs {b[tuple(idx)]!r}; max|diff|={np.nanmax(np.abs(a - b)):.3e}")
+
+
+# constructor kwargs of the env fixtures (same as oracle/gen_golden.py::ENV_CASES)
+ENV_DYN = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+ENV_KW = {
+    "env_hover": dict(max_episode_steps=64),
+    "env_hover_256": dict(max_episode_steps=256),
+    "env_nav": dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [
+        {"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}),
+    "env_nav_close": dict(max_episode_steps=96, target=[2.5, 0., 1.5], random_kwargs={"state_generator": {
+        "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
+                                        "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
+                                        "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}),
+}

@@ -1,0 +1,121 @@
+"""Parity of the fused HIP env step (HoverEnv / NavigationEnv classes -> C-ABI -> kernel) with the
+per-step traces captured from the reference envs:
+  * scripted resets: reward / done / step_count / collision flags / collision_dis / pre-reset state
+    bit-exact at every step (Nav reward to the acos tolerance stated in test_oracle_env_golden.py);
+  * replay spawn mode: the env runs on its own from seed 42 -- spawn states, auto-resets and
+    returned observations are bit-identical to the reference's run."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import ENV_DYN, ENV_KW, assert_bits_equal, consts_of, decode_actions, load
+from test_oracle_env_golden import ENVS, run_env_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def make(name, fx, **kw):
+    from visfly_amd.envs import HoverEnv, NavigationEnv
+    cls = {"hover": HoverEnv, "nav": NavigationEnv}[str(fx["kind"])]
+    return cls(num_agent_per_scene=fx["fs_init"].shape[0], num_scene=1, seed=int(fx["seed"]), visual=False,
+               dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True, constants=consts_of(fx),
+               **ENV_KW[name], **kw)
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_env_trace_scripted_resets(name):
+    def make_env(fx):
+        env = make(name, fx)
+        env.reset(state=torch.from_numpy(fx["fs_init"]))
+        return env
+
+    def step_fn(env, a):
+        obs, reward, done, info = env.step(torch.from_numpy(a).cuda(), is_test=True)
+        n = lambda t: t.cpu().numpy()
+        return dict(reward=n(reward), done=n(done), step_count=n(env._step_count), is_collision=n(env.is_collision),
+                    is_out_bounds=n(env.is_out_bounds), success=n(env.success), col_dis=n(env.collision_dis),
+                    ext=n(env.extend_state))
+
+    def reset_fn(env, idx, fs):
+        env.reset_agent_by_id(torch.from_numpy(idx.astype(np.int64)), state=torch.from_numpy(fs))
+
+    run_env_fixture(name, make_env, step_fn, reset_fn, lambda env: env.state.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_env_replay_mode_matches_reference_run(name):
+    fx = load(name)
+    acts = decode_actions(fx)
+    env = make(name, fx, spawn="replay")
+    obs0 = env.reset()
+    assert_bits_equal(env.full_state.cpu().numpy(), fx["fs_init"], f"{name} spawn states")
+    assert_bits_equal(obs0["state"].cpu().numpy(), fx["obs0_state"], f"{name} reset() observation")
+    keep = list(fx["keep_steps"])
+    is_nav = str(fx["kind"]) == "nav"
+    for k in range(acts.shape[0]):
+        obs, reward, done, info = env.step(torch.from_numpy(acts[k]).cuda())
+        r = reward.cpu().numpy()
+        if is_nav:
+            assert (np.abs(r - fx["reward"][k]) <= 5e-8 + 1.2e-7 * np.abs(fx["reward"][k])).all(), f"reward @ {k}"
+        else:
+            assert_bits_equal(r, fx["reward"][k], f"{name} reward @ {k}")
+        d = done.cpu().numpy()
+        assert np.array_equal(d.astype(np.uint8), fx["done"][k]), f"{name} done @ {k}"
+        sel = fx["ev_step"] == k
+        if sel.any():
+            idx = fx["ev_agent"][sel]
+            assert_bits_equal(env.full_state.cpu().numpy()[idx], fx["ev_fs"][sel], f"{name} auto-reset states @ {k}")
+            i0 = int(idx[0])
+            assert info[i0]["episode"]["l"] == fx["step_count"][k][i0]
+            assert info[i0]["TimeLimit.truncated"] == bool(fx["step_count"][k][i0] >= int(fx["max_episode_steps"]))
+        if k in keep:
+            assert_bits_equal(obs["state"].cpu().numpy(), fx["obs_state_keep"][keep.index(k)], f"{name} obs @ {k}")
+
+
+def test_device_spawn_statistics_and_conventions():
+    """device (Philox) spawn mode: one launch per step; spawn box respected, counters reset, reward/done
+    are the pre-reset values, obs the post-reset ones, episode stats consistent."""
+    from visfly_amd.envs import HoverEnv
+    N = 4096
+    env = HoverEnv(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(ENV_DYN), device="cuda:0",
+                   max_episode_steps=32, tensor_output=True)
+    obs = env.reset()
+    p = obs["state"][:, :3]
+    lo, hi = torch.tensor([0., -1., 1.], device="cuda"), torch.tensor([2., 1., 2.], device="cuda")
+    assert (p >= lo).all() and (p <= hi).all()
+    assert p.std(dim=0).min() > 0.2  # actually random
+    assert (obs["state"][:, 3:7] == torch.tensor([1., 0, 0, 0], device="cuda")).all()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    seen_done = 0
+    for k in range(70):
+        a = (torch.rand((N, 4), device="cuda", generator=g) * 2 - 1) * 0.3 + torch.tensor([-1 / 3, 0, 0, 0], device="cuda")
+        obs, reward, done, info = env.step(a.clamp(-1, 1))
+        sc = env._step_count
+        assert (sc[done] == 0).all()          # counters of reset agents cleared
+        assert (sc <= 32).all()
+        if done.any():
+            seen_done += int(done.sum())
+            i = int(torch.where(done)[0][0])
+            d = info[i]
+            assert d["episode"]["l"] >= 1 and ("terminal_observation" in d)
+            pr = obs["state"][done][:, :3]
+            assert (pr >= lo).all() and (pr <= hi).all()   # post-reset observation is a fresh spawn
+            assert (env.t[done] <= 6.28).all()
+    assert seen_done >= 2 * N  # every agent timed out at least twice
+    # different seeds / agents give different spawns; same seed reproduces
+    env2 = HoverEnv(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True)
+    env3 = HoverEnv(num_agent_per_scene=N, seed=4, dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True)
+    a, b, c = env2.reset()["state"], HoverEnv(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(ENV_DYN),
+                                             device="cuda:0", tensor_output=True).reset()["state"], env3.reset()["state"]
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_numpy_output_convention():
+    from visfly_amd.envs import HoverEnv
+    env = HoverEnv(num_agent_per_scene=64, dynamics_kwargs=dict(ENV_DYN), device="cuda:0")  # tensor_output=False default
+    obs = env.reset()
+    assert isinstance(obs["state"], np.ndarray)
+    obs, r, d, info = env.step(np.zeros((64, 4), np.float32))
+    assert isinstance(r, np.ndarray) and r.dtype == np.float32 and d.dtype == np.int32   # droneGymEnv.py:218
+    with pytest.raises(AssertionError):
+        HoverEnv(num_agent_per_scene=4, dynamics_kwargs=dict(ENV_DYN), device="cuda:0").step(np.zeros((4, 4)))

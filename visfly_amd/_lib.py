@@ -60,6 +60,41 @@ class DynCfg(C.Structure):
         return c
 
 
+MAX_GATES, MAX_SPAWN = 8, 4
+
+
+class SpawnBox(C.Structure):
+    """mirror of vf_spawn_box"""
+    _fields_ = [(n, C.c_float * 3) for n in ("pos_mean", "pos_half", "ori_mean", "ori_half",
+                                              "vel_mean", "vel_half", "omg_mean", "omg_half")]
+
+
+class EnvCfg(C.Structure):
+    """mirror of vf_env_cfg"""
+    _fields_ = [
+        ("kind", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("is_collision_reset", C.c_int32), ("n_gates", C.c_int32),
+        ("bbox_lo", C.c_float * 3), ("bbox_hi", C.c_float * 3),
+        ("uav_radius", C.c_float), ("success_radius", C.c_float),
+        ("target", C.c_float * 3), ("gates", (C.c_float * 3) * MAX_GATES),
+        ("n_spawn", C.c_int32), ("pad0", C.c_int32),
+        ("spawn", SpawnBox * MAX_SPAWN),
+        ("seed", C.c_uint64),
+    ]
+
+
+class EnvOut(C.Structure):
+    """mirror of vf_env_out (device pointers)"""
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "reward", "done", "ep_return", "ep_length", "ep_flags",
+                                          "terminal_obs", "gate")]
+
+
+class EnvView(C.Structure):
+    """mirror of vf_env_view (device pointers)"""
+    _fields_ = [(n, C.c_void_p) for n in ("step_count", "rewards", "flags", "col_point", "col_vec", "col_dis",
+                                          "gate", "past_gates")]
+
+
 class VisflyError(RuntimeError):
     pass
 
@@ -79,6 +114,16 @@ SIGNATURES = {
     "vf_dyn_step": (C.c_int, [_vp, _vp, _vp, _vp]),
     "vf_dyn_reset": (C.c_int, [_vp, _vp, C.c_int32] + [_vp] * 10 + [_vp]),
     "vf_dyn_time_steps": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.POINTER(C.c_float)]),
+    "vf_env_create": (C.c_int, [C.POINTER(DynCfg), C.POINTER(EnvCfg), C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "vf_env_destroy": (None, [_vp]),
+    "vf_env_granules": (C.c_int32, [_vp]),
+    "vf_env_slab_floats": (C.c_int64, [_vp]),
+    "vf_env_bind": (C.c_int, [_vp, _vp]),
+    "vf_env_dyn": (_vp, [_vp]),
+    "vf_env_reset": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
+    "vf_env_step": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, _vp]),
+    "vf_env_query": (C.c_int, [_vp, C.POINTER(EnvView), _vp]),
+    "vf_env_time_steps": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, C.c_int32, _vp, C.POINTER(C.c_float)]),
 }
 
 

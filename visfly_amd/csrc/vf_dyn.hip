@@ -8,6 +8,7 @@
 // staged through LDS for coalesced stores.
 #include "vf_common.hpp"
 #include "vf_dyn_device.hpp"
+#include "vf_handles.hpp"
 
 #pragma clang fp contract(off)
 
@@ -17,49 +18,6 @@ char* err_buf()
 {
     static thread_local char buf[512] = "";
     return buf;
-}
-
-struct DynArgs {
-    int N;      // live agents
-    int G;      // granules per agent
-    int g_drag; // first drag granule or -1
-    float* S;   // slab
-    const float4* action;  // (N,4)
-    float* obs;            // (N,13) or null
-};
-
-// Pops the oldest action of agent i from its ring slot and pushes the new one
-// (dynamics.py:323-328).  The ring head is per agent and lives in the spare component of
-// the velocity granule (bit pattern of a small int), so the launch needs no cross-block
-// state and replays from a hipGraph unchanged; a reset zeroes all slots, after which any
-// head position is equivalent.
-__device__ __forceinline__ void ring_exchange(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, float& head_bits,
-                                              float* a)
-{
-    float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) an = g.action[i];
-    if (c.delay_steps > 0) {
-        int head = __float_as_int(head_bits);
-        head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
-        float4* slot = granule(g.S, g.G, i, VF_G_RING + head);
-        const float4 old = *slot;
-        *slot = an;
-        an = old;
-        head_bits = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
-    }
-    a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
-}
-
-__device__ __forceinline__ void drag_of(const vf_dyn_cfg& c, const DynArgs& g, int i, float* kl, float* kq)
-{
-    if (g.g_drag >= 0) {
-        const float4 a = *granule(g.S, g.G, i, g.g_drag), b = *granule(g.S, g.G, i, g.g_drag + 1);
-        kl[0] = a.y; kl[1] = a.z; kl[2] = a.w;
-        kq[0] = b.y; kq[1] = b.z; kq[2] = b.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
-    }
 }
 
 // grid covers the padded agent count (multiple of 64); pad lanes integrate an inert hover state
@@ -143,11 +101,6 @@ __global__ __launch_bounds__(kBlock) void k_dyn_reset(const vf_dyn_cfg c, const 
 
 }  // namespace vf
 
-struct vf_dyn {
-    vf_dyn_cfg cfg;
-    int N, Npad, G, g_drag;
-    float* S = nullptr;
-};
 
 namespace {
 
@@ -188,19 +141,9 @@ int32_t vf_abi_version(void) { return VF_ABI_VERSION; }
 int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, int32_t per_agent_drag, vf_dyn** out)
 {
     if (!cfg || !out || N <= 0) return vf::fail(VF_EINVAL, "vf_dyn_create: null argument or N <= 0");
-    if (cfg->action_type != VF_ACT_THRUST && cfg->action_type != VF_ACT_BODYRATE)
-        return vf::fail(VF_EINVAL, "vf_dyn_create: action_type %d not supported (thrust=0, bodyrate=1)", cfg->action_type);
-    if (cfg->integrator != VF_INT_EULER && cfg->integrator != VF_INT_RK4)
-        return vf::fail(VF_EINVAL, "vf_dyn_create: integrator %d not supported (euler=0, rk4=1)", cfg->integrator);
-    if (cfg->interval_steps <= 0 || cfg->delay_steps < 0 || cfg->delay_steps > 64)
-        return vf::fail(VF_EINVAL, "vf_dyn_create: bad interval_steps/delay_steps");
+    if (int rc = vf::check_dyn_cfg(cfg)) return rc;
     vf_dyn* h = new vf_dyn;
-    h->cfg = *cfg;
-    h->N = N;
-    // pad to whole workgroups so that every lane of every wave owns a (possibly inert) agent
-    h->Npad = (N + vf::kBlock - 1) / vf::kBlock * vf::kBlock;
-    h->g_drag = per_agent_drag ? VF_G_FIXED + cfg->delay_steps : -1;
-    h->G = VF_G_FIXED + cfg->delay_steps + (per_agent_drag ? 2 : 0);
+    vf::init_dyn_handle(h, cfg, N, per_agent_drag, 0);
     *out = h;
     return VF_OK;
 }

@@ -315,6 +315,49 @@ __device__ __forceinline__ void store_agent(float* __restrict__ S, int G, int i,
     *granule(S, G, i, VF_G_ACC) = make_float4(sp.acc, s.acc[0], s.acc[1], s.acc[2]);
 }
 
+struct DynArgs {
+    int N;      // live agents
+    int G;      // granules per agent
+    int g_drag; // first drag granule or -1
+    float* S;   // slab
+    const float4* action;  // (N,4)
+    float* obs;            // (N,13) or null
+};
+
+// Pops the oldest action of agent i from its ring slot and pushes the new one
+// (dynamics.py:323-328).  The ring head is per agent and lives in the spare component of
+// the velocity granule (bit pattern of a small int), so the launch needs no cross-block
+// state and replays from a hipGraph unchanged; a reset zeroes all slots, after which any
+// head position is equivalent.
+__device__ __forceinline__ void ring_exchange(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, float& head_bits,
+                                              float* a)
+{
+    float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) an = g.action[i];
+    if (c.delay_steps > 0) {
+        int head = __float_as_int(head_bits);
+        head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
+        float4* slot = granule(g.S, g.G, i, VF_G_RING + head);
+        const float4 old = *slot;
+        *slot = an;
+        an = old;
+        head_bits = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
+    }
+    a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
+}
+
+__device__ __forceinline__ void drag_of(const vf_dyn_cfg& c, const DynArgs& g, int i, float* kl, float* kq)
+{
+    if (g.g_drag >= 0) {
+        const float4 a = *granule(g.S, g.G, i, g.g_drag), b = *granule(g.S, g.G, i, g.g_drag + 1);
+        kl[0] = a.y; kl[1] = a.z; kl[2] = a.w;
+        kq[0] = b.y; kq[1] = b.z; kq[2] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
+    }
+}
+
 // state(N,13) row of one agent: [p, q wxyz, v + wind, w]  (dynamics.py:779-786)
 __device__ __forceinline__ void obs_row(const vf_dyn_cfg& c, const Agent& s, float* o)
 {

@@ -1,0 +1,384 @@
+// vf_env.hip -- the whole visual=False env step in one launch (gfx950).
+//
+// Replaces, per control step, the chain DroneGymEnvsBase.step -> DroneEnvsBase.step ->
+// Dynamics.step -> update_collision -> get_success/get_reward -> done masks -> per-agent
+// Python info loop -> examine()/reset_agent_by_id with its per-agent randomizer loop
+// (envs/base/droneGymEnv.py:141-218,339-423; envs/base/droneEnv.py:237-288,345-379;
+// envs/HoverEnv.py, envs/NavigationEnv.py, envs/RacingEnv.py).  One thread per agent; the
+// env counters ride in the spare components of the dynamics granules, so the env step
+// moves the same bytes as the bare dynamics step plus its outputs.
+#include "vf_env_device.hpp"
+#include "vf_handles.hpp"
+
+#pragma clang fp contract(off)
+
+struct vf_env {
+    vf_dyn dyn;
+    vf_env_cfg cfg;
+    int g_race;  // racing granule or -1
+};
+
+namespace vf {
+
+struct EnvArgs {
+    DynArgs d;
+    vf_env_out out;
+    int g_race;
+    int auto_reset;
+};
+
+// env counters <-> spare slots
+struct EnvRegs {
+    int step_count;
+    float rewards;
+    int flags;  // VF_F_* | episode << 8
+};
+
+__device__ __forceinline__ EnvRegs unpack_env(const Spares& sp)
+{
+    return EnvRegs{__float_as_int(sp.omg), sp.aacc, __float_as_int(sp.acc)};
+}
+__device__ __forceinline__ void pack_env(const EnvRegs& r, Spares& sp)
+{
+    sp.omg = __int_as_float(r.step_count);
+    sp.aacc = r.rewards;
+    sp.acc = __int_as_float(r.flags);
+}
+
+__device__ __forceinline__ int set_flag(int flags, int bit, bool on) { return on ? (flags | bit) : (flags & ~bit); }
+
+// collision flags of the current position into the flag word (droneEnv.py:361-369)
+__device__ __forceinline__ int collision_flags(int flags, const Collision& col)
+{
+    flags = set_flag(flags, VF_F_COLLISION, col.hit);
+    flags = set_flag(flags, VF_F_OUT_BOUNDS, col.oob);
+    if (col.hit) flags |= VF_F_ONCE_COLLIDED;
+    return flags;
+}
+
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g)
+{
+    __shared__ float tile[kBlock * 13];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < g.d.N;
+    Agent s;
+    Spares sp;
+    load_agent(g.d.S, g.d.G, i, s, sp);
+    float a[4];
+    ring_exchange(c, g.d, i, live, sp.vel, a);
+    float kl[3], kq[3];
+    drag_of(c, g.d, i, kl, kq);
+    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
+
+    EnvRegs er = unpack_env(sp);
+    const float vel[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};  // dynamics.py:751-752
+    Collision col = bbox_collision(e, s.p);
+    er.flags = collision_flags(er.flags, col);
+    er.step_count += 1;                                                                  // droneGymEnv.py:163
+
+    bool success = false;
+    float reward;
+    int gate = 0, passed = 0;
+    float4 race = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (KIND == VF_ENV_HOVER) {
+        reward = hover_reward(s.p, e.target, s.q, vel, s.w);
+    } else if constexpr (KIND == VF_ENV_NAV) {
+        success = norm3(s.p[0] - e.target[0], s.p[1] - e.target[1], s.p[2] - e.target[2]) <= e.success_radius;
+        reward = nav_reward(e, s.p, s.q, vel, s.w, col, success, er.step_count);
+    } else {  // RacingEnv.get_success / get_reward (RacingEnv.py:142-148,199-215)
+        race = *granule(g.d.S, g.d.G, i, g.g_race);
+        gate = __float_as_int(race.x);
+        gate = (unsigned)gate < (unsigned)e.n_gates ? gate : 0;
+        passed = __float_as_int(race.y);
+        const float* gt = e.gates[gate];
+        const bool pass = norm3(s.p[0] - gt[0], s.p[1] - gt[1], s.p[2] - gt[2]) <= e.success_radius;
+        gate = gate + (pass ? 1 : 0);
+        gate = gate == e.n_gates ? 0 : gate;
+        passed += pass ? 1 : 0;
+        reward = hover_reward(s.p, e.gates[gate], s.q, vel, s.w);
+        reward = reward + (pass ? 1.0f : 0.0f) * 20.0f;
+        race.z = __int_as_float(pass ? 1 : 0);
+    }
+    er.rewards = er.rewards + reward;                                                    // :185
+    bool ep_done = (er.flags & VF_F_EPISODE_DONE) || success || (er.flags & VF_F_OUT_BOUNDS);   // :188
+    if (e.is_collision_reset) ep_done = ep_done || (er.flags & VF_F_COLLISION);          // :189-190
+    const bool truncated = er.step_count >= e.max_episode_steps;
+    const bool done = ep_done || truncated;                                              // :193
+    er.flags = set_flag(er.flags, VF_F_EPISODE_DONE, ep_done);
+    er.flags = set_flag(er.flags, VF_F_SUCCESS, success);
+    er.flags = set_flag(er.flags, VF_F_DONE, done);
+
+    float o[13];
+    obs_row(c, s, o);
+    if (live) {
+        g.out.reward[i] = reward;
+        g.out.done[i] = done ? 1 : 0;
+        if (done) {  // collect_info (:238-275)
+            if (g.out.ep_return) g.out.ep_return[i] = er.rewards;
+            if (g.out.ep_length) g.out.ep_length[i] = er.step_count;
+            if (g.out.ep_flags)
+                g.out.ep_flags[i] = (success ? VF_EP_SUCCESS : 0) | (truncated ? VF_EP_TRUNCATED : 0) |
+                                    ((er.flags & VF_F_ONCE_COLLIDED) ? VF_EP_COLLIDED : 0) |
+                                    (ep_done ? VF_EP_EPISODE_DONE : 0);
+            if (g.out.terminal_obs) {
+                float* to = g.out.terminal_obs + 13 * (size_t)i;
+#pragma unroll
+                for (int k = 0; k < 13; ++k) to[k] = o[k];
+            }
+        }
+    }
+    if (done && g.auto_reset) {  // examine() -> reset_agent_by_id (:339-349,420-423)
+        unsigned episode = ((unsigned)er.flags >> 8) + 1u;
+        spawn_agent(e, i, episode, true, s);
+        reset_rotors(c, s);
+        for (int q = 0; q < c.delay_steps; ++q)
+            *granule(g.d.S, g.d.G, i, VF_G_RING + q) = make_float4(0.f, 0.f, 0.f, 0.f);     // dynamics.py:262-263
+        col = bbox_collision(e, s.p);                                                       // droneEnv.py:285-288
+        er.flags = (int)(episode << 8);
+        er.flags = set_flag(er.flags, VF_F_COLLISION, col.hit);
+        er.flags = set_flag(er.flags, VF_F_OUT_BOUNDS, col.oob);
+        er.step_count = 0;                                                                  // :387-392
+        er.rewards = 0.0f;
+        if constexpr (KIND == VF_ENV_RACING) {
+            gate = racing_choose_gate(s.p);
+            passed = 0;
+            race.z = __int_as_float(0);
+        }
+        obs_row(c, s, o);
+    }
+    if constexpr (KIND == VF_ENV_RACING) {
+        race.x = __int_as_float(gate);
+        race.y = __int_as_float(passed);
+        *granule(g.d.S, g.d.G, i, g.g_race) = race;
+        if (live && g.out.gate) g.out.gate[i] = gate;
+    }
+    pack_env(er, sp);
+    store_agent(g.d.S, g.d.G, i, s, sp);
+    store_rows_coalesced<13>(g.out.obs, g.d.N, blockIdx.x * kBlock, o, tile);
+}
+
+struct EnvResetArgs {
+    DynArgs d;
+    int k, g_race;
+    const int* idx;
+    const float* fs;  // (k,22) or null
+};
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_env_reset(const vf_dyn_cfg c, const vf_env_cfg e, const EnvResetArgs r)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= r.k) return;
+    const int i = r.idx ? r.idx[j] : j;
+    const bool pad = !r.idx && j >= r.d.N;
+    Agent s;
+    Spares sp;
+    load_agent(r.d.S, r.d.G, i, s, sp);
+    EnvRegs er = unpack_env(sp);
+    unsigned episode = ((unsigned)er.flags >> 8) + 1u;
+    if (!r.idx) { sp.vel = __int_as_float(0); }  // ring head
+    reset_rotors(c, s);
+    if (r.fs && !pad) {
+        const float* f = r.fs + 22 * (size_t)j;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { s.p[d] = f[d]; s.v[d] = f[7 + d]; s.w[d] = f[10 + d]; }
+        s.q = Quat{f[3], f[4], f[5], f[6]};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { s.wm[d] = f[13 + d]; s.T[d] = f[17 + d]; }
+        s.t = f[21];
+    } else {
+        spawn_agent(e, i, episode, r.idx != nullptr, s);
+    }
+    for (int q = 0; q < c.delay_steps; ++q) *granule(r.d.S, r.d.G, i, VF_G_RING + q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const Collision col = bbox_collision(e, s.p);
+    er.flags = (int)(episode << 8);
+    er.flags = set_flag(er.flags, VF_F_COLLISION, col.hit);
+    er.flags = set_flag(er.flags, VF_F_OUT_BOUNDS, col.oob);
+    er.step_count = 0;
+    er.rewards = 0.0f;
+    pack_env(er, sp);
+    store_agent(r.d.S, r.d.G, i, s, sp);
+    if (r.d.g_drag >= 0 && !r.idx) {  // shared mean coefficients until a drag randomisation overwrites them
+        *granule(r.d.S, r.d.G, i, r.d.g_drag) = make_float4(0.f, c.k_lin[0], c.k_lin[1], c.k_lin[2]);
+        *granule(r.d.S, r.d.G, i, r.d.g_drag + 1) = make_float4(0.f, c.k_quad[0], c.k_quad[1], c.k_quad[2]);
+    }
+    if constexpr (KIND == VF_ENV_RACING) {
+        float4 race = *granule(r.d.S, r.d.G, i, r.g_race);
+        race.x = __int_as_float(racing_choose_gate(s.p));
+        if (r.idx) race.y = __int_as_float(0);  // RacingEnv.reset keeps _past_targets_num (RacingEnv.py:165-170)
+        race.z = __int_as_float(0);
+        *granule(r.d.S, r.d.G, i, r.g_race) = race;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_env_query(const vf_dyn_cfg c, const vf_env_cfg e, const DynArgs d, int g_race,
+                                                      const vf_env_view v)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.N) return;
+    Agent s;
+    Spares sp;
+    load_agent(d.S, d.G, i, s, sp);
+    const EnvRegs er = unpack_env(sp);
+    const Collision col = bbox_collision(e, s.p);
+    if (v.step_count) v.step_count[i] = er.step_count;
+    if (v.rewards) v.rewards[i] = er.rewards;
+    if (v.flags) v.flags[i] = (uint8_t)(er.flags & 0xff);
+    if (v.col_dis) v.col_dis[i] = col.dis;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (v.col_point) v.col_point[3 * (size_t)i + k] = col.cp[k];
+        if (v.col_vec) v.col_vec[3 * (size_t)i + k] = col.vec[k];
+    }
+    if (g_race >= 0) {
+        const float4 race = *granule(d.S, d.G, i, g_race);
+        if (v.gate) v.gate[i] = __float_as_int(race.x);
+        if (v.past_gates) v.past_gates[i] = __float_as_int(race.y);
+    }
+}
+
+}  // namespace vf
+
+namespace {
+
+using EnvKernel = void (*)(const vf_dyn_cfg, const vf_env_cfg, const vf::EnvArgs);
+
+template <int KIND>
+EnvKernel pick_env_kernel_k(const vf_dyn_cfg& c)
+{
+    const int key = (c.action_type == VF_ACT_BODYRATE ? 4 : 0) | (c.integrator == VF_INT_RK4 ? 2 : 0) |
+                    (c.ctrl_delay ? 1 : 0);
+    switch (key) {
+    case 0: return vf::k_env_step<KIND, VF_ACT_THRUST, VF_INT_EULER, false>;
+    case 1: return vf::k_env_step<KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    case 2: return vf::k_env_step<KIND, VF_ACT_THRUST, VF_INT_RK4, false>;
+    case 3: return vf::k_env_step<KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
+    case 4: return vf::k_env_step<KIND, VF_ACT_BODYRATE, VF_INT_EULER, false>;
+    case 5: return vf::k_env_step<KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    case 6: return vf::k_env_step<KIND, VF_ACT_BODYRATE, VF_INT_RK4, false>;
+    default: return vf::k_env_step<KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
+    }
+}
+
+EnvKernel pick_env_kernel(const vf_env* h)
+{
+    switch (h->cfg.kind) {
+    case VF_ENV_HOVER: return pick_env_kernel_k<VF_ENV_HOVER>(h->dyn.cfg);
+    case VF_ENV_NAV: return pick_env_kernel_k<VF_ENV_NAV>(h->dyn.cfg);
+    default: return pick_env_kernel_k<VF_ENV_RACING>(h->dyn.cfg);
+    }
+}
+
+vf::DynArgs dyn_args(const vf_env* h, const float* action, float* obs)
+{
+    return vf::DynArgs{h->dyn.N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(action), obs};
+}
+
+int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int auto_reset, hipStream_t st)
+{
+    vf::EnvArgs g{dyn_args(h, action, out->obs), *out, h->g_race, auto_reset};
+    hipLaunchKernelGGL(pick_env_kernel(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_env_create(const vf_dyn_cfg* dyn, const vf_env_cfg* env, int32_t N, int32_t per_agent_drag, vf_env** out)
+{
+    if (!dyn || !env || !out || N <= 0) return vf::fail(VF_EINVAL, "vf_env_create: null argument or N <= 0");
+    if (int rc = vf::check_dyn_cfg(dyn)) return rc;
+    if (env->kind < VF_ENV_HOVER || env->kind > VF_ENV_RACING) return vf::fail(VF_EINVAL, "vf_env_create: bad env kind %d", env->kind);
+    if (env->n_spawn < 1 || env->n_spawn > VF_MAX_SPAWN) return vf::fail(VF_EINVAL, "vf_env_create: n_spawn must be 1..%d", VF_MAX_SPAWN);
+    if (env->kind == VF_ENV_RACING && (env->n_gates < 1 || env->n_gates > VF_MAX_GATES))
+        return vf::fail(VF_EINVAL, "vf_env_create: n_gates must be 1..%d", VF_MAX_GATES);
+    if (env->max_episode_steps <= 0) return vf::fail(VF_EINVAL, "vf_env_create: max_episode_steps must be > 0");
+    vf_env* h = new vf_env;
+    const int extra = env->kind == VF_ENV_RACING ? 1 : 0;
+    vf::init_dyn_handle(&h->dyn, dyn, N, per_agent_drag, extra);
+    h->cfg = *env;
+    h->g_race = extra ? h->dyn.g_extra : -1;
+    *out = h;
+    return VF_OK;
+}
+
+void vf_env_destroy(vf_env* h) { delete h; }
+
+int32_t vf_env_granules(const vf_env* h) { return h ? h->dyn.G : 0; }
+
+int64_t vf_env_slab_floats(const vf_env* h) { return h ? (int64_t)h->dyn.Npad * h->dyn.G * 4 : 0; }
+
+int vf_env_bind(vf_env* h, float* slab)
+{
+    if (!h) return vf::fail(VF_EINVAL, "vf_env_bind: null handle");
+    return vf_dyn_bind(&h->dyn, slab);
+}
+
+vf_dyn* vf_env_dyn(vf_env* h) { return h ? &h->dyn : nullptr; }
+
+int vf_env_reset(vf_env* h, const int32_t* idx, int32_t k, const float* full_state, vf_stream_t stream)
+{
+    if (!h) return vf::fail(VF_EINVAL, "vf_env_reset: null handle");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_reset: vf_env_bind has not been called");
+    const int n = idx ? k : h->dyn.Npad;
+    if (n < 0) return vf::fail(VF_EINVAL, "vf_env_reset: k < 0");
+    if (n == 0) return VF_OK;
+    vf::EnvResetArgs r{dyn_args(h, nullptr, nullptr), n, h->g_race, idx, full_state};
+    hipStream_t st = vf::as_stream(stream);
+    const dim3 grid(vf::blocks_for(n)), block(vf::kBlock);
+    switch (h->cfg.kind) {
+    case VF_ENV_HOVER: hipLaunchKernelGGL(vf::k_env_reset<VF_ENV_HOVER>, grid, block, 0, st, h->dyn.cfg, h->cfg, r); break;
+    case VF_ENV_NAV: hipLaunchKernelGGL(vf::k_env_reset<VF_ENV_NAV>, grid, block, 0, st, h->dyn.cfg, h->cfg, r); break;
+    default: hipLaunchKernelGGL(vf::k_env_reset<VF_ENV_RACING>, grid, block, 0, st, h->dyn.cfg, h->cfg, r); break;
+    }
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_env_step(vf_env* h, const float* action, const vf_env_out* out, int32_t auto_reset, vf_stream_t stream)
+{
+    if (!h || !action || !out) return vf::fail(VF_EINVAL, "vf_env_step: null argument");
+    if (!out->obs || !out->reward || !out->done) return vf::fail(VF_EINVAL, "vf_env_step: obs, reward and done outputs are required");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_step: vf_env_bind has not been called");
+    return launch_env_step(h, action, out, auto_reset, vf::as_stream(stream));
+}
+
+int vf_env_query(vf_env* h, const vf_env_view* view, vf_stream_t stream)
+{
+    if (!h || !view) return vf::fail(VF_EINVAL, "vf_env_query: null argument");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_query: vf_env_bind has not been called");
+    hipLaunchKernelGGL(vf::k_env_query, dim3(vf::blocks_for(h->dyn.N)), dim3(vf::kBlock), 0, vf::as_stream(stream),
+                       h->dyn.cfg, h->cfg, dyn_args(h, nullptr, nullptr), h->g_race, *view);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_env_time_steps(vf_env* h, const float* action, const vf_env_out* out, int32_t auto_reset, int32_t iters,
+                      vf_stream_t stream, float* mean_us)
+{
+    if (!h || !action || !out || !mean_us || iters <= 0) return vf::fail(VF_EINVAL, "vf_env_time_steps: bad argument");
+    if (!out->obs || !out->reward || !out->done) return vf::fail(VF_EINVAL, "vf_env_time_steps: obs, reward and done outputs are required");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_time_steps: vf_env_bind has not been called");
+    hipStream_t st = vf::as_stream(stream);
+    hipEvent_t e0, e1;
+    VF_HIP(hipEventCreate(&e0));
+    VF_HIP(hipEventCreate(&e1));
+    VF_HIP(hipEventRecord(e0, st));
+    for (int it = 0; it < iters; ++it) {
+        int rc = launch_env_step(h, action, out, auto_reset, st);
+        if (rc != VF_OK) return rc;
+    }
+    VF_HIP(hipEventRecord(e1, st));
+    VF_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    VF_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *mean_us = ms * 1000.0f / (float)iters;
+    return VF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// Per-agent env arithmetic fused behind the dynamics interval (gfx950): bbox collision,
+// task success / reward, counters and done masks, on-device spawning.
+//
+// Rounding follows the reference's torch ops: elementwise ops rounded
+// separately, x.norm(dim=1) over 3 columns = sqrt(fma(z,z,fma(y,y,x*x))), over 4 columns
+// separately rounded squares, (a*b).sum(dim=1) = (a0*b0 + a1*b1) + a2*b2, python scalars cast
+// to fp32 at the op, `scalar / tensor` = reciprocal(tensor) * scalar.
+#pragma once
+#include "vf_dyn_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vf {
+
+__device__ __forceinline__ float norm3(float x, float y, float z)
+{
+    return sqrtf(__builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+}
+__device__ __forceinline__ float norm4(float a, float b, float c, float d)
+{
+    return sqrtf(((a * a + b * b) + c * c) + d * d);
+}
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+struct Collision {
+    float cp[3], vec[3], dis;
+    bool hit, oob;
+};
+
+// DroneEnvsBase.update_collision, bbox branch (envs/base/droneEnv.py:345-369)
+__device__ __forceinline__ Collision bbox_collision(const vf_env_cfg& e, const float* p)
+{
+    Collision c;
+    float best = p[0] - e.bbox_lo[0];
+    int bi = 0;
+#pragma unroll
+    for (int d = 1; d < 6; ++d) {  // hstack([p - lo, hi - p]).min(dim=1): first minimum wins
+        const float v = d < 3 ? p[d] - e.bbox_lo[d] : e.bbox_hi[d - 3] - p[d - 3];
+        if (v < best) { best = v; bi = d; }
+    }
+    c.oob = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        c.cp[d] = p[d];
+        if (bi == d) c.cp[d] = e.bbox_lo[d];
+        if (bi == d + 3) c.cp[d] = e.bbox_hi[d];
+        c.oob = c.oob || (p[d] < e.bbox_lo[d]) || (p[d] > e.bbox_hi[d]);
+        c.vec[d] = c.cp[d] - p[d];
+    }
+    c.dis = norm3(c.vec[0], c.vec[1], c.vec[2]);
+    c.hit = c.dis < e.uav_radius;
+    return c;
+}
+
+// HoverEnv.get_reward (envs/HoverEnv.py:83-94), also the positional RacingEnv reward
+__device__ __forceinline__ float hover_reward(const float* p, const float* tgt, const Quat& q, const float* v,
+                                              const float* w)
+{
+    const float c1 = (float)(-0.1 * 1 / 9), c2 = (float)-0.00001, c3 = (float)-0.002;
+    float r = 0.1f + norm3(p[0] - tgt[0], p[1] - tgt[1], p[2] - tgt[2]) * c1;
+    r = r + norm4(q.w - 1.0f, q.x, q.y, q.z) * c2;
+    r = r + norm3(v[0], v[1], v[2]) * c3;
+    r = r + norm3(w[0], w[1], w[2]) * c3;
+    return r;
+}
+
+// NavigationEnv.get_reward (envs/NavigationEnv.py:84-99); step_count already incremented
+__device__ __forceinline__ float nav_reward(const vf_env_cfg& e, const float* p, const Quat& q, const float* v,
+                                            const float* w, const Collision& col, bool success, int step_count)
+{
+    const float tp[3] = {e.target[0] - p[0], e.target[1] - p[1], e.target[2] - p[2]};
+    float t1 = dot3(v, tp) / (1e-6f + norm3(tp[0], tp[1], tp[2]));
+    t1 = (t1 > 10.0f ? 10.0f : t1) * 0.01f;
+    float dir[3];  // Quaternion.x_axis (utils/maths.py:123-133)
+    dir[0] = 1.0f - 2.0f * (q.y * q.y + q.z * q.z);
+    dir[1] = 2.0f * (q.x * q.y + q.z * q.w);
+    dir[2] = 2.0f * (q.x * q.z - q.y * q.w);
+    const float thrd = (float)(3.14159265358979323846 / 18.0);
+    const float vn = norm3(v[0], v[1], v[2]);
+    float cs = dot3(dir, v) / (1e-6f + vn) / 1.0f;
+    cs = clampf(cs, -1.0f, 1.0f);
+    float ang = acosf(cs);
+    ang = ang < thrd ? thrd : ang;
+    const float t2 = (ang - thrd) * -0.01f;
+    const float t3 = norm4(q.w - 1.0f, q.x, q.y, q.z) * (float)-0.00001;
+    const float t4 = vn * -0.002f;
+    const float t5 = norm3(w[0], w[1], w[2]) * -0.002f;
+    const float t6 = 1.0f / (col.dis + 0.2f) * -0.01f;
+    float relu1 = 1.0f - col.dis;
+    relu1 = relu1 > 0.0f ? relu1 : 0.0f;
+    float ap = dot3(col.vec, v) / (1e-6f + col.dis);
+    ap = ap > 0.0f ? ap : 0.0f;
+    const float t7 = relu1 * ap * -0.005f;
+    const float sterm = (float)(success ? e.max_episode_steps - step_count : 0);
+    const float t8 = sterm * 0.1f * (0.2f + (1.0f / (1.0f + 1.0f * vn)) * 0.8f);
+    float r = 0.1f * 0.0f + t1;
+    r = r + t2; r = r + t3; r = r + t4; r = r + t5; r = r + t6; r = r + t7; r = r + t8;
+    return r;
+}
+
+// ---- Philox4x32-10 counter RNG for the on-device spawner ----
+struct U4 {
+    unsigned x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 ctr, unsigned k0, unsigned k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = U4{hi1 ^ ctr.y ^ k0, lo1, hi0 ^ ctr.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f); }
+
+// UniformStateRandomizer._generate + safe_generate (utils/randomization.py:64-96,153-170) and
+// UnionRandomizer (:284-296) for one agent.  Draw order per agent mirrors the reference
+// (pos, ori, vel, ang-vel, then the union pick and t); the stream itself is Philox keyed by
+// (seed, agent, episode) instead of the reference's global MT19937, so spawns are statistically
+// -- not bitwise -- equivalent; bitwise parity uses host-replayed states (vf_env_reset).
+__device__ __forceinline__ void spawn_agent(const vf_env_cfg& e, int agent, unsigned episode, bool indexed, Agent& s)
+{
+    const unsigned k0 = (unsigned)e.seed, k1 = (unsigned)(e.seed >> 32);
+    const U4 r0 = philox4x32_10(U4{(unsigned)agent, episode, 0u, 0x5eedu}, k0, k1);
+    const U4 r1 = philox4x32_10(U4{(unsigned)agent, episode, 1u, 0x5eedu}, k0, k1);
+    const U4 r2 = philox4x32_10(U4{(unsigned)agent, episode, 2u, 0x5eedu}, k0, k1);
+    const U4 r3 = philox4x32_10(U4{(unsigned)agent, episode, 3u, 0x5eedu}, k0, k1);
+    const float u[12] = {u01(r0.x), u01(r0.y), u01(r0.z), u01(r0.w), u01(r1.x), u01(r1.y),
+                         u01(r1.z), u01(r1.w), u01(r2.x), u01(r2.y), u01(r2.z), u01(r2.w)};
+    int b = 0;
+    if (e.n_spawn > 1) b = (int)(r3.x % (unsigned)e.n_spawn);  // th.randint(0, M)
+    const vf_spawn_box& sb = e.spawn[b];
+    float eul[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        s.p[d] = sb.pos_mean[d] + (2.0f * u[d] - 1.0f) * sb.pos_half[d];                 // :154-156
+        eul[d] = (2.0f * u[3 + d] - 1.0f) * sb.ori_half[d] + sb.ori_mean[d];             // :167
+        s.v[d] = (2.0f * u[6 + d] - 1.0f) * sb.vel_half[d] + sb.vel_mean[d];             // :168
+        s.w[d] = (2.0f * u[9 + d] - 1.0f) * sb.omg_half[d] + sb.omg_mean[d];             // :169
+    }
+    // Quaternion.from_euler(roll, pitch, yaw), zyx (utils/maths.py:256-269)
+    const float cy = cosf(eul[2] * 0.5f), sy = sinf(eul[2] * 0.5f);
+    const float cp = cosf(eul[1] * 0.5f), sp = sinf(eul[1] * 0.5f);
+    const float cr = cosf(eul[0] * 0.5f), sr = sinf(eul[0] * 0.5f);
+    s.q.w = cr * cp * cy + sr * sp * sy;
+    s.q.x = sr * cp * cy - cr * sp * sy;
+    s.q.y = cr * sp * cy + sr * cp * sy;
+    s.q.z = cr * cp * sy - sr * sp * cy;
+    s.t = indexed ? 0.0f + u01(r3.y) * 3.14f * 2.0f : 0.0f;                              // dynamics.py:236,256
+}
+
+// Dynamics.reset defaults for everything the spawner does not draw (dynamics.py:229-263)
+__device__ __forceinline__ void reset_rotors(const vf_dyn_cfg& c, Agent& s)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s.wm[k] = c.w_init; s.T[k] = c.T_init; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s.aa[k] = 0.0f; s.acc[k] = 0.0f; }
+}
+
+// RacingEnv._choose_target (envs/RacingEnv.py:172-185)
+__device__ __forceinline__ int racing_choose_gate(const float* p)
+{
+    const float rx = p[0] - 4.0f, ry = p[1] - 0.0f;
+    if (rx < 0.0f) return ry > 0.0f ? 0 : 3;
+    return rx > 0.0f ? 1 : 2;
+}
+
+}  // namespace vf

@@ -1,0 +1,37 @@
+// Host-side handle layouts shared by the translation units of libvisfly_amd.so.
+#pragma once
+#include "vf_common.hpp"
+
+struct vf_dyn {
+    vf_dyn_cfg cfg;
+    int N, Npad, G, g_drag, g_extra;  // g_extra: first granule after the dynamics ones (env layer)
+    float* S = nullptr;
+};
+
+namespace vf {
+
+inline int check_dyn_cfg(const vf_dyn_cfg* cfg)
+{
+    if (cfg->action_type != VF_ACT_THRUST && cfg->action_type != VF_ACT_BODYRATE)
+        return fail(VF_EINVAL, "action_type %d not supported (thrust=0, bodyrate=1)", cfg->action_type);
+    if (cfg->integrator != VF_INT_EULER && cfg->integrator != VF_INT_RK4)
+        return fail(VF_EINVAL, "integrator %d not supported (euler=0, rk4=1)", cfg->integrator);
+    if (cfg->interval_steps <= 0 || cfg->delay_steps < 0 || cfg->delay_steps > 64)
+        return fail(VF_EINVAL, "bad interval_steps/delay_steps");
+    return VF_OK;
+}
+
+// granule budget: 8 dynamics + delay ring + optional per-agent drag pair + `extra` env granules
+inline void init_dyn_handle(vf_dyn* h, const vf_dyn_cfg* cfg, int N, int per_agent_drag, int extra)
+{
+    h->cfg = *cfg;
+    h->N = N;
+    // pad to whole workgroups so that every lane of every wave owns a (possibly inert) agent
+    h->Npad = (N + kBlock - 1) / kBlock * kBlock;
+    h->g_drag = per_agent_drag ? VF_G_FIXED + cfg->delay_steps : -1;
+    h->g_extra = VF_G_FIXED + cfg->delay_steps + (per_agent_drag ? 2 : 0);
+    h->G = h->g_extra + extra;
+    h->S = nullptr;
+}
+
+}  // namespace vf

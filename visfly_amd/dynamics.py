@@ -49,6 +49,7 @@ class Dynamics:
             wind_settings: Optional[List] = (0, 0, 0),
             rotor_sim: bool = True,
             constants: Optional[dict] = None,
+            _attach=None,
     ):
         assert action_type in ["bodyrate", "thrust", "velocity", "position"]
         assert ori_output_type in ["quaternion", "euler"]
@@ -78,25 +79,28 @@ class Dynamics:
         self.name = cfg if isinstance(cfg, str) else cfg.get("name", "custom")
 
         self.set_seed(seed)
-
-        N = self.num
-        with th.cuda.device(self.device):
-            self._wind = th.as_tensor(np.asarray(c["wind"], np.float32), device=self.device).reshape(1, 3)
+        self._owns_handle = True
+        self._wind = th.as_tensor(np.asarray(c["wind"], np.float32), device=self.device).reshape(1, 3)
+        if _attach is None:
+            with th.cuda.device(self.device):
+                self._cfg = _lib.DynCfg.from_dict(c)
+                h = _lib._vp()
+                _lib.check(_lib.lib().vf_dyn_create(self._cfg, self.num, 1 if drag_random else 0, h))
+                self._h = h
+                self._G = int(_lib.lib().vf_dyn_granules(self._h))
+                floats = int(_lib.lib().vf_dyn_slab_floats(self._h))
+                self._slab = th.zeros((floats // (self._G * TILE * 4), self._G, TILE, 4), dtype=th.float32,
+                                      device=self.device)
+                _lib.check(_lib.lib().vf_dyn_bind(self._h, _lib.ptr(self._slab)))
+            self.reset()
+        else:  # embedded in an env handle that owns slab and lifetime (DroneEnvsBase.dynamics)
+            self._h, self._slab, self._G = _attach
             self._cfg = _lib.DynCfg.from_dict(c)
-            h = _lib._vp()
-            _lib.check(_lib.lib().vf_dyn_create(self._cfg, N, 1 if drag_random else 0, h))
-            self._h = h
-            self._G = int(_lib.lib().vf_dyn_granules(self._h))
-            floats = int(_lib.lib().vf_dyn_slab_floats(self._h))
-            self._slab = th.zeros((floats // (self._G * TILE * 4), self._G, TILE, 4), dtype=th.float32,
-                                  device=self.device)
-            _lib.check(_lib.lib().vf_dyn_bind(self._h, _lib.ptr(self._slab)))
-        self.reset()
-
+            self._owns_handle = False
     # ------------------------------------------------------------------ lifecycle
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and getattr(self, "_owns_handle", False):
             _lib.lib().vf_dyn_destroy(h)
 
     def __del__(self):

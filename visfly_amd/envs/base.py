@@ -1,0 +1,471 @@
+"""VecEnv surface of the visual=False drone envs, backed by the fused HIP env-step kernel.
+
+Mirrors ``DroneGymEnvsBase`` / ``DroneEnvsBase`` of the reference (envs/base/droneGymEnv.py:19,
+envs/base/droneEnv.py:18): same constructor kwargs, ``reset() / step(action[, is_test]) /
+reset_agent_by_id() / get_observation() / detach()``, same ``(obs, reward, done, info)``
+conventions (obs = post-auto-reset, reward/done = pre-reset; ``tensor_output`` switches the
+numpy return path, droneGymEnv.py:209-218), same properties.
+
+Two spawn modes:
+  ``spawn="device"`` (default): done agents are re-spawned inside the step kernel with a Philox
+      counter RNG -- one launch per step, no host round trip.
+  ``spawn="replay"``: parity mode.  The reference's global-RNG draw order is
+      replayed on the host generator shared with ``Dynamics`` and the drawn states are scattered
+      by ``vf_env_reset``; reset states, counters and done flags are then bit-identical to the
+      reference on the same seed (one host sync per step).
+"""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch as th
+
+from .. import _lib
+from .._lib import TILE, VisflyError
+from ..constants import derive_constants
+from ..dynamics import Dynamics
+from ..type import TensorDict
+from . import spaces
+from .randomization import ReplaySpawner, spawn_boxes
+
+HOVER, NAV, RACING = 0, 1, 2
+F_EPISODE_DONE, F_ONCE_COLLIDED, F_COLLISION, F_OUT_BOUNDS, F_SUCCESS, F_FAILURE, F_DONE = 1, 2, 4, 8, 16, 32, 64
+EP_SUCCESS, EP_TRUNCATED, EP_COLLIDED, EP_EPISODE_DONE = 1, 2, 4, 8
+
+
+class _Info(list):
+    """per-agent info dicts (droneGymEnv.py:238-275), materialised from the step's device outputs
+    on first access so that the hot loop never syncs for them."""
+
+    def __init__(self, env, done, ep_return, ep_length, ep_flags, terminal_obs, extra=None):
+        super().__init__()
+        self._src = (env, done, ep_return, ep_length, ep_flags, terminal_obs, extra)
+        self._ready = False
+
+    def _build(self):
+        if self._ready:
+            return
+        env, done, ret, length, flags, tobs, extra = self._src
+        self._ready = True
+        super().extend(env._info)
+        idx = th.nonzero(done).flatten().cpu().numpy()
+        if len(idx):
+            ret, length, flags = ret.cpu().numpy(), length.cpu().numpy(), flags.cpu().numpy()
+            tobs = tobs.cpu() if not env.tensor_output else tobs
+            for i in idx:
+                f = int(flags[i])
+                d = {"episode_done": bool(f & EP_EPISODE_DONE), "is_success": bool(f & EP_SUCCESS),
+                     "episode": {"r": np.asarray(ret[i]), "l": np.asarray(length[i]),
+                                 "t": np.asarray(length[i] * np.float32(env.envs.dynamics.ctrl_dt)),
+                                 "extra": {"collision": np.asarray(bool(f & EP_COLLIDED))}},
+                     "terminal_observation": {"state": tobs[i], **env._static_obs(i)},
+                     "TimeLimit.truncated": bool(f & EP_TRUNCATED)}
+                if extra is not None:
+                    d["episode"]["extra"].update({k: v[i].item() for k, v in extra.items()})
+                super().__setitem__(int(i), d)
+            env._info = list(super().__iter__())
+
+    def __getitem__(self, i):
+        self._build()
+        return super().__getitem__(i)
+
+    def __iter__(self):
+        self._build()
+        return super().__iter__()
+
+    def __len__(self):
+        return self._src[0].num_agent
+
+    def copy(self):
+        self._build()
+        return list(super().__iter__())
+
+
+class DroneEnvsBase:
+    """``env.envs`` of the reference (envs/base/droneEnv.py:18): owns ``dynamics`` and the
+    collision queries; here a view onto the env's device handle."""
+
+    def __init__(self, owner, dynamics: Dynamics):
+        self._o = owner
+        self.dynamics = dynamics
+        self.device = dynamics.device
+        self.visual = False
+        self.uav_radius = 0.1
+        self.sceneManager = None
+
+    def _q(self, name):
+        return self._o._query()[name]
+
+    is_collision = property(lambda s: (s._q("flags") & F_COLLISION) != 0)
+    is_out_bounds = property(lambda s: (s._q("flags") & F_OUT_BOUNDS) != 0)
+    once_collided = property(lambda s: (s._q("flags") & F_ONCE_COLLIDED) != 0)
+    collision_point = property(lambda s: s._q("col_point"))
+    collision_vector = property(lambda s: s._q("col_vec"))
+    collision_dis = property(lambda s: s._q("col_dis"))
+
+    def __getattr__(self, name):  # state, position, orientation, velocity, ... (droneEnv.py:416-478)
+        if name in ("state", "position", "orientation", "velocity", "angular_velocity", "direction", "t",
+                    "thrusts", "full_state", "extend_state", "acceleration", "angular_acceleration"):
+            return getattr(self.dynamics, name)
+        raise AttributeError(name)
+
+    def detach(self):
+        self.dynamics.detach()
+
+    def close(self):
+        pass
+
+
+class DroneGymEnvsBase:
+    KIND = HOVER
+
+    def __init__(
+            self,
+            num_agent_per_scene: int = 1,
+            num_scene: int = 1,
+            seed: int = 42,
+            visual: bool = False,
+            max_episode_steps: int = 1000,
+            device="cuda",
+            dynamics_kwargs: Optional[Dict] = None,
+            random_kwargs: Optional[Dict] = None,
+            requires_grad: bool = False,
+            scene_kwargs: Optional[Dict] = None,
+            sensor_kwargs: Optional[List] = None,
+            tensor_output: bool = True,
+            is_train: bool = False,
+            is_collision_reset: bool = True,
+            spawn: str = "device",
+            validate_actions: Optional[bool] = None,
+            target=None,
+            success_radius: float = 0.5,
+            gates=None,
+            constants: Optional[dict] = None,
+    ):
+        if visual:
+            raise NotImplementedError("visual=True needs the external Habitat-sim renderer; the MI355X engine "
+                                      "covers the visual=False path (SURVEY.md 8)")
+        if requires_grad:
+            raise NotImplementedError("requires_grad=True (BPTT through the simulator) is not available yet")
+        if spawn not in ("device", "replay"):
+            raise ValueError("spawn must be 'device' or 'replay'")
+        self.device = th.device(device)
+        if self.device.type != "cuda":
+            raise VisflyError(f"visfly_amd envs run on an MI355X only (device='{device}'); there is no CPU fallback")
+        if self.device.index is None:
+            self.device = th.device("cuda", th.cuda.current_device())
+        dynamics_kwargs = dict(dynamics_kwargs or {})
+        self.num_agent = self.num_envs = num_agent_per_scene * num_scene
+        self.num_scene, self.num_agent_per_scene = num_scene, num_agent_per_scene
+        self.requires_grad, self.tensor_output = requires_grad, tensor_output
+        self.is_train, self.is_collision_reset = is_train, is_collision_reset
+        self.max_episode_steps = int(max_episode_steps)
+        self.max_sense_radius = 10
+        self.spawn_mode = spawn
+        self.validate_actions = (spawn == "replay") if validate_actions is None else validate_actions
+        self.seed = seed
+        N = self.num_agent
+
+        dkw = {k: v for k, v in dynamics_kwargs.items() if k not in ("seed", "device", "num")}
+        drag_random = dkw.get("drag_random", 0)
+        consts = constants if constants is not None else derive_constants(
+            **{k: v for k, v in dkw.items() if k in ("action_type", "dt", "ctrl_dt", "ctrl_delay", "comm_delay",
+                                                     "action_space", "integrator", "cfg", "wind_settings")})
+        self._boxes = spawn_boxes(random_kwargs)
+        self.target = th.as_tensor([1., 0., 1.5] if target is None else target, dtype=th.float32).reshape(3)
+        self.success_radius = success_radius
+        self.targets = None if gates is None else th.as_tensor(gates, dtype=th.float32)
+
+        e = _lib.EnvCfg()
+        e.kind, e.max_episode_steps = self.KIND, self.max_episode_steps
+        e.is_collision_reset = int(bool(is_collision_reset))
+        lo, hi = (-30., -30., 0.), (30., 30., 8.)                                     # droneEnv.py:129
+        for d in range(3):
+            e.bbox_lo[d], e.bbox_hi[d], e.target[d] = lo[d], hi[d], float(self.target[d])
+        e.uav_radius, e.success_radius = 0.1, float(success_radius)
+        e.n_gates = 0 if gates is None else len(gates)
+        for gi in range(e.n_gates):
+            for d in range(3):
+                e.gates[gi][d] = float(gates[gi][d])
+        if len(self._boxes) > _lib.MAX_SPAWN:
+            raise ValueError(f"at most {_lib.MAX_SPAWN} spawn boxes")
+        e.n_spawn = len(self._boxes)
+        for bi, b in enumerate(self._boxes):
+            sb = e.spawn[bi]
+            for name, f in (("pos", "position"), ("ori", "orientation"), ("vel", "velocity"), ("omg", "angular_velocity")):
+                for d in range(3):
+                    getattr(sb, name + "_mean")[d] = b[f]["mean"][d]
+                    getattr(sb, name + "_half")[d] = b[f]["half"][d]
+        e.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._ecfg = e
+
+        L = _lib.lib()
+        with th.cuda.device(self.device):
+            self._dcfg = _lib.DynCfg.from_dict(consts)
+            h = _lib._vp()
+            _lib.check(L.vf_env_create(self._dcfg, self._ecfg, N, 1 if drag_random else 0, h))
+            self._h = h
+            G = int(L.vf_env_granules(h))
+            floats = int(L.vf_env_slab_floats(h))
+            self._slab = th.zeros((floats // (G * TILE * 4), G, TILE, 4), dtype=th.float32, device=self.device)
+            _lib.check(L.vf_env_bind(h, _lib.ptr(self._slab)))
+            hd = _lib._vp(L.vf_env_dyn(h))
+            dyn = Dynamics(num=N, seed=seed, device=self.device, constants=consts,
+                           **{k: v for k, v in dkw.items() if k != "constants"}, _attach=(hd, self._slab, G))
+            self.envs = DroneEnvsBase(self, dyn)
+            self._spawner = ReplaySpawner(self._boxes, dyn.rng)
+            # step outputs (re-used every step; the returned tensors are fresh clones only where the
+            # reference returns fresh tensors to the caller)
+            f32 = dict(dtype=th.float32, device=self.device)
+            self._ep_return = th.zeros(N, **f32)
+            self._ep_length = th.zeros(N, dtype=th.int32, device=self.device)
+            self._ep_flags = th.zeros(N, dtype=th.uint8, device=self.device)
+            self._terminal_obs = th.zeros((N, 13), **f32)
+            self._gate = th.zeros(N, dtype=th.int32, device=self.device) if self.KIND == RACING else None
+
+        state_size = 3 + 3 + 3 + (3 if dyn.angular_output_type == "euler" else 4)
+        self.observation_space = spaces.Dict({"state": spaces.Box(low=-np.inf, high=np.inf, shape=(state_size,),
+                                                                  dtype=np.float32)})
+        self.action_space = spaces.Box(low=-1, high=1, shape=(4,), dtype=np.float32)
+        self.render_mode = ["None" for _ in range(N)]
+        self.deter = self.stoch = None
+        self._is_initial = False
+        self._info = [{"TimeLimit.truncated": False} for _ in range(N)]
+        self._observations = TensorDict({})
+        self._reward = th.zeros(N, device=self.device)
+        self._done = th.zeros(N, dtype=th.bool, device=self.device)
+        self._action = th.zeros((N, 4), device=self.device)
+        self._qcache = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return _lib.current_stream(self.device)
+
+    def _out(self, obs, reward, done):
+        o = _lib.EnvOut()
+        o.obs, o.reward, o.done = _lib.ptr(obs), _lib.ptr(reward), _lib.ptr(done)
+        o.ep_return, o.ep_length = _lib.ptr(self._ep_return), _lib.ptr(self._ep_length)
+        o.ep_flags, o.terminal_obs = _lib.ptr(self._ep_flags), _lib.ptr(self._terminal_obs)
+        o.gate = _lib.ptr(self._gate)
+        return o
+
+    def _query(self):
+        if self._qcache is None:
+            N, dev = self.num_agent, self.device
+            q = dict(step_count=th.empty(N, dtype=th.int32, device=dev), rewards=th.empty(N, device=dev),
+                     flags=th.empty(N, dtype=th.uint8, device=dev), col_point=th.empty((N, 3), device=dev),
+                     col_vec=th.empty((N, 3), device=dev), col_dis=th.empty(N, device=dev),
+                     gate=th.empty(N, dtype=th.int32, device=dev), past_gates=th.empty(N, dtype=th.int32, device=dev))
+            v = _lib.EnvView()
+            for k, t in q.items():
+                setattr(v, k, _lib.ptr(t))
+            with th.cuda.device(dev):
+                _lib.check(_lib.lib().vf_env_query(self._h, C.byref(v), self._stream()))
+            self._qcache = q
+        return self._qcache
+
+    def _static_obs(self, i=None):
+        """observation entries that do not come out of the kernel (targets, gates)"""
+        return {}
+
+    def _full_obs(self, state):
+        obs = TensorDict({"state": state})
+        obs.update(self._static_obs())
+        return obs
+
+    # ------------------------------------------------------------------ reset
+    def _reset_kernel(self, idx, fs):
+        with th.cuda.device(self.device):
+            di = None if idx is None else th.as_tensor(idx, dtype=th.int32).reshape(-1).to(self.device).contiguous()
+            k = self.num_agent if di is None else di.numel()
+            dfs = None
+            if fs is not None:
+                dfs = th.as_tensor(fs, dtype=th.float32).to(self.device).reshape(k, 22).contiguous()
+            _lib.check(_lib.lib().vf_env_reset(self._h, _lib.ptr(di), k, _lib.ptr(dfs), self._stream()))
+            self._keep = (di, dfs)
+        self._qcache = None
+
+    def _replay_states(self, k, indexed):
+        """host replay of the reference's draw order for k agents -> (k,22) full states
+        (droneEnv.py:237-251, dynamics.py:229-256)"""
+        dyn = self.envs.dynamics
+        p, q, v, w = self._spawner.generate(k)
+        fs = th.zeros((k, 22))
+        fs[:, 0:3], fs[:, 3:7], fs[:, 7:10], fs[:, 10:13] = p, q, v, w
+        fs[:, 13:17] = float(dyn.constants["w_init"])
+        fs[:, 17:21] = float(dyn.constants["T_init"])
+        if indexed:
+            fs[:, 21] = th.zeros((k,)) + th.rand((k,), generator=dyn.rng) * 3.14 * 2    # dynamics.py:256
+        return fs
+
+    def _consume_imu_noise(self):
+        """the reference draws th.rand(N,13) for the (zero-amplitude) IMU noise at every
+        update_observation (droneEnv.py:114-116,333); keep the shared stream aligned in replay mode"""
+        th.rand((self.num_agent, 13), generator=self.envs.dynamics.rng)
+
+    def reset(self, state=None, **_unused):
+        """DroneGymEnvsBase.reset (droneGymEnv.py:302-327) -> observations"""
+        self._is_initial = True
+        if state is not None:
+            fs = th.as_tensor(state, dtype=th.float32)
+            if fs.shape != (self.num_agent, 22):
+                raise ValueError("reset(state=...) expects the (N,22) full_state layout")
+            self._reset_kernel(None, fs)
+            if self.spawn_mode == "replay":
+                self._consume_imu_noise()
+        elif self.spawn_mode == "replay":
+            self._reset_kernel(None, self._replay_states(self.num_agent, indexed=False))
+            self._consume_imu_noise()
+        else:
+            self._reset_kernel(None, None)
+        self._info = [{"TimeLimit.truncated": False, "episode_done": False} for _ in range(self.num_agent)]
+        self._reward = th.zeros(self.num_agent, device=self.device)
+        self._done = th.zeros(self.num_agent, dtype=th.bool, device=self.device)
+        self._observations = self._full_obs(self.envs.dynamics.state)
+        return self._format_obs(self._observations)
+
+    def reset_agent_by_id(self, agent_indices=None, state=None, reset_obs=None):
+        """droneGymEnv.py:339-349: re-spawn the given agents, clear their counters"""
+        assert not isinstance(agent_indices, bool)
+        idx = th.arange(self.num_agent) if agent_indices is None else th.as_tensor(agent_indices).reshape(-1).cpu()
+        if state is not None:
+            fs = th.as_tensor(state, dtype=th.float32)
+        elif self.spawn_mode == "replay":
+            fs = self._replay_states(len(idx), indexed=True)
+        else:
+            fs = None
+        self._reset_kernel(idx, fs)
+        if self.spawn_mode == "replay":
+            self._consume_imu_noise()
+        self._observations = self._full_obs(self.envs.dynamics.state)
+        for i in idx.tolist():
+            self._info[i] = {"TimeLimit.truncated": False, "episode_done": False}
+        return self._observations
+
+    def examine(self):
+        if bool(self._done.any()):
+            self.reset_agent_by_id(th.where(self._done)[0])
+        return self._observations
+
+    # ------------------------------------------------------------------ step
+    def step(self, _action, is_test=False, **_unused):
+        """DroneGymEnvsBase.step (droneGymEnv.py:141-218) -> (obs, reward, done, info)"""
+        assert self._is_initial, "You should call reset() before step()"
+        a = _action if isinstance(_action, th.Tensor) else th.as_tensor(np.asarray(_action))
+        a = a.to(self.device, dtype=th.float32).reshape(self.num_agent, 4).contiguous()
+        if self.validate_actions:
+            assert a.max() <= 1 and a.min() >= -1                                           # :144
+        self._action = a
+        N = self.num_agent
+        with th.cuda.device(self.device):
+            state = th.empty((N, 13), dtype=th.float32, device=self.device)
+            reward = th.empty(N, dtype=th.float32, device=self.device)
+            done_u8 = th.empty(N, dtype=th.uint8, device=self.device)
+            auto = 0 if (is_test or self.spawn_mode == "replay") else 1
+            out = self._out(state, reward, done_u8)
+            _lib.check(_lib.lib().vf_env_step(self._h, _lib.ptr(a), C.byref(out), auto, self._stream()))
+        self._qcache = None
+        done = done_u8.bool()
+        self._reward, self._done = reward, done
+        self._observations = self._full_obs(state)
+        if self.spawn_mode == "replay":
+            self._consume_imu_noise()
+        info = _Info(self, done, self._ep_return.clone(), self._ep_length.clone(), self._ep_flags.clone(),
+                     self._terminal_obs.clone(), self._extra_info())
+        if self.spawn_mode == "replay" and not is_test:
+            info._build()  # the info dicts of done agents are collected before the reset (:197-208)
+            idx = th.where(done)[0]
+            if idx.numel():
+                self.reset_agent_by_id(idx)
+        obs = self._observations
+        if self.tensor_output:
+            return obs, reward, done, info
+        return self._format_obs(obs), reward.cpu().numpy(), done.cpu().numpy().astype(np.int32), info   # :218
+
+    def _extra_info(self):
+        return None
+
+    def _format_obs(self, obs):
+        if self.tensor_output:
+            return obs
+        return TensorDict({k: v.detach().cpu().numpy() for k, v in obs.items()})
+
+    # ------------------------------------------------------------------ reference surface
+    def get_observation(self, indices=None, predicted_obs=None):
+        return self._observations
+
+    def get_full_observation(self, indice=None, predicted_obs=None):
+        return self._observations
+
+    def get_success(self):
+        return self.success
+
+    def get_failure(self):
+        return th.zeros(self.num_agent, dtype=th.bool, device=self.device)
+
+    def get_reward(self, predicted_obs=None):
+        return self._reward
+
+    def detach(self):
+        self.envs.detach()
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().vf_env_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_requires_grad(self, requires_grad: bool):
+        if requires_grad:
+            raise NotImplementedError("requires_grad=True is not available yet")
+
+    def to(self, device):
+        if th.device(device).type != "cuda":
+            raise VisflyError("visfly_amd envs cannot move off the GPU")
+
+    def env_is_wrapped(self):
+        return False
+
+    def get_attr(self, attr_name, indices=None):
+        if indices is None:
+            return getattr(self, attr_name)
+
+    def __len__(self):
+        return self.num_envs
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(NumAgentPerScene={self.num_agent_per_scene}, NumScene={self.num_scene}, "
+                f"tensorOut={self.tensor_output}, spawn={self.spawn_mode}, device={self.device})")
+
+    # properties (droneGymEnv.py:477-571)
+    reward = property(lambda s: s._reward)
+    done = property(lambda s: s._done)
+    info = property(lambda s: s._info)
+    state = property(lambda s: s.envs.dynamics.state)
+    position = property(lambda s: s.envs.dynamics.position)
+    orientation = property(lambda s: s.envs.dynamics.orientation)
+    velocity = property(lambda s: s.envs.dynamics.velocity)
+    angular_velocity = property(lambda s: s.envs.dynamics.angular_velocity)
+    direction = property(lambda s: s.envs.dynamics.direction)
+    t = property(lambda s: s.envs.dynamics.t)
+    full_state = property(lambda s: s.envs.dynamics.full_state)
+    extend_state = property(lambda s: s.envs.dynamics.extend_state)
+    visual = property(lambda s: False)
+    sensor_obs = property(lambda s: {"IMU": s.envs.dynamics.state})
+    is_collision = property(lambda s: s.envs.is_collision)
+    is_out_bounds = property(lambda s: s.envs.is_out_bounds)
+    collision_point = property(lambda s: s.envs.collision_point)
+    collision_vector = property(lambda s: s.envs.collision_vector)
+    collision_dis = property(lambda s: s.envs.collision_dis)
+    episode_done = property(lambda s: (s._query()["flags"] & F_EPISODE_DONE) != 0)
+    success = property(lambda s: (s._query()["flags"] & F_SUCCESS) != 0)
+    failure = property(lambda s: (s._query()["flags"] & F_FAILURE) != 0)
+    _step_count = property(lambda s: s._query()["step_count"])
+    _rewards = property(lambda s: s._query()["rewards"])
+    _success = property(lambda s: s.success)
+    _episode_done = property(lambda s: s.episode_done)

@@ -1,0 +1,105 @@
+"""Task envs named in BASELINE.json: HoverEnv, NavigationEnv, RacingEnv (visual=False).
+
+Constructor kwargs follow the reference (envs/HoverEnv.py:15-30, envs/NavigationEnv.py:27-41,
+envs/RacingEnv.py:17-31); observation / reward / success definitions live in the fused kernel
+(visfly_amd/csrc/vf_env_device.hpp) and are listed next to each class.
+"""
+from typing import Optional
+
+import numpy as np
+import torch as th
+
+from . import spaces
+from .base import HOVER, NAV, RACING, DroneGymEnvsBase
+
+_HOVER_SPAWN = {"state_generator": {"class": "Uniform", "kwargs": [
+    {"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]}}
+
+_RACING_SPAWN = {"state_generator": {"class": "Union", "kwargs": [{"randomizers_kwargs": [
+    {"class": "Uniform", "kwargs": {"position": {"mean": [2., 2., 1], "half": [.2, .2, 0.2]}}},
+    {"class": "Uniform", "kwargs": {"position": {"mean": [6., 2., 1.5], "half": [.2, .2, 0.2]}}},
+    {"class": "Uniform", "kwargs": {"position": {"mean": [6., -2., 1.5], "half": [.2, .2, 0.2]}}},
+    {"class": "Uniform", "kwargs": {"position": {"mean": [2., 0., 1], "half": [.2, .2, 0.2]}}},
+]}]}}
+
+_RACING_GATES = [[4, 4, 1.], [8, 0, 2.], [5, -4, 1.], [1, -1, 1.]]
+
+
+class HoverEnv(DroneGymEnvsBase):
+    """obs {"state": (N,13)}; success == False; reward = 0.1 - |p-target|/90 - 1e-5|q-[1,0,0,0]|
+    - 0.002|v| - 0.002|w| (envs/HoverEnv.py:62-94); default target [1,0,1.5], default spawn box
+    mean [1,0,1.5] half [1,1,.5] (:32-41,:59)."""
+    KIND = HOVER
+
+    def __init__(self, num_agent_per_scene: int = 1, num_scene: int = 1, seed: int = 42, visual: bool = False,
+                 requires_grad: bool = False, random_kwargs: Optional[dict] = None, dynamics_kwargs: Optional[dict] = None,
+                 scene_kwargs: Optional[dict] = None, sensor_kwargs: Optional[list] = None, device="cuda",
+                 target=None, max_episode_steps: int = 256, tensor_output: bool = False, **kw):
+        super().__init__(num_agent_per_scene=num_agent_per_scene, num_scene=num_scene, seed=seed, visual=visual,
+                         requires_grad=requires_grad, random_kwargs=_HOVER_SPAWN if random_kwargs is None else random_kwargs,
+                         dynamics_kwargs=dynamics_kwargs, scene_kwargs=scene_kwargs, sensor_kwargs=sensor_kwargs,
+                         device=device, max_episode_steps=max_episode_steps, tensor_output=tensor_output,
+                         target=[1., 0., 1.5] if target is None else target, success_radius=0.5, **kw)
+        self.target = th.ones((self.num_envs, 1), device=self.device) @ self.target.reshape(1, -1).to(self.device)
+
+
+class NavigationEnv(DroneGymEnvsBase):
+    """obs {"state": (N,13), "target": (N,3)}; success |p-target| <= 0.5; reward = progress toward the
+    target, view-angle / attitude / speed penalties, obstacle terms and the success bonus
+    (envs/NavigationEnv.py:63-99); default target [9,0,1] (:58)."""
+    KIND = NAV
+
+    def __init__(self, num_agent_per_scene: int = 1, num_scene: int = 1, seed: int = 42, visual: bool = False,
+                 requires_grad: bool = False, random_kwargs: Optional[dict] = None, dynamics_kwargs: Optional[dict] = None,
+                 scene_kwargs: Optional[dict] = None, sensor_kwargs: Optional[list] = None, device="cuda",
+                 target=None, max_episode_steps: int = 256, tensor_output: bool = True, **kw):
+        super().__init__(num_agent_per_scene=num_agent_per_scene, num_scene=num_scene, seed=seed, visual=visual,
+                         requires_grad=requires_grad, random_kwargs=random_kwargs or {}, dynamics_kwargs=dynamics_kwargs,
+                         scene_kwargs=scene_kwargs, sensor_kwargs=sensor_kwargs, device=device,
+                         max_episode_steps=max_episode_steps, tensor_output=tensor_output,
+                         target=[9., 0., 1.] if target is None else target, success_radius=0.5, **kw)
+        self.target = th.ones((self.num_envs, 1), device=self.device) @ self.target.reshape(1, -1).to(self.device)
+        self.observation_space["target"] = spaces.Box(low=-np.inf, high=np.inf, shape=(3,), dtype=np.float32)
+
+    def _static_obs(self, i=None):
+        return {"target": self.target if i is None else self.target[i]}
+
+
+class RacingEnv(DroneGymEnvsBase):
+    """obs {"state": (N,13), "gate": (N,) next-gate index}; 4 gates, pass radius 0.3; passing advances
+    the gate (mod 4) and pays +20 on top of the hover-style reward toward the next gate; gate chosen at
+    reset from the spawn position; Union-of-4-Uniform spawn (envs/RacingEnv.py:33-70,87-98,142-215)."""
+    KIND = RACING
+
+    def __init__(self, num_agent_per_scene: int = 1, num_scene: int = 1, seed: int = 42, visual: bool = False,
+                 requires_grad: bool = False, random_kwargs: Optional[dict] = None, dynamics_kwargs: Optional[dict] = None,
+                 scene_kwargs: Optional[dict] = None, sensor_kwargs: Optional[list] = None, device="cuda",
+                 target=None, max_episode_steps: int = 256, tensor_output: bool = True, latent_dim=None, **kw):
+        # the reference ignores a caller's random_kwargs and always uses the 4-box union (RacingEnv.py:32-70)
+        super().__init__(num_agent_per_scene=num_agent_per_scene, num_scene=num_scene, seed=seed, visual=visual,
+                         requires_grad=requires_grad, random_kwargs=_RACING_SPAWN, dynamics_kwargs=dynamics_kwargs,
+                         scene_kwargs=scene_kwargs, sensor_kwargs=sensor_kwargs, device=device,
+                         max_episode_steps=max_episode_steps, tensor_output=tensor_output,
+                         success_radius=0.3, gates=_RACING_GATES, **kw)
+        self._next_target_num = 2
+        self.success_r = 20
+        self.observation_space["gate"] = spaces.Box(low=0, high=len(_RACING_GATES), shape=(1,), dtype=np.int32)
+        self.observation_space["state"] = spaces.Box(
+            low=-np.inf, high=np.inf,
+            shape=(3 * (self._next_target_num - 1) + self.observation_space["state"].shape[0],), dtype=np.float32)
+
+    def _static_obs(self, i=None):
+        g = self._gate if self._qcache is None else self._query()["gate"]
+        return {"gate": g if i is None else g[i]}
+
+    def _extra_info(self):
+        return {"past_gate": self._query()["past_gates"]}
+
+    def reset(self, state=None, obs=None, **kw):
+        out = super().reset(state)
+        self._gate = self._query()["gate"].clone()
+        self._observations = self._full_obs(self._observations["state"])
+        return self._format_obs(self._observations)
+
+    _next_target_i = property(lambda s: s._query()["gate"])
+    _past_targets_num = property(lambda s: s._query()["past_gates"])
