@@ -25,6 +25,7 @@ import torch  # noqa: E402
 AGENTS_PER_GPU = 65536
 DYN_KW = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
 BYTES_PER_AGENT_STEP = 244      # 116 B read + 128 B written per agent-step (Dynamics.step)
+BYTES_PER_ENV_STEP = 350        # full env.step adds obs, reward, counters and flags
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -75,13 +76,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from visfly_amd import Dynamics
+    from visfly_amd.envs import HoverEnv
     N = args.agents
-    dyn = Dynamics(num=N, device=dev, seed=42 + rank, **DYN_KW)
+    env = HoverEnv(num_agent_per_scene=N, num_scene=1, seed=42 + rank, visual=False, dynamics_kwargs=dict(DYN_KW),
+                   device=dev, max_episode_steps=256, tensor_output=True)   # spawn box: HoverEnv default
+    env.reset()
+    dyn = env.envs.dynamics
     g = torch.Generator(device=dev).manual_seed(rank)
-    spawn = torch.tensor([1, 0, 1.5], device=dev) + \
-        (torch.rand((N, 3), device=dev, generator=g) * 2 - 1) * torch.tensor([1, 1, .5], device=dev)
-    dyn.reset(pos=spawn)
     hover = torch.tensor([-1 / 3, 0, 0, 0], device=dev)
     pool = [(hover + (torch.rand((N, 4), device=dev, generator=g) * 2 - 1) * 0.02).clamp(-1, 1).contiguous()
             for _ in range(16)]
@@ -92,12 +93,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    step = env.step
     for k in range(args.warmup):
-        dyn.step(pool[k % 16])
+        step(pool[k % 16])
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        dyn.step(pool[k % 16])
+        step(pool[k % 16])
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:
@@ -106,24 +108,29 @@ def main():
         el = float(t.item())
 
     # dominant kernel, HIP events on the launch stream
-    kern_us = dyn.time_steps(pool[0], iters=200)
+    kern_us = env.time_steps(pool[0], iters=200)
+    dyn_us = dyn.time_steps(pool[0], iters=200)
     assert torch.isfinite(dyn.state).all()
 
     if rank == 0:
         value = world * N * args.steps / el
-        achieved = BYTES_PER_AGENT_STEP * N / (kern_us * 1e-6) / 1e9
+        achieved = BYTES_PER_ENV_STEP * N / (kern_us * 1e-6) / 1e9
         out = {
             "metric": "agent-steps/sec (dynamics.step, visual=False)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"HoverEnv dynamics, {N} agents/GPU, visual=False, bodyrate+euler, "
-                                   "dt=0.0025/ctrl_dt=0.02, ctrl_delay, 3-slot delay ring (BASELINE configs[1])",
+            "config": {"workload": f"HoverEnv.step (fused dynamics + collision + reward + done + on-device auto-reset), "
+                                   f"{N} agents/GPU, visual=False, bodyrate+euler, dt=0.0025/ctrl_dt=0.02, ctrl_delay, "
+                                   "3-slot delay ring, max_episode_steps=256 (BASELINE configs[1])",
                        "agents_per_gpu": N, "parallelism": f"agents sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_dyn_step<bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
-                         "bytes_per_agent_step": BYTES_PER_AGENT_STEP},
+                         "kernel": "k_env_step<hover,bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
+                         "bytes_per_agent_step": BYTES_PER_ENV_STEP,
+                         "dyn_only": {"kernel": "k_dyn_step<bodyrate,euler,ctrl_delay>", "kernel_us": dyn_us,
+                                      "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
+                                      "achieved": BYTES_PER_AGENT_STEP * N / (dyn_us * 1e-6) / 1e9}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dyn.constants)

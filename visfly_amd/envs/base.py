@@ -35,7 +35,9 @@ EP_SUCCESS, EP_TRUNCATED, EP_COLLIDED, EP_EPISODE_DONE = 1, 2, 4, 8
 
 class _Info(list):
     """per-agent info dicts (droneGymEnv.py:238-275), materialised from the step's device outputs
-    on first access so that the hot loop never syncs for them."""
+    on first access so that the hot loop never syncs for them.  The episode buffers hold, per agent,
+    the most recently finished episode (what the reference keeps in ``self._info[i]``); read an info
+    before that agent finishes another episode."""
 
     def __init__(self, env, done, ep_return, ep_length, ep_flags, terminal_obs, extra=None):
         super().__init__()
@@ -236,6 +238,9 @@ class DroneGymEnvsBase:
         self._done = th.zeros(N, dtype=th.bool, device=self.device)
         self._action = th.zeros((N, 4), device=self.device)
         self._qcache = None
+        self._outs = self._out(self._terminal_obs, self._ep_return, self._ep_flags)  # obs/reward/done patched per step
+        self._outs_ref = C.byref(self._outs)
+        self._vf_env_step = _lib.lib().vf_env_step
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -351,33 +356,40 @@ class DroneGymEnvsBase:
     def step(self, _action, is_test=False, **_unused):
         """DroneGymEnvsBase.step (droneGymEnv.py:141-218) -> (obs, reward, done, info)"""
         assert self._is_initial, "You should call reset() before step()"
-        a = _action if isinstance(_action, th.Tensor) else th.as_tensor(np.asarray(_action))
-        a = a.to(self.device, dtype=th.float32).reshape(self.num_agent, 4).contiguous()
+        N, dev = self.num_agent, self.device
+        a = _action
+        if not (isinstance(a, th.Tensor) and a.is_cuda and a.dtype == th.float32 and a.dim() == 2
+                and a.shape[0] == N and a.is_contiguous()):
+            a = a if isinstance(a, th.Tensor) else th.as_tensor(np.asarray(a))
+            a = a.to(dev, dtype=th.float32).reshape(N, 4).contiguous()
         if self.validate_actions:
             assert a.max() <= 1 and a.min() >= -1                                           # :144
         self._action = a
-        N = self.num_agent
-        with th.cuda.device(self.device):
-            state = th.empty((N, 13), dtype=th.float32, device=self.device)
-            reward = th.empty(N, dtype=th.float32, device=self.device)
-            done_u8 = th.empty(N, dtype=th.uint8, device=self.device)
-            auto = 0 if (is_test or self.spawn_mode == "replay") else 1
-            out = self._out(state, reward, done_u8)
-            _lib.check(_lib.lib().vf_env_step(self._h, _lib.ptr(a), C.byref(out), auto, self._stream()))
+        if th.cuda.current_device() != dev.index:
+            th.cuda.set_device(dev)
+        state = th.empty((N, 13), dtype=th.float32, device=dev)
+        reward = th.empty(N, dtype=th.float32, device=dev)
+        done = th.empty(N, dtype=th.bool, device=dev)      # the kernel writes 0/1 bytes
+        replay = self.spawn_mode == "replay"
+        o = self._outs
+        o.obs, o.reward, o.done = state.data_ptr(), reward.data_ptr(), done.data_ptr()
+        rc = self._vf_env_step(self._h, a.data_ptr(), self._outs_ref, 0 if (is_test or replay) else 1,
+                               th.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            _lib.check(rc)
         self._qcache = None
-        done = done_u8.bool()
         self._reward, self._done = reward, done
-        self._observations = self._full_obs(state)
-        if self.spawn_mode == "replay":
+        self._observations = obs = self._full_obs(state)
+        info = _Info(self, done, self._ep_return, self._ep_length, self._ep_flags, self._terminal_obs,
+                     self._extra_info())
+        if replay:
             self._consume_imu_noise()
-        info = _Info(self, done, self._ep_return.clone(), self._ep_length.clone(), self._ep_flags.clone(),
-                     self._terminal_obs.clone(), self._extra_info())
-        if self.spawn_mode == "replay" and not is_test:
-            info._build()  # the info dicts of done agents are collected before the reset (:197-208)
-            idx = th.where(done)[0]
-            if idx.numel():
-                self.reset_agent_by_id(idx)
-        obs = self._observations
+            if not is_test:
+                info._build()  # the info dicts of done agents are collected before the reset (:197-208)
+                idx = th.where(done)[0]
+                if idx.numel():
+                    self.reset_agent_by_id(idx)
+                obs = self._observations
         if self.tensor_output:
             return obs, reward, done, info
         return self._format_obs(obs), reward.cpu().numpy(), done.cpu().numpy().astype(np.int32), info   # :218
@@ -389,6 +401,21 @@ class DroneGymEnvsBase:
         if self.tensor_output:
             return obs
         return TensorDict({k: v.detach().cpu().numpy() for k, v in obs.items()})
+
+    def time_steps(self, action, iters=100, auto_reset=True):
+        """mean device microseconds per fused env-step launch (HIP events on the current stream)"""
+        N, dev = self.num_agent, self.device
+        a = th.as_tensor(action, dtype=th.float32).to(dev).reshape(N, 4).contiguous()
+        state = th.empty((N, 13), dtype=th.float32, device=dev)
+        reward = th.empty(N, dtype=th.float32, device=dev)
+        done = th.empty(N, dtype=th.bool, device=dev)
+        o = self._out(state, reward, done)
+        us = C.c_float(0)
+        with th.cuda.device(dev):
+            _lib.check(_lib.lib().vf_env_time_steps(self._h, _lib.ptr(a), C.byref(o), 1 if auto_reset else 0, int(iters),
+                                                    self._stream(), C.byref(us)))
+        self._qcache = None
+        return float(us.value)
 
     # ------------------------------------------------------------------ reference surface
     def get_observation(self, indices=None, predicted_obs=None):
