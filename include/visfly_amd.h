@@ -224,6 +224,79 @@ int vf_env_query(vf_env* h, const vf_env_view* view, vf_stream_t stream);
 int vf_env_time_steps(vf_env* h, const float* action, const vf_env_out* out, int32_t auto_reset, int32_t iters,
                       vf_stream_t stream, float* mean_us);
 
+/* =====================================================================================
+ * PPO inner loop on the device (utils/algorithms/PPO.py:177-337; SB3 2.2.1 RolloutBuffer /
+ * collect_rollouts, mirrored in utils/algorithms/common.py:97-132; utils/policies/policies.py:195-254;
+ * utils/policies/extractors.py:376-449).  All matrices row-major fp32; GEMMs run on the fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered FMA chain), fp32 accumulate.
+ * ===================================================================================== */
+
+/* GAE backward scan, thread per env (common.py:119-132).  [T][N] arrays; gamma/lam are the python
+ * floats SB3 holds (gamma rounded to fp32 at the multiply, gamma*lam rounded once). */
+int vf_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
+           const float* dones, float* adv, float* ret, int32_t T, int32_t N, double gamma, double lam,
+           vf_stream_t stream);
+
+/* Advantage normalisation of one minibatch (PPO.py:215-220): (A - mean) / (std_unbiased + 1e-8).
+ * scratch: >= 2*1024 floats.  If sums_inout != NULL the two partial sums (sum, sum of squares, fp64
+ * as 2 doubles) are left there after `phase` 0 and consumed in `phase` 1, so that a multi-GPU caller
+ * can all-reduce them in between (count = global element count); phase 2 = both in one call. */
+int vf_adv_normalize(const float* adv, float* out, int64_t n, int64_t count, double* sums_inout, float* scratch,
+                     int32_t phase, vf_stream_t stream);
+
+/* Y[M][No] (+)= act(X[M][K] @ W^T + b)   nn.Linear + ReLU (extractors.py:421-445)
+ *   W [No][K], b [No] or NULL; ldx / ldy row strides in floats; relu: 0/1; K, No <= 128. */
+int vf_linear_fwd(const float* X, int32_t ldx, const float* W, const float* b, float* Y, int32_t ldy,
+                  int32_t M, int32_t K, int32_t No, int32_t relu, vf_stream_t stream);
+
+/* dX[M][K] (+)= (dY * [Y > 0]) @ W ; Ymask = the layer's saved post-ReLU output or NULL (no ReLU);
+ * accumulate != 0 adds into dX (a tensor consumed by two branches). */
+int vf_linear_bwd_data(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* W,
+                       float* dX, int32_t lddx, int32_t M, int32_t K, int32_t No, int32_t accumulate,
+                       vf_stream_t stream);
+
+/* dW[No][K] = (dY * [Y > 0])^T @ X, db[No] = column sums; deterministic two-stage reduction.
+ * scratch: vf_linear_bwd_scratch_floats(M, K, No) floats. */
+int64_t vf_linear_bwd_scratch_floats(int32_t M, int32_t K, int32_t No);
+int vf_linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X,
+                         int32_t ldx, float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch,
+                         vf_stream_t stream);
+
+/* Squashed diagonal Gaussian head (SB3 SquashedDiagGaussianDistribution as used by
+ * policies.py:114,177-181,195-226): a = tanh(mean + exp(log_std) * eps), eps ~ N(0,1) from
+ * Philox4x32-10 keyed by (seed, row, step); log_prob as SB3 computes it.  deterministic != 0: a = tanh(mean). */
+int vf_head_sample(const float* mean, const float* log_std, float* action, float* log_prob, int32_t M,
+                   uint64_t seed, uint64_t step, int32_t deterministic, vf_stream_t stream);
+
+typedef struct vf_ppo_loss_cfg {
+    float clip_range, ent_coef, vf_coef;
+    float inv_batch;        /* 1 / global minibatch rows (means are over the global minibatch) */
+} vf_ppo_loss_cfg;
+
+/* Clipped-surrogate PPO loss and its gradient w.r.t. the head outputs (PPO.py:210-263;
+ * evaluate_actions policies.py:228-254).  Inputs per row: mean[4], value, action[4] (squashed),
+ * old_log_prob, normalised advantage, return; log_std[4] shared.
+ * Outputs: d_mean (M,4), d_value (M,), and stats[16] (fp32, sums over THIS call's rows; divide by the
+ * global batch): 0 policy_loss, 1 value_loss, 2 entropy_loss, 3 approx_kl, 4 clip_fraction,
+ * 5..8 d_log_std[4] (already scaled by inv_batch).  scratch >= 16*1024 floats. */
+int vf_ppo_loss(const float* mean, const float* value, const float* log_std, const float* action,
+                const float* old_log_prob, const float* adv, const float* ret, float* d_mean, float* d_value,
+                float* stats, int32_t M, const vf_ppo_loss_cfg* cfg, float* scratch, vf_stream_t stream);
+
+typedef struct vf_adam_cfg {
+    float lr, beta1, beta2, eps, weight_decay;
+    float max_grad_norm;    /* <= 0: no clipping */
+    int32_t step;           /* 1-based step count AFTER this update */
+    int32_t pad0;
+} vf_adam_cfg;
+
+/* clip_grad_norm_ + torch.optim.Adam (weight_decay as L2) over one flat fp32 parameter buffer
+ * (PPO.py:285-292).  grad_sumsq: device fp32[1] = sum of squares of the (already all-reduced) gradient,
+ * produced by vf_sumsq.  */
+int vf_sumsq(const float* x, int64_t n, float* out1, float* scratch /* >= 1024 floats */, vf_stream_t stream);
+int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 const float* grad_sumsq, const vf_adam_cfg* cfg, vf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,207 @@
+"""PPO inner loop kernels against plain PyTorch fp32 references (and the CPU oracle for GAE).
+Floating-point tolerances are stated per test; they cover fp32 summation-order differences only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def L():
+    from visfly_amd import _lib
+    return _lib, _lib.lib()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_gae_kernel_bit_exact_vs_oracle():
+    _lib, lib = L()
+    for T, N in [(16, 5), (256, 4099), (64, 65536)]:
+        g = torch.Generator().manual_seed(T + N)
+        r, v = torch.randn((T, N), generator=g), torch.randn((T, N), generator=g)
+        es = (torch.rand((T, N), generator=g) < 0.05).float()
+        lv, d = torch.randn(N, generator=g), (torch.rand(N, generator=g) < 0.2).float()
+        dr, dv, des, dlv, dd = (x.to(DEV) for x in (r, v, es, lv, d))
+        adv, ret = torch.empty_like(dr), torch.empty_like(dr)
+        _lib.check(lib.vf_gae(dr.data_ptr(), dv.data_ptr(), des.data_ptr(), dlv.data_ptr(), dd.data_ptr(), adv.data_ptr(),
+                              ret.data_ptr(), T, N, 0.99, 0.95, st()))
+        a0, r0 = oracle.gae(r.numpy(), v.numpy(), es.numpy(), lv.numpy(), d.numpy(), 0.99, 0.95)
+        assert np.array_equal(adv.cpu().numpy().view(np.uint32), a0.view(np.uint32))
+        assert np.array_equal(ret.cpu().numpy().view(np.uint32), r0.view(np.uint32))
+
+
+def test_adv_normalize_vs_torch():
+    _lib, lib = L()
+    for n in [2, 1000, 25600, 1 << 20]:
+        a = torch.randn(n, device=DEV) * 3 + 1.5
+        out, scratch = torch.empty_like(a), torch.zeros(4096, device=DEV)
+        _lib.check(lib.vf_adv_normalize(a.data_ptr(), out.data_ptr(), n, n, None, scratch.data_ptr(), 2, st()))
+        ref = (a - a.mean()) / (a.std() + 1e-8)          # PPO.py:217-220 (unbiased std)
+        assert torch.allclose(out, ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("K,No", [(13, 128), (128, 64), (3, 128), (64, 64), (64, 4), (64, 1), (128, 128), (7, 33)])
+@pytest.mark.parametrize("M", [1, 63, 200, 25600])
+def test_linear_layers_vs_torch(K, No, M):
+    _lib, lib = L()
+    g = torch.Generator(device=DEV).manual_seed(K * 1000 + No + M)
+    X = torch.randn((M, K), device=DEV, generator=g)
+    W = torch.randn((No, K), device=DEV, generator=g) / np.sqrt(K)
+    b = torch.randn(No, device=DEV, generator=g)
+    # asymmetric operands (transposes cannot hide), fp64 reference
+    Yref = (X.double() @ W.double().T + b.double())
+    for relu in (0, 1):
+        Y = torch.full((M, No + 3), -7.0, device=DEV)     # ldy > No: columns beyond stay untouched
+        _lib.check(lib.vf_linear_fwd(X.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), No + 3, M, K, No, relu, st()))
+        ref = Yref.clamp_min(0) if relu else Yref
+        assert torch.allclose(Y[:, :No].double(), ref, rtol=1e-5, atol=1e-5 * np.sqrt(K))
+        assert (Y[:, No:] == -7.0).all()
+    Ypost = Yref.clamp_min(0).float()
+    dY = torch.randn((M, No), device=DEV, generator=g)
+    dYm = (dY * (Ypost > 0)).double()
+    # data gradient with mask, then accumulate
+    dX = torch.zeros((M, K), device=DEV)
+    _lib.check(lib.vf_linear_bwd_data(dY.data_ptr(), No, Ypost.data_ptr(), No, W.data_ptr(), dX.data_ptr(), K, M, K, No, 0, st()))
+    ref = dYm @ W.double()
+    assert torch.allclose(dX.double(), ref, rtol=1e-5, atol=1e-5 * np.sqrt(No))
+    _lib.check(lib.vf_linear_bwd_data(dY.data_ptr(), No, None, 0, W.data_ptr(), dX.data_ptr(), K, M, K, No, 1, st()))
+    assert torch.allclose(dX.double(), ref + dY.double() @ W.double(), rtol=1e-5, atol=2e-5 * np.sqrt(No))
+    # weight / bias gradient
+    need = int(lib.vf_linear_bwd_scratch_floats(M, K, No))
+    scratch = torch.empty(need, device=DEV)
+    dW, db = torch.empty((No, K), device=DEV), torch.empty(No, device=DEV)
+    _lib.check(lib.vf_linear_bwd_weight(dY.data_ptr(), No, Ypost.data_ptr(), No, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(),
+                                        M, K, No, scratch.data_ptr(), st()))
+    tol = 2e-5 * np.sqrt(M)
+    assert torch.allclose(dW.double(), dYm.T @ X.double(), rtol=1e-5, atol=tol)
+    assert torch.allclose(db.double(), dYm.sum(0), rtol=1e-5, atol=tol)
+
+
+def sb3_squashed_log_prob(mean, log_std, actions):
+    """SB3 SquashedDiagGaussianDistribution.log_prob(actions) with gaussian_actions=None"""
+    eps = torch.finfo(torch.float32).eps
+    g = torch.atanh(actions.clamp(-1 + eps, 1 - eps))
+    dist = torch.distributions.Normal(mean, log_std.exp().expand_as(mean))
+    lp = dist.log_prob(g).sum(dim=1)
+    return lp - torch.log(1 - actions ** 2 + 1e-6).sum(dim=1)
+
+
+def torch_ppo_loss(ref, obs, actions, old_lp, adv, ret, clip, ent_coef, vf_coef):
+    """PPO.train's loss (utils/algorithms/PPO.py:210-263) in plain torch"""
+    mean, value = ref(obs)
+    lp = sb3_squashed_log_prob(mean, ref.log_std, actions)
+    ratio = torch.exp(lp - old_lp)
+    pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+    vl = torch.nn.functional.mse_loss(ret, value.flatten())
+    el = -torch.mean(-lp)
+    return pl + ent_coef * el + vf_coef * vl, (pl, vl, el, ((ratio - 1) - (lp - old_lp)).mean(),
+                                               ((ratio - 1).abs() > clip).float().mean())
+
+
+@pytest.mark.parametrize("keys", [("state",), ("state", "target")])
+def test_policy_loss_and_gradients_vs_torch_autograd(keys):
+    from visfly_amd.ppo import MlpPolicy
+    _lib, lib = L()
+    dims = {"state": 13, "target": 3}
+    pol = MlpPolicy({k: dims[k] for k in keys}, {k: [128, 64] for k in keys}, [64, 64], [64, 64], DEV, seed=5,
+                    log_std_init=-0.3)
+    assert pol.n_params == (43977 if len(keys) == 2 else 27017)          # SURVEY a19 [probe]
+    B = 3000
+    g = torch.Generator(device=DEV).manual_seed(11)
+    obs = {k: torch.randn((B, dims[k]), device=DEV, generator=g) for k in keys}
+    mean, value = pol.forward(obs)
+    ref = pol.to_torch().double()
+    obs64 = {k: v.cpu().double() for k, v in obs.items()}
+    rmean, rvalue = ref(obs64)
+    assert torch.allclose(mean.cpu().double(), rmean, rtol=1e-4, atol=2e-5)
+    assert torch.allclose(value.cpu().double(), rvalue, rtol=1e-4, atol=2e-5)
+    # rollout-like data: actions sampled near the policy, some far (clipping active), mixed-sign advantages
+    actions = torch.tanh(mean + 0.7 * torch.randn((B, 4), device=DEV, generator=g)).contiguous()
+    old_lp = sb3_squashed_log_prob(mean, pol.log_std, actions) + 0.3 * torch.randn(B, device=DEV, generator=g)
+    adv = torch.randn(B, device=DEV, generator=g)
+    ret = torch.randn(B, device=DEV, generator=g)
+    clip, ent, vf = 0.2, 0.01, 0.5
+    d_mean, d_value = torch.empty((B, 4), device=DEV), torch.empty(B, device=DEV)
+    stats, scratch = torch.zeros(16, device=DEV), torch.zeros(16 * 1024, device=DEV)
+    cfg = _lib.PpoLossCfg(clip, ent, vf, 1.0 / B)
+    _lib.check(lib.vf_ppo_loss(mean.data_ptr(), value.data_ptr(), pol.log_std.data_ptr(), actions.data_ptr(), old_lp.data_ptr(),
+                               adv.data_ptr(), ret.data_ptr(), d_mean.data_ptr(), d_value.data_ptr(), stats.data_ptr(), B,
+                               C.byref(cfg), scratch.data_ptr(), st()))
+    pol.backward(d_mean, d_value, stats[5:9])
+    loss, parts = torch_ppo_loss(ref, obs64, actions.cpu().double(), old_lp.cpu().double(), adv.cpu().double(),
+                                 ret.cpu().double(), clip, ent, vf)
+    loss.backward()
+    got = (stats[:5] / B).cpu().double()
+    want = torch.stack([p.detach() for p in parts])
+    assert torch.allclose(got, want, rtol=2e-4, atol=2e-6), (got, want)
+    gref = ref.flat_grad().double()
+    gk = pol.grad.cpu().double()
+    scale = gref.abs().max()
+    assert (gk - gref).abs().max() <= 2e-4 * scale, ((gk - gref).abs().max(), scale)
+    assert torch.allclose(gk[pol.log_std_off:], gref[pol.log_std_off:], rtol=1e-3, atol=1e-6)
+
+
+def test_adam_with_grad_clip_vs_torch():
+    _lib, lib = L()
+    n = 43977
+    g = torch.Generator(device=DEV).manual_seed(1)
+    p = torch.randn(n, device=DEV, generator=g)
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=1e-5, eps=1e-8)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sumsq, scratch = torch.zeros(1, device=DEV), torch.zeros(4096, device=DEV)
+    for step in range(1, 6):
+        grad = torch.randn(n, device=DEV, generator=g) * (10.0 if step % 2 else 0.001)
+        pr.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 0.5)
+        opt.step()
+        _lib.check(lib.vf_sumsq(grad.data_ptr(), n, sumsq.data_ptr(), scratch.data_ptr(), st()))
+        cfg = _lib.AdamCfg(1e-3, 0.9, 0.999, 1e-8, 1e-5, 0.5, step, 0)
+        _lib.check(lib.vf_adam_step(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, sumsq.data_ptr(),
+                                    C.byref(cfg), st()))
+        assert torch.allclose(p, pr.data, rtol=1e-5, atol=1e-6), (step, (p - pr.data).abs().max())
+
+
+def test_head_sample_distribution_and_log_prob():
+    _lib, lib = L()
+    M = 200000
+    mean = torch.zeros((M, 4), device=DEV) + torch.tensor([0.0, 0.5, -0.5, 1.0], device=DEV)
+    log_std = torch.tensor([0.0, -0.5, -1.0, -2.0], device=DEV)
+    a, lp = torch.empty((M, 4), device=DEV), torch.empty(M, device=DEV)
+    _lib.check(lib.vf_head_sample(mean.data_ptr(), log_std.data_ptr(), a.data_ptr(), lp.data_ptr(), M, 123, 1, 0, st()))
+    gz = torch.atanh(a.clamp(-1 + 1e-6, 1 - 1e-6))
+    z = (gz - mean) / log_std.exp()
+    ok = a.abs().max(dim=1).values < 0.999          # away from tanh saturation
+    assert abs(float(z[ok].mean())) < 0.02 and abs(float(z[ok].std()) - 1.0) < 0.03
+    assert torch.allclose(lp[ok], sb3_squashed_log_prob(mean, log_std, a)[ok], rtol=1e-4, atol=1e-3)
+    a2, lp2 = torch.empty_like(a), torch.empty_like(lp)
+    _lib.check(lib.vf_head_sample(mean.data_ptr(), log_std.data_ptr(), a2.data_ptr(), lp2.data_ptr(), M, 123, 1, 0, st()))
+    assert torch.equal(a, a2)                                       # counter RNG: reproducible
+    _lib.check(lib.vf_head_sample(mean.data_ptr(), log_std.data_ptr(), a2.data_ptr(), lp2.data_ptr(), M, 123, 2, 0, st()))
+    assert not torch.equal(a, a2)
+    _lib.check(lib.vf_head_sample(mean.data_ptr(), log_std.data_ptr(), a2.data_ptr(), lp2.data_ptr(), M, 123, 2, 1, st()))
+    assert torch.allclose(a2, torch.tanh(mean), atol=1e-6)
+
+
+def test_ppo_learn_runs_and_improves_value_fit():
+    """end-to-end: rollouts from the fused env, GAE, minibatch updates; the value loss must drop"""
+    from visfly_amd.envs import HoverEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    env = HoverEnv(num_agent_per_scene=2048, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64,
+                   tensor_output=True)
+    ppo = PPO(env, n_steps=32, batch_size=8192, n_epochs=4, learning_rate=3e-4, seed=3)
+    p0 = ppo.policy.flat.clone()
+    ppo.learn(32 * 2048)
+    v_first = ppo.logs["train/value_loss"]
+    ppo.learn(32 * 2048 * 6)
+    assert torch.isfinite(ppo.policy.flat).all() and not torch.equal(p0, ppo.policy.flat)
+    assert ppo.logs["train/value_loss"] < v_first
+    assert 0.0 <= ppo.logs["train/clip_fraction"] <= 1.0 and ppo.logs["time/fps"] > 0

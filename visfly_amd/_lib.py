@@ -95,6 +95,17 @@ class EnvView(C.Structure):
                                           "gate", "past_gates")]
 
 
+class PpoLossCfg(C.Structure):
+    """mirror of vf_ppo_loss_cfg"""
+    _fields_ = [("clip_range", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("inv_batch", C.c_float)]
+
+
+class AdamCfg(C.Structure):
+    """mirror of vf_adam_cfg"""
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", C.c_int32), ("pad0", C.c_int32)]
+
+
 class VisflyError(RuntimeError):
     pass
 
@@ -124,6 +135,18 @@ SIGNATURES = {
     "vf_env_step": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, _vp]),
     "vf_env_query": (C.c_int, [_vp, C.POINTER(EnvView), _vp]),
     "vf_env_time_steps": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, C.c_int32, _vp, C.POINTER(C.c_float)]),
+    "vf_gae": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int32, C.c_double, C.c_double, _vp]),
+    "vf_adv_normalize": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp]),
+    "vf_linear_fwd": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "vf_linear_bwd_data": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, _vp]),
+    "vf_linear_bwd_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "vf_linear_bwd_weight": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
+                                       C.c_int32, _vp, _vp]),
+    "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
+    "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
+    "vf_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    "vf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.POINTER(AdamCfg), _vp]),
 }
 
 

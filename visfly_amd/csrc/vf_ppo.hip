@@ -1,0 +1,600 @@
+// vf_ppo.hip -- PPO inner loop on the device (gfx950): GAE scan, advantage normalisation,
+// nn.Linear forward / backward on the fp32 MFMA, squashed-Gaussian head, clipped-surrogate
+// loss, gradient clipping + Adam.
+//
+// Reference: utils/algorithms/PPO.py:177-337 (train), SB3 2.2.1 RolloutBuffer /
+// collect_rollouts (mirrored in utils/algorithms/common.py:97-132), utils/policies/policies.py:
+// 195-254, utils/policies/extractors.py:376-449.  The reference runs these as torch autograd
+// over nn.Linear/ReLU; here each piece is one launch.  GEMMs use v_mfma_f32_32x32x2_f32
+// (exact fp32 products, fp32 accumulate, k-ordered), operands staged through LDS with an
+// odd row stride (conflict-free ds_read_b32 for the MFMA A/B fragments).
+#include "vf_common.hpp"
+#include "vf_env_device.hpp"  // Philox
+
+namespace vf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ------------------------------------------------------------------------------------------------
+// GAE: thread per env walks T backwards; loads are coalesced across envs (common.py:119-132)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_gae(const float* __restrict__ r, const float* __restrict__ v,
+                                                const float* __restrict__ es, const float* __restrict__ lastv,
+                                                const float* __restrict__ dones, float* __restrict__ adv,
+                                                float* __restrict__ ret, int T, int N, float gamma, float gl)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    float last = 0.0f;
+    float nnt = 1.0f - dones[i];
+    float nv = lastv[i];
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t o = (size_t)t * N + i;
+        const float vt = v[o];
+        const float delta = r[o] + gamma * nv * nnt - vt;
+        last = delta + gl * nnt * last;
+        adv[o] = last;
+        ret[o] = last + vt;
+        nnt = 1.0f - es[o];  // for step t-1: next_non_terminal = 1 - episode_starts[t]
+        nv = vt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_sumf(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+
+// sum and sum of squares in fp64: per-block partials, then one block folds them (deterministic)
+__global__ __launch_bounds__(kBlock) void k_sum2_partial(const float* __restrict__ x, long n, double* __restrict__ part)
+{
+    __shared__ double sh[2][4];
+    double s = 0.0, ss = 0.0;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        const double a = x[i];
+        s += a;
+        ss += a * a;
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+
+__global__ void k_sum2_final(const double* __restrict__ part, int nblk, double* __restrict__ out2, float* out_ss_f32)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0, ss = 0.0;
+        for (int b = 0; b < nblk; ++b) { s += part[2 * b]; ss += part[2 * b + 1]; }
+        if (out2) { out2[0] = s; out2[1] = ss; }
+        if (out_ss_f32) *out_ss_f32 = (float)ss;
+    }
+}
+
+// (A - mean) / (std_unbiased + 1e-8)   (PPO.py:217-220)
+__global__ __launch_bounds__(kBlock) void k_adv_apply(const float* __restrict__ a, float* __restrict__ out, long n,
+                                                      const double* __restrict__ sums, double count)
+{
+    const double mean = sums[0] / count;
+    double var = (sums[1] - sums[0] * mean) / (count - 1.0);
+    var = var > 0.0 ? var : 0.0;
+    const float m = (float)mean, sd = (float)sqrt(var) + 1e-8f;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) out[i] = (a[i] - m) / sd;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear layers on the fp32 MFMA.  Block = 4 waves, 64 output rows; each wave owns one 32-row
+// half and every other 32-column tile.  C/D fragment of v_mfma_f32_32x32x2_f32:
+// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// ------------------------------------------------------------------------------------------------
+constexpr int kRows = 64;
+
+// BWD == false: C[m][n] = act(sum_k A[m][k] * W[n][k] + b[n])          (forward; red = K, cols = No)
+// BWD == true : C[m][k] = sum_n (A[m][n] * [Ymask[m][n] > 0]) * W[n][k]  (data grad; red = No, cols = K)
+template <bool BWD, bool RELU>
+__global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, int lda, const float* __restrict__ Ym,
+                                                   int ldym, const float* __restrict__ W, const float* __restrict__ bias,
+                                                   float* __restrict__ C, int ldc, int M, int K, int No, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int red = BWD ? No : K;         // reduction length
+    const int cols = BWD ? K : No;        // output columns
+    const int redp = (red + 1) & ~1;      // MFMA consumes k in pairs
+    const int ct = (cols + 31) >> 5;      // 32-column tiles
+    const int sa = redp + 1;              // odd LDS row strides
+    float* As = lds;                      // [64][sa]
+    float* Ws = lds + kRows * sa;         // fwd: [ct*32][sa] (col-major over red) ; bwd: [redp][ct*32+1]
+    const int sw = BWD ? ct * 32 + 1 : sa;
+    const int m0 = blockIdx.x * kRows;
+    const int tid = threadIdx.x;
+
+    for (int idx = tid; idx < kRows * redp; idx += kBlock) {
+        const int r = idx / redp, k = idx - r * redp;
+        float x = 0.0f;
+        if (m0 + r < M && k < red) {
+            x = A[(size_t)(m0 + r) * lda + k];
+            if (BWD && Ym && !(Ym[(size_t)(m0 + r) * ldym + k] > 0.0f)) x = 0.0f;
+        }
+        As[r * sa + k] = x;
+    }
+    if (!BWD) {
+        for (int idx = tid; idx < ct * 32 * redp; idx += kBlock) {
+            const int n = idx / redp, k = idx - n * redp;
+            Ws[n * sw + k] = (n < No && k < K) ? W[(size_t)n * K + k] : 0.0f;
+        }
+    } else {
+        const int cw = ct * 32;
+        for (int idx = tid; idx < redp * cw; idx += kBlock) {
+            const int n = idx / cw, k = idx - n * cw;
+            Ws[n * sw + k] = (n < No && k < K) ? W[(size_t)n * K + k] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lk = lane >> 5;
+    const int rt = wave & 1;              // row half
+    const int c0 = wave >> 1;             // column tiles c0, c0 + 2
+    f32x16 acc0 = {0}, acc1 = {0};
+    const bool has0 = c0 < ct, has1 = c0 + 2 < ct;
+    const float* ap = As + (rt * 32 + lr) * sa + lk;
+    if (!BWD) {
+        const float* b0 = Ws + (c0 * 32 + lr) * sw + lk;
+        const float* b1 = Ws + ((c0 + 2) * 32 + lr) * sw + lk;
+        for (int k0 = 0; k0 < redp; k0 += 2) {
+            const float a = ap[k0];
+            if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[k0], acc0, 0, 0, 0);
+            if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[k0], acc1, 0, 0, 0);
+        }
+    } else {
+        const float* b0 = Ws + lk * sw + c0 * 32 + lr;
+        const float* b1 = Ws + lk * sw + (c0 + 2) * 32 + lr;
+        for (int k0 = 0; k0 < redp; k0 += 2) {
+            const float a = ap[k0];
+            if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[k0 * sw], acc0, 0, 0, 0);
+            if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[k0 * sw], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (!(t ? has1 : has0)) continue;
+        const f32x16& acc = t ? acc1 : acc0;
+        const int n = (c0 + 2 * t) * 32 + lr;
+        if (n >= cols) continue;
+        const float bn = (!BWD && bias) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = m0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            if (m >= M) continue;
+            float y = acc[reg] + bn;
+            if (RELU) y = y > 0.0f ? y : 0.0f;
+            float* dst = C + (size_t)m * ldc + n;
+            *dst = accumulate ? *dst + y : y;
+        }
+    }
+}
+
+// dW[n][k] = sum_m dYm[m][n] X[m][k]; block = one chunk of rows, partial written to part[blk][No*K + No]
+__global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict__ dY, int lddy, const float* __restrict__ Ym,
+                                                         int ldym, const float* __restrict__ X, int ldx,
+                                                         float* __restrict__ part, int M, int K, int No, int rows_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nt = (No + 31) >> 5, kt = (K + 31) >> 5;
+    const int sd = nt * 32 + 1, sx = kt * 32 + 1;
+    float* Ds = lds;               // [64][sd]  masked dY rows
+    float* Xs = lds + kRows * sd;  // [64][sx]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lk = lane >> 5;
+    const int mb = blockIdx.x * rows_per_block;
+    const int me = min(M, mb + rows_per_block);
+    const int ntiles = nt * kt;  // <= 16, wave takes tiles wave, wave+4, ...
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    float bsum = 0.0f;  // thread tid < No: column sum of masked dY
+    for (int m0 = mb; m0 < me; m0 += kRows) {
+        for (int idx = tid; idx < kRows * nt * 32; idx += kBlock) {
+            const int r = idx / (nt * 32), n = idx - r * (nt * 32);
+            float x = 0.0f;
+            if (m0 + r < me && n < No) {
+                x = dY[(size_t)(m0 + r) * lddy + n];
+                if (Ym && !(Ym[(size_t)(m0 + r) * ldym + n] > 0.0f)) x = 0.0f;
+            }
+            Ds[r * sd + n] = x;
+        }
+        for (int idx = tid; idx < kRows * kt * 32; idx += kBlock) {
+            const int r = idx / (kt * 32), k = idx - r * (kt * 32);
+            Xs[r * sx + k] = (m0 + r < me && k < K) ? X[(size_t)(m0 + r) * ldx + k] : 0.0f;
+        }
+        __syncthreads();
+        if (tid < No) {
+            float s = 0.0f;
+            for (int r = 0; r < kRows; ++r) s += Ds[r * sd + tid];
+            bsum += s;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = wave + 4 * q;
+            if (tile >= ntiles) break;
+            const int it = tile / kt, jt = tile - it * kt;
+            const float* ap = Ds + lk * sd + it * 32 + lr;
+            const float* bp = Xs + lk * sx + jt * 32 + lr;
+            f32x16 c = acc[q];
+            for (int k0 = 0; k0 < kRows; k0 += 2)
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k0 * sd], bp[k0 * sx], c, 0, 0, 0);
+            acc[q] = c;
+        }
+        __syncthreads();
+    }
+    float* p = part + (size_t)blockIdx.x * ((size_t)No * K + No);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tile = wave + 4 * q;
+        if (tile >= ntiles) break;
+        const int it = tile / kt, jt = tile - it * kt;
+        const int k = jt * 32 + lr;
+        if (k >= K) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int n = it * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            if (n < No) p[(size_t)n * K + k] = acc[q][reg];
+        }
+    }
+    if (tid < No) p[(size_t)No * K + tid] = bsum;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fold_partials(const float* __restrict__ part, int nblk, int nw, int nb,
+                                                          float* __restrict__ dW, float* __restrict__ db)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int n = nw + nb;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
+    if (i < nw) dW[i] = s;
+    else if (db) db[i - nw] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Squashed diagonal Gaussian head
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float atanh_clamped(float a)
+{
+    // TanhBijector.inverse: atanh(clamp(a, -1 + eps, 1 - eps)), eps = float32 eps
+    const float eps = 1.1920929e-07f;
+    const float x = fminf(fmaxf(a, -1.0f + eps), 1.0f - eps);
+    return 0.5f * (log1pf(x) - log1pf(-x));
+}
+
+// log N(g; mu, sigma) summed over 4 dims minus the tanh correction sum log(1 - a^2 + 1e-6)
+__device__ __forceinline__ float squashed_log_prob(const float* mu, const float* ls, const float* a, float* g)
+{
+    float lp = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        g[d] = atanh_clamped(a[d]);
+        const float sd = expf(ls[d]);
+        const float z = (g[d] - mu[d]) / sd;
+        lp += -0.5f * z * z - ls[d] - 0.91893853320467274178f;
+        lp -= logf(1.0f - a[d] * a[d] + 1e-6f);
+    }
+    return lp;
+}
+
+__global__ __launch_bounds__(kBlock) void k_head_sample(const float4* __restrict__ mean, const float* __restrict__ log_std,
+                                                        float4* __restrict__ action, float* __restrict__ logp, int M,
+                                                        unsigned long long seed, unsigned long long step, int deterministic)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    const float4 m4 = mean[i];
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+    const float ls[4] = {log_std[0], log_std[1], log_std[2], log_std[3]};
+    float a[4];
+    if (deterministic) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) a[d] = tanhf(mu[d]);
+    } else {
+        const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)step, (unsigned)(step >> 32), 0xac7u}, (unsigned)seed,
+                                   (unsigned)(seed >> 32));
+        const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+        const float u3 = ((float)(r.z >> 8) + 1.0f) * (1.0f / 16777216.0f), u4 = (float)(r.w >> 8) * (1.0f / 16777216.0f);
+        const float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+        const float two_pi = 6.28318530717958647692f;
+        const float e[4] = {ra * cosf(two_pi * u2), ra * sinf(two_pi * u2), rb * cosf(two_pi * u4), rb * sinf(two_pi * u4)};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) a[d] = tanhf(mu[d] + expf(ls[d]) * e[d]);
+    }
+    float g[4];
+    logp[i] = squashed_log_prob(mu, ls, a, g);
+    action[i] = make_float4(a[0], a[1], a[2], a[3]);
+}
+
+// PPO clipped surrogate + value MSE + "entropy" (= mean log-prob for the squashed head), PPO.py:210-263
+constexpr int kStats = 16;
+__global__ __launch_bounds__(kBlock) void k_ppo_loss(const float4* __restrict__ mean, const float* __restrict__ value,
+                                                     const float* __restrict__ log_std, const float4* __restrict__ action,
+                                                     const float* __restrict__ old_lp, const float* __restrict__ adv,
+                                                     const float* __restrict__ ret, float4* __restrict__ d_mean,
+                                                     float* __restrict__ d_value, float* __restrict__ part, int M,
+                                                     const vf_ppo_loss_cfg cfg)
+{
+    __shared__ float sh[4][kStats];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    float st[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < M) {
+        const float4 m4 = mean[i], a4 = action[i];
+        const float mu[4] = {m4.x, m4.y, m4.z, m4.w}, a[4] = {a4.x, a4.y, a4.z, a4.w};
+        const float ls[4] = {log_std[0], log_std[1], log_std[2], log_std[3]};
+        float g[4];
+        const float lp = squashed_log_prob(mu, ls, a, g);
+        const float log_ratio = lp - old_lp[i];
+        const float ratio = expf(log_ratio);
+        const float A = adv[i];
+        const float lo = 1.0f - cfg.clip_range, hi = 1.0f + cfg.clip_range;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = A * ratio, s2 = A * rc;
+        const bool clipped = ratio < lo || ratio > hi;
+        // d(-min(s1,s2))/d ratio: through s1 when it is the smaller one (or equal: unclipped), else 0
+        const float dl_dratio = (s1 <= s2 || !clipped) ? -A : 0.0f;
+        const float v = value[i], R = ret[i];
+        const float dv = v - R;
+        // d loss / d log_prob per row (means over the global batch)
+        const float dl_dlp = (dl_dratio * ratio + cfg.ent_coef) * cfg.inv_batch;
+        float dm[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float sd = expf(ls[d]);
+            const float z = (g[d] - mu[d]) / sd;
+            dm[d] = dl_dlp * z / sd;
+            st[5 + d] = dl_dlp * (z * z - 1.0f);
+        }
+        d_mean[i] = make_float4(dm[0], dm[1], dm[2], dm[3]);
+        d_value[i] = cfg.vf_coef * 2.0f * dv * cfg.inv_batch;
+        st[0] = -fminf(s1, s2);
+        st[1] = dv * dv;
+        st[2] = lp;
+        st[3] = (ratio - 1.0f) - log_ratio;
+        st[4] = fabsf(ratio - 1.0f) > cfg.clip_range ? 1.0f : 0.0f;
+    }
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float s = wave_sumf(st[k]);
+        if ((threadIdx.x & 63) == 0) sh[w][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int k = threadIdx.x;
+        part[(size_t)blockIdx.x * kStats + k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+    }
+}
+
+__global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __restrict__ stats)
+{
+    const int k = threadIdx.x;
+    if (k >= kStats) return;
+    float s = 0.0f;
+    if (k < 9)
+        for (int b = 0; b < nblk; ++b) s += part[(size_t)b * kStats + k];
+    stats[k] = s;
+}
+
+// clip_grad_norm_ + Adam with L2 weight decay (torch.optim.Adam semantics), PPO.py:285-292
+__global__ __launch_bounds__(kBlock) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, long n, const float* __restrict__ sumsq,
+                                                 const vf_adam_cfg c, float bc1, float bc2_sqrt)
+{
+    float coef = 1.0f;
+    if (c.max_grad_norm > 0.0f) {
+        const float total = sqrtf(*sumsq);
+        coef = fminf(c.max_grad_norm / (total + 1e-6f), 1.0f);
+    }
+    const float step = c.lr / bc1;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        const float pi = p[i];
+        float gi = g[i] * coef;
+        gi = gi + c.weight_decay * pi;
+        const float mi = c.beta1 * m[i] + (1.0f - c.beta1) * gi;
+        const float vi = c.beta2 * v[i] + (1.0f - c.beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
+        p[i] = pi - step * (mi / denom);
+    }
+}
+
+inline int grid_for(long n, int cap = 512)
+{
+    long b = (n + kBlock - 1) / kBlock;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace vf
+
+namespace {
+
+size_t linear_lds_bytes(bool bwd, int K, int No)
+{
+    const int red = bwd ? No : K, cols = bwd ? K : No;
+    const int redp = (red + 1) & ~1, ct = (cols + 31) >> 5, sa = redp + 1;
+    const size_t ws = bwd ? (size_t)redp * (ct * 32 + 1) : (size_t)ct * 32 * sa;
+    return ((size_t)vf::kRows * sa + ws) * sizeof(float);
+}
+
+template <typename Kern>
+int allow_lds(Kern k, size_t bytes)
+{
+    if (bytes > 64 * 1024) VF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return VF_OK;
+}
+
+int wgrad_rows_per_block(int M)
+{
+    int rpb = (M + 511) / 512;  // aim at <= 512 chunks
+    rpb = (rpb + vf::kRows - 1) / vf::kRows * vf::kRows;
+    return rpb < vf::kRows ? vf::kRows : rpb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
+           const float* dones, float* adv, float* ret, int32_t T, int32_t N, double gamma, double lam, vf_stream_t stream)
+{
+    if (!rewards || !values || !episode_starts || !last_values || !dones || !adv || !ret || T <= 0 || N <= 0)
+        return vf::fail(VF_EINVAL, "vf_gae: bad argument");
+    hipLaunchKernelGGL(vf::k_gae, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), rewards, values,
+                       episode_starts, last_values, dones, adv, ret, T, N, (float)gamma, (float)(gamma * lam));
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_adv_normalize(const float* adv, float* out, int64_t n, int64_t count, double* sums_inout, float* scratch,
+                     int32_t phase, vf_stream_t stream)
+{
+    if (!adv || !out || !scratch || n <= 0 || count < 2 || phase < 0 || phase > 2)
+        return vf::fail(VF_EINVAL, "vf_adv_normalize: bad argument");
+    hipStream_t st = vf::as_stream(stream);
+    double* part = reinterpret_cast<double*>(scratch);  // [2*nblk] + 2 doubles for the sums
+    const int nblk = vf::grid_for(n, 256);
+    double* sums = sums_inout ? sums_inout : part + 2 * 256;
+    if (phase == 0 || phase == 2) {
+        hipLaunchKernelGGL(vf::k_sum2_partial, dim3(nblk), dim3(vf::kBlock), 0, st, adv, (long)n, part);
+        hipLaunchKernelGGL(vf::k_sum2_final, dim3(1), dim3(64), 0, st, part, nblk, sums, (float*)nullptr);
+    }
+    if (phase == 1 || phase == 2)
+        hipLaunchKernelGGL(vf::k_adv_apply, dim3(vf::grid_for(n, 1024)), dim3(vf::kBlock), 0, st, adv, out, (long)n, sums,
+                           (double)count);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_linear_fwd(const float* X, int32_t ldx, const float* W, const float* b, float* Y, int32_t ldy, int32_t M,
+                  int32_t K, int32_t No, int32_t relu, vf_stream_t stream)
+{
+    if (!X || !W || !Y || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128 || ldx < K || ldy < No)
+        return vf::fail(VF_EINVAL, "vf_linear_fwd: bad argument (K, No <= 128)");
+    const size_t lds = linear_lds_bytes(false, K, No);
+    const dim3 grid((M + vf::kRows - 1) / vf::kRows), block(vf::kBlock);
+    hipStream_t st = vf::as_stream(stream);
+    if (relu) {
+        if (int rc = allow_lds(vf::k_linear<false, true>, lds)) return rc;
+        hipLaunchKernelGGL((vf::k_linear<false, true>), grid, block, lds, st, X, ldx, (const float*)nullptr, 0, W, b, Y, ldy, M, K, No, 0);
+    } else {
+        if (int rc = allow_lds(vf::k_linear<false, false>, lds)) return rc;
+        hipLaunchKernelGGL((vf::k_linear<false, false>), grid, block, lds, st, X, ldx, (const float*)nullptr, 0, W, b, Y, ldy, M, K, No, 0);
+    }
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_linear_bwd_data(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* W, float* dX,
+                       int32_t lddx, int32_t M, int32_t K, int32_t No, int32_t accumulate, vf_stream_t stream)
+{
+    if (!dY || !W || !dX || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128 || lddy < No || lddx < K)
+        return vf::fail(VF_EINVAL, "vf_linear_bwd_data: bad argument (K, No <= 128)");
+    const size_t lds = linear_lds_bytes(true, K, No);
+    if (int rc = allow_lds(vf::k_linear<true, false>, lds)) return rc;
+    hipLaunchKernelGGL((vf::k_linear<true, false>), dim3((M + vf::kRows - 1) / vf::kRows), dim3(vf::kBlock), lds,
+                       vf::as_stream(stream), dY, lddy, Ymask, ldym, W, (const float*)nullptr, dX, lddx, M, K, No, accumulate);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int64_t vf_linear_bwd_scratch_floats(int32_t M, int32_t K, int32_t No)
+{
+    const int rpb = wgrad_rows_per_block(M);
+    const int nblk = (M + rpb - 1) / rpb;
+    return (int64_t)nblk * ((int64_t)No * K + No);
+}
+
+int vf_linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X, int32_t ldx,
+                         float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream)
+{
+    if (!dY || !X || !dW || !scratch || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128)
+        return vf::fail(VF_EINVAL, "vf_linear_bwd_weight: bad argument (K, No <= 128)");
+    const int rpb = wgrad_rows_per_block(M);
+    const int nblk = (M + rpb - 1) / rpb;
+    const int nt = (No + 31) >> 5, kt = (K + 31) >> 5;
+    const size_t lds = (size_t)vf::kRows * ((nt * 32 + 1) + (kt * 32 + 1)) * sizeof(float);
+    if (int rc = allow_lds(vf::k_linear_wgrad, lds)) return rc;
+    hipStream_t st = vf::as_stream(stream);
+    hipLaunchKernelGGL(vf::k_linear_wgrad, dim3(nblk), dim3(vf::kBlock), lds, st, dY, lddy, Ymask, ldym, X, ldx, scratch, M, K,
+                       No, rpb);
+    const int n = No * K + No;
+    hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + vf::kBlock - 1) / vf::kBlock), dim3(vf::kBlock), 0, st, scratch, nblk,
+                       No * K, No, dW, db);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_head_sample(const float* mean, const float* log_std, float* action, float* log_prob, int32_t M, uint64_t seed,
+                   uint64_t step, int32_t deterministic, vf_stream_t stream)
+{
+    if (!mean || !log_std || !action || !log_prob || M <= 0) return vf::fail(VF_EINVAL, "vf_head_sample: bad argument");
+    hipLaunchKernelGGL(vf::k_head_sample, dim3(vf::blocks_for(M)), dim3(vf::kBlock), 0, vf::as_stream(stream),
+                       reinterpret_cast<const float4*>(mean), log_std, reinterpret_cast<float4*>(action), log_prob, M,
+                       (unsigned long long)seed, (unsigned long long)step, deterministic);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_ppo_loss(const float* mean, const float* value, const float* log_std, const float* action, const float* old_log_prob,
+                const float* adv, const float* ret, float* d_mean, float* d_value, float* stats, int32_t M,
+                const vf_ppo_loss_cfg* cfg, float* scratch, vf_stream_t stream)
+{
+    if (!mean || !value || !log_std || !action || !old_log_prob || !adv || !ret || !d_mean || !d_value || !stats || !cfg ||
+        !scratch || M <= 0)
+        return vf::fail(VF_EINVAL, "vf_ppo_loss: bad argument");
+    const int nblk = vf::blocks_for(M);
+    if (nblk > 1024) return vf::fail(VF_EINVAL, "vf_ppo_loss: at most 262144 rows per call (scratch contract)");
+    hipStream_t st = vf::as_stream(stream);
+    hipLaunchKernelGGL(vf::k_ppo_loss, dim3(nblk), dim3(vf::kBlock), 0, st, reinterpret_cast<const float4*>(mean), value,
+                       log_std, reinterpret_cast<const float4*>(action), old_log_prob, adv, ret,
+                       reinterpret_cast<float4*>(d_mean), d_value, scratch, M, *cfg);
+    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(64), 0, st, scratch, nblk, stats);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_sumsq(const float* x, int64_t n, float* out1, float* scratch, vf_stream_t stream)
+{
+    if (!x || !out1 || !scratch || n <= 0) return vf::fail(VF_EINVAL, "vf_sumsq: bad argument");
+    hipStream_t st = vf::as_stream(stream);
+    double* part = reinterpret_cast<double*>(scratch);
+    const int nblk = vf::grid_for(n, 256);
+    hipLaunchKernelGGL(vf::k_sum2_partial, dim3(nblk), dim3(vf::kBlock), 0, st, x, (long)n, part);
+    hipLaunchKernelGGL(vf::k_sum2_final, dim3(1), dim3(64), 0, st, part, nblk, (double*)nullptr, out1);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* grad_sumsq,
+                 const vf_adam_cfg* cfg, vf_stream_t stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !cfg || n <= 0 || cfg->step <= 0 || (cfg->max_grad_norm > 0 && !grad_sumsq))
+        return vf::fail(VF_EINVAL, "vf_adam_step: bad argument");
+    const float bc1 = 1.0f - (float)pow((double)cfg->beta1, (double)cfg->step);
+    const float bc2 = 1.0f - (float)pow((double)cfg->beta2, (double)cfg->step);
+    hipLaunchKernelGGL(vf::k_adam, dim3(vf::grid_for(n, 1024)), dim3(vf::kBlock), 0, vf::as_stream(stream), param, grad, exp_avg,
+                       exp_avg_sq, (long)n, grad_sumsq, *cfg, bc1, sqrtf(bc2));
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+}  // extern "C"

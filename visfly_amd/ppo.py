@@ -1,0 +1,402 @@
+"""On-device PPO for the state-vector drone envs.
+
+Restates the reference's PPO path (utils/algorithms/PPO.py:116-337 on top of SB3 2.2.1
+``OnPolicyAlgorithm.collect_rollouts`` / ``RolloutBuffer``; policy = ``CustomMultiInputActorCriticPolicy``
+with ``StateExtractor`` / ``StateTargetExtractor`` MLPs, utils/policies/policies.py:195-254,
+utils/policies/extractors.py:376-449,578-592,662-678) with every arithmetic piece running as a HIP
+kernel behind the C-ABI: policy/value MLP forward + backward on the fp32 MFMA, squashed-Gaussian
+head sampling, GAE scan, advantage normalisation, clipped-surrogate loss, grad-norm clip + Adam.
+The rollout buffer lives on the device ([T][N] SoA); nothing crosses PCIe inside ``learn``.
+
+Multi-GPU: one process per GPU, agents sharded by rank; the only exchange is ONE all-reduce of the
+flat fp32 gradient buffer per optimiser step (plus the two fp64 advantage sums so that the
+normalisation is over the global minibatch) through ``torch.distributed`` (RCCL on ROCm).
+"""
+import ctypes as C
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch as th
+
+from . import _lib
+
+
+def _ptr(t, off=0):
+    return None if t is None else t.data_ptr() + 4 * off
+
+
+class _Linear:
+    """one nn.Linear (+ReLU) of the schedule: reads src[:, sc:sc+K], writes dst[:, dc:dc+No]"""
+
+    def __init__(self, K, No, relu, src, sc, dst, dc, w_off, b_off, first):
+        self.K, self.No, self.relu = K, No, relu
+        self.src, self.sc, self.dst, self.dc = src, sc, dst, dc
+        self.w_off, self.b_off, self.first = w_off, b_off, first
+
+
+class MlpPolicy:
+    """Actor-critic MLP over dict observations of flat vectors.
+
+    ``extractor``: {obs key: hidden layer sizes} -- one ReLU MLP per key, outputs concatenated
+    (StateExtractor / StateTargetExtractor); ``pi`` / ``vf``: hidden sizes of the policy / value
+    trunks (MlpExtractor2); heads: action_net (-> 4) and value_net (-> 1); state-independent
+    ``log_std`` (4), tanh-squashed Gaussian (policies.py:114,177-181).  All parameters live in one
+    flat fp32 device buffer (weights [No][K] row-major like nn.Linear, then biases, ... , log_std).
+    """
+
+    def __init__(self, obs_dims: Dict[str, int], extractor: Dict[str, List[int]], pi: List[int], vf: List[int],
+                 device, action_dim: int = 4, log_std_init: float = 0.0, seed: int = 0):
+        assert action_dim == 4, "the head kernels are written for the 4-d drone action"
+        self.device = th.device(device)
+        self.obs_keys = list(extractor.keys())
+        self.obs_dims = {k: int(obs_dims[k]) for k in self.obs_keys}
+        self.spec = dict(extractor={k: list(v) for k, v in extractor.items()}, pi=list(pi), vf=list(vf))
+        # ---- activation buffers (name -> width) and the layer schedule ----
+        self.widths: Dict[str, int] = {}
+        self.layers: List[_Linear] = []
+        off = 0
+
+        def add(K, No, relu, src, sc, dst, dc, first=False):
+            nonlocal off
+            self.layers.append(_Linear(K, No, relu, src, sc, dst, dc, off, off + K * No, first))
+            off += K * No + No
+
+        feat_w = sum((v[-1] if v else self.obs_dims[k]) for k, v in extractor.items())
+        self.widths["feat"] = feat_w
+        col = 0
+        for k, hidden in extractor.items():
+            src, sc, K = "obs:" + k, 0, self.obs_dims[k]
+            if not hidden:
+                raise NotImplementedError("identity extractor branches are not supported")
+            for li, h in enumerate(hidden):
+                last = li == len(hidden) - 1
+                dst = "feat" if last else f"x:{k}:{li}"
+                dc = col if last else 0
+                if not last:
+                    self.widths[dst] = h
+                add(K, h, True, src, sc, dst, dc, first=(li == 0))
+                src, sc, K = dst, dc, h
+            col += hidden[-1]
+        for trunk, hidden, head_dim, head in (("pi", pi, action_dim, "mean"), ("vf", vf, 1, "value")):
+            src, sc, K = "feat", 0, feat_w
+            for li, h in enumerate(hidden):
+                dst = f"{trunk}:{li}"
+                self.widths[dst] = h
+                add(K, h, True, src, sc, dst, 0)
+                src, sc, K = dst, 0, h
+            self.widths[head] = head_dim
+            add(K, head_dim, False, src, sc, head, 0)
+        self.log_std_off = off
+        self.n_params = off + action_dim
+        for ly in self.layers:
+            if ly.K > 128 or ly.No > 128:
+                raise ValueError("layer widths up to 128 are supported by the MFMA linear kernels")
+        # ---- parameters: nn.Linear default init (kaiming-uniform), reproducible from `seed` ----
+        g = th.Generator().manual_seed(seed)
+        flat = th.zeros(self.n_params)
+        for ly in self.layers:
+            bound = 1.0 / np.sqrt(ly.K)
+            flat[ly.w_off:ly.w_off + ly.K * ly.No] = (th.rand(ly.K * ly.No, generator=g) * 2 - 1) * bound
+            flat[ly.b_off:ly.b_off + ly.No] = (th.rand(ly.No, generator=g) * 2 - 1) * bound
+        flat[self.log_std_off:] = log_std_init
+        self.flat = flat.to(self.device)
+        self.grad = th.zeros_like(self.flat)
+        self._bufs: Dict[int, Dict[str, th.Tensor]] = {}
+        self._scratch = None
+
+    # -------------------------------------------------------------------------------------------
+    def weight(self, ly):
+        return self.flat[ly.w_off:ly.w_off + ly.K * ly.No].view(ly.No, ly.K)
+
+    def bias(self, ly):
+        return self.flat[ly.b_off:ly.b_off + ly.No]
+
+    @property
+    def log_std(self):
+        return self.flat[self.log_std_off:]
+
+    def _buffers(self, M):
+        b = self._bufs.get(M)
+        if b is None:
+            b = {name: th.empty((M, w), dtype=th.float32, device=self.device) for name, w in self.widths.items()}
+            b.update({"g:" + name: th.empty((M, w), dtype=th.float32, device=self.device)
+                      for name, w in self.widths.items() if name not in ("mean", "value")})
+            if len(self._bufs) > 4:
+                self._bufs.clear()
+            self._bufs[M] = b
+        return b
+
+    def _stream(self):
+        return th.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self, obs: Dict[str, th.Tensor]):
+        """-> mean (M,4), value (M,1); activations are kept for ``backward``"""
+        M = obs[self.obs_keys[0]].shape[0]
+        b = self._buffers(M)
+        L, st = _lib.lib(), self._stream()
+        for k in self.obs_keys:
+            t = obs[k]
+            assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
+            b["obs:" + k] = t
+        for ly in self.layers:
+            X, Y = b[ly.src], b[ly.dst]
+            rc = L.vf_linear_fwd(_ptr(X, ly.sc), X.shape[1], _ptr(self.flat, ly.w_off), _ptr(self.flat, ly.b_off),
+                                 _ptr(Y, ly.dc), Y.shape[1], M, ly.K, ly.No, 1 if ly.relu else 0, st)
+            if rc:
+                _lib.check(rc)
+        self._last_M = M
+        return b["mean"], b["value"]
+
+    def backward(self, d_mean: th.Tensor, d_value: th.Tensor, d_log_std: th.Tensor):
+        """fills ``self.grad`` (flat, same layout as ``self.flat``) from the head gradients"""
+        M = self._last_M
+        b = self._buffers(M)
+        L, st = _lib.lib(), self._stream()
+        need = max(int(L.vf_linear_bwd_scratch_floats(M, ly.K, ly.No)) for ly in self.layers)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = th.empty(need, dtype=th.float32, device=self.device)
+        gbuf = {"mean": d_mean, "value": d_value.view(M, 1)}
+        touched = set()
+        for ly in reversed(self.layers):
+            dY = gbuf.get(ly.dst, b.get("g:" + ly.dst))
+            Y, X = b[ly.dst], b[ly.src]
+            ym = _ptr(Y, ly.dc) if ly.relu else None
+            rc = L.vf_linear_bwd_weight(_ptr(dY, ly.dc), dY.shape[1], ym, Y.shape[1], _ptr(X, ly.sc), X.shape[1],
+                                        _ptr(self.grad, ly.w_off), _ptr(self.grad, ly.b_off), M, ly.K, ly.No,
+                                        _ptr(self._scratch), st)
+            if rc:
+                _lib.check(rc)
+            if not ly.first:
+                dX = b["g:" + ly.src]
+                key = (ly.src, ly.sc)
+                rc = L.vf_linear_bwd_data(_ptr(dY, ly.dc), dY.shape[1], ym, Y.shape[1], _ptr(self.flat, ly.w_off),
+                                          _ptr(dX, ly.sc), dX.shape[1], M, ly.K, ly.No, 1 if key in touched else 0, st)
+                if rc:
+                    _lib.check(rc)
+                touched.add(key)
+        self.grad[self.log_std_off:] = d_log_std
+
+    # -------------------------------------------------------------------------------------------
+    def to_torch(self):
+        """equivalent torch.nn module (fp32) sharing NO storage -- the plain-PyTorch reference the
+        numerics tests compare against"""
+        import torch.nn as nn
+        pol = self
+
+        class Ref(nn.Module):
+            def __init__(s):
+                super().__init__()
+                s.lin = nn.ModuleList()
+                for ly in pol.layers:
+                    m = nn.Linear(ly.K, ly.No)
+                    m.weight.data.copy_(pol.weight(ly).cpu())
+                    m.bias.data.copy_(pol.bias(ly).cpu())
+                    s.lin.append(m)
+                s.log_std = nn.Parameter(pol.log_std.detach().cpu().clone())
+
+            def forward(s, obs):
+                acts = {"obs:" + k: v for k, v in obs.items()}
+                M = next(iter(obs.values())).shape[0]
+                for ly, m in zip(pol.layers, s.lin):
+                    x = acts[ly.src][:, ly.sc:ly.sc + ly.K]
+                    y = m(x)
+                    y = th.relu(y) if ly.relu else y
+                    if ly.dst == "feat":
+                        if "feat" not in acts:
+                            acts["feat"] = th.zeros((M, pol.widths["feat"]), dtype=y.dtype, device=y.device)
+                        acts["feat"] = th.cat([acts["feat"][:, :ly.dc], y, acts["feat"][:, ly.dc + ly.No:]], dim=1)
+                    else:
+                        acts[ly.dst] = y
+                return acts["mean"], acts["value"]
+
+            def flat_grad(s):
+                g = th.zeros(pol.n_params)
+                for ly, m in zip(pol.layers, s.lin):
+                    g[ly.w_off:ly.w_off + ly.K * ly.No] = m.weight.grad.reshape(-1)
+                    g[ly.b_off:ly.b_off + ly.No] = m.bias.grad
+                g[pol.log_std_off:] = s.log_std.grad
+                return g
+
+        return Ref()
+
+
+class RolloutBuffer:
+    """[T][N] device-resident rollout storage (SB3 RolloutBuffer semantics; mirror at
+    utils/algorithms/common.py:46-215)"""
+
+    def __init__(self, T, N, obs_dims: Dict[str, int], device):
+        f = dict(dtype=th.float32, device=device)
+        self.T, self.N = T, N
+        self.obs = {k: th.zeros((T, N, d), **f) for k, d in obs_dims.items()}
+        self.actions = th.zeros((T, N, 4), **f)
+        self.rewards, self.values, self.log_probs = th.zeros((T, N), **f), th.zeros((T, N), **f), th.zeros((T, N), **f)
+        self.episode_starts = th.zeros((T, N), **f)
+        self.advantages, self.returns = th.zeros((T, N), **f), th.zeros((T, N), **f)
+
+
+class PPO:
+    """PPO.learn / collect_rollouts / train of the reference (utils/algorithms/PPO.py:116-337)."""
+
+    def __init__(self, env, n_steps=256, batch_size=25600, n_epochs=5, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
+                 ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, learning_rate=1e-4, weight_decay=1e-5,
+                 normalize_advantage=True, policy_kwargs: Optional[dict] = None, seed=0, adam_eps=1e-8,
+                 betas=(0.9, 0.999), target_kl=None):
+        self.env = env
+        env.tensor_output, env.requires_grad = True, False        # PPO.py:80-82 forces the non-grad path
+        self.device = env.device
+        self.n_envs = env.num_envs
+        self.n_steps, self.batch_size, self.n_epochs = n_steps, batch_size, n_epochs
+        self.gamma, self.gae_lambda, self.clip_range = gamma, gae_lambda, clip_range
+        self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
+        self.lr, self.weight_decay, self.adam_eps, self.betas = learning_rate, weight_decay, adam_eps, betas
+        self.normalize_advantage, self.target_kl, self.seed = normalize_advantage, target_kl, seed
+        obs = env.get_observation()
+        self.obs_keys = [k for k in obs.keys() if k in ("state", "target")]
+        obs_dims = {k: obs[k].shape[1] for k in self.obs_keys}
+        pk = dict(policy_kwargs or {})
+        extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
+        self.policy = MlpPolicy(obs_dims, extractor, pk.get("pi", [64, 64]), pk.get("vf", [64, 64]), self.device,
+                                log_std_init=pk.get("log_std_init", 0.0), seed=seed)
+        self.buf = RolloutBuffer(n_steps, self.n_envs, obs_dims, self.device)
+        n = self.policy.n_params
+        dev = self.device
+        self.exp_avg, self.exp_avg_sq = th.zeros(n, device=dev), th.zeros(n, device=dev)
+        self._scratch = th.zeros(16 * 1024 + 4096, device=dev)
+        self._stats = th.zeros(16, device=dev)
+        self._sumsq = th.zeros(1, device=dev)
+        self._sums = th.zeros(2, dtype=th.float64, device=dev)
+        self._opt_step = 0
+        self._sample_step = 0
+        self.num_timesteps = 0
+        self._last_obs = None
+        self._last_starts = th.ones(self.n_envs, device=dev)
+        # bounded list of truncated-episode terminal observations per rollout (timeout bootstrap)
+        self.world = th.distributed.get_world_size() if th.distributed.is_available() and th.distributed.is_initialized() else 1
+        self.logs: Dict[str, float] = {}
+
+    def _stream(self):
+        return th.cuda.current_stream(self.device).cuda_stream
+
+    # ------------------------------------------------------------------------------------------
+    def _act(self, obs, deterministic=False):
+        """policy.forward (policies.py:195-226): action, value, log_prob"""
+        mean, value = self.policy.forward({k: obs[k] for k in self.obs_keys})
+        M = mean.shape[0]
+        action = th.empty((M, 4), device=self.device)
+        logp = th.empty(M, device=self.device)
+        self._sample_step += 1
+        _lib.check(_lib.lib().vf_head_sample(_ptr(mean), _ptr(self.policy.log_std), _ptr(action), _ptr(logp), M,
+                                             int(self.seed) & (2 ** 64 - 1), self._sample_step, 1 if deterministic else 0,
+                                             self._stream()))
+        return action, value.view(M), logp
+
+    def predict_values(self, obs):
+        _, value = self.policy.forward({k: obs[k] for k in self.obs_keys})
+        return value.view(-1).clone()
+
+    def collect_rollouts(self):
+        """SB3 OnPolicyAlgorithm.collect_rollouts: n_steps of policy -> env.step -> buffer, with the
+        TimeLimit bootstrap reward += gamma * V(terminal_obs) for truncated episodes, then GAE."""
+        env, buf = self.env, self.buf
+        if self._last_obs is None:
+            self._last_obs = env.reset()
+            self._last_starts = th.ones(self.n_envs, device=self.device)
+        obs = self._last_obs
+        EP_TRUNC = 2
+        for t in range(self.n_steps):
+            action, value, logp = self._act(obs)
+            for k in self.obs_keys:
+                buf.obs[k][t].copy_(obs[k])
+            buf.actions[t].copy_(action)
+            buf.values[t].copy_(value)
+            buf.log_probs[t].copy_(logp)
+            buf.episode_starts[t].copy_(self._last_starts)
+            obs, reward, done, _info = env.step(action)
+            # TimeLimit.truncated bootstrap: SB3 adds gamma * V(terminal_observation) where the info says truncated
+            trunc = done & ((env._ep_flags & EP_TRUNC) != 0)
+            tobs = {"state": env._terminal_obs}
+            if "target" in self.obs_keys:
+                tobs["target"] = obs["target"]
+            tv = self.predict_values(tobs)
+            buf.rewards[t] = reward + self.gamma * tv * trunc
+            self._last_starts = done.float()
+        self._last_obs = obs
+        last_values = self.predict_values(obs)
+        _lib.check(_lib.lib().vf_gae(_ptr(buf.rewards), _ptr(buf.values), _ptr(buf.episode_starts), _ptr(last_values),
+                                     _ptr(self._last_starts), _ptr(buf.advantages), _ptr(buf.returns), self.n_steps,
+                                     self.n_envs, float(self.gamma), float(self.gae_lambda), self._stream()))
+        self.num_timesteps += self.n_steps * self.n_envs * self.world
+
+    # ------------------------------------------------------------------------------------------
+    def _minibatch_update(self, idx):
+        """one optimiser step on the rows `idx` of the flattened buffer (PPO.py:203-292)"""
+        L, st, buf, pol = _lib.lib(), self._stream(), self.buf, self.policy
+        B = idx.numel()
+        obs = {k: buf.obs[k].view(-1, buf.obs[k].shape[-1]).index_select(0, idx) for k in self.obs_keys}
+        actions = buf.actions.view(-1, 4).index_select(0, idx)
+        old_lp = buf.log_probs.view(-1).index_select(0, idx)
+        adv = buf.advantages.view(-1).index_select(0, idx)
+        ret = buf.returns.view(-1).index_select(0, idx)
+        gB = B * self.world
+        if self.normalize_advantage and gB > 1:
+            advn = th.empty_like(adv)
+            if self.world > 1:
+                _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, self._sums.data_ptr(), _ptr(self._scratch), 0, st))
+                th.distributed.all_reduce(self._sums)
+                _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, self._sums.data_ptr(), _ptr(self._scratch), 1, st))
+            else:
+                _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, None, _ptr(self._scratch), 2, st))
+            adv = advn
+        mean, value = pol.forward(obs)
+        d_mean, d_value = th.empty((B, 4), device=self.device), th.empty(B, device=self.device)
+        cfg = _lib.PpoLossCfg(self.clip_range, self.ent_coef, self.vf_coef, 1.0 / gB)
+        _lib.check(L.vf_ppo_loss(_ptr(mean), _ptr(value), _ptr(pol.log_std), _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret),
+                                 _ptr(d_mean), _ptr(d_value), _ptr(self._stats), B, C.byref(cfg), _ptr(self._scratch), st))
+        pol.backward(d_mean, d_value, self._stats[5:9])
+        if self.world > 1:
+            th.distributed.all_reduce(pol.grad)      # sum over ranks: every term is already / global batch
+        self._opt_step += 1
+        _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
+        acfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, self.weight_decay,
+                            self.max_grad_norm if self.max_grad_norm is not None else 0.0, self._opt_step, 0)
+        _lib.check(L.vf_adam_step(_ptr(pol.flat), _ptr(pol.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params,
+                                  _ptr(self._sumsq), C.byref(acfg), st))
+        return self._stats
+
+    def train(self):
+        """PPO.train (PPO.py:177-337): n_epochs passes over random minibatches"""
+        total = self.n_steps * self.n_envs
+        bs = min(self.batch_size, total)
+        g = th.Generator(device=self.device)
+        g.manual_seed(self.seed + 7919 * (self._opt_step + 1))
+        stats_acc = th.zeros(16, device=self.device)
+        n_mb = 0
+        for _epoch in range(self.n_epochs):
+            perm = th.randperm(total, device=self.device, generator=g)
+            for s in range(0, total - bs + 1, bs):
+                stats_acc += self._minibatch_update(perm[s:s + bs])
+                n_mb += 1
+        rows = float(bs * n_mb)
+        s = (stats_acc / rows).tolist()
+        self.logs.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/entropy_loss": s[2],
+                          "train/approx_kl": s[3], "train/clip_fraction": s[4], "train/n_updates": self._opt_step})
+
+    def learn(self, total_timesteps: int, log_interval: Optional[int] = None):
+        """PPO.learn (PPO.py:116-175): alternate rollout collection and training"""
+        t0 = time.time()
+        start = self.num_timesteps
+        it = 0
+        while self.num_timesteps - start < total_timesteps:
+            self.collect_rollouts()
+            self.train()
+            it += 1
+            if log_interval and it % log_interval == 0:
+                th.cuda.synchronize(self.device)
+                fps = (self.num_timesteps - start) / max(time.time() - t0, 1e-9)       # PPO._dump_logs :394-395
+                self.logs["time/fps"] = fps
+                print(f"[ppo] it {it} steps {self.num_timesteps} fps {fps:.3e} "
+                      f"pg {self.logs['train/policy_gradient_loss']:.4f} v {self.logs['train/value_loss']:.4f}")
+        th.cuda.synchronize(self.device)
+        self.logs["time/fps"] = (self.num_timesteps - start) / max(time.time() - t0, 1e-9)
+        return self
