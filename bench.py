@@ -55,6 +55,37 @@ def cpu_baseline(consts, seconds_target=15.0):
             "sample": f"oracle/vf_oracle.c (OpenMP, {cores} threads), N={N}, {steps} control steps, {el:.1f} s"}
 
 
+def bench_ppo(args, rank, world, dev):
+    """secondary measurement (not the driver's metric): NavigationEnv + PPO full train loop,
+    agents sharded by rank, one RCCL all-reduce of the flat gradient per optimiser step."""
+    from visfly_amd import parallel
+    from visfly_amd.envs import NavigationEnv
+    from visfly_amd.ppo import PPO
+    N = args.agents if args.agents != AGENTS_PER_GPU else 32768
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+    env = NavigationEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dict(DYN_KW), random_kwargs=spawn,
+                        device=dev, max_episode_steps=256)
+    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=0)
+    ppo.learn(256 * N * world)   # warm-up iteration
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    iters = max(1, args.steps // 256)
+    ppo.learn(256 * N * world * iters)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
+                          "value": 256 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
+                          "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"NavigationEnv {N} agents/GPU, n_steps=256, batch 25600/GPU, 5 epochs",
+                                     "logs": {k: float(v) for k, v in ppo.logs.items()}}}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,19 +93,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--agents", type=int, default=AGENTS_PER_GPU, help="agents per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="env", choices=["env", "ppo"],
+                    help="env: fused HoverEnv.step (the BASELINE metric, default); ppo: full PPO loop (configs[3] shape)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from visfly_amd import parallel
+    rank, world, local = parallel.init("nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    if args.workload == "ppo":
+        return bench_ppo(args, rank, world, dev)
 
     from visfly_amd.envs import HoverEnv
     N = args.agents

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch as th
 
-from . import _lib
+from . import _lib, parallel
 
 
 def _ptr(t, off=0):
@@ -251,6 +251,9 @@ class PPO:
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
         self.lr, self.weight_decay, self.adam_eps, self.betas = learning_rate, weight_decay, adam_eps, betas
         self.normalize_advantage, self.target_kl, self.seed = normalize_advantage, target_kl, seed
+        self._last_obs = None
+        if not getattr(env, "_is_initial", False):
+            self._last_obs = env.reset()
         obs = env.get_observation()
         self.obs_keys = [k for k in obs.keys() if k in ("state", "target")]
         obs_dims = {k: obs[k].shape[1] for k in self.obs_keys}
@@ -269,10 +272,9 @@ class PPO:
         self._opt_step = 0
         self._sample_step = 0
         self.num_timesteps = 0
-        self._last_obs = None
         self._last_starts = th.ones(self.n_envs, device=dev)
         # bounded list of truncated-episode terminal observations per rollout (timeout bootstrap)
-        self.world = th.distributed.get_world_size() if th.distributed.is_available() and th.distributed.is_initialized() else 1
+        self.world = parallel.world_size()
         self.logs: Dict[str, float] = {}
 
     def _stream(self):
@@ -343,7 +345,7 @@ class PPO:
             advn = th.empty_like(adv)
             if self.world > 1:
                 _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, self._sums.data_ptr(), _ptr(self._scratch), 0, st))
-                th.distributed.all_reduce(self._sums)
+                parallel.allreduce_sum_(self._sums)
                 _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, self._sums.data_ptr(), _ptr(self._scratch), 1, st))
             else:
                 _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, None, _ptr(self._scratch), 2, st))
@@ -355,7 +357,7 @@ class PPO:
                                  _ptr(d_mean), _ptr(d_value), _ptr(self._stats), B, C.byref(cfg), _ptr(self._scratch), st))
         pol.backward(d_mean, d_value, self._stats[5:9])
         if self.world > 1:
-            th.distributed.all_reduce(pol.grad)      # sum over ranks: every term is already / global batch
+            parallel.allreduce_sum_(pol.grad)      # sum over ranks: every term is already / global batch
         self._opt_step += 1
         _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
         acfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, self.weight_decay,
