@@ -240,13 +240,22 @@ class OracleEnv:
         lib().vfo_update_collision(C.byref(self.e), self.N, _fp(self.dyn.S), C.byref(self.es), _ip(idx),
                                    0 if idx is None else len(idx))
 
+    def choose_gate(self, idx):
+        """RacingEnv._choose_target (envs/RacingEnv.py:172-185)"""
+        for i in idx:
+            rx = self.dyn.S[POS, i] - np.float32(4.0)
+            ry = self.dyn.S[POS + 1, i] - np.float32(0.0)
+            self.a["next_gate"][i] = (0 if ry > 0 else 3) if rx < 0 else (1 if rx > 0 else 2)
+
     def reset_full_state(self, fs):
-        """env.reset() with the spawn states given (droneGymEnv.py:302-327)"""
+        """env.reset() with the spawn states given (droneGymEnv.py:302-327; RacingEnv.py:165-170)"""
         self.dyn.set_full_state(fs)
         self.a["once_collided"][:] = 0
         self.update_collision()
         for k in ("reward", "rewards", "done", "episode_done", "step_count"):
             self.a[k][:] = 0
+        if self.e.kind == self.KINDS["racing"]:
+            self.choose_gate(range(self.N))
 
     def step(self, action):
         """-> (obs_pre_reset (N,13), reward, done) ; no auto reset here"""
@@ -259,8 +268,15 @@ class OracleEnv:
         """reset_agent_by_id with given full states (droneGymEnv.py:339-349, droneEnv.py:260-288)"""
         idx = np.ascontiguousarray(idx, np.int32)
         fs = np.asarray(fs, np.float32)
+        if self.e.kind == self.KINDS["racing"]:
+            # RacingEnv.reset_agent_by_id (RacingEnv.py:150-163) picks the gate BEFORE the base class
+            # re-spawns the agent, i.e. from the terminal position of the finished episode
+            self.choose_gate(idx)
+            self.a["past_gates"][idx] = 0
+            self.a["is_pass_next"][idx] = 0
         self.dyn.reset(pos=fs[:, 0:3], quat=fs[:, 3:7], vel=fs[:, 7:10], omg=fs[:, 10:13], mot=fs[:, 13:17],
                        thr=fs[:, 17:21], t=fs[:, 21], idx=idx)
         self.update_collision(idx)
         self.a["once_collided"][idx] = 0
         lib().vfo_env_reset_attr(self.N, C.byref(self.es), _ip(idx), len(idx))
+

@@ -314,10 +314,24 @@ def import_envs():
         def get_reward(self, predicted_obs=None):
             return super().get_reward()
 
-    return HoverEnvShim, NavigationEnv, RacingEnv
+    class RacingEnvShim(RacingEnv):  # defect C-4: signatures predate the base class, self.latent undefined
+        def get_observation(self, indices=None, predicted_obs=None):
+            from VisFly.utils.type import TensorDict
+            return TensorDict({"state": self.state, "gate": self._next_target_i})
+
+        def get_reward(self, predicted_obs=None):
+            return super().get_reward()
+
+        def reset(self, state=None, obs=None, **kw):
+            return super().reset(state)
+
+    return HoverEnvShim, NavigationEnv, RacingEnvShim
 
 
 ENV_DYN = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+RACING_DYN = dict(action_type="thrust", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+# gates moved next to the spawn boxes so that random flight passes them (the pass / advance / +20 logic)
+RACING_TEST_GATES = [[2.1, 0.1, 1.0], [6., 2., 1.45], [6.1, -2., 1.5], [2., 2.1, 1.05]]
 
 ENV_CASES = {
     # name: (env, ctor kwargs, hover, scale, steps)
@@ -325,6 +339,7 @@ ENV_CASES = {
     "env_hover_256": ("hover", dict(max_episode_steps=256), [-1 / 3, 0, 0, 0], 0.3, 256),
     "env_nav": ("nav", dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [
         {"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}), [-0.2, 0, 0, 0], 0.6, 200),
+    "env_racing": ("racing", dict(max_episode_steps=48), [-0.8333] * 4, 0.08, 160),
     "env_nav_close": ("nav", dict(max_episode_steps=96, target=[2.5, 0., 1.5], random_kwargs={"state_generator": {
         "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
                                         "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
@@ -337,21 +352,25 @@ def gen_env(name, N=128, seed=42):
     HoverEnvShim, NavigationEnv, RacingEnv = import_envs()
     kind, kw, hover, scale, steps = ENV_CASES[name]
     use_cr_sqrt(True)
-    cls = {"hover": HoverEnvShim, "nav": NavigationEnv}[kind]
+    cls = {"hover": HoverEnvShim, "nav": NavigationEnv, "racing": RacingEnv}[kind]
     kw = dict(kw)
     if "target" in kw:
         kw["target"] = th.tensor(kw["target"])
-    env = cls(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False, dynamics_kwargs=dict(ENV_DYN),
+    env = cls(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False,
+              dynamics_kwargs=dict(RACING_DYN if kind == "racing" else ENV_DYN),
               device="cpu", **({"tensor_output": True} if kind == "hover" else {}), **kw)
     env.tensor_output = True
+    if kind == "racing":
+        env.targets = th.as_tensor(RACING_TEST_GATES)
     consts = extract_consts(env.envs.dynamics)
     rng = np.random.default_rng(seed + 1)
     q = rng.integers(-127, 128, size=(steps, N, 4), dtype=np.int8)
     actions = decode_actions(q, hover, scale)
     obs0 = env.reset()
+    env_gate0 = env._next_target_i.clone().numpy().astype(np.int32) if kind == "racing" else None
     dyn = env.envs.dynamics
     rec = dict(reward=[], done=[], step_count=[], is_collision=[], is_out_bounds=[], success=[],
-               col_dis=[], obs_state=[], ext_pre=[])
+               col_dis=[], obs_state=[], ext_pre=[], gate=[], past=[])
     ev_step, ev_agent, ev_fs = [], [], []
     fs_init = f32(dyn.full_state)
 
@@ -389,13 +408,16 @@ def gen_env(name, N=128, seed=42):
             rec["is_out_bounds"].append(env.is_out_bounds.clone().numpy().astype(np.uint8))
         rec["success"].append(env._success.clone().numpy().astype(np.uint8))
         rec["obs_state"].append(f32(o["state"]))
+        if kind == "racing":   # post-auto-reset values, as returned in the observation
+            rec["gate"].append(env._next_target_i.clone().numpy().astype(np.int32))
+            rec["past"].append(env._past_targets_num.clone().numpy().astype(np.int32))
     print(f"{name}: N={N} steps={steps} resets={len(ev_step)} "
           f"(collisions {int(np.sum(rec['is_collision']))}, success {int(np.sum(rec['success']))})")
     # keep the fixture small: full pre-reset state only at sparse steps
     keep = sorted(set([0, 1, 2, 3, 7, 15, 31, 63, 64, 65, 127, 128, steps - 1]) & set(range(steps)))
     save = {
         "kind": np.asarray(kind), "max_episode_steps": np.int32(kw["max_episode_steps"]),
-        "target": f32(env.target[0]), "seed": np.int32(seed),
+        "target": f32(env.target[0]) if kind != "racing" else np.zeros(3, np.float32), "seed": np.int32(seed),
         "actions_q": q, "hover": np.asarray(hover, np.float32), "scale": np.float32(scale),
         "fs_init": fs_init, "obs0_state": f32(obs0["state"]),
         "reward": np.stack(rec["reward"]), "done": np.stack(rec["done"]),
@@ -408,8 +430,12 @@ def gen_env(name, N=128, seed=42):
         "ev_step": np.asarray(ev_step, np.int32), "ev_agent": np.asarray(ev_agent, np.int32),
         "ev_fs": np.stack(ev_fs) if ev_fs else np.zeros((0, 22), np.float32),
         "spawn": np.asarray(repr(kw.get("random_kwargs", "hover-default"))),
-        "label": np.asarray("cr-sqrt-oracle"),
+        "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle"),
     }
+    if kind == "racing":
+        save.update(gates=np.asarray(RACING_TEST_GATES, np.float32), gate=np.stack(rec["gate"]), past=np.stack(rec["past"]),
+                    gate0=env_gate0)
+        print("   gate passes:", int(np.sum(np.diff(np.stack(rec["past"]), axis=0) > 0)))
     save.update({"c_" + k: v for k, v in consts.items()})
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 

@@ -313,14 +313,17 @@ void vfo_dyn_reset(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick
 
 /* ---------- env layer ---------- */
 
-/* x.norm(dim=1) for 3 / 4 columns as torch's reduce kernel rounds it (App. B.4) */
+/* x.norm(dim=1) for 3 / 4 columns as torch's reduce kernel rounds it for the transposed (stride (1,N))
+ * views the reference passes (App. B.4; probed again for 4 columns when pinning RacingEnv) */
 static inline float norm3(float x, float y, float z)
 {
     return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
 }
 static inline float norm4(float a, float b, float c_, float d)
 {
-    return sqrtf(((a * a + b * b) + c_ * c_) + d * d);
+    /* (N,4) view with strides (1,N) (orientation = toTensor().T): torch's column-strided reduce
+     * accumulates with FMAs, like the 3-column case; a contiguous (N,4) would round separately. */
+    return sqrtf(fmaf(d, d, fmaf(c_, c_, fmaf(b, b, a * a))));
 }
 /* (a*b).sum(dim=1) over 3 columns: separately rounded products, fp32 adds in order */
 static inline float dot3_sum(const float* a, const float* b)

@@ -39,7 +39,9 @@ def assert_bits_equal(a, b, what=""):
 
 # constructor kwargs of the env fixtures (same as oracle/gen_golden.py::ENV_CASES)
 ENV_DYN = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+RACING_DYN = dict(action_type="thrust", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
 ENV_KW = {
+    "env_racing": dict(max_episode_steps=48),
     "env_hover": dict(max_episode_steps=64),
     "env_hover_256": dict(max_episode_steps=256),
     "env_nav": dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [

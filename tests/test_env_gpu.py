@@ -8,18 +8,21 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import ENV_DYN, ENV_KW, assert_bits_equal, consts_of, decode_actions, load
+from _golden import ENV_DYN, ENV_KW, RACING_DYN, assert_bits_equal, consts_of, decode_actions, load
 from test_oracle_env_golden import ENVS, run_env_fixture
 
 pytestmark = pytest.mark.gpu
 
 
 def make(name, fx, **kw):
-    from visfly_amd.envs import HoverEnv, NavigationEnv
-    cls = {"hover": HoverEnv, "nav": NavigationEnv}[str(fx["kind"])]
+    from visfly_amd.envs import HoverEnv, NavigationEnv, RacingEnv
+    kind = str(fx["kind"])
+    cls = {"hover": HoverEnv, "nav": NavigationEnv, "racing": RacingEnv}[kind]
+    if kind == "racing":
+        kw["gates"] = fx["gates"].tolist()
     return cls(num_agent_per_scene=fx["fs_init"].shape[0], num_scene=1, seed=int(fx["seed"]), visual=False,
-               dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True, constants=consts_of(fx),
-               **ENV_KW[name], **kw)
+               dynamics_kwargs=dict(RACING_DYN if kind == "racing" else ENV_DYN), device="cuda:0", tensor_output=True,
+               constants=consts_of(fx), **ENV_KW[name], **kw)
 
 
 @pytest.mark.parametrize("name", ENVS)
@@ -39,7 +42,9 @@ def test_env_trace_scripted_resets(name):
     def reset_fn(env, idx, fs):
         env.reset_agent_by_id(torch.from_numpy(idx.astype(np.int64)), state=torch.from_numpy(fs))
 
-    run_env_fixture(name, make_env, step_fn, reset_fn, lambda env: env.state.cpu().numpy())
+    run_env_fixture(name, make_env, step_fn, reset_fn, lambda env: env.state.cpu().numpy(),
+                    lambda env: (env._next_target_i.cpu().numpy(), env._past_targets_num.cpu().numpy())
+                    if str(load(name)["kind"]) == "racing" else None)
 
 
 @pytest.mark.parametrize("name", ENVS)
@@ -70,6 +75,8 @@ def test_env_replay_mode_matches_reference_run(name):
             assert info[i0]["TimeLimit.truncated"] == bool(fx["step_count"][k][i0] >= int(fx["max_episode_steps"]))
         if k in keep:
             assert_bits_equal(obs["state"].cpu().numpy(), fx["obs_state_keep"][keep.index(k)], f"{name} obs @ {k}")
+        if str(fx["kind"]) == "racing":
+            assert np.array_equal(obs["gate"].cpu().numpy(), fx["gate"][k]), f"{name} gate obs @ {k}"
 
 
 def test_device_spawn_statistics_and_conventions():

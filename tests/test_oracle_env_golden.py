@@ -7,10 +7,10 @@ import pytest
 import oracle
 from _golden import assert_bits_equal, consts_of, decode_actions, load
 
-ENVS = ["env_hover", "env_hover_256", "env_nav", "env_nav_close"]
+ENVS = ["env_hover", "env_hover_256", "env_nav", "env_nav_close", "env_racing"]
 
 
-def run_env_fixture(name, make_env, step_fn, reset_fn, state_fn):
+def run_env_fixture(name, make_env, step_fn, reset_fn, state_fn, gates_fn=None):
     """drives any env implementation through the fixture; shared with the GPU parity test"""
     fx = load(name)
     acts = decode_actions(fx)
@@ -43,14 +43,22 @@ def run_env_fixture(name, make_env, step_fn, reset_fn, state_fn):
             reset_fn(env, fx["ev_agent"][sel], fx["ev_fs"][sel])
         if k in keep:
             assert_bits_equal(state_fn(env), fx["obs_state_keep"][keep.index(k)], f"{name} obs(post-reset) @ {k}")
+        if str(fx["kind"]) == "racing":   # gate bookkeeping after the auto-reset, as observed
+            g, p = gates_fn(env)
+            assert np.array_equal(g, fx["gate"][k]), f"{name} next gate @ {k}"
+            assert np.array_equal(p, fx["past"][k]), f"{name} passed gates @ {k}"
 
 
 @pytest.mark.parametrize("name", ENVS)
 def test_oracle_env_trace(name):
     def make_env(fx):
+        racing = str(fx["kind"]) == "racing"
         env = oracle.OracleEnv(consts_of(fx), fx["fs_init"].shape[0], str(fx["kind"]),
-                               int(fx["max_episode_steps"]), target=fx["target"])
+                               int(fx["max_episode_steps"]), target=fx["target"],
+                               success_radius=0.3 if racing else 0.5, gates=fx["gates"] if racing else None)
         env.reset_full_state(fx["fs_init"])
+        if racing:
+            assert np.array_equal(env.a["next_gate"], fx["gate0"])
         return env
 
     def step_fn(env, a):
@@ -62,4 +70,5 @@ def test_oracle_env_trace(name):
     def state_fn(env):
         return env.dyn.extend_state[:, :13]
 
-    run_env_fixture(name, make_env, step_fn, lambda env, idx, fs: env.reset_agents(idx, fs), state_fn)
+    run_env_fixture(name, make_env, step_fn, lambda env, idx, fs: env.reset_agents(idx, fs), state_fn,
+                    lambda env: (env.a["next_gate"], env.a["past_gates"]))

@@ -130,6 +130,13 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const v
     }
     if (done && g.auto_reset) {  // examine() -> reset_agent_by_id (:339-349,420-423)
         unsigned episode = ((unsigned)er.flags >> 8) + 1u;
+        if constexpr (KIND == VF_ENV_RACING) {
+            // RacingEnv.reset_agent_by_id (RacingEnv.py:150-163) picks the next gate BEFORE the base class
+            // re-spawns the agent: the choice is made from the terminal position of the finished episode
+            gate = racing_choose_gate(s.p);
+            passed = 0;
+            race.z = __int_as_float(0);
+        }
         spawn_agent(e, i, episode, true, s);
         reset_rotors(c, s);
         for (int q = 0; q < c.delay_steps; ++q)
@@ -140,11 +147,6 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const v
         er.flags = set_flag(er.flags, VF_F_OUT_BOUNDS, col.oob);
         er.step_count = 0;                                                                  // :387-392
         er.rewards = 0.0f;
-        if constexpr (KIND == VF_ENV_RACING) {
-            gate = racing_choose_gate(s.p);
-            passed = 0;
-            race.z = __int_as_float(0);
-        }
         obs_row(c, s, o);
     }
     if constexpr (KIND == VF_ENV_RACING) {
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_env_reset(const vf_dyn_cfg c, const 
     EnvRegs er = unpack_env(sp);
     unsigned episode = ((unsigned)er.flags >> 8) + 1u;
     if (!r.idx) { sp.vel = __int_as_float(0); }  // ring head
+    const int gate_before = racing_choose_gate(s.p);  // indexed racing resets choose from the OLD position
     reset_rotors(c, s);
     if (r.fs && !pad) {
         const float* f = r.fs + 22 * (size_t)j;
@@ -205,8 +208,9 @@ __global__ __launch_bounds__(kBlock) void k_env_reset(const vf_dyn_cfg c, const 
     }
     if constexpr (KIND == VF_ENV_RACING) {
         float4 race = *granule(r.d.S, r.d.G, i, r.g_race);
-        race.x = __int_as_float(racing_choose_gate(s.p));
-        if (r.idx) race.y = __int_as_float(0);  // RacingEnv.reset keeps _past_targets_num (RacingEnv.py:165-170)
+        // full reset: _choose_target() runs after the spawn (RacingEnv.py:165-170); indexed: before (:150-163)
+        race.x = __int_as_float(r.idx ? gate_before : racing_choose_gate(s.p));
+        if (r.idx) race.y = __int_as_float(0);  // RacingEnv.reset keeps _past_targets_num
         race.z = __int_as_float(0);
         *granule(r.d.S, r.d.G, i, r.g_race) = race;
     }

@@ -2,8 +2,8 @@
 // task success / reward, counters and done masks, on-device spawning.
 //
 // Rounding follows the reference's torch ops: elementwise ops rounded
-// separately, x.norm(dim=1) over 3 columns = sqrt(fma(z,z,fma(y,y,x*x))), over 4 columns
-// separately rounded squares, (a*b).sum(dim=1) = (a0*b0 + a1*b1) + a2*b2, python scalars cast
+// separately, x.norm(dim=1) over the reference's transposed (N,3)/(N,4) views = an FMA chain
+// sqrt(fma(z,z,fma(y,y,x*x))) (4 columns: one more fma), (a*b).sum(dim=1) = (a0*b0 + a1*b1) + a2*b2, python scalars cast
 // to fp32 at the op, `scalar / tensor` = reciprocal(tensor) * scalar.
 #pragma once
 #include "vf_dyn_device.hpp"
@@ -18,7 +18,7 @@ __device__ __forceinline__ float norm3(float x, float y, float z)
 }
 __device__ __forceinline__ float norm4(float a, float b, float c, float d)
 {
-    return sqrtf(((a * a + b * b) + c * c) + d * d);
+    return sqrtf(__builtin_fmaf(d, d, __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a))));
 }
 __device__ __forceinline__ float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 

@@ -74,13 +74,13 @@ class RacingEnv(DroneGymEnvsBase):
     def __init__(self, num_agent_per_scene: int = 1, num_scene: int = 1, seed: int = 42, visual: bool = False,
                  requires_grad: bool = False, random_kwargs: Optional[dict] = None, dynamics_kwargs: Optional[dict] = None,
                  scene_kwargs: Optional[dict] = None, sensor_kwargs: Optional[list] = None, device="cuda",
-                 target=None, max_episode_steps: int = 256, tensor_output: bool = True, latent_dim=None, **kw):
+                 target=None, max_episode_steps: int = 256, tensor_output: bool = True, latent_dim=None, gates=None, **kw):
         # the reference ignores a caller's random_kwargs and always uses the 4-box union (RacingEnv.py:32-70)
         super().__init__(num_agent_per_scene=num_agent_per_scene, num_scene=num_scene, seed=seed, visual=visual,
                          requires_grad=requires_grad, random_kwargs=_RACING_SPAWN, dynamics_kwargs=dynamics_kwargs,
                          scene_kwargs=scene_kwargs, sensor_kwargs=sensor_kwargs, device=device,
                          max_episode_steps=max_episode_steps, tensor_output=tensor_output,
-                         success_radius=0.3, gates=_RACING_GATES, **kw)
+                         success_radius=0.3, gates=_RACING_GATES if gates is None else gates, **kw)
         self._next_target_num = 2
         self.success_r = 20
         self.observation_space["gate"] = spaces.Box(low=0, high=len(_RACING_GATES), shape=(1,), dtype=np.int32)
@@ -89,17 +89,17 @@ class RacingEnv(DroneGymEnvsBase):
             shape=(3 * (self._next_target_num - 1) + self.observation_space["state"].shape[0],), dtype=np.float32)
 
     def _static_obs(self, i=None):
-        g = self._gate if self._qcache is None else self._query()["gate"]
-        return {"gate": g if i is None else g[i]}
+        return {"gate": self._gate if i is None else self._gate[i]}
+
+    def _reset_kernel(self, idx, fs):
+        super()._reset_kernel(idx, fs)
+        self._gate.copy_(self._query()["gate"])     # in place: the step kernel holds this buffer's address
 
     def _extra_info(self):
         return {"past_gate": self._query()["past_gates"]}
 
     def reset(self, state=None, obs=None, **kw):
-        out = super().reset(state)
-        self._gate = self._query()["gate"].clone()
-        self._observations = self._full_obs(self._observations["state"])
-        return self._format_obs(self._observations)
+        return super().reset(state)
 
     _next_target_i = property(lambda s: s._query()["gate"])
     _past_targets_num = property(lambda s: s._query()["past_gates"])
