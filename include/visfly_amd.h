@@ -172,7 +172,8 @@ typedef struct vf_env_cfg {
     float target[3];              /* Hover / Navigation target                           */
     float gates[VF_MAX_GATES][3];
     int32_t n_spawn;              /* 1 = Uniform, >1 = Union of Uniform boxes (randomization.py:250-296) */
-    int32_t pad0;
+    float drag_random;            /* >0: per-agent drag factors 1 + clamp((U-.5)*2*r, -.5, .5) drawn at every
+                                     (re)spawn (dynamics.py:244-246; needs per_agent_drag at create)   */
     vf_spawn_box spawn[VF_MAX_SPAWN];
     uint64_t seed;                /* Philox key of the on-device spawner                 */
 } vf_env_cfg;

@@ -126,3 +126,43 @@ def test_numpy_output_convention():
     assert isinstance(r, np.ndarray) and r.dtype == np.float32 and d.dtype == np.int32   # droneGymEnv.py:218
     with pytest.raises(AssertionError):
         HoverEnv(num_agent_per_scene=4, dynamics_kwargs=dict(ENV_DYN), device="cuda:0").step(np.zeros((4, 4)))
+
+
+def test_config3_navigation_rk4_ctrl_delay_drag_randomisation():
+    """BASELINE configs[2]: NavigationEnv, RK4 + ctrl_delay + drag domain randomisation.  The RK4 path is
+    the documented repair; per-agent drag coefficients drawn on the device are fed to
+    the CPU oracle, after which dynamics AND env outputs must agree bit-for-bit (reward to acos tolerance)."""
+    import oracle
+    from visfly_amd.envs import NavigationEnv
+    N = 1000
+    dkw = dict(action_type="bodyrate", integrator="rk4", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True, drag_random=0.1)
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+    env = NavigationEnv(num_agent_per_scene=N, seed=9, dynamics_kwargs=dkw, random_kwargs=spawn, device="cuda:0",
+                        max_episode_steps=40, tensor_output=True)
+    obs = env.reset()
+    dyn = env.envs.dynamics
+    kl, kq = dyn.drag_coefficients
+    c = dyn.constants
+    for k, mean in ((kl, c["k_lin"]), (kq, c["k_quad"])):
+        f = (k / torch.tensor(mean, device="cuda")).cpu()
+        assert (f >= 0.9 - 1e-6).all() and (f <= 1.1 + 1e-6).all() and f.std(dim=0).min() > 0.02
+    ref = oracle.OracleEnv(c, N, "nav", 40, target=[9., 0., 1.])
+    ref.dyn.klin = np.ascontiguousarray(kl.cpu().numpy().T)
+    ref.dyn.kquad = np.ascontiguousarray(kq.cpu().numpy().T)
+    ref.reset_full_state(env.full_state.cpu().numpy())
+    g = torch.Generator().manual_seed(0)
+    for k in range(30):   # < max_episode_steps: no timeouts; collisions may end episodes -> is_test keeps both in step
+        a = ((torch.rand((N, 4), generator=g) * 2 - 1) * 0.5 + torch.tensor([-0.3, 0, 0, 0])).clamp(-1, 1)
+        o, r, d, _ = env.step(a.cuda(), is_test=True)
+        ro, rr, rd = ref.step(a.numpy())
+        assert_bits_equal(o["state"].cpu().numpy(), ro, f"rk4+drag state @ {k}")
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), rd)
+        assert (np.abs(r.cpu().numpy() - rr) <= 5e-8 + 1.2e-7 * np.abs(rr)).all()
+    # auto-reset redraws the drag factors of the re-spawned agents
+    env2 = NavigationEnv(num_agent_per_scene=256, seed=9, dynamics_kwargs=dkw, random_kwargs=spawn, device="cuda:0",
+                         max_episode_steps=5, tensor_output=True)
+    env2.reset()
+    k0 = env2.envs.dynamics.drag_coefficients[0].clone()
+    for _ in range(5):
+        env2.step(torch.zeros((256, 4), device="cuda"))
+    assert (env2.envs.dynamics.drag_coefficients[0] != k0).any(dim=1).all()

@@ -77,7 +77,7 @@ class EnvCfg(C.Structure):
         ("bbox_lo", C.c_float * 3), ("bbox_hi", C.c_float * 3),
         ("uav_radius", C.c_float), ("success_radius", C.c_float),
         ("target", C.c_float * 3), ("gates", (C.c_float * 3) * MAX_GATES),
-        ("n_spawn", C.c_int32), ("pad0", C.c_int32),
+        ("n_spawn", C.c_int32), ("drag_random", C.c_float),
         ("spawn", SpawnBox * MAX_SPAWN),
         ("seed", C.c_uint64),
     ]

@@ -141,6 +141,12 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const v
         reset_rotors(c, s);
         for (int q = 0; q < c.delay_steps; ++q)
             *granule(g.d.S, g.d.G, i, VF_G_RING + q) = make_float4(0.f, 0.f, 0.f, 0.f);     // dynamics.py:262-263
+        if (g.d.g_drag >= 0 && e.drag_random > 0.0f) {
+            float4 kl4, kq4;
+            spawn_drag(c, e, i, episode, kl4, kq4);
+            *granule(g.d.S, g.d.G, i, g.d.g_drag) = kl4;
+            *granule(g.d.S, g.d.G, i, g.d.g_drag + 1) = kq4;
+        }
         col = bbox_collision(e, s.p);                                                       // droneEnv.py:285-288
         er.flags = (int)(episode << 8);
         er.flags = set_flag(er.flags, VF_F_COLLISION, col.hit);
@@ -202,9 +208,16 @@ __global__ __launch_bounds__(kBlock) void k_env_reset(const vf_dyn_cfg c, const 
     er.rewards = 0.0f;
     pack_env(er, sp);
     store_agent(r.d.S, r.d.G, i, s, sp);
-    if (r.d.g_drag >= 0 && !r.idx) {  // shared mean coefficients until a drag randomisation overwrites them
-        *granule(r.d.S, r.d.G, i, r.d.g_drag) = make_float4(0.f, c.k_lin[0], c.k_lin[1], c.k_lin[2]);
-        *granule(r.d.S, r.d.G, i, r.d.g_drag + 1) = make_float4(0.f, c.k_quad[0], c.k_quad[1], c.k_quad[2]);
+    if (r.d.g_drag >= 0) {
+        if (e.drag_random > 0.0f && !(r.fs && !pad)) {  // device spawn: per-agent drag factors
+            float4 kl4, kq4;
+            spawn_drag(c, e, i, episode, kl4, kq4);
+            *granule(r.d.S, r.d.G, i, r.d.g_drag) = kl4;
+            *granule(r.d.S, r.d.G, i, r.d.g_drag + 1) = kq4;
+        } else if (!r.idx) {  // mean coefficients; a host-side (replay) randomisation overwrites them
+            *granule(r.d.S, r.d.G, i, r.d.g_drag) = make_float4(0.f, c.k_lin[0], c.k_lin[1], c.k_lin[2]);
+            *granule(r.d.S, r.d.G, i, r.d.g_drag + 1) = make_float4(0.f, c.k_quad[0], c.k_quad[1], c.k_quad[2]);
+        }
     }
     if constexpr (KIND == VF_ENV_RACING) {
         float4 race = *granule(r.d.S, r.d.G, i, r.g_race);

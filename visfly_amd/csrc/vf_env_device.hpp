@@ -154,6 +154,26 @@ __device__ __forceinline__ void spawn_agent(const vf_env_cfg& e, int agent, unsi
     s.t = indexed ? 0.0f + u01(r3.y) * 3.14f * 2.0f : 0.0f;                              // dynamics.py:236,256
 }
 
+// Drag domain randomisation (dynamics.py:244-246): k = k_mean * (clamp((U - .5) * 2 r, -.5, .5) + 1),
+// one factor per axis and per coefficient set, drawn per agent at every (re)spawn.
+__device__ __forceinline__ void spawn_drag(const vf_dyn_cfg& c, const vf_env_cfg& e, int agent, unsigned episode,
+                                           float4& kl, float4& kq)
+{
+    const unsigned k0 = (unsigned)e.seed, k1 = (unsigned)(e.seed >> 32);
+    const U4 a = philox4x32_10(U4{(unsigned)agent, episode, 4u, 0x5eedu}, k0, k1);
+    const U4 b = philox4x32_10(U4{(unsigned)agent, episode, 5u, 0x5eedu}, k0, k1);
+    const float r2 = 2.0f * e.drag_random;
+    const float ul[3] = {u01(a.x), u01(a.y), u01(a.z)}, uq[3] = {u01(b.x), u01(b.y), u01(b.z)};
+    float fl[3], fq[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        fl[d] = c.k_lin[d] * (clampf((ul[d] - 0.5f) * r2, -0.5f, 0.5f) + 1.0f);
+        fq[d] = c.k_quad[d] * (clampf((uq[d] - 0.5f) * r2, -0.5f, 0.5f) + 1.0f);
+    }
+    kl = make_float4(0.f, fl[0], fl[1], fl[2]);
+    kq = make_float4(0.f, fq[0], fq[1], fq[2]);
+}
+
 // Dynamics.reset defaults for everything the spawner does not draw (dynamics.py:229-263)
 __device__ __forceinline__ void reset_rotors(const vf_dyn_cfg& c, Agent& s)
 {

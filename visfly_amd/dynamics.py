@@ -253,6 +253,14 @@ class Dynamics:
         return self._gran(G_THR)
 
     @property
+    def drag_coefficients(self):
+        """per-agent (N,3) linear and quadratic drag coefficients, or None when they are shared constants"""
+        if not self._drag_random:
+            return None
+        g = _lib.G_RING + self._comm_delay_steps
+        return self._vec(g), self._vec(g + 1)
+
+    @property
     def delay_ring(self):
         """(D, N, 4) delayed actions in slot order (slot = ring head at the time of the push)"""
         D = self._comm_delay_steps

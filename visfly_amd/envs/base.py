@@ -192,6 +192,8 @@ class DroneGymEnvsBase:
         if len(self._boxes) > _lib.MAX_SPAWN:
             raise ValueError(f"at most {_lib.MAX_SPAWN} spawn boxes")
         e.n_spawn = len(self._boxes)
+        e.drag_random = float(drag_random or 0.0)
+        self._drag_random = float(drag_random or 0.0)
         for bi, b in enumerate(self._boxes):
             sb = e.spawn[bi]
             for name, f in (("pos", "position"), ("ori", "orientation"), ("vel", "velocity"), ("omg", "angular_velocity")):
@@ -320,6 +322,14 @@ class DroneGymEnvsBase:
                 self._consume_imu_noise()
         elif self.spawn_mode == "replay":
             self._reset_kernel(None, self._replay_states(self.num_agent, indexed=False))
+            if self._drag_random:   # Dynamics.reset draws ONE (3,1) factor pair for all agents (dynamics.py:244-246)
+                dyn, r = self.envs.dynamics, self._drag_random
+                fl = ((th.rand((3, 1), generator=dyn.rng) - 0.5) * 2 * r).clamp(-0.5, .5) + 1
+                fq = ((th.rand((3, 1), generator=dyn.rng) - 0.5) * 2 * r).clamp(-0.5, .5) + 1
+                kl, kq = dyn._drag_rows(fl.reshape(1, 3), fq.reshape(1, 3), 1)
+                gd = dyn._G - 2 - (1 if self.KIND == RACING else 0)
+                self._slab[:, gd, :, 1:4] = kl.to(self.device)
+                self._slab[:, gd + 1, :, 1:4] = kq.to(self.device)
             self._consume_imu_noise()
         else:
             self._reset_kernel(None, None)
