@@ -225,6 +225,26 @@ int vf_env_query(vf_env* h, const vf_env_view* view, vf_stream_t stream);
 int vf_env_time_steps(vf_env* h, const float* action, const vf_env_out* out, int32_t auto_reset, int32_t iters,
                       vf_stream_t stream, float* mean_us);
 
+/* Adjoint of one env step for first-order (BPTT) policy optimisation: replaces the torch autograd
+ * tape over Dynamics.step + reward that `requires_grad=True` builds in the reference
+ * (utils/algorithms/BPTT.py:107-134; envs/base/droneGymEnv.py:209-213; envs/base/dynamics.py:176-190).
+ * The caller checkpoints the slab before each forward step (tape) and walks the steps in reverse:
+ *   tape_slab    slab copy taken BEFORE the forward step (vf_env_slab_floats() floats)
+ *   action       (N,4) action that was passed to that step
+ *   d_obs        (N,13) dLoss/d(state observation returned by that step) or NULL
+ *   d_reward     (N,)   dLoss/d(reward returned by that step) or NULL
+ *   done         (N,)   done flags that step returned (reset agents stop the gradient, like the
+ *                       in-place reset writes of the reference)
+ *   adj_slab     in/out adjoint of the persistent state, same layout as the slab: on entry the
+ *                adjoint w.r.t. the state AFTER the step, on exit w.r.t. the state BEFORE it
+ *   d_action     (N,4) out: dLoss/d(action)
+ * Euler integrator, thrust / bodyrate actions, Hover and Racing rewards (hover-style terms). */
+typedef struct vf_env_bwd_args {
+    const float* tape_slab; const float* action; const float* d_obs; const float* d_reward;
+    const uint8_t* done; float* adj_slab; float* d_action;
+} vf_env_bwd_args;
+int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* args, vf_stream_t stream);
+
 /* =====================================================================================
  * PPO inner loop on the device (utils/algorithms/PPO.py:177-337; SB3 2.2.1 RolloutBuffer /
  * collect_rollouts, mirrored in utils/algorithms/common.py:97-132; utils/policies/policies.py:195-254;
@@ -262,6 +282,10 @@ int64_t vf_linear_bwd_scratch_floats(int32_t M, int32_t K, int32_t No);
 int vf_linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X,
                          int32_t ldx, float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch,
                          vf_stream_t stream);
+/* same, adding into dW / db (gradient accumulation over the steps of a BPTT horizon) */
+int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X,
+                             int32_t ldx, float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch,
+                             vf_stream_t stream);
 
 /* Squashed diagonal Gaussian head (SB3 SquashedDiagGaussianDistribution as used by
  * policies.py:114,177-181,195-226): a = tanh(mean + exp(log_std) * eps), eps ~ N(0,1) from

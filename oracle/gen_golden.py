@@ -440,6 +440,65 @@ def gen_env(name, N=128, seed=42):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+BPTT_CASES = {
+    # name: (env kind, dynamics kwargs, ctor kwargs, hover action, action noise, horizon)
+    "bptt_hover_bodyrate": ("hover", ENV_DYN, dict(max_episode_steps=1000), [-1 / 3, 0, 0, 0], 0.3, 12),
+    "bptt_hover_thrust": ("hover", RACING_DYN, dict(max_episode_steps=1000), [-0.8333] * 4, 0.05, 12),
+    "bptt_hover_resets": ("hover", ENV_DYN, dict(max_episode_steps=5), [-1 / 3, 0, 0, 0], 0.3, 12),
+    "bptt_hover_nodelay": ("hover", dict(ENV_DYN, ctrl_delay=False, comm_delay=0.0), dict(max_episode_steps=1000),
+                           [-1 / 3, 0, 0, 0], 0.3, 8),
+    "bptt_racing_thrust": ("racing", RACING_DYN, dict(max_episode_steps=1000), [-0.8333] * 4, 0.08, 12),
+}
+
+
+def gen_bptt(name, N=64, seed=42):
+    """dLoss/dAction through H env steps of the reference with requires_grad=True (torch autograd over
+    Dynamics.step + reward; BPTT.py:107-134), loss = sum_t <Wr[t], reward_t> + <Wo[t], obs_t>."""
+    HoverEnvShim, NavigationEnv, RacingEnv = import_envs()
+    kind, dkw, kw, hover, scale, H = BPTT_CASES[name]
+    use_cr_sqrt(True)
+    cls = {"hover": HoverEnvShim, "racing": RacingEnv}[kind]
+    env = cls(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False, dynamics_kwargs=dict(dkw), device="cpu",
+              requires_grad=True, **({"tensor_output": True} if kind == "hover" else {}), **kw)
+    env.tensor_output = True
+    if kind == "racing":
+        env.targets = th.as_tensor(RACING_TEST_GATES)
+    consts = extract_consts(env.envs.dynamics)
+    rng = np.random.default_rng(seed + 5)
+    acts = th.tensor(decode_actions(rng.integers(-127, 128, size=(H, N, 4), dtype=np.int8), hover, scale),
+                     requires_grad=True)
+    Wr = th.tensor(rng.normal(size=(H, N)).astype(np.float32))
+    Wo = th.tensor((rng.normal(size=(H, N, 13)) * 0.1).astype(np.float32))
+    env.reset()
+    dyn = env.envs.dynamics
+    fs_init = f32(dyn.full_state)
+    gate0 = env._next_target_i.clone().numpy().astype(np.int32) if kind == "racing" else None
+    loss = 0
+    dones, rewards, ev_step, ev_agent, ev_fs = [], [], [], [], []
+    for t in range(H):
+        o, r, d, info = env.step(acts[t])
+        loss = loss + (Wr[t] * r).sum() + (Wo[t] * o["state"]).sum()
+        dones.append(d.numpy().astype(np.uint8)); rewards.append(f32(r))
+        didx = np.nonzero(d.numpy())[0]
+        if len(didx):
+            fs = f32(dyn.full_state)
+            for i in didx:
+                ev_step.append(t); ev_agent.append(i); ev_fs.append(fs[i])
+    loss.backward()
+    g = f32(acts.grad)
+    print(f"{name}: N={N} H={H} resets={len(ev_step)} |dL/da| max {np.abs(g).max():.3e} loss {float(loss):.4f}")
+    save = {"kind": np.asarray(kind), "max_episode_steps": np.int32(kw["max_episode_steps"]), "seed": np.int32(seed),
+            "fs_init": fs_init, "actions": f32(acts), "Wr": f32(Wr), "Wo": f32(Wo), "d_actions": g, "loss": np.float64(float(loss)),
+            "done": np.stack(dones), "reward": np.stack(rewards),
+            "ev_step": np.asarray(ev_step, np.int32), "ev_agent": np.asarray(ev_agent, np.int32),
+            "ev_fs": np.stack(ev_fs) if ev_fs else np.zeros((0, 22), np.float32),
+            "dyn_kw": np.asarray(repr(dkw)), "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle")}
+    if kind == "racing":
+        save.update(gates=np.asarray(RACING_TEST_GATES, np.float32), gate0=gate0)
+    save.update({"c_" + k: v for k, v in consts.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -451,6 +510,9 @@ def main():
     for name in ENV_CASES:
         if args.only in (None, name):
             gen_env(name)
+    for name in BPTT_CASES:
+        if args.only in (None, name):
+            gen_bptt(name)
 
 
 if __name__ == "__main__":

@@ -95,6 +95,11 @@ class EnvView(C.Structure):
                                           "gate", "past_gates")]
 
 
+class EnvBwdArgs(C.Structure):
+    """mirror of vf_env_bwd_args (device pointers)"""
+    _fields_ = [(n, C.c_void_p) for n in ("tape_slab", "action", "d_obs", "d_reward", "done", "adj_slab", "d_action")]
+
+
 class PpoLossCfg(C.Structure):
     """mirror of vf_ppo_loss_cfg"""
     _fields_ = [("clip_range", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("inv_batch", C.c_float)]
@@ -135,6 +140,9 @@ SIGNATURES = {
     "vf_env_step": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, _vp]),
     "vf_env_query": (C.c_int, [_vp, C.POINTER(EnvView), _vp]),
     "vf_env_time_steps": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, C.c_int32, _vp, C.POINTER(C.c_float)]),
+    "vf_env_step_bwd": (C.c_int, [_vp, C.POINTER(EnvBwdArgs), _vp]),
+    "vf_linear_bwd_weight_acc": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
+                                           C.c_int32, _vp, _vp]),
     "vf_gae": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int32, C.c_double, C.c_double, _vp]),
     "vf_adv_normalize": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp]),
     "vf_linear_fwd": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),

@@ -12,12 +12,6 @@
 
 #pragma clang fp contract(off)
 
-struct vf_env {
-    vf_dyn dyn;
-    vf_env_cfg cfg;
-    int g_race;  // racing granule or -1
-};
-
 namespace vf {
 
 struct EnvArgs {

@@ -8,6 +8,12 @@ struct vf_dyn {
     float* S = nullptr;
 };
 
+struct vf_env {
+    vf_dyn dyn;
+    vf_env_cfg cfg;
+    int g_race;  // racing granule or -1
+};
+
 namespace vf {
 
 inline int check_dyn_cfg(const vf_dyn_cfg* cfg)

@@ -257,15 +257,15 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
 }
 
 __global__ __launch_bounds__(kBlock) void k_fold_partials(const float* __restrict__ part, int nblk, int nw, int nb,
-                                                          float* __restrict__ dW, float* __restrict__ db)
+                                                          float* __restrict__ dW, float* __restrict__ db, int accumulate)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int n = nw + nb;
     if (i >= n) return;
     float s = 0.0f;
     for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
-    if (i < nw) dW[i] = s;
-    else if (db) db[i - nw] = s;
+    if (i < nw) dW[i] = accumulate ? dW[i] + s : s;
+    else if (db) db[i - nw] = accumulate ? db[i - nw] + s : s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -523,8 +523,9 @@ int64_t vf_linear_bwd_scratch_floats(int32_t M, int32_t K, int32_t No)
     return (int64_t)nblk * ((int64_t)No * K + No);
 }
 
-int vf_linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X, int32_t ldx,
-                         float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream)
+static int linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X, int32_t ldx,
+                             float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream,
+                             int accumulate)
 {
     if (!dY || !X || !dW || !scratch || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128)
         return vf::fail(VF_EINVAL, "vf_linear_bwd_weight: bad argument (K, No <= 128)");
@@ -538,9 +539,21 @@ int vf_linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int3
                        No, rpb);
     const int n = No * K + No;
     hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + vf::kBlock - 1) / vf::kBlock), dim3(vf::kBlock), 0, st, scratch, nblk,
-                       No * K, No, dW, db);
+                       No * K, No, dW, db, accumulate);
     VF_HIP(hipGetLastError());
     return VF_OK;
+}
+
+int vf_linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X, int32_t ldx,
+                         float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream)
+{
+    return linear_bwd_weight(dY, lddy, Ymask, ldym, X, ldx, dW, db, M, K, No, scratch, stream, 0);
+}
+
+int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X, int32_t ldx,
+                             float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream)
+{
+    return linear_bwd_weight(dY, lddy, Ymask, ldym, X, ldx, dW, db, M, K, No, scratch, stream, 1);
 }
 
 int vf_head_sample(const float* mean, const float* log_std, float* action, float* log_prob, int32_t M, uint64_t seed,

@@ -240,6 +240,7 @@ class DroneGymEnvsBase:
         self._done = th.zeros(N, dtype=th.bool, device=self.device)
         self._action = th.zeros((N, 4), device=self.device)
         self._qcache = None
+        self._tape = None
         self._outs = self._out(self._terminal_obs, self._ep_return, self._ep_flags)  # obs/reward/done patched per step
         self._outs_ref = C.byref(self._outs)
         self._vf_env_step = _lib.lib().vf_env_step
@@ -381,6 +382,14 @@ class DroneGymEnvsBase:
         reward = th.empty(N, dtype=th.float32, device=dev)
         done = th.empty(N, dtype=th.bool, device=dev)      # the kernel writes 0/1 bytes
         replay = self.spawn_mode == "replay"
+        tape_t = -1
+        if self._tape is not None:                          # checkpoint for the adjoint pass
+            tape_t = self._tape_t
+            if tape_t >= self._tape.shape[0]:
+                raise VisflyError("tape is full: call env.detach() (BPTT horizon exceeded)")
+            self._tape[tape_t].copy_(self._slab)
+            self._tape_actions[tape_t].copy_(a)
+            self._tape_t += 1
         o = self._outs
         o.obs, o.reward, o.done = state.data_ptr(), reward.data_ptr(), done.data_ptr()
         rc = self._vf_env_step(self._h, a.data_ptr(), self._outs_ref, 0 if (is_test or replay) else 1,
@@ -388,6 +397,8 @@ class DroneGymEnvsBase:
         if rc:
             _lib.check(rc)
         self._qcache = None
+        if tape_t >= 0:
+            self._tape_done[tape_t].copy_(done)
         self._reward, self._done = reward, done
         self._observations = obs = self._full_obs(state)
         info = _Info(self, done, self._ep_return, self._ep_length, self._ep_flags, self._terminal_obs,
@@ -411,6 +422,43 @@ class DroneGymEnvsBase:
         if self.tensor_output:
             return obs
         return TensorDict({k: v.detach().cpu().numpy() for k, v in obs.items()})
+
+    # ------------------------------------------------------------------ adjoint (first-order / BPTT) support
+    def enable_tape(self, horizon: int):
+        """record what the reverse pass needs: per step a copy of the slab (pre-step state), the action
+        and the done flags.  Replaces the autograd graph requires_grad=True builds in the reference."""
+        dev = self.device
+        self._tape = th.empty((horizon,) + tuple(self._slab.shape), dtype=th.float32, device=dev)
+        self._tape_actions = th.empty((horizon, self.num_agent, 4), dtype=th.float32, device=dev)
+        self._tape_done = th.zeros((horizon, self.num_agent), dtype=th.bool, device=dev)
+        self._adj = th.zeros_like(self._slab)
+        self._tape_t = 0
+
+    def clear_tape(self):
+        """env.detach() of the reference (droneGymEnv.py:286-300): cut the graph at the current state"""
+        if self._tape is not None:
+            self._tape_t = 0
+            self._adj.zero_()
+
+    def backward_step(self, t: int, d_obs=None, d_reward=None):
+        """reverse pass of recorded step t; call for t = last .. 0.  d_obs (N,13) / d_reward (N,) are the
+        loss gradients w.r.t. what step t returned; returns dLoss/d(action of step t) (N,4)."""
+        if self._tape is None or not (0 <= t < self._tape_t):
+            raise VisflyError("backward_step: no recorded step %d" % t)
+        dev = self.device
+        d_action = th.empty((self.num_agent, 4), dtype=th.float32, device=dev)
+        a = _lib.EnvBwdArgs()
+        a.tape_slab, a.action = self._tape[t].data_ptr(), self._tape_actions[t].data_ptr()
+        keep = []
+        for name, x, shape in (("d_obs", d_obs, (self.num_agent, 13)), ("d_reward", d_reward, (self.num_agent,))):
+            if x is not None:
+                x = x.to(dev, dtype=th.float32).reshape(shape).contiguous()
+                keep.append(x)
+                setattr(a, name, x.data_ptr())
+        a.done, a.adj_slab, a.d_action = self._tape_done[t].data_ptr(), self._adj.data_ptr(), d_action.data_ptr()
+        with th.cuda.device(dev):
+            _lib.check(_lib.lib().vf_env_step_bwd(self._h, C.byref(a), self._stream()))
+        return d_action
 
     def time_steps(self, action, iters=100, auto_reset=True):
         """mean device microseconds per fused env-step launch (HIP events on the current stream)"""
@@ -445,6 +493,7 @@ class DroneGymEnvsBase:
 
     def detach(self):
         self.envs.detach()
+        self.clear_tape()
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
