@@ -1,0 +1,127 @@
+"""First-order (differentiable-simulation) policy optimisation: BPTT over a horizon of env steps.
+
+Restates ``BPTT.learn`` of the reference (utils/algorithms/BPTT.py:77-180): roll the policy through
+H env steps with ``requires_grad=True``, loss = mean_i sum_t -reward_t * discount_t with
+``discount <- discount * gamma * ~done + done`` (:107-124), back-propagate through the simulator,
+clip the gradient norm to 0.5, Adam step, ``env.detach()`` (:127-134).
+
+Where the reference relies on a torch autograd tape of ~3.8k nodes per control step, here the
+simulator's reverse pass is the hand-written adjoint kernel ``vf_env_step_bwd`` (one launch per
+step) and the policy's is the MFMA linear-layer kernels; ``torch.autograd`` is only the scheduler
+that orders those launches (two custom Functions), so any torch policy can be dropped in as well.
+"""
+import ctypes as C
+import time
+from typing import Dict, Optional
+
+import torch as th
+
+from . import _lib, parallel
+from .ppo import MlpPolicy, _ptr
+
+
+class EnvStepFunction(th.autograd.Function):
+    """env.step with the adjoint kernel as backward.  `token` threads the hidden simulator state through
+    the graph so that autograd runs step t's backward after step t+1's (the adjoint slab is in/out)."""
+
+    @staticmethod
+    def forward(ctx, action, token, env, is_test):
+        obs, reward, done, info = env._step_no_grad(action.detach(), is_test, record=True)
+        ctx.env, ctx.t = env, env._tape_t - 1
+        env._last_step_aux = (obs, done, info)
+        return obs["state"], reward, token + 1
+
+    @staticmethod
+    def backward(ctx, d_obs, d_reward, d_token):
+        d_action = ctx.env.backward_step(ctx.t, d_obs, d_reward)
+        return d_action, d_token, None, None
+
+
+class PolicyFunction(th.autograd.Function):
+    """MlpPolicy mean head: forward / backward on the MFMA linear kernels; parameter gradients are
+    accumulated into ``policy.grad`` (flat), the observation gradient is returned to autograd."""
+
+    @staticmethod
+    def forward(ctx, policy, keys, *obs):
+        ctx.policy, ctx.keys = policy, keys
+        ctx.save_for_backward(*obs)
+        mean, _ = policy.forward({k: o.detach().contiguous() for k, o in zip(keys, obs)})
+        return mean.clone()
+
+    @staticmethod
+    def backward(ctx, d_mean):
+        pol = ctx.policy
+        obs = ctx.saved_tensors
+        pol.forward({k: o.detach().contiguous() for k, o in zip(ctx.keys, obs)})   # activations of THIS step
+        d_in = pol.backward(d_mean.contiguous(), None, None, accumulate=True, need_input_grad=True)
+        return (None, None) + tuple(d_in.get(k) for k in ctx.keys)
+
+
+class BPTT:
+    def __init__(self, env, horizon: int = 32, gamma: float = 0.99, learning_rate: float = 1e-3,
+                 max_grad_norm: float = 0.5, weight_decay: float = 0.0, policy_kwargs: Optional[dict] = None,
+                 seed: int = 0, betas=(0.9, 0.999), adam_eps: float = 1e-8):
+        self.env, self.H, self.gamma = env, horizon, gamma
+        self.lr, self.max_grad_norm, self.weight_decay, self.betas, self.adam_eps = learning_rate, max_grad_norm, weight_decay, betas, adam_eps
+        self.device = env.device
+        env.set_requires_grad(True, horizon=horizon)        # shac.py:124 sets env.requires_grad = True
+        env.tensor_output = True
+        if not env._is_initial:
+            env.reset()
+        obs = env.get_observation()
+        self.obs_keys = [k for k in obs.keys() if k in ("state", "target")]
+        pk = dict(policy_kwargs or {})
+        self.policy = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},
+                                pk.get("extractor", {k: [128, 64] for k in self.obs_keys}), pk.get("pi", [64, 64]),
+                                pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed)
+        n = self.policy.n_params
+        self.exp_avg, self.exp_avg_sq = th.zeros(n, device=self.device), th.zeros(n, device=self.device)
+        self._sumsq, self._scratch = th.zeros(1, device=self.device), th.zeros(4096, device=self.device)
+        self._gen = th.Generator(device=self.device).manual_seed(seed)
+        self._opt_step = 0
+        self.num_timesteps = 0
+        self.world = parallel.world_size()
+        self.logs: Dict[str, float] = {}
+
+    def _update(self):
+        """one horizon: roll out, back-propagate through simulator and policy, clip + Adam (BPTT.py:100-134)"""
+        env, pol, N = self.env, self.policy, self.env.num_envs
+        pol.grad.zero_()
+        log_std = pol.log_std.detach().clone().requires_grad_(True)
+        disc = th.ones(N, device=self.device)
+        loss_vec = th.zeros(N, device=self.device)
+        obs = env.get_observation()
+        for _ in range(self.H):
+            mean = PolicyFunction.apply(pol, self.obs_keys, *[obs[k] for k in self.obs_keys])
+            eps = th.randn((N, 4), device=self.device, generator=self._gen)
+            action = th.tanh(mean + log_std.exp() * eps)     # reparameterised squashed Gaussian (td_policies Actor)
+            obs, reward, done, _ = env.step(action)
+            loss_vec = loss_vec + -1 * reward * disc          # :123
+            disc = disc * self.gamma * ~done + done           # :124
+        loss = loss_vec.mean() / self.world
+        loss.backward()
+        pol.grad[pol.log_std_off:] = log_std.grad
+        parallel.allreduce_sum_(pol.grad)
+        L, st = _lib.lib(), th.cuda.current_stream(self.device).cuda_stream
+        self._opt_step += 1
+        _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
+        cfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, self.weight_decay, self.max_grad_norm,
+                           self._opt_step, 0)
+        _lib.check(L.vf_adam_step(_ptr(pol.flat), _ptr(pol.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params,
+                                  _ptr(self._sumsq), C.byref(cfg), st))
+        env.detach()                                          # :134
+        self.num_timesteps += self.H * N * self.world
+        return loss.detach() * self.world
+
+    def learn(self, total_timesteps: int, log_interval: Optional[int] = None):
+        t0, start, it = time.time(), self.num_timesteps, 0
+        while self.num_timesteps - start < total_timesteps:
+            loss = self._update()
+            it += 1
+            if log_interval and it % log_interval == 0:
+                self.logs["train/actor_loss"] = float(loss)
+                print(f"[bptt] it {it} steps {self.num_timesteps} actor_loss {self.logs['train/actor_loss']:.4f}")
+        th.cuda.synchronize(self.device)
+        self.logs["train/actor_loss"] = float(loss)
+        self.logs["time/fps"] = (self.num_timesteps - start) / max(time.time() - t0, 1e-9)
+        return self.policy

@@ -147,8 +147,6 @@ class DroneGymEnvsBase:
         if visual:
             raise NotImplementedError("visual=True needs the external Habitat-sim renderer; the MI355X engine "
                                       "covers the visual=False path (SURVEY.md 8)")
-        if requires_grad:
-            raise NotImplementedError("requires_grad=True (BPTT through the simulator) is not available yet")
         if spawn not in ("device", "replay"):
             raise ValueError("spawn must be 'device' or 'replay'")
         self.device = th.device(device)
@@ -241,6 +239,8 @@ class DroneGymEnvsBase:
         self._action = th.zeros((N, 4), device=self.device)
         self._qcache = None
         self._tape = None
+        if requires_grad:
+            self.set_requires_grad(True)
         self._outs = self._out(self._terminal_obs, self._ep_return, self._ep_flags)  # obs/reward/done patched per step
         self._outs_ref = C.byref(self._outs)
         self._vf_env_step = _lib.lib().vf_env_step
@@ -365,7 +365,21 @@ class DroneGymEnvsBase:
 
     # ------------------------------------------------------------------ step
     def step(self, _action, is_test=False, **_unused):
-        """DroneGymEnvsBase.step (droneGymEnv.py:141-218) -> (obs, reward, done, info)"""
+        """DroneGymEnvsBase.step (droneGymEnv.py:141-218) -> (obs, reward, done, info).  With
+        requires_grad=True the returned state observation and reward are attached to the autograd graph
+        (droneGymEnv.py:209-213); their backward is the adjoint kernel (visfly_amd/bptt.py)."""
+        if self.requires_grad and isinstance(_action, th.Tensor) and th.is_grad_enabled():
+            from ..bptt import EnvStepFunction
+            if not self.tensor_output:
+                raise ValueError("requires_grad should be False if tensor_output is False")          # :211-212
+            state, reward, self._token = EnvStepFunction.apply(_action, self._token, self, is_test)
+            obs0, done, info = self._last_step_aux
+            obs = self._full_obs(state)
+            self._observations = obs
+            return obs, reward, done, info
+        return self._step_no_grad(_action, is_test)
+
+    def _step_no_grad(self, _action, is_test=False, record=False):
         assert self._is_initial, "You should call reset() before step()"
         N, dev = self.num_agent, self.device
         a = _action
@@ -383,7 +397,7 @@ class DroneGymEnvsBase:
         done = th.empty(N, dtype=th.bool, device=dev)      # the kernel writes 0/1 bytes
         replay = self.spawn_mode == "replay"
         tape_t = -1
-        if self._tape is not None:                          # checkpoint for the adjoint pass
+        if self._tape is not None and (record or self._record_all):   # checkpoint for the adjoint pass
             tape_t = self._tape_t
             if tape_t >= self._tape.shape[0]:
                 raise VisflyError("tape is full: call env.detach() (BPTT horizon exceeded)")
@@ -433,12 +447,14 @@ class DroneGymEnvsBase:
         self._tape_done = th.zeros((horizon, self.num_agent), dtype=th.bool, device=dev)
         self._adj = th.zeros_like(self._slab)
         self._tape_t = 0
+        self._record_all = True      # manual mode: every step() is recorded until clear_tape()/detach()
 
     def clear_tape(self):
         """env.detach() of the reference (droneGymEnv.py:286-300): cut the graph at the current state"""
         if self._tape is not None:
             self._tape_t = 0
             self._adj.zero_()
+            self._token = th.zeros(1, device=self.device, requires_grad=True)
 
     def backward_step(self, t: int, d_obs=None, d_reward=None):
         """reverse pass of recorded step t; call for t = last .. 0.  d_obs (N,13) / d_reward (N,) are the
@@ -492,8 +508,12 @@ class DroneGymEnvsBase:
         return self._reward
 
     def detach(self):
+        """droneGymEnv.py:286-300: cut the autograd graph at the current state"""
         self.envs.detach()
         self.clear_tape()
+        self._observations = TensorDict({k: (v.detach() if isinstance(v, th.Tensor) else v)
+                                         for k, v in self._observations.items()})
+        self._reward = self._reward.detach()
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -506,9 +526,17 @@ class DroneGymEnvsBase:
         except Exception:
             pass
 
-    def set_requires_grad(self, requires_grad: bool):
+    def set_requires_grad(self, requires_grad: bool, horizon: int = 64):
+        """droneGymEnv.py:628-633.  True: record the per-step checkpoints the adjoint kernel needs (up to
+        `horizon` steps between two detach() calls) and return graph-attached obs / reward from step()."""
+        self.requires_grad = bool(requires_grad)
         if requires_grad:
-            raise NotImplementedError("requires_grad=True is not available yet")
+            if self._tape is None or self._tape.shape[0] < horizon:
+                self.enable_tape(horizon)
+            self._record_all = False  # autograd mode: only graph-attached steps are recorded
+            self._token = th.zeros(1, device=self.device, requires_grad=True)
+        else:
+            self._tape = None
 
     def to(self, device):
         if th.device(device).type != "cuda":

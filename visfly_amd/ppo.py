@@ -148,34 +148,51 @@ class MlpPolicy:
         self._last_M = M
         return b["mean"], b["value"]
 
-    def backward(self, d_mean: th.Tensor, d_value: th.Tensor, d_log_std: th.Tensor):
-        """fills ``self.grad`` (flat, same layout as ``self.flat``) from the head gradients"""
+    def backward(self, d_mean: th.Tensor, d_value: Optional[th.Tensor], d_log_std: Optional[th.Tensor],
+                 accumulate: bool = False, need_input_grad: bool = False):
+        """fills (or, with ``accumulate``, adds into) ``self.grad`` -- flat, same layout as ``self.flat`` --
+        from the head gradients.  d_value None skips the value trunk (first-order policy optimisation has
+        no critic); need_input_grad also returns {obs key: dLoss/d obs} (BPTT differentiates through obs)."""
         M = self._last_M
         b = self._buffers(M)
         L, st = _lib.lib(), self._stream()
         need = max(int(L.vf_linear_bwd_scratch_floats(M, ly.K, ly.No)) for ly in self.layers)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
-        gbuf = {"mean": d_mean, "value": d_value.view(M, 1)}
+        gbuf = {"mean": d_mean}
+        if d_value is not None:
+            gbuf["value"] = d_value.view(M, 1)
+        wgrad = L.vf_linear_bwd_weight_acc if accumulate else L.vf_linear_bwd_weight
         touched = set()
+        d_in = {}
         for ly in reversed(self.layers):
+            if d_value is None and (ly.dst == "value" or ly.dst.startswith("vf:")):
+                continue
             dY = gbuf.get(ly.dst, b.get("g:" + ly.dst))
             Y, X = b[ly.dst], b[ly.src]
             ym = _ptr(Y, ly.dc) if ly.relu else None
-            rc = L.vf_linear_bwd_weight(_ptr(dY, ly.dc), dY.shape[1], ym, Y.shape[1], _ptr(X, ly.sc), X.shape[1],
-                                        _ptr(self.grad, ly.w_off), _ptr(self.grad, ly.b_off), M, ly.K, ly.No,
-                                        _ptr(self._scratch), st)
+            rc = wgrad(_ptr(dY, ly.dc), dY.shape[1], ym, Y.shape[1], _ptr(X, ly.sc), X.shape[1],
+                       _ptr(self.grad, ly.w_off), _ptr(self.grad, ly.b_off), M, ly.K, ly.No, _ptr(self._scratch), st)
             if rc:
                 _lib.check(rc)
-            if not ly.first:
+            if ly.first and not need_input_grad:
+                continue
+            if ly.first:
+                dX = d_in.setdefault(ly.src[4:], th.empty((M, ly.K), dtype=th.float32, device=self.device))
+            else:
                 dX = b["g:" + ly.src]
-                key = (ly.src, ly.sc)
-                rc = L.vf_linear_bwd_data(_ptr(dY, ly.dc), dY.shape[1], ym, Y.shape[1], _ptr(self.flat, ly.w_off),
-                                          _ptr(dX, ly.sc), dX.shape[1], M, ly.K, ly.No, 1 if key in touched else 0, st)
-                if rc:
-                    _lib.check(rc)
-                touched.add(key)
-        self.grad[self.log_std_off:] = d_log_std
+            key = (ly.src, ly.sc)
+            rc = L.vf_linear_bwd_data(_ptr(dY, ly.dc), dY.shape[1], ym, Y.shape[1], _ptr(self.flat, ly.w_off),
+                                      _ptr(dX, ly.sc), dX.shape[1], M, ly.K, ly.No, 1 if key in touched else 0, st)
+            if rc:
+                _lib.check(rc)
+            touched.add(key)
+        if d_log_std is not None:
+            if accumulate:
+                self.grad[self.log_std_off:] += d_log_std
+            else:
+                self.grad[self.log_std_off:] = d_log_std
+        return d_in
 
     # -------------------------------------------------------------------------------------------
     def to_torch(self):
