@@ -147,6 +147,12 @@ def main():
     if rank == 0:
         value = world * N * args.steps / el
         achieved = BYTES_PER_ENV_STEP * N / (kern_us * 1e-6) / 1e9
+        traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (per-agent figure x N)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = (pmc["fetch_bytes_per_agent"] + pmc["write_bytes_per_agent"]) * N
+        except Exception:
+            pass
         out = {
             "metric": "agent-steps/sec (dynamics.step, visual=False)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,7 +163,7 @@ def main():
                                    "3-slot delay ring, max_episode_steps=256 (BASELINE configs[1])",
                        "agents_per_gpu": N, "parallelism": f"agents sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_env_step<hover,bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
                          "bytes_per_agent_step": BYTES_PER_ENV_STEP,
                          "dyn_only": {"kernel": "k_dyn_step<bodyrate,euler,ctrl_delay>", "kernel_us": dyn_us,

@@ -1,0 +1,13 @@
+"""run the fused HoverEnv step kernel a few times at a given N (for rocprofv3 --pmc passes)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visfly_amd.envs import HoverEnv
+N = int(sys.argv[1]); iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+kw = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+env = HoverEnv(num_agent_per_scene=N, dynamics_kwargs=kw, device="cuda:0", tensor_output=True, max_episode_steps=256)
+env.reset()
+a = (torch.rand((N, 4), device="cuda") * 2 - 1) * 0.02 + torch.tensor([-1 / 3, 0, 0, 0], device="cuda")
+for _ in range(iters):
+    env.step(a)
+torch.cuda.synchronize()
