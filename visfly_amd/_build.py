@@ -26,12 +26,13 @@ def _stale():
     return os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    out = out or LIB
+    if not force and out == LIB and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", LIB]
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out

@@ -130,18 +130,15 @@ __device__ __forceinline__ void desired_thrusts(const vf_dyn_cfg& c, const Agent
     for (int k = 0; k < 4; ++k) Td[k] = clampf(Td[k], c.T_min, c.T_max);
 }
 
-// All sub-steps of one control interval, then t += ctrl_dt and the state clamps
-// (dynamics.py:335-382).  kl/kq: this agent's drag coefficients.
-template <int ACT, int INTEG, bool CTRL_DELAY>
-__device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, const float* a,
-                                                 const float* kl, const float* kq)
-{
-    float Td[4];
-    desired_thrusts<ACT>(c, s, a, Td);
+// ---- the three recurrences of one sub-step (dynamics.py:335-367) ----------------------------------
+// They only couple one way: motors -> (F, tau); rotation (q, w) needs tau; translation (p, v) needs
+// q and F.  The fused kernels run them either in one thread or on two co-resident waves.
 
-    // rotor set-point: loop invariant (thrust_des is fixed for the interval), so the
-    // quadratic root of dynamics.py:545-553 is taken once instead of once per sub-step.
-    float wd[4];
+// rotor set-point contribution (1 - c) * omega_des: loop invariant (thrust_des is fixed for the
+// interval), so the quadratic root of dynamics.py:545-553 is taken once, not once per sub-step.
+template <bool CTRL_DELAY>
+__device__ __forceinline__ void rotor_setpoint(const vf_dyn_cfg& c, const float* Td, float* wd)
+{
     if constexpr (CTRL_DELAY) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -149,120 +146,151 @@ __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, 
             wd[k] = (c.one_minus_c) * (c.rot_scale * (c.rot_neg_tm1 + sqrtf(d3)));
         }
     }
-    const float dt = c.dt;
+}
 
-    for (int sub = 0; sub < c.interval_steps; ++sub) {
-        if constexpr (CTRL_DELAY) {
+// _run_motors + allocation (:338-339,505-534): wm, T updated; ft = [F, tau]
+template <bool CTRL_DELAY>
+__device__ __forceinline__ void motor_substep(const vf_dyn_cfg& c, const float* Td, const float* wd, float* wm, float* T,
+                                              float* ft)
+{
+    if constexpr (CTRL_DELAY) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s.wm[k] = c.c_motor * s.wm[k] + wd[k];                        // :514
-                const float wp = s.wm[k] + 0.0f;
-                s.T[k] = (c.tm0 * (wp * wp) + c.tm1 * s.wm[k]) + c.tm2;       // :530-534
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s.T[k] = Td[k];                       // :518
+        for (int k = 0; k < 4; ++k) {
+            wm[k] = c.c_motor * wm[k] + wd[k];                        // :514
+            const float wp = wm[k] + 0.0f;
+            T[k] = (c.tm0 * (wp * wp) + c.tm1 * wm[k]) + c.tm2;       // :530-534
         }
-        float ft[4];
-        mat4(c.B, s.T, ft);                                                    // :339
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) T[k] = Td[k];                     // :518
+    }
+    mat4(c.B, T, ft);                                                  // :339
+}
 
-        // body-frame velocity and drag (:342-345)
-        const Quat vq{0.0f, s.v[0] + 0.0f, s.v[1] + 0.0f, s.v[2] + 0.0f};
-        const Quat vb = qmul(qmul(qconj(s.q), vq), s.q);
-        const float vbv[3] = {vb.x, vb.y, vb.z};
-        float u[3];
+// linear acceleration from the state at the START of the sub-step (:342-347)
+__device__ __forceinline__ void linear_acc(const vf_dyn_cfg& c, const Quat& q, const float* v, float F, const float* kl,
+                                           const float* kq, float* acc)
+{
+    const Quat vq{0.0f, v[0] + 0.0f, v[1] + 0.0f, v[2] + 0.0f};
+    const Quat vb = qmul(qmul(qconj(q), vq), q);
+    const float vbv[3] = {vb.x, vb.y, vb.z};
+    float u[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float drag = kl[k] * vbv[k] + (kq[k] * vbv[k]) * __builtin_fabsf(vbv[k]);
+        const float zf = (k == 2 ? 1.0f : 0.0f) * F;
+        u[k] = zf - drag;
+    }
+    const Quat uq{0.0f, u[0], u[1], u[2]};
+    const Quat ra = qmul(qmul(q, uq), qconj(q));
+    acc[0] = ra.x / c.m + 0.0f;
+    acc[1] = ra.y / c.m + 0.0f;
+    acc[2] = ra.z / c.m + c.g_z;
+}
+
+// translation: acc, then p and v advance (maths.py:310,344,346 / repaired rk4 :353-386)
+template <int INTEG>
+__device__ __forceinline__ void trans_substep(const vf_dyn_cfg& c, const Quat& q, float F, const float* kl, const float* kq,
+                                              float* p, float* v, float* acc)
+{
+    linear_acc(c, q, v, F, kl, kq, acc);
+    const float dt = c.dt;
+    if constexpr (INTEG == VF_INT_EULER) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = p[k] + (v[k] + c.wind[k]) * dt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] + acc[k] * dt;
+    } else {
+        const float ks0 = 1.0f / 6.0f, ks1 = 2.0f / 6.0f;
+        float sp[3], sv[3];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float h = st == 3 ? 1.0f : 0.5f;
+            const float ks = (st == 0 || st == 3) ? ks0 : ks1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float vc = st == 0 ? v[k] : v[k] + acc[k] * h * dt;
+                const float kp = (vc + c.wind[k]) * ks, kv = acc[k] * ks;
+                sp[k] = st == 0 ? kp : sp[k] + kp;
+                sv[k] = st == 0 ? kv : sv[k] + kv;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = p[k] + sp[k] * dt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] + sv[k] * dt;
+    }
+}
+
+// rotation: q and w advance, aa = angular acceleration handed to the controller, q re-normalised
+// (maths.py:311,314,345,347,351; dynamics.py:367; repaired rk4: SURVEY App. C-1 -- stages see the
+// caller's wind, ks-contractions are ((k1*w0 + k2*w1) + k3*w2) + k4*w3, tau stays frozen)
+template <int INTEG>
+__device__ __forceinline__ void rot_substep(const vf_dyn_cfg& c, const float* tq, Quat& q, float* w, float* aa)
+{
+    const float dt = c.dt;
+    if constexpr (INTEG == VF_INT_EULER) {
+        float dq[4], dw[3];
+        derivs(c, q, w, tq, dq, dw);
+        q.w = q.w + dq[0] * dt;
+        q.x = q.x + dq[1] * dt;
+        q.y = q.y + dq[2] * dt;
+        q.z = q.z + dq[3] * dt;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float drag = kl[k] * vbv[k] + (kq[k] * vbv[k]) * __builtin_fabsf(vbv[k]);
-            const float zf = (k == 2 ? 1.0f : 0.0f) * ft[0];
-            u[k] = zf - drag;
+            w[k] = w[k] + dw[k] * dt;
+            aa[k] = dw[k];
         }
-        // acc = q (x) (z F - drag) (x) q* / m + g   (:347)
-        const Quat uq{0.0f, u[0], u[1], u[2]};
-        const Quat ra = qmul(qmul(s.q, uq), qconj(s.q));
-        s.acc[0] = ra.x / c.m + 0.0f;
-        s.acc[1] = ra.y / c.m + 0.0f;
-        s.acc[2] = ra.z / c.m + c.g_z;
-
-        const float* tq = ft + 1;
-        if constexpr (INTEG == VF_INT_EULER) {
-            float dq[4], dw[3];
-            derivs(c, s.q, s.w, tq, dq, dw);
+    } else {
+        const float ks0 = 1.0f / 6.0f, ks1 = 2.0f / 6.0f;
+        Quat qc = q;
+        float wc[3] = {w[0], w[1], w[2]};
+        float sq[4], sw[3], dq[4], dw[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s.p[k] = s.p[k] + (s.v[k] + c.wind[k]) * dt;   // maths.py:310,344
-            s.q.w = s.q.w + dq[0] * dt;
-            s.q.x = s.q.x + dq[1] * dt;
-            s.q.y = s.q.y + dq[2] * dt;
-            s.q.z = s.q.z + dq[3] * dt;
+        for (int st = 0; st < 4; ++st) {
+            if (st != 0) {
+                const float h = st == 3 ? 1.0f : 0.5f;
+                qc.w = q.w + dq[0] * h * dt;
+                qc.x = q.x + dq[1] * h * dt;
+                qc.y = q.y + dq[2] * h * dt;
+                qc.z = q.z + dq[3] * h * dt;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s.v[k] = s.v[k] + s.acc[k] * dt;
+                for (int k = 0; k < 3; ++k) wc[k] = w[k] + dw[k] * h * dt;
+            }
+            derivs(c, qc, wc, tq, dq, dw);
+            const float ks = (st == 0 || st == 3) ? ks0 : ks1;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                s.w[k] = s.w[k] + dw[k] * dt;
-                s.aa[k] = dw[k];                                                       // maths.py:351
-            }
-        } else {
-            // Repaired RK4 (utils/maths.py:353-386 is not executable in the
-            // reference): stages see the caller's wind, the ks-contractions are the explicit
-            // sums ((k1*w0 + k2*w1) + k3*w2) + k4*w3, acc/tau stay frozen, and the weighted
-            // d_ori_vel is the angular acceleration handed to the controller.
-            const float ks0 = 1.0f / 6.0f, ks1 = 2.0f / 6.0f;
-            Quat qc = s.q;
-            float vc[3] = {s.v[0], s.v[1], s.v[2]};
-            float wc[3] = {s.w[0], s.w[1], s.w[2]};
-            float sp[3], sq[4], sv[3], sw[3];
-            float dq[4], dw[3];
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                if (st != 0) {
-                    const float h = st == 3 ? 1.0f : 0.5f;
-                    qc.w = s.q.w + dq[0] * h * dt;
-                    qc.x = s.q.x + dq[1] * h * dt;
-                    qc.y = s.q.y + dq[2] * h * dt;
-                    qc.z = s.q.z + dq[3] * h * dt;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) vc[k] = s.v[k] + s.acc[k] * h * dt;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) wc[k] = s.w[k] + dw[k] * h * dt;
-                }
-                derivs(c, qc, wc, tq, dq, dw);
-                const float ks = (st == 0 || st == 3) ? ks0 : ks1;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float kp = (vc[k] + c.wind[k]) * ks, kv = s.acc[k] * ks, kw = dw[k] * ks;
-                    sp[k] = st == 0 ? kp : sp[k] + kp;
-                    sv[k] = st == 0 ? kv : sv[k] + kv;
-                    sw[k] = st == 0 ? kw : sw[k] + kw;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float kq4 = dq[k] * ks;
-                    sq[k] = st == 0 ? kq4 : sq[k] + kq4;
-                }
+                const float kw = dw[k] * ks;
+                sw[k] = st == 0 ? kw : sw[k] + kw;
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s.p[k] = s.p[k] + sp[k] * dt;
-            s.q.w = s.q.w + sq[0] * dt;
-            s.q.x = s.q.x + sq[1] * dt;
-            s.q.y = s.q.y + sq[2] * dt;
-            s.q.z = s.q.z + sq[3] * dt;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s.v[k] = s.v[k] + sv[k] * dt;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                s.w[k] = s.w[k] + sw[k] * dt;
-                s.aa[k] = sw[k];
+            for (int k = 0; k < 4; ++k) {
+                const float kq4 = dq[k] * ks;
+                sq[k] = st == 0 ? kq4 : sq[k] + kq4;
             }
         }
-        // normalize (:367, maths.py:226-230)
-        const float nn = sqrtf(((s.q.w * s.q.w + s.q.x * s.q.x) + s.q.y * s.q.y) + s.q.z * s.q.z);
-        s.q.w = s.q.w / nn;
-        s.q.x = s.q.x / nn;
-        s.q.y = s.q.y / nn;
-        s.q.z = s.q.z / nn;
+        q.w = q.w + sq[0] * dt;
+        q.x = q.x + sq[1] * dt;
+        q.y = q.y + sq[2] * dt;
+        q.z = q.z + sq[3] * dt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            w[k] = w[k] + sw[k] * dt;
+            aa[k] = sw[k];
+        }
     }
-    s.t = s.t + c.ctrl_dt;                                                             // :368
-    // _ugly_fix (:374-382)
+    const float nn = sqrtf(((q.w * q.w + q.x * q.x) + q.y * q.y) + q.z * q.z);   // :367, maths.py:226-230
+    q.w = q.w / nn;
+    q.x = q.x / nn;
+    q.y = q.y / nn;
+    q.z = q.z / nn;
+}
+
+// t += ctrl_dt and the state clamps (_ugly_fix, dynamics.py:368-382)
+__device__ __forceinline__ void finish_interval(const vf_dyn_cfg& c, Agent& s)
+{
+    s.t = s.t + c.ctrl_dt;
     s.p[0] = clampf(s.p[0], -c.pos_xy_lim, c.pos_xy_lim);
     s.p[1] = clampf(s.p[1], -c.pos_xy_lim, c.pos_xy_lim);
     s.p[2] = clampf(s.p[2], c.pos_z_lo, c.pos_z_hi);
@@ -270,6 +298,23 @@ __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, 
     for (int k = 0; k < 3; ++k) s.v[k] = clampf(s.v[k], -c.vel_lim, c.vel_lim);
 #pragma unroll
     for (int k = 0; k < 3; ++k) s.w[k] = clampf(s.w[k], -c.omg_lim, c.omg_lim);
+}
+
+// All sub-steps of one control interval in ONE thread (dynamics.py:335-382).  kl/kq: this agent's drag.
+template <int ACT, int INTEG, bool CTRL_DELAY>
+__device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, const float* a,
+                                                 const float* kl, const float* kq)
+{
+    float Td[4], wd[4];
+    desired_thrusts<ACT>(c, s, a, Td);
+    rotor_setpoint<CTRL_DELAY>(c, Td, wd);
+    for (int sub = 0; sub < c.interval_steps; ++sub) {
+        float ft[4];
+        motor_substep<CTRL_DELAY>(c, Td, wd, s.wm, s.T, ft);
+        trans_substep<INTEG>(c, s.q, ft[0], kl, kq, s.p, s.v, s.acc);   // uses q of the sub-step start
+        rot_substep<INTEG>(c, ft + 1, s.q, s.w, s.aa);
+    }
+    finish_interval(c, s);
 }
 
 // ---- slab I/O: wave-tile AoSoA, one 16-byte granule per lane per access ----
