@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "visfly_amd.h"
 
@@ -33,5 +34,18 @@ inline hipStream_t as_stream(vf_stream_t s) { return reinterpret_cast<hipStream_
 constexpr int kBlock = 256;  // 4 wave64 per workgroup
 
 inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+// Kernel shape per launch: while one-thread-per-agent work cannot even give every SIMD a wave
+// (<= 32768 agents) the two-wave split (rotation | translation on co-resident waves) wins; from one
+// wave per SIMD on, the plain kernel issues fewer instructions in total and has no hand-off barriers.  VISFLY_AMD_SPLIT=0/1 forces a shape (A/B experiments).
+inline bool use_split(int agents_padded)
+{
+    static const int forced = [] {
+        const char* e = getenv("VISFLY_AMD_SPLIT");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0) return forced != 0;
+    return agents_padded <= 32768;   // measured on MI355X: 32768 agents 9.4 us (split) vs 11.3 us; 65536: 13.3 vs 12.5
+}
 
 }  // namespace vf

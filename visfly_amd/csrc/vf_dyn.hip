@@ -39,7 +39,34 @@ __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg c, const D
     if (g.obs) {
         float o[13];
         obs_row(c, s, o);
-        store_rows_coalesced<13>(g.obs, g.N, blockIdx.x * kBlock, o, tile);
+        const int wave = threadIdx.x >> 6;
+        store_rows_coalesced<13>(g.obs, g.N, blockIdx.x * kBlock + wave * 64, o, tile + wave * 64 * 13);
+    }
+}
+
+// Two-wave variant (see SplitShared): 256-thread workgroups = 2 rotation + 2 translation waves for 128
+// agents, so that every workgroup puts exactly one wave on each SIMD of its CU.
+template <int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(kBlock) void k_dyn_step_split(const vf_dyn_cfg c, const DynArgs g)
+{
+    __shared__ SplitShared shs[2];
+    const int grp = (threadIdx.x >> 6) & 1;
+    SplitShared& sh = shs[grp];
+    const int first = blockIdx.x * 128 + grp * 64;
+    const int i = first + (threadIdx.x & 63);
+    const bool live = i < g.N;
+    if (threadIdx.x < 128) {
+        split_rotation_wave<ACT, INTEG, CTRL_DELAY>(c, g, i, live, sh);
+        return;
+    }
+    Agent s;
+    Spares sp;
+    split_translation_wave<INTEG>(c, g, i, sh, s, sp);
+    store_agent(g.S, g.G, i, s, sp);
+    if (g.obs) {
+        float o[13];
+        obs_row(c, s, o);
+        store_rows_coalesced<13>(g.obs, g.N, first, o, sh.tile);
     }
 }
 
@@ -106,6 +133,22 @@ namespace {
 
 using StepKernel = void (*)(const vf_dyn_cfg, const vf::DynArgs);
 
+StepKernel pick_split_kernel(const vf_dyn_cfg& c)
+{
+    const int key = (c.action_type == VF_ACT_BODYRATE ? 4 : 0) | (c.integrator == VF_INT_RK4 ? 2 : 0) |
+                    (c.ctrl_delay ? 1 : 0);
+    switch (key) {
+    case 0: return vf::k_dyn_step_split<VF_ACT_THRUST, VF_INT_EULER, false>;
+    case 1: return vf::k_dyn_step_split<VF_ACT_THRUST, VF_INT_EULER, true>;
+    case 2: return vf::k_dyn_step_split<VF_ACT_THRUST, VF_INT_RK4, false>;
+    case 3: return vf::k_dyn_step_split<VF_ACT_THRUST, VF_INT_RK4, true>;
+    case 4: return vf::k_dyn_step_split<VF_ACT_BODYRATE, VF_INT_EULER, false>;
+    case 5: return vf::k_dyn_step_split<VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    case 6: return vf::k_dyn_step_split<VF_ACT_BODYRATE, VF_INT_RK4, false>;
+    default: return vf::k_dyn_step_split<VF_ACT_BODYRATE, VF_INT_RK4, true>;
+    }
+}
+
 StepKernel pick_step_kernel(const vf_dyn_cfg& c)
 {
     const int key = (c.action_type == VF_ACT_BODYRATE ? 4 : 0) | (c.integrator == VF_INT_RK4 ? 2 : 0) |
@@ -125,7 +168,10 @@ StepKernel pick_step_kernel(const vf_dyn_cfg& c)
 int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st)
 {
     vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out};
-    hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->cfg, g);
+    if (vf::use_split(h->Npad))
+        hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->cfg, g);
+    else
+        hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->cfg, g);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

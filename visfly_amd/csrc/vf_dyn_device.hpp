@@ -412,27 +412,122 @@ __device__ __forceinline__ void obs_row(const vf_dyn_cfg& c, const Agent& s, flo
     o[10] = s.w[0]; o[11] = s.w[1]; o[12] = s.w[2];
 }
 
-// AoS (N,C) output through LDS so that the global stores are coalesced dwords:
-// thread t parks its C-float row at lds[t*C..] (C odd -> conflict-free), then the block
-// streams the tile out linearly.  `tile` must hold blockDim.x*C floats.
+// AoS (N,C) output through LDS so that the global stores are coalesced dwords.  Wave-local: lane l parks
+// its C-float row at tile[l*C..] (C odd -> conflict-free), then the wave streams its 64 rows out linearly.
+// No workgroup barrier: one wave's LDS operations execute in order.  `tile` holds 64*C floats per wave.
 template <int C>
-__device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, int N, int block_first,
-                                                     const float* row, float* tile)
+__device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, int N, int wave_first, const float* row,
+                                                     float* tile)
 {
-    const int t = threadIdx.x;
+    const int l = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < C; ++k) tile[t * C + k] = row[k];
-    // raw barrier: only the LDS writes above must land; outstanding global stores keep flying
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    const int rows_here = min((int)blockDim.x, N - block_first);
+    for (int k = 0; k < C; ++k) tile[l * C + k] = row[k];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const int rows_here = min(64, N - wave_first);
     const int total = rows_here * C;
-    float* dst = out + (size_t)block_first * C;
+    float* dst = out + (size_t)wave_first * C;
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-        const int j = k * blockDim.x + t;
+        const int j = k * 64 + l;
         if (j < total) dst[j] = tile[j];
     }
+}
+
+// ---- two-wave split of the control interval --------------------------------------------------------
+// One wave per SIMD cannot hide its own dependent-issue latency (measured 4.6 cycles / instruction,
+// 2.5 with four waves per SIMD).  Rotation (motors -> torque -> q, w) never reads the translational
+// state, so a 128-thread workgroup runs the two recurrences of the SAME 64 agents on two waves, the
+// translation wave one hand-off behind: per sub-step the rotation wave publishes (q, F) through LDS.
+struct SplitShared {
+    float xq[2][5][64];   // double-buffered (q.w, q.x, q.y, q.z, F) of the sub-step start
+    float fin[20][64];    // final q, w, wm, T, aa + the two env spares the rotation wave loaded
+    float tile[64 * 13];  // observation transpose of the translation wave
+};
+
+__device__ __forceinline__ void lds_publish_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+}
+
+// rotation wave: everything that does not need p / v.  Returns after the final hand-off.
+template <int ACT, int INTEG, bool CTRL_DELAY>
+__device__ __forceinline__ void split_rotation_wave(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, SplitShared& sh)
+{
+    const int l = threadIdx.x & 63;
+    const float4 g1 = *granule(g.S, g.G, i, VF_G_QUAT), g3 = *granule(g.S, g.G, i, VF_G_OMG);
+    const float4 g4 = *granule(g.S, g.G, i, VF_G_MOT), g5 = *granule(g.S, g.G, i, VF_G_THR);
+    const float4 g6 = *granule(g.S, g.G, i, VF_G_AACC);
+    float head_bits = granule(g.S, g.G, i, VF_G_VEL)->x;
+    Agent s;
+    s.q = Quat{g1.x, g1.y, g1.z, g1.w};
+    s.w[0] = g3.y; s.w[1] = g3.z; s.w[2] = g3.w;
+    s.wm[0] = g4.x; s.wm[1] = g4.y; s.wm[2] = g4.z; s.wm[3] = g4.w;
+    s.T[0] = g5.x; s.T[1] = g5.y; s.T[2] = g5.z; s.T[3] = g5.w;
+    s.aa[0] = g6.y; s.aa[1] = g6.z; s.aa[2] = g6.w;
+    float a[4];
+    ring_exchange(c, g, i, live, head_bits, a);   // pushes the new action; the translation wave advances the head word
+    float Td[4], wd[4];
+    desired_thrusts<ACT>(c, s, a, Td);
+    rotor_setpoint<CTRL_DELAY>(c, Td, wd);
+    for (int sub = 0; sub < c.interval_steps; ++sub) {
+        float ft[4];
+        motor_substep<CTRL_DELAY>(c, Td, wd, s.wm, s.T, ft);
+        float(*x)[64] = sh.xq[sub & 1];
+        x[0][l] = s.q.w; x[1][l] = s.q.x; x[2][l] = s.q.y; x[3][l] = s.q.z; x[4][l] = ft[0];
+        lds_publish_barrier();
+        rot_substep<INTEG>(c, ft + 1, s.q, s.w, s.aa);
+    }
+    float(*f)[64] = sh.fin;
+    f[0][l] = s.q.w; f[1][l] = s.q.x; f[2][l] = s.q.y; f[3][l] = s.q.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { f[4 + k][l] = s.w[k]; f[15 + k][l] = s.aa[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[7 + k][l] = s.wm[k]; f[11 + k][l] = s.T[k]; }
+    f[18][l] = g3.x;   // spare of the omega granule (env: step counter)
+    f[19][l] = g6.x;   // spare of the angular-acceleration granule (env: reward sum)
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): the ring push is globally performed before the
+    __builtin_amdgcn_s_barrier();        // translation wave may overwrite the same slot (reset) after this barrier
+}
+
+// translation wave: p, v, acc through the sub-steps, then assembles the full agent state (clamped, t advanced)
+template <int INTEG>
+__device__ __forceinline__ void split_translation_wave(const vf_dyn_cfg& c, const DynArgs& g, int i, SplitShared& sh, Agent& s,
+                                                       Spares& sp)
+{
+    const int l = threadIdx.x & 63;
+    const float4 g0 = *granule(g.S, g.G, i, VF_G_POS), g2 = *granule(g.S, g.G, i, VF_G_VEL);
+    const float4 g7 = *granule(g.S, g.G, i, VF_G_ACC);
+    float kl[3], kq[3];
+    drag_of(c, g, i, kl, kq);
+    s.t = g0.x; s.p[0] = g0.y; s.p[1] = g0.z; s.p[2] = g0.w;
+    s.v[0] = g2.y; s.v[1] = g2.z; s.v[2] = g2.w;
+    s.acc[0] = g7.y; s.acc[1] = g7.z; s.acc[2] = g7.w;
+    sp.acc = g7.x;
+    sp.vel = g2.x;
+    if (c.delay_steps > 0) {  // same head update ring_exchange applies (the rotation wave did the exchange itself)
+        int head = __float_as_int(g2.x);
+        head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
+        sp.vel = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
+    }
+    for (int sub = 0; sub < c.interval_steps; ++sub) {
+        __builtin_amdgcn_s_barrier();
+        const float(*x)[64] = sh.xq[sub & 1];
+        const Quat q{x[0][l], x[1][l], x[2][l], x[3][l]};
+        const float F = x[4][l];
+        trans_substep<INTEG>(c, q, F, kl, kq, s.p, s.v, s.acc);
+    }
+    __builtin_amdgcn_s_barrier();
+    const float(*f)[64] = sh.fin;
+    s.q = Quat{f[0][l], f[1][l], f[2][l], f[3][l]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s.w[k] = f[4 + k][l]; s.aa[k] = f[15 + k][l]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s.wm[k] = f[7 + k][l]; s.T[k] = f[11 + k][l]; }
+    sp.omg = f[18][l];
+    sp.aacc = f[19][l];
+    finish_interval(c, s);
 }
 
 }  // namespace vf

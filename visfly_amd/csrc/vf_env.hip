@@ -50,21 +50,13 @@ __device__ __forceinline__ int collision_flags(int flags, const Collision& col)
     return flags;
 }
 
-template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g)
+// Everything of DroneGymEnvsBase.step that follows the dynamics interval, for ONE agent held in
+// registers: bbox collision, counters, success / reward, done masks, episode outputs, auto-reset,
+// stores (envs/base/droneGymEnv.py:161-218,339-423; envs/base/droneEnv.py:345-371).
+template <int KIND>
+__device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
+                                             Agent& s, Spares& sp, int wave_first, float* tile)
 {
-    __shared__ float tile[kBlock * 13];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = i < g.d.N;
-    Agent s;
-    Spares sp;
-    load_agent(g.d.S, g.d.G, i, s, sp);
-    float a[4];
-    ring_exchange(c, g.d, i, live, sp.vel, a);
-    float kl[3], kq[3];
-    drag_of(c, g.d, i, kl, kq);
-    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
-
     EnvRegs er = unpack_env(sp);
     const float vel[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};  // dynamics.py:751-752
     Collision col = bbox_collision(e, s.p);
@@ -157,7 +149,47 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const v
     }
     pack_env(er, sp);
     store_agent(g.d.S, g.d.G, i, s, sp);
-    store_rows_coalesced<13>(g.out.obs, g.d.N, blockIdx.x * kBlock, o, tile);
+    store_rows_coalesced<13>(g.out.obs, g.d.N, wave_first, o, tile);
+}
+
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g)
+{
+    __shared__ float tile[kBlock * 13];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < g.d.N;
+    Agent s;
+    Spares sp;
+    load_agent(g.d.S, g.d.G, i, s, sp);
+    float a[4];
+    ring_exchange(c, g.d, i, live, sp.vel, a);
+    float kl[3], kq[3];
+    drag_of(c, g.d, i, kl, kq);
+    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
+    const int wave = threadIdx.x >> 6;
+    env_epilogue<KIND>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+}
+
+// Two-wave variant (SplitShared in vf_dyn_device.hpp): 256-thread workgroups = 2 rotation + 2 translation
+// waves for 128 agents (one wave per SIMD of the CU); the translation waves own the env epilogue and
+// every store.
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(kBlock) void k_env_step_split(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g)
+{
+    __shared__ SplitShared shs[2];
+    const int grp = (threadIdx.x >> 6) & 1;
+    SplitShared& sh = shs[grp];
+    const int first = blockIdx.x * 128 + grp * 64;
+    const int i = first + (threadIdx.x & 63);
+    const bool live = i < g.d.N;
+    if (threadIdx.x < 128) {
+        split_rotation_wave<ACT, INTEG, CTRL_DELAY>(c, g.d, i, live, sh);
+        return;
+    }
+    Agent s;
+    Spares sp;
+    split_translation_wave<INTEG>(c, g.d, i, sh, s, sp);
+    env_epilogue<KIND>(c, e, g, i, live, s, sp, first, sh.tile);
 }
 
 struct EnvResetArgs {
@@ -272,6 +304,32 @@ EnvKernel pick_env_kernel_k(const vf_dyn_cfg& c)
     }
 }
 
+template <int KIND>
+EnvKernel pick_env_split_k(const vf_dyn_cfg& c)
+{
+    const int key = (c.action_type == VF_ACT_BODYRATE ? 4 : 0) | (c.integrator == VF_INT_RK4 ? 2 : 0) |
+                    (c.ctrl_delay ? 1 : 0);
+    switch (key) {
+    case 0: return vf::k_env_step_split<KIND, VF_ACT_THRUST, VF_INT_EULER, false>;
+    case 1: return vf::k_env_step_split<KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    case 2: return vf::k_env_step_split<KIND, VF_ACT_THRUST, VF_INT_RK4, false>;
+    case 3: return vf::k_env_step_split<KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
+    case 4: return vf::k_env_step_split<KIND, VF_ACT_BODYRATE, VF_INT_EULER, false>;
+    case 5: return vf::k_env_step_split<KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    case 6: return vf::k_env_step_split<KIND, VF_ACT_BODYRATE, VF_INT_RK4, false>;
+    default: return vf::k_env_step_split<KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
+    }
+}
+
+EnvKernel pick_env_split(const vf_env* h)
+{
+    switch (h->cfg.kind) {
+    case VF_ENV_HOVER: return pick_env_split_k<VF_ENV_HOVER>(h->dyn.cfg);
+    case VF_ENV_NAV: return pick_env_split_k<VF_ENV_NAV>(h->dyn.cfg);
+    default: return pick_env_split_k<VF_ENV_RACING>(h->dyn.cfg);
+    }
+}
+
 EnvKernel pick_env_kernel(const vf_env* h)
 {
     switch (h->cfg.kind) {
@@ -289,7 +347,10 @@ vf::DynArgs dyn_args(const vf_env* h, const float* action, float* obs)
 int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int auto_reset, hipStream_t st)
 {
     vf::EnvArgs g{dyn_args(h, action, out->obs), *out, h->g_race, auto_reset};
-    hipLaunchKernelGGL(pick_env_kernel(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);
+    if (vf::use_split(h->dyn.Npad))
+        hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);
+    else
+        hipLaunchKernelGGL(pick_env_kernel(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
