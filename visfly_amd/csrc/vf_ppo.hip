@@ -79,9 +79,12 @@ __global__ __launch_bounds__(kBlock) void k_sum2_partial(const float* __restrict
 
 __global__ void k_sum2_final(const double* __restrict__ part, int nblk, double* __restrict__ out2, float* out_ss_f32)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0, ss = 0.0;
-        for (int b = 0; b < nblk; ++b) { s += part[2 * b]; ss += part[2 * b + 1]; }
+    // one wave: lane-strided partial sums, then the fixed shuffle tree (deterministic)
+    double s = 0.0, ss = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) { s += part[2 * b]; ss += part[2 * b + 1]; }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (threadIdx.x == 0) {
         if (out2) { out2[0] = s; out2[1] = ss; }
         if (out_ss_f32) *out_ss_f32 = (float)ss;
     }
@@ -105,8 +108,49 @@ __global__ __launch_bounds__(kBlock) void k_adv_apply(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 constexpr int kRows = 64;
 
+// Stage one 64-row tile of A (optionally masked by Ym > 0) into LDS rows of odd stride `sa`.
+// Vector path: 16-byte global loads when the row length is a multiple of 4 with a power-of-two
+// number of float4 per row (K, No in {4, 8, ..., 128}); scalar path otherwise (K = 13, 3).
+template <bool MASK>
+__device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const float* __restrict__ A, int lda,
+                                           const float* __restrict__ Ym, int ldym, int m0, int M, int red, int redp)
+{
+    const int tid = threadIdx.x;
+    const int c4 = red >> 2;
+    const bool vec = (red & 3) == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 32 && (lda & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (!MASK || !Ym || ((ldym & 3) == 0 && (reinterpret_cast<uintptr_t>(Ym) & 15) == 0));
+    if (vec) {
+        const int sh = 31 - __clz(c4);            // log2(float4 per row)
+        const int col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
+        for (int r = r0; r < kRows; r += rstep) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < M) {
+                x = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + col);
+                if (MASK && Ym) {
+                    const float4 y = *reinterpret_cast<const float4*>(Ym + (size_t)(m0 + r) * ldym + col);
+                    x.x = y.x > 0.0f ? x.x : 0.0f; x.y = y.y > 0.0f ? x.y : 0.0f;
+                    x.z = y.z > 0.0f ? x.z : 0.0f; x.w = y.w > 0.0f ? x.w : 0.0f;
+                }
+            }
+            float* d = As + r * sa + col;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        }
+    } else {
+        for (int idx = tid; idx < kRows * redp; idx += kBlock) {
+            const int r = idx / redp, k = idx - r * redp;
+            float x = 0.0f;
+            if (m0 + r < M && k < red) {
+                x = A[(size_t)(m0 + r) * lda + k];
+                if (MASK && Ym && !(Ym[(size_t)(m0 + r) * ldym + k] > 0.0f)) x = 0.0f;
+            }
+            As[r * sa + k] = x;
+        }
+    }
+}
+
 // BWD == false: C[m][n] = act(sum_k A[m][k] * W[n][k] + b[n])          (forward; red = K, cols = No)
 // BWD == true : C[m][k] = sum_n (A[m][n] * [Ymask[m][n] > 0]) * W[n][k]  (data grad; red = No, cols = K)
+// Weight-stationary: a block stages W once and walks 64-row tiles with stride gridDim.x.
 template <bool BWD, bool RELU>
 __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, int lda, const float* __restrict__ Ym,
                                                    int ldym, const float* __restrict__ W, const float* __restrict__ bias,
@@ -121,18 +165,8 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
     float* As = lds;                      // [64][sa]
     float* Ws = lds + kRows * sa;         // fwd: [ct*32][sa] (col-major over red) ; bwd: [redp][ct*32+1]
     const int sw = BWD ? ct * 32 + 1 : sa;
-    const int m0 = blockIdx.x * kRows;
     const int tid = threadIdx.x;
 
-    for (int idx = tid; idx < kRows * redp; idx += kBlock) {
-        const int r = idx / redp, k = idx - r * redp;
-        float x = 0.0f;
-        if (m0 + r < M && k < red) {
-            x = A[(size_t)(m0 + r) * lda + k];
-            if (BWD && Ym && !(Ym[(size_t)(m0 + r) * ldym + k] > 0.0f)) x = 0.0f;
-        }
-        As[r * sa + k] = x;
-    }
     if (!BWD) {
         for (int idx = tid; idx < ct * 32 * redp; idx += kBlock) {
             const int n = idx / redp, k = idx - n * redp;
@@ -145,46 +179,53 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
             Ws[n * sw + k] = (n < No && k < K) ? W[(size_t)n * K + k] : 0.0f;
         }
     }
-    __syncthreads();
+    if ((red & 1) && tid < kRows) As[tid * sa + red] = 0.0f;   // the pad column of an odd reduction length
 
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lk = lane >> 5;
     const int rt = wave & 1;              // row half
     const int c0 = wave >> 1;             // column tiles c0, c0 + 2
-    f32x16 acc0 = {0}, acc1 = {0};
     const bool has0 = c0 < ct, has1 = c0 + 2 < ct;
     const float* ap = As + (rt * 32 + lr) * sa + lk;
-    if (!BWD) {
-        const float* b0 = Ws + (c0 * 32 + lr) * sw + lk;
-        const float* b1 = Ws + ((c0 + 2) * 32 + lr) * sw + lk;
-        for (int k0 = 0; k0 < redp; k0 += 2) {
-            const float a = ap[k0];
-            if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[k0], acc0, 0, 0, 0);
-            if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[k0], acc1, 0, 0, 0);
+    const int ntiles = (M + kRows - 1) / kRows;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * kRows;
+        __syncthreads();                  // previous tile's MFMA reads of As are done (and W is staged)
+        stage_rows<BWD>(As, sa, A, lda, Ym, ldym, m0, M, red, redp);
+        __syncthreads();
+        f32x16 acc0 = {0}, acc1 = {0};
+        if (!BWD) {
+            const float* b0 = Ws + (c0 * 32 + lr) * sw + lk;
+            const float* b1 = Ws + ((c0 + 2) * 32 + lr) * sw + lk;
+            for (int k0 = 0; k0 < redp; k0 += 2) {
+                const float a = ap[k0];
+                if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[k0], acc0, 0, 0, 0);
+                if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[k0], acc1, 0, 0, 0);
+            }
+        } else {
+            const float* b0 = Ws + lk * sw + c0 * 32 + lr;
+            const float* b1 = Ws + lk * sw + (c0 + 2) * 32 + lr;
+            for (int k0 = 0; k0 < redp; k0 += 2) {
+                const float a = ap[k0];
+                if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[k0 * sw], acc0, 0, 0, 0);
+                if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[k0 * sw], acc1, 0, 0, 0);
+            }
         }
-    } else {
-        const float* b0 = Ws + lk * sw + c0 * 32 + lr;
-        const float* b1 = Ws + lk * sw + (c0 + 2) * 32 + lr;
-        for (int k0 = 0; k0 < redp; k0 += 2) {
-            const float a = ap[k0];
-            if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[k0 * sw], acc0, 0, 0, 0);
-            if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[k0 * sw], acc1, 0, 0, 0);
-        }
-    }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (!(t ? has1 : has0)) continue;
-        const f32x16& acc = t ? acc1 : acc0;
-        const int n = (c0 + 2 * t) * 32 + lr;
-        if (n >= cols) continue;
-        const float bn = (!BWD && bias) ? bias[n] : 0.0f;
+        for (int t = 0; t < 2; ++t) {
+            if (!(t ? has1 : has0)) continue;
+            const f32x16& acc = t ? acc1 : acc0;
+            const int n = (c0 + 2 * t) * 32 + lr;
+            if (n >= cols) continue;
+            const float bn = (!BWD && bias) ? bias[n] : 0.0f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int m = m0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-            if (m >= M) continue;
-            float y = acc[reg] + bn;
-            if (RELU) y = y > 0.0f ? y : 0.0f;
-            float* dst = C + (size_t)m * ldc + n;
-            *dst = accumulate ? *dst + y : y;
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                if (m >= M) continue;
+                float y = acc[reg] + bn;
+                if (RELU) y = y > 0.0f ? y : 0.0f;
+                float* dst = C + (size_t)m * ldc + n;
+                *dst = accumulate ? *dst + y : y;
+            }
         }
     }
 }
@@ -205,20 +246,11 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
     const int ntiles = nt * kt;  // <= 16, wave takes tiles wave, wave+4, ...
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
     float bsum = 0.0f;  // thread tid < No: column sum of masked dY
+    for (int idx = tid; idx < kRows * (sd + sx); idx += kBlock) lds[idx] = 0.0f;   // pad columns stay zero
+    __syncthreads();
     for (int m0 = mb; m0 < me; m0 += kRows) {
-        for (int idx = tid; idx < kRows * nt * 32; idx += kBlock) {
-            const int r = idx / (nt * 32), n = idx - r * (nt * 32);
-            float x = 0.0f;
-            if (m0 + r < me && n < No) {
-                x = dY[(size_t)(m0 + r) * lddy + n];
-                if (Ym && !(Ym[(size_t)(m0 + r) * ldym + n] > 0.0f)) x = 0.0f;
-            }
-            Ds[r * sd + n] = x;
-        }
-        for (int idx = tid; idx < kRows * kt * 32; idx += kBlock) {
-            const int r = idx / (kt * 32), k = idx - r * (kt * 32);
-            Xs[r * sx + k] = (m0 + r < me && k < K) ? X[(size_t)(m0 + r) * ldx + k] : 0.0f;
-        }
+        stage_rows<true>(Ds, sd, dY, lddy, Ym, ldym, m0, me, No, nt * 32);
+        stage_rows<false>(Xs, sx, X, ldx, nullptr, 0, m0, me, K, kt * 32);
         __syncthreads();
         if (tid < No) {
             float s = 0.0f;
@@ -256,16 +288,28 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
     if (tid < No) p[(size_t)No * K + tid] = bsum;
 }
 
+// deterministic second stage: 16 lanes share one output element, each summing every 16th partial,
+// then a fixed-order shuffle tree; 16 elements per 256-thread block
 __global__ __launch_bounds__(kBlock) void k_fold_partials(const float* __restrict__ part, int nblk, int nw, int nb,
                                                           float* __restrict__ dW, float* __restrict__ db, int accumulate)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
     const int n = nw + nb;
-    if (i >= n) return;
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15);   // output element
+    const int sl = threadIdx.x >> 4;                       // slice 0..15 (same wave: lanes e + 16*k)
     float s = 0.0f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
-    if (i < nw) dW[i] = accumulate ? dW[i] + s : s;
-    else if (db) db[i - nw] = accumulate ? db[i - nw] + s : s;
+    if (e < n)
+        for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * n + e];
+    s += __shfl_down(s, 32, 64);   // slices k and k+2 (lane + 32)
+    s += __shfl_down(s, 16, 64);   // slices k and k+1 (lane + 16)
+    __shared__ float sh[4][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 16) sh[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && e < n) {
+        const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        if (e < nw) dW[e] = accumulate ? dW[e] + t : t;
+        else if (db) db[e - nw] = accumulate ? db[e - nw] + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -385,12 +429,14 @@ __global__ __launch_bounds__(kBlock) void k_ppo_loss(const float4* __restrict__ 
 
 __global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __restrict__ stats)
 {
-    const int k = threadIdx.x;
-    if (k >= kStats) return;
+    // 16 stats x 16 lanes (256 threads): lane-strided sums over the blocks, shuffle tree over the 16 lanes
+    const int k = threadIdx.x >> 4, sl = threadIdx.x & 15;
     float s = 0.0f;
     if (k < 9)
-        for (int b = 0; b < nblk; ++b) s += part[(size_t)b * kStats + k];
-    stats[k] = s;
+        for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * kStats + k];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
+    if (sl == 0) stats[k] = s;
 }
 
 // clip_grad_norm_ + Adam with L2 weight decay (torch.optim.Adam semantics), PPO.py:285-292
@@ -442,9 +488,15 @@ int allow_lds(Kern k, size_t bytes)
     return VF_OK;
 }
 
+int linear_grid(int M)
+{
+    const int ntiles = (M + vf::kRows - 1) / vf::kRows;
+    return ntiles < 512 ? ntiles : 512;   // weight-stationary blocks, two per CU
+}
+
 int wgrad_rows_per_block(int M)
 {
-    int rpb = (M + 511) / 512;  // aim at <= 512 chunks
+    int rpb = (M + 255) / 256;  // aim at <= 256 chunks (one per CU), each a multiple of the 64-row tile
     rpb = (rpb + vf::kRows - 1) / vf::kRows * vf::kRows;
     return rpb < vf::kRows ? vf::kRows : rpb;
 }
@@ -490,7 +542,7 @@ int vf_linear_fwd(const float* X, int32_t ldx, const float* W, const float* b, f
     if (!X || !W || !Y || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128 || ldx < K || ldy < No)
         return vf::fail(VF_EINVAL, "vf_linear_fwd: bad argument (K, No <= 128)");
     const size_t lds = linear_lds_bytes(false, K, No);
-    const dim3 grid((M + vf::kRows - 1) / vf::kRows), block(vf::kBlock);
+    const dim3 grid(linear_grid(M)), block(vf::kBlock);
     hipStream_t st = vf::as_stream(stream);
     if (relu) {
         if (int rc = allow_lds(vf::k_linear<false, true>, lds)) return rc;
@@ -510,7 +562,7 @@ int vf_linear_bwd_data(const float* dY, int32_t lddy, const float* Ymask, int32_
         return vf::fail(VF_EINVAL, "vf_linear_bwd_data: bad argument (K, No <= 128)");
     const size_t lds = linear_lds_bytes(true, K, No);
     if (int rc = allow_lds(vf::k_linear<true, false>, lds)) return rc;
-    hipLaunchKernelGGL((vf::k_linear<true, false>), dim3((M + vf::kRows - 1) / vf::kRows), dim3(vf::kBlock), lds,
+    hipLaunchKernelGGL((vf::k_linear<true, false>), dim3(linear_grid(M)), dim3(vf::kBlock), lds,
                        vf::as_stream(stream), dY, lddy, Ymask, ldym, W, (const float*)nullptr, dX, lddx, M, K, No, accumulate);
     VF_HIP(hipGetLastError());
     return VF_OK;
@@ -538,7 +590,7 @@ static int linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, 
     hipLaunchKernelGGL(vf::k_linear_wgrad, dim3(nblk), dim3(vf::kBlock), lds, st, dY, lddy, Ymask, ldym, X, ldx, scratch, M, K,
                        No, rpb);
     const int n = No * K + No;
-    hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + vf::kBlock - 1) / vf::kBlock), dim3(vf::kBlock), 0, st, scratch, nblk,
+    hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 15) / 16), dim3(vf::kBlock), 0, st, scratch, nblk,
                        No * K, No, dW, db, accumulate);
     VF_HIP(hipGetLastError());
     return VF_OK;
@@ -580,7 +632,7 @@ int vf_ppo_loss(const float* mean, const float* value, const float* log_std, con
     hipLaunchKernelGGL(vf::k_ppo_loss, dim3(nblk), dim3(vf::kBlock), 0, st, reinterpret_cast<const float4*>(mean), value,
                        log_std, reinterpret_cast<const float4*>(action), old_log_prob, adv, ret,
                        reinterpret_cast<float4*>(d_mean), d_value, scratch, M, *cfg);
-    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(64), 0, st, scratch, nblk, stats);
+    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(256), 0, st, scratch, nblk, stats);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
