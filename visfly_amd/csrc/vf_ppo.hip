@@ -113,7 +113,8 @@ constexpr int kRows = 64;
 // number of float4 per row (K, No in {4, 8, ..., 128}); scalar path otherwise (K = 13, 3).
 template <bool MASK>
 __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const float* __restrict__ A, int lda,
-                                           const float* __restrict__ Ym, int ldym, int m0, int M, int red, int redp)
+                                           const float* __restrict__ Ym, int ldym, int m0, int M, int red, int redp,
+                                           int nrows = kRows)
 {
     const int tid = threadIdx.x;
     const int c4 = red >> 2;
@@ -122,7 +123,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
     if (vec) {
         const int sh = 31 - __clz(c4);            // log2(float4 per row)
         const int col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
-        for (int r = r0; r < kRows; r += rstep) {
+        for (int r = r0; r < nrows; r += rstep) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m0 + r < M) {
                 x = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + col);
@@ -136,7 +137,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
             d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
         }
     } else {
-        for (int idx = tid; idx < kRows * redp; idx += kBlock) {
+        for (int idx = tid; idx < nrows * redp; idx += kBlock) {
             const int r = idx / redp, k = idx - r * redp;
             float x = 0.0f;
             if (m0 + r < M && k < red) {
@@ -167,19 +168,12 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
     const int sw = BWD ? ct * 32 + 1 : sa;
     const int tid = threadIdx.x;
 
-    if (!BWD) {
-        for (int idx = tid; idx < ct * 32 * redp; idx += kBlock) {
-            const int n = idx / redp, k = idx - n * redp;
-            Ws[n * sw + k] = (n < No && k < K) ? W[(size_t)n * K + k] : 0.0f;
-        }
-    } else {
-        const int cw = ct * 32;
-        for (int idx = tid; idx < redp * cw; idx += kBlock) {
-            const int n = idx / cw, k = idx - n * cw;
-            Ws[n * sw + k] = (n < No && k < K) ? W[(size_t)n * K + k] : 0.0f;
-        }
-    }
-    if ((red & 1) && tid < kRows) As[tid * sa + red] = 0.0f;   // the pad column of an odd reduction length
+    // W image: Ws[n * sw + k] = W[n][k] for both directions (forward reads it column-major over the
+    // reduction, the data gradient row-major); pads are zero.
+    const int wrows = BWD ? redp : ct * 32, wcols = BWD ? ct * 32 : redp;
+    for (int idx = tid; idx < kRows * sa + wrows * sw; idx += kBlock) lds[idx] = 0.0f;
+    __syncthreads();
+    stage_rows<false>(Ws, sw, W, K, nullptr, 0, 0, No, K, wcols, wrows);
 
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lk = lane >> 5;
     const int rt = wave & 1;              // row half
@@ -193,21 +187,24 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
         stage_rows<BWD>(As, sa, A, lda, Ym, ldym, m0, M, red, redp);
         __syncthreads();
         f32x16 acc0 = {0}, acc1 = {0};
-        if (!BWD) {
-            const float* b0 = Ws + (c0 * 32 + lr) * sw + lk;
-            const float* b1 = Ws + ((c0 + 2) * 32 + lr) * sw + lk;
-            for (int k0 = 0; k0 < redp; k0 += 2) {
-                const float a = ap[k0];
-                if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[k0], acc0, 0, 0, 0);
-                if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[k0], acc1, 0, 0, 0);
+        // fragments for 8 k-pairs are fetched from LDS ahead of the 8 (or 16) MFMAs that consume them
+        const float* b0 = BWD ? Ws + lk * sw + c0 * 32 + lr : Ws + (c0 * 32 + lr) * sw + lk;
+        const float* b1 = BWD ? Ws + lk * sw + (c0 + 2) * 32 + lr : Ws + ((c0 + 2) * 32 + lr) * sw + lk;
+        const int bs = BWD ? sw : 1;      // LDS stride of one step along the reduction for the B fragment
+        for (int k0 = 0; k0 < redp; k0 += 16) {
+            float a[8], x0[8], x1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + 2 * j;
+                const bool ok = k < redp;
+                a[j] = ok ? ap[k] : 0.0f;
+                x0[j] = (ok && has0) ? b0[k * bs] : 0.0f;
+                x1[j] = (ok && has1) ? b1[k * bs] : 0.0f;
             }
-        } else {
-            const float* b0 = Ws + lk * sw + c0 * 32 + lr;
-            const float* b1 = Ws + lk * sw + (c0 + 2) * 32 + lr;
-            for (int k0 = 0; k0 < redp; k0 += 2) {
-                const float a = ap[k0];
-                if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[k0 * sw], acc0, 0, 0, 0);
-                if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[k0 * sw], acc1, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x0[j], acc0, 0, 0, 0);
+                if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x1[j], acc1, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -252,10 +249,14 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
         stage_rows<true>(Ds, sd, dY, lddy, Ym, ldym, m0, me, No, nt * 32);
         stage_rows<false>(Xs, sx, X, ldx, nullptr, 0, m0, me, K, kt * 32);
         __syncthreads();
-        if (tid < No) {
-            float s = 0.0f;
-            for (int r = 0; r < kRows; ++r) s += Ds[r * sd + tid];
-            bsum += s;
+        {   // bias gradient: every thread owns (column, row-slice); slices are combined at the end
+            const int cgrp = No <= 64 ? 64 : 128, c = tid & (cgrp - 1), part = tid / cgrp, rows = kRows * cgrp / kBlock;
+            if (c < No) {
+                float s0 = 0.0f, s1 = 0.0f;
+                const float* dp = Ds + (part * rows) * sd + c;
+                for (int r = 0; r < rows; r += 2) { s0 += dp[r * sd]; s1 += dp[(r + 1) * sd]; }
+                bsum += s0 + s1;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -265,8 +266,14 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
             const float* ap = Ds + lk * sd + it * 32 + lr;
             const float* bp = Xs + lk * sx + jt * 32 + lr;
             f32x16 c = acc[q];
-            for (int k0 = 0; k0 < kRows; k0 += 2)
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k0 * sd], bp[k0 * sx], c, 0, 0, 0);
+#pragma unroll
+            for (int k0 = 0; k0 < kRows; k0 += 16) {   // fetch 8 fragment pairs, then 8 MFMAs
+                float fa[8], fb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { fa[j] = ap[(k0 + 2 * j) * sd]; fb[j] = bp[(k0 + 2 * j) * sx]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], c, 0, 0, 0);
+            }
             acc[q] = c;
         }
         __syncthreads();
@@ -285,7 +292,17 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
             if (n < No) p[(size_t)n * K + k] = acc[q][reg];
         }
     }
-    if (tid < No) p[(size_t)No * K + tid] = bsum;
+    {
+        __syncthreads();
+        const int cgrp = No <= 64 ? 64 : 128, c = tid & (cgrp - 1), part = tid / cgrp, nparts = kBlock / cgrp;
+        lds[part * cgrp + c] = bsum;
+        __syncthreads();
+        if (tid < No) {
+            float t = 0.0f;
+            for (int q = 0; q < nparts; ++q) t += lds[q * cgrp + tid];
+            p[(size_t)No * K + tid] = t;
+        }
+    }
 }
 
 // deterministic second stage: 16 lanes share one output element, each summing every 16th partial,
