@@ -258,6 +258,11 @@ int vf_gae(const float* rewards, const float* values, const float* episode_start
            const float* dones, float* adv, float* ret, int32_t T, int32_t N, double gamma, double lam,
            vf_stream_t stream);
 
+/* TD-lambda returns with a per-env lambda reset on done (SHAC critic targets,
+ * utils/algorithms/common.py:893-923), thread per env.  [H][N] arrays; episode_done NULL = done. */
+int vf_td_returns(const float* r, const uint8_t* done, const uint8_t* episode_done, const float* next_value,
+                  float* returns, int32_t H, int32_t N, double gamma, double lamda, vf_stream_t stream);
+
 /* Advantage normalisation of one minibatch (PPO.py:215-220): (A - mean) / (std_unbiased + 1e-8).
  * scratch: >= 2*1024 floats.  If sums_inout != NULL the two partial sums (sum, sum of squares, fp64
  * as 2 doubles) are left there after `phase` 0 and consumed in `phase` 1, so that a multi-GPU caller

@@ -120,6 +120,9 @@ def lib():
         L.vfo_env_reset_attr.restype = None
         L.vfo_gae.argtypes = [fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_double, C.c_double]
         L.vfo_gae.restype = None
+        up = C.POINTER(C.c_uint8)
+        L.vfo_td_returns.argtypes = [fp, up, up, fp, fp, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.vfo_td_returns.restype = None
         _lib = L
     return _lib
 
@@ -280,3 +283,14 @@ class OracleEnv:
         self.a["once_collided"][idx] = 0
         lib().vfo_env_reset_attr(self.N, C.byref(self.es), _ip(idx), len(idx))
 
+
+
+def td_returns(r, done, next_value, episode_done=None, gamma=0.99, lamda=0.95):
+    H, N = r.shape
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    u = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+    r, nv, d, ed = f(r), f(next_value), u(done), u(episode_done)
+    out = np.empty((H, N), np.float32)
+    up = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
+    lib().vfo_td_returns(_fp(r), up(d), up(ed), _fp(nv), _fp(out), H, N, float(gamma), float(lamda))
+    return out

@@ -499,6 +499,30 @@ def gen_bptt(name, N=64, seed=42):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def gen_td(name="td_lambda", H=24, N=40, seed=3):
+    """compute_td_returns of the reference (utils/algorithms/common.py:893-923), imported through the stubs"""
+    import_envs()
+    for n in ("stable_baselines3.common.buffers", "stable_baselines3.common.type_aliases",
+              "stable_baselines3.common.preprocessing", "stable_baselines3.common.utils", "stable_baselines3.common.vec_env.base_vec_env"):
+        if n not in sys.modules:
+            _auto(n)
+    sys.modules["stable_baselines3.common.buffers"].BaseBuffer = type("BaseBuffer", (), {})
+    from VisFly.utils.algorithms.common import compute_td_returns
+    rng = np.random.default_rng(seed)
+    r = rng.normal(size=(H, N)).astype(np.float32)
+    nv = rng.normal(size=(H, N)).astype(np.float32)
+    done = rng.uniform(size=(H, N)) < 0.12
+    ep = done & (rng.uniform(size=(H, N)) < 0.6)
+    out = {}
+    for tag, e in (("", None), ("_ep", ep)):
+        ret = compute_td_returns([th.from_numpy(x) for x in r], [th.from_numpy(x) for x in done], [th.from_numpy(x) for x in nv],
+                                 None if e is None else [th.from_numpy(x) for x in e], gamma=0.99, lamda=0.95)
+        out["returns" + tag] = np.stack([f32(x) for x in ret])
+    print(f"{name}: H={H} N={N} dones={int(done.sum())}")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), r=r, next_value=nv, done=done.astype(np.uint8),
+                        episode_done=ep.astype(np.uint8), gamma=np.float64(0.99), lamda=np.float64(0.95), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -513,6 +537,8 @@ def main():
     for name in BPTT_CASES:
         if args.only in (None, name):
             gen_bptt(name)
+    if args.only in (None, "td_lambda"):
+        gen_td()
 
 
 if __name__ == "__main__":

@@ -488,3 +488,27 @@ void vfo_gae(const float* rewards, const float* values, const float* episode_sta
             ret[(size_t)t * N + i] = adv[(size_t)t * N + i] + values[(size_t)t * N + i];
     }
 }
+
+/* ---------- TD-lambda returns (SHAC critic targets) ---------- */
+
+void vfo_td_returns(const float* r, const uint8_t* done, const uint8_t* episode_done, const float* next_value,
+                    float* returns, int H, int N, double gamma_d, double lamda_d)
+{
+    /* utils/algorithms/common.py:893-923.  python floats enter each torch op as fp32 scalars:
+     * lamda*gamma is a double product rounded once; (1.0 - lamda) likewise. */
+    const float gamma = (float)gamma_d, lamda = (float)lamda_d, lg = (float)(lamda_d * gamma_d);
+    const float oml = (float)(1.0 - lamda_d);
+    if (!episode_done) episode_done = done;
+    for (int i = 0; i < N; ++i) {
+        float Ai = 0.0f, lam = 1.0f;
+        float Bi = next_value[(size_t)(H - 1) * N + i] * (float)(!done[(size_t)(H - 1) * N + i]);
+        for (int t = H - 1; t >= 0; --t) {
+            const size_t o = (size_t)t * N + i;
+            const float active = (float)(!done[o]), dm = (float)(done[o] != 0), ea = (float)(!episode_done[o]);
+            lam = lam * lamda * active + dm;
+            Ai = active * ((lg * Ai + gamma * next_value[o]) + ((1.0f - lam) / oml) * r[o]);
+            Bi = gamma * (next_value[o] * dm * ea + Bi * active) + r[o];
+            returns[o] = oml * Ai + lam * Bi;
+        }
+    }
+}

@@ -57,3 +57,15 @@ def test_gae_hand_computed():
     es[2, 0] = 1.0
     a, _ = oracle.gae(r, v, es, lv, d, 0.5, 0.5)
     assert a[:, 0].tolist() == [1 + .25 * 1.0, 2.0 - 1.0, 6.0]
+
+
+def test_td_lambda_oracle_bit_exact_vs_reference_function():
+    """vfo_td_returns against golden vectors produced by the reference's compute_td_returns
+    (utils/algorithms/common.py:893-923, imported through the stubs by oracle/gen_golden.py::gen_td)"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _golden import load
+    fx = load("td_lambda")
+    for tag, ed in (("", None), ("_ep", fx["episode_done"])):
+        out = oracle.td_returns(fx["r"], fx["done"], fx["next_value"], ed, float(fx["gamma"]), float(fx["lamda"]))
+        assert np.array_equal(out.view(np.uint32), fx["returns" + tag].view(np.uint32))

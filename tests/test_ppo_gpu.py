@@ -37,6 +37,28 @@ def test_gae_kernel_bit_exact_vs_oracle():
         assert np.array_equal(ret.cpu().numpy().view(np.uint32), r0.view(np.uint32))
 
 
+def test_td_lambda_kernel_bit_exact_vs_golden_and_oracle():
+    from _golden import load
+    _lib, lib = L()
+    fx = load("td_lambda")
+    for tag, ed in (("", None), ("_ep", fx["episode_done"])):
+        H, N = fx["r"].shape
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        r, d, e, nv = t(fx["r"]), t(fx["done"]), t(ed), t(fx["next_value"])
+        out = torch.empty((H, N), device=DEV)
+        _lib.check(lib.vf_td_returns(r.data_ptr(), d.data_ptr(), None if e is None else e.data_ptr(), nv.data_ptr(),
+                                     out.data_ptr(), H, N, float(fx["gamma"]), float(fx["lamda"]), st()))
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), fx["returns" + tag].view(np.uint32))
+    g = np.random.default_rng(0)
+    H, N = 64, 70001
+    r, nv = g.normal(size=(H, N)).astype(np.float32), g.normal(size=(H, N)).astype(np.float32)
+    d = (g.uniform(size=(H, N)) < 0.05).astype(np.uint8)
+    out = torch.empty((H, N), device=DEV)
+    rd, dd, nvd = (torch.from_numpy(x).to(DEV) for x in (r, d, nv))
+    _lib.check(lib.vf_td_returns(rd.data_ptr(), dd.data_ptr(), None, nvd.data_ptr(), out.data_ptr(), H, N, 0.99, 0.95, st()))
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.td_returns(r, d, nv, None, 0.99, 0.95).view(np.uint32))
+
+
 def test_adv_normalize_vs_torch():
     _lib, lib = L()
     for n in [2, 1000, 25600, 1 << 20]:

@@ -40,6 +40,26 @@ __global__ __launch_bounds__(kBlock) void k_gae(const float* __restrict__ r, con
     }
 }
 
+// TD-lambda returns (utils/algorithms/common.py:893-923): same access pattern as GAE
+__global__ __launch_bounds__(kBlock) void k_td_returns(const float* __restrict__ r, const unsigned char* __restrict__ done,
+                                                       const unsigned char* __restrict__ ep_done,
+                                                       const float* __restrict__ nv, float* __restrict__ ret, int H, int N,
+                                                       float gamma, float lamda, float lg, float oml)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    float Ai = 0.0f, lam = 1.0f;
+    float Bi = nv[(size_t)(H - 1) * N + i] * (done[(size_t)(H - 1) * N + i] ? 0.0f : 1.0f);
+    for (int t = H - 1; t >= 0; --t) {
+        const size_t o = (size_t)t * N + i;
+        const float active = done[o] ? 0.0f : 1.0f, dm = done[o] ? 1.0f : 0.0f, ea = ep_done[o] ? 0.0f : 1.0f;
+        lam = lam * lamda * active + dm;
+        Ai = active * ((lg * Ai + gamma * nv[o]) + ((1.0f - lam) / oml) * r[o]);
+        Bi = gamma * (nv[o] * dm * ea + Bi * active) + r[o];
+        ret[o] = oml * Ai + lam * Bi;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------
@@ -529,6 +549,17 @@ int vf_gae(const float* rewards, const float* values, const float* episode_start
         return vf::fail(VF_EINVAL, "vf_gae: bad argument");
     hipLaunchKernelGGL(vf::k_gae, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), rewards, values,
                        episode_starts, last_values, dones, adv, ret, T, N, (float)gamma, (float)(gamma * lam));
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_td_returns(const float* r, const uint8_t* done, const uint8_t* episode_done, const float* next_value, float* returns,
+                  int32_t H, int32_t N, double gamma, double lamda, vf_stream_t stream)
+{
+    if (!r || !done || !next_value || !returns || H <= 0 || N <= 0) return vf::fail(VF_EINVAL, "vf_td_returns: bad argument");
+    hipLaunchKernelGGL(vf::k_td_returns, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), r, done,
+                       episode_done ? episode_done : done, next_value, returns, H, N, (float)gamma, (float)lamda,
+                       (float)(lamda * gamma), (float)(1.0 - lamda));
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
