@@ -30,29 +30,37 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def cpu_baseline(consts, seconds_target=15.0):
-    """TEST/BENCH INFRASTRUCTURE: time the CPU oracle (C restatement, OpenMP over agents) on the
-    host cores of this box on a bounded sample of the same workload."""
+    """TEST/BENCH INFRASTRUCTURE: time the CPU oracle (C restatement, OpenMP over agents) on the host
+    cores of this box on a bounded sample of the same workload: HoverEnv.step = dynamics interval +
+    bbox collision + reward / counters / done masks (no auto-reset inside the sample: episodes are
+    256 steps long and the sample is re-spawned every 192 steps)."""
     import oracle
     N = AGENTS_PER_GPU
-    od = oracle.OracleDynamics(consts, N)
+    env = oracle.OracleEnv(consts, N, "hover", 256, target=(1.0, 0.0, 1.5))
     rng = np.random.default_rng(0)
-    pos = (np.array([1, 0, 1.5]) + rng.uniform(-1, 1, (N, 3)) * np.array([1, 1, .5])).astype(np.float32)
-    od.reset(pos=pos)
+    fs = np.zeros((N, 22), np.float32)
+    fs[:, 0:3] = (np.array([1, 0, 1.5]) + rng.uniform(-1, 1, (N, 3)) * np.array([1, 1, .5])).astype(np.float32)
+    fs[:, 3] = 1.0
+    fs[:, 13:17], fs[:, 17:21] = consts["w_init"], consts["T_init"]
     a = np.clip(np.array([-1 / 3, 0, 0, 0]) + rng.uniform(-.02, .02, (N, 4)), -1, 1).astype(np.float32)
+    env.reset_full_state(fs)
     for _ in range(2):
-        od.step(a)
+        env.step(a)
     t0 = time.perf_counter()
     steps = 0
     while True:
+        if steps % 192 == 0:
+            env.reset_full_state(fs)
         for _ in range(8):
-            od.step(a)
+            env.step(a)
         steps += 8
         el = time.perf_counter() - t0
-        if el > seconds_target or steps >= 4096:
+        if el > seconds_target or steps >= 8192:
             break
     cores = len(os.sched_getaffinity(0))
     return {"value": N * steps / el, "unit": "agent-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/vf_oracle.c (OpenMP, {cores} threads), N={N}, {steps} control steps, {el:.1f} s"}
+            "sample": f"oracle/vf_oracle.c HoverEnv.step restatement (OpenMP, {cores} threads), N={N}, "
+                      f"{steps} control steps, {el:.1f} s"}
 
 
 def bench_ppo(args, rank, world, dev):

@@ -96,7 +96,7 @@ void vfo_dyn_step(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
     const int slot = D > 0 ? (int)((*tick) % D) : 0;
     const float dt = c->dt;
 
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N >= 4096)
     for (int i = 0; i < N; ++i) {
 #define ROW(r) S[(size_t)(r) * N + i]
         /* ---- delay queue: use oldest, store newest   dynamics.py:323-328 ---- */
@@ -337,6 +337,7 @@ void vfo_update_collision(const vfo_env_consts* e, int N, const float* S, vfo_en
     /* NB the reference recomputes vector/dis/flags for ALL agents even for an
      * indexed call (droneEnv.py:364-369); only collision_point is indexed. */
     const int n = idx ? k : N;
+#pragma omp parallel for schedule(static) if (N >= 4096)
     for (int j = 0; j < n; ++j) {
         const int i = idx ? idx[j] : j;
         float p[3] = { S[(size_t)(VFO_POS)*N + i], S[(size_t)(VFO_POS + 1) * N + i], S[(size_t)(VFO_POS + 2) * N + i] };
@@ -349,6 +350,7 @@ void vfo_update_collision(const vfo_env_consts* e, int N, const float* S, vfo_en
         cp[best % 3] = best < 3 ? e->bbox_lo[best] : e->bbox_hi[best - 3]; /* :352 */
         for (int d = 0; d < 3; ++d) es->col_point[3 * (size_t)i + d] = cp[d];
     }
+#pragma omp parallel for schedule(static) if (N >= 4096)
     for (int i = 0; i < N; ++i) {
         float p[3] = { S[(size_t)(VFO_POS)*N + i], S[(size_t)(VFO_POS + 1) * N + i], S[(size_t)(VFO_POS + 2) * N + i] };
         uint8_t oob = 0;
@@ -379,6 +381,7 @@ static float hover_like_reward(const float* p, const float* tgt, const float* q,
 void vfo_env_post_step(const vfo_consts* c, const vfo_env_consts* e, int N, const float* S,
                        vfo_env_state* es)
 {
+#pragma omp parallel for schedule(static) if (N >= 4096)
     for (int i = 0; i < N; ++i) {
 #define ROW(r) S[(size_t)(r) * N + i]
         float p[3] = { ROW(VFO_POS), ROW(VFO_POS + 1), ROW(VFO_POS + 2) };
