@@ -166,3 +166,54 @@ def test_config3_navigation_rk4_ctrl_delay_drag_randomisation():
     for _ in range(5):
         env2.step(torch.zeros((256, 4), device="cuda"))
     assert (env2.envs.dynamics.drag_coefficients[0] != k0).any(dim=1).all()
+
+
+def test_edge_cases_empty_reset_single_agent_action_validation():
+    import oracle
+    from visfly_amd.envs import HoverEnv
+    from visfly_amd import Dynamics
+    # empty index list: no-op
+    d = Dynamics(num=70, device="cuda:0", action_type="bodyrate", dt=0.0025, ctrl_dt=0.02)
+    before = d.full_state.clone()
+    d.reset(indices=torch.zeros(0, dtype=torch.int64))
+    assert torch.equal(before, d.full_state)
+    # one agent (a single lane of a padded wave), euler orientation output shape
+    env = HoverEnv(num_agent_per_scene=1, dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True, seed=11)
+    obs = env.reset()
+    ref = oracle.OracleEnv(env.envs.dynamics.constants, 1, "hover", 256)
+    ref.reset_full_state(env.full_state.cpu().numpy())
+    for k in range(20):
+        a = torch.tensor([[-0.3, 0.1 * np.sin(k), 0.05, 0.0]])
+        o, r, dn, _ = env.step(a.cuda())
+        ro, rr, rd = ref.step(a.numpy())
+        assert_bits_equal(o["state"].cpu().numpy(), ro, f"single agent @ {k}")
+        assert_bits_equal(r.cpu().numpy(), rr, f"single agent reward @ {k}")
+    de = Dynamics(num=5, device="cuda:0", ori_output_type="euler")
+    assert de.orientation.shape == (5, 3) and de.state.shape == (5, 12)
+    # |action| > 1 is an AssertionError when validation is on (droneGymEnv.py:144)
+    env2 = HoverEnv(num_agent_per_scene=8, dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True,
+                    validate_actions=True)
+    env2.reset()
+    with pytest.raises(AssertionError):
+        env2.step(torch.full((8, 4), 1.5, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        HoverEnv(num_agent_per_scene=8, visual=True, device="cuda:0")
+
+
+def test_million_agent_invariants():
+    """maximum practical size: 1 048 576 agents through the fused env step (plain kernel shape)"""
+    from visfly_amd.envs import HoverEnv
+    N = 1 << 20
+    env = HoverEnv(num_agent_per_scene=N, dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True,
+                   max_episode_steps=16, seed=2)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    total_done = 0
+    for k in range(20):
+        a = ((torch.rand((N, 4), device="cuda", generator=g) * 2 - 1) * 0.2 + torch.tensor([-1 / 3, 0, 0, 0], device="cuda"))
+        obs, r, d, _ = env.step(a)
+        total_done += int(d.sum())
+    assert torch.isfinite(obs["state"]).all() and torch.isfinite(r).all()
+    assert total_done >= N                       # everyone timed out once at step 16
+    assert int(env._step_count.max()) <= 16
+    assert ((obs["state"][:, 3:7].norm(dim=1) - 1).abs() < 1e-5).all()

@@ -1,0 +1,65 @@
+"""Host-side logic that needs no GPU: spawn-box parsing, the replay spawner's draw order,
+TensorDict, airframe table."""
+import numpy as np
+import pytest
+import torch
+
+from visfly_amd.envs.randomization import ReplaySpawner, spawn_boxes
+from visfly_amd.type import TensorDict
+
+
+def test_spawn_boxes_parsing():
+    assert spawn_boxes(None)[0]["position"] == {"mean": [0., 0., 0.], "half": [0., 0., 0.]}
+    rk = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1, 0, 1.5], "half": [1, 1, .5]}}]}}
+    b = spawn_boxes(rk)
+    assert len(b) == 1 and b[0]["position"]["half"] == [1.0, 1.0, 0.5] and b[0]["velocity"]["half"] == [0., 0., 0.]
+    union = {"state_generator": {"class": "Union", "kwargs": [{"randomizers_kwargs": [
+        {"class": "Uniform", "kwargs": {"position": {"mean": [2, 2, 1], "half": [.2, .2, .2]}}},
+        {"class": "Uniform", "kwargs": {"position": {"mean": [6, 2, 1.5], "half": [.2, .2, .2]}}}]}]}}
+    assert len(spawn_boxes(union)) == 2
+    with pytest.raises(NotImplementedError):
+        spawn_boxes({"state_generator": {"class": "Normal", "kwargs": [{}]}})
+    with pytest.raises(NotImplementedError):
+        spawn_boxes({"state_generator": {"class": "Uniform", "kwargs": [{"heading": True}]}})
+
+
+def test_replay_spawner_draw_order_uniform():
+    """per agent: pos(3), ori(3), vel(3), ang-vel(3) uniforms, agent after agent (randomization.py:153-170,
+    droneEnv.py:243-249) -- reproduced with explicit per-agent draws on an equally seeded generator"""
+    box = spawn_boxes({"state_generator": {"class": "Uniform", "kwargs": [
+        {"position": {"mean": [1., 0., 1.5], "half": [1., 1., .5]}, "orientation": {"mean": [0., 0., 0.], "half": [.1, .2, .3]},
+         "velocity": {"mean": [0., 0., 0.], "half": [1., 1., 1.]}}]}})
+    g1, g2 = torch.Generator().manual_seed(42), torch.Generator().manual_seed(42)
+    p, q, v, w = ReplaySpawner(box, g1).generate(5)
+    for i in range(5):
+        up, uo, uv, uw = (2 * torch.rand(1, 3, generator=g2) - 1 for _ in range(4))
+        assert torch.equal(p[i], (torch.tensor([1., 0., 1.5]) + up * torch.tensor([1., 1., .5]))[0])
+        assert torch.equal(v[i], (uv * torch.tensor([1., 1., 1.]))[0])
+        assert torch.equal(w[i], (uw * 0)[0])
+    assert torch.allclose(q.norm(dim=1), torch.ones(5), atol=1e-6)
+    assert torch.equal(torch.rand(3, generator=g1), torch.rand(3, generator=g2))      # streams stay aligned
+
+
+def test_replay_spawner_union_draw_order():
+    boxes = spawn_boxes({"state_generator": {"class": "Union", "kwargs": [{"randomizers_kwargs": [
+        {"class": "Uniform", "kwargs": {"position": {"mean": [2., 2., 1.], "half": [.2, .2, .2]}}},
+        {"class": "Uniform", "kwargs": {"position": {"mean": [6., 2., 1.5], "half": [.2, .2, .2]}}},
+        {"class": "Uniform", "kwargs": {"position": {"mean": [6., -2., 1.5], "half": [.2, .2, .2]}}}]}]}})
+    g1, g2 = torch.Generator().manual_seed(7), torch.Generator().manual_seed(7)
+    p, _, _, _ = ReplaySpawner(boxes, g1).generate(4)
+    means = torch.tensor([[2., 2., 1.], [6., 2., 1.5], [6., -2., 1.5]])
+    for i in range(4):
+        cand = []
+        for m in means:                       # every member draws its 12 uniforms (randomization.py:286-290)
+            u = [2 * torch.rand(1, 3, generator=g2) - 1 for _ in range(4)]
+            cand.append(m + u[0][0] * 0.2)
+        sel = int(torch.randint(0, 3, (1,), generator=g2))
+        assert torch.equal(p[i], cand[sel])
+
+
+def test_tensordict_surface():
+    d = TensorDict({"state": torch.arange(6.).reshape(2, 3), "target": torch.ones(2, 3)})
+    assert len(d) == 2 and d[0]["state"].shape == (1, 3) and set(d.detach().keys()) == {"state", "target"}
+    s = TensorDict.stack([d, d])
+    assert s["state"].shape == (2, 2, 3)
+    assert isinstance(d.numpy()["state"], np.ndarray)
