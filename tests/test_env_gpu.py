@@ -217,3 +217,23 @@ def test_million_agent_invariants():
     assert total_done >= N                       # everyone timed out once at step 16
     assert int(env._step_count.max()) <= 16
     assert ((obs["state"][:, 3:7].norm(dim=1) - 1).abs() < 1e-5).all()
+
+
+def test_scene_reset_and_stack_recover():
+    from visfly_amd.envs import HoverEnv
+    env = HoverEnv(num_agent_per_scene=8, num_scene=4, dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True, seed=1)
+    env.reset()
+    for _ in range(5):
+        env.step(torch.zeros((32, 4), device="cuda"))
+    before = env.full_state.clone()
+    env.reset_env_by_id(torch.tensor([1, 3]))                       # droneGymEnv.py:329-337
+    after, sc = env.full_state, env._step_count
+    changed = (after != before).any(dim=1).cpu()
+    assert changed.tolist() == [False] * 8 + [True] * 8 + [False] * 8 + [True] * 8
+    assert sc.cpu().tolist() == [5] * 8 + [0] * 8 + [5] * 8 + [0] * 8
+    env.envs.stack()                                                # droneEnv.py:387-396
+    q, v = env.orientation.clone(), env.velocity.clone()
+    for _ in range(3):
+        env.step(torch.rand((32, 4), device="cuda") * 0.2 - 0.4)
+    env.envs.recover()
+    assert torch.equal(env.orientation, q) and torch.equal(env.velocity, v) and int(env._step_count.max()) == 0

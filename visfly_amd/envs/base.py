@@ -114,6 +114,25 @@ class DroneEnvsBase:
     def detach(self):
         self.dynamics.detach()
 
+    def stack(self):
+        """droneEnv.py:387-393: in-memory snapshot of the pose of every agent"""
+        d = self.dynamics
+        self._stack_cache = (d.position.clone(), d.quaternion.clone(), d.velocity.clone(), d.angular_velocity.clone())
+
+    def recover(self):
+        """droneEnv.py:395-396: reset_agents(state=snapshot) -- positions are re-drawn (pos_reset_by_state=False)"""
+        p, q, v, w = self._stack_cache
+        o, d = self._o, self.dynamics
+        fs = th.zeros((d.num, 22), device=d.device)
+        fs[:, 3:7], fs[:, 7:10], fs[:, 10:13] = q, v - d._wind, w
+        fs[:, 13:17], fs[:, 17:21] = float(d.constants["w_init"]), float(d.constants["T_init"])
+        if o.spawn_mode == "replay":
+            fs[:, 0:3] = o._spawner.generate(d.num)[0].to(d.device)
+        else:
+            o._reset_kernel(None, None)               # device spawn draws the positions ...
+            fs[:, 0:3] = d.position
+        o._reset_kernel(None, fs)                     # ... then the snapshot attitude / velocities are restored
+
     def close(self):
         pass
 
@@ -357,6 +376,13 @@ class DroneGymEnvsBase:
         for i in idx.tolist():
             self._info[i] = {"TimeLimit.truncated": False, "episode_done": False}
         return self._observations
+
+    def reset_env_by_id(self, scene_indices=None):
+        """droneGymEnv.py:329-337: re-spawn every agent of the given scenes"""
+        assert not isinstance(scene_indices, bool)
+        sc = th.arange(self.num_scene) if scene_indices is None else th.atleast_1d(th.as_tensor(scene_indices)).cpu()
+        agents = (th.arange(self.num_agent_per_scene).unsqueeze(0) + sc.unsqueeze(1) * self.num_agent_per_scene).flatten()
+        return self.reset_agent_by_id(agents)
 
     def examine(self):
         if bool(self._done.any()):

@@ -391,11 +391,22 @@ class PPO:
         g.manual_seed(self.seed + 7919 * (self._opt_step + 1))
         stats_acc = th.zeros(16, device=self.device)
         n_mb = 0
+        stop = False
         for _epoch in range(self.n_epochs):
             perm = th.randperm(total, device=self.device, generator=g)
             for s in range(0, total - bs + 1, bs):
-                stats_acc += self._minibatch_update(perm[s:s + bs])
+                st = self._minibatch_update(perm[s:s + bs])
+                stats_acc += st
                 n_mb += 1
+                if self.target_kl is not None:
+                    # PPO.py:269-282 checks the KL before the optimiser step; here the check follows the step
+                    # that produced it (one host sync per minibatch, only when target_kl is set)
+                    kl = parallel.allreduce_sum_(st[3:4].clone()).item() / (bs * self.world)
+                    if kl > 1.5 * self.target_kl:
+                        stop = True
+                        break
+            if stop:
+                break
         rows = float(bs * n_mb)
         s = (stats_acc / rows).tolist()
         self.logs.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/entropy_loss": s[2],
