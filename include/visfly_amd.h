@@ -292,6 +292,34 @@ int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, 
                              int32_t ldx, float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch,
                              vf_stream_t stream);
 
+/* Whole actor-critic MLP forward in ONE launch (policies.py:195-254: extract_features -> mlp_extractor ->
+ * action_net / value_net).  A workgroup walks 64-row tiles; activations live in LDS between layers,
+ * each layer's weights are streamed through LDS once per tile, GEMMs on the fp32 MFMA.
+ * Buffers are numbered: 0..3 = the observation inputs (global, row-major, width in_dim[i]);
+ * 4.. = LDS activation regions laid out by the host (offset / row stride in floats, stride odd);
+ * VF_MLP_OUT0 / VF_MLP_OUT1 = the global outputs (mean (M,4), value (M,1)). */
+#define VF_MLP_MAX_LAYERS 16
+#define VF_MLP_MAX_BUFS 12
+enum { VF_MLP_OUT0 = 100, VF_MLP_OUT1 = 101 };
+typedef struct vf_mlp_layer {
+    int32_t K, No, relu;
+    int32_t src, src_col;        /* buffer id and first column read  */
+    int32_t dst, dst_col;        /* buffer id and first column written */
+    int32_t w_off, b_off;        /* offsets into the flat parameter buffer */
+    int32_t save_ld;             /* row stride of `save`, 0 if none */
+    float* save;                 /* optional global copy of the layer output (training keeps activations) */
+} vf_mlp_layer;
+typedef struct vf_mlp_desc {
+    int32_t n_layers, n_inputs;
+    int32_t in_dim[4];
+    int32_t lds_off[VF_MLP_MAX_BUFS], lds_stride[VF_MLP_MAX_BUFS];   /* indexed by buffer id (ids < 4: staged inputs) */
+    int32_t w_region_off;        /* LDS offset of the weight staging region */
+    int32_t lds_floats;          /* total dynamic LDS, floats */
+    vf_mlp_layer layer[VF_MLP_MAX_LAYERS];
+} vf_mlp_desc;
+int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* in0, const float* in1, const float* in2,
+                   const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream);
+
 /* Squashed diagonal Gaussian head (SB3 SquashedDiagGaussianDistribution as used by
  * policies.py:114,177-181,195-226): a = tanh(mean + exp(log_std) * eps), eps ~ N(0,1) from
  * Philox4x32-10 keyed by (seed, row, step); log_prob as SB3 computes it.  deterministic != 0: a = tanh(mean). */

@@ -170,6 +170,31 @@ def test_policy_loss_and_gradients_vs_torch_autograd(keys):
     assert torch.allclose(gk[pol.log_std_off:], gref[pol.log_std_off:], rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("M", [1, 63, 777, 25600])
+def test_fused_forward_equals_layerwise(M):
+    """the one-launch whole-network forward (activations in LDS) is bit-identical to the per-layer kernels:
+    heads, and every saved activation the backward pass reads"""
+    from visfly_amd.ppo import MlpPolicy
+    pol = MlpPolicy({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64], DEV, seed=9)
+    assert pol._plan is not None and pol._plan["total"] * 4 <= 160 * 1024
+    g = torch.Generator(device=DEV).manual_seed(M)
+    obs = {"state": torch.randn((M, 13), device=DEV, generator=g), "target": torch.randn((M, 3), device=DEV, generator=g)}
+    pol.fused = True
+    mean, value = pol.forward(obs, save_activations=True)
+    fused = {k: v.clone() for k, v in pol._buffers(M).items() if not k.startswith(("g:", "obs:"))}
+    for v in pol._buffers(M).values():
+        if v.dtype == torch.float32 and v.data_ptr() not in (obs["state"].data_ptr(), obs["target"].data_ptr()):
+            v.fill_(-123.0)
+    pol.fused = False
+    pol.forward(obs)
+    for k, v in pol._buffers(M).items():
+        if k in fused:
+            assert torch.equal(fused[k], v), k
+    pol.fused = True
+    m2, v2 = pol.forward(obs, save_activations=False)       # inference: only the heads leave the chip
+    assert torch.equal(m2, fused["mean"]) and torch.equal(v2, fused["value"])
+
+
 def test_adam_with_grad_clip_vs_torch():
     _lib, lib = L()
     n = 43977

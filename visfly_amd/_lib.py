@@ -100,6 +100,23 @@ class EnvBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("tape_slab", "action", "d_obs", "d_reward", "done", "adj_slab", "d_action")]
 
 
+MLP_MAX_LAYERS, MLP_MAX_BUFS, MLP_OUT0, MLP_OUT1 = 16, 12, 100, 101
+
+
+class MlpLayer(C.Structure):
+    """mirror of vf_mlp_layer"""
+    _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("relu", C.c_int32), ("src", C.c_int32), ("src_col", C.c_int32),
+                ("dst", C.c_int32), ("dst_col", C.c_int32), ("w_off", C.c_int32), ("b_off", C.c_int32),
+                ("save_ld", C.c_int32), ("save", C.c_void_p)]
+
+
+class MlpDesc(C.Structure):
+    """mirror of vf_mlp_desc"""
+    _fields_ = [("n_layers", C.c_int32), ("n_inputs", C.c_int32), ("in_dim", C.c_int32 * 4),
+                ("lds_off", C.c_int32 * MLP_MAX_BUFS), ("lds_stride", C.c_int32 * MLP_MAX_BUFS),
+                ("w_region_off", C.c_int32), ("lds_floats", C.c_int32), ("layer", MlpLayer * MLP_MAX_LAYERS)]
+
+
 class PpoLossCfg(C.Structure):
     """mirror of vf_ppo_loss_cfg"""
     _fields_ = [("clip_range", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("inv_batch", C.c_float)]
@@ -152,6 +169,7 @@ SIGNATURES = {
     "vf_linear_bwd_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "vf_linear_bwd_weight": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
                                        C.c_int32, _vp, _vp]),
+    "vf_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),

@@ -128,6 +128,36 @@ __global__ __launch_bounds__(kBlock) void k_adv_apply(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 constexpr int kRows = 64;
 
+// Branch-free MFMA sweeps over a reduction padded to a multiple of 16 (pad columns are zero in LDS):
+// per chunk, the fragments of 8 k-pairs are fetched from LDS ahead of the MFMAs that consume them.
+// `bs` = LDS stride of one reduction step for the B fragment.  Callers pick the variant with a
+// wave-uniform (SGPR) condition, so there is no exec-mask traffic around the matrix instructions.
+__device__ __forceinline__ void mfma_sweep1(const float* __restrict__ ap, const float* __restrict__ b0, int bs, int red16,
+                                            f32x16& acc0)
+{
+    for (int k0 = 0; k0 < red16; k0 += 16) {
+        float a[8], x0[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = ap[k0 + 2 * j]; x0[j] = b0[(k0 + 2 * j) * bs]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x0[j], acc0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void mfma_sweep2(const float* __restrict__ ap, const float* __restrict__ b0,
+                                            const float* __restrict__ b1, int bs, int red16, f32x16& acc0, f32x16& acc1)
+{
+    for (int k0 = 0; k0 < red16; k0 += 16) {
+        float a[8], x0[8], x1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = ap[k0 + 2 * j]; x0[j] = b0[(k0 + 2 * j) * bs]; x1[j] = b1[(k0 + 2 * j) * bs]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x0[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x1[j], acc1, 0, 0, 0);
+        }
+    }
+}
+
 // Stage one 64-row tile of A (optionally masked by Ym > 0) into LDS rows of odd stride `sa`.
 // Vector path: 16-byte global loads when the row length is a multiple of 4 with a power-of-two
 // number of float4 per row (K, No in {4, 8, ..., 128}); scalar path otherwise (K = 13, 3).
@@ -143,18 +173,31 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
     if (vec) {
         const int sh = 31 - __clz(c4);            // log2(float4 per row)
         const int col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
-        for (int r = r0; r < nrows; r += rstep) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < M) {
-                x = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + col);
-                if (MASK && Ym) {
-                    const float4 y = *reinterpret_cast<const float4*>(Ym + (size_t)(m0 + r) * ldym + col);
-                    x.x = y.x > 0.0f ? x.x : 0.0f; x.y = y.y > 0.0f ? x.y : 0.0f;
-                    x.z = y.z > 0.0f ? x.z : 0.0f; x.w = y.w > 0.0f ? x.w : 0.0f;
+        // batches of 8 independent 16-byte loads, then the LDS writes: one memory latency per batch
+        for (int rb = r0; rb < nrows; rb += 8 * rstep) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = rb + j * rstep;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nrows && m0 + r < M) {
+                    x = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + col);
+                    if (MASK && Ym) {
+                        const float4 y = *reinterpret_cast<const float4*>(Ym + (size_t)(m0 + r) * ldym + col);
+                        x.x = y.x > 0.0f ? x.x : 0.0f; x.y = y.y > 0.0f ? x.y : 0.0f;
+                        x.z = y.z > 0.0f ? x.z : 0.0f; x.w = y.w > 0.0f ? x.w : 0.0f;
+                    }
+                }
+                v[j] = x;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = rb + j * rstep;
+                if (r < nrows) {
+                    float* d = As + r * sa + col;
+                    d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
                 }
             }
-            float* d = As + r * sa + col;
-            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
         }
     } else {
         for (int idx = tid; idx < nrows * redp; idx += kBlock) {
@@ -169,9 +212,60 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
     }
 }
 
+// Split staging for latency overlap: `load` issues up to 8 independent 16-byte global loads per thread
+// into registers (64 rows x <= 128 floats), `store` parks them in LDS later.  Same vector conditions
+// as stage_rows; `ok()` false -> the caller falls back to stage_rows.
+template <bool MASK>
+struct RowPrefetch {
+    float4 v[8];
+    int sh, col, r0, rstep;
+    bool vec;
+    __device__ __forceinline__ void setup(const float* A, int lda, const float* Ym, int ldym, int red)
+    {
+        const int c4 = red >> 2;
+        vec = (red & 3) == 0 && (c4 & (c4 - 1)) == 0 && c4 >= 1 && c4 <= 32 && (lda & 3) == 0 &&
+              ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+              (!MASK || !Ym || ((ldym & 3) == 0 && (reinterpret_cast<uintptr_t>(Ym) & 15) == 0));
+        sh = 31 - __clz(c4 > 0 ? c4 : 1);
+        col = (threadIdx.x & (c4 - 1)) << 2;
+        r0 = threadIdx.x >> sh;
+        rstep = kBlock >> sh;          // rows covered per pass; 64 rows -> 64 / rstep <= 8 passes
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ A, int lda, const float* __restrict__ Ym, int ldym, int m0,
+                                         int M)
+    {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + j * rstep;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < kRows && m0 + r < M) {
+                x = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + col);
+                if (MASK && Ym) {
+                    const float4 y = *reinterpret_cast<const float4*>(Ym + (size_t)(m0 + r) * ldym + col);
+                    x.x = y.x > 0.0f ? x.x : 0.0f; x.y = y.y > 0.0f ? x.y : 0.0f;
+                    x.z = y.z > 0.0f ? x.z : 0.0f; x.w = y.w > 0.0f ? x.w : 0.0f;
+                }
+            }
+            v[j] = x;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ As, int sa) const
+    {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + j * rstep;
+            if (r < kRows) {
+                float* d = As + r * sa + col;
+                d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+            }
+        }
+    }
+};
+
 // BWD == false: C[m][n] = act(sum_k A[m][k] * W[n][k] + b[n])          (forward; red = K, cols = No)
 // BWD == true : C[m][k] = sum_n (A[m][n] * [Ymask[m][n] > 0]) * W[n][k]  (data grad; red = No, cols = K)
-// Weight-stationary: a block stages W once and walks 64-row tiles with stride gridDim.x.
+// Weight-stationary: a block stages W once and walks 64-row tiles with stride gridDim.x; the next
+// tile's rows are fetched into registers while the MFMAs of the current one run.
 template <bool BWD, bool RELU>
 __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, int lda, const float* __restrict__ Ym,
                                                    int ldym, const float* __restrict__ W, const float* __restrict__ bias,
@@ -180,59 +274,51 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int red = BWD ? No : K;         // reduction length
     const int cols = BWD ? K : No;        // output columns
-    const int redp = (red + 1) & ~1;      // MFMA consumes k in pairs
+    const int red16 = (red + 15) & ~15;   // the MFMA sweeps consume 16 reduction steps per chunk; pads are zero
     const int ct = (cols + 31) >> 5;      // 32-column tiles
-    const int sa = redp + 1;              // odd LDS row strides
+    const int sa = red16 + 1;             // odd LDS row strides
     float* As = lds;                      // [64][sa]
-    float* Ws = lds + kRows * sa;         // fwd: [ct*32][sa] (col-major over red) ; bwd: [redp][ct*32+1]
+    float* Ws = lds + kRows * sa;         // fwd: [ct*32][sa] (col-major over red) ; bwd: [red16][ct*32+1]
     const int sw = BWD ? ct * 32 + 1 : sa;
     const int tid = threadIdx.x;
+    const int ntiles = (M + kRows - 1) / kRows;
+
+    RowPrefetch<BWD> pf;
+    pf.setup(A, lda, Ym, ldym, red);
+    int tile = blockIdx.x;
+    if (pf.vec && tile < ntiles) pf.load(A, lda, Ym, ldym, tile * kRows, M);   // in flight while W is staged
 
     // W image: Ws[n * sw + k] = W[n][k] for both directions (forward reads it column-major over the
     // reduction, the data gradient row-major); pads are zero.
-    const int wrows = BWD ? redp : ct * 32, wcols = BWD ? ct * 32 : redp;
-    for (int idx = tid; idx < kRows * sa + wrows * sw; idx += kBlock) lds[idx] = 0.0f;
-    __syncthreads();
-    stage_rows<false>(Ws, sw, W, K, nullptr, 0, 0, No, K, wcols, wrows);
+    const int wrows = BWD ? red16 : ct * 32, wcols = BWD ? ct * 32 : red16;
+    const bool padded = wrows != No || wcols != K || red16 != red;
+    if (padded) {
+        for (int idx = tid; idx < kRows * sa + wrows * sw; idx += kBlock) lds[idx] = 0.0f;
+        __syncthreads();
+    }
+    stage_rows<false>(Ws, sw, W, K, nullptr, 0, 0, No, K, K, wrows);
 
-    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose (SGPR control flow)
+    const int lane = tid & 63, lr = lane & 31, lk = lane >> 5;
     const int rt = wave & 1;              // row half
     const int c0 = wave >> 1;             // column tiles c0, c0 + 2
-    const bool has0 = c0 < ct, has1 = c0 + 2 < ct;
+    const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
     const float* ap = As + (rt * 32 + lr) * sa + lk;
-    const int ntiles = (M + kRows - 1) / kRows;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const float* b0 = BWD ? Ws + lk * sw + c0 * 32 + lr : Ws + (c0 * 32 + lr) * sw + lk;
+    const float* b1 = BWD ? Ws + lk * sw + (c0 + 2) * 32 + lr : Ws + ((c0 + 2) * 32 + lr) * sw + lk;
+    const int bs = BWD ? sw : 1;
+    for (; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * kRows;
-        __syncthreads();                  // previous tile's MFMA reads of As are done (and W is staged)
-        stage_rows<BWD>(As, sa, A, lda, Ym, ldym, m0, M, red, redp);
+        if (pf.vec) pf.store(As, sa);
+        else stage_rows<BWD>(As, sa, A, lda, Ym, ldym, m0, M, red, red);
         __syncthreads();
+        if (pf.vec && tile + gridDim.x < ntiles) pf.load(A, lda, Ym, ldym, (tile + gridDim.x) * kRows, M);
         f32x16 acc0 = {0}, acc1 = {0};
-        // fragments for 8 k-pairs are fetched from LDS ahead of the 8 (or 16) MFMAs that consume them
-        const float* b0 = BWD ? Ws + lk * sw + c0 * 32 + lr : Ws + (c0 * 32 + lr) * sw + lk;
-        const float* b1 = BWD ? Ws + lk * sw + (c0 + 2) * 32 + lr : Ws + ((c0 + 2) * 32 + lr) * sw + lk;
-        const int bs = BWD ? sw : 1;      // LDS stride of one step along the reduction for the B fragment
-        for (int k0 = 0; k0 < redp; k0 += 16) {
-            float a[8], x0[8], x1[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + 2 * j;
-                const bool ok = k < redp;
-                a[j] = ok ? ap[k] : 0.0f;
-                x0[j] = (ok && has0) ? b0[k * bs] : 0.0f;
-                x1[j] = (ok && has1) ? b1[k * bs] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (has0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x0[j], acc0, 0, 0, 0);
-                if (has1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x1[j], acc1, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (!(t ? has1 : has0)) continue;
-            const f32x16& acc = t ? acc1 : acc0;
-            const int n = (c0 + 2 * t) * 32 + lr;
-            if (n >= cols) continue;
+        if (nacc == 2) mfma_sweep2(ap, b0, b1, bs, red16, acc0, acc1);
+        else if (nacc == 1) mfma_sweep1(ap, b0, bs, red16, acc0);
+        auto emit = [&](const f32x16& acc, int ctile) {
+            const int n = ctile * 32 + lr;
+            if (n >= cols) return;
             const float bn = (!BWD && bias) ? bias[n] : 0.0f;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -242,6 +328,82 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
                 if (RELU) y = y > 0.0f ? y : 0.0f;
                 float* dst = C + (size_t)m * ldc + n;
                 *dst = accumulate ? *dst + y : y;
+            }
+        };
+        if (nacc >= 1) emit(acc0, c0);
+        if (nacc == 2) emit(acc1, c0 + 2);
+        __syncthreads();                  // every wave is done reading As before the next tile overwrites it
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole-network forward: activations stay in LDS, weights streamed per layer (see vf_mlp_desc)
+// ------------------------------------------------------------------------------------------------
+struct MlpIo {
+    const float* in[4];
+    float* out[2];
+};
+
+__global__ __launch_bounds__(kBlock) void k_mlp_forward(const vf_mlp_desc d, const float* __restrict__ params, const MlpIo io,
+                                                        int M)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 31, lk = lane >> 5;
+    const int rt = wave & 1, c0 = wave >> 1;
+    float* Ws = lds + d.w_region_off;
+    const int ntiles = (M + kRows - 1) / kRows;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * kRows;
+        __syncthreads();                                   // previous tile is completely consumed
+        for (int b = 0; b < d.n_inputs; ++b) {              // observations -> LDS (zero padded to an even width)
+            const int w = d.in_dim[b], wp = (w + 15) & ~15;   // zero padded to the MFMA chunk
+            stage_rows<false>(lds + d.lds_off[b], d.lds_stride[b], io.in[b], w, nullptr, 0, m0, M, w, wp);
+        }
+        for (int li = 0; li < d.n_layers; ++li) {
+            const vf_mlp_layer L = d.layer[li];
+            const int red16 = (L.K + 15) & ~15, ct = (L.No + 31) >> 5, sw = red16 + 1;
+            __syncthreads();                               // inputs of this layer are in LDS; W region is free
+            if (ct * 32 != L.No || red16 != L.K) {
+                for (int idx = tid; idx < ct * 32 * sw; idx += kBlock) Ws[idx] = 0.0f;
+                __syncthreads();
+            }
+            stage_rows<false>(Ws, sw, params + L.w_off, L.K, nullptr, 0, 0, L.No, L.K, L.K, ct * 32);
+            __syncthreads();
+            const float* As = lds + d.lds_off[L.src] + L.src_col;
+            const int sa = d.lds_stride[L.src];
+            const float* ap = As + (rt * 32 + lr) * sa + lk;
+            const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
+            const bool has0 = nacc >= 1, has1 = nacc == 2;
+            const float* b0 = Ws + (c0 * 32 + lr) * sw + lk;
+            const float* b1 = Ws + ((c0 + 2) * 32 + lr) * sw + lk;
+            f32x16 acc0 = {0}, acc1 = {0};
+            if (nacc == 2) mfma_sweep2(ap, b0, b1, 1, red16, acc0, acc1);
+            else if (nacc == 1) mfma_sweep1(ap, b0, 1, red16, acc0);
+            // epilogue: bias + ReLU, into the destination region (LDS or global) and the optional saved copy
+            float* dl = nullptr;
+            int sd = 0;
+            float* dg = nullptr;
+            int ldg = 0;
+            if (L.dst >= VF_MLP_OUT0) { dg = io.out[L.dst - VF_MLP_OUT0]; ldg = L.No; }
+            else { dl = lds + d.lds_off[L.dst] + L.dst_col; sd = d.lds_stride[L.dst]; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (!(t ? has1 : has0)) continue;
+                const f32x16& acc = t ? acc1 : acc0;
+                const int n = (c0 + 2 * t) * 32 + lr;
+                if (n >= L.No) continue;
+                const float bn = params[L.b_off + n];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                    float y = acc[reg] + bn;
+                    if (L.relu) y = y > 0.0f ? y : 0.0f;
+                    if (dl) dl[r * sd + n] = y;
+                    if (m0 + r < M) {
+                        if (dg) dg[(size_t)(m0 + r) * ldg + n] = y;
+                        if (L.save) L.save[(size_t)(m0 + r) * L.save_ld + L.dst_col + n] = y;
+                    }
+                }
             }
         }
     }
@@ -257,7 +419,7 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
     const int sd = nt * 32 + 1, sx = kt * 32 + 1;
     float* Ds = lds;               // [64][sd]  masked dY rows
     float* Xs = lds + kRows * sd;  // [64][sx]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lk = lane >> 5;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 31, lk = lane >> 5;
     const int mb = blockIdx.x * rows_per_block;
     const int me = min(M, mb + rows_per_block);
     const int ntiles = nt * kt;  // <= 16, wave takes tiles wave, wave+4, ...
@@ -513,8 +675,8 @@ namespace {
 size_t linear_lds_bytes(bool bwd, int K, int No)
 {
     const int red = bwd ? No : K, cols = bwd ? K : No;
-    const int redp = (red + 1) & ~1, ct = (cols + 31) >> 5, sa = redp + 1;
-    const size_t ws = bwd ? (size_t)redp * (ct * 32 + 1) : (size_t)ct * 32 * sa;
+    const int red16 = (red + 15) & ~15, ct = (cols + 31) >> 5, sa = red16 + 1;
+    const size_t ws = bwd ? (size_t)red16 * (ct * 32 + 1) : (size_t)ct * 32 * sa;
     return ((size_t)vf::kRows * sa + ws) * sizeof(float);
 }
 
@@ -654,6 +816,28 @@ int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, 
                              float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream)
 {
     return linear_bwd_weight(dY, lddy, Ymask, ldym, X, ldx, dW, db, M, K, No, scratch, stream, 1);
+}
+
+int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* in0, const float* in1, const float* in2,
+                   const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream)
+{
+    if (!desc || !params || !in0 || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_forward: bad argument");
+    if (desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS || desc->n_inputs < 1 || desc->n_inputs > 4)
+        return vf::fail(VF_EINVAL, "vf_mlp_forward: bad layer / input count");
+    for (int i = 0; i < desc->n_layers; ++i) {
+        const vf_mlp_layer& L = desc->layer[i];
+        if (L.K < 1 || L.K > 128 || L.No < 1 || L.No > 128) return vf::fail(VF_EINVAL, "vf_mlp_forward: layer %d: K, No must be 1..128", i);
+        if (L.dst >= VF_MLP_OUT0 && !(L.dst == VF_MLP_OUT0 ? out0 : out1)) return vf::fail(VF_EINVAL, "vf_mlp_forward: missing output %d", L.dst);
+    }
+    const size_t lds = (size_t)desc->lds_floats * sizeof(float);
+    if (lds > 160 * 1024) return vf::fail(VF_EINVAL, "vf_mlp_forward: LDS plan needs %zu bytes (> 160 KiB)", lds);
+    if (int rc = allow_lds(vf::k_mlp_forward, lds)) return rc;
+    const int ntiles = (M + vf::kRows - 1) / vf::kRows;
+    vf::MlpIo io{{in0, in1, in2, in3}, {out0, out1}};
+    hipLaunchKernelGGL(vf::k_mlp_forward, dim3(ntiles < 256 ? ntiles : 256), dim3(vf::kBlock), lds, vf::as_stream(stream), *desc,
+                       params, io, M);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
 }
 
 int vf_head_sample(const float* mean, const float* log_std, float* action, float* log_prob, int32_t M, uint64_t seed,

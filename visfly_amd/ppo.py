@@ -104,6 +104,79 @@ class MlpPolicy:
         self.grad = th.zeros_like(self.flat)
         self._bufs: Dict[int, Dict[str, th.Tensor]] = {}
         self._scratch = None
+        self._plan = self._plan_fused()
+        self._descs = {}
+        self.fused = True
+
+    def _plan_fused(self):
+        """LDS layout for the one-launch forward (vf_mlp_forward): every activation gets a [64][w|1] region
+        (odd row stride), regions are recycled once their last reader has run (first fit); None if the
+        network does not fit in the 160 KiB LDS budget -> layer-by-layer launches."""
+        rows = 64
+        odd = lambda w: ((w + 15) & ~15) + 1                      # odd stride covering the width padded to 16
+        names = ["obs:" + k for k in self.obs_keys]
+        if len(names) > 4 or len(self.layers) > _lib.MLP_MAX_LAYERS:
+            return None
+        last_read = {}
+        for li, ly in enumerate(self.layers):
+            last_read[ly.src] = li
+        ids, off, stride, size = {}, {}, {}, {}
+        free, top = [], 0
+
+        def alloc(name, w):
+            nonlocal top
+            st = odd(w)
+            need = rows * st
+            for fi, (fo, fs) in enumerate(free):
+                if fs >= need:
+                    free.pop(fi)
+                    if fs > need:
+                        free.append((fo + need, fs - need))
+                    off[name], stride[name], size[name] = fo, st, need
+                    return
+            off[name], stride[name], size[name] = top, st, need
+            top += need
+
+        for bi, n in enumerate(names):
+            ids[n] = bi
+            alloc(n, self.obs_dims[n[4:]])
+        nxt = 4
+        written = set()
+        for li, ly in enumerate(self.layers):
+            if ly.dst not in ("mean", "value") and ly.dst not in ids:
+                ids[ly.dst] = nxt
+                nxt += 1
+                alloc(ly.dst, self.widths[ly.dst])
+            written.add(ly.dst)
+            for n in list(off):            # release regions nobody reads any more (never the one being written)
+                if last_read.get(n, -1) <= li and n in size and n != ly.dst and n not in ("mean", "value"):
+                    free.append((off[n], size.pop(n)))
+        if nxt > _lib.MLP_MAX_BUFS:
+            return None
+        wmax = max((((ly.No + 31) // 32) * 32) * (((ly.K + 15) & ~15) + 1) for ly in self.layers)
+        total = top + wmax
+        if total * 4 > 160 * 1024:
+            return None
+        return dict(ids=ids, off=off, stride=stride, w_off=top, total=total)
+
+    def _fused_desc(self, b, save: bool):
+        p = self._plan
+        d = _lib.MlpDesc()
+        d.n_layers, d.n_inputs = len(self.layers), len(self.obs_keys)
+        for i, k in enumerate(self.obs_keys):
+            d.in_dim[i] = self.obs_dims[k]
+        for n, bid in p["ids"].items():
+            d.lds_off[bid], d.lds_stride[bid] = p["off"][n], p["stride"][n]
+        d.w_region_off, d.lds_floats = p["w_off"], p["total"]
+        for li, ly in enumerate(self.layers):
+            L = d.layer[li]
+            L.K, L.No, L.relu = ly.K, ly.No, 1 if ly.relu else 0
+            L.src, L.src_col = p["ids"][ly.src], ly.sc
+            L.dst = {"mean": _lib.MLP_OUT0, "value": _lib.MLP_OUT1}.get(ly.dst, p["ids"].get(ly.dst, 0))
+            L.dst_col, L.w_off, L.b_off = ly.dc, ly.w_off, ly.b_off
+            if save and ly.dst not in ("mean", "value"):
+                L.save, L.save_ld = b[ly.dst].data_ptr(), b[ly.dst].shape[1]
+        return d
 
     # -------------------------------------------------------------------------------------------
     def weight(self, ly):
@@ -124,14 +197,17 @@ class MlpPolicy:
                       for name, w in self.widths.items() if name not in ("mean", "value")})
             if len(self._bufs) > 4:
                 self._bufs.clear()
+                self._descs.clear()
             self._bufs[M] = b
         return b
 
     def _stream(self):
         return th.cuda.current_stream(self.device).cuda_stream
 
-    def forward(self, obs: Dict[str, th.Tensor]):
-        """-> mean (M,4), value (M,1); activations are kept for ``backward``"""
+    def forward(self, obs: Dict[str, th.Tensor], save_activations: bool = True):
+        """-> mean (M,4), value (M,1).  One launch for the whole network when the LDS plan fits
+        (``self.fused``); ``save_activations`` keeps every layer output in HBM for ``backward``
+        (inference passes False and moves only observations in and heads out)."""
         M = obs[self.obs_keys[0]].shape[0]
         b = self._buffers(M)
         L, st = _lib.lib(), self._stream()
@@ -139,13 +215,24 @@ class MlpPolicy:
             t = obs[k]
             assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
             b["obs:" + k] = t
+        self._last_M = M
+        if self._plan is not None and self.fused:
+            key = (M, bool(save_activations))
+            d = self._descs.get(key)
+            if d is None:
+                d = self._descs[key] = self._fused_desc(b, save_activations)
+            ins = [_ptr(obs[k]) for k in self.obs_keys] + [None] * (4 - len(self.obs_keys))
+            rc = L.vf_mlp_forward(C.byref(d), _ptr(self.flat), ins[0], ins[1], ins[2], ins[3], _ptr(b["mean"]),
+                                  _ptr(b["value"]), M, st)
+            if rc:
+                _lib.check(rc)
+            return b["mean"], b["value"]
         for ly in self.layers:
             X, Y = b[ly.src], b[ly.dst]
             rc = L.vf_linear_fwd(_ptr(X, ly.sc), X.shape[1], _ptr(self.flat, ly.w_off), _ptr(self.flat, ly.b_off),
                                  _ptr(Y, ly.dc), Y.shape[1], M, ly.K, ly.No, 1 if ly.relu else 0, st)
             if rc:
                 _lib.check(rc)
-        self._last_M = M
         return b["mean"], b["value"]
 
     def backward(self, d_mean: th.Tensor, d_value: Optional[th.Tensor], d_log_std: Optional[th.Tensor],
@@ -300,7 +387,7 @@ class PPO:
     # ------------------------------------------------------------------------------------------
     def _act(self, obs, deterministic=False):
         """policy.forward (policies.py:195-226): action, value, log_prob"""
-        mean, value = self.policy.forward({k: obs[k] for k in self.obs_keys})
+        mean, value = self.policy.forward({k: obs[k] for k in self.obs_keys}, save_activations=False)
         M = mean.shape[0]
         action = th.empty((M, 4), device=self.device)
         logp = th.empty(M, device=self.device)
@@ -311,7 +398,7 @@ class PPO:
         return action, value.view(M), logp
 
     def predict_values(self, obs):
-        _, value = self.policy.forward({k: obs[k] for k in self.obs_keys})
+        _, value = self.policy.forward({k: obs[k] for k in self.obs_keys}, save_activations=False)
         return value.view(-1).clone()
 
     def collect_rollouts(self):
