@@ -57,7 +57,7 @@ enum {
     VF_G_FIXED = 8
 };
 
-enum { VF_ACT_THRUST = 0, VF_ACT_BODYRATE = 1 };   /* utils/type.py:14-18 */
+enum { VF_ACT_THRUST = 0, VF_ACT_BODYRATE = 1, VF_ACT_VELOCITY = 2, VF_ACT_POSITION = 3 };   /* utils/type.py:14-18 */
 enum { VF_INT_EULER = 0, VF_INT_RK4 = 1 };         /* utils/maths.py:331,353 */
 
 /* Constants derived once on the host (envs/base/dynamics.py:26-130,562-689).
@@ -90,6 +90,12 @@ typedef struct vf_dyn_cfg {
     float wind[3];            /* constant wind velocity          dynamics.py:135,388 */
     float pos_xy_lim, pos_z_lo, pos_z_hi, vel_lim, omg_lim; /* _ugly_fix dynamics.py:374-382 */
     float T_init, w_init;     /* hover thrust / rotor speed      dynamics.py:85-86 */
+    /* velocity / position action types: geometric SO(3) controller, dynamics.py:414-496 */
+    float vel_half, vel_mean; /* "velocity" range (position mode: position range) dynamics.py:660-685 */
+    float yaw_half, yaw_mean; /* "yaw" range (velocity mode: both 0, dynamics.py:671) */
+    float vel_p, vel_d, pos_d;/* VELOCITY_PID.p/.d, POSITION_PID.d  dynamics.py:416,433,456-457,468 */
+    float Pm[9];              /* BODYRATE_PID.p                  dynamics.py:451,490 */
+    float P12[9];             /* 1.2 * BODYRATE_PID.p            dynamics.py:491 */
 } vf_dyn_cfg;
 
 typedef struct vf_dyn vf_dyn;

@@ -39,6 +39,10 @@ class Consts(C.Structure):
         ("pos_xy_lim", C.c_float), ("pos_z_lo", C.c_float), ("pos_z_hi", C.c_float),
         ("vel_lim", C.c_float), ("omg_lim", C.c_float),
         ("T_init", C.c_float), ("w_init", C.c_float),
+        ("vel_half", C.c_float), ("vel_mean", C.c_float),
+        ("yaw_half", C.c_float), ("yaw_mean", C.c_float),
+        ("vel_p", C.c_float), ("vel_d", C.c_float), ("pos_d", C.c_float),
+        ("Pm", C.c_float * 9), ("P12", C.c_float * 9),
     ]
 
 
@@ -65,12 +69,15 @@ class EnvState(C.Structure):
 
 # name -> (ctypes field, is_array) ; constants are passed around as a dict of
 # float32 numpy scalars/arrays (bit patterns are the parity contract)
+GEOMETRIC_FIELDS = ("vel_half", "vel_mean", "yaw_half", "yaw_mean", "vel_p", "vel_d", "pos_d", "Pm", "P12")
 CONST_FIELDS = [f[0] for f in Consts._fields_ if f[0] != "pad0"]
 
 
 def consts_from_dict(d):
     c = Consts()
     for name in CONST_FIELDS:
+        if name not in d and name in GEOMETRIC_FIELDS:
+            continue      # fixtures of the bodyrate/thrust cases predate the geometric-controller constants
         v = d[name]
         cur = getattr(c, name)
         if isinstance(cur, (int, float)):

@@ -63,9 +63,13 @@ def extract_consts(d):
     the reference applies at run time so the bits are the reference's bits."""
     RD = sys.modules[type(d).__module__]   # reference dynamics module (holds the global g)
     tm = d._thrust_map
-    is_bodyrate = d.action_type.name == "BODYRATE"
+    at = d.action_type.name
+    is_bodyrate = at == "BODYRATE"
+    geometric = at in ("VELOCITY", "POSITION")
+    npar = d._normal_params
+    zero = th.zeros(1)
     c = {
-        "action_type": np.int32(1 if is_bodyrate else 0),
+        "action_type": np.int32({"THRUST": 0, "BODYRATE": 1, "VELOCITY": 2, "POSITION": 3}[at]),
         "integrator": np.int32(1 if d._integrator == "rk4" else 0),
         "interval_steps": np.int32(d._interval_steps),
         "delay_steps": np.int32(d._comm_delay_steps),
@@ -80,8 +84,8 @@ def extract_consts(d):
         "rot_scale": f32(1 / (2 * tm[0])), "rot_neg_tm1": f32(-tm[1]),
         "rot_tm1sq": f32(tm[1].pow(2)), "rot_4tm0": f32(4 * tm[0]),
         "T_min": np.float32(d._bd_thrust.min), "T_max": f32(d._bd_thrust.max),
-        "acc_half": f32(d._normal_params["acc"].half[0]),
-        "acc_mean": f32(d._normal_params["acc"].mean[0]),
+        "acc_half": np.float32(0) if geometric else f32(npar["acc"].half[0]),
+        "acc_mean": np.float32(0) if geometric else f32(npar["acc"].mean[0]),
         "rate_half": f32(d._normal_params["bodyrate"].half[0]) if is_bodyrate else np.float32(0),
         "rate_mean": f32(d._normal_params["bodyrate"].mean[0]) if is_bodyrate else np.float32(0),
         "k_lin": f32(d._linear_drag_coeffs_mean[:, 0]), "k_quad": f32(d._quad_drag_coeffs_mean[:, 0]),
@@ -89,6 +93,13 @@ def extract_consts(d):
         "pos_xy_lim": np.float32(100), "pos_z_lo": np.float32(0), "pos_z_hi": np.float32(20),
         "vel_lim": np.float32(20), "omg_lim": np.float32(10),
         "T_init": f32(d._init_thrust[0]), "w_init": f32(d._init_motor_omega[0]),
+        # geometric controller of the velocity / position action types (dynamics.py:414-496)
+        "vel_half": f32(npar["velocity"].half.reshape(-1)[0]) if geometric else np.float32(0),
+        "vel_mean": f32(npar["velocity"].mean.reshape(-1)[0]) if geometric else np.float32(0),
+        "yaw_half": f32(npar["yaw"].half.reshape(-1)[0]) if geometric else np.float32(0),
+        "yaw_mean": f32(npar["yaw"].mean.reshape(-1)[0]) if geometric else np.float32(0),
+        "vel_p": f32(d._VELOCITY_PID.p), "vel_d": f32(d._VELOCITY_PID.d), "pos_d": f32(d._POSITION_PID.d),
+        "Pm": f32(d._BODYRATE_PID.p), "P12": f32(1.2 * d._BODYRATE_PID.p),
     }
     return {k: np.asarray(v) for k, v in c.items()}
 
@@ -183,6 +194,12 @@ DYN_CASES = {
                                 integrator="euler", wind_settings=[0.5, -0.25, 0.125]), [-1 / 3, 0, 0, 0], 0.3),
     "dyn_bodyrate_rk4": (dict(action_type="bodyrate", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True,
                               integrator="rk4"), [-1 / 3, 0, 0, 0], 0.3),
+    # geometric controller: sin/cos/atan2 are SLEEF in torch -> tolerance-level fixtures.
+    # velocity: command = [yaw (ignored), v / 10 m/s]; position: [yaw / pi, p / 10 m]
+    "dyn_velocity_euler": (dict(action_type="velocity", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True,
+                                integrator="euler"), [0, 0.05, 0, 0], 0.15),
+    "dyn_position_euler": (dict(action_type="position", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True,
+                                integrator="euler"), [0.1, 0.1, 0, 0.15], 0.1),
 }
 
 

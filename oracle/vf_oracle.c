@@ -86,6 +86,111 @@ static inline void derivs(const vfo_consts* c, quat q, const float* w, const flo
     mat3_chain(c->Jinv, r0, r1, r2, dw);
 }
 
+
+/* Geometric SO(3) controller of the velocity / position action types
+ * (envs/base/dynamics.py:414-452 velocity, :453-496 position), once per control
+ * interval.  x.norm(dim=0) over (2,N)/(3,N) rows = FMA chain + IEEE sqrt [probe];
+ * cross() is the helper of utils/maths.py:392-394 (separately rounded, "+ 0");
+ * 3x3 @ 3x3 and 3x3 @ (3,N) are k-ordered FMA chains (App. B.4).  sin/cos/atan2
+ * are the libm ones: torch's vectorised SLEEF variants are not reproducible, so
+ * parity for these two action types is tolerance-level, not bit-level. */
+static inline void cross_helper(const float* a, const float* b, float* o)
+{
+    o[0] = (a[1] * b[2] - a[2] * b[1]) + 0.0f;
+    o[1] = (a[2] * b[0] - a[0] * b[2]) + 0.0f;
+    o[2] = (a[0] * b[1] - a[1] * b[0]) + 0.0f;
+}
+
+static void geometric_controller(const vfo_consts* c, const float* a, const float* p, quat q,
+                                 const float* v, const float* w, const float* al, float* Td)
+{
+    const int pos_mode = c->action_type == VFO_ACT_POSITION;
+    /* _de_normalize :716-730 -> [yaw, x, y, z] */
+    float cmd[4];
+    cmd[0] = a[0] * c->yaw_half + c->yaw_mean;
+    for (int k = 1; k < 4; ++k) cmd[k] = a[k] * c->vel_half + c->vel_mean;
+    float F[3];
+    for (int k = 0; k < 3; ++k) {
+        float a_des;
+        if (pos_mode) {
+            float v_des = c->pos_d * (cmd[k + 1] - p[k]);      /* :456 */
+            a_des = c->vel_d * (v_des - v[k]);                 /* :457 */
+        } else {
+            a_des = c->vel_p * (cmd[k + 1] - v[k]);            /* :416 */
+        }
+        F[k] = c->m * (a_des - (k == 2 ? c->g_z : 0.0f));      /* :417,458 */
+    }
+    /* Quaternion.toEuler()[2] (utils/maths.py:248) */
+    float yaw_cur = atan2f(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
+    float yaw_des, gain;
+    if (pos_mode) {
+        yaw_des = cmd[0];                                      /* :461 */
+        gain = c->pos_d;                                       /* :468 */
+    } else {
+        float vn = sqrtf(fmaf(v[1], v[1], v[0] * v[0]));       /* :421 */
+        yaw_des = vn > 0.1f ? atan2f(v[1], v[0]) : yaw_cur;    /* :423-427 */
+        gain = c->vel_d;                                       /* :433 */
+    }
+    float ye = yaw_des - yaw_cur;
+    ye = atan2f(sinf(ye), cosf(ye));                           /* :432,467 */
+    float yaw_spd = ye * gain * 2.0f;
+    /* gross thrust = (conj(q) * (0,F) * q).imag[2]            :435, maths.py:49,103 */
+    quat fq = { 0.0f, F[0], F[1], F[2] };
+    quat fb = qmul(qmul(qconj(q), fq), q);
+    float gross = fb.z;
+    /* Quaternion.R (utils/maths.py:116-120) */
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * (q.y * q.y + q.z * q.z); R[0][1] = 2.0f * (q.x * q.y - q.z * q.w); R[0][2] = 2.0f * (q.x * q.z + q.y * q.w);
+    R[1][0] = 2.0f * (q.x * q.y + q.z * q.w); R[1][1] = 1.0f - 2.0f * (q.x * q.x + q.z * q.z); R[1][2] = 2.0f * (q.y * q.z - q.x * q.w);
+    R[2][0] = 2.0f * (q.x * q.z - q.y * q.w); R[2][1] = 2.0f * (q.y * q.z + q.x * q.w); R[2][2] = 1.0f - 2.0f * (q.x * q.x + q.y * q.y);
+    /* desired frame :437-442 */
+    float fn = sqrtf(fmaf(F[2], F[2], fmaf(F[1], F[1], F[0] * F[0])));
+    float b3[3] = { F[0] / fn, F[1] / fn, F[2] / fn };
+    float c1[3] = { cosf(yaw_des), sinf(yaw_des), 0.0f };
+    float b2[3], b1[3];
+    cross_helper(b3, c1, b2);
+    float bn = sqrtf(fmaf(b2[2], b2[2], fmaf(b2[1], b2[1], b2[0] * b2[0])));
+    for (int k = 0; k < 3; ++k) b2[k] = b2[k] / bn;
+    cross_helper(b2, b3, b1);
+    float Rd[3][3];                                            /* columns b1, b2, b3 */
+    for (int r = 0; r < 3; ++r) { Rd[r][0] = b1[r]; Rd[r][1] = b2[r]; Rd[r][2] = b3[r]; }
+    /* per-agent loop body :446-450: A = Rd^T R, Bm = R^T Rd, m = 0.5 (A - Bm) */
+    float A[3][3], Bm[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float s = Rd[0][i] * R[0][j]; s = fmaf(Rd[1][i], R[1][j], s); s = fmaf(Rd[2][i], R[2][j], s);
+            A[i][j] = s;
+            float u = R[0][i] * Rd[0][j]; u = fmaf(R[1][i], Rd[1][j], u); u = fmaf(R[2][i], Rd[2][j], u);
+            Bm[i][j] = u;
+        }
+    float m12 = 0.5f * (A[1][2] - Bm[1][2]), m02 = 0.5f * (A[0][2] - Bm[0][2]), m01 = 0.5f * (A[0][1] - Bm[0][1]);
+    float pose[3] = { -(-m12), -m02, -(-m01) };
+    float ang[3];
+    for (int i = 0; i < 3; ++i) {
+        float s = A[i][0] * 0.0f; s = fmaf(A[i][1], 0.0f, s); s = fmaf(A[i][2], yaw_spd, s);
+        ang[i] = s - w[i];
+    }
+    float t1[3], t2[3], inner[3], tau[3], cr[3];
+    mat3_chain(c->Pm, pose[0], pose[1], pose[2], t1);
+    if (pos_mode) {
+        /* :489-494 */
+        float t3[3], Jw[3];
+        mat3_chain(c->P12, ang[0], ang[1], ang[2], t2);
+        mat3_chain(c->Dm, al[0], al[1], al[2], t3);
+        mat3_chain(c->J, w[0], w[1], w[2], Jw);
+        cross_helper(w, Jw, cr);
+        for (int k = 0; k < 3; ++k) inner[k] = ((t1[k] + t2[k]) - t3[k]) - cr[k];
+    } else {
+        /* :451 */
+        mat3_chain(c->Pm, ang[0], ang[1], ang[2], t2);
+        cross_helper(w, w, cr);
+        for (int k = 0; k < 3; ++k) inner[k] = (t1[k] + t2[k]) - cr[k];
+    }
+    mat3_chain(c->J, inner[0], inner[1], inner[2], tau);
+    float u[4] = { gross, tau[0], tau[1], tau[2] };
+    mat4_chain(c->Binv, u, Td);                                /* :453,496 */
+}
+
 /* ---------- Dynamics.step ---------- */
 
 void vfo_dyn_step(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
@@ -148,6 +253,8 @@ void vfo_dyn_step(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
             u[0] = Fc;
             for (int k = 0; k < 3; ++k) u[k + 1] = (t1[k] + cr[k]) - t3[k];
             mat4_chain(c->Binv, u, Td);
+        } else if (c->action_type == VFO_ACT_VELOCITY || c->action_type == VFO_ACT_POSITION) {
+            geometric_controller(c, a, p, q, v, w, al, Td);
         } else {
             /* THRUST: dynamics.py:712-714,398-399 */
             for (int k = 0; k < 4; ++k) Td[k] = c->m * (a[k] * c->acc_half + c->acc_mean);

@@ -14,6 +14,8 @@ CASES = {
     "dyn_bodyrate_dt005": dict(action_type="bodyrate", dt=0.005, ctrl_dt=0.03, ctrl_delay=True,
                                wind_settings=[0.5, -0.25, 0.125]),
     "dyn_bodyrate_rk4": dict(action_type="bodyrate", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True, integrator="rk4"),
+    "dyn_velocity_euler": dict(action_type="velocity", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True),
+    "dyn_position_euler": dict(action_type="position", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True),
 }
 
 
@@ -21,7 +23,11 @@ CASES = {
 def test_constant_bits(name):
     want = consts_of(load(name))
     got = derive_constants(**CASES[name])
-    assert set(got) == set(want)
+    # fixtures generated before the geometric-controller constants existed lack those keys
+    from visfly_amd._lib import GEOMETRIC_FIELDS
+    assert set(want) <= set(got) and set(got) - set(want) <= set(GEOMETRIC_FIELDS)
+    if "velocity" in name or "position" in name:
+        assert set(got) == set(want)
     for k in want:
         a, b = np.asarray(got[k]), np.asarray(want[k])
         assert a.dtype == b.dtype and a.shape == b.shape, (k, a.dtype, b.dtype, a.shape, b.shape)

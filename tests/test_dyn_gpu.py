@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from _golden import assert_bits_equal, consts_of, decode_actions, load
+from _golden import GEOMETRIC, assert_bits_equal, assert_geometric_close, consts_of, decode_actions, load
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,7 @@ DYN = ["dyn_bodyrate_euler", "dyn_bodyrate_euler_wide", "dyn_thrust_euler", "dyn
 
 def make_dyn(consts, N, **kw):
     from visfly_amd import Dynamics
-    names = {0: "thrust", 1: "bodyrate"}
+    names = {0: "thrust", 1: "bodyrate", 2: "velocity", 3: "position"}
     return Dynamics(num=N, device="cuda:0", action_type=names[int(consts["action_type"])],
                     integrator="rk4" if int(consts["integrator"]) else "euler",
                     dt=float(consts["dt"]), ctrl_dt=float(consts["ctrl_dt"]), constants=consts, **kw)
@@ -48,6 +48,56 @@ def test_golden_bit_exact(name):
     # north_star tolerance, also against the un-patched reference (drift from its non-IEEE sqrt is reported)
     drift = np.abs(dyn.extend_state.cpu().numpy()[:, :13] - fx["raw_ext_last"][:, :13]).max()
     print(f"{name}: |HIP - unpatched reference| @ {acts.shape[0]} steps = {drift:.3e}")
+
+
+@pytest.mark.parametrize("name", GEOMETRIC)
+def test_geometric_controller_golden(name):
+    """velocity / position action types: the reference's per-agent Python loop
+    (dynamics.py:446-450) as one fused launch; tolerance-level parity (device sin/cos/atan2 vs SLEEF)"""
+    fx = load(name)
+    consts = consts_of(fx)
+    acts = decode_actions(fx)
+    N = fx["fs0"].shape[0]
+    dyn = make_dyn(consts, N)
+    set_full_state(dyn, fx["fs0"])
+    cps = list(fx["checkpoints"])
+    acts_d = torch.from_numpy(acts).cuda()
+    worst = 0.0
+    for k in range(acts.shape[0]):
+        obs = dyn.step(acts_d[k])
+        if (k + 1) in cps:
+            j = cps.index(k + 1)
+            worst = max(worst, assert_geometric_close(dyn.extend_state.cpu().numpy(), fx["ext"], fx["ext"][j],
+                                                      f"{name} extend_state @ {k + 1}"))
+            assert_geometric_close(obs.cpu().numpy(), fx["obs"], fx["obs"][j], f"{name} step() return @ {k + 1}")
+    print(f"{name}: worst deviation = {worst:.3f} of the tolerance")
+
+
+@pytest.mark.parametrize("mode", ["velocity", "position"])
+def test_geometric_vs_oracle_one_step(mode):
+    """single control steps from identical states: HIP vs the C oracle (libm) within 2e-6 relative"""
+    from visfly_amd import Dynamics
+    N = 1000
+    kw = dict(action_type=mode, dt=0.0025, ctrl_dt=0.02, ctrl_delay=True, comm_delay=0.0)
+    dyn = Dynamics(num=N, device="cuda:0", **kw)
+    ref = oracle.OracleDynamics(dyn.constants, N)
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        pos = (np.array([1, 0, 1.5]) + rng.uniform(-1, 1, (N, 3))).astype(np.float32)
+        vel = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+        eul = rng.uniform(-0.5, 0.5, (N, 3))
+        q = np.stack([np.cos(eul[:, 2] / 2), eul[:, 0] / 2, eul[:, 1] / 2, np.sin(eul[:, 2] / 2)], 1)
+        q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+        omg = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+        dyn.reset(pos=torch.from_numpy(pos), ori=torch.from_numpy(q), vel=torch.from_numpy(vel), ori_vel=torch.from_numpy(omg))
+        ref.reset(pos=pos, quat=q, vel=vel, omg=omg)
+        a = rng.uniform(-0.3, 0.3, (N, 4)).astype(np.float32)
+        s = dyn.step(torch.from_numpy(a).cuda()).cpu().numpy()
+        so = ref.step(a)
+        e, eo = dyn.extend_state.cpu().numpy(), ref.extend_state
+        scale = np.maximum(np.abs(eo).max(0), 1e-3)
+        assert (np.abs(e - eo) <= 2e-6 * scale).all(), (np.abs(e - eo) / scale).max()
+        assert (np.abs(s - so) <= 2e-6 * np.maximum(np.abs(so).max(0), 1e-3)).all()
 
 
 @pytest.mark.parametrize("N", [1, 63, 64, 65, 257, 4099])

@@ -168,6 +168,37 @@ def test_config3_navigation_rk4_ctrl_delay_drag_randomisation():
     assert (env2.envs.dynamics.drag_coefficients[0] != k0).any(dim=1).all()
 
 
+@pytest.mark.parametrize("mode", ["velocity", "position"])
+def test_env_with_geometric_controller(mode):
+    """HoverEnv driven through the velocity / position action types: same fused launch, the
+    geometric controller in front of the sub-steps.  State within 1e-4 of the oracle's column scale over 30
+    free-running steps (same bound as the golden fixtures), masks and counters exact."""
+    import oracle
+    from visfly_amd.envs import HoverEnv
+    N = 777
+    dkw = dict(action_type=mode, integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+    env = HoverEnv(num_agent_per_scene=N, seed=3, dynamics_kwargs=dkw, device="cuda:0", max_episode_steps=64,
+                   tensor_output=True)
+    env.reset()
+    c = env.envs.dynamics.constants
+    assert int(c["action_type"]) == {"velocity": 2, "position": 3}[mode]
+    ref = oracle.OracleEnv(c, N, "hover", 64, target=[1., 0., 1.5])
+    ref.reset_full_state(env.full_state.cpu().numpy())
+    g = torch.Generator().manual_seed(1)
+    worst = 0.0
+    for k in range(30):
+        a = (torch.rand((N, 4), generator=g) * 2 - 1) * 0.2
+        o, r, d, _ = env.step(a.cuda(), is_test=True)
+        ro, rr, rd = ref.step(a.numpy())
+        scale = np.maximum(np.abs(ro).max(0), 1e-3)
+        dev = (np.abs(o["state"].cpu().numpy() - ro) / scale).max()
+        worst = max(worst, dev)
+        assert dev <= 1e-4, f"{mode} state @ {k}: {dev:.2e}"
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), rd)
+        assert np.allclose(r.cpu().numpy(), rr, rtol=0, atol=1e-5)
+    print(f"{mode}: worst state deviation / column scale = {worst:.2e}")
+
+
 def test_edge_cases_empty_reset_single_agent_action_validation():
     import oracle
     from visfly_amd.envs import HoverEnv

@@ -16,6 +16,9 @@ TILE = 64
 G_POS, G_QUAT, G_VEL, G_OMG, G_MOT, G_THR, G_AACC, G_ACC, G_RING = range(9)
 
 
+GEOMETRIC_FIELDS = ("vel_half", "vel_mean", "yaw_half", "yaw_mean", "vel_p", "vel_d", "pos_d", "Pm", "P12")
+
+
 class DynCfg(C.Structure):
     """mirror of vf_dyn_cfg"""
     _fields_ = [
@@ -39,6 +42,10 @@ class DynCfg(C.Structure):
         ("pos_xy_lim", C.c_float), ("pos_z_lo", C.c_float), ("pos_z_hi", C.c_float),
         ("vel_lim", C.c_float), ("omg_lim", C.c_float),
         ("T_init", C.c_float), ("w_init", C.c_float),
+        ("vel_half", C.c_float), ("vel_mean", C.c_float),
+        ("yaw_half", C.c_float), ("yaw_mean", C.c_float),
+        ("vel_p", C.c_float), ("vel_d", C.c_float), ("pos_d", C.c_float),
+        ("Pm", C.c_float * 9), ("P12", C.c_float * 9),
     ]
 
     @classmethod
@@ -47,6 +54,8 @@ class DynCfg(C.Structure):
         for name, _ in cls._fields_:
             if name == "pad0":
                 continue
+            if name not in d and name in GEOMETRIC_FIELDS:
+                continue                     # constants of the velocity/position controller: zero when unused
             v = d[name]
             cur = getattr(c, name)
             if isinstance(cur, (int, float)):

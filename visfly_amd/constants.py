@@ -72,14 +72,21 @@ def derive_constants(
     B_inv = th.inverse(B)
 
     lo, hi = action_space
-    if ACTION_TYPES[action_type] > 1:
-        raise NotImplementedError(
-            f"action_type '{action_type}': the velocity/position geometric controllers are not part of the "
-            "MI355X hot path yet (SURVEY.md 8f-1); use 'bodyrate' or 'thrust'")
     acc_half = (acc_max - acc_min) / (hi - lo)                                # :627-631,650-654
     acc_mean = acc_max - acc_half * hi
     rate_half = (rate_max - rate_min) / (hi - lo)                             # :635-638
     rate_mean = rate_max - rate_half * hi
+    # velocity / position action types (:660-689): the "velocity" Uniform holds the speed range in
+    # velocity mode and the position range in position mode; the velocity-mode yaw Uniform is built
+    # with half = yaw_bias (= 0, :671), i.e. the yaw channel is ignored there.
+    rng_max = th.tensor(data["max_pos"] if action_type == "position" else data["max_spd"])
+    vel_half = (rng_max - (-rng_max)) / (hi - lo)
+    vel_mean = rng_max - vel_half * hi
+    yaw_scale = th.as_tensor(th.pi - (-th.pi)) / (hi - lo)
+    yaw_bias = th.pi - yaw_scale * hi
+    yaw_half, yaw_mean = (yaw_scale, yaw_bias) if action_type == "position" else (yaw_bias, yaw_bias)
+    geometric = action_type in ("velocity", "position")
+    vel_pid, pos_pid = data["VELOCITY_PID"], data["POSITION_PID"]
 
     scale = 1 / (2 * tm[0])                                                   # :545
 
@@ -108,7 +115,8 @@ def derive_constants(
         "rot_scale": _f(scale), "rot_neg_tm1": _f(-tm[1]),
         "rot_tm1sq": _f(tm[1].pow(2)), "rot_4tm0": _f(4 * tm[0]),
         "T_min": np.float32(0), "T_max": _f(T_max),
-        "acc_half": _f(acc_half[0]), "acc_mean": _f(acc_mean[0]),
+        "acc_half": np.float32(0) if geometric else _f(acc_half[0]),
+        "acc_mean": np.float32(0) if geometric else _f(acc_mean[0]),
         "rate_half": _f(rate_half) if action_type == "bodyrate" else np.float32(0),
         "rate_mean": _f(rate_mean) if action_type == "bodyrate" else np.float32(0),
         "k_lin": _f(k_lin[:, 0]), "k_quad": _f(k_quad[:, 0]),
@@ -116,5 +124,12 @@ def derive_constants(
         "pos_xy_lim": np.float32(100), "pos_z_lo": np.float32(0), "pos_z_hi": np.float32(20),   # :374-382
         "vel_lim": np.float32(20), "omg_lim": np.float32(10),
         "T_init": _f(T_init[0]), "w_init": _f(w_init[0]),
+        "vel_half": _f(vel_half) if geometric else np.float32(0),
+        "vel_mean": _f(vel_mean) if geometric else np.float32(0),
+        "yaw_half": _f(yaw_half) if geometric else np.float32(0),
+        "yaw_mean": _f(yaw_mean) if geometric else np.float32(0),
+        "vel_p": _f(th.tensor(vel_pid["p"])), "vel_d": _f(th.tensor(vel_pid["d"])),
+        "pos_d": _f(th.tensor(pos_pid["d"])),
+        "Pm": _f(P), "P12": _f(1.2 * P),                                       # :451,491
     }
     return {k: np.asarray(v) for k, v in c.items()}

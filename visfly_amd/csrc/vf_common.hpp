@@ -38,8 +38,10 @@ inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
 // Kernel shape per launch: while one-thread-per-agent work cannot even give every SIMD a wave
 // (<= 32768 agents) the two-wave split (rotation | translation on co-resident waves) wins; from one
 // wave per SIMD on, the plain kernel issues fewer instructions in total and has no hand-off barriers.  VISFLY_AMD_SPLIT=0/1 forces a shape (A/B experiments).
-inline bool use_split(int agents_padded)
+inline bool use_split(int agents_padded, const vf_dyn_cfg& cfg)
 {
+    // the geometric controller (velocity / position) needs the whole state in one thread
+    if (cfg.action_type != VF_ACT_THRUST && cfg.action_type != VF_ACT_BODYRATE) return false;
     static const int forced = [] {
         const char* e = getenv("VISFLY_AMD_SPLIT");
         return e ? atoi(e) : -1;

@@ -149,26 +149,32 @@ StepKernel pick_split_kernel(const vf_dyn_cfg& c)
     }
 }
 
+template <int ACT>
+StepKernel pick_step_kernel_a(const vf_dyn_cfg& c)
+{
+    const int key = (c.integrator == VF_INT_RK4 ? 2 : 0) | (c.ctrl_delay ? 1 : 0);
+    switch (key) {
+    case 0: return vf::k_dyn_step<ACT, VF_INT_EULER, false>;
+    case 1: return vf::k_dyn_step<ACT, VF_INT_EULER, true>;
+    case 2: return vf::k_dyn_step<ACT, VF_INT_RK4, false>;
+    default: return vf::k_dyn_step<ACT, VF_INT_RK4, true>;
+    }
+}
+
 StepKernel pick_step_kernel(const vf_dyn_cfg& c)
 {
-    const int key = (c.action_type == VF_ACT_BODYRATE ? 4 : 0) | (c.integrator == VF_INT_RK4 ? 2 : 0) |
-                    (c.ctrl_delay ? 1 : 0);
-    switch (key) {
-    case 0: return vf::k_dyn_step<VF_ACT_THRUST, VF_INT_EULER, false>;
-    case 1: return vf::k_dyn_step<VF_ACT_THRUST, VF_INT_EULER, true>;
-    case 2: return vf::k_dyn_step<VF_ACT_THRUST, VF_INT_RK4, false>;
-    case 3: return vf::k_dyn_step<VF_ACT_THRUST, VF_INT_RK4, true>;
-    case 4: return vf::k_dyn_step<VF_ACT_BODYRATE, VF_INT_EULER, false>;
-    case 5: return vf::k_dyn_step<VF_ACT_BODYRATE, VF_INT_EULER, true>;
-    case 6: return vf::k_dyn_step<VF_ACT_BODYRATE, VF_INT_RK4, false>;
-    default: return vf::k_dyn_step<VF_ACT_BODYRATE, VF_INT_RK4, true>;
+    switch (c.action_type) {
+    case VF_ACT_THRUST: return pick_step_kernel_a<VF_ACT_THRUST>(c);
+    case VF_ACT_BODYRATE: return pick_step_kernel_a<VF_ACT_BODYRATE>(c);
+    case VF_ACT_VELOCITY: return pick_step_kernel_a<VF_ACT_VELOCITY>(c);
+    default: return pick_step_kernel_a<VF_ACT_POSITION>(c);
     }
 }
 
 int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st)
 {
     vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out};
-    if (vf::use_split(h->Npad))
+    if (vf::use_split(h->Npad, h->cfg))
         hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->cfg, g);
     else
         hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->cfg, g);

@@ -97,6 +97,105 @@ __device__ __forceinline__ void derivs(const vf_dyn_cfg& c, const Quat& q, const
     mat3(c.Jinv, tq[0] - c0, tq[1] - c1, tq[2] - c2, dw);
 }
 
+// cross() helper of utils/maths.py:392-394: separately rounded products, then "+ 0"
+__device__ __forceinline__ void cross_helper(const float* a, const float* b, float* o)
+{
+    o[0] = (a[1] * b[2] - a[2] * b[1]) + 0.0f;
+    o[1] = (a[2] * b[0] - a[0] * b[2]) + 0.0f;
+    o[2] = (a[0] * b[1] - a[1] * b[0]) + 0.0f;
+}
+
+// Geometric SO(3) controller of the velocity / position action types (dynamics.py:414-452 / :453-496),
+// evaluated once per control interval; the reference walks the agents in a Python loop (:446-450).
+// x.norm(dim=0) = FMA chain + IEEE sqrt, 3x3 products = k-ordered FMA chains.
+// sin/cos/atan2 come from the device math library; torch's SLEEF variants differ in the last bit, so
+// these two action types are held to a tolerance, not to the bit (tests/test_dyn_gpu.py).
+template <bool POSITION>
+__device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const Agent& s, const float* a, float* Td)
+{
+    float cmd[4];   // _de_normalize :716-730 -> [yaw, x, y, z]
+    cmd[0] = a[0] * c.yaw_half + c.yaw_mean;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) cmd[k] = a[k] * c.vel_half + c.vel_mean;
+    float F[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float a_des;
+        if constexpr (POSITION) {
+            const float v_des = c.pos_d * (cmd[k + 1] - s.p[k]);   // :456
+            a_des = c.vel_d * (v_des - s.v[k]);                    // :457
+        } else {
+            a_des = c.vel_p * (cmd[k + 1] - s.v[k]);               // :416
+        }
+        F[k] = c.m * (a_des - (k == 2 ? c.g_z : 0.0f));            // :417,458
+    }
+    const Quat& q = s.q;
+    const float yaw_cur = atan2f(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));   // maths.py:248
+    float yaw_des, gain;
+    if constexpr (POSITION) {
+        yaw_des = cmd[0];                                          // :461
+        gain = c.pos_d;                                            // :468
+    } else {
+        const float vn = sqrtf(__builtin_fmaf(s.v[1], s.v[1], s.v[0] * s.v[0]));   // :421
+        yaw_des = vn > 0.1f ? atan2f(s.v[1], s.v[0]) : yaw_cur;                     // :423-427
+        gain = c.vel_d;                                            // :433
+    }
+    float ye = yaw_des - yaw_cur;
+    ye = atan2f(sinf(ye), cosf(ye));                               // :432,467
+    const float yaw_spd = ye * gain * 2.0f;
+    // gross thrust = (conj(q) * (0, F) * q).imag[2]               :435, maths.py:49,103
+    const Quat fb = qmul(qmul(Quat{q.w, -q.x, -q.y, -q.z}, Quat{0.0f, F[0], F[1], F[2]}), q);
+    float R[3][3];   // Quaternion.R (maths.py:116-120)
+    R[0][0] = 1.0f - 2.0f * (q.y * q.y + q.z * q.z); R[0][1] = 2.0f * (q.x * q.y - q.z * q.w); R[0][2] = 2.0f * (q.x * q.z + q.y * q.w);
+    R[1][0] = 2.0f * (q.x * q.y + q.z * q.w); R[1][1] = 1.0f - 2.0f * (q.x * q.x + q.z * q.z); R[1][2] = 2.0f * (q.y * q.z - q.x * q.w);
+    R[2][0] = 2.0f * (q.x * q.z - q.y * q.w); R[2][1] = 2.0f * (q.y * q.z + q.x * q.w); R[2][2] = 1.0f - 2.0f * (q.x * q.x + q.y * q.y);
+    // desired frame :437-442
+    const float fn = sqrtf(__builtin_fmaf(F[2], F[2], __builtin_fmaf(F[1], F[1], F[0] * F[0])));
+    const float b3[3] = {F[0] / fn, F[1] / fn, F[2] / fn};
+    const float c1[3] = {cosf(yaw_des), sinf(yaw_des), 0.0f};
+    float b2[3], b1[3];
+    cross_helper(b3, c1, b2);
+    const float bn = sqrtf(__builtin_fmaf(b2[2], b2[2], __builtin_fmaf(b2[1], b2[1], b2[0] * b2[0])));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b2[k] = b2[k] / bn;
+    cross_helper(b2, b3, b1);
+    float Rd[3][3];   // columns b1, b2, b3
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { Rd[r][0] = b1[r]; Rd[r][1] = b2[r]; Rd[r][2] = b3[r]; }
+    // :446-450 per agent: A = Rd^T R, Bm = R^T Rd (= A^T to the bit: products commute, same k order)
+    float A[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            A[i][j] = __builtin_fmaf(Rd[2][i], R[2][j], __builtin_fmaf(Rd[1][i], R[1][j], Rd[0][i] * R[0][j]));
+    const float m12 = 0.5f * (A[1][2] - A[2][1]), m02 = 0.5f * (A[0][2] - A[2][0]), m01 = 0.5f * (A[0][1] - A[1][0]);
+    const float pose[3] = {m12, -m02, m01};
+    float ang[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        ang[i] = __builtin_fmaf(A[i][2], yaw_spd, __builtin_fmaf(A[i][1], 0.0f, A[i][0] * 0.0f)) - s.w[i];
+    float t1[3], t2[3], inner[3], tau[3], cr[3];
+    mat3(c.Pm, pose[0], pose[1], pose[2], t1);
+    if constexpr (POSITION) {   // :489-494
+        float t3[3], Jw[3];
+        mat3(c.P12, ang[0], ang[1], ang[2], t2);
+        mat3(c.Dm, s.aa[0], s.aa[1], s.aa[2], t3);
+        mat3(c.J, s.w[0], s.w[1], s.w[2], Jw);
+        cross_helper(s.w, Jw, cr);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) inner[k] = ((t1[k] + t2[k]) - t3[k]) - cr[k];
+    } else {                    // :451
+        mat3(c.Pm, ang[0], ang[1], ang[2], t2);
+        cross_helper(s.w, s.w, cr);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) inner[k] = (t1[k] + t2[k]) - cr[k];
+    }
+    mat3(c.J, inner[0], inner[1], inner[2], tau);
+    const float u[4] = {fb.z, tau[0], tau[1], tau[2]};
+    mat4(c.Binv, u, Td);        // :453,496
+}
+
 // De-normalise the (delayed) action and run the low-level controller once per control
 // interval -> clamped desired rotor thrusts (dynamics.py:692-714,389-413,501).
 template <int ACT>
@@ -122,6 +221,8 @@ __device__ __forceinline__ void desired_thrusts(const vf_dyn_cfg& c, const Agent
 #pragma unroll
         for (int k = 0; k < 3; ++k) u[k + 1] = (t1[k] + cr[k]) - t3[k];
         mat4(c.Binv, u, Td);
+    } else if constexpr (ACT == VF_ACT_VELOCITY || ACT == VF_ACT_POSITION) {
+        geometric_controller<ACT == VF_ACT_POSITION>(c, s, a, Td);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) Td[k] = c.m * (a[k] * c.acc_half + c.acc_mean);

@@ -287,20 +287,26 @@ namespace {
 
 using EnvKernel = void (*)(const vf_dyn_cfg, const vf_env_cfg, const vf::EnvArgs);
 
+template <int KIND, int ACT>
+EnvKernel pick_env_kernel_ka(const vf_dyn_cfg& c)
+{
+    const int key = (c.integrator == VF_INT_RK4 ? 2 : 0) | (c.ctrl_delay ? 1 : 0);
+    switch (key) {
+    case 0: return vf::k_env_step<KIND, ACT, VF_INT_EULER, false>;
+    case 1: return vf::k_env_step<KIND, ACT, VF_INT_EULER, true>;
+    case 2: return vf::k_env_step<KIND, ACT, VF_INT_RK4, false>;
+    default: return vf::k_env_step<KIND, ACT, VF_INT_RK4, true>;
+    }
+}
+
 template <int KIND>
 EnvKernel pick_env_kernel_k(const vf_dyn_cfg& c)
 {
-    const int key = (c.action_type == VF_ACT_BODYRATE ? 4 : 0) | (c.integrator == VF_INT_RK4 ? 2 : 0) |
-                    (c.ctrl_delay ? 1 : 0);
-    switch (key) {
-    case 0: return vf::k_env_step<KIND, VF_ACT_THRUST, VF_INT_EULER, false>;
-    case 1: return vf::k_env_step<KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
-    case 2: return vf::k_env_step<KIND, VF_ACT_THRUST, VF_INT_RK4, false>;
-    case 3: return vf::k_env_step<KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
-    case 4: return vf::k_env_step<KIND, VF_ACT_BODYRATE, VF_INT_EULER, false>;
-    case 5: return vf::k_env_step<KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
-    case 6: return vf::k_env_step<KIND, VF_ACT_BODYRATE, VF_INT_RK4, false>;
-    default: return vf::k_env_step<KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
+    switch (c.action_type) {
+    case VF_ACT_THRUST: return pick_env_kernel_ka<KIND, VF_ACT_THRUST>(c);
+    case VF_ACT_BODYRATE: return pick_env_kernel_ka<KIND, VF_ACT_BODYRATE>(c);
+    case VF_ACT_VELOCITY: return pick_env_kernel_ka<KIND, VF_ACT_VELOCITY>(c);
+    default: return pick_env_kernel_ka<KIND, VF_ACT_POSITION>(c);
     }
 }
 
@@ -347,7 +353,7 @@ vf::DynArgs dyn_args(const vf_env* h, const float* action, float* obs)
 int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int auto_reset, hipStream_t st)
 {
     vf::EnvArgs g{dyn_args(h, action, out->obs), *out, h->g_race, auto_reset};
-    if (vf::use_split(h->dyn.Npad))
+    if (vf::use_split(h->dyn.Npad, h->dyn.cfg))
         hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);
     else
         hipLaunchKernelGGL(pick_env_kernel(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);

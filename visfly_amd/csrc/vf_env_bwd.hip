@@ -422,6 +422,8 @@ extern "C" int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* a, vf_stream_t 
 {
     if (!h || !a || !a->tape_slab || !a->action || !a->done || !a->adj_slab || !a->d_action)
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: null argument");
+    if (h->dyn.cfg.action_type != VF_ACT_THRUST && h->dyn.cfg.action_type != VF_ACT_BODYRATE)
+        return vf::fail(VF_EINVAL, "vf_env_step_bwd: the adjoint covers the thrust and bodyrate action types only");
     if (h->dyn.cfg.integrator != VF_INT_EULER)
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: only the Euler integrator has an adjoint (RK4: not yet)");
     if (h->cfg.kind == VF_ENV_NAV)

@@ -18,8 +18,9 @@ namespace vf {
 
 inline int check_dyn_cfg(const vf_dyn_cfg* cfg)
 {
-    if (cfg->action_type != VF_ACT_THRUST && cfg->action_type != VF_ACT_BODYRATE)
-        return fail(VF_EINVAL, "action_type %d not supported (thrust=0, bodyrate=1)", cfg->action_type);
+    if (cfg->action_type < VF_ACT_THRUST || cfg->action_type > VF_ACT_POSITION)
+        return fail(VF_EINVAL, "action_type %d not supported (thrust=0, bodyrate=1, velocity=2, position=3)",
+                    cfg->action_type);
     if (cfg->integrator != VF_INT_EULER && cfg->integrator != VF_INT_RK4)
         return fail(VF_EINVAL, "integrator %d not supported (euler=0, rk4=1)", cfg->integrator);
     if (cfg->interval_steps <= 0 || cfg->delay_steps < 0 || cfg->delay_steps > 64)
