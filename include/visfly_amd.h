@@ -326,6 +326,36 @@ typedef struct vf_mlp_desc {
 int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* in0, const float* in1, const float* in2,
                    const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream);
 
+/* Whole-network backward in ONE launch (+ one fold): what loss.backward() does for the actor-critic MLP
+ * (PPO.py:286-287, BPTT.py:127-129).  Layers are listed in execution (reverse) order.  A 64-row tile
+ * is owned by one block for ALL layers, so the data gradient a layer writes to dX is read back as dY
+ * by later entries of the same block without any grid-wide synchronisation; each block keeps dW/db
+ * of the current layer in MFMA accumulators across its tiles and writes ONE partial per layer into
+ * its row of `partials`; a fixed-order fold then produces grad[0:n_fold] (deterministic).
+ *   dY (M, ld_dy) upstream gradient, Y (M, ld_y) saved layer output for the ReLU mask or NULL,
+ *   X (M, ld_x) saved layer input, dX (M, ld_dx) data gradient or NULL; need_dx: 0 none, 1 store,
+ *   2 add into dX.  Column offsets are folded into the pointers.
+ *   partials: vf_mlp_backward_blocks(M) * n_fold floats.  accumulate != 0: grad += fold. */
+typedef struct vf_mlp_bwd_layer {
+    int32_t K, No;
+    int32_t need_dx;
+    int32_t ld_dy, ld_y, ld_x, ld_dx;
+    int32_t pad0;
+    int64_t w_off, b_off;        /* offsets into the flat parameter buffer == into a partial row */
+    const float* dY;
+    const float* Y;
+    const float* X;
+    float* dX;
+} vf_mlp_bwd_layer;
+typedef struct vf_mlp_bwd_desc {
+    int32_t n_layers;
+    int32_t n_fold;              /* number of leading parameters covered by the layers (row length of a partial) */
+    vf_mlp_bwd_layer layer[VF_MLP_MAX_LAYERS];
+} vf_mlp_bwd_desc;
+int32_t vf_mlp_backward_blocks(int32_t M);
+int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* params, float* partials, float* grad, int32_t M,
+                    int32_t accumulate, vf_stream_t stream);
+
 /* Squashed diagonal Gaussian head (SB3 SquashedDiagGaussianDistribution as used by
  * policies.py:114,177-181,195-226): a = tanh(mean + exp(log_std) * eps), eps ~ N(0,1) from
  * Philox4x32-10 keyed by (seed, row, step); log_prob as SB3 computes it.  deterministic != 0: a = tanh(mean). */

@@ -195,6 +195,55 @@ def test_fused_forward_equals_layerwise(M):
     assert torch.equal(m2, fused["mean"]) and torch.equal(v2, fused["value"])
 
 
+@pytest.mark.parametrize("M", [1, 63, 777, 25600, 40000])
+@pytest.mark.parametrize("with_value", [True, False])
+def test_fused_backward_equals_layerwise_and_torch(M, with_value):
+    """one-launch whole-network backward (block-private tiles, dW kept in MFMA accumulators across a block's
+    tiles) vs the per-layer kernels (data gradients bit-identical: same per-row arithmetic; weight gradients
+    equal up to the order of the fp32 row sums) and vs torch autograd on the same weights"""
+    from visfly_amd.ppo import MlpPolicy
+    pol = MlpPolicy({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64], DEV, seed=9)
+    g = torch.Generator(device=DEV).manual_seed(M)
+    obs = {"state": torch.randn((M, 13), device=DEV, generator=g), "target": torch.randn((M, 3), device=DEV, generator=g)}
+    d_mean = torch.randn((M, 4), device=DEV, generator=g) / M
+    d_value = torch.randn(M, device=DEV, generator=g) / M if with_value else None
+    d_ls = torch.randn(4, device=DEV, generator=g)
+    res = {}
+    for fused in (False, True):
+        pol.fused_backward = fused
+        pol.grad.fill_(7.0)
+        pol.forward(obs)
+        d_in = pol.backward(d_mean, d_value, d_ls, need_input_grad=True)
+        res[fused] = (pol.grad.clone(), {k: v.clone() for k, v in d_in.items()})
+    (g0, in0), (g1, in1) = res[False], res[True]
+    for k in in0:
+        assert torch.equal(in0[k], in1[k]), k                   # dLoss/d obs: bit-identical
+    scale = g0.abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 2e-6 * scale
+    if not with_value:                                           # the value trunk was skipped: its entries are untouched
+        vf = [ly for ly in pol.layers if ly.dst == "value" or ly.dst.startswith("vf:")]
+        assert all((g1[ly.w_off:ly.w_off + ly.K * ly.No] == 7.0).all() for ly in vf)
+    # accumulate mode adds the same gradient once more
+    pol.forward(obs)
+    pol.backward(d_mean, d_value, d_ls, accumulate=True)
+    live = g1 != 7.0
+    assert torch.allclose(pol.grad[live], 2 * g1[live], rtol=1e-5, atol=1e-6 * scale)
+    # torch autograd reference
+    ref = pol.to_torch()
+    o = {k: v.cpu().double() for k, v in obs.items()}
+    ref = ref.double()
+    mean, value = ref(o)
+    loss = (mean * d_mean.cpu().double()).sum() + ((value.view(-1) * d_value.cpu().double()).sum() if with_value else 0.0)
+    loss.backward()
+    for ly, m in zip(pol.layers, ref.lin):
+        if m.weight.grad is None:
+            continue
+        got = g1[ly.w_off:ly.w_off + ly.K * ly.No].view(ly.No, ly.K).cpu().double()
+        assert (got - m.weight.grad).abs().max().item() <= 2e-5 * max(m.weight.grad.abs().max().item(), 1e-6), ly.dst
+        gb = g1[ly.b_off:ly.b_off + ly.No].cpu().double()
+        assert (gb - m.bias.grad).abs().max().item() <= 2e-5 * max(m.bias.grad.abs().max().item(), 1e-6), ly.dst
+
+
 def test_adam_with_grad_clip_vs_torch():
     _lib, lib = L()
     n = 43977

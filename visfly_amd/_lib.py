@@ -126,6 +126,18 @@ class MlpDesc(C.Structure):
                 ("w_region_off", C.c_int32), ("lds_floats", C.c_int32), ("layer", MlpLayer * MLP_MAX_LAYERS)]
 
 
+class MlpBwdLayer(C.Structure):
+    """mirror of vf_mlp_bwd_layer"""
+    _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("need_dx", C.c_int32), ("ld_dy", C.c_int32), ("ld_y", C.c_int32),
+                ("ld_x", C.c_int32), ("ld_dx", C.c_int32), ("pad0", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64),
+                ("dY", C.c_void_p), ("Y", C.c_void_p), ("X", C.c_void_p), ("dX", C.c_void_p)]
+
+
+class MlpBwdDesc(C.Structure):
+    """mirror of vf_mlp_bwd_desc"""
+    _fields_ = [("n_layers", C.c_int32), ("n_fold", C.c_int32), ("layer", MlpBwdLayer * MLP_MAX_LAYERS)]
+
+
 class PpoLossCfg(C.Structure):
     """mirror of vf_ppo_loss_cfg"""
     _fields_ = [("clip_range", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("inv_batch", C.c_float)]
@@ -179,6 +191,8 @@ SIGNATURES = {
     "vf_linear_bwd_weight": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
                                        C.c_int32, _vp, _vp]),
     "vf_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
+    "vf_mlp_backward_blocks": (C.c_int32, [C.c_int32]),
+    "vf_mlp_backward": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),

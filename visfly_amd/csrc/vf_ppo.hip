@@ -8,6 +8,9 @@
 // over nn.Linear/ReLU; here each piece is one launch.  GEMMs use v_mfma_f32_32x32x2_f32
 // (exact fp32 products, fp32 accumulate, k-ordered), operands staged through LDS with an
 // odd row stride (conflict-free ds_read_b32 for the MFMA A/B fragments).
+#include <algorithm>
+#include <utility>
+
 #include "vf_common.hpp"
 #include "vf_env_device.hpp"  // Philox
 
@@ -409,6 +412,121 @@ __global__ __launch_bounds__(kBlock) void k_mlp_forward(const vf_mlp_desc d, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Whole-network backward: block-private row tiles, layer-major sweep (see vf_mlp_bwd_desc)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_mlp_backward(const vf_mlp_bwd_desc d, const float* __restrict__ params,
+                                                         float* __restrict__ part, int M)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 31, lk = lane >> 5;
+    const int rt = wave & 1, c0 = wave >> 1;
+    const int mtiles = (M + kRows - 1) / kRows;
+    float* prow = part + (size_t)blockIdx.x * d.n_fold;
+    for (int li = 0; li < d.n_layers; ++li) {
+        const vf_mlp_bwd_layer L = d.layer[li];
+        const int K = L.K, No = L.No;
+        const int nt = (No + 31) >> 5, kt = (K + 31) >> 5;
+        const int sd = nt * 32 + 1, sx = kt * 32 + 1, sw = kt * 32 + 1;
+        const int red16 = (No + 15) & ~15;
+        float* Ds = lds;                  // [64][sd]   masked dY rows (pad columns zero)
+        float* Xs = Ds + kRows * sd;      // [64][sx]   layer inputs
+        float* Ws = Xs + kRows * sx;      // [red16][sw] W image for the data gradient
+        __syncthreads();                  // the previous layer is done with LDS and its dX stores are issued
+        if ((No & 31) || (K & 31)) {      // stale words of the previous layer must not sit in pad columns
+            const int n = kRows * (sd + sx) + (L.need_dx ? red16 * sw : 0);
+            for (int idx = tid; idx < n; idx += kBlock) lds[idx] = 0.0f;
+            __syncthreads();
+        }
+        if (L.need_dx) stage_rows<false>(Ws, sw, params + L.w_off, K, nullptr, 0, 0, No, K, K, red16);
+        const int wtiles = nt * kt;       // <= 16 weight-gradient tiles of 32x32; wave takes wave, wave+4, ...
+        f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+        float bsum = 0.0f;
+        const int ct = kt;
+        const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
+        const int cgrp = No <= 64 ? 64 : 128;
+        for (int tile = blockIdx.x; tile < mtiles; tile += gridDim.x) {
+            const int m0 = tile * kRows;
+            stage_rows<true>(Ds, sd, L.dY, L.ld_dy, L.Y, L.ld_y, m0, M, No, No);
+            stage_rows<false>(Xs, sx, L.X, L.ld_x, nullptr, 0, m0, M, K, K);
+            __syncthreads();
+            {   // bias gradient: thread = (column, row slice)
+                const int c = tid & (cgrp - 1), sl = tid / cgrp, rows = kRows * cgrp / kBlock;
+                if (c < No) {
+                    float s0 = 0.0f, s1 = 0.0f;
+                    const float* dp = Ds + (sl * rows) * sd + c;
+                    for (int r = 0; r < rows; r += 2) { s0 += dp[r * sd]; s1 += dp[(r + 1) * sd]; }
+                    bsum += s0 + s1;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // dW[n][k] += sum_m dYm[m][n] X[m][k]
+                const int wt = wave + 4 * q;
+                if (wt >= wtiles) break;
+                const int it = wt / kt, jt = wt - it * kt;
+                const float* ap = Ds + lk * sd + it * 32 + lr;
+                const float* bp = Xs + lk * sx + jt * 32 + lr;
+                f32x16 c = acc[q];
+#pragma unroll
+                for (int k0 = 0; k0 < kRows; k0 += 16) {
+                    float fa[8], fb[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { fa[j] = ap[(k0 + 2 * j) * sd]; fb[j] = bp[(k0 + 2 * j) * sx]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], c, 0, 0, 0);
+                }
+                acc[q] = c;
+            }
+            if (L.need_dx) {               // dX[m][k] = sum_n dYm[m][n] W[n][k]
+                const float* ap = Ds + (rt * 32 + lr) * sd + lk;
+                const float* b0 = Ws + lk * sw + c0 * 32 + lr;
+                const float* b1 = Ws + lk * sw + (c0 + 2) * 32 + lr;
+                f32x16 a0 = {0}, a1 = {0};
+                if (nacc == 2) mfma_sweep2(ap, b0, b1, sw, red16, a0, a1);
+                else if (nacc == 1) mfma_sweep1(ap, b0, sw, red16, a0);
+                auto emit = [&](const f32x16& a, int ctile) {
+                    const int n = ctile * 32 + lr;
+                    if (n >= K) return;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int m = m0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                        if (m >= M) continue;
+                        float* dst = L.dX + (size_t)m * L.ld_dx + n;
+                        *dst = L.need_dx == 2 ? *dst + a[reg] : a[reg];
+                    }
+                };
+                if (nacc >= 1) emit(a0, c0);
+                if (nacc == 2) emit(a1, c0 + 2);
+            }
+            __syncthreads();               // all waves are done with Ds / Xs
+        }
+        // one partial per layer and block: weights, then the bias column sums
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wt = wave + 4 * q;
+            if (wt >= wtiles) break;
+            const int it = wt / kt, jt = wt - it * kt;
+            const int k = jt * 32 + lr;
+            if (k >= K) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int n = it * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                if (n < No) prow[L.w_off + (size_t)n * K + k] = acc[q][reg];
+            }
+        }
+        {
+            const int c = tid & (cgrp - 1), sl = tid / cgrp, nsl = kBlock / cgrp;
+            Ds[sl * cgrp + c] = bsum;      // Ds is free: the tile loop ended on a barrier
+            __syncthreads();
+            if (tid < No) {
+                float t = 0.0f;
+                for (int q = 0; q < nsl; ++q) t += Ds[q * cgrp + tid];
+                prow[L.b_off + tid] = t;
+            }
+        }
+    }
+}
+
 // dW[n][k] = sum_m dYm[m][n] X[m][k]; block = one chunk of rows, partial written to part[blk][No*K + No]
 __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict__ dY, int lddy, const float* __restrict__ Ym,
                                                          int ldym, const float* __restrict__ X, int ldx,
@@ -489,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
 
 // deterministic second stage: 16 lanes share one output element, each summing every 16th partial,
 // then a fixed-order shuffle tree; 16 elements per 256-thread block
-__global__ __launch_bounds__(kBlock) void k_fold_partials(const float* __restrict__ part, int nblk, int nw, int nb,
+__global__ __launch_bounds__(kBlock) void k_fold_partials(const float* __restrict__ part, int nblk, int stride, int nw, int nb,
                                                           float* __restrict__ dW, float* __restrict__ db, int accumulate)
 {
     const int n = nw + nb;
@@ -497,7 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_partials(const float* __restric
     const int sl = threadIdx.x >> 4;                       // slice 0..15 (same wave: lanes e + 16*k)
     float s = 0.0f;
     if (e < n)
-        for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * n + e];
+        for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * stride + e];
     s += __shfl_down(s, 32, 64);   // slices k and k+2 (lane + 32)
     s += __shfl_down(s, 16, 64);   // slices k and k+1 (lane + 16)
     __shared__ float sh[4][16];
@@ -800,7 +918,7 @@ static int linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, 
     hipLaunchKernelGGL(vf::k_linear_wgrad, dim3(nblk), dim3(vf::kBlock), lds, st, dY, lddy, Ymask, ldym, X, ldx, scratch, M, K,
                        No, rpb);
     const int n = No * K + No;
-    hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 15) / 16), dim3(vf::kBlock), 0, st, scratch, nblk,
+    hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 15) / 16), dim3(vf::kBlock), 0, st, scratch, nblk, n,
                        No * K, No, dW, db, accumulate);
     VF_HIP(hipGetLastError());
     return VF_OK;
@@ -836,6 +954,58 @@ int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* in
     vf::MlpIo io{{in0, in1, in2, in3}, {out0, out1}};
     hipLaunchKernelGGL(vf::k_mlp_forward, dim3(ntiles < 256 ? ntiles : 256), dim3(vf::kBlock), lds, vf::as_stream(stream), *desc,
                        params, io, M);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int32_t vf_mlp_backward_blocks(int32_t M)
+{
+    if (M <= 0) return 0;
+    const int mtiles = (M + vf::kRows - 1) / vf::kRows;
+    const int rounds = (mtiles + 255) / 256;      // tiles per block: equal work, at most one block per CU
+    return (mtiles + rounds - 1) / rounds;
+}
+
+int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* params, float* partials, float* grad, int32_t M,
+                    int32_t accumulate, vf_stream_t stream)
+{
+    if (!desc || !params || !partials || !grad || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_backward: bad argument");
+    if (desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS || desc->n_fold < 1)
+        return vf::fail(VF_EINVAL, "vf_mlp_backward: bad layer count / n_fold");
+    size_t lds = 0;
+    for (int i = 0; i < desc->n_layers; ++i) {
+        const vf_mlp_bwd_layer& L = desc->layer[i];
+        if (L.K < 1 || L.K > 128 || L.No < 1 || L.No > 128) return vf::fail(VF_EINVAL, "vf_mlp_backward: layer %d: K, No must be 1..128", i);
+        if (!L.dY || !L.X || L.ld_dy < L.No || L.ld_x < L.K || (L.Y && L.ld_y < L.No) || (L.need_dx && (!L.dX || L.ld_dx < L.K)))
+            return vf::fail(VF_EINVAL, "vf_mlp_backward: layer %d: missing pointer or short row stride", i);
+        if (L.w_off < 0 || L.b_off < 0 || L.w_off + (int64_t)L.K * L.No > desc->n_fold || L.b_off + L.No > desc->n_fold)
+            return vf::fail(VF_EINVAL, "vf_mlp_backward: layer %d: parameter offsets outside n_fold", i);
+        const int nt = (L.No + 31) >> 5, kt = (L.K + 31) >> 5, red16 = (L.No + 15) & ~15;
+        const size_t need = ((size_t)vf::kRows * (nt * 32 + 1 + kt * 32 + 1) + (L.need_dx ? (size_t)red16 * (kt * 32 + 1) : 0)) * sizeof(float);
+        lds = need > lds ? need : lds;
+    }
+    if (int rc = allow_lds(vf::k_mlp_backward, lds)) return rc;
+    const int nblk = vf_mlp_backward_blocks(M);
+    hipStream_t st = vf::as_stream(stream);
+    hipLaunchKernelGGL(vf::k_mlp_backward, dim3(nblk), dim3(vf::kBlock), lds, st, *desc, params, partials, M);
+    // fold the parameter ranges the listed layers cover (a skipped trunk leaves its columns of `partials` unwritten)
+    std::pair<int64_t, int64_t> iv[2 * VF_MLP_MAX_LAYERS];
+    int niv = 0;
+    for (int i = 0; i < desc->n_layers; ++i) {
+        const vf_mlp_bwd_layer& L = desc->layer[i];
+        iv[niv++] = {L.w_off, L.w_off + (int64_t)L.K * L.No};
+        iv[niv++] = {L.b_off, L.b_off + L.No};
+    }
+    std::sort(iv, iv + niv);
+    for (int i = 0; i < niv;) {
+        int64_t lo = iv[i].first, hi = iv[i].second;
+        int j = i + 1;
+        while (j < niv && iv[j].first <= hi) { hi = iv[j].second > hi ? iv[j].second : hi; ++j; }
+        const int n = (int)(hi - lo);
+        hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 15) / 16), dim3(vf::kBlock), 0, st, partials + lo, nblk, desc->n_fold, n, 0,
+                           grad + lo, (float*)nullptr, accumulate ? 1 : 0);
+        i = j;
+    }
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

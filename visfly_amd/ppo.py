@@ -107,6 +107,7 @@ class MlpPolicy:
         self._plan = self._plan_fused()
         self._descs = {}
         self.fused = True
+        self.fused_backward = True
 
     def _plan_fused(self):
         """LDS layout for the one-launch forward (vf_mlp_forward): every activation gets a [64][w|1] region
@@ -243,6 +244,8 @@ class MlpPolicy:
         M = self._last_M
         b = self._buffers(M)
         L, st = _lib.lib(), self._stream()
+        if self.fused_backward:
+            return self._backward_fused(b, M, d_mean, d_value, d_log_std, accumulate, need_input_grad)
         need = max(int(L.vf_linear_bwd_scratch_floats(M, ly.K, ly.No)) for ly in self.layers)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
@@ -274,6 +277,52 @@ class MlpPolicy:
             if rc:
                 _lib.check(rc)
             touched.add(key)
+        if d_log_std is not None:
+            if accumulate:
+                self.grad[self.log_std_off:] += d_log_std
+            else:
+                self.grad[self.log_std_off:] = d_log_std
+        return d_in
+
+    def _backward_fused(self, b, M, d_mean, d_value, d_log_std, accumulate, need_input_grad):
+        """the same sweep as the layer-by-layer path, as ONE launch + one fold (vf_mlp_backward): a block owns
+        its 64-row tiles for every layer, so g:* buffers written by one entry are read by the next without
+        a grid-wide barrier."""
+        L, st = _lib.lib(), self._stream()
+        gbuf = {"mean": d_mean}
+        if d_value is not None:
+            gbuf["value"] = d_value.view(M, 1)
+        d = _lib.MlpBwdDesc()
+        d.n_fold = self.log_std_off
+        touched, d_in, keep, n = set(), {}, [], 0
+        for ly in reversed(self.layers):
+            if d_value is None and (ly.dst == "value" or ly.dst.startswith("vf:")):
+                continue
+            dY = gbuf.get(ly.dst, b.get("g:" + ly.dst))
+            Y, X = b[ly.dst], b[ly.src]
+            e = d.layer[n]
+            n += 1
+            e.K, e.No, e.w_off, e.b_off = ly.K, ly.No, ly.w_off, ly.b_off
+            e.dY, e.ld_dy = _ptr(dY, ly.dc), dY.shape[1]
+            e.Y, e.ld_y = (_ptr(Y, ly.dc) if ly.relu else None), Y.shape[1]
+            e.X, e.ld_x = _ptr(X, ly.sc), X.shape[1]
+            e.need_dx = 0
+            if ly.first and not need_input_grad:
+                continue
+            if ly.first:
+                dX = d_in.setdefault(ly.src[4:], th.empty((M, ly.K), dtype=th.float32, device=self.device))
+            else:
+                dX = b["g:" + ly.src]
+            key = (ly.src, ly.sc)
+            e.dX, e.ld_dx, e.need_dx = _ptr(dX, ly.sc), dX.shape[1], (2 if key in touched else 1)
+            touched.add(key)
+            keep.append(dX)
+        d.n_layers = n
+        need = int(L.vf_mlp_backward_blocks(M)) * self.log_std_off
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = th.empty(need, dtype=th.float32, device=self.device)
+        _lib.check(L.vf_mlp_backward(C.byref(d), _ptr(self.flat), _ptr(self._scratch), _ptr(self.grad), M,
+                                     1 if accumulate else 0, st))
         if d_log_std is not None:
             if accumulate:
                 self.grad[self.log_std_off:] += d_log_std
@@ -435,15 +484,12 @@ class PPO:
         self.num_timesteps += self.n_steps * self.n_envs * self.world
 
     # ------------------------------------------------------------------------------------------
-    def _minibatch_update(self, idx):
-        """one optimiser step on the rows `idx` of the flattened buffer (PPO.py:203-292)"""
-        L, st, buf, pol = _lib.lib(), self._stream(), self.buf, self.policy
-        B = idx.numel()
-        obs = {k: buf.obs[k].view(-1, buf.obs[k].shape[-1]).index_select(0, idx) for k in self.obs_keys}
-        actions = buf.actions.view(-1, 4).index_select(0, idx)
-        old_lp = buf.log_probs.view(-1).index_select(0, idx)
-        adv = buf.advantages.view(-1).index_select(0, idx)
-        ret = buf.returns.view(-1).index_select(0, idx)
+    def _minibatch_update(self, mb):
+        """one optimiser step on a minibatch {obs:*, actions, old_lp, adv, ret} of contiguous rows (PPO.py:203-292)"""
+        L, st, pol = _lib.lib(), self._stream(), self.policy
+        obs = {k: mb["obs:" + k] for k in self.obs_keys}
+        actions, old_lp, adv, ret = mb["actions"], mb["old_lp"], mb["adv"], mb["ret"]
+        B = adv.numel()
         gB = B * self.world
         if self.normalize_advantage and gB > 1:
             advn = th.empty_like(adv)
@@ -479,10 +525,17 @@ class PPO:
         stats_acc = th.zeros(16, device=self.device)
         n_mb = 0
         stop = False
+        buf = self.buf
+        flat = {"actions": buf.actions.view(-1, 4), "old_lp": buf.log_probs.view(-1), "adv": buf.advantages.view(-1),
+                "ret": buf.returns.view(-1)}
+        flat.update({"obs:" + k: buf.obs[k].view(-1, buf.obs[k].shape[-1]) for k in self.obs_keys})
         for _epoch in range(self.n_epochs):
+            # one gather per epoch instead of one per minibatch: the shuffled copy makes every minibatch a
+            # contiguous slice (same rows, same order as indexing the buffer with perm[s:s+bs])
             perm = th.randperm(total, device=self.device, generator=g)
+            shuf = {k: v.index_select(0, perm) for k, v in flat.items()}
             for s in range(0, total - bs + 1, bs):
-                st = self._minibatch_update(perm[s:s + bs])
+                st = self._minibatch_update({k: v[s:s + bs] for k, v in shuf.items()})
                 stats_acc += st
                 n_mb += 1
                 if self.target_kl is not None:
