@@ -18,6 +18,22 @@ namespace vf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+#ifdef VF_PROBE   // tools/exp_probe.py: shader-clock time of block 0 per kernel phase (never part of the product build)
+__device__ unsigned long long g_probe[32];
+#define VF_PROBE_INIT() unsigned long long probe_t = clock64()
+#define VF_PROBE_AT(i)                                                \
+    do {                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                    \
+            const unsigned long long t_ = clock64();                  \
+            g_probe[i] += t_ - probe_t;                               \
+            probe_t = t_;                                             \
+        }                                                             \
+    } while (0)
+#else
+#define VF_PROBE_INIT()
+#define VF_PROBE_AT(i)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // GAE: thread per env walks T backwards; loads are coalesced across envs (common.py:119-132)
 // ------------------------------------------------------------------------------------------------
@@ -173,44 +189,43 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
     const int c4 = red >> 2;
     const bool vec = (red & 3) == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 32 && (lda & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (!MASK || !Ym || ((ldym & 3) == 0 && (reinterpret_cast<uintptr_t>(Ym) & 15) == 0));
+    const bool mask = MASK && Ym != nullptr;
     if (vec) {
         const int sh = 31 - __clz(c4);            // log2(float4 per row)
         const int col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
-        // batches of 8 independent 16-byte loads, then the LDS writes: one memory latency per batch
+        // batches of 8 independent 16-byte loads, then the LDS writes: one memory latency per batch.  Rows past
+        // the matrix read row M-1 again (valid address, no divergent branch around the load) and are zeroed by a select.
         for (int rb = r0; rb < nrows; rb += 8 * rstep) {
-            float4 v[8];
+            float4 v[8], y[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int r = rb + j * rstep;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < nrows && m0 + r < M) {
-                    x = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + col);
-                    if (MASK && Ym) {
-                        const float4 y = *reinterpret_cast<const float4*>(Ym + (size_t)(m0 + r) * ldym + col);
-                        x.x = y.x > 0.0f ? x.x : 0.0f; x.y = y.y > 0.0f ? x.y : 0.0f;
-                        x.z = y.z > 0.0f ? x.z : 0.0f; x.w = y.w > 0.0f ? x.w : 0.0f;
-                    }
-                }
-                v[j] = x;
+                const int m = min(m0 + rb + j * rstep, M - 1);
+                v[j] = *reinterpret_cast<const float4*>(A + (size_t)m * lda + col);
+                if (mask) y[j] = *reinterpret_cast<const float4*>(Ym + (size_t)m * ldym + col);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = rb + j * rstep;
+                const bool ok = m0 + r < M;
+                float4 x = v[j];
+                if (mask) {
+                    x.x = y[j].x > 0.0f ? x.x : 0.0f; x.y = y[j].y > 0.0f ? x.y : 0.0f;
+                    x.z = y[j].z > 0.0f ? x.z : 0.0f; x.w = y[j].w > 0.0f ? x.w : 0.0f;
+                }
                 if (r < nrows) {
                     float* d = As + r * sa + col;
-                    d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+                    d[0] = ok ? x.x : 0.0f; d[1] = ok ? x.y : 0.0f; d[2] = ok ? x.z : 0.0f; d[3] = ok ? x.w : 0.0f;
                 }
             }
         }
     } else {
         for (int idx = tid; idx < nrows * redp; idx += kBlock) {
             const int r = idx / redp, k = idx - r * redp;
-            float x = 0.0f;
-            if (m0 + r < M && k < red) {
-                x = A[(size_t)(m0 + r) * lda + k];
-                if (MASK && Ym && !(Ym[(size_t)(m0 + r) * ldym + k] > 0.0f)) x = 0.0f;
-            }
-            As[r * sa + k] = x;
+            const bool ok = m0 + r < M && k < red;
+            const int m = min(m0 + r, M - 1), kc = min(k, red - 1);
+            float x = A[(size_t)m * lda + kc];
+            if (mask) x = Ym[(size_t)m * ldym + kc] > 0.0f ? x : 0.0f;
+            As[r * sa + k] = ok ? x : 0.0f;
         }
     }
 }
@@ -237,19 +252,23 @@ struct RowPrefetch {
     __device__ __forceinline__ void load(const float* __restrict__ A, int lda, const float* __restrict__ Ym, int ldym, int m0,
                                          int M)
     {
+        const bool mask = MASK && Ym != nullptr;
+        float4 y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {       // rows past the matrix re-read row M-1 (no branch around the load), zeroed below
+            const int m = min(m0 + r0 + j * rstep, M - 1);
+            v[j] = *reinterpret_cast<const float4*>(A + (size_t)m * lda + col);
+            if (mask) y[j] = *reinterpret_cast<const float4*>(Ym + (size_t)m * ldym + col);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int r = r0 + j * rstep;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < kRows && m0 + r < M) {
-                x = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + col);
-                if (MASK && Ym) {
-                    const float4 y = *reinterpret_cast<const float4*>(Ym + (size_t)(m0 + r) * ldym + col);
-                    x.x = y.x > 0.0f ? x.x : 0.0f; x.y = y.y > 0.0f ? x.y : 0.0f;
-                    x.z = y.z > 0.0f ? x.z : 0.0f; x.w = y.w > 0.0f ? x.w : 0.0f;
-                }
+            const bool ok = m0 + r0 + j * rstep < M;
+            float4 x = v[j];
+            if (mask) {
+                x.x = y[j].x > 0.0f ? x.x : 0.0f; x.y = y[j].y > 0.0f ? x.y : 0.0f;
+                x.z = y[j].z > 0.0f ? x.z : 0.0f; x.w = y[j].w > 0.0f ? x.w : 0.0f;
             }
-            v[j] = x;
+            v[j] = make_float4(ok ? x.x : 0.0f, ok ? x.y : 0.0f, ok ? x.z : 0.0f, ok ? x.w : 0.0f);
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ As, int sa) const
@@ -347,6 +366,72 @@ struct MlpIo {
     float* out[2];
 };
 
+// Register prefetch of one layer's weights W[No][K] (row-major, contiguous): the global loads are issued a
+// whole layer ahead (before the MFMA sweep of the previous layer) and parked in LDS as Ws[n * sw + k]
+// after the barrier that frees the weight region.  vec: 16-byte loads (K/4 a power of two), up to 16 per
+// thread (128 x 128); narrow: up to 8 scalars per thread (K = 13, 3); anything else is staged directly.
+struct WeightPrefetch {
+    float4 v[16];
+    int mode;       // 0 direct, 1 vec, 2 narrow
+    int K, No;
+    const float* W;
+    __device__ __forceinline__ void issue(const float* __restrict__ W_, int K_, int No_)
+    {
+        W = W_; K = K_; No = No_;
+        const int c4 = K >> 2, tid = threadIdx.x;
+        const bool vec = (K & 3) == 0 && (c4 & (c4 - 1)) == 0 && c4 >= 1 && c4 <= 32 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
+                         K * No <= 16 * 4 * kBlock;
+        mode = vec ? 1 : (K * No <= 8 * kBlock ? 2 : 0);
+        if (mode == 1) {
+            const int sh = 31 - __clz(c4), col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
+            const int nj = (No + rstep - 1) >> (8 - sh);      // wave-uniform trip count; rows past No re-read row No-1
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < nj) v[j] = *reinterpret_cast<const float4*>(W + (size_t)min(r0 + j * rstep, No - 1) * K + col);
+        } else if (mode == 2) {
+            const int n = K * No, nj = (n + kBlock - 1) / kBlock;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nj) reinterpret_cast<float*>(v)[j] = W[min(tid + j * kBlock, n - 1)];
+        }
+    }
+    // rows No..rows_pad and columns K..cols_pad of the image are zeroed (disjoint from the data words: one barrier after)
+    __device__ __forceinline__ void park(float* __restrict__ Ws, int sw, int rows_pad, int cols_pad) const
+    {
+        const int tid = threadIdx.x;
+        if (rows_pad != No || cols_pad != K) {
+            for (int idx = tid; idx < rows_pad * cols_pad; idx += kBlock) {
+                const int r = idx / cols_pad, k = idx - r * cols_pad;
+                if (r >= No || k >= K) Ws[r * sw + k] = 0.0f;
+            }
+        }
+        if (mode == 1) {   // lanes past No hold a copy of row No-1 and write it again: same words, same values
+            const int c4 = K >> 2, sh = 31 - __clz(c4), col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
+            const int nj = (No + rstep - 1) >> (8 - sh);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < nj) {
+                    float* dst = Ws + min(r0 + j * rstep, No - 1) * sw + col;
+                    dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w;
+                }
+        } else if (mode == 2) {
+            const int n = K * No, nj = (n + kBlock - 1) / kBlock;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nj) {
+                    const int idx = min(tid + j * kBlock, n - 1);
+                    const int r = idx / K, k = idx - r * K;
+                    Ws[r * sw + k] = reinterpret_cast<const float*>(v)[j];
+                }
+        } else {
+            for (int idx = tid; idx < No * K; idx += kBlock) {
+                const int r = idx / K, k = idx - r * K;
+                Ws[r * sw + k] = W[idx];
+            }
+        }
+    }
+};
+
 __global__ __launch_bounds__(kBlock) void k_mlp_forward(const vf_mlp_desc d, const float* __restrict__ params, const MlpIo io,
                                                         int M)
 {
@@ -355,59 +440,83 @@ __global__ __launch_bounds__(kBlock) void k_mlp_forward(const vf_mlp_desc d, con
     const int rt = wave & 1, c0 = wave >> 1;
     float* Ws = lds + d.w_region_off;
     const int ntiles = (M + kRows - 1) / kRows;
+    VF_PROBE_INIT();
+    WeightPrefetch wp;
+    if ((int)blockIdx.x < ntiles) wp.issue(params + d.layer[0].w_off, d.layer[0].K, d.layer[0].No);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * kRows;
+        const bool full = m0 + kRows <= M;                 // no row guards in the epilogue except on the last tile
         __syncthreads();                                   // previous tile is completely consumed
-        for (int b = 0; b < d.n_inputs; ++b) {              // observations -> LDS (zero padded to an even width)
-            const int w = d.in_dim[b], wp = (w + 15) & ~15;   // zero padded to the MFMA chunk
-            stage_rows<false>(lds + d.lds_off[b], d.lds_stride[b], io.in[b], w, nullptr, 0, m0, M, w, wp);
+        VF_PROBE_AT(0);
+        for (int b = 0; b < d.n_inputs; ++b) {              // observations -> LDS
+            const int w = d.in_dim[b], wp16 = (w + 15) & ~15;   // zero padded to the MFMA chunk
+            stage_rows<false>(lds + d.lds_off[b], d.lds_stride[b], io.in[b], w, nullptr, 0, m0, M, w, wp16);
         }
+        VF_PROBE_AT(1);
         for (int li = 0; li < d.n_layers; ++li) {
             const vf_mlp_layer L = d.layer[li];
             const int red16 = (L.K + 15) & ~15, ct = (L.No + 31) >> 5, sw = red16 + 1;
             __syncthreads();                               // inputs of this layer are in LDS; W region is free
-            if (ct * 32 != L.No || red16 != L.K) {
-                for (int idx = tid; idx < ct * 32 * sw; idx += kBlock) Ws[idx] = 0.0f;
-                __syncthreads();
-            }
-            stage_rows<false>(Ws, sw, params + L.w_off, L.K, nullptr, 0, 0, L.No, L.K, L.K, ct * 32);
+            VF_PROBE_AT(2);
+            wp.park(Ws, sw, ct * 32, red16);
+            VF_PROBE_AT(3);
             __syncthreads();
+            VF_PROBE_AT(4);
+            {   // weights of the next layer (of the next tile's first layer after the last one) start travelling now
+                const bool wrap = li + 1 == d.n_layers;
+                if (!wrap || tile + (int)gridDim.x < ntiles) {
+                    const vf_mlp_layer& Nx = d.layer[wrap ? 0 : li + 1];
+                    wp.issue(params + Nx.w_off, Nx.K, Nx.No);
+                }
+            }
             const float* As = lds + d.lds_off[L.src] + L.src_col;
             const int sa = d.lds_stride[L.src];
             const float* ap = As + (rt * 32 + lr) * sa + lk;
             const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
-            const bool has0 = nacc >= 1, has1 = nacc == 2;
             const float* b0 = Ws + (c0 * 32 + lr) * sw + lk;
             const float* b1 = Ws + ((c0 + 2) * 32 + lr) * sw + lk;
             f32x16 acc0 = {0}, acc1 = {0};
             if (nacc == 2) mfma_sweep2(ap, b0, b1, 1, red16, acc0, acc1);
             else if (nacc == 1) mfma_sweep1(ap, b0, 1, red16, acc0);
+            VF_PROBE_AT(5);
             // epilogue: bias + ReLU, into the destination region (LDS or global) and the optional saved copy
-            float* dl = nullptr;
-            int sd = 0;
-            float* dg = nullptr;
-            int ldg = 0;
-            if (L.dst >= VF_MLP_OUT0) { dg = io.out[L.dst - VF_MLP_OUT0]; ldg = L.No; }
-            else { dl = lds + d.lds_off[L.dst] + L.dst_col; sd = d.lds_stride[L.dst]; }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (!(t ? has1 : has0)) continue;
-                const f32x16& acc = t ? acc1 : acc0;
-                const int n = (c0 + 2 * t) * 32 + lr;
-                if (n >= L.No) continue;
+            const int rb = rt * 32 + 4 * lk;               // first row of this lane's accumulator column
+            auto emit = [&](f32x16 acc, int ctile) {
+                const int n = ctile * 32 + lr;
+                if (n >= L.No) return;
                 const float bn = params[L.b_off + n];
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
                     float y = acc[reg] + bn;
                     if (L.relu) y = y > 0.0f ? y : 0.0f;
-                    if (dl) dl[r * sd + n] = y;
-                    if (m0 + r < M) {
-                        if (dg) dg[(size_t)(m0 + r) * ldg + n] = y;
-                        if (L.save) L.save[(size_t)(m0 + r) * L.save_ld + L.dst_col + n] = y;
+                    acc[reg] = y;
+                }
+                if (L.dst < VF_MLP_OUT0) {
+                    float* dl = lds + d.lds_off[L.dst] + L.dst_col + rb * d.lds_stride[L.dst] + n;
+                    const int sd = d.lds_stride[L.dst];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) dl[((reg & 3) + 8 * (reg >> 2)) * sd] = acc[reg];
+                }
+                float* gp = nullptr;
+                int ldg = 0;
+                if (L.dst >= VF_MLP_OUT0) { gp = io.out[L.dst - VF_MLP_OUT0] + (size_t)(m0 + rb) * L.No + n; ldg = L.No; }
+                else if (L.save) { gp = L.save + (size_t)(m0 + rb) * L.save_ld + L.dst_col + n; ldg = L.save_ld; }
+                if (gp) {
+                    if (full) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) gp[((reg & 3) + 8 * (reg >> 2)) * ldg] = acc[reg];
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int ro = (reg & 3) + 8 * (reg >> 2);
+                            if (m0 + rb + ro < M) gp[ro * ldg] = acc[reg];
+                        }
                     }
                 }
-            }
+            };
+            if (nacc >= 1) emit(acc0, c0);
+            if (nacc == 2) emit(acc1, c0 + 2);
+            VF_PROBE_AT(6);
         }
     }
 }
@@ -423,6 +532,7 @@ __global__ __launch_bounds__(kBlock) void k_mlp_backward(const vf_mlp_bwd_desc d
     const int rt = wave & 1, c0 = wave >> 1;
     const int mtiles = (M + kRows - 1) / kRows;
     float* prow = part + (size_t)blockIdx.x * d.n_fold;
+    VF_PROBE_INIT();
     for (int li = 0; li < d.n_layers; ++li) {
         const vf_mlp_bwd_layer L = d.layer[li];
         const int K = L.K, No = L.No;
@@ -432,13 +542,16 @@ __global__ __launch_bounds__(kBlock) void k_mlp_backward(const vf_mlp_bwd_desc d
         float* Ds = lds;                  // [64][sd]   masked dY rows (pad columns zero)
         float* Xs = Ds + kRows * sd;      // [64][sx]   layer inputs
         float* Ws = Xs + kRows * sx;      // [red16][sw] W image for the data gradient
+        VF_PROBE_AT(8);
         __syncthreads();                  // the previous layer is done with LDS and its dX stores are issued
+        VF_PROBE_AT(9);
         if ((No & 31) || (K & 31)) {      // stale words of the previous layer must not sit in pad columns
             const int n = kRows * (sd + sx) + (L.need_dx ? red16 * sw : 0);
             for (int idx = tid; idx < n; idx += kBlock) lds[idx] = 0.0f;
             __syncthreads();
         }
         if (L.need_dx) stage_rows<false>(Ws, sw, params + L.w_off, K, nullptr, 0, 0, No, K, K, red16);
+        VF_PROBE_AT(10);
         const int wtiles = nt * kt;       // <= 16 weight-gradient tiles of 32x32; wave takes wave, wave+4, ...
         f32x16 acc[4] = {{0}, {0}, {0}, {0}};
         float bsum = 0.0f;
@@ -449,7 +562,9 @@ __global__ __launch_bounds__(kBlock) void k_mlp_backward(const vf_mlp_bwd_desc d
             const int m0 = tile * kRows;
             stage_rows<true>(Ds, sd, L.dY, L.ld_dy, L.Y, L.ld_y, m0, M, No, No);
             stage_rows<false>(Xs, sx, L.X, L.ld_x, nullptr, 0, m0, M, K, K);
+            VF_PROBE_AT(11);
             __syncthreads();
+            VF_PROBE_AT(12);
             {   // bias gradient: thread = (column, row slice)
                 const int c = tid & (cgrp - 1), sl = tid / cgrp, rows = kRows * cgrp / kBlock;
                 if (c < No) {
@@ -477,6 +592,7 @@ __global__ __launch_bounds__(kBlock) void k_mlp_backward(const vf_mlp_bwd_desc d
                 }
                 acc[q] = c;
             }
+            VF_PROBE_AT(13);
             if (L.need_dx) {               // dX[m][k] = sum_n dYm[m][n] W[n][k]
                 const float* ap = Ds + (rt * 32 + lr) * sd + lk;
                 const float* b0 = Ws + lk * sw + c0 * 32 + lr;
@@ -498,7 +614,9 @@ __global__ __launch_bounds__(kBlock) void k_mlp_backward(const vf_mlp_bwd_desc d
                 if (nacc >= 1) emit(a0, c0);
                 if (nacc == 2) emit(a1, c0 + 2);
             }
+            VF_PROBE_AT(14);
             __syncthreads();               // all waves are done with Ds / Xs
+            VF_PROBE_AT(15);
         }
         // one partial per layer and block: weights, then the bias column sums
 #pragma unroll
@@ -957,6 +1075,19 @@ int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* in
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
+
+#ifdef VF_PROBE
+int vf_probe_read(unsigned long long* out, int32_t reset)
+{
+    VF_HIP(hipDeviceSynchronize());
+    VF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(vf::g_probe), sizeof(unsigned long long) * 32));
+    if (reset) {
+        unsigned long long z[32] = {0};
+        VF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vf::g_probe), z, sizeof(z)));
+    }
+    return VF_OK;
+}
+#endif
 
 int32_t vf_mlp_backward_blocks(int32_t M)
 {
