@@ -300,7 +300,7 @@ int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, 
 
 /* Whole actor-critic MLP forward in ONE launch (policies.py:195-254: extract_features -> mlp_extractor ->
  * action_net / value_net).  A workgroup walks 64-row tiles; activations live in LDS between layers,
- * each layer's weights are streamed through LDS once per tile, GEMMs on the fp32 MFMA.
+ * the weights come from the packed copy below as the MFMA B operand (two workgroups per CU), fp32 MFMA.
  * Buffers are numbered: 0..3 = the observation inputs (global, row-major, width in_dim[i]);
  * 4.. = LDS activation regions laid out by the host (offset / row stride in floats, stride odd);
  * VF_MLP_OUT0 / VF_MLP_OUT1 = the global outputs (mean (M,4), value (M,1)). */
@@ -313,6 +313,8 @@ typedef struct vf_mlp_layer {
     int32_t dst, dst_col;        /* buffer id and first column written */
     int32_t w_off, b_off;        /* offsets into the flat parameter buffer */
     int32_t save_ld;             /* row stride of `save`, 0 if none */
+    int32_t wt_off;              /* offset of this layer's packed (transposed, zero padded) weights, see below */
+    int32_t pad0;
     float* save;                 /* optional global copy of the layer output (training keeps activations) */
 } vf_mlp_layer;
 typedef struct vf_mlp_desc {
@@ -323,8 +325,14 @@ typedef struct vf_mlp_desc {
     int32_t lds_floats;          /* total dynamic LDS, floats */
     vf_mlp_layer layer[VF_MLP_MAX_LAYERS];
 } vf_mlp_desc;
-int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* in0, const float* in1, const float* in2,
-                   const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream);
+/* The forward reads its MFMA B operand straight from global memory: `packed` holds, per layer at float offset
+ * wt_off, Wt[k][n] = W[n][k] for k < round16(K), n < round32(No), zero padded (so neither the kernel nor
+ * the L1/L2-resident loads need guards).  vf_mlp_pack_weights refreshes it from `params` (call it after
+ * every optimiser step); vf_mlp_packed_floats = size of the packed buffer the layer table implies. */
+int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc);
+int vf_mlp_pack_weights(const vf_mlp_desc* desc, const float* params, float* packed, vf_stream_t stream);
+int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
+                   const float* in2, const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream);
 
 /* Whole-network backward in ONE launch (+ one fold): what loss.backward() does for the actor-critic MLP
  * (PPO.py:286-287, BPTT.py:127-129).  Layers are listed in execution (reverse) order.  A 64-row tile

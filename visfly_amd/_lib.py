@@ -116,7 +116,7 @@ class MlpLayer(C.Structure):
     """mirror of vf_mlp_layer"""
     _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("relu", C.c_int32), ("src", C.c_int32), ("src_col", C.c_int32),
                 ("dst", C.c_int32), ("dst_col", C.c_int32), ("w_off", C.c_int32), ("b_off", C.c_int32),
-                ("save_ld", C.c_int32), ("save", C.c_void_p)]
+                ("save_ld", C.c_int32), ("wt_off", C.c_int32), ("pad0", C.c_int32), ("save", C.c_void_p)]
 
 
 class MlpDesc(C.Structure):
@@ -190,7 +190,9 @@ SIGNATURES = {
     "vf_linear_bwd_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "vf_linear_bwd_weight": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
                                        C.c_int32, _vp, _vp]),
-    "vf_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
+    "vf_mlp_packed_floats": (C.c_int64, [C.POINTER(MlpDesc)]),
+    "vf_mlp_pack_weights": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp]),
+    "vf_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_mlp_backward_blocks": (C.c_int32, [C.c_int32]),
     "vf_mlp_backward": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),

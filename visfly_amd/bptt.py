@@ -74,6 +74,7 @@ class BPTT:
         self.policy = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},
                                 pk.get("extractor", {k: [128, 64] for k in self.obs_keys}), pk.get("pi", [64, 64]),
                                 pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed)
+        self.policy.lazy_pack = True        # this trainer calls mark_updated() after every optimiser step
         n = self.policy.n_params
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=self.device), th.zeros(n, device=self.device)
         self._sumsq, self._scratch = th.zeros(1, device=self.device), th.zeros(4096, device=self.device)
@@ -109,6 +110,7 @@ class BPTT:
                            self._opt_step, 0)
         _lib.check(L.vf_adam_step(_ptr(pol.flat), _ptr(pol.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params,
                                   _ptr(self._sumsq), C.byref(cfg), st))
+        pol.mark_updated()
         env.detach()                                          # :134
         self.num_timesteps += self.H * N * self.world
         return loss.detach() * self.world

@@ -366,83 +366,92 @@ struct MlpIo {
     float* out[2];
 };
 
-// Register prefetch of one layer's weights W[No][K] (row-major, contiguous): the global loads are issued a
-// whole layer ahead (before the MFMA sweep of the previous layer) and parked in LDS as Ws[n * sw + k]
-// after the barrier that frees the weight region.  vec: 16-byte loads (K/4 a power of two), up to 16 per
-// thread (128 x 128); narrow: up to 8 scalars per thread (K = 13, 3); anything else is staged directly.
-struct WeightPrefetch {
-    float4 v[16];
-    int mode;       // 0 direct, 1 vec, 2 narrow
-    int K, No;
-    const float* W;
-    __device__ __forceinline__ void issue(const float* __restrict__ W_, int K_, int No_)
-    {
-        W = W_; K = K_; No = No_;
-        const int c4 = K >> 2, tid = threadIdx.x;
-        const bool vec = (K & 3) == 0 && (c4 & (c4 - 1)) == 0 && c4 >= 1 && c4 <= 32 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
-                         K * No <= 16 * 4 * kBlock;
-        mode = vec ? 1 : (K * No <= 8 * kBlock ? 2 : 0);
-        if (mode == 1) {
-            const int sh = 31 - __clz(c4), col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
-            const int nj = (No + rstep - 1) >> (8 - sh);      // wave-uniform trip count; rows past No re-read row No-1
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j < nj) v[j] = *reinterpret_cast<const float4*>(W + (size_t)min(r0 + j * rstep, No - 1) * K + col);
-        } else if (mode == 2) {
-            const int n = K * No, nj = (n + kBlock - 1) / kBlock;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < nj) reinterpret_cast<float*>(v)[j] = W[min(tid + j * kBlock, n - 1)];
-        }
-    }
-    // rows No..rows_pad and columns K..cols_pad of the image are zeroed (disjoint from the data words: one barrier after)
-    __device__ __forceinline__ void park(float* __restrict__ Ws, int sw, int rows_pad, int cols_pad) const
-    {
-        const int tid = threadIdx.x;
-        if (rows_pad != No || cols_pad != K) {
-            for (int idx = tid; idx < rows_pad * cols_pad; idx += kBlock) {
-                const int r = idx / cols_pad, k = idx - r * cols_pad;
-                if (r >= No || k >= K) Ws[r * sw + k] = 0.0f;
-            }
-        }
-        if (mode == 1) {   // lanes past No hold a copy of row No-1 and write it again: same words, same values
-            const int c4 = K >> 2, sh = 31 - __clz(c4), col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
-            const int nj = (No + rstep - 1) >> (8 - sh);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j < nj) {
-                    float* dst = Ws + min(r0 + j * rstep, No - 1) * sw + col;
-                    dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w;
-                }
-        } else if (mode == 2) {
-            const int n = K * No, nj = (n + kBlock - 1) / kBlock;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < nj) {
-                    const int idx = min(tid + j * kBlock, n - 1);
-                    const int r = idx / K, k = idx - r * K;
-                    Ws[r * sw + k] = reinterpret_cast<const float*>(v)[j];
-                }
-        } else {
-            for (int idx = tid; idx < No * K; idx += kBlock) {
-                const int r = idx / K, k = idx - r * K;
-                Ws[r * sw + k] = W[idx];
-            }
-        }
-    }
+// MFMA sweeps with the B operand read straight from global memory (L1/L2-resident packed weights,
+// coalesced: lane lr = output column) and the A operand from LDS.  Fragments of the next 16 reduction
+// steps are fetched while the MFMAs of the current 16 run; the first B chunk is passed in by the caller,
+// who issues it before the barrier that publishes the A tile.  `ldb` = floats between reduction steps of B.
+struct BFrag {
+    float x[8];
 };
+__device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ bg, int ldb)
+{
+    BFrag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.x[j] = bg[(size_t)(2 * j) * ldb];
+    return f;
+}
+__device__ __forceinline__ void mfma_sweep_gb1(const float* __restrict__ ap, const float* __restrict__ bg0, int ldb, int red16,
+                                               BFrag x0, f32x16& acc0)
+{
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = ap[2 * j];
+    for (int k0 = 0; k0 < red16; k0 += 16) {
+        float an[8];
+        BFrag n0;
+        if (k0 + 16 < red16) {
+            n0 = load_bfrag(bg0 + (size_t)(k0 + 16) * ldb, ldb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) an[j] = ap[k0 + 16 + 2 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x0.x[j], acc0, 0, 0, 0);
+        if (k0 + 16 < red16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = an[j]; x0.x[j] = n0.x[j]; }
+        }
+    }
+}
+__device__ __forceinline__ void mfma_sweep_gb2(const float* __restrict__ ap, const float* __restrict__ bg0,
+                                               const float* __restrict__ bg1, int ldb, int red16, BFrag x0, BFrag x1,
+                                               f32x16& acc0, f32x16& acc1)
+{
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = ap[2 * j];
+    for (int k0 = 0; k0 < red16; k0 += 16) {
+        float an[8];
+        BFrag n0, n1;
+        if (k0 + 16 < red16) {
+            n0 = load_bfrag(bg0 + (size_t)(k0 + 16) * ldb, ldb);
+            n1 = load_bfrag(bg1 + (size_t)(k0 + 16) * ldb, ldb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) an[j] = ap[k0 + 16 + 2 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x0.x[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x1.x[j], acc1, 0, 0, 0);
+        }
+        if (k0 + 16 < red16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = an[j]; x0.x[j] = n0.x[j]; x1.x[j] = n1.x[j]; }
+        }
+    }
+}
 
-__global__ __launch_bounds__(kBlock) void k_mlp_forward(const vf_mlp_desc d, const float* __restrict__ params, const MlpIo io,
-                                                        int M)
+// Packed forward weights: per layer Wt[k][n] = W[n][k] for k < K16 = round16(K), n < N32 = round32(No), zero padded,
+// at float offset wt_off of the packed buffer (vf_mlp_pack_weights) -- the forward B operand without any guard.
+__global__ __launch_bounds__(kBlock) void k_mlp_pack_weights(const vf_mlp_desc d, const float* __restrict__ params,
+                                                             float* __restrict__ packed)
+{
+    const vf_mlp_layer L = d.layer[blockIdx.y];
+    if ((int)blockIdx.y >= d.n_layers) return;
+    const int K16 = (L.K + 15) & ~15, N32 = (L.No + 31) & ~31;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < K16 * N32; idx += gridDim.x * kBlock) {
+        const int k = idx / N32, n = idx - k * N32;
+        packed[L.wt_off + idx] = (k < L.K && n < L.No) ? params[L.w_off + n * L.K + k] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, const float* __restrict__ params,
+                                                           const float* __restrict__ packed, const MlpIo io, int M)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 31, lk = lane >> 5;
     const int rt = wave & 1, c0 = wave >> 1;
-    float* Ws = lds + d.w_region_off;
     const int ntiles = (M + kRows - 1) / kRows;
     VF_PROBE_INIT();
-    WeightPrefetch wp;
-    if ((int)blockIdx.x < ntiles) wp.issue(params + d.layer[0].w_off, d.layer[0].K, d.layer[0].No);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * kRows;
         const bool full = m0 + kRows <= M;                 // no row guards in the epilogue except on the last tile
@@ -455,29 +464,21 @@ __global__ __launch_bounds__(kBlock) void k_mlp_forward(const vf_mlp_desc d, con
         VF_PROBE_AT(1);
         for (int li = 0; li < d.n_layers; ++li) {
             const vf_mlp_layer L = d.layer[li];
-            const int red16 = (L.K + 15) & ~15, ct = (L.No + 31) >> 5, sw = red16 + 1;
-            __syncthreads();                               // inputs of this layer are in LDS; W region is free
+            const int red16 = (L.K + 15) & ~15, ct = (L.No + 31) >> 5, ldb = ct * 32;
+            const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
+            const float* bg0 = packed + L.wt_off + (size_t)lk * ldb + c0 * 32 + lr;
+            const float* bg1 = bg0 + 64;
+            BFrag x0, x1;                                   // first weight fragments travel while the barrier is pending
+            if (nacc >= 1) x0 = load_bfrag(bg0, ldb);
+            if (nacc == 2) x1 = load_bfrag(bg1, ldb);
+            __syncthreads();                               // inputs of this layer are in LDS
             VF_PROBE_AT(2);
-            wp.park(Ws, sw, ct * 32, red16);
-            VF_PROBE_AT(3);
-            __syncthreads();
-            VF_PROBE_AT(4);
-            {   // weights of the next layer (of the next tile's first layer after the last one) start travelling now
-                const bool wrap = li + 1 == d.n_layers;
-                if (!wrap || tile + (int)gridDim.x < ntiles) {
-                    const vf_mlp_layer& Nx = d.layer[wrap ? 0 : li + 1];
-                    wp.issue(params + Nx.w_off, Nx.K, Nx.No);
-                }
-            }
             const float* As = lds + d.lds_off[L.src] + L.src_col;
             const int sa = d.lds_stride[L.src];
             const float* ap = As + (rt * 32 + lr) * sa + lk;
-            const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
-            const float* b0 = Ws + (c0 * 32 + lr) * sw + lk;
-            const float* b1 = Ws + ((c0 + 2) * 32 + lr) * sw + lk;
             f32x16 acc0 = {0}, acc1 = {0};
-            if (nacc == 2) mfma_sweep2(ap, b0, b1, 1, red16, acc0, acc1);
-            else if (nacc == 1) mfma_sweep1(ap, b0, 1, red16, acc0);
+            if (nacc == 2) mfma_sweep_gb2(ap, bg0, bg1, ldb, red16, x0, x1, acc0, acc1);
+            else if (nacc == 1) mfma_sweep_gb1(ap, bg0, ldb, red16, x0, acc0);
             VF_PROBE_AT(5);
             // epilogue: bias + ReLU, into the destination region (LDS or global) and the optional saved copy
             const int rb = rt * 32 + 4 * lk;               // first row of this lane's accumulator column
@@ -1054,10 +1055,32 @@ int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, 
     return linear_bwd_weight(dY, lddy, Ymask, ldym, X, ldx, dW, db, M, K, No, scratch, stream, 1);
 }
 
-int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* in0, const float* in1, const float* in2,
-                   const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream)
+int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc)
 {
-    if (!desc || !params || !in0 || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_forward: bad argument");
+    if (!desc || desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS) return -1;
+    int64_t n = 0;
+    for (int i = 0; i < desc->n_layers; ++i) {
+        const vf_mlp_layer& L = desc->layer[i];
+        const int64_t end = L.wt_off + (int64_t)((L.K + 15) & ~15) * ((L.No + 31) & ~31);
+        n = end > n ? end : n;
+    }
+    return n;
+}
+
+int vf_mlp_pack_weights(const vf_mlp_desc* desc, const float* params, float* packed, vf_stream_t stream)
+{
+    if (!desc || !params || !packed || desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS)
+        return vf::fail(VF_EINVAL, "vf_mlp_pack_weights: bad argument");
+    hipLaunchKernelGGL(vf::k_mlp_pack_weights, dim3(8, desc->n_layers), dim3(vf::kBlock), 0, vf::as_stream(stream), *desc, params,
+                       packed);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
+                   const float* in2, const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream)
+{
+    if (!desc || !params || !packed || !in0 || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_forward: bad argument");
     if (desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS || desc->n_inputs < 1 || desc->n_inputs > 4)
         return vf::fail(VF_EINVAL, "vf_mlp_forward: bad layer / input count");
     for (int i = 0; i < desc->n_layers; ++i) {
@@ -1069,9 +1092,11 @@ int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* in
     if (lds > 160 * 1024) return vf::fail(VF_EINVAL, "vf_mlp_forward: LDS plan needs %zu bytes (> 160 KiB)", lds);
     if (int rc = allow_lds(vf::k_mlp_forward, lds)) return rc;
     const int ntiles = (M + vf::kRows - 1) / vf::kRows;
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;           // workgroups that fit one CU's 160 KiB
+    const int cap = 256 * per_cu;
     vf::MlpIo io{{in0, in1, in2, in3}, {out0, out1}};
-    hipLaunchKernelGGL(vf::k_mlp_forward, dim3(ntiles < 256 ? ntiles : 256), dim3(vf::kBlock), lds, vf::as_stream(stream), *desc,
-                       params, io, M);
+    hipLaunchKernelGGL(vf::k_mlp_forward, dim3(ntiles < cap ? ntiles : cap), dim3(vf::kBlock), lds, vf::as_stream(stream), *desc,
+                       params, packed, io, M);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -108,11 +108,13 @@ class MlpPolicy:
         self._descs = {}
         self.fused = True
         self.fused_backward = True
+        self._packed, self._pack_desc, self._stamp, self._packed_stamp, self.lazy_pack = None, None, 0, -1, False
 
     def _plan_fused(self):
         """LDS layout for the one-launch forward (vf_mlp_forward): every activation gets a [64][w|1] region
-        (odd row stride), regions are recycled once their last reader has run (first fit); None if the
-        network does not fit in the 160 KiB LDS budget -> layer-by-layer launches."""
+        (odd row stride); regions are recycled once their last reader has run (first fit over a coalescing
+        free list).  The weights do not occupy LDS (packed copy in global memory, read as the MFMA B operand).
+        None if the activations do not fit the 160 KiB LDS -> layer-by-layer launches."""
         rows = 64
         odd = lambda w: ((w + 15) & ~15) + 1                      # odd stride covering the width padded to 16
         names = ["obs:" + k for k in self.obs_keys]
@@ -124,6 +126,17 @@ class MlpPolicy:
         ids, off, stride, size = {}, {}, {}, {}
         free, top = [], 0
 
+        def release(o, n):
+            free.append((o, n))
+            free.sort()
+            merged = []
+            for fo, fs in free:
+                if merged and merged[-1][0] + merged[-1][1] == fo:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + fs)
+                else:
+                    merged.append((fo, fs))
+            free[:] = merged
+
         def alloc(name, w):
             nonlocal top
             st = odd(w)
@@ -132,7 +145,7 @@ class MlpPolicy:
                 if fs >= need:
                     free.pop(fi)
                     if fs > need:
-                        free.append((fo + need, fs - need))
+                        release(fo + need, fs - need)
                     off[name], stride[name], size[name] = fo, st, need
                     return
             off[name], stride[name], size[name] = top, st, need
@@ -142,23 +155,23 @@ class MlpPolicy:
             ids[n] = bi
             alloc(n, self.obs_dims[n[4:]])
         nxt = 4
-        written = set()
         for li, ly in enumerate(self.layers):
             if ly.dst not in ("mean", "value") and ly.dst not in ids:
                 ids[ly.dst] = nxt
                 nxt += 1
                 alloc(ly.dst, self.widths[ly.dst])
-            written.add(ly.dst)
             for n in list(off):            # release regions nobody reads any more (never the one being written)
                 if last_read.get(n, -1) <= li and n in size and n != ly.dst and n not in ("mean", "value"):
-                    free.append((off[n], size.pop(n)))
+                    release(off[n], size.pop(n))
         if nxt > _lib.MLP_MAX_BUFS:
             return None
-        wmax = max((((ly.No + 31) // 32) * 32) * (((ly.K + 15) & ~15) + 1) for ly in self.layers)
-        total = top + wmax
-        if total * 4 > 160 * 1024:
+        if top * 4 > 160 * 1024:
             return None
-        return dict(ids=ids, off=off, stride=stride, w_off=top, total=total)
+        wt_off, o = [], 0
+        for ly in self.layers:               # packed forward weights: [round16(K)][round32(No)] per layer
+            wt_off.append(o)
+            o += ((ly.K + 15) & ~15) * ((ly.No + 31) & ~31)
+        return dict(ids=ids, off=off, stride=stride, total=top, wt_off=wt_off, packed_floats=o)
 
     def _fused_desc(self, b, save: bool):
         p = self._plan
@@ -168,16 +181,31 @@ class MlpPolicy:
             d.in_dim[i] = self.obs_dims[k]
         for n, bid in p["ids"].items():
             d.lds_off[bid], d.lds_stride[bid] = p["off"][n], p["stride"][n]
-        d.w_region_off, d.lds_floats = p["w_off"], p["total"]
+        d.w_region_off, d.lds_floats = 0, p["total"]
         for li, ly in enumerate(self.layers):
             L = d.layer[li]
             L.K, L.No, L.relu = ly.K, ly.No, 1 if ly.relu else 0
             L.src, L.src_col = p["ids"][ly.src], ly.sc
             L.dst = {"mean": _lib.MLP_OUT0, "value": _lib.MLP_OUT1}.get(ly.dst, p["ids"].get(ly.dst, 0))
-            L.dst_col, L.w_off, L.b_off = ly.dc, ly.w_off, ly.b_off
-            if save and ly.dst not in ("mean", "value"):
+            L.dst_col, L.w_off, L.b_off, L.wt_off = ly.dc, ly.w_off, ly.b_off, p["wt_off"][li]
+            if save and b is not None and ly.dst not in ("mean", "value"):
                 L.save, L.save_ld = b[ly.dst].data_ptr(), b[ly.dst].shape[1]
         return d
+
+    def mark_updated(self):
+        """call after writing ``self.flat`` (optimiser step, load): the packed forward weights are refreshed
+        by the next forward.  With ``lazy_pack`` False (default) every forward repacks -- safe for callers that
+        write ``flat`` directly; the trainers set ``lazy_pack`` and call this after each step."""
+        self._stamp += 1
+
+    def _pack(self):
+        if self._packed is None:
+            self._packed = th.empty(self._plan["packed_floats"], dtype=th.float32, device=self.device)
+            self._pack_desc = self._fused_desc(None, False)
+        if self.lazy_pack and self._packed_stamp == self._stamp:
+            return
+        _lib.check(_lib.lib().vf_mlp_pack_weights(C.byref(self._pack_desc), _ptr(self.flat), _ptr(self._packed), self._stream()))
+        self._packed_stamp = self._stamp
 
     # -------------------------------------------------------------------------------------------
     def weight(self, ly):
@@ -223,8 +251,9 @@ class MlpPolicy:
             if d is None:
                 d = self._descs[key] = self._fused_desc(b, save_activations)
             ins = [_ptr(obs[k]) for k in self.obs_keys] + [None] * (4 - len(self.obs_keys))
-            rc = L.vf_mlp_forward(C.byref(d), _ptr(self.flat), ins[0], ins[1], ins[2], ins[3], _ptr(b["mean"]),
-                                  _ptr(b["value"]), M, st)
+            self._pack()
+            rc = L.vf_mlp_forward(C.byref(d), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], ins[2], ins[3],
+                                  _ptr(b["mean"]), _ptr(b["value"]), M, st)
             if rc:
                 _lib.check(rc)
             return b["mean"], b["value"]
@@ -414,6 +443,7 @@ class PPO:
         extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
         self.policy = MlpPolicy(obs_dims, extractor, pk.get("pi", [64, 64]), pk.get("vf", [64, 64]), self.device,
                                 log_std_init=pk.get("log_std_init", 0.0), seed=seed)
+        self.policy.lazy_pack = True        # this trainer calls mark_updated() after every optimiser step
         self.buf = RolloutBuffer(n_steps, self.n_envs, obs_dims, self.device)
         n = self.policy.n_params
         dev = self.device
@@ -514,6 +544,7 @@ class PPO:
                             self.max_grad_norm if self.max_grad_norm is not None else 0.0, self._opt_step, 0)
         _lib.check(L.vf_adam_step(_ptr(pol.flat), _ptr(pol.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params,
                                   _ptr(self._sumsq), C.byref(acfg), st))
+        pol.mark_updated()
         return self._stats
 
     def train(self):
