@@ -313,8 +313,8 @@ typedef struct vf_mlp_layer {
     int32_t dst, dst_col;        /* buffer id and first column written */
     int32_t w_off, b_off;        /* offsets into the flat parameter buffer */
     int32_t save_ld;             /* row stride of `save`, 0 if none */
-    int32_t wt_off;              /* offset of this layer's packed (transposed, zero padded) weights, see below */
-    int32_t pad0;
+    int32_t wt_off;              /* offset of this layer's packed forward weights (transposed, zero padded), see below */
+    int32_t wb_off;              /* offset of this layer's packed data-gradient weights (zero padded), see below */
     float* save;                 /* optional global copy of the layer output (training keeps activations) */
 } vf_mlp_layer;
 typedef struct vf_mlp_desc {
@@ -327,8 +327,10 @@ typedef struct vf_mlp_desc {
 } vf_mlp_desc;
 /* The forward reads its MFMA B operand straight from global memory: `packed` holds, per layer at float offset
  * wt_off, Wt[k][n] = W[n][k] for k < round16(K), n < round32(No), zero padded (so neither the kernel nor
- * the L1/L2-resident loads need guards).  vf_mlp_pack_weights refreshes it from `params` (call it after
- * every optimiser step); vf_mlp_packed_floats = size of the packed buffer the layer table implies. */
+ * the L1/L2-resident loads need guards); the data gradient of vf_mlp_backward reads, at wb_off,
+ * Wb[n][k] = W[n][k] for n < round16(No), k < round32(K).  vf_mlp_pack_weights refreshes both from
+ * `params` (call it after every optimiser step); vf_mlp_packed_floats = size of the packed buffer the
+ * layer table implies. */
 int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc);
 int vf_mlp_pack_weights(const vf_mlp_desc* desc, const float* params, float* packed, vf_stream_t stream);
 int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
@@ -348,7 +350,7 @@ typedef struct vf_mlp_bwd_layer {
     int32_t K, No;
     int32_t need_dx;
     int32_t ld_dy, ld_y, ld_x, ld_dx;
-    int32_t pad0;
+    int32_t wb_off;              /* packed data-gradient weights of this layer (vf_mlp_layer.wb_off) */
     int64_t w_off, b_off;        /* offsets into the flat parameter buffer == into a partial row */
     const float* dY;
     const float* Y;
@@ -361,7 +363,7 @@ typedef struct vf_mlp_bwd_desc {
     vf_mlp_bwd_layer layer[VF_MLP_MAX_LAYERS];
 } vf_mlp_bwd_desc;
 int32_t vf_mlp_backward_blocks(int32_t M);
-int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* params, float* partials, float* grad, int32_t M,
+int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* partials, float* grad, int32_t M,
                     int32_t accumulate, vf_stream_t stream);
 
 /* Squashed diagonal Gaussian head (SB3 SquashedDiagGaussianDistribution as used by

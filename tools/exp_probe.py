@@ -20,8 +20,8 @@ DEV = "cuda:0"
 pol = MlpPolicy({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64], DEV, seed=9)
 FWD = {0: "tile-top barrier", 1: "obs -> LDS", 2: "layer-top barrier", 3: "zero + W loads/ds_write", 4: "barrier after W",
        5: "MFMA sweep", 6: "epilogue"}
-BWD = {8: "partials of prev layer", 9: "layer-top barrier", 10: "zero + W stage", 11: "dY/Y/X stage", 12: "barrier",
-       13: "bias + dW MFMA", 14: "dX MFMA + store", 15: "tail barrier"}
+BWD = {8: "item 0 staging", 9: "issue next item + B frag", 13: "bias + dW MFMA", 14: "dX MFMA + store", 10: "partials (layer end)",
+       15: "barrier (buffer consumed)", 11: "park next item", 12: "barrier (buffer ready)"}
 for M in (64, 25600):
     obs = {"state": torch.randn((M, 13), device=DEV), "target": torch.randn((M, 3), device=DEV)}
     dm, dv, dl = torch.randn((M, 4), device=DEV), torch.randn(M, device=DEV), torch.randn(4, device=DEV)

@@ -116,7 +116,7 @@ class MlpLayer(C.Structure):
     """mirror of vf_mlp_layer"""
     _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("relu", C.c_int32), ("src", C.c_int32), ("src_col", C.c_int32),
                 ("dst", C.c_int32), ("dst_col", C.c_int32), ("w_off", C.c_int32), ("b_off", C.c_int32),
-                ("save_ld", C.c_int32), ("wt_off", C.c_int32), ("pad0", C.c_int32), ("save", C.c_void_p)]
+                ("save_ld", C.c_int32), ("wt_off", C.c_int32), ("wb_off", C.c_int32), ("save", C.c_void_p)]
 
 
 class MlpDesc(C.Structure):
@@ -129,7 +129,7 @@ class MlpDesc(C.Structure):
 class MlpBwdLayer(C.Structure):
     """mirror of vf_mlp_bwd_layer"""
     _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("need_dx", C.c_int32), ("ld_dy", C.c_int32), ("ld_y", C.c_int32),
-                ("ld_x", C.c_int32), ("ld_dx", C.c_int32), ("pad0", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64),
+                ("ld_x", C.c_int32), ("ld_dx", C.c_int32), ("wb_off", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64),
                 ("dY", C.c_void_p), ("Y", C.c_void_p), ("X", C.c_void_p), ("dX", C.c_void_p)]
 
 

@@ -180,7 +180,7 @@ __device__ __forceinline__ void mfma_sweep2(const float* __restrict__ ap, const 
 // Stage one 64-row tile of A (optionally masked by Ym > 0) into LDS rows of odd stride `sa`.
 // Vector path: 16-byte global loads when the row length is a multiple of 4 with a power-of-two
 // number of float4 per row (K, No in {4, 8, ..., 128}); scalar path otherwise (K = 13, 3).
-template <bool MASK>
+template <bool MASK, int NT = kBlock>
 __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const float* __restrict__ A, int lda,
                                            const float* __restrict__ Ym, int ldym, int m0, int M, int red, int redp,
                                            int nrows = kRows)
@@ -190,42 +190,65 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
     const bool vec = (red & 3) == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 32 && (lda & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (!MASK || !Ym || ((ldym & 3) == 0 && (reinterpret_cast<uintptr_t>(Ym) & 15) == 0));
     const bool mask = MASK && Ym != nullptr;
+    // wave-uniform 64-bit bases + 32-bit lane offsets (one VGPR per address).  Rows past the matrix read row
+    // M-1 again (valid address, no divergent branch around the load) and are zeroed by a select.
+    const float* Ab = A + (size_t)m0 * lda;
+    const float* Yb = mask ? Ym + (size_t)m0 * ldym : nullptr;
+    const int rmax = M - 1 - m0;                  // last valid row of this tile
     if (vec) {
         const int sh = 31 - __clz(c4);            // log2(float4 per row)
-        const int col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBlock >> sh;
-        // batches of 8 independent 16-byte loads, then the LDS writes: one memory latency per batch.  Rows past
-        // the matrix read row M-1 again (valid address, no divergent branch around the load) and are zeroed by a select.
-        for (int rb = r0; rb < nrows; rb += 8 * rstep) {
+        const int col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = NT >> sh;
+        for (int rb0 = 0; rb0 < nrows; rb0 += 8 * rstep) {   // batches of <= 8 independent 16-byte loads, then the LDS writes
+            const int rb = rb0 + r0;
+            const int nj = min(8, (nrows - rb0 + rstep - 1) / rstep);   // wave-uniform trip count: no loads for rows that do not exist
             float4 v[8], y[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int m = min(m0 + rb + j * rstep, M - 1);
-                v[j] = *reinterpret_cast<const float4*>(A + (size_t)m * lda + col);
-                if (mask) y[j] = *reinterpret_cast<const float4*>(Ym + (size_t)m * ldym + col);
+                if (j < nj) {
+                    const int r = min(rb + j * rstep, rmax);
+                    v[j] = *reinterpret_cast<const float4*>(Ab + (unsigned)(r * lda + col));
+                    if (mask) y[j] = *reinterpret_cast<const float4*>(Yb + (unsigned)(r * ldym + col));
+                }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int r = rb + j * rstep;
-                const bool ok = m0 + r < M;
-                float4 x = v[j];
-                if (mask) {
-                    x.x = y[j].x > 0.0f ? x.x : 0.0f; x.y = y[j].y > 0.0f ? x.y : 0.0f;
-                    x.z = y[j].z > 0.0f ? x.z : 0.0f; x.w = y[j].w > 0.0f ? x.w : 0.0f;
-                }
-                if (r < nrows) {
-                    float* d = As + r * sa + col;
-                    d[0] = ok ? x.x : 0.0f; d[1] = ok ? x.y : 0.0f; d[2] = ok ? x.z : 0.0f; d[3] = ok ? x.w : 0.0f;
+                if (j < nj) {
+                    const int r = rb + j * rstep;
+                    const bool ok = r <= rmax;
+                    float4 x = v[j];
+                    if (mask) {
+                        x.x = y[j].x > 0.0f ? x.x : 0.0f; x.y = y[j].y > 0.0f ? x.y : 0.0f;
+                        x.z = y[j].z > 0.0f ? x.z : 0.0f; x.w = y[j].w > 0.0f ? x.w : 0.0f;
+                    }
+                    if (r < nrows) {
+                        float* d = As + r * sa + col;
+                        d[0] = ok ? x.x : 0.0f; d[1] = ok ? x.y : 0.0f; d[2] = ok ? x.z : 0.0f; d[3] = ok ? x.w : 0.0f;
+                    }
                 }
             }
         }
     } else {
-        for (int idx = tid; idx < nrows * redp; idx += kBlock) {
-            const int r = idx / redp, k = idx - r * redp;
-            const bool ok = m0 + r < M && k < red;
-            const int m = min(m0 + r, M - 1), kc = min(k, red - 1);
-            float x = A[(size_t)m * lda + kc];
-            if (mask) x = Ym[(size_t)m * ldym + kc] > 0.0f ? x : 0.0f;
-            As[r * sa + k] = ok ? x : 0.0f;
+        const int total = nrows * redp;
+        for (int base = tid; base < total; base += 4 * NT) {     // 4 independent loads in flight per thread
+            float x[4], y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = min(base + j * NT, total - 1);
+                const int r = idx / redp, k = idx - r * redp;
+                const int rc = min(r, rmax), kc = min(k, red - 1);
+                x[j] = Ab[(unsigned)(rc * lda + kc)];
+                if (mask) y[j] = Yb[(unsigned)(rc * ldym + kc)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = base + j * NT;
+                if (idx < total) {
+                    const int r = idx / redp, k = idx - r * redp;
+                    float v = x[j];
+                    if (mask) v = y[j] > 0.0f ? v : 0.0f;
+                    As[r * sa + k] = (r <= rmax && k < red) ? v : 0.0f;
+                }
+            }
         }
     }
 }
@@ -373,15 +396,16 @@ struct MlpIo {
 struct BFrag {
     float x[8];
 };
-__device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ bg, int ldb)
+// bg = wave-uniform base of the layer's packed image, off = this lane's float offset for reduction step 0
+__device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ bg, int off, int ldb)
 {
     BFrag f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f.x[j] = bg[(size_t)(2 * j) * ldb];
+    for (int j = 0; j < 8; ++j) f.x[j] = bg[(unsigned)(off + 2 * j * ldb)];
     return f;
 }
-__device__ __forceinline__ void mfma_sweep_gb1(const float* __restrict__ ap, const float* __restrict__ bg0, int ldb, int red16,
-                                               BFrag x0, f32x16& acc0)
+__device__ __forceinline__ void mfma_sweep_gb1(const float* __restrict__ ap, const float* __restrict__ bg, int off0, int ldb,
+                                               int red16, BFrag x0, f32x16& acc0)
 {
     float a[8];
 #pragma unroll
@@ -390,7 +414,7 @@ __device__ __forceinline__ void mfma_sweep_gb1(const float* __restrict__ ap, con
         float an[8];
         BFrag n0;
         if (k0 + 16 < red16) {
-            n0 = load_bfrag(bg0 + (size_t)(k0 + 16) * ldb, ldb);
+            n0 = load_bfrag(bg, off0 + (k0 + 16) * ldb, ldb);
 #pragma unroll
             for (int j = 0; j < 8; ++j) an[j] = ap[k0 + 16 + 2 * j];
         }
@@ -402,9 +426,8 @@ __device__ __forceinline__ void mfma_sweep_gb1(const float* __restrict__ ap, con
         }
     }
 }
-__device__ __forceinline__ void mfma_sweep_gb2(const float* __restrict__ ap, const float* __restrict__ bg0,
-                                               const float* __restrict__ bg1, int ldb, int red16, BFrag x0, BFrag x1,
-                                               f32x16& acc0, f32x16& acc1)
+__device__ __forceinline__ void mfma_sweep_gb2(const float* __restrict__ ap, const float* __restrict__ bg, int off0, int off1,
+                                               int ldb, int red16, BFrag x0, BFrag x1, f32x16& acc0, f32x16& acc1)
 {
     float a[8];
 #pragma unroll
@@ -413,8 +436,8 @@ __device__ __forceinline__ void mfma_sweep_gb2(const float* __restrict__ ap, con
         float an[8];
         BFrag n0, n1;
         if (k0 + 16 < red16) {
-            n0 = load_bfrag(bg0 + (size_t)(k0 + 16) * ldb, ldb);
-            n1 = load_bfrag(bg1 + (size_t)(k0 + 16) * ldb, ldb);
+            n0 = load_bfrag(bg, off0 + (k0 + 16) * ldb, ldb);
+            n1 = load_bfrag(bg, off1 + (k0 + 16) * ldb, ldb);
 #pragma unroll
             for (int j = 0; j < 8; ++j) an[j] = ap[k0 + 16 + 2 * j];
         }
@@ -442,6 +465,12 @@ __global__ __launch_bounds__(kBlock) void k_mlp_pack_weights(const vf_mlp_desc d
         const int k = idx / N32, n = idx - k * N32;
         packed[L.wt_off + idx] = (k < L.K && n < L.No) ? params[L.w_off + n * L.K + k] : 0.0f;
     }
+    // data-gradient image: Wb[n][k] = W[n][k] for n < round16(No), k < round32(K), zero padded
+    const int N16 = (L.No + 15) & ~15, K32 = (L.K + 31) & ~31;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < N16 * K32; idx += gridDim.x * kBlock) {
+        const int n = idx / K32, k = idx - n * K32;
+        packed[L.wb_off + idx] = (k < L.K && n < L.No) ? params[L.w_off + n * L.K + k] : 0.0f;
+    }
 }
 
 __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, const float* __restrict__ params,
@@ -466,19 +495,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, 
             const vf_mlp_layer L = d.layer[li];
             const int red16 = (L.K + 15) & ~15, ct = (L.No + 31) >> 5, ldb = ct * 32;
             const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
-            const float* bg0 = packed + L.wt_off + (size_t)lk * ldb + c0 * 32 + lr;
-            const float* bg1 = bg0 + 64;
+            const float* bg = packed + L.wt_off;            // wave-uniform base, 32-bit lane offsets
+            const int off0 = lk * ldb + c0 * 32 + lr, off1 = off0 + 64;
             BFrag x0, x1;                                   // first weight fragments travel while the barrier is pending
-            if (nacc >= 1) x0 = load_bfrag(bg0, ldb);
-            if (nacc == 2) x1 = load_bfrag(bg1, ldb);
+            if (nacc >= 1) x0 = load_bfrag(bg, off0, ldb);
+            if (nacc == 2) x1 = load_bfrag(bg, off1, ldb);
             __syncthreads();                               // inputs of this layer are in LDS
             VF_PROBE_AT(2);
             const float* As = lds + d.lds_off[L.src] + L.src_col;
             const int sa = d.lds_stride[L.src];
             const float* ap = As + (rt * 32 + lr) * sa + lk;
             f32x16 acc0 = {0}, acc1 = {0};
-            if (nacc == 2) mfma_sweep_gb2(ap, bg0, bg1, ldb, red16, x0, x1, acc0, acc1);
-            else if (nacc == 1) mfma_sweep_gb1(ap, bg0, ldb, red16, x0, acc0);
+            if (nacc == 2) mfma_sweep_gb2(ap, bg, off0, off1, ldb, red16, x0, x1, acc0, acc1);
+            else if (nacc == 1) mfma_sweep_gb1(ap, bg, off0, ldb, red16, x0, acc0);
             VF_PROBE_AT(5);
             // epilogue: bias + ReLU, into the destination region (LDS or global) and the optional saved copy
             const int rb = rt * 32 + 4 * lk;               // first row of this lane's accumulator column
@@ -498,19 +527,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, 
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) dl[((reg & 3) + 8 * (reg >> 2)) * sd] = acc[reg];
                 }
-                float* gp = nullptr;
+                float* gp = nullptr;                         // wave-uniform base of this tile's rows
                 int ldg = 0;
-                if (L.dst >= VF_MLP_OUT0) { gp = io.out[L.dst - VF_MLP_OUT0] + (size_t)(m0 + rb) * L.No + n; ldg = L.No; }
-                else if (L.save) { gp = L.save + (size_t)(m0 + rb) * L.save_ld + L.dst_col + n; ldg = L.save_ld; }
+                if (L.dst >= VF_MLP_OUT0) { gp = io.out[L.dst - VF_MLP_OUT0] + (size_t)m0 * L.No; ldg = L.No; }
+                else if (L.save) { gp = L.save + (size_t)m0 * L.save_ld + L.dst_col; ldg = L.save_ld; }
                 if (gp) {
+                    const int o = rb * ldg + n;
                     if (full) {
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) gp[((reg & 3) + 8 * (reg >> 2)) * ldg] = acc[reg];
+                        for (int reg = 0; reg < 16; ++reg) gp[(unsigned)(o + ((reg & 3) + 8 * (reg >> 2)) * ldg)] = acc[reg];
                     } else {
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
                             const int ro = (reg & 3) + 8 * (reg >> 2);
-                            if (m0 + rb + ro < M) gp[ro * ldg] = acc[reg];
+                            if (m0 + rb + ro < M) gp[(unsigned)(o + ro * ldg)] = acc[reg];
                         }
                     }
                 }
@@ -525,124 +555,268 @@ __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, 
 // ------------------------------------------------------------------------------------------------
 // Whole-network backward: block-private row tiles, layer-major sweep (see vf_mlp_bwd_desc)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_mlp_backward(const vf_mlp_bwd_desc d, const float* __restrict__ params,
-                                                         float* __restrict__ part, int M)
+constexpr int kBwdThreads = 512;   // 8 waves: (row half) x (4 column tiles) for the data gradient, 2 dW tiles each
+
+// Register prefetch of one [64][w] fp32 tile by 512 threads: `issue` starts the global loads one work item
+// ahead, `park` writes them to LDS rows of stride `sa` (optionally masked by a second prefetched tile > 0,
+// rows past the matrix and the pad columns w..wpad zeroed).  mode 1: 16-byte loads (w/4 a power of two,
+// <= 4 per thread); mode 2: narrow tiles (w <= 16, 2 scalars per thread); mode 0: staged directly at park time.
+struct TilePf {
+    float4 v[4];
+    static __device__ __forceinline__ int mode_of(const float* A, int lda, int w)
+    {
+        const int c4 = w >> 2;
+        if ((w & 3) == 0 && c4 >= 1 && (c4 & (c4 - 1)) == 0 && c4 <= 32 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) return 1;
+        return w <= 16 ? 2 : 0;
+    }
+    __device__ __forceinline__ void issue(int mode, const float* __restrict__ A, int lda, int m0, int M, int w)
+    {
+        const int tid = threadIdx.x, rmax = M - 1 - m0;
+        const float* Ab = A + (size_t)m0 * lda;               // wave-uniform base, 32-bit lane offsets
+        if (mode == 1) {
+            const int c4 = w >> 2, sh = 31 - __clz(c4), col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBwdThreads >> sh;
+            const int nj = rstep >= kRows ? 1 : kRows / rstep;   // 4, 2 or 1 rows per thread
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nj) v[j] = *reinterpret_cast<const float4*>(Ab + (unsigned)(min(r0 + j * rstep, rmax) * lda + col));
+        } else if (mode == 2) {
+            const int total = kRows * w;
+            float t[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = min(tid + j * kBwdThreads, total - 1), r = idx / w, k = idx - r * w;
+                t[j] = Ab[(unsigned)(min(r, rmax) * lda + k)];
+            }
+            v[0].x = t[0]; v[0].y = t[1];
+        }
+    }
+    __device__ __forceinline__ void park(int mode, float* __restrict__ As, int sa, int m0, int M, int w, int wpad, const TilePf* ym) const
+    {
+        const int tid = threadIdx.x, rmax = M - 1 - m0;
+        if (wpad > w) {                                        // pad columns hold stale words of another layer
+            const int pw = wpad - w;
+            for (int idx = tid; idx < kRows * pw; idx += kBwdThreads) {
+                const int r = idx / pw, k = w + idx - r * pw;
+                As[r * sa + k] = 0.0f;
+            }
+        }
+        if (mode == 1) {
+            const int c4 = w >> 2, sh = 31 - __clz(c4), col = (tid & (c4 - 1)) << 2, r0 = tid >> sh, rstep = kBwdThreads >> sh;
+            const int nj = rstep >= kRows ? 1 : kRows / rstep;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nj) {
+                    const int r = r0 + j * rstep;
+                    float4 x = v[j];
+                    if (ym) {
+                        const float4 y = ym->v[j];
+                        x.x = y.x > 0.0f ? x.x : 0.0f; x.y = y.y > 0.0f ? x.y : 0.0f;
+                        x.z = y.z > 0.0f ? x.z : 0.0f; x.w = y.w > 0.0f ? x.w : 0.0f;
+                    }
+                    const bool ok = r <= rmax;
+                    if (r < kRows) {
+                        float* d = As + r * sa + col;
+                        d[0] = ok ? x.x : 0.0f; d[1] = ok ? x.y : 0.0f; d[2] = ok ? x.z : 0.0f; d[3] = ok ? x.w : 0.0f;
+                    }
+                }
+            }
+        } else if (mode == 2) {
+            const int total = kRows * w;
+            const float t[2] = {v[0].x, v[0].y};
+            const float ty[2] = {ym ? ym->v[0].x : 1.0f, ym ? ym->v[0].y : 1.0f};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + j * kBwdThreads;
+                if (idx < total) {
+                    const int r = idx / w, k = idx - r * w;
+                    As[r * sa + k] = (r <= rmax && ty[j] > 0.0f) ? t[j] : 0.0f;
+                }
+            }
+        }
+    }
+};
+
+// Work items of a block: (layer, tile) in layer-major order over the block's own tiles.  While the MFMAs of item
+// i run on LDS buffer i&1, the global loads of item i+1 (saved input X, saved output Y for the ReLU mask and --
+// when its producer is not item i itself -- the upstream gradient dY) are in flight into registers; they are
+// parked in the other buffer behind one barrier.  The data-gradient B operand streams from the packed weights.
+__global__ __launch_bounds__(kBwdThreads) void k_mlp_backward(const vf_mlp_bwd_desc d, const float* __restrict__ packed,
+                                                            float* __restrict__ part, int M)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 31, lk = lane >> 5;
-    const int rt = wave & 1, c0 = wave >> 1;
+    const int rt = wave & 1, c0 = wave >> 1;   // c0 = 0..3: this wave's 32-column tile of dX
     const int mtiles = (M + kRows - 1) / kRows;
+    const int T = (mtiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block (>= 1)
+    const int nitems = d.n_layers * T;
+    const bool early_dy = T >= 2;              // with one tile per block the producer of the next dY is the current item
+    constexpr int kBuf = kRows * (129 + 129);  // floats per staging buffer (max strides)
+    float* Bs = lds + 2 * kBuf;                // [kBwdThreads] bias partial sums
     float* prow = part + (size_t)blockIdx.x * d.n_fold;
     VF_PROBE_INIT();
-    for (int li = 0; li < d.n_layers; ++li) {
+
+    TilePf pfX, pfY, pfD;
+    auto geometry = [&](const vf_mlp_bwd_layer& L, int& sd, int& sx) {
+        sd = ((L.No + 31) & ~31) + 1;
+        sx = ((L.K + 31) & ~31) + 1;
+    };
+    auto modes = [&](const vf_mlp_bwd_layer& L, int& mx, int& md) {
+        mx = TilePf::mode_of(L.X, L.ld_x, L.K);
+        md = TilePf::mode_of(L.dY, L.ld_dy, L.No);
+        if (L.Y && TilePf::mode_of(L.Y, L.ld_y, L.No) != md) md = 0;   // mask and gradient must share the thread mapping
+    };
+    auto park_item = [&](const vf_mlp_bwd_layer& L, int m0, float* buf, bool dy_late) {
+        int sd, sx, mx, md;
+        geometry(L, sd, sx);
+        modes(L, mx, md);
+        float* Ds = buf;
+        float* Xs = buf + kRows * sd;
+        if (dy_late && md) {
+            pfD.issue(md, L.dY, L.ld_dy, m0, M, L.No);
+        }
+        if (mx) pfX.park(mx, Xs, sx, m0, M, L.K, sx - 1, nullptr);
+        else {
+            if (sx - 1 > L.K) pfX.park(0, Xs, sx, m0, M, L.K, sx - 1, nullptr);   // pads only
+            stage_rows<false, kBwdThreads>(Xs, sx, L.X, L.ld_x, nullptr, 0, m0, M, L.K, L.K);
+        }
+        if (md) pfD.park(md, Ds, sd, m0, M, L.No, sd - 1, L.Y ? &pfY : nullptr);
+        else {
+            if (sd - 1 > L.No) pfD.park(0, Ds, sd, m0, M, L.No, sd - 1, nullptr);
+            stage_rows<true, kBwdThreads>(Ds, sd, L.dY, L.ld_dy, L.Y, L.ld_y, m0, M, L.No, L.No);
+        }
+    };
+    auto issue_item = [&](const vf_mlp_bwd_layer& L, int m0, bool with_dy) {
+        int mx, md;
+        modes(L, mx, md);
+        if (mx) pfX.issue(mx, L.X, L.ld_x, m0, M, L.K);
+        if (md && L.Y) pfY.issue(md, L.Y, L.ld_y, m0, M, L.No);
+        if (md && with_dy) pfD.issue(md, L.dY, L.ld_dy, m0, M, L.No);
+    };
+
+    {   // item 0
+        const int m0 = (int)blockIdx.x * kRows;
+        issue_item(d.layer[0], m0, true);
+        park_item(d.layer[0], m0, lds, false);
+    }
+    __syncthreads();
+    VF_PROBE_AT(8);
+
+    f32x16 acc[2] = {{0}, {0}};
+    float bsum = 0.0f;
+    int li = 0, ti = 0;                        // layer / tile index of the current item
+    for (int it = 0; it < nitems; ++it) {
         const vf_mlp_bwd_layer L = d.layer[li];
         const int K = L.K, No = L.No;
         const int nt = (No + 31) >> 5, kt = (K + 31) >> 5;
-        const int sd = nt * 32 + 1, sx = kt * 32 + 1, sw = kt * 32 + 1;
-        const int red16 = (No + 15) & ~15;
-        float* Ds = lds;                  // [64][sd]   masked dY rows (pad columns zero)
-        float* Xs = Ds + kRows * sd;      // [64][sx]   layer inputs
-        float* Ws = Xs + kRows * sx;      // [red16][sw] W image for the data gradient
-        VF_PROBE_AT(8);
-        __syncthreads();                  // the previous layer is done with LDS and its dX stores are issued
+        const int sd = nt * 32 + 1, sx = kt * 32 + 1, ldb = kt * 32, red16 = (No + 15) & ~15;
+        float* buf = lds + (it & 1) * kBuf;
+        const float* Ds = buf;
+        const float* Xs = buf + kRows * sd;
+        const int m0 = ((int)blockIdx.x + ti * (int)gridDim.x) * kRows;
+        const int nli = ti + 1 == T ? li + 1 : li, nti = ti + 1 == T ? 0 : ti + 1;   // next item
+        const bool has_next = it + 1 < nitems;
+        const int nm0 = ((int)blockIdx.x + nti * (int)gridDim.x) * kRows;
+        if (has_next) issue_item(d.layer[nli], nm0, early_dy);
+        const int nacc = c0 < kt ? 1 : 0;
+        const float* bg = packed + L.wb_off;   // wave-uniform base, 32-bit lane offsets
+        const int off0 = lk * ldb + c0 * 32 + lr;
+        BFrag x0;
+        if (L.need_dx && nacc) x0 = load_bfrag(bg, off0, ldb);
         VF_PROBE_AT(9);
-        if ((No & 31) || (K & 31)) {      // stale words of the previous layer must not sit in pad columns
-            const int n = kRows * (sd + sx) + (L.need_dx ? red16 * sw : 0);
-            for (int idx = tid; idx < n; idx += kBlock) lds[idx] = 0.0f;
-            __syncthreads();
-        }
-        if (L.need_dx) stage_rows<false>(Ws, sw, params + L.w_off, K, nullptr, 0, 0, No, K, K, red16);
-        VF_PROBE_AT(10);
-        const int wtiles = nt * kt;       // <= 16 weight-gradient tiles of 32x32; wave takes wave, wave+4, ...
-        f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-        float bsum = 0.0f;
-        const int ct = kt;
-        const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
         const int cgrp = No <= 64 ? 64 : 128;
-        for (int tile = blockIdx.x; tile < mtiles; tile += gridDim.x) {
-            const int m0 = tile * kRows;
-            stage_rows<true>(Ds, sd, L.dY, L.ld_dy, L.Y, L.ld_y, m0, M, No, No);
-            stage_rows<false>(Xs, sx, L.X, L.ld_x, nullptr, 0, m0, M, K, K);
-            VF_PROBE_AT(11);
-            __syncthreads();
-            VF_PROBE_AT(12);
-            {   // bias gradient: thread = (column, row slice)
-                const int c = tid & (cgrp - 1), sl = tid / cgrp, rows = kRows * cgrp / kBlock;
-                if (c < No) {
-                    float s0 = 0.0f, s1 = 0.0f;
-                    const float* dp = Ds + (sl * rows) * sd + c;
-                    for (int r = 0; r < rows; r += 2) { s0 += dp[r * sd]; s1 += dp[(r + 1) * sd]; }
-                    bsum += s0 + s1;
-                }
+        {   // bias gradient: thread = (column, row slice)
+            const int c = tid & (cgrp - 1), sl = tid / cgrp, rows = kRows * cgrp / kBwdThreads;
+            if (c < No) {
+                float s0 = 0.0f, s1 = 0.0f;
+                const float* dp = Ds + (sl * rows) * sd + c;
+                for (int r = 0; r < rows; r += 2) { s0 += dp[r * sd]; s1 += dp[(r + 1) * sd]; }
+                bsum += s0 + s1;
             }
+        }
+        const int wtiles = nt * kt;            // <= 16 weight-gradient tiles of 32x32; wave takes wave, wave+8
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {  // dW[n][k] += sum_m dYm[m][n] X[m][k]
-                const int wt = wave + 4 * q;
-                if (wt >= wtiles) break;
-                const int it = wt / kt, jt = wt - it * kt;
-                const float* ap = Ds + lk * sd + it * 32 + lr;
-                const float* bp = Xs + lk * sx + jt * 32 + lr;
-                f32x16 c = acc[q];
+        for (int q = 0; q < 2; ++q) {          // dW[n][k] += sum_m dYm[m][n] X[m][k]
+            const int wt = wave + 8 * q;
+            if (wt >= wtiles) break;
+            const int itn = wt / kt, jt = wt - itn * kt;
+            const float* ap = Ds + lk * sd + itn * 32 + lr;
+            const float* bp = Xs + lk * sx + jt * 32 + lr;
+            f32x16 c = acc[q];
 #pragma unroll
-                for (int k0 = 0; k0 < kRows; k0 += 16) {
-                    float fa[8], fb[8];
+            for (int k0 = 0; k0 < kRows; k0 += 16) {
+                float fa[8], fb[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { fa[j] = ap[(k0 + 2 * j) * sd]; fb[j] = bp[(k0 + 2 * j) * sx]; }
+                for (int j = 0; j < 8; ++j) { fa[j] = ap[(k0 + 2 * j) * sd]; fb[j] = bp[(k0 + 2 * j) * sx]; }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], c, 0, 0, 0);
-                }
-                acc[q] = c;
+                for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], c, 0, 0, 0);
             }
-            VF_PROBE_AT(13);
-            if (L.need_dx) {               // dX[m][k] = sum_n dYm[m][n] W[n][k]
-                const float* ap = Ds + (rt * 32 + lr) * sd + lk;
-                const float* b0 = Ws + lk * sw + c0 * 32 + lr;
-                const float* b1 = Ws + lk * sw + (c0 + 2) * 32 + lr;
-                f32x16 a0 = {0}, a1 = {0};
-                if (nacc == 2) mfma_sweep2(ap, b0, b1, sw, red16, a0, a1);
-                else if (nacc == 1) mfma_sweep1(ap, b0, sw, red16, a0);
-                auto emit = [&](const f32x16& a, int ctile) {
-                    const int n = ctile * 32 + lr;
-                    if (n >= K) return;
+            acc[q] = c;
+        }
+        VF_PROBE_AT(13);
+        if (L.need_dx && nacc) {               // dX[m][k] = sum_n dYm[m][n] W[n][k]
+            const float* ap = Ds + (rt * 32 + lr) * sd + lk;
+            f32x16 a = {0};
+            mfma_sweep_gb1(ap, bg, off0, ldb, red16, x0, a);
+            float* dxb = L.dX + (size_t)m0 * L.ld_dx;   // wave-uniform base of this tile's rows
+            const int n = c0 * 32 + lr;
+            if (n < K) {
+                const int rb = rt * 32 + 4 * lk, o = rb * L.ld_dx + n, rmax = M - 1 - m0 - rb;
+                if (L.need_dx == 2) {          // second consumer of the same activation: add (all loads first)
+                    float old[16];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        old[reg] = dxb[(unsigned)(o + max(min((reg & 3) + 8 * (reg >> 2), rmax), 0) * L.ld_dx)];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) a[reg] += old[reg];
+                }
+                if (rmax >= 27) {              // every row of this lane's column exists
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) dxb[(unsigned)(o + ((reg & 3) + 8 * (reg >> 2)) * L.ld_dx)] = a[reg];
+                } else {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const int m = m0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                        if (m >= M) continue;
-                        float* dst = L.dX + (size_t)m * L.ld_dx + n;
-                        *dst = L.need_dx == 2 ? *dst + a[reg] : a[reg];
+                        const int ro = (reg & 3) + 8 * (reg >> 2);
+                        if (ro <= rmax) dxb[(unsigned)(o + ro * L.ld_dx)] = a[reg];
                     }
-                };
-                if (nacc >= 1) emit(a0, c0);
-                if (nacc == 2) emit(a1, c0 + 2);
+                }
             }
-            VF_PROBE_AT(14);
-            __syncthreads();               // all waves are done with Ds / Xs
-            VF_PROBE_AT(15);
         }
-        // one partial per layer and block: weights, then the bias column sums
+        VF_PROBE_AT(14);
+        const bool layer_done = ti + 1 == T;
+        if (layer_done) {                      // one partial per layer and block: weights, then the bias column sums
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int wt = wave + 4 * q;
-            if (wt >= wtiles) break;
-            const int it = wt / kt, jt = wt - it * kt;
-            const int k = jt * 32 + lr;
-            if (k >= K) continue;
+            for (int q = 0; q < 2; ++q) {
+                const int wt = wave + 8 * q;
+                if (wt >= wtiles) break;
+                const int itn = wt / kt, jt = wt - itn * kt;
+                const int k = jt * 32 + lr;
+                if (k < K) {
+                    float* pw = prow + L.w_off;    // wave-uniform base
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int n = it * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                if (n < No) prow[L.w_off + (size_t)n * K + k] = acc[q][reg];
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int n = itn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                        if (n < No) pw[(unsigned)(n * K + k)] = acc[q][reg];
+                    }
+                }
+                acc[q] = f32x16{0};
             }
+            Bs[tid] = bsum;
+            bsum = 0.0f;
         }
-        {
-            const int c = tid & (cgrp - 1), sl = tid / cgrp, nsl = kBlock / cgrp;
-            Ds[sl * cgrp + c] = bsum;      // Ds is free: the tile loop ended on a barrier
-            __syncthreads();
-            if (tid < No) {
-                float t = 0.0f;
-                for (int q = 0; q < nsl; ++q) t += Ds[q * cgrp + tid];
-                prow[L.b_off + tid] = t;
-            }
+        VF_PROBE_AT(10);
+        __syncthreads();                       // buffer it&1 is consumed, this item's dX stores have completed
+        VF_PROBE_AT(15);
+        if (layer_done && tid < No) {
+            float t = 0.0f;
+            const int nsl = kBwdThreads / cgrp;
+            for (int q = 0; q < nsl; ++q) t += Bs[q * cgrp + tid];
+            prow[L.b_off + tid] = t;
         }
+        if (has_next) park_item(d.layer[nli], nm0, lds + ((it + 1) & 1) * kBuf, !early_dy);
+        VF_PROBE_AT(11);
+        __syncthreads();
+        VF_PROBE_AT(12);
+        li = nli; ti = nti;
     }
 }
 
@@ -1062,7 +1236,9 @@ int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc)
     for (int i = 0; i < desc->n_layers; ++i) {
         const vf_mlp_layer& L = desc->layer[i];
         const int64_t end = L.wt_off + (int64_t)((L.K + 15) & ~15) * ((L.No + 31) & ~31);
+        const int64_t endb = L.wb_off + (int64_t)((L.No + 15) & ~15) * ((L.K + 31) & ~31);
         n = end > n ? end : n;
+        n = endb > n ? endb : n;
     }
     return n;
 }
@@ -1118,14 +1294,14 @@ int32_t vf_mlp_backward_blocks(int32_t M)
 {
     if (M <= 0) return 0;
     const int mtiles = (M + vf::kRows - 1) / vf::kRows;
-    const int rounds = (mtiles + 255) / 256;      // tiles per block: equal work, at most one block per CU
+    const int rounds = (mtiles + 255) / 256;      // tiles per block: equal work, at most one (8-wave) block per CU
     return (mtiles + rounds - 1) / rounds;
 }
 
-int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* params, float* partials, float* grad, int32_t M,
+int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* partials, float* grad, int32_t M,
                     int32_t accumulate, vf_stream_t stream)
 {
-    if (!desc || !params || !partials || !grad || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_backward: bad argument");
+    if (!desc || !packed || !partials || !grad || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_backward: bad argument");
     if (desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS || desc->n_fold < 1)
         return vf::fail(VF_EINVAL, "vf_mlp_backward: bad layer count / n_fold");
     size_t lds = 0;
@@ -1136,14 +1312,12 @@ int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* params, float* par
             return vf::fail(VF_EINVAL, "vf_mlp_backward: layer %d: missing pointer or short row stride", i);
         if (L.w_off < 0 || L.b_off < 0 || L.w_off + (int64_t)L.K * L.No > desc->n_fold || L.b_off + L.No > desc->n_fold)
             return vf::fail(VF_EINVAL, "vf_mlp_backward: layer %d: parameter offsets outside n_fold", i);
-        const int nt = (L.No + 31) >> 5, kt = (L.K + 31) >> 5, red16 = (L.No + 15) & ~15;
-        const size_t need = ((size_t)vf::kRows * (nt * 32 + 1 + kt * 32 + 1) + (L.need_dx ? (size_t)red16 * (kt * 32 + 1) : 0)) * sizeof(float);
-        lds = need > lds ? need : lds;
     }
+    lds = ((size_t)2 * vf::kRows * (129 + 129) + vf::kBwdThreads) * sizeof(float);   // two staging buffers + bias scratch
     if (int rc = allow_lds(vf::k_mlp_backward, lds)) return rc;
     const int nblk = vf_mlp_backward_blocks(M);
     hipStream_t st = vf::as_stream(stream);
-    hipLaunchKernelGGL(vf::k_mlp_backward, dim3(nblk), dim3(vf::kBlock), lds, st, *desc, params, partials, M);
+    hipLaunchKernelGGL(vf::k_mlp_backward, dim3(nblk), dim3(vf::kBwdThreads), lds, st, *desc, packed, partials, M);
     // fold the parameter ranges the listed layers cover (a skipped trunk leaves its columns of `partials` unwritten)
     std::pair<int64_t, int64_t> iv[2 * VF_MLP_MAX_LAYERS];
     int niv = 0;

@@ -167,11 +167,13 @@ class MlpPolicy:
             return None
         if top * 4 > 160 * 1024:
             return None
-        wt_off, o = [], 0
-        for ly in self.layers:               # packed forward weights: [round16(K)][round32(No)] per layer
+        wt_off, wb_off, o = [], [], 0
+        for ly in self.layers:               # packed weights: forward [round16(K)][round32(No)], data gradient [round16(No)][round32(K)]
             wt_off.append(o)
             o += ((ly.K + 15) & ~15) * ((ly.No + 31) & ~31)
-        return dict(ids=ids, off=off, stride=stride, total=top, wt_off=wt_off, packed_floats=o)
+            wb_off.append(o)
+            o += ((ly.No + 15) & ~15) * ((ly.K + 31) & ~31)
+        return dict(ids=ids, off=off, stride=stride, total=top, wt_off=wt_off, wb_off=wb_off, packed_floats=o)
 
     def _fused_desc(self, b, save: bool):
         p = self._plan
@@ -187,7 +189,7 @@ class MlpPolicy:
             L.K, L.No, L.relu = ly.K, ly.No, 1 if ly.relu else 0
             L.src, L.src_col = p["ids"][ly.src], ly.sc
             L.dst = {"mean": _lib.MLP_OUT0, "value": _lib.MLP_OUT1}.get(ly.dst, p["ids"].get(ly.dst, 0))
-            L.dst_col, L.w_off, L.b_off, L.wt_off = ly.dc, ly.w_off, ly.b_off, p["wt_off"][li]
+            L.dst_col, L.w_off, L.b_off, L.wt_off, L.wb_off = ly.dc, ly.w_off, ly.b_off, p["wt_off"][li], p["wb_off"][li]
             if save and b is not None and ly.dst not in ("mean", "value"):
                 L.save, L.save_ld = b[ly.dst].data_ptr(), b[ly.dst].shape[1]
         return d
@@ -273,7 +275,7 @@ class MlpPolicy:
         M = self._last_M
         b = self._buffers(M)
         L, st = _lib.lib(), self._stream()
-        if self.fused_backward:
+        if self.fused_backward and self._plan is not None:
             return self._backward_fused(b, M, d_mean, d_value, d_log_std, accumulate, need_input_grad)
         need = max(int(L.vf_linear_bwd_scratch_floats(M, ly.K, ly.No)) for ly in self.layers)
         if self._scratch is None or self._scratch.numel() < need:
@@ -332,6 +334,7 @@ class MlpPolicy:
             e = d.layer[n]
             n += 1
             e.K, e.No, e.w_off, e.b_off = ly.K, ly.No, ly.w_off, ly.b_off
+            e.wb_off = self._plan["wb_off"][self.layers.index(ly)]
             e.dY, e.ld_dy = _ptr(dY, ly.dc), dY.shape[1]
             e.Y, e.ld_y = (_ptr(Y, ly.dc) if ly.relu else None), Y.shape[1]
             e.X, e.ld_x = _ptr(X, ly.sc), X.shape[1]
@@ -350,7 +353,8 @@ class MlpPolicy:
         need = int(L.vf_mlp_backward_blocks(M)) * self.log_std_off
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
-        _lib.check(L.vf_mlp_backward(C.byref(d), _ptr(self.flat), _ptr(self._scratch), _ptr(self.grad), M,
+        self._pack()
+        _lib.check(L.vf_mlp_backward(C.byref(d), _ptr(self._packed), _ptr(self._scratch), _ptr(self.grad), M,
                                      1 if accumulate else 0, st))
         if d_log_std is not None:
             if accumulate:
