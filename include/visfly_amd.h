@@ -276,6 +276,13 @@ int vf_td_returns(const float* r, const uint8_t* done, const uint8_t* episode_do
 int vf_adv_normalize(const float* adv, float* out, int64_t n, int64_t count, double* sums_inout, float* scratch,
                      int32_t phase, vf_stream_t stream);
 
+/* The same normalisation for n_seg consecutive minibatches of seg_len rows in one launch (the epoch buffer
+ * is shuffled once, so minibatches are contiguous slices).  sums: n_seg x 2 doubles (sum, sum of squares),
+ * written by phase 0 / 2, read by phase 1 / 2 (all-reduce them in between for a multi-GPU minibatch);
+ * count = rows of the GLOBAL minibatch. */
+int vf_adv_normalize_segments(const float* adv, float* out, int32_t n_seg, int64_t seg_len, int64_t count, double* sums,
+                              int32_t phase, vf_stream_t stream);
+
 /* Y[M][No] (+)= act(X[M][K] @ W^T + b)   nn.Linear + ReLU (extractors.py:421-445)
  *   W [No][K], b [No] or NULL; ldx / ldy row strides in floats; relu: 0/1; K, No <= 128. */
 int vf_linear_fwd(const float* X, int32_t ldx, const float* W, const float* b, float* Y, int32_t ldy,

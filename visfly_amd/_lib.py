@@ -184,6 +184,7 @@ SIGNATURES = {
     "vf_gae": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int32, C.c_double, C.c_double, _vp]),
     "vf_td_returns": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp]),
     "vf_adv_normalize": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp]),
+    "vf_adv_normalize_segments": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int64, _vp, C.c_int32, _vp]),
     "vf_linear_fwd": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "vf_linear_bwd_data": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, _vp]),

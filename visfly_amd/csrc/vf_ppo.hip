@@ -140,6 +140,41 @@ __global__ __launch_bounds__(kBlock) void k_adv_apply(const float* __restrict__ 
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) out[i] = (a[i] - m) / sd;
 }
 
+// segmented variant: one block per minibatch (contiguous slice of the shuffled epoch buffer)
+__global__ __launch_bounds__(kBlock) void k_adv_seg_sums(const float* __restrict__ x, long seg_len, double* __restrict__ sums)
+{
+    __shared__ double sh[2][4];
+    const float* xs = x + (size_t)blockIdx.x * seg_len;
+    double s = 0.0, ss = 0.0;
+    for (long i = threadIdx.x; i < seg_len; i += kBlock) {
+        const double a = xs[i];
+        s += a;
+        ss += a * a;
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums[2 * blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        sums[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_adv_seg_apply(const float* __restrict__ a, float* __restrict__ out, long seg_len,
+                                                          const double* __restrict__ sums, double count)
+{
+    const double s0 = sums[2 * blockIdx.y], s1 = sums[2 * blockIdx.y + 1];
+    const double mean = s0 / count;
+    double var = (s1 - s0 * mean) / (count - 1.0);
+    var = var > 0.0 ? var : 0.0;
+    const float m = (float)mean, sd = (float)sqrt(var) + 1e-8f;
+    const size_t base = (size_t)blockIdx.y * seg_len;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < seg_len; i += (long)gridDim.x * kBlock)
+        out[base + i] = (a[base + i] - m) / sd;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Linear layers on the fp32 MFMA.  Block = 4 waves, 64 output rows; each wave owns one 32-row
 // half and every other 32-column tile.  C/D fragment of v_mfma_f32_32x32x2_f32:
@@ -1153,6 +1188,23 @@ int vf_adv_normalize(const float* adv, float* out, int64_t n, int64_t count, dou
     if (phase == 1 || phase == 2)
         hipLaunchKernelGGL(vf::k_adv_apply, dim3(vf::grid_for(n, 1024)), dim3(vf::kBlock), 0, st, adv, out, (long)n, sums,
                            (double)count);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_adv_normalize_segments(const float* adv, float* out, int32_t n_seg, int64_t seg_len, int64_t count, double* sums,
+                              int32_t phase, vf_stream_t stream)
+{
+    if (!adv || !out || !sums || n_seg <= 0 || n_seg > 65535 || seg_len <= 0 || count < 2 || phase < 0 || phase > 2)
+        return vf::fail(VF_EINVAL, "vf_adv_normalize_segments: bad argument");
+    hipStream_t st = vf::as_stream(stream);
+    if (phase == 0 || phase == 2)
+        hipLaunchKernelGGL(vf::k_adv_seg_sums, dim3(n_seg), dim3(vf::kBlock), 0, st, adv, (long)seg_len, sums);
+    if (phase == 1 || phase == 2) {
+        const int bx = (int)((seg_len + 4 * vf::kBlock - 1) / (4 * vf::kBlock));
+        hipLaunchKernelGGL(vf::k_adv_seg_apply, dim3(bx < 64 ? bx : 64, n_seg), dim3(vf::kBlock), 0, st, adv, out, (long)seg_len,
+                           sums, (double)count);
+    }
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

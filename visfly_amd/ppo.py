@@ -525,15 +525,6 @@ class PPO:
         actions, old_lp, adv, ret = mb["actions"], mb["old_lp"], mb["adv"], mb["ret"]
         B = adv.numel()
         gB = B * self.world
-        if self.normalize_advantage and gB > 1:
-            advn = th.empty_like(adv)
-            if self.world > 1:
-                _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, self._sums.data_ptr(), _ptr(self._scratch), 0, st))
-                parallel.allreduce_sum_(self._sums)
-                _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, self._sums.data_ptr(), _ptr(self._scratch), 1, st))
-            else:
-                _lib.check(L.vf_adv_normalize(_ptr(adv), _ptr(advn), B, gB, None, _ptr(self._scratch), 2, st))
-            adv = advn
         mean, value = pol.forward(obs)
         d_mean, d_value = th.empty((B, 4), device=self.device), th.empty(B, device=self.device)
         cfg = _lib.PpoLossCfg(self.clip_range, self.ent_coef, self.vf_coef, 1.0 / gB)
@@ -569,6 +560,21 @@ class PPO:
             # contiguous slice (same rows, same order as indexing the buffer with perm[s:s+bs])
             perm = th.randperm(total, device=self.device, generator=g)
             shuf = {k: v.index_select(0, perm) for k, v in flat.items()}
+            n_seg = total // bs
+            if self.normalize_advantage and bs * self.world > 1:
+                # PPO.py:215-220 normalises per minibatch; all minibatches of the epoch in one launch (+ one
+                # all-reduce of the per-minibatch sums when the minibatch spans several GPUs)
+                advn = th.empty_like(shuf["adv"])
+                sums = th.empty((n_seg, 2), dtype=th.float64, device=self.device)
+                L, stv = _lib.lib(), self._stream()
+                args = (_ptr(shuf["adv"]), _ptr(advn), n_seg, bs, bs * self.world, sums.data_ptr())
+                if self.world > 1:
+                    _lib.check(L.vf_adv_normalize_segments(*args, 0, stv))
+                    parallel.allreduce_sum_(sums)
+                    _lib.check(L.vf_adv_normalize_segments(*args, 1, stv))
+                else:
+                    _lib.check(L.vf_adv_normalize_segments(*args, 2, stv))
+                shuf["adv"] = advn
             for s in range(0, total - bs + 1, bs):
                 st = self._minibatch_update({k: v[s:s + bs] for k, v in shuf.items()})
                 stats_acc += st
