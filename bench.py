@@ -94,6 +94,37 @@ def bench_ppo(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def bench_bptt(args, rank, world, dev):
+    """secondary measurement (BASELINE configs[4]): RacingEnv, thrust actions, BPTT H=64 through the adjoint kernel,
+    agents sharded by rank, one all-reduce of the flat gradient per update."""
+    from visfly_amd import parallel
+    from visfly_amd.bptt import BPTT
+    from visfly_amd.envs import RacingEnv
+    N = args.agents if args.agents != AGENTS_PER_GPU else 16384
+    dkw = dict(DYN_KW, action_type="thrust")
+    env = RacingEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dkw, device=dev, max_episode_steps=256,
+                    requires_grad=True, tensor_output=True)
+    algo = BPTT(env, horizon=64, gamma=0.99, learning_rate=1e-3, seed=0)
+    algo.learn(64 * N * world)     # warm-up update
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    iters = max(1, args.steps // 64)
+    algo.learn(64 * N * world * iters)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "BPTT env-steps/s (H=64 rollout + adjoint + actor update, RacingEnv)",
+                          "value": 64 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
+                          "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"RacingEnv {N} agents/GPU, thrust actions, horizon 64",
+                                     "logs": {k: float(v) for k, v in algo.logs.items()}}}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,7 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--agents", type=int, default=AGENTS_PER_GPU, help="agents per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="env", choices=["env", "ppo"],
+    ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt"],
                     help="env: fused HoverEnv.step (the BASELINE metric, default); ppo: full PPO loop (configs[3] shape)")
     args = ap.parse_args()
 
@@ -113,6 +144,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+    if args.workload == "bptt":
+        return bench_bptt(args, rank, world, dev)
     if args.workload == "ppo":
         return bench_ppo(args, rank, world, dev)
 
