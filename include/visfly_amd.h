@@ -155,6 +155,8 @@ enum {
     VF_F_EPISODE_DONE = 1, VF_F_ONCE_COLLIDED = 2, VF_F_COLLISION = 4, VF_F_OUT_BOUNDS = 8,
     VF_F_SUCCESS = 16, VF_F_FAILURE = 32, VF_F_DONE = 64
 };
+enum { VF_OBS_STATE = 0, VF_OBS_HOVER2 = 1, VF_OBS_NAV2 = 2 };
+enum { VF_REWARD_DEFAULT = 0, VF_REWARD_NAV2 = 1 };
 enum { VF_EP_SUCCESS = 1, VF_EP_TRUNCATED = 2, VF_EP_COLLIDED = 4, VF_EP_EPISODE_DONE = 8 };
 #define VF_MAX_GATES 8
 #define VF_MAX_SPAWN 4
@@ -182,6 +184,9 @@ typedef struct vf_env_cfg {
                                      (re)spawn (dynamics.py:244-246; needs per_agent_drag at create)   */
     vf_spawn_box spawn[VF_MAX_SPAWN];
     uint64_t seed;                /* Philox key of the on-device spawner                 */
+    /* observation / reward variants */
+    int32_t obs_mode;             /* VF_OBS_*: raw state | HoverEnv2 (HoverEnv.py:136-152) | NavigationEnv2 (NavigationEnv.py:163-183) */
+    int32_t reward_mode;          /* VF_REWARD_*: the kind's own reward | NavigationEnv2 reward + failure = is_collision (:155-224) */
 } vf_env_cfg;
 
 /* Outputs of one env step; obs/reward/done are required, the rest may be NULL. */

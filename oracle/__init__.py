@@ -123,6 +123,8 @@ def lib():
         L.vfo_env_post_step.argtypes = [C.POINTER(Consts), C.POINTER(EnvConsts), C.c_int, fp,
                                         C.POINTER(EnvState)]
         L.vfo_env_post_step.restype = None
+        L.vfo_env_obs.argtypes = [C.POINTER(Consts), C.POINTER(EnvConsts), C.c_int, fp, fp]
+        L.vfo_env_obs.restype = None
         L.vfo_env_reset_attr.argtypes = [C.c_int, C.POINTER(EnvState), ip, C.c_int]
         L.vfo_env_reset_attr.restype = None
         L.vfo_gae.argtypes = [fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_double, C.c_double]
@@ -212,7 +214,7 @@ class OracleEnv:
     """CPU restatement of DroneGymEnvsBase.step with visual=False (droneGymEnv.py:141-218):
     dynamics step -> bbox collision -> counters/masks/reward -> (scripted) auto-reset."""
 
-    KINDS = {"hover": 0, "nav": 1, "racing": 2}
+    KINDS = {"hover": 0, "nav": 1, "racing": 2, "hover2": 3, "nav2": 4}
 
     def __init__(self, consts, N, kind, max_episode_steps, target=(1.0, 0.0, 1.5), success_radius=0.5,
                  is_collision_reset=True, gates=None):
@@ -273,6 +275,13 @@ class OracleEnv:
         self.update_collision()
         lib().vfo_env_post_step(C.byref(self.dyn.c), C.byref(self.e), self.N, _fp(self.dyn.S), C.byref(self.es))
         return obs, self.a["reward"].copy(), self.a["done"].copy()
+
+    @property
+    def obs_state(self):
+        """get_observation()["state"] of the env kind (raw state or the HoverEnv2 / NavigationEnv2 variants)"""
+        out = np.empty((self.N, 13), np.float32)
+        lib().vfo_env_obs(C.byref(self.dyn.c), C.byref(self.e), self.N, _fp(self.dyn.S), _fp(out))
+        return out
 
     def reset_agents(self, idx, fs):
         """reset_agent_by_id with given full states (droneGymEnv.py:339-349, droneEnv.py:260-288)"""

@@ -345,6 +345,20 @@ def import_envs():
     return HoverEnvShim, NavigationEnv, RacingEnvShim
 
 
+def import_envs2():
+    """HoverEnv2 / NavigationEnv2: relative-position observations, Nav2 reward"""
+    import_envs()
+    from VisFly.envs.HoverEnv import HoverEnv2
+    from VisFly.envs.NavigationEnv import NavigationEnv2
+
+    class HoverEnv2Shim(HoverEnv2):  # same defect C-3 as HoverEnv: the base passes predicted_obs
+        def get_reward(self, predicted_obs=None):
+            from VisFly.envs.HoverEnv import HoverEnv
+            return HoverEnv.get_reward(self)
+
+    return HoverEnv2Shim, NavigationEnv2
+
+
 ENV_DYN = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
 RACING_DYN = dict(action_type="thrust", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
 # gates moved next to the spawn boxes so that random flight passes them (the pass / advance / +20 logic)
@@ -362,6 +376,14 @@ ENV_CASES = {
                                         "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
                                         "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}),
                       [-0.3, 0, 0, 0], 0.5, 200),
+    # observation / reward variants
+    "env_hover2": ("hover2", dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [
+        {"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]}}), [-1 / 3, 0, 0, 0], 0.5, 160),
+    "env_nav2": ("nav2", dict(max_episode_steps=96, target=[2.5, 0., 1.5], random_kwargs={"state_generator": {
+        "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
+                                        "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
+                                        "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}),
+                 [-0.3, 0, 0, 0], 0.5, 200),
 }
 
 
@@ -369,13 +391,16 @@ def gen_env(name, N=128, seed=42):
     HoverEnvShim, NavigationEnv, RacingEnv = import_envs()
     kind, kw, hover, scale, steps = ENV_CASES[name]
     use_cr_sqrt(True)
-    cls = {"hover": HoverEnvShim, "nav": NavigationEnv, "racing": RacingEnv}[kind]
+    cls = {"hover": HoverEnvShim, "nav": NavigationEnv, "racing": RacingEnv}.get(kind)
+    if cls is None:
+        H2, N2 = import_envs2()
+        cls = {"hover2": H2, "nav2": N2}[kind]
     kw = dict(kw)
     if "target" in kw:
         kw["target"] = th.tensor(kw["target"])
     env = cls(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False,
               dynamics_kwargs=dict(RACING_DYN if kind == "racing" else ENV_DYN),
-              device="cpu", **({"tensor_output": True} if kind == "hover" else {}), **kw)
+              device="cpu", **({"tensor_output": True} if kind in ("hover", "hover2", "nav2") else {}), **kw)
     env.tensor_output = True
     if kind == "racing":
         env.targets = th.as_tensor(RACING_TEST_GATES)

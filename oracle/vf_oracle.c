@@ -420,6 +420,27 @@ void vfo_dyn_reset(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick
 
 /* ---------- env layer ---------- */
 
+/* get_observation()["state"] of the task envs: HoverEnv/NavigationEnv/RacingEnv return the raw state
+ * (HoverEnv.py:62-77); HoverEnv2 [(target-p)/10, q, v/10, w/10] (HoverEnv.py:136-152); NavigationEnv2
+ * [target-p, q, v, w] (NavigationEnv.py:163-183). */
+void vfo_env_obs(const vfo_consts* c, const vfo_env_consts* e, int N, const float* S, float* obs)
+{
+    for (int i = 0; i < N; ++i) {
+#define ROW(r) S[(size_t)(r) * N + i]
+        float* o = obs + 13 * (size_t)i;
+        float p[3] = { ROW(VFO_POS), ROW(VFO_POS + 1), ROW(VFO_POS + 2) };
+        float v[3] = { ROW(VFO_VEL) + c->wind[0], ROW(VFO_VEL + 1) + c->wind[1], ROW(VFO_VEL + 2) + c->wind[2] };
+        for (int d = 0; d < 4; ++d) o[3 + d] = ROW(VFO_QUAT + d);
+        for (int d = 0; d < 3; ++d) {
+            float w = ROW(VFO_OMG + d);
+            if (e->kind == VFO_ENV_HOVER2) { o[d] = (e->target[d] - p[d]) / 10.0f; o[7 + d] = v[d] / 10.0f; o[10 + d] = w / 10.0f; }
+            else if (e->kind == VFO_ENV_NAV2) { o[d] = e->target[d] - p[d]; o[7 + d] = v[d]; o[10 + d] = w; }
+            else { o[d] = p[d]; o[7 + d] = v[d]; o[10 + d] = w; }
+        }
+#undef ROW
+    }
+}
+
 /* x.norm(dim=1) for 3 / 4 columns as torch's reduce kernel rounds it for the transposed (stride (1,N))
  * views the reference passes (App. B.4; probed again for 4 columns when pinning RacingEnv) */
 static inline float norm3(float x, float y, float z)
@@ -499,9 +520,29 @@ void vfo_env_post_step(const vfo_consts* c, const vfo_env_consts* e, int N, cons
         es->step_count[i] += 1; /* droneGymEnv.py:163 */
         uint8_t success = 0, failure = 0;
         float r = 0.0f;
-        if (e->kind == VFO_ENV_HOVER) {
-            success = 0; /* HoverEnv.py:79-80 */
+        if (e->kind == VFO_ENV_HOVER || e->kind == VFO_ENV_HOVER2) {
+            success = 0; /* HoverEnv.py:79-80; HoverEnv2 (:97-152) only changes the observation */
             r = hover_like_reward(p, e->target, q, v, w);
+        } else if (e->kind == VFO_ENV_NAV2) {
+            /* NavigationEnv2.get_success/get_failure/get_reward (NavigationEnv.py:155-224): of the many
+             * terms computed there only r_target_spd + r_omega + r_success reach the returned reward */
+            float dp[3] = { p[0] - e->target[0], p[1] - e->target[1], p[2] - e->target[2] };
+            success = norm3(dp[0], dp[1], dp[2]) <= e->success_radius;
+            failure = es->is_collision[i];
+            /* get_along_vertical_vector(target - p, v)  (NavigationEnv.py:16-24) */
+            float base[3] = { e->target[0] - p[0], e->target[1] - p[1], e->target[2] - p[2] };
+            float bn = norm3(base[0], base[1], base[2]);
+            float den = bn + 1e-8f;
+            float bnorm[3] = { base[0] / den, base[1] / den, base[2] / den };
+            float along = dot3_sum(v, bnorm);
+            float vert[3] = { v[0] - bnorm[0] * along, v[1] - bnorm[1] * along, v[2] - bnorm[2] * along };
+            float away = norm3(vert[0], vert[1], vert[2]);
+            float r_target_spd = (along - away * 1.0f) * 0.02f;
+            float r_omega = norm3(w[0] - 0.0f, w[1] - 0.0f, w[2] - 0.0f) * -0.001f;
+            float r_success = (float)(success ? 1 : 0);
+            r = 0.0f + r_target_spd;
+            r = r + r_omega;
+            r = r + r_success;
         } else if (e->kind == VFO_ENV_NAV) {
             /* NavigationEnv.py:81-99 */
             float dp[3] = { p[0] - e->target[0], p[1] - e->target[1], p[2] - e->target[2] };

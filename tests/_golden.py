@@ -60,7 +60,14 @@ def assert_geometric_close(got, want_all, want, what=""):
 # constructor kwargs of the env fixtures (same as oracle/gen_golden.py::ENV_CASES)
 ENV_DYN = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
 RACING_DYN = dict(action_type="thrust", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+_NAV_CLOSE_SPAWN = {"state_generator": {
+    "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
+                                    "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
+                                    "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}
 ENV_KW = {
+    "env_hover2": dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [
+        {"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]}}),
+    "env_nav2": dict(max_episode_steps=96, target=[2.5, 0., 1.5], random_kwargs=_NAV_CLOSE_SPAWN),
     "env_racing": dict(max_episode_steps=48),
     "env_hover": dict(max_episode_steps=64),
     "env_hover_256": dict(max_episode_steps=256),

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 def make(name, fx, **kw):
-    from visfly_amd.envs import HoverEnv, NavigationEnv, RacingEnv
+    from visfly_amd.envs import HoverEnv, HoverEnv2, NavigationEnv, NavigationEnv2, RacingEnv
     kind = str(fx["kind"])
-    cls = {"hover": HoverEnv, "nav": NavigationEnv, "racing": RacingEnv}[kind]
+    cls = {"hover": HoverEnv, "nav": NavigationEnv, "racing": RacingEnv, "hover2": HoverEnv2, "nav2": NavigationEnv2}[kind]
     if kind == "racing":
         kw["gates"] = fx["gates"].tolist()
     return cls(num_agent_per_scene=fx["fs_init"].shape[0], num_scene=1, seed=int(fx["seed"]), visual=False,
@@ -42,7 +42,7 @@ def test_env_trace_scripted_resets(name):
     def reset_fn(env, idx, fs):
         env.reset_agent_by_id(torch.from_numpy(idx.astype(np.int64)), state=torch.from_numpy(fs))
 
-    run_env_fixture(name, make_env, step_fn, reset_fn, lambda env: env.state.cpu().numpy(),
+    run_env_fixture(name, make_env, step_fn, reset_fn, lambda env: env.get_observation()["state"].cpu().numpy(),
                     lambda env: (env._next_target_i.cpu().numpy(), env._past_targets_num.cpu().numpy())
                     if str(load(name)["kind"]) == "racing" else None)
 

@@ -7,7 +7,7 @@ import pytest
 import oracle
 from _golden import assert_bits_equal, consts_of, decode_actions, load
 
-ENVS = ["env_hover", "env_hover_256", "env_nav", "env_nav_close", "env_racing"]
+ENVS = ["env_hover", "env_hover_256", "env_nav", "env_nav_close", "env_racing", "env_hover2", "env_nav2"]
 
 
 def run_env_fixture(name, make_env, step_fn, reset_fn, state_fn, gates_fn=None):
@@ -68,7 +68,7 @@ def test_oracle_env_trace(name):
         return out
 
     def state_fn(env):
-        return env.dyn.extend_state[:, :13]
+        return env.obs_state
 
     run_env_fixture(name, make_env, step_fn, lambda env, idx, fs: env.reset_agents(idx, fs), state_fn,
                     lambda env: (env.a["next_gate"], env.a["past_gates"]))

@@ -89,6 +89,7 @@ class EnvCfg(C.Structure):
         ("n_spawn", C.c_int32), ("drag_random", C.c_float),
         ("spawn", SpawnBox * MAX_SPAWN),
         ("seed", C.c_uint64),
+        ("obs_mode", C.c_int32), ("reward_mode", C.c_int32),
     ]
 
 

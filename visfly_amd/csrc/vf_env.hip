@@ -63,7 +63,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     er.flags = collision_flags(er.flags, col);
     er.step_count += 1;                                                                  // droneGymEnv.py:163
 
-    bool success = false;
+    bool success = false, failure = false;
     float reward;
     int gate = 0, passed = 0;
     float4 race = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -71,7 +71,12 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         reward = hover_reward(s.p, e.target, s.q, vel, s.w);
     } else if constexpr (KIND == VF_ENV_NAV) {
         success = norm3(s.p[0] - e.target[0], s.p[1] - e.target[1], s.p[2] - e.target[2]) <= e.success_radius;
-        reward = nav_reward(e, s.p, s.q, vel, s.w, col, success, er.step_count);
+        if (e.reward_mode == VF_REWARD_NAV2) {   // NavigationEnv2: failure = is_collision (NavigationEnv.py:159-160)
+            failure = col.hit;
+            reward = nav2_reward(e, s.p, vel, s.w, success);
+        } else {
+            reward = nav_reward(e, s.p, s.q, vel, s.w, col, success, er.step_count);
+        }
     } else {  // RacingEnv.get_success / get_reward (RacingEnv.py:142-148,199-215)
         race = *granule(g.d.S, g.d.G, i, g.g_race);
         gate = __float_as_int(race.x);
@@ -87,16 +92,18 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         race.z = __int_as_float(pass ? 1 : 0);
     }
     er.rewards = er.rewards + reward;                                                    // :185
-    bool ep_done = (er.flags & VF_F_EPISODE_DONE) || success || (er.flags & VF_F_OUT_BOUNDS);   // :188
+    bool ep_done = (er.flags & VF_F_EPISODE_DONE) || success || failure || (er.flags & VF_F_OUT_BOUNDS);   // :188
     if (e.is_collision_reset) ep_done = ep_done || (er.flags & VF_F_COLLISION);          // :189-190
     const bool truncated = er.step_count >= e.max_episode_steps;
     const bool done = ep_done || truncated;                                              // :193
     er.flags = set_flag(er.flags, VF_F_EPISODE_DONE, ep_done);
     er.flags = set_flag(er.flags, VF_F_SUCCESS, success);
+    er.flags = set_flag(er.flags, VF_F_FAILURE, failure);
     er.flags = set_flag(er.flags, VF_F_DONE, done);
 
     float o[13];
     obs_row(c, s, o);
+    obs_variant(e, o);
     if (live) {
         g.out.reward[i] = reward;
         g.out.done[i] = done ? 1 : 0;
@@ -140,6 +147,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         er.step_count = 0;                                                                  // :387-392
         er.rewards = 0.0f;
         obs_row(c, s, o);
+        obs_variant(e, o);
     }
     if constexpr (KIND == VF_ENV_RACING) {
         race.x = __int_as_float(gate);

@@ -98,6 +98,34 @@ __device__ __forceinline__ float nav_reward(const vf_env_cfg& e, const float* p,
     return r;
 }
 
+// NavigationEnv2.get_reward (envs/NavigationEnv.py:185-224): of the terms computed there only
+// r_target_spd + r_omega + r_success reach the returned value; get_along_vertical_vector (:16-24)
+__device__ __forceinline__ float nav2_reward(const vf_env_cfg& e, const float* p, const float* v, const float* w, bool success)
+{
+    const float base[3] = {e.target[0] - p[0], e.target[1] - p[1], e.target[2] - p[2]};
+    const float den = norm3(base[0], base[1], base[2]) + 1e-8f;
+    const float bn[3] = {base[0] / den, base[1] / den, base[2] / den};
+    const float along = dot3(v, bn);
+    const float away = norm3(v[0] - bn[0] * along, v[1] - bn[1] * along, v[2] - bn[2] * along);
+    float r = 0.0f + (along - away * 1.0f) * 0.02f;
+    r = r + norm3(w[0], w[1], w[2]) * -0.001f;
+    r = r + (success ? 1.0f : 0.0f);
+    return r;
+}
+
+// observation variants: HoverEnv2 [(target-p)/10, q, v/10, w/10] (HoverEnv.py:136-152), NavigationEnv2
+// [target-p, q, v, w] (NavigationEnv.py:163-183); o holds the raw state row [p, q, v+wind, w] on entry
+__device__ __forceinline__ void obs_variant(const vf_env_cfg& e, float* o)
+{
+    if (e.obs_mode == VF_OBS_HOVER2) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { o[d] = (e.target[d] - o[d]) / 10.0f; o[7 + d] = o[7 + d] / 10.0f; o[10 + d] = o[10 + d] / 10.0f; }
+    } else if (e.obs_mode == VF_OBS_NAV2) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[d] = e.target[d] - o[d];
+    }
+}
+
 // ---- Philox4x32-10 counter RNG for the on-device spawner ----
 struct U4 {
     unsigned x, y, z, w;

@@ -139,6 +139,8 @@ class DroneEnvsBase:
 
 class DroneGymEnvsBase:
     KIND = HOVER
+    OBS_MODE = 0        # VF_OBS_STATE
+    REWARD_MODE = 0     # VF_REWARD_DEFAULT
 
     def __init__(
             self,
@@ -197,6 +199,7 @@ class DroneGymEnvsBase:
 
         e = _lib.EnvCfg()
         e.kind, e.max_episode_steps = self.KIND, self.max_episode_steps
+        e.obs_mode, e.reward_mode = self.OBS_MODE, self.REWARD_MODE
         e.is_collision_reset = int(bool(is_collision_reset))
         lo, hi = (-30., -30., 0.), (30., 30., 8.)                                     # droneEnv.py:129
         for d in range(3):
@@ -295,8 +298,13 @@ class DroneGymEnvsBase:
         """observation entries that do not come out of the kernel (targets, gates)"""
         return {}
 
-    def _full_obs(self, state):
-        obs = TensorDict({"state": state})
+    def _state_obs(self, raw_state):
+        """observation "state" from the raw (N,13) dynamics state; the step kernel applies the same map on the
+        device (vf_env_cfg.obs_mode), this host version only runs after resets"""
+        return raw_state
+
+    def _full_obs(self, state, raw=False):
+        obs = TensorDict({"state": self._state_obs(state) if raw else state})
         obs.update(self._static_obs())
         return obs
 
@@ -356,7 +364,7 @@ class DroneGymEnvsBase:
         self._info = [{"TimeLimit.truncated": False, "episode_done": False} for _ in range(self.num_agent)]
         self._reward = th.zeros(self.num_agent, device=self.device)
         self._done = th.zeros(self.num_agent, dtype=th.bool, device=self.device)
-        self._observations = self._full_obs(self.envs.dynamics.state)
+        self._observations = self._full_obs(self.envs.dynamics.state, raw=True)
         return self._format_obs(self._observations)
 
     def reset_agent_by_id(self, agent_indices=None, state=None, reset_obs=None):
@@ -372,7 +380,7 @@ class DroneGymEnvsBase:
         self._reset_kernel(idx, fs)
         if self.spawn_mode == "replay":
             self._consume_imu_noise()
-        self._observations = self._full_obs(self.envs.dynamics.state)
+        self._observations = self._full_obs(self.envs.dynamics.state, raw=True)
         for i in idx.tolist():
             self._info[i] = {"TimeLimit.truncated": False, "episode_done": False}
         return self._observations
@@ -555,6 +563,9 @@ class DroneGymEnvsBase:
     def set_requires_grad(self, requires_grad: bool, horizon: int = 64):
         """droneGymEnv.py:628-633.  True: record the per-step checkpoints the adjoint kernel needs (up to
         `horizon` steps between two detach() calls) and return graph-attached obs / reward from step()."""
+        if requires_grad and (self.OBS_MODE or self.REWARD_MODE):
+            raise NotImplementedError("the adjoint kernel differentiates the raw-state observation and the Hover / "
+                                      "Racing rewards; the HoverEnv2 / NavigationEnv2 variants run forward only")
         self.requires_grad = bool(requires_grad)
         if requires_grad:
             if self._tape is None or self._tape.shape[0] < horizon:

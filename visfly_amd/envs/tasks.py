@@ -65,6 +65,42 @@ class NavigationEnv(DroneGymEnvsBase):
         return {"target": self.target if i is None else self.target[i]}
 
 
+class HoverEnv2(HoverEnv):
+    """HoverEnv with the scaled relative observation [(target - p)/10, q, v/10, w/10]
+    (envs/HoverEnv.py:97-152); reward and success as HoverEnv.  The reference forces a depth sensor into
+    sensor_kwargs (:115-119), which only matters with visual=True."""
+    OBS_MODE = 1        # VF_OBS_HOVER2
+
+    def _state_obs(self, raw):
+        # tensor divisor: torch turns `x / python_scalar` on the GPU into x * (1/10), which is not the reference's
+        # (CPU, true division) rounding; tensor / tensor is an IEEE division like the kernel's
+        ten = th.full((1,), 10.0, device=raw.device)
+        return th.hstack([(self.target - raw[:, 0:3]) / ten, raw[:, 3:7], raw[:, 7:10] / ten, raw[:, 10:13] / ten])
+
+
+class NavigationEnv2(NavigationEnv):
+    """obs {"state": [target - p, q, v, w], "collision_vector": (N,3)}; success |p-target| <= 0.5; failure =
+    is_collision; reward = 0.02 (v_along - v_across toward the target) - 0.001 |w| + success
+    (envs/NavigationEnv.py:102-224); default target [14,0,1], default spawn U(mean [9,0,1.5], half [8,6,1])."""
+    OBS_MODE = 2        # VF_OBS_NAV2
+    REWARD_MODE = 1     # VF_REWARD_NAV2
+
+    def __init__(self, *a, random_kwargs=None, target=None, **kw):
+        spawn = {"state_generator": {"class": "Uniform", "kwargs": [
+            {"position": {"mean": [9., 0., 1.5], "half": [8.0, 6., 1.]}}]}} if random_kwargs is None else random_kwargs
+        super().__init__(*a, random_kwargs=spawn, target=[14., 0., 1.] if target is None else target, **kw)
+        self.max_sense_radius = 10
+        del self.observation_space.spaces["target"]
+        self.observation_space["collision_vector"] = spaces.Box(low=-np.inf, high=np.inf, shape=(3,), dtype=np.float32)
+
+    def _state_obs(self, raw):
+        return th.hstack([self.target - raw[:, 0:3], raw[:, 3:13]])
+
+    def _static_obs(self, i=None):
+        cv = self.collision_vector
+        return {"collision_vector": cv if i is None else cv[i]}
+
+
 class RacingEnv(DroneGymEnvsBase):
     """obs {"state": (N,13), "gate": (N,) next-gate index}; 4 gates, pass radius 0.3; passing advances
     the gate (mod 4) and pays +20 on top of the hover-style reward toward the next gate; gate chosen at
