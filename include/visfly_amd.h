@@ -387,6 +387,8 @@ int vf_head_sample(const float* mean, const float* log_std, float* action, float
 typedef struct vf_ppo_loss_cfg {
     float clip_range, ent_coef, vf_coef;
     float inv_batch;        /* 1 / global minibatch rows (means are over the global minibatch) */
+    float* d_log_std_out;   /* optional: the 4 log_std gradients are also written here (tail of the flat gradient) */
+    float* stats_accum;     /* optional: stats[0..15] are also added to this running fp32[16] accumulator */
 } vf_ppo_loss_cfg;
 
 /* Clipped-surrogate PPO loss and its gradient w.r.t. the head outputs (PPO.py:210-263;
@@ -404,6 +406,10 @@ typedef struct vf_adam_cfg {
     float max_grad_norm;    /* <= 0: no clipping */
     int32_t step;           /* 1-based step count AFTER this update */
     int32_t pad0;
+    /* optional: refresh the packed MLP weights (vf_mlp_pack_weights layout) in the same launch.  pack_map holds two
+     * int32 per parameter: the float offsets of its copies in `packed` (forward / data-gradient image), -1 = none */
+    const int32_t* pack_map;
+    float* packed;
 } vf_adam_cfg;
 
 /* clip_grad_norm_ + torch.optim.Adam (weight_decay as L2) over one flat fp32 parameter buffer

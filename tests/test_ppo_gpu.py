@@ -301,3 +301,10 @@ def test_ppo_learn_runs_and_improves_value_fit():
     assert torch.isfinite(ppo.policy.flat).all() and not torch.equal(p0, ppo.policy.flat)
     assert ppo.logs["train/value_loss"] < v_first
     assert 0.0 <= ppo.logs["train/clip_fraction"] <= 1.0 and ppo.logs["time/fps"] > 0
+    # Adam refreshed the packed MFMA weight images incrementally (vf_adam_cfg.pack_map): they must equal a fresh pack
+    pol = ppo.policy
+    kept = pol._packed.clone()
+    assert pol._packed_stamp == pol._stamp
+    pol.lazy_pack = False
+    pol._pack()
+    assert torch.equal(kept, pol._packed)

@@ -141,13 +141,15 @@ class MlpBwdDesc(C.Structure):
 
 class PpoLossCfg(C.Structure):
     """mirror of vf_ppo_loss_cfg"""
-    _fields_ = [("clip_range", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("inv_batch", C.c_float)]
+    _fields_ = [("clip_range", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("inv_batch", C.c_float),
+                ("d_log_std_out", C.c_void_p), ("stats_accum", C.c_void_p)]
 
 
 class AdamCfg(C.Structure):
     """mirror of vf_adam_cfg"""
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", C.c_int32), ("pad0", C.c_int32)]
+                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", C.c_int32), ("pad0", C.c_int32),
+                ("pack_map", C.c_void_p), ("packed", C.c_void_p)]
 
 
 class VisflyError(RuntimeError):

@@ -106,11 +106,12 @@ class BPTT:
         L, st = _lib.lib(), th.cuda.current_stream(self.device).cuda_stream
         self._opt_step += 1
         _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
+        pmap, packed = pol.pack_map()
         cfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, self.weight_decay, self.max_grad_norm,
-                           self._opt_step, 0)
+                           self._opt_step, 0, _ptr(pmap), _ptr(packed))
         _lib.check(L.vf_adam_step(_ptr(pol.flat), _ptr(pol.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params,
                                   _ptr(self._sumsq), C.byref(cfg), st))
-        pol.mark_updated()
+        pol.mark_updated(packed_current=pmap is not None)
         env.detach()                                          # :134
         self.num_timesteps += self.H * N * self.world
         return loss.detach() * self.world

@@ -1072,7 +1072,8 @@ __global__ __launch_bounds__(kBlock) void k_ppo_loss(const float4* __restrict__ 
     }
 }
 
-__global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __restrict__ stats)
+__global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __restrict__ stats, float* __restrict__ d_log_std_out,
+                             float* __restrict__ stats_accum)
 {
     // 16 stats x 16 lanes (256 threads): lane-strided sums over the blocks, shuffle tree over the 16 lanes
     const int k = threadIdx.x >> 4, sl = threadIdx.x & 15;
@@ -1081,7 +1082,31 @@ __global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __
         for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * kStats + k];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
-    if (sl == 0) stats[k] = s;
+    if (sl == 0) {
+        stats[k] = s;
+        if (d_log_std_out && k >= 5 && k < 9) d_log_std_out[k - 5] = s;
+        if (stats_accum) stats_accum[k] += s;
+    }
+}
+
+// sum of squares of a short vector (the flat gradient: tens of thousands of floats) in ONE block: fp64 lane sums,
+// fixed-order tree -- one launch instead of the partial/final pair
+__global__ __launch_bounds__(1024) void k_sumsq_block(const float* __restrict__ x, long n, float* __restrict__ out)
+{
+    __shared__ double sh[16];
+    double ss = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const double a = x[i];
+        ss += a * a;
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        *out = (float)t;
+    }
 }
 
 // clip_grad_norm_ + Adam with L2 weight decay (torch.optim.Adam semantics), PPO.py:285-292
@@ -1104,7 +1129,13 @@ __global__ __launch_bounds__(kBlock) void k_adam(float* __restrict__ p, const fl
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
-        p[i] = pi - step * (mi / denom);
+        const float pn = pi - step * (mi / denom);
+        p[i] = pn;
+        if (c.pack_map) {   // keep the packed MFMA images of the weights current (vf_mlp_pack_weights layout)
+            const int a = c.pack_map[2 * i], b = c.pack_map[2 * i + 1];
+            if (a >= 0) c.packed[a] = pn;
+            if (b >= 0) c.packed[b] = pn;
+        }
     }
 }
 
@@ -1416,7 +1447,7 @@ int vf_ppo_loss(const float* mean, const float* value, const float* log_std, con
     hipLaunchKernelGGL(vf::k_ppo_loss, dim3(nblk), dim3(vf::kBlock), 0, st, reinterpret_cast<const float4*>(mean), value,
                        log_std, reinterpret_cast<const float4*>(action), old_log_prob, adv, ret,
                        reinterpret_cast<float4*>(d_mean), d_value, scratch, M, *cfg);
-    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(256), 0, st, scratch, nblk, stats);
+    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(256), 0, st, scratch, nblk, stats, cfg->d_log_std_out, cfg->stats_accum);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
@@ -1425,6 +1456,11 @@ int vf_sumsq(const float* x, int64_t n, float* out1, float* scratch, vf_stream_t
 {
     if (!x || !out1 || !scratch || n <= 0) return vf::fail(VF_EINVAL, "vf_sumsq: bad argument");
     hipStream_t st = vf::as_stream(stream);
+    if (n <= (1 << 20)) {      // the flat gradient of the actor-critic MLP: one block, one launch
+        hipLaunchKernelGGL(vf::k_sumsq_block, dim3(1), dim3(1024), 0, st, x, (long)n, out1);
+        VF_HIP(hipGetLastError());
+        return VF_OK;
+    }
     double* part = reinterpret_cast<double*>(scratch);
     const int nblk = vf::grid_for(n, 256);
     hipLaunchKernelGGL(vf::k_sum2_partial, dim3(nblk), dim3(vf::kBlock), 0, st, x, (long)n, part);
@@ -1438,6 +1474,8 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !cfg || n <= 0 || cfg->step <= 0 || (cfg->max_grad_norm > 0 && !grad_sumsq))
         return vf::fail(VF_EINVAL, "vf_adam_step: bad argument");
+    if ((cfg->pack_map == nullptr) != (cfg->packed == nullptr))
+        return vf::fail(VF_EINVAL, "vf_adam_step: pack_map and packed must be given together");
     const float bc1 = 1.0f - (float)pow((double)cfg->beta1, (double)cfg->step);
     const float bc2 = 1.0f - (float)pow((double)cfg->beta2, (double)cfg->step);
     hipLaunchKernelGGL(vf::k_adam, dim3(vf::grid_for(n, 1024)), dim3(vf::kBlock), 0, vf::as_stream(stream), param, grad, exp_avg,

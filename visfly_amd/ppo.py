@@ -109,6 +109,7 @@ class MlpPolicy:
         self.fused = True
         self.fused_backward = True
         self._packed, self._pack_desc, self._stamp, self._packed_stamp, self.lazy_pack = None, None, 0, -1, False
+        self._pack_map = None
 
     def _plan_fused(self):
         """LDS layout for the one-launch forward (vf_mlp_forward): every activation gets a [64][w|1] region
@@ -194,11 +195,32 @@ class MlpPolicy:
                 L.save, L.save_ld = b[ly.dst].data_ptr(), b[ly.dst].shape[1]
         return d
 
-    def mark_updated(self):
+    def mark_updated(self, packed_current: bool = False):
         """call after writing ``self.flat`` (optimiser step, load): the packed forward weights are refreshed
         by the next forward.  With ``lazy_pack`` False (default) every forward repacks -- safe for callers that
-        write ``flat`` directly; the trainers set ``lazy_pack`` and call this after each step."""
+        write ``flat`` directly; the trainers set ``lazy_pack`` and call this after each step.
+        ``packed_current``: the writer already refreshed the packed images (vf_adam_step with a pack map)."""
         self._stamp += 1
+        if packed_current and self._packed is not None:
+            self._packed_stamp = self._stamp
+
+    def pack_map(self):
+        """-> (int32 [n_params, 2] device tensor, packed buffer): for every parameter the float offsets of its copies in
+        the packed forward / data-gradient weight images (-1: biases, log_std), for vf_adam_cfg.pack_map"""
+        if self._plan is None:
+            return None, None
+        if self._pack_map is None:
+            import numpy as np
+            m = np.full((self.n_params, 2), -1, np.int32)
+            for li, ly in enumerate(self.layers):
+                n, k = np.meshgrid(np.arange(ly.No), np.arange(ly.K), indexing="ij")
+                flat = ly.w_off + n * ly.K + k
+                m[flat, 0] = self._plan["wt_off"][li] + k * ((ly.No + 31) & ~31) + n
+                m[flat, 1] = self._plan["wb_off"][li] + n * ((ly.K + 31) & ~31) + k
+            self._pack_map = th.from_numpy(m).to(self.device)
+            self._stamp += 1          # force one full pack (zero pads) before the incremental refreshes
+            self._pack()
+        return self._pack_map, self._packed
 
     def _pack(self):
         if self._packed is None:
@@ -518,7 +540,7 @@ class PPO:
         self.num_timesteps += self.n_steps * self.n_envs * self.world
 
     # ------------------------------------------------------------------------------------------
-    def _minibatch_update(self, mb):
+    def _minibatch_update(self, mb, stats_acc=None):
         """one optimiser step on a minibatch {obs:*, actions, old_lp, adv, ret} of contiguous rows (PPO.py:203-292)"""
         L, st, pol = _lib.lib(), self._stream(), self.policy
         obs = {k: mb["obs:" + k] for k in self.obs_keys}
@@ -527,19 +549,24 @@ class PPO:
         gB = B * self.world
         mean, value = pol.forward(obs)
         d_mean, d_value = th.empty((B, 4), device=self.device), th.empty(B, device=self.device)
-        cfg = _lib.PpoLossCfg(self.clip_range, self.ent_coef, self.vf_coef, 1.0 / gB)
+        # the loss launch also writes d(loss)/d(log_std) into the tail of the flat gradient and adds the minibatch
+        # statistics to the epoch accumulator (no separate copy / add launches)
+        cfg = _lib.PpoLossCfg(self.clip_range, self.ent_coef, self.vf_coef, 1.0 / gB, _ptr(pol.grad, pol.log_std_off),
+                              None if stats_acc is None else _ptr(stats_acc))
         _lib.check(L.vf_ppo_loss(_ptr(mean), _ptr(value), _ptr(pol.log_std), _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret),
                                  _ptr(d_mean), _ptr(d_value), _ptr(self._stats), B, C.byref(cfg), _ptr(self._scratch), st))
-        pol.backward(d_mean, d_value, self._stats[5:9])
+        pol.backward(d_mean, d_value, None)
         if self.world > 1:
             parallel.allreduce_sum_(pol.grad)      # sum over ranks: every term is already / global batch
         self._opt_step += 1
         _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
+        pmap, packed = pol.pack_map()          # Adam refreshes the packed MFMA weight images in the same launch
         acfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, self.weight_decay,
-                            self.max_grad_norm if self.max_grad_norm is not None else 0.0, self._opt_step, 0)
+                            self.max_grad_norm if self.max_grad_norm is not None else 0.0, self._opt_step, 0,
+                            _ptr(pmap), _ptr(packed))
         _lib.check(L.vf_adam_step(_ptr(pol.flat), _ptr(pol.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params,
                                   _ptr(self._sumsq), C.byref(acfg), st))
-        pol.mark_updated()
+        pol.mark_updated(packed_current=pmap is not None)
         return self._stats
 
     def train(self):
@@ -576,8 +603,7 @@ class PPO:
                     _lib.check(L.vf_adv_normalize_segments(*args, 2, stv))
                 shuf["adv"] = advn
             for s in range(0, total - bs + 1, bs):
-                st = self._minibatch_update({k: v[s:s + bs] for k, v in shuf.items()})
-                stats_acc += st
+                st = self._minibatch_update({k: v[s:s + bs] for k, v in shuf.items()}, stats_acc)
                 n_mb += 1
                 if self.target_kl is not None:
                     # PPO.py:269-282 checks the KL before the optimiser step; here the check follows the step
