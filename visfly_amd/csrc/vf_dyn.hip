@@ -29,7 +29,7 @@ __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg c, const D
     const bool live = i < g.N;
     Agent s;
     Spares sp;
-    load_agent(g.S, g.G, i, s, sp);
+    load_agent<false>(g.S, g.G, i, s, sp);
     float a[4];
     ring_exchange(c, g, i, live, sp.vel, a);
     float kl[3], kq[3];

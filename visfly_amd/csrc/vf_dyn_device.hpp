@@ -429,6 +429,10 @@ struct Spares {  // component 0 of the vector granules (env-layer slots), carrie
     float vel, omg, aacc, acc;
 };
 
+// LOAD_THRUSTS = false: the step kernels never read the rotor thrusts of the previous interval (every sub-step
+// recomputes them from the rotor speeds, or takes the set-point when ctrl_delay is off: dynamics.py:505-534), so that
+// granule is written but not fetched -- 16 of the 160 B an agent-step used to load.
+template <bool LOAD_THRUSTS = true>
 __device__ __forceinline__ void load_agent(float* __restrict__ S, int G, int i, Agent& s, Spares& sp)
 {
     const float4 g0 = *granule(S, G, i, VF_G_POS);
@@ -436,7 +440,8 @@ __device__ __forceinline__ void load_agent(float* __restrict__ S, int G, int i, 
     const float4 g2 = *granule(S, G, i, VF_G_VEL);
     const float4 g3 = *granule(S, G, i, VF_G_OMG);
     const float4 g4 = *granule(S, G, i, VF_G_MOT);
-    const float4 g5 = *granule(S, G, i, VF_G_THR);
+    float4 g5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (LOAD_THRUSTS) g5 = *granule(S, G, i, VF_G_THR);
     const float4 g6 = *granule(S, G, i, VF_G_AACC);
     const float4 g7 = *granule(S, G, i, VF_G_ACC);
     s.t = g0.x; s.p[0] = g0.y; s.p[1] = g0.z; s.p[2] = g0.w;

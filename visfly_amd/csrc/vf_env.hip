@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const v
     const bool live = i < g.d.N;
     Agent s;
     Spares sp;
-    load_agent(g.d.S, g.d.G, i, s, sp);
+    load_agent<false>(g.d.S, g.d.G, i, s, sp);
     float a[4];
     ring_exchange(c, g.d, i, live, sp.vel, a);
     float kl[3], kq[3];
