@@ -378,6 +378,17 @@ int32_t vf_mlp_backward_blocks(int32_t M);
 int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* partials, float* grad, int32_t M,
                     int32_t accumulate, vf_stream_t stream);
 
+/* First-order policy optimisation glue (utils/algorithms/BPTT.py:107-134), one launch each instead of a chain of
+ * elementwise autograd nodes:
+ *   vf_reparam_fwd     a = tanh(mean + exp(log_std) * eps)           (N,4) rows, log_std[4] shared
+ *   vf_reparam_bwd     d_mean = d_action * (1 - a^2);  g_log_std (N,4) += d_mean * exp(log_std) * eps
+ *   vf_bptt_accumulate loss += -reward * disc;  d_reward = -disc * scale;  disc <- disc * gamma * ~done + done  (:123-124) */
+int vf_reparam_fwd(const float* mean, const float* log_std, const float* eps, float* action, int32_t N, vf_stream_t stream);
+int vf_reparam_bwd(const float* d_action, const float* action, const float* log_std, const float* eps, float* d_mean,
+                   float* g_log_std, int32_t N, vf_stream_t stream);
+int vf_bptt_accumulate(const float* reward, const uint8_t* done, float* disc, float* loss, float* d_reward, float gamma,
+                       float scale, int32_t N, vf_stream_t stream);
+
 /* Squashed diagonal Gaussian head (SB3 SquashedDiagGaussianDistribution as used by
  * policies.py:114,177-181,195-226): a = tanh(mean + exp(log_std) * eps), eps ~ N(0,1) from
  * Philox4x32-10 keyed by (seed, row, step); log_prob as SB3 computes it.  deterministic != 0: a = tanh(mean). */

@@ -42,7 +42,10 @@ class PolicyFunction(th.autograd.Function):
     accumulated into ``policy.grad`` (flat), the observation gradient is returned to autograd."""
 
     @staticmethod
-    def forward(ctx, policy, keys, *obs):
+    def forward(ctx, policy, keys, anchor, *obs):
+        # `anchor` is a dummy leaf that requires grad: the parameters live outside autograd (flat buffer), so without
+        # it the node of the FIRST step -- whose observation carries no graph -- would never run its backward and
+        # that step's parameter gradient would be lost
         ctx.policy, ctx.keys = policy, keys
         ctx.save_for_backward(*obs)
         mean, _ = policy.forward({k: o.detach().contiguous() for k, o in zip(keys, obs)})
@@ -54,7 +57,7 @@ class PolicyFunction(th.autograd.Function):
         obs = ctx.saved_tensors
         pol.forward({k: o.detach().contiguous() for k, o in zip(ctx.keys, obs)})   # activations of THIS step
         d_in = pol.backward(d_mean.contiguous(), None, None, accumulate=True, need_input_grad=True)
-        return (None, None) + tuple(d_in.get(k) for k in ctx.keys)
+        return (None, None, None) + tuple(d_in.get(k) for k in ctx.keys)
 
 
 class BPTT:
@@ -75,6 +78,7 @@ class BPTT:
                                 pk.get("extractor", {k: [128, 64] for k in self.obs_keys}), pk.get("pi", [64, 64]),
                                 pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed)
         self.policy.lazy_pack = True        # this trainer calls mark_updated() after every optimiser step
+        self.use_autograd = False           # True: torch.autograd schedules the same kernels (cross-check path)
         n = self.policy.n_params
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=self.device), th.zeros(n, device=self.device)
         self._sumsq, self._scratch = th.zeros(1, device=self.device), th.zeros(4096, device=self.device)
@@ -86,14 +90,55 @@ class BPTT:
 
     def _update(self):
         """one horizon: roll out, back-propagate through simulator and policy, clip + Adam (BPTT.py:100-134)"""
+        loss = self._grad_autograd() if self.use_autograd else self._grad_reverse_sweep()
+        return self._apply(loss)
+
+    def _grad_reverse_sweep(self):
+        """explicit reverse sweep: no autograd tape.  Forward: policy (activations of every step stay resident in their
+        own slot) -> reparameterised action -> fused env step (state checkpoint on the tape) -> loss / discount
+        bookkeeping, one launch each.  Reverse, t = H-1 .. 0: adjoint env step -> action head -> whole-network backward
+        (parameter gradients accumulate in MFMA partials + fold) -> gradient w.r.t. the observation of step t, which
+        is what step t-1 returned.  dLoss/d reward_t = -disc_t / N is known in the forward pass (:123)."""
+        env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
+        L, st, dev = _lib.lib(), th.cuda.current_stream(self.device).cuda_stream, self.device
+        pol.grad.zero_()
+        disc, loss_vec = th.ones(N, device=dev), th.zeros(N, device=dev)
+        g_ls = th.zeros((N, 4), device=dev)
+        log_std = pol.log_std
+        t0 = env._tape_t
+        obs = env.get_observation()
+        acts, epss, drews = [], [], []
+        for t in range(H):
+            mean, _ = pol.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, slot=t)
+            eps = th.randn((N, 4), device=dev, generator=self._gen)
+            action = th.empty((N, 4), device=dev)
+            _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(eps), _ptr(action), N, st))
+            obs, reward, done, _ = env._step_no_grad(action, False, record=True)
+            d_rew = th.empty(N, device=dev)
+            _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(d_rew),
+                                            float(self.gamma), 1.0 / (N * self.world), N, st))
+            acts.append(action); epss.append(eps); drews.append(d_rew)
+        g_obs, d_mean = None, th.empty((N, 4), device=dev)
+        for t in reversed(range(H)):
+            d_action = env.backward_step(t0 + t, g_obs, drews[t])
+            _lib.check(L.vf_reparam_bwd(_ptr(d_action), _ptr(acts[t]), _ptr(log_std), _ptr(epss[t]), _ptr(d_mean), _ptr(g_ls), N, st))
+            d_in = pol.backward(d_mean, None, None, accumulate=True, need_input_grad=t > 0, slot=t)
+            g_obs = d_in.get("state") if t > 0 else None
+        pol.grad[pol.log_std_off:] = g_ls.sum(dim=0)
+        return loss_vec.mean() / self.world
+
+    def _grad_autograd(self):
+        """the same gradient with torch.autograd as the scheduler (two custom Functions wrap the kernels); kept as the
+        cross-check of the reverse sweep and as the template for dropping in an arbitrary torch policy"""
         env, pol, N = self.env, self.policy, self.env.num_envs
         pol.grad.zero_()
         log_std = pol.log_std.detach().clone().requires_grad_(True)
+        anchor = th.zeros(1, device=self.device, requires_grad=True)
         disc = th.ones(N, device=self.device)
         loss_vec = th.zeros(N, device=self.device)
         obs = env.get_observation()
         for _ in range(self.H):
-            mean = PolicyFunction.apply(pol, self.obs_keys, *[obs[k] for k in self.obs_keys])
+            mean = PolicyFunction.apply(pol, self.obs_keys, anchor, *[obs[k] for k in self.obs_keys])
             eps = th.randn((N, 4), device=self.device, generator=self._gen)
             action = th.tanh(mean + log_std.exp() * eps)     # reparameterised squashed Gaussian (td_policies Actor)
             obs, reward, done, _ = env.step(action)
@@ -102,6 +147,10 @@ class BPTT:
         loss = loss_vec.mean() / self.world
         loss.backward()
         pol.grad[pol.log_std_off:] = log_std.grad
+        return loss.detach()
+
+    def _apply(self, loss):
+        env, pol, N = self.env, self.policy, self.env.num_envs
         parallel.allreduce_sum_(pol.grad)
         L, st = _lib.lib(), th.cuda.current_stream(self.device).cuda_stream
         self._opt_step += 1

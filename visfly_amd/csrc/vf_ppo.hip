@@ -1072,6 +1072,49 @@ __global__ __launch_bounds__(kBlock) void k_ppo_loss(const float4* __restrict__ 
     }
 }
 
+// ---- first-order policy optimisation glue (BPTT.py:107-134): reparameterised action, its reverse, loss bookkeeping ----
+// a = tanh(mean + exp(log_std) * eps)   (reparameterised squashed Gaussian, one thread per row)
+__global__ __launch_bounds__(kBlock) void k_reparam_fwd(const float4* __restrict__ mean, const float* __restrict__ log_std,
+                                                        const float4* __restrict__ eps, float4* __restrict__ action, int N)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const float4 m = mean[i], e = eps[i];
+    action[i] = make_float4(tanhf(m.x + expf(log_std[0]) * e.x), tanhf(m.y + expf(log_std[1]) * e.y),
+                            tanhf(m.z + expf(log_std[2]) * e.z), tanhf(m.w + expf(log_std[3]) * e.w));
+}
+
+// d_mean = d_action * (1 - a^2);  g_log_std += d_mean * exp(log_std) * eps   (per row; summed over rows by the caller)
+__global__ __launch_bounds__(kBlock) void k_reparam_bwd(const float4* __restrict__ d_action, const float4* __restrict__ action,
+                                                        const float* __restrict__ log_std, const float4* __restrict__ eps,
+                                                        float4* __restrict__ d_mean, float4* __restrict__ g_log_std, int N)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const float4 da = d_action[i], a = action[i], e = eps[i];
+    const float4 dm = make_float4(da.x * (1.0f - a.x * a.x), da.y * (1.0f - a.y * a.y), da.z * (1.0f - a.z * a.z),
+                                  da.w * (1.0f - a.w * a.w));
+    d_mean[i] = dm;
+    float4 g = g_log_std[i];
+    g.x += dm.x * expf(log_std[0]) * e.x; g.y += dm.y * expf(log_std[1]) * e.y;
+    g.z += dm.z * expf(log_std[2]) * e.z; g.w += dm.w * expf(log_std[3]) * e.w;
+    g_log_std[i] = g;
+}
+
+// loss_i += -reward_i * disc_i; d_reward_i = -disc_i * scale; disc_i <- disc_i * gamma * ~done_i + done_i   (BPTT.py:123-124)
+__global__ __launch_bounds__(kBlock) void k_bptt_accumulate(const float* __restrict__ reward, const uint8_t* __restrict__ done,
+                                                            float* __restrict__ disc, float* __restrict__ loss,
+                                                            float* __restrict__ d_reward, float gamma, float scale, int N)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const float d = disc[i];
+    loss[i] = loss[i] + -1.0f * reward[i] * d;
+    d_reward[i] = -d * scale;
+    const float dn = done[i] ? 1.0f : 0.0f;
+    disc[i] = d * gamma * (1.0f - dn) + dn;
+}
+
 __global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __restrict__ stats, float* __restrict__ d_log_std_out,
                              float* __restrict__ stats_accum)
 {
@@ -1419,6 +1462,39 @@ int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* par
                            grad + lo, (float*)nullptr, accumulate ? 1 : 0);
         i = j;
     }
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_reparam_fwd(const float* mean, const float* log_std, const float* eps, float* action, int32_t N, vf_stream_t stream)
+{
+    if (!mean || !log_std || !eps || !action || N <= 0) return vf::fail(VF_EINVAL, "vf_reparam_fwd: bad argument");
+    hipLaunchKernelGGL(vf::k_reparam_fwd, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream),
+                       reinterpret_cast<const float4*>(mean), log_std, reinterpret_cast<const float4*>(eps),
+                       reinterpret_cast<float4*>(action), N);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_reparam_bwd(const float* d_action, const float* action, const float* log_std, const float* eps, float* d_mean,
+                   float* g_log_std, int32_t N, vf_stream_t stream)
+{
+    if (!d_action || !action || !log_std || !eps || !d_mean || !g_log_std || N <= 0)
+        return vf::fail(VF_EINVAL, "vf_reparam_bwd: bad argument");
+    hipLaunchKernelGGL(vf::k_reparam_bwd, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream),
+                       reinterpret_cast<const float4*>(d_action), reinterpret_cast<const float4*>(action), log_std,
+                       reinterpret_cast<const float4*>(eps), reinterpret_cast<float4*>(d_mean),
+                       reinterpret_cast<float4*>(g_log_std), N);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_bptt_accumulate(const float* reward, const uint8_t* done, float* disc, float* loss, float* d_reward, float gamma,
+                       float scale, int32_t N, vf_stream_t stream)
+{
+    if (!reward || !done || !disc || !loss || !d_reward || N <= 0) return vf::fail(VF_EINVAL, "vf_bptt_accumulate: bad argument");
+    hipLaunchKernelGGL(vf::k_bptt_accumulate, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done,
+                       disc, loss, d_reward, gamma, scale, N);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -102,7 +102,8 @@ class MlpPolicy:
         flat[self.log_std_off:] = log_std_init
         self.flat = flat.to(self.device)
         self.grad = th.zeros_like(self.flat)
-        self._bufs: Dict[int, Dict[str, th.Tensor]] = {}
+        self._bufs: Dict[tuple, Dict[str, th.Tensor]] = {}
+        self._gbufs: Dict[int, Dict[str, th.Tensor]] = {}
         self._scratch = None
         self._plan = self._plan_fused()
         self._descs = {}
@@ -242,35 +243,42 @@ class MlpPolicy:
     def log_std(self):
         return self.flat[self.log_std_off:]
 
-    def _buffers(self, M):
-        b = self._bufs.get(M)
+    def _buffers(self, M, slot=0):
+        """activation buffers of one forward pass (kept for backward).  ``slot`` selects one of several resident
+        sets for the same M -- a BPTT horizon keeps every step's activations (HBM is plentiful: 60 MB per step at
+        16 384 rows) instead of recomputing the forward in the reverse sweep; gradient buffers are shared."""
+        b = self._bufs.get((M, slot))
         if b is None:
-            b = {name: th.empty((M, w), dtype=th.float32, device=self.device) for name, w in self.widths.items()}
-            b.update({"g:" + name: th.empty((M, w), dtype=th.float32, device=self.device)
-                      for name, w in self.widths.items() if name not in ("mean", "value")})
-            if len(self._bufs) > 4:
+            if len({m for m, _ in self._bufs}) > 4 and M not in {m for m, _ in self._bufs}:
                 self._bufs.clear()
+                self._gbufs.clear()
                 self._descs.clear()
-            self._bufs[M] = b
+            b = {name: th.empty((M, w), dtype=th.float32, device=self.device) for name, w in self.widths.items()}
+            g = self._gbufs.get(M)
+            if g is None:
+                g = self._gbufs[M] = {"g:" + name: th.empty((M, w), dtype=th.float32, device=self.device)
+                                      for name, w in self.widths.items() if name not in ("mean", "value")}
+            b.update(g)
+            self._bufs[(M, slot)] = b
         return b
 
     def _stream(self):
         return th.cuda.current_stream(self.device).cuda_stream
 
-    def forward(self, obs: Dict[str, th.Tensor], save_activations: bool = True):
+    def forward(self, obs: Dict[str, th.Tensor], save_activations: bool = True, slot: int = 0):
         """-> mean (M,4), value (M,1).  One launch for the whole network when the LDS plan fits
         (``self.fused``); ``save_activations`` keeps every layer output in HBM for ``backward``
         (inference passes False and moves only observations in and heads out)."""
         M = obs[self.obs_keys[0]].shape[0]
-        b = self._buffers(M)
+        b = self._buffers(M, slot)
         L, st = _lib.lib(), self._stream()
         for k in self.obs_keys:
             t = obs[k]
             assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
             b["obs:" + k] = t
-        self._last_M = M
+        self._last_M, self._last_slot = M, slot
         if self._plan is not None and self.fused:
-            key = (M, bool(save_activations))
+            key = (M, slot, bool(save_activations))
             d = self._descs.get(key)
             if d is None:
                 d = self._descs[key] = self._fused_desc(b, save_activations)
@@ -290,12 +298,12 @@ class MlpPolicy:
         return b["mean"], b["value"]
 
     def backward(self, d_mean: th.Tensor, d_value: Optional[th.Tensor], d_log_std: Optional[th.Tensor],
-                 accumulate: bool = False, need_input_grad: bool = False):
+                 accumulate: bool = False, need_input_grad: bool = False, slot: Optional[int] = None):
         """fills (or, with ``accumulate``, adds into) ``self.grad`` -- flat, same layout as ``self.flat`` --
         from the head gradients.  d_value None skips the value trunk (first-order policy optimisation has
         no critic); need_input_grad also returns {obs key: dLoss/d obs} (BPTT differentiates through obs)."""
         M = self._last_M
-        b = self._buffers(M)
+        b = self._buffers(M, self._last_slot if slot is None else slot)
         L, st = _lib.lib(), self._stream()
         if self.fused_backward and self._plan is not None:
             return self._backward_fused(b, M, d_mean, d_value, d_log_std, accumulate, need_input_grad)
