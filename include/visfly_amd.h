@@ -333,8 +333,8 @@ typedef struct vf_mlp_desc {
     int32_t n_layers, n_inputs;
     int32_t in_dim[4];
     int32_t lds_off[VF_MLP_MAX_BUFS], lds_stride[VF_MLP_MAX_BUFS];   /* indexed by buffer id (ids < 4: staged inputs) */
-    int32_t w_region_off;        /* LDS offset of the weight staging region */
-    int32_t lds_floats;          /* total dynamic LDS, floats */
+    int32_t lds_floats;          /* total dynamic LDS, floats (activations only; <= 80 KiB lets two workgroups share a CU) */
+    int32_t pad0;
     vf_mlp_layer layer[VF_MLP_MAX_LAYERS];
 } vf_mlp_desc;
 /* The forward reads its MFMA B operand straight from global memory: `packed` holds, per layer at float offset

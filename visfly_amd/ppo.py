@@ -185,7 +185,7 @@ class MlpPolicy:
             d.in_dim[i] = self.obs_dims[k]
         for n, bid in p["ids"].items():
             d.lds_off[bid], d.lds_stride[bid] = p["off"][n], p["stride"][n]
-        d.w_region_off, d.lds_floats = 0, p["total"]
+        d.lds_floats = p["total"]
         for li, ly in enumerate(self.layers):
             L = d.layer[li]
             L.K, L.No, L.relu = ly.K, ly.No, 1 if ly.relu else 0
