@@ -5,7 +5,7 @@ sys.path.insert(0, root)
 import torch
 from visfly_amd import _build, _lib
 so = os.path.join(root, "visfly_amd", "csrc", "libvf_probe.so")
-if not os.path.exists(so) or "--rebuild" in sys.argv:
+if not os.path.exists(so) or "--rebuild" in sys.argv or os.path.getmtime(so) < os.path.getmtime(os.path.join(root, "visfly_amd", "csrc", "vf_ppo.hip")):
     _build.build(force=True, extra_flags=["-DVF_PROBE"], out=so)
 _lib.LIB = so
 from visfly_amd.ppo import MlpPolicy
