@@ -113,7 +113,9 @@ class BPTT:
             eps = th.randn((N, 4), device=dev, generator=self._gen)
             action = th.empty((N, 4), device=dev)
             _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(eps), _ptr(action), N, st))
+            pre_obs = obs
             obs, reward, done, _ = env._step_no_grad(action, False, record=True)
+            self._on_step(t, pre_obs, action, obs, reward, done, disc)
             d_rew = th.empty(N, device=dev)
             _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(d_rew),
                                             float(self.gamma), 1.0 / (N * self.world), N, st))
@@ -126,6 +128,9 @@ class BPTT:
             g_obs = d_in.get("state") if t > 0 else None
         pol.grad[pol.log_std_off:] = g_ls.sum(dim=0)
         return loss_vec.mean() / self.world
+
+    def _on_step(self, t, pre_obs, action, obs, reward, done, disc):
+        """hook for subclasses (SHAC collects its critic buffer here); disc is the discount BEFORE this step's update"""
 
     def _grad_autograd(self):
         """the same gradient with torch.autograd as the scheduler (two custom Functions wrap the kernels); kept as the

@@ -301,7 +301,8 @@ class MlpPolicy:
                  accumulate: bool = False, need_input_grad: bool = False, slot: Optional[int] = None):
         """fills (or, with ``accumulate``, adds into) ``self.grad`` -- flat, same layout as ``self.flat`` --
         from the head gradients.  d_value None skips the value trunk (first-order policy optimisation has
-        no critic); need_input_grad also returns {obs key: dLoss/d obs} (BPTT differentiates through obs)."""
+        no critic), d_mean None the policy trunk (a critic network uses the value trunk only);
+        need_input_grad also returns {obs key: dLoss/d obs} (BPTT differentiates through obs)."""
         M = self._last_M
         b = self._buffers(M, self._last_slot if slot is None else slot)
         L, st = _lib.lib(), self._stream()
@@ -310,7 +311,7 @@ class MlpPolicy:
         need = max(int(L.vf_linear_bwd_scratch_floats(M, ly.K, ly.No)) for ly in self.layers)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
-        gbuf = {"mean": d_mean}
+        gbuf = {} if d_mean is None else {"mean": d_mean}
         if d_value is not None:
             gbuf["value"] = d_value.view(M, 1)
         wgrad = L.vf_linear_bwd_weight_acc if accumulate else L.vf_linear_bwd_weight
@@ -318,6 +319,8 @@ class MlpPolicy:
         d_in = {}
         for ly in reversed(self.layers):
             if d_value is None and (ly.dst == "value" or ly.dst.startswith("vf:")):
+                continue
+            if d_mean is None and (ly.dst == "mean" or ly.dst.startswith("pi:")):
                 continue
             dY = gbuf.get(ly.dst, b.get("g:" + ly.dst))
             Y, X = b[ly.dst], b[ly.src]
@@ -350,7 +353,7 @@ class MlpPolicy:
         its 64-row tiles for every layer, so g:* buffers written by one entry are read by the next without
         a grid-wide barrier."""
         L, st = _lib.lib(), self._stream()
-        gbuf = {"mean": d_mean}
+        gbuf = {} if d_mean is None else {"mean": d_mean}
         if d_value is not None:
             gbuf["value"] = d_value.view(M, 1)
         d = _lib.MlpBwdDesc()
@@ -358,6 +361,8 @@ class MlpPolicy:
         touched, d_in, keep, n = set(), {}, [], 0
         for ly in reversed(self.layers):
             if d_value is None and (ly.dst == "value" or ly.dst.startswith("vf:")):
+                continue
+            if d_mean is None and (ly.dst == "mean" or ly.dst.startswith("pi:")):
                 continue
             dY = gbuf.get(ly.dst, b.get("g:" + ly.dst))
             Y, X = b[ly.dst], b[ly.src]
