@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 1
+#define VF_ABI_VERSION 2   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward */
 
 typedef void* vf_stream_t;
 

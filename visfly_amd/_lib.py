@@ -69,6 +69,7 @@ class DynCfg(C.Structure):
         return c
 
 
+ABI_VERSION = 2          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
 MAX_GATES, MAX_SPAWN = 8, 4
 
 
@@ -234,7 +235,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.vf_abi_version() != 1:
+        if L.vf_abi_version() != ABI_VERSION:
             raise VisflyError("libvisfly_amd.so ABI version mismatch; rebuild")
         _lib = L
     return _lib
