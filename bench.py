@@ -194,6 +194,16 @@ def main():
             traffic = (pmc["fetch_bytes_per_agent"] + pmc["write_bytes_per_agent"]) * N
         except Exception:
             pass
+        valu = None      # second roofline: fp32 VALU issue, from the PMC instruction count committed under profiles/
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_env_sq.json")))
+            per_wave = sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]
+            waves_per_simd = -(-(-(-N // 64)) // 1024)                 # ceil(waves / (256 CUs x 4 SIMDs))
+            floor_us = waves_per_simd * per_wave * 4 / 2.4e3          # 4 cycles per wave64 VALU instruction at 2.4 GHz
+            valu = {"valu_instr_per_wave": per_wave, "waves_per_simd": waves_per_simd, "floor_us": floor_us,
+                    "frac": floor_us / kern_us}
+        except Exception:
+            pass
         out = {
             "metric": "agent-steps/sec (dynamics.step, visual=False)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,7 +216,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_env_step<hover,bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
-                         "bytes_per_agent_step": BYTES_PER_ENV_STEP,
+                         "bytes_per_agent_step": BYTES_PER_ENV_STEP, "valu": valu,
                          "dyn_only": {"kernel": "k_dyn_step<bodyrate,euler,ctrl_delay>", "kernel_us": dyn_us,
                                       "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
                                       "achieved": BYTES_PER_AGENT_STEP * N / (dyn_us * 1e-6) / 1e9}},
