@@ -31,8 +31,14 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     if not force and out == LIB and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", out]
+    tmp = f"{out}.{os.getpid()}.tmp"          # link to a private name, then rename: concurrent builders never see a torn file
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return out
