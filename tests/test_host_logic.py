@@ -63,3 +63,23 @@ def test_tensordict_surface():
     s = TensorDict.stack([d, d])
     assert s["state"].shape == (2, 2, 3)
     assert isinstance(d.numpy()["state"], np.ndarray)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it"""
+    import ast
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    for path in sorted((root / "visfly_amd").rglob("*.py")):
+        tree = ast.parse(path.read_text())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{path} imports the oracle"
+    for path in sorted((root / "visfly_amd" / "csrc").glob("*.h*")):
+        assert "vf_oracle" not in path.read_text(), f"{path} references the oracle"
+    bench = (root / "bench.py").read_text()
+    assert bench.count("import oracle") == 1 and "def cpu_baseline" in bench     # the one sanctioned use

@@ -308,3 +308,19 @@ def test_ppo_learn_runs_and_improves_value_fit():
     pol.lazy_pack = False
     pol._pack()
     assert torch.equal(kept, pol._packed)
+
+
+def test_ppo_training_is_bitwise_reproducible():
+    """every reduction on the path (MFMA partial folds, loss statistics, grad norm) has a fixed order: two runs from the
+    same seeds end with bit-identical parameters"""
+    from visfly_amd.envs import HoverEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    flats = []
+    for _ in range(2):
+        env = HoverEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64,
+                       tensor_output=True)
+        ppo = PPO(env, n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3)
+        ppo.learn(16 * 1024 * 3)
+        flats.append(ppo.policy.flat.clone())
+    assert torch.equal(flats[0], flats[1])
