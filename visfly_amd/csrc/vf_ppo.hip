@@ -488,6 +488,58 @@ __device__ __forceinline__ void mfma_sweep_gb2(const float* __restrict__ ap, con
     }
 }
 
+// Fully unrolled sweep for a compile-time chunk count (NCH x 16 reduction steps, NACC accumulators): three chunks of B
+// fragments are in flight (every launch starts with cold L2s and all CUs walk the layers in lock-step, so each weight
+// chunk is a first-touch miss of ~2 k cycles), buffers rotate by NAME -- no register copies, no branches -- so that
+// hipcc's waitcnt insertion can leave the younger chunks outstanding (vmcnt(N) instead of vmcnt(0)).
+template <int NCH, int NACC>
+__device__ __forceinline__ void mfma_sweep_static(const float* __restrict__ ap, const float* __restrict__ bg, int off0, int off1,
+                                                  int ldb, f32x16& acc0, f32x16& acc1)
+{
+    constexpr int D = NCH < 3 ? NCH : 3;
+    float xb[3][2][8];
+    float a[2][8];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xb[c][0][j] = bg[(unsigned)(off0 + (16 * c + 2 * j) * ldb)];
+            if (NACC == 2) xb[c][1][j] = bg[(unsigned)(off1 + (16 * c + 2 * j) * ldb)];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[0][j] = ap[2 * j];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        // load group: A fragments of the next chunk (LDS) and the refill of the B buffer chunk c-1 just released
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[(c + 1) & 1][j] = ap[16 * (c + 1) + 2 * j];
+        }
+        if (c >= 1 && c - 1 + D < NCH) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xb[(c - 1) % 3][0][j] = bg[(unsigned)(off0 + (16 * (c - 1 + D) + 2 * j) * ldb)];
+                if (NACC == 2) xb[(c - 1) % 3][1][j] = bg[(unsigned)(off1 + (16 * (c - 1 + D) + 2 * j) * ldb)];
+            }
+        }
+        // MFMA group, nothing in between: any other instruction between two MFMAs on the same accumulator costs
+        // ~43 extra cycles (MI355X_MICROARCH.md, per-instruction constants), and the narrow layers have one accumulator
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // touch every operand of the group: ONE s_waitcnt in front instead of one per MFMA
+            asm volatile("" : "+v"(a[c & 1][j]), "+v"(xb[c % 3][0][j]));
+            if (NACC == 2) asm volatile("" : "+v"(xb[c % 3][1][j]));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][j], xb[c % 3][0][j], acc0, 0, 0, 0);
+            if (NACC == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][j], xb[c % 3][1][j], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Packed forward weights: per layer Wt[k][n] = W[n][k] for k < K16 = round16(K), n < N32 = round32(No), zero padded,
 // at float offset wt_off of the packed buffer (vf_mlp_pack_weights) -- the forward B operand without any guard.
 __global__ __launch_bounds__(kBlock) void k_mlp_pack_weights(const vf_mlp_desc d, const float* __restrict__ params,
@@ -532,17 +584,24 @@ __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, 
             const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
             const float* bg = packed + L.wt_off;            // wave-uniform base, 32-bit lane offsets
             const int off0 = lk * ldb + c0 * 32 + lr, off1 = off0 + 64;
-            BFrag x0, x1;                                   // first weight fragments travel while the barrier is pending
-            if (nacc >= 1) x0 = load_bfrag(bg, off0, ldb);
-            if (nacc == 2) x1 = load_bfrag(bg, off1, ldb);
             __syncthreads();                               // inputs of this layer are in LDS
             VF_PROBE_AT(2);
             const float* As = lds + d.lds_off[L.src] + L.src_col;
             const int sa = d.lds_stride[L.src];
             const float* ap = As + (rt * 32 + lr) * sa + lk;
             f32x16 acc0 = {0}, acc1 = {0};
-            if (nacc == 2) mfma_sweep_gb2(ap, bg, off0, off1, ldb, red16, x0, x1, acc0, acc1);
-            else if (nacc == 1) mfma_sweep_gb1(ap, bg, off0, ldb, red16, x0, acc0);
+            const int nch = red16 >> 4;                    // 1 (K = 13, 3), 4 (K = 64), 8 (K = 128): unrolled sweeps; else generic
+            if (nacc == 2) {
+                if (nch == 8) mfma_sweep_static<8, 2>(ap, bg, off0, off1, ldb, acc0, acc1);
+                else if (nch == 4) mfma_sweep_static<4, 2>(ap, bg, off0, off1, ldb, acc0, acc1);
+                else if (nch == 1) mfma_sweep_static<1, 2>(ap, bg, off0, off1, ldb, acc0, acc1);
+                else mfma_sweep_gb2(ap, bg, off0, off1, ldb, red16, load_bfrag(bg, off0, ldb), load_bfrag(bg, off1, ldb), acc0, acc1);
+            } else if (nacc == 1) {
+                if (nch == 8) mfma_sweep_static<8, 1>(ap, bg, off0, off1, ldb, acc0, acc1);
+                else if (nch == 4) mfma_sweep_static<4, 1>(ap, bg, off0, off1, ldb, acc0, acc1);
+                else if (nch == 1) mfma_sweep_static<1, 1>(ap, bg, off0, off1, ldb, acc0, acc1);
+                else mfma_sweep_gb1(ap, bg, off0, ldb, red16, load_bfrag(bg, off0, ldb), acc0);
+            }
             VF_PROBE_AT(5);
             // epilogue: bias + ReLU, into the destination region (LDS or global) and the optional saved copy
             const int rb = rt * 32 + 4 * lk;               // first row of this lane's accumulator column
