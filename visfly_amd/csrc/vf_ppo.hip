@@ -1196,12 +1196,15 @@ __global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __
 __global__ __launch_bounds__(1024) void k_sumsq_block(const float* __restrict__ x, long n, float* __restrict__ out)
 {
     __shared__ double sh[16];
-    double ss = 0.0;
-    for (long i = threadIdx.x; i < n; i += 1024) {
-        const double a = x[i];
-        ss += a * a;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;       // four independent chains, 16-byte loads (all in flight at once)
+    const long n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n >> 2 : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = x4[i];
+        s0 += (double)v.x * v.x; s1 += (double)v.y * v.y; s2 += (double)v.z * v.z; s3 += (double)v.w * v.w;
     }
-    ss = wave_sum(ss);
+    for (long i = 4 * n4 + threadIdx.x; i < n; i += 1024) s0 += (double)x[i] * x[i];
+    double ss = wave_sum((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
     __syncthreads();
     if (threadIdx.x == 0) {
