@@ -305,3 +305,26 @@ def test_full_size_batch_vs_oracle(kind):
             assert (np.abs(r.cpu().numpy() - rr) <= 5e-8 + 1.2e-7 * np.abs(rr)).all()
         else:
             assert_bits_equal(r.cpu().numpy(), rr, f"{kind} reward @ {k}")
+
+
+def test_racing_info_reports_gates_passed_in_the_finished_episode():
+    """info["episode"]["extra"]["past_gate"] (RacingEnv.collect_info, RacingEnv.py:113-116) is the count of the episode
+    that just ended -- captured by the step kernel before the auto-reset clears it; a pass pays +20 (:215)"""
+    from visfly_amd.envs import RacingEnv
+    gates = load("env_racing")["gates"].tolist()          # gates next to the spawn boxes: random flight passes them
+    N = 512
+    env = RacingEnv(num_agent_per_scene=N, seed=4, dynamics_kwargs=dict(RACING_DYN), device="cuda:0", max_episode_steps=48,
+                    tensor_output=True, gates=gates)
+    env.reset()
+    g = torch.Generator().manual_seed(2)
+    count = np.zeros(N, np.int64)
+    seen = 0
+    for k in range(120):
+        a = (torch.tensor([-0.8333] * 4) + (torch.rand((N, 4), generator=g) * 2 - 1) * 0.08).clamp(-1, 1)
+        obs, r, d, info = env.step(a.cuda())
+        count += (r.cpu().numpy() > 10.0)
+        for i in np.nonzero(d.cpu().numpy())[0]:
+            assert info[i]["episode"]["extra"]["past_gate"] == count[i], (k, i)
+            seen += int(count[i] > 0)
+            count[i] = 0
+    assert seen > 0

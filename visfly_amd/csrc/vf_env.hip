@@ -114,6 +114,9 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
                 g.out.ep_flags[i] = (success ? VF_EP_SUCCESS : 0) | (truncated ? VF_EP_TRUNCATED : 0) |
                                     ((er.flags & VF_F_ONCE_COLLIDED) ? VF_EP_COLLIDED : 0) |
                                     (ep_done ? VF_EP_EPISODE_DONE : 0);
+            if constexpr (KIND == VF_ENV_RACING) {
+                if (g.out.ep_past_gates) g.out.ep_past_gates[i] = passed;
+            }
             if (g.out.terminal_obs) {
                 float* to = g.out.terminal_obs + 13 * (size_t)i;
 #pragma unroll

@@ -244,6 +244,7 @@ class DroneGymEnvsBase:
             self._ep_return = th.zeros(N, **f32)
             self._ep_length = th.zeros(N, dtype=th.int32, device=self.device)
             self._ep_flags = th.zeros(N, dtype=th.uint8, device=self.device)
+            self._ep_past_gates = th.zeros(N, dtype=th.int32, device=self.device) if self.KIND == RACING else None
             self._terminal_obs = th.zeros((N, 13), **f32)
             self._gate = th.zeros(N, dtype=th.int32, device=self.device) if self.KIND == RACING else None
 
@@ -277,6 +278,7 @@ class DroneGymEnvsBase:
         o.ep_return, o.ep_length = _lib.ptr(self._ep_return), _lib.ptr(self._ep_length)
         o.ep_flags, o.terminal_obs = _lib.ptr(self._ep_flags), _lib.ptr(self._terminal_obs)
         o.gate = _lib.ptr(self._gate)
+        o.ep_past_gates = _lib.ptr(self._ep_past_gates)
         return o
 
     def _query(self):

@@ -132,7 +132,8 @@ class RacingEnv(DroneGymEnvsBase):
         self._gate.copy_(self._query()["gate"])     # in place: the step kernel holds this buffer's address
 
     def _extra_info(self):
-        return {"past_gate": self._query()["past_gates"]}
+        # gates passed in the episode that just ended, written by the step kernel where done (RacingEnv.py:113-116)
+        return {"past_gate": self._ep_past_gates}
 
     def reset(self, state=None, obs=None, **kw):
         return super().reset(state)
