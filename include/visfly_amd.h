@@ -200,6 +200,7 @@ typedef struct vf_env_out {
     float* terminal_obs;  /* (N,13) pre-reset observation rows, written where done        (:260) */
     int32_t* gate;        /* (N,)   RacingEnv next-gate observation after auto-reset            */
     int32_t* ep_past_gates; /* (N,) RacingEnv gates passed in the finished episode, written where done (RacingEnv.py:113-116) */
+    int32_t* terminal_gate; /* (N,) RacingEnv "gate" entry of the terminal observation (pre-reset), written where done */
 } vf_env_out;
 
 /* Dense per-agent view of the env state for the reference's properties (droneGymEnv.py:477-571,

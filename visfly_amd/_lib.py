@@ -97,7 +97,7 @@ class EnvCfg(C.Structure):
 class EnvOut(C.Structure):
     """mirror of vf_env_out (device pointers)"""
     _fields_ = [(n, C.c_void_p) for n in ("obs", "reward", "done", "ep_return", "ep_length", "ep_flags",
-                                          "terminal_obs", "gate", "ep_past_gates")]
+                                          "terminal_obs", "gate", "ep_past_gates", "terminal_gate")]
 
 
 class EnvView(C.Structure):

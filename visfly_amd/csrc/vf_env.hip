@@ -116,6 +116,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
                                     (ep_done ? VF_EP_EPISODE_DONE : 0);
             if constexpr (KIND == VF_ENV_RACING) {
                 if (g.out.ep_past_gates) g.out.ep_past_gates[i] = passed;
+                if (g.out.terminal_gate) g.out.terminal_gate[i] = gate;
             }
             if (g.out.terminal_obs) {
                 float* to = g.out.terminal_obs + 13 * (size_t)i;

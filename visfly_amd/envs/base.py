@@ -60,7 +60,7 @@ class _Info(list):
                      "episode": {"r": np.asarray(ret[i]), "l": np.asarray(length[i]),
                                  "t": np.asarray(length[i] * np.float32(env.envs.dynamics.ctrl_dt)),
                                  "extra": {"collision": np.asarray(bool(f & EP_COLLIDED))}},
-                     "terminal_observation": {"state": tobs[i], **env._static_obs(i)},
+                     "terminal_observation": {"state": tobs[i], **env._terminal_static_obs(i)},
                      "TimeLimit.truncated": bool(f & EP_TRUNCATED)}
                 if extra is not None:
                     d["episode"]["extra"].update({k: v[i].item() for k, v in extra.items()})
@@ -245,6 +245,7 @@ class DroneGymEnvsBase:
             self._ep_length = th.zeros(N, dtype=th.int32, device=self.device)
             self._ep_flags = th.zeros(N, dtype=th.uint8, device=self.device)
             self._ep_past_gates = th.zeros(N, dtype=th.int32, device=self.device) if self.KIND == RACING else None
+            self._terminal_gate = th.zeros(N, dtype=th.int32, device=self.device) if self.KIND == RACING else None
             self._terminal_obs = th.zeros((N, 13), **f32)
             self._gate = th.zeros(N, dtype=th.int32, device=self.device) if self.KIND == RACING else None
 
@@ -279,6 +280,7 @@ class DroneGymEnvsBase:
         o.ep_flags, o.terminal_obs = _lib.ptr(self._ep_flags), _lib.ptr(self._terminal_obs)
         o.gate = _lib.ptr(self._gate)
         o.ep_past_gates = _lib.ptr(self._ep_past_gates)
+        o.terminal_gate = _lib.ptr(self._terminal_gate)
         return o
 
     def _query(self):
@@ -299,6 +301,10 @@ class DroneGymEnvsBase:
     def _static_obs(self, i=None):
         """observation entries that do not come out of the kernel (targets, gates)"""
         return {}
+
+    def _terminal_static_obs(self, i):
+        """the same entries as they were in the terminal (pre-reset) observation of agent i"""
+        return self._static_obs(i)
 
     def _state_obs(self, raw_state):
         """observation "state" from the raw (N,13) dynamics state; the step kernel applies the same map on the

@@ -131,6 +131,9 @@ class RacingEnv(DroneGymEnvsBase):
         super()._reset_kernel(idx, fs)
         self._gate.copy_(self._query()["gate"])     # in place: the step kernel holds this buffer's address
 
+    def _terminal_static_obs(self, i):
+        return {"gate": self._terminal_gate[i]}
+
     def _extra_info(self):
         # gates passed in the episode that just ended, written by the step kernel where done (RacingEnv.py:113-116)
         return {"past_gate": self._ep_past_gates}
