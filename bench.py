@@ -137,7 +137,12 @@ def main():
     args = ap.parse_args()
 
     from visfly_amd import parallel
-    rank, world, local = parallel.init("nccl")
+    # RCCL in production; VISFLY_AMD_DIST_BACKEND=gloo lets the N > 1 control flow be exercised on a box with fewer GPUs than
+    # ranks (ranks then share devices round-robin) -- used by tests/test_parallel_gpu.py, never by the driver
+    backend = os.environ.get("VISFLY_AMD_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    rank, world, local = parallel.init(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

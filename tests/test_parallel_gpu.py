@@ -57,3 +57,24 @@ def test_two_ranks_stay_in_lockstep(algo):
     assert [r[0] for r in res] == [0, 1]
     assert all(r[1] for r in res), "parameters diverged between the ranks"
     assert res[0][2] == res[1][2] and res[0][2] > 0          # num_timesteps counts the global batch on every rank
+
+
+def test_bench_two_ranks_control_flow():
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run), with the exchange over gloo because the
+    test box has one GPU: barrier + max-over-ranks timing, ONE JSON line from rank 0, whole-job value"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VISFLY_AMD_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "200",
+           "--warmup", "20", "--agents", "16384"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 200 and out["scaling"] == "weak" and out["value"] > 0
+    assert abs(out["value"] - 2 * 16384 * 200 / (out["ms_per_step"] * 1e-3 * 200)) < 1e-3 * out["value"]
+    assert "cpu_baseline" not in out                       # rank 0 times the CPU port at N = 1 only
