@@ -992,25 +992,32 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
     }
 }
 
-// deterministic second stage: 16 lanes share one output element, each summing every 16th partial,
-// then a fixed-order shuffle tree; 16 elements per 256-thread block
+// deterministic second stage: a block owns 64 consecutive output elements (one 256-byte row segment per wave-load);
+// wave w sums the partial rows b = w, w+4, w+8, ... with four independent chains, the four waves are combined through
+// LDS in a fixed order
 __global__ __launch_bounds__(kBlock) void k_fold_partials(const float* __restrict__ part, int nblk, int stride, int nw, int nb,
                                                           float* __restrict__ dW, float* __restrict__ db, int accumulate)
 {
     const int n = nw + nb;
-    const int e = blockIdx.x * 16 + (threadIdx.x & 15);   // output element
-    const int sl = threadIdx.x >> 4;                       // slice 0..15 (same wave: lanes e + 16*k)
-    float s = 0.0f;
-    if (e < n)
-        for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * stride + e];
-    s += __shfl_down(s, 32, 64);   // slices k and k+2 (lane + 32)
-    s += __shfl_down(s, 16, 64);   // slices k and k+1 (lane + 16)
-    __shared__ float sh[4][16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < 16) sh[wave][lane] = s;
+    const int e = blockIdx.x * 64 + lane;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (e < n) {
+        const float* p = part + e;
+        int r = wave;
+        for (; r + 12 < nblk; r += 16) {
+            s0 += p[(size_t)r * stride];
+            s1 += p[(size_t)(r + 4) * stride];
+            s2 += p[(size_t)(r + 8) * stride];
+            s3 += p[(size_t)(r + 12) * stride];
+        }
+        for (; r < nblk; r += 4) s0 += p[(size_t)r * stride];
+    }
+    __shared__ float sh[4][64];
+    sh[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (threadIdx.x < 16 && e < n) {
-        const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (wave == 0 && e < n) {
+        const float t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
         if (e < nw) dW[e] = accumulate ? dW[e] + t : t;
         else if (db) db[e - nw] = accumulate ? db[e - nw] + t : t;
     }
@@ -1399,7 +1406,7 @@ static int linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, 
     hipLaunchKernelGGL(vf::k_linear_wgrad, dim3(nblk), dim3(vf::kBlock), lds, st, dY, lddy, Ymask, ldym, X, ldx, scratch, M, K,
                        No, rpb);
     const int n = No * K + No;
-    hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 15) / 16), dim3(vf::kBlock), 0, st, scratch, nblk, n,
+    hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 63) / 64), dim3(vf::kBlock), 0, st, scratch, nblk, n,
                        No * K, No, dW, db, accumulate);
     VF_HIP(hipGetLastError());
     return VF_OK;
@@ -1520,7 +1527,7 @@ int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* par
         int j = i + 1;
         while (j < niv && iv[j].first <= hi) { hi = iv[j].second > hi ? iv[j].second : hi; ++j; }
         const int n = (int)(hi - lo);
-        hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 15) / 16), dim3(vf::kBlock), 0, st, partials + lo, nblk, desc->n_fold, n, 0,
+        hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 63) / 64), dim3(vf::kBlock), 0, st, partials + lo, nblk, desc->n_fold, n, 0,
                            grad + lo, (float*)nullptr, accumulate ? 1 : 0);
         i = j;
     }
