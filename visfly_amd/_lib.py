@@ -257,5 +257,12 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream(device):
+    """raw hipStream_t of torch's current stream on `device` (no Python Stream object on the hot path)"""
+    if _raw_stream is not None:
+        idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream

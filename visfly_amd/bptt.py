@@ -100,7 +100,7 @@ class BPTT:
         (parameter gradients accumulate in MFMA partials + fold) -> gradient w.r.t. the observation of step t, which
         is what step t-1 returned.  dLoss/d reward_t = -disc_t / N is known in the forward pass (:123)."""
         env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
-        L, st, dev = _lib.lib(), th.cuda.current_stream(self.device).cuda_stream, self.device
+        L, st, dev = _lib.lib(), _lib.current_stream(self.device), self.device
         pol.grad.zero_()
         disc, loss_vec = th.ones(N, device=dev), th.zeros(N, device=dev)
         g_ls = th.zeros((N, 4), device=dev)
@@ -157,7 +157,7 @@ class BPTT:
     def _apply(self, loss):
         env, pol, N = self.env, self.policy, self.env.num_envs
         parallel.allreduce_sum_(pol.grad)
-        L, st = _lib.lib(), th.cuda.current_stream(self.device).cuda_stream
+        L, st = _lib.lib(), _lib.current_stream(self.device)
         self._opt_step += 1
         _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
         pmap, packed = pol.pack_map()

@@ -28,6 +28,11 @@ from ..type import TensorDict
 from . import spaces
 from .randomization import ReplaySpawner, spawn_boxes
 
+# hot-path helpers: the raw handle of torch's current stream / device without building Python wrapper objects
+# (the env step is one ~11 us launch; the host side of a step must stay below that)
+_raw_stream = getattr(th._C, "_cuda_getCurrentRawStream", None) or (lambda idx: th.cuda.current_stream(idx).cuda_stream)
+_cuda_get_device = getattr(th._C, "_cuda_getDevice", None) or th.cuda.current_device
+
 HOVER, NAV, RACING = 0, 1, 2
 F_EPISODE_DONE, F_ONCE_COLLIDED, F_COLLISION, F_OUT_BOUNDS, F_SUCCESS, F_FAILURE, F_DONE = 1, 2, 4, 8, 16, 32, 64
 EP_SUCCESS, EP_TRUNCATED, EP_COLLIDED, EP_EPISODE_DONE = 1, 2, 4, 8
@@ -432,7 +437,7 @@ class DroneGymEnvsBase:
         if self.validate_actions:
             assert a.max() <= 1 and a.min() >= -1                                           # :144
         self._action = a
-        if th.cuda.current_device() != dev.index:
+        if _cuda_get_device() != dev.index:
             th.cuda.set_device(dev)
         state = th.empty((N, 13), dtype=th.float32, device=dev)
         reward = th.empty(N, dtype=th.float32, device=dev)
@@ -449,7 +454,7 @@ class DroneGymEnvsBase:
         o = self._outs
         o.obs, o.reward, o.done = state.data_ptr(), reward.data_ptr(), done.data_ptr()
         rc = self._vf_env_step(self._h, a.data_ptr(), self._outs_ref, 0 if (is_test or replay) else 1,
-                               th.cuda.current_stream(dev).cuda_stream)
+                               _raw_stream(dev.index))
         if rc:
             _lib.check(rc)
         self._qcache = None

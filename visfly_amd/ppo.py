@@ -263,7 +263,7 @@ class MlpPolicy:
         return b
 
     def _stream(self):
-        return th.cuda.current_stream(self.device).cuda_stream
+        return _lib.current_stream(self.device)
 
     def forward(self, obs: Dict[str, th.Tensor], save_activations: bool = True, slot: int = 0):
         """-> mean (M,4), value (M,1).  One launch for the whole network when the LDS plan fits
@@ -500,7 +500,7 @@ class PPO:
         self.logs: Dict[str, float] = {}
 
     def _stream(self):
-        return th.cuda.current_stream(self.device).cuda_stream
+        return _lib.current_stream(self.device)
 
     # ------------------------------------------------------------------------------------------
     def _act(self, obs, deterministic=False):

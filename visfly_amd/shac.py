@@ -79,7 +79,7 @@ class SHAC(BPTT):
         eps = th.randn((N, 4), device=dev, generator=self._gen)
         nxt = th.empty((N, 4), device=dev)
         _lib.check(_lib.lib().vf_reparam_fwd(_ptr(mean), _ptr(self.policy.log_std), _ptr(eps), _ptr(nxt), N,
-                                             th.cuda.current_stream(dev).cuda_stream))
+                                             _lib.current_stream(dev)))
         sa_next = self._sa(obs, nxt)
         nv = th.minimum(self.targets[0].q(sa_next).clone(), self.targets[1].q(sa_next))
         ep_done = done & ((env._ep_flags & EP_EPISODE_DONE) != 0)
@@ -97,7 +97,7 @@ class SHAC(BPTT):
         b, N, H = self._buf, self.env.num_envs, self.H
         actor_loss = loss - b["boot"].mean() / self.world
         out = self._apply(actor_loss)
-        L, st = _lib.lib(), th.cuda.current_stream(self.device).cuda_stream
+        L, st = _lib.lib(), _lib.current_stream(self.device)
         returns = th.empty((H, N), device=self.device)
         # SimpleRolloutBuffer.compute_returns passes the literal 0.99 (common.py:1232-1239)
         _lib.check(L.vf_td_returns(_ptr(b["reward"]), b["done"].data_ptr(), b["ep_done"].data_ptr(), _ptr(b["next_value"]),
@@ -108,7 +108,7 @@ class SHAC(BPTT):
         return out
 
     def _train_critics(self, sa, target):
-        L, st, M = _lib.lib(), th.cuda.current_stream(self.device).cuda_stream, sa.shape[0]
+        L, st, M = _lib.lib(), _lib.current_stream(self.device), sa.shape[0]
         gM = M * self.world
         loss = None
         for _ in range(self.gradient_steps):
