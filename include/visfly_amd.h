@@ -380,6 +380,12 @@ int32_t vf_mlp_backward_blocks(int32_t M);
 int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* partials, float* grad, int32_t M,
                     int32_t accumulate, vf_stream_t stream);
 
+/* Training-log statistics of one env step (PPO._dump_logs, utils/algorithms/PPO.py:392-414): acc4 (fp64, device) +=
+ * {episodes finished this step, sum of their returns, sum of their lengths, successes}, from the step outputs
+ * done / ep_return / ep_length / ep_flags (vf_env_out).  No host synchronisation. */
+int vf_episode_stats(const uint8_t* done, const float* ep_return, const int32_t* ep_length, const uint8_t* ep_flags,
+                     double* acc4, int32_t N, vf_stream_t stream);
+
 /* First-order policy optimisation glue (utils/algorithms/BPTT.py:107-134), one launch each instead of a chain of
  * elementwise autograd nodes:
  *   vf_reparam_fwd     a = tanh(mean + exp(log_std) * eps)           (N,4) rows, log_std[4] shared

@@ -301,6 +301,9 @@ def test_ppo_learn_runs_and_improves_value_fit():
     assert torch.isfinite(ppo.policy.flat).all() and not torch.equal(p0, ppo.policy.flat)
     assert ppo.logs["train/value_loss"] < v_first
     assert 0.0 <= ppo.logs["train/clip_fraction"] <= 1.0 and ppo.logs["time/fps"] > 0
+    # rollout statistics (PPO._dump_logs): every agent times out after 64 steps, so 32-step rollouts finish one episode per two
+    assert ppo.logs["rollout/episodes"] == 2048 and 0 < ppo.logs["rollout/ep_len_mean"] <= 64
+    assert np.isfinite(ppo.logs["rollout/ep_rew_mean"]) and 0.0 <= ppo.logs["rollout/ep_success_rate"] <= 1.0
     # Adam refreshed the packed MFMA weight images incrementally (vf_adam_cfg.pack_map): they must equal a fresh pack
     pol = ppo.policy
     kept = pol._packed.clone()

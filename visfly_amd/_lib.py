@@ -195,6 +195,7 @@ SIGNATURES = {
     "vf_linear_bwd_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "vf_linear_bwd_weight": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
                                        C.c_int32, _vp, _vp]),
+    "vf_episode_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_reparam_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_bptt_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_int32, _vp]),

@@ -1198,6 +1198,36 @@ __global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __
     }
 }
 
+// episode statistics of one env step for the training log (PPO._dump_logs: rollout/ep_rew_mean, ep_len_mean, success rate;
+// PPO.py:392-414): acc += {episodes finished, sum of their returns, sum of their lengths, successes}.  One block, fixed
+// reduction order, no host synchronisation in the rollout loop.
+__global__ __launch_bounds__(1024) void k_episode_stats(const uint8_t* __restrict__ done, const float* __restrict__ ep_return,
+                                                        const int32_t* __restrict__ ep_length, const uint8_t* __restrict__ ep_flags,
+                                                        double* __restrict__ acc, int N)
+{
+    __shared__ double sh[4][16];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        if (done[i]) {
+            v[0] += 1.0;
+            v[1] += (double)ep_return[i];
+            v[2] += (double)ep_length[i];
+            v[3] += (ep_flags[i] & VF_EP_SUCCESS) ? 1.0 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double s = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[threadIdx.x][w];
+        acc[threadIdx.x] += t;
+    }
+}
+
 // sum of squares of a short vector (the flat gradient: tens of thousands of floats) in ONE block: fp64 lane sums,
 // fixed-order tree -- one launch instead of the partial/final pair
 __global__ __launch_bounds__(1024) void k_sumsq_block(const float* __restrict__ x, long n, float* __restrict__ out)
@@ -1564,6 +1594,15 @@ int vf_bptt_accumulate(const float* reward, const uint8_t* done, float* disc, fl
     if (!reward || !done || !disc || !loss || !d_reward || N <= 0) return vf::fail(VF_EINVAL, "vf_bptt_accumulate: bad argument");
     hipLaunchKernelGGL(vf::k_bptt_accumulate, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done,
                        disc, loss, d_reward, gamma, scale, N);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_episode_stats(const uint8_t* done, const float* ep_return, const int32_t* ep_length, const uint8_t* ep_flags, double* acc4,
+                     int32_t N, vf_stream_t stream)
+{
+    if (!done || !ep_return || !ep_length || !ep_flags || !acc4 || N <= 0) return vf::fail(VF_EINVAL, "vf_episode_stats: bad argument");
+    hipLaunchKernelGGL(vf::k_episode_stats, dim3(1), dim3(1024), 0, vf::as_stream(stream), done, ep_return, ep_length, ep_flags, acc4, N);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -489,6 +489,7 @@ class PPO:
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=dev), th.zeros(n, device=dev)
         self._scratch = th.zeros(16 * 1024 + 4096, device=dev)
         self._stats = th.zeros(16, device=dev)
+        self._ep_stats = th.zeros(4, dtype=th.float64, device=dev)   # episodes, sum return, sum length, successes
         self._sumsq = th.zeros(1, device=dev)
         self._sums = th.zeros(2, dtype=th.float64, device=dev)
         self._opt_step = 0
@@ -537,6 +538,8 @@ class PPO:
             buf.log_probs[t].copy_(logp)
             buf.episode_starts[t].copy_(self._last_starts)
             obs, reward, done, _info = env.step(action)
+            _lib.check(_lib.lib().vf_episode_stats(done.data_ptr(), _ptr(env._ep_return), _ptr(env._ep_length), _ptr(env._ep_flags),
+                                                   self._ep_stats.data_ptr(), self.n_envs, self._stream()))
             # TimeLimit.truncated bootstrap: SB3 adds gamma * V(terminal_observation) where the info says truncated
             trunc = done & ((env._ep_flags & EP_TRUNC) != 0)
             tobs = {"state": env._terminal_obs}
@@ -629,6 +632,11 @@ class PPO:
                 break
         rows = float(bs * n_mb)
         s = (stats_acc / rows).tolist()
+        ep = parallel.allreduce_sum_(self._ep_stats.clone()).tolist()          # rollout statistics of this iteration (:398-414)
+        self._ep_stats.zero_()
+        if ep[0] > 0:
+            self.logs.update({"rollout/ep_rew_mean": ep[1] / ep[0], "rollout/ep_len_mean": ep[2] / ep[0],
+                              "rollout/ep_success_rate": ep[3] / ep[0], "rollout/episodes": ep[0]})
         self.logs.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/entropy_loss": s[2],
                           "train/approx_kl": s[3], "train/clip_fraction": s[4], "train/n_updates": self._opt_step})
 
