@@ -435,14 +435,17 @@ struct Spares {  // component 0 of the vector granules (env-layer slots), carrie
 template <bool LOAD_THRUSTS = true>
 __device__ __forceinline__ void load_agent(float* __restrict__ S, int G, int i, Agent& s, Spares& sp)
 {
-    const float4 g0 = *granule(S, G, i, VF_G_POS);
-    const float4 g1 = *granule(S, G, i, VF_G_QUAT);
+    // issue order = order of first use: ring head (velocity granule) and the controller's inputs (body rates, angular
+    // acceleration) first, then the rotors, then what the translation needs -- loads return in order, so the controller
+    // and the ring exchange run while the tail of the burst is still in flight
     const float4 g2 = *granule(S, G, i, VF_G_VEL);
     const float4 g3 = *granule(S, G, i, VF_G_OMG);
+    const float4 g6 = *granule(S, G, i, VF_G_AACC);
     const float4 g4 = *granule(S, G, i, VF_G_MOT);
+    const float4 g1 = *granule(S, G, i, VF_G_QUAT);
+    const float4 g0 = *granule(S, G, i, VF_G_POS);
     float4 g5 = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (LOAD_THRUSTS) g5 = *granule(S, G, i, VF_G_THR);
-    const float4 g6 = *granule(S, G, i, VF_G_AACC);
     const float4 g7 = *granule(S, G, i, VF_G_ACC);
     s.t = g0.x; s.p[0] = g0.y; s.p[1] = g0.z; s.p[2] = g0.w;
     s.q = Quat{g1.x, g1.y, g1.z, g1.w};
