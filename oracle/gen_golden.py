@@ -490,6 +490,13 @@ BPTT_CASES = {
     "bptt_hover_nodelay": ("hover", dict(ENV_DYN, ctrl_delay=False, comm_delay=0.0), dict(max_episode_steps=1000),
                            [-1 / 3, 0, 0, 0], 0.3, 8),
     "bptt_racing_thrust": ("racing", RACING_DYN, dict(max_episode_steps=1000), [-0.8333] * 4, 0.08, 12),
+    # NavigationEnv reward (progress, view angle through acos, obstacle terms, success bonus): close target so that
+    # successes (bonus with a velocity gradient) and their resets fall inside the horizon
+    "bptt_nav_bodyrate": ("nav", ENV_DYN, dict(max_episode_steps=1000, target=[1.6, 0., 1.5], random_kwargs={"state_generator": {
+        "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
+                                        "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
+                                        "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}),
+                          [-0.3, 0, 0, 0], 0.5, 12),
 }
 
 
@@ -499,7 +506,10 @@ def gen_bptt(name, N=64, seed=42):
     HoverEnvShim, NavigationEnv, RacingEnv = import_envs()
     kind, dkw, kw, hover, scale, H = BPTT_CASES[name]
     use_cr_sqrt(True)
-    cls = {"hover": HoverEnvShim, "racing": RacingEnv}[kind]
+    cls = {"hover": HoverEnvShim, "racing": RacingEnv, "nav": NavigationEnv}[kind]
+    kw = dict(kw)
+    if "target" in kw:
+        kw["target"] = th.tensor(kw["target"])
     env = cls(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False, dynamics_kwargs=dict(dkw), device="cpu",
               requires_grad=True, **({"tensor_output": True} if kind == "hover" else {}), **kw)
     env.tensor_output = True
@@ -534,7 +544,9 @@ def gen_bptt(name, N=64, seed=42):
             "done": np.stack(dones), "reward": np.stack(rewards),
             "ev_step": np.asarray(ev_step, np.int32), "ev_agent": np.asarray(ev_agent, np.int32),
             "ev_fs": np.stack(ev_fs) if ev_fs else np.zeros((0, 22), np.float32),
-            "dyn_kw": np.asarray(repr(dkw)), "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle")}
+            "dyn_kw": np.asarray(repr(dkw)), "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle"),
+            "target": f32(env.target[0]) if kind != "racing" else np.zeros(3, np.float32),
+            "spawn": np.asarray(repr(kw.get("random_kwargs", "default")))}
     if kind == "racing":
         save.update(gates=np.asarray(RACING_TEST_GATES, np.float32), gate0=gate0)
     save.update({"c_" + k: v for k, v in consts.items()})

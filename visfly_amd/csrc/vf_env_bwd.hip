@@ -208,7 +208,81 @@ __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg c, con
         }
     }
     // reward gradient (computed on the pre-reset post-step state, so it survives a reset)
-    if (live && g.d_reward) {
+    if (live && g.d_reward && KIND == VF_ENV_NAV) {
+        // NavigationEnv.get_reward (envs/NavigationEnv.py:84-99).  What autograd differentiates there: position, orientation,
+        // velocity, angular velocity and -- through collision_vector = collision_point.detach() - position
+        // (droneEnv.py:345-366) -- the distance / direction to the closest bbox face; success and the step counter are
+        // constants.  clamp / clamp_max / clamp_min pass the gradient on the closed side, relu'(0) = 0, norm'(0) = 0.
+        const float dr = g.d_reward[i];
+        const float vv[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};
+        const Collision col = bbox_collision(e, s.p);
+        const bool success = norm3(s.p[0] - e.target[0], s.p[1] - e.target[1], s.p[2] - e.target[2]) <= e.success_radius;
+        const int step_count = __float_as_int(sp.omg) + 1;        // counter of THIS step (the tape holds the pre-step slab)
+        float ltp[3] = {0.f, 0.f, 0.f}, lcv[3] = {0.f, 0.f, 0.f}, ldis = 0.0f;
+        // t1 = clamp_max(<v, tp> / (1e-6 + |tp|), 10) * 0.01,  tp = target - p
+        const float tp[3] = {e.target[0] - s.p[0], e.target[1] - s.p[1], e.target[2] - s.p[2]};
+        const float ntp = norm3(tp[0], tp[1], tp[2]), den1 = 1e-6f + ntp, dot1 = dot3(vv, tp);
+        if (dot1 / den1 <= 10.0f) {
+            const float gq = dr * 0.01f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lv[k] += gq * tp[k] / den1;
+                ltp[k] += gq * (vv[k] / den1 - (ntp > 0.0f ? dot1 / (den1 * den1) * tp[k] / ntp : 0.0f));
+            }
+        }
+        // t2 = (clamp_min(acos(clamp(<dir, v> / (1e-6 + |v|), -1, 1)), pi/18) - pi/18) * -0.01,  dir = x_axis(q)
+        const Quat& q = s.q;
+        const float dir[3] = {1.0f - 2.0f * (q.y * q.y + q.z * q.z), 2.0f * (q.x * q.y + q.z * q.w), 2.0f * (q.x * q.z - q.y * q.w)};
+        const float vn = norm3(vv[0], vv[1], vv[2]), den2 = 1e-6f + vn, dot2 = dot3(dir, vv);
+        const float cs0 = dot2 / den2;
+        const float thrd = (float)(3.14159265358979323846 / 18.0);
+        if (cs0 >= -1.0f && cs0 <= 1.0f && acosf(cs0) >= thrd) {
+            const float gcs = dr * -0.01f * (-1.0f / sqrtf(1.0f - cs0 * cs0));
+            float ldir[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ldir[k] = gcs * vv[k] / den2;
+                lv[k] += gcs * (dir[k] / den2 - (vn > 0.0f ? dot2 / (den2 * den2) * vv[k] / vn : 0.0f));
+            }
+            lq.w += ldir[1] * 2.0f * q.z - ldir[2] * 2.0f * q.y;
+            lq.x += ldir[1] * 2.0f * q.y + ldir[2] * 2.0f * q.z;
+            lq.y += ldir[0] * -4.0f * q.y + ldir[1] * 2.0f * q.x - ldir[2] * 2.0f * q.w;
+            lq.z += ldir[0] * -4.0f * q.z + ldir[1] * 2.0f * q.w + ldir[2] * 2.0f * q.x;
+        }
+        // t3 .. t5: -1e-5 |q - 1|, -0.002 |v|, -0.002 |w|
+        const float dqv[4] = {q.w - 1.0f, q.x, q.y, q.z};
+        const float nq = norm4(dqv[0], dqv[1], dqv[2], dqv[3]), nw = norm3(s.w[0], s.w[1], s.w[2]);
+        if (nq > 0.0f) {
+            const float gq = dr * (float)-0.00001 / nq;
+            lq.w += gq * dqv[0]; lq.x += gq * dqv[1]; lq.y += gq * dqv[2]; lq.z += gq * dqv[3];
+        }
+        // t8 = success * (max_steps - step) * 0.1 * (0.2 + 0.8 / (1 + |v|)): the only other |v| term
+        const float sterm = (float)(success ? e.max_episode_steps - step_count : 0);
+        const float lvn = dr * (-0.002f + sterm * 0.1f * 0.8f * (-1.0f / ((1.0f + vn) * (1.0f + vn))));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (vn > 0.0f) lv[k] += lvn * vv[k] / vn;
+            if (nw > 0.0f) lw[k] += dr * -0.002f * s.w[k] / nw;
+        }
+        // t6 = -0.01 / (dis + 0.2);  t7 = relu(1 - dis) * relu(<cv, v> / (1e-6 + dis)) * -0.005
+        ldis += dr * 0.01f / ((col.dis + 0.2f) * (col.dis + 0.2f));
+        const float relu1 = 1.0f - col.dis > 0.0f ? 1.0f - col.dis : 0.0f;
+        const float den7 = 1e-6f + col.dis, dot7 = dot3(col.vec, vv), ap = dot7 / den7;
+        const float g7 = dr * -0.005f;
+        if (1.0f - col.dis > 0.0f) ldis -= g7 * (ap > 0.0f ? ap : 0.0f);
+        if (ap > 0.0f) {
+            const float lap = g7 * relu1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lcv[k] += lap * vv[k] / den7; lv[k] += lap * col.vec[k] / den7; }
+            ldis -= lap * dot7 / (den7 * den7);
+        }
+        if (col.dis > 0.0f) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lcv[k] += ldis * col.vec[k] / col.dis;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lp[k] -= ltp[k] + lcv[k];     // tp = target - p,  cv = const - p
+    } else if (live && g.d_reward) {
         const float dr = g.d_reward[i];
         const float* tgt = e.target;
         if constexpr (KIND == VF_ENV_RACING) {
@@ -426,12 +500,13 @@ extern "C" int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* a, vf_stream_t 
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: the adjoint covers the thrust and bodyrate action types only");
     if (h->dyn.cfg.integrator != VF_INT_EULER)
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: only the Euler integrator has an adjoint (RK4: not yet)");
-    if (h->cfg.kind == VF_ENV_NAV)
-        return vf::fail(VF_EINVAL, "vf_env_step_bwd: NavigationEnv's reward has no adjoint yet (Hover / Racing do)");
+    if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
+        return vf::fail(VF_EINVAL, "vf_env_step_bwd: the HoverEnv2 / NavigationEnv2 observation and reward variants have no adjoint");
     const int S = h->dyn.cfg.interval_steps;
     if (S > 10) return vf::fail(VF_EINVAL, "vf_env_step_bwd: at most 10 sub-steps per control interval (LDS budget)");
     const size_t lds = (size_t)S * vf::kSave * vf::kBlock * sizeof(float);
-    BwdKernel k = h->cfg.kind == VF_ENV_RACING ? pick_bwd<VF_ENV_RACING>(h->dyn.cfg) : pick_bwd<VF_ENV_HOVER>(h->dyn.cfg);
+    BwdKernel k = h->cfg.kind == VF_ENV_RACING ? pick_bwd<VF_ENV_RACING>(h->dyn.cfg)
+                  : (h->cfg.kind == VF_ENV_NAV ? pick_bwd<VF_ENV_NAV>(h->dyn.cfg) : pick_bwd<VF_ENV_HOVER>(h->dyn.cfg));
     if (lds > 64 * 1024)
         VF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     vf::BwdArgs g{h->dyn.N, h->dyn.G, h->dyn.g_drag, h->g_race, a->tape_slab, reinterpret_cast<const float4*>(a->action),
