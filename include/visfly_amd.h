@@ -251,7 +251,8 @@ int vf_env_time_steps(vf_env* h, const float* action, const vf_env_out* out, int
  *   adj_slab     in/out adjoint of the persistent state, same layout as the slab: on entry the
  *                adjoint w.r.t. the state AFTER the step, on exit w.r.t. the state BEFORE it
  *   d_action     (N,4) out: dLoss/d(action)
- * Euler integrator, thrust / bodyrate actions, Hover / Racing (hover-style terms) and NavigationEnv rewards. */
+ * Euler and (repaired) RK4 integrators, thrust / bodyrate actions, Hover / Racing (hover-style terms) and
+ * NavigationEnv rewards; anything else returns VF_EINVAL. */
 typedef struct vf_env_bwd_args {
     const float* tape_slab; const float* action; const float* d_obs; const float* d_reward;
     const uint8_t* done; float* adj_slab; float* d_action;

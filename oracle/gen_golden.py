@@ -145,13 +145,17 @@ def run_dyn(Dynamics, kwargs, fs0, actions, checkpoints):
     return d, out, obs
 
 
-def repair_rk4():
+def repair_rk4(module="reference.utils.maths"):
     """SURVEY App. C-1 minimal repair of Integrator.integrate(type='rk4') as a runtime patch
     of the imported reference (nothing written to /root/reference).  (i) wind passed to each
     stage, (ii) `d_* @ ks` restated as explicit elementwise weighted sums, (iii) the weighted
     d_ori_vel returned.  Fixtures produced with it are labelled repaired-oracle."""
-    import reference.utils.maths as M
+    import importlib
+    M = importlib.import_module(module)     # "VisFly.utils.maths" when the env layer was imported through the stubs
     Integrator = M.Integrator
+    if getattr(Integrator, "_vf_repaired", False):
+        return
+    Integrator._vf_repaired = True
     orig = Integrator.integrate
 
     def integrate(pos, ori, vel, ori_vel, acc, tau, J, J_inv, dt, wind=th.zeros([3, 1]), type="euler"):
@@ -490,6 +494,8 @@ BPTT_CASES = {
     "bptt_hover_nodelay": ("hover", dict(ENV_DYN, ctrl_delay=False, comm_delay=0.0), dict(max_episode_steps=1000),
                            [-1 / 3, 0, 0, 0], 0.3, 8),
     "bptt_racing_thrust": ("racing", RACING_DYN, dict(max_episode_steps=1000), [-0.8333] * 4, 0.08, 12),
+    # repaired RK4: stages chained through the (q, omega) derivatives, acc / tau frozen over the sub-step
+    "bptt_hover_rk4": ("hover", dict(ENV_DYN, integrator="rk4"), dict(max_episode_steps=1000), [-1 / 3, 0, 0, 0], 0.3, 12),
     # NavigationEnv reward (progress, view angle through acos, obstacle terms, success bonus): close target so that
     # successes (bonus with a velocity gradient) and their resets fall inside the horizon
     "bptt_nav_bodyrate": ("nav", ENV_DYN, dict(max_episode_steps=1000, target=[1.6, 0., 1.5], random_kwargs={"state_generator": {
@@ -505,6 +511,8 @@ def gen_bptt(name, N=64, seed=42):
     Dynamics.step + reward; BPTT.py:107-134), loss = sum_t <Wr[t], reward_t> + <Wo[t], obs_t>."""
     HoverEnvShim, NavigationEnv, RacingEnv = import_envs()
     kind, dkw, kw, hover, scale, H = BPTT_CASES[name]
+    if dkw.get("integrator") == "rk4":
+        repair_rk4("VisFly.utils.maths")
     use_cr_sqrt(True)
     cls = {"hover": HoverEnvShim, "racing": RacingEnv, "nav": NavigationEnv}[kind]
     kw = dict(kw)
@@ -544,7 +552,7 @@ def gen_bptt(name, N=64, seed=42):
             "done": np.stack(dones), "reward": np.stack(rewards),
             "ev_step": np.asarray(ev_step, np.int32), "ev_agent": np.asarray(ev_agent, np.int32),
             "ev_fs": np.stack(ev_fs) if ev_fs else np.zeros((0, 22), np.float32),
-            "dyn_kw": np.asarray(repr(dkw)), "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle"),
+            "dyn_kw": np.asarray(repr(dkw)), "label": np.asarray("repaired-oracle" if kind == "racing" or dkw.get("integrator") == "rk4" else "cr-sqrt-oracle"),
             "target": f32(env.target[0]) if kind != "racing" else np.zeros(3, np.float32),
             "spawn": np.asarray(repr(kw.get("random_kwargs", "default")))}
     if kind == "racing":

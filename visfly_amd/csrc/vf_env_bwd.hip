@@ -70,7 +70,27 @@ __device__ __forceinline__ void rotate_bwd(const Quat& q, const float* x, const 
 
 constexpr int kSave = 14;  // per sub-step: q(4) v(3) w(3) wm(4)
 
-template <int KIND, int ACT, bool CTRL_DELAY>
+// adjoint of (dq, dw) = derivs(q, w, tau)  (utils/maths.py:311,314): dq = 0.5 q (0,w), dw = Jinv (tau - w x (J w))
+__device__ __forceinline__ void derivs_bwd(const vf_dyn_cfg& c, const Quat& q, const float* w, const Quat& ldq, const float* ldw,
+                                           Quat& lq, float* lw, float* ltau)
+{
+    float lr[3] = {0, 0, 0};
+    mat3T_acc(c.Jinv, ldw, lr);
+    const float lc[3] = {-lr[0], -lr[1], -lr[2]};
+    float Jw[3], t0[3], t1[3];
+    mat3(c.J, w[0], w[1], w[2], Jw);
+    cross3(Jw, lc, t0);        // lam_w += (Jw) x lc
+    cross3(lc, w, t1);         // lam_(Jw) = lc x w
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ltau[k] += lr[k]; lw[k] += t0[k]; }
+    mat3T_acc(c.J, t1, lw);
+    const Quat L = qscale(ldq, 0.5f), W{0.0f, w[0], w[1], w[2]};
+    qacc(lq, qmul(L, qconj(W)));
+    const Quat lW = qmul(qconj(q), L);
+    lw[0] += lW.x; lw[1] += lW.y; lw[2] += lW.z;
+}
+
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
 __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg c, const vf_env_cfg e, const BwdArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [S*kSave][kBlock]
@@ -160,15 +180,20 @@ __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg c, con
         const Quat uq{0.0f, u[0], u[1], u[2]};
         const Quat ra = qmul(qmul(s.q, uq), qconj(s.q));
         s.acc[0] = ra.x / c.m; s.acc[1] = ra.y / c.m; s.acc[2] = ra.z / c.m + c.g_z;
-        float dq[4], dw[3];
-        derivs(c, s.q, s.w, ft + 1, dq, dw);
+        if constexpr (INTEG == VF_INT_EULER) {
+            float dq[4], dw[3];
+            derivs(c, s.q, s.w, ft + 1, dq, dw);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s.p[k] += (s.v[k] + c.wind[k]) * dt;
-        s.q.w += dq[0] * dt; s.q.x += dq[1] * dt; s.q.y += dq[2] * dt; s.q.z += dq[3] * dt;
+            for (int k = 0; k < 3; ++k) s.p[k] += (s.v[k] + c.wind[k]) * dt;
+            s.q.w += dq[0] * dt; s.q.x += dq[1] * dt; s.q.y += dq[2] * dt; s.q.z += dq[3] * dt;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { s.v[k] += s.acc[k] * dt; s.w[k] += dw[k] * dt; }
-        const float nn = sqrtf(((s.q.w * s.q.w + s.q.x * s.q.x) + s.q.y * s.q.y) + s.q.z * s.q.z);
-        s.q = qscale(s.q, 1.0f / nn);
+            for (int k = 0; k < 3; ++k) { s.v[k] += s.acc[k] * dt; s.w[k] += dw[k] * dt; }
+            const float nn = sqrtf(((s.q.w * s.q.w + s.q.x * s.q.x) + s.q.y * s.q.y) + s.q.z * s.q.z);
+            s.q = qscale(s.q, 1.0f / nn);
+        } else {   // repaired RK4: the forward kernels' own sub-step functions
+            trans_substep<VF_INT_RK4>(c, s.q, ft[0], kl, kq, s.p, s.v, s.acc);
+            rot_substep<VF_INT_RK4>(c, ft + 1, s.q, s.w, s.aa);
+        }
     }
     // pre-clamp values decide the clamp masks; clamped values are the step's outputs
     const float pm[3] = {in_closed(s.p[0], -c.pos_xy_lim, c.pos_xy_lim), in_closed(s.p[1], -c.pos_xy_lim, c.pos_xy_lim),
@@ -343,45 +368,86 @@ __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg c, con
         float u[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) u[k] = (k == 2 ? ft[0] : 0.0f) - (kl[k] * vbv[k] + (kq[k] * vbv[k]) * fabsf(vbv[k]));
-        float dq[4], dw[3];
-        derivs(c, q, w, ft + 1, dq, dw);
-        const Quat qt{q.w + dq[0] * dt, q.x + dq[1] * dt, q.y + dq[2] * dt, q.z + dq[3] * dt};
-        const float nn = sqrtf(((qt.w * qt.w + qt.x * qt.x) + qt.y * qt.y) + qt.z * qt.z);
-        const Quat qn = qscale(qt, 1.0f / nn);
-
-        // normalise: q' = qt / |qt|
-        const float dotl = qn.w * lq.w + qn.x * lq.x + qn.y * lq.y + qn.z * lq.z;
-        const Quat lqt{(lq.w - qn.w * dotl) / nn, (lq.x - qn.x * dotl) / nn, (lq.y - qn.y * dotl) / nn,
-                       (lq.z - qn.z * dotl) / nn};
-        // Euler update
-        float ldw[3], lacc[3];
+        float lacc[3], ltau[3] = {0, 0, 0};
+        Quat lq_in;
+        if constexpr (INTEG == VF_INT_EULER) {
+            float dq[4], dw[3];
+            derivs(c, q, w, ft + 1, dq, dw);
+            const Quat qt{q.w + dq[0] * dt, q.x + dq[1] * dt, q.y + dq[2] * dt, q.z + dq[3] * dt};
+            const float nn = sqrtf(((qt.w * qt.w + qt.x * qt.x) + qt.y * qt.y) + qt.z * qt.z);
+            const Quat qn = qscale(qt, 1.0f / nn);
+            // normalise: q' = qt / |qt|
+            const float dotl = qn.w * lq.w + qn.x * lq.x + qn.y * lq.y + qn.z * lq.z;
+            const Quat lqt{(lq.w - qn.w * dotl) / nn, (lq.x - qn.x * dotl) / nn, (lq.y - qn.y * dotl) / nn,
+                           (lq.z - qn.z * dotl) / nn};
+            // Euler update
+            float ldw[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            ldw[k] = lw[k] * dt + ldw_in[k];
-            lacc[k] = lv[k] * dt;
-            lv[k] += lp[k] * dt;   // p' = p + (v + wind) dt ; lp, lw, lv carry through (identity part)
-            ldw_in[k] = 0.0f;
-        }
-        Quat lq_in = lqt;          // q~ = q + dq dt
-        const Quat ldq = qscale(lqt, dt);
-        // dw = Jinv (tau - w x (J w))
-        float lr[3] = {0, 0, 0};
-        mat3T_acc(c.Jinv, ldw, lr);
-        float ltau[3] = {lr[0], lr[1], lr[2]};
-        const float lc[3] = {-lr[0], -lr[1], -lr[2]};
-        float Jw[3], t0[3], t1[3];
-        mat3(c.J, w[0], w[1], w[2], Jw);
-        cross3(Jw, lc, t0);        // lam_w += (Jw) x lc
-        cross3(lc, w, t1);         // lam_(Jw) = lc x w
+            for (int k = 0; k < 3; ++k) {
+                ldw[k] = lw[k] * dt + ldw_in[k];
+                lacc[k] = lv[k] * dt;
+                lv[k] += lp[k] * dt;   // p' = p + (v + wind) dt ; lp, lw, lv carry through (identity part)
+                ldw_in[k] = 0.0f;
+            }
+            lq_in = lqt;               // q~ = q + dq dt
+            derivs_bwd(c, q, w, qscale(lqt, dt), ldw, lq_in, lw, ltau);
+        } else {
+            // RK4 over (q, w) with tau frozen: stage st sees q + dq_{st-1} h dt, w + dw_{st-1} h dt (h = .5, .5, 1);
+            // q~ = q + dt sum ks dq_st, w' = w + dt sum ks dw_st, aa = sum ks dw_st
+            const float ks[4] = {1.0f / 6.0f, 2.0f / 6.0f, 2.0f / 6.0f, 1.0f / 6.0f}, hs[4] = {0.0f, 0.5f, 0.5f, 1.0f};
+            Quat qs[4];
+            float ws[4][3], dq[4], dw[3], sq[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) lw[k] += t0[k];
-        mat3T_acc(c.J, t1, lw);
-        // dq = 0.5 * q * (0, w)
-        {
-            const Quat L = qscale(ldq, 0.5f), W{0.0f, w[0], w[1], w[2]};
-            qacc(lq_in, qmul(L, qconj(W)));
-            const Quat lW = qmul(qconj(q), L);
-            lw[0] += lW.x; lw[1] += lW.y; lw[2] += lW.z;
+            for (int st = 0; st < 4; ++st) {
+                if (st == 0) {
+                    qs[0] = q;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) ws[0][k] = w[k];
+                } else {
+                    const float h = hs[st] * dt;
+                    qs[st] = Quat{q.w + dq[0] * h, q.x + dq[1] * h, q.y + dq[2] * h, q.z + dq[3] * h};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) ws[st][k] = w[k] + dw[k] * h;
+                }
+                derivs(c, qs[st], ws[st], ft + 1, dq, dw);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sq[k] += dq[k] * ks[st];
+            }
+            const Quat qt{q.w + sq[0] * dt, q.x + sq[1] * dt, q.y + sq[2] * dt, q.z + sq[3] * dt};
+            const float nn = sqrtf(((qt.w * qt.w + qt.x * qt.x) + qt.y * qt.y) + qt.z * qt.z);
+            const Quat qn = qscale(qt, 1.0f / nn);
+            const float dotl = qn.w * lq.w + qn.x * lq.x + qn.y * lq.y + qn.z * lq.z;
+            const Quat lqt{(lq.w - qn.w * dotl) / nn, (lq.x - qn.x * dotl) / nn, (lq.y - qn.y * dotl) / nn,
+                           (lq.z - qn.z * dotl) / nn};
+            float lsw[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lsw[k] = lw[k] * dt + ldw_in[k];
+                ldw_in[k] = 0.0f;
+                // translation: p' = p + dt sum ks (v + acc h dt + wind), v' = v + dt sum ks acc  (sum ks = 1, sum ks h = 1/2)
+                lacc[k] = lv[k] * dt + lp[k] * dt * (0.5f * dt);
+                lv[k] += lp[k] * dt;
+            }
+            const Quat lsq = qscale(lqt, dt);
+            lq_in = lqt;
+            Quat ldq_c = qscale(lsq, ks[3]);                 // adjoint of the stage derivative currently being unwound
+            float ldw_c[3] = {lsw[0] * ks[3], lsw[1] * ks[3], lsw[2] * ks[3]};
+#pragma unroll
+            for (int st = 3; st >= 0; --st) {
+                Quat lqc{0, 0, 0, 0};
+                float lwc[3] = {0, 0, 0};
+                derivs_bwd(c, qs[st], ws[st], ldq_c, ldw_c, lqc, lwc, ltau);
+                qacc(lq_in, lqc);                               // every stage state contains q and w once
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lw[k] += lwc[k];
+                if (st > 0) {                                   // ... and the previous stage's derivative times h dt
+                    const float h = hs[st] * dt;
+                    ldq_c = qscale(lsq, ks[st - 1]);
+                    qacc(ldq_c, qscale(lqc, h));
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) ldw_c[k] = lsw[k] * ks[st - 1] + lwc[k] * h;
+                }
+            }
         }
         // acc = rotate(q, u) / m + g
         float lra[3] = {lacc[0] / c.m, lacc[1] / c.m, lacc[2] / c.m}, lu[3] = {0, 0, 0};
@@ -481,12 +547,16 @@ using BwdKernel = void (*)(const vf_dyn_cfg, const vf_env_cfg, const vf::BwdArgs
 template <int KIND>
 BwdKernel pick_bwd(const vf_dyn_cfg& c)
 {
-    const int key = (c.action_type == VF_ACT_BODYRATE ? 2 : 0) | (c.ctrl_delay ? 1 : 0);
+    const int key = (c.integrator == VF_INT_RK4 ? 4 : 0) | (c.action_type == VF_ACT_BODYRATE ? 2 : 0) | (c.ctrl_delay ? 1 : 0);
     switch (key) {
-    case 0: return vf::k_env_step_bwd<KIND, VF_ACT_THRUST, false>;
-    case 1: return vf::k_env_step_bwd<KIND, VF_ACT_THRUST, true>;
-    case 2: return vf::k_env_step_bwd<KIND, VF_ACT_BODYRATE, false>;
-    default: return vf::k_env_step_bwd<KIND, VF_ACT_BODYRATE, true>;
+    case 0: return vf::k_env_step_bwd<KIND, VF_ACT_THRUST, VF_INT_EULER, false>;
+    case 1: return vf::k_env_step_bwd<KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    case 2: return vf::k_env_step_bwd<KIND, VF_ACT_BODYRATE, VF_INT_EULER, false>;
+    case 3: return vf::k_env_step_bwd<KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    case 4: return vf::k_env_step_bwd<KIND, VF_ACT_THRUST, VF_INT_RK4, false>;
+    case 5: return vf::k_env_step_bwd<KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
+    case 6: return vf::k_env_step_bwd<KIND, VF_ACT_BODYRATE, VF_INT_RK4, false>;
+    default: return vf::k_env_step_bwd<KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
     }
 }
 
@@ -498,8 +568,8 @@ extern "C" int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* a, vf_stream_t 
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: null argument");
     if (h->dyn.cfg.action_type != VF_ACT_THRUST && h->dyn.cfg.action_type != VF_ACT_BODYRATE)
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: the adjoint covers the thrust and bodyrate action types only");
-    if (h->dyn.cfg.integrator != VF_INT_EULER)
-        return vf::fail(VF_EINVAL, "vf_env_step_bwd: only the Euler integrator has an adjoint (RK4: not yet)");
+    if (h->dyn.cfg.integrator != VF_INT_EULER && h->dyn.cfg.integrator != VF_INT_RK4)
+        return vf::fail(VF_EINVAL, "vf_env_step_bwd: unknown integrator");
     if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: the HoverEnv2 / NavigationEnv2 observation and reward variants have no adjoint");
     const int S = h->dyn.cfg.interval_steps;
