@@ -327,3 +327,34 @@ def test_ppo_training_is_bitwise_reproducible():
         ppo.learn(16 * 1024 * 3)
         flats.append(ppo.policy.flat.clone())
     assert torch.equal(flats[0], flats[1])
+
+
+def test_ppo_checkpoint_round_trip_and_reference_yaml_kwargs(tmp_path):
+    """the `algorithm:` block of the reference's YAMLs passes as **kwargs; save -> load restores the
+    policy, the Adam moments and the step count, and the loaded trainer acts identically"""
+    from visfly_amd.envs import NavigationEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    alg = dict(policy="CustomMultiInputPolicy", verbose=1, device="cuda", gamma=0.99, n_steps=16, ent_coef=0.0,
+               learning_rate=5e-5, vf_coef=0.5, max_grad_norm=0.5, batch_size=4096, gae_lambda=0.95, n_epochs=2, clip_range=0.2,
+               policy_kwargs=dict(ortho_init=False, features_extractor_class="StateTargetExtractor",
+                                  features_extractor_kwargs=dict(net_arch=dict(state=dict(layer=[128, 64]), target=dict(layer=[128, 64]))),
+                                  net_arch=dict(pi=[64, 64], vf=[64, 64]), activation_fn="ReLU",
+                                  optimizer_kwargs=dict(weight_decay=2e-5)))
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1.0, 0.0, 1.5], "half": [0.0, 2.0, 1.0]}}]}}
+
+    def make():
+        return NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64,
+                             tensor_output=True, random_kwargs=spawn)
+    ppo = PPO(make(), seed=3, **alg)
+    assert ppo.weight_decay == 2e-5 and ppo.policy.spec["extractor"] == {"state": [128, 64], "target": [128, 64]}
+    ppo.learn(16 * 1024 * 2)
+    path = ppo.save(str(tmp_path / "PPO_std_1"))
+    new = PPO.load(path, make(), seed=3, **alg)
+    assert torch.equal(new.policy.flat, ppo.policy.flat)
+    assert torch.equal(new.exp_avg, ppo.exp_avg) and torch.equal(new.exp_avg_sq, ppo.exp_avg_sq)
+    assert new._opt_step == ppo._opt_step and new.num_timesteps == ppo.num_timesteps
+    obs = ppo.env.get_observation()
+    a0 = ppo.policy.forward({k: obs[k] for k in ppo.obs_keys}, save_activations=False)
+    a1 = new.policy.forward({k: obs[k] for k in ppo.obs_keys}, save_activations=False)
+    assert torch.equal(a0[0], a1[0]) and torch.equal(a0[1], a1[1])

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import torch as th
 
-from . import _lib, parallel
+from . import _lib, checkpoint, parallel
 from .ppo import MlpPolicy, _ptr
 
 
@@ -73,7 +73,8 @@ class BPTT:
             env.reset()
         obs = env.get_observation()
         self.obs_keys = [k for k in obs.keys() if k in ("state", "target")]
-        pk = dict(policy_kwargs or {})
+        pk = checkpoint.policy_kwargs_from_reference(policy_kwargs, self.obs_keys)
+        self.weight_decay = pk.get("weight_decay", self.weight_decay)
         self.policy = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},
                                 pk.get("extractor", {k: [128, 64] for k in self.obs_keys}), pk.get("pi", [64, 64]),
                                 pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed)
@@ -169,6 +170,16 @@ class BPTT:
         env.detach()                                          # :134
         self.num_timesteps += self.H * N * self.world
         return loss.detach() * self.world
+
+    def save(self, path: str):
+        return checkpoint.save(self, path)
+
+    def set_parameters(self, path: str, load_optimizer: bool = True):
+        return checkpoint.load_into(self, path, load_optimizer)
+
+    @classmethod
+    def load(cls, path: str, env, **kwargs):
+        return checkpoint.load_into(cls(env, **kwargs), path)
 
     def learn(self, total_timesteps: int, log_interval: Optional[int] = None):
         t0, start, it = time.time(), self.num_timesteps, 0

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch as th
 
-from . import _lib, parallel
+from . import _lib, checkpoint, parallel
 
 
 def _ptr(t, off=0):
@@ -462,7 +462,11 @@ class PPO:
     def __init__(self, env, n_steps=256, batch_size=25600, n_epochs=5, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
                  ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, learning_rate=1e-4, weight_decay=1e-5,
                  normalize_advantage=True, policy_kwargs: Optional[dict] = None, seed=0, adam_eps=1e-8,
-                 betas=(0.9, 0.999), target_kl=None):
+                 betas=(0.9, 0.999), target_kl=None, policy=None, verbose=0, device=None):
+        # `policy`, `verbose`, `device`: accepted so that the `algorithm:` block of the reference's YAMLs can be passed
+        # as **kwargs (exps/examples/alg_cfgs/*/PPO.yaml); the policy is always the MFMA MlpPolicy on the env's device
+        if policy not in (None, "CustomMultiInputPolicy", "MultiInputPolicy", "MlpPolicy"):
+            raise NotImplementedError(f"policy {policy}: vector-observation actor-critic policies only")
         self.env = env
         env.tensor_output, env.requires_grad = True, False        # PPO.py:80-82 forces the non-grad path
         self.device = env.device
@@ -478,7 +482,8 @@ class PPO:
         obs = env.get_observation()
         self.obs_keys = [k for k in obs.keys() if k in ("state", "target")]
         obs_dims = {k: obs[k].shape[1] for k in self.obs_keys}
-        pk = dict(policy_kwargs or {})
+        pk = checkpoint.policy_kwargs_from_reference(policy_kwargs, self.obs_keys)
+        self.weight_decay = pk.get("weight_decay", self.weight_decay)   # optimizer_kwargs.weight_decay of the YAMLs
         extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
         self.policy = MlpPolicy(obs_dims, extractor, pk.get("pi", [64, 64]), pk.get("vf", [64, 64]), self.device,
                                 log_std_init=pk.get("log_std_init", 0.0), seed=seed)
@@ -502,6 +507,19 @@ class PPO:
 
     def _stream(self):
         return _lib.current_stream(self.device)
+
+    def save(self, path: str):
+        """zip archive in the layout of SB3's BaseAlgorithm.save (PPO.py:418-430): see checkpoint.py"""
+        return checkpoint.save(self, path)
+
+    def set_parameters(self, path: str, load_optimizer: bool = True):
+        return checkpoint.load_into(self, path, load_optimizer)
+
+    @classmethod
+    def load(cls, path: str, env, **kwargs):
+        """PPO.py:432-572: re-create the trainer on `env`, then load policy (and optimiser) state; also reads
+        archives written by the reference (policy.pth with the reference's parameter names)"""
+        return checkpoint.load_into(cls(env, **kwargs), path)
 
     # ------------------------------------------------------------------------------------------
     def _act(self, obs, deterministic=False):
