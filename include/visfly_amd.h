@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 2   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward */
+#define VF_ABI_VERSION 3   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
+                              3: register-chain weight image (vf_mlp_layer.wr_off, three-column pack_map) */
 
 typedef void* vf_stream_t;
 
@@ -330,6 +331,8 @@ typedef struct vf_mlp_layer {
     int32_t save_ld;             /* row stride of `save`, 0 if none */
     int32_t wt_off;              /* offset of this layer's packed forward weights (transposed, zero padded), see below */
     int32_t wb_off;              /* offset of this layer's packed data-gradient weights (zero padded), see below */
+    int32_t wr_off;              /* offset of this layer's register-chain image (multiple of 4), see below */
+    int32_t pad1;
     float* save;                 /* optional global copy of the layer output (training keeps activations) */
 } vf_mlp_layer;
 typedef struct vf_mlp_desc {
@@ -343,9 +346,18 @@ typedef struct vf_mlp_desc {
 /* The forward reads its MFMA B operand straight from global memory: `packed` holds, per layer at float offset
  * wt_off, Wt[k][n] = W[n][k] for k < round16(K), n < round32(No), zero padded (so neither the kernel nor
  * the L1/L2-resident loads need guards); the data gradient of vf_mlp_backward reads, at wb_off,
- * Wb[n][k] = W[n][k] for n < round16(No), k < round32(K).  vf_mlp_pack_weights refreshes both from
- * `params` (call it after every optimiser step); vf_mlp_packed_floats = size of the packed buffer the
- * layer table implies. */
+ * Wb[n][k] = W[n][k] for n < round16(No), k < round32(K).
+ * Register-chain image (wr_off): when the layer table is one of the network classes the register-chained forward is
+ * instantiated for (reference default policies: one or two [128, 64] extractor branches, [64, 64] trunks), a wave64
+ * carries 32 rows through the whole network with the activations in MFMA accumulator registers; its A operand is
+ * read as one float4 per lane from blocks of 256 floats: block (a, g) of a layer with G = Kp / 8 reduction groups
+ * (Kp = round8(K) if the layer reads an observation, else round32(K)) sits at wr_off + (a G + g) 256, and lane l,
+ * word j of it holds W[32 a + (l & 31)][k], k = 8 g + 2 j + (l >> 5) for observation layers,
+ * k = 32 (g / 4) + 8 (g % 4) + 4 (l >> 5) + j otherwise (the order in which an accumulator lane holds its row's
+ * features), zero padded; ceil(No / 32) G 256 floats per layer.
+ * vf_mlp_pack_weights refreshes all three images from `params` (call it after every optimiser step, or let
+ * vf_adam_step do it through vf_adam_cfg.pack_map); vf_mlp_packed_floats = size of the packed buffer the layer
+ * table implies. */
 int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc);
 int vf_mlp_pack_weights(const vf_mlp_desc* desc, const float* params, float* packed, vf_stream_t stream);
 int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
@@ -426,8 +438,9 @@ typedef struct vf_adam_cfg {
     float max_grad_norm;    /* <= 0: no clipping */
     int32_t step;           /* 1-based step count AFTER this update */
     int32_t pad0;
-    /* optional: refresh the packed MLP weights (vf_mlp_pack_weights layout) in the same launch.  pack_map holds two
-     * int32 per parameter: the float offsets of its copies in `packed` (forward / data-gradient image), -1 = none */
+    /* optional: refresh the packed MLP weights (vf_mlp_pack_weights layout) in the same launch.  pack_map holds three
+     * int32 per parameter: the float offsets of its copies in `packed` (forward / data-gradient / register-chain
+     * image), -1 = none */
     const int32_t* pack_map;
     float* packed;
 } vf_adam_cfg;

@@ -69,7 +69,7 @@ class DynCfg(C.Structure):
         return c
 
 
-ABI_VERSION = 2          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
+ABI_VERSION = 3          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
 MAX_GATES, MAX_SPAWN = 8, 4
 
 
@@ -118,7 +118,8 @@ class MlpLayer(C.Structure):
     """mirror of vf_mlp_layer"""
     _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("relu", C.c_int32), ("src", C.c_int32), ("src_col", C.c_int32),
                 ("dst", C.c_int32), ("dst_col", C.c_int32), ("w_off", C.c_int32), ("b_off", C.c_int32),
-                ("save_ld", C.c_int32), ("wt_off", C.c_int32), ("wb_off", C.c_int32), ("save", C.c_void_p)]
+                ("save_ld", C.c_int32), ("wt_off", C.c_int32), ("wb_off", C.c_int32), ("wr_off", C.c_int32),
+                ("pad1", C.c_int32), ("save", C.c_void_p)]
 
 
 class MlpDesc(C.Structure):

@@ -50,4 +50,8 @@ inline bool use_split(int agents_padded, const vf_dyn_cfg& cfg)
     return agents_padded <= 32768;   // measured on MI355X: 32768 agents 9.4 us (split) vs 11.3 us; 65536: 13.3 vs 12.5
 }
 
+// vf_mlp_chain.hip: register-chained forward for the reference-default network shapes (1: launched, 0: no match)
+int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
+                          float* out0, float* out1, int M, hipStream_t st);
+
 }  // namespace vf

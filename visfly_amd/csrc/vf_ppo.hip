@@ -558,6 +558,15 @@ __global__ __launch_bounds__(kBlock) void k_mlp_pack_weights(const vf_mlp_desc d
         const int n = idx / K32, k = idx - n * K32;
         packed[L.wb_off + idx] = (k < L.K && n < L.No) ? params[L.w_off + n * L.K + k] : 0.0f;
     }
+    // register-chain image (vf_mlp_chain.hip): block (a, g) = A fragments of four reduction steps, float4 per lane
+    const bool nat = L.src < 4;                       // reads an observation: natural k order
+    const int G = nat ? (L.K + 7) >> 3 : ((L.K + 31) >> 5) * 4, NT = (L.No + 31) >> 5;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < NT * G * 256; idx += gridDim.x * kBlock) {
+        const int j = idx & 3, l = (idx >> 2) & 63, blk = idx >> 8, a = blk / G, g = blk - a * G;
+        const int n = 32 * a + (l & 31), h = l >> 5;
+        const int k = nat ? 8 * g + 2 * j + h : 32 * (g >> 2) + 8 * (g & 3) + 4 * h + j;
+        packed[L.wr_off + idx] = (k < L.K && n < L.No) ? params[L.w_off + n * L.K + k] : 0.0f;
+    }
 }
 
 __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, const float* __restrict__ params,
@@ -859,7 +868,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_mlp_backward(const vf_mlp_bwd_d
                     float old[16];
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg)
-                        old[reg] = dxb[(unsigned)(o + max(min((reg & 3) + 8 * (reg >> 2), rmax), 0) * L.ld_dx)];
+                        old[reg] = dxb[(unsigned)(min(rb + (reg & 3) + 8 * (reg >> 2), M - 1 - m0) * L.ld_dx + n)];   // rows past M: clamped, never stored
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) a[reg] += old[reg];
                 }
@@ -1274,9 +1283,10 @@ __global__ __launch_bounds__(kBlock) void k_adam(float* __restrict__ p, const fl
         const float pn = pi - step * (mi / denom);
         p[i] = pn;
         if (c.pack_map) {   // keep the packed MFMA images of the weights current (vf_mlp_pack_weights layout)
-            const int a = c.pack_map[2 * i], b = c.pack_map[2 * i + 1];
+            const int a = c.pack_map[3 * i], b = c.pack_map[3 * i + 1], r = c.pack_map[3 * i + 2];
             if (a >= 0) c.packed[a] = pn;
             if (b >= 0) c.packed[b] = pn;
+            if (r >= 0) c.packed[r] = pn;
         }
     }
 }
@@ -1462,8 +1472,11 @@ int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc)
         const vf_mlp_layer& L = desc->layer[i];
         const int64_t end = L.wt_off + (int64_t)((L.K + 15) & ~15) * ((L.No + 31) & ~31);
         const int64_t endb = L.wb_off + (int64_t)((L.No + 15) & ~15) * ((L.K + 31) & ~31);
+        const int64_t G = L.src < 4 ? (L.K + 7) >> 3 : ((L.K + 31) >> 5) * 4;
+        const int64_t endr = L.wr_off + (int64_t)((L.No + 31) >> 5) * G * 256;
         n = end > n ? end : n;
         n = endb > n ? endb : n;
+        n = endr > n ? endr : n;
     }
     return n;
 }
@@ -1489,6 +1502,8 @@ int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* pa
         if (L.K < 1 || L.K > 128 || L.No < 1 || L.No > 128) return vf::fail(VF_EINVAL, "vf_mlp_forward: layer %d: K, No must be 1..128", i);
         if (L.dst >= VF_MLP_OUT0 && !(L.dst == VF_MLP_OUT0 ? out0 : out1)) return vf::fail(VF_EINVAL, "vf_mlp_forward: missing output %d", L.dst);
     }
+    // reference-default network shapes: activations chained through MFMA accumulator registers (vf_mlp_chain.hip)
+    if (int rc = vf::mlp_forward_chain_try(desc, params, packed, in0, in1, out0, out1, M, vf::as_stream(stream))) return rc < 0 ? rc : VF_OK;
     const size_t lds = (size_t)desc->lds_floats * sizeof(float);
     if (lds > 160 * 1024) return vf::fail(VF_EINVAL, "vf_mlp_forward: LDS plan needs %zu bytes (> 160 KiB)", lds);
     if (int rc = allow_lds(vf::k_mlp_forward, lds)) return rc;

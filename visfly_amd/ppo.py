@@ -169,13 +169,20 @@ class MlpPolicy:
             return None
         if top * 4 > 160 * 1024:
             return None
-        wt_off, wb_off, o = [], [], 0
-        for ly in self.layers:               # packed weights: forward [round16(K)][round32(No)], data gradient [round16(No)][round32(K)]
-            wt_off.append(o)
+        wt_off, wb_off, wr_off, o = [], [], [], 0
+        for ly in self.layers:               # packed weights: forward [round16(K)][round32(No)], data gradient [round16(No)][round32(K)],
+            wt_off.append(o)                 # register-chain image: ceil(No / 32) * G blocks of 256 floats (include/visfly_amd.h)
             o += ((ly.K + 15) & ~15) * ((ly.No + 31) & ~31)
             wb_off.append(o)
             o += ((ly.No + 15) & ~15) * ((ly.K + 31) & ~31)
-        return dict(ids=ids, off=off, stride=stride, total=top, wt_off=wt_off, wb_off=wb_off, packed_floats=o)
+            wr_off.append(o)
+            o += ((ly.No + 31) >> 5) * self._chain_groups(ly) * 256
+        return dict(ids=ids, off=off, stride=stride, total=top, wt_off=wt_off, wb_off=wb_off, wr_off=wr_off, packed_floats=o)
+
+    @staticmethod
+    def _chain_groups(ly):
+        """reduction groups (of 8) of a layer's register-chain image: observation layers keep the natural k order"""
+        return (ly.K + 7) >> 3 if ly.first else ((ly.K + 31) >> 5) * 4
 
     def _fused_desc(self, b, save: bool):
         p = self._plan
@@ -192,6 +199,7 @@ class MlpPolicy:
             L.src, L.src_col = p["ids"][ly.src], ly.sc
             L.dst = {"mean": _lib.MLP_OUT0, "value": _lib.MLP_OUT1}.get(ly.dst, p["ids"].get(ly.dst, 0))
             L.dst_col, L.w_off, L.b_off, L.wt_off, L.wb_off = ly.dc, ly.w_off, ly.b_off, p["wt_off"][li], p["wb_off"][li]
+            L.wr_off = p["wr_off"][li]
             if save and b is not None and ly.dst not in ("mean", "value"):
                 L.save, L.save_ld = b[ly.dst].data_ptr(), b[ly.dst].shape[1]
         return d
@@ -206,18 +214,24 @@ class MlpPolicy:
             self._packed_stamp = self._stamp
 
     def pack_map(self):
-        """-> (int32 [n_params, 2] device tensor, packed buffer): for every parameter the float offsets of its copies in
+        """-> (int32 [n_params, 3] device tensor, packed buffer): for every parameter the float offsets of its copies in
         the packed forward / data-gradient weight images (-1: biases, log_std), for vf_adam_cfg.pack_map"""
         if self._plan is None:
             return None, None
         if self._pack_map is None:
             import numpy as np
-            m = np.full((self.n_params, 2), -1, np.int32)
+            m = np.full((self.n_params, 3), -1, np.int32)
             for li, ly in enumerate(self.layers):
                 n, k = np.meshgrid(np.arange(ly.No), np.arange(ly.K), indexing="ij")
                 flat = ly.w_off + n * ly.K + k
                 m[flat, 0] = self._plan["wt_off"][li] + k * ((ly.No + 31) & ~31) + n
                 m[flat, 1] = self._plan["wb_off"][li] + n * ((ly.K + 31) & ~31) + k
+                G, a, i = self._chain_groups(ly), n >> 5, n & 31
+                if ly.first:          # k = 8 g + 2 j + h
+                    g, j, h = k >> 3, (k & 7) >> 1, k & 1
+                else:                 # k = 32 (g / 4) + 8 (g % 4) + 4 h + j
+                    g, h, j = (k >> 5) * 4 + ((k & 31) >> 3), (k & 7) >> 2, k & 3
+                m[flat, 2] = self._plan["wr_off"][li] + (((a * G + g) * 64 + h * 32 + i) << 2) + j
             self._pack_map = th.from_numpy(m).to(self.device)
             self._stamp += 1          # force one full pack (zero pads) before the incremental refreshes
             self._pack()
