@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 #define VF_ABI_VERSION 3   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
-                              3: register-chain weight image (vf_mlp_layer.wr_off, three-column pack_map) */
+                              3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
+                                 vf_mlp_backward_partial_floats */
 
 typedef void* vf_stream_t;
 
@@ -332,7 +333,7 @@ typedef struct vf_mlp_layer {
     int32_t wt_off;              /* offset of this layer's packed forward weights (transposed, zero padded), see below */
     int32_t wb_off;              /* offset of this layer's packed data-gradient weights (zero padded), see below */
     int32_t wr_off;              /* offset of this layer's register-chain image (multiple of 4), see below */
-    int32_t pad1;
+    int32_t wq_off;              /* offset of this layer's reverse-chain (data-gradient) image, see below */
     float* save;                 /* optional global copy of the layer output (training keeps activations) */
 } vf_mlp_layer;
 typedef struct vf_mlp_desc {
@@ -355,7 +356,10 @@ typedef struct vf_mlp_desc {
  * word j of it holds W[32 a + (l & 31)][k], k = 8 g + 2 j + (l >> 5) for observation layers,
  * k = 32 (g / 4) + 8 (g % 4) + 4 (l >> 5) + j otherwise (the order in which an accumulator lane holds its row's
  * features), zero padded; ceil(No / 32) G 256 floats per layer.
- * vf_mlp_pack_weights refreshes all three images from `params` (call it after every optimiser step, or let
+ * Reverse-chain image (wq_off): the same construction for the data gradient dA^T = W^T dZ^T: block (a, g),
+ * a < ceil(K / 32), g < G = ceil(No / 8), at wq_off + (a G + g) 256; lane l, word j holds
+ * W[32 (g / 4) + 8 (g % 4) + 4 (l >> 5) + j][32 a + (l & 31)], zero padded.
+ * vf_mlp_pack_weights refreshes all four images from `params` (call it after every optimiser step, or let
  * vf_adam_step do it through vf_adam_cfg.pack_map); vf_mlp_packed_floats = size of the packed buffer the layer
  * table implies. */
 int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc);
@@ -372,12 +376,18 @@ int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* pa
  *   dY (M, ld_dy) upstream gradient, Y (M, ld_y) saved layer output for the ReLU mask or NULL,
  *   X (M, ld_x) saved layer input, dX (M, ld_dx) data gradient or NULL; need_dx: 0 none, 1 store,
  *   2 add into dX.  Column offsets are folded into the pointers.
- *   partials: vf_mlp_backward_blocks(M) * n_fold floats.  accumulate != 0: grad += fold. */
+ *   partials: vf_mlp_backward_partial_floats(desc, M) floats.  accumulate != 0: grad += fold.
+ * For the reference-default network classes (see the register-chain images above) the same result is produced by
+ * three launches instead: reverse chain in registers (data gradients, one wave per 32 rows), weight / bias gradients
+ * with both MFMA operands read straight from the saved activations and masked gradients, table-driven fold; the
+ * intermediate dX buffers then hold the ReLU-masked gradients. */
 typedef struct vf_mlp_bwd_layer {
     int32_t K, No;
     int32_t need_dx;
     int32_t ld_dy, ld_y, ld_x, ld_dx;
     int32_t wb_off;              /* packed data-gradient weights of this layer (vf_mlp_layer.wb_off) */
+    int32_t wq_off;              /* reverse-chain image of this layer (vf_mlp_layer.wq_off) */
+    int32_t pad0;
     int64_t w_off, b_off;        /* offsets into the flat parameter buffer == into a partial row */
     const float* dY;
     const float* Y;
@@ -390,6 +400,9 @@ typedef struct vf_mlp_bwd_desc {
     vf_mlp_bwd_layer layer[VF_MLP_MAX_LAYERS];
 } vf_mlp_bwd_desc;
 int32_t vf_mlp_backward_blocks(int32_t M);
+/* floats `partials` must hold for this layer table and M (covers both the block-tile kernel and, for the network
+ * classes it is instantiated for, the register-chained reverse sweep + row-slab weight-gradient kernel) */
+int64_t vf_mlp_backward_partial_floats(const vf_mlp_bwd_desc* desc, int32_t M);
 int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* partials, float* grad, int32_t M,
                     int32_t accumulate, vf_stream_t stream);
 
@@ -438,9 +451,9 @@ typedef struct vf_adam_cfg {
     float max_grad_norm;    /* <= 0: no clipping */
     int32_t step;           /* 1-based step count AFTER this update */
     int32_t pad0;
-    /* optional: refresh the packed MLP weights (vf_mlp_pack_weights layout) in the same launch.  pack_map holds three
-     * int32 per parameter: the float offsets of its copies in `packed` (forward / data-gradient / register-chain
-     * image), -1 = none */
+    /* optional: refresh the packed MLP weights (vf_mlp_pack_weights layout) in the same launch.  pack_map holds four
+     * int32 per parameter: the float offsets of its copies in `packed` (forward / data-gradient / register-chain /
+     * reverse-chain image), -1 = none */
     const int32_t* pack_map;
     float* packed;
 } vf_adam_cfg;

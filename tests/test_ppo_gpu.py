@@ -242,7 +242,10 @@ def test_fused_backward_equals_layerwise_and_torch(M, with_value):
         res[fused] = (pol.grad.clone(), {k: v.clone() for k, v in d_in.items()})
     (g0, in0), (g1, in1) = res[False], res[True]
     for k in in0:
-        assert torch.equal(in0[k], in1[k]), k                   # dLoss/d obs: bit-identical
+        if with_value:      # both trunks + observation gradient: block-tile kernel, same per-row arithmetic as the layer kernels
+            assert torch.equal(in0[k], in1[k]), k
+        else:               # policy trunk + observation gradient: register-chained reverse sweep (other reduction order)
+            assert torch.allclose(in0[k], in1[k], rtol=1e-4, atol=1e-6 * in0[k].abs().max().item()), k
     scale = g0.abs().max().item()
     assert (g0 - g1).abs().max().item() <= 2e-6 * scale
     if not with_value:                                           # the value trunk was skipped: its entries are untouched
@@ -383,3 +386,50 @@ def test_ppo_checkpoint_round_trip_and_reference_yaml_kwargs(tmp_path):
     a0 = ppo.policy.forward({k: obs[k] for k in ppo.obs_keys}, save_activations=False)
     a1 = new.policy.forward({k: obs[k] for k in ppo.obs_keys}, save_activations=False)
     assert torch.equal(a0[0], a1[0]) and torch.equal(a0[1], a1[1])
+
+
+@pytest.mark.parametrize("M", [1, 33, 777, 25600])
+@pytest.mark.parametrize("net,mode", [("nav", "ppo"), ("hover", "ppo"), ("nav", "bptt"), ("hover", "bptt")])
+def test_chain_backward_vs_torch_and_block_tile_kernel(M, net, mode):
+    """reverse chain in registers + row-slab weight gradients (vf_mlp_chain.hip, vf_mlp_wgrad.hip), the two variants the
+    trainers use (PPO update: both trunks, no observation gradient; first-order optimisation: policy trunk + observation
+    gradient), against torch autograd on the same weights and against the layer-by-layer kernels; deterministic"""
+    from visfly_amd.ppo import MlpPolicy
+    dims = {"state": 13, "target": 3} if net == "nav" else {"state": 13}
+    pol = MlpPolicy(dims, {k: [128, 64] for k in dims}, [64, 64], [64, 64], DEV, seed=9)
+    g = torch.Generator(device=DEV).manual_seed(M)
+    obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+    d_mean = torch.randn((M, 4), device=DEV, generator=g) / M
+    d_value = torch.randn(M, device=DEV, generator=g) / M if mode == "ppo" else None
+    ig = mode == "bptt"
+    ref = pol.to_torch().to(DEV)
+    xs = {k: v.clone().requires_grad_(ig) for k, v in obs.items()}
+    m0, v0 = ref(xs)
+    loss = (m0 * d_mean).sum() + ((v0.view(-1) * d_value).sum() if d_value is not None else 0.0) + 0.0 * ref.log_std.sum()
+    loss.backward()
+    for mod in ref.lin:
+        for prm in mod.parameters():
+            if prm.grad is None:
+                prm.grad = torch.zeros_like(prm)
+    gref = ref.flat_grad().to(DEV)
+    res = {}
+    for fused in (True, False, True):
+        pol.fused_backward = fused
+        pol.grad.fill_(0.0)
+        pol.forward(obs)
+        d_in = pol.backward(d_mean, d_value, None, need_input_grad=ig)
+        if fused and fused in res:                               # second run of the chain path: bit-identical
+            assert torch.equal(res[True][0], pol.grad)
+        res[fused] = (pol.grad.clone(), {k: v.clone() for k, v in d_in.items()})
+    scale = gref.abs().max().item()
+    for fused in (True, False):
+        gk = res[fused][0].clone()
+        gk[pol.log_std_off:] = 0
+        assert (gk - gref).abs().max().item() <= 5e-6 * scale, (fused, (gk - gref).abs().max().item(), scale)
+        for k, v in res[fused][1].items():
+            assert torch.allclose(v, xs[k].grad, rtol=1e-4, atol=1e-6 * xs[k].grad.abs().max().item())
+    # accumulate mode
+    pol.fused_backward = True
+    pol.forward(obs)
+    pol.backward(d_mean, d_value, None, accumulate=True, need_input_grad=ig)
+    assert torch.allclose(pol.grad, 2 * res[True][0], rtol=1e-5, atol=1e-6 * scale)

@@ -119,7 +119,7 @@ class MlpLayer(C.Structure):
     _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("relu", C.c_int32), ("src", C.c_int32), ("src_col", C.c_int32),
                 ("dst", C.c_int32), ("dst_col", C.c_int32), ("w_off", C.c_int32), ("b_off", C.c_int32),
                 ("save_ld", C.c_int32), ("wt_off", C.c_int32), ("wb_off", C.c_int32), ("wr_off", C.c_int32),
-                ("pad1", C.c_int32), ("save", C.c_void_p)]
+                ("wq_off", C.c_int32), ("save", C.c_void_p)]
 
 
 class MlpDesc(C.Structure):
@@ -132,7 +132,8 @@ class MlpDesc(C.Structure):
 class MlpBwdLayer(C.Structure):
     """mirror of vf_mlp_bwd_layer"""
     _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("need_dx", C.c_int32), ("ld_dy", C.c_int32), ("ld_y", C.c_int32),
-                ("ld_x", C.c_int32), ("ld_dx", C.c_int32), ("wb_off", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64),
+                ("ld_x", C.c_int32), ("ld_dx", C.c_int32), ("wb_off", C.c_int32), ("wq_off", C.c_int32), ("pad0", C.c_int32),
+                ("w_off", C.c_int64), ("b_off", C.c_int64),
                 ("dY", C.c_void_p), ("Y", C.c_void_p), ("X", C.c_void_p), ("dX", C.c_void_p)]
 
 
@@ -204,6 +205,7 @@ SIGNATURES = {
     "vf_mlp_pack_weights": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp]),
     "vf_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_mlp_backward_blocks": (C.c_int32, [C.c_int32]),
+    "vf_mlp_backward_partial_floats": (C.c_int64, [C.POINTER(MlpBwdDesc), C.c_int32]),
     "vf_mlp_backward": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),

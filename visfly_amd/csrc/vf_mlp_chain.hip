@@ -272,6 +272,288 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
     chain_items<N, 0>(g, st, lane, row, live);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Reverse chain: data gradients of the whole network for 32 rows per wave, again in registers.
+// dA^T[k][m] = sum_n W[n][k] dZ^T[n][m] has the same shape as the forward step (A operand = W^T blocks in the order an
+// accumulator lane holds its row's features: image at vf_mlp_layer.wq_off; B operand = the masked gradient tiles),
+// so the gradient tiles are fed back exactly like the activations.  After a layer's gradient w.r.t. the previous
+// activation is complete it is masked with that activation (> 0, read back from the copy the forward saved) and
+// stored to the buffer the weight-gradient kernel (vf_mlp_wgrad.hip) reads as dZ; the stores trickle out through the
+// items of the next op like the forward's.  The weight / bias gradients are NOT formed here: they reduce over rows,
+// i.e. across waves, and have their own kernel with row-slab partials.
+// ------------------------------------------------------------------------------------------------
+struct BwdFin {     // mask tiles [t0, t0 + nt) with the saved output of forward layer fl and store them as its dZ
+    int fl, t0, nt, ym0;
+};
+struct BwdOp {
+    int fl;         // forward layer whose weights are applied (MlpPolicy order)
+    int in_kind;    // 0: gradient tiles, 1: d_mean (M,4), 2: d_value (M,)
+    int in0, G;     // first input tile, number of 8-feature groups of the input gradient
+    int out0, nout; // output tiles = ceil(K / 32)
+    int accum;      // 1: keep accumulating into the output tiles
+    int obs;        // >= 0: the output is dLoss/d observation `obs` (stored directly, no mask)
+    int nfin;
+    BwdFin fin[2];
+};
+
+template <class N, bool PI, bool VF, bool IG>
+struct BwdProg {
+    static constexpr int NB = N::NB;
+    static constexpr int L_pi0 = 2 * NB, L_pi1 = 2 * NB + 1, L_mean = 2 * NB + 2, L_vf0 = 2 * NB + 3, L_vf1 = 2 * NB + 4, L_val = 2 * NB + 5;
+    // gradient tiles
+    static constexpr int g_p2 = 0, g_v2 = g_p2 + N::P2, g_p1 = g_v2 + N::V2, g_v1 = g_p1 + N::P1, g_feat = g_v1 + N::V1;
+    static constexpr int g_e1(int b) { return g_feat + NB * N::E2 + b * N::E1; }
+    static constexpr int g_in(int b) { return g_e1(NB) + b; }
+    static constexpr int n_tiles = g_in(NB);
+    static constexpr int n_ops = (PI ? 3 : 0) + (VF ? 3 : 0) + NB + (IG ? NB : 0);
+    static constexpr bool included(int l) { return l < 2 * NB || (l >= L_pi0 && l <= L_mean && PI) || (l >= L_vf0 && VF); }
+    static constexpr int entry(int fl)      // index of forward layer fl in the (reversed, trunk-skipping) vf_mlp_bwd_desc
+    {
+        int e = 0;
+        for (int l = fl + 1; l < 2 * NB + 6; ++l) e += included(l) ? 1 : 0;
+        return e;
+    }
+    static constexpr BwdOp feat_fins(BwdOp o)
+    {
+        o.nfin = NB;
+        for (int b = 0; b < NB; ++b) o.fin[b] = BwdFin{2 * b + 1, g_feat + b * N::E2, N::E2, b * N::E2};
+        return o;
+    }
+    static constexpr BwdOp op(int i)
+    {
+        // order: heads, second trunk layers, first trunk layers (-> feat), extractor L2 layers, [extractor L1 layers]
+        int k = 0;
+        if (PI) { if (i == k) return BwdOp{L_mean, 1, 0, 1, g_p2, N::P2, 0, -1, 1, {BwdFin{L_pi1, g_p2, N::P2, 0}, {}}}; ++k; }
+        if (VF) { if (i == k) return BwdOp{L_val, 2, 0, 1, g_v2, N::V2, 0, -1, 1, {BwdFin{L_vf1, g_v2, N::V2, 2}, {}}}; ++k; }
+        if (PI) { if (i == k) return BwdOp{L_pi1, 0, g_p2, N::P2 * 4, g_p1, N::P1, 0, -1, 1, {BwdFin{L_pi0, g_p1, N::P1, 0}, {}}}; ++k; }
+        if (VF) { if (i == k) return BwdOp{L_vf1, 0, g_v2, N::V2 * 4, g_v1, N::V1, 0, -1, 1, {BwdFin{L_vf0, g_v1, N::V1, 2}, {}}}; ++k; }
+        if (PI) {
+            if (i == k) {
+                BwdOp o{L_pi0, 0, g_p1, N::P1 * 4, g_feat, NB * N::E2, 0, -1, 0, {}};
+                return VF ? o : feat_fins(o);
+            }
+            ++k;
+        }
+        if (VF) {
+            if (i == k) return feat_fins(BwdOp{L_vf0, 0, g_v1, N::V1 * 4, g_feat, NB * N::E2, PI ? 1 : 0, -1, 0, {}});
+            ++k;
+        }
+        for (int b = 0; b < NB; ++b) {
+            if (i == k) return BwdOp{2 * b + 1, 0, g_feat + b * N::E2, N::E2 * 4, g_e1(b), N::E1, 0, -1, 1, {BwdFin{2 * b, g_e1(b), N::E1, 0}, {}}};
+            ++k;
+        }
+        for (int b = 0; b < NB; ++b) {
+            if (i == k) return BwdOp{2 * b, 0, g_e1(b), N::E1 * 4, g_in(b), 1, 0, b, 0, {}};
+            ++k;
+        }
+        return BwdOp{};
+    }
+    static constexpr int items(int i) { return op(i).G * op(i).nout; }
+    static constexpr int n_items()
+    {
+        int n = 0;
+        for (int i = 0; i < n_ops; ++i) n += items(i);
+        return n;
+    }
+    static constexpr int op_of(int item)
+    {
+        int i = 0;
+        while (item >= items(i)) { item -= items(i); ++i; }
+        return i;
+    }
+    static constexpr int first_item(int oi)
+    {
+        int n = 0;
+        for (int i = 0; i < oi; ++i) n += items(i);
+        return n;
+    }
+};
+
+struct BwdArgsChain {
+    vf_mlp_bwd_desc d;
+    const float* packed;
+    int M;
+};
+
+template <class P>
+struct BwdState {
+    f32x16 t[P::n_tiles];
+    float4 ring[kChainDepth];
+    float4 ym[4][4];             // saved activations (mask source) of the tiles being finalised
+    float hin[2][4];             // head gradients of this lane's row: d_mean[0..3] / d_value (lane half 0), else 0
+};
+
+template <class P, int I>
+__device__ __forceinline__ float4 bwd_load(const BwdArgsChain& g, int lane)
+{
+    constexpr int oi = P::op_of(I), local = I - P::first_item(oi);
+    constexpr BwdOp O = P::op(oi);
+    constexpr int gq = local / O.nout, a = local % O.nout;
+    const float4* img = reinterpret_cast<const float4*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off);
+    return img[(a * O.G + gq) * 64 + lane];
+}
+
+template <class P, int OI>
+__device__ __forceinline__ void bwd_mask_load(const BwdArgsChain& g, BwdState<P>& st, int rc, int h)
+{
+    constexpr BwdOp O = P::op(OI);
+#pragma unroll
+    for (int f = 0; f < O.nfin; ++f) {
+        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fin[f].fl)];
+        const float* y = E.Y + (size_t)rc * E.ld_y + 4 * h;
+#pragma unroll
+        for (int a = 0; a < O.fin[f].nt; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st.ym[O.fin[f].ym0 + a][q] = *reinterpret_cast<const float4*>(y + 32 * a + 8 * q);
+    }
+}
+
+template <class P, int OI>
+__device__ __forceinline__ void bwd_finalize(const BwdArgsChain& g, BwdState<P>& st, int row, int h, bool live)
+{
+    constexpr BwdOp O = P::op(OI);
+#pragma unroll
+    for (int f = 0; f < O.nfin; ++f)
+#pragma unroll
+        for (int a = 0; a < O.fin[f].nt; ++a) {
+            f32x16& v = st.t[O.fin[f].t0 + a];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 y = st.ym[O.fin[f].ym0 + a][q];
+                v[4 * q + 0] = y.x > 0.0f ? v[4 * q + 0] : 0.0f;
+                v[4 * q + 1] = y.y > 0.0f ? v[4 * q + 1] : 0.0f;
+                v[4 * q + 2] = y.z > 0.0f ? v[4 * q + 2] : 0.0f;
+                v[4 * q + 3] = y.w > 0.0f ? v[4 * q + 3] : 0.0f;
+            }
+        }
+    if constexpr (O.obs >= 0) {        // dLoss/d observation: features 4 h + (r & 3) + 8 (r >> 2) of this lane's row
+        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];
+        if (live) {
+            const f32x16& v = st.t[O.out0];
+            float* dx = E.dX + (size_t)row * E.ld_dx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 4 * h + (r & 3) + 8 * (r >> 2);
+                if (k < E.K) dx[k] = v[r];
+            }
+        }
+    }
+}
+
+// stores of the tiles the PREVIOUS op finalised, spread over this op's items
+template <class P, int OI, int LOCAL>
+__device__ __forceinline__ void bwd_deferred_store(const BwdArgsChain& g, const BwdState<P>& st, int row, int h, bool live)
+{
+    if constexpr (OI >= 1) {
+        constexpr BwdOp Q = P::op(OI - 1);
+        constexpr int S0 = Q.nfin > 0 ? Q.fin[0].nt * 4 : 0, S = S0 + (Q.nfin > 1 ? Q.fin[1].nt * 4 : 0);
+        constexpr int n_it = P::items(OI), per = (S + n_it - 1) / n_it;
+        constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
+        if constexpr (s0 < s1) {
+            if (live) {
+#pragma unroll
+                for (int i = s0; i < s1; ++i) {
+                    const int f = i < S0 ? 0 : 1, ii = i - (f ? S0 : 0), a = ii / 4, q = ii % 4;
+                    const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
+                    float* base = const_cast<float*>(E.dY) + (size_t)row * E.ld_dy + 4 * h;
+                    const f32x16& v = st.t[Q.fin[f].t0 + a];
+                    *reinterpret_cast<float4*>(base + 32 * a + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                }
+            }
+        }
+    }
+}
+
+template <class P, int I>
+__device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st, int lane, int row, int rc, bool live)
+{
+    if constexpr (I < P::n_items()) {
+        constexpr int oi = P::op_of(I), local = I - P::first_item(oi);
+        constexpr BwdOp O = P::op(oi);
+        constexpr int gq = local / O.nout, a = local % O.nout;
+        const int h = lane >> 5;
+        const float4 w = st.ring[I % kChainDepth];
+        if constexpr (I + kChainDepth < P::n_items()) st.ring[I % kChainDepth] = bwd_load<P, I + kChainDepth>(g, lane);
+        if constexpr (local == 0 && O.in_kind == 0) bwd_mask_load<P, oi>(g, st, rc, h);   // head ops: loaded in the prologue
+        f32x16& acc = st.t[O.out0 + a];
+        if constexpr (gq == 0 && !O.accum) acc = f32x16{0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float b;
+            if constexpr (O.in_kind == 0) b = st.t[O.in0 + gq / 4][4 * (gq % 4) + j];
+            else b = st.hin[O.in_kind - 1][j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
+        }
+        bwd_deferred_store<P, oi, local>(g, st, row, h, live);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (local == P::items(oi) - 1) bwd_finalize<P, oi>(g, st, row, h, live);
+        bwd_items<P, I + 1>(g, st, lane, row, rc, live);
+    }
+}
+
+template <class P, int I>
+__device__ __forceinline__ void bwd_prologue(const BwdArgsChain& g, BwdState<P>& st, int lane)
+{
+    if constexpr (I < kChainDepth && I < P::n_items()) {
+        st.ring[I] = bwd_load<P, I>(g, lane);
+        bwd_prologue<P, I + 1>(g, st, lane);
+    }
+}
+
+template <class P, int OI>
+__device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdState<P>& st, int rc, int h)
+{
+    if constexpr (OI < P::n_ops) {
+        constexpr BwdOp O = P::op(OI);
+        if constexpr (O.in_kind != 0) {
+            const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];
+            const float* dy = E.dY + (size_t)rc * E.ld_dy;
+            if constexpr (O.in_kind == 1) {
+                st.hin[0][0] = h == 0 ? dy[0] : 0.0f; st.hin[0][1] = h == 0 ? dy[1] : 0.0f;
+                st.hin[0][2] = h == 0 ? dy[2] : 0.0f; st.hin[0][3] = h == 0 ? dy[3] : 0.0f;
+            } else {
+                st.hin[1][0] = h == 0 ? dy[0] : 0.0f; st.hin[1][1] = 0.0f; st.hin[1][2] = 0.0f; st.hin[1][3] = 0.0f;
+            }
+            bwd_mask_load<P, OI>(g, st, rc, h);
+            bwd_head_prologue<P, OI + 1>(g, st, rc, h);
+        }
+    }
+}
+
+// the last op's finalised tiles have no following items to carry their stores
+template <class P>
+__device__ __forceinline__ void bwd_tail_store(const BwdArgsChain& g, const BwdState<P>& st, int row, int h, bool live)
+{
+    constexpr BwdOp Q = P::op(P::n_ops - 1);
+    if (!live) return;
+#pragma unroll
+    for (int f = 0; f < Q.nfin; ++f) {
+        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
+        float* base = const_cast<float*>(E.dY) + (size_t)row * E.ld_dy + 4 * h;
+#pragma unroll
+        for (int a = 0; a < Q.fin[f].nt; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x16& v = st.t[Q.fin[f].t0 + a];
+                *reinterpret_cast<float4*>(base + 32 * a + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            }
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
+{
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int row = blockIdx.x * 32 + m;
+    const bool live = row < g.M;
+    const int rc = live ? row : g.M - 1;
+    BwdState<P> st;
+    bwd_prologue<P, 0>(g, st, lane);
+    bwd_head_prologue<P, 0>(g, st, rc, h);
+    bwd_items<P, 0>(g, st, lane, row, rc, live);
+    bwd_tail_store<P>(g, st, row, h, live);
+}
+
 using NetHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2>;   // StateExtractor [128, 64], pi / vf [64, 64]
 using NetNav = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2>;     // StateTargetExtractor [128, 64] x 2, pi / vf [64, 64]
 
@@ -317,6 +599,68 @@ int chain_launch(const vf_mlp_desc& d, const float* params, const float* packed,
     hipLaunchKernelGGL(k_mlp_forward_chain<N>, dim3((M + 31) / 32), dim3(64), 0, st, g);
     VF_HIP(hipGetLastError());
     return 1;
+}
+
+template <class N, bool PI, bool VF, bool IG>
+bool bwd_chain_matches(const vf_mlp_bwd_desc& d)
+{
+    using P = BwdProg<N, PI, VF, IG>;
+    if (d.n_layers != 2 * N::NB + 3 * ((PI ? 1 : 0) + (VF ? 1 : 0))) return false;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    auto is = [&](int fl, int K, int No, bool relu, bool first) {
+        const vf_mlp_bwd_layer& E = d.layer[P::entry(fl)];
+        if (E.K != K || E.No != No || (E.Y != nullptr) != relu || E.wq_off < 0 || (E.wq_off & 3)) return false;
+        if (relu && (!al16(E.Y) || (E.ld_y & 3) || !al16(E.dY) || (E.ld_dy & 3))) return false;   // float4 mask loads / dZ stores
+        if (first ? (E.need_dx != 0) != IG : E.need_dx == 0) return false;
+        return true;
+    };
+    for (int b = 0; b < N::NB; ++b) {
+        const int K0 = d.layer[P::entry(2 * b)].K;
+        if (K0 < 1 || K0 > N::kin(b) || K0 > 32) return false;
+        if (!is(2 * b, K0, N::E1 * 32, true, true) || !is(2 * b + 1, N::E1 * 32, N::E2 * 32, true, false)) return false;
+    }
+    const int feat = N::NB * N::E2 * 32;
+    if (PI && (!is(P::L_pi0, feat, N::P1 * 32, true, false) || !is(P::L_pi1, N::P1 * 32, N::P2 * 32, true, false) ||
+               !is(P::L_mean, N::P2 * 32, 4, false, false)))
+        return false;
+    if (VF && (!is(P::L_vf0, feat, N::V1 * 32, true, false) || !is(P::L_vf1, N::V1 * 32, N::V2 * 32, true, false) ||
+               !is(P::L_val, N::V2 * 32, 1, false, false)))
+        return false;
+    // wiring: the gradient a layer's consumer produces is that layer's dY buffer (incl. the feature concat)
+    for (int b = 0; b < N::NB; ++b) {
+        if (d.layer[P::entry(2 * b + 1)].dX != d.layer[P::entry(2 * b)].dY) return false;
+        const vf_mlp_bwd_layer& first_trunk = d.layer[P::entry(PI ? P::L_pi0 : P::L_vf0)];
+        if (d.layer[P::entry(2 * b + 1)].dY != first_trunk.dX + b * N::E2 * 32 || d.layer[P::entry(2 * b + 1)].ld_dy != first_trunk.ld_dx) return false;
+    }
+    if (PI && (d.layer[P::entry(P::L_pi1)].dX != d.layer[P::entry(P::L_pi0)].dY || d.layer[P::entry(P::L_mean)].dX != d.layer[P::entry(P::L_pi1)].dY))
+        return false;
+    if (VF && (d.layer[P::entry(P::L_vf1)].dX != d.layer[P::entry(P::L_vf0)].dY || d.layer[P::entry(P::L_val)].dX != d.layer[P::entry(P::L_vf1)].dY))
+        return false;
+    if (PI && VF && d.layer[P::entry(P::L_pi0)].dX != d.layer[P::entry(P::L_vf0)].dX) return false;
+    return true;
+}
+
+template <class N, bool PI, bool VF, bool IG>
+int bwd_chain_launch(const vf_mlp_bwd_desc& d, const float* packed, int M, hipStream_t st)
+{
+    BwdArgsChain g{d, packed, M};
+    hipLaunchKernelGGL((k_mlp_backward_chain<BwdProg<N, PI, VF, IG>>), dim3((M + 31) / 32), dim3(64), 0, st, g);
+    VF_HIP(hipGetLastError());
+    return 1;
+}
+
+// data gradients of the whole network (masked dZ of every hidden layer left in the dY buffers, optional observation
+// gradients): 1 launched, 0 not an instantiated class / variant, < 0 error.  Variants: PPO update (both trunks, no
+// observation gradient) and first-order policy optimisation (policy trunk only, observation gradient).
+int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st)
+{
+    static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
+    if (off) return 0;
+    if (bwd_chain_matches<NetNav, true, true, false>(*d)) return bwd_chain_launch<NetNav, true, true, false>(*d, packed, M, st);
+    if (bwd_chain_matches<NetNav, true, false, true>(*d)) return bwd_chain_launch<NetNav, true, false, true>(*d, packed, M, st);
+    if (bwd_chain_matches<NetHover, true, true, false>(*d)) return bwd_chain_launch<NetHover, true, true, false>(*d, packed, M, st);
+    if (bwd_chain_matches<NetHover, true, false, true>(*d)) return bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st);
+    return 0;
 }
 
 // 1: launched, 0: the layer table is not one of the instantiated network classes, < 0: error

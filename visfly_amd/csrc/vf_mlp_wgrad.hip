@@ -1,0 +1,286 @@
+// Weight / bias gradients of all layers in one launch, MFMA operands straight from global memory.
+//
+// dW[n][k] = sum_m dZ[m][n] X[m][k] reduces over rows, so with v_mfma_f32_32x32x2_f32
+//     A[i = n][kk] = dZ[m0 + 2 s + kk][n]    lane = n + 32 kk      (row-major dZ: 32 lanes read 128 contiguous bytes)
+//     B[kk][j = k] = X [m0 + 2 s + kk][k]    lane = k + 32 kk      (row-major X:  likewise)
+// both fragments are plain coalesced dword loads of the buffers the forward / reverse chain kernels left in HBM -- no
+// LDS staging, no transposes.  A wave owns ONE layer and a slab of rows: the whole dW of the layer (up to 4 x 4 tiles
+// = 256 accumulator registers) stays in registers over the slab, the bias gradient is the running sum of the A
+// fragments.  Slabs are sized so that every wave issues about the same number of MFMAs (rows per wave inversely
+// proportional to the layer's tile count); each wave writes one partial [No][K] + [No], and a table-driven fold sums
+// the partials of a layer in a fixed order (deterministic).
+#include "vf_common.hpp"
+
+namespace vf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// row pairs in flight per wave.  The kernel streams 2 rows x (No + K) floats per step and is bandwidth-bound: by
+// Little's law the chip needs ~16 KiB in flight per wave (1024 waves x 16 KiB / ~2.5 us = 6.5 TB/s), i.e.
+// 64 / (NT + KT) steps of 256 (NT + KT) bytes
+constexpr int wg_depth(int nt, int kt)
+{
+    const int d = 64 / (nt + kt);
+    return d > 16 ? 16 : (d < 4 ? 4 : d);
+}
+
+struct WgradTable {
+    int32_t n_layers;
+    int32_t first_wave[VF_MLP_MAX_LAYERS + 1];   // waves [first_wave[l], first_wave[l + 1]) work on layer l
+    int32_t rows_per_wave[VF_MLP_MAX_LAYERS];    // even
+    int64_t part_off[VF_MLP_MAX_LAYERS];          // float offset of the layer's partial block: waves x (K No + No)
+};
+
+// VA / VB: the layer's No / K is exactly NT / KT full tiles and the rows are 16-byte aligned: a lane then loads NT
+// (KT) CONSECUTIVE columns of its row with one vector load (32 lanes = one contiguous 128 NT bytes) and feeds component
+// i to tile i -- the (tile, lane) -> column assignment is a free choice, it only permutes where dW lands in the
+// accumulators: n = NT lane + i instead of 32 i + lane.
+template <int NT, int KT, bool VA, bool VB>
+__device__ __forceinline__ void wgrad_slab(const vf_mlp_bwd_layer& L, int r0, int r1, float* __restrict__ part)
+{
+    constexpr int kWgDepth = wg_depth(NT, KT);
+    const int lane = threadIdx.x & 63, c = lane & 31, kk = lane >> 5;
+    f32x16 acc[NT][KT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = f32x16{0};
+    float bsum[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) bsum[i] = 0.0f;
+    // scalar mode: column guards hoisted (clamped column + multiplier 0 / 1)
+    int an[NT], bk[KT];
+    float am[NT], bm[KT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { const int n = 32 * i + c; an[i] = n < L.No ? n : L.No - 1; am[i] = n < L.No ? 1.0f : 0.0f; }
+#pragma unroll
+    for (int j = 0; j < KT; ++j) { const int k = 32 * j + c; bk[j] = k < L.K ? k : L.K - 1; bm[j] = k < L.K ? 1.0f : 0.0f; }
+    float ra[kWgDepth][NT], rb[kWgDepth][KT];
+    const int steps = (r1 - r0 + 1) >> 1;
+    auto issue = [&](int s, float (&fa)[NT], float (&fb)[KT]) {
+        const int m = r0 + 2 * s + kk, mc = m < r1 ? m : r1 - 1;
+        const float* dz = L.dY + (size_t)mc * L.ld_dy;
+        const float* x = L.X + (size_t)mc * L.ld_x;
+        if constexpr (VA) {
+            using vec = __attribute__((ext_vector_type(NT))) float;
+            const vec v = *reinterpret_cast<const vec*>(dz + NT * c);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) fa[i] = v[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) fa[i] = dz[an[i]];
+        }
+        if constexpr (VB) {
+            using vec = __attribute__((ext_vector_type(KT))) float;
+            const vec v = *reinterpret_cast<const vec*>(x + KT * c);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) fb[j] = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < KT; ++j) fb[j] = x[bk[j]];
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < kWgDepth; ++p) issue(p, ra[p], rb[p]);      // rows past the slab are clamped inside
+    for (int s0 = 0; s0 < steps; s0 += kWgDepth) {     // branch-free body: steps past the slab run with live = 0
+#pragma unroll
+        for (int p = 0; p < kWgDepth; ++p) {
+            const int s = s0 + p;
+            const float live = (r0 + 2 * s + kk) < r1 ? 1.0f : 0.0f;
+            float fa[NT], fb[KT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) { fa[i] = ra[p][i] * (VA ? live : am[i] * live); bsum[i] += fa[i]; }
+#pragma unroll
+            for (int j = 0; j < KT; ++j) fb[j] = VB ? rb[p][j] : rb[p][j] * bm[j];
+            issue(s + kWgDepth, ra[p], rb[p]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            // keep the steps in program order: the scheduler otherwise clusters all loads of the unrolled body at its
+            // top and drains them (vmcnt(0)) by its end, which collapses the prefetch distance to less than one body
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // partial in accumulator order (every store instruction writes 256 contiguous bytes): tile (i, j), register r, lane;
+    // then the bias sums [NT][32].  k_wgrad_fold maps the positions back to (n, k) with wgrad_nk().
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[((i * KT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const float other = __shfl_xor(bsum[i], 32);
+        if (kk == 0) part[NT * KT * 1024 + 32 * i + c] = bsum[i] + other;
+    }
+}
+
+__host__ __device__ inline bool wgrad_vec_ok(const float* p, int ld, int w, int tiles)
+{
+    return (tiles == 2 || tiles == 4) && w == 32 * tiles && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
+// floats of one wave's partial of this layer
+__host__ __device__ inline int wgrad_partial_size(const vf_mlp_bwd_layer& L)
+{
+    const int NT = (L.No + 31) >> 5, KT = (L.K + 31) >> 5;
+    return NT * KT * 1024 + NT * 32;
+}
+
+// element e of a partial -> parameter offset in [dW (No x K) | db (No)], or -1 (padding)
+__device__ __forceinline__ int wgrad_param_of(const vf_mlp_bwd_layer& L, int e)
+{
+    const int NT = (L.No + 31) >> 5, KT = (L.K + 31) >> 5;
+    const bool va = wgrad_vec_ok(L.dY, L.ld_dy, L.No, NT), vb = wgrad_vec_ok(L.X, L.ld_x, L.K, KT);
+    if (e >= NT * KT * 1024) {
+        const int b = e - NT * KT * 1024, i = b >> 5, c = b & 31, n = va ? NT * c + i : 32 * i + c;
+        return n < L.No ? L.K * L.No + n : -1;
+    }
+    const int lane = e & 63, r = (e >> 6) & 15, t = e >> 10, i = t / KT, j = t - i * KT, c = lane & 31, kk = lane >> 5;
+    const int ia = 4 * kk + (r & 3) + 8 * (r >> 2);
+    const int n = va ? NT * ia + i : 32 * i + ia, k = vb ? KT * c + j : 32 * j + c;
+    return (n < L.No && k < L.K) ? n * L.K + k : -1;
+}
+
+template <int NT, int KT>
+__device__ __forceinline__ void wgrad_slab_pick(const vf_mlp_bwd_layer& L, int r0, int r1, float* __restrict__ part)
+{
+    const bool va = wgrad_vec_ok(L.dY, L.ld_dy, L.No, NT), vb = wgrad_vec_ok(L.X, L.ld_x, L.K, KT);
+    if constexpr ((NT == 2 || NT == 4) && (KT == 2 || KT == 4)) {
+        if (va && vb) return wgrad_slab<NT, KT, true, true>(L, r0, r1, part);
+    }
+    if constexpr (NT == 2 || NT == 4) {
+        if (va) return wgrad_slab<NT, KT, true, false>(L, r0, r1, part);
+    }
+    if constexpr (KT == 2 || KT == 4) {
+        if (vb) return wgrad_slab<NT, KT, false, true>(L, r0, r1, part);
+    }
+    wgrad_slab<NT, KT, false, false>(L, r0, r1, part);
+}
+
+__global__ __launch_bounds__(64) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const WgradTable t, float* __restrict__ partials, int M)
+{
+    const int w = blockIdx.x;
+    int l = 0;
+    while (l + 1 < t.n_layers && w >= t.first_wave[l + 1]) ++l;
+    const vf_mlp_bwd_layer& L = d.layer[l];
+    const int lw = w - t.first_wave[l];
+    const int r0 = lw * t.rows_per_wave[l], r1 = min(r0 + t.rows_per_wave[l], M);
+    float* part = partials + t.part_off[l] + (size_t)lw * wgrad_partial_size(L);
+    const int NT = (L.No + 31) >> 5, KT = (L.K + 31) >> 5;
+    if (r0 >= r1) {        // empty slab (rounding): the fold still reads this partial
+        for (int i = threadIdx.x; i < wgrad_partial_size(L); i += 64) part[i] = 0.0f;
+        return;
+    }
+    switch (NT * 4 + KT - 5) {
+    case 0: wgrad_slab_pick<1, 1>(L, r0, r1, part); break;
+    case 1: wgrad_slab_pick<1, 2>(L, r0, r1, part); break;
+    case 2: wgrad_slab_pick<1, 3>(L, r0, r1, part); break;
+    case 3: wgrad_slab_pick<1, 4>(L, r0, r1, part); break;
+    case 4: wgrad_slab_pick<2, 1>(L, r0, r1, part); break;
+    case 5: wgrad_slab_pick<2, 2>(L, r0, r1, part); break;
+    case 6: wgrad_slab_pick<2, 3>(L, r0, r1, part); break;
+    case 7: wgrad_slab_pick<2, 4>(L, r0, r1, part); break;
+    case 8: wgrad_slab_pick<3, 1>(L, r0, r1, part); break;
+    case 9: wgrad_slab_pick<3, 2>(L, r0, r1, part); break;
+    case 10: wgrad_slab_pick<3, 3>(L, r0, r1, part); break;
+    case 11: wgrad_slab_pick<3, 4>(L, r0, r1, part); break;
+    case 12: wgrad_slab_pick<4, 1>(L, r0, r1, part); break;
+    case 13: wgrad_slab_pick<4, 2>(L, r0, r1, part); break;
+    case 14: wgrad_slab_pick<4, 3>(L, r0, r1, part); break;
+    default: wgrad_slab_pick<4, 4>(L, r0, r1, part); break;
+    }
+}
+
+// grad (+)= sum over the layer's waves of partial[wave][e]; 64 consecutive partial elements per block, the 4 waves of
+// the block split the partial rows (8 loads in flight each) and combine through LDS in a fixed order
+__global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, const WgradTable t, const float* __restrict__ partials,
+                                                       float* __restrict__ grad, int accumulate)
+{
+    __shared__ float red[4][64];
+    int b = blockIdx.x, l = 0;
+    for (; l < t.n_layers; ++l) {
+        const int nb = (wgrad_partial_size(d.layer[l]) + 63) / 64;
+        if (b < nb) break;
+        b -= nb;
+    }
+    if (l >= t.n_layers) return;
+    const vf_mlp_bwd_layer& L = d.layer[l];
+    const int tot = wgrad_partial_size(L), waves = t.first_wave[l + 1] - t.first_wave[l];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, e = b * 64 + lane;
+    const int prm = e < tot ? wgrad_param_of(L, e) : -1;
+    float s = 0.0f;
+    if (prm >= 0) {
+        const float* p = partials + t.part_off[l] + e;
+        float s4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int w = q;
+        for (; w + 28 < waves; w += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s4[u] += p[(size_t)(w + 4 * u) * tot];
+        }
+        for (; w < waves; w += 4) s4[0] += p[(size_t)w * tot];
+        s = ((s4[0] + s4[1]) + (s4[2] + s4[3])) + ((s4[4] + s4[5]) + (s4[6] + s4[7]));
+    }
+    red[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && prm >= 0) {
+        const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        const int nw = L.K * L.No;
+        float* g = grad + (prm < nw ? L.w_off + prm : L.b_off + (prm - nw));
+        *g = accumulate ? *g + v : v;
+    }
+}
+
+// waves per layer proportional to its MFMA count per row pair; -> total waves, partial floats
+int64_t wgrad_plan(const vf_mlp_bwd_desc& d, int M, WgradTable& t, int* total_waves)
+{
+    int tiles[VF_MLP_MAX_LAYERS], sum = 0;
+    for (int l = 0; l < d.n_layers; ++l) {
+        tiles[l] = ((d.layer[l].No + 31) >> 5) * ((d.layer[l].K + 31) >> 5) + 2;   // + per-row-pair overhead (loads, guards) in MFMA units
+        sum += tiles[l];
+    }
+    const int budget = 1024;                       // one wave per SIMD
+    t.n_layers = d.n_layers;
+    int w = 0;
+    int64_t off = 0;
+    for (int l = 0; l < d.n_layers; ++l) {
+        int nw = (int)(((int64_t)budget * tiles[l] + sum / 2) / sum);
+        if (nw < 1) nw = 1;
+        int rows = (M + nw - 1) / nw;
+        rows = (rows + 1) & ~1;
+        if (rows < 2) rows = 2;
+        nw = (M + rows - 1) / rows;
+        t.first_wave[l] = w;
+        t.rows_per_wave[l] = rows;
+        t.part_off[l] = off;
+        w += nw;
+        off += (int64_t)nw * wgrad_partial_size(d.layer[l]);
+    }
+    t.first_wave[d.n_layers] = w;
+    *total_waves = w;
+    return off;
+}
+
+int64_t mlp_wgrad_partial_floats(const vf_mlp_bwd_desc* d, int M)
+{
+    WgradTable t;
+    int w;
+    return wgrad_plan(*d, M, t, &w);
+}
+
+int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, hipStream_t st)
+{
+    WgradTable t;
+    int waves = 0;
+    wgrad_plan(*d, M, t, &waves);
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
+    int nb = 0;
+    for (int l = 0; l < d->n_layers; ++l) nb += (wgrad_partial_size(d->layer[l]) + 63) / 64;
+    hipLaunchKernelGGL(k_wgrad_fold, dim3(nb), dim3(kBlock), 0, st, *d, t, (const float*)partials, grad, accumulate);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+}  // namespace vf

@@ -567,6 +567,13 @@ __global__ __launch_bounds__(kBlock) void k_mlp_pack_weights(const vf_mlp_desc d
         const int k = nat ? 8 * g + 2 * j + h : 32 * (g >> 2) + 8 * (g & 3) + 4 * h + j;
         packed[L.wr_off + idx] = (k < L.K && n < L.No) ? params[L.w_off + n * L.K + k] : 0.0f;
     }
+    // reverse-chain image: block (a, g), a < ceil(K / 32), g < ceil(No / 8): W[32 (g / 4) + 8 (g % 4) + 4 h + j][32 a + (l & 31)]
+    const int GQ = (L.No + 7) >> 3, KT = (L.K + 31) >> 5;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < KT * GQ * 256; idx += gridDim.x * kBlock) {
+        const int j = idx & 3, l = (idx >> 2) & 63, blk = idx >> 8, a = blk / GQ, g = blk - a * GQ;
+        const int k = 32 * a + (l & 31), n = 32 * (g >> 2) + 8 * (g & 3) + 4 * (l >> 5) + j;
+        packed[L.wq_off + idx] = (k < L.K && n < L.No) ? params[L.w_off + n * L.K + k] : 0.0f;
+    }
 }
 
 __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, const float* __restrict__ params,
@@ -1283,10 +1290,11 @@ __global__ __launch_bounds__(kBlock) void k_adam(float* __restrict__ p, const fl
         const float pn = pi - step * (mi / denom);
         p[i] = pn;
         if (c.pack_map) {   // keep the packed MFMA images of the weights current (vf_mlp_pack_weights layout)
-            const int a = c.pack_map[3 * i], b = c.pack_map[3 * i + 1], r = c.pack_map[3 * i + 2];
-            if (a >= 0) c.packed[a] = pn;
-            if (b >= 0) c.packed[b] = pn;
-            if (r >= 0) c.packed[r] = pn;
+            const int4 o = reinterpret_cast<const int4*>(c.pack_map)[i];
+            if (o.x >= 0) c.packed[o.x] = pn;
+            if (o.y >= 0) c.packed[o.y] = pn;
+            if (o.z >= 0) c.packed[o.z] = pn;
+            if (o.w >= 0) c.packed[o.w] = pn;
         }
     }
 }
@@ -1476,7 +1484,9 @@ int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc)
         const int64_t endr = L.wr_off + (int64_t)((L.No + 31) >> 5) * G * 256;
         n = end > n ? end : n;
         n = endb > n ? endb : n;
+        const int64_t endq = L.wq_off + (int64_t)((L.K + 31) >> 5) * ((L.No + 7) >> 3) * 256;
         n = endr > n ? endr : n;
+        n = endq > n ? endq : n;
     }
     return n;
 }
@@ -1538,6 +1548,13 @@ int32_t vf_mlp_backward_blocks(int32_t M)
     return (mtiles + rounds - 1) / rounds;
 }
 
+int64_t vf_mlp_backward_partial_floats(const vf_mlp_bwd_desc* desc, int32_t M)
+{
+    if (!desc || desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS || M <= 0) return -1;
+    const int64_t a = (int64_t)vf_mlp_backward_blocks(M) * desc->n_fold, b = vf::mlp_wgrad_partial_floats(desc, M);
+    return a > b ? a : b;
+}
+
 int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* partials, float* grad, int32_t M,
                     int32_t accumulate, vf_stream_t stream)
 {
@@ -1552,6 +1569,11 @@ int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* par
             return vf::fail(VF_EINVAL, "vf_mlp_backward: layer %d: missing pointer or short row stride", i);
         if (L.w_off < 0 || L.b_off < 0 || L.w_off + (int64_t)L.K * L.No > desc->n_fold || L.b_off + L.No > desc->n_fold)
             return vf::fail(VF_EINVAL, "vf_mlp_backward: layer %d: parameter offsets outside n_fold", i);
+    }
+    // reference-default network classes: reverse chain in registers + row-slab weight gradients (vf_mlp_chain.hip, vf_mlp_wgrad.hip)
+    if (int rc = vf::mlp_backward_chain_try(desc, packed, M, vf::as_stream(stream))) {
+        if (rc < 0) return rc;
+        return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, vf::as_stream(stream));
     }
     lds = ((size_t)2 * vf::kRows * (129 + 129) + vf::kBwdThreads) * sizeof(float);   // two staging buffers + bias scratch
     if (int rc = allow_lds(vf::k_mlp_backward, lds)) return rc;

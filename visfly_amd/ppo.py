@@ -169,7 +169,7 @@ class MlpPolicy:
             return None
         if top * 4 > 160 * 1024:
             return None
-        wt_off, wb_off, wr_off, o = [], [], [], 0
+        wt_off, wb_off, wr_off, wq_off, o = [], [], [], [], 0
         for ly in self.layers:               # packed weights: forward [round16(K)][round32(No)], data gradient [round16(No)][round32(K)],
             wt_off.append(o)                 # register-chain image: ceil(No / 32) * G blocks of 256 floats (include/visfly_amd.h)
             o += ((ly.K + 15) & ~15) * ((ly.No + 31) & ~31)
@@ -177,7 +177,10 @@ class MlpPolicy:
             o += ((ly.No + 15) & ~15) * ((ly.K + 31) & ~31)
             wr_off.append(o)
             o += ((ly.No + 31) >> 5) * self._chain_groups(ly) * 256
-        return dict(ids=ids, off=off, stride=stride, total=top, wt_off=wt_off, wb_off=wb_off, wr_off=wr_off, packed_floats=o)
+            wq_off.append(o)                 # reverse-chain image: ceil(K / 32) * ceil(No / 8) blocks
+            o += ((ly.K + 31) >> 5) * ((ly.No + 7) >> 3) * 256
+        return dict(ids=ids, off=off, stride=stride, total=top, wt_off=wt_off, wb_off=wb_off, wr_off=wr_off, wq_off=wq_off,
+                    packed_floats=o)
 
     @staticmethod
     def _chain_groups(ly):
@@ -199,7 +202,7 @@ class MlpPolicy:
             L.src, L.src_col = p["ids"][ly.src], ly.sc
             L.dst = {"mean": _lib.MLP_OUT0, "value": _lib.MLP_OUT1}.get(ly.dst, p["ids"].get(ly.dst, 0))
             L.dst_col, L.w_off, L.b_off, L.wt_off, L.wb_off = ly.dc, ly.w_off, ly.b_off, p["wt_off"][li], p["wb_off"][li]
-            L.wr_off = p["wr_off"][li]
+            L.wr_off, L.wq_off = p["wr_off"][li], p["wq_off"][li]
             if save and b is not None and ly.dst not in ("mean", "value"):
                 L.save, L.save_ld = b[ly.dst].data_ptr(), b[ly.dst].shape[1]
         return d
@@ -214,13 +217,13 @@ class MlpPolicy:
             self._packed_stamp = self._stamp
 
     def pack_map(self):
-        """-> (int32 [n_params, 3] device tensor, packed buffer): for every parameter the float offsets of its copies in
+        """-> (int32 [n_params, 4] device tensor, packed buffer): for every parameter the float offsets of its copies in
         the packed forward / data-gradient weight images (-1: biases, log_std), for vf_adam_cfg.pack_map"""
         if self._plan is None:
             return None, None
         if self._pack_map is None:
             import numpy as np
-            m = np.full((self.n_params, 3), -1, np.int32)
+            m = np.full((self.n_params, 4), -1, np.int32)
             for li, ly in enumerate(self.layers):
                 n, k = np.meshgrid(np.arange(ly.No), np.arange(ly.K), indexing="ij")
                 flat = ly.w_off + n * ly.K + k
@@ -232,6 +235,9 @@ class MlpPolicy:
                 else:                 # k = 32 (g / 4) + 8 (g % 4) + 4 h + j
                     g, h, j = (k >> 5) * 4 + ((k & 31) >> 3), (k & 7) >> 2, k & 3
                 m[flat, 2] = self._plan["wr_off"][li] + (((a * G + g) * 64 + h * 32 + i) << 2) + j
+                # reverse chain: block (k / 32, n / 8), lane (n % 8) / 4 * 32 + k % 32, word n % 4
+                GQ = (ly.No + 7) >> 3
+                m[flat, 3] = self._plan["wq_off"][li] + ((((k >> 5) * GQ + (n >> 3)) * 64 + ((n & 7) >> 2) * 32 + (k & 31)) << 2) + (n & 3)
             self._pack_map = th.from_numpy(m).to(self.device)
             self._stamp += 1          # force one full pack (zero pads) before the incremental refreshes
             self._pack()
@@ -384,6 +390,7 @@ class MlpPolicy:
             n += 1
             e.K, e.No, e.w_off, e.b_off = ly.K, ly.No, ly.w_off, ly.b_off
             e.wb_off = self._plan["wb_off"][self.layers.index(ly)]
+            e.wq_off = self._plan["wq_off"][self.layers.index(ly)]
             e.dY, e.ld_dy = _ptr(dY, ly.dc), dY.shape[1]
             e.Y, e.ld_y = (_ptr(Y, ly.dc) if ly.relu else None), Y.shape[1]
             e.X, e.ld_x = _ptr(X, ly.sc), X.shape[1]
@@ -399,7 +406,7 @@ class MlpPolicy:
             touched.add(key)
             keep.append(dX)
         d.n_layers = n
-        need = int(L.vf_mlp_backward_blocks(M)) * self.log_std_off
+        need = int(L.vf_mlp_backward_partial_floats(C.byref(d), M))
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
         self._pack()
