@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* vf_stream_t;
 
-enum { VF_OK = 0, VF_EINVAL = -1, VF_EHIP = -2, VF_ESTATE = -3 };
+enum { VF_OK = 0, VF_EINVAL = -1, VF_EHIP = -2, VF_ESTATE = -3, VF_EUNSUPPORTED = -4 };
 
 /* ---- state slab: wave-tile AoSoA with 16-byte granules -------------------------------
  * The reference keeps component-major (C, N) tensors (envs/base/dynamics.py:116-123).  On
@@ -364,6 +364,8 @@ typedef struct vf_mlp_desc {
  * table implies. */
 int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc);
 int vf_mlp_pack_weights(const vf_mlp_desc* desc, const float* params, float* packed, vf_stream_t stream);
+/* out1 == NULL: the caller does not need the value head -- the register-chained kernel then skips the value trunk
+ * (its saved activations are left untouched); layer tables that run on the LDS kernel return VF_EUNSUPPORTED. */
 int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
                    const float* in2, const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream);
 
@@ -405,6 +407,19 @@ int32_t vf_mlp_backward_blocks(int32_t M);
 int64_t vf_mlp_backward_partial_floats(const vf_mlp_bwd_desc* desc, int32_t M);
 int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* partials, float* grad, int32_t M,
                     int32_t accumulate, vf_stream_t stream);
+/* The two halves of the register-chained backward, for callers that reduce the weight gradient over several batches
+ * at once (BPTT: one weight-gradient launch per horizon instead of one per step, BPTT.py:107-129):
+ *   vf_mlp_backward_data   reverse chain only: leaves the ReLU-masked gradient of every hidden layer in its dY buffer and
+ *                          (need_dx on the first layers) dLoss/d observation in dX; VF_EUNSUPPORTED if the layer table is
+ *                          not an instantiated network class / variant (vf_mlp_backward_data_supported: 1 / 0)
+ *   vf_mlp_weight_grad     dW / db of every listed layer from dY (masked, as left by vf_mlp_backward_data) and X over M
+ *                          rows + fold into grad; any layer table.  With the buffers of n batches stored back to back
+ *                          (row stride unchanged) one call with M = n * rows covers them all.
+ *                          partials: vf_mlp_backward_partial_floats(desc, M) floats. */
+int vf_mlp_backward_data_supported(const vf_mlp_bwd_desc* desc);
+int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32_t M, vf_stream_t stream);
+int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
+                       vf_stream_t stream);
 
 /* Training-log statistics of one env step (PPO._dump_logs, utils/algorithms/PPO.py:392-414): acc4 (fp64, device) +=
  * {episodes finished this step, sum of their returns, sum of their lengths, successes}, from the step outputs

@@ -433,3 +433,41 @@ def test_chain_backward_vs_torch_and_block_tile_kernel(M, net, mode):
     pol.forward(obs)
     pol.backward(d_mean, d_value, None, accumulate=True, need_input_grad=ig)
     assert torch.allclose(pol.grad, 2 * res[True][0], rtol=1e-5, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize("shape", ["reference", "other"])
+def test_policy_only_forward_and_split_backward(shape):
+    """need_value=False: same action mean (the register-chained kernel skips the value trunk, other layer tables fall
+    back to the full forward); backward_data + weight_grad_slots over reserved slots == per-slot backward, summed"""
+    from visfly_amd.ppo import MlpPolicy
+    ext = {"state": [128, 64]} if shape == "reference" else {"state": [96, 64]}
+    pol = MlpPolicy({"state": 13}, ext, [64, 64], [64, 64], DEV, seed=21)
+    M, n = 777, 3
+    g = torch.Generator(device=DEV).manual_seed(5)
+    obs = [{"state": torch.randn((M, 13), device=DEV, generator=g)} for _ in range(n)]
+    m_full, v_full = pol.forward(obs[0])
+    m_full = m_full.clone()
+    m_pi, v_pi = pol.forward(obs[0], need_value=False)
+    assert v_pi is None and torch.equal(m_pi, m_full)
+    d_means = torch.randn((n, M, 4), device=DEV, generator=g) / M
+    # reference: per-slot fused backward, accumulated
+    pol.grad.zero_()
+    want_in = []
+    for s in range(n):
+        pol.forward(obs[s], slot=s, need_value=False)
+        want_in.append(pol.backward(d_means[s], None, None, accumulate=True, need_input_grad=True, slot=s)["state"].clone())
+    want = pol.grad.clone()
+    if not pol.backward_data_supported(M):
+        assert shape == "other"
+        return
+    assert shape == "reference"
+    pol.reserve_slots(M, n)
+    pol.grad.zero_()
+    for s in range(n):
+        pol.forward(obs[s], slot=s, need_value=False)
+    for s in reversed(range(n)):
+        got_in = pol.backward_data(d_means[s], slot=s)["state"]
+        assert torch.equal(got_in, want_in[s])
+    pol.weight_grad_slots(M, n, d_means, accumulate=True)
+    scale = want.abs().max().item()
+    assert (pol.grad - want).abs().max().item() <= 2e-6 * scale

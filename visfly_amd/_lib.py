@@ -69,6 +69,7 @@ class DynCfg(C.Structure):
         return c
 
 
+EUNSUPPORTED = -4         # VF_EUNSUPPORTED
 ABI_VERSION = 3          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
 MAX_GATES, MAX_SPAWN = 8, 4
 
@@ -207,6 +208,9 @@ SIGNATURES = {
     "vf_mlp_backward_blocks": (C.c_int32, [C.c_int32]),
     "vf_mlp_backward_partial_floats": (C.c_int64, [C.POINTER(MlpBwdDesc), C.c_int32]),
     "vf_mlp_backward": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "vf_mlp_backward_data_supported": (C.c_int, [C.POINTER(MlpBwdDesc)]),
+    "vf_mlp_backward_data": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, C.c_int32, _vp]),
+    "vf_mlp_weight_grad": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),

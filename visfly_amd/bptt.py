@@ -80,6 +80,7 @@ class BPTT:
                                 pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed)
         self.policy.lazy_pack = True        # this trainer calls mark_updated() after every optimiser step
         self.use_autograd = False           # True: torch.autograd schedules the same kernels (cross-check path)
+        self._defer_wgrad = None            # decided at the first update (MlpPolicy.backward_data_supported)
         n = self.policy.n_params
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=self.device), th.zeros(n, device=self.device)
         self._sumsq, self._scratch = th.zeros(1, device=self.device), th.zeros(4096, device=self.device)
@@ -103,6 +104,13 @@ class BPTT:
         env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
         L, st, dev = _lib.lib(), _lib.current_stream(self.device), self.device
         pol.grad.zero_()
+        if self._defer_wgrad is None:
+            # reference-default policy shapes: the weight gradient is reduced ONCE per horizon over the rows of all H
+            # steps (their activations / masked gradients are stored back to back), the per-step reverse pass is the
+            # register-chained data-gradient kernel only
+            pol.reserve_slots(N, H)
+            self._defer_wgrad = pol.backward_data_supported(N)
+        defer = self._defer_wgrad
         disc, loss_vec = th.ones(N, device=dev), th.zeros(N, device=dev)
         g_ls = th.zeros((N, 4), device=dev)
         log_std = pol.log_std
@@ -110,7 +118,7 @@ class BPTT:
         obs = env.get_observation()
         acts, epss, drews = [], [], []
         for t in range(H):
-            mean, _ = pol.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, slot=t)
+            mean, _ = pol.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, slot=t, need_value=False)
             eps = th.randn((N, 4), device=dev, generator=self._gen)
             action = th.empty((N, 4), device=dev)
             _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(eps), _ptr(action), N, st))
@@ -121,12 +129,19 @@ class BPTT:
             _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(d_rew),
                                             float(self.gamma), 1.0 / (N * self.world), N, st))
             acts.append(action); epss.append(eps); drews.append(d_rew)
-        g_obs, d_mean = None, th.empty((N, 4), device=dev)
+        g_obs = None
+        d_means = th.empty((H, N, 4), device=dev)
         for t in reversed(range(H)):
             d_action = env.backward_step(t0 + t, g_obs, drews[t])
+            d_mean = d_means[t]
             _lib.check(L.vf_reparam_bwd(_ptr(d_action), _ptr(acts[t]), _ptr(log_std), _ptr(epss[t]), _ptr(d_mean), _ptr(g_ls), N, st))
-            d_in = pol.backward(d_mean, None, None, accumulate=True, need_input_grad=t > 0, slot=t)
+            if defer:
+                d_in = pol.backward_data(d_mean, slot=t)      # (step 0's observation gradient is computed but unused)
+            else:
+                d_in = pol.backward(d_mean, None, None, accumulate=True, need_input_grad=t > 0, slot=t)
             g_obs = d_in.get("state") if t > 0 else None
+        if defer:
+            pol.weight_grad_slots(N, H, d_means, accumulate=True)
         pol.grad[pol.log_std_off:] = g_ls.sum(dim=0)
         return loss_vec.mean() / self.world
 

@@ -45,11 +45,15 @@ struct ChainLayer {
 };
 
 // NB branches (KA / KB = first-layer widths padded to 8), hidden widths in 32-feature tiles
-template <int NB_, int KA_, int KB_, int E1_, int E2_, int P1_, int P2_, int V1_, int V2_>
+// VF_ = false: the value trunk is not executed (first-order policy optimisation only needs the action mean)
+template <int NB_, int KA_, int KB_, int E1_, int E2_, int P1_, int P2_, int V1_, int V2_, bool VF_ = true>
 struct ChainNet {
     static constexpr int NB = NB_, E1 = E1_, E2 = E2_, P1 = P1_, P2 = P2_, V1 = V1_, V2 = V2_;
+    static constexpr bool VF = VF_;
     static constexpr int kin(int b) { return b == 0 ? KA_ : KB_; }
-    static constexpr int n_layers = 2 * NB + 6;
+    static constexpr int n_layers = 2 * NB + 6;              // layers of the vf_mlp_desc this class matches
+    static constexpr int n_exec = 2 * NB + (VF ? 6 : 3);     // layers the kernel runs
+    static constexpr int L_mean = 2 * NB + 2, L_value = 2 * NB + 5;   // desc indices of the heads
     // tiles: [branch L1 outputs][feat][pi1][pi2][mean][vf1][vf2][value]
     static constexpr int t_e1(int b) { return b * E1; }
     static constexpr int t_feat = NB * E1;
@@ -63,6 +67,13 @@ struct ChainNet {
         if (i < NB) return ChainLayer{2 * i, i, 0, kin(i) / 8, t_e1(i), E1, 1};
         if (i < 2 * NB) return ChainLayer{2 * (i - NB) + 1, -1, t_e1(i - NB), E1, t_feat + (i - NB) * E2, E2, 1};
         const int base = 2 * NB;
+        if (!VF) {
+            switch (i - base) {
+            case 0: return ChainLayer{base + 0, -1, t_feat, NB * E2, t_p1, P1, 1};
+            case 1: return ChainLayer{base + 1, -1, t_p1, P1, t_p2, P2, 1};
+            default: return ChainLayer{base + 2, -1, t_p2, P2, t_mean, 1, 0};
+            }
+        }
         switch (i - base) {
         case 0: return ChainLayer{base + 0, -1, t_feat, NB * E2, t_p1, P1, 1};
         case 1: return ChainLayer{base + 3, -1, t_feat, NB * E2, t_v1, V1, 1};
@@ -77,9 +88,10 @@ struct ChainNet {
     static constexpr int n_items()
     {
         int n = 0;
-        for (int i = 0; i < n_layers; ++i) n += items(i);
+        for (int i = 0; i < n_exec; ++i) n += items(i);
         return n;
     }
+    static constexpr bool is_head(int i) { return layer(i).desc == L_mean || layer(i).desc == L_value; }
     static constexpr int layer_of(int item)
     {
         int i = 0;
@@ -129,9 +141,9 @@ __device__ __forceinline__ void chain_bias_load(const ChainArgs& g, ChainState<N
 {
     constexpr ChainLayer L = N::layer(LI);
     const float* b = g.params + g.d.layer[L.desc].b_off;    // b_off is only dword aligned
-    if constexpr (LI == N::n_layers - 1) {
+    if constexpr (L.desc == N::L_value) {
         st.bias[0][0] = make_float4(b[0], 0.0f, 0.0f, 0.0f);
-    } else if constexpr (LI == N::n_layers - 2) {
+    } else if constexpr (L.desc == N::L_mean) {
         const f32x4u v = *reinterpret_cast<const f32x4u*>(b);
         st.bias[0][0] = make_float4(v.x, v.y, v.z, v.w);
     } else {
@@ -149,11 +161,11 @@ template <class N, int LI>
 __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>& st, int row, int h, bool live)
 {
     constexpr ChainLayer L = N::layer(LI);
-    if constexpr (LI >= N::n_layers - 2) {             // heads: mean (M,4) / value (M,1); only lane half 0 holds them
+    if constexpr (N::is_head(LI)) {                    // heads: mean (M,4) / value (M,1); only lane half 0 holds them
         const f32x16& y = st.t[L.out0];
         const float4 bq = st.bias[0][0];
         if (live && h == 0) {
-            if constexpr (LI == N::n_layers - 2)
+            if constexpr (L.desc == N::L_mean)
                 *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0] + bq.x, y[1] + bq.y, y[2] + bq.z, y[3] + bq.w);
             else g.io.value[row] = y[0] + bq.x;
         }
@@ -178,7 +190,7 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>
 template <class N, int LI, int LOCAL>
 __device__ __forceinline__ void chain_deferred_store(const ChainArgs& g, const ChainState<N>& st, int row, int h, bool live)
 {
-    if constexpr (LI >= 1 && LI - 1 < N::n_layers - 2) {
+    if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
         constexpr ChainLayer P = N::layer(LI - 1);
         constexpr int S = P.nout * 4, per = (S + N::items(LI) - 1) / N::items(LI);
         constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
@@ -556,6 +568,8 @@ __global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
 
 using NetHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2>;   // StateExtractor [128, 64], pi / vf [64, 64]
 using NetNav = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2>;     // StateTargetExtractor [128, 64] x 2, pi / vf [64, 64]
+using NetHoverPi = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, false>;
+using NetNavPi = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2, false>;
 
 // does the layer table describe network class N (shapes, wiring, execution order of MlpPolicy)?
 template <class N>
@@ -656,10 +670,11 @@ int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M,
 {
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
     if (off) return 0;
-    if (bwd_chain_matches<NetNav, true, true, false>(*d)) return bwd_chain_launch<NetNav, true, true, false>(*d, packed, M, st);
-    if (bwd_chain_matches<NetNav, true, false, true>(*d)) return bwd_chain_launch<NetNav, true, false, true>(*d, packed, M, st);
-    if (bwd_chain_matches<NetHover, true, true, false>(*d)) return bwd_chain_launch<NetHover, true, true, false>(*d, packed, M, st);
-    if (bwd_chain_matches<NetHover, true, false, true>(*d)) return bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st);
+    const bool launch = packed != nullptr;       // packed == nullptr: capability query only
+    if (bwd_chain_matches<NetNav, true, true, false>(*d)) return launch ? bwd_chain_launch<NetNav, true, true, false>(*d, packed, M, st) : 1;
+    if (bwd_chain_matches<NetNav, true, false, true>(*d)) return launch ? bwd_chain_launch<NetNav, true, false, true>(*d, packed, M, st) : 1;
+    if (bwd_chain_matches<NetHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetHover, true, true, false>(*d, packed, M, st) : 1;
+    if (bwd_chain_matches<NetHover, true, false, true>(*d)) return launch ? bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st) : 1;
     return 0;
 }
 
@@ -668,7 +683,12 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
                           float* out0, float* out1, int M, hipStream_t st)
 {
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
-    if (off || !out0 || !out1 || (reinterpret_cast<uintptr_t>(out0) & 15)) return 0;
+    if (off || !out0 || (reinterpret_cast<uintptr_t>(out0) & 15)) return 0;
+    if (!out1) {      // no value requested: the value trunk is skipped
+        if (chain_matches<NetNavPi>(*d) && in1) return chain_launch<NetNavPi>(*d, params, packed, in0, in1, out0, out1, M, st);
+        if (chain_matches<NetHoverPi>(*d)) return chain_launch<NetHoverPi>(*d, params, packed, in0, nullptr, out0, out1, M, st);
+        return 0;
+    }
     if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st);
     if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st);
     return 0;

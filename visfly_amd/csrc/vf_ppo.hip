@@ -1510,10 +1510,15 @@ int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* pa
     for (int i = 0; i < desc->n_layers; ++i) {
         const vf_mlp_layer& L = desc->layer[i];
         if (L.K < 1 || L.K > 128 || L.No < 1 || L.No > 128) return vf::fail(VF_EINVAL, "vf_mlp_forward: layer %d: K, No must be 1..128", i);
-        if (L.dst >= VF_MLP_OUT0 && !(L.dst == VF_MLP_OUT0 ? out0 : out1)) return vf::fail(VF_EINVAL, "vf_mlp_forward: missing output %d", L.dst);
     }
-    // reference-default network shapes: activations chained through MFMA accumulator registers (vf_mlp_chain.hip)
+    // reference-default network shapes: activations chained through MFMA accumulator registers (vf_mlp_chain.hip);
+    // out1 == NULL there means "skip the value trunk"
     if (int rc = vf::mlp_forward_chain_try(desc, params, packed, in0, in1, out0, out1, M, vf::as_stream(stream))) return rc < 0 ? rc : VF_OK;
+    for (int i = 0; i < desc->n_layers; ++i) {
+        const vf_mlp_layer& L = desc->layer[i];
+        if (L.dst >= VF_MLP_OUT0 && !(L.dst == VF_MLP_OUT0 ? out0 : out1))
+            return vf::fail(L.dst == VF_MLP_OUT1 ? VF_EUNSUPPORTED : VF_EINVAL, "vf_mlp_forward: missing output %d", L.dst);
+    }
     const size_t lds = (size_t)desc->lds_floats * sizeof(float);
     if (lds > 160 * 1024) return vf::fail(VF_EINVAL, "vf_mlp_forward: LDS plan needs %zu bytes (> 160 KiB)", lds);
     if (int rc = allow_lds(vf::k_mlp_forward, lds)) return rc;
@@ -1600,6 +1605,43 @@ int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* par
     }
     VF_HIP(hipGetLastError());
     return VF_OK;
+}
+
+static int check_bwd_desc(const vf_mlp_bwd_desc* desc, const char* who)
+{
+    if (!desc || desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS || desc->n_fold < 1) return vf::fail(VF_EINVAL, "%s: bad layer count / n_fold", who);
+    for (int i = 0; i < desc->n_layers; ++i) {
+        const vf_mlp_bwd_layer& L = desc->layer[i];
+        if (L.K < 1 || L.K > 128 || L.No < 1 || L.No > 128) return vf::fail(VF_EINVAL, "%s: layer %d: K, No must be 1..128", who, i);
+        if (!L.dY || !L.X || L.ld_dy < L.No || L.ld_x < L.K || (L.Y && L.ld_y < L.No) || (L.need_dx && (!L.dX || L.ld_dx < L.K)))
+            return vf::fail(VF_EINVAL, "%s: layer %d: missing pointer or short row stride", who, i);
+        if (L.w_off < 0 || L.b_off < 0 || L.w_off + (int64_t)L.K * L.No > desc->n_fold || L.b_off + L.No > desc->n_fold)
+            return vf::fail(VF_EINVAL, "%s: layer %d: parameter offsets outside n_fold", who, i);
+    }
+    return VF_OK;
+}
+
+int vf_mlp_backward_data_supported(const vf_mlp_bwd_desc* desc)
+{
+    if (check_bwd_desc(desc, "vf_mlp_backward_data_supported")) return 0;
+    return vf::mlp_backward_chain_try(desc, nullptr, 1, nullptr) == 1 ? 1 : 0;
+}
+
+int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32_t M, vf_stream_t stream)
+{
+    if (!packed || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_backward_data: bad argument");
+    if (int rc = check_bwd_desc(desc, "vf_mlp_backward_data")) return rc;
+    const int rc = vf::mlp_backward_chain_try(desc, packed, M, vf::as_stream(stream));
+    if (rc < 0) return rc;
+    if (rc == 0) return vf::fail(VF_EUNSUPPORTED, "vf_mlp_backward_data: the layer table is not an instantiated network class / variant");
+    return VF_OK;
+}
+
+int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate, vf_stream_t stream)
+{
+    if (!partials || !grad || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad: bad argument");
+    if (int rc = check_bwd_desc(desc, "vf_mlp_weight_grad")) return rc;
+    return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, vf::as_stream(stream));
 }
 
 int vf_reparam_fwd(const float* mean, const float* log_std, const float* eps, float* action, int32_t N, vf_stream_t stream)

@@ -111,6 +111,8 @@ class MlpPolicy:
         self.fused_backward = True
         self._packed, self._pack_desc, self._stamp, self._packed_stamp, self.lazy_pack = None, None, 0, -1, False
         self._pack_map = None
+        self._pi_only_ok = True
+        self._slot_blocks: Dict[int, tuple] = {}
 
     def _plan_fused(self):
         """LDS layout for the one-launch forward (vf_mlp_forward): every activation gets a [64][w|1] region
@@ -273,6 +275,7 @@ class MlpPolicy:
                 self._bufs.clear()
                 self._gbufs.clear()
                 self._descs.clear()
+                self._slot_blocks.clear()
             b = {name: th.empty((M, w), dtype=th.float32, device=self.device) for name, w in self.widths.items()}
             g = self._gbufs.get(M)
             if g is None:
@@ -282,11 +285,31 @@ class MlpPolicy:
             self._bufs[(M, slot)] = b
         return b
 
+    def reserve_slots(self, M, n):
+        """activation / gradient buffers of slots 0..n-1 stored back to back per buffer ([n][M][w]), observations
+        copied in: the rows of all slots then form ONE (n M, w) matrix per buffer, which is what lets
+        ``weight_grad_slots`` reduce the weight gradient of a whole BPTT horizon in one launch"""
+        if self._slot_blocks.get(M, (0,))[0] >= n:
+            return
+        for key in [k for k in self._bufs if k[0] == M]:
+            del self._bufs[key]
+        self._descs = {k: v for k, v in self._descs.items() if k[0] != M}
+        f = dict(dtype=th.float32, device=self.device)
+        blk = {name: th.empty((n, M, w), **f) for name, w in self.widths.items()}
+        blk.update({"g:" + name: th.empty((n, M, w), **f) for name, w in self.widths.items() if name not in ("mean", "value")})
+        blk.update({"obs:" + k: th.empty((n, M, d), **f) for k, d in self.obs_dims.items()})
+        self._slot_blocks[M] = (n, blk)
+        for s in range(n):
+            b = {name: t[s] for name, t in blk.items()}
+            b["_contig"] = True
+            self._bufs[(M, s)] = b
+
     def _stream(self):
         return _lib.current_stream(self.device)
 
-    def forward(self, obs: Dict[str, th.Tensor], save_activations: bool = True, slot: int = 0):
-        """-> mean (M,4), value (M,1).  One launch for the whole network when the LDS plan fits
+    def forward(self, obs: Dict[str, th.Tensor], save_activations: bool = True, slot: int = 0, need_value: bool = True):
+        """-> mean (M,4), value (M,1) (``need_value=False``: value is None and, where the kernel supports it, the value
+        trunk is not run).  One launch for the whole network when the LDS plan fits
         (``self.fused``); ``save_activations`` keeps every layer output in HBM for ``backward``
         (inference passes False and moves only observations in and heads out)."""
         M = obs[self.obs_keys[0]].shape[0]
@@ -295,20 +318,28 @@ class MlpPolicy:
         for k in self.obs_keys:
             t = obs[k]
             assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
-            b["obs:" + k] = t
+            if b.get("_contig"):
+                b["obs:" + k].copy_(t)           # reserved slots own their observation rows
+            else:
+                b["obs:" + k] = t
         self._last_M, self._last_slot = M, slot
         if self._plan is not None and self.fused:
             key = (M, slot, bool(save_activations))
             d = self._descs.get(key)
             if d is None:
                 d = self._descs[key] = self._fused_desc(b, save_activations)
-            ins = [_ptr(obs[k]) for k in self.obs_keys] + [None] * (4 - len(self.obs_keys))
+            ins = [_ptr(b["obs:" + k]) for k in self.obs_keys] + [None] * (4 - len(self.obs_keys))
             self._pack()
+            skip_vf = not need_value and self._pi_only_ok
             rc = L.vf_mlp_forward(C.byref(d), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], ins[2], ins[3],
-                                  _ptr(b["mean"]), _ptr(b["value"]), M, st)
+                                  _ptr(b["mean"]), None if skip_vf else _ptr(b["value"]), M, st)
+            if rc == _lib.EUNSUPPORTED and skip_vf:      # this layer table runs on the LDS kernel: it computes both heads
+                self._pi_only_ok = False
+                rc = L.vf_mlp_forward(C.byref(d), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], ins[2], ins[3],
+                                      _ptr(b["mean"]), _ptr(b["value"]), M, st)
             if rc:
                 _lib.check(rc)
-            return b["mean"], b["value"]
+            return b["mean"], (b["value"] if need_value else None)
         for ly in self.layers:
             X, Y = b[ly.src], b[ly.dst]
             rc = L.vf_linear_fwd(_ptr(X, ly.sc), X.shape[1], _ptr(self.flat, ly.w_off), _ptr(self.flat, ly.b_off),
@@ -368,17 +399,15 @@ class MlpPolicy:
                 self.grad[self.log_std_off:] = d_log_std
         return d_in
 
-    def _backward_fused(self, b, M, d_mean, d_value, d_log_std, accumulate, need_input_grad):
-        """the same sweep as the layer-by-layer path, as ONE launch + one fold (vf_mlp_backward): a block owns
-        its 64-row tiles for every layer, so g:* buffers written by one entry are read by the next without
-        a grid-wide barrier."""
-        L, st = _lib.lib(), self._stream()
+    def _bwd_desc(self, b, M, d_mean, d_value, need_input_grad):
+        """vf_mlp_bwd_desc of the reverse sweep over buffer set b: layers in reverse order, a trunk without head
+        gradient skipped -> (desc, {obs key: dLoss/d obs tensor})"""
         gbuf = {} if d_mean is None else {"mean": d_mean}
         if d_value is not None:
-            gbuf["value"] = d_value.view(M, 1)
+            gbuf["value"] = d_value.view(-1, 1)
         d = _lib.MlpBwdDesc()
         d.n_fold = self.log_std_off
-        touched, d_in, keep, n = set(), {}, [], 0
+        touched, d_in, n = set(), {}, 0
         for ly in reversed(self.layers):
             if d_value is None and (ly.dst == "value" or ly.dst.startswith("vf:")):
                 continue
@@ -389,11 +418,11 @@ class MlpPolicy:
             e = d.layer[n]
             n += 1
             e.K, e.No, e.w_off, e.b_off = ly.K, ly.No, ly.w_off, ly.b_off
-            e.wb_off = self._plan["wb_off"][self.layers.index(ly)]
-            e.wq_off = self._plan["wq_off"][self.layers.index(ly)]
-            e.dY, e.ld_dy = _ptr(dY, ly.dc), dY.shape[1]
-            e.Y, e.ld_y = (_ptr(Y, ly.dc) if ly.relu else None), Y.shape[1]
-            e.X, e.ld_x = _ptr(X, ly.sc), X.shape[1]
+            li = self.layers.index(ly)
+            e.wb_off, e.wq_off = self._plan["wb_off"][li], self._plan["wq_off"][li]
+            e.dY, e.ld_dy = _ptr(dY, ly.dc), dY.shape[-1]
+            e.Y, e.ld_y = (_ptr(Y, ly.dc) if ly.relu else None), Y.shape[-1]
+            e.X, e.ld_x = _ptr(X, ly.sc), X.shape[-1]
             e.need_dx = 0
             if ly.first and not need_input_grad:
                 continue
@@ -402,10 +431,49 @@ class MlpPolicy:
             else:
                 dX = b["g:" + ly.src]
             key = (ly.src, ly.sc)
-            e.dX, e.ld_dx, e.need_dx = _ptr(dX, ly.sc), dX.shape[1], (2 if key in touched else 1)
+            e.dX, e.ld_dx, e.need_dx = _ptr(dX, ly.sc), dX.shape[-1], (2 if key in touched else 1)
             touched.add(key)
-            keep.append(dX)
         d.n_layers = n
+        return d, d_in
+
+    def backward_data_supported(self, M, slot=0):
+        """can ``backward_data`` (policy trunk + observation gradient) run for this network?"""
+        if self._plan is None or not self.fused_backward:
+            return False
+        b = self._buffers(M, slot)
+        dm = th.empty((M, 4), dtype=th.float32, device=self.device)
+        d, _ = self._bwd_desc(b, M, dm, None, True)
+        return bool(_lib.lib().vf_mlp_backward_data_supported(C.byref(d)))
+
+    def backward_data(self, d_mean, slot):
+        """reverse chain of slot `slot` only (policy trunk): masked layer gradients stay in the slot's g: buffers for
+        ``weight_grad_slots``; -> {obs key: dLoss/d obs}"""
+        M = d_mean.shape[0]
+        b = self._buffers(M, slot)
+        d, d_in = self._bwd_desc(b, M, d_mean, None, True)
+        self._pack()
+        _lib.check(_lib.lib().vf_mlp_backward_data(C.byref(d), _ptr(self._packed), M, self._stream()))
+        return d_in
+
+    def weight_grad_slots(self, M, n, d_mean_all, accumulate=False):
+        """weight / bias gradients of the policy trunk + extractors summed over slots 0..n-1 (reserved with
+        ``reserve_slots``; d_mean_all (n, M, 4) holds the head gradients the ``backward_data`` calls were given)"""
+        nblk, blk = self._slot_blocks[M]
+        assert n <= nblk and d_mean_all.shape == (n, M, 4) and d_mean_all.is_contiguous()
+        b = {name: t.view(-1, t.shape[-1]) for name, t in blk.items()}
+        d, _ = self._bwd_desc(b, n * M, d_mean_all.view(-1, 4), None, False)
+        L = _lib.lib()
+        need = int(L.vf_mlp_backward_partial_floats(C.byref(d), n * M))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = th.empty(need, dtype=th.float32, device=self.device)
+        _lib.check(L.vf_mlp_weight_grad(C.byref(d), _ptr(self._scratch), _ptr(self.grad), n * M, 1 if accumulate else 0, self._stream()))
+
+    def _backward_fused(self, b, M, d_mean, d_value, d_log_std, accumulate, need_input_grad):
+        """the same sweep as the layer-by-layer path, as ONE launch + one fold (vf_mlp_backward): a block owns
+        its 64-row tiles for every layer, so g:* buffers written by one entry are read by the next without
+        a grid-wide barrier."""
+        L, st = _lib.lib(), self._stream()
+        d, d_in = self._bwd_desc(b, M, d_mean, d_value, need_input_grad)
         need = int(L.vf_mlp_backward_partial_floats(C.byref(d), M))
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)

@@ -75,7 +75,7 @@ class SHAC(BPTT):
         b = self._buf
         # next action of the (stochastic) actor on the new observation, Q-target on (obs', a') -- all detached (:242-247)
         mean, _ = self.policy.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, save_activations=False,
-                                      slot=self.H)      # a slot of its own: the horizon's activations stay intact
+                                      slot=self.H, need_value=False)      # a slot of its own: the horizon's activations stay intact
         eps = th.randn((N, 4), device=dev, generator=self._gen)
         nxt = th.empty((N, 4), device=dev)
         _lib.check(_lib.lib().vf_reparam_fwd(_ptr(mean), _ptr(self.policy.log_std), _ptr(eps), _ptr(nxt), N,
