@@ -458,7 +458,8 @@ def test_policy_only_forward_and_split_backward(shape):
         want_in.append(pol.backward(d_means[s], None, None, accumulate=True, need_input_grad=True, slot=s)["state"].clone())
     want = pol.grad.clone()
     if not pol.backward_data_supported(M):
-        assert shape == "other"
+        import os
+        assert shape == "other" or os.environ.get("VISFLY_AMD_MLP_CHAIN") == "0"     # A/B switch of the chain kernels
         return
     assert shape == "reference"
     pol.reserve_slots(M, n)
