@@ -473,6 +473,19 @@ typedef struct vf_adam_cfg {
     float* packed;
 } vf_adam_cfg;
 
+/* One PPO minibatch step up to the weight gradients, for the network classes of the register-chained kernels: forward +
+ * vf_ppo_loss + reverse chain in ONE launch (a wave carries 32 rows through the network, evaluates their loss terms on the
+ * head outputs in its registers and walks back, masking with its own still-live activations), then the loss-statistic
+ * fold.  fwd: the forward layer table with every `save` pointer set; bwd: the backward table (both trunks, no observation
+ * gradient) whose head entries' dY buffers receive d_mean (M,4) / d_value (M,).  Afterwards the dY buffers hold the masked
+ * layer gradients: call vf_mlp_weight_grad(bwd, ...) for dW / db.  stats / cfg / scratch as in vf_ppo_loss (scratch >=
+ * 16 * ceil(M / 32) floats, M <= 32768).  VF_EUNSUPPORTED: not an instantiated class -> use vf_mlp_forward, vf_ppo_loss,
+ * vf_mlp_backward. */
+int vf_ppo_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const float* params, const float* packed,
+                  const float* in0, const float* in1, const float* log_std, const float* action, const float* old_log_prob,
+                  const float* adv, const float* ret, float* stats, int32_t M, const vf_ppo_loss_cfg* cfg, float* scratch,
+                  vf_stream_t stream);
+
 /* clip_grad_norm_ + torch.optim.Adam (weight_decay as L2) over one flat fp32 parameter buffer
  * (PPO.py:285-292).  grad_sumsq: device fp32[1] = sum of squares of the (already all-reduced) gradient,
  * produced by vf_sumsq.  */

@@ -472,3 +472,41 @@ def test_policy_only_forward_and_split_backward(shape):
     pol.weight_grad_slots(M, n, d_means, accumulate=True)
     scale = want.abs().max().item()
     assert (pol.grad - want).abs().max().item() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("net", ["nav", "hover"])
+@pytest.mark.parametrize("B", [25600, 1000, 33])
+def test_fused_ppo_update_equals_separate_launches(net, B):
+    """vf_ppo_update (forward + loss + reverse chain in one launch, masks from the live forward registers) + vf_mlp_weight_grad
+    vs forward / vf_ppo_loss / backward: same statistics, same gradient (up to fp32 summation order)"""
+    from visfly_amd.ppo import MlpPolicy
+    _lib, lib = L()
+    dims = {"state": 13, "target": 3} if net == "nav" else {"state": 13}
+    pol = MlpPolicy(dims, {k: [128, 64] for k in dims}, [64, 64], [64, 64], DEV, seed=5, log_std_init=-0.3)
+    g = torch.Generator(device=DEV).manual_seed(B)
+    obs = {k: torch.randn((B, d), device=DEV, generator=g) for k, d in dims.items()}
+    mean, value = pol.forward(obs)
+    actions = torch.tanh(mean + 0.7 * torch.randn((B, 4), device=DEV, generator=g)).contiguous()
+    old_lp = sb3_squashed_log_prob(mean, pol.log_std, actions) + 0.3 * torch.randn(B, device=DEV, generator=g)
+    adv, ret = torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g)
+    scratch = torch.zeros(16 * 1024, device=DEV)
+    res = {}
+    for fused in (True, False):
+        stats = torch.zeros(16, device=DEV)
+        pol.grad.fill_(3.0)
+        cfg = _lib.PpoLossCfg(0.2, 0.01, 0.5, 1.0 / B, pol.grad.data_ptr() + 4 * pol.log_std_off, None)
+        if fused:
+            assert pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch)
+        else:
+            m, v = pol.forward(obs)
+            d_mean, d_value = torch.empty((B, 4), device=DEV), torch.empty(B, device=DEV)
+            _lib.check(lib.vf_ppo_loss(m.data_ptr(), v.data_ptr(), pol.log_std.data_ptr(), actions.data_ptr(), old_lp.data_ptr(),
+                                       adv.data_ptr(), ret.data_ptr(), d_mean.data_ptr(), d_value.data_ptr(), stats.data_ptr(), B,
+                                       C.byref(cfg), scratch.data_ptr(), st()))
+            pol.backward(d_mean, d_value, None)
+        res[fused] = (pol.grad.clone(), stats.clone())
+    (g1, s1), (g0, s0) = res[True], res[False]
+    assert torch.allclose(s1[:9], s0[:9], rtol=2e-5, atol=1e-6 * max(1.0, s0[:9].abs().max().item())), (s1, s0)
+    scale = g0.abs().max().item()
+    assert (g1 - g0).abs().max().item() <= 5e-6 * scale, ((g1 - g0).abs().max().item(), scale)
+    assert torch.allclose(g1[pol.log_std_off:], g0[pol.log_std_off:], rtol=1e-4, atol=1e-7)

@@ -56,6 +56,9 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
 
 // reverse chain (data gradients) for the same network classes: 1 launched, 0 no match, < 0 error
 int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st);
+int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,
+                         const float* in1, const float* log_std, const float* action, const float* old_lp, const float* adv,
+                         const float* ret, float* part, const vf_ppo_loss_cfg* cfg, int M, hipStream_t st);
 // vf_mlp_wgrad.hip: weight / bias gradients of every listed layer from dY (masked) and X, + fold into grad
 int64_t mlp_wgrad_partial_floats(const vf_mlp_bwd_desc* d, int M);
 int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, hipStream_t st);

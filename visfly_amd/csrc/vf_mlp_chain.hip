@@ -20,6 +20,9 @@
 // ReLU layers with a 4-wide / 1-wide head.  vf_mlp_forward picks it when the layer table matches an instantiated
 // shape and falls back to the LDS kernel (k_mlp_forward) otherwise.
 #include "vf_common.hpp"
+#include "vf_ppo_device.hpp"
+
+#include <type_traits>
 
 namespace vf {
 
@@ -92,6 +95,19 @@ struct ChainNet {
         return n;
     }
     static constexpr bool is_head(int i) { return layer(i).desc == L_mean || layer(i).desc == L_value; }
+    // first output tile of desc layer fl (MlpPolicy order)
+    static constexpr int tile_of_layer(int fl)
+    {
+        if (fl < 2 * NB) return (fl & 1) ? t_feat + (fl >> 1) * E2 : t_e1(fl >> 1);
+        switch (fl - 2 * NB) {
+        case 0: return t_p1;
+        case 1: return t_p2;
+        case 2: return t_mean;
+        case 3: return t_v1;
+        case 4: return t_v2;
+        default: return t_val;
+        }
+    }
     static constexpr int layer_of(int item)
     {
         int i = 0;
@@ -162,12 +178,15 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>
 {
     constexpr ChainLayer L = N::layer(LI);
     if constexpr (N::is_head(LI)) {                    // heads: mean (M,4) / value (M,1); only lane half 0 holds them
-        const f32x16& y = st.t[L.out0];
+        f32x16& y = st.t[L.out0];
         const float4 bq = st.bias[0][0];
-        if (live && h == 0) {
-            if constexpr (L.desc == N::L_mean)
-                *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0] + bq.x, y[1] + bq.y, y[2] + bq.z, y[3] + bq.w);
-            else g.io.value[row] = y[0] + bq.x;
+        y[0] += bq.x; y[1] += bq.y; y[2] += bq.z; y[3] += bq.w;
+        if (live && h == 0) {                          // (the fused PPO kernel keeps the heads in registers: no pointers)
+            if constexpr (L.desc == N::L_mean) {
+                if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+                if (g.io.value) g.io.value[row] = y[0];
+            }
         }
     } else {
 #pragma unroll
@@ -310,6 +329,7 @@ struct BwdOp {
 
 template <class N, bool PI, bool VF, bool IG>
 struct BwdProg {
+    using Net = N;
     static constexpr int NB = N::NB;
     static constexpr int L_pi0 = 2 * NB, L_pi1 = 2 * NB + 1, L_mean = 2 * NB + 2, L_vf0 = 2 * NB + 3, L_vf1 = 2 * NB + 4, L_val = 2 * NB + 5;
     // gradient tiles
@@ -420,8 +440,10 @@ __device__ __forceinline__ void bwd_mask_load(const BwdArgsChain& g, BwdState<P>
     }
 }
 
-template <class P, int OI>
-__device__ __forceinline__ void bwd_finalize(const BwdArgsChain& g, BwdState<P>& st, int row, int h, bool live)
+struct NoFwd {};     // FS of the stand-alone reverse chain: masks are read back from HBM
+
+template <class P, class FS, int OI>
+__device__ __forceinline__ void bwd_finalize(const BwdArgsChain& g, BwdState<P>& st, const FS& fs, int row, int h, bool live)
 {
     constexpr BwdOp O = P::op(OI);
 #pragma unroll
@@ -431,7 +453,12 @@ __device__ __forceinline__ void bwd_finalize(const BwdArgsChain& g, BwdState<P>&
             f32x16& v = st.t[O.fin[f].t0 + a];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 y = st.ym[O.fin[f].ym0 + a][q];
+                float4 y;
+                if constexpr (std::is_same<FS, NoFwd>::value) y = st.ym[O.fin[f].ym0 + a][q];
+                else {      // fused kernel: the forward's own accumulator tile of that layer is still in registers
+                    const f32x16& t = fs.t[P::Net::tile_of_layer(O.fin[f].fl) + a];
+                    y = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+                }
                 v[4 * q + 0] = y.x > 0.0f ? v[4 * q + 0] : 0.0f;
                 v[4 * q + 1] = y.y > 0.0f ? v[4 * q + 1] : 0.0f;
                 v[4 * q + 2] = y.z > 0.0f ? v[4 * q + 2] : 0.0f;
@@ -476,8 +503,8 @@ __device__ __forceinline__ void bwd_deferred_store(const BwdArgsChain& g, const 
     }
 }
 
-template <class P, int I>
-__device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st, int lane, int row, int rc, bool live)
+template <class P, class FS, int I>
+__device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st, const FS& fs, int lane, int row, int rc, bool live)
 {
     if constexpr (I < P::n_items()) {
         constexpr int oi = P::op_of(I), local = I - P::first_item(oi);
@@ -486,7 +513,7 @@ __device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st
         const int h = lane >> 5;
         const float4 w = st.ring[I % kChainDepth];
         if constexpr (I + kChainDepth < P::n_items()) st.ring[I % kChainDepth] = bwd_load<P, I + kChainDepth>(g, lane);
-        if constexpr (local == 0 && O.in_kind == 0) bwd_mask_load<P, oi>(g, st, rc, h);   // head ops: loaded in the prologue
+        if constexpr (local == 0 && O.in_kind == 0 && std::is_same<FS, NoFwd>::value) bwd_mask_load<P, oi>(g, st, rc, h);   // head ops: in the prologue
         f32x16& acc = st.t[O.out0 + a];
         if constexpr (gq == 0 && !O.accum) acc = f32x16{0};
 #pragma unroll
@@ -498,8 +525,8 @@ __device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st
         }
         bwd_deferred_store<P, oi, local>(g, st, row, h, live);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (local == P::items(oi) - 1) bwd_finalize<P, oi>(g, st, row, h, live);
-        bwd_items<P, I + 1>(g, st, lane, row, rc, live);
+        if constexpr (local == P::items(oi) - 1) bwd_finalize<P, FS, oi>(g, st, fs, row, h, live);
+        bwd_items<P, FS, I + 1>(g, st, fs, lane, row, rc, live);
     }
 }
 
@@ -562,8 +589,87 @@ __global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
     BwdState<P> st;
     bwd_prologue<P, 0>(g, st, lane);
     bwd_head_prologue<P, 0>(g, st, rc, h);
-    bwd_items<P, 0>(g, st, lane, row, rc, live);
+    bwd_items<P, NoFwd, 0>(g, st, NoFwd{}, lane, row, rc, live);
     bwd_tail_store<P>(g, st, row, h, live);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PPO minibatch step, everything that is per-row in ONE launch: forward chain -> clipped-surrogate loss of the wave's
+// 32 rows (their head outputs never leave the registers) -> reverse chain, whose ReLU masks are the forward's own
+// accumulator tiles (still live), so nothing is read back.  Left in HBM for the weight-gradient kernel: the layer
+// inputs X (forward's saved copies), the masked gradients dZ, d_mean / d_value; per wave one row of loss-statistic
+// partials (folded by the loss kernel's k_fold_stats).
+// ------------------------------------------------------------------------------------------------
+struct PpoRowArgs {
+    const float* log_std;
+    const float4* action;
+    const float* old_lp;
+    const float* adv;
+    const float* ret;
+    float* part;             // [n_waves][kStats]
+    vf_ppo_loss_cfg cfg;
+};
+
+template <class N>
+__global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, const BwdArgsChain gb, const PpoRowArgs pr)
+{
+    using P = BwdProg<N, true, true, false>;
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int row = blockIdx.x * 32 + m;
+    const bool live = row < g.M;
+    const int rc = live ? row : g.M - 1;
+    ChainState<N> fs;
+    chain_prologue<N, 0>(g, fs, lane);
+#pragma unroll
+    for (int b = 0; b < N::NB; ++b) {
+        const int w = g.d.in_dim[b];
+        const float* x = g.io.in[b] + (size_t)rc * w;
+#pragma unroll
+        for (int s = 0; s < N::kin(b) / 2; ++s) {
+            const int k = 2 * s + h;
+            const float v = x[k < w ? k : w - 1];
+            fs.x[b][s] = k < w ? v : 0.0f;
+        }
+    }
+    // per-row loss inputs: issued before the forward so that they have arrived when it ends
+    const float4 a4 = pr.action[rc];
+    const float old_lp = pr.old_lp[rc], adv = pr.adv[rc], ret = pr.ret[rc];
+    const float ls[4] = {pr.log_std[0], pr.log_std[1], pr.log_std[2], pr.log_std[3]};
+    chain_items<N, 0>(g, fs, lane, row, live);
+    BwdState<P> bs;
+    bwd_prologue<P, 0>(gb, bs, lane);                  // first weight blocks of the reverse chain: in flight during the loss arithmetic
+    // ---- loss of this lane's row (lane half 0 holds mean[0..3] / value in registers 0..3 / 0 of the head tiles) ----
+    float stt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dm[4] = {0, 0, 0, 0}, dvl = 0.0f;
+    {
+        const f32x16& mt = fs.t[N::t_mean];
+        const float mu[4] = {mt[0], mt[1], mt[2], mt[3]}, a[4] = {a4.x, a4.y, a4.z, a4.w};
+        float st1[9], dm1[4], dv1;
+        ppo_row(mu, fs.t[N::t_val][0], ls, a, old_lp, adv, ret, pr.cfg, dm1, dv1, st1);
+        const bool on = live && h == 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) stt[k] = on ? st1[k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dm[k] = on ? dm1[k] : 0.0f;
+        dvl = on ? dv1 : 0.0f;
+        if (on) {         // head gradients: dZ of the head layers for the weight-gradient kernel
+            const vf_mlp_bwd_layer& Em = gb.d.layer[P::entry(P::L_mean)];
+            const vf_mlp_bwd_layer& Ev = gb.d.layer[P::entry(P::L_val)];
+            *reinterpret_cast<float4*>(const_cast<float*>(Em.dY) + (size_t)row * Em.ld_dy) = make_float4(dm[0], dm[1], dm[2], dm[3]);
+            const_cast<float*>(Ev.dY)[(size_t)row * Ev.ld_dy] = dvl;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float s = stt[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) pr.part[(size_t)blockIdx.x * kStats + k] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bs.hin[0][k] = dm[k];
+    bs.hin[1][0] = dvl; bs.hin[1][1] = 0.0f; bs.hin[1][2] = 0.0f; bs.hin[1][3] = 0.0f;
+    bwd_items<P, ChainState<N>, 0>(gb, bs, fs, lane, row, rc, live);
+    bwd_tail_store<P>(gb, bs, row, h, live);
 }
 
 using NetHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2>;   // StateExtractor [128, 64], pi / vf [64, 64]
@@ -676,6 +782,31 @@ int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M,
     if (bwd_chain_matches<NetHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetHover, true, true, false>(*d, packed, M, st) : 1;
     if (bwd_chain_matches<NetHover, true, false, true>(*d)) return launch ? bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st) : 1;
     return 0;
+}
+
+// fused PPO step (forward + loss + reverse chain): 1 launched, 0 not an instantiated class, < 0 error.
+// part: ceil(M / 32) x kStats floats of loss-statistic partials
+int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,
+                         const float* in1, const float* log_std, const float* action, const float* old_lp, const float* adv,
+                         const float* ret, float* part, const vf_ppo_loss_cfg* cfg, int M, hipStream_t st)
+{
+    static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
+    if (off) return 0;
+    for (int i = 0; i < d->n_layers; ++i)
+        if (d->layer[i].dst < VF_MLP_OUT0 && !d->layer[i].save) return 0;          // the weight gradients need every layer input
+    ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M};
+    BwdArgsChain gb{*bd, packed, M};
+    PpoRowArgs pr{log_std, reinterpret_cast<const float4*>(action), old_lp, adv, ret, part, *cfg};
+    const dim3 grid((M + 31) / 32);
+    if (chain_matches<NetNav>(*d) && in1 && bwd_chain_matches<NetNav, true, true, false>(*bd)) {
+        hipLaunchKernelGGL(k_ppo_update_chain<NetNav>, grid, dim3(64), 0, st, g, gb, pr);
+    } else if (chain_matches<NetHover>(*d) && bwd_chain_matches<NetHover, true, true, false>(*bd)) {
+        hipLaunchKernelGGL(k_ppo_update_chain<NetHover>, grid, dim3(64), 0, st, g, gb, pr);
+    } else {
+        return 0;
+    }
+    VF_HIP(hipGetLastError());
+    return 1;
 }
 
 // 1: launched, 0: the layer table is not one of the instantiated network classes, < 0: error

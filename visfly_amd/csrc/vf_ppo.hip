@@ -12,6 +12,7 @@
 #include <utility>
 
 #include "vf_common.hpp"
+#include "vf_ppo_device.hpp"
 #include "vf_env_device.hpp"  // Philox
 
 namespace vf {
@@ -1042,29 +1043,6 @@ __global__ __launch_bounds__(kBlock) void k_fold_partials(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // Squashed diagonal Gaussian head
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float atanh_clamped(float a)
-{
-    // TanhBijector.inverse: atanh(clamp(a, -1 + eps, 1 - eps)), eps = float32 eps
-    const float eps = 1.1920929e-07f;
-    const float x = fminf(fmaxf(a, -1.0f + eps), 1.0f - eps);
-    return 0.5f * (log1pf(x) - log1pf(-x));
-}
-
-// log N(g; mu, sigma) summed over 4 dims minus the tanh correction sum log(1 - a^2 + 1e-6)
-__device__ __forceinline__ float squashed_log_prob(const float* mu, const float* ls, const float* a, float* g)
-{
-    float lp = 0.0f;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        g[d] = atanh_clamped(a[d]);
-        const float sd = expf(ls[d]);
-        const float z = (g[d] - mu[d]) / sd;
-        lp += -0.5f * z * z - ls[d] - 0.91893853320467274178f;
-        lp -= logf(1.0f - a[d] * a[d] + 1e-6f);
-    }
-    return lp;
-}
-
 __global__ __launch_bounds__(kBlock) void k_head_sample(const float4* __restrict__ mean, const float* __restrict__ log_std,
                                                         float4* __restrict__ action, float* __restrict__ logp, int M,
                                                         unsigned long long seed, unsigned long long step, int deterministic)
@@ -1095,7 +1073,6 @@ __global__ __launch_bounds__(kBlock) void k_head_sample(const float4* __restrict
 }
 
 // PPO clipped surrogate + value MSE + "entropy" (= mean log-prob for the squashed head), PPO.py:210-263
-constexpr int kStats = 16;
 __global__ __launch_bounds__(kBlock) void k_ppo_loss(const float4* __restrict__ mean, const float* __restrict__ value,
                                                      const float* __restrict__ log_std, const float4* __restrict__ action,
                                                      const float* __restrict__ old_lp, const float* __restrict__ adv,
@@ -1110,36 +1087,10 @@ __global__ __launch_bounds__(kBlock) void k_ppo_loss(const float4* __restrict__ 
         const float4 m4 = mean[i], a4 = action[i];
         const float mu[4] = {m4.x, m4.y, m4.z, m4.w}, a[4] = {a4.x, a4.y, a4.z, a4.w};
         const float ls[4] = {log_std[0], log_std[1], log_std[2], log_std[3]};
-        float g[4];
-        const float lp = squashed_log_prob(mu, ls, a, g);
-        const float log_ratio = lp - old_lp[i];
-        const float ratio = expf(log_ratio);
-        const float A = adv[i];
-        const float lo = 1.0f - cfg.clip_range, hi = 1.0f + cfg.clip_range;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
-        const float s1 = A * ratio, s2 = A * rc;
-        const bool clipped = ratio < lo || ratio > hi;
-        // d(-min(s1,s2))/d ratio: through s1 when it is the smaller one (or equal: unclipped), else 0
-        const float dl_dratio = (s1 <= s2 || !clipped) ? -A : 0.0f;
-        const float v = value[i], R = ret[i];
-        const float dv = v - R;
-        // d loss / d log_prob per row (means over the global batch)
-        const float dl_dlp = (dl_dratio * ratio + cfg.ent_coef) * cfg.inv_batch;
-        float dm[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const float sd = expf(ls[d]);
-            const float z = (g[d] - mu[d]) / sd;
-            dm[d] = dl_dlp * z / sd;
-            st[5 + d] = dl_dlp * (z * z - 1.0f);
-        }
+        float dm[4], dvl;
+        ppo_row(mu, value[i], ls, a, old_lp[i], adv[i], ret[i], cfg, dm, dvl, st);
         d_mean[i] = make_float4(dm[0], dm[1], dm[2], dm[3]);
-        d_value[i] = cfg.vf_coef * 2.0f * dv * cfg.inv_batch;
-        st[0] = -fminf(s1, s2);
-        st[1] = dv * dv;
-        st[2] = lp;
-        st[3] = (ratio - 1.0f) - log_ratio;
-        st[4] = fabsf(ratio - 1.0f) > cfg.clip_range ? 1.0f : 0.0f;
+        d_value[i] = dvl;
     }
     const int w = threadIdx.x >> 6;
 #pragma unroll
@@ -1197,16 +1148,16 @@ __global__ __launch_bounds__(kBlock) void k_bptt_accumulate(const float* __restr
     disc[i] = d * gamma * (1.0f - dn) + dn;
 }
 
-__global__ void k_fold_stats(const float* __restrict__ part, int nblk, float* __restrict__ stats, float* __restrict__ d_log_std_out,
-                             float* __restrict__ stats_accum)
+__global__ __launch_bounds__(1024) void k_fold_stats(const float* __restrict__ part, int nblk, float* __restrict__ stats,
+                                                     float* __restrict__ d_log_std_out, float* __restrict__ stats_accum)
 {
-    // 16 stats x 16 lanes (256 threads): lane-strided sums over the blocks, shuffle tree over the 16 lanes
-    const int k = threadIdx.x >> 4, sl = threadIdx.x & 15;
+    // 16 stats x 64 lanes (1024 threads, one wave per statistic): lane-strided sums over the partial rows, then a
+    // shuffle tree over the wave -- fixed order, deterministic
+    const int k = threadIdx.x >> 6, sl = threadIdx.x & 63;
     float s = 0.0f;
     if (k < 9)
-        for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * kStats + k];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
+        for (int b = sl; b < nblk; b += 64) s += part[(size_t)b * kStats + k];
+    s = wave_sumf(s);
     if (sl == 0) {
         stats[k] = s;
         if (d_log_std_out && k >= 5 && k < 9) d_log_std_out[k - 5] = s;
@@ -1710,7 +1661,27 @@ int vf_ppo_loss(const float* mean, const float* value, const float* log_std, con
     hipLaunchKernelGGL(vf::k_ppo_loss, dim3(nblk), dim3(vf::kBlock), 0, st, reinterpret_cast<const float4*>(mean), value,
                        log_std, reinterpret_cast<const float4*>(action), old_log_prob, adv, ret,
                        reinterpret_cast<float4*>(d_mean), d_value, scratch, M, *cfg);
-    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(256), 0, st, scratch, nblk, stats, cfg->d_log_std_out, cfg->stats_accum);
+    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(1024), 0, st, scratch, nblk, stats, cfg->d_log_std_out, cfg->stats_accum);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_ppo_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const float* params, const float* packed,
+                  const float* in0, const float* in1, const float* log_std, const float* action, const float* old_log_prob,
+                  const float* adv, const float* ret, float* stats, int32_t M, const vf_ppo_loss_cfg* cfg, float* scratch,
+                  vf_stream_t stream)
+{
+    if (!fwd || !params || !packed || !in0 || !log_std || !action || !old_log_prob || !adv || !ret || !stats || !cfg || !scratch || M <= 0)
+        return vf::fail(VF_EINVAL, "vf_ppo_update: bad argument");
+    if (fwd->n_layers < 1 || fwd->n_layers > VF_MLP_MAX_LAYERS) return vf::fail(VF_EINVAL, "vf_ppo_update: bad layer count");
+    if (int rc = check_bwd_desc(bwd, "vf_ppo_update")) return rc;
+    const int nwaves = (M + 31) / 32;
+    if (nwaves > 1024) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_update: at most 32768 rows per call (scratch contract)");
+    hipStream_t st = vf::as_stream(stream);
+    const int rc = vf::ppo_update_chain_try(fwd, bwd, params, packed, in0, in1, log_std, action, old_log_prob, adv, ret, scratch, cfg, M, st);
+    if (rc < 0) return rc;
+    if (rc == 0) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_update: the layer tables are not an instantiated network class");
+    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(1024), 0, st, scratch, nwaves, stats, cfg->d_log_std_out, cfg->stats_accum);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -112,6 +112,7 @@ class MlpPolicy:
         self._packed, self._pack_desc, self._stamp, self._packed_stamp, self.lazy_pack = None, None, 0, -1, False
         self._pack_map = None
         self._pi_only_ok = True
+        self._fused_ppo = None             # None: untried, False: vf_ppo_update does not support this network
         self._slot_blocks: Dict[int, tuple] = {}
 
     def _plan_fused(self):
@@ -293,7 +294,7 @@ class MlpPolicy:
             return
         for key in [k for k in self._bufs if k[0] == M]:
             del self._bufs[key]
-        self._descs = {k: v for k, v in self._descs.items() if k[0] != M}
+        self._descs = {k: v for k, v in self._descs.items() if M not in k[:2]}
         f = dict(dtype=th.float32, device=self.device)
         blk = {name: th.empty((n, M, w), **f) for name, w in self.widths.items()}
         blk.update({"g:" + name: th.empty((n, M, w), **f) for name, w in self.widths.items() if name not in ("mean", "value")})
@@ -467,6 +468,47 @@ class MlpPolicy:
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
         _lib.check(L.vf_mlp_weight_grad(C.byref(d), _ptr(self._scratch), _ptr(self.grad), n * M, 1 if accumulate else 0, self._stream()))
+
+    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch):
+        """forward + PPO loss + reverse chain in one launch, then the weight gradients into ``self.grad`` (vf_ppo_update +
+        vf_mlp_weight_grad).  -> False when the network is not one of the register-chained classes (the caller then
+        runs forward / vf_ppo_loss / backward)."""
+        if self._fused_ppo is False or self._plan is None or not (self.fused and self.fused_backward):
+            return False
+        M = actions.shape[0]
+        b = self._buffers(M, 0)
+        L, st = _lib.lib(), self._stream()
+        for k in self.obs_keys:
+            t = obs[k]
+            assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
+            if b.get("_contig"):
+                b["obs:" + k].copy_(t)
+            else:
+                b["obs:" + k] = t
+        self._last_M, self._last_slot = M, 0
+        key = (M, 0, True)
+        d = self._descs.get(key)
+        if d is None:
+            d = self._descs[key] = self._fused_desc(b, True)
+        if "d:mean" not in b:
+            b["d:mean"], b["d:value"] = th.empty((M, 4), dtype=th.float32, device=self.device), th.empty(M, dtype=th.float32, device=self.device)
+        bd = self._descs.get(("ppo_bwd", M))
+        if bd is None:
+            bd = self._descs[("ppo_bwd", M)] = self._bwd_desc(b, M, b["d:mean"], b["d:value"], False)[0]
+        ins = [_ptr(b["obs:" + k]) for k in self.obs_keys] + [None] * (2 - len(self.obs_keys))
+        self._pack()
+        rc = L.vf_ppo_update(C.byref(d), C.byref(bd), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], _ptr(self.log_std),
+                             _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret), _ptr(stats), M, C.byref(loss_cfg), _ptr(loss_scratch), st)
+        if rc == _lib.EUNSUPPORTED:
+            self._fused_ppo = False
+            return False
+        if rc:
+            _lib.check(rc)
+        need = int(L.vf_mlp_backward_partial_floats(C.byref(bd), M))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = th.empty(need, dtype=th.float32, device=self.device)
+        _lib.check(L.vf_mlp_weight_grad(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, st))
+        return True
 
     def _backward_fused(self, b, M, d_mean, d_value, d_log_std, accumulate, need_input_grad):
         """the same sweep as the layer-by-layer path, as ONE launch + one fold (vf_mlp_backward): a block owns
@@ -670,15 +712,17 @@ class PPO:
         actions, old_lp, adv, ret = mb["actions"], mb["old_lp"], mb["adv"], mb["ret"]
         B = adv.numel()
         gB = B * self.world
-        mean, value = pol.forward(obs)
-        d_mean, d_value = th.empty((B, 4), device=self.device), th.empty(B, device=self.device)
         # the loss launch also writes d(loss)/d(log_std) into the tail of the flat gradient and adds the minibatch
         # statistics to the epoch accumulator (no separate copy / add launches)
         cfg = _lib.PpoLossCfg(self.clip_range, self.ent_coef, self.vf_coef, 1.0 / gB, _ptr(pol.grad, pol.log_std_off),
                               None if stats_acc is None else _ptr(stats_acc))
-        _lib.check(L.vf_ppo_loss(_ptr(mean), _ptr(value), _ptr(pol.log_std), _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret),
-                                 _ptr(d_mean), _ptr(d_value), _ptr(self._stats), B, C.byref(cfg), _ptr(self._scratch), st))
-        pol.backward(d_mean, d_value, None)
+        # reference-default policy shapes: forward + loss + reverse chain are one launch (vf_ppo_update)
+        if not pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch):
+            mean, value = pol.forward(obs)
+            d_mean, d_value = th.empty((B, 4), device=self.device), th.empty(B, device=self.device)
+            _lib.check(L.vf_ppo_loss(_ptr(mean), _ptr(value), _ptr(pol.log_std), _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret),
+                                     _ptr(d_mean), _ptr(d_value), _ptr(self._stats), B, C.byref(cfg), _ptr(self._scratch), st))
+            pol.backward(d_mean, d_value, None)
         if self.world > 1:
             parallel.allreduce_sum_(pol.grad)      # sum over ranks: every term is already / global batch
         self._opt_step += 1
