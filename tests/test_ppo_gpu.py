@@ -379,7 +379,7 @@ def test_ppo_checkpoint_round_trip_and_reference_yaml_kwargs(tmp_path):
     ppo.learn(16 * 1024 * 2)
     path = ppo.save(str(tmp_path / "PPO_std_1"))
     new = PPO.load(path, make(), seed=3, **alg)
-    assert torch.equal(new.policy.flat, ppo.policy.flat)
+    assert torch.equal(new.policy.flat, ppo.policy.flat), (int((new.policy.flat != ppo.policy.flat).sum()), int(torch.isnan(ppo.policy.flat).sum()), int(torch.isnan(new.policy.flat).sum()))
     assert torch.equal(new.exp_avg, ppo.exp_avg) and torch.equal(new.exp_avg_sq, ppo.exp_avg_sq)
     assert new._opt_step == ppo._opt_step and new.num_timesteps == ppo.num_timesteps
     obs = ppo.env.get_observation()
@@ -496,6 +496,10 @@ def test_fused_ppo_update_equals_separate_launches(net, B):
         pol.grad.fill_(3.0)
         cfg = _lib.PpoLossCfg(0.2, 0.01, 0.5, 1.0 / B, pol.grad.data_ptr() + 4 * pol.log_std_off, None)
         if fused:
+            # a first call on OTHER observation tensors: the cached layer tables must follow the caller's tensors
+            other = {k: torch.randn_like(v) for k, v in obs.items()}
+            assert pol.ppo_update(other, actions, old_lp, adv, ret, cfg, stats, scratch)
+            del other
             assert pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch)
         else:
             m, v = pol.forward(obs)

@@ -492,9 +492,15 @@ class MlpPolicy:
             d = self._descs[key] = self._fused_desc(b, True)
         if "d:mean" not in b:
             b["d:mean"], b["d:value"] = th.empty((M, 4), dtype=th.float32, device=self.device), th.empty(M, dtype=th.float32, device=self.device)
-        bd = self._descs.get(("ppo_bwd", M))
-        if bd is None:
-            bd = self._descs[("ppo_bwd", M)] = self._bwd_desc(b, M, b["d:mean"], b["d:value"], False)[0]
+        cached = self._descs.get(("ppo_bwd", M))
+        if cached is None:
+            bd = self._bwd_desc(b, M, b["d:mean"], b["d:value"], False)[0]
+            # entries whose X is an observation: that pointer is the caller's tensor and changes from call to call
+            firsts = [(i, ly.src) for i, ly in enumerate(reversed(self.layers)) if ly.first]
+            cached = self._descs[("ppo_bwd", M)] = (bd, firsts)
+        bd, firsts = cached
+        for i, src in firsts:
+            bd.layer[i].X = _ptr(b[src])
         ins = [_ptr(b["obs:" + k]) for k in self.obs_keys] + [None] * (2 - len(self.obs_keys))
         self._pack()
         rc = L.vf_ppo_update(C.byref(d), C.byref(bd), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], _ptr(self.log_std),
