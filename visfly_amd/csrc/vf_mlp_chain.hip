@@ -146,8 +146,9 @@ __device__ __forceinline__ float4 chain_load(const ChainArgs& g, int lane)
     constexpr int li = N::layer_of(I), local = I - N::first_item(li);
     constexpr ChainLayer L = N::layer(li);
     constexpr int G = N::groups(li), gq = local / L.nout, a = local % L.nout;
-    const float4* img = reinterpret_cast<const float4*>(g.packed + g.d.layer[L.desc].wr_off);
-    return img[(a * G + gq) * 64 + lane];
+    // wave-uniform base (scalar registers) + 32-bit lane offset: no 64-bit VGPR address arithmetic per load
+    const char* base = reinterpret_cast<const char*>(g.packed + g.d.layer[L.desc].wr_off) + (a * G + gq) * 1024;
+    return *reinterpret_cast<const float4*>(base + (unsigned)lane * 16u);
 }
 
 // widths are compile-time (hidden layers: whole tiles; heads: 4 / 1 features in lane half 0, q = 0), so the bias loads
@@ -216,12 +217,13 @@ __device__ __forceinline__ void chain_deferred_store(const ChainArgs& g, const C
         if constexpr (s0 < s1) {
             const vf_mlp_layer& D = g.d.layer[P.desc];
             if (D.save && live) {
-                float* base = D.save + (size_t)row * D.save_ld + D.dst_col + 4 * h;
+                const unsigned off = (unsigned)row * (unsigned)D.save_ld + 4u * h;     // lane offset, elements
 #pragma unroll
                 for (int i = s0; i < s1; ++i) {
                     const int a = i / 4, q = i % 4;
                     const f32x16& y = st.t[P.out0 + a];
-                    *reinterpret_cast<float4*>(base + 32 * a + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                    float* base = D.save + D.dst_col + 32 * a + 8 * q;               // wave-uniform
+                    *reinterpret_cast<float4*>(base + off) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
                 }
             }
         }
@@ -421,8 +423,8 @@ __device__ __forceinline__ float4 bwd_load(const BwdArgsChain& g, int lane)
     constexpr int oi = P::op_of(I), local = I - P::first_item(oi);
     constexpr BwdOp O = P::op(oi);
     constexpr int gq = local / O.nout, a = local % O.nout;
-    const float4* img = reinterpret_cast<const float4*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off);
-    return img[(a * O.G + gq) * 64 + lane];
+    const char* base = reinterpret_cast<const char*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off) + (a * O.G + gq) * 1024;
+    return *reinterpret_cast<const float4*>(base + (unsigned)lane * 16u);
 }
 
 template <class P, int OI>
@@ -494,9 +496,10 @@ __device__ __forceinline__ void bwd_deferred_store(const BwdArgsChain& g, const 
                 for (int i = s0; i < s1; ++i) {
                     const int f = i < S0 ? 0 : 1, ii = i - (f ? S0 : 0), a = ii / 4, q = ii % 4;
                     const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
-                    float* base = const_cast<float*>(E.dY) + (size_t)row * E.ld_dy + 4 * h;
+                    float* base = const_cast<float*>(E.dY) + 32 * a + 8 * q;            // wave-uniform
+                    const unsigned off = (unsigned)row * (unsigned)E.ld_dy + 4u * h;
                     const f32x16& v = st.t[Q.fin[f].t0 + a];
-                    *reinterpret_cast<float4*>(base + 32 * a + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    *reinterpret_cast<float4*>(base + off) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 }
             }
         }
