@@ -448,10 +448,18 @@ class MlpPolicy:
 
     def backward_data(self, d_mean, slot):
         """reverse chain of slot `slot` only (policy trunk): masked layer gradients stay in the slot's g: buffers for
-        ``weight_grad_slots``; -> {obs key: dLoss/d obs}"""
+        ``weight_grad_slots``; -> {obs key: dLoss/d obs} (for reserved slots the returned tensors are reused by the next
+        call on the same slot)"""
         M = d_mean.shape[0]
         b = self._buffers(M, slot)
-        d, d_in = self._bwd_desc(b, M, d_mean, None, True)
+        cached = self._descs.get(("bwd_data", M, slot)) if b.get("_contig") else None    # reserved slots: fixed buffers
+        if cached is None:
+            d, d_in = self._bwd_desc(b, M, d_mean, None, True)
+            if b.get("_contig"):
+                self._descs[("bwd_data", M, slot)] = (d, d_in)
+        else:
+            d, d_in = cached
+            d.layer[0].dY = _ptr(d_mean)           # entry 0 = action head: its gradient is the caller's tensor
         self._pack()
         _lib.check(_lib.lib().vf_mlp_backward_data(C.byref(d), _ptr(self._packed), M, self._stream()))
         return d_in
