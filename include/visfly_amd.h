@@ -421,6 +421,13 @@ int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32
 int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
                        vf_stream_t stream);
 
+/* Post-step bookkeeping of the rollout loop (SB3 OnPolicyAlgorithm.collect_rollouts; utils/algorithms/PPO.py:146): the
+ * TimeLimit bootstrap reward_out = reward + gamma * V(terminal_observation) where the episode ended by truncation
+ * (done && ep_flags bit 1, vf_env_out.ep_flags), and the next step's episode_start flags = float(done).  One launch instead
+ * of a chain of elementwise tensor ops. */
+int vf_rollout_post(const float* reward, const uint8_t* done, const uint8_t* ep_flags, const float* terminal_value, float gamma,
+                    float* reward_out, float* next_episode_start, int32_t N, vf_stream_t stream);
+
 /* Training-log statistics of one env step (PPO._dump_logs, utils/algorithms/PPO.py:392-414): acc4 (fp64, device) +=
  * {episodes finished this step, sum of their returns, sum of their lengths, successes}, from the step outputs
  * done / ep_return / ep_length / ep_flags (vf_env_out).  No host synchronisation. */

@@ -213,6 +213,7 @@ SIGNATURES = {
     "vf_mlp_weight_grad": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
+    "vf_rollout_post": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _vp, _vp, C.c_int32, _vp]),
     "vf_ppo_update": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpBwdDesc)] + [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     "vf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.POINTER(AdamCfg), _vp]),

@@ -1165,6 +1165,19 @@ __global__ __launch_bounds__(1024) void k_fold_stats(const float* __restrict__ p
     }
 }
 
+// reward + gamma * V(terminal obs) on truncated episodes; next episode_start = float(done)   (SB3 collect_rollouts)
+__global__ __launch_bounds__(kBlock) void k_rollout_post(const float* __restrict__ reward, const uint8_t* __restrict__ done,
+                                                         const uint8_t* __restrict__ ep_flags, const float* __restrict__ tv, float gamma,
+                                                         float* __restrict__ reward_out, float* __restrict__ next_start, int N)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const bool d = done[i] != 0;
+    const float trunc = (d && (ep_flags[i] & 2)) ? 1.0f : 0.0f;
+    reward_out[i] = reward[i] + (gamma * tv[i]) * trunc;
+    next_start[i] = d ? 1.0f : 0.0f;
+}
+
 // episode statistics of one env step for the training log (PPO._dump_logs: rollout/ep_rew_mean, ep_len_mean, success rate;
 // PPO.py:392-414): acc += {episodes finished, sum of their returns, sum of their lengths, successes}.  One block, fixed
 // reduction order, no host synchronisation in the rollout loop.
@@ -1662,6 +1675,17 @@ int vf_ppo_loss(const float* mean, const float* value, const float* log_std, con
                        log_std, reinterpret_cast<const float4*>(action), old_log_prob, adv, ret,
                        reinterpret_cast<float4*>(d_mean), d_value, scratch, M, *cfg);
     hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(1024), 0, st, scratch, nblk, stats, cfg->d_log_std_out, cfg->stats_accum);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_rollout_post(const float* reward, const uint8_t* done, const uint8_t* ep_flags, const float* terminal_value, float gamma,
+                    float* reward_out, float* next_episode_start, int32_t N, vf_stream_t stream)
+{
+    if (!reward || !done || !ep_flags || !terminal_value || !reward_out || !next_episode_start || N <= 0)
+        return vf::fail(VF_EINVAL, "vf_rollout_post: bad argument");
+    hipLaunchKernelGGL(vf::k_rollout_post, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done, ep_flags,
+                       terminal_value, gamma, reward_out, next_episode_start, N);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -308,9 +308,11 @@ class MlpPolicy:
     def _stream(self):
         return _lib.current_stream(self.device)
 
-    def forward(self, obs: Dict[str, th.Tensor], save_activations: bool = True, slot: int = 0, need_value: bool = True):
+    def forward(self, obs: Dict[str, th.Tensor], save_activations: bool = True, slot: int = 0, need_value: bool = True,
+                out_value: Optional[th.Tensor] = None):
         """-> mean (M,4), value (M,1) (``need_value=False``: value is None and, where the kernel supports it, the value
-        trunk is not run).  One launch for the whole network when the LDS plan fits
+        trunk is not run; ``out_value``: the value head is written there -- a (M,) row of the rollout buffer -- instead
+        of the internal buffer).  One launch for the whole network when the LDS plan fits
         (``self.fused``); ``save_activations`` keeps every layer output in HBM for ``backward``
         (inference passes False and moves only observations in and heads out)."""
         M = obs[self.obs_keys[0]].shape[0]
@@ -332,21 +334,25 @@ class MlpPolicy:
             ins = [_ptr(b["obs:" + k]) for k in self.obs_keys] + [None] * (4 - len(self.obs_keys))
             self._pack()
             skip_vf = not need_value and self._pi_only_ok
+            vout = b["value"] if out_value is None else out_value
             rc = L.vf_mlp_forward(C.byref(d), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], ins[2], ins[3],
-                                  _ptr(b["mean"]), None if skip_vf else _ptr(b["value"]), M, st)
+                                  _ptr(b["mean"]), None if skip_vf else _ptr(vout), M, st)
             if rc == _lib.EUNSUPPORTED and skip_vf:      # this layer table runs on the LDS kernel: it computes both heads
                 self._pi_only_ok = False
                 rc = L.vf_mlp_forward(C.byref(d), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], ins[2], ins[3],
-                                      _ptr(b["mean"]), _ptr(b["value"]), M, st)
+                                      _ptr(b["mean"]), _ptr(vout), M, st)
             if rc:
                 _lib.check(rc)
-            return b["mean"], (b["value"] if need_value else None)
+            return b["mean"], (vout if need_value else None)
         for ly in self.layers:
             X, Y = b[ly.src], b[ly.dst]
             rc = L.vf_linear_fwd(_ptr(X, ly.sc), X.shape[1], _ptr(self.flat, ly.w_off), _ptr(self.flat, ly.b_off),
                                  _ptr(Y, ly.dc), Y.shape[1], M, ly.K, ly.No, 1 if ly.relu else 0, st)
             if rc:
                 _lib.check(rc)
+        if out_value is not None:
+            out_value.copy_(b["value"].view(-1))
+            return b["mean"], out_value
         return b["mean"], b["value"]
 
     def backward(self, d_mean: th.Tensor, d_value: Optional[th.Tensor], d_log_std: Optional[th.Tensor],
@@ -691,26 +697,28 @@ class PPO:
             self._last_obs = env.reset()
             self._last_starts = th.ones(self.n_envs, device=self.device)
         obs = self._last_obs
-        EP_TRUNC = 2
+        L, pol, N = _lib.lib(), self.policy, self.n_envs
+        buf.episode_starts[0].copy_(self._last_starts)
         for t in range(self.n_steps):
-            action, value, logp = self._act(obs)
+            # policy.forward (policies.py:195-226) straight into row t of the buffer: value head, sampled action, log-prob
+            action, logp = buf.actions[t], buf.log_probs[t]
+            mean, _ = pol.forward({k: obs[k] for k in self.obs_keys}, save_activations=False, out_value=buf.values[t])
+            self._sample_step += 1
+            _lib.check(L.vf_head_sample(_ptr(mean), _ptr(pol.log_std), _ptr(action), _ptr(logp), N, int(self.seed) & (2 ** 64 - 1),
+                                        self._sample_step, 0, self._stream()))
             for k in self.obs_keys:
                 buf.obs[k][t].copy_(obs[k])
-            buf.actions[t].copy_(action)
-            buf.values[t].copy_(value)
-            buf.log_probs[t].copy_(logp)
-            buf.episode_starts[t].copy_(self._last_starts)
             obs, reward, done, _info = env.step(action)
-            _lib.check(_lib.lib().vf_episode_stats(done.data_ptr(), _ptr(env._ep_return), _ptr(env._ep_length), _ptr(env._ep_flags),
-                                                   self._ep_stats.data_ptr(), self.n_envs, self._stream()))
+            _lib.check(L.vf_episode_stats(done.data_ptr(), _ptr(env._ep_return), _ptr(env._ep_length), _ptr(env._ep_flags),
+                                          self._ep_stats.data_ptr(), N, self._stream()))
             # TimeLimit.truncated bootstrap: SB3 adds gamma * V(terminal_observation) where the info says truncated
-            trunc = done & ((env._ep_flags & EP_TRUNC) != 0)
             tobs = {"state": env._terminal_obs}
             if "target" in self.obs_keys:
                 tobs["target"] = obs["target"]
-            tv = self.predict_values(tobs)
-            buf.rewards[t] = reward + self.gamma * tv * trunc
-            self._last_starts = done.float()
+            _, tv = pol.forward(tobs, save_activations=False)
+            nxt = buf.episode_starts[t + 1] if t + 1 < self.n_steps else self._last_starts
+            _lib.check(L.vf_rollout_post(_ptr(reward), done.data_ptr(), _ptr(env._ep_flags), _ptr(tv), float(self.gamma),
+                                         _ptr(buf.rewards[t]), _ptr(nxt), N, self._stream()))
         self._last_obs = obs
         last_values = self.predict_values(obs)
         _lib.check(_lib.lib().vf_gae(_ptr(buf.rewards), _ptr(buf.values), _ptr(buf.episode_starts), _ptr(last_values),
