@@ -116,19 +116,18 @@ class BPTT:
         log_std = pol.log_std
         t0 = env._tape_t
         obs = env.get_observation()
-        acts, epss, drews = [], [], []
+        # per-horizon buffers in one allocation each; the exploration noise of the whole horizon is one draw
+        acts, drews = th.empty((H, N, 4), device=dev), th.empty((H, N), device=dev)
+        epss = th.randn((H, N, 4), device=dev, generator=self._gen)
         for t in range(H):
             mean, _ = pol.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, slot=t, need_value=False)
-            eps = th.randn((N, 4), device=dev, generator=self._gen)
-            action = th.empty((N, 4), device=dev)
-            _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(eps), _ptr(action), N, st))
+            action = acts[t]
+            _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(epss[t]), _ptr(action), N, st))
             pre_obs = obs
             obs, reward, done, _ = env._step_no_grad(action, False, record=True)
             self._on_step(t, pre_obs, action, obs, reward, done, disc)
-            d_rew = th.empty(N, device=dev)
-            _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(d_rew),
+            _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(drews[t]),
                                             float(self.gamma), 1.0 / (N * self.world), N, st))
-            acts.append(action); epss.append(eps); drews.append(d_rew)
         g_obs = None
         d_means = th.empty((H, N, 4), device=dev)
         for t in reversed(range(H)):
@@ -158,10 +157,10 @@ class BPTT:
         disc = th.ones(N, device=self.device)
         loss_vec = th.zeros(N, device=self.device)
         obs = env.get_observation()
-        for _ in range(self.H):
+        epss = th.randn((self.H, N, 4), device=self.device, generator=self._gen)     # same draw as the reverse sweep
+        for t in range(self.H):
             mean = PolicyFunction.apply(pol, self.obs_keys, anchor, *[obs[k] for k in self.obs_keys])
-            eps = th.randn((N, 4), device=self.device, generator=self._gen)
-            action = th.tanh(mean + log_std.exp() * eps)     # reparameterised squashed Gaussian (td_policies Actor)
+            action = th.tanh(mean + log_std.exp() * epss[t])     # reparameterised squashed Gaussian (td_policies Actor)
             obs, reward, done, _ = env.step(action)
             loss_vec = loss_vec + -1 * reward * disc          # :123
             disc = disc * self.gamma * ~done + done           # :124
