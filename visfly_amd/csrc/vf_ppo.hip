@@ -1187,12 +1187,27 @@ __global__ __launch_bounds__(1024) void k_episode_stats(const uint8_t* __restric
 {
     __shared__ double sh[4][16];
     double v[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < N; i += 1024) {
-        if (done[i]) {
-            v[0] += 1.0;
-            v[1] += (double)ep_return[i];
-            v[2] += (double)ep_length[i];
-            v[3] += (ep_flags[i] & VF_EP_SUCCESS) ? 1.0 : 0.0;
+    // branch-free and unrolled: the loads of eight strides are in flight together (a `if (done[i])` around the other
+    // three loads made every iteration a dependent round trip: 16 us for 32 768 agents)
+    for (int i0 = threadIdx.x; i0 < N; i0 += 8 * 1024) {
+        uint8_t d[8], f[8];
+        float r[8];
+        int32_t l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 1024, ic = i < N ? i : N - 1;
+            d[u] = i < N ? done[ic] : (uint8_t)0;
+            r[u] = ep_return[ic];
+            l[u] = ep_length[ic];
+            f[u] = ep_flags[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double on = d[u] ? 1.0 : 0.0;
+            v[0] += on;
+            v[1] += d[u] ? (double)r[u] : 0.0;
+            v[2] += d[u] ? (double)l[u] : 0.0;
+            v[3] += (d[u] && (f[u] & VF_EP_SUCCESS)) ? 1.0 : 0.0;
         }
     }
 #pragma unroll
