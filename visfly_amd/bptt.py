@@ -185,6 +185,16 @@ class BPTT:
         self.num_timesteps += self.H * N * self.world
         return loss.detach() * self.world
 
+    def predict(self, obs, state=None, episode_start=None, deterministic: bool = False):
+        """SB3-style predict (utils/evaluate.py:94): -> (action, None); deterministic: a = tanh(mean)"""
+        N = obs[self.obs_keys[0]].shape[0]
+        mean, _ = self.policy.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, save_activations=False,
+                                      slot=self.H + 1, need_value=False)
+        if deterministic:
+            return th.tanh(mean), None
+        eps = th.randn((N, 4), device=self.device, generator=self._gen)
+        return th.tanh(mean + self.policy.log_std.exp() * eps), None
+
     def save(self, path: str):
         return checkpoint.save(self, path)
 

@@ -689,6 +689,11 @@ class PPO:
         _, value = self.policy.forward({k: obs[k] for k in self.obs_keys}, save_activations=False)
         return value.view(-1).clone()
 
+    def predict(self, obs, state=None, episode_start=None, deterministic: bool = False):
+        """SB3 ``BaseAlgorithm.predict`` as the evaluation harness calls it (utils/evaluate.py:94): -> (action, None);
+        deterministic: a = tanh(mean)"""
+        return self._act(obs, deterministic)[0], None
+
     def collect_rollouts(self):
         """SB3 OnPolicyAlgorithm.collect_rollouts: n_steps of policy -> env.step -> buffer, with the
         TimeLimit bootstrap reward += gamma * V(terminal_obs) for truncated episodes, then GAE."""
