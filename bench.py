@@ -83,12 +83,29 @@ def bench_ppo(args, rank, world, dev):
     torch.cuda.synchronize()
     parallel.barrier()
     el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    # MFMA roofline of the optimiser steps (outside the timed region): one more train() pass over the last rollout,
+    # timed with device events; algorithmic flops = 2 x weights x rows for each of forward, data gradient, weight gradient
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n0 = ppo._opt_step
+    e0.record()
+    ppo.train()
+    e1.record()
+    torch.cuda.synchronize()
+    n_upd = max(1, ppo._opt_step - n0)
+    us_upd = e0.elapsed_time(e1) * 1e3 / n_upd
+    rows = min(ppo.batch_size, 256 * N)
+    flops = 6.0 * ppo.policy.log_std_off * rows          # log_std_off = number of weights + biases of the network
+    tfs = flops / (us_upd * 1e-6) / 1e12
+    roof = {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
+            "kernel": "optimiser step: k_ppo_update_chain + k_mlp_wgrad + fold + grad norm + Adam", "us_per_update": us_upd,
+            "rows": rows, "note": "fp32 v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md); PMC breakdown in profiles/r01_pmc_mlp.json"}
     if rank == 0:
         print(json.dumps({"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
                           "value": 256 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
                           "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"NavigationEnv {N} agents/GPU, n_steps=256, batch 25600/GPU, 5 epochs",
-                                     "logs": {k: float(v) for k, v in ppo.logs.items()}}}), flush=True)
+                                     "logs": {k: float(v) for k, v in ppo.logs.items()}},
+                          "roofline": roof}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
