@@ -421,6 +421,18 @@ int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32
 int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
                        vf_stream_t stream);
 
+/* Row gather of the rollout buffer for one epoch's permutation (SB3 RolloutBuffer.get: indices = np.random.permutation,
+ * utils/algorithms/common.py:161-215 mirror): dst_f[i, :] = src_f[perm[i], :] for up to 8 row-major fp32 fields of `rows`
+ * rows in ONE launch, so that every minibatch of the epoch is a contiguous slice. */
+#define VF_GATHER_MAX_FIELDS 8
+typedef struct vf_gather_fields {
+    int32_t n_fields;
+    int32_t width[VF_GATHER_MAX_FIELDS];
+    const float* src[VF_GATHER_MAX_FIELDS];
+    float* dst[VF_GATHER_MAX_FIELDS];
+} vf_gather_fields;
+int vf_gather_rows(const vf_gather_fields* fields, const int64_t* perm, int64_t rows, vf_stream_t stream);
+
 /* Post-step bookkeeping of the rollout loop (SB3 OnPolicyAlgorithm.collect_rollouts; utils/algorithms/PPO.py:146): the
  * TimeLimit bootstrap reward_out = reward + gamma * V(terminal_observation) where the episode ended by truncation
  * (done && ep_flags bit 1, vf_env_out.ep_flags), and the next step's episode_start flags = float(done).  One launch instead

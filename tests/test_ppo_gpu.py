@@ -531,3 +531,20 @@ def test_evaluation_harness_runs_one_episode_per_agent():
     mean_r, mean_l = tb.test()
     assert len(tb.eq_r) == 256 and 1 <= mean_l <= 48 and mean_r == mean_r
     assert len(tb.reward_all) == len(tb.action_all) == len(tb.state_all) - 1 <= 48
+
+
+def test_gather_rows_equals_index_select():
+    """vf_gather_rows: all rollout-buffer fields of an epoch's permutation in one launch == torch.index_select per field"""
+    _lib, lib = L()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    rows = 70001
+    fields = [torch.randn((rows, w), device=DEV, generator=g) if w > 1 else torch.randn(rows, device=DEV, generator=g) for w in (13, 3, 4, 1, 1, 1)]
+    perm = torch.randperm(rows, device=DEV, generator=g)
+    outs = [torch.empty_like(f) for f in fields]
+    gf = _lib.GatherFields()
+    gf.n_fields = len(fields)
+    for i, (f, o) in enumerate(zip(fields, outs)):
+        gf.width[i], gf.src[i], gf.dst[i] = (f.shape[1] if f.dim() == 2 else 1), f.data_ptr(), o.data_ptr()
+    _lib.check(lib.vf_gather_rows(C.byref(gf), perm.data_ptr(), rows, st()))
+    for f, o in zip(fields, outs):
+        assert torch.equal(o, f.index_select(0, perm))

@@ -130,6 +130,11 @@ class MlpDesc(C.Structure):
                 ("lds_floats", C.c_int32), ("pad0", C.c_int32), ("layer", MlpLayer * MLP_MAX_LAYERS)]
 
 
+class GatherFields(C.Structure):
+    """mirror of vf_gather_fields"""
+    _fields_ = [("n_fields", C.c_int32), ("width", C.c_int32 * 8), ("src", C.c_void_p * 8), ("dst", C.c_void_p * 8)]
+
+
 class MlpBwdLayer(C.Structure):
     """mirror of vf_mlp_bwd_layer"""
     _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("need_dx", C.c_int32), ("ld_dy", C.c_int32), ("ld_y", C.c_int32),
@@ -213,6 +218,7 @@ SIGNATURES = {
     "vf_mlp_weight_grad": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
+    "vf_gather_rows": (C.c_int, [C.POINTER(GatherFields), _vp, C.c_int64, _vp]),
     "vf_rollout_post": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _vp, _vp, C.c_int32, _vp]),
     "vf_ppo_update": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpBwdDesc)] + [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),

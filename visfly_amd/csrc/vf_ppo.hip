@@ -1165,6 +1165,22 @@ __global__ __launch_bounds__(1024) void k_fold_stats(const float* __restrict__ p
     }
 }
 
+// dst[i, :] = src[perm[i], :] for every field (blockIdx.y); one thread per output element: coalesced stores, the w
+// consecutive words of a source row read by consecutive lanes
+__global__ __launch_bounds__(kBlock) void k_gather_rows(const vf_gather_fields f, const int64_t* __restrict__ perm, long rows)
+{
+    const int fi = blockIdx.y;
+    const int w = f.width[fi];
+    const float* __restrict__ src = f.src[fi];
+    float* __restrict__ dst = f.dst[fi];
+    const long n = rows * w;
+    for (long idx = (long)blockIdx.x * kBlock + threadIdx.x; idx < n; idx += (long)gridDim.x * kBlock) {
+        const long r = idx / w;
+        const int c = (int)(idx - r * w);
+        dst[idx] = src[perm[r] * w + c];
+    }
+}
+
 // reward + gamma * V(terminal obs) on truncated episodes; next episode_start = float(done)   (SB3 collect_rollouts)
 __global__ __launch_bounds__(kBlock) void k_rollout_post(const float* __restrict__ reward, const uint8_t* __restrict__ done,
                                                          const uint8_t* __restrict__ ep_flags, const float* __restrict__ tv, float gamma,
@@ -1690,6 +1706,22 @@ int vf_ppo_loss(const float* mean, const float* value, const float* log_std, con
                        log_std, reinterpret_cast<const float4*>(action), old_log_prob, adv, ret,
                        reinterpret_cast<float4*>(d_mean), d_value, scratch, M, *cfg);
     hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(1024), 0, st, scratch, nblk, stats, cfg->d_log_std_out, cfg->stats_accum);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_gather_rows(const vf_gather_fields* fields, const int64_t* perm, int64_t rows, vf_stream_t stream)
+{
+    if (!fields || !perm || rows <= 0 || fields->n_fields < 1 || fields->n_fields > VF_GATHER_MAX_FIELDS)
+        return vf::fail(VF_EINVAL, "vf_gather_rows: bad argument");
+    int wmax = 1;
+    for (int i = 0; i < fields->n_fields; ++i) {
+        if (!fields->src[i] || !fields->dst[i] || fields->width[i] < 1) return vf::fail(VF_EINVAL, "vf_gather_rows: field %d: bad pointer / width", i);
+        wmax = fields->width[i] > wmax ? fields->width[i] : wmax;
+    }
+    const long blocks = (rows * wmax + vf::kBlock - 1) / vf::kBlock;
+    hipLaunchKernelGGL(vf::k_gather_rows, dim3((unsigned)(blocks < 65536 ? blocks : 65536), fields->n_fields), dim3(vf::kBlock), 0,
+                       vf::as_stream(stream), *fields, perm, (long)rows);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -652,6 +652,7 @@ class PPO:
         self._sample_step = 0
         self.num_timesteps = 0
         self._last_starts = th.ones(self.n_envs, device=dev)
+        self._shuf = None
         # bounded list of truncated-episode terminal observations per rollout (timeout bootstrap)
         self.world = parallel.world_size()
         self.logs: Dict[str, float] = {}
@@ -780,7 +781,7 @@ class PPO:
             # one gather per epoch instead of one per minibatch: the shuffled copy makes every minibatch a
             # contiguous slice (same rows, same order as indexing the buffer with perm[s:s+bs])
             perm = th.randperm(total, device=self.device, generator=g)
-            shuf = {k: v.index_select(0, perm) for k, v in flat.items()}
+            shuf = self._gather(flat, perm)
             n_seg = total // bs
             if self.normalize_advantage and bs * self.world > 1:
                 # PPO.py:215-220 normalises per minibatch; all minibatches of the epoch in one launch (+ one
@@ -817,6 +818,18 @@ class PPO:
                               "rollout/ep_success_rate": ep[3] / ep[0], "rollout/episodes": ep[0]})
         self.logs.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/entropy_loss": s[2],
                           "train/approx_kl": s[3], "train/clip_fraction": s[4], "train/n_updates": self._opt_step})
+
+    def _gather(self, flat, perm):
+        """{name: rows of flat[name] in the order of perm} -- all fields in one launch (vf_gather_rows); the destination
+        buffers are kept between epochs"""
+        if self._shuf is None or any(self._shuf[k].shape != v.shape for k, v in flat.items()):
+            self._shuf = {k: th.empty_like(v) for k, v in flat.items()}
+        gf = _lib.GatherFields()
+        gf.n_fields = len(flat)
+        for i, (k, v) in enumerate(flat.items()):
+            gf.width[i], gf.src[i], gf.dst[i] = (v.shape[1] if v.dim() == 2 else 1), _ptr(v), _ptr(self._shuf[k])
+        _lib.check(_lib.lib().vf_gather_rows(C.byref(gf), perm.data_ptr(), perm.numel(), self._stream()))
+        return dict(self._shuf)
 
     def learn(self, total_timesteps: int, log_interval: Optional[int] = None):
         """PPO.learn (PPO.py:116-175): alternate rollout collection and training"""
