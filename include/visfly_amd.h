@@ -420,6 +420,11 @@ int vf_mlp_backward_data_supported(const vf_mlp_bwd_desc* desc);
 int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32_t M, vf_stream_t stream);
 int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
                        vf_stream_t stream);
+/* same, and the fold also leaves sum(grad[i]^2) of the values it wrote as vf_mlp_weight_grad_fold_blocks(desc) fp64
+ * partials in sumsq_partials (for vf_adam_cfg.sumsq_partials) */
+int32_t vf_mlp_weight_grad_fold_blocks(const vf_mlp_bwd_desc* desc);
+int vf_mlp_weight_grad_sumsq(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
+                             double* sumsq_partials, vf_stream_t stream);
 
 /* Row gather of the rollout buffer for one epoch's permutation (SB3 RolloutBuffer.get: indices = np.random.permutation,
  * utils/algorithms/common.py:161-215 mirror): dst_f[i, :] = src_f[perm[i], :] for up to 8 row-major fp32 fields of `rows`
@@ -490,6 +495,12 @@ typedef struct vf_adam_cfg {
      * reverse-chain image), -1 = none */
     const int32_t* pack_map;
     float* packed;
+    /* optional: the squared gradient norm as per-block partial sums left by vf_mlp_weight_grad (sumsq_partials != NULL
+     * there) instead of grad_sumsq: total = sum of the n_sumsq_partials partials + sum of grad[i]^2 for i >= sumsq_tail_from
+     * (the parameters the weight-gradient fold does not cover: log_std).  Saves the separate vf_sumsq launch. */
+    const double* sumsq_partials;
+    int32_t n_sumsq_partials;
+    int32_t sumsq_tail_from;
 } vf_adam_cfg;
 
 /* One PPO minibatch step up to the weight gradients, for the network classes of the register-chained kernels: forward +

@@ -548,3 +548,35 @@ def test_gather_rows_equals_index_select():
     _lib.check(lib.vf_gather_rows(C.byref(gf), perm.data_ptr(), rows, st()))
     for f, o in zip(fields, outs):
         assert torch.equal(o, f.index_select(0, perm))
+
+
+def test_adam_takes_the_grad_norm_from_the_fold_partials():
+    """vf_mlp_weight_grad_sumsq leaves sum(grad^2) as per-block fp64 partials; vf_adam_step (sumsq_partials) adds them
+    (+ the log_std tail) itself: same clipped update as with a separate vf_sumsq launch"""
+    from visfly_amd.ppo import MlpPolicy
+    _lib, lib = L()
+    B = 4096
+    pol = MlpPolicy({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64], DEV, seed=5)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    obs = {"state": torch.randn((B, 13), device=DEV, generator=g), "target": torch.randn((B, 3), device=DEV, generator=g)}
+    mean, _ = pol.forward(obs)
+    actions = torch.tanh(mean + torch.randn((B, 4), device=DEV, generator=g)).contiguous()
+    old_lp, adv, ret = torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g)
+    stats, scratch = torch.zeros(16, device=DEV), torch.zeros(16 * 1024, device=DEV)
+    cfg = _lib.PpoLossCfg(0.2, 0.0, 0.5, 1.0 / B, pol.grad.data_ptr() + 4 * pol.log_std_off, None)
+    sq, nb = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch, want_sumsq=True)
+    total = float(sq[:nb].sum() + (pol.grad[pol.log_std_off:].double() ** 2).sum())
+    assert abs(total - float((pol.grad.double() ** 2).sum())) <= 1e-9 * total
+    assert total ** 0.5 > 0.05                                   # clipping at 0.05 is active
+    outs = []
+    for use_partials in (True, False):
+        p, m, v = pol.flat.clone(), torch.zeros_like(pol.flat), torch.zeros_like(pol.flat)
+        ss = torch.zeros(1, device=DEV)
+        if not use_partials:
+            _lib.check(lib.vf_sumsq(pol.grad.data_ptr(), pol.n_params, ss.data_ptr(), scratch.data_ptr(), st()))
+        acfg = _lib.AdamCfg(1e-3, 0.9, 0.999, 1e-8, 1e-5, 0.05, 1, 0, None, None, sq.data_ptr() if use_partials else None,
+                            nb if use_partials else 0, pol.log_std_off)
+        _lib.check(lib.vf_adam_step(p.data_ptr(), pol.grad.data_ptr(), m.data_ptr(), v.data_ptr(), pol.n_params, ss.data_ptr(),
+                                    C.byref(acfg), st()))
+        outs.append(p)
+    assert torch.allclose(outs[0], outs[1], rtol=1e-6, atol=1e-9) and not torch.equal(outs[0], pol.flat)

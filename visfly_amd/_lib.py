@@ -158,7 +158,8 @@ class AdamCfg(C.Structure):
     """mirror of vf_adam_cfg"""
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", C.c_int32), ("pad0", C.c_int32),
-                ("pack_map", C.c_void_p), ("packed", C.c_void_p)]
+                ("pack_map", C.c_void_p), ("packed", C.c_void_p), ("sumsq_partials", C.c_void_p),
+                ("n_sumsq_partials", C.c_int32), ("sumsq_tail_from", C.c_int32)]
 
 
 class VisflyError(RuntimeError):
@@ -216,6 +217,8 @@ SIGNATURES = {
     "vf_mlp_backward_data_supported": (C.c_int, [C.POINTER(MlpBwdDesc)]),
     "vf_mlp_backward_data": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, C.c_int32, _vp]),
     "vf_mlp_weight_grad": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "vf_mlp_weight_grad_fold_blocks": (C.c_int32, [C.POINTER(MlpBwdDesc)]),
+    "vf_mlp_weight_grad_sumsq": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_gather_rows": (C.c_int, [C.POINTER(GatherFields), _vp, C.c_int64, _vp]),

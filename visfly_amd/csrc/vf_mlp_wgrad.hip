@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const
 // grad (+)= sum over the layer's waves of partial[wave][e]; 64 consecutive partial elements per block, the 4 waves of
 // the block split the partial rows (8 loads in flight each) and combine through LDS in a fixed order
 __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, const WgradTable t, const float* __restrict__ partials,
-                                                       float* __restrict__ grad, int accumulate)
+                                                       float* __restrict__ grad, int accumulate, double* __restrict__ sq_part)
 {
     __shared__ float red[4][64];
     int b = blockIdx.x, l = 0;
@@ -225,11 +225,19 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, 
     }
     red[q][lane] = s;
     __syncthreads();
+    double sq = 0.0;
     if (q == 0 && prm >= 0) {
         const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
         const int nw = L.K * L.No;
         float* g = grad + (prm < nw ? L.w_off + prm : L.b_off + (prm - nw));
-        *g = accumulate ? *g + v : v;
+        const float nv = accumulate ? *g + v : v;
+        *g = nv;
+        sq = (double)nv * (double)nv;
+    }
+    if (sq_part && q == 0) {       // squared norm of what this block wrote: fixed-order wave sum
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+        if (lane == 0) sq_part[blockIdx.x] = sq;
     }
 }
 
@@ -270,15 +278,20 @@ int64_t mlp_wgrad_partial_floats(const vf_mlp_bwd_desc* d, int M)
     return wgrad_plan(*d, M, t, &w);
 }
 
-int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, hipStream_t st)
+int mlp_wgrad_fold_blocks(const vf_mlp_bwd_desc* d)
+{
+    int nb = 0;
+    for (int l = 0; l < d->n_layers; ++l) nb += (wgrad_partial_size(d->layer[l]) + 63) / 64;
+    return nb;
+}
+
+int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, double* sq_part, hipStream_t st)
 {
     WgradTable t;
     int waves = 0;
     wgrad_plan(*d, M, t, &waves);
     hipLaunchKernelGGL(k_mlp_wgrad, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
-    int nb = 0;
-    for (int l = 0; l < d->n_layers; ++l) nb += (wgrad_partial_size(d->layer[l]) + 63) / 64;
-    hipLaunchKernelGGL(k_wgrad_fold, dim3(nb), dim3(kBlock), 0, st, *d, t, (const float*)partials, grad, accumulate);
+    hipLaunchKernelGGL(k_wgrad_fold, dim3(mlp_wgrad_fold_blocks(d)), dim3(kBlock), 0, st, *d, t, (const float*)partials, grad, accumulate, sq_part);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

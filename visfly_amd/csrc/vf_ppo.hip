@@ -1269,7 +1269,20 @@ __global__ __launch_bounds__(kBlock) void k_adam(float* __restrict__ p, const fl
 {
     float coef = 1.0f;
     if (c.max_grad_norm > 0.0f) {
-        const float total = sqrtf(*sumsq);
+        float ss;
+        if (c.sumsq_partials) {     // every block sums the fold's partials (+ the uncovered tail) in the same fixed order
+            __shared__ double sh[4];
+            double a = 0.0;
+            for (int i = threadIdx.x; i < c.n_sumsq_partials; i += kBlock) a += c.sumsq_partials[i];
+            for (long i = c.sumsq_tail_from + threadIdx.x; i < n; i += kBlock) a += (double)g[i] * (double)g[i];
+            a = wave_sum(a);
+            if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+            __syncthreads();
+            ss = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        } else {
+            ss = *sumsq;
+        }
+        const float total = sqrtf(ss);
         coef = fminf(c.max_grad_norm / (total + 1e-6f), 1.0f);
     }
     const float step = c.lr / bc1;
@@ -1573,7 +1586,7 @@ int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* par
     // reference-default network classes: reverse chain in registers + row-slab weight gradients (vf_mlp_chain.hip, vf_mlp_wgrad.hip)
     if (int rc = vf::mlp_backward_chain_try(desc, packed, M, vf::as_stream(stream))) {
         if (rc < 0) return rc;
-        return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, vf::as_stream(stream));
+        return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, nullptr, vf::as_stream(stream));
     }
     lds = ((size_t)2 * vf::kRows * (129 + 129) + vf::kBwdThreads) * sizeof(float);   // two staging buffers + bias scratch
     if (int rc = allow_lds(vf::k_mlp_backward, lds)) return rc;
@@ -1636,7 +1649,21 @@ int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad
 {
     if (!partials || !grad || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad: bad argument");
     if (int rc = check_bwd_desc(desc, "vf_mlp_weight_grad")) return rc;
-    return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, vf::as_stream(stream));
+    return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, nullptr, vf::as_stream(stream));
+}
+
+int32_t vf_mlp_weight_grad_fold_blocks(const vf_mlp_bwd_desc* desc)
+{
+    if (check_bwd_desc(desc, "vf_mlp_weight_grad_fold_blocks")) return -1;
+    return vf::mlp_wgrad_fold_blocks(desc);
+}
+
+int vf_mlp_weight_grad_sumsq(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
+                             double* sumsq_partials, vf_stream_t stream)
+{
+    if (!partials || !grad || !sumsq_partials || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_sumsq: bad argument");
+    if (int rc = check_bwd_desc(desc, "vf_mlp_weight_grad_sumsq")) return rc;
+    return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, sumsq_partials, vf::as_stream(stream));
 }
 
 int vf_reparam_fwd(const float* mean, const float* log_std, const float* eps, float* action, int32_t N, vf_stream_t stream)
@@ -1777,7 +1804,8 @@ int vf_sumsq(const float* x, int64_t n, float* out1, float* scratch, vf_stream_t
 int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* grad_sumsq,
                  const vf_adam_cfg* cfg, vf_stream_t stream)
 {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !cfg || n <= 0 || cfg->step <= 0 || (cfg->max_grad_norm > 0 && !grad_sumsq))
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !cfg || n <= 0 || cfg->step <= 0 ||
+        (cfg->max_grad_norm > 0 && !grad_sumsq && !cfg->sumsq_partials))
         return vf::fail(VF_EINVAL, "vf_adam_step: bad argument");
     if ((cfg->pack_map == nullptr) != (cfg->packed == nullptr))
         return vf::fail(VF_EINVAL, "vf_adam_step: pack_map and packed must be given together");

@@ -113,6 +113,7 @@ class MlpPolicy:
         self._pack_map = None
         self._pi_only_ok = True
         self._fused_ppo = None             # None: untried, False: vf_ppo_update does not support this network
+        self._sq_part = None
         self._slot_blocks: Dict[int, tuple] = {}
 
     def _plan_fused(self):
@@ -483,10 +484,11 @@ class MlpPolicy:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
         _lib.check(L.vf_mlp_weight_grad(C.byref(d), _ptr(self._scratch), _ptr(self.grad), n * M, 1 if accumulate else 0, self._stream()))
 
-    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch):
+    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch, want_sumsq=False):
         """forward + PPO loss + reverse chain in one launch, then the weight gradients into ``self.grad`` (vf_ppo_update +
         vf_mlp_weight_grad).  -> False when the network is not one of the register-chained classes (the caller then
-        runs forward / vf_ppo_loss / backward)."""
+        runs forward / vf_ppo_loss / backward).  ``want_sumsq``: -> (fp64 partials tensor, count) of the squared norm of the
+        gradient the fold wrote, for vf_adam_cfg.sumsq_partials (no separate grad-norm launch)."""
         if self._fused_ppo is False or self._plan is None or not (self.fused and self.fused_backward):
             return False
         M = actions.shape[0]
@@ -527,6 +529,12 @@ class MlpPolicy:
         need = int(L.vf_mlp_backward_partial_floats(C.byref(bd), M))
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
+        if want_sumsq:
+            nb = int(L.vf_mlp_weight_grad_fold_blocks(C.byref(bd)))
+            if self._sq_part is None or self._sq_part.numel() < nb:
+                self._sq_part = th.empty(nb, dtype=th.float64, device=self.device)
+            _lib.check(L.vf_mlp_weight_grad_sumsq(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, self._sq_part.data_ptr(), st))
+            return self._sq_part, nb
         _lib.check(L.vf_mlp_weight_grad(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, st))
         return True
 
@@ -745,7 +753,10 @@ class PPO:
         cfg = _lib.PpoLossCfg(self.clip_range, self.ent_coef, self.vf_coef, 1.0 / gB, _ptr(pol.grad, pol.log_std_off),
                               None if stats_acc is None else _ptr(stats_acc))
         # reference-default policy shapes: forward + loss + reverse chain are one launch (vf_ppo_update)
-        if not pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch):
+        # single GPU: the weight-gradient fold also leaves the squared gradient norm as partial sums, which Adam adds up itself
+        res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch, want_sumsq=self.world == 1)
+        sq = res if isinstance(res, tuple) else None
+        if res is False:
             mean, value = pol.forward(obs)
             d_mean, d_value = th.empty((B, 4), device=self.device), th.empty(B, device=self.device)
             _lib.check(L.vf_ppo_loss(_ptr(mean), _ptr(value), _ptr(pol.log_std), _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret),
@@ -754,11 +765,13 @@ class PPO:
         if self.world > 1:
             parallel.allreduce_sum_(pol.grad)      # sum over ranks: every term is already / global batch
         self._opt_step += 1
-        _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
+        if sq is None:
+            _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
         pmap, packed = pol.pack_map()          # Adam refreshes the packed MFMA weight images in the same launch
         acfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, self.weight_decay,
                             self.max_grad_norm if self.max_grad_norm is not None else 0.0, self._opt_step, 0,
-                            _ptr(pmap), _ptr(packed))
+                            _ptr(pmap), _ptr(packed), None if sq is None else sq[0].data_ptr(), 0 if sq is None else sq[1],
+                            pol.log_std_off)
         _lib.check(L.vf_adam_step(_ptr(pol.flat), _ptr(pol.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params,
                                   _ptr(self._sumsq), C.byref(acfg), st))
         pol.mark_updated(packed_current=pmap is not None)
