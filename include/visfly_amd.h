@@ -421,10 +421,19 @@ int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32
 int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
                        vf_stream_t stream);
 /* same, and the fold also leaves sum(grad[i]^2) of the values it wrote as vf_mlp_weight_grad_fold_blocks(desc) fp64
- * partials in sumsq_partials (for vf_adam_cfg.sumsq_partials) */
+ * partials in sumsq_partials (for vf_adam_cfg.sumsq_partials).  loss_stats (optional): one more block of the same fold
+ * launch sums the loss-statistic partial rows a vf_ppo_update call with stats == NULL left in its scratch -- what
+ * vf_ppo_loss / vf_ppo_update otherwise spend a launch of their own on (same reduction order, same results). */
+typedef struct vf_stats_fold {
+    const float* part;       /* n_rows x 16 partial rows (vf_ppo_update scratch) */
+    int32_t n_rows, pad0;
+    float* stats;            /* fp32[16] out, as vf_ppo_loss */
+    float* d_log_std_out;    /* optional, as vf_ppo_loss_cfg */
+    float* stats_accum;      /* optional, as vf_ppo_loss_cfg */
+} vf_stats_fold;
 int32_t vf_mlp_weight_grad_fold_blocks(const vf_mlp_bwd_desc* desc);
 int vf_mlp_weight_grad_sumsq(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
-                             double* sumsq_partials, vf_stream_t stream);
+                             double* sumsq_partials, const vf_stats_fold* loss_stats, vf_stream_t stream);
 
 /* Row gather of the rollout buffer for one epoch's permutation (SB3 RolloutBuffer.get: indices = np.random.permutation,
  * utils/algorithms/common.py:161-215 mirror): dst_f[i, :] = src_f[perm[i], :] for up to 8 row-major fp32 fields of `rows`
@@ -509,7 +518,8 @@ typedef struct vf_adam_cfg {
  * fold.  fwd: the forward layer table with every `save` pointer set; bwd: the backward table (both trunks, no observation
  * gradient) whose head entries' dY buffers receive d_mean (M,4) / d_value (M,).  Afterwards the dY buffers hold the masked
  * layer gradients: call vf_mlp_weight_grad(bwd, ...) for dW / db.  stats / cfg / scratch as in vf_ppo_loss (scratch >=
- * 16 * ceil(M / 32) floats, M <= 32768).  VF_EUNSUPPORTED: not an instantiated class -> use vf_mlp_forward, vf_ppo_loss,
+ * 16 * ceil(M / 32) floats, M <= 32768); stats == NULL: the partial rows stay in scratch for vf_mlp_weight_grad_sumsq's
+ * loss_stats.  VF_EUNSUPPORTED: not an instantiated class -> use vf_mlp_forward, vf_ppo_loss,
  * vf_mlp_backward. */
 int vf_ppo_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const float* params, const float* packed,
                   const float* in0, const float* in1, const float* log_std, const float* action, const float* old_log_prob,

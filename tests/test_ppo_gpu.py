@@ -564,7 +564,12 @@ def test_adam_takes_the_grad_norm_from_the_fold_partials():
     old_lp, adv, ret = torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g)
     stats, scratch = torch.zeros(16, device=DEV), torch.zeros(16 * 1024, device=DEV)
     cfg = _lib.PpoLossCfg(0.2, 0.0, 0.5, 1.0 / B, pol.grad.data_ptr() + 4 * pol.log_std_off, None)
+    assert pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch) is True
+    stats0, grad0 = stats.clone(), pol.grad.clone()
+    stats.zero_()
     sq, nb = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch, want_sumsq=True)
+    # the loss-statistic rows folded by the weight-gradient fold launch: same order, same bits
+    assert torch.equal(stats, stats0) and torch.equal(pol.grad, grad0)
     total = float(sq[:nb].sum() + (pol.grad[pol.log_std_off:].double() ** 2).sum())
     assert abs(total - float((pol.grad.double() ** 2).sum())) <= 1e-9 * total
     assert total ** 0.5 > 0.05                                   # clipping at 0.05 is active

@@ -130,6 +130,12 @@ class MlpDesc(C.Structure):
                 ("lds_floats", C.c_int32), ("pad0", C.c_int32), ("layer", MlpLayer * MLP_MAX_LAYERS)]
 
 
+class StatsFold(C.Structure):
+    """mirror of vf_stats_fold"""
+    _fields_ = [("part", C.c_void_p), ("n_rows", C.c_int32), ("pad0", C.c_int32), ("stats", C.c_void_p),
+                ("d_log_std_out", C.c_void_p), ("stats_accum", C.c_void_p)]
+
+
 class GatherFields(C.Structure):
     """mirror of vf_gather_fields"""
     _fields_ = [("n_fields", C.c_int32), ("width", C.c_int32 * 8), ("src", C.c_void_p * 8), ("dst", C.c_void_p * 8)]
@@ -218,7 +224,7 @@ SIGNATURES = {
     "vf_mlp_backward_data": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, C.c_int32, _vp]),
     "vf_mlp_weight_grad": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_mlp_weight_grad_fold_blocks": (C.c_int32, [C.POINTER(MlpBwdDesc)]),
-    "vf_mlp_weight_grad_sumsq": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
+    "vf_mlp_weight_grad_sumsq": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(StatsFold), _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_gather_rows": (C.c_int, [C.POINTER(GatherFields), _vp, C.c_int64, _vp]),

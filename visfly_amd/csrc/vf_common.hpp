@@ -62,6 +62,7 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
 // vf_mlp_wgrad.hip: weight / bias gradients of every listed layer from dY (masked) and X, + fold into grad
 int64_t mlp_wgrad_partial_floats(const vf_mlp_bwd_desc* d, int M);
 int mlp_wgrad_fold_blocks(const vf_mlp_bwd_desc* d);
-int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, double* sq_part, hipStream_t st);
+int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, double* sq_part,
+                     const vf_stats_fold* loss_stats, hipStream_t st);
 
 }  // namespace vf

@@ -197,9 +197,26 @@ __global__ __launch_bounds__(64) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const
 // grad (+)= sum over the layer's waves of partial[wave][e]; 64 consecutive partial elements per block, the 4 waves of
 // the block split the partial rows (8 loads in flight each) and combine through LDS in a fixed order
 __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, const WgradTable t, const float* __restrict__ partials,
-                                                       float* __restrict__ grad, int accumulate, double* __restrict__ sq_part)
+                                                       float* __restrict__ grad, int accumulate, double* __restrict__ sq_part,
+                                                       const vf_stats_fold ls, int n_param_blocks)
 {
     __shared__ float red[4][64];
+    if ((int)blockIdx.x >= n_param_blocks) {     // the extra block: loss-statistic partial rows (vf_ppo_update) -> stats
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int k = w; k < 16; k += 4) {         // 64 lanes stride over the rows, shuffle tree: the order of k_fold_stats
+            float s = 0.0f;
+            if (k < 9)
+                for (int b = lane; b < ls.n_rows; b += 64) s += ls.part[(size_t)b * 16 + k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            if (lane == 0) {
+                ls.stats[k] = s;
+                if (ls.d_log_std_out && k >= 5 && k < 9) ls.d_log_std_out[k - 5] = s;
+                if (ls.stats_accum) ls.stats_accum[k] += s;
+            }
+        }
+        return;
+    }
     int b = blockIdx.x, l = 0;
     for (; l < t.n_layers; ++l) {
         const int nb = (wgrad_partial_size(d.layer[l]) + 63) / 64;
@@ -285,13 +302,17 @@ int mlp_wgrad_fold_blocks(const vf_mlp_bwd_desc* d)
     return nb;
 }
 
-int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, double* sq_part, hipStream_t st)
+int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, double* sq_part,
+                     const vf_stats_fold* loss_stats, hipStream_t st)
 {
     WgradTable t;
     int waves = 0;
     wgrad_plan(*d, M, t, &waves);
     hipLaunchKernelGGL(k_mlp_wgrad, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
-    hipLaunchKernelGGL(k_wgrad_fold, dim3(mlp_wgrad_fold_blocks(d)), dim3(kBlock), 0, st, *d, t, (const float*)partials, grad, accumulate, sq_part);
+    const int nb = mlp_wgrad_fold_blocks(d);
+    const vf_stats_fold ls = loss_stats ? *loss_stats : vf_stats_fold{};
+    hipLaunchKernelGGL(k_wgrad_fold, dim3(nb + (loss_stats ? 1 : 0)), dim3(kBlock), 0, st, *d, t, (const float*)partials, grad, accumulate,
+                       sq_part, ls, nb);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

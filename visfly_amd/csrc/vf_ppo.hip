@@ -1586,7 +1586,7 @@ int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* par
     // reference-default network classes: reverse chain in registers + row-slab weight gradients (vf_mlp_chain.hip, vf_mlp_wgrad.hip)
     if (int rc = vf::mlp_backward_chain_try(desc, packed, M, vf::as_stream(stream))) {
         if (rc < 0) return rc;
-        return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, nullptr, vf::as_stream(stream));
+        return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, nullptr, nullptr, vf::as_stream(stream));
     }
     lds = ((size_t)2 * vf::kRows * (129 + 129) + vf::kBwdThreads) * sizeof(float);   // two staging buffers + bias scratch
     if (int rc = allow_lds(vf::k_mlp_backward, lds)) return rc;
@@ -1649,7 +1649,7 @@ int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad
 {
     if (!partials || !grad || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad: bad argument");
     if (int rc = check_bwd_desc(desc, "vf_mlp_weight_grad")) return rc;
-    return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, nullptr, vf::as_stream(stream));
+    return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, nullptr, nullptr, vf::as_stream(stream));
 }
 
 int32_t vf_mlp_weight_grad_fold_blocks(const vf_mlp_bwd_desc* desc)
@@ -1659,11 +1659,13 @@ int32_t vf_mlp_weight_grad_fold_blocks(const vf_mlp_bwd_desc* desc)
 }
 
 int vf_mlp_weight_grad_sumsq(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
-                             double* sumsq_partials, vf_stream_t stream)
+                             double* sumsq_partials, const vf_stats_fold* loss_stats, vf_stream_t stream)
 {
     if (!partials || !grad || !sumsq_partials || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_sumsq: bad argument");
+    if (loss_stats && (!loss_stats->part || !loss_stats->stats || loss_stats->n_rows < 1))
+        return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_sumsq: bad loss_stats");
     if (int rc = check_bwd_desc(desc, "vf_mlp_weight_grad_sumsq")) return rc;
-    return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, sumsq_partials, vf::as_stream(stream));
+    return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, sumsq_partials, loss_stats, vf::as_stream(stream));
 }
 
 int vf_reparam_fwd(const float* mean, const float* log_std, const float* eps, float* action, int32_t N, vf_stream_t stream)
@@ -1769,7 +1771,7 @@ int vf_ppo_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const floa
                   const float* adv, const float* ret, float* stats, int32_t M, const vf_ppo_loss_cfg* cfg, float* scratch,
                   vf_stream_t stream)
 {
-    if (!fwd || !params || !packed || !in0 || !log_std || !action || !old_log_prob || !adv || !ret || !stats || !cfg || !scratch || M <= 0)
+    if (!fwd || !params || !packed || !in0 || !log_std || !action || !old_log_prob || !adv || !ret || !cfg || !scratch || M <= 0)
         return vf::fail(VF_EINVAL, "vf_ppo_update: bad argument");
     if (fwd->n_layers < 1 || fwd->n_layers > VF_MLP_MAX_LAYERS) return vf::fail(VF_EINVAL, "vf_ppo_update: bad layer count");
     if (int rc = check_bwd_desc(bwd, "vf_ppo_update")) return rc;
@@ -1779,7 +1781,8 @@ int vf_ppo_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const floa
     const int rc = vf::ppo_update_chain_try(fwd, bwd, params, packed, in0, in1, log_std, action, old_log_prob, adv, ret, scratch, cfg, M, st);
     if (rc < 0) return rc;
     if (rc == 0) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_update: the layer tables are not an instantiated network class");
-    hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(1024), 0, st, scratch, nwaves, stats, cfg->d_log_std_out, cfg->stats_accum);
+    if (stats)      // else: the caller folds the partial rows (vf_mlp_weight_grad_sumsq loss_stats)
+        hipLaunchKernelGGL(vf::k_fold_stats, dim3(1), dim3(1024), 0, st, scratch, nwaves, stats, cfg->d_log_std_out, cfg->stats_accum);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

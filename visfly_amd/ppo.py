@@ -519,8 +519,10 @@ class MlpPolicy:
             bd.layer[i].X = _ptr(b[src])
         ins = [_ptr(b["obs:" + k]) for k in self.obs_keys] + [None] * (2 - len(self.obs_keys))
         self._pack()
+        # want_sumsq: the loss-statistic rows are folded by the weight-gradient fold launch (one launch less)
         rc = L.vf_ppo_update(C.byref(d), C.byref(bd), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], _ptr(self.log_std),
-                             _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret), _ptr(stats), M, C.byref(loss_cfg), _ptr(loss_scratch), st)
+                             _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret), None if want_sumsq else _ptr(stats), M,
+                             C.byref(loss_cfg), _ptr(loss_scratch), st)
         if rc == _lib.EUNSUPPORTED:
             self._fused_ppo = False
             return False
@@ -533,7 +535,9 @@ class MlpPolicy:
             nb = int(L.vf_mlp_weight_grad_fold_blocks(C.byref(bd)))
             if self._sq_part is None or self._sq_part.numel() < nb:
                 self._sq_part = th.empty(nb, dtype=th.float64, device=self.device)
-            _lib.check(L.vf_mlp_weight_grad_sumsq(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, self._sq_part.data_ptr(), st))
+            ls = _lib.StatsFold(_ptr(loss_scratch), (M + 31) // 32, 0, _ptr(stats), loss_cfg.d_log_std_out, loss_cfg.stats_accum)
+            _lib.check(L.vf_mlp_weight_grad_sumsq(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, self._sq_part.data_ptr(),
+                                                  C.byref(ls), st))
             return self._sq_part, nb
         _lib.check(L.vf_mlp_weight_grad(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, st))
         return True
