@@ -238,33 +238,17 @@ __device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& s
         constexpr ChainLayer L = N::layer(li);
         constexpr int gq = local / L.nout, a = local % L.nout;
         const int h = lane >> 5;
-        if constexpr (I + kChainDepth < N::n_items()) {
-            const float4 nxt = chain_load<N, I + kChainDepth>(g, lane);
-            // the slot being refilled is the one this item consumes: read it first
-            const float4 w = st.ring[I % kChainDepth];
-            st.ring[I % kChainDepth] = nxt;
-            if constexpr (local == 0) chain_bias_load<N, li>(g, st, h);
-            f32x16& acc = st.t[L.out0 + a];
-            if constexpr (gq == 0) acc = f32x16{0};
+        const float4 w = st.ring[I % kChainDepth];       // the slot being refilled is the one this item consumes: read it first
+        if constexpr (I + kChainDepth < N::n_items()) st.ring[I % kChainDepth] = chain_load<N, I + kChainDepth>(g, lane);
+        if constexpr (local == 0) chain_bias_load<N, li>(g, st, h);
+        f32x16& acc = st.t[L.out0 + a];
+        if constexpr (gq == 0) acc = f32x16{0};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float b;
-                if constexpr (L.obs >= 0) b = st.x[L.obs][4 * gq + j];
-                else b = st.t[L.in0 + gq / 4][4 * (gq % 4) + j];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
-            }
-        } else {
-            const float4 w = st.ring[I % kChainDepth];
-            if constexpr (local == 0) chain_bias_load<N, li>(g, st, h);
-            f32x16& acc = st.t[L.out0 + a];
-            if constexpr (gq == 0) acc = f32x16{0};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float b;
-                if constexpr (L.obs >= 0) b = st.x[L.obs][4 * gq + j];
-                else b = st.t[L.in0 + gq / 4][4 * (gq % 4) + j];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
-            }
+        for (int j = 0; j < 4; ++j) {
+            float b;
+            if constexpr (L.obs >= 0) b = st.x[L.obs][4 * gq + j];
+            else b = st.t[L.in0 + gq / 4][4 * (gq % 4) + j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
         }
         chain_deferred_store<N, li, local>(g, st, row, h, live);
         __builtin_amdgcn_sched_barrier(0);
