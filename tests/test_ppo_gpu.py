@@ -585,3 +585,32 @@ def test_adam_takes_the_grad_norm_from_the_fold_partials():
                                     C.byref(acfg), st()))
         outs.append(p)
     assert torch.allclose(outs[0], outs[1], rtol=1e-6, atol=1e-9) and not torch.equal(outs[0], pol.flat)
+
+
+def test_action_head_fused_into_the_chain_kernels():
+    """vf_mlp_forward_act / vf_mlp_backward_data_act == vf_mlp_forward + vf_reparam_fwd / vf_reparam_bwd + vf_mlp_backward_data,
+    bit for bit (same arithmetic on the head, in the kernel's registers)"""
+    from visfly_amd.ppo import MlpPolicy
+    _lib, lib = L()
+    M = 1000
+    pol = MlpPolicy({"state": 13}, {"state": [128, 64]}, [64, 64], [64, 64], DEV, seed=8, log_std_init=-0.7)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    obs = {"state": torch.randn((M, 13), device=DEV, generator=g)}
+    eps = torch.randn((M, 4), device=DEV, generator=g)
+    d_action = torch.randn((M, 4), device=DEV, generator=g) / M
+    pol.reserve_slots(M, 2)
+    # separate launches on slot 0
+    mean, _ = pol.forward(obs, slot=0, need_value=False)
+    a0 = torch.empty((M, 4), device=DEV)
+    _lib.check(lib.vf_reparam_fwd(mean.data_ptr(), pol.log_std.data_ptr(), eps.data_ptr(), a0.data_ptr(), M, st()))
+    dm0, gl0 = torch.empty((M, 4), device=DEV), torch.zeros((M, 4), device=DEV)
+    _lib.check(lib.vf_reparam_bwd(d_action.data_ptr(), a0.data_ptr(), pol.log_std.data_ptr(), eps.data_ptr(), dm0.data_ptr(), gl0.data_ptr(), M, st()))
+    din0 = pol.backward_data(dm0, slot=0)["state"].clone()
+    # fused on slot 1
+    a1 = torch.empty((M, 4), device=DEV)
+    assert pol.forward_act(obs, eps, a1, slot=1)
+    dm1, gl1 = torch.empty((M, 4), device=DEV), torch.zeros((M, 4), device=DEV)
+    din1 = pol.backward_data_act(d_action, a1, eps, gl1, dm1, slot=1)["state"]
+    assert torch.equal(a0, a1) and torch.equal(dm0, dm1) and torch.equal(gl0, gl1) and torch.equal(din0, din1)
+    for name in ("x:state:0", "feat", "pi:0", "pi:1", "g:feat", "g:pi:1"):
+        assert torch.equal(pol._buffers(M, 0)[name], pol._buffers(M, 1)[name]), name

@@ -120,9 +120,11 @@ class BPTT:
         acts, drews = th.empty((H, N, 4), device=dev), th.empty((H, N), device=dev)
         epss = th.randn((H, N, 4), device=dev, generator=self._gen)
         for t in range(H):
-            mean, _ = pol.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, slot=t, need_value=False)
             action = acts[t]
-            _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(epss[t]), _ptr(action), N, st))
+            o = {k: obs[k].detach().contiguous() for k in self.obs_keys}
+            if not (defer and pol.forward_act(o, epss[t], action, slot=t)):      # action head fused into the forward launch
+                mean, _ = pol.forward(o, slot=t, need_value=False)
+                _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(epss[t]), _ptr(action), N, st))
             pre_obs = obs
             obs, reward, done, _ = env._step_no_grad(action, False, record=True)
             self._on_step(t, pre_obs, action, obs, reward, done, disc)
@@ -133,10 +135,10 @@ class BPTT:
         for t in reversed(range(H)):
             d_action = env.backward_step(t0 + t, g_obs, drews[t])
             d_mean = d_means[t]
-            _lib.check(L.vf_reparam_bwd(_ptr(d_action), _ptr(acts[t]), _ptr(log_std), _ptr(epss[t]), _ptr(d_mean), _ptr(g_ls), N, st))
-            if defer:
-                d_in = pol.backward_data(d_mean, slot=t)      # (step 0's observation gradient is computed but unused)
+            if defer:       # action head's reverse + reverse chain in one launch (step 0's observation gradient is unused)
+                d_in = pol.backward_data_act(d_action, acts[t], epss[t], g_ls, d_mean, slot=t)
             else:
+                _lib.check(L.vf_reparam_bwd(_ptr(d_action), _ptr(acts[t]), _ptr(log_std), _ptr(epss[t]), _ptr(d_mean), _ptr(g_ls), N, st))
                 d_in = pol.backward(d_mean, None, None, accumulate=True, need_input_grad=t > 0, slot=t)
             g_obs = d_in.get("state") if t > 0 else None
         if defer:

@@ -50,12 +50,25 @@ inline bool use_split(int agents_padded, const vf_dyn_cfg& cfg)
     return agents_padded <= 32768;   // measured on MI355X: 32768 agents 9.4 us (split) vs 11.3 us; 65536: 13.3 vs 12.5
 }
 
+// action head fused into the chain kernels (vf_mlp_forward_act / vf_mlp_backward_data_act); all-null: off
+struct ReparamFwd {
+    const float* log_std;
+    const float* eps;
+    float* action;
+};
+struct ReparamBwd {
+    const float* d_action;
+    const float* action;
+    const float* log_std;
+    const float* eps;
+    float* g_log_std;
+};
 // vf_mlp_chain.hip: register-chained forward for the reference-default network shapes (1: launched, 0: no match)
 int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                          float* out0, float* out1, int M, hipStream_t st);
+                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rp = nullptr);
 
 // reverse chain (data gradients) for the same network classes: 1 launched, 0 no match, < 0 error
-int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st);
+int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp = nullptr);
 int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,
                          const float* in1, const float* log_std, const float* action, const float* old_lp, const float* adv,
                          const float* ret, float* part, const vf_ppo_loss_cfg* cfg, int M, hipStream_t st);

@@ -138,6 +138,10 @@ struct ChainArgs {
     const float* packed;
     ChainIo io;
     int M;
+    // optional action head (vf_mlp_forward_act): action = tanh(mean + exp(log_std) * eps) instead of the mean
+    const float* rp_log_std;
+    const float4* rp_eps;
+    float4* rp_action;
 };
 
 template <class N, int I>
@@ -185,6 +189,11 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>
         if (live && h == 0) {                          // (the fused PPO kernel keeps the heads in registers: no pointers)
             if constexpr (L.desc == N::L_mean) {
                 if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
+                if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers
+                    const float4 e = g.rp_eps[row];
+                    g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
+                                                   tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                }
             } else {
                 if (g.io.value) g.io.value[row] = y[0];
             }
@@ -391,6 +400,12 @@ struct BwdArgsChain {
     vf_mlp_bwd_desc d;
     const float* packed;
     int M;
+    // optional action head (vf_mlp_backward_data_act): the head gradient is formed here from d_action
+    const float4* rp_d_action;
+    const float4* rp_action;
+    const float* rp_log_std;
+    const float4* rp_eps;
+    float4* rp_g_log_std;
 };
 
 template <class P>
@@ -527,7 +542,7 @@ __device__ __forceinline__ void bwd_prologue(const BwdArgsChain& g, BwdState<P>&
 }
 
 template <class P, int OI>
-__device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdState<P>& st, int rc, int h)
+__device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdState<P>& st, int rc, int h, bool live)
 {
     if constexpr (OI < P::n_ops) {
         constexpr BwdOp O = P::op(OI);
@@ -535,13 +550,28 @@ __device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdStat
             const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];
             const float* dy = E.dY + (size_t)rc * E.ld_dy;
             if constexpr (O.in_kind == 1) {
-                st.hin[0][0] = h == 0 ? dy[0] : 0.0f; st.hin[0][1] = h == 0 ? dy[1] : 0.0f;
-                st.hin[0][2] = h == 0 ? dy[2] : 0.0f; st.hin[0][3] = h == 0 ? dy[3] : 0.0f;
+                if (g.rp_d_action) {       // k_reparam_bwd's arithmetic; lane half 0 of a live row writes d_mean / g_log_std
+                    const float4 da = g.rp_d_action[rc], a = g.rp_action[rc], e = g.rp_eps[rc];
+                    const float4 dm = make_float4(da.x * (1.0f - a.x * a.x), da.y * (1.0f - a.y * a.y), da.z * (1.0f - a.z * a.z),
+                                                  da.w * (1.0f - a.w * a.w));
+                    if (live && h == 0) {
+                        *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
+                        float4 gl = g.rp_g_log_std[rc];
+                        gl.x += dm.x * expf(g.rp_log_std[0]) * e.x; gl.y += dm.y * expf(g.rp_log_std[1]) * e.y;
+                        gl.z += dm.z * expf(g.rp_log_std[2]) * e.z; gl.w += dm.w * expf(g.rp_log_std[3]) * e.w;
+                        g.rp_g_log_std[rc] = gl;
+                    }
+                    st.hin[0][0] = h == 0 ? dm.x : 0.0f; st.hin[0][1] = h == 0 ? dm.y : 0.0f;
+                    st.hin[0][2] = h == 0 ? dm.z : 0.0f; st.hin[0][3] = h == 0 ? dm.w : 0.0f;
+                } else {
+                    st.hin[0][0] = h == 0 ? dy[0] : 0.0f; st.hin[0][1] = h == 0 ? dy[1] : 0.0f;
+                    st.hin[0][2] = h == 0 ? dy[2] : 0.0f; st.hin[0][3] = h == 0 ? dy[3] : 0.0f;
+                }
             } else {
                 st.hin[1][0] = h == 0 ? dy[0] : 0.0f; st.hin[1][1] = 0.0f; st.hin[1][2] = 0.0f; st.hin[1][3] = 0.0f;
             }
             bwd_mask_load<P, OI>(g, st, rc, h);
-            bwd_head_prologue<P, OI + 1>(g, st, rc, h);
+            bwd_head_prologue<P, OI + 1>(g, st, rc, h, live);
         }
     }
 }
@@ -575,7 +605,7 @@ __global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
     const int rc = live ? row : g.M - 1;
     BwdState<P> st;
     bwd_prologue<P, 0>(g, st, lane);
-    bwd_head_prologue<P, 0>(g, st, rc, h);
+    bwd_head_prologue<P, 0>(g, st, rc, h, live);
     bwd_items<P, NoFwd, 0>(g, st, NoFwd{}, lane, row, rc, live);
     bwd_tail_store<P>(g, st, row, h, live);
 }
@@ -700,9 +730,9 @@ bool chain_matches(const vf_mlp_desc& d)
 
 template <class N>
 int chain_launch(const vf_mlp_desc& d, const float* params, const float* packed, const float* in0, const float* in1, float* out0,
-                 float* out1, int M, hipStream_t st)
+                 float* out1, int M, hipStream_t st, const ReparamFwd& rp)
 {
-    ChainArgs g{d, params, packed, ChainIo{{in0, in1}, out0, out1}, M};
+    ChainArgs g{d, params, packed, ChainIo{{in0, in1}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.action)};
     hipLaunchKernelGGL(k_mlp_forward_chain<N>, dim3((M + 31) / 32), dim3(64), 0, st, g);
     VF_HIP(hipGetLastError());
     return 1;
@@ -748,9 +778,10 @@ bool bwd_chain_matches(const vf_mlp_bwd_desc& d)
 }
 
 template <class N, bool PI, bool VF, bool IG>
-int bwd_chain_launch(const vf_mlp_bwd_desc& d, const float* packed, int M, hipStream_t st)
+int bwd_chain_launch(const vf_mlp_bwd_desc& d, const float* packed, int M, hipStream_t st, const ReparamBwd& rp)
 {
-    BwdArgsChain g{d, packed, M};
+    BwdArgsChain g{d, packed, M, reinterpret_cast<const float4*>(rp.d_action), reinterpret_cast<const float4*>(rp.action), rp.log_std,
+                   reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.g_log_std)};
     hipLaunchKernelGGL((k_mlp_backward_chain<BwdProg<N, PI, VF, IG>>), dim3((M + 31) / 32), dim3(64), 0, st, g);
     VF_HIP(hipGetLastError());
     return 1;
@@ -759,15 +790,16 @@ int bwd_chain_launch(const vf_mlp_bwd_desc& d, const float* packed, int M, hipSt
 // data gradients of the whole network (masked dZ of every hidden layer left in the dY buffers, optional observation
 // gradients): 1 launched, 0 not an instantiated class / variant, < 0 error.  Variants: PPO update (both trunks, no
 // observation gradient) and first-order policy optimisation (policy trunk only, observation gradient).
-int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st)
+int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rpp)
 {
+    const ReparamBwd rp = rpp ? *rpp : ReparamBwd{};
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
     if (off) return 0;
     const bool launch = packed != nullptr;       // packed == nullptr: capability query only
-    if (bwd_chain_matches<NetNav, true, true, false>(*d)) return launch ? bwd_chain_launch<NetNav, true, true, false>(*d, packed, M, st) : 1;
-    if (bwd_chain_matches<NetNav, true, false, true>(*d)) return launch ? bwd_chain_launch<NetNav, true, false, true>(*d, packed, M, st) : 1;
-    if (bwd_chain_matches<NetHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetHover, true, true, false>(*d, packed, M, st) : 1;
-    if (bwd_chain_matches<NetHover, true, false, true>(*d)) return launch ? bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st) : 1;
+    if (bwd_chain_matches<NetNav, true, true, false>(*d)) return launch ? bwd_chain_launch<NetNav, true, true, false>(*d, packed, M, st, rp) : 1;
+    if (bwd_chain_matches<NetNav, true, false, true>(*d)) return launch ? bwd_chain_launch<NetNav, true, false, true>(*d, packed, M, st, rp) : 1;
+    if (bwd_chain_matches<NetHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetHover, true, true, false>(*d, packed, M, st, rp) : 1;
+    if (bwd_chain_matches<NetHover, true, false, true>(*d)) return launch ? bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st, rp) : 1;
     return 0;
 }
 
@@ -781,8 +813,8 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
     if (off) return 0;
     for (int i = 0; i < d->n_layers; ++i)
         if (d->layer[i].dst < VF_MLP_OUT0 && !d->layer[i].save) return 0;          // the weight gradients need every layer input
-    ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M};
-    BwdArgsChain gb{*bd, packed, M};
+    ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M, nullptr, nullptr, nullptr};
+    BwdArgsChain gb{*bd, packed, M, nullptr, nullptr, nullptr, nullptr, nullptr};
     PpoRowArgs pr{log_std, reinterpret_cast<const float4*>(action), old_lp, adv, ret, part, *cfg};
     const dim3 grid((M + 31) / 32);
     if (chain_matches<NetNav>(*d) && in1 && bwd_chain_matches<NetNav, true, true, false>(*bd)) {
@@ -798,17 +830,18 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
 
 // 1: launched, 0: the layer table is not one of the instantiated network classes, < 0: error
 int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                          float* out0, float* out1, int M, hipStream_t st)
+                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rpp)
 {
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
-    if (off || !out0 || (reinterpret_cast<uintptr_t>(out0) & 15)) return 0;
+    const ReparamFwd rp = rpp ? *rpp : ReparamFwd{};
+    if (off || (!out0 && !rp.action) || (reinterpret_cast<uintptr_t>(out0) & 15) || (reinterpret_cast<uintptr_t>(rp.action) & 15)) return 0;
     if (!out1) {      // no value requested: the value trunk is skipped
-        if (chain_matches<NetNavPi>(*d) && in1) return chain_launch<NetNavPi>(*d, params, packed, in0, in1, out0, out1, M, st);
-        if (chain_matches<NetHoverPi>(*d)) return chain_launch<NetHoverPi>(*d, params, packed, in0, nullptr, out0, out1, M, st);
+        if (chain_matches<NetNavPi>(*d) && in1) return chain_launch<NetNavPi>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
+        if (chain_matches<NetHoverPi>(*d)) return chain_launch<NetHoverPi>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
         return 0;
     }
-    if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st);
-    if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st);
+    if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
+    if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
     return 0;
 }
 

@@ -1645,6 +1645,30 @@ int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32
     return VF_OK;
 }
 
+int vf_mlp_forward_act(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
+                       const float* log_std, const float* eps, float* action, int32_t M, vf_stream_t stream)
+{
+    if (!desc || !params || !packed || !in0 || !log_std || !eps || !action || M <= 0 || desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS)
+        return vf::fail(VF_EINVAL, "vf_mlp_forward_act: bad argument");
+    const vf::ReparamFwd rp{log_std, eps, action};
+    const int rc = vf::mlp_forward_chain_try(desc, params, packed, in0, in1, nullptr, nullptr, M, vf::as_stream(stream), &rp);
+    if (rc < 0) return rc;
+    if (rc == 0) return vf::fail(VF_EUNSUPPORTED, "vf_mlp_forward_act: the layer table is not an instantiated network class");
+    return VF_OK;
+}
+
+int vf_mlp_backward_data_act(const vf_mlp_bwd_desc* desc, const float* packed, const float* d_action, const float* action,
+                             const float* log_std, const float* eps, float* g_log_std, int32_t M, vf_stream_t stream)
+{
+    if (!packed || !d_action || !action || !log_std || !eps || !g_log_std || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_backward_data_act: bad argument");
+    if (int rc = check_bwd_desc(desc, "vf_mlp_backward_data_act")) return rc;
+    const vf::ReparamBwd rp{d_action, action, log_std, eps, g_log_std};
+    const int rc = vf::mlp_backward_chain_try(desc, packed, M, vf::as_stream(stream), &rp);
+    if (rc < 0) return rc;
+    if (rc == 0) return vf::fail(VF_EUNSUPPORTED, "vf_mlp_backward_data_act: the layer table is not an instantiated network class / variant");
+    return VF_OK;
+}
+
 int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate, vf_stream_t stream)
 {
     if (!partials || !grad || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad: bad argument");

@@ -113,6 +113,7 @@ class MlpPolicy:
         self._pack_map = None
         self._pi_only_ok = True
         self._fused_ppo = None             # None: untried, False: vf_ppo_update does not support this network
+        self._act_fused = None             # likewise for vf_mlp_forward_act
         self._sq_part = None
         self._slot_blocks: Dict[int, tuple] = {}
 
@@ -443,6 +444,54 @@ class MlpPolicy:
             touched.add(key)
         d.n_layers = n
         return d, d_in
+
+    def forward_act(self, obs, eps, action, slot=0):
+        """policy trunk + action head in one launch (vf_mlp_forward_act): ``action`` (M,4) <- tanh(mean + exp(log_std) eps),
+        activations saved for the reverse pass of `slot`.  -> False when the network is not a register-chained class."""
+        if self._act_fused is False or self._plan is None or not self.fused:
+            return False
+        M = action.shape[0]
+        b = self._buffers(M, slot)
+        for k in self.obs_keys:
+            t = obs[k]
+            assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
+            if b.get("_contig"):
+                b["obs:" + k].copy_(t)
+            else:
+                b["obs:" + k] = t
+        self._last_M, self._last_slot = M, slot
+        key = (M, slot, True)
+        d = self._descs.get(key)
+        if d is None:
+            d = self._descs[key] = self._fused_desc(b, True)
+        ins = [_ptr(b["obs:" + k]) for k in self.obs_keys] + [None] * (2 - len(self.obs_keys))
+        self._pack()
+        rc = _lib.lib().vf_mlp_forward_act(C.byref(d), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], _ptr(self.log_std),
+                                           _ptr(eps), _ptr(action), M, self._stream())
+        if rc == _lib.EUNSUPPORTED:
+            self._act_fused = False
+            return False
+        if rc:
+            _lib.check(rc)
+        return True
+
+    def backward_data_act(self, d_action, action, eps, g_log_std, d_mean, slot):
+        """``backward_data`` with the action head's reverse fused in (vf_mlp_backward_data_act): d_mean (M,4) is written for
+        ``weight_grad_slots``, g_log_std (M,4) accumulated; -> {obs key: dLoss/d obs}"""
+        M = d_action.shape[0]
+        b = self._buffers(M, slot)
+        cached = self._descs.get(("bwd_data", M, slot)) if b.get("_contig") else None
+        if cached is None:
+            d, d_in = self._bwd_desc(b, M, d_mean, None, True)
+            if b.get("_contig"):
+                self._descs[("bwd_data", M, slot)] = (d, d_in)
+        else:
+            d, d_in = cached
+            d.layer[0].dY = _ptr(d_mean)
+        self._pack()
+        _lib.check(_lib.lib().vf_mlp_backward_data_act(C.byref(d), _ptr(self._packed), _ptr(d_action), _ptr(action), _ptr(self.log_std),
+                                                       _ptr(eps), _ptr(g_log_std), M, self._stream()))
+        return d_in
 
     def backward_data_supported(self, M, slot=0):
         """can ``backward_data`` (policy trunk + observation gradient) run for this network?"""
