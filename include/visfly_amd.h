@@ -457,13 +457,16 @@ int vf_rollout_post(const float* reward, const uint8_t* done, const uint8_t* ep_
 /* First-order policy optimisation with the action head fused into the chain kernels (reference-default policy shapes only;
  * VF_EUNSUPPORTED otherwise -> vf_mlp_forward + vf_reparam_fwd, vf_reparam_bwd + vf_mlp_backward_data):
  *   vf_mlp_forward_act        policy trunk only; writes action = tanh(mean + exp(log_std) * eps) (M,4), nothing else leaves
- *                             the chip besides the saved activations (same arithmetic as vf_reparam_fwd)
+ *                             the chip besides the saved activations (same arithmetic as vf_reparam_fwd); obs_copy0/1
+ *                             (optional): the observation rows are also written there -- the contiguous per-step copy a
+ *                             horizon-wide vf_mlp_weight_grad reads as the first layers' X
  *   vf_mlp_backward_data_act  head gradient formed in the kernel: d_mean = d_action * (1 - action^2) is written to the action
  *                             head's dY buffer (the weight-gradient kernel reads it), g_log_std (M,4) += d_mean *
  *                             exp(log_std) * eps (same arithmetic as vf_reparam_bwd), then the reverse chain of
  *                             vf_mlp_backward_data */
 int vf_mlp_forward_act(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
-                       const float* log_std, const float* eps, float* action, int32_t M, vf_stream_t stream);
+                       const float* log_std, const float* eps, float* action, float* obs_copy0, float* obs_copy1, int32_t M,
+                       vf_stream_t stream);
 int vf_mlp_backward_data_act(const vf_mlp_bwd_desc* desc, const float* packed, const float* d_action, const float* action,
                              const float* log_std, const float* eps, float* g_log_std, int32_t M, vf_stream_t stream);
 

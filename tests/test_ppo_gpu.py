@@ -614,3 +614,4 @@ def test_action_head_fused_into_the_chain_kernels():
     assert torch.equal(a0, a1) and torch.equal(dm0, dm1) and torch.equal(gl0, gl1) and torch.equal(din0, din1)
     for name in ("x:state:0", "feat", "pi:0", "pi:1", "g:feat", "g:pi:1"):
         assert torch.equal(pol._buffers(M, 0)[name], pol._buffers(M, 1)[name]), name
+    assert torch.equal(pol._buffers(M, 1)["obs:state"], obs["state"])       # the slot's observation copy, written by the kernel

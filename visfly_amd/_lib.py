@@ -222,7 +222,7 @@ SIGNATURES = {
     "vf_mlp_backward": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_mlp_backward_data_supported": (C.c_int, [C.POINTER(MlpBwdDesc)]),
     "vf_mlp_backward_data": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, C.c_int32, _vp]),
-    "vf_mlp_forward_act": (C.c_int, [C.POINTER(MlpDesc)] + [_vp] * 7 + [C.c_int32, _vp]),
+    "vf_mlp_forward_act": (C.c_int, [C.POINTER(MlpDesc)] + [_vp] * 9 + [C.c_int32, _vp]),
     "vf_mlp_backward_data_act": (C.c_int, [C.POINTER(MlpBwdDesc)] + [_vp] * 6 + [C.c_int32, _vp]),
     "vf_mlp_weight_grad": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_mlp_weight_grad_fold_blocks": (C.c_int32, [C.POINTER(MlpBwdDesc)]),

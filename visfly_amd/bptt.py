@@ -126,7 +126,7 @@ class BPTT:
                 mean, _ = pol.forward(o, slot=t, need_value=False)
                 _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(epss[t]), _ptr(action), N, st))
             pre_obs = obs
-            obs, reward, done, _ = env._step_no_grad(action, False, record=True)
+            obs, reward, done, _ = env._step_no_grad(action, False, record=True, borrow=True)   # acts[t] outlives the reverse sweep
             self._on_step(t, pre_obs, action, obs, reward, done, disc)
             _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(drews[t]),
                                             float(self.gamma), 1.0 / (N * self.world), N, st))

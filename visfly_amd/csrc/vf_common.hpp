@@ -55,6 +55,7 @@ struct ReparamFwd {
     const float* log_std;
     const float* eps;
     float* action;
+    float* obs_copy[2];
 };
 struct ReparamBwd {
     const float* d_action;

@@ -142,6 +142,7 @@ struct ChainArgs {
     const float* rp_log_std;
     const float4* rp_eps;
     float4* rp_action;
+    float* obs_copy[2];      // optional: the observation rows are also written here (a trainer's contiguous per-slot copy)
 };
 
 template <class N, int I>
@@ -288,11 +289,13 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
     for (int b = 0; b < N::NB; ++b) {
         const int w = g.d.in_dim[b];
         const float* x = g.io.in[b] + (size_t)rc * w;
+        float* xc = g.obs_copy[b] ? g.obs_copy[b] + (size_t)rc * w : nullptr;
 #pragma unroll
         for (int s = 0; s < N::kin(b) / 2; ++s) {
             const int k = 2 * s + h;
             const float v = x[k < w ? k : w - 1];
             st.x[b][s] = k < w ? v : 0.0f;
+            if (xc && live && k < w) xc[k] = v;
         }
     }
     chain_items<N, 0>(g, st, lane, row, live);
@@ -732,7 +735,8 @@ template <class N>
 int chain_launch(const vf_mlp_desc& d, const float* params, const float* packed, const float* in0, const float* in1, float* out0,
                  float* out1, int M, hipStream_t st, const ReparamFwd& rp)
 {
-    ChainArgs g{d, params, packed, ChainIo{{in0, in1}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.action)};
+    ChainArgs g{d, params, packed, ChainIo{{in0, in1}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.action),
+                {rp.obs_copy[0], rp.obs_copy[1]}};
     hipLaunchKernelGGL(k_mlp_forward_chain<N>, dim3((M + 31) / 32), dim3(64), 0, st, g);
     VF_HIP(hipGetLastError());
     return 1;
@@ -813,7 +817,7 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
     if (off) return 0;
     for (int i = 0; i < d->n_layers; ++i)
         if (d->layer[i].dst < VF_MLP_OUT0 && !d->layer[i].save) return 0;          // the weight gradients need every layer input
-    ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M, nullptr, nullptr, nullptr};
+    ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M, nullptr, nullptr, nullptr, {nullptr, nullptr}};
     BwdArgsChain gb{*bd, packed, M, nullptr, nullptr, nullptr, nullptr, nullptr};
     PpoRowArgs pr{log_std, reinterpret_cast<const float4*>(action), old_lp, adv, ret, part, *cfg};
     const dim3 grid((M + 31) / 32);

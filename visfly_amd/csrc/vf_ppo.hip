@@ -1646,11 +1646,12 @@ int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32
 }
 
 int vf_mlp_forward_act(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
-                       const float* log_std, const float* eps, float* action, int32_t M, vf_stream_t stream)
+                       const float* log_std, const float* eps, float* action, float* obs_copy0, float* obs_copy1, int32_t M,
+                       vf_stream_t stream)
 {
     if (!desc || !params || !packed || !in0 || !log_std || !eps || !action || M <= 0 || desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS)
         return vf::fail(VF_EINVAL, "vf_mlp_forward_act: bad argument");
-    const vf::ReparamFwd rp{log_std, eps, action};
+    const vf::ReparamFwd rp{log_std, eps, action, {obs_copy0, obs_copy1}};
     const int rc = vf::mlp_forward_chain_try(desc, params, packed, in0, in1, nullptr, nullptr, M, vf::as_stream(stream), &rp);
     if (rc < 0) return rc;
     if (rc == 0) return vf::fail(VF_EUNSUPPORTED, "vf_mlp_forward_act: the layer table is not an instantiated network class");

@@ -426,7 +426,9 @@ class DroneGymEnvsBase:
             return obs, reward, done, info
         return self._step_no_grad(_action, is_test)
 
-    def _step_no_grad(self, _action, is_test=False, record=False):
+    def _step_no_grad(self, _action, is_test=False, record=False, borrow=False):
+        # borrow (trainers that own their per-horizon buffers): the tape keeps a REFERENCE to the action tensor and the step's
+        # done flags are written straight into the tape row (returned as such) -- two device copies per step less
         assert self._is_initial, "You should call reset() before step()"
         N, dev = self.num_agent, self.device
         a = _action
@@ -441,7 +443,6 @@ class DroneGymEnvsBase:
             th.cuda.set_device(dev)
         state = th.empty((N, 13), dtype=th.float32, device=dev)
         reward = th.empty(N, dtype=th.float32, device=dev)
-        done = th.empty(N, dtype=th.bool, device=dev)      # the kernel writes 0/1 bytes
         replay = self.spawn_mode == "replay"
         tape_t = -1
         if self._tape is not None and (record or self._record_all):   # checkpoint for the adjoint pass
@@ -449,8 +450,14 @@ class DroneGymEnvsBase:
             if tape_t >= self._tape.shape[0]:
                 raise VisflyError("tape is full: call env.detach() (BPTT horizon exceeded)")
             self._tape[tape_t].copy_(self._slab)
-            self._tape_actions[tape_t].copy_(a)
+            if borrow:
+                self._tape_action_ref[tape_t] = a
+            else:
+                self._tape_action_ref[tape_t] = None
+                self._tape_actions[tape_t].copy_(a)
             self._tape_t += 1
+        borrow_done = borrow and tape_t >= 0
+        done = self._tape_done[tape_t] if borrow_done else th.empty(N, dtype=th.bool, device=dev)      # the kernel writes 0/1 bytes
         o = self._outs
         o.obs, o.reward, o.done = state.data_ptr(), reward.data_ptr(), done.data_ptr()
         rc = self._vf_env_step(self._h, a.data_ptr(), self._outs_ref, 0 if (is_test or replay) else 1,
@@ -458,7 +465,7 @@ class DroneGymEnvsBase:
         if rc:
             _lib.check(rc)
         self._qcache = None
-        if tape_t >= 0:
+        if tape_t >= 0 and not borrow_done:
             self._tape_done[tape_t].copy_(done)
         self._reward, self._done = reward, done
         self._observations = obs = self._full_obs(state)
@@ -492,6 +499,7 @@ class DroneGymEnvsBase:
         self._tape = th.empty((horizon,) + tuple(self._slab.shape), dtype=th.float32, device=dev)
         self._tape_actions = th.empty((horizon, self.num_agent, 4), dtype=th.float32, device=dev)
         self._tape_done = th.zeros((horizon, self.num_agent), dtype=th.bool, device=dev)
+        self._tape_action_ref = [None] * horizon          # borrowed action tensors (see _step_no_grad)
         self._adj = th.zeros_like(self._slab)
         self._tape_t = 0
         self._record_all = True      # manual mode: every step() is recorded until clear_tape()/detach()
@@ -511,7 +519,8 @@ class DroneGymEnvsBase:
         dev = self.device
         d_action = th.empty((self.num_agent, 4), dtype=th.float32, device=dev)
         a = _lib.EnvBwdArgs()
-        a.tape_slab, a.action = self._tape[t].data_ptr(), self._tape_actions[t].data_ptr()
+        ref = self._tape_action_ref[t]
+        a.tape_slab, a.action = self._tape[t].data_ptr(), (self._tape_actions[t] if ref is None else ref).data_ptr()
         keep = []
         for name, x, shape in (("d_obs", d_obs, (self.num_agent, 13)), ("d_reward", d_reward, (self.num_agent,))):
             if x is not None:

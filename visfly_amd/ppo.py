@@ -452,22 +452,26 @@ class MlpPolicy:
             return False
         M = action.shape[0]
         b = self._buffers(M, slot)
+        ins, copies = [], []
         for k in self.obs_keys:
             t = obs[k]
             assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
+            ins.append(_ptr(t))
             if b.get("_contig"):
-                b["obs:" + k].copy_(t)
+                copies.append(_ptr(b["obs:" + k]))       # reserved slots own their observation rows: written by the kernel
             else:
                 b["obs:" + k] = t
+                copies.append(None)
+        ins += [None] * (2 - len(ins))
+        copies += [None] * (2 - len(copies))
         self._last_M, self._last_slot = M, slot
         key = (M, slot, True)
         d = self._descs.get(key)
         if d is None:
             d = self._descs[key] = self._fused_desc(b, True)
-        ins = [_ptr(b["obs:" + k]) for k in self.obs_keys] + [None] * (2 - len(self.obs_keys))
         self._pack()
         rc = _lib.lib().vf_mlp_forward_act(C.byref(d), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], _ptr(self.log_std),
-                                           _ptr(eps), _ptr(action), M, self._stream())
+                                           _ptr(eps), _ptr(action), copies[0], copies[1], M, self._stream())
         if rc == _lib.EUNSUPPORTED:
             self._act_fused = False
             return False
