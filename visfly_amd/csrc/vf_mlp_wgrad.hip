@@ -205,8 +205,18 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, 
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         for (int k = w; k < 16; k += 4) {         // 64 lanes stride over the rows, shuffle tree: the order of k_fold_stats
             float s = 0.0f;
-            if (k < 9)
-                for (int b = lane; b < ls.n_rows; b += 64) s += ls.part[(size_t)b * 16 + k];
+            if (k < 9) {
+                // rows are at most 1024 (vf_ppo_update's contract): all of a lane's loads are issued before the first add
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int b = lane + 64 * i;
+                    v[i] = b < ls.n_rows ? ls.part[(size_t)b * 16 + k] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += (lane + 64 * i < ls.n_rows) ? v[i] : 0.0f;
+                for (int b = lane + 1024; b < ls.n_rows; b += 64) s += ls.part[(size_t)b * 16 + k];
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
             if (lane == 0) {
