@@ -104,11 +104,11 @@ class BPTT:
         env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
         L, st, dev = _lib.lib(), _lib.current_stream(self.device), self.device
         pol.grad.zero_()
+        # reference-default policy shapes: the weight gradient is reduced ONCE per horizon over the rows of all H
+        # steps (their activations / masked gradients are stored back to back), the per-step reverse pass is the
+        # register-chained data-gradient kernel only
+        pol.reserve_slots(N, H)          # no-op while the slots exist (they are dropped if many other batch sizes pass through)
         if self._defer_wgrad is None:
-            # reference-default policy shapes: the weight gradient is reduced ONCE per horizon over the rows of all H
-            # steps (their activations / masked gradients are stored back to back), the per-step reverse pass is the
-            # register-chained data-gradient kernel only
-            pol.reserve_slots(N, H)
             self._defer_wgrad = pol.backward_data_supported(N)
         defer = self._defer_wgrad
         disc, loss_vec = th.ones(N, device=dev), th.zeros(N, device=dev)
