@@ -454,7 +454,8 @@ int vf_gather_rows(const vf_gather_fields* fields, const int64_t* perm, int64_t 
 int vf_rollout_post(const float* reward, const uint8_t* done, const uint8_t* ep_flags, const float* terminal_value, float gamma,
                     float* reward_out, float* next_episode_start, int32_t N, vf_stream_t stream);
 
-/* First-order policy optimisation with the action head fused into the chain kernels (reference-default policy shapes only;
+/* First-order policy optimisation (utils/algorithms/BPTT.py:107-129; the reparameterised squashed-Gaussian actor of
+ * utils/policies/td_policies.py) with the action head fused into the chain kernels (reference-default policy shapes only;
  * VF_EUNSUPPORTED otherwise -> vf_mlp_forward + vf_reparam_fwd, vf_reparam_bwd + vf_mlp_backward_data):
  *   vf_mlp_forward_act        policy trunk only; writes action = tanh(mean + exp(log_std) * eps) (M,4), nothing else leaves
  *                             the chip besides the saved activations (same arithmetic as vf_reparam_fwd); obs_copy0/1
@@ -528,7 +529,8 @@ typedef struct vf_adam_cfg {
     int32_t sumsq_tail_from;
 } vf_adam_cfg;
 
-/* One PPO minibatch step up to the weight gradients, for the network classes of the register-chained kernels: forward +
+/* One PPO minibatch step up to the weight gradients (utils/algorithms/PPO.py:203-287: evaluate_actions, the clipped-surrogate
+ * loss, loss.backward()), for the network classes of the register-chained kernels: forward +
  * vf_ppo_loss + reverse chain in ONE launch (a wave carries 32 rows through the network, evaluates their loss terms on the
  * head outputs in its registers and walks back, masking with its own still-live activations), then the loss-statistic
  * fold.  fwd: the forward layer table with every `save` pointer set; bwd: the backward table (both trunks, no observation
