@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,43 +30,57 @@ BYTES_PER_ENV_STEP = 350        # full env.step adds obs, reward, c
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(consts, seconds_target=15.0):
-    """TEST/BENCH INFRASTRUCTURE: time the CPU oracle (C restatement, OpenMP over agents) on the host
-    cores of this box on a bounded sample of the same workload: HoverEnv.step = dynamics interval +
-    bbox collision + reward / counters / done masks (no auto-reset inside the sample: episodes are
-    256 steps long and the sample is re-spawned every 192 steps)."""
+def cpu_baseline_env(consts, kind, N, seconds_target=15.0, threads=None, note=None):
+    """TEST/BENCH INFRASTRUCTURE: time the CPU oracle (C restatement of the reference's env.step: dynamics interval + bbox
+    collision + reward / counters / done masks) on the host cores of this box on a bounded sample of the same workload.
+    The sample runs inside ONE OpenMP region per block of 64 steps (oracle.OracleEnv.run_steps: every thread walks its own
+    contiguous agent chunk through the steps -- agents are independent), so 256 threads are not fork-join-bound; no
+    auto-reset inside the sample: episodes are 256 steps long and the sample is re-spawned every 192 steps."""
     import oracle
-    N = AGENTS_PER_GPU
-    env = oracle.OracleEnv(consts, N, "hover", 256, target=(1.0, 0.0, 1.5))
+    cores = len(os.sched_getaffinity(0))
+    threads = min(threads or cores, cores)
+    oracle.set_threads(threads)
+    gates = [[4, 4, 1.], [8, 0, 2.], [5, -4, 1.], [1, -1, 1.]] if kind == "racing" else None
+    target = (1.0, 0.0, 1.5) if kind == "hover" else (9.0, 0.0, 1.0)
+    env = oracle.OracleEnv(consts, N, kind, 256, target=target, success_radius=0.3 if kind == "racing" else 0.5, gates=gates)
     rng = np.random.default_rng(0)
     fs = np.zeros((N, 22), np.float32)
     fs[:, 0:3] = (np.array([1, 0, 1.5]) + rng.uniform(-1, 1, (N, 3)) * np.array([1, 1, .5])).astype(np.float32)
     fs[:, 3] = 1.0
     fs[:, 13:17], fs[:, 17:21] = consts["w_init"], consts["T_init"]
-    a = np.clip(np.array([-1 / 3, 0, 0, 0]) + rng.uniform(-.02, .02, (N, 4)), -1, 1).astype(np.float32)
+    hover = np.array([-1 / 3, 0, 0, 0]) if int(consts["action_type"]) == 1 else np.zeros(4)
+    a = np.clip(hover + rng.uniform(-.02, .02, (16, N, 4)), -1, 1).astype(np.float32)
     env.reset_full_state(fs)
-    for _ in range(2):
-        env.step(a)
+    env.run_steps(a, 2)
+    block = 64 if threads > 1 else 8
     t0 = time.perf_counter()
     steps = 0
     while True:
         if steps % 192 == 0:
             env.reset_full_state(fs)
-        for _ in range(8):
-            env.step(a)
-        steps += 8
+        env.run_steps(a, block)
+        steps += block
         el = time.perf_counter() - t0
-        if el > seconds_target or steps >= 8192:
+        if el > seconds_target or steps >= 16384:
             break
-    cores = len(os.sched_getaffinity(0))
-    return {"value": N * steps / el, "unit": "agent-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/vf_oracle.c HoverEnv.step restatement (OpenMP, {cores} threads), N={N}, "
-                      f"{steps} control steps, {el:.1f} s"}
+    assert np.isfinite(env.dyn.S).all()
+    oracle.set_threads(cores)
+    out = {"value": N * steps / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+           "sample": f"oracle/vf_oracle.c {kind} env.step restatement (OpenMP, {threads} thread{'s' if threads > 1 else ''}, one "
+                     f"parallel region per {block} steps), N={N}, {steps} control steps, {el:.1f} s"}
+    if note:
+        out["note"] = note
+    return out
 
 
-def bench_ppo(args, rank, world, dev):
-    """secondary measurement (not the driver's metric): NavigationEnv + PPO full train loop,
-    agents sharded by rank, one RCCL all-reduce of the flat gradient per optimiser step."""
+def cpu_baseline(consts, seconds_target=15.0, threads=None):
+    return cpu_baseline_env(consts, "hover", AGENTS_PER_GPU, seconds_target, threads)
+
+
+def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
+    """BASELINE configs[3] shape: NavigationEnv + PPO full train loop (rollout + GAE + 5 epochs of minibatch updates),
+    32 768 agents per GPU (262 144 / 8), agents sharded by rank, one RCCL all-reduce of the flat gradient per
+    optimiser step.  Returns the result dict (rank 0 prints it for --workload ppo; main() embeds it as "secondary")."""
     from visfly_amd import parallel
     from visfly_amd.envs import NavigationEnv
     from visfly_amd.ppo import PPO
@@ -78,42 +93,50 @@ def bench_ppo(args, rank, world, dev):
     torch.cuda.synchronize()
     parallel.barrier()
     t0 = time.perf_counter()
-    iters = max(1, args.steps // 256)
+    iters = iters or max(1, args.steps // 256)
     ppo.learn(256 * N * world * iters)
     torch.cuda.synchronize()
     parallel.barrier()
     el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-    # MFMA roofline of the optimiser steps (outside the timed region): one more train() pass over the last rollout,
-    # timed with device events; algorithmic flops = 2 x weights x rows for each of forward, data gradient, weight gradient
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # split of one iteration and the MFMA roofline of the optimiser steps (outside the timed region): one more rollout and
+    # one more train() pass, each timed with device events; algorithmic flops = 2 x weights x rows for each of forward,
+    # data gradient and weight gradient
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     n0 = ppo._opt_step
-    e0.record()
+    ev[0].record()
+    ppo.collect_rollouts()
+    ev[1].record()
     ppo.train()
-    e1.record()
+    ev[2].record()
     torch.cuda.synchronize()
     n_upd = max(1, ppo._opt_step - n0)
-    us_upd = e0.elapsed_time(e1) * 1e3 / n_upd
+    us_upd = ev[1].elapsed_time(ev[2]) * 1e3 / n_upd
     rows = min(ppo.batch_size, 256 * N)
     flops = 6.0 * ppo.policy.log_std_off * rows          # log_std_off = number of weights + biases of the network
     tfs = flops / (us_upd * 1e-6) / 1e12
     roof = {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
-            "kernel": "optimiser step: k_ppo_update_chain + k_mlp_wgrad + fold + grad norm + Adam", "us_per_update": us_upd,
-            "rows": rows, "note": "fp32 v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md); PMC breakdown in profiles/r01_pmc_mlp.json"}
-    if rank == 0:
-        print(json.dumps({"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
-                          "value": 256 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
-                          "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": f"NavigationEnv {N} agents/GPU, n_steps=256, batch 25600/GPU, 5 epochs",
-                                     "logs": {k: float(v) for k, v in ppo.logs.items()}},
-                          "roofline": roof}), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+            "kernel": "optimiser step: k_ppo_update_chain + k_mlp_wgrad + fold + Adam", "us_per_update": us_upd,
+            "rows": rows, "note": "fp32 v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)"}
+    out = {"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
+           "value": 256 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
+           "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
+           "split_ms": {"collect_rollouts": ev[0].elapsed_time(ev[1]), "train": ev[1].elapsed_time(ev[2]),
+                        "optimiser_steps": n_upd},
+           "config": {"workload": f"NavigationEnv {N} agents/GPU, n_steps=256, batch 25600/GPU, 5 epochs "
+                                  "(BASELINE configs[3] shard)",
+                      "logs": {k: float(v) for k, v in ppo.logs.items()}},
+           "roofline": roof}
+    if cpu_ref and rank == 0:
+        out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "nav", 32768, seconds_target=6.0,
+                                               note="env.step part of the loop only (the reference's PPO runs its MLP on "
+                                                    "torch CPU; not ported to C)")
+    env.close()
+    return out
 
 
-def bench_bptt(args, rank, world, dev):
-    """secondary measurement (BASELINE configs[4]): RacingEnv, thrust actions, BPTT H=64 through the adjoint kernel,
-    agents sharded by rank, one all-reduce of the flat gradient per update."""
+def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
+    """BASELINE configs[4] shape: RacingEnv, thrust actions, BPTT H=64 through the adjoint kernel, 16 384 agents per GPU
+    (131 072 / 8), agents sharded by rank, one all-reduce of the flat gradient per update."""
     from visfly_amd import parallel
     from visfly_amd.bptt import BPTT
     from visfly_amd.envs import RacingEnv
@@ -126,20 +149,43 @@ def bench_bptt(args, rank, world, dev):
     torch.cuda.synchronize()
     parallel.barrier()
     t0 = time.perf_counter()
-    iters = max(1, args.steps // 64)
+    iters = iters or max(1, args.steps // 64)
     algo.learn(64 * N * world * iters)
     torch.cuda.synchronize()
     parallel.barrier()
     el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-    if rank == 0:
-        print(json.dumps({"metric": "BPTT env-steps/s (H=64 rollout + adjoint + actor update, RacingEnv)",
-                          "value": 64 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
-                          "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": f"RacingEnv {N} agents/GPU, thrust actions, horizon 64",
-                                     "logs": {k: float(v) for k, v in algo.logs.items()}}}), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    out = {"metric": "BPTT env-steps/s (H=64 rollout + adjoint + actor update, RacingEnv)",
+           "value": 64 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
+           "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"RacingEnv {N} agents/GPU, thrust actions, horizon 64 (BASELINE configs[4] shard)",
+                      "logs": {k: float(v) for k, v in algo.logs.items()}}}
+    if cpu_ref and rank == 0:
+        out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "racing", 16384, seconds_target=4.0,
+                                               note="forward env.step only (no adjoint on the CPU side)")
+    env.close()
+    return out
+
+
+def _with_watchdog(fn, seconds, what):
+    """secondary measurements must never cost the primary line: run fn() and give up after `seconds`"""
+    import threading
+    box = {}
+
+    dev_index = torch.cuda.current_device()
+
+    def work():
+        try:
+            torch.cuda.set_device(dev_index)          # the current device is per thread
+            box["out"] = fn()
+        except Exception as e:  # noqa: BLE001
+            box["out"] = {"error": f"{type(e).__name__}: {e}"}
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": f"{what}: no result after {seconds} s"}, True
+    return box["out"], False
 
 
 def main():
@@ -148,9 +194,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--agents", type=int, default=AGENTS_PER_GPU, help="agents per GPU")
+    ap.add_argument("--repeats", type=int, default=7, help="the timed --steps region is repeated; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
     ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt"],
-                    help="env: fused HoverEnv.step (the BASELINE metric, default); ppo: full PPO loop (configs[3] shape)")
+                    help="env: fused HoverEnv.step (the BASELINE metric, default); ppo / bptt: that loop only")
     args = ap.parse_args()
 
     from visfly_amd import parallel
@@ -166,21 +214,27 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-    if args.workload == "bptt":
-        return bench_bptt(args, rank, world, dev)
-    if args.workload == "ppo":
-        return bench_ppo(args, rank, world, dev)
+    if args.workload in ("ppo", "bptt"):
+        out = (bench_ppo if args.workload == "ppo" else bench_bptt)(args, rank, world, dev, cpu_ref=world == 1)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from visfly_amd.envs import HoverEnv
-    N = args.agents
+    N, K, W = args.agents, args.steps, args.warmup
     env = HoverEnv(num_agent_per_scene=N, num_scene=1, seed=42 + rank, visual=False, dynamics_kwargs=dict(DYN_KW),
-                   device=dev, max_episode_steps=256, tensor_output=True)   # spawn box: HoverEnv default
+                   device=dev, max_episode_steps=256, tensor_output=True, out_buffers=4)   # spawn box: HoverEnv default
     env.reset()
     dyn = env.envs.dynamics
     g = torch.Generator(device=dev).manual_seed(rank)
     hover = torch.tensor([-1 / 3, 0, 0, 0], device=dev)
-    pool = [(hover + (torch.rand((N, 4), device=dev, generator=g) * 2 - 1) * 0.02).clamp(-1, 1).contiguous()
-            for _ in range(16)]
+    pool = (hover + (torch.rand((16, N, 4), device=dev, generator=g) * 2 - 1) * 0.02).clamp(-1, 1).contiguous()
+    # the K actions of a timed region: a (K,N,4) sequence cycling through 16 distinct synthetic action batches
+    Kc = min(K, 4096)                                    # rollouts longer than 4096 steps are driven in chunks
+    seq = pool.repeat(((Kc + 15) // 16, 1, 1))[:Kc].contiguous()
+    wseq = pool.repeat(((max(W, 1) + 15) // 16, 1, 1))[:max(W, 1)].contiguous()
 
     def barrier():
         torch.cuda.synchronize()
@@ -188,27 +242,57 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    step = env.step
-    for k in range(args.warmup):
-        step(pool[k % 16])
+    def run_steps(n, s):
+        """exactly n env steps, launch loop in C (vf_env_step_n): same kernels, same order, same outputs as n step() calls"""
+        done = 0
+        while done < n:
+            k = min(n - done, s.shape[0])
+            env.step_n(s if k == s.shape[0] else s[:k])
+            done += k
+
+    if W > 0:
+        run_steps(W, wseq)
+    run_steps(min(K, 64), seq)                            # first use of the K-step output buffers is an allocation
+    walls, hosts, events = [], [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()
+        run_steps(K, seq)
+        e1.record()
+        t1 = time.perf_counter()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        walls.append(el)
+        hosts.append(t1 - t0)
+        events.append(e0.elapsed_time(e1) * 1e-3)
+    el = statistics.median(walls)
+
+    # the reference-style driver for comparison: one Python env.step() call per step (zero-allocation output ring)
+    for k in range(min(W, 50)):
+        env.step(pool[k % 16])
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(pool[k % 16])
+    for k in range(K):
+        env.step(pool[k % 16])
+    t1 = time.perf_counter()
     barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    per_call = {"ms_per_step": (time.perf_counter() - t0) / K * 1e3, "host_us_per_step": (t1 - t0) / K * 1e6,
+                "driver": "Python loop over env.step(), out_buffers=4"}
 
     # dominant kernel, HIP events on the launch stream
-    kern_us = env.time_steps(pool[0], iters=200)
-    dyn_us = dyn.time_steps(pool[0], iters=200)
+    kern_us = env.time_steps(pool[0], iters=300)
+    dyn_us = dyn.time_steps(pool[0], iters=300)
     assert torch.isfinite(dyn.state).all()
 
+    out = None
     if rank == 0:
-        value = world * N * args.steps / el
+        value = world * N * K / el
         achieved = BYTES_PER_ENV_STEP * N / (kern_us * 1e-6) / 1e9
         traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (per-agent figure x N)
         try:
@@ -228,13 +312,21 @@ def main():
             pass
         out = {
             "metric": "agent-steps/sec (dynamics.step, visual=False)",
-            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"HoverEnv.step (fused dynamics + collision + reward + done + on-device auto-reset), "
                                    f"{N} agents/GPU, visual=False, bodyrate+euler, dt=0.0025/ctrl_dt=0.02, ctrl_delay, "
                                    "3-slot delay ring, max_episode_steps=256 (BASELINE configs[1])",
-                       "agents_per_gpu": N, "parallelism": f"agents sharded x{world}, no data-path collective"},
+                       "agents_per_gpu": N, "parallelism": f"agents sharded x{world}, no data-path collective",
+                       "driver": "env.step_n(): the K launches of the timed region are enqueued by one C call "
+                                 "(vf_env_step_n); bit-identical to K env.step() calls (tests/test_env_multistep_gpu.py)"},
+            "timing": {"repeats": len(walls), "statistic": "median of the repeated --steps regions, each bracketed by "
+                                                            "barrier + synchronize, max over ranks",
+                       "ms_per_step_all": [w / K * 1e3 for w in walls], "ms_per_step_min": min(walls) / K * 1e3,
+                       "host_us_per_step": statistics.median(hosts) / K * 1e6,
+                       "event_us_per_step": statistics.median(events) / K * 1e6,
+                       "wall_over_kernel": el / K * 1e6 / kern_us, "per_call": per_call},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_env_step<hover,bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
@@ -245,6 +337,25 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dyn.constants)
+            out["cpu_baseline_1core"] = cpu_baseline(dyn.constants, seconds_target=5.0, threads=1)
+    env.close()
+
+    # configs[3] / configs[4] under the same clock: ONE PPO iteration and TWO BPTT updates (after one warm-up each)
+    if not args.no_secondary and os.environ.get("VISFLY_BENCH_SECONDARY", "1") != "0":
+        sec, dead = {}, False
+        for name, fn, iters in (("ppo", bench_ppo, 1), ("bptt", bench_bptt, 2)):
+            res, dead = _with_watchdog(lambda fn=fn, iters=iters: fn(args, rank, world, dev, iters=iters, cpu_ref=world == 1),
+                                       240, name)
+            sec[name] = res
+            if dead:
+                break
+        if out is not None:
+            out["secondary"] = sec
+        if dead:                 # a hung collective: print what we have and leave without joining the stuck thread
+            if out is not None:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+    if out is not None:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

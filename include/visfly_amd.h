@@ -24,9 +24,10 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 3   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
+#define VF_ABI_VERSION 4   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
-                                 vf_mlp_backward_partial_floats */
+                                 vf_mlp_backward_partial_floats;
+                              4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose */
 
 typedef void* vf_stream_t;
 
@@ -233,6 +234,39 @@ int vf_env_reset(vf_env* h, const int32_t* idx, int32_t k, const float* full_sta
  * success/failure + reward + done masks, and, if auto_reset, the examine()/reset_agent_by_id of
  * done agents with on-device spawning.  action (N,4) AoS in [-1,1]. */
 int vf_env_step(vf_env* h, const float* action, const vf_env_out* out, int32_t auto_reset, vf_stream_t stream);
+
+/* K consecutive DroneGymEnvsBase.step calls (droneGymEnv.py:141-218) from ONE host call: the launch loop the
+ * reference drives from Python (`for _ in range(n): env.step(a)`, e.g. exps/ and the test harness
+ * utils/evaluate.py:62-103 with a fixed action sequence) runs in C, so that the host cost per step stays well
+ * below the ~11 us kernel.  Step k reads actions + k*action_stride and writes obs + k*obs_stride,
+ * reward + k*reward_stride, done + k*done_stride (strides in ELEMENTS of the respective array; a stride of 0
+ * re-uses the same rows every step, e.g. one constant action, or outputs that only keep the last step).
+ * The episode outputs of `out` (ep_return ... terminal_gate) are shared by all K steps: each holds the most
+ * recently finished episode per agent.  Results are bit-identical to K vf_env_step calls. */
+typedef struct vf_env_rollout {
+    const float* actions;      /* step 0: (N,4) AoS */
+    int64_t action_stride;
+    vf_env_out out;            /* pointers of step 0 */
+    int64_t obs_stride, reward_stride, done_stride;
+    int32_t K, auto_reset;
+} vf_env_rollout;
+int vf_env_step_n(vf_env* h, const vf_env_rollout* r, vf_stream_t stream);
+
+/* The same K launches captured once into a hipGraph and replayed with one hipGraphLaunch per rollout (the
+ * per-agent delay-ring head lives in the slab, so a launch carries no per-step host state and the captured
+ * kernel arguments stay valid for every replay).  The rollout's pointers are baked into the graph: the caller
+ * keeps those buffers alive and refills `actions` between replays. */
+typedef struct vf_env_graph vf_env_graph;
+int vf_env_graph_create(vf_env* h, const vf_env_rollout* r, vf_env_graph** out);
+int vf_env_graph_launch(vf_env_graph* g, vf_stream_t stream);
+void vf_env_graph_destroy(vf_env_graph* g);
+
+/* Pose hand-off to an external renderer / scene manager: what DroneEnvsBase.step passes to
+ * sceneManager.set_pose(position, orientation, velocity) when visual=True (envs/base/droneEnv.py:375-377,
+ * utils/SceneManager.py:336-361) as AoS device arrays of the CURRENT state: pos (N,3), quat (N,4) wxyz
+ * (16-byte aligned), vel (N,3) incl. wind (dynamics.py:751-752), omg (N,3); every pointer optional.  A renderer
+ * that can read the slab layout above may instead take zero-copy views of the VF_G_POS / VF_G_QUAT granules. */
+int vf_env_export_pose(vf_env* h, float* pos, float* quat, float* vel, float* omg, vf_stream_t stream);
 
 int vf_env_query(vf_env* h, const vf_env_view* view, vf_stream_t stream);
 

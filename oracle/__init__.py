@@ -92,10 +92,8 @@ def consts_from_dict(d):
 
 def build(force=False):
     """compile oracle/libvf_oracle.so with gcc (checker only)"""
-    src = os.path.join(_HERE, "vf_oracle.c")
-    hdr = os.path.join(_HERE, "vf_oracle.h")
-    if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    deps = [os.path.join(_HERE, f) for f in ("vf_oracle.c", "vf_oracle.h", "vf_sleef.h")]
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "libvf_oracle.so"],
                           stdout=subprocess.DEVNULL)
@@ -123,6 +121,15 @@ def lib():
         L.vfo_env_post_step.argtypes = [C.POINTER(Consts), C.POINTER(EnvConsts), C.c_int, fp,
                                         C.POINTER(EnvState)]
         L.vfo_env_post_step.restype = None
+        L.vfo_env_run_steps.argtypes = [C.POINTER(Consts), C.POINTER(EnvConsts), C.c_int, fp, fp, ip, fp, fp, fp, C.c_int,
+                                        C.POINTER(EnvState), C.c_int]
+        L.vfo_env_run_steps.restype = None
+        L.vfo_xmath.argtypes = [C.c_int, fp, fp, fp, C.c_int64]
+        L.vfo_xmath.restype = None
+        L.vfo_set_threads.argtypes = [C.c_int]
+        L.vfo_set_threads.restype = None
+        L.vfo_max_threads.argtypes = []
+        L.vfo_max_threads.restype = C.c_int
         L.vfo_env_obs.argtypes = [C.POINTER(Consts), C.POINTER(EnvConsts), C.c_int, fp, fp]
         L.vfo_env_obs.restype = None
         L.vfo_env_reset_attr.argtypes = [C.c_int, C.POINTER(EnvState), ip, C.c_int]
@@ -276,6 +283,14 @@ class OracleEnv:
         lib().vfo_env_post_step(C.byref(self.dyn.c), C.byref(self.e), self.N, _fp(self.dyn.S), C.byref(self.es))
         return obs, self.a["reward"].copy(), self.a["done"].copy()
 
+    def run_steps(self, actions, steps):
+        """`steps` consecutive step() calls without resets in one OpenMP region (thread-chunked agents): the timing path of
+        bench.py's cpu_baseline; arithmetic identical to step().  actions: (n,N,4), used cyclically."""
+        actions = np.ascontiguousarray(actions, np.float32).reshape(-1, self.N, 4)
+        d = self.dyn
+        lib().vfo_env_run_steps(C.byref(d.c), C.byref(self.e), self.N, _fp(d.S), _fp(d.Q), C.byref(d.tick),
+                                _fp(d.klin), _fp(d.kquad), _fp(actions), actions.shape[0], C.byref(self.es), int(steps))
+
     @property
     def obs_state(self):
         """get_observation()["state"] of the env kind (raw state or the HoverEnv2 / NavigationEnv2 variants)"""
@@ -299,6 +314,25 @@ class OracleEnv:
         self.a["once_collided"][idx] = 0
         lib().vfo_env_reset_attr(self.N, C.byref(self.es), _ip(idx), len(idx))
 
+
+
+def xmath(kind, a, b=None):
+    """vf_sleef.h (SLEEF u10 routines restated) over arrays: kind in atan2 | sin | cos | acos"""
+    k = {"atan2": 0, "sin": 1, "cos": 2, "acos": 3}[kind]
+    a = np.ascontiguousarray(a, np.float32)
+    b = a if b is None else np.ascontiguousarray(b, np.float32)
+    out = np.empty_like(a)
+    lib().vfo_xmath(k, _fp(a), _fp(b), _fp(out), a.size)
+    return out
+
+
+def set_threads(n):
+    """OpenMP threads used by the following oracle calls (cpu_baseline reports the count it used)"""
+    lib().vfo_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().vfo_max_threads())
 
 
 def td_returns(r, done, next_value, episode_done=None, gamma=0.99, lamda=0.95):

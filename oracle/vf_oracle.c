@@ -10,10 +10,45 @@
  * explicitly; everything else relies on -ffp-contract=off.
  */
 #include "vf_oracle.h"
+#include "vf_sleef.h"   /* atan2 = SLEEF u10 restated; all SLEEF u10 restated (see its header) */
 
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* contiguous agent range of the calling OpenMP thread (whole range outside a parallel region) */
+static inline void thread_range(int N, int* i0, int* i1)
+{
+#ifdef _OPENMP
+    const int nt = omp_get_num_threads(), t = omp_get_thread_num();
+#else
+    const int nt = 1, t = 0;
+#endif
+    const int per = (N + nt - 1) / nt;
+    *i0 = t * per < N ? t * per : N;
+    *i1 = *i0 + per < N ? *i0 + per : N;
+}
+
+void vfo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+int vfo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ---------- small helpers ---------- */
 
@@ -121,18 +156,18 @@ static void geometric_controller(const vfo_consts* c, const float* a, const floa
         F[k] = c->m * (a_des - (k == 2 ? c->g_z : 0.0f));      /* :417,458 */
     }
     /* Quaternion.toEuler()[2] (utils/maths.py:248) */
-    float yaw_cur = atan2f(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
+    float yaw_cur = vfs_atan2f_u10(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
     float yaw_des, gain;
     if (pos_mode) {
         yaw_des = cmd[0];                                      /* :461 */
         gain = c->pos_d;                                       /* :468 */
     } else {
         float vn = sqrtf(fmaf(v[1], v[1], v[0] * v[0]));       /* :421 */
-        yaw_des = vn > 0.1f ? atan2f(v[1], v[0]) : yaw_cur;    /* :423-427 */
+        yaw_des = vn > 0.1f ? vfs_atan2f_u10(v[1], v[0]) : yaw_cur;    /* :423-427 */
         gain = c->vel_d;                                       /* :433 */
     }
     float ye = yaw_des - yaw_cur;
-    ye = atan2f(sinf(ye), cosf(ye));                           /* :432,467 */
+    ye = vfs_atan2f_u10(vfs_sinf_u10(ye), vfs_cosf_u10(ye));                           /* :432,467 */
     float yaw_spd = ye * gain * 2.0f;
     /* gross thrust = (conj(q) * (0,F) * q).imag[2]            :435, maths.py:49,103 */
     quat fq = { 0.0f, F[0], F[1], F[2] };
@@ -146,7 +181,7 @@ static void geometric_controller(const vfo_consts* c, const float* a, const floa
     /* desired frame :437-442 */
     float fn = sqrtf(fmaf(F[2], F[2], fmaf(F[1], F[1], F[0] * F[0])));
     float b3[3] = { F[0] / fn, F[1] / fn, F[2] / fn };
-    float c1[3] = { cosf(yaw_des), sinf(yaw_des), 0.0f };
+    float c1[3] = { vfs_cosf_u10(yaw_des), vfs_sinf_u10(yaw_des), 0.0f };
     float b2[3], b1[3];
     cross_helper(b3, c1, b2);
     float bn = sqrtf(fmaf(b2[2], b2[2], fmaf(b2[1], b2[1], b2[0] * b2[0])));
@@ -193,16 +228,14 @@ static void geometric_controller(const vfo_consts* c, const float* a, const floa
 
 /* ---------- Dynamics.step ---------- */
 
-void vfo_dyn_step(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
-                  const float* klin, const float* kquad,
-                  const float* action, float* obs)
+static void dyn_step_range(const vfo_consts* c, int N, float* S, float* Q, int slot,
+                           const float* klin, const float* kquad,
+                           const float* action, float* obs, int i0, int i1)
 {
     const int D = c->delay_steps;
-    const int slot = D > 0 ? (int)((*tick) % D) : 0;
     const float dt = c->dt;
 
-#pragma omp parallel for schedule(static) if (N >= 4096)
-    for (int i = 0; i < N; ++i) {
+    for (int i = i0; i < i1; ++i) {
 #define ROW(r) S[(size_t)(r) * N + i]
         /* ---- delay queue: use oldest, store newest   dynamics.py:323-328 ---- */
         float a[4];
@@ -385,6 +418,20 @@ void vfo_dyn_step(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
         }
 #undef ROW
     }
+}
+
+void vfo_dyn_step(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
+                  const float* klin, const float* kquad,
+                  const float* action, float* obs)
+{
+    const int D = c->delay_steps;
+    const int slot = D > 0 ? (int)((*tick) % D) : 0;
+#pragma omp parallel if (N >= 4096)
+    {
+        int i0, i1;
+        thread_range(N, &i0, &i1);
+        dyn_step_range(c, N, S, Q, slot, klin, kquad, action, obs, i0, i1);
+    }
     if (D > 0) *tick = (*tick + 1) % D;
 }
 
@@ -459,14 +506,10 @@ static inline float dot3_sum(const float* a, const float* b)
     return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
 }
 
-void vfo_update_collision(const vfo_env_consts* e, int N, const float* S, vfo_env_state* es,
-                          const int32_t* idx, int k)
+static void collision_point_range(const vfo_env_consts* e, int N, const float* S, vfo_env_state* es,
+                                  const int32_t* idx, int j0, int j1)
 {
-    /* NB the reference recomputes vector/dis/flags for ALL agents even for an
-     * indexed call (droneEnv.py:364-369); only collision_point is indexed. */
-    const int n = idx ? k : N;
-#pragma omp parallel for schedule(static) if (N >= 4096)
-    for (int j = 0; j < n; ++j) {
+    for (int j = j0; j < j1; ++j) {
         const int i = idx ? idx[j] : j;
         float p[3] = { S[(size_t)(VFO_POS)*N + i], S[(size_t)(VFO_POS + 1) * N + i], S[(size_t)(VFO_POS + 2) * N + i] };
         /* hstack([p - lo, hi - p]).min(dim=1)   :347-350 ; first minimum wins */
@@ -478,8 +521,11 @@ void vfo_update_collision(const vfo_env_consts* e, int N, const float* S, vfo_en
         cp[best % 3] = best < 3 ? e->bbox_lo[best] : e->bbox_hi[best - 3]; /* :352 */
         for (int d = 0; d < 3; ++d) es->col_point[3 * (size_t)i + d] = cp[d];
     }
-#pragma omp parallel for schedule(static) if (N >= 4096)
-    for (int i = 0; i < N; ++i) {
+}
+
+static void collision_flags_range(const vfo_env_consts* e, int N, const float* S, vfo_env_state* es, int i0, int i1)
+{
+    for (int i = i0; i < i1; ++i) {
         float p[3] = { S[(size_t)(VFO_POS)*N + i], S[(size_t)(VFO_POS + 1) * N + i], S[(size_t)(VFO_POS + 2) * N + i] };
         uint8_t oob = 0;
         for (int d = 0; d < 3; ++d) oob |= (p[d] < e->bbox_lo[d]) | (p[d] > e->bbox_hi[d]); /* :361-362 */
@@ -491,6 +537,23 @@ void vfo_update_collision(const vfo_env_consts* e, int N, const float* S, vfo_en
         es->is_out_bounds[i] = oob;
         es->is_collision[i] = dis < e->uav_radius;                                    /* :367 */
         es->once_collided[i] = es->once_collided[i] | es->is_collision[i];            /* :369 */
+    }
+}
+
+void vfo_update_collision(const vfo_env_consts* e, int N, const float* S, vfo_env_state* es,
+                          const int32_t* idx, int k)
+{
+    /* NB the reference recomputes vector/dis/flags for ALL agents even for an
+     * indexed call (droneEnv.py:364-369); only collision_point is indexed. */
+    const int n = idx ? k : N;
+#pragma omp parallel if (N >= 4096)
+    {
+        int j0, j1, i0, i1;
+        thread_range(n, &j0, &j1);
+        collision_point_range(e, N, S, es, idx, j0, j1);
+#pragma omp barrier
+        thread_range(N, &i0, &i1);
+        collision_flags_range(e, N, S, es, i0, i1);
     }
 }
 
@@ -506,11 +569,10 @@ static float hover_like_reward(const float* p, const float* tgt, const float* q,
     return r;
 }
 
-void vfo_env_post_step(const vfo_consts* c, const vfo_env_consts* e, int N, const float* S,
-                       vfo_env_state* es)
+static void env_post_step_range(const vfo_consts* c, const vfo_env_consts* e, int N, const float* S,
+                                vfo_env_state* es, int i0, int i1)
 {
-#pragma omp parallel for schedule(static) if (N >= 4096)
-    for (int i = 0; i < N; ++i) {
+    for (int i = i0; i < i1; ++i) {
 #define ROW(r) S[(size_t)(r) * N + i]
         float p[3] = { ROW(VFO_POS), ROW(VFO_POS + 1), ROW(VFO_POS + 2) };
         float q[4] = { ROW(VFO_QUAT), ROW(VFO_QUAT + 1), ROW(VFO_QUAT + 2), ROW(VFO_QUAT + 3) };
@@ -558,7 +620,7 @@ void vfo_env_post_step(const vfo_consts* c, const vfo_env_consts* e, int N, cons
             const float thrd = (float)(3.14159265358979323846 / 18.0);
             float cs = dot3_sum(dir, v) / (1e-6f + norm3(v[0], v[1], v[2])) / 1.0f;
             cs = clampf(cs, -1.0f, 1.0f);
-            float ang = acosf(cs);
+            float ang = vfs_acosf_u10(cs);
             ang = ang < thrd ? thrd : ang;
             float t2 = (ang - thrd) * -0.01f;
             float t3 = norm4(q[0] - 1.0f, q[1] - 0.0f, q[2] - 0.0f, q[3] - 0.0f) * (float)-0.00001;
@@ -599,6 +661,42 @@ void vfo_env_post_step(const vfo_consts* c, const vfo_env_consts* e, int N, cons
         es->episode_done[i] = ed;
         es->done[i] = ed | (es->step_count[i] >= e->max_episode_steps);                /* :193 */
     }
+}
+
+void vfo_env_post_step(const vfo_consts* c, const vfo_env_consts* e, int N, const float* S,
+                       vfo_env_state* es)
+{
+#pragma omp parallel if (N >= 4096)
+    {
+        int i0, i1;
+        thread_range(N, &i0, &i1);
+        env_post_step_range(c, e, N, S, es, i0, i1);
+    }
+}
+
+/* bench.py's cpu_baseline leg: `steps` consecutive env steps (dynamics interval + bbox collision + counters / reward /
+ * done masks, no resets) with ONE parallel region -- agents are independent, so every thread walks its own contiguous
+ * agent chunk through all the steps (no fork-join per step, the chunk stays in that core's cache).  The same range
+ * functions as the per-step entry points above; `actions` holds n_actions (N,4) batches used cyclically. */
+void vfo_env_run_steps(const vfo_consts* c, const vfo_env_consts* e, int N, float* S, float* Q, int32_t* tick,
+                       const float* klin, const float* kquad, const float* actions, int n_actions,
+                       vfo_env_state* es, int steps)
+{
+    const int D = c->delay_steps;
+    const int tick0 = *tick;
+#pragma omp parallel
+    {
+        int i0, i1;
+        thread_range(N, &i0, &i1);
+        for (int s = 0; s < steps; ++s) {
+            const int slot = D > 0 ? (tick0 + s) % D : 0;
+            dyn_step_range(c, N, S, Q, slot, klin, kquad, actions + (size_t)(s % n_actions) * 4 * N, NULL, i0, i1);
+            collision_point_range(e, N, S, es, NULL, i0, i1);
+            collision_flags_range(e, N, S, es, i0, i1);
+            env_post_step_range(c, e, N, S, es, i0, i1);
+        }
+    }
+    if (D > 0) *tick = (tick0 + steps) % D;
 }
 
 void vfo_env_reset_attr(int N, vfo_env_state* es, const int32_t* idx, int k)
@@ -660,6 +758,19 @@ void vfo_td_returns(const float* r, const uint8_t* done, const uint8_t* episode_
             Ai = active * ((lg * Ai + gamma * next_value[o]) + ((1.0f - lam) / oml) * r[o]);
             Bi = gamma * (next_value[o] * dm * ea + Bi * active) + r[o];
             returns[o] = oml * Ai + lam * Bi;
+        }
+    }
+}
+
+/* ---------- transcendentals (vf_sleef.h) over arrays, for tests/test_sleef_restatement.py ---------- */
+void vfo_xmath(int kind, const float* a, const float* b, float* out, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        switch (kind) {
+        case 0: out[i] = vfs_atan2f_u10(a[i], b[i]); break;
+        case 1: out[i] = vfs_sinf_u10(a[i]); break;
+        case 2: out[i] = vfs_cosf_u10(a[i]); break;
+        default: out[i] = vfs_acosf_u10(a[i]); break;
         }
     }
 }

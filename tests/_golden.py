@@ -41,13 +41,16 @@ GEOMETRIC = ["dyn_velocity_euler", "dyn_position_euler"]
 
 
 def assert_geometric_close(got, want_all, want, what=""):
-    """velocity / position action types: the controller evaluates sin/cos/atan2, which torch takes
-    from its vectorised SLEEF build and which no libm / device library reproduces to the bit.
-    Tolerance (north_star: 1e-5 relative after 256 steps): per extend_state column,
-    |diff| <= 1e-4 * max|column| over the fixture -- measured worst case 2e-5."""
+    """velocity / position action types: the controller evaluates sin / cos / atan2.  torch.atan2 is SLEEF's
+    atan2f_u10 and is restated bit for bit; torch.sin / torch.cos run Intel MKL VML (closed source), so the oracle and
+    the kernels use SLEEF's sinf_u10 / cosf_u10 (restated bit for bit, the closest published algorithms), which differ
+    from MKL by one ulp in ~2 % of the calls (oracle/vf_sleef.h, tests/test_sleef_restatement.py).  After ONE control
+    step >= 98 % of the state words are bit-identical; the closed attitude loop then amplifies the one-ulp
+    differences.  Tolerance per extend_state column: |diff| <= 5e-5 * max|column| over the 256-step fixture -- looser
+    than north_star's 1e-5, which these two action types cannot meet without MKL's algorithm."""
     got = np.asarray(got, np.float32)
     scale = np.abs(want_all).reshape(-1, want_all.shape[-1]).max(0)
-    lim = 1e-4 * np.maximum(scale, 1e-3)
+    lim = 5e-5 * np.maximum(scale, 1e-3)
     d = np.abs(got - want)
     bad = d > lim
     if bad.any():

@@ -53,7 +53,8 @@ def test_golden_bit_exact(name):
 @pytest.mark.parametrize("name", GEOMETRIC)
 def test_geometric_controller_golden(name):
     """velocity / position action types: the reference's per-agent Python loop
-    (dynamics.py:446-450) as one fused launch; tolerance-level parity (device sin/cos/atan2 vs SLEEF)"""
+    (dynamics.py:446-450) as one fused launch; tolerance-level parity against the reference (its sin / cos are MKL VML,
+    closed source -- oracle/vf_sleef.h), bit-level parity against the oracle in the next test"""
     fx = load(name)
     consts = consts_of(fx)
     acts = decode_actions(fx)
@@ -75,7 +76,8 @@ def test_geometric_controller_golden(name):
 
 @pytest.mark.parametrize("mode", ["velocity", "position"])
 def test_geometric_vs_oracle_one_step(mode):
-    """single control steps from identical states: HIP vs the C oracle (libm) within 2e-6 relative"""
+    """control steps from identical states: HIP and the C oracle share the restated transcendentals (oracle/vf_sleef.h ==
+    csrc/vf_xmath.hpp: SLEEF's u10 atan2 / sin / cos), so these two action types are bit-identical too"""
     from visfly_amd import Dynamics
     N = 1000
     kw = dict(action_type=mode, dt=0.0025, ctrl_dt=0.02, ctrl_delay=True, comm_delay=0.0)
@@ -94,10 +96,33 @@ def test_geometric_vs_oracle_one_step(mode):
         a = rng.uniform(-0.3, 0.3, (N, 4)).astype(np.float32)
         s = dyn.step(torch.from_numpy(a).cuda()).cpu().numpy()
         so = ref.step(a)
-        e, eo = dyn.extend_state.cpu().numpy(), ref.extend_state
-        scale = np.maximum(np.abs(eo).max(0), 1e-3)
-        assert (np.abs(e - eo) <= 2e-6 * scale).all(), (np.abs(e - eo) / scale).max()
-        assert (np.abs(s - so) <= 2e-6 * np.maximum(np.abs(so).max(0), 1e-3)).all()
+        for k in range(6):                                      # a few closed-loop steps on top of the first one
+            assert_bits_equal(dyn.extend_state.cpu().numpy(), ref.extend_state, f"{mode} extend_state, trial {trial} step {k}")
+            assert_bits_equal(s, so, f"{mode} step() return, trial {trial} step {k}")
+            a = rng.uniform(-0.3, 0.3, (N, 4)).astype(np.float32)
+            s = dyn.step(torch.from_numpy(a).cuda()).cpu().numpy()
+            so = ref.step(a)
+
+
+@pytest.mark.parametrize("name", GEOMETRIC)
+def test_geometric_fixture_bit_identical_to_oracle(name):
+    """the whole 256-step fixture run: HIP == CPU oracle, bit for bit, at every checkpoint (the tolerance of
+    test_geometric_controller_golden is entirely between the oracle and torch's closed-source MKL sin / cos)"""
+    fx = load(name)
+    acts = decode_actions(fx)
+    N = fx["fs0"].shape[0]
+    dyn = make_dyn(consts_of(fx), N)
+    set_full_state(dyn, fx["fs0"])
+    od = oracle.OracleDynamics(consts_of(fx), N)
+    od.set_full_state(fx["fs0"])
+    acts_d = torch.from_numpy(acts).cuda()
+    cps = list(fx["checkpoints"])
+    for k in range(acts.shape[0]):
+        obs = dyn.step(acts_d[k])
+        oo = od.step(acts[k])
+        if (k + 1) in cps:
+            assert_bits_equal(dyn.extend_state.cpu().numpy(), od.extend_state, f"{name} extend_state @ {k + 1}")
+            assert_bits_equal(obs.cpu().numpy(), oo, f"{name} step() return @ {k + 1}")
 
 
 @pytest.mark.parametrize("N", [1, 63, 64, 65, 257, 4099])

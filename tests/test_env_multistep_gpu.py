@@ -1,0 +1,202 @@
+"""Multi-step launch paths of the env boundary (vf_env_step_n, vf_env_graph_*, the output ring of step()) against the
+per-call path: same seeds, same actions -> every returned array and the final slab bit-identical, through auto-resets.
+Pose hand-off (vf_env_export_pose) against the full_state columns, after steps and after auto-resets."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DYN = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+
+
+def bits(t):
+    return t.detach().cpu().contiguous().view(torch.uint8 if t.dtype == torch.bool else torch.int32).numpy()
+
+
+def same(a, b, what):
+    assert np.array_equal(bits(a), bits(b)), what
+
+
+def make(cls_name, N, seed=7, **kw):
+    import visfly_amd.envs as E
+    dyn = dict(DYN, action_type="thrust") if cls_name == "RacingEnv" else dict(DYN)
+    env = getattr(E, cls_name)(num_agent_per_scene=N, seed=seed, dynamics_kwargs=dyn, device="cuda:0", tensor_output=True,
+                               max_episode_steps=12, **kw)          # short episodes: auto-resets inside every run
+    env.reset()
+    return env
+
+
+def actions(N, K, seed=0, wide=0.6):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.rand((K, N, 4), device="cuda", generator=g) * 2 - 1).mul_(wide).contiguous()
+
+
+@pytest.mark.parametrize("cls_name,N", [("HoverEnv", 1000), ("NavigationEnv", 4099), ("RacingEnv", 777), ("HoverEnv", 40000)])
+def test_step_n_equals_k_steps(cls_name, N):
+    K = 40
+    A = actions(N, K)
+    ref, env = make(cls_name, N), make(cls_name, N)
+    outs = [ref.step(A[k]) for k in range(K)]
+    obs, reward, done = env.step_n(A)
+    assert obs.shape == (K, N, 13) and reward.shape == (K, N) and done.shape == (K, N) and done.dtype == torch.bool
+    assert bool(done.any()), "the run must contain auto-resets"
+    for k in range(K):
+        same(obs[k], outs[k][0]["state"], f"obs @ {k}")
+        same(reward[k], outs[k][1], f"reward @ {k}")
+        same(done[k], outs[k][2], f"done @ {k}")
+    same(env._slab, ref._slab, "slab after the rollout")
+    same(env._ep_return, ref._ep_return, "episode returns")
+    same(env._ep_length, ref._ep_length, "episode lengths")
+    same(env.get_observation()["state"], outs[-1][0]["state"], "get_observation() after step_n")
+    same(env.reward, outs[-1][1], "env.reward after step_n")
+    if cls_name == "RacingEnv":
+        same(env.get_observation()["gate"], outs[-1][0]["gate"], "gate observation")
+    # a second rollout continues from the same state as further step() calls
+    B = actions(N, K, seed=1)
+    outs2 = [ref.step(B[k]) for k in range(K)]
+    obs2, reward2, done2 = env.step_n(B)
+    same(obs2[K - 1], outs2[-1][0]["state"], "second rollout: last obs")
+    same(env._slab, ref._slab, "slab after the second rollout")
+
+
+def test_step_n_is_test_keeps_done_agents():
+    N, K = 512, 30
+    A = actions(N, K)
+    ref, env = make("HoverEnv", N), make("HoverEnv", N)
+    outs = [ref.step(A[k], is_test=True) for k in range(K)]
+    obs, reward, done = env.step_n(A, is_test=True)
+    for k in (0, 11, 12, K - 1):
+        same(obs[k], outs[k][0]["state"], f"obs @ {k}")
+        same(done[k], outs[k][2], f"done @ {k}")
+    same(env._slab, ref._slab, "slab")
+
+
+def test_graph_replay_equals_k_steps():
+    N, K = 3000, 24
+    ref, env = make("NavigationEnv", N), make("NavigationEnv", N)
+    buf = torch.empty((K, N, 4), device="cuda")
+    for rnd in range(3):                      # the SAME captured graph replays with refilled actions
+        A = actions(N, K, seed=rnd)
+        buf.copy_(A)
+        outs = [ref.step(A[k]) for k in range(K)]
+        obs, reward, done = env.step_n(buf, graph=True)
+        for k in range(K):
+            same(obs[k], outs[k][0]["state"], f"round {rnd} obs @ {k}")
+            same(reward[k], outs[k][1], f"round {rnd} reward @ {k}")
+            same(done[k], outs[k][2], f"round {rnd} done @ {k}")
+        same(env._slab, ref._slab, f"round {rnd} slab")
+    assert len(env._rollouts[K]["graphs"]) == 1
+    env.close()
+
+
+def test_output_ring_equals_fresh_tensors():
+    N, K, R = 2049, 30, 3
+    A = actions(N, K)
+    ref, env = make("RacingEnv", N), make("RacingEnv", N, out_buffers=R)
+    held = []
+    for k in range(K):
+        o0, r0, d0, i0 = ref.step(A[k])
+        o1, r1, d1, i1 = env.step(A[k])
+        same(o1["state"], o0["state"], f"obs @ {k}")
+        same(o1["gate"], o0["gate"], f"gate @ {k}")
+        same(r1, r0, f"reward @ {k}")
+        same(d1, d0, f"done @ {k}")
+        idx = torch.nonzero(d0).flatten().cpu().numpy()
+        if len(idx):
+            j = int(idx[0])
+            assert i1[j]["episode"]["l"] == i0[j]["episode"]["l"] and i1[j]["TimeLimit.truncated"] == i0[j]["TimeLimit.truncated"]
+            assert i1[j]["episode"]["extra"]["past_gate"] == i0[j]["episode"]["extra"]["past_gate"]
+        held.append((o1["state"], o0["state"].clone()))
+        if k >= R - 1:                         # what step t returned is still intact R-1 steps later
+            same(held[k - (R - 1)][0], held[k - (R - 1)][1], f"slot of step {k - (R - 1)} still valid at step {k}")
+    assert held[0][0].data_ptr() == held[R][0].data_ptr(), "ring re-uses its buffers"
+    with pytest.raises(ValueError):
+        make("HoverEnv", 64, out_buffers=1)
+
+
+def test_step_n_rejects_replay_and_tape():
+    from visfly_amd._lib import VisflyError
+    env = make("HoverEnv", 128, spawn="replay")
+    with pytest.raises(VisflyError):
+        env.step_n(actions(128, 2))
+    env2 = make("HoverEnv", 128, requires_grad=True)
+    with pytest.raises(VisflyError):
+        env2.step_n(actions(128, 2))
+    env3 = make("HoverEnv", 128)
+    with pytest.raises(ValueError):
+        env3.step_n(actions(64, 2))
+
+
+def test_step_n_c_abi_strides_and_errors():
+    """direct C-ABI call: stride 0 = one constant action / outputs that keep only the last step"""
+    from visfly_amd import _lib
+    L = _lib.lib()
+    N, K = 640, 9
+    ref, env = make("HoverEnv", N), make("HoverEnv", N)
+    a = actions(N, 1)[0]
+    for _ in range(K):
+        o, r, d, _i = ref.step(a)
+    obs, rew, done = torch.empty((N, 13), device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, dtype=torch.bool, device="cuda")
+    ro = _lib.EnvRollout()
+    ro.out = env._out(obs, rew, done)
+    ro.actions, ro.K, ro.auto_reset = a.data_ptr(), K, 1          # every stride 0
+    _lib.check(L.vf_env_step_n(env._h, C.byref(ro), _lib.current_stream(env.device)))
+    same(obs, o["state"], "last obs")
+    same(rew, r, "last reward")
+    same(env._slab, ref._slab, "slab")
+    ro.K = 0
+    assert L.vf_env_step_n(env._h, C.byref(ro), None) == -1 and b"K must be > 0" in L.vf_last_error()
+    ro.K, ro.actions = 2, None
+    assert L.vf_env_step_n(env._h, C.byref(ro), None) == -1
+    g = _lib._vp()
+    assert L.vf_env_graph_create(env._h, C.byref(ro), C.byref(g)) == -1
+    assert L.vf_env_graph_launch(None, None) == -1
+
+
+@pytest.mark.parametrize("cls_name", ["HoverEnv", "NavigationEnv"])
+def test_export_pose_matches_full_state(cls_name):
+    N = 1500
+    env = make(cls_name, N)
+    A = actions(N, 20)
+    pose = None
+    saw_reset = False
+    for k in range(20):
+        obs, reward, done, info = env.step(A[k])
+        saw_reset |= bool(done.any())
+        pose = env.export_pose(pose)
+        fs = env.full_state
+        same(pose["position"], fs[:, 0:3].contiguous(), f"position @ {k}")
+        same(pose["rotation"], fs[:, 3:7].contiguous(), f"rotation @ {k}")
+        same(pose["velocity"], fs[:, 7:10].contiguous(), f"velocity @ {k}")
+        same(pose["angular_velocity"], fs[:, 10:13].contiguous(), f"angular velocity @ {k}")
+        same(pose["position"], obs["state"][:, 0:3].contiguous(), "pose == returned observation (post auto-reset)")
+        same(pose["rotation"], env.envs.dynamics.quaternion.contiguous(), "Dynamics.quaternion")
+    assert saw_reset
+
+    class Scene:                               # the stub an external renderer plugs in
+        def set_pose(self, position, rotation, velocity=None):
+            self.got = (position, rotation, velocity)
+
+    sc = Scene()
+    p = env.export_pose()
+    sc.set_pose(p["position"], p["rotation"], p["velocity"])
+    assert sc.got[1].shape == (N, 4)
+
+
+def test_export_pose_wind_and_partial_outputs():
+    from visfly_amd import _lib
+    import visfly_amd.envs as E
+    N = 300
+    env = E.HoverEnv(num_agent_per_scene=N, dynamics_kwargs=dict(DYN, wind_settings=(0.5, -0.25, 0.125)), device="cuda:0",
+                     tensor_output=True)
+    env.reset()
+    obs, _r, _d, _i = env.step(actions(N, 1)[0])
+    pos, vel = torch.empty((N, 3), device="cuda"), torch.empty((N, 3), device="cuda")
+    _lib.check(_lib.lib().vf_env_export_pose(env._h, pos.data_ptr(), None, vel.data_ptr(), None, _lib.current_stream(env.device)))
+    same(pos, env.position.contiguous(), "position only")
+    same(vel, obs["state"][:, 7:10].contiguous(), "velocity includes the wind (dynamics.py:751-752)")
+    same(vel, env.velocity.contiguous(), "Dynamics.velocity")
+    assert _lib.lib().vf_env_export_pose(None, None, None, None, None, None) == -1

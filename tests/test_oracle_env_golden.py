@@ -20,9 +20,9 @@ def run_env_fixture(name, make_env, step_fn, reset_fn, state_fn, gates_fn=None):
     for k in range(steps):
         out = step_fn(env, acts[k])
         if str(fx["kind"]) == "nav":
-            # NavigationEnv's reward goes through acos (NavigationEnv.py:88): torch's vectorised CPU acos
-            # (SLEEF, <=1 ulp, not correctly rounded -- SURVEY App. B.4) cannot be reproduced bit-for-bit
-            # by another libm.  1 ulp of acos (<=2.4e-7) * 0.01 -> a few 1e-9 absolute through the partial sums (bound used: 5e-8), plus one final-rounding
+            # NavigationEnv's reward goes through acos (NavigationEnv.py:88): torch's CPU acos is Intel MKL VML
+            # (closed source; oracle/probe_torch_transcendentals.py); the closest published algorithm, SLEEF's acosf_u10
+            # (restated in oracle/vf_sleef.h), differs from it by one ulp for ~8 % of the arguments.  1 ulp of acos (<=2.4e-7) * 0.01 -> a few 1e-9 absolute through the partial sums (bound used: 5e-8), plus one final-rounding
             # ulp (2^-23 relative) when that perturbation crosses a rounding boundary of the summed reward;
             # everything that feeds done / counters / state stays bit-exact below.
             tol = 5e-8 + 1.2e-7 * np.abs(fx["reward"][k])
@@ -72,3 +72,32 @@ def test_oracle_env_trace(name):
 
     run_env_fixture(name, make_env, step_fn, lambda env, idx, fs: env.reset_agents(idx, fs), state_fn,
                     lambda env: (env.a["next_gate"], env.a["past_gates"]))
+
+
+def test_run_steps_equals_step_loop():
+    """the chunked multi-step driver bench.py times (vfo_env_run_steps, one OpenMP region) is the same arithmetic as the
+    per-step entry points the golden fixtures pin"""
+    import oracle
+    from _golden import consts_of, load
+    fx = load("env_hover")
+    c = consts_of(fx)
+    N = 5000                       # > 4096: the per-step path takes its OpenMP branch too
+    rng = np.random.default_rng(3)
+    fs = np.zeros((N, 22), np.float32)
+    fs[:, 0:3] = (np.array([1, 0, 1.5]) + rng.uniform(-1, 1, (N, 3))).astype(np.float32)
+    fs[:, 3] = 1.0
+    fs[:, 13:17], fs[:, 17:21] = c["w_init"], c["T_init"]
+    acts = np.clip(rng.uniform(-.5, .5, (5, N, 4)), -1, 1).astype(np.float32)
+    for threads in (1, 3, oracle.max_threads()):
+        oracle.set_threads(threads)
+        a, b = (oracle.OracleEnv(c, N, "hover", 256) for _ in range(2))
+        a.reset_full_state(fs)
+        b.reset_full_state(fs)
+        for k in range(13):
+            a.step(acts[k % 5])
+        b.run_steps(acts, 13)
+        assert np.array_equal(a.dyn.S.view(np.uint32), b.dyn.S.view(np.uint32))
+        assert np.array_equal(a.dyn.Q.view(np.uint32), b.dyn.Q.view(np.uint32)) and a.dyn.tick.value == b.dyn.tick.value
+        for k in ("reward", "rewards", "done", "step_count", "col_dis", "once_collided"):
+            assert np.array_equal(a.a[k], b.a[k]), k
+    oracle.set_threads(oracle.max_threads())

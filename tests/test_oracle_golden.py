@@ -12,9 +12,9 @@ DYN = ["dyn_bodyrate_euler", "dyn_bodyrate_euler_wide", "dyn_thrust_euler", "dyn
 
 @pytest.mark.parametrize("name", GEOMETRIC)
 def test_geometric_controller_vs_reference(name):
-    """velocity / position action types (dynamics.py:414-496): tolerance-level pin (libm vs SLEEF
-    sin/cos/atan2); after ONE control step >= 95 % of all state words are still bit-identical,
-    which pins the operation order of the restated controller."""
+    """velocity / position action types (dynamics.py:414-496): tolerance-level pin (torch's sin / cos are closed-source
+    MKL VML, see _golden.assert_geometric_close); after ONE control step >= 98 % of all state words are still
+    bit-identical, which pins the operation order of the restated controller and the SLEEF atan2 restatement."""
     fx = load(name)
     acts = decode_actions(fx)
     N = fx["fs0"].shape[0]
@@ -29,7 +29,7 @@ def test_geometric_controller_vs_reference(name):
             assert_geometric_close(obs, fx["obs"], fx["obs"][j], f"{name} obs @ step {k + 1}")
             if k == 0:
                 same = (bits(od.extend_state) == bits(fx["ext"][j])).mean()
-                assert same >= 0.95, same
+                assert same >= 0.98, same
 
 
 @pytest.mark.parametrize("name", DYN)

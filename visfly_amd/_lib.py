@@ -70,7 +70,7 @@ class DynCfg(C.Structure):
 
 
 EUNSUPPORTED = -4         # VF_EUNSUPPORTED
-ABI_VERSION = 3          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
+ABI_VERSION = 4          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
 MAX_GATES, MAX_SPAWN = 8, 4
 
 
@@ -99,6 +99,13 @@ class EnvOut(C.Structure):
     """mirror of vf_env_out (device pointers)"""
     _fields_ = [(n, C.c_void_p) for n in ("obs", "reward", "done", "ep_return", "ep_length", "ep_flags",
                                           "terminal_obs", "gate", "ep_past_gates", "terminal_gate")]
+
+
+class EnvRollout(C.Structure):
+    """mirror of vf_env_rollout"""
+    _fields_ = [("actions", C.c_void_p), ("action_stride", C.c_int64), ("out", EnvOut),
+                ("obs_stride", C.c_int64), ("reward_stride", C.c_int64), ("done_stride", C.c_int64),
+                ("K", C.c_int32), ("auto_reset", C.c_int32)]
 
 
 class EnvView(C.Structure):
@@ -195,6 +202,11 @@ SIGNATURES = {
     "vf_env_dyn": (_vp, [_vp]),
     "vf_env_reset": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     "vf_env_step": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, _vp]),
+    "vf_env_step_n": (C.c_int, [_vp, C.POINTER(EnvRollout), _vp]),
+    "vf_env_graph_create": (C.c_int, [_vp, C.POINTER(EnvRollout), C.POINTER(_vp)]),
+    "vf_env_graph_launch": (C.c_int, [_vp, _vp]),
+    "vf_env_graph_destroy": (None, [_vp]),
+    "vf_env_export_pose": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "vf_env_query": (C.c_int, [_vp, C.POINTER(EnvView), _vp]),
     "vf_env_time_steps": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, C.c_int32, _vp, C.POINTER(C.c_float)]),
     "vf_env_step_bwd": (C.c_int, [_vp, C.POINTER(EnvBwdArgs), _vp]),

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "vf_xmath.hpp"
 #include "visfly_amd.h"
 
 #pragma clang fp contract(off)
@@ -108,8 +109,9 @@ __device__ __forceinline__ void cross_helper(const float* a, const float* b, flo
 // Geometric SO(3) controller of the velocity / position action types (dynamics.py:414-452 / :453-496),
 // evaluated once per control interval; the reference walks the agents in a Python loop (:446-450).
 // x.norm(dim=0) = FMA chain + IEEE sqrt, 3x3 products = k-ordered FMA chains.
-// sin/cos/atan2 come from the device math library; torch's SLEEF variants differ in the last bit, so
-// these two action types are held to a tolerance, not to the bit (tests/test_dyn_gpu.py).
+// atan2 is SLEEF's atan2f_u10 restated (what torch.atan2 runs); sin / cos are SLEEF's u10 routines restated (torch runs
+// closed-source MKL VML there; one ulp apart for ~2 % of the arguments), see vf_xmath.hpp: bit-identical to the CPU oracle,
+// and held to a stated tolerance against the reference for these two action types (tests/test_dyn_gpu.py).
 template <bool POSITION>
 __device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const Agent& s, const float* a, float* Td)
 {
@@ -130,18 +132,18 @@ __device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const 
         F[k] = c.m * (a_des - (k == 2 ? c.g_z : 0.0f));            // :417,458
     }
     const Quat& q = s.q;
-    const float yaw_cur = atan2f(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));   // maths.py:248
+    const float yaw_cur = vfs_atan2f_u10(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));   // maths.py:248
     float yaw_des, gain;
     if constexpr (POSITION) {
         yaw_des = cmd[0];                                          // :461
         gain = c.pos_d;                                            // :468
     } else {
         const float vn = sqrtf(__builtin_fmaf(s.v[1], s.v[1], s.v[0] * s.v[0]));   // :421
-        yaw_des = vn > 0.1f ? atan2f(s.v[1], s.v[0]) : yaw_cur;                     // :423-427
+        yaw_des = vn > 0.1f ? vfs_atan2f_u10(s.v[1], s.v[0]) : yaw_cur;                     // :423-427
         gain = c.vel_d;                                            // :433
     }
     float ye = yaw_des - yaw_cur;
-    ye = atan2f(sinf(ye), cosf(ye));                               // :432,467
+    ye = vfs_atan2f_u10(vfs_sinf_u10(ye), vfs_cosf_u10(ye));                               // :432,467
     const float yaw_spd = ye * gain * 2.0f;
     // gross thrust = (conj(q) * (0, F) * q).imag[2]               :435, maths.py:49,103
     const Quat fb = qmul(qmul(Quat{q.w, -q.x, -q.y, -q.z}, Quat{0.0f, F[0], F[1], F[2]}), q);
@@ -152,7 +154,7 @@ __device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const 
     // desired frame :437-442
     const float fn = sqrtf(__builtin_fmaf(F[2], F[2], __builtin_fmaf(F[1], F[1], F[0] * F[0])));
     const float b3[3] = {F[0] / fn, F[1] / fn, F[2] / fn};
-    const float c1[3] = {cosf(yaw_des), sinf(yaw_des), 0.0f};
+    const float c1[3] = {vfs_cosf_u10(yaw_des), vfs_sinf_u10(yaw_des), 0.0f};
     float b2[3], b1[3];
     cross_helper(b3, c1, b2);
     const float bn = sqrtf(__builtin_fmaf(b2[2], b2[2], __builtin_fmaf(b2[1], b2[1], b2[0] * b2[0])));

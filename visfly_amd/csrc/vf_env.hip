@@ -293,7 +293,28 @@ __global__ __launch_bounds__(kBlock) void k_env_query(const vf_dyn_cfg c, const 
     }
 }
 
+// Pose hand-off to an external renderer / scene manager (droneEnv.py:375-377: sceneManager.set_pose(position,
+// orientation wxyz, velocity)): AoS rows of the CURRENT slab state, straight from the granules.
+__global__ __launch_bounds__(kBlock) void k_env_export_pose(const vf_dyn_cfg c, const DynArgs d, float* pos, float* quat,
+                                                            float* vel, float* omg)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.N) return;
+    const float4 g0 = *granule(d.S, d.G, i, VF_G_POS), g1 = *granule(d.S, d.G, i, VF_G_QUAT);
+    const float4 g2 = *granule(d.S, d.G, i, VF_G_VEL), g3 = *granule(d.S, d.G, i, VF_G_OMG);
+    if (pos) { float* o = pos + 3 * (size_t)i; o[0] = g0.y; o[1] = g0.z; o[2] = g0.w; }
+    if (quat) *(reinterpret_cast<float4*>(quat) + i) = g1;
+    if (vel) { float* o = vel + 3 * (size_t)i; o[0] = g2.y + c.wind[0]; o[1] = g2.z + c.wind[1]; o[2] = g2.w + c.wind[2]; }   // dynamics.py:751-752
+    if (omg) { float* o = omg + 3 * (size_t)i; o[0] = g3.y; o[1] = g3.z; o[2] = g3.w; }
+}
+
 }  // namespace vf
+
+struct vf_env_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int K = 0;
+};
 
 namespace {
 
@@ -434,6 +455,95 @@ int vf_env_step(vf_env* h, const float* action, const vf_env_out* out, int32_t a
     if (!out->obs || !out->reward || !out->done) return vf::fail(VF_EINVAL, "vf_env_step: obs, reward and done outputs are required");
     if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_step: vf_env_bind has not been called");
     return launch_env_step(h, action, out, auto_reset, vf::as_stream(stream));
+}
+
+namespace {
+
+int check_rollout(const vf_env* h, const vf_env_rollout* r, const char* who)
+{
+    if (!h || !r) return vf::fail(VF_EINVAL, "%s: null argument", who);
+    if (!r->actions || !r->out.obs || !r->out.reward || !r->out.done)
+        return vf::fail(VF_EINVAL, "%s: actions, obs, reward and done are required", who);
+    if (r->K <= 0) return vf::fail(VF_EINVAL, "%s: K must be > 0", who);
+    if (r->action_stride < 0 || r->obs_stride < 0 || r->reward_stride < 0 || r->done_stride < 0)
+        return vf::fail(VF_EINVAL, "%s: negative stride", who);
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "%s: vf_env_bind has not been called", who);
+    return VF_OK;
+}
+
+// the K launches of a rollout, in stream order; step k sees the k-th action / output rows
+int enqueue_rollout(vf_env* h, const vf_env_rollout* r, hipStream_t st)
+{
+    vf_env_out o = r->out;
+    const float* a = r->actions;
+    for (int k = 0; k < r->K; ++k) {
+        if (int rc = launch_env_step(h, a, &o, r->auto_reset, st)) return rc;
+        a += r->action_stride;
+        o.obs += r->obs_stride;
+        o.reward += r->reward_stride;
+        o.done += r->done_stride;
+    }
+    return VF_OK;
+}
+
+}  // namespace
+
+int vf_env_step_n(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
+{
+    if (int rc = check_rollout(h, r, "vf_env_step_n")) return rc;
+    return enqueue_rollout(h, r, vf::as_stream(stream));
+}
+
+int vf_env_graph_create(vf_env* h, const vf_env_rollout* r, vf_env_graph** out)
+{
+    if (!out) return vf::fail(VF_EINVAL, "vf_env_graph_create: null argument");
+    if (int rc = check_rollout(h, r, "vf_env_graph_create")) return rc;
+    hipStream_t cs;
+    VF_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    vf_env_graph* g = new vf_env_graph;
+    g->K = r->K;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
+    int rc = VF_OK;
+    if (e == hipSuccess) {
+        rc = enqueue_rollout(h, r, cs);
+        e = hipStreamEndCapture(cs, &g->graph);
+    }
+    if (e == hipSuccess && rc == VF_OK) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    (void)hipStreamDestroy(cs);
+    if (e != hipSuccess || rc != VF_OK) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        if (rc != VF_OK) return rc;
+        return vf::fail(VF_EHIP, "vf_env_graph_create: %s", hipGetErrorString(e));
+    }
+    *out = g;
+    return VF_OK;
+}
+
+int vf_env_graph_launch(vf_env_graph* g, vf_stream_t stream)
+{
+    if (!g || !g->exec) return vf::fail(VF_EINVAL, "vf_env_graph_launch: null graph");
+    VF_HIP(hipGraphLaunch(g->exec, vf::as_stream(stream)));
+    return VF_OK;
+}
+
+void vf_env_graph_destroy(vf_env_graph* g)
+{
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
+int vf_env_export_pose(vf_env* h, float* pos, float* quat, float* vel, float* omg, vf_stream_t stream)
+{
+    if (!h) return vf::fail(VF_EINVAL, "vf_env_export_pose: null handle");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_export_pose: vf_env_bind has not been called");
+    if (quat && reinterpret_cast<uintptr_t>(quat) % 16) return vf::fail(VF_EINVAL, "vf_env_export_pose: quat must be 16-byte aligned");
+    hipLaunchKernelGGL(vf::k_env_export_pose, dim3(vf::blocks_for(h->dyn.N)), dim3(vf::kBlock), 0, vf::as_stream(stream),
+                       h->dyn.cfg, dyn_args(h, nullptr, nullptr), pos, quat, vel, omg);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
 }
 
 int vf_env_query(vf_env* h, const vf_env_view* view, vf_stream_t stream)

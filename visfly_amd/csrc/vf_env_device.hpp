@@ -79,7 +79,7 @@ __device__ __forceinline__ float nav_reward(const vf_env_cfg& e, const float* p,
     const float vn = norm3(v[0], v[1], v[2]);
     float cs = dot3(dir, v) / (1e-6f + vn) / 1.0f;
     cs = clampf(cs, -1.0f, 1.0f);
-    float ang = acosf(cs);
+    float ang = vfs_acosf_u10(cs);
     ang = ang < thrd ? thrd : ang;
     const float t2 = (ang - thrd) * -0.01f;
     const float t3 = norm4(q.w - 1.0f, q.x, q.y, q.z) * (float)-0.00001;

@@ -72,6 +72,11 @@ class _Info(list):
                 super().__setitem__(int(i), d)
             env._info = list(super().__iter__())
 
+    def _clear(self):
+        """back to the un-materialised state (ring slots re-use their info object)"""
+        super().clear()
+        self._ready = False
+
     def __getitem__(self, i):
         self._build()
         return super().__getitem__(i)
@@ -86,6 +91,60 @@ class _Info(list):
     def copy(self):
         self._build()
         return list(super().__iter__())
+
+
+class _OutSlot:
+    """one pre-allocated output set of step(): tensors, the observation dict, the lazy info list and the C struct
+    that points at them (out_buffers > 0)"""
+    __slots__ = ("state", "reward", "done", "obs", "info", "outs", "ref")
+
+    def __init__(self, env):
+        N, dev = env.num_agent, env.device
+        self.state = th.zeros((N, 13), dtype=th.float32, device=dev)
+        self.reward = th.zeros(N, dtype=th.float32, device=dev)
+        self.done = th.zeros(N, dtype=th.bool, device=dev)
+        self.outs = env._out(self.state, self.reward, self.done)
+        self.ref = C.byref(self.outs)
+        self.obs = None
+        self.info = _Info(env, self.done, env._ep_return, env._ep_length, env._ep_flags, env._terminal_obs, None)
+
+
+def _imu_noise_model(random_kwargs):
+    """random_kwargs["noise_kwargs"]["IMU"] (droneEnv.py:53,99-112) -> None | (mean(13,), half(13,)) of the uniform model"""
+    nk = (random_kwargs or {}).get("noise_kwargs") or {}
+    unknown = set(nk) - {"IMU"}
+    if unknown:
+        raise NotImplementedError(f"noise_kwargs for {sorted(unknown)}: only the IMU (state) noise exists with visual=False")
+    imu = nk.get("IMU")
+    if imu is None:
+        return None
+    model = imu.get("model", "UniformNoiseModel")
+    if model == "GaussianNoiseModel":
+        raise NotImplementedError("GaussianNoiseModel: the reference's Normal.generate (utils/type.py:56-57) calls "
+                                  "th.normal(mean, std, int) and raises for every input, so there is nothing to mirror")
+    if model != "UniformNoiseModel":
+        raise ValueError("IMU Noise model does not exist.")                                   # droneEnv.py:112
+    kw = imu.get("kwargs", {})
+    mean = th.atleast_1d(th.as_tensor(kw.get("mean", th.zeros(13)), dtype=th.float32))
+    half = th.atleast_1d(th.as_tensor(kw.get("half", th.zeros(13)), dtype=th.float32))
+    if mean.numel() != 13 or half.numel() != 13:
+        raise ValueError("IMU noise mean / half must have 13 entries (one per state component)")
+    return mean, half
+
+
+def _reject_unsupported(scene_kwargs, sensor_kwargs):
+    """With visual=False the reference never renders (droneEnv.py:296-333 reads the sensors only if self.visual) and forces the
+    empty box scene (:69-71), so visual sensors / scene objects change nothing there either -- say so once instead of
+    dropping them silently."""
+    import warnings
+    visual = [s.get("uuid") for s in (sensor_kwargs or []) if "IMU" not in str(s.get("uuid", ""))]
+    if visual:
+        warnings.warn(f"visfly_amd: sensor_kwargs {visual} are not rendered (visual=False path; the reference ignores them "
+                      "too when visual=False)", stacklevel=4)
+    ignored = [k for k in ("obj_settings", "render_settings", "update_approaching_info", "path") if (scene_kwargs or {}).get(k)]
+    if ignored:
+        warnings.warn(f"visfly_amd: scene_kwargs {ignored} have no effect with visual=False (collisions use the "
+                      "[-30,-30,0]..[30,30,8] box of droneEnv.py:129)", stacklevel=4)
 
 
 class DroneEnvsBase:
@@ -146,6 +205,7 @@ class DroneGymEnvsBase:
     KIND = HOVER
     OBS_MODE = 0        # VF_OBS_STATE
     REWARD_MODE = 0     # VF_REWARD_DEFAULT
+    _STATIC_OBS_CONST = True   # _static_obs() returns the same tensor objects every step (the ring path caches the dict)
 
     def __init__(
             self,
@@ -169,7 +229,11 @@ class DroneGymEnvsBase:
             success_radius: float = 0.5,
             gates=None,
             constants: Optional[dict] = None,
+            out_buffers: int = 0,
     ):
+        """out_buffers = R > 0: step() writes into a ring of R pre-allocated (obs, reward, done) sets instead of fresh tensors
+        -- no allocation and no Python object construction on the hot path; what step t returned stays valid until step
+        t + R.  0 (default) returns fresh tensors every step like the reference."""
         if visual:
             raise NotImplementedError("visual=True needs the external Habitat-sim renderer; the MI355X engine "
                                       "covers the visual=False path (SURVEY.md 8)")
@@ -198,6 +262,8 @@ class DroneGymEnvsBase:
             **{k: v for k, v in dkw.items() if k in ("action_type", "dt", "ctrl_dt", "ctrl_delay", "comm_delay",
                                                      "action_space", "integrator", "cfg", "wind_settings")})
         self._boxes = spawn_boxes(random_kwargs)
+        self._imu_noise = _imu_noise_model(random_kwargs)
+        _reject_unsupported(scene_kwargs, sensor_kwargs)     # warns
         self.target = th.as_tensor([1., 0., 1.5] if target is None else target, dtype=th.float32).reshape(3)
         self.success_radius = success_radius
         self.targets = None if gates is None else th.as_tensor(gates, dtype=th.float32)
@@ -273,6 +339,15 @@ class DroneGymEnvsBase:
         self._outs = self._out(self._terminal_obs, self._ep_return, self._ep_flags)  # obs/reward/done patched per step
         self._outs_ref = C.byref(self._outs)
         self._vf_env_step = _lib.lib().vf_env_step
+        self._ring, self._ring_i = [], 0
+        if out_buffers:
+            if out_buffers < 2:
+                raise ValueError("out_buffers must be 0 (fresh tensors) or >= 2")
+            with th.cuda.device(self.device):
+                for _ in range(int(out_buffers)):
+                    self._ring.append(_OutSlot(self))
+        self._rollouts = {}      # step_n: K -> cached output buffers / launch descriptor / graph
+        self._imu_cache = None
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -347,9 +422,30 @@ class DroneGymEnvsBase:
         return fs
 
     def _consume_imu_noise(self):
-        """the reference draws th.rand(N,13) for the (zero-amplitude) IMU noise at every
-        update_observation (droneEnv.py:114-116,333); keep the shared stream aligned in replay mode"""
-        th.rand((self.num_agent, 13), generator=self.envs.dynamics.rng)
+        """the reference draws th.rand(N,13) for the IMU noise at every update_observation (droneEnv.py:114-116,333;
+        utils/type.py:37-38) -- also when its amplitude is zero; replay mode keeps the shared stream aligned and keeps
+        the draw for sensor_obs["IMU"]"""
+        u = th.rand((self.num_agent, 13), generator=self.envs.dynamics.rng)
+        self._imu_cache = None
+        self._imu_draw = u if self._imu_noise is not None else None
+
+    def _imu_obs(self):
+        """sensor_obs["IMU"] = state + noise, quaternion re-normalised (droneEnv.py:114-125).  Nothing on the visual=False
+        observation path reads it (HoverEnv.py:62-70), so it is formed on demand, once per step: replay mode uses the
+        draw the reference would have made at this step, device mode draws from the device generator."""
+        st = self.envs.dynamics.state
+        if self._imu_noise is None:
+            return st
+        if self._imu_cache is None:
+            mean, half = (x.to(self.device) for x in self._imu_noise)
+            if self.spawn_mode == "replay" and getattr(self, "_imu_draw", None) is not None:
+                u = self._imu_draw.to(self.device)
+            else:
+                u = th.rand((self.num_agent, 13), device=self.device)
+            noisy = st + ((u - 0.5) * half + mean)                                          # utils/type.py:37-38
+            noisy = th.cat([noisy[:, :3], th.nn.functional.normalize(noisy[:, 3:7], p=2, dim=1), noisy[:, 7:]], dim=1)
+            self._imu_cache = noisy
+        return self._imu_cache
 
     def reset(self, state=None, **_unused):
         """DroneGymEnvsBase.reset (droneGymEnv.py:302-327) -> observations"""
@@ -441,9 +537,27 @@ class DroneGymEnvsBase:
         self._action = a
         if _cuda_get_device() != dev.index:
             th.cuda.set_device(dev)
+        replay = self.spawn_mode == "replay"
+        if self._ring and self._tape is None and not replay and self.tensor_output:
+            # zero-allocation path: pre-built output set, one ctypes call, no per-step Python objects
+            slot = self._ring[self._ring_i]
+            self._ring_i = self._ring_i + 1 if self._ring_i + 1 < len(self._ring) else 0
+            rc = self._vf_env_step(self._h, a.data_ptr(), slot.ref, 0 if is_test else 1, _raw_stream(dev.index))
+            if rc:
+                _lib.check(rc)
+            self._qcache = self._imu_cache = None
+            obs = slot.obs
+            if obs is None or not self._STATIC_OBS_CONST:
+                obs = slot.obs = self._full_obs(slot.state)
+            info = slot.info
+            if info._ready:
+                info._clear()
+            info._src = (self, slot.done, self._ep_return, self._ep_length, self._ep_flags, self._terminal_obs,
+                         self._extra_info())
+            self._reward, self._done, self._observations = slot.reward, slot.done, obs
+            return obs, slot.reward, slot.done, info
         state = th.empty((N, 13), dtype=th.float32, device=dev)
         reward = th.empty(N, dtype=th.float32, device=dev)
-        replay = self.spawn_mode == "replay"
         tape_t = -1
         if self._tape is not None and (record or self._record_all):   # checkpoint for the adjoint pass
             tape_t = self._tape_t
@@ -464,7 +578,7 @@ class DroneGymEnvsBase:
                                _raw_stream(dev.index))
         if rc:
             _lib.check(rc)
-        self._qcache = None
+        self._qcache = self._imu_cache = None
         if tape_t >= 0 and not borrow_done:
             self._tape_done[tape_t].copy_(done)
         self._reward, self._done = reward, done
@@ -482,6 +596,77 @@ class DroneGymEnvsBase:
         if self.tensor_output:
             return obs, reward, done, info
         return self._format_obs(obs), reward.cpu().numpy(), done.cpu().numpy().astype(np.int32), info   # :218
+
+    # ------------------------------------------------------------------ multi-step launch (open-loop action sequences)
+    def step_n(self, actions, is_test=False, graph=False):
+        """K consecutive step() calls with the launch loop in C (vf_env_step_n): `actions` is a (K,N,4) device tensor.
+        Returns (obs (K,N,13), reward (K,N), done (K,N)) -- row k is what the k-th step()
+        would have returned (obs after auto-reset, reward / done before); bit-identical to K step() calls.  The output
+        buffers are cached per K and re-used by the next step_n call of the same K.  graph=True replays the K launches from
+        a hipGraph captured on the first call for this (K, actions buffer): the caller refills that SAME actions tensor
+        between calls.  The reference has no counterpart (its loop is `for a in seq: env.step(a)`, e.g.
+        utils/evaluate.py:62-103); not available in replay-spawn mode or while a BPTT tape is recording."""
+        assert self._is_initial, "You should call reset() before step()"
+        if self.spawn_mode == "replay":
+            raise VisflyError("step_n: spawn='replay' needs a host round trip per step; use step()")
+        if self._tape is not None:
+            raise VisflyError("step_n: a BPTT tape is recording (requires_grad / enable_tape); use step()")
+        N, dev = self.num_agent, self.device
+        a = actions
+        if not (isinstance(a, th.Tensor) and a.is_cuda and a.dtype == th.float32 and a.is_contiguous()):
+            a = th.as_tensor(np.asarray(a) if not isinstance(a, th.Tensor) else a).to(dev, dtype=th.float32).contiguous()
+        if a.dim() != 3 or a.shape[1:] != (N, 4):
+            raise ValueError(f"step_n expects actions of shape (K,{N},4), got {tuple(a.shape)}")
+        K = a.shape[0]
+        if self.validate_actions:
+            assert a.max() <= 1 and a.min() >= -1
+        if _cuda_get_device() != dev.index:
+            th.cuda.set_device(dev)
+        ro = self._rollouts.get(K)
+        if ro is None:
+            obs = th.empty((K, N, 13), dtype=th.float32, device=dev)
+            reward = th.empty((K, N), dtype=th.float32, device=dev)
+            done = th.empty((K, N), dtype=th.bool, device=dev)
+            r = _lib.EnvRollout()
+            r.out = self._out(obs, reward, done)
+            r.action_stride, r.obs_stride, r.reward_stride, r.done_stride = 4 * N, 13 * N, N, N
+            r.K = K
+            ro = self._rollouts[K] = {"obs": obs, "reward": reward, "done": done, "r": r, "ref": C.byref(r), "graphs": {}}
+        r = ro["r"]
+        r.actions, r.auto_reset = a.data_ptr(), 0 if is_test else 1
+        L = _lib.lib()
+        if graph:
+            key = (a.data_ptr(), r.auto_reset)
+            g = ro["graphs"].get(key)
+            if g is None:
+                g = _lib._vp()
+                _lib.check(L.vf_env_graph_create(self._h, ro["ref"], C.byref(g)))
+                ro["graphs"][key] = g
+                ro.setdefault("keep", []).append(a)          # the graph holds this buffer's address
+            rc = L.vf_env_graph_launch(g, _raw_stream(dev.index))
+        else:
+            rc = L.vf_env_step_n(self._h, ro["ref"], _raw_stream(dev.index))
+        if rc:
+            _lib.check(rc)
+        self._qcache = self._imu_cache = None
+        self._action = a[K - 1]
+        self._reward, self._done = ro["reward"][K - 1], ro["done"][K - 1]
+        self._observations = self._full_obs(ro["obs"][K - 1])
+        return ro["obs"], ro["reward"], ro["done"]
+
+    def export_pose(self, out=None):
+        """what DroneEnvsBase.step hands to sceneManager.set_pose when visual=True (droneEnv.py:375-377): AoS device tensors
+        {"position" (N,3), "rotation" (N,4) wxyz, "velocity" (N,3) incl. wind, "angular_velocity" (N,3)} of the CURRENT state,
+        written by one launch (vf_env_export_pose).  `out`: a dict from a previous call to refill in place."""
+        N, dev = self.num_agent, self.device
+        if out is None:
+            out = {"position": th.empty((N, 3), device=dev), "rotation": th.empty((N, 4), device=dev),
+                   "velocity": th.empty((N, 3), device=dev), "angular_velocity": th.empty((N, 3), device=dev)}
+        with th.cuda.device(dev):
+            _lib.check(_lib.lib().vf_env_export_pose(self._h, _lib.ptr(out["position"]), _lib.ptr(out["rotation"]),
+                                                     _lib.ptr(out["velocity"]), _lib.ptr(out["angular_velocity"]),
+                                                     self._stream()))
+        return out
 
     def _extra_info(self):
         return None
@@ -574,6 +759,10 @@ class DroneGymEnvsBase:
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
+            for ro in getattr(self, "_rollouts", {}).values():
+                for g in ro["graphs"].values():
+                    _lib.lib().vf_env_graph_destroy(g)
+            self._rollouts = {}
             _lib.lib().vf_env_destroy(h)
 
     def __del__(self):
@@ -629,7 +818,7 @@ class DroneGymEnvsBase:
     full_state = property(lambda s: s.envs.dynamics.full_state)
     extend_state = property(lambda s: s.envs.dynamics.extend_state)
     visual = property(lambda s: False)
-    sensor_obs = property(lambda s: {"IMU": s.envs.dynamics.state})
+    sensor_obs = property(lambda s: {"IMU": s._imu_obs()})
     is_collision = property(lambda s: s.envs.is_collision)
     is_out_bounds = property(lambda s: s.envs.is_out_bounds)
     collision_point = property(lambda s: s.envs.collision_point)

@@ -84,6 +84,7 @@ class NavigationEnv2(NavigationEnv):
     (envs/NavigationEnv.py:102-224); default target [14,0,1], default spawn U(mean [9,0,1.5], half [8,6,1])."""
     OBS_MODE = 2        # VF_OBS_NAV2
     REWARD_MODE = 1     # VF_REWARD_NAV2
+    _STATIC_OBS_CONST = False   # collision_vector is queried per step
 
     def __init__(self, *a, random_kwargs=None, target=None, **kw):
         spawn = {"state_generator": {"class": "Uniform", "kwargs": [

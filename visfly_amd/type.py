@@ -25,13 +25,14 @@ class TensorDict(dict):
         raise TypeError("Invalid key type. Must be either str or int.")
 
     def __setitem__(self, key: Any, value: Any) -> None:
+        """field assignment by name, or row assignment into every field (value: mapping field -> rows)"""
         if isinstance(key, str):
-            super().__setitem__(key, value)
-        elif isinstance(key, (int, th.Tensor, np.ndarray, list)):
-            for k in self.keys():
-                self[k][key] = value[k]
-        else:
-            raise TypeError("Invalid key type. Must be either str or int.")
+            dict.__setitem__(self, key, value)
+            return
+        if not isinstance(key, (int, slice, list, np.ndarray, th.Tensor)):
+            raise TypeError(f"TensorDict index must be a field name or a row index, not {type(key).__name__}")
+        for name, column in self.items():
+            column[key] = value[name]
 
     def append(self, data):
         for k, v in data.items():
