@@ -27,7 +27,8 @@ extern "C" {
 #define VF_ABI_VERSION 4   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
-                              4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose */
+                              4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_ppo_loss_cfg.old_value /
+                                 clip_range_vf, vf_comm_* / vf_allreduce_grads (RCCL) */
 
 typedef void* vf_stream_t;
 
@@ -533,6 +534,11 @@ typedef struct vf_ppo_loss_cfg {
     float inv_batch;        /* 1 / global minibatch rows (means are over the global minibatch) */
     float* d_log_std_out;   /* optional: the 4 log_std gradients are also written here (tail of the flat gradient) */
     float* stats_accum;     /* optional: stats[0..15] are also added to this running fp32[16] accumulator */
+    /* value-function clipping (PPO.py:237-243): values_pred = old_value + clamp(value - old_value, +-clip_range_vf);
+     * old_value (M,) = the values stored at rollout time for THIS call's rows.  clip_range_vf <= 0 or old_value NULL: off */
+    const float* old_value;
+    float clip_range_vf;
+    int32_t pad0;
 } vf_ppo_loss_cfg;
 
 /* Clipped-surrogate PPO loss and its gradient w.r.t. the head outputs (PPO.py:210-263;
@@ -584,6 +590,24 @@ int vf_ppo_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const floa
 int vf_sumsq(const float* x, int64_t n, float* out1, float* scratch /* >= 1024 floats */, vf_stream_t stream);
 int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  const float* grad_sumsq, const vf_adam_cfg* cfg, vf_stream_t stream);
+
+/* =====================================================================================
+ * Multi-GPU: the ONE exchange step of the path.  Agents shard by rank with no data-path collective; a
+ * data-parallel PPO / BPTT optimiser step (utils/algorithms/PPO.py:285-292, BPTT.py:127-134) sums the flat fp32 gradient
+ * buffer over the ranks -- one ncclAllReduce (RCCL over xGMI) per step, enqueued on the caller's stream.
+ * Bootstrap: rank 0 calls vf_comm_unique_id, the 128 bytes travel through torch.distributed (or any side channel), every
+ * rank calls vf_comm_init (collective).  RCCL is resolved from `path` at run time -- pass the librccl.so the process
+ * already maps (PyTorch ships its own copy).
+ * ===================================================================================== */
+#define VF_COMM_ID_BYTES 128
+typedef struct vf_comm vf_comm;
+int vf_comm_library(const char* path);
+int vf_comm_unique_id(uint8_t* id /* VF_COMM_ID_BYTES, host */);
+int vf_comm_init(const uint8_t* id, int32_t world, int32_t rank, vf_comm** out);
+/* in-place sum over the ranks of buf[0..n): the flat gradient (+ loss statistics in its tail) / fp64 partial sums */
+int vf_allreduce_grads(vf_comm* c, float* buf, int64_t n, vf_stream_t stream);
+int vf_allreduce_f64(vf_comm* c, double* buf, int64_t n, vf_stream_t stream);
+void vf_comm_destroy(vf_comm* c);
 
 #ifdef __cplusplus
 }

@@ -589,6 +589,123 @@ def gen_td(name="td_lambda", H=24, N=40, seed=3):
                         episode_done=ep.astype(np.uint8), gamma=np.float64(0.99), lamda=np.float64(0.95), **out)
 
 
+def _sb3_stubs():
+    """the SB3 names utils/algorithms/common.py and utils/policies/extractors.py import, as minimal stand-ins: the code under
+    test (RolloutBuffer.compute_returns_and_advantage, StateTargetExtractor, create_mlp) is the reference's own"""
+    import torch.nn as nn
+    for n in ("stable_baselines3.common.buffers", "stable_baselines3.common.type_aliases", "stable_baselines3.common.preprocessing",
+              "stable_baselines3.common.utils", "stable_baselines3.common.vec_env.base_vec_env",
+              "stable_baselines3.common.torch_layers", "stable_baselines3.common.policies",
+              "stable_baselines3.common.distributions"):
+        if n not in sys.modules:
+            _auto(n)
+
+    class BaseFeaturesExtractor(nn.Module):          # SB3 torch_layers.BaseFeaturesExtractor: holds features_dim
+        def __init__(self, observation_space, features_dim=0):
+            super().__init__()
+            self._observation_space, self._features_dim = observation_space, features_dim
+
+        @property
+        def features_dim(self):
+            return self._features_dim
+
+    class BaseBuffer:                                # SB3 buffers.BaseBuffer: sizes + write cursor
+        def __init__(self, buffer_size, observation_space, action_space, device="auto", n_envs=1):
+            self.buffer_size, self.observation_space, self.action_space = buffer_size, observation_space, action_space
+            self.obs_shape, self.action_dim = tuple(observation_space.shape), int(np.prod(action_space.shape))
+            self.pos, self.full, self.device, self.n_envs = 0, False, th.device("cpu"), n_envs
+
+        def reset(self):
+            self.pos, self.full = 0, False
+
+    sys.modules["stable_baselines3.common.torch_layers"].BaseFeaturesExtractor = BaseFeaturesExtractor
+    sys.modules["stable_baselines3.common.buffers"].BaseBuffer = BaseBuffer
+
+
+def gen_ppo(name, T=16, N=64, seed=11, clip_range_vf=None):
+    """PPO-side golden: one rollout T x N + MLP weights -> advantages / returns from the reference's own
+    RolloutBuffer.compute_returns_and_advantage (utils/algorithms/common.py:97-132, called the way SB3's collect_rollouts
+    calls it: `dones` as a float numpy array), then ONE PPO.train minibatch over all T*N rows: the arithmetic of
+    utils/algorithms/PPO.py:210-263 evaluated by torch autograd on a network assembled from the reference's own
+    StateTargetExtractor (utils/policies/extractors.py:662-678) and create_mlp (:376-449, what MlpExtractor2 builds,
+    policies.py:34-49) plus the action_net / value_net / log_std heads of policies.py:195-254.  Stable-baselines3 itself is
+    not installable here; the two SB3 pieces on this path are transcribed in this function and marked [SB3]."""
+    import torch.nn as nn
+    import_envs()
+    _sb3_stubs()
+    from VisFly.utils.algorithms.common import RolloutBuffer
+    import VisFly.utils.policies.extractors as E
+    sp = sys.modules["gymnasium.spaces"]
+    rng = np.random.default_rng(seed)
+    th.manual_seed(seed)
+    gamma, lam, clip_range, ent_coef, vf_coef = 0.99, 0.95, 0.2, 0.01, 0.5
+    f = lambda a: th.from_numpy(np.ascontiguousarray(a, np.float32))
+    # ---- rollout ----
+    obs_state = rng.normal(size=(T, N, 13)).astype(np.float32)
+    obs_target = rng.normal(size=(T, N, 3)).astype(np.float32)
+    rewards = rng.normal(scale=0.3, size=(T, N)).astype(np.float32)
+    values = rng.normal(size=(T, N)).astype(np.float32)
+    episode_starts = (rng.uniform(size=(T, N)) < 0.12).astype(np.float32)
+    last_values = rng.normal(size=N).astype(np.float32)
+    dones = (rng.uniform(size=N) < 0.25).astype(np.float32)
+    buf = RolloutBuffer(T, sp.Box(-1, 1, (13,)), sp.Box(-1, 1, (4,)), gae_lambda=lam, gamma=gamma, n_envs=N)
+    buf.rewards[:], buf.values[:], buf.episode_starts[:] = f(rewards), f(values), f(episode_starts)
+    buf.compute_returns_and_advantage(f(last_values), dones)
+    adv, ret = f32(buf.advantages), f32(buf.returns)
+    # ---- network (reference modules) ----
+    space = sp.Dict({"state": sp.Box(-1, 1, (13,)), "target": sp.Box(-1, 1, (3,))})
+    ext = E.StateTargetExtractor(space, net_arch={"state": {"layer": [128, 64]}, "target": {"layer": [128, 64]}}, activation_fn=nn.ReLU)
+    pi_net, _ = E.create_mlp(input_dim=128, layer=[64, 64], activation_fn=nn.ReLU)
+    vf_net, _ = E.create_mlp(input_dim=128, layer=[64, 64], activation_fn=nn.ReLU)
+    action_net, value_net = nn.Linear(64, 4), nn.Linear(64, 1)
+    log_std = nn.Parameter(th.full((4,), -0.5))
+    with th.no_grad():
+        action_net.weight.mul_(0.3)
+    linears = [m for net in (ext.state_extractor, ext.target_extractor, pi_net) for m in net if isinstance(m, nn.Linear)]
+    linears += [action_net] + [m for m in vf_net if isinstance(m, nn.Linear)] + [value_net]     # visfly_amd MlpPolicy schedule order
+    params = [q for m in linears for q in (m.weight, m.bias)] + [log_std]
+    flat = np.concatenate([f32(q).reshape(-1) for q in params])
+    # ---- the minibatch: all rows, buffer order (swap_and_flatten order is irrelevant for ONE full batch) ----
+    M = T * N
+    o = {"state": f(obs_state.reshape(M, 13)), "target": f(obs_target.reshape(M, 3))}
+    actions = np.tanh(rng.normal(scale=0.8, size=(M, 4))).astype(np.float32)
+    A, R, old_v = f(adv.reshape(M)), f(ret.reshape(M)), f(values.reshape(M))
+    features = ext.extract(o)                                                        # policies.py:235-236
+    mean, v = action_net(pi_net(features)), value_net(vf_net(features)).flatten()    # :240-246
+    # [SB3] SquashedDiagGaussianDistribution.log_prob(actions): TanhBijector.inverse + Gaussian log-density - tanh correction
+    a = f(actions)
+    eps = th.finfo(th.float32).eps
+    gauss = 0.5 * (th.log1p(a.clamp(-1 + eps, 1 - eps)) - th.log1p(-a.clamp(-1 + eps, 1 - eps)))
+    sd = log_std.exp()
+    log_prob = (-((gauss - mean) ** 2) / (2 * sd ** 2) - log_std - np.log(np.sqrt(2 * np.pi))).sum(1)
+    log_prob = log_prob - th.log(1 - a ** 2 + 1e-6).sum(1)
+    old_log_prob = (log_prob.detach() + f(rng.normal(scale=0.15, size=M))).contiguous()
+    # ---- PPO.py:210-263 ----
+    advantages = (A - A.mean()) / (A.std() + 1e-8)                                   # :215-220
+    ratio = th.exp(log_prob - old_log_prob)                                          # :223
+    policy_loss = -th.min(advantages * ratio, advantages * th.clamp(ratio, 1 - clip_range, 1 + clip_range)).mean()   # :226-230
+    clip_fraction = th.mean((th.abs(ratio - 1) > clip_range).float())
+    values_pred = v if clip_range_vf is None else old_v + th.clamp(v - old_v, -clip_range_vf, clip_range_vf)   # :237-243
+    value_loss = th.nn.functional.mse_loss(R, values_pred)                           # :245
+    entropy_loss = -th.mean(-log_prob)                                               # :249-251 (squashed Gaussian: no analytic entropy)
+    loss = policy_loss + ent_coef * entropy_loss + vf_coef * value_loss              # :257-261
+    log_ratio = log_prob - old_log_prob
+    approx_kl = th.mean((th.exp(log_ratio) - 1) - log_ratio)                         # :267-270
+    loss.backward()
+    grad = np.concatenate([f32(q.grad).reshape(-1) for q in params])
+    print(f"{name}: T={T} N={N} params={flat.size} loss={float(loss):.6f} pg={float(policy_loss):.6f} v={float(value_loss):.6f} "
+          f"kl={float(approx_kl):.5f} clipfrac={float(clip_fraction):.3f} |grad|={np.linalg.norm(grad):.4f}")
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), obs_state=obs_state, obs_target=obs_target, rewards=rewards, values=values,
+        episode_starts=episode_starts, last_values=last_values, dones=dones, advantages=adv, returns=ret,
+        params=flat, actions=actions, old_log_prob=f32(old_log_prob), adv_normalized=f32(advantages),
+        policy_loss=f32(policy_loss), value_loss=f32(value_loss), entropy_loss=f32(entropy_loss), approx_kl=f32(approx_kl),
+        clip_fraction=f32(clip_fraction), loss=f32(loss), grad=grad, mean=f32(mean), value=f32(v), log_prob=f32(log_prob),
+        gamma=np.float64(gamma), gae_lambda=np.float64(lam), clip_range=np.float32(clip_range), ent_coef=np.float32(ent_coef),
+        vf_coef=np.float32(vf_coef), clip_range_vf=np.float32(-1.0 if clip_range_vf is None else clip_range_vf),
+        label=np.asarray("reference RolloutBuffer + StateTargetExtractor + create_mlp; SB3 distribution transcribed"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -605,6 +722,10 @@ def main():
             gen_bptt(name)
     if args.only in (None, "td_lambda"):
         gen_td()
+    if args.only in (None, "ppo_nav"):
+        gen_ppo("ppo_nav")
+    if args.only in (None, "ppo_nav_vclip"):
+        gen_ppo("ppo_nav_vclip", seed=12, clip_range_vf=0.3)
 
 
 if __name__ == "__main__":

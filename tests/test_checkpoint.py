@@ -96,7 +96,14 @@ def test_reference_yaml_blocks(tmp_path):
     assert cfg["eval_env"]["num_agent_per_scene"] == 1 and cfg["eval_env"]["max_episode_steps"] == 256   # deep merge
     assert cfg["env"]["num_agent_per_scene"] == 48
     pk = checkpoint.policy_kwargs_from_reference(cfg["algorithm"]["policy_kwargs"], ["state", "target"])
-    assert pk == dict(extractor={"state": [128, 64], "target": [96, 32]}, pi=[64, 48], vf=[64, 64], weight_decay=1e-5)
+    assert pk == dict(extractor={"state": [128, 64], "target": [96, 32]}, pi=[64, 48], vf=[64, 64], weight_decay=1e-5,
+                      ortho_init=False)            # the YAML sets ortho_init: false; the default (key absent) is the reference's True
+    no_ortho_key = {k: v for k, v in cfg["algorithm"]["policy_kwargs"].items() if k != "ortho_init"}
+    assert checkpoint.policy_kwargs_from_reference(no_ortho_key, ["state", "target"])["ortho_init"] is True
+    for missing_or_bad in ({k: v for k, v in cfg["algorithm"]["policy_kwargs"].items() if k != "activation_fn"},   # reference default: Tanh
+                           dict(cfg["algorithm"]["policy_kwargs"], squash_output=False)):
+        with pytest.raises(NotImplementedError):
+            checkpoint.policy_kwargs_from_reference(missing_or_bad, ["state", "target"])
     native = dict(extractor={"state": [32]}, pi=[16], vf=[16])
     assert checkpoint.policy_kwargs_from_reference(native, ["state"]) == native
     bad = dict(cfg["algorithm"]["policy_kwargs"], features_extractor_class="StateTargetImageExtractor")
@@ -106,6 +113,21 @@ def test_reference_yaml_blocks(tmp_path):
         checkpoint.policy_kwargs_from_reference(dict(cfg["algorithm"]["policy_kwargs"], activation_fn="tanh"), ["state", "target"])
     with pytest.raises(ValueError):
         checkpoint.policy_kwargs_from_reference(cfg["algorithm"]["policy_kwargs"], ["state"])
+
+
+def test_orthogonal_init_matches_sb3_gains():
+    """reference default ortho_init=True (policies.py:109): SB3 ActorCriticPolicy._build -- orthogonal weights with gain
+    sqrt(2) (extractor, trunks), 0.01 (action_net), 1 (value_net), zero biases"""
+    pol = MlpPolicy({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64], "cpu", seed=1)
+    for ly in pol.layers:
+        w = pol.weight(ly)
+        gain = {"mean": 0.01, "value": 1.0}.get(ly.dst, 2 ** 0.5)
+        rows, cols = w.shape
+        gram = (w @ w.T) if rows <= cols else (w.T @ w)
+        assert torch.allclose(gram, gain ** 2 * torch.eye(min(rows, cols)), atol=1e-4), ly.dst
+        assert float(pol.bias(ly).abs().max()) == 0.0
+    kaiming = MlpPolicy({"state": 13}, {"state": [32]}, [16], [16], "cpu", seed=1, ortho_init=False)
+    assert float(kaiming.bias(kaiming.layers[0]).abs().max()) > 0.0
 
 
 def test_state_dict_uses_the_reference_parameter_names():

@@ -1,0 +1,120 @@
+"""BASELINE.json configs at the sizes ONE GPU of the 8-GPU job runs them:
+  configs[2]  NavigationEnv, 65 536 agents, RK4 + ctrl_delay + drag randomisation  -> bit-identical to the CPU oracle
+  configs[3]  NavigationEnv, 32 768 agents (262 144 / 8), PPO n_steps 256, batch 25 600, 5 epochs: one full iteration
+  configs[4]  RacingEnv, 16 384 agents (131 072 / 8), thrust actions, BPTT over H = 64: one update, reverse sweep == autograd
+plus size-independent properties at the headline size (65 536 agents): step_n == step, linearity of the episode counters."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+DYN = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+NAV_SPAWN = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+
+
+def test_config2_rk4_drag_65536_bit_identical_to_oracle():
+    import oracle
+    from visfly_amd.envs import NavigationEnv
+    N = 65536
+    dkw = dict(DYN, integrator="rk4", drag_random=0.1)
+    env = NavigationEnv(num_agent_per_scene=N, seed=21, dynamics_kwargs=dkw, random_kwargs=NAV_SPAWN, device="cuda:0",
+                        max_episode_steps=256, tensor_output=True)
+    env.reset()
+    dyn = env.envs.dynamics
+    kl, kq = dyn.drag_coefficients
+    ref = oracle.OracleEnv(dyn.constants, N, "nav", 256, target=[9., 0., 1.])
+    ref.dyn.klin = np.ascontiguousarray(kl.cpu().numpy().T)
+    ref.dyn.kquad = np.ascontiguousarray(kq.cpu().numpy().T)
+    ref.reset_full_state(env.full_state.cpu().numpy())
+    g = torch.Generator().manual_seed(4)
+    for k in range(6):
+        a = ((torch.rand((N, 4), generator=g) * 2 - 1) * 0.6 + torch.tensor([-0.3, 0, 0, 0])).clamp(-1, 1)
+        o, r, d, _ = env.step(a.cuda(), is_test=True)
+        ro, rr, rd = ref.step(a.numpy())
+        assert_bits_equal(o["state"].cpu().numpy(), ro, f"state @ {k}")
+        assert_bits_equal(r.cpu().numpy(), rr, f"reward @ {k}")
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), rd), f"done @ {k}"
+    assert_bits_equal(env.extend_state.cpu().numpy(), ref.dyn.extend_state, "extend_state after 6 steps")
+
+
+def _ppo_iteration(seed):
+    from visfly_amd.envs import NavigationEnv
+    from visfly_amd.ppo import PPO
+    N = 32768
+    env = NavigationEnv(num_agent_per_scene=N, seed=42, dynamics_kwargs=dict(DYN), random_kwargs=NAV_SPAWN, device="cuda:0",
+                        max_episode_steps=256)
+    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=seed)
+    ppo.learn(256 * N)
+    torch.cuda.synchronize()
+    out = (ppo.policy.flat.clone(), dict(ppo.logs), ppo._opt_step, ppo.num_timesteps)
+    env.close()
+    return out
+
+
+def test_config3_ppo_iteration_at_shard_scale():
+    flat, logs, steps, ts = _ppo_iteration(0)
+    rows = 256 * 32768
+    assert ts == rows
+    assert steps == 5 * -(-rows // 25600), "SB3's RolloutBuffer.get trains on the trailing partial minibatch too"
+    assert torch.isfinite(flat).all()
+    for k in ("train/policy_gradient_loss", "train/value_loss", "train/entropy_loss", "train/approx_kl", "train/clip_fraction"):
+        assert np.isfinite(logs[k]), k
+    assert 0 <= logs["train/approx_kl"] < 0.05 and 0 <= logs["train/clip_fraction"] < 0.5
+    assert logs["rollout/episodes"] > 0.5 * rows / 256          # episodes end (collisions / timeouts) and are counted
+    flat2, logs2, _, _ = _ppo_iteration(0)
+    assert torch.equal(flat, flat2), "one PPO iteration must be bitwise reproducible"
+    assert logs == logs2
+    flat3, _, _, _ = _ppo_iteration(1)
+    assert not torch.equal(flat, flat3)
+
+
+def test_config4_bptt_update_at_shard_scale_reverse_sweep_equals_autograd():
+    from visfly_amd.bptt import BPTT
+    from visfly_amd.envs import RacingEnv
+    N, H = 16384, 64
+    grads, losses = [], []
+    for use_autograd in (False, True):
+        env = RacingEnv(num_agent_per_scene=N, seed=42, dynamics_kwargs=dict(DYN, action_type="thrust"), device="cuda:0",
+                        max_episode_steps=40, requires_grad=True, tensor_output=True)     # episodes end inside the horizon
+        algo = BPTT(env, horizon=H, gamma=0.99, learning_rate=1e-3, seed=0)
+        loss = algo._grad_autograd() if use_autograd else algo._grad_reverse_sweep()
+        torch.cuda.synchronize()
+        grads.append(algo.policy.grad.clone())
+        losses.append(float(loss))
+        if not use_autograd:                      # the full update (clip + Adam + detach) also runs at this size
+            p0 = algo.policy.flat.clone()
+            algo._apply(loss)
+            assert torch.isfinite(algo.policy.flat).all() and not torch.equal(p0, algo.policy.flat)
+            assert algo.num_timesteps == H * N
+        env.close()
+        del algo, env
+        torch.cuda.empty_cache()
+    g0, g1 = grads
+    assert np.isfinite(losses[0]) and abs(losses[0] - losses[1]) <= 2e-6 * max(1.0, abs(losses[0]))
+    scale = g1.abs().max().item()
+    assert scale > 0 and (g0 - g1).abs().max().item() <= 5e-5 * scale, ((g0 - g1).abs().max().item(), scale)
+
+
+def test_headline_size_properties_65536():
+    """size-independent properties at BASELINE configs[1]: K fused-loop steps == K step() calls bit for bit, every agent's
+    episode counter advances by exactly one per step until its episode ends, done agents restart at zero"""
+    from visfly_amd.envs import HoverEnv
+    N, K = 65536, 12
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = ((torch.rand((K, N, 4), device="cuda", generator=g) * 2 - 1) * 0.5).contiguous()
+    a, b = (HoverEnv(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(DYN), device="cuda:0", tensor_output=True,
+                     max_episode_steps=8) for _ in range(2))
+    a.reset(), b.reset()
+    obs, reward, done = b.step_n(A)
+    count = torch.zeros(N, dtype=torch.int32, device="cuda")
+    for k in range(K):
+        o, r, d, _ = a.step(A[k])
+        assert torch.equal(o["state"], obs[k]) and torch.equal(r, reward[k]) and torch.equal(d, done[k]), k
+        count = torch.where(d, torch.zeros_like(count), count + 1)
+        assert torch.equal(a._step_count, count), f"step counters @ {k}"
+        assert bool((d | (count < 8)).all())
+    assert torch.equal(a._slab, b._slab)
+    assert int(done.sum()) >= N                       # every agent hit the 8-step time limit at least once

@@ -11,33 +11,37 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q, algo):
+def _worker(rank, world, port, q, algo, backend="gloo"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    local = rank if backend == "nccl" else 0
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from visfly_amd import parallel
     from _golden import ENV_DYN
-    r, w, _ = parallel.init("gloo")
-    dev = "cuda:0"
+    r, w, _ = parallel.init(backend)
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
     if algo == "ppo":
         from visfly_amd.envs import HoverEnv
         from visfly_amd.ppo import PPO
         env = HoverEnv(num_agent_per_scene=1024, seed=10 + rank, dynamics_kwargs=dict(ENV_DYN), device=dev, max_episode_steps=64,
                        tensor_output=True)
-        tr = PPO(env, n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3)
+        tr = PPO(env, n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3 + 17 * rank)   # rank-dependent seed: the ctor broadcasts rank 0's weights
         tr.learn(16 * 1024 * world * 2)
     else:
         from visfly_amd.bptt import BPTT
         from visfly_amd.envs import HoverEnv
         env = HoverEnv(num_agent_per_scene=512, seed=10 + rank, dynamics_kwargs=dict(ENV_DYN), device=dev, max_episode_steps=64,
                        tensor_output=True)
-        tr = BPTT(env, horizon=8, learning_rate=1e-3, seed=3)
+        tr = BPTT(env, horizon=8, learning_rate=1e-3, seed=3 + 17 * rank)
         tr.learn(8 * 512 * world * 3)
-    flat = tr.policy.flat.detach().cpu()
+    flat = tr.policy.flat.detach() if backend == "nccl" else tr.policy.flat.detach().cpu()
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     ok = bool(torch.isfinite(flat).all()) and all(torch.equal(both[0], b) for b in both)
+    if backend == "nccl":
+        ok = ok and parallel.native_comm() is not None          # the gradient went through vf_allreduce_grads
     q.put((rank, ok, tr.num_timesteps))
     dist.destroy_process_group()
 
@@ -57,6 +61,50 @@ def test_two_ranks_stay_in_lockstep(algo):
     assert [r[0] for r in res] == [0, 1]
     assert all(r[1] for r in res), "parameters diverged between the ranks"
     assert res[0][2] == res[1][2] and res[0][2] > 0          # num_timesteps counts the global batch on every rank
+
+
+@pytest.mark.parametrize("algo", ["ppo", "bptt"])
+def test_two_ranks_rccl(algo):
+    """the same lock-step check over RCCL (backend "nccl", gradient through vf_allreduce_grads) -- needs two GPUs; the
+    single-GPU test box skips it, an 8-GPU node runs it"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29750 + os.getpid() % 100 + (0 if algo == "ppo" else 1)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get() for _ in range(2))
+    assert all(r[1] for r in res), "parameters diverged between the ranks (or the native communicator was not used)"
+
+
+def test_native_rccl_communicator_single_rank():
+    """vf_comm_* / vf_allreduce_grads on a world-of-one communicator: RCCL resolved from the library torch already maps,
+    the unique id / init / all-reduce / destroy sequence runs on this process's stream; a sum over one rank is the identity"""
+    import ctypes as C
+    from visfly_amd import _lib, parallel
+    L = _lib.lib()
+    assert L.vf_allreduce_grads(None, None, 1, None) == -1
+    c = parallel.native_comm(force=True)
+    assert c is not None, "RCCL communicator could not be created"
+    g = torch.randn(43977 + 16, device="cuda:0")
+    g0 = g.clone()
+    _lib.check(L.vf_allreduce_grads(c, g.data_ptr(), g.numel(), _lib.current_stream(g.device)))
+    d = torch.randn(14, dtype=torch.float64, device="cuda:0")
+    d0 = d.clone()
+    _lib.check(L.vf_allreduce_f64(c, d.data_ptr(), d.numel(), _lib.current_stream(d.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(g, g0) and torch.equal(d, d0)
+    assert L.vf_allreduce_grads(c, None, 4, None) == -1 and L.vf_allreduce_grads(c, g.data_ptr(), 0, None) == -1
+    ident = (C.c_uint8 * 128)()
+    _lib.check(L.vf_comm_unique_id(ident))
+    assert any(ident)
+    h = _lib._vp()
+    assert L.vf_comm_init(ident, 2, 5, C.byref(h)) == -1          # rank outside the world
 
 
 def test_bench_two_ranks_control_flow():

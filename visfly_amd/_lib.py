@@ -164,7 +164,8 @@ class MlpBwdDesc(C.Structure):
 class PpoLossCfg(C.Structure):
     """mirror of vf_ppo_loss_cfg"""
     _fields_ = [("clip_range", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("inv_batch", C.c_float),
-                ("d_log_std_out", C.c_void_p), ("stats_accum", C.c_void_p)]
+                ("d_log_std_out", C.c_void_p), ("stats_accum", C.c_void_p),
+                ("old_value", C.c_void_p), ("clip_range_vf", C.c_float), ("pad0", C.c_int32)]
 
 
 class AdamCfg(C.Structure):
@@ -245,6 +246,12 @@ SIGNATURES = {
     "vf_rollout_post": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _vp, _vp, C.c_int32, _vp]),
     "vf_ppo_update": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpBwdDesc)] + [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    "vf_comm_library": (C.c_int, [C.c_char_p]),
+    "vf_comm_unique_id": (C.c_int, [_vp]),
+    "vf_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "vf_allreduce_grads": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "vf_allreduce_f64": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "vf_comm_destroy": (None, [_vp]),
     "vf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.POINTER(AdamCfg), _vp]),
 }
 

@@ -77,17 +77,22 @@ class BPTT:
         self.weight_decay = pk.get("weight_decay", self.weight_decay)
         self.policy = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},
                                 pk.get("extractor", {k: [128, 64] for k in self.obs_keys}), pk.get("pi", [64, 64]),
-                                pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed)
+                                pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed,
+                                ortho_init=pk.get("ortho_init", True))
         self.policy.lazy_pack = True        # this trainer calls mark_updated() after every optimiser step
+        self.world, self.rank = parallel.world_size(), parallel.rank()
+        # same initial parameters on every rank (only gradients are exchanged afterwards), different exploration noise
+        parallel.broadcast_(self.policy.flat)
+        self.policy.mark_updated()
         self.use_autograd = False           # True: torch.autograd schedules the same kernels (cross-check path)
         self._defer_wgrad = None            # decided at the first update (MlpPolicy.backward_data_supported)
         n = self.policy.n_params
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=self.device), th.zeros(n, device=self.device)
         self._sumsq, self._scratch = th.zeros(1, device=self.device), th.zeros(4096, device=self.device)
-        self._gen = th.Generator(device=self.device).manual_seed(seed)
+        self.seed = seed
+        self._gen = th.Generator(device=self.device).manual_seed(int(seed) + 1000003 * self.rank)
         self._opt_step = 0
         self.num_timesteps = 0
-        self.world = parallel.world_size()
         self.logs: Dict[str, float] = {}
 
     def _update(self):
@@ -205,7 +210,7 @@ class BPTT:
 
     @classmethod
     def load(cls, path: str, env, **kwargs):
-        return checkpoint.load_into(cls(env, **kwargs), path)
+        return checkpoint.load_into(cls(env, **checkpoint.ctor_kwargs_from_archive(path, kwargs)), path)
 
     def learn(self, total_timesteps: int, log_interval: Optional[int] = None):
         t0, start, it = time.time(), self.num_timesteps, 0

@@ -72,10 +72,20 @@ def policy_kwargs_from_reference(pk: Optional[dict], obs_keys: List[str]) -> dic
             raise NotImplementedError("batch / layer norm in the extractor MLPs is not implemented")
         ext[k] = list(a.get("layer", []))
     out["extractor"] = ext
-    act = pk.get("activation_fn", "relu")
+    # the reference policy's default activation is Tanh (policies.py:108); its YAMLs set relu explicitly.  A missing key would
+    # silently build a different network than the reference does, so it is required here.
+    if "activation_fn" not in pk:
+        raise NotImplementedError("policy_kwargs without activation_fn: the reference would build Tanh networks "
+                                  "(policies.py:108); the fused MLP kernels implement ReLU -- set activation_fn: relu")
+    act = pk["activation_fn"]
     act = act if isinstance(act, str) else act.__name__
     if act.lower() != "relu":
         raise NotImplementedError(f"activation_fn {act}: the fused MLP kernels implement ReLU")
+    if pk.get("squash_output", True) is False:
+        raise NotImplementedError("squash_output=False: the action head is the tanh-squashed Gaussian (policies.py:114,177-181)")
+    if pk.get("use_sde"):
+        raise NotImplementedError("use_sde: state-dependent exploration is not implemented")
+    out["ortho_init"] = bool(pk.get("ortho_init", True))           # policies.py:109, SB3 ActorCriticPolicy._build
     na = pk.get("net_arch") or {}
     if isinstance(na, list):        # SB3 shorthand: shared sizes for both trunks
         na = dict(pi=na, vf=na)
@@ -162,7 +172,8 @@ def _param_order(policy):
 
 def _hyper(trainer) -> dict:
     keys = ("n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range", "ent_coef", "vf_coef", "max_grad_norm",
-            "lr", "weight_decay", "adam_eps", "betas", "normalize_advantage", "target_kl", "seed", "H", "num_timesteps", "_opt_step")
+            "lr", "weight_decay", "adam_eps", "betas", "normalize_advantage", "target_kl", "seed", "H", "num_timesteps", "_opt_step",
+            "clip_range_vf")
     out = {k: getattr(trainer, k) for k in keys if hasattr(trainer, k)}
     out["learning_rate"] = out.pop("lr", None)
     out["algorithm"], out["policy_spec"] = type(trainer).__name__, trainer.policy.spec
@@ -215,6 +226,29 @@ def read_archive(path: str):
     return sd, opt, data
 
 
+_CTOR_KEYS = ("n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range", "clip_range_vf", "ent_coef", "vf_coef",
+              "max_grad_norm", "learning_rate", "weight_decay", "adam_eps", "betas", "normalize_advantage", "target_kl", "seed",
+              "horizon")
+
+
+def ctor_kwargs_from_archive(path: str, overrides: Optional[dict] = None) -> dict:
+    """constructor kwargs for ``cls.load`` (SB3 BaseAlgorithm.load restores them from the archive's `data`, PPO.py:432-572):
+    the saved hyper-parameters and network shape, overridden by the caller's kwargs.  Archives written by the reference carry
+    a pickled `data` this package does not unpickle -- then only the caller's kwargs apply."""
+    _sd, _opt, data = read_archive(path)
+    kw = {}
+    if isinstance(data, dict):
+        for k in _CTOR_KEYS:
+            v = data.get("H") if k == "horizon" else data.get(k)
+            if v is not None and not isinstance(v, dict):
+                kw[k] = tuple(v) if k == "betas" else v
+        spec = data.get("policy_spec")
+        if isinstance(spec, dict) and "extractor" in spec:
+            kw["policy_kwargs"] = dict(extractor=spec["extractor"], pi=spec["pi"], vf=spec["vf"])
+    kw.update(overrides or {})
+    return kw
+
+
 def load_into(trainer, path: str, load_optimizer: bool = True):
     """in-place load (SB3 ``set_parameters``): policy parameters and, if the archive has them and the layout matches,
     the Adam moments and step count"""
@@ -230,6 +264,10 @@ def load_into(trainer, path: str, load_optimizer: bool = True):
                 trainer.exp_avg[off:off + n] = st[i]["exp_avg"].reshape(-1).to(pol.device, th.float32)
                 trainer.exp_avg_sq[off:off + n] = st[i]["exp_avg_sq"].reshape(-1).to(pol.device, th.float32)
             trainer._opt_step = int(float(st[0]["step"]))
+        else:
+            import warnings
+            warnings.warn(f"{path}: the optimiser state does not match this policy's parameter layout "
+                          f"({len(st)} vs {len(order)} tensors) -- Adam moments NOT restored", stacklevel=2)
     if isinstance(data, dict) and "num_timesteps" in data and not isinstance(data["num_timesteps"], dict):
         trainer.num_timesteps = int(data["num_timesteps"])
     return trainer

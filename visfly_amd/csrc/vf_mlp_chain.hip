@@ -664,7 +664,7 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
         const f32x16& mt = fs.t[N::t_mean];
         const float mu[4] = {mt[0], mt[1], mt[2], mt[3]}, a[4] = {a4.x, a4.y, a4.z, a4.w};
         float st1[9], dm1[4], dv1;
-        ppo_row(mu, fs.t[N::t_val][0], ls, a, old_lp, adv, ret, pr.cfg, dm1, dv1, st1);
+        ppo_row(mu, fs.t[N::t_val][0], ls, a, old_lp, adv, ret, pr.cfg, dm1, dv1, st1, rc);
         const bool on = live && h == 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) stt[k] = on ? st1[k] : 0.0f;

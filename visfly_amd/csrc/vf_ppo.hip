@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(kBlock) void k_ppo_loss(const float4* __restrict__ 
         const float mu[4] = {m4.x, m4.y, m4.z, m4.w}, a[4] = {a4.x, a4.y, a4.z, a4.w};
         const float ls[4] = {log_std[0], log_std[1], log_std[2], log_std[3]};
         float dm[4], dvl;
-        ppo_row(mu, value[i], ls, a, old_lp[i], adv[i], ret[i], cfg, dm, dvl, st);
+        ppo_row(mu, value[i], ls, a, old_lp[i], adv[i], ret[i], cfg, dm, dvl, st, i);
         d_mean[i] = make_float4(dm[0], dm[1], dm[2], dm[3]);
         d_value[i] = dvl;
     }

@@ -32,8 +32,9 @@ __device__ __forceinline__ float squashed_log_prob(const float* mu, const float*
 
 // one row of the clipped-surrogate loss: gradients w.r.t. the head outputs and the 9 statistics
 // st = {policy loss, value loss, log prob, approx kl, clipped?, d_log_std[4]}
+// `row`: index of this row in the call's arrays (for cfg.old_value)
 __device__ __forceinline__ void ppo_row(const float* mu, float v, const float* ls, const float* a, float old_lp, float A, float R,
-                                        const vf_ppo_loss_cfg& cfg, float* dm, float& d_value, float* st)
+                                        const vf_ppo_loss_cfg& cfg, float* dm, float& d_value, float* st, int row = 0)
 {
     float g[4];
     const float lp = squashed_log_prob(mu, ls, a, g);
@@ -45,7 +46,13 @@ __device__ __forceinline__ void ppo_row(const float* mu, float v, const float* l
     const bool clipped = ratio < lo || ratio > hi;
     // d(-min(s1,s2))/d ratio: through s1 when it is the smaller one (or equal: unclipped), else 0
     const float dl_dratio = (s1 <= s2 || !clipped) ? -A : 0.0f;
-    const float dv = v - R;
+    float vp = v, vgate = 1.0f;
+    if (cfg.clip_range_vf > 0.0f && cfg.old_value) {   // PPO.py:237-243; torch.clamp passes the gradient inside [min, max]
+        const float old_v = cfg.old_value[row], dvo = v - old_v;
+        vp = old_v + fminf(fmaxf(dvo, -cfg.clip_range_vf), cfg.clip_range_vf);
+        vgate = (dvo >= -cfg.clip_range_vf && dvo <= cfg.clip_range_vf) ? 1.0f : 0.0f;
+    }
+    const float dv = vp - R;
     // d loss / d log_prob per row (means over the global batch)
     const float dl_dlp = (dl_dratio * ratio + cfg.ent_coef) * cfg.inv_batch;
 #pragma unroll
@@ -55,7 +62,7 @@ __device__ __forceinline__ void ppo_row(const float* mu, float v, const float* l
         dm[d] = dl_dlp * z / sd;
         st[5 + d] = dl_dlp * (z * z - 1.0f);
     }
-    d_value = cfg.vf_coef * 2.0f * dv * cfg.inv_batch;
+    d_value = cfg.vf_coef * 2.0f * dv * cfg.inv_batch * vgate;
     st[0] = -fminf(s1, s2);
     st[1] = dv * dv;
     st[2] = lp;

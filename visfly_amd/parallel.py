@@ -30,6 +30,17 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def broadcast_(t: th.Tensor, src: int = 0) -> th.Tensor:
+    """rank `src`'s tensor to every rank (initial parameters: only gradients are exchanged afterwards)"""
+    if world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def shard(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     """contiguous agent shard of rank: (first agent id, count); remainders go to the low ranks"""
     base, rem = divmod(n_total, world)
@@ -38,9 +49,71 @@ def shard(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return first, count
 
 
+_native = {"comm": None, "tried": False}
+
+
+def _rccl_path() -> str:
+    """the librccl.so this process already maps (PyTorch ships its own copy), else PyTorch's, else the ROCm one"""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl.so" in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    cand = os.path.join(os.path.dirname(th.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else "/opt/rocm/lib/librccl.so"
+
+
+def native_comm(force: bool = False):
+    """vf_comm handle for vf_allreduce_grads (RCCL straight from C on the caller's stream), created once per process.
+    torch.distributed is the bootstrap: rank 0's ncclUniqueId is broadcast through the existing process group.  Only for
+    the nccl backend (the gloo test configurations keep torch.distributed); VISFLY_AMD_NATIVE_ALLREDUCE=0 disables it.
+    If RCCL refuses the communicator the reason is printed once and torch.distributed's RCCL all-reduce is used."""
+    if _native["tried"] and not force:
+        return _native["comm"]
+    _native["tried"] = True
+    if os.environ.get("VISFLY_AMD_NATIVE_ALLREDUCE", "1") == "0":
+        return None
+    w = world_size()
+    if not force and (w == 1 or dist.get_backend() != "nccl"):
+        return None
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    try:
+        _lib.check(L.vf_comm_library(_rccl_path().encode()))
+        ident = (C.c_uint8 * 128)()
+        if rank() == 0:
+            _lib.check(L.vf_comm_unique_id(ident))
+        if w > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = _lib._vp()
+        _lib.check(L.vf_comm_init(ident, w, rank(), C.byref(h)))
+        _native["comm"] = h
+    except Exception as e:  # noqa: BLE001
+        import warnings
+        warnings.warn(f"visfly_amd: native RCCL communicator unavailable ({e}); gradient all-reduce goes through "
+                      "torch.distributed (same RCCL collective, Python dispatch)")
+        _native["comm"] = None
+    return _native["comm"]
+
+
 def allreduce_sum_(t: th.Tensor) -> th.Tensor:
+    """in-place sum over the ranks.  fp32 / fp64 device tensors on the nccl backend: one ncclAllReduce enqueued from C on
+    torch's current stream (vf_allreduce_grads); anything else: torch.distributed"""
     if world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        c = native_comm() if (t.is_cuda and t.is_contiguous() and t.dtype in (th.float32, th.float64)) else None
+        if c is not None:
+            from . import _lib
+            L = _lib.lib()
+            fn = L.vf_allreduce_grads if t.dtype == th.float32 else L.vf_allreduce_f64
+            with th.cuda.device(t.device):
+                _lib.check(fn(c, t.data_ptr(), t.numel(), _lib.current_stream(t.device)))
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 

@@ -46,7 +46,7 @@ class MlpPolicy:
     """
 
     def __init__(self, obs_dims: Dict[str, int], extractor: Dict[str, List[int]], pi: List[int], vf: List[int],
-                 device, action_dim: int = 4, log_std_init: float = 0.0, seed: int = 0):
+                 device, action_dim: int = 4, log_std_init: float = 0.0, seed: int = 0, ortho_init: bool = True):
         assert action_dim == 4, "the head kernels are written for the 4-d drone action"
         self.device = th.device(device)
         self.obs_keys = list(extractor.keys())
@@ -92,13 +92,22 @@ class MlpPolicy:
         for ly in self.layers:
             if ly.K > 128 or ly.No > 128:
                 raise ValueError("layer widths up to 128 are supported by the MFMA linear kernels")
-        # ---- parameters: nn.Linear default init (kaiming-uniform), reproducible from `seed` ----
+        # ---- parameters, reproducible from `seed`.  ortho_init (the reference's default, policies.py:109): SB3's
+        # ActorCriticPolicy._build -- orthogonal weights with gain sqrt(2) for the extractor and trunk layers, 0.01 for
+        # action_net, 1 for value_net, zero biases; otherwise nn.Linear's default (kaiming-uniform) ----
         g = th.Generator().manual_seed(seed)
         flat = th.zeros(self.n_params)
+        self.ortho_init = bool(ortho_init)
         for ly in self.layers:
-            bound = 1.0 / np.sqrt(ly.K)
-            flat[ly.w_off:ly.w_off + ly.K * ly.No] = (th.rand(ly.K * ly.No, generator=g) * 2 - 1) * bound
-            flat[ly.b_off:ly.b_off + ly.No] = (th.rand(ly.No, generator=g) * 2 - 1) * bound
+            if ortho_init:
+                gain = {"mean": 0.01, "value": 1.0}.get(ly.dst, float(np.sqrt(2.0)))
+                w = th.empty(ly.No, ly.K)
+                th.nn.init.orthogonal_(w, gain=gain, generator=g)
+                flat[ly.w_off:ly.w_off + ly.K * ly.No] = w.reshape(-1)
+            else:
+                bound = 1.0 / np.sqrt(ly.K)
+                flat[ly.w_off:ly.w_off + ly.K * ly.No] = (th.rand(ly.K * ly.No, generator=g) * 2 - 1) * bound
+                flat[ly.b_off:ly.b_off + ly.No] = (th.rand(ly.No, generator=g) * 2 - 1) * bound
         flat[self.log_std_off:] = log_std_init
         self.flat = flat.to(self.device)
         self.grad = th.zeros_like(self.flat)
@@ -116,6 +125,17 @@ class MlpPolicy:
         self._act_fused = None             # likewise for vf_mlp_forward_act
         self._sq_part = None
         self._slot_blocks: Dict[int, tuple] = {}
+
+    def _warn_fallback(self, what):
+        """the register-chained kernels are instantiated for the reference-default shapes only (one or two [128, 64] extractor
+        branches, [64, 64] trunks); any other net_arch runs on the general block-tile / per-layer kernels -- correct, but
+        at roughly half the MFMA throughput.  Say so once instead of silently."""
+        if not getattr(self, "_warned_fallback", False):
+            self._warned_fallback = True
+            import warnings
+            warnings.warn(f"visfly_amd: {what} has no register-chained instance for this network "
+                          f"(extractor {self.spec['extractor']}, pi {self.spec['pi']}, vf {self.spec['vf']}); "
+                          "falling back to the block-tile MFMA kernels (about half the throughput)", stacklevel=3)
 
     def _plan_fused(self):
         """LDS layout for the one-launch forward (vf_mlp_forward): every activation gets a [64][w|1] region
@@ -578,6 +598,7 @@ class MlpPolicy:
                              C.byref(loss_cfg), _ptr(loss_scratch), st)
         if rc == _lib.EUNSUPPORTED:
             self._fused_ppo = False
+            self._warn_fallback("vf_ppo_update")
             return False
         if rc:
             _lib.check(rc)
@@ -678,7 +699,7 @@ class PPO:
     def __init__(self, env, n_steps=256, batch_size=25600, n_epochs=5, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
                  ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, learning_rate=1e-4, weight_decay=1e-5,
                  normalize_advantage=True, policy_kwargs: Optional[dict] = None, seed=0, adam_eps=1e-8,
-                 betas=(0.9, 0.999), target_kl=None, policy=None, verbose=0, device=None):
+                 betas=(0.9, 0.999), target_kl=None, policy=None, verbose=0, device=None, clip_range_vf=None):
         # `policy`, `verbose`, `device`: accepted so that the `algorithm:` block of the reference's YAMLs can be passed
         # as **kwargs (exps/examples/alg_cfgs/*/PPO.yaml); the policy is always the MFMA MlpPolicy on the env's device
         if policy not in (None, "CustomMultiInputPolicy", "MultiInputPolicy", "MlpPolicy"):
@@ -692,6 +713,7 @@ class PPO:
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
         self.lr, self.weight_decay, self.adam_eps, self.betas = learning_rate, weight_decay, adam_eps, betas
         self.normalize_advantage, self.target_kl, self.seed = normalize_advantage, target_kl, seed
+        self.clip_range_vf = clip_range_vf                          # PPO.py:237-243; None = no value clipping
         self._last_obs = None
         if not getattr(env, "_is_initial", False):
             self._last_obs = env.reset()
@@ -702,14 +724,23 @@ class PPO:
         self.weight_decay = pk.get("weight_decay", self.weight_decay)   # optimizer_kwargs.weight_decay of the YAMLs
         extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
         self.policy = MlpPolicy(obs_dims, extractor, pk.get("pi", [64, 64]), pk.get("vf", [64, 64]), self.device,
-                                log_std_init=pk.get("log_std_init", 0.0), seed=seed)
+                                log_std_init=pk.get("log_std_init", 0.0), seed=seed, ortho_init=pk.get("ortho_init", True))
         self.policy.lazy_pack = True        # this trainer calls mark_updated() after every optimiser step
+        self.world, self.rank = parallel.world_size(), parallel.rank()
+        # every rank must start from the SAME parameters (only gradients are exchanged afterwards) and draw DIFFERENT
+        # exploration noise for its agents: rank 0's initial weights go to everybody, the rank goes into the Philox key
+        parallel.broadcast_(self.policy.flat)
+        self.policy.mark_updated()
+        self._noise_key = (int(seed) ^ (self.rank << 32)) & (2 ** 64 - 1)
         self.buf = RolloutBuffer(n_steps, self.n_envs, obs_dims, self.device)
         n = self.policy.n_params
         dev = self.device
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=dev), th.zeros(n, device=dev)
         self._scratch = th.zeros(16 * 1024 + 4096, device=dev)
-        self._stats = th.zeros(16, device=dev)
+        # flat gradient and the 16 loss statistics in ONE buffer: an optimiser step on several GPUs is exactly one all-reduce
+        self._gbuf = th.zeros(n + 16, device=dev)
+        self.policy.grad = self._gbuf[:n]
+        self._stats = self._gbuf[n:]
         self._ep_stats = th.zeros(4, dtype=th.float64, device=dev)   # episodes, sum return, sum length, successes
         self._sumsq = th.zeros(1, device=dev)
         self._sums = th.zeros(2, dtype=th.float64, device=dev)
@@ -718,8 +749,6 @@ class PPO:
         self.num_timesteps = 0
         self._last_starts = th.ones(self.n_envs, device=dev)
         self._shuf = None
-        # bounded list of truncated-episode terminal observations per rollout (timeout bootstrap)
-        self.world = parallel.world_size()
         self.logs: Dict[str, float] = {}
 
     def _stream(self):
@@ -736,7 +765,7 @@ class PPO:
     def load(cls, path: str, env, **kwargs):
         """PPO.py:432-572: re-create the trainer on `env`, then load policy (and optimiser) state; also reads
         archives written by the reference (policy.pth with the reference's parameter names)"""
-        return checkpoint.load_into(cls(env, **kwargs), path)
+        return checkpoint.load_into(cls(env, **checkpoint.ctor_kwargs_from_archive(path, kwargs)), path)
 
     # ------------------------------------------------------------------------------------------
     def _act(self, obs, deterministic=False):
@@ -747,7 +776,7 @@ class PPO:
         logp = th.empty(M, device=self.device)
         self._sample_step += 1
         _lib.check(_lib.lib().vf_head_sample(_ptr(mean), _ptr(self.policy.log_std), _ptr(action), _ptr(logp), M,
-                                             int(self.seed) & (2 ** 64 - 1), self._sample_step, 1 if deterministic else 0,
+                                             self._noise_key, self._sample_step, 1 if deterministic else 0,
                                              self._stream()))
         return action, value.view(M), logp
 
@@ -775,7 +804,7 @@ class PPO:
             action, logp = buf.actions[t], buf.log_probs[t]
             mean, _ = pol.forward({k: obs[k] for k in self.obs_keys}, save_activations=False, out_value=buf.values[t])
             self._sample_step += 1
-            _lib.check(L.vf_head_sample(_ptr(mean), _ptr(pol.log_std), _ptr(action), _ptr(logp), N, int(self.seed) & (2 ** 64 - 1),
+            _lib.check(L.vf_head_sample(_ptr(mean), _ptr(pol.log_std), _ptr(action), _ptr(logp), N, self._noise_key,
                                         self._sample_step, 0, self._stream()))
             for k in self.obs_keys:
                 buf.obs[k][t].copy_(obs[k])
@@ -799,7 +828,9 @@ class PPO:
 
     # ------------------------------------------------------------------------------------------
     def _minibatch_update(self, mb, stats_acc=None):
-        """one optimiser step on a minibatch {obs:*, actions, old_lp, adv, ret} of contiguous rows (PPO.py:203-292)"""
+        """one optimiser step on a minibatch {obs:*, actions, old_lp, adv, ret[, old_v]} of contiguous rows (PPO.py:203-292).
+        Returns the loss statistics of the (global) minibatch, or None when target_kl stopped the update BEFORE the
+        optimiser step (PPO.py:269-282)."""
         L, st, pol = _lib.lib(), self._stream(), self.policy
         obs = {k: mb["obs:" + k] for k in self.obs_keys}
         actions, old_lp, adv, ret = mb["actions"], mb["old_lp"], mb["adv"], mb["ret"]
@@ -807,8 +838,10 @@ class PPO:
         gB = B * self.world
         # the loss launch also writes d(loss)/d(log_std) into the tail of the flat gradient and adds the minibatch
         # statistics to the epoch accumulator (no separate copy / add launches)
+        vclip = self.clip_range_vf is not None
         cfg = _lib.PpoLossCfg(self.clip_range, self.ent_coef, self.vf_coef, 1.0 / gB, _ptr(pol.grad, pol.log_std_off),
-                              None if stats_acc is None else _ptr(stats_acc))
+                              None if stats_acc is None else _ptr(stats_acc),
+                              _ptr(mb["old_v"]) if vclip else None, float(self.clip_range_vf) if vclip else 0.0, 0)
         # reference-default policy shapes: forward + loss + reverse chain are one launch (vf_ppo_update)
         # single GPU: the weight-gradient fold also leaves the squared gradient norm as partial sums, which Adam adds up itself
         res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch, want_sumsq=self.world == 1)
@@ -820,7 +853,15 @@ class PPO:
                                      _ptr(d_mean), _ptr(d_value), _ptr(self._stats), B, C.byref(cfg), _ptr(self._scratch), st))
             pol.backward(d_mean, d_value, None)
         if self.world > 1:
-            parallel.allreduce_sum_(pol.grad)      # sum over ranks: every term is already / global batch
+            # ONE collective per optimiser step: the flat gradient and the 16 loss statistics are one buffer
+            # (sum over ranks: every gradient term is already / global batch, the statistics are per-rank sums)
+            parallel.allreduce_sum_(self._gbuf)
+        if self.target_kl is not None:
+            # PPO.py:269-282: approx_kl of THIS minibatch, checked before optimizer.step() (one host sync per minibatch,
+            # only when target_kl is set; with several ranks the statistics came back with the gradient)
+            kl = float(self._stats[3].item()) / gB
+            if kl > 1.5 * self.target_kl:
+                return None
         self._opt_step += 1
         if sq is None:
             _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
@@ -835,59 +876,69 @@ class PPO:
         return self._stats
 
     def train(self):
-        """PPO.train (PPO.py:177-337): n_epochs passes over random minibatches"""
+        """PPO.train (PPO.py:177-337): n_epochs passes over random minibatches (SB3 RolloutBuffer.get: the trailing
+        partial minibatch of an epoch is trained on too)"""
         total = self.n_steps * self.n_envs
         bs = min(self.batch_size, total)
         g = th.Generator(device=self.device)
         g.manual_seed(self.seed + 7919 * (self._opt_step + 1))
         stats_acc = th.zeros(16, device=self.device)
-        n_mb = 0
+        rows_done = 0
         stop = False
         buf = self.buf
         flat = {"actions": buf.actions.view(-1, 4), "old_lp": buf.log_probs.view(-1), "adv": buf.advantages.view(-1),
                 "ret": buf.returns.view(-1)}
+        if self.clip_range_vf is not None:
+            flat["old_v"] = buf.values.view(-1)
         flat.update({"obs:" + k: buf.obs[k].view(-1, buf.obs[k].shape[-1]) for k in self.obs_keys})
+        n_seg, rem = divmod(total, bs)
         for _epoch in range(self.n_epochs):
             # one gather per epoch instead of one per minibatch: the shuffled copy makes every minibatch a
             # contiguous slice (same rows, same order as indexing the buffer with perm[s:s+bs])
             perm = th.randperm(total, device=self.device, generator=g)
             shuf = self._gather(flat, perm)
-            n_seg = total // bs
             if self.normalize_advantage and bs * self.world > 1:
                 # PPO.py:215-220 normalises per minibatch; all minibatches of the epoch in one launch (+ one
                 # all-reduce of the per-minibatch sums when the minibatch spans several GPUs)
                 advn = th.empty_like(shuf["adv"])
-                sums = th.empty((n_seg, 2), dtype=th.float64, device=self.device)
+                sums = th.empty((n_seg + 1, 2), dtype=th.float64, device=self.device)
                 L, stv = _lib.lib(), self._stream()
-                args = (_ptr(shuf["adv"]), _ptr(advn), n_seg, bs, bs * self.world, sums.data_ptr())
+                calls = [(_ptr(shuf["adv"]), _ptr(advn), n_seg, bs, bs * self.world, sums.data_ptr())]
+                if rem > 1 or (rem == 1 and self.world > 1):       # PPO.py:216: only `if len(advantages) > 1`
+                    calls.append((_ptr(shuf["adv"], n_seg * bs), _ptr(advn, n_seg * bs), 1, rem, rem * self.world,
+                                  sums.data_ptr() + 16 * n_seg))
+                elif rem == 1:
+                    advn[n_seg * bs:] = shuf["adv"][n_seg * bs:]
                 if self.world > 1:
-                    _lib.check(L.vf_adv_normalize_segments(*args, 0, stv))
+                    for args in calls:
+                        _lib.check(L.vf_adv_normalize_segments(*args, 0, stv))
                     parallel.allreduce_sum_(sums)
-                    _lib.check(L.vf_adv_normalize_segments(*args, 1, stv))
+                    for args in calls:
+                        _lib.check(L.vf_adv_normalize_segments(*args, 1, stv))
                 else:
-                    _lib.check(L.vf_adv_normalize_segments(*args, 2, stv))
+                    for args in calls:
+                        _lib.check(L.vf_adv_normalize_segments(*args, 2, stv))
                 shuf["adv"] = advn
-            for s in range(0, total - bs + 1, bs):
-                st = self._minibatch_update({k: v[s:s + bs] for k, v in shuf.items()}, stats_acc)
-                n_mb += 1
-                if self.target_kl is not None:
-                    # PPO.py:269-282 checks the KL before the optimiser step; here the check follows the step
-                    # that produced it (one host sync per minibatch, only when target_kl is set)
-                    kl = parallel.allreduce_sum_(st[3:4].clone()).item() / (bs * self.world)
-                    if kl > 1.5 * self.target_kl:
-                        stop = True
-                        break
+            for s in range(0, total, bs):
+                e = min(s + bs, total)
+                st = self._minibatch_update({k: v[s:e] for k, v in shuf.items()}, stats_acc)
+                rows_done += e - s
+                if st is None:
+                    stop = True
+                    break
             if stop:
                 break
-        rows = float(bs * n_mb)
-        s = (stats_acc / rows).tolist()
+        if self.world > 1:
+            parallel.allreduce_sum_(stats_acc)                       # log the global means, like a single-process run would
+        s = (stats_acc / float(max(rows_done, 1) * self.world)).tolist()
         ep = parallel.allreduce_sum_(self._ep_stats.clone()).tolist()          # rollout statistics of this iteration (:398-414)
         self._ep_stats.zero_()
         if ep[0] > 0:
             self.logs.update({"rollout/ep_rew_mean": ep[1] / ep[0], "rollout/ep_len_mean": ep[2] / ep[0],
                               "rollout/ep_success_rate": ep[3] / ep[0], "rollout/episodes": ep[0]})
         self.logs.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/entropy_loss": s[2],
-                          "train/approx_kl": s[3], "train/clip_fraction": s[4], "train/n_updates": self._opt_step})
+                          "train/approx_kl": s[3], "train/clip_fraction": s[4], "train/n_updates": self._opt_step,
+                          "train/early_stop": float(stop)})
 
     def _gather(self, flat, perm):
         """{name: rows of flat[name] in the order of perm} -- all fields in one launch (vf_gather_rows); the destination
