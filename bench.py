@@ -30,6 +30,27 @@ BYTES_PER_ENV_STEP = 350        # full env.step adds obs, reward, c
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def host_cores():
+    """cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU box advertises 256 CPUs
+    but may schedule far fewer; 256 OpenMP threads on a handful of cores only measure context switching)"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(np.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(np.ceil(q / per))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline_env(consts, kind, N, seconds_target=15.0, threads=None, note=None):
     """TEST/BENCH INFRASTRUCTURE: time the CPU oracle (C restatement of the reference's env.step: dynamics interval + bbox
     collision + reward / counters / done masks) on the host cores of this box on a bounded sample of the same workload.
@@ -37,7 +58,7 @@ def cpu_baseline_env(consts, kind, N, seconds_target=15.0, threads=None, note=No
     contiguous agent chunk through the steps -- agents are independent), so 256 threads are not fork-join-bound; no
     auto-reset inside the sample: episodes are 256 steps long and the sample is re-spawned every 192 steps."""
     import oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     threads = min(threads or cores, cores)
     oracle.set_threads(threads)
     gates = [[4, 4, 1.], [8, 0, 2.], [5, -4, 1.], [1, -1, 1.]] if kind == "racing" else None
@@ -65,7 +86,7 @@ def cpu_baseline_env(consts, kind, N, seconds_target=15.0, threads=None, note=No
             break
     assert np.isfinite(env.dyn.S).all()
     oracle.set_threads(cores)
-    out = {"value": N * steps / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+    out = {"value": N * steps / el, "affinity_cpus": len(os.sched_getaffinity(0)), "unit": "agent-steps/s", "cores": threads, "kind": "port",
            "sample": f"oracle/vf_oracle.c {kind} env.step restatement (OpenMP, {threads} thread{'s' if threads > 1 else ''}, one "
                      f"parallel region per {block} steps), N={N}, {steps} control steps, {el:.1f} s"}
     if note:
@@ -236,7 +257,14 @@ def main():
     seq = pool.repeat(((Kc + 15) // 16, 1, 1))[:Kc].contiguous()
     wseq = pool.repeat(((max(W, 1) + 15) // 16, 1, 1))[:max(W, 1)].contiguous()
 
+    tail = torch.cuda.Event()
+
     def barrier():
+        # poll an event first: hipDeviceSynchronize parks the thread and wakes up tens of microseconds late, which a
+        # 20-step region (~250 us) would count as step time; the synchronize the contract asks for follows immediately
+        tail.record()
+        while not tail.query():
+            pass
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -254,13 +282,10 @@ def main():
         run_steps(W, wseq)
     run_steps(min(K, 64), seq)                            # first use of the K-step output buffers is an allocation
     walls, hosts, events = [], [], []
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(max(1, args.repeats)):
+    for _ in range(max(1, args.repeats)):          # wall clock: nothing but the K launches between the two barriers
         barrier()
         t0 = time.perf_counter()
-        e0.record()
         run_steps(K, seq)
-        e1.record()
         t1 = time.perf_counter()
         barrier()
         el = time.perf_counter() - t0
@@ -270,6 +295,13 @@ def main():
             el = float(t.item())
         walls.append(el)
         hosts.append(t1 - t0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):                              # the same region on the device's clock (HIP events on the launch stream)
+        barrier()
+        e0.record()
+        run_steps(K, seq)
+        e1.record()
+        barrier()
         events.append(e0.elapsed_time(e1) * 1e-3)
     el = statistics.median(walls)
 

@@ -50,7 +50,8 @@ enum { VF_OK = 0, VF_EINVAL = -1, VF_EHIP = -2, VF_ESTATE = -3, VF_EUNSUPPORTED 
 enum {
     VF_G_POS = 0,   /* t,  p.x, p.y, p.z                                 */
     VF_G_QUAT = 1,  /* q.w, q.x, q.y, q.z                                */
-    VF_G_VEL = 2,   /* h,  v.x, v.y, v.z   (velocity without wind; h = delay-ring head, int bits) */
+    VF_G_VEL = 2,   /* h,  v.x, v.y, v.z   (velocity without wind; h = delay-ring head, int bits: the same for every agent,
+                       = control steps since the last full reset mod delay_steps; the handle keeps the launch-uniform copy) */
     VF_G_OMG = 3,   /* s,  w.x, w.y, w.z   (body rates)                  */
     VF_G_MOT = 4,   /* motor omega 0..3                                  */
     VF_G_THR = 5,   /* rotor thrusts 0..3                                */
@@ -253,11 +254,13 @@ typedef struct vf_env_rollout {
 } vf_env_rollout;
 int vf_env_step_n(vf_env* h, const vf_env_rollout* r, vf_stream_t stream);
 
-/* The same K launches captured once into a hipGraph and replayed with one hipGraphLaunch per rollout (the
- * per-agent delay-ring head lives in the slab, so a launch carries no per-step host state and the captured
- * kernel arguments stay valid for every replay).  The rollout's pointers are baked into the graph: the caller
- * keeps those buffers alive and refills `actions` between replays. */
+/* The same K launches captured once into a hipGraph and replayed with one hipGraphLaunch per rollout.  The rollout's
+ * pointers and the delay-ring slot of every captured launch are baked into the graph: the caller keeps those buffers alive,
+ * refills `actions` between replays, and replays a graph only at the ring phase it was captured at (vf_env_ring_phase ==
+ * steps since the last full reset mod delay_steps; vf_env_graph_launch returns VF_ESTATE otherwise) -- with K a multiple of
+ * delay_steps one graph serves every replay, else keep one graph per phase. */
 typedef struct vf_env_graph vf_env_graph;
+int32_t vf_env_ring_phase(const vf_env* h);
 int vf_env_graph_create(vf_env* h, const vf_env_rollout* r, vf_env_graph** out);
 int vf_env_graph_launch(vf_env_graph* g, vf_stream_t stream);
 void vf_env_graph_destroy(vf_env_graph* g);

@@ -486,6 +486,48 @@ def gen_env(name, N=128, seed=42):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+IMU_NOISE = {"IMU": {"model": "UniformNoiseModel", "kwargs": {
+    "mean": [0.01, -0.02, 0.0, 0.0, 0.0, 0.0, 0.0, 0.05, 0.0, -0.05, 0.0, 0.01, 0.0],
+    "half": [0.10, 0.10, 0.2, 0.05, 0.05, 0.05, 0.05, 0.30, 0.3, 0.30, 0.2, 0.20, 0.2]}}}
+
+
+def gen_imu(name="env_hover_imu", N=128, steps=40, seed=42):
+    """IMU noise with NON-ZERO amplitude (envs/base/droneEnv.py:99-125, utils/type.py:25-38): HoverEnv from seed 42, the
+    noisy state sensor_obs["IMU"] after reset() and after every step (the draws come from the global generator between
+    the spawn draws)"""
+    HoverEnvShim, _, _ = import_envs()
+    use_cr_sqrt(True)
+    rk = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]},
+          "noise_kwargs": {k: {"model": v["model"], "kwargs": {a: th.tensor(b) for a, b in v["kwargs"].items()}}
+                           for k, v in IMU_NOISE.items()}}
+    env = HoverEnvShim(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False, dynamics_kwargs=dict(ENV_DYN), device="cpu",
+                       tensor_output=True, max_episode_steps=16, random_kwargs=rk)
+    consts = extract_consts(env.envs.dynamics)
+    rng = np.random.default_rng(seed + 5)
+    q = rng.integers(-127, 128, size=(steps, N, 4), dtype=np.int8)
+    actions = decode_actions(q, [-1 / 3, 0, 0, 0], 0.5)
+    env.reset()
+    imu = [f32(env.sensor_obs["IMU"])]
+    state = [f32(env.state)]
+    done_count = 0
+    for k in range(steps):
+        _o, _r, d, _i = env.step(th.from_numpy(actions[k].copy()))
+        done_count += int(d.sum())
+        imu.append(f32(env.sensor_obs["IMU"]))
+        state.append(f32(env.state))
+    keep = np.asarray([0, 1, 2, 8, 16, 17, 18, 32, steps], np.int32)      # index 0 = after reset(), k = after step k
+    imu, state = np.stack(imu)[keep], np.stack(state)[keep]
+    dev = np.abs(imu - state)
+    print(f"{name}: N={N} steps={steps} resets={done_count} mean|imu - state|={dev.mean():.4f} max={dev.max():.4f}")
+    save = {"kind": np.asarray("hover"), "seed": np.int32(seed), "max_episode_steps": np.int32(16), "actions_q": q,
+            "hover": np.asarray([-1 / 3, 0, 0, 0], np.float32), "scale": np.float32(0.5), "imu": imu, "state": state, "keep": keep,
+            "noise_mean": np.asarray(IMU_NOISE["IMU"]["kwargs"]["mean"], np.float32),
+            "noise_half": np.asarray(IMU_NOISE["IMU"]["kwargs"]["half"], np.float32),
+            "label": np.asarray("cr-sqrt-oracle")}
+    save.update({"c_" + k: v for k, v in consts.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 BPTT_CASES = {
     # name: (env kind, dynamics kwargs, ctor kwargs, hover action, action noise, horizon)
     "bptt_hover_bodyrate": ("hover", ENV_DYN, dict(max_episode_steps=1000), [-1 / 3, 0, 0, 0], 0.3, 12),
@@ -722,6 +764,8 @@ def main():
             gen_bptt(name)
     if args.only in (None, "td_lambda"):
         gen_td()
+    if args.only in (None, "env_hover_imu"):
+        gen_imu()
     if args.only in (None, "ppo_nav"):
         gen_ppo("ppo_nav")
     if args.only in (None, "ppo_nav_vclip"):

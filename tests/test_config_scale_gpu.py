@@ -66,7 +66,7 @@ def test_config3_ppo_iteration_at_shard_scale():
     assert logs["rollout/episodes"] > 0.5 * rows / 256          # episodes end (collisions / timeouts) and are counted
     flat2, logs2, _, _ = _ppo_iteration(0)
     assert torch.equal(flat, flat2), "one PPO iteration must be bitwise reproducible"
-    assert logs == logs2
+    assert {k: v for k, v in logs.items() if not k.startswith("time/")} == {k: v for k, v in logs2.items() if not k.startswith("time/")}
     flat3, _, _, _ = _ppo_iteration(1)
     assert not torch.equal(flat, flat3)
 

@@ -325,3 +325,44 @@ def test_racing_info_reports_gates_passed_in_the_finished_episode():
             seen += int(count[i] > 0)
             count[i] = 0
     assert seen > 0
+
+
+def test_imu_noise_replay_mode_matches_reference():
+    """random_kwargs["noise_kwargs"]["IMU"] with non-zero amplitude (droneEnv.py:99-125): in replay-spawn mode the env draws the
+    reference's th.rand(N,13) at every update_observation, so sensor_obs["IMU"] = state + (u - 0.5) * half + mean with the
+    quaternion re-normalised is the reference's, through resets"""
+    from visfly_amd.envs import HoverEnv
+    fx = load("env_hover_imu")
+    acts = decode_actions(fx)
+    N = fx["imu"].shape[1]
+    noise = {"IMU": {"model": "UniformNoiseModel", "kwargs": {"mean": fx["noise_mean"], "half": fx["noise_half"]}}}
+    rk = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]},
+          "noise_kwargs": noise}
+    env = HoverEnv(num_agent_per_scene=N, seed=int(fx["seed"]), dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True,
+                   max_episode_steps=int(fx["max_episode_steps"]), random_kwargs=rk, spawn="replay", constants=consts_of(fx))
+    env.reset()
+    keep = list(fx["keep"])
+    for k in range(acts.shape[0] + 1):
+        if k in keep:
+            j = keep.index(k)
+            assert_bits_equal(env.state.cpu().numpy(), fx["state"][j], f"state @ {k}")
+            imu = env.sensor_obs["IMU"].cpu().numpy()
+            # th.nn.functional.normalize on the GPU vs the reference's CPU: one division by max(norm, eps) per element
+            assert np.abs(imu - fx["imu"][j]).max() <= 2.4e-7, (k, np.abs(imu - fx["imu"][j]).max())
+            same = (imu.view(np.uint32) == fx["imu"][j].view(np.uint32)).mean()
+            assert same > 0.93, same      # measured 0.965: the quaternion columns go through a GPU normalise
+        if k < acts.shape[0]:
+            env.step(torch.from_numpy(acts[k]).cuda())
+    # device-spawn mode: same distribution, own generator
+    env2 = HoverEnv(num_agent_per_scene=4096, dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True, random_kwargs=rk)
+    env2.reset()
+    env2.step(torch.zeros((4096, 4), device="cuda"))
+    d = (env2.sensor_obs["IMU"] - env2.state).cpu().numpy()
+    mean, half = fx["noise_mean"], fx["noise_half"]
+    cols = [0, 1, 2, 7, 8, 9, 10, 11, 12]                                  # quaternion columns are re-normalised
+    assert np.abs(d[:, cols].mean(0) - mean[cols]).max() < 0.02 and (np.abs(d[:, cols] - mean[cols]) <= half[cols] / 2 + 1e-6).all()
+    assert np.allclose(np.linalg.norm(env2.sensor_obs["IMU"][:, 3:7].cpu().numpy(), axis=1), 1.0, atol=1e-6)
+    assert env2.sensor_obs["IMU"] is env2.sensor_obs["IMU"]                # one draw per step
+    with pytest.raises(NotImplementedError):
+        HoverEnv(num_agent_per_scene=4, dynamics_kwargs=dict(ENV_DYN), device="cuda:0",
+                 random_kwargs=dict(rk, noise_kwargs={"IMU": {"model": "GaussianNoiseModel", "kwargs": {"mean": 0, "std": 1}}}))

@@ -88,8 +88,34 @@ def test_graph_replay_equals_k_steps():
             same(reward[k], outs[k][1], f"round {rnd} reward @ {k}")
             same(done[k], outs[k][2], f"round {rnd} done @ {k}")
         same(env._slab, ref._slab, f"round {rnd} slab")
-    assert len(env._rollouts[K]["graphs"]) == 1
+    assert len(env._rollouts[K]["graphs"]) == 1          # K is a multiple of the 3-slot delay ring: one graph serves every replay
     env.close()
+
+
+def test_graph_replay_ring_phases_and_interleaved_steps():
+    """K not a multiple of delay_steps: the ring phase at the start of a replay cycles, one graph per phase is captured;
+    single step() calls in between shift the phase too"""
+    from visfly_amd import _lib
+    N, K = 1000, 20
+    ref, env = make("HoverEnv", N), make("HoverEnv", N)
+    buf = torch.empty((K, N, 4), device="cuda")
+    for rnd in range(5):
+        A = actions(N, K, seed=10 + rnd)
+        buf.copy_(A)
+        outs = [ref.step(A[k]) for k in range(K)]
+        obs, reward, done = env.step_n(buf, graph=True)
+        for k in (0, 1, 2, K - 1):
+            same(obs[k], outs[k][0]["state"], f"round {rnd} obs @ {k}")
+        same(env._slab, ref._slab, f"round {rnd} slab")
+        if rnd == 2:
+            extra = actions(N, 1, seed=99)[0]
+            same(env.step(extra)[0]["state"], ref.step(extra)[0]["state"], "interleaved step()")
+    assert len(env._rollouts[K]["graphs"]) == 3
+    L = _lib.lib()
+    phase = int(L.vf_env_ring_phase(env._h))
+    wrong = next(g for key, g in env._rollouts[K]["graphs"].items() if key[2] != phase)
+    assert L.vf_env_graph_launch(wrong, _lib.current_stream(env.device)) == -3 and b"phase" in L.vf_last_error()
+    same(env._slab, ref._slab, "a refused replay leaves the env untouched")
 
 
 def test_output_ring_equals_fresh_tensors():

@@ -44,9 +44,9 @@ def test_ppo_chain_matches_reference_golden(name):
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     # ---- vf_gae: bit-identical to the reference's RolloutBuffer ----
     adv, ret = torch.empty((T, N), device=dev), torch.empty((T, N), device=dev)
-    _lib.check(L.vf_gae(d(fx["rewards"]).data_ptr(), d(fx["values"]).data_ptr(), d(fx["episode_starts"]).data_ptr(),
-                        d(fx["last_values"]).data_ptr(), d(fx["dones"]).data_ptr(), adv.data_ptr(), ret.data_ptr(), T, N,
-                        float(fx["gamma"]), float(fx["gae_lambda"]), st()))
+    rw, vl, es, lv, dn = (d(fx[k]) for k in ("rewards", "values", "episode_starts", "last_values", "dones"))
+    _lib.check(L.vf_gae(rw.data_ptr(), vl.data_ptr(), es.data_ptr(), lv.data_ptr(), dn.data_ptr(), adv.data_ptr(), ret.data_ptr(),
+                        T, N, float(fx["gamma"]), float(fx["gae_lambda"]), st()))
     assert np.array_equal(adv.cpu().numpy().view(np.uint32), fx["advantages"].view(np.uint32))
     assert np.array_equal(ret.cpu().numpy().view(np.uint32), fx["returns"].view(np.uint32))
     # ---- advantage normalisation of the (single, full) minibatch: PPO.py:215-220 ----
@@ -70,7 +70,8 @@ def test_ppo_chain_matches_reference_golden(name):
     cfg = _lib.PpoLossCfg(float(fx["clip_range"]), float(fx["ent_coef"]), float(fx["vf_coef"]), 1.0 / M,
                           pol.grad.data_ptr() + 4 * pol.log_std_off, None,
                           old_v.data_ptr() if vclip > 0 else None, vclip if vclip > 0 else 0.0, 0)
-    res = pol.ppo_update(obs, d(fx["actions"]), d(fx["old_log_prob"]), d(want), ret.reshape(M).contiguous(), cfg, stats, scratch)
+    act, olp, advn_ref, ret_flat = d(fx["actions"]), d(fx["old_log_prob"]), d(want), ret.reshape(M).contiguous()
+    res = pol.ppo_update(obs, act, olp, advn_ref, ret_flat, cfg, stats, scratch)
     assert res is True, "the StateTarget network must run on the register-chained kernels"
     s = (stats[:5] / M).cpu().numpy()
     gold = np.array([fx["policy_loss"], fx["value_loss"], fx["entropy_loss"], fx["approx_kl"], fx["clip_fraction"]], np.float32)
@@ -88,7 +89,7 @@ def test_ppo_chain_matches_reference_golden(name):
     d_mean, d_value = torch.empty((M, 4), device=dev), torch.empty(M, device=dev)
     stats2 = torch.zeros(16, device=dev)
     mean, value = pol.forward(obs)
-    _lib.check(L.vf_ppo_loss(mean.data_ptr(), value.data_ptr(), pol.log_std.data_ptr(), d(fx["actions"]).data_ptr(),
-                             d(fx["old_log_prob"]).data_ptr(), d(want).data_ptr(), ret.reshape(M).contiguous().data_ptr(),
-                             d_mean.data_ptr(), d_value.data_ptr(), stats2.data_ptr(), M, C.byref(cfg), scratch.data_ptr(), st()))
+    _lib.check(L.vf_ppo_loss(mean.data_ptr(), value.data_ptr(), pol.log_std.data_ptr(), act.data_ptr(), olp.data_ptr(),
+                             advn_ref.data_ptr(), ret_flat.data_ptr(), d_mean.data_ptr(), d_value.data_ptr(), stats2.data_ptr(), M,
+                             C.byref(cfg), scratch.data_ptr(), st()))
     assert np.allclose((stats2[:5] / M).cpu().numpy(), gold, rtol=3e-5, atol=2e-6)

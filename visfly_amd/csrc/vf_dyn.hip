@@ -24,14 +24,15 @@ char* err_buf()
 template <int ACT, int INTEG, bool CTRL_DELAY>
 __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg c, const DynArgs g)
 {
-    __shared__ float tile[kBlock * 13];
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.N;
     Agent s;
     Spares sp;
+    float a[4], head_bits = 0.0f;
+    ring_exchange(c, g, i, live, head_bits, a);   // issued first: its two loads are the first values the controller needs
     load_agent<false>(g.S, g.G, i, s, sp);
-    float a[4];
-    ring_exchange(c, g, i, live, sp.vel, a);
+    if (c.delay_steps > 0) sp.vel = head_bits;
     float kl[3], kq[3];
     drag_of(c, g, i, kl, kq);
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg c, const D
 template <int ACT, int INTEG, bool CTRL_DELAY>
 __global__ __launch_bounds__(kBlock) void k_dyn_step_split(const vf_dyn_cfg c, const DynArgs g)
 {
-    __shared__ SplitShared shs[2];
+    __shared__ __attribute__((aligned(16))) SplitShared shs[2];
     const int grp = (threadIdx.x >> 6) & 1;
     SplitShared& sh = shs[grp];
     const int first = blockIdx.x * 128 + grp * 64;
@@ -173,7 +174,8 @@ StepKernel pick_step_kernel(const vf_dyn_cfg& c)
 
 int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st)
 {
-    vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out};
+    vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out, vf::ring_head(h)};
+    h->tick += 1;
     if (vf::use_split(h->Npad, h->cfg))
         hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->cfg, g);
     else
@@ -237,6 +239,7 @@ int vf_dyn_reset(vf_dyn* h, const int32_t* idx, int32_t k, const float* pos, con
     if (n < 0) return vf::fail(VF_EINVAL, "vf_dyn_reset: k < 0");
     hipStream_t st = vf::as_stream(stream);
     if (n == 0) return VF_OK;
+    if (!idx) h->tick = 0;   // full reset: every head word goes to 0 (k_dyn_reset), and so does the launch-uniform phase
     vf::ResetArgs r{h->N, h->Npad, n, h->G, h->g_drag, h->S, idx, pos, quat, vel, omg, mot, thr, t, t_rand, klin, kquad};
     hipLaunchKernelGGL(vf::k_dyn_reset, dim3(vf::blocks_for(n)), dim3(vf::kBlock), 0, st, h->cfg, r);
     VF_HIP(hipGetLastError());

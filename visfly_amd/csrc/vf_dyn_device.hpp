@@ -420,6 +420,43 @@ __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, 
     finish_interval(c, s);
 }
 
+// ---- global stores of the step kernels ----
+// A step leaves ~200 B per agent dirty (13 MB at 65 536 agents).  With plain stores those lines sit in the XCD L2s until the
+// end-of-kernel release writes them back, which the NEXT launch waits for (MI355X_MICROARCH.md "boundary": + B / 6 TB/s when
+// the predecessor leaves B bytes dirty); write-through stores (sc1) push them out while the other waves still compute.
+// VF_STORE_MODE: 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1 -- A/B knob of tools/env_step_probe.hip.
+#ifndef VF_STORE_MODE
+#define VF_STORE_MODE 0
+#endif
+typedef float vf_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4(float4* p, const float4 v)
+{
+#if VF_STORE_MODE != 0
+    const vf_f4 x = {v.x, v.y, v.z, v.w};
+#endif
+#if VF_STORE_MODE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+#elif VF_STORE_MODE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
+#elif VF_STORE_MODE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st1(float* p, const float v)
+{
+#if VF_STORE_MODE == 1
+    asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#elif VF_STORE_MODE == 2
+    asm volatile("global_store_dword %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+#elif VF_STORE_MODE == 3
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+
 // ---- slab I/O: wave-tile AoSoA, one 16-byte granule per lane per access ----
 // float4 address of (agent i, granule g): see include/visfly_amd.h
 __device__ __forceinline__ float4* granule(float* __restrict__ S, int G, int i, int g)
@@ -461,14 +498,14 @@ __device__ __forceinline__ void load_agent(float* __restrict__ S, int G, int i, 
 
 __device__ __forceinline__ void store_agent(float* __restrict__ S, int G, int i, const Agent& s, const Spares& sp)
 {
-    *granule(S, G, i, VF_G_POS) = make_float4(s.t, s.p[0], s.p[1], s.p[2]);
-    *granule(S, G, i, VF_G_QUAT) = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
-    *granule(S, G, i, VF_G_VEL) = make_float4(sp.vel, s.v[0], s.v[1], s.v[2]);
-    *granule(S, G, i, VF_G_OMG) = make_float4(sp.omg, s.w[0], s.w[1], s.w[2]);
-    *granule(S, G, i, VF_G_MOT) = make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]);
-    *granule(S, G, i, VF_G_THR) = make_float4(s.T[0], s.T[1], s.T[2], s.T[3]);
-    *granule(S, G, i, VF_G_AACC) = make_float4(sp.aacc, s.aa[0], s.aa[1], s.aa[2]);
-    *granule(S, G, i, VF_G_ACC) = make_float4(sp.acc, s.acc[0], s.acc[1], s.acc[2]);
+    st4(granule(S, G, i, VF_G_POS), make_float4(s.t, s.p[0], s.p[1], s.p[2]));
+    st4(granule(S, G, i, VF_G_QUAT), make_float4(s.q.w, s.q.x, s.q.y, s.q.z));
+    st4(granule(S, G, i, VF_G_VEL), make_float4(sp.vel, s.v[0], s.v[1], s.v[2]));
+    st4(granule(S, G, i, VF_G_OMG), make_float4(sp.omg, s.w[0], s.w[1], s.w[2]));
+    st4(granule(S, G, i, VF_G_MOT), make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]));
+    st4(granule(S, G, i, VF_G_THR), make_float4(s.T[0], s.T[1], s.T[2], s.T[3]));
+    st4(granule(S, G, i, VF_G_AACC), make_float4(sp.aacc, s.aa[0], s.aa[1], s.aa[2]));
+    st4(granule(S, G, i, VF_G_ACC), make_float4(sp.acc, s.acc[0], s.acc[1], s.acc[2]));
 }
 
 struct DynArgs {
@@ -478,24 +515,24 @@ struct DynArgs {
     float* S;   // slab
     const float4* action;  // (N,4)
     float* obs;            // (N,13) or null
+    int head;              // delay-ring slot of this launch (= every agent's head word; vf_handles.hpp)
 };
 
-// Pops the oldest action of agent i from its ring slot and pushes the new one
-// (dynamics.py:323-328).  The ring head is per agent and lives in the spare component of
-// the velocity granule (bit pattern of a small int), so the launch needs no cross-block
-// state and replays from a hipGraph unchanged; a reset zeroes all slots, after which any
-// head position is equivalent.
+// Pops the oldest action of agent i from its ring slot and pushes the new one (dynamics.py:323-328).  The slot index is
+// launch-uniform (g.head = control steps since the last full reset mod delay_steps, kept by the host handle): the address is
+// known before any state arrives, so the slot load travels with the first burst instead of waiting for the velocity
+// granule.  The per-agent head word in that granule's spare component is still advanced -- the adjoint kernel reads it
+// from its tape -- and a reset zeroes all slots, after which any head position is equivalent.
 __device__ __forceinline__ void ring_exchange(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, float& head_bits,
                                               float* a)
 {
     float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) an = g.action[i];
     if (c.delay_steps > 0) {
-        int head = __float_as_int(head_bits);
-        head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
+        const int head = g.head;
         float4* slot = granule(g.S, g.G, i, VF_G_RING + head);
         const float4 old = *slot;
-        *slot = an;
+        st4(slot, an);
         an = old;
         head_bits = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
     }
@@ -536,12 +573,24 @@ __device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, in
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     const int rows_here = min(64, N - wave_first);
-    const int total = rows_here * C;
     float* dst = out + (size_t)wave_first * C;
+    // a full wave's 64 rows are 64 * C contiguous floats starting at a 16-byte boundary (64 * C * 4 B per wave): stream them
+    // out as 16-byte stores -- C dwordx4 per 4 lanes instead of C dword stores per lane (the tail of the launch is bound by
+    // the number of store instructions, not by their bytes)
+    if (rows_here == 64 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        constexpr int Q = 16 * C;   // float4 per wave
+#pragma unroll
+        for (int k = 0; k < (Q + 63) / 64; ++k) {
+            const int j = k * 64 + l;
+            if (j < Q) st4(reinterpret_cast<float4*>(dst) + j, *reinterpret_cast<const float4*>(tile + 4 * j));
+        }
+        return;
+    }
+    const int total = rows_here * C;
 #pragma unroll
     for (int k = 0; k < C; ++k) {
         const int j = k * 64 + l;
-        if (j < total) dst[j] = tile[j];
+        if (j < total) st1(dst + j, tile[j]);
     }
 }
 
@@ -550,7 +599,7 @@ __device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, in
 // 2.5 with four waves per SIMD).  Rotation (motors -> torque -> q, w) never reads the translational
 // state, so a 128-thread workgroup runs the two recurrences of the SAME 64 agents on two waves, the
 // translation wave one hand-off behind: per sub-step the rotation wave publishes (q, F) through LDS.
-struct SplitShared {
+struct __attribute__((aligned(16))) SplitShared {
     float xq[2][5][64];   // double-buffered (q.w, q.x, q.y, q.z, F) of the sub-step start
     float fin[20][64];    // final q, w, wm, T, aa + the two env spares the rotation wave loaded
     float tile[64 * 13];  // observation transpose of the translation wave
@@ -570,7 +619,7 @@ __device__ __forceinline__ void split_rotation_wave(const vf_dyn_cfg& c, const D
     const float4 g1 = *granule(g.S, g.G, i, VF_G_QUAT), g3 = *granule(g.S, g.G, i, VF_G_OMG);
     const float4 g4 = *granule(g.S, g.G, i, VF_G_MOT), g5 = *granule(g.S, g.G, i, VF_G_THR);
     const float4 g6 = *granule(g.S, g.G, i, VF_G_AACC);
-    float head_bits = granule(g.S, g.G, i, VF_G_VEL)->x;
+    float head_bits = 0.0f;   // out-parameter only: the translation wave owns the head word
     Agent s;
     s.q = Quat{g1.x, g1.y, g1.z, g1.w};
     s.w[0] = g3.y; s.w[1] = g3.z; s.w[2] = g3.w;
@@ -617,11 +666,8 @@ __device__ __forceinline__ void split_translation_wave(const vf_dyn_cfg& c, cons
     s.acc[0] = g7.y; s.acc[1] = g7.z; s.acc[2] = g7.w;
     sp.acc = g7.x;
     sp.vel = g2.x;
-    if (c.delay_steps > 0) {  // same head update ring_exchange applies (the rotation wave did the exchange itself)
-        int head = __float_as_int(g2.x);
-        head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
-        sp.vel = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
-    }
+    if (c.delay_steps > 0)    // same head update ring_exchange applies (the rotation wave did the exchange itself)
+        sp.vel = __int_as_float(g.head + 1 == c.delay_steps ? 0 : g.head + 1);
     for (int sub = 0; sub < c.interval_steps; ++sub) {
         __builtin_amdgcn_s_barrier();
         const float(*x)[64] = sh.xq[sub & 1];

@@ -105,7 +105,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     obs_row(c, s, o);
     obs_variant(e, o);
     if (live) {
-        g.out.reward[i] = reward;
+        st1(g.out.reward + i, reward);
         g.out.done[i] = done ? 1 : 0;
         if (done) {  // collect_info (:238-275)
             if (g.out.ep_return) g.out.ep_return[i] = er.rewards;
@@ -167,14 +167,15 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
 __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g)
 {
-    __shared__ float tile[kBlock * 13];
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.d.N;
     Agent s;
     Spares sp;
+    float a[4], head_bits = 0.0f;
+    ring_exchange(c, g.d, i, live, head_bits, a);   // issued first: its two loads are the first values the controller needs
     load_agent<false>(g.d.S, g.d.G, i, s, sp);
-    float a[4];
-    ring_exchange(c, g.d, i, live, sp.vel, a);
+    if (c.delay_steps > 0) sp.vel = head_bits;
     float kl[3], kq[3];
     drag_of(c, g.d, i, kl, kq);
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const v
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
 __global__ __launch_bounds__(kBlock) void k_env_step_split(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g)
 {
-    __shared__ SplitShared shs[2];
+    __shared__ __attribute__((aligned(16))) SplitShared shs[2];
     const int grp = (threadIdx.x >> 6) & 1;
     SplitShared& sh = shs[grp];
     const int first = blockIdx.x * 128 + grp * 64;
@@ -313,7 +314,9 @@ __global__ __launch_bounds__(kBlock) void k_env_export_pose(const vf_dyn_cfg c, 
 struct vf_env_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    vf_env* env = nullptr;
     int K = 0;
+    int phase = 0;   // delay-ring slot of the first captured launch (baked into the kernel arguments)
 };
 
 namespace {
@@ -378,14 +381,16 @@ EnvKernel pick_env_kernel(const vf_env* h)
     }
 }
 
-vf::DynArgs dyn_args(const vf_env* h, const float* action, float* obs)
+vf::DynArgs dyn_args(const vf_env* h, const float* action, float* obs, int ahead = 0)
 {
-    return vf::DynArgs{h->dyn.N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(action), obs};
+    return vf::DynArgs{h->dyn.N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(action), obs,
+                       vf::ring_head(&h->dyn, ahead)};
 }
 
-int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int auto_reset, hipStream_t st)
+// `ahead`: position of this launch in a sequence enqueued (or captured) before the handle's step counter advances
+int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int auto_reset, hipStream_t st, int ahead = 0)
 {
-    vf::EnvArgs g{dyn_args(h, action, out->obs), *out, h->g_race, auto_reset};
+    vf::EnvArgs g{dyn_args(h, action, out->obs, ahead), *out, h->g_race, auto_reset};
     if (vf::use_split(h->dyn.Npad, h->dyn.cfg))
         hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);
     else
@@ -437,6 +442,7 @@ int vf_env_reset(vf_env* h, const int32_t* idx, int32_t k, const float* full_sta
     const int n = idx ? k : h->dyn.Npad;
     if (n < 0) return vf::fail(VF_EINVAL, "vf_env_reset: k < 0");
     if (n == 0) return VF_OK;
+    if (!idx) h->dyn.tick = 0;   // full reset: head words go to 0 (k_env_reset) and so does the launch-uniform phase
     vf::EnvResetArgs r{dyn_args(h, nullptr, nullptr), n, h->g_race, idx, full_state};
     hipStream_t st = vf::as_stream(stream);
     const dim3 grid(vf::blocks_for(n)), block(vf::kBlock);
@@ -454,7 +460,9 @@ int vf_env_step(vf_env* h, const float* action, const vf_env_out* out, int32_t a
     if (!h || !action || !out) return vf::fail(VF_EINVAL, "vf_env_step: null argument");
     if (!out->obs || !out->reward || !out->done) return vf::fail(VF_EINVAL, "vf_env_step: obs, reward and done outputs are required");
     if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_step: vf_env_bind has not been called");
-    return launch_env_step(h, action, out, auto_reset, vf::as_stream(stream));
+    if (int rc = launch_env_step(h, action, out, auto_reset, vf::as_stream(stream))) return rc;
+    h->dyn.tick += 1;
+    return VF_OK;
 }
 
 namespace {
@@ -477,7 +485,7 @@ int enqueue_rollout(vf_env* h, const vf_env_rollout* r, hipStream_t st)
     vf_env_out o = r->out;
     const float* a = r->actions;
     for (int k = 0; k < r->K; ++k) {
-        if (int rc = launch_env_step(h, a, &o, r->auto_reset, st)) return rc;
+        if (int rc = launch_env_step(h, a, &o, r->auto_reset, st, k)) return rc;
         a += r->action_stride;
         o.obs += r->obs_stride;
         o.reward += r->reward_stride;
@@ -491,8 +499,12 @@ int enqueue_rollout(vf_env* h, const vf_env_rollout* r, hipStream_t st)
 int vf_env_step_n(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
 {
     if (int rc = check_rollout(h, r, "vf_env_step_n")) return rc;
-    return enqueue_rollout(h, r, vf::as_stream(stream));
+    if (int rc = enqueue_rollout(h, r, vf::as_stream(stream))) return rc;
+    h->dyn.tick += r->K;
+    return VF_OK;
 }
+
+int32_t vf_env_ring_phase(const vf_env* h) { return h ? vf::ring_head(&h->dyn) : 0; }
 
 int vf_env_graph_create(vf_env* h, const vf_env_rollout* r, vf_env_graph** out)
 {
@@ -502,6 +514,8 @@ int vf_env_graph_create(vf_env* h, const vf_env_rollout* r, vf_env_graph** out)
     VF_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     vf_env_graph* g = new vf_env_graph;
     g->K = r->K;
+    g->env = h;
+    g->phase = vf::ring_head(&h->dyn);
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
     int rc = VF_OK;
     if (e == hipSuccess) {
@@ -523,7 +537,11 @@ int vf_env_graph_create(vf_env* h, const vf_env_rollout* r, vf_env_graph** out)
 int vf_env_graph_launch(vf_env_graph* g, vf_stream_t stream)
 {
     if (!g || !g->exec) return vf::fail(VF_EINVAL, "vf_env_graph_launch: null graph");
+    if (vf::ring_head(&g->env->dyn) != g->phase)
+        return vf::fail(VF_ESTATE, "vf_env_graph_launch: the graph was captured at delay-ring phase %d, the env is at phase %d "
+                                   "(vf_env_ring_phase): capture one graph per phase", g->phase, vf::ring_head(&g->env->dyn));
     VF_HIP(hipGraphLaunch(g->exec, vf::as_stream(stream)));
+    g->env->dyn.tick += g->K;
     return VF_OK;
 }
 
@@ -570,6 +588,7 @@ int vf_env_time_steps(vf_env* h, const float* action, const vf_env_out* out, int
     for (int it = 0; it < iters; ++it) {
         int rc = launch_env_step(h, action, out, auto_reset, st);
         if (rc != VF_OK) return rc;
+        h->dyn.tick += 1;
     }
     VF_HIP(hipEventRecord(e1, st));
     VF_HIP(hipEventSynchronize(e1));

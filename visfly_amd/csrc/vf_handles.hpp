@@ -6,6 +6,11 @@ struct vf_dyn {
     vf_dyn_cfg cfg;
     int N, Npad, G, g_drag, g_extra;  // g_extra: first granule after the dynamics ones (env layer)
     float* S = nullptr;
+    // control steps since the last full reset.  Every agent's delay-ring head equals tick % delay_steps (all agents push
+    // once per step; an indexed reset zeroes the agent's slots, after which the head position is immaterial), so the step
+    // kernels take the slot index from the launch arguments -- the ring-slot load no longer waits for the velocity granule
+    // that carries the per-agent copy (still written: the adjoint kernel reads it from its tape).
+    long long tick = 0;
 };
 
 struct vf_env {
@@ -39,6 +44,13 @@ inline void init_dyn_handle(vf_dyn* h, const vf_dyn_cfg* cfg, int N, int per_age
     h->g_extra = VF_G_FIXED + cfg->delay_steps + (per_agent_drag ? 2 : 0);
     h->G = h->g_extra + extra;
     h->S = nullptr;
+    h->tick = 0;
+}
+
+// ring slot of the step that is `ahead` launches after the next one
+inline int ring_head(const vf_dyn* h, int ahead = 0)
+{
+    return h->cfg.delay_steps > 0 ? (int)((h->tick + ahead) % h->cfg.delay_steps) : 0;
 }
 
 }  // namespace vf

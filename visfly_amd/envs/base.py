@@ -636,7 +636,7 @@ class DroneGymEnvsBase:
         r.actions, r.auto_reset = a.data_ptr(), 0 if is_test else 1
         L = _lib.lib()
         if graph:
-            key = (a.data_ptr(), r.auto_reset)
+            key = (a.data_ptr(), r.auto_reset, int(L.vf_env_ring_phase(self._h)))   # one graph per delay-ring phase
             g = ro["graphs"].get(key)
             if g is None:
                 g = _lib._vp()
