@@ -305,6 +305,19 @@ def main():
         events.append(e0.elapsed_time(e1) * 1e-3)
     el = statistics.median(walls)
 
+    # open-loop rollout in ONE launch (vf_env_rollout_fused: agents stay in registers between the steps; same outputs bit for bit).
+    # NOT the headline: a policy in the loop needs one launch per step; reported as a separate figure
+    fused_walls = []
+    run_fused = lambda: [env.step_n(seq[:min(K - d, seq.shape[0])], fused=True) for d in range(0, K, seq.shape[0])]
+    run_fused()
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        run_fused()
+        barrier()
+        fused_walls.append(time.perf_counter() - t0)
+    fused_el = statistics.median(fused_walls)
+
     # the reference-style driver for comparison: one Python env.step() call per step (zero-allocation output ring)
     for k in range(min(W, 50)):
         env.step(pool[k % 16])
@@ -359,6 +372,10 @@ def main():
                        "host_us_per_step": statistics.median(hosts) / K * 1e6,
                        "event_us_per_step": statistics.median(events) / K * 1e6,
                        "wall_over_kernel": el / K * 1e6 / kern_us, "per_call": per_call},
+            "rollout_fused": {"value": world * N * K / fused_el, "unit": "agent-steps/s", "us_per_step": fused_el / K * 1e6,
+                              "driver": "env.step_n(fused=True): the K steps of the region in ONE launch (vf_env_rollout_fused), agents "
+                                        "held in registers between the steps; open-loop only (actions known up front), bit-identical "
+                                        "outputs (tests/test_env_multistep_gpu.py); per rank, not max-reduced over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_env_step<hover,bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,

@@ -254,6 +254,14 @@ typedef struct vf_env_rollout {
 } vf_env_rollout;
 int vf_env_step_n(vf_env* h, const vf_env_rollout* r, vf_stream_t stream);
 
+/* The same K steps in ONE launch: every thread keeps its agent in registers from step to step (the state slab is read once
+ * before step 0 and written once after step K-1; per step only the action row is read and obs / reward / done / episode
+ * outputs are written), which removes K-1 launch boundaries and 2(K-1) state round trips.  Results are bit-identical to K
+ * vf_env_step calls, auto-resets included.  Open-loop use (the actions of all K steps exist up front: evaluation with a
+ * fixed sequence, sampling-based planners, system identification); a policy in the loop needs vf_env_step.
+ * action_stride must be a multiple of 4 floats. */
+int vf_env_rollout_fused(vf_env* h, const vf_env_rollout* r, vf_stream_t stream);
+
 /* The same K launches captured once into a hipGraph and replayed with one hipGraphLaunch per rollout.  The rollout's
  * pointers and the delay-ring slot of every captured launch are baked into the graph: the caller keeps those buffers alive,
  * refills `actions` between replays, and replays a graph only at the ring phase it was captured at (vf_env_ring_phase ==

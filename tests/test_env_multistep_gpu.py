@@ -62,6 +62,52 @@ def test_step_n_equals_k_steps(cls_name, N):
     same(env._slab, ref._slab, "slab after the second rollout")
 
 
+@pytest.mark.parametrize("cls_name,N", [("HoverEnv", 1000), ("NavigationEnv", 4099), ("RacingEnv", 777), ("HoverEnv", 70000)])
+def test_fused_rollout_equals_k_steps(cls_name, N):
+    """vf_env_rollout_fused: K steps inside one launch, agents held in registers between the steps -- bit-identical to K
+    step() calls through auto-resets (ring / racing / spawn state goes through memory inside the launch), for row counts
+    whose per-step output rows are and are not 16-byte aligned, and a second rollout continues where per-step calls would"""
+    K = 40
+    A = actions(N, K)
+    ref, env = make(cls_name, N), make(cls_name, N)
+    outs = [ref.step(A[k]) for k in range(K)]
+    obs, reward, done = env.step_n(A, fused=True)
+    assert bool(done.any())
+    for k in range(K):
+        same(obs[k], outs[k][0]["state"], f"obs @ {k}")
+        same(reward[k], outs[k][1], f"reward @ {k}")
+        same(done[k], outs[k][2], f"done @ {k}")
+    same(env._slab, ref._slab, "slab after the fused rollout")
+    same(env._ep_return, ref._ep_return, "episode returns")
+    same(env._terminal_obs, ref._terminal_obs, "terminal observations")
+    if cls_name == "RacingEnv":
+        same(env.get_observation()["gate"], outs[-1][0]["gate"], "gate observation")
+    B = actions(N, 7, seed=1)
+    outs2 = [ref.step(B[k]) for k in range(7)]
+    obs2, _, _ = env.step_n(B, fused=True)
+    same(obs2[6], outs2[-1][0]["state"], "second fused rollout")
+    x = actions(N, 1, seed=2)[0]
+    same(env.step(x)[0]["state"], ref.step(x)[0]["state"], "step() after fused rollouts (ring phase, counters)")
+    same(env._slab, ref._slab, "slab")
+
+
+def test_fused_rollout_rk4_drag_randomisation():
+    import visfly_amd.envs as E
+    N, K = 2048, 30
+    dyn = dict(DYN, integrator="rk4", drag_random=0.1)
+    mk = lambda: E.NavigationEnv(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(dyn), device="cuda:0", tensor_output=True,
+                                 max_episode_steps=9)
+    ref, env = mk(), mk()
+    ref.reset(), env.reset()
+    A = actions(N, K)
+    outs = [ref.step(A[k]) for k in range(K)]
+    obs, reward, done = env.step_n(A, fused=True)
+    for k in range(K):
+        same(obs[k], outs[k][0]["state"], f"obs @ {k}")
+        same(reward[k], outs[k][1], f"reward @ {k}")
+    same(env._slab, ref._slab, "slab (re-drawn per-agent drag granules included)")
+
+
 def test_step_n_is_test_keeps_done_agents():
     N, K = 512, 30
     A = actions(N, K)

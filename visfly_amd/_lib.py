@@ -205,6 +205,7 @@ SIGNATURES = {
     "vf_env_step": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, _vp]),
     "vf_env_step_n": (C.c_int, [_vp, C.POINTER(EnvRollout), _vp]),
     "vf_env_ring_phase": (C.c_int32, [_vp]),
+    "vf_env_rollout_fused": (C.c_int, [_vp, C.POINTER(EnvRollout), _vp]),
     "vf_env_graph_create": (C.c_int, [_vp, C.POINTER(EnvRollout), C.POINTER(_vp)]),
     "vf_env_graph_launch": (C.c_int, [_vp, _vp]),
     "vf_env_graph_destroy": (None, [_vp]),

@@ -19,6 +19,10 @@ struct EnvArgs {
     vf_env_out out;
     int g_race;
     int auto_reset;
+    // K consecutive steps inside ONE launch (vf_env_rollout_fused): the agent stays in registers from step to step, only the
+    // per-step action is read and the per-step outputs are written; strides in elements between consecutive steps
+    int K = 1;
+    long long action_stride = 0, obs_stride = 0, reward_stride = 0, done_stride = 0;
 };
 
 // env counters <-> spare slots
@@ -53,7 +57,7 @@ __device__ __forceinline__ int collision_flags(int flags, const Collision& col)
 // Everything of DroneGymEnvsBase.step that follows the dynamics interval, for ONE agent held in
 // registers: bbox collision, counters, success / reward, done masks, episode outputs, auto-reset,
 // stores (envs/base/droneGymEnv.py:161-218,339-423; envs/base/droneEnv.py:345-371).
-template <int KIND>
+template <int KIND, bool STORE_STATE = true>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile)
 {
@@ -160,7 +164,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         if (live && g.out.gate) g.out.gate[i] = gate;
     }
     pack_env(er, sp);
-    store_agent(g.d.S, g.d.G, i, s, sp);
+    if constexpr (STORE_STATE) store_agent(g.d.S, g.d.G, i, s, sp);
     store_rows_coalesced<13>(g.out.obs, g.d.N, wave_first, o, tile);
 }
 
@@ -181,6 +185,41 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const v
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
     const int wave = threadIdx.x >> 6;
     env_epilogue<KIND>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+}
+
+// K consecutive steps in one launch: see vf_env_rollout_fused (include/visfly_amd.h)
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(kBlock) void k_env_rollout(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g0)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
+    EnvArgs g = g0;
+    const bool live = i < g.d.N;
+    Agent s;
+    Spares sp;
+    float a[4], head_bits = 0.0f;
+    ring_exchange(c, g.d, i, live, head_bits, a);   // issued first: its two loads are the first values the controller needs
+    load_agent<false>(g.d.S, g.d.G, i, s, sp);
+    // one launch = K control steps (vf_env_rollout_fused; a separate kernel from k_env_step: the loop-carried pointers cost the
+    // single step ~1 us of register pressure / scheduling when both shared one body).  The agent lives in registers
+    // across the steps; the delay ring, per-agent drag and racing granules go through memory as in the single step (a thread
+    // sees its own earlier stores), so a reset inside the rollout behaves exactly as between two launches
+    for (int k = 0;;) {
+        if (c.delay_steps > 0) sp.vel = head_bits;
+        float kl[3], kq[3];
+        drag_of(c, g.d, i, kl, kq);
+        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
+        env_epilogue<KIND, false>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+        if (++k >= g.K) break;
+        g.d.action += g.action_stride;            // float4 units
+        g.out.obs += g.obs_stride;
+        g.out.reward += g.reward_stride;
+        g.out.done += g.done_stride;
+        g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
+        ring_exchange(c, g.d, i, live, head_bits, a);
+    }
+    store_agent(g.d.S, g.d.G, i, s, sp);
 }
 
 // Two-wave variant (SplitShared in vf_dyn_device.hpp): 256-thread workgroups = 2 rotation + 2 translation
@@ -346,6 +385,38 @@ EnvKernel pick_env_kernel_k(const vf_dyn_cfg& c)
     }
 }
 
+template <int KIND, int ACT>
+EnvKernel pick_env_rollout_ka(const vf_dyn_cfg& c)
+{
+    const int key = (c.integrator == VF_INT_RK4 ? 2 : 0) | (c.ctrl_delay ? 1 : 0);
+    switch (key) {
+    case 0: return vf::k_env_rollout<KIND, ACT, VF_INT_EULER, false>;
+    case 1: return vf::k_env_rollout<KIND, ACT, VF_INT_EULER, true>;
+    case 2: return vf::k_env_rollout<KIND, ACT, VF_INT_RK4, false>;
+    default: return vf::k_env_rollout<KIND, ACT, VF_INT_RK4, true>;
+    }
+}
+
+template <int KIND>
+EnvKernel pick_env_rollout_k(const vf_dyn_cfg& c)
+{
+    switch (c.action_type) {
+    case VF_ACT_THRUST: return pick_env_rollout_ka<KIND, VF_ACT_THRUST>(c);
+    case VF_ACT_BODYRATE: return pick_env_rollout_ka<KIND, VF_ACT_BODYRATE>(c);
+    case VF_ACT_VELOCITY: return pick_env_rollout_ka<KIND, VF_ACT_VELOCITY>(c);
+    default: return pick_env_rollout_ka<KIND, VF_ACT_POSITION>(c);
+    }
+}
+
+EnvKernel pick_env_rollout(const vf_env* h)
+{
+    switch (h->cfg.kind) {
+    case VF_ENV_HOVER: return pick_env_rollout_k<VF_ENV_HOVER>(h->dyn.cfg);
+    case VF_ENV_NAV: return pick_env_rollout_k<VF_ENV_NAV>(h->dyn.cfg);
+    default: return pick_env_rollout_k<VF_ENV_RACING>(h->dyn.cfg);
+    }
+}
+
 template <int KIND>
 EnvKernel pick_env_split_k(const vf_dyn_cfg& c)
 {
@@ -505,6 +576,22 @@ int vf_env_step_n(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
 }
 
 int32_t vf_env_ring_phase(const vf_env* h) { return h ? vf::ring_head(&h->dyn) : 0; }
+
+int vf_env_rollout_fused(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
+{
+    if (int rc = check_rollout(h, r, "vf_env_rollout_fused")) return rc;
+    if (r->action_stride % 4) return vf::fail(VF_EINVAL, "vf_env_rollout_fused: action_stride must be a multiple of 4 floats");
+    vf::EnvArgs g{dyn_args(h, r->actions, r->out.obs), r->out, h->g_race, r->auto_reset};
+    g.K = r->K;
+    g.action_stride = r->action_stride / 4;
+    g.obs_stride = r->obs_stride;
+    g.reward_stride = r->reward_stride;
+    g.done_stride = r->done_stride;
+    hipLaunchKernelGGL(pick_env_rollout(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, vf::as_stream(stream), h->dyn.cfg, h->cfg, g);
+    VF_HIP(hipGetLastError());
+    h->dyn.tick += r->K;
+    return VF_OK;
+}
 
 int vf_env_graph_create(vf_env* h, const vf_env_rollout* r, vf_env_graph** out)
 {

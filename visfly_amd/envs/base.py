@@ -598,13 +598,15 @@ class DroneGymEnvsBase:
         return self._format_obs(obs), reward.cpu().numpy(), done.cpu().numpy().astype(np.int32), info   # :218
 
     # ------------------------------------------------------------------ multi-step launch (open-loop action sequences)
-    def step_n(self, actions, is_test=False, graph=False):
+    def step_n(self, actions, is_test=False, graph=False, fused=False):
         """K consecutive step() calls with the launch loop in C (vf_env_step_n): `actions` is a (K,N,4) device tensor.
         Returns (obs (K,N,13), reward (K,N), done (K,N)) -- row k is what the k-th step()
         would have returned (obs after auto-reset, reward / done before); bit-identical to K step() calls.  The output
         buffers are cached per K and re-used by the next step_n call of the same K.  graph=True replays the K launches from
         a hipGraph captured on the first call for this (K, actions buffer): the caller refills that SAME actions tensor
-        between calls.  The reference has no counterpart (its loop is `for a in seq: env.step(a)`, e.g.
+        between calls.  fused=True runs the K steps inside ONE launch with the agents held in registers between the steps
+        (vf_env_rollout_fused: no per-step launch boundary, no per-step state round trip; same results).  The reference has
+        no counterpart (its loop is `for a in seq: env.step(a)`, e.g.
         utils/evaluate.py:62-103); not available in replay-spawn mode or while a BPTT tape is recording."""
         assert self._is_initial, "You should call reset() before step()"
         if self.spawn_mode == "replay":
@@ -644,6 +646,8 @@ class DroneGymEnvsBase:
                 ro["graphs"][key] = g
                 ro.setdefault("keep", []).append(a)          # the graph holds this buffer's address
             rc = L.vf_env_graph_launch(g, _raw_stream(dev.index))
+        elif fused:
+            rc = L.vf_env_rollout_fused(self._h, ro["ref"], _raw_stream(dev.index))
         else:
             rc = L.vf_env_step_n(self._h, ro["ref"], _raw_stream(dev.index))
         if rc:
