@@ -341,18 +341,21 @@ def main():
         achieved = BYTES_PER_ENV_STEP * N / (kern_us * 1e-6) / 1e9
         traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (per-agent figure x N)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             traffic = (pmc["fetch_bytes_per_agent"] + pmc["write_bytes_per_agent"]) * N
         except Exception:
             pass
-        valu = None      # second roofline: fp32 VALU issue, from the PMC instruction count committed under profiles/
+        # the unit that is actually busy: fp32 VALU ISSUE of a single wave per SIMD.  Instruction count per wave
+        # from the PMC pass committed under profiles/, 4.1 cycles per wave64 VALU instruction for a lone wave
+        # (profiles/r02_valu_cost_probe.txt), 2.4 GHz.  Reported next to the HBM roofline the contract asks for.
+        valu = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_env_sq.json")))
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_env_sq.json")))["k_env_step"]
             per_wave = sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]
             waves_per_simd = -(-(-(-N // 64)) // 1024)                 # ceil(waves / (256 CUs x 4 SIMDs))
-            floor_us = waves_per_simd * per_wave * 4 / 2.4e3          # 4 cycles per wave64 VALU instruction at 2.4 GHz
-            valu = {"valu_instr_per_wave": per_wave, "waves_per_simd": waves_per_simd, "floor_us": floor_us,
-                    "frac": floor_us / kern_us}
+            floor_us = waves_per_simd * per_wave * 4.1 / 2.4e3
+            valu = {"valu_instr_per_wave": per_wave, "waves_per_simd": waves_per_simd, "cycles_per_instr_single_wave": 4.1,
+                    "floor_us": floor_us, "frac": floor_us / kern_us}
         except Exception:
             pass
         out = {
@@ -379,7 +382,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_env_step<hover,bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
-                         "bytes_per_agent_step": BYTES_PER_ENV_STEP, "valu": valu,
+                         "bytes_per_agent_step": BYTES_PER_ENV_STEP, "valu_issue": valu,
+                         "note": "bound by the contract's definition (algorithmic HBM bytes / launch time); the launch is in fact "
+                                 "limited by single-wave VALU issue (valu_issue) plus ~4 us of launch boundary and state round "
+                                 "trip per step -- profiles/r02_env_step_ablation.txt, DESIGN.md 4",
                          "dyn_only": {"kernel": "k_dyn_step<bodyrate,euler,ctrl_delay>", "kernel_us": dyn_us,
                                       "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
                                       "achieved": BYTES_PER_AGENT_STEP * N / (dyn_us * 1e-6) / 1e9}},

@@ -1,4 +1,6 @@
-"""SHAC as the reference runs it (utils/algorithms/shac.py:215-278): a short-horizon first-order actor update through
+"""EXPERIMENTAL (parity unpinned, network shapes NOT the reference's -- see "Parity status" below).
+
+SHAC as the reference runs it (utils/algorithms/shac.py:215-278): a short-horizon first-order actor update through
 the differentiable simulator plus twin Q critics regressed onto TD-lambda returns.
 
 What the reference's ``learn`` loop does per iteration, and where each piece runs here:
@@ -17,7 +19,10 @@ Parity status: UNPINNED -- the reference's SHAC needs stable-baselines3 (SACPoli
 importable in the build container, so no golden vectors exist for the loop itself.  Network shapes differ from SB3's
 where the MFMA kernels' layer model requires it: the actor keeps a state-independent log_std (SB3's Actor has a
 log_std head), and each Q network is an ``MlpPolicy`` value trunk over the concatenated (observation, action) row
-instead of SB3's shared features extractor followed by a Q MLP.
+instead of SB3's features extractor -> concat(features, action) -> Q MLP (utils/policies/td_policies.py:146-252; it would
+need an identity extractor branch for the action columns, which the fused MLP layer tables do not have).  What IS pinned:
+the actor gradient (= the BPTT reverse sweep, gradient fixtures from the reference's autograd) and ``vf_td_returns``
+(bit-identical to the reference's compute_td_returns).  Treat learning curves from this class as indicative only.
 """
 import ctypes as C
 from typing import Optional
