@@ -138,11 +138,31 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
     roof = {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
             "kernel": "optimiser step: k_ppo_update_chain + k_mlp_wgrad + fold + Adam", "us_per_update": us_upd,
             "rows": rows, "note": "fp32 v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)"}
+    # the one exchange step of the path, timed on its own: 50 all-reduces of the gradient + statistics buffer on this stream
+    # (vf_allreduce_grads on the nccl backend), as a share of the optimiser steps of one iteration
+    exchange = None
+    if world > 1:
+        ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        scratch = torch.zeros_like(ppo._gbuf)
+        parallel.allreduce_sum_(scratch)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        ev2[0].record()
+        for _ in range(50):
+            parallel.allreduce_sum_(scratch)
+        ev2[1].record()
+        torch.cuda.synchronize()
+        ar_us = parallel.max_over_ranks(ev2[0].elapsed_time(ev2[1]) * 1e3 / 50, dev)
+        exchange = {"allreduce_us": ar_us, "floats": int(scratch.numel()), "per_iteration_ms": ar_us * n_upd * 1e-3,
+                    "share_of_iteration": ar_us * n_upd * 1e-6 / (el / iters),
+                    "native_rccl": parallel.native_comm() is not None}
     out = {"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
            "value": 256 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
            "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
            "split_ms": {"collect_rollouts": ev[0].elapsed_time(ev[1]), "train": ev[1].elapsed_time(ev[2]),
-                        "optimiser_steps": n_upd},
+                        "optimiser_steps": n_upd, "note": "rank 0's device clock: env + policy rollout (no collective) vs "
+                                                            "the optimiser steps (one all-reduce each)"},
+           "exchange": exchange,
            "config": {"workload": f"NavigationEnv {N} agents/GPU, n_steps=256, batch 25600/GPU, 5 epochs "
                                   "(BASELINE configs[3] shard)",
                       "logs": {k: float(v) for k, v in ppo.logs.items()}},

@@ -17,6 +17,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef VF_SUBSTEP_UNROLL
+#define VF_SUBSTEP_UNROLL 1
+#endif
+
 namespace vf {
 
 struct Quat {
@@ -411,6 +415,15 @@ __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, 
     float Td[4], wd[4];
     desired_thrusts<ACT>(c, s, a, Td);
     rotor_setpoint<CTRL_DELAY>(c, Td, wd);
+#if VF_SUBSTEP_UNROLL == 2
+#pragma unroll 2
+#elif VF_SUBSTEP_UNROLL == 4
+#pragma unroll 4
+#elif VF_SUBSTEP_UNROLL == 8
+#pragma unroll 8
+#else
+#pragma unroll 1
+#endif
     for (int sub = 0; sub < c.interval_steps; ++sub) {
         float ft[4];
         motor_substep<CTRL_DELAY>(c, Td, wd, s.wm, s.T, ft);
