@@ -57,6 +57,59 @@ __global__ __launch_bounds__(kBlock) void k_probe(const vf_dyn_cfg c, const vf_e
     env_epilogue<VF_ENV_HOVER>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
 }
 
+// exhaustive checks of the VF_FAST_EXACT fast paths against the compiler's IEEE expansions
+__global__ void k_check_sqrt(unsigned long long* bad, unsigned* first)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= 0x7f800000ull; b += stride) {
+        const float x = __uint_as_float((unsigned)b);
+        if (!(x == 0.0f || x >= 0x1p-96f)) continue;
+        const float a = sqrt_exact_core(x), r = sqrtf(x);
+        if (__float_as_uint(a) != __float_as_uint(r)) { if (atomicAdd(bad, 1ull) == 0) *first = (unsigned)b; }
+    }
+}
+__global__ void k_check_div(float m, unsigned long long* bad, unsigned* first)
+{
+    const float y = 1.0f / m;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((unsigned)b);
+        const float ax = __builtin_fabsf(x);
+        if (!(ax >= 0x1p-100f && ax <= 0x1p100f)) continue;
+        const float a = div_const_core(x, m, y), r = x / m;
+        if (__float_as_uint(a) != __float_as_uint(r)) { if (atomicAdd(bad, 1ull) == 0) *first = (unsigned)b; }
+    }
+}
+
+void exhaustive_checks(float mass)
+{
+    unsigned long long* bad;
+    unsigned* first;
+    hipMalloc(&bad, 8);
+    hipMalloc(&first, 4);
+    auto report = [&](const char* what) {
+        unsigned long long hb = 0;
+        unsigned hf = 0;
+        hipDeviceSynchronize();
+        hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(&hf, first, 4, hipMemcpyDeviceToHost);
+        printf("exhaustive %-60s mismatches %llu%s\n", what, hb, hb ? " (first bits below)" : "");
+        if (hb) printf("    first mismatching bit pattern 0x%08x\n", hf);
+    };
+    hipMemset(bad, 0, 8);
+    k_check_sqrt<<<4096, 256>>>(bad, first);
+    report("sqrt_exact_core vs sqrtf, x = 0 and all x >= 2^-96:");
+    for (float m : {mass, 0.46f, 0.68f, 1.0f, 1.5f, 0.033f, 3.3f, 0.7500001f}) {
+        hipMemset(bad, 0, 8);
+        k_check_div<<<4096, 256>>>(m, bad, first);
+        char buf[96];
+        snprintf(buf, sizeof buf, "div_const_core vs x / m, m = %.9g, 2^-100 <= |x| <= 2^100:", m);
+        report(buf);
+    }
+    hipFree(bad);
+    hipFree(first);
+}
+
 template <int MODE>
 float time_mode(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, float* sink, int blocks, int iters)
 {
@@ -81,6 +134,8 @@ int main(int argc, char** argv)
     FILE* f = fopen(argv[1], "rb");
     if (!f || fread(&c, sizeof(c), 1, f) != 1 || fread(&e, sizeof(e), 1, f) != 1) { printf("cfg file?\n"); return 1; }
     fclose(f);
+    printf("VF_FAST_EXACT=%d VF_STORE_MODE=%d\n", VF_FAST_EXACT, VF_STORE_MODE);
+    if (argc > 2) exhaustive_checks(c.m);
     for (int N : {64, 32768, 65536, 131072, 1048576}) {
         const int G = VF_G_FIXED + c.delay_steps;
         const int blocks = (N + kBlock - 1) / kBlock;

@@ -28,3 +28,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
                                f"-DVF_STORE_MODE={mode}", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "visfly_amd", "csrc"),
                                os.path.join(ROOT, "tools", "env_step_probe.hip"), "-o", out])
         print("built", out)
+    out = os.path.join(ROOT, "tools", "env_step_probe_fast")          # VF_FAST_EXACT=1: exact fast paths for sqrt and x / m
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-w",
+                           "-DVF_FAST_EXACT=1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "visfly_amd", "csrc"),
+                           os.path.join(ROOT, "tools", "env_step_probe.hip"), "-o", out])
+    print("built", out)

@@ -20,6 +20,12 @@
 #ifndef VF_SUBSTEP_UNROLL
 #define VF_SUBSTEP_UNROLL 1
 #endif
+// 1: IEEE-exact fast paths for sqrt and for the division by the (launch-uniform) mass, each behind a wave-uniform range
+// guard; every other value of the guard takes the compiler's own expansion.  A/B knob of tools/env_step_probe.hip, which
+// also checks both fast paths exhaustively against `sqrtf` / `x / m`.
+#ifndef VF_FAST_EXACT
+#define VF_FAST_EXACT 0
+#endif
 
 namespace vf {
 
@@ -51,6 +57,41 @@ __device__ __forceinline__ Quat qmul(const Quat& a, const Quat& b)
 }
 
 __device__ __forceinline__ Quat qconj(const Quat& a) { return Quat{a.w, -a.x, -a.y, -a.z}; }
+
+// ---- exact fp32 sqrt / division by a launch-uniform constant without the compiler's range handling ----------------
+// hipcc expands sqrtf (denormals preserved) to: rescale tiny inputs by 2^32, v_sqrt_f32 (<= 1 ulp), pick among the
+// result and its two neighbours by the sign of the fma residuals, undo the rescale, patch 0 / inf -- 16 instructions, 88
+// cycles for a lone wave (tools/valu_cost_probe).  For x = 0 or x >= 2^-96 (finite or not) the rescale and the patch are
+// no-ops: sqrt_exact_core is the remaining 9 instructions and returns the same bits.
+__device__ __forceinline__ float sqrt_exact_core(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    s = ru > 0.0f ? su : s;
+    return s;
+}
+__device__ __forceinline__ float vf_sqrt(float x)
+{
+#if VF_FAST_EXACT == 2
+    return sqrt_exact_core(x);                          // measurement only: no guard
+#elif VF_FAST_EXACT
+    if (__builtin_amdgcn_ballot_w64(x < 0x1p-96f && x != 0.0f) == 0) return sqrt_exact_core(x);   // wave-uniform
+#endif
+    return sqrtf(x);
+}
+// x / m for a constant m with y = 1 / m (IEEE): twice-corrected reciprocal product.  Equal to the IEEE quotient for every
+// x with |x| in [2^-100, 2^100] (the residuals are exact there; tools/div_const_probe.hip, tools/env_step_probe.hip check all
+// 2^32 numerators); for x = 0 it returns +0 / -0 with possibly the other sign.
+__device__ __forceinline__ float div_const_core(float x, float m, float y)
+{
+    float q = x * y;
+    float e = __builtin_fmaf(-m, q, x);
+    q = __builtin_fmaf(e, y, q);
+    e = __builtin_fmaf(-m, q, x);
+    return __builtin_fmaf(e, y, q);
+}
 
 // th.clamp: min(max(v, lo), hi) with NaN passing through
 __device__ __forceinline__ float clampf(float v, float lo, float hi)
@@ -250,7 +291,7 @@ __device__ __forceinline__ void rotor_setpoint(const vf_dyn_cfg& c, const float*
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float d3 = c.rot_tm1sq - c.rot_4tm0 * (c.tm2 - Td[k]);
-            wd[k] = (c.one_minus_c) * (c.rot_scale * (c.rot_neg_tm1 + sqrtf(d3)));
+            wd[k] = (c.one_minus_c) * (c.rot_scale * (c.rot_neg_tm1 + vf_sqrt(d3)));
         }
     }
 }
@@ -290,6 +331,21 @@ __device__ __forceinline__ void linear_acc(const vf_dyn_cfg& c, const Quat& q, c
     }
     const Quat uq{0.0f, u[0], u[1], u[2]};
     const Quat ra = qmul(qmul(q, uq), qconj(q));
+#if VF_FAST_EXACT
+    {   // wave-uniform guard: every numerator is 0 or has 2^-100 <= |x| <= 2^100; the sign of a zero quotient does not
+        // survive the "+ 0.0f" / "+ g_z" below
+        const int e0 = __builtin_amdgcn_frexp_expf(ra.x), e1 = __builtin_amdgcn_frexp_expf(ra.y), e2 = __builtin_amdgcn_frexp_expf(ra.z);
+        const int emin = min(min(e0, e1), e2);
+        const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ra.x), __builtin_fabsf(ra.y)), __builtin_fabsf(ra.z));
+        if (VF_FAST_EXACT == 2 || __builtin_amdgcn_ballot_w64(!(emin >= -99 && amax <= 0x1p100f)) == 0) {
+            const float y = 1.0f / c.m;
+            acc[0] = div_const_core(ra.x, c.m, y) + 0.0f;
+            acc[1] = div_const_core(ra.y, c.m, y) + 0.0f;
+            acc[2] = div_const_core(ra.z, c.m, y) + c.g_z;
+            return;
+        }
+    }
+#endif
     acc[0] = ra.x / c.m + 0.0f;
     acc[1] = ra.y / c.m + 0.0f;
     acc[2] = ra.z / c.m + c.g_z;
@@ -387,7 +443,7 @@ __device__ __forceinline__ void rot_substep(const vf_dyn_cfg& c, const float* tq
             aa[k] = sw[k];
         }
     }
-    const float nn = sqrtf(((q.w * q.w + q.x * q.x) + q.y * q.y) + q.z * q.z);   // :367, maths.py:226-230
+    const float nn = vf_sqrt(((q.w * q.w + q.x * q.x) + q.y * q.y) + q.z * q.z);   // :367, maths.py:226-230
     q.w = q.w / nn;
     q.x = q.x / nn;
     q.y = q.y / nn;

@@ -14,11 +14,11 @@ namespace vf {
 
 __device__ __forceinline__ float norm3(float x, float y, float z)
 {
-    return sqrtf(__builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+    return vf_sqrt(__builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
 }
 __device__ __forceinline__ float norm4(float a, float b, float c, float d)
 {
-    return sqrtf(__builtin_fmaf(d, d, __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a))));
+    return vf_sqrt(__builtin_fmaf(d, d, __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a))));
 }
 __device__ __forceinline__ float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 
