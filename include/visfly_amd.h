@@ -500,6 +500,21 @@ int vf_gather_rows(const vf_gather_fields* fields, const int64_t* perm, int64_t 
 int vf_rollout_post(const float* reward, const uint8_t* done, const uint8_t* ep_flags, const float* terminal_value, float gamma,
                     float* reward_out, float* next_episode_start, int32_t N, vf_stream_t stream);
 
+/* The same bookkeeping with the bootstrap deferred to the end of the rollout: reward_out = reward, next_episode_start =
+ * float(done), and every truncated agent's flat reward index (flat_base + i, flat_base = t * N) and terminal observation
+ * row(s) (obs0 (N,w0), optional obs1 (N,w1)) are appended to a compact list through the device cursor (entries beyond
+ * `capacity` are counted but not stored: the caller checks the cursor).  After the rollout the caller evaluates the value
+ * head ONCE over the collected rows and vf_bootstrap_scatter performs rewards_flat[idx[j]] += gamma * values[j] -- the same
+ * arithmetic as vf_rollout_post, without a second policy forward per step.  episode_stat (optional, (N,4) fp32, 16-byte
+ * aligned): per-agent accumulators {episodes finished, sum of their returns, sum of their lengths, successes} advanced where
+ * done (the rollout log of PPO._dump_logs, PPO.py:392-414; replaces the per-step vf_episode_stats launch). */
+int vf_rollout_post_collect(const float* reward, const uint8_t* done, const uint8_t* ep_flags, float* reward_out,
+                            float* next_episode_start, const float* obs0, const float* obs1, int32_t w0, int32_t w1, int32_t* cursor,
+                            int32_t capacity, int32_t* idx_list, float* rows0, float* rows1, int32_t flat_base, int32_t N,
+                            const float* ep_return, const int32_t* ep_length, float* episode_stat, vf_stream_t stream);
+int vf_bootstrap_scatter(const int32_t* idx_list, const float* values, int32_t count, float gamma, float* rewards_flat,
+                         vf_stream_t stream);
+
 /* First-order policy optimisation (utils/algorithms/BPTT.py:107-129; the reparameterised squashed-Gaussian actor of
  * utils/policies/td_policies.py) with the action head fused into the chain kernels (reference-default policy shapes only;
  * VF_EUNSUPPORTED otherwise -> vf_mlp_forward + vf_reparam_fwd, vf_reparam_bwd + vf_mlp_backward_data):

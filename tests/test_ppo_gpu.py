@@ -615,3 +615,35 @@ def test_action_head_fused_into_the_chain_kernels():
     for name in ("x:state:0", "feat", "pi:0", "pi:1", "g:feat", "g:pi:1"):
         assert torch.equal(pol._buffers(M, 0)[name], pol._buffers(M, 1)[name]), name
     assert torch.equal(pol._buffers(M, 1)["obs:state"], obs["state"])       # the slot's observation copy, written by the kernel
+
+
+@pytest.mark.parametrize("env_name", ["NavigationEnv", "HoverEnv"])
+def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
+    """the TimeLimit bootstrap valued once per rollout over the compact list of truncated rows (vf_rollout_post_collect +
+    vf_bootstrap_scatter) leaves exactly the rollout buffer that the per-step second forward + vf_rollout_post leaves"""
+    import visfly_amd.envs as E
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    bufs = []
+    for defer in (True, False):
+        kw = {}
+        if env_name == "NavigationEnv":       # its default spawn box is the origin, i.e. inside the floor
+            kw["random_kwargs"] = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+        env = getattr(E, env_name)(num_agent_per_scene=3000, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=11,
+                                   tensor_output=True, **kw)
+        ppo = PPO(env, n_steps=48, batch_size=4096, n_epochs=1, seed=2)
+        ppo.defer_bootstrap = defer
+        ppo.collect_rollouts()
+        torch.cuda.synchronize()
+        if defer:
+            cnt = int(ppo._boot["cursor"].item())
+            assert 3000 * 3 <= cnt <= ppo._boot["cap"], cnt            # every agent is truncated ~4 times in 48 steps of 11-step episodes
+        bufs.append({k: getattr(ppo.buf, k).clone() for k in ("rewards", "values", "advantages", "returns", "episode_starts", "log_probs")})
+        bufs[-1]["_ep_stats"] = ppo._ep_stats.clone()
+        env.close()
+    ep0, ep1 = bufs[0].pop("_ep_stats"), bufs[1].pop("_ep_stats")          # episodes, sum of returns, sum of lengths, successes
+    assert ep0[0] == ep1[0] and ep0[2] == ep1[2] and ep0[3] == ep1[3] and ep0[0] >= 3000 * 3
+    assert torch.allclose(ep0[1], ep1[1], rtol=1e-6)                        # per-agent fp32 sums folded once vs fp64 sums per step
+    for k in bufs[0]:
+        assert torch.equal(bufs[0][k], bufs[1][k]), k
+    assert float((bufs[0]["rewards"].abs() > 0).float().mean()) > 0.5

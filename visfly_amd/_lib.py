@@ -246,6 +246,8 @@ SIGNATURES = {
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_gather_rows": (C.c_int, [C.POINTER(GatherFields), _vp, C.c_int64, _vp]),
     "vf_rollout_post": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _vp, _vp, C.c_int32, _vp]),
+    "vf_rollout_post_collect": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    "vf_bootstrap_scatter": (C.c_int, [_vp, _vp, C.c_int32, C.c_float, _vp, _vp]),
     "vf_ppo_update": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpBwdDesc)] + [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     "vf_comm_library": (C.c_int, [C.c_char_p]),

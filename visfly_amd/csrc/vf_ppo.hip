@@ -1194,6 +1194,53 @@ __global__ __launch_bounds__(kBlock) void k_rollout_post(const float* __restrict
     next_start[i] = d ? 1.0f : 0.0f;
 }
 
+// The same bookkeeping with the TimeLimit bootstrap DEFERRED: instead of evaluating V(terminal observation) for all N agents
+// at every step (a second policy forward per rollout step), the rows that need it -- done && truncated, a handful per step -- are
+// appended to a compact list (flat buffer index t * N + i and the terminal observation rows); after the rollout ONE value
+// forward over the collected rows and k_bootstrap_scatter add gamma * V to the listed rewards.  The list order depends on the
+// atomic cursor, the result does not: every entry is independent and names a distinct reward.
+__global__ __launch_bounds__(kBlock) void k_rollout_post_collect(const float* __restrict__ reward, const uint8_t* __restrict__ done,
+                                                                 const uint8_t* __restrict__ ep_flags, float* __restrict__ reward_out,
+                                                                 float* __restrict__ next_start, const float* __restrict__ obs0,
+                                                                 const float* __restrict__ obs1, int w0, int w1, int* __restrict__ cursor,
+                                                                 int capacity, int* __restrict__ idx_list, float* __restrict__ rows0,
+                                                                 float* __restrict__ rows1, int flat_base, int N,
+                                                                 const float* __restrict__ ep_return, const int* __restrict__ ep_length,
+                                                                 float* __restrict__ stat)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const bool d = done[i] != 0;
+    reward_out[i] = reward[i];
+    next_start[i] = d ? 1.0f : 0.0f;
+    if (d && stat) {   // per-agent episode statistics (PPO._dump_logs): every thread owns its agent's four accumulators, summed once per rollout
+        float4* a = reinterpret_cast<float4*>(stat) + i;
+        float4 v = *a;
+        v.x += 1.0f;
+        v.y += ep_return[i];
+        v.z += (float)ep_length[i];
+        v.w += (ep_flags[i] & VF_EP_SUCCESS) ? 1.0f : 0.0f;
+        *a = v;
+    }
+    if (d && (ep_flags[i] & VF_EP_TRUNCATED)) {
+        const int slot = atomicAdd(cursor, 1);
+        if (slot < capacity) {
+            idx_list[slot] = flat_base + i;
+            for (int k = 0; k < w0; ++k) rows0[(size_t)slot * w0 + k] = obs0[(size_t)i * w0 + k];
+            for (int k = 0; k < w1; ++k) rows1[(size_t)slot * w1 + k] = obs1[(size_t)i * w1 + k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bootstrap_scatter(const int* __restrict__ idx_list, const float* __restrict__ values,
+                                                              int count, float gamma, float* __restrict__ rewards_flat)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= count) return;
+    const int at = idx_list[j];
+    rewards_flat[at] = rewards_flat[at] + gamma * values[j];      // same rounding as reward + (gamma * tv) of k_rollout_post
+}
+
 // episode statistics of one env step for the training log (PPO._dump_logs: rollout/ep_rew_mean, ep_len_mean, success rate;
 // PPO.py:392-414): acc += {episodes finished, sum of their returns, sum of their lengths, successes}.  One block, fixed
 // reduction order, no host synchronisation in the rollout loop.
@@ -1787,6 +1834,33 @@ int vf_rollout_post(const float* reward, const uint8_t* done, const uint8_t* ep_
         return vf::fail(VF_EINVAL, "vf_rollout_post: bad argument");
     hipLaunchKernelGGL(vf::k_rollout_post, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done, ep_flags,
                        terminal_value, gamma, reward_out, next_episode_start, N);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_rollout_post_collect(const float* reward, const uint8_t* done, const uint8_t* ep_flags, float* reward_out,
+                            float* next_episode_start, const float* obs0, const float* obs1, int32_t w0, int32_t w1, int32_t* cursor,
+                            int32_t capacity, int32_t* idx_list, float* rows0, float* rows1, int32_t flat_base, int32_t N,
+                            const float* ep_return, const int32_t* ep_length, float* episode_stat, vf_stream_t stream)
+{
+    if (!reward || !done || !ep_flags || !reward_out || !next_episode_start || !obs0 || !cursor || !idx_list || !rows0 || N <= 0 ||
+        w0 <= 0 || w1 < 0 || capacity <= 0 || (w1 > 0 && (!obs1 || !rows1)) || (episode_stat && (!ep_return || !ep_length)))
+        return vf::fail(VF_EINVAL, "vf_rollout_post_collect: bad argument");
+    if (episode_stat && reinterpret_cast<uintptr_t>(episode_stat) % 16) return vf::fail(VF_EINVAL, "vf_rollout_post_collect: episode_stat must be 16-byte aligned");
+    hipLaunchKernelGGL(vf::k_rollout_post_collect, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done,
+                       ep_flags, reward_out, next_episode_start, obs0, obs1, w0, w1, cursor, capacity, idx_list, rows0, rows1, flat_base, N,
+                       ep_return, ep_length, episode_stat);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_bootstrap_scatter(const int32_t* idx_list, const float* values, int32_t count, float gamma, float* rewards_flat,
+                         vf_stream_t stream)
+{
+    if (!idx_list || !values || !rewards_flat || count < 0) return vf::fail(VF_EINVAL, "vf_bootstrap_scatter: bad argument");
+    if (count == 0) return VF_OK;
+    hipLaunchKernelGGL(vf::k_bootstrap_scatter, dim3(vf::blocks_for(count)), dim3(vf::kBlock), 0, vf::as_stream(stream), idx_list, values,
+                       count, gamma, rewards_flat);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -714,6 +714,7 @@ class PPO:
         self.lr, self.weight_decay, self.adam_eps, self.betas = learning_rate, weight_decay, adam_eps, betas
         self.normalize_advantage, self.target_kl, self.seed = normalize_advantage, target_kl, seed
         self.clip_range_vf = clip_range_vf                          # PPO.py:237-243; None = no value clipping
+        self.defer_bootstrap, self._boot = True, None                # TimeLimit bootstrap valued once per rollout (collect_rollouts)
         self._last_obs = None
         if not getattr(env, "_is_initial", False):
             self._last_obs = env.reset()
@@ -753,6 +754,21 @@ class PPO:
 
     def _stream(self):
         return _lib.current_stream(self.device)
+
+    def _bootstrap_list(self):
+        """compact list of the rollout's truncated rows (vf_rollout_post_collect): an agent is truncated at most once per
+        max_episode_steps steps, plus the episode it is in when the rollout starts"""
+        if self._boot is None:
+            N, dev = self.n_envs, self.device
+            per_agent = self.n_steps // max(int(getattr(self.env, "max_episode_steps", self.n_steps)), 1) + 2
+            cap = (N * per_agent + 8191) // 8192 * 8192
+            w1 = self.policy.obs_dims.get("target", 0) if "target" in self.obs_keys else 0
+            self._boot = {"cap": cap, "cursor": th.zeros(1, dtype=th.int32, device=dev), "idx": th.zeros(cap, dtype=th.int32, device=dev),
+                          "rows0": th.zeros((cap, 13), device=dev), "rows1": th.zeros((cap, w1), device=dev) if w1 else None,
+                          "stat": th.zeros((N, 4), device=dev)}
+        self._boot["cursor"].zero_()
+        self._boot["stat"].zero_()
+        return self._boot
 
     def save(self, path: str):
         """zip archive in the layout of SB3's BaseAlgorithm.save (PPO.py:418-430): see checkpoint.py"""
@@ -799,6 +815,7 @@ class PPO:
         obs = self._last_obs
         L, pol, N = _lib.lib(), self.policy, self.n_envs
         buf.episode_starts[0].copy_(self._last_starts)
+        bs = self._bootstrap_list() if self.defer_bootstrap else None
         for t in range(self.n_steps):
             # policy.forward (policies.py:195-226) straight into row t of the buffer: value head, sampled action, log-prob
             action, logp = buf.actions[t], buf.log_probs[t]
@@ -809,16 +826,40 @@ class PPO:
             for k in self.obs_keys:
                 buf.obs[k][t].copy_(obs[k])
             obs, reward, done, _info = env.step(action)
-            _lib.check(L.vf_episode_stats(done.data_ptr(), _ptr(env._ep_return), _ptr(env._ep_length), _ptr(env._ep_flags),
-                                          self._ep_stats.data_ptr(), N, self._stream()))
-            # TimeLimit.truncated bootstrap: SB3 adds gamma * V(terminal_observation) where the info says truncated
-            tobs = {"state": env._terminal_obs}
-            if "target" in self.obs_keys:
-                tobs["target"] = obs["target"]
-            _, tv = pol.forward(tobs, save_activations=False)
+            if not self.defer_bootstrap:
+                _lib.check(L.vf_episode_stats(done.data_ptr(), _ptr(env._ep_return), _ptr(env._ep_length), _ptr(env._ep_flags),
+                                              self._ep_stats.data_ptr(), N, self._stream()))
+            # TimeLimit.truncated bootstrap: SB3 adds gamma * V(terminal_observation) where the info says truncated.  Deferred:
+            # the few truncated rows of this step are appended to a compact list, valued once after the loop
             nxt = buf.episode_starts[t + 1] if t + 1 < self.n_steps else self._last_starts
-            _lib.check(L.vf_rollout_post(_ptr(reward), done.data_ptr(), _ptr(env._ep_flags), _ptr(tv), float(self.gamma),
-                                         _ptr(buf.rewards[t]), _ptr(nxt), N, self._stream()))
+            if self.defer_bootstrap:
+                o1 = obs["target"] if "target" in self.obs_keys else None
+                _lib.check(L.vf_rollout_post_collect(_ptr(reward), done.data_ptr(), _ptr(env._ep_flags), _ptr(buf.rewards[t]), _ptr(nxt),
+                                                     _ptr(env._terminal_obs), _ptr(o1), 13, 0 if o1 is None else o1.shape[1],
+                                                     bs["cursor"].data_ptr(), bs["cap"], bs["idx"].data_ptr(), _ptr(bs["rows0"]),
+                                                     _ptr(bs["rows1"]), t * N, N, _ptr(env._ep_return), env._ep_length.data_ptr(),
+                                                     _ptr(bs["stat"]), self._stream()))
+            else:
+                tobs = {"state": env._terminal_obs}
+                if "target" in self.obs_keys:
+                    tobs["target"] = obs["target"]
+                _, tv = pol.forward(tobs, save_activations=False)
+                _lib.check(L.vf_rollout_post(_ptr(reward), done.data_ptr(), _ptr(env._ep_flags), _ptr(tv), float(self.gamma),
+                                             _ptr(buf.rewards[t]), _ptr(nxt), N, self._stream()))
+        if self.defer_bootstrap:
+            self._ep_stats += bs["stat"].double().sum(dim=0)     # episode statistics of the rollout, per-agent sums folded once
+            cnt = int(bs["cursor"].item())                       # one host sync per rollout
+            if cnt > bs["cap"]:
+                raise _lib.VisflyError(f"deferred bootstrap list overflow ({cnt} > {bs['cap']} truncated rows in one rollout)")
+            CH = 8192                                            # fixed chunk: one set of forward buffers whatever the count
+            for s0 in range(0, cnt, CH):
+                m = min(CH, cnt - s0)
+                rows = {"state": bs["rows0"][s0:s0 + CH]}
+                if bs["rows1"] is not None:
+                    rows["target"] = bs["rows1"][s0:s0 + CH]
+                _, tv = pol.forward(rows, save_activations=False)
+                _lib.check(L.vf_bootstrap_scatter(bs["idx"].data_ptr() + 4 * s0, _ptr(tv), m, float(self.gamma), _ptr(buf.rewards),
+                                                  self._stream()))
         self._last_obs = obs
         last_values = self.predict_values(obs)
         _lib.check(_lib.lib().vf_gae(_ptr(buf.rewards), _ptr(buf.values), _ptr(buf.episode_starts), _ptr(last_values),
