@@ -19,6 +19,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (visfly_amd/__init__.py); before torch
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

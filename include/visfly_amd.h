@@ -108,7 +108,9 @@ typedef struct vf_dyn vf_dyn;
 const char* vf_last_error(void);
 int32_t vf_abi_version(void);
 
-/* Dynamics.__init__ (envs/base/dynamics.py:26-130): copies cfg; no device allocation. */
+/* Dynamics.__init__ (envs/base/dynamics.py:26-130): copies cfg to the handle and to a small device block on the CURRENT HIP
+ * device (the step kernels read their constants through it); vf_dyn_destroy frees it.  Nothing else is allocated: the state
+ * slab is the caller's. */
 int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, int32_t per_agent_drag, vf_dyn** out);
 void vf_dyn_destroy(vf_dyn* h);
 

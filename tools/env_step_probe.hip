@@ -110,6 +110,52 @@ void exhaustive_checks(float mass)
     hipFree(first);
 }
 
+// the full step with the two constant blocks read through pointers into persistent device memory instead of by-value kernel
+// arguments (a fresh kernarg block per launch)
+__global__ __launch_bounds__(kBlock) void k_probe_ptr(const vf_dyn_cfg* cp, const vf_env_cfg* ep, const EnvArgs g)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
+    const vf_dyn_cfg& c = *cp;
+    const vf_env_cfg& e = *ep;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < g.d.N;
+    Agent s;
+    Spares sp;
+    float a[4], head_bits = 0.0f;
+    ring_exchange(c, g.d, i, live, head_bits, a);
+    load_agent<false>(g.d.S, g.d.G, i, s, sp);
+    if (c.delay_steps > 0) sp.vel = head_bits;
+    float kl[3], kq[3];
+    drag_of(c, g.d, i, kl, kq);
+    control_interval<VF_ACT_BODYRATE, VF_INT_EULER, true>(c, s, a, kl, kq);
+    const int wave = threadIdx.x >> 6;
+    env_epilogue<VF_ENV_HOVER>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+}
+
+float time_ptr(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int blocks, int iters)
+{
+    vf_dyn_cfg* cp;
+    vf_env_cfg* ep;
+    hipMalloc(&cp, sizeof(c));
+    hipMalloc(&ep, sizeof(e));
+    hipMemcpy(cp, &c, sizeof(c), hipMemcpyHostToDevice);
+    hipMemcpy(ep, &e, sizeof(e), hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(k_probe_ptr, dim3(blocks), dim3(kBlock), 0, 0, cp, ep, g);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int k = 0; k < iters; ++k) hipLaunchKernelGGL(k_probe_ptr, dim3(blocks), dim3(kBlock), 0, 0, cp, ep, g);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipFree(cp);
+    hipFree(ep);
+    return ms * 1000.0f / iters;
+}
+
 template <int MODE>
 float time_mode(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, float* sink, int blocks, int iters)
 {
@@ -165,6 +211,7 @@ int main(int argc, char** argv)
             cc.interval_steps = sub;
             printf("  full(sub=%d) %.2f", sub, time_mode<0>(cc, e, g, sink, blocks, iters));
         }
+        printf("  | cfg through device pointers %.2f", time_ptr(c, e, g, blocks, iters));
         printf("\n           no-stores %.2f | state load+store only %.2f | loads only %.2f | empty %.2f | no-loads(+stores) %.2f us\n",
                time_mode<1>(c, e, g, sink, blocks, iters), time_mode<2>(c, e, g, sink, blocks, iters),
                time_mode<3>(c, e, g, sink, blocks, iters), time_mode<4>(c, e, g, sink, blocks, iters),

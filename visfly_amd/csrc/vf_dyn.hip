@@ -22,8 +22,9 @@ char* err_buf()
 
 // grid covers the padded agent count (multiple of 64); pad lanes integrate an inert hover state
 template <int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg c, const DynArgs g)
+__global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg* __restrict__ cp, const DynArgs g)
 {
+    const vf_dyn_cfg& c = *cp;   // persistent device copy (vf_handles.hpp): stays L2-resident from launch to launch
     __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.N;
@@ -48,8 +49,9 @@ __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg c, const D
 // Two-wave variant (see SplitShared): 256-thread workgroups = 2 rotation + 2 translation waves for 128
 // agents, so that every workgroup puts exactly one wave on each SIMD of its CU.
 template <int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_dyn_step_split(const vf_dyn_cfg c, const DynArgs g)
+__global__ __launch_bounds__(kBlock) void k_dyn_step_split(const vf_dyn_cfg* __restrict__ cp, const DynArgs g)
 {
+    const vf_dyn_cfg& c = *cp;
     __shared__ __attribute__((aligned(16))) SplitShared shs[2];
     const int grp = (threadIdx.x >> 6) & 1;
     SplitShared& sh = shs[grp];
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_dyn_reset(const vf_dyn_cfg c, const 
 
 namespace {
 
-using StepKernel = void (*)(const vf_dyn_cfg, const vf::DynArgs);
+using StepKernel = void (*)(const vf_dyn_cfg*, const vf::DynArgs);
 
 StepKernel pick_split_kernel(const vf_dyn_cfg& c)
 {
@@ -177,9 +179,9 @@ int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st
     vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out, vf::ring_head(h)};
     h->tick += 1;
     if (vf::use_split(h->Npad, h->cfg))
-        hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->cfg, g);
+        hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->d_cfg, g);
     else
-        hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->cfg, g);
+        hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->d_cfg, g);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
@@ -198,6 +200,10 @@ int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, int32_t per_agent_drag, vf_d
     if (int rc = vf::check_dyn_cfg(cfg)) return rc;
     vf_dyn* h = new vf_dyn;
     vf::init_dyn_handle(h, cfg, N, per_agent_drag, 0);
+    if (int rc = vf::upload_cfg(h->cfg, &h->d_cfg)) {
+        delete h;
+        return rc;
+    }
     *out = h;
     return VF_OK;
 }
@@ -205,6 +211,7 @@ int vf_dyn_create(const vf_dyn_cfg* cfg, int32_t N, int32_t per_agent_drag, vf_d
 void vf_dyn_destroy(vf_dyn* h)
 {
     if (!h) return;
+    vf::release_cfg(&h->d_cfg);
     delete h;
 }
 

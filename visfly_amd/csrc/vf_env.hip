@@ -169,8 +169,10 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
 }
 
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g)
+__global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g)
 {
+    const vf_dyn_cfg& c = *cp;   // persistent device copies (vf_handles.hpp): L2-resident from launch to launch
+    const vf_env_cfg& e = *ep;
     __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.d.N;
@@ -189,8 +191,10 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg c, const v
 
 // K consecutive steps in one launch: see vf_env_rollout_fused (include/visfly_amd.h)
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_env_rollout(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g0)
+__global__ __launch_bounds__(kBlock) void k_env_rollout(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g0)
 {
+    const vf_dyn_cfg& c = *cp;
+    const vf_env_cfg& e = *ep;
     __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int wave = threadIdx.x >> 6;
@@ -226,8 +230,10 @@ __global__ __launch_bounds__(kBlock) void k_env_rollout(const vf_dyn_cfg c, cons
 // waves for 128 agents (one wave per SIMD of the CU); the translation waves own the env epilogue and
 // every store.
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_env_step_split(const vf_dyn_cfg c, const vf_env_cfg e, const EnvArgs g)
+__global__ __launch_bounds__(kBlock) void k_env_step_split(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g)
 {
+    const vf_dyn_cfg& c = *cp;
+    const vf_env_cfg& e = *ep;
     __shared__ __attribute__((aligned(16))) SplitShared shs[2];
     const int grp = (threadIdx.x >> 6) & 1;
     SplitShared& sh = shs[grp];
@@ -360,7 +366,7 @@ struct vf_env_graph {
 
 namespace {
 
-using EnvKernel = void (*)(const vf_dyn_cfg, const vf_env_cfg, const vf::EnvArgs);
+using EnvKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvArgs);
 
 template <int KIND, int ACT>
 EnvKernel pick_env_kernel_ka(const vf_dyn_cfg& c)
@@ -463,9 +469,9 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
 {
     vf::EnvArgs g{dyn_args(h, action, out->obs, ahead), *out, h->g_race, auto_reset};
     if (vf::use_split(h->dyn.Npad, h->dyn.cfg))
-        hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);
+        hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
     else
-        hipLaunchKernelGGL(pick_env_kernel(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->dyn.cfg, h->cfg, g);
+        hipLaunchKernelGGL(pick_env_kernel(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
@@ -488,11 +494,23 @@ int vf_env_create(const vf_dyn_cfg* dyn, const vf_env_cfg* env, int32_t N, int32
     vf::init_dyn_handle(&h->dyn, dyn, N, per_agent_drag, extra);
     h->cfg = *env;
     h->g_race = extra ? h->dyn.g_extra : -1;
+    int rc = vf::upload_cfg(h->dyn.cfg, &h->dyn.d_cfg);
+    if (rc == VF_OK) rc = vf::upload_cfg(h->cfg, &h->d_cfg);
+    if (rc != VF_OK) {
+        vf_env_destroy(h);
+        return rc;
+    }
     *out = h;
     return VF_OK;
 }
 
-void vf_env_destroy(vf_env* h) { delete h; }
+void vf_env_destroy(vf_env* h)
+{
+    if (!h) return;
+    vf::release_cfg(&h->dyn.d_cfg);
+    vf::release_cfg(&h->d_cfg);
+    delete h;
+}
 
 int32_t vf_env_granules(const vf_env* h) { return h ? h->dyn.G : 0; }
 
@@ -587,7 +605,7 @@ int vf_env_rollout_fused(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
     g.obs_stride = r->obs_stride;
     g.reward_stride = r->reward_stride;
     g.done_stride = r->done_stride;
-    hipLaunchKernelGGL(pick_env_rollout(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, vf::as_stream(stream), h->dyn.cfg, h->cfg, g);
+    hipLaunchKernelGGL(pick_env_rollout(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, g);
     VF_HIP(hipGetLastError());
     h->dyn.tick += r->K;
     return VF_OK;

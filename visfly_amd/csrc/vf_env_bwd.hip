@@ -91,8 +91,10 @@ __device__ __forceinline__ void derivs_bwd(const vf_dyn_cfg& c, const Quat& q, c
 }
 
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg c, const vf_env_cfg e, const BwdArgs g)
+__global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const BwdArgs g)
 {
+    const vf_dyn_cfg& c = *cp;   // persistent device copies of the constant blocks (vf_handles.hpp)
+    const vf_env_cfg& e = *ep;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [S*kSave][kBlock]
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int tx = threadIdx.x;
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg c, con
 
 namespace {
 
-using BwdKernel = void (*)(const vf_dyn_cfg, const vf_env_cfg, const vf::BwdArgs);
+using BwdKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::BwdArgs);
 
 template <int KIND>
 BwdKernel pick_bwd(const vf_dyn_cfg& c)
@@ -581,7 +583,7 @@ extern "C" int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* a, vf_stream_t 
         VF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     vf::BwdArgs g{h->dyn.N, h->dyn.G, h->dyn.g_drag, h->g_race, a->tape_slab, reinterpret_cast<const float4*>(a->action),
                   a->d_obs, a->d_reward, a->done, a->adj_slab, reinterpret_cast<float4*>(a->d_action)};
-    hipLaunchKernelGGL(k, dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), lds, vf::as_stream(stream), h->dyn.cfg, h->cfg, g);
+    hipLaunchKernelGGL(k, dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, g);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -11,12 +11,18 @@ struct vf_dyn {
     // kernels take the slot index from the launch arguments -- the ring-slot load no longer waits for the velocity granule
     // that carries the per-agent copy (still written: the adjoint kernel reads it from its tape).
     long long tick = 0;
+    // device copy of cfg (vf_dyn_create / vf_env_create): the step kernels read their ~600 B of constants through this pointer
+    // instead of by-value kernel arguments.  A by-value block lives at a fresh kernarg address every launch, so each wave's
+    // scalar loads miss all the way to HBM; the persistent copy stays in the XCD L2s from launch to launch (65 536 agents:
+    // 11.5 -> 10.7 us per step, tools/env_step_probe.hip; a lone 64-agent wave pays ~1 us for the extra dependent load).
+    vf_dyn_cfg* d_cfg = nullptr;
 };
 
 struct vf_env {
     vf_dyn dyn;
     vf_env_cfg cfg;
     int g_race;  // racing granule or -1
+    vf_env_cfg* d_cfg = nullptr;   // device copy of cfg, see vf_dyn::d_cfg
 };
 
 namespace vf {
@@ -45,6 +51,21 @@ inline void init_dyn_handle(vf_dyn* h, const vf_dyn_cfg* cfg, int N, int per_age
     h->G = h->g_extra + extra;
     h->S = nullptr;
     h->tick = 0;
+}
+
+// device copies of the constant blocks (current HIP device); freed by release_cfg
+template <class T>
+inline int upload_cfg(const T& host, T** dev)
+{
+    VF_HIP(hipMalloc(reinterpret_cast<void**>(dev), sizeof(T)));
+    VF_HIP(hipMemcpy(*dev, &host, sizeof(T), hipMemcpyHostToDevice));
+    return VF_OK;
+}
+template <class T>
+inline void release_cfg(T** dev)
+{
+    if (*dev) (void)hipFree(*dev);
+    *dev = nullptr;
 }
 
 // ring slot of the step that is `ahead` launches after the next one
