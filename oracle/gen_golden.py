@@ -748,6 +748,31 @@ def gen_ppo(name, T=16, N=64, seed=11, clip_range_vf=None):
         label=np.asarray("reference RolloutBuffer + StateTargetExtractor + create_mlp; SB3 distribution transcribed"))
 
 
+def gen_ckpt_keys(name="ckpt_keys"):
+    """parameter names and shapes of the reference's own policy sub-modules for the default StateTarget network: the
+    StateTargetExtractor instance (utils/policies/extractors.py:662-678; sub-module names come from set_mlp_feature_extractor,
+    :464-486) and the two create_mlp trunks MlpExtractor2 holds as policy_net / value_net (policies.py:34-49).  Pins the key
+    names visfly_amd/checkpoint.py writes below SB3's own prefixes (features_extractor. / mlp_extractor.*)."""
+    import json
+    import torch.nn as nn
+    import_envs()
+    _sb3_stubs()
+    import VisFly.utils.policies.extractors as E
+    sp = sys.modules["gymnasium.spaces"]
+    space = sp.Dict({"state": sp.Box(-1, 1, (13,)), "target": sp.Box(-1, 1, (3,))})
+    ext = E.StateTargetExtractor(space, net_arch={"state": {"layer": [128, 64]}, "target": {"layer": [96, 32]}}, activation_fn=nn.ReLU)
+    pi_net, _ = E.create_mlp(input_dim=96, layer=[64, 48], activation_fn=nn.ReLU)
+    vf_net, _ = E.create_mlp(input_dim=96, layer=[64, 64], activation_fn=nn.ReLU)
+    keys = {}
+    for prefix, mod in (("features_extractor", ext), ("mlp_extractor.policy_net", pi_net), ("mlp_extractor.value_net", vf_net)):
+        for k, v in mod.state_dict().items():
+            keys[f"{prefix}.{k}"] = list(v.shape)
+    keys["features_dim"] = int(ext.features_dim)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(keys, f, indent=1, sort_keys=True)
+    print(f"{name}: {len(keys) - 1} parameter tensors, features_dim {keys['features_dim']}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -764,6 +789,8 @@ def main():
             gen_bptt(name)
     if args.only in (None, "td_lambda"):
         gen_td()
+    if args.only in (None, "ckpt_keys"):
+        gen_ckpt_keys()
     if args.only in (None, "env_hover_imu"):
         gen_imu()
     if args.only in (None, "ppo_nav"):

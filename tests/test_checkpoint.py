@@ -130,6 +130,24 @@ def test_orthogonal_init_matches_sb3_gains():
     assert float(kaiming.bias(kaiming.layers[0]).abs().max()) > 0.0
 
 
+def test_state_dict_keys_match_the_references_own_modules():
+    """tests/golden/ckpt_keys.json (oracle/gen_golden.py::gen_ckpt_keys): names and shapes read off the reference's own
+    StateTargetExtractor and create_mlp modules for the YAML above -- every one of them is in the state_dict this package
+    writes, with the same shape (the remaining keys are SB3's action_net / value_net / log_std and the pi_/vf_ aliases)"""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_keys.json")))
+    _, pol = _policy()
+    got = {k: list(v.shape) for k, v in checkpoint.policy_state_dict(pol).items()}
+    assert gold.pop("features_dim") == pol.widths["feat"]
+    assert len(gold) == 16
+    for k, shape in gold.items():
+        assert got.get(k) == shape, (k, shape, got.get(k))
+    rest = set(got) - set(gold)
+    assert {k for k in rest if not k.startswith(("pi_features_extractor.", "vf_features_extractor."))} == {
+        "action_net.weight", "action_net.bias", "value_net.weight", "value_net.bias", "log_std"}
+
+
 def test_state_dict_uses_the_reference_parameter_names():
     _, pol = _policy()
     ref = _ReferenceShapedPolicy()
