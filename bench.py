@@ -274,7 +274,7 @@ def main():
     hover = torch.tensor([-1 / 3, 0, 0, 0], device=dev)
     pool = (hover + (torch.rand((16, N, 4), device=dev, generator=g) * 2 - 1) * 0.02).clamp(-1, 1).contiguous()
     # the K actions of a timed region: a (K,N,4) sequence cycling through 16 distinct synthetic action batches
-    Kc = min(K, 4096)                                    # rollouts longer than 4096 steps are driven in chunks
+    Kc = min(K, 512)                                     # regions longer than 512 steps are driven in chunks (output buffers: 3.6 MB per step)
     seq = pool.repeat(((Kc + 15) // 16, 1, 1))[:Kc].contiguous()
     wseq = pool.repeat(((max(W, 1) + 15) // 16, 1, 1))[:max(W, 1)].contiguous()
 

@@ -626,6 +626,10 @@ class DroneGymEnvsBase:
             th.cuda.set_device(dev)
         ro = self._rollouts.get(K)
         if ro is None:
+            while len(self._rollouts) >= 4:                      # bounded cache: output buffers are K x N x 18 floats each
+                old = self._rollouts.pop(next(iter(self._rollouts)))
+                for gph in old["graphs"].values():
+                    _lib.lib().vf_env_graph_destroy(gph)
             obs = th.empty((K, N, 13), dtype=th.float32, device=dev)
             reward = th.empty((K, N), dtype=th.float32, device=dev)
             done = th.empty((K, N), dtype=th.bool, device=dev)
