@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--agents", type=int, default=AGENTS_PER_GPU, help="agents per GPU")
+    ap.add_argument("--chunk", type=int, default=512, help="steps per vf_env_step_n call (= depth of the (K,N,...) output buffers)")
     ap.add_argument("--repeats", type=int, default=7, help="the timed --steps region is repeated; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
@@ -274,7 +275,7 @@ def main():
     hover = torch.tensor([-1 / 3, 0, 0, 0], device=dev)
     pool = (hover + (torch.rand((16, N, 4), device=dev, generator=g) * 2 - 1) * 0.02).clamp(-1, 1).contiguous()
     # the K actions of a timed region: a (K,N,4) sequence cycling through 16 distinct synthetic action batches
-    Kc = min(K, 512)                                     # regions longer than 512 steps are driven in chunks (output buffers: 3.6 MB per step)
+    Kc = min(K, args.chunk)                                     # regions longer than 512 steps are driven in chunks (output buffers: 3.6 MB per step)
     seq = pool.repeat(((Kc + 15) // 16, 1, 1))[:Kc].contiguous()
     wseq = pool.repeat(((max(W, 1) + 15) // 16, 1, 1))[:max(W, 1)].contiguous()
 
@@ -325,6 +326,10 @@ def main():
         barrier()
         events.append(e0.elapsed_time(e1) * 1e-3)
     el = statistics.median(walls)
+    # how often the reset path ran in the last chunk: the share of agent-steps that ended an episode and the share of steps in
+    # which at least one agent did (one wave per SIMD: the launch lasts as long as its slowest wave, so ANY reset costs the step)
+    dn = env._rollouts[seq.shape[0]]["done"]
+    end_rate, steps_with_reset = float(dn.float().mean()), float(dn.any(dim=1).float().mean())
 
     # open-loop rollout in ONE launch (vf_env_rollout_fused: agents stay in registers between the steps; same outputs bit for bit).
     # NOT the headline: a policy in the loop needs one launch per step; reported as a separate figure
@@ -395,7 +400,8 @@ def main():
                        "ms_per_step_all": [w / K * 1e3 for w in walls], "ms_per_step_min": min(walls) / K * 1e3,
                        "host_us_per_step": statistics.median(hosts) / K * 1e6,
                        "event_us_per_step": statistics.median(events) / K * 1e6,
-                       "wall_over_kernel": el / K * 1e6 / kern_us, "per_call": per_call},
+                       "wall_over_kernel": el / K * 1e6 / kern_us, "per_call": per_call,
+                       "episode_end_rate": end_rate, "steps_with_a_reset": steps_with_reset},
             "rollout_fused": {"value": world * N * K / fused_el, "unit": "agent-steps/s", "us_per_step": fused_el / K * 1e6,
                               "driver": "env.step_n(fused=True): the K steps of the region in ONE launch (vf_env_rollout_fused), agents "
                                         "held in registers between the steps; open-loop only (actions known up front), bit-identical "

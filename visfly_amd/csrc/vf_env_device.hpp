@@ -146,22 +146,44 @@ __device__ __forceinline__ U4 philox4x32_10(U4 ctr, unsigned k0, unsigned k1)
 
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f); }
 
+// sin and cos of one angle with ONE range reduction (Cody-Waite on pi/2, cephes-style minimax polynomials on
+// [-pi/4, pi/4]; ~1 ulp for the |x| < 1e3 a spawn half-angle can take).  The spawner sits on the step's critical path
+// whenever one agent of one wave ends an episode (one wave per SIMD: the launch lasts as long as its slowest wave), so its
+// six libm sinf / cosf calls (~45 instructions each) were ~0.4 us of every such step.
+__device__ __forceinline__ void sincos_spawn(float x, float& sn, float& cs)
+{
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(k, -1.5707962512969971f, x);          // pi/2 split in two: hi has 9 trailing zero bits
+    r = fmaf(k, -7.5497894158615964e-8f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                          fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k;
+    const float a = (q & 1) ? pc : ps, b = (q & 1) ? ps : pc;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+
 // UniformStateRandomizer._generate + safe_generate (utils/randomization.py:64-96,153-170) and
 // UnionRandomizer (:284-296) for one agent.  Draw order per agent mirrors the reference
 // (pos, ori, vel, ang-vel, then the union pick and t); the stream itself is Philox keyed by
 // (seed, agent, episode) instead of the reference's global MT19937, so spawns are statistically
 // -- not bitwise -- equivalent; bitwise parity uses host-replayed states (vf_env_reset).
+// Three Philox blocks per spawn: the twelve uniforms take the low 24 bits of the twelve words, the union pick and the
+// indexed reset's t take the twelve spare top bytes (Philox output bits are independent; a fourth block was 90 instructions).
 __device__ __forceinline__ void spawn_agent(const vf_env_cfg& e, int agent, unsigned episode, bool indexed, Agent& s)
 {
     const unsigned k0 = (unsigned)e.seed, k1 = (unsigned)(e.seed >> 32);
     const U4 r0 = philox4x32_10(U4{(unsigned)agent, episode, 0u, 0x5eedu}, k0, k1);
     const U4 r1 = philox4x32_10(U4{(unsigned)agent, episode, 1u, 0x5eedu}, k0, k1);
     const U4 r2 = philox4x32_10(U4{(unsigned)agent, episode, 2u, 0x5eedu}, k0, k1);
-    const U4 r3 = philox4x32_10(U4{(unsigned)agent, episode, 3u, 0x5eedu}, k0, k1);
     const float u[12] = {u01(r0.x), u01(r0.y), u01(r0.z), u01(r0.w), u01(r1.x), u01(r1.y),
                          u01(r1.z), u01(r1.w), u01(r2.x), u01(r2.y), u01(r2.z), u01(r2.w)};
+    const unsigned pick = (r0.x >> 24) | ((r0.y >> 24) << 8) | ((r0.z >> 24) << 16) | ((r0.w >> 24) << 24);
+    const unsigned tbits = (r1.x >> 24) | ((r1.y >> 24) << 8) | ((r1.z >> 24) << 16);
     int b = 0;
-    if (e.n_spawn > 1) b = (int)(r3.x % (unsigned)e.n_spawn);  // th.randint(0, M)
+    if (e.n_spawn > 1) b = (int)(pick % (unsigned)e.n_spawn);  // th.randint(0, M)
     const vf_spawn_box& sb = e.spawn[b];
     float eul[3];
 #pragma unroll
@@ -172,14 +194,15 @@ __device__ __forceinline__ void spawn_agent(const vf_env_cfg& e, int agent, unsi
         s.w[d] = (2.0f * u[9 + d] - 1.0f) * sb.omg_half[d] + sb.omg_mean[d];             // :169
     }
     // Quaternion.from_euler(roll, pitch, yaw), zyx (utils/maths.py:256-269)
-    const float cy = cosf(eul[2] * 0.5f), sy = sinf(eul[2] * 0.5f);
-    const float cp = cosf(eul[1] * 0.5f), sp = sinf(eul[1] * 0.5f);
-    const float cr = cosf(eul[0] * 0.5f), sr = sinf(eul[0] * 0.5f);
+    float cy, sy, cp, sp, cr, sr;
+    sincos_spawn(eul[2] * 0.5f, sy, cy);
+    sincos_spawn(eul[1] * 0.5f, sp, cp);
+    sincos_spawn(eul[0] * 0.5f, sr, cr);
     s.q.w = cr * cp * cy + sr * sp * sy;
     s.q.x = sr * cp * cy - cr * sp * sy;
     s.q.y = cr * sp * cy + sr * cp * sy;
     s.q.z = cr * cp * sy - sr * sp * cy;
-    s.t = indexed ? 0.0f + u01(r3.y) * 3.14f * 2.0f : 0.0f;                              // dynamics.py:236,256
+    s.t = indexed ? 0.0f + u01(tbits) * 3.14f * 2.0f : 0.0f;                             // dynamics.py:236,256
 }
 
 // Drag domain randomisation (dynamics.py:244-246): k = k_mean * (clamp((U - .5) * 2 r, -.5, .5) + 1),
