@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--agents", type=int, default=AGENTS_PER_GPU, help="agents per GPU")
-    ap.add_argument("--chunk", type=int, default=512, help="steps per vf_env_step_n call (= depth of the (K,N,...) output buffers)")
+    ap.add_argument("--chunk", type=int, default=16, help="steps per vf_env_step_n call = depth of the (K,N,...) output ring (16 x 3.6 MB stays in the Infinity Cache; profiles/r02_reset_regime.txt)")
     ap.add_argument("--repeats", type=int, default=7, help="the timed --steps region is repeated; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
@@ -356,10 +356,29 @@ def main():
     per_call = {"ms_per_step": (time.perf_counter() - t0) / K * 1e3, "host_us_per_step": (t1 - t0) / K * 1e6,
                 "driver": "Python loop over env.step(), out_buffers=4"}
 
-    # dominant kernel, HIP events on the launch stream
+    # dominant kernel, HIP events on the launch stream (BEFORE the reset-heavy leg below desynchronises the episodes)
     kern_us = env.time_steps(pool[0], iters=300)
+    dyn.time_steps(pool[0], iters=20)               # first use of k_dyn_step in this process: code load (~1 ms) stays out of the mean
     dyn_us = dyn.time_steps(pool[0], iters=300)
     assert torch.isfinite(dyn.state).all()
+
+    # SURVEY 8(d) input 2, second run: actions U(-1,1) -- agents crash at random times, so the re-spawn path (device Philox
+    # spawner, second collision query and observation row, terminal-observation stores) runs in essentially every step
+    rseq = (torch.rand((seq.shape[0], N, 4), device=dev, generator=g) * 2 - 1).contiguous()
+    run_steps(max(256, seq.shape[0]), rseq)         # let the crashes spread over the episode phase
+    rwalls = []
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(K, rseq)
+        barrier()
+        rwalls.append(time.perf_counter() - t0)
+    rel = statistics.median(rwalls)
+    dn = env._rollouts[rseq.shape[0]]["done"]
+    with_resets = {"value": world * N * K / rel, "unit": "agent-steps/s", "us_per_step": rel / K * 1e6,
+                   "kernel_us": env.time_steps(rseq[0], iters=300),
+                   "episode_end_rate": float(dn.float().mean()), "steps_with_a_reset": float(dn.any(dim=1).float().mean()),
+                   "actions": "U(-1,1) (SURVEY 8(d) input 2, second run): per rank, not max-reduced over ranks"}
 
     out = None
     if rank == 0:
@@ -402,6 +421,7 @@ def main():
                        "event_us_per_step": statistics.median(events) / K * 1e6,
                        "wall_over_kernel": el / K * 1e6 / kern_us, "per_call": per_call,
                        "episode_end_rate": end_rate, "steps_with_a_reset": steps_with_reset},
+            "with_resets": with_resets,
             "rollout_fused": {"value": world * N * K / fused_el, "unit": "agent-steps/s", "us_per_step": fused_el / K * 1e6,
                               "driver": "env.step_n(fused=True): the K steps of the region in ONE launch (vf_env_rollout_fused), agents "
                                         "held in registers between the steps; open-loop only (actions known up front), bit-identical "
