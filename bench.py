@@ -237,6 +237,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--agents", type=int, default=AGENTS_PER_GPU, help="agents per GPU")
     ap.add_argument("--chunk", type=int, default=16, help="steps per vf_env_step_n call = depth of the (K,N,...) output ring (16 x 3.6 MB stays in the Infinity Cache; profiles/r02_reset_regime.txt)")
+    ap.add_argument("--no-reset-leg", action="store_true", help="skip the U(-1,1) reset-heavy leg (kernel-trace profiles of the headline regime)")
     ap.add_argument("--repeats", type=int, default=7, help="the timed --steps region is repeated; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
@@ -364,21 +365,23 @@ def main():
 
     # SURVEY 8(d) input 2, second run: actions U(-1,1) -- agents crash at random times, so the re-spawn path (device Philox
     # spawner, second collision query and observation row, terminal-observation stores) runs in essentially every step
-    rseq = (torch.rand((seq.shape[0], N, 4), device=dev, generator=g) * 2 - 1).contiguous()
-    run_steps(max(256, seq.shape[0]), rseq)         # let the crashes spread over the episode phase
-    rwalls = []
-    for _ in range(3):
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(K, rseq)
-        barrier()
-        rwalls.append(time.perf_counter() - t0)
-    rel = statistics.median(rwalls)
-    dn = env._rollouts[rseq.shape[0]]["done"]
-    with_resets = {"value": world * N * K / rel, "unit": "agent-steps/s", "us_per_step": rel / K * 1e6,
-                   "kernel_us": env.time_steps(rseq[0], iters=300),
-                   "episode_end_rate": float(dn.float().mean()), "steps_with_a_reset": float(dn.any(dim=1).float().mean()),
-                   "actions": "U(-1,1) (SURVEY 8(d) input 2, second run): per rank, not max-reduced over ranks"}
+    with_resets = None
+    if not args.no_reset_leg:
+        rseq = (torch.rand((seq.shape[0], N, 4), device=dev, generator=g) * 2 - 1).contiguous()
+        run_steps(max(256, seq.shape[0]), rseq)         # let the crashes spread over the episode phase
+        rwalls = []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(K, rseq)
+            barrier()
+            rwalls.append(time.perf_counter() - t0)
+        rel = statistics.median(rwalls)
+        dn = env._rollouts[rseq.shape[0]]["done"]
+        with_resets = {"value": world * N * K / rel, "unit": "agent-steps/s", "us_per_step": rel / K * 1e6,
+                       "kernel_us": env.time_steps(rseq[0], iters=300),
+                       "episode_end_rate": float(dn.float().mean()), "steps_with_a_reset": float(dn.any(dim=1).float().mean()),
+                       "actions": "U(-1,1) (SURVEY 8(d) input 2, second run): per rank, not max-reduced over ranks"}
 
     out = None
     if rank == 0:

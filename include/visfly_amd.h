@@ -27,7 +27,7 @@ extern "C" {
 #define VF_ABI_VERSION 4   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
-                              4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_ppo_loss_cfg.old_value /
+                              4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_ppo_loss_cfg.old_value /
                                  clip_range_vf, vf_comm_* / vf_allreduce_grads (RCCL) */
 
 typedef void* vf_stream_t;
@@ -281,6 +281,20 @@ void vf_env_graph_destroy(vf_env_graph* g);
  * (16-byte aligned), vel (N,3) incl. wind (dynamics.py:751-752), omg (N,3); every pointer optional.  A renderer
  * that can read the slab layout above may instead take zero-copy views of the VF_G_POS / VF_G_QUAT granules. */
 int vf_env_export_pose(vf_env* h, float* pos, float* quat, float* vel, float* omg, vf_stream_t stream);
+
+/* The step split around an external scene manager, as DroneEnvsBase.step does it with visual=True (droneEnv.py:374-379):
+ *   vf_dyn_step(vf_env_dyn(h), action, NULL, stream)           dynamics.step(action)                       :375
+ *   vf_env_export_pose(h, pos, quat, vel, NULL, stream)        sceneManager.set_pose(...); .step()         :376-378
+ *   ... the scene manager computes, for these poses, its closest scene point per agent and its out-of-bounds flags ...
+ *   vf_env_finish_step(h, closest_point, out_bounds, out, auto_reset, stream)
+ *                                                              update_collision (visual branch :330-342: collision_point from
+ *                                                              the scene, vector / distance / is_collision :364-367), then the
+ *                                                              rest of DroneGymEnvsBase.step (droneGymEnv.py:161-218)
+ * ext_collision_point (N,3) and ext_out_bounds (N, 0/1 bytes) are device arrays; either may be NULL = this library's bounding-box
+ * query, and with both NULL the two launches equal one vf_env_step bit for bit.  Agents that auto-reset inside the call take
+ * the bounding-box query for their re-spawn position (the reference asks the scene manager again, :339-341). */
+int vf_env_finish_step(vf_env* h, const float* ext_collision_point, const uint8_t* ext_out_bounds, const vf_env_out* out,
+                       int32_t auto_reset, vf_stream_t stream);
 
 int vf_env_query(vf_env* h, const vf_env_view* view, vf_stream_t stream);
 

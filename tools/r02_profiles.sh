@@ -6,8 +6,8 @@ R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 RP="rocprofv3 --output-format csv"
 # 1. kernel stats of the same commands the bench line comes from
-timeout 600 $RP --kernel-trace --stats -d /tmp/p_env -- python $R/bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline > $O/bench_env_profiled.log 2>&1
-python $R/tools/prof_summary.py $(ls /tmp/p_env/*/*kernel_stats.csv | head -1) $O/r02_env_step_kernel_stats.txt "python bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline" > /dev/null 2>&1
+timeout 600 $RP --kernel-trace --stats -d /tmp/p_env -- python $R/bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline --no-reset-leg > $O/bench_env_profiled.log 2>&1
+python $R/tools/prof_summary.py $(ls /tmp/p_env/*/*kernel_stats.csv | head -1) $O/r02_env_step_kernel_stats.txt "python bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline --no-reset-leg" > /dev/null 2>&1
 timeout 600 $RP --kernel-trace --stats -d /tmp/p_ppo -- python $R/bench.py --workload ppo --steps 256 > $O/bench_ppo_profiled.log 2>&1
 python $R/tools/prof_summary.py $(ls /tmp/p_ppo/*/*kernel_stats.csv | head -1) $O/r02_ppo_kernel_stats.txt "python bench.py --workload ppo --steps 256" > /dev/null 2>&1
 timeout 600 $RP --kernel-trace --stats -d /tmp/p_bptt -- python $R/bench.py --workload bptt --steps 128 > $O/bench_bptt_profiled.log 2>&1

@@ -23,6 +23,10 @@ struct EnvArgs {
     // per-step action is read and the per-step outputs are written; strides in elements between consecutive steps
     int K = 1;
     long long action_stride = 0, obs_stride = 0, reward_stride = 0, done_stride = 0;
+    // vf_env_finish_step only: the closest scene point per agent (N,3) and the scene's out-of-bounds flags (N) that an external
+    // scene manager computed for the pose the dynamics interval produced (droneEnv.py:330-342); null = the bbox query
+    const float* ext_point = nullptr;
+    const unsigned char* ext_oob = nullptr;
 };
 
 // env counters <-> spare slots
@@ -57,13 +61,23 @@ __device__ __forceinline__ int collision_flags(int flags, const Collision& col)
 // Everything of DroneGymEnvsBase.step that follows the dynamics interval, for ONE agent held in
 // registers: bbox collision, counters, success / reward, done masks, episode outputs, auto-reset,
 // stores (envs/base/droneGymEnv.py:161-218,339-423; envs/base/droneEnv.py:345-371).
-template <int KIND, bool STORE_STATE = true>
+template <int KIND, bool STORE_STATE = true, bool EXT = false>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile)
 {
     EnvRegs er = unpack_env(sp);
     const float vel[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};  // dynamics.py:751-752
     Collision col = bbox_collision(e, s.p);
+    if constexpr (EXT) {   // visual branch of update_collision (droneEnv.py:330-342,364-367): the scene manager's closest point
+        if (g.ext_point && live) {
+            const float* q = g.ext_point + 3 * (size_t)i;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { col.cp[d] = q[d]; col.vec[d] = q[d] - s.p[d]; }
+            col.dis = norm3(col.vec[0], col.vec[1], col.vec[2]);
+            col.hit = col.dis < e.uav_radius;
+        }
+        if (g.ext_oob && live) col.oob = g.ext_oob[i] != 0;
+    }
     er.flags = collision_flags(er.flags, col);
     er.step_count += 1;                                                                  // droneGymEnv.py:163
 
@@ -187,6 +201,24 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
     const int wave = threadIdx.x >> 6;
     env_epilogue<KIND>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+}
+
+// The part of the step that follows the dynamics interval, as a launch of its own (vf_env_finish_step): the dynamics ran
+// in vf_dyn_step on the same slab, an external scene manager then answered the collision query for the new poses
+// (droneEnv.py:374-379 with visual=True).  With ext_point = ext_oob = null the two launches equal one vf_env_step bit for bit.
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_env_finish(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g)
+{
+    const vf_dyn_cfg& c = *cp;
+    const vf_env_cfg& e = *ep;
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < g.d.N;
+    Agent s;
+    Spares sp;
+    load_agent<false>(g.d.S, g.d.G, i, s, sp);
+    const int wave = threadIdx.x >> 6;
+    env_epilogue<KIND, true, true>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
 }
 
 // K consecutive steps in one launch: see vf_env_rollout_fused (include/visfly_amd.h)
@@ -665,6 +697,26 @@ int vf_env_export_pose(vf_env* h, float* pos, float* quat, float* vel, float* om
     if (quat && reinterpret_cast<uintptr_t>(quat) % 16) return vf::fail(VF_EINVAL, "vf_env_export_pose: quat must be 16-byte aligned");
     hipLaunchKernelGGL(vf::k_env_export_pose, dim3(vf::blocks_for(h->dyn.N)), dim3(vf::kBlock), 0, vf::as_stream(stream),
                        h->dyn.cfg, dyn_args(h, nullptr, nullptr), pos, quat, vel, omg);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_env_finish_step(vf_env* h, const float* ext_collision_point, const uint8_t* ext_out_bounds, const vf_env_out* out,
+                       int32_t auto_reset, vf_stream_t stream)
+{
+    if (!h || !out) return vf::fail(VF_EINVAL, "vf_env_finish_step: null argument");
+    if (!out->obs || !out->reward || !out->done) return vf::fail(VF_EINVAL, "vf_env_finish_step: obs, reward and done outputs are required");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_finish_step: vf_env_bind has not been called");
+    vf::EnvArgs g{dyn_args(h, nullptr, out->obs), *out, h->g_race, auto_reset};
+    g.ext_point = ext_collision_point;
+    g.ext_oob = ext_out_bounds;
+    const dim3 grid(h->dyn.Npad / vf::kBlock), block(vf::kBlock);
+    hipStream_t st = vf::as_stream(stream);
+    switch (h->cfg.kind) {
+    case VF_ENV_HOVER: hipLaunchKernelGGL(vf::k_env_finish<VF_ENV_HOVER>, grid, block, 0, st, h->dyn.d_cfg, h->d_cfg, g); break;
+    case VF_ENV_NAV: hipLaunchKernelGGL(vf::k_env_finish<VF_ENV_NAV>, grid, block, 0, st, h->dyn.d_cfg, h->d_cfg, g); break;
+    default: hipLaunchKernelGGL(vf::k_env_finish<VF_ENV_RACING>, grid, block, 0, st, h->dyn.d_cfg, h->d_cfg, g); break;
+    }
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

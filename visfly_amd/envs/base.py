@@ -332,7 +332,8 @@ class DroneGymEnvsBase:
         self._reward = th.zeros(N, device=self.device)
         self._done = th.zeros(N, dtype=th.bool, device=self.device)
         self._action = th.zeros((N, 4), device=self.device)
-        self._qcache = None
+        self._qcache = self._ext_col = None
+        self._half_step = False
         self._tape = None
         if requires_grad:
             self.set_requires_grad(True)
@@ -375,6 +376,13 @@ class DroneGymEnvsBase:
                 setattr(v, k, _lib.ptr(t))
             with th.cuda.device(dev):
                 _lib.check(_lib.lib().vf_env_query(self._h, C.byref(v), self._stream()))
+            ext = getattr(self, "_ext_col", None)
+            if ext is not None:      # after step_finish(collision_point=...): the scene's closest point, except where the agent re-spawned
+                cp, done = ext
+                keep = done.view(-1, 1)
+                q["col_point"] = th.where(keep, q["col_point"], cp)
+                q["col_vec"] = th.where(keep, q["col_vec"], cp - self.envs.dynamics.position)
+                q["col_dis"] = th.where(done, q["col_dis"], q["col_vec"].norm(dim=1))
             self._qcache = q
         return self._qcache
 
@@ -406,7 +414,7 @@ class DroneGymEnvsBase:
                 dfs = th.as_tensor(fs, dtype=th.float32).to(self.device).reshape(k, 22).contiguous()
             _lib.check(_lib.lib().vf_env_reset(self._h, _lib.ptr(di), k, _lib.ptr(dfs), self._stream()))
             self._keep = (di, dfs)
-        self._qcache = None
+        self._qcache = self._ext_col = None
 
     def _replay_states(self, k, indexed):
         """host replay of the reference's draw order for k agents -> (k,22) full states
@@ -545,7 +553,7 @@ class DroneGymEnvsBase:
             rc = self._vf_env_step(self._h, a.data_ptr(), slot.ref, 0 if is_test else 1, _raw_stream(dev.index))
             if rc:
                 _lib.check(rc)
-            self._qcache = self._imu_cache = None
+            self._qcache = self._imu_cache = self._ext_col = None
             obs = slot.obs
             if obs is None or not self._STATIC_OBS_CONST:
                 obs = slot.obs = self._full_obs(slot.state)
@@ -578,7 +586,7 @@ class DroneGymEnvsBase:
                                _raw_stream(dev.index))
         if rc:
             _lib.check(rc)
-        self._qcache = self._imu_cache = None
+        self._qcache = self._imu_cache = self._ext_col = None
         if tape_t >= 0 and not borrow_done:
             self._tape_done[tape_t].copy_(done)
         self._reward, self._done = reward, done
@@ -656,11 +664,64 @@ class DroneGymEnvsBase:
             rc = L.vf_env_step_n(self._h, ro["ref"], _raw_stream(dev.index))
         if rc:
             _lib.check(rc)
-        self._qcache = self._imu_cache = None
+        self._qcache = self._imu_cache = self._ext_col = None
         self._action = a[K - 1]
         self._reward, self._done = ro["reward"][K - 1], ro["done"][K - 1]
         self._observations = self._full_obs(ro["obs"][K - 1])
         return ro["obs"], ro["reward"], ro["done"]
+
+    # ------------------------------------------------------------------ the step split around an external scene manager
+    def step_begin(self, _action, pose_out=None):
+        """first half of DroneEnvsBase.step with visual=True (droneEnv.py:374-377): the dynamics interval alone, then the pose an
+        external renderer / scene manager takes through set_pose -> the dict of export_pose().  Follow with step_finish().
+        Not available in replay-spawn mode, while a BPTT tape is recording, or with IMU noise switched on."""
+        assert self._is_initial, "You should call reset() before step()"
+        if self.spawn_mode == "replay" or self._tape is not None:
+            raise VisflyError("step_begin: needs spawn='device' and no recording tape")
+        N, dev = self.num_agent, self.device
+        a = _action
+        if not (isinstance(a, th.Tensor) and a.is_cuda and a.dtype == th.float32 and a.dim() == 2
+                and a.shape[0] == N and a.is_contiguous()):
+            a = a if isinstance(a, th.Tensor) else th.as_tensor(np.asarray(a))
+            a = a.to(dev, dtype=th.float32).reshape(N, 4).contiguous()
+        if self.validate_actions:
+            assert a.max() <= 1 and a.min() >= -1                                           # droneGymEnv.py:144
+        self._action = a
+        self.envs.dynamics.step(a)                                                          # droneEnv.py:375
+        self._qcache = self._imu_cache = self._ext_col = None
+        self._half_step = True
+        return self.export_pose(pose_out)
+
+    def step_finish(self, collision_point=None, is_out_bounds=None, is_test=False):
+        """second half: update_collision with the scene manager's answer for the poses step_begin returned -- `collision_point`
+        (N,3) = its closest scene point per agent, `is_out_bounds` (N,) bool (droneEnv.py:330-342; either None = the bounding
+        box of this library) -- then everything DroneGymEnvsBase.step does after the simulator step (droneGymEnv.py:161-218).
+        Returns (obs, reward, done, info) like step().  Re-spawned agents take the bounding-box query until the next step."""
+        if not getattr(self, "_half_step", False):
+            raise VisflyError("step_finish: call step_begin(action) first")
+        N, dev = self.num_agent, self.device
+        cp = ob = None
+        if collision_point is not None:
+            cp = th.as_tensor(collision_point).to(dev, dtype=th.float32).reshape(N, 3).contiguous()
+        if is_out_bounds is not None:
+            ob = th.as_tensor(is_out_bounds).to(dev).reshape(N).to(th.uint8).contiguous()
+        state = th.empty((N, 13), dtype=th.float32, device=dev)
+        reward = th.empty(N, dtype=th.float32, device=dev)
+        done = th.empty(N, dtype=th.bool, device=dev)
+        o = self._outs
+        o.obs, o.reward, o.done = state.data_ptr(), reward.data_ptr(), done.data_ptr()
+        with th.cuda.device(dev):
+            _lib.check(_lib.lib().vf_env_finish_step(self._h, _lib.ptr(cp), _lib.ptr(ob), self._outs_ref, 0 if is_test else 1,
+                                                     self._stream()))
+        self._half_step = False
+        self._qcache = self._imu_cache = None
+        self._ext_col = (cp, done) if cp is not None else None     # collision_point / _vector / _dis properties follow the scene
+        self._reward, self._done = reward, done
+        self._observations = obs = self._full_obs(state)
+        info = _Info(self, done, self._ep_return, self._ep_length, self._ep_flags, self._terminal_obs, self._extra_info())
+        if self.tensor_output:
+            return obs, reward, done, info
+        return self._format_obs(obs), reward.cpu().numpy(), done.cpu().numpy().astype(np.int32), info
 
     def export_pose(self, out=None):
         """what DroneEnvsBase.step hands to sceneManager.set_pose when visual=True (droneEnv.py:375-377): AoS device tensors
