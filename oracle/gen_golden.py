@@ -349,6 +349,24 @@ def import_envs():
     return HoverEnvShim, NavigationEnv, RacingEnvShim
 
 
+def import_racing2():
+    """RacingEnv2 (envs/RacingEnv.py:218-267) under the same C-4 repairs as RacingEnv; its get_observation is the class's own"""
+    import_envs()
+    from VisFly.envs.RacingEnv import RacingEnv2
+
+    class RacingEnv2Shim(RacingEnv2):
+        def get_observation(self, indices=None, predicted_obs=None):
+            return RacingEnv2.get_observation(self, indices)
+
+        def get_reward(self, predicted_obs=None):
+            return super().get_reward()
+
+        def reset(self, state=None, obs=None, **kw):
+            return super().reset(state)
+
+    return RacingEnv2Shim
+
+
 def import_envs2():
     """HoverEnv2 / NavigationEnv2: relative-position observations, Nav2 reward"""
     import_envs()
@@ -375,6 +393,7 @@ ENV_CASES = {
     "env_nav": ("nav", dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [
         {"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}), [-0.2, 0, 0, 0], 0.6, 200),
     "env_racing": ("racing", dict(max_episode_steps=48), [-0.8333] * 4, 0.08, 160),
+    "env_racing2": ("racing2", dict(max_episode_steps=48), [-0.8333] * 4, 0.08, 120),
     "env_nav_close": ("nav", dict(max_episode_steps=96, target=[2.5, 0., 1.5], random_kwargs={"state_generator": {
         "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
                                         "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
@@ -396,7 +415,9 @@ def gen_env(name, N=128, seed=42):
     kind, kw, hover, scale, steps = ENV_CASES[name]
     use_cr_sqrt(True)
     cls = {"hover": HoverEnvShim, "nav": NavigationEnv, "racing": RacingEnv}.get(kind)
-    if cls is None:
+    if kind == "racing2":
+        cls, kind = import_racing2(), "racing"        # everything but the observation is RacingEnv
+    elif cls is None:
         H2, N2 = import_envs2()
         cls = {"hover2": H2, "nav2": N2}[kind]
     kw = dict(kw)
@@ -454,6 +475,10 @@ def gen_env(name, N=128, seed=42):
             rec["is_out_bounds"].append(env.is_out_bounds.clone().numpy().astype(np.uint8))
         rec["success"].append(env._success.clone().numpy().astype(np.uint8))
         rec["obs_state"].append(f32(o["state"]))
+        if "gate" in o:      # the gate index INSIDE the returned observation (not always env._next_target_i, see visfly_amd/envs/tasks.py)
+            rec.setdefault("obs_gate", []).append(o["gate"].clone().numpy().astype(np.int32).reshape(N, -1))
+            for i in didx:   # and inside the terminal observation of the agents that ended an episode in this step
+                rec.setdefault("ev_tgate", []).append(int(np.asarray(info[i]["terminal_observation"]["gate"]).reshape(-1)[0]))
         if kind == "racing":   # post-auto-reset values, as returned in the observation
             rec["gate"].append(env._next_target_i.clone().numpy().astype(np.int32))
             rec["past"].append(env._past_targets_num.clone().numpy().astype(np.int32))
@@ -478,6 +503,10 @@ def gen_env(name, N=128, seed=42):
         "spawn": np.asarray(repr(kw.get("random_kwargs", "hover-default"))),
         "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle"),
     }
+    if "obs_gate" in rec:
+        save["obs_gate"] = np.stack(rec["obs_gate"])
+        save["obs0_gate"] = np.asarray(obs0["gate"]).astype(np.int32).reshape(N, -1)
+        save["ev_tgate"] = np.asarray(rec.get("ev_tgate", []), np.int32)
     if kind == "racing":
         save.update(gates=np.asarray(RACING_TEST_GATES, np.float32), gate=np.stack(rec["gate"]), past=np.stack(rec["past"]),
                     gate0=env_gate0)

@@ -72,6 +72,7 @@ ENV_KW = {
         {"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]}}),
     "env_nav2": dict(max_episode_steps=96, target=[2.5, 0., 1.5], random_kwargs=_NAV_CLOSE_SPAWN),
     "env_racing": dict(max_episode_steps=48),
+    "env_racing2": dict(max_episode_steps=48),
     "env_hover": dict(max_episode_steps=64),
     "env_hover_256": dict(max_episode_steps=256),
     "env_nav": dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [

@@ -55,6 +55,8 @@ def test_env_replay_mode_matches_reference_run(name):
     obs0 = env.reset()
     assert_bits_equal(env.full_state.cpu().numpy(), fx["fs_init"], f"{name} spawn states")
     assert_bits_equal(obs0["state"].cpu().numpy(), fx["obs0_state"], f"{name} reset() observation")
+    if str(fx["kind"]) == "racing":
+        assert np.array_equal(obs0["gate"].cpu().numpy(), fx["obs0_gate"][:, 0]), f"{name} reset() gate entry (the stale one)"
     keep = list(fx["keep_steps"])
     is_nav = str(fx["kind"]) == "nav"
     for k in range(acts.shape[0]):
@@ -76,7 +78,48 @@ def test_env_replay_mode_matches_reference_run(name):
         if k in keep:
             assert_bits_equal(obs["state"].cpu().numpy(), fx["obs_state_keep"][keep.index(k)], f"{name} obs @ {k}")
         if str(fx["kind"]) == "racing":
-            assert np.array_equal(obs["gate"].cpu().numpy(), fx["gate"][k]), f"{name} gate obs @ {k}"
+            # the index INSIDE the returned observation (pre-pass unless some agent ended its episode in the step), and the env's own
+            assert np.array_equal(obs["gate"].cpu().numpy(), fx["obs_gate"][k][:, 0]), f"{name} gate obs @ {k}"
+            assert np.array_equal(env._next_target_i.cpu().numpy(), fx["gate"][k]), f"{name} _next_target_i @ {k}"
+            if sel.any():
+                tg = [int(info[int(i)]["terminal_observation"]["gate"]) for i in fx["ev_agent"][sel]]
+                assert tg == list(fx["ev_tgate"][np.nonzero(sel)[0]]), f"{name} terminal gate @ {k}"
+
+
+def test_racing2_replay_matches_reference_run():
+    """RacingEnv2 (envs/RacingEnv.py:218-267; repaired-oracle fixture env_racing2): the 16-column gate-relative observation and
+    the (N,1) gate entry, bit for bit over the reference's own seed-42 run incl. auto-resets; reward / done as RacingEnv"""
+    from visfly_amd.envs import RacingEnv2
+    fx = load("env_racing2")
+    acts = decode_actions(fx)
+    env = RacingEnv2(num_agent_per_scene=fx["fs_init"].shape[0], num_scene=1, seed=int(fx["seed"]), visual=False,
+                     dynamics_kwargs=dict(RACING_DYN), device="cuda:0", tensor_output=True, constants=consts_of(fx),
+                     gates=fx["gates"].tolist(), spawn="replay", **ENV_KW["env_racing2"])
+    assert env.observation_space["state"].shape == (16,)
+    obs0 = env.reset()
+    assert_bits_equal(env.full_state.cpu().numpy(), fx["fs_init"], "racing2 spawn states")
+    assert_bits_equal(obs0["state"].cpu().numpy(), fx["obs0_state"], "racing2 reset() observation")
+    assert np.array_equal(obs0["gate"].cpu().numpy(), fx["obs0_gate"])
+    keep = list(fx["keep_steps"])
+    checked_terminal = 0
+    for k in range(acts.shape[0]):
+        obs, reward, done, info = env.step(torch.from_numpy(acts[k]).cuda())
+        assert_bits_equal(reward.cpu().numpy(), fx["reward"][k], f"racing2 reward @ {k}")
+        assert np.array_equal(done.cpu().numpy().astype(np.uint8), fx["done"][k]), f"racing2 done @ {k}"
+        assert obs["gate"].shape == (fx["fs_init"].shape[0], 1)
+        assert np.array_equal(obs["gate"].cpu().numpy(), fx["obs_gate"][k]), f"racing2 gate obs @ {k}"
+        if k in keep:
+            assert_bits_equal(obs["state"].cpu().numpy(), fx["obs_state_keep"][keep.index(k)], f"racing2 obs @ {k}")
+        sel = fx["ev_step"] == k
+        if sel.any():
+            for i, want in zip(fx["ev_agent"][sel], fx["ev_tgate"][np.nonzero(sel)[0]]):
+                t = info[int(i)]["terminal_observation"]
+                assert t["state"].shape == (16,) and t["gate"].shape == (1,)
+                assert int(t["gate"][0]) == int(want), f"racing2 terminal gate @ {k}"
+            checked_terminal += 1
+    assert checked_terminal > 0
+    with pytest.raises(Exception):
+        env.step_n(torch.zeros((2, fx["fs_init"].shape[0], 4), device="cuda"))
 
 
 def test_device_spawn_statistics_and_conventions():

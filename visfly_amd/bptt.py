@@ -73,6 +73,8 @@ class BPTT:
             env.reset()
         obs = env.get_observation()
         self.obs_keys = [k for k in obs.keys() if k in ("state", "target")]
+        if hasattr(env, "obs_gate_exact"):       # RacingEnv: the policy does not read "gate"; skip its per-step bookkeeping launches
+            env.obs_gate_exact = False
         pk = checkpoint.policy_kwargs_from_reference(policy_kwargs, self.obs_keys)
         self.weight_decay = pk.get("weight_decay", self.weight_decay)
         self.policy = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},

@@ -83,7 +83,8 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
 
     bool success = false, failure = false;
     float reward;
-    int gate = 0, passed = 0;
+    int gate = 0, passed = 0, gate_pre = 0;   // gate_pre: the index the terminal observation carries -- the observation is
+                                              // refreshed before get_success() advances it (droneGymEnv.py:161-166,197-208)
     float4 race = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (KIND == VF_ENV_HOVER) {
         reward = hover_reward(s.p, e.target, s.q, vel, s.w);
@@ -99,6 +100,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         race = *granule(g.d.S, g.d.G, i, g.g_race);
         gate = __float_as_int(race.x);
         gate = (unsigned)gate < (unsigned)e.n_gates ? gate : 0;
+        gate_pre = gate;
         passed = __float_as_int(race.y);
         const float* gt = e.gates[gate];
         const bool pass = norm3(s.p[0] - gt[0], s.p[1] - gt[1], s.p[2] - gt[2]) <= e.success_radius;
@@ -134,7 +136,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
                                     (ep_done ? VF_EP_EPISODE_DONE : 0);
             if constexpr (KIND == VF_ENV_RACING) {
                 if (g.out.ep_past_gates) g.out.ep_past_gates[i] = passed;
-                if (g.out.terminal_gate) g.out.terminal_gate[i] = gate;
+                if (g.out.terminal_gate) g.out.terminal_gate[i] = gate_pre;
             }
             if (g.out.terminal_obs) {
                 float* to = g.out.terminal_obs + 13 * (size_t)i;

@@ -65,7 +65,7 @@ class _Info(list):
                      "episode": {"r": np.asarray(ret[i]), "l": np.asarray(length[i]),
                                  "t": np.asarray(length[i] * np.float32(env.envs.dynamics.ctrl_dt)),
                                  "extra": {"collision": np.asarray(bool(f & EP_COLLIDED))}},
-                     "terminal_observation": {"state": tobs[i], **env._terminal_static_obs(i)},
+                     "terminal_observation": {"state": env._terminal_state_obs(tobs, i), **env._terminal_static_obs(i)},
                      "TimeLimit.truncated": bool(f & EP_TRUNCATED)}
                 if extra is not None:
                     d["episode"]["extra"].update({k: v[i].item() for k, v in extra.items()})
@@ -394,6 +394,11 @@ class DroneGymEnvsBase:
         """the same entries as they were in the terminal (pre-reset) observation of agent i"""
         return self._static_obs(i)
 
+    def _terminal_state_obs(self, tobs, i):
+        """ "state" entry of agent i's terminal observation from the (N,13) rows the step kernel wrote where done (already in
+        the env's obs_mode); envs that assemble their observation on the host override this"""
+        return tobs[i]
+
     def _state_obs(self, raw_state):
         """observation "state" from the raw (N,13) dynamics state; the step kernel applies the same map on the
         device (vf_env_cfg.obs_mode), this host version only runs after resets"""
@@ -621,6 +626,8 @@ class DroneGymEnvsBase:
             raise VisflyError("step_n: spawn='replay' needs a host round trip per step; use step()")
         if self._tape is not None:
             raise VisflyError("step_n: a BPTT tape is recording (requires_grad / enable_tape); use step()")
+        if getattr(self, "_HOST_OBS", False):
+            raise VisflyError(f"step_n: {type(self).__name__} assembles its observation on the host per step; use step()")
         N, dev = self.num_agent, self.device
         a = actions
         if not (isinstance(a, th.Tensor) and a.is_cuda and a.dtype == th.float32 and a.is_contiguous()):

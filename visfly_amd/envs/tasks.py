@@ -10,6 +10,7 @@ import numpy as np
 import torch as th
 
 from . import spaces
+from ..type import TensorDict
 from .base import HOVER, NAV, RACING, DroneGymEnvsBase
 
 _HOVER_SPAWN = {"state_generator": {"class": "Uniform", "kwargs": [
@@ -125,12 +126,52 @@ class RacingEnv(DroneGymEnvsBase):
             low=-np.inf, high=np.inf,
             shape=(3 * (self._next_target_num - 1) + self.observation_space["state"].shape[0],), dtype=np.float32)
 
+    # The gate index inside the observation step() / reset() RETURN is not always the env's current one (all of it pinned by the
+    # repaired-oracle fixtures env_racing / env_racing2):
+    #  * DroneGymEnvsBase.step refreshes the observation BEFORE get_success() advances the gate of an agent that just passed one
+    #    (droneGymEnv.py:161-166): the returned entry is the gate the agent was flying to at the START of the step;
+    #  * unless some agent ended its episode in this step: examine() -> reset_agent_by_id -> get_full_observation(indices)
+    #    ignores its indices and rebuilds EVERY agent's observation (:347,460-469), now with the advanced / newly chosen gates;
+    #  * RacingEnv.reset builds its observation inside super().reset(), before it re-chooses the gates (RacingEnv.py:165-170):
+    #    the returned entry is the previous episode's (zeros on the first reset).
+    # `obs_gate_exact = False` (set by trainers whose policy does not read "gate") skips the two small launches this costs per
+    # step and returns the current index.
+    obs_gate_exact = True
+    _g_obs = None
+    _STATIC_OBS_CONST = False
+
     def _static_obs(self, i=None):
-        return {"gate": self._gate if i is None else self._gate[i]}
+        g = self._gate if self._g_obs is None else self._g_obs
+        return {"gate": g if i is None else g[i]}
+
+    def _full_obs(self, state, raw=False):
+        self._last_raw = state
+        return super()._full_obs(state, raw)
+
+    def _step_no_grad(self, _action, is_test=False, **kw):
+        self._g_obs = None
+        if not self.obs_gate_exact:
+            return super()._step_no_grad(_action, is_test=is_test, **kw)
+        prev = self._gate.clone()
+        _, reward, done, info = super()._step_no_grad(_action, is_test=is_test, **kw)
+        self._g_obs = prev if is_test else th.where(self._done.any(), self._gate, prev)
+        self._observations = obs = self._full_obs(self._last_raw)
+        return (obs if self.tensor_output else self._format_obs(obs)), reward, done, info
+
+    def step_n(self, *a, **kw):
+        self._g_obs = None          # step_n returns raw rows only; get_observation() afterwards reports the current gates
+        return super().step_n(*a, **kw)
+
+    def get_observation(self, indices=None, predicted_obs=None):
+        # the reference recomputes the observation from its attributes on every call (RacingEnv.py:118-134): current gates
+        self._g_obs = None
+        self._observations = self._full_obs(self._last_raw)
+        return self._observations
 
     def _reset_kernel(self, idx, fs):
         super()._reset_kernel(idx, fs)
         self._gate.copy_(self._query()["gate"])     # in place: the step kernel holds this buffer's address
+        self._g_obs = None
 
     def _terminal_static_obs(self, i):
         return {"gate": self._terminal_gate[i]}
@@ -140,7 +181,51 @@ class RacingEnv(DroneGymEnvsBase):
         return {"past_gate": self._ep_past_gates}
 
     def reset(self, state=None, obs=None, **kw):
-        return super().reset(state)
+        stale = self._gate.clone()
+        out = super().reset(state)
+        if not self.obs_gate_exact:
+            return out
+        self._g_obs = stale
+        self._observations = o = self._full_obs(self.envs.dynamics.state, raw=True)
+        return self._format_obs(o)
 
     _next_target_i = property(lambda s: s._query()["gate"])
     _past_targets_num = property(lambda s: s._query()["past_gates"])
+
+
+class RacingEnv2(RacingEnv):
+    """RacingEnv with the gate-relative observation (envs/RacingEnv.py:218-267): "state" = [(next `_next_target_num` gates -
+    p) / max_sense_radius (6), q (4), v / 10 (3), w / 10 (3)] = 16 columns, "gate" = next-gate index as (N,1).  Dynamics, reward,
+    gate bookkeeping and re-spawn are RacingEnv's (the step kernel); the observation is assembled from the kernel's raw state rows
+    with the reference's own torch expressions, one small launch sequence per step (NEXT tier; forward only --
+    requires_grad=True raises, and step_n() is refused)."""
+    _HOST_OBS = True
+
+    def __init__(self, *a, requires_grad: bool = False, **kw):
+        if requires_grad:
+            raise NotImplementedError("RacingEnv2: the host-side observation has no adjoint; use RacingEnv for BPTT / SHAC")
+        super().__init__(*a, requires_grad=False, **kw)
+        self.max_sense_radius = 10                                                     # droneGymEnv.py:69
+        g = kw.get("gates")
+        self.targets = th.as_tensor(_RACING_GATES if g is None else g, dtype=th.float32, device=self.device)
+
+    def _race_state(self, raw, gate):
+        idx = th.stack([gate + i for i in range(self._next_target_num)]).T % len(self.targets)    # RacingEnv.py:254
+        rel = (self.targets[idx.long()] - raw[:, 0:3].unsqueeze(1)).reshape(raw.shape[0], -1)       # :255-256
+        # divisors as device tensors: torch's GPU kernels turn `x / python_scalar` into x * (1 / scalar), one ulp off the CPU
+        # reference's IEEE division
+        ten = th.full((1,), 10.0, device=raw.device)
+        return th.hstack([rel / th.full((1,), float(self.max_sense_radius), device=raw.device), raw[:, 3:7],
+                          raw[:, 7:10] / ten, raw[:, 10:13] / ten])                                    # :257-262
+
+    def _full_obs(self, state, raw=False):          # RacingEnv's rules for WHICH gate index the returned rows use apply unchanged
+        self._last_raw = state
+        g = self._gate if self._g_obs is None else self._g_obs
+        return TensorDict({"state": self._race_state(state, g), "gate": g.unsqueeze(1).clone()})      # :264-267
+
+    def _terminal_state_obs(self, tobs, i):
+        raw = tobs[i].reshape(1, 13).to(self.device)
+        return self._race_state(raw, self._terminal_gate[i].reshape(1))[0]
+
+    def _terminal_static_obs(self, i):
+        return {"gate": self._terminal_gate[i].reshape(1)}
