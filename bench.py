@@ -20,6 +20,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (visfly_amd/__init__.py); before torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -282,13 +283,16 @@ def main():
 
     tail = torch.cuda.Event()
 
-    def barrier():
+    def drain():
         # poll an event first: hipDeviceSynchronize parks the thread and wakes up tens of microseconds late, which a
         # 20-step region (~250 us) would count as step time; the synchronize the contract asks for follows immediately
         tail.record()
         while not tail.query():
             pass
         torch.cuda.synchronize()
+
+    def barrier():
+        drain()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
@@ -310,8 +314,9 @@ def main():
         t0 = time.perf_counter()
         run_steps(K, seq)
         t1 = time.perf_counter()
-        barrier()
+        drain()                                    # this rank's K steps are done: its clock stops here ...
         el = time.perf_counter() - t0
+        barrier()                                  # ... the closing barrier follows, and the MAX over ranks is what is reported
         if dist is not None:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -417,8 +422,9 @@ def main():
                        "agents_per_gpu": N, "parallelism": f"agents sharded x{world}, no data-path collective",
                        "driver": "env.step_n(): the K launches of the timed region are enqueued by one C call "
                                  "(vf_env_step_n); bit-identical to K env.step() calls (tests/test_env_multistep_gpu.py)"},
-            "timing": {"repeats": len(walls), "statistic": "median of the repeated --steps regions, each bracketed by "
-                                                            "barrier + synchronize, max over ranks",
+            "timing": {"repeats": len(walls), "statistic": "median of the repeated --steps regions, each bracketed by barrier + synchronize; "
+                                                            "a rank's clock stops when ITS K steps have drained, the closing "
+                                                            "barrier follows, max over ranks",
                        "ms_per_step_all": [w / K * 1e3 for w in walls], "ms_per_step_min": min(walls) / K * 1e3,
                        "host_us_per_step": statistics.median(hosts) / K * 1e6,
                        "event_us_per_step": statistics.median(events) / K * 1e6,
