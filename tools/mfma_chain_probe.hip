@@ -162,6 +162,9 @@ int main()
         const float e = time_us([&] { hipLaunchKernelGGL(k_chain16<2>, dim3(2048), dim3(64), 0, 0, w, x, out, M); }, 50);
         printf("25600 rows: 32 rows/wave (800 waves) %.1f us | 16 rows/wave (1600 waves, 2 per SIMD) %.1f us | 16 rows/wave launch_bounds(64,1) %.1f us\n", a, b, c);
         printf("full chip : 32 rows/wave x 1024 waves (32768 rows) %.1f us | 16 rows/wave x 2048 waves (32768 rows) %.1f us\n", d, e);
+        const float f = time_us([&] { hipLaunchKernelGGL(k_chain32, dim3(512), dim3(64), 0, 0, w, x, out, M); }, 50);
+        const float h = time_us([&] { hipLaunchKernelGGL(k_chain16<1>, dim3(1024), dim3(64), 0, 0, w, x, out, M); }, 50);
+        printf("half chip : 32 rows/wave x 512 waves (16384 rows) %.1f us | 16 rows/wave x 1024 waves (16384 rows) %.1f us\n", f, h);
     }
     CK(hipDeviceSynchronize());
     return 0;

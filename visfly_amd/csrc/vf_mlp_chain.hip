@@ -24,9 +24,35 @@
 
 #include <type_traits>
 
+#ifndef VF_CHAIN16_DEPTH
+#define VF_CHAIN16_DEPTH 24
+#endif
+
 namespace vf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Pull the whole kernel-argument block into the scalar cache with one batch of loads (24 lines per batch).  The chain kernels
+// take their layer tables by value (1.2 - 2.8 KB of kernel arguments at a fresh address every launch) and the compiler fetches a
+// field where it is first used: k_ppo_update_chain had 314 s_load / 216 s_waitcnt lgkmcnt in its body, ~44 of them first touches
+// of a 64-byte line that go all the way to memory, and with ONE wave per SIMD nothing hides such a stall.  One dword per line,
+// kept alive by an empty asm that wants it in an SGPR; afterwards every field load hits the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void prefetch_kernarg()
+{
+    typedef const unsigned __attribute__((address_space(4))) * kptr;
+    const kptr w = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int L = (BYTES + 63) / 64;
+#pragma unroll
+    for (int b0 = 0; b0 < L; b0 += 24) {
+        unsigned x[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) x[k] = b0 + k < L ? w[16 * (b0 + k)] : 0u;
+        asm volatile("" ::"s"(x[0]), "s"(x[1]), "s"(x[2]), "s"(x[3]), "s"(x[4]), "s"(x[5]), "s"(x[6]), "s"(x[7]), "s"(x[8]), "s"(x[9]),
+                     "s"(x[10]), "s"(x[11]), "s"(x[12]), "s"(x[13]), "s"(x[14]), "s"(x[15]), "s"(x[16]), "s"(x[17]), "s"(x[18]),
+                     "s"(x[19]), "s"(x[20]), "s"(x[21]), "s"(x[22]), "s"(x[23]));
+    }
+}
 
 struct __attribute__((packed, aligned(4))) f32x4u {   // 4 consecutive floats at dword alignment (bias vectors)
     float x, y, z, w;
@@ -299,6 +325,212 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
         }
     }
     chain_items<N, 0>(g, st, lane, row, live);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same forward with 16 rows per wave (v_mfma_f32_16x16x4_f32) for SMALL row counts.  The 32-row chain puts M / 32 waves on
+// 1 024 SIMDs and lasts as long as one wave needs for the whole network whatever M is; at the BPTT shard (16 384 rows = 512
+// waves) half of the chip idles.  With 16 rows a wave does half the work and twice as many waves run (probe, same skeleton:
+// 47 -> 28 us at 16 384 rows; no gain once the chip is full -- profiles/r02_mfma_chain_probe.txt), so vf_mlp_forward picks
+// this kernel for M <= 16 384.
+//     A operand = weights   A[i = n][k]    lane = n + 16 kq
+//     B operand = X^T       B[k][j = m]    lane = m + 16 kq
+//     C / D     = Y^T       D[i = n][j = m] lane (m, gq = lane >> 4) holds n = 4 gq + r, r = 0..3
+// An accumulator lane holds features 4 gq .. 4 gq + 3 of its own row: as the B operand of step r of the next layer it supplies
+// k = (feature 4 gq + r of that 16-feature tile), so step r's A fragment is W[n][16 T + 4 gq + r] -- the four steps of an
+// (output tile, input tile) pair are ONE float4 of the row-major weight matrix itself.  No packed image at all.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// weight fragments in flight: an item is 4 MFMAs x 32 cycles here, so the same ~2 k cycles of cover need more slots than the
+// 32-row chain's 8 (measured: 8 slots 17.9 us, i.e. load-latency bound)
+constexpr int kChain16Depth = VF_CHAIN16_DEPTH;
+
+template <class N>
+struct Chain16 {
+    static constexpr int nin(int i) { return N::layer(i).obs >= 0 ? 1 : 2 * N::layer(i).nin; }       // 16-feature input tiles
+    static constexpr int nout(int i) { return N::is_head(i) ? 1 : 2 * N::layer(i).nout; }
+    static constexpr int items(int i) { return nin(i) * nout(i); }
+    static constexpr int n_items()
+    {
+        int n = 0;
+        for (int i = 0; i < N::n_exec; ++i) n += items(i);
+        return n;
+    }
+    static constexpr int layer_of(int item)
+    {
+        int i = 0;
+        while (item >= items(i)) { item -= items(i); ++i; }
+        return i;
+    }
+    static constexpr int first_item(int li)
+    {
+        int n = 0;
+        for (int i = 0; i < li; ++i) n += items(i);
+        return n;
+    }
+};
+
+template <class N>
+struct ChainState16 {
+    f32x4 t[2 * N::n_tiles];
+    float x[2][4];               // observation fragment: x[b][j] = X[m][4 gq + j] (K <= 16)
+    float4 ring[kChain16Depth];
+    float4 bias[8];              // bias of the layer in flight: [out tile] -> features 16 a + 4 gq .. + 3
+};
+
+template <class N, int I>
+__device__ __forceinline__ float4 chain16_load(const ChainArgs& g, int lane)
+{
+    using C = Chain16<N>;
+    constexpr int li = C::layer_of(I), local = I - C::first_item(li);
+    constexpr ChainLayer L = N::layer(li);
+    constexpr int T = local / C::nout(li), a = local % C::nout(li);
+    const vf_mlp_layer& D = g.d.layer[L.desc];
+    const int n = 16 * a + (lane & 15), gq = lane >> 4;
+    const float* w = g.params + D.w_off;
+    if constexpr (L.obs >= 0) {          // K = in_dim <= 16, rows not 16-byte aligned: guarded scalar loads
+        const float* r = w + (size_t)n * D.K;
+        const int k = 4 * gq;
+        return make_float4(k < D.K ? r[k] : 0.0f, k + 1 < D.K ? r[k + 1] : 0.0f, k + 2 < D.K ? r[k + 2] : 0.0f, k + 3 < D.K ? r[k + 3] : 0.0f);
+    } else {
+        const int nc = n < D.No ? n : D.No - 1;      // heads: rows past No repeat the last one (their outputs are never read)
+        return *reinterpret_cast<const float4*>(w + (size_t)nc * D.K + 16 * T + 4 * gq);
+    }
+}
+
+template <class N, int LI>
+__device__ __forceinline__ void chain16_bias_load(const ChainArgs& g, ChainState16<N>& st, int gq)
+{
+    constexpr ChainLayer L = N::layer(LI);
+    const float* b = g.params + g.d.layer[L.desc].b_off;    // b_off is only dword aligned
+    if constexpr (L.desc == N::L_value) {
+        st.bias[0] = make_float4(b[0], 0.0f, 0.0f, 0.0f);
+    } else if constexpr (L.desc == N::L_mean) {
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(b);
+        st.bias[0] = make_float4(v.x, v.y, v.z, v.w);
+    } else {
+#pragma unroll
+        for (int a = 0; a < Chain16<N>::nout(LI); ++a) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(b + 16 * a + 4 * gq);
+            st.bias[a] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
+template <class N, int LI>
+__device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState16<N>& st, int row, int gq, bool live)
+{
+    constexpr ChainLayer L = N::layer(LI);
+    if constexpr (N::is_head(LI)) {                    // heads: mean (M,4) / value (M,1); lane group 0 holds them
+        f32x4& y = st.t[2 * L.out0];
+        const float4 bq = st.bias[0];
+        y[0] += bq.x; y[1] += bq.y; y[2] += bq.z; y[3] += bq.w;
+        if (live && gq == 0) {
+            if constexpr (L.desc == N::L_mean) {
+                if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
+                if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers (as chain_epilogue)
+                    const float4 e = g.rp_eps[row];
+                    g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
+                                                   tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                }
+            } else {
+                if (g.io.value) g.io.value[row] = y[0];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < Chain16<N>::nout(LI); ++a) {
+            f32x4& y = st.t[2 * L.out0 + a];
+            const float4 bq = st.bias[a];
+            y[0] = fmaxf(y[0] + bq.x, 0.0f); y[1] = fmaxf(y[1] + bq.y, 0.0f);
+            y[2] = fmaxf(y[2] + bq.z, 0.0f); y[3] = fmaxf(y[3] + bq.w, 0.0f);
+        }
+    }
+}
+
+// saved copies of the previous layer's output, trickled out under this layer's items (see chain_deferred_store)
+template <class N, int LI, int LOCAL>
+__device__ __forceinline__ void chain16_deferred_store(const ChainArgs& g, const ChainState16<N>& st, int row, int gq, bool live)
+{
+    if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
+        using C = Chain16<N>;
+        constexpr ChainLayer P = N::layer(LI - 1);
+        constexpr int S = C::nout(LI - 1), per = (S + C::items(LI) - 1) / C::items(LI);
+        constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
+        if constexpr (s0 < s1) {
+            const vf_mlp_layer& D = g.d.layer[P.desc];
+            if (D.save && live) {
+                const unsigned off = (unsigned)row * (unsigned)D.save_ld + 4u * gq;
+#pragma unroll
+                for (int a = s0; a < s1; ++a) {
+                    const f32x4& y = st.t[2 * P.out0 + a];
+                    *reinterpret_cast<float4*>(D.save + D.dst_col + 16 * a + off) = make_float4(y[0], y[1], y[2], y[3]);
+                }
+            }
+        }
+    }
+}
+
+template <class N, int I>
+__device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N>& st, int lane, int row, bool live)
+{
+    using C = Chain16<N>;
+    if constexpr (I < C::n_items()) {
+        constexpr int li = C::layer_of(I), local = I - C::first_item(li);
+        constexpr ChainLayer L = N::layer(li);
+        constexpr int T = local / C::nout(li), a = local % C::nout(li);
+        const int gq = lane >> 4;
+        const float4 w = st.ring[I % kChain16Depth];
+        if constexpr (I + kChain16Depth < C::n_items()) st.ring[I % kChain16Depth] = chain16_load<N, I + kChain16Depth>(g, lane);
+        if constexpr (local == 0) chain16_bias_load<N, li>(g, st, gq);
+        f32x4& acc = st.t[2 * L.out0 + a];
+        if constexpr (T == 0) acc = f32x4{0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float b;
+            if constexpr (L.obs >= 0) b = st.x[L.obs][j];
+            else b = st.t[2 * L.in0 + T][j];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
+        }
+        chain16_deferred_store<N, li, local>(g, st, row, gq, live);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (local == C::items(li) - 1) chain16_epilogue<N, li>(g, st, row, gq, live);
+        chain16_items<N, I + 1>(g, st, lane, row, live);
+    }
+}
+
+template <class N, int I>
+__device__ __forceinline__ void chain16_prologue(const ChainArgs& g, ChainState16<N>& st, int lane)
+{
+    if constexpr (I < kChain16Depth && I < Chain16<N>::n_items()) {
+        st.ring[I] = chain16_load<N, I>(g, lane);
+        chain16_prologue<N, I + 1>(g, st, lane);
+    }
+}
+
+template <class N>
+__global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
+{
+    const int lane = threadIdx.x, m = lane & 15, gq = lane >> 4;
+    const int row = blockIdx.x * 16 + m;
+    const bool live = row < g.M;
+    const int rc = live ? row : g.M - 1;
+    ChainState16<N> st;
+    chain16_prologue<N, 0>(g, st, lane);
+#pragma unroll
+    for (int b = 0; b < N::NB; ++b) {
+        const int w = g.d.in_dim[b];
+        const float* x = g.io.in[b] + (size_t)rc * w;
+        float* xc = g.obs_copy[b] ? g.obs_copy[b] + (size_t)rc * w : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * gq + j;
+            const float v = x[k < w ? k : w - 1];
+            st.x[b][j] = k < w ? v : 0.0f;
+            if (xc && live && k < w) xc[k] = v;
+        }
+    }
+    chain16_items<N, 0>(g, st, lane, row, live);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,6 +866,7 @@ template <class N>
 __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, const BwdArgsChain gb, const PpoRowArgs pr)
 {
     using P = BwdProg<N, true, true, false>;
+    prefetch_kernarg<sizeof(ChainArgs) + sizeof(BwdArgsChain) + sizeof(PpoRowArgs)>();
     const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
     const int row = blockIdx.x * 32 + m;
     const bool live = row < g.M;
@@ -731,13 +964,33 @@ bool chain_matches(const vf_mlp_desc& d)
     return true;
 }
 
+// 16 rows per wave: only while it doubles the waves without exceeding one per SIMD (M <= 16 384), K <= 16 observation rows,
+// and the weight rows the kernel reads as float4 are 16-byte aligned.  VISFLY_AMD_MLP_CHAIN16=0/1 forces the choice (A/B).
+template <class N>
+bool chain16_ok(const vf_mlp_desc& d, const float* params, int M)
+{
+    static const int forced = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN16"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || (forced < 0 && M > 16384)) return false;
+    if (reinterpret_cast<uintptr_t>(params) & 15) return false;
+    for (int b = 0; b < N::NB; ++b)
+        if (d.in_dim[b] > 16) return false;
+    for (int i = 0; i < N::n_exec; ++i) {
+        const vf_mlp_layer& L = d.layer[N::layer(i).desc];
+        if (N::layer(i).obs < 0 && ((L.w_off & 3) || (L.K & 15))) return false;
+    }
+    return true;
+}
+
 template <class N>
 int chain_launch(const vf_mlp_desc& d, const float* params, const float* packed, const float* in0, const float* in1, float* out0,
                  float* out1, int M, hipStream_t st, const ReparamFwd& rp)
 {
     ChainArgs g{d, params, packed, ChainIo{{in0, in1}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.action),
                 {rp.obs_copy[0], rp.obs_copy[1]}};
-    hipLaunchKernelGGL(k_mlp_forward_chain<N>, dim3((M + 31) / 32), dim3(64), 0, st, g);
+    if (chain16_ok<N>(d, params, M))
+        hipLaunchKernelGGL(k_mlp_forward_chain16<N>, dim3((M + 15) / 16), dim3(64), 0, st, g);
+    else
+        hipLaunchKernelGGL(k_mlp_forward_chain<N>, dim3((M + 31) / 32), dim3(64), 0, st, g);
     VF_HIP(hipGetLastError());
     return 1;
 }
