@@ -50,6 +50,30 @@ inline bool use_split(int agents_padded, const vf_dyn_cfg& cfg)
     return agents_padded <= 32768;   // measured on MI355X: 32768 agents 9.4 us (split) vs 11.3 us; 65536: 13.3 vs 12.5
 }
 
+#ifdef __HIPCC__
+// Pull the whole kernel-argument block into the scalar cache with one batch of loads (24 lines per batch).  The chain kernels
+// take their layer tables by value (1.2 - 2.8 KB of kernel arguments at a fresh address every launch) and the compiler fetches a
+// field where it is first used: k_ppo_update_chain had 314 s_load / 216 s_waitcnt lgkmcnt in its body, ~44 of them first touches
+// of a 64-byte line that go all the way to memory, and with ONE wave per SIMD nothing hides such a stall.  One dword per line,
+// kept alive by an empty asm that wants it in an SGPR; afterwards every field load hits the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void prefetch_kernarg()
+{
+    typedef const unsigned __attribute__((address_space(4))) * kptr;
+    const kptr w = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int L = (BYTES + 63) / 64;
+#pragma unroll
+    for (int b0 = 0; b0 < L; b0 += 24) {
+        unsigned x[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) x[k] = b0 + k < L ? w[16 * (b0 + k)] : 0u;
+        asm volatile("" ::"s"(x[0]), "s"(x[1]), "s"(x[2]), "s"(x[3]), "s"(x[4]), "s"(x[5]), "s"(x[6]), "s"(x[7]), "s"(x[8]), "s"(x[9]),
+                     "s"(x[10]), "s"(x[11]), "s"(x[12]), "s"(x[13]), "s"(x[14]), "s"(x[15]), "s"(x[16]), "s"(x[17]), "s"(x[18]),
+                     "s"(x[19]), "s"(x[20]), "s"(x[21]), "s"(x[22]), "s"(x[23]));
+    }
+}
+#endif
+
 // action head fused into the chain kernels (vf_mlp_forward_act / vf_mlp_backward_data_act); all-null: off
 struct ReparamFwd {
     const float* log_std;

@@ -32,28 +32,6 @@ namespace vf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// Pull the whole kernel-argument block into the scalar cache with one batch of loads (24 lines per batch).  The chain kernels
-// take their layer tables by value (1.2 - 2.8 KB of kernel arguments at a fresh address every launch) and the compiler fetches a
-// field where it is first used: k_ppo_update_chain had 314 s_load / 216 s_waitcnt lgkmcnt in its body, ~44 of them first touches
-// of a 64-byte line that go all the way to memory, and with ONE wave per SIMD nothing hides such a stall.  One dword per line,
-// kept alive by an empty asm that wants it in an SGPR; afterwards every field load hits the scalar cache.
-template <int BYTES>
-__device__ __forceinline__ void prefetch_kernarg()
-{
-    typedef const unsigned __attribute__((address_space(4))) * kptr;
-    const kptr w = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr int L = (BYTES + 63) / 64;
-#pragma unroll
-    for (int b0 = 0; b0 < L; b0 += 24) {
-        unsigned x[24];
-#pragma unroll
-        for (int k = 0; k < 24; ++k) x[k] = b0 + k < L ? w[16 * (b0 + k)] : 0u;
-        asm volatile("" ::"s"(x[0]), "s"(x[1]), "s"(x[2]), "s"(x[3]), "s"(x[4]), "s"(x[5]), "s"(x[6]), "s"(x[7]), "s"(x[8]), "s"(x[9]),
-                     "s"(x[10]), "s"(x[11]), "s"(x[12]), "s"(x[13]), "s"(x[14]), "s"(x[15]), "s"(x[16]), "s"(x[17]), "s"(x[18]),
-                     "s"(x[19]), "s"(x[20]), "s"(x[21]), "s"(x[22]), "s"(x[23]));
-    }
-}
-
 struct __attribute__((packed, aligned(4))) f32x4u {   // 4 consecutive floats at dword alignment (bias vectors)
     float x, y, z, w;
 };
@@ -305,6 +283,7 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs& g, ChainState<N>
 template <class N>
 __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
 {
+    prefetch_kernarg<sizeof(ChainArgs)>();
     const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
     const int row = blockIdx.x * 32 + m;
     const bool live = row < g.M;
@@ -511,6 +490,7 @@ __device__ __forceinline__ void chain16_prologue(const ChainArgs& g, ChainState1
 template <class N>
 __global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
 {
+    prefetch_kernarg<sizeof(ChainArgs)>();
     const int lane = threadIdx.x, m = lane & 15, gq = lane >> 4;
     const int row = blockIdx.x * 16 + m;
     const bool live = row < g.M;
@@ -834,6 +814,7 @@ __device__ __forceinline__ void bwd_tail_store(const BwdArgsChain& g, const BwdS
 template <class P>
 __global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
 {
+    prefetch_kernarg<sizeof(BwdArgsChain)>();
     const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
     const int row = blockIdx.x * 32 + m;
     const bool live = row < g.M;

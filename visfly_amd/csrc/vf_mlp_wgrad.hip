@@ -162,6 +162,7 @@ __device__ __forceinline__ void wgrad_slab_pick(const vf_mlp_bwd_layer& L, int r
 
 __global__ __launch_bounds__(64) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const WgradTable t, float* __restrict__ partials, int M)
 {
+    prefetch_kernarg<sizeof(vf_mlp_bwd_desc) + sizeof(WgradTable) + 16>();
     const int w = blockIdx.x;
     int l = 0;
     while (l + 1 < t.n_layers && w >= t.first_wave[l + 1]) ++l;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, 
                                                        float* __restrict__ grad, int accumulate, double* __restrict__ sq_part,
                                                        const vf_stats_fold ls, int n_param_blocks)
 {
+    prefetch_kernarg<sizeof(vf_mlp_bwd_desc) + sizeof(WgradTable) + 40 + sizeof(vf_stats_fold)>();
     __shared__ float red[4][64];
     if ((int)blockIdx.x >= n_param_blocks) {     // the extra block: loss-statistic partial rows (vf_ppo_update) -> stats
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
