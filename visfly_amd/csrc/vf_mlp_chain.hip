@@ -320,6 +320,13 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
 // (output tile, input tile) pair are ONE float4 of the row-major weight matrix itself.  No packed image at all.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+#ifdef VF_CHAIN_TRACE
+__device__ long long vf_chain_trace[2][32];
+#define VF_TRACE(k) do { if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 0) vf_chain_trace[blockIdx.x ? 1 : 0][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VF_TRACE(k) do { } while (0)
+#endif
+
 // weight fragments in flight: an item is 4 MFMAs x 32 cycles here, so the same ~2 k cycles of cover need more slots than the
 // 32-row chain's 8 (measured: 8 slots 17.9 us, i.e. load-latency bound)
 constexpr int kChain16Depth = VF_CHAIN16_DEPTH;
@@ -473,7 +480,11 @@ __device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N
         }
         chain16_deferred_store<N, li, local>(g, st, row, gq, live);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (local == C::items(li) - 1) chain16_epilogue<N, li>(g, st, row, gq, live);
+        if constexpr (local == 0) VF_TRACE(2 + 2 * li);
+        if constexpr (local == C::items(li) - 1) {
+            chain16_epilogue<N, li>(g, st, row, gq, live);
+            VF_TRACE(3 + 2 * li);
+        }
         chain16_items<N, I + 1>(g, st, lane, row, live);
     }
 }
@@ -490,6 +501,7 @@ __device__ __forceinline__ void chain16_prologue(const ChainArgs& g, ChainState1
 template <class N>
 __global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
 {
+    VF_TRACE(0);
     prefetch_kernarg<sizeof(ChainArgs)>();
     const int lane = threadIdx.x, m = lane & 15, gq = lane >> 4;
     const int row = blockIdx.x * 16 + m;
@@ -510,7 +522,9 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
             if (xc && live && k < w) xc[k] = v;
         }
     }
+    VF_TRACE(1);
     chain16_items<N, 0>(g, st, lane, row, live);
+    VF_TRACE(31);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1084,3 +1098,10 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
 }
 
 }  // namespace vf
+
+#ifdef VF_CHAIN_TRACE
+extern "C" int vf_debug_chain_trace(long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vf::vf_chain_trace), sizeof(long long) * 64, 0, hipMemcpyDeviceToHost);
+}
+#endif
