@@ -564,6 +564,10 @@ int vf_reparam_bwd(const float* d_action, const float* action, const float* log_
                    float* g_log_std, int32_t N, vf_stream_t stream);
 int vf_bptt_accumulate(const float* reward, const uint8_t* done, float* disc, float* loss, float* d_reward, float gamma,
                        float scale, int32_t N, vf_stream_t stream);
+/* the same bookkeeping fused with the state checkpoint of the NEXT step (tape_row <- slab, slab_floats floats, both 16-byte
+ * aligned): the two things the BPTT forward pass does between env step t and env step t + 1, as one launch */
+int vf_bptt_accumulate_checkpoint(const float* reward, const uint8_t* done, float* disc, float* loss, float* d_reward, float gamma,
+                                  float scale, int32_t N, const float* slab, float* tape_row, int64_t slab_floats, vf_stream_t stream);
 
 /* Squashed diagonal Gaussian head (SB3 SquashedDiagGaussianDistribution as used by
  * policies.py:114,177-181,195-226): a = tanh(mean + exp(log_std) * eps), eps ~ N(0,1) from

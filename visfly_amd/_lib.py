@@ -230,6 +230,7 @@ SIGNATURES = {
     "vf_reparam_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_bptt_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_int32, _vp]),
+    "vf_bptt_accumulate_checkpoint": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_int32, _vp, _vp, C.c_int64, _vp]),
     "vf_mlp_packed_floats": (C.c_int64, [C.POINTER(MlpDesc)]),
     "vf_mlp_pack_weights": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp]),
     "vf_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),

@@ -126,6 +126,7 @@ class BPTT:
         # per-horizon buffers in one allocation each; the exploration noise of the whole horizon is one draw
         acts, drews = th.empty((H, N, 4), device=dev), th.empty((H, N), device=dev)
         epss = th.randn((H, N, 4), device=dev, generator=self._gen)
+        ckpt_done = False
         for t in range(H):
             action = acts[t]
             o = {k: obs[k].detach().contiguous() for k in self.obs_keys}
@@ -133,10 +134,18 @@ class BPTT:
                 mean, _ = pol.forward(o, slot=t, need_value=False)
                 _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(epss[t]), _ptr(action), N, st))
             pre_obs = obs
-            obs, reward, done, _ = env._step_no_grad(action, False, record=True, borrow=True)   # acts[t] outlives the reverse sweep
+            obs, reward, done, _ = env._step_no_grad(action, False, record=True, borrow=True,   # acts[t] outlives the reverse sweep
+                                                     prefilled=ckpt_done)
             self._on_step(t, pre_obs, action, obs, reward, done, disc)
-            _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(drews[t]),
-                                            float(self.gamma), 1.0 / (N * self.world), N, st))
+            # loss / discount bookkeeping, fused with the state checkpoint of step t + 1 (one launch instead of two)
+            ckpt_done = t + 1 < H and env._tape_t < env._tape.shape[0]
+            if ckpt_done:
+                _lib.check(L.vf_bptt_accumulate_checkpoint(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(drews[t]),
+                                                           float(self.gamma), 1.0 / (N * self.world), N, _ptr(env._slab),
+                                                           _ptr(env._tape[env._tape_t]), env._slab.numel(), st))
+            else:
+                _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(drews[t]),
+                                                float(self.gamma), 1.0 / (N * self.world), N, st))
         g_obs = None
         d_means = th.empty((H, N, 4), device=dev)
         for t in reversed(range(H)):

@@ -1148,6 +1148,26 @@ __global__ __launch_bounds__(kBlock) void k_bptt_accumulate(const float* __restr
     disc[i] = d * gamma * (1.0f - dn) + dn;
 }
 
+// k_bptt_accumulate + the state checkpoint of the NEXT step (a plain slab -> tape row copy) in one launch: both sit between
+// env step t and env step t + 1 of the BPTT forward pass, one launch boundary (~5 us at 16 384 agents) instead of two
+__global__ __launch_bounds__(kBlock) void k_bptt_accumulate_checkpoint(const float* __restrict__ reward, const uint8_t* __restrict__ done,
+                                                                       float* __restrict__ disc, float* __restrict__ loss,
+                                                                       float* __restrict__ d_reward, float gamma, float scale, int N,
+                                                                       const float4* __restrict__ slab, float4* __restrict__ tape,
+                                                                       long long n4)
+{
+    const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x, stride = (long long)gridDim.x * kBlock;
+    for (long long j = tid; j < n4; j += stride) tape[j] = slab[j];
+    if (tid < N) {
+        const int i = (int)tid;
+        const float d = disc[i];
+        loss[i] = loss[i] + -1.0f * reward[i] * d;
+        d_reward[i] = -d * scale;
+        const float dn = done[i] ? 1.0f : 0.0f;
+        disc[i] = d * gamma * (1.0f - dn) + dn;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_fold_stats(const float* __restrict__ part, int nblk, float* __restrict__ stats,
                                                      float* __restrict__ d_log_std_out, float* __restrict__ stats_accum)
 {
@@ -1769,6 +1789,24 @@ int vf_bptt_accumulate(const float* reward, const uint8_t* done, float* disc, fl
     if (!reward || !done || !disc || !loss || !d_reward || N <= 0) return vf::fail(VF_EINVAL, "vf_bptt_accumulate: bad argument");
     hipLaunchKernelGGL(vf::k_bptt_accumulate, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done,
                        disc, loss, d_reward, gamma, scale, N);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_bptt_accumulate_checkpoint(const float* reward, const uint8_t* done, float* disc, float* loss, float* d_reward, float gamma,
+                                  float scale, int32_t N, const float* slab, float* tape_row, int64_t slab_floats, vf_stream_t stream)
+{
+    if (!reward || !done || !disc || !loss || !d_reward || N <= 0 || !slab || !tape_row || slab_floats <= 0 || (slab_floats & 3))
+        return vf::fail(VF_EINVAL, "vf_bptt_accumulate_checkpoint: bad argument");
+    if ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(tape_row)) & 15)
+        return vf::fail(VF_EINVAL, "vf_bptt_accumulate_checkpoint: slab and tape row must be 16-byte aligned");
+    const long long n4 = slab_floats / 4;
+    long long blocks = (n4 + vf::kBlock - 1) / vf::kBlock;
+    if (blocks < vf::blocks_for(N)) blocks = vf::blocks_for(N);
+    if (blocks > 4096) blocks = 4096;                    // grid-stride copy; 4096 x 256 threads cover the accumulate for N <= 1 M
+    if ((long long)N > blocks * vf::kBlock) return vf::fail(VF_EINVAL, "vf_bptt_accumulate_checkpoint: N too large for one launch");
+    hipLaunchKernelGGL(vf::k_bptt_accumulate_checkpoint, dim3((unsigned)blocks), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done,
+                       disc, loss, d_reward, gamma, scale, N, reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(tape_row), n4);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

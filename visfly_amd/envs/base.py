@@ -535,9 +535,10 @@ class DroneGymEnvsBase:
             return obs, reward, done, info
         return self._step_no_grad(_action, is_test)
 
-    def _step_no_grad(self, _action, is_test=False, record=False, borrow=False):
+    def _step_no_grad(self, _action, is_test=False, record=False, borrow=False, prefilled=False):
         # borrow (trainers that own their per-horizon buffers): the tape keeps a REFERENCE to the action tensor and the step's
-        # done flags are written straight into the tape row (returned as such) -- two device copies per step less
+        # done flags are written straight into the tape row (returned as such) -- two device copies per step less;
+        # prefilled: tape row `_tape_t` already holds the current slab (vf_bptt_accumulate_checkpoint after the previous step)
         assert self._is_initial, "You should call reset() before step()"
         N, dev = self.num_agent, self.device
         a = _action
@@ -576,7 +577,8 @@ class DroneGymEnvsBase:
             tape_t = self._tape_t
             if tape_t >= self._tape.shape[0]:
                 raise VisflyError("tape is full: call env.detach() (BPTT horizon exceeded)")
-            self._tape[tape_t].copy_(self._slab)
+            if not prefilled:          # prefilled: the caller's previous launch already checkpointed the slab into this row
+                self._tape[tape_t].copy_(self._slab)
             if borrow:
                 self._tape_action_ref[tape_t] = a
             else:
