@@ -79,3 +79,16 @@ def test_scene_answer_drives_collision_and_done():
         assert th.allclose(env.collision_point[alive], cp[alive])
         hits += int(hit.sum())
     assert hits > 0                                                           # the ball was actually hit
+
+
+def test_half_step_is_guarded():
+    from visfly_amd.envs.base import VisflyError
+    env = _mk(HoverEnv, 64)
+    a = th.zeros((64, 4), device="cuda")
+    with pytest.raises(VisflyError):
+        env.step_finish()
+    env.step_begin(a)
+    with pytest.raises(VisflyError):
+        env.step(a)
+    env.step_finish()
+    env.step(a)

@@ -463,6 +463,7 @@ class DroneGymEnvsBase:
     def reset(self, state=None, **_unused):
         """DroneGymEnvsBase.reset (droneGymEnv.py:302-327) -> observations"""
         self._is_initial = True
+        self._half_step = False
         if state is not None:
             fs = th.as_tensor(state, dtype=th.float32)
             if fs.shape != (self.num_agent, 22):
@@ -540,6 +541,8 @@ class DroneGymEnvsBase:
         # done flags are written straight into the tape row (returned as such) -- two device copies per step less;
         # prefilled: tape row `_tape_t` already holds the current slab (vf_bptt_accumulate_checkpoint after the previous step)
         assert self._is_initial, "You should call reset() before step()"
+        if self._half_step:
+            raise VisflyError("step(): step_begin() is waiting for its step_finish()")
         N, dev = self.num_agent, self.device
         a = _action
         if not (isinstance(a, th.Tensor) and a.is_cuda and a.dtype == th.float32 and a.dim() == 2
