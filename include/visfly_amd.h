@@ -227,6 +227,15 @@ int64_t vf_env_slab_floats(const vf_env* h);
 int vf_env_bind(vf_env* h, float* slab);
 vf_dyn* vf_env_dyn(vf_env* h);   /* embedded dynamics handle sharing the slab (DroneEnvsBase.dynamics) */
 
+/* Time-varying / per-agent wind (envs/base/dynamics.py:132-174,384-388: wind_settings given as strings are eval'ed into
+ * functions of (t, previous wind) and re-evaluated by update_wind() at the top of every step; the value then holds for the
+ * whole control interval and enters p' = v + wind and the velocity observation, :751-752).  The functions themselves are host
+ * code (user lambdas); the step kernels take their result: N rows of 4 floats (x, y, z, unused), 16-byte aligned device
+ * memory owned by the caller and rewritten by it before each step.  NULL returns to the constant vf_dyn_cfg.wind.  Works on
+ * the embedded handle of an env (vf_env_dyn) for vf_env_step / vf_env_finish_step / vf_env_export_pose; the adjoint kernel and
+ * the multi-step entry points (vf_env_step_n, vf_env_rollout_fused, vf_env_graph_*) see one wind for all their steps. */
+int vf_dyn_set_wind(vf_dyn* h, const float* wind_Nx4);
+
 /* DroneGymEnvsBase.reset / reset_agent_by_id (droneGymEnv.py:302-349, droneEnv.py:260-288).
  *   idx NULL: all agents.  full_state (k,22) = [p q v w motor thrust t] (dynamics.py:793-803)
  *   gives the spawn states (host-replayed randomizer, parity mode); NULL draws them on the

@@ -198,6 +198,11 @@ DYN_CASES = {
                                 integrator="euler", wind_settings=[0.5, -0.25, 0.125]), [-1 / 3, 0, 0, 0], 0.3),
     "dyn_bodyrate_rk4": (dict(action_type="bodyrate", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True,
                               integrator="rk4"), [-1 / 3, 0, 0, 0], 0.3),
+    # string wind functions (dynamics.py:132-174,384-388): two triples of expressions in x = t and y = previous value, re-evaluated
+    # at the top of every step.  Polynomials only: +, -, * round identically on the reference's CPU tensors and on GPU tensors
+    "dyn_wind_functions": (dict(action_type="bodyrate", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True, integrator="euler",
+                                wind_settings=["0.3 - 0.05*x", "0.02*x*x", "0.5*y + 0.1", "0*x + 0.125", "-0.01*x", "0.25*y - 0.05"]),
+                           [-1 / 3, 0, 0, 0], 0.3),
     # geometric controller: sin/cos/atan2 are SLEEF in torch -> tolerance-level fixtures.
     # velocity: command = [yaw (ignored), v / 10 m/s]; position: [yaw / pi, p / 10 m]
     "dyn_velocity_euler": (dict(action_type="velocity", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True,
@@ -233,6 +238,9 @@ def gen_dyn(name, N=128, steps=256, seed=1234):
         "raw_ext_last": raw[steps],                            # un-patched torch.sqrt reference
         "label": np.asarray("repaired-oracle" if "rk4" in name else "cr-sqrt-oracle"),
     }
+    if isinstance(kwargs.get("wind_settings", [0])[0], str):
+        save["wind_fn"] = np.asarray(kwargs["wind_settings"])
+        save["wind_last"] = f32(d.wind_velocity)              # (3,N) after the last step
     save.update({"c_" + k: v for k, v in consts.items()})
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 

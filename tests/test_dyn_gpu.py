@@ -200,3 +200,51 @@ def test_errors():
     d = Dynamics(num=8, device="cuda:0")
     with pytest.raises(ValueError):
         d.step(torch.zeros((7, 4), device="cuda"))
+
+
+def test_string_wind_functions_match_reference():
+    """wind_settings as six expression strings (dynamics.py:132-174,384-388): lambdas of (t, previous value) re-evaluated on
+    the host at the top of every step, their result handed to the kernel as per-agent rows (vf_dyn_set_wind).  Fixture
+    dyn_wind_functions from the reference's own Dynamics: state and step() return bit-exact over 256 steps."""
+    fx = load("dyn_wind_functions")
+    consts = consts_of(fx)
+    acts = decode_actions(fx)
+    N = fx["fs0"].shape[0]
+    dyn = make_dyn(consts, N, wind_settings=[str(s) for s in fx["wind_fn"]])
+    set_full_state(dyn, fx["fs0"])
+    cps = list(fx["checkpoints"])
+    acts_d = torch.from_numpy(acts).cuda()
+    for k in range(acts.shape[0]):
+        obs = dyn.step(acts_d[k])
+        if (k + 1) in cps:
+            j = cps.index(k + 1)
+            assert_bits_equal(dyn.extend_state.cpu().numpy(), fx["ext"][j], f"wind functions: extend_state @ {k + 1}")
+            assert_bits_equal(obs.cpu().numpy(), fx["obs"][j], f"wind functions: step() return @ {k + 1}")
+    assert_bits_equal(dyn.wind_velocity.cpu().numpy(), fx["wind_last"], "wind_velocity after the run")
+    with pytest.raises(NotImplementedError):
+        make_dyn(consts, 8, wind_settings=["0*x", "0*x", "0*x"])       # the reference's own constructor raises for this form
+
+
+def test_string_wind_functions_through_the_env_step():
+    """the fused env step takes the same rows: HoverEnv with wind functions == Dynamics.step on a twin + the velocity column"""
+    from visfly_amd.envs import HoverEnv
+    W = ["0.3 - 0.05*x", "0.02*x*x", "0.5*y + 0.1", "0*x + 0.125", "-0.01*x", "0.25*y - 0.05"]
+    kw = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True, wind_settings=W)
+    N = 300
+    env = HoverEnv(num_agent_per_scene=N, seed=5, dynamics_kwargs=kw, device="cuda:0", tensor_output=True, max_episode_steps=1000)
+    env.reset()
+    from visfly_amd import Dynamics
+    twin = Dynamics(num=N, device="cuda:0", **kw)
+    fs = env.full_state.cpu().numpy()
+    from visfly_amd._lib import G_VEL
+    fs[:, 7:10] = env.envs.dynamics._vec(G_VEL).cpu().numpy()      # full_state carries v + wind (dynamics.py:779-786); seed the raw one
+    set_full_state(twin, fs)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for k in range(20):
+        a = ((torch.rand((N, 4), device="cuda", generator=g) * 2 - 1) * 0.2 + torch.tensor([-1 / 3, 0, 0, 0], device="cuda")).contiguous()
+        obs, _, done, _ = env.step(a, is_test=True)
+        ref = twin.step(a)
+        assert_bits_equal(obs["state"].cpu().numpy(), ref.cpu().numpy(), f"env step with wind functions @ {k}")
+    assert float(env.envs.dynamics.wind_velocity.abs().max()) > 0.1
+    with pytest.raises(Exception):
+        env.step_n(torch.zeros((2, N, 4), device="cuda"))

@@ -210,6 +210,7 @@ SIGNATURES = {
     "vf_env_graph_launch": (C.c_int, [_vp, _vp]),
     "vf_env_graph_destroy": (None, [_vp]),
     "vf_env_export_pose": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "vf_dyn_set_wind": (C.c_int, [_vp, _vp]),
     "vf_env_finish_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(EnvOut), C.c_int32, _vp]),
     "vf_env_query": (C.c_int, [_vp, C.POINTER(EnvView), _vp]),
     "vf_env_time_steps": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, C.c_int32, _vp, C.POINTER(C.c_float)]),

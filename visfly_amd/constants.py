@@ -96,9 +96,12 @@ def derive_constants(
     T_init = -(m * g / 4)[-1]                                                 # :85
     w_init = rotor_omega(T_init)                                              # :86
 
-    wind = th.tensor(list(wind_settings)).reshape(3, 1) + th.zeros((3, 1))    # :135,172-174,388
-    if not all(isinstance(x, (int, float)) for x in wind_settings):
-        raise NotImplementedError("string wind functions are not supported on the MI355X hot path (SURVEY.md 8f-3)")
+    if len(wind_settings) and isinstance(wind_settings[0], str):
+        # string wind functions (:136-165): host lambdas of (t, previous wind), evaluated by Dynamics.update_wind() before every
+        # step; the kernels then take per-agent rows (vf_dyn_set_wind) and this constant is not used
+        wind = th.zeros((3, 1))
+    else:
+        wind = th.tensor(list(wind_settings)).reshape(3, 1) + th.zeros((3, 1))    # :135,172-174,388
 
     c = {
         "action_type": np.int32(ACTION_TYPES[action_type]),

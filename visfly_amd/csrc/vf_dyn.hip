@@ -33,6 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg* __restric
     float a[4], head_bits = 0.0f;
     ring_exchange(c, g, i, live, head_bits, a);   // issued first: its two loads are the first values the controller needs
     load_agent<false>(g.S, g.G, i, s, sp);
+    load_wind(c, g, i, live, s);
     if (c.delay_steps > 0) sp.vel = head_bits;
     float kl[3], kq[3];
     drag_of(c, g, i, kl, kq);
@@ -176,7 +177,8 @@ StepKernel pick_step_kernel(const vf_dyn_cfg& c)
 
 int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st)
 {
-    vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out, vf::ring_head(h)};
+    vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out, vf::ring_head(h),
+                  reinterpret_cast<const float4*>(h->wind)};
     h->tick += 1;
     if (vf::use_split(h->Npad, h->cfg))
         hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->d_cfg, g);
@@ -250,6 +252,14 @@ int vf_dyn_reset(vf_dyn* h, const int32_t* idx, int32_t k, const float* pos, con
     vf::ResetArgs r{h->N, h->Npad, n, h->G, h->g_drag, h->S, idx, pos, quat, vel, omg, mot, thr, t, t_rand, klin, kquad};
     hipLaunchKernelGGL(vf::k_dyn_reset, dim3(vf::blocks_for(n)), dim3(vf::kBlock), 0, st, h->cfg, r);
     VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_dyn_set_wind(vf_dyn* h, const float* wind_Nx4)
+{
+    if (!h) return vf::fail(VF_EINVAL, "vf_dyn_set_wind: null handle");
+    if (reinterpret_cast<uintptr_t>(wind_Nx4) & 15) return vf::fail(VF_EINVAL, "vf_dyn_set_wind: rows must be 16-byte aligned");
+    h->wind = wind_Nx4;
     return VF_OK;
 }
 

@@ -43,6 +43,7 @@ struct Agent {
     float aa[3];  // angular acceleration of the last sub-step
     float acc[3]; // linear acceleration of the last sub-step
     float t;
+    float wnd[3]; // wind velocity of this control interval: vf_dyn_cfg.wind, or the agent's row of vf_*_set_wind (not slab state)
 };
 
 // Hamilton product; term order and rounding of utils/maths.py:168-174
@@ -354,13 +355,13 @@ __device__ __forceinline__ void linear_acc(const vf_dyn_cfg& c, const Quat& q, c
 // translation: acc, then p and v advance (maths.py:310,344,346 / repaired rk4 :353-386)
 template <int INTEG>
 __device__ __forceinline__ void trans_substep(const vf_dyn_cfg& c, const Quat& q, float F, const float* kl, const float* kq,
-                                              float* p, float* v, float* acc)
+                                              const float* wind, float* p, float* v, float* acc)
 {
     linear_acc(c, q, v, F, kl, kq, acc);
     const float dt = c.dt;
     if constexpr (INTEG == VF_INT_EULER) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = p[k] + (v[k] + c.wind[k]) * dt;
+        for (int k = 0; k < 3; ++k) p[k] = p[k] + (v[k] + wind[k]) * dt;
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[k] = v[k] + acc[k] * dt;
     } else {
@@ -373,7 +374,7 @@ __device__ __forceinline__ void trans_substep(const vf_dyn_cfg& c, const Quat& q
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float vc = st == 0 ? v[k] : v[k] + acc[k] * h * dt;
-                const float kp = (vc + c.wind[k]) * ks, kv = acc[k] * ks;
+                const float kp = (vc + wind[k]) * ks, kv = acc[k] * ks;
                 sp[k] = st == 0 ? kp : sp[k] + kp;
                 sv[k] = st == 0 ? kv : sv[k] + kv;
             }
@@ -483,7 +484,7 @@ __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, 
     for (int sub = 0; sub < c.interval_steps; ++sub) {
         float ft[4];
         motor_substep<CTRL_DELAY>(c, Td, wd, s.wm, s.T, ft);
-        trans_substep<INTEG>(c, s.q, ft[0], kl, kq, s.p, s.v, s.acc);   // uses q of the sub-step start
+        trans_substep<INTEG>(c, s.q, ft[0], kl, kq, s.wnd, s.p, s.v, s.acc);   // uses q of the sub-step start
         rot_substep<INTEG>(c, ft + 1, s.q, s.w, s.aa);
     }
     finish_interval(c, s);
@@ -546,6 +547,7 @@ __device__ __forceinline__ void load_agent(float* __restrict__ S, int G, int i, 
     // issue order = order of first use: ring head (velocity granule) and the controller's inputs (body rates, angular
     // acceleration) first, then the rotors, then what the translation needs -- loads return in order, so the controller
     // and the ring exchange run while the tail of the burst is still in flight
+    s.wnd[0] = s.wnd[1] = s.wnd[2] = 0.0f;      // set by load_wind where the wind matters
     const float4 g2 = *granule(S, G, i, VF_G_VEL);
     const float4 g3 = *granule(S, G, i, VF_G_OMG);
     const float4 g6 = *granule(S, G, i, VF_G_AACC);
@@ -585,7 +587,18 @@ struct DynArgs {
     const float4* action;  // (N,4)
     float* obs;            // (N,13) or null
     int head;              // delay-ring slot of this launch (= every agent's head word; vf_handles.hpp)
+    const float4* wind = nullptr;   // per-agent wind of this control interval (N rows x,y,z,-; vf_*_set_wind) or null = vf_dyn_cfg.wind
 };
+
+// wind velocity of the interval (dynamics.py:320,384-388: update_wind() runs first in step(), the value holds for all sub-steps)
+__device__ __forceinline__ void load_wind(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, Agent& s)
+{
+    s.wnd[0] = c.wind[0]; s.wnd[1] = c.wind[1]; s.wnd[2] = c.wind[2];
+    if (g.wind && live) {
+        const float4 w = g.wind[i];
+        s.wnd[0] = w.x; s.wnd[1] = w.y; s.wnd[2] = w.z;
+    }
+}
 
 // Pops the oldest action of agent i from its ring slot and pushes the new one (dynamics.py:323-328).  The slot index is
 // launch-uniform (g.head = control steps since the last full reset mod delay_steps, kept by the host handle): the address is
@@ -625,7 +638,7 @@ __device__ __forceinline__ void obs_row(const vf_dyn_cfg& c, const Agent& s, flo
 {
     o[0] = s.p[0]; o[1] = s.p[1]; o[2] = s.p[2];
     o[3] = s.q.w; o[4] = s.q.x; o[5] = s.q.y; o[6] = s.q.z;
-    o[7] = s.v[0] + c.wind[0]; o[8] = s.v[1] + c.wind[1]; o[9] = s.v[2] + c.wind[2];
+    o[7] = s.v[0] + s.wnd[0]; o[8] = s.v[1] + s.wnd[1]; o[9] = s.v[2] + s.wnd[2];
     o[10] = s.w[0]; o[11] = s.w[1]; o[12] = s.w[2];
 }
 
@@ -730,6 +743,7 @@ __device__ __forceinline__ void split_translation_wave(const vf_dyn_cfg& c, cons
     const float4 g7 = *granule(g.S, g.G, i, VF_G_ACC);
     float kl[3], kq[3];
     drag_of(c, g, i, kl, kq);
+    load_wind(c, g, i, i < g.N, s);
     s.t = g0.x; s.p[0] = g0.y; s.p[1] = g0.z; s.p[2] = g0.w;
     s.v[0] = g2.y; s.v[1] = g2.z; s.v[2] = g2.w;
     s.acc[0] = g7.y; s.acc[1] = g7.z; s.acc[2] = g7.w;
@@ -742,7 +756,7 @@ __device__ __forceinline__ void split_translation_wave(const vf_dyn_cfg& c, cons
         const float(*x)[64] = sh.xq[sub & 1];
         const Quat q{x[0][l], x[1][l], x[2][l], x[3][l]};
         const float F = x[4][l];
-        trans_substep<INTEG>(c, q, F, kl, kq, s.p, s.v, s.acc);
+        trans_substep<INTEG>(c, q, F, kl, kq, s.wnd, s.p, s.v, s.acc);
     }
     __builtin_amdgcn_s_barrier();
     const float(*f)[64] = sh.fin;

@@ -66,7 +66,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
                                              Agent& s, Spares& sp, int wave_first, float* tile)
 {
     EnvRegs er = unpack_env(sp);
-    const float vel[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};  // dynamics.py:751-752
+    const float vel[3] = {s.v[0] + s.wnd[0], s.v[1] + s.wnd[1], s.v[2] + s.wnd[2]};  // dynamics.py:751-752
     Collision col = bbox_collision(e, s.p);
     if constexpr (EXT) {   // visual branch of update_collision (droneEnv.py:330-342,364-367): the scene manager's closest point
         if (g.ext_point && live) {
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     float a[4], head_bits = 0.0f;
     ring_exchange(c, g.d, i, live, head_bits, a);   // issued first: its two loads are the first values the controller needs
     load_agent<false>(g.d.S, g.d.G, i, s, sp);
+    load_wind(c, g.d, i, live, s);
     if (c.delay_steps > 0) sp.vel = head_bits;
     float kl[3], kq[3];
     drag_of(c, g.d, i, kl, kq);
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(kBlock) void k_env_finish(const vf_dyn_cfg* __restr
     Agent s;
     Spares sp;
     load_agent<false>(g.d.S, g.d.G, i, s, sp);
+    load_wind(c, g.d, i, live, s);
     const int wave = threadIdx.x >> 6;
     env_epilogue<KIND, true, true>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
 }
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(kBlock) void k_env_rollout(const vf_dyn_cfg* __rest
     float a[4], head_bits = 0.0f;
     ring_exchange(c, g.d, i, live, head_bits, a);   // issued first: its two loads are the first values the controller needs
     load_agent<false>(g.d.S, g.d.G, i, s, sp);
+    load_wind(c, g.d, i, live, s);
     // one launch = K control steps (vf_env_rollout_fused; a separate kernel from k_env_step: the loop-carried pointers cost the
     // single step ~1 us of register pressure / scheduling when both shared one body).  The agent lives in registers
     // across the steps; the delay ring, per-agent drag and racing granules go through memory as in the single step (a thread
@@ -384,7 +387,12 @@ __global__ __launch_bounds__(kBlock) void k_env_export_pose(const vf_dyn_cfg c, 
     const float4 g2 = *granule(d.S, d.G, i, VF_G_VEL), g3 = *granule(d.S, d.G, i, VF_G_OMG);
     if (pos) { float* o = pos + 3 * (size_t)i; o[0] = g0.y; o[1] = g0.z; o[2] = g0.w; }
     if (quat) *(reinterpret_cast<float4*>(quat) + i) = g1;
-    if (vel) { float* o = vel + 3 * (size_t)i; o[0] = g2.y + c.wind[0]; o[1] = g2.z + c.wind[1]; o[2] = g2.w + c.wind[2]; }   // dynamics.py:751-752
+    if (vel) {   // dynamics.py:751-752
+        float4 w = make_float4(c.wind[0], c.wind[1], c.wind[2], 0.0f);
+        if (d.wind) w = d.wind[i];
+        float* o = vel + 3 * (size_t)i;
+        o[0] = g2.y + w.x; o[1] = g2.z + w.y; o[2] = g2.w + w.z;
+    }
     if (omg) { float* o = omg + 3 * (size_t)i; o[0] = g3.y; o[1] = g3.z; o[2] = g3.w; }
 }
 
@@ -495,7 +503,7 @@ EnvKernel pick_env_kernel(const vf_env* h)
 vf::DynArgs dyn_args(const vf_env* h, const float* action, float* obs, int ahead = 0)
 {
     return vf::DynArgs{h->dyn.N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(action), obs,
-                       vf::ring_head(&h->dyn, ahead)};
+                       vf::ring_head(&h->dyn, ahead), reinterpret_cast<const float4*>(h->dyn.wind)};
 }
 
 // `ahead`: position of this launch in a sequence enqueued (or captured) before the handle's step counter advances

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg* __res
             const float nn = sqrtf(((s.q.w * s.q.w + s.q.x * s.q.x) + s.q.y * s.q.y) + s.q.z * s.q.z);
             s.q = qscale(s.q, 1.0f / nn);
         } else {   // repaired RK4: the forward kernels' own sub-step functions
-            trans_substep<VF_INT_RK4>(c, s.q, ft[0], kl, kq, s.p, s.v, s.acc);
+            trans_substep<VF_INT_RK4>(c, s.q, ft[0], kl, kq, c.wind, s.p, s.v, s.acc);
             rot_substep<VF_INT_RK4>(c, ft + 1, s.q, s.w, s.aa);
         }
     }

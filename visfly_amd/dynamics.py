@@ -6,6 +6,7 @@ return shapes, same properties.  State lives in ONE device slab ``[N/64][G][64][
 tiled per wavefront in 16-byte granules, include/visfly_amd.h); the public properties
 gather the requested components out of it.
 """
+import math
 from typing import List, Optional, Tuple, Union
 
 import numpy as np
@@ -80,7 +81,8 @@ class Dynamics:
 
         self.set_seed(seed)
         self._owns_handle = True
-        self._wind = th.as_tensor(np.asarray(c["wind"], np.float32), device=self.device).reshape(1, 3)
+        self._wind_const = th.as_tensor(np.asarray(c["wind"], np.float32), device=self.device).reshape(1, 3)
+        self._wind_fn = None
         if _attach is None:
             with th.cuda.device(self.device):
                 self._cfg = _lib.DynCfg.from_dict(c)
@@ -97,6 +99,43 @@ class Dynamics:
             self._h, self._slab, self._G = _attach
             self._cfg = _lib.DynCfg.from_dict(c)
             self._owns_handle = False
+        if len(wind_settings) and isinstance(wind_settings[0], str):
+            self._create_wind(wind_settings)
+
+    # ------------------------------------------------------------------ wind functions (dynamics.py:132-174,384-388)
+    def _create_wind(self, wind_settings):
+        """six strings = two (x, y, z) triples of expressions in x (= the agents' time, (N,)) and y (= the previous value of
+        that component, (N,)), eval'ed into lambdas exactly as the reference does -- arbitrary Python from the caller's config,
+        like there.  The reference's three-string form builds a 3-argument lambda and calls it with two (:159-165): it raises
+        TypeError inside its own constructor, so there is nothing to mirror."""
+        if len(wind_settings) == 3:
+            raise NotImplementedError("wind_settings with three strings cannot run in the reference (dynamics.py:159-165 builds "
+                                      "`lambda x,y,z` and update_wind calls it with two arguments); pass six strings")
+        if len(wind_settings) != 6:
+            raise ValueError("wind_settings should be a list of length 3 or 6, or a string function")           # :168
+        ns = {"th": th, "torch": th, "np": np, "math": math}
+        fn = [eval("lambda x,y:" + s, ns) for s in wind_settings]                                                 # :139-144
+        self._wind_fn = (fn[:3], fn[3:])
+        self._wind_1 = th.zeros((3, self.num), device=self.device)                                                # :172-173
+        self._wind_2 = th.zeros((3, self.num), device=self.device)
+        self._wind_rows = th.zeros((self.num, 4), device=self.device)
+        self.update_wind()                                                                                        # :174
+        _lib.check(_lib.lib().vf_dyn_set_wind(self._h, _lib.ptr(self._wind_rows)))
+
+    def update_wind(self):
+        """dynamics.py:384-388; runs at the top of every step (:320).  The result goes to the per-agent rows the kernels read."""
+        if self._wind_fn is None:
+            return
+        t = self.t
+        f1, f2 = self._wind_fn
+        self._wind_1 = th.stack([f1[0](t, self._wind_1[0]), f1[1](t, self._wind_1[1]), f1[2](t, self._wind_1[2])])
+        self._wind_2 = th.stack([f2[0](t, self._wind_2[0]), f2[1](t, self._wind_2[1]), f2[2](t, self._wind_2[2])])
+        self._wind_rows[:, :3] = (self._wind_1 + self._wind_2).T
+
+    @property
+    def _wind(self):
+        """(1,3) constant wind or (N,3) per-agent rows"""
+        return self._wind_const if self._wind_fn is None else self._wind_rows[:, :3]
     # ------------------------------------------------------------------ lifecycle
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -177,6 +216,7 @@ class Dynamics:
             if a.shape[0] != self.num:
                 raise ValueError(f"step: action must be ({self.num},4), got {tuple(a.shape)}")
             out = th.empty((self.num, 13), dtype=th.float32, device=self.device)
+            self.update_wind()                                                              # :320
             _lib.check(_lib.lib().vf_dyn_step(self._h, _lib.ptr(a), _lib.ptr(out), self._stream()))
             self._last_action = a
         return out
@@ -268,7 +308,7 @@ class Dynamics:
 
     @property
     def wind_velocity(self):
-        return self._wind.T.expand(3, self.num)
+        return self._wind.T.expand(3, self.num)                 # (3,N) as the reference's attribute
 
     @property
     def is_quat_output(self):

@@ -543,6 +543,10 @@ class DroneGymEnvsBase:
         assert self._is_initial, "You should call reset() before step()"
         if self._half_step:
             raise VisflyError("step(): step_begin() is waiting for its step_finish()")
+        if self.envs.dynamics._wind_fn is not None:
+            if self._tape is not None:
+                raise NotImplementedError("string wind functions have no adjoint (the tape does not record the wind rows)")
+            self.envs.dynamics.update_wind()                                                # dynamics.py:320
         N, dev = self.num_agent, self.device
         a = _action
         if not (isinstance(a, th.Tensor) and a.is_cuda and a.dtype == th.float32 and a.dim() == 2
@@ -633,6 +637,8 @@ class DroneGymEnvsBase:
             raise VisflyError("step_n: a BPTT tape is recording (requires_grad / enable_tape); use step()")
         if getattr(self, "_HOST_OBS", False):
             raise VisflyError(f"step_n: {type(self).__name__} assembles its observation on the host per step; use step()")
+        if self.envs.dynamics._wind_fn is not None:
+            raise VisflyError("step_n: string wind functions are re-evaluated on the host before every step; use step()")
         N, dev = self.num_agent, self.device
         a = actions
         if not (isinstance(a, th.Tensor) and a.is_cuda and a.dtype == th.float32 and a.is_contiguous()):
