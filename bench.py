@@ -96,8 +96,16 @@ def cpu_baseline_env(consts, kind, N, seconds_target=15.0, threads=None, note=No
     return out
 
 
+# The reference itself (PyTorch CPU) cannot travel to the GPU box; its own numbers were recorded once in the build container
+# (SURVEY.md section 6, 8-core Xeon 2.1 GHz, torch 2.10 CPU, 8 threads) and ride along for orientation (last row)
+REFERENCE_RECORDED = {"where": "build container, 8-core Xeon 2.1 GHz, torch 2.10 CPU, 8 threads (SURVEY.md section 6); not measured on this box",
+                      "Dynamics.step_agent_steps_per_s@N=65536": 1.21e6, "HoverEnv.step_agent_steps_per_s@N=65536": 2.92e5}
+
+
 def cpu_baseline(consts, seconds_target=15.0, threads=None):
-    return cpu_baseline_env(consts, "hover", AGENTS_PER_GPU, seconds_target, threads)
+    out = cpu_baseline_env(consts, "hover", AGENTS_PER_GPU, seconds_target, threads)
+    out["reference_recorded"] = REFERENCE_RECORDED
+    return out
 
 
 def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
