@@ -248,3 +248,13 @@ def test_string_wind_functions_through_the_env_step():
     assert float(env.envs.dynamics.wind_velocity.abs().max()) > 0.1
     with pytest.raises(Exception):
         env.step_n(torch.zeros((2, N, 4), device="cuda"))
+
+
+def test_set_wind_argument_checks():
+    from visfly_amd import _lib
+    dyn = make_dyn(consts_of(load("dyn_bodyrate_euler")), 64)
+    rows = torch.zeros((65, 4), device="cuda")
+    assert _lib.lib().vf_dyn_set_wind(dyn._h, _lib.ptr(rows.view(-1)[1:])) == -1      # VF_EINVAL: not 16-byte aligned
+    assert _lib.lib().vf_dyn_set_wind(None, _lib.ptr(rows)) == -1
+    assert _lib.lib().vf_dyn_set_wind(dyn._h, _lib.ptr(rows)) == 0
+    assert _lib.lib().vf_dyn_set_wind(dyn._h, None) == 0                                          # back to the constant wind

@@ -409,3 +409,19 @@ def test_imu_noise_replay_mode_matches_reference():
     with pytest.raises(NotImplementedError):
         HoverEnv(num_agent_per_scene=4, dynamics_kwargs=dict(ENV_DYN), device="cuda:0",
                  random_kwargs=dict(rk, noise_kwargs={"IMU": {"model": "GaussianNoiseModel", "kwargs": {"mean": 0, "std": 1}}}))
+
+
+def test_racing_gate_entry_switch():
+    """obs_gate_exact=False (what trainers set when their policy does not read "gate"): the returned entry is the env's
+    current index, no per-step bookkeeping; True (default): the reference's returned entry (checked against the fixture above)"""
+    from visfly_amd.envs import RacingEnv
+    fx = load("env_racing")
+    env = RacingEnv(num_agent_per_scene=256, seed=3, dynamics_kwargs=dict(RACING_DYN), device="cuda:0", tensor_output=True,
+                    max_episode_steps=64, gates=fx["gates"].tolist())
+    env.obs_gate_exact = False
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(40):
+        a = ((torch.rand((256, 4), device="cuda", generator=g) * 2 - 1) * 0.08 - 0.8333).clamp(-1, 1)
+        obs, _, _, _ = env.step(a)
+        assert torch.equal(obs["gate"], env._next_target_i)
