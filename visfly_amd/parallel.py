@@ -79,25 +79,47 @@ def native_comm(force: bool = False):
     if not force and (w == 1 or dist.get_backend() != "nccl"):
         return None
     import ctypes as C
+    import warnings
     from . import _lib
     L = _lib.lib()
-    try:
+
+    def agreed(ok: bool) -> bool:
+        """every rank must take the same path (one rank on torch.distributed and the others on the native communicator would
+        hang in their first all-reduce): logical AND over the ranks through the bootstrap process group"""
+        if w == 1:
+            return ok
+        flag = th.tensor([1 if ok else 0], dtype=th.int32, device=th.device("cuda", th.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    why, h = None, None
+    ident = (C.c_uint8 * 128)()
+    try:                                    # phase 1, local: find RCCL, rank 0 draws the id
         _lib.check(L.vf_comm_library(_rccl_path().encode()))
-        ident = (C.c_uint8 * 128)()
         if rank() == 0:
             _lib.check(L.vf_comm_unique_id(ident))
-        if w > 1:
-            box = [bytes(ident)]
-            dist.broadcast_object_list(box, src=0)
-            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
-        h = _lib._vp()
-        _lib.check(L.vf_comm_init(ident, w, rank(), C.byref(h)))
-        _native["comm"] = h
     except Exception as e:  # noqa: BLE001
-        import warnings
-        warnings.warn(f"visfly_amd: native RCCL communicator unavailable ({e}); gradient all-reduce goes through "
+        why = e
+    if agreed(why is None):
+        try:                                # phase 2, collective: id to everybody, ncclCommInitRank
+            if w > 1:
+                box = [bytes(ident)]
+                dist.broadcast_object_list(box, src=0)
+                ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            h = _lib._vp()
+            _lib.check(L.vf_comm_init(ident, w, rank(), C.byref(h)))
+        except Exception as e:  # noqa: BLE001
+            why, h = e, None
+        if not agreed(h is not None):
+            if h is not None:
+                L.vf_comm_destroy(h)
+            h, why = None, why or RuntimeError("another rank could not create its communicator")
+    else:
+        why = why or RuntimeError("another rank could not load RCCL")
+    if h is None:
+        warnings.warn(f"visfly_amd: native RCCL communicator unavailable ({why}); gradient all-reduce goes through "
                       "torch.distributed (same RCCL collective, Python dispatch)")
-        _native["comm"] = None
+    _native["comm"] = h
     return _native["comm"]
 
 
