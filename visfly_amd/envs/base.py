@@ -707,6 +707,8 @@ class DroneGymEnvsBase:
         self._action = a
         self.envs.dynamics.step(a)                                                          # droneEnv.py:375
         self._qcache = self._imu_cache = self._ext_col = None
+        if hasattr(self, "_g_obs"):
+            self._g_obs = None              # RacingEnv: the split step reports the env's current gate index
         self._half_step = True
         return self.export_pose(pose_out)
 
