@@ -247,6 +247,7 @@ def main():
     ap.add_argument("--agents", type=int, default=AGENTS_PER_GPU, help="agents per GPU")
     ap.add_argument("--chunk", type=int, default=16, help="steps per vf_env_step_n call = depth of the (K,N,...) output ring (16 x 3.6 MB stays in the Infinity Cache; profiles/r02_reset_regime.txt)")
     ap.add_argument("--no-reset-leg", action="store_true", help="skip the U(-1,1) reset-heavy leg (kernel-trace profiles of the headline regime)")
+    ap.add_argument("--spinup-ms", type=float, default=25.0, help="untimed device spin-up before the warm-up steps (clock governor); 0 = off")
     ap.add_argument("--repeats", type=int, default=7, help="the timed --steps region is repeated; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
@@ -313,6 +314,14 @@ def main():
             env.step_n(s if k == s.shape[0] else s[:k])
             done += k
 
+    # Device spin-up, disclosed as timing.spinup_steps: the driver's W = 5 warm-up steps last 60 us, the GPU's clock governor needs
+    # ~20 ms of load to leave its idle state (a 20-step region right after process start runs at 12.85 us per step, the same region
+    # after 2 000 untimed steps at 12.1 -- `--spinup-ms 0` switches this off).  Untimed, before the W warm-up steps; the timed
+    # regions below still consist of exactly K steps each.
+    spin = int(args.spinup_ms * 1e3 / 11.0)
+    if spin > 0:
+        run_steps(spin, seq)
+        torch.cuda.synchronize()
     if W > 0:
         run_steps(W, wseq)
     run_steps(min(K, 64), seq)                            # first use of the K-step output buffers is an allocation
@@ -437,7 +446,9 @@ def main():
                        "host_us_per_step": statistics.median(hosts) / K * 1e6,
                        "event_us_per_step": statistics.median(events) / K * 1e6,
                        "wall_over_kernel": el / K * 1e6 / kern_us, "per_call": per_call,
-                       "episode_end_rate": end_rate, "steps_with_a_reset": steps_with_reset},
+                       "episode_end_rate": end_rate, "steps_with_a_reset": steps_with_reset,
+                       "spinup_steps": spin, "spinup_note": "untimed env steps before the W warm-up steps so that the device is at "
+                                                            "its sustained clocks (--spinup-ms, default 25 ms)"},
             "with_resets": with_resets,
             "rollout_fused": {"value": world * N * K / fused_el, "unit": "agent-steps/s", "us_per_step": fused_el / K * 1e6,
                               "driver": "env.step_n(fused=True): the K steps of the region in ONE launch (vf_env_rollout_fused), agents "
