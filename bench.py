@@ -325,15 +325,20 @@ def main():
     if W > 0:
         run_steps(W, wseq)
     run_steps(min(K, 64), seq)                            # first use of the K-step output buffers is an allocation
-    walls, hosts, events = [], [], []
+    walls, hosts, events, done_at = [], [], [], []
     for _ in range(max(1, args.repeats)):          # wall clock: nothing but the K launches between the two barriers
         barrier()
         t0 = time.perf_counter()
         run_steps(K, seq)
         t1 = time.perf_counter()
-        drain()                                    # this rank's K steps are done: its clock stops here ...
-        el = time.perf_counter() - t0
-        barrier()                                  # ... the closing barrier follows, and the MAX over ranks is what is reported
+        tail.record()                              # drain(), with a time stamp in the middle:
+        while not tail.query():
+            pass
+        t2 = time.perf_counter()                   # ... the K steps have completed (the event behind them reports it) ...
+        torch.cuda.synchronize()                   # ... and the synchronize the contract asks for has returned:
+        el = time.perf_counter() - t0              # this rank's clock stops here
+        done_at.append(t2 - t0)
+        barrier()                                  # the closing barrier follows, and the MAX over ranks is what is reported
         if dist is not None:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -380,7 +385,12 @@ def main():
                 "driver": "Python loop over env.step(), out_buffers=4"}
 
     # dominant kernel, HIP events on the launch stream (BEFORE the reset-heavy leg below desynchronises the episodes)
-    kern_us = env.time_steps(pool[0], iters=300)
+    # kernel_us = HIP events over the timed K-step regions (median of the three event-bracketed repeats above): K launches back to
+    # back on one stream, so events / K is the average launch duration plus whatever gap the launches leave (>= the kernel alone).
+    # The second figure is 300 launches of ONE action from vf_env_time_steps -- same kernel, but the constant action lets agents
+    # drift out of the box at different times, so part of it runs in the re-spawn regime (see with_resets).
+    kern_us = statistics.median(events) / K * 1e6
+    kern_us_300 = env.time_steps(pool[0], iters=300)
     dyn.time_steps(pool[0], iters=20)               # first use of k_dyn_step in this process: code load (~1 ms) stays out of the mean
     dyn_us = dyn.time_steps(pool[0], iters=300)
     assert torch.isfinite(dyn.state).all()
@@ -447,6 +457,10 @@ def main():
                        "event_us_per_step": statistics.median(events) / K * 1e6,
                        "wall_over_kernel": el / K * 1e6 / kern_us, "per_call": per_call,
                        "episode_end_rate": end_rate, "steps_with_a_reset": steps_with_reset,
+                       "ms_per_step_at_completion": statistics.median(done_at) / K * 1e3,
+                       "completion_note": "the same regions with the clock read when the event recorded behind the K launches reports "
+                                          "completion, i.e. without the ~20 us torch.cuda.synchronize() takes to return on an already "
+                                          "idle device (1 us per step at --steps 20); rank 0's figure",
                        "spinup_steps": spin, "spinup_note": "untimed env steps before the W warm-up steps so that the device is at "
                                                             "its sustained clocks (--spinup-ms, default 25 ms)"},
             "with_resets": with_resets,
@@ -457,6 +471,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_env_step<hover,bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
+                         "kernel_us_source": "HIP events on the launch stream over the timed K-step regions / K (median of 3)",
+                         "kernel_us_300_launches_one_action": kern_us_300,
                          "bytes_per_agent_step": BYTES_PER_ENV_STEP, "valu_issue": valu,
                          "note": "bound by the contract's definition (algorithmic HBM bytes / launch time); the launch is in fact "
                                  "limited by single-wave VALU issue (valu_issue) plus ~4 us of launch boundary and state round "
