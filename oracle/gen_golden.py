@@ -483,6 +483,8 @@ def gen_env(name, N=128, seed=42):
             rec["is_out_bounds"].append(env.is_out_bounds.clone().numpy().astype(np.uint8))
         rec["success"].append(env._success.clone().numpy().astype(np.uint8))
         rec["obs_state"].append(f32(o["state"]))
+        if "collision_vector" in o:      # NavigationEnv2's second observation entry, as returned
+            rec.setdefault("obs_cv", []).append(f32(o["collision_vector"]))
         if "gate" in o:      # the gate index INSIDE the returned observation (not always env._next_target_i, see visfly_amd/envs/tasks.py)
             rec.setdefault("obs_gate", []).append(o["gate"].clone().numpy().astype(np.int32).reshape(N, -1))
             for i in didx:   # and inside the terminal observation of the agents that ended an episode in this step
@@ -511,6 +513,9 @@ def gen_env(name, N=128, seed=42):
         "spawn": np.asarray(repr(kw.get("random_kwargs", "hover-default"))),
         "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle"),
     }
+    if "obs_cv" in rec:
+        save["obs_cv"] = np.stack(rec["obs_cv"])
+        save["obs0_cv"] = f32(obs0["collision_vector"])
     if "obs_gate" in rec:
         save["obs_gate"] = np.stack(rec["obs_gate"])
         save["obs0_gate"] = np.asarray(obs0["gate"]).astype(np.int32).reshape(N, -1)

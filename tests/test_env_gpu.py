@@ -55,6 +55,8 @@ def test_env_replay_mode_matches_reference_run(name):
     obs0 = env.reset()
     assert_bits_equal(env.full_state.cpu().numpy(), fx["fs_init"], f"{name} spawn states")
     assert_bits_equal(obs0["state"].cpu().numpy(), fx["obs0_state"], f"{name} reset() observation")
+    if "obs0_cv" in fx:
+        assert_bits_equal(obs0["collision_vector"].cpu().numpy(), fx["obs0_cv"], f"{name} reset() collision_vector entry")
     if str(fx["kind"]) == "racing":
         assert np.array_equal(obs0["gate"].cpu().numpy(), fx["obs0_gate"][:, 0]), f"{name} reset() gate entry (the stale one)"
     keep = list(fx["keep_steps"])
@@ -77,6 +79,8 @@ def test_env_replay_mode_matches_reference_run(name):
             assert info[i0]["TimeLimit.truncated"] == bool(fx["step_count"][k][i0] >= int(fx["max_episode_steps"]))
         if k in keep:
             assert_bits_equal(obs["state"].cpu().numpy(), fx["obs_state_keep"][keep.index(k)], f"{name} obs @ {k}")
+        if "obs_cv" in fx:      # NavigationEnv2: the collision_vector entry of the returned observation
+            assert_bits_equal(obs["collision_vector"].cpu().numpy(), fx["obs_cv"][k], f"{name} collision_vector obs @ {k}")
         if str(fx["kind"]) == "racing":
             # the index INSIDE the returned observation (pre-pass unless some agent ended its episode in the step), and the env's own
             assert np.array_equal(obs["gate"].cpu().numpy(), fx["obs_gate"][k][:, 0]), f"{name} gate obs @ {k}"
