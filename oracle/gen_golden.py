@@ -470,6 +470,14 @@ def gen_env(name, N=128, seed=42):
             fs = f32(dyn.full_state)
             for i in didx:
                 ev_step.append(k); ev_agent.append(i); ev_fs.append(fs[i])
+                # what collect_info put into the info dict of the finished episode (droneGymEnv.py:238-275)
+                ep = info[i]["episode"]
+                rec.setdefault("ev_r", []).append(np.float32(ep["r"])); rec.setdefault("ev_l", []).append(np.int32(ep["l"]))
+                rec.setdefault("ev_t", []).append(np.float32(ep["t"]))
+                rec.setdefault("ev_tobs", []).append(f32(info[i]["terminal_observation"]["state"]))
+                rec.setdefault("ev_flags", []).append(np.uint8(int(bool(info[i]["is_success"])) | (int(bool(info[i]["TimeLimit.truncated"])) << 1)
+                                                               | (int(bool(info[i]["episode_done"])) << 2)
+                                                               | (int(bool(ep["extra"]["collision"])) << 3)))
         rec["reward"].append(f32(r)); rec["done"].append(d.numpy().astype(np.uint8))
         if pre:
             rec["step_count"].append(pre["step_count"].astype(np.int32))
@@ -513,6 +521,9 @@ def gen_env(name, N=128, seed=42):
         "spawn": np.asarray(repr(kw.get("random_kwargs", "hover-default"))),
         "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle"),
     }
+    if "ev_r" in rec:
+        save.update(ev_r=np.asarray(rec["ev_r"], np.float32), ev_l=np.asarray(rec["ev_l"], np.int32), ev_t=np.asarray(rec["ev_t"], np.float32),
+                    ev_tobs=np.stack(rec["ev_tobs"]), ev_flags=np.asarray(rec["ev_flags"], np.uint8))
     if "obs_cv" in rec:
         save["obs_cv"] = np.stack(rec["obs_cv"])
         save["obs0_cv"] = f32(obs0["collision_vector"])

@@ -77,6 +77,22 @@ def test_env_replay_mode_matches_reference_run(name):
             i0 = int(idx[0])
             assert info[i0]["episode"]["l"] == fx["step_count"][k][i0]
             assert info[i0]["TimeLimit.truncated"] == bool(fx["step_count"][k][i0] >= int(fx["max_episode_steps"]))
+            # everything collect_info (droneGymEnv.py:238-275) put into the info dict of EVERY episode that ended in this step
+            for j in np.nonzero(sel)[0]:
+                d = info[int(fx["ev_agent"][j])]
+                ep = d["episode"]
+                if is_nav:      # the episode return sums rewards that carry the acos tolerance
+                    assert abs(float(ep["r"]) - float(fx["ev_r"][j])) <= 2e-6 + 2e-6 * abs(float(fx["ev_r"][j])), f"{name} episode r @ {k}"
+                else:
+                    assert_bits_equal(np.float32(ep["r"]), fx["ev_r"][j], f"{name} episode r @ {k}")
+                assert int(ep["l"]) == int(fx["ev_l"][j])
+                assert_bits_equal(np.float32(ep["t"]), fx["ev_t"][j], f"{name} episode t @ {k}")
+                got = (int(bool(d["is_success"])) | (int(bool(d["TimeLimit.truncated"])) << 1) | (int(bool(d["episode_done"])) << 2)
+                       | (int(bool(ep["extra"]["collision"])) << 3))
+                assert got == int(fx["ev_flags"][j]), f"{name} info flags @ {k}: {got} vs {int(fx['ev_flags'][j])}"
+                tob = d["terminal_observation"]["state"]
+                tob = tob.cpu().numpy() if hasattr(tob, "cpu") else np.asarray(tob)
+                assert_bits_equal(tob, fx["ev_tobs"][j], f"{name} terminal observation @ {k}")
         if k in keep:
             assert_bits_equal(obs["state"].cpu().numpy(), fx["obs_state_keep"][keep.index(k)], f"{name} obs @ {k}")
         if "obs_cv" in fx:      # NavigationEnv2: the collision_vector entry of the returned observation
@@ -116,10 +132,14 @@ def test_racing2_replay_matches_reference_run():
             assert_bits_equal(obs["state"].cpu().numpy(), fx["obs_state_keep"][keep.index(k)], f"racing2 obs @ {k}")
         sel = fx["ev_step"] == k
         if sel.any():
-            for i, want in zip(fx["ev_agent"][sel], fx["ev_tgate"][np.nonzero(sel)[0]]):
-                t = info[int(i)]["terminal_observation"]
+            for j in np.nonzero(sel)[0]:
+                d = info[int(fx["ev_agent"][j])]
+                t = d["terminal_observation"]
                 assert t["state"].shape == (16,) and t["gate"].shape == (1,)
-                assert int(t["gate"][0]) == int(want), f"racing2 terminal gate @ {k}"
+                assert int(t["gate"][0]) == int(fx["ev_tgate"][j]), f"racing2 terminal gate @ {k}"
+                assert_bits_equal(t["state"].cpu().numpy(), fx["ev_tobs"][j], f"racing2 terminal observation @ {k}")
+                assert_bits_equal(np.float32(d["episode"]["r"]), fx["ev_r"][j], f"racing2 episode r @ {k}")
+                assert int(d["episode"]["l"]) == int(fx["ev_l"][j])
             checked_terminal += 1
     assert checked_terminal > 0
     with pytest.raises(Exception):
