@@ -238,6 +238,11 @@ def gen_dyn(name, N=128, steps=256, seed=1234):
         "raw_ext_last": raw[steps],                            # un-patched torch.sqrt reference
         "label": np.asarray("repaired-oracle" if "rk4" in name else "cr-sqrt-oracle"),
     }
+    # derived read-outs of the duck type at the last step: direction = body x axis (maths.py:123-133), Euler angles
+    # (maths.py:244-249), accelerations and rotor state as the properties return them (dynamics.py:745-777)
+    save.update(prop_direction=f32(d.direction), prop_euler=f32(d._orientation.toEuler().T), prop_acc=f32(d.acceleration),
+                prop_ang_acc=f32(d.angular_acceleration), prop_motor_omega=f32(d.motor_omega), prop_thrusts=f32(d.thrusts),
+                prop_t=f32(d.t), prop_velocity=f32(d.velocity))
     if isinstance(kwargs.get("wind_settings", [0])[0], str):
         save["wind_fn"] = np.asarray(kwargs["wind_settings"])
         save["wind_last"] = f32(d.wind_velocity)              # (3,N) after the last step

@@ -258,3 +258,31 @@ def test_set_wind_argument_checks():
     assert _lib.lib().vf_dyn_set_wind(None, _lib.ptr(rows)) == -1
     assert _lib.lib().vf_dyn_set_wind(dyn._h, _lib.ptr(rows)) == 0
     assert _lib.lib().vf_dyn_set_wind(dyn._h, None) == 0                                          # back to the constant wind
+
+
+def test_property_readouts_match_reference():
+    """the read-outs DroneEnvsBase / the trainers take from the Dynamics duck type (dynamics.py:735-786) after the
+    256-step run of a fixture with wind: arithmetic ones bit-exact, Euler angles (atan2 / asin on GPU tensors) to 1e-6"""
+    fx = load("dyn_bodyrate_dt005")
+    consts = consts_of(fx)
+    acts = decode_actions(fx)
+    N = fx["fs0"].shape[0]
+    dyn = make_dyn(consts, N)
+    set_full_state(dyn, fx["fs0"])
+    acts_d = torch.from_numpy(acts).cuda()
+    for k in range(acts.shape[0]):
+        dyn.step(acts_d[k])
+    n = lambda t: t.cpu().numpy()
+    assert_bits_equal(n(dyn.direction), fx["prop_direction"], "direction")
+    assert_bits_equal(n(dyn.acceleration), fx["prop_acc"], "acceleration")
+    assert_bits_equal(n(dyn.angular_acceleration), fx["prop_ang_acc"], "angular_acceleration")
+    assert_bits_equal(n(dyn.motor_omega), fx["prop_motor_omega"], "motor_omega")
+    assert_bits_equal(n(dyn.thrusts), fx["prop_thrusts"], "thrusts")
+    assert_bits_equal(n(dyn.t), fx["prop_t"], "t")
+    assert_bits_equal(n(dyn.velocity), fx["prop_velocity"], "velocity (incl. wind)")
+    eul = make_dyn(consts, N, ori_output_type="euler")
+    set_full_state(eul, fx["fs0"])
+    for k in range(acts.shape[0]):
+        eul.step(acts_d[k])
+    assert np.abs(n(eul.orientation) - fx["prop_euler"]).max() <= 1e-6
+    assert eul.state.shape == (N, 12) and not eul.is_quat_output
