@@ -27,7 +27,8 @@ extern "C" {
 #define VF_ABI_VERSION 4   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
-                              4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_ppo_loss_cfg.old_value /
+                              4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_dyn_set_wind,
+                                 vf_bptt_accumulate_checkpoint, vf_ppo_loss_cfg.old_value /
                                  clip_range_vf, vf_comm_* / vf_allreduce_grads (RCCL) */
 
 typedef void* vf_stream_t;
