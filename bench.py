@@ -239,6 +239,21 @@ def _with_watchdog(fn, seconds, what):
     return box["out"], False
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this very command line as N ranks (one per GPU) under
+    torch.distributed.run on the loopback address -- what the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` does.
+    Rank 0 of the children prints the ONE JSON line; the parent only forwards the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,9 +268,23 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
     ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt"],
                     help="env: fused HoverEnv.step (the BASELINE metric, default); ppo / bptt: that loop only")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins the process group, one barrier, rank 0 prints the world size "
+                         "(no GPU work; tests/test_parallel_gloo.py runs the plain `--gpus 2` command through it on CPU)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))
 
     from visfly_amd import parallel
+    if args.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group(os.environ.get("VISFLY_AMD_DIST_BACKEND", "gloo"))
+        assert dist.get_world_size() == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={dist.get_world_size()}"
+        dist.barrier()
+        if dist.get_rank() == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size()}), flush=True)
+        dist.destroy_process_group()
+        return
     # RCCL in production; VISFLY_AMD_DIST_BACKEND=gloo lets the N > 1 control flow be exercised on a box with fewer GPUs than
     # ranks (ranks then share devices round-robin) -- used by tests/test_parallel_gpu.py, never by the driver
     backend = os.environ.get("VISFLY_AMD_DIST_BACKEND", "nccl")

@@ -60,3 +60,21 @@ def test_shard_edges():
     assert parallel.shard(10, 0, 1) == (0, 10)
     assert [parallel.shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
     assert sum(parallel.shard(262144, r, 8)[1] for r in range(8)) == 262144
+
+
+def test_bench_plain_command_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver starts the N = 1 run): bench.py re-runs itself
+    as 2 ranks under torch.distributed.run on 127.0.0.1 and rank 0 prints ONE line -- rendezvous only (--launch-check, gloo);
+    the GPU variant of the same command is tests/test_parallel_gpu.py::test_bench_two_ranks_control_flow[plain]"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VISFLY_AMD_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": True, "n_gpus": 2}, r.stdout[-2000:]

@@ -107,17 +107,24 @@ def test_native_rccl_communicator_single_rank():
     assert L.vf_comm_init(ident, 2, 5, C.byref(h)) == -1          # rank outside the world
 
 
-def test_bench_two_ranks_control_flow():
-    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run), with the exchange over gloo because the
-    test box has one GPU: barrier + max-over-ranks timing, ONE JSON line from rank 0, whole-job value"""
+@pytest.mark.parametrize("launcher", ["torchrun", "plain"])
+def test_bench_two_ranks_control_flow(launcher):
+    """bench.py --gpus 2 both ways the driver may start it -- under torch.distributed.run, and as the plain
+    `python bench.py --gpus 2` (bench.py then spawns its own ranks, bench._self_launch) -- with the exchange over gloo because
+    the test box has one GPU: barrier + max-over-ranks timing, ONE JSON line from rank 0, whole-job value"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VISFLY_AMD_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "200",
-           "--warmup", "20", "--agents", "16384"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20", "--agents", "16384"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29900 + os.getpid() % 90)] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -516,10 +516,9 @@ def test_fused_ppo_update_equals_separate_launches(net, B):
     assert torch.allclose(g1[pol.log_std_off:], g0[pol.log_std_off:], rtol=1e-4, atol=1e-7)
 
 
-def test_evaluation_harness_runs_one_episode_per_agent():
-    """utils/evaluate.py:57-129 (numeric part): deterministic actions until every agent finished an episode"""
+def test_predict_is_deterministic_and_bounded():
+    """SB3 ``predict(obs, deterministic=True)`` as evaluation harnesses call it (utils/evaluate.py:94): a = tanh(mean)"""
     from visfly_amd.envs import HoverEnv
-    from visfly_amd.evaluate import TestBase
     from visfly_amd.ppo import PPO
     from _golden import ENV_DYN
     env = HoverEnv(num_agent_per_scene=256, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=48, tensor_output=True)
@@ -527,10 +526,6 @@ def test_evaluation_harness_runs_one_episode_per_agent():
     a0, _ = ppo.predict(env.reset(), deterministic=True)
     a1, _ = ppo.predict(env.get_observation(), deterministic=True)
     assert torch.equal(a0, a1) and a0.shape == (256, 4) and float(a0.abs().max()) <= 1.0
-    tb = TestBase(ppo, env)
-    mean_r, mean_l = tb.test()
-    assert len(tb.eq_r) == 256 and 1 <= mean_l <= 48 and mean_r == mean_r
-    assert len(tb.reward_all) == len(tb.action_all) == len(tb.state_all) - 1 <= 48
 
 
 def test_gather_rows_equals_index_select():
