@@ -24,12 +24,14 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 4   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
+#define VF_ABI_VERSION 5   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
                               4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_dyn_set_wind,
                                  vf_bptt_accumulate_checkpoint, vf_ppo_loss_cfg.old_value /
-                                 clip_range_vf, vf_comm_* / vf_allreduce_grads (RCCL) */
+                                 clip_range_vf, vf_comm_* / vf_allreduce_grads (RCCL);
+                              5: vf_dyn_ring_phase / vf_dyn_set_ring_phase / vf_env_set_ring_phase, capture guard on
+                                 vf_dyn_step / vf_env_step */
 
 typedef void* vf_stream_t;
 
@@ -127,6 +129,19 @@ int vf_dyn_bind(vf_dyn* h, float* slab);
 /* Dynamics.step (envs/base/dynamics.py:319-372): one control interval, all sub-steps fused.
  *   action  (N,4) AoS in [-1,1];  state_out (N,13) AoS [p, q wxyz, v+wind, w] or NULL. */
 int vf_dyn_step(vf_dyn* h, const float* action, float* state_out, vf_stream_t stream);
+
+/* Delay-ring phase.  The comm-delay queue (dynamics.py:322-327) is a ring of delay_steps slots per agent; every agent pushes
+ * once per step, so all agents share one head = control steps since the last full reset mod delay_steps.  The HANDLE keeps
+ * that count on the host and passes the slot index with each launch (the per-agent head word in the slab is still written,
+ * for the adjoint's tape).  Two consequences for callers that bypass the handle's bookkeeping:
+ *   - a slab restored from a snapshot (or bound to a handle other than the one that stepped it) must be followed by
+ *     vf_dyn_set_ring_phase / vf_env_set_ring_phase with the phase the snapshot was taken at (vf_*_ring_phase);
+ *     vf_dyn_bind / vf_env_bind leave the phase alone;
+ *   - a vf_dyn_step / vf_env_step launch captured into a caller's hipGraph (or torch CUDA graph) would bake ONE slot index
+ *     into the graph and every replay would pop and push that same slot: with delay_steps > 1 both entry points therefore
+ *     return VF_ESTATE while `stream` is capturing.  Use vf_env_graph_create (one graph per phase, checked at launch). */
+int32_t vf_dyn_ring_phase(const vf_dyn* h);
+int vf_dyn_set_ring_phase(vf_dyn* h, int32_t phase);
 
 /* Dynamics.reset (envs/base/dynamics.py:218-269).
  *   idx == NULL: full reset, arrays hold N rows in agent order; else k indexed agents.
@@ -281,6 +296,7 @@ int vf_env_rollout_fused(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
  * delay_steps one graph serves every replay, else keep one graph per phase. */
 typedef struct vf_env_graph vf_env_graph;
 int32_t vf_env_ring_phase(const vf_env* h);
+int vf_env_set_ring_phase(vf_env* h, int32_t phase);   /* see vf_dyn_set_ring_phase */
 int vf_env_graph_create(vf_env* h, const vf_env_rollout* r, vf_env_graph** out);
 int vf_env_graph_launch(vf_env_graph* g, vf_stream_t stream);
 void vf_env_graph_destroy(vf_env_graph* g);
@@ -326,7 +342,9 @@ int vf_env_time_steps(vf_env* h, const float* action, const vf_env_out* out, int
  *                adjoint w.r.t. the state AFTER the step, on exit w.r.t. the state BEFORE it
  *   d_action     (N,4) out: dLoss/d(action)
  * Euler and (repaired) RK4 integrators, thrust / bodyrate actions, Hover / Racing (hover-style terms) and
- * NavigationEnv rewards; anything else returns VF_EINVAL. */
+ * NavigationEnv rewards; anything else returns VF_EINVAL.  With per-agent wind rows set (vf_dyn_set_wind) the call returns
+ * VF_EUNSUPPORTED: the tape does not record the rows, and replaying the interval with the constant wind would differentiate a
+ * different trajectory. */
 typedef struct vf_env_bwd_args {
     const float* tape_slab; const float* action; const float* d_obs; const float* d_reward;
     const uint8_t* done; float* adj_slab; float* d_action;

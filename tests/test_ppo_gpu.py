@@ -642,3 +642,23 @@ def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
     for k in bufs[0]:
         assert torch.equal(bufs[0][k], bufs[1][k]), k
     assert float((bufs[0]["rewards"].abs() > 0).float().mean()) > 0.5
+
+
+def test_ppo_on_a_host_observation_env_values_its_own_terminal_rows():
+    """RacingEnv2 hands the policy 16 gate-relative columns assembled on the host: the TimeLimit bootstrap must value THOSE rows
+    (env._terminal_state_rows()), not the kernel's raw 13-column terminal state (the width was hard-coded)"""
+    from visfly_amd.envs import RacingEnv2
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    env = RacingEnv2(num_agent_per_scene=512, seed=4, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=9, tensor_output=True)
+    ppo = PPO(env, n_steps=24, batch_size=2048, n_epochs=1, seed=1)
+    assert ppo.policy.obs_dims["state"] == 16 and ppo.defer_bootstrap is False
+    ppo.collect_rollouts()
+    torch.cuda.synchronize()
+    rows = env._terminal_state_rows()
+    assert rows.shape == (512, 16)
+    assert float(ppo._ep_stats[0]) >= 512 * 2                     # every agent is truncated at least twice in 24 steps
+    assert torch.isfinite(ppo.buf.rewards).all() and torch.isfinite(ppo.buf.advantages).all()
+    ppo.train()
+    assert torch.isfinite(ppo.policy.flat).all()
+    env.close()

@@ -70,7 +70,7 @@ class DynCfg(C.Structure):
 
 
 EUNSUPPORTED = -4         # VF_EUNSUPPORTED
-ABI_VERSION = 4          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
+ABI_VERSION = 5          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
 MAX_GATES, MAX_SPAWN = 8, 4
 
 
@@ -205,6 +205,9 @@ SIGNATURES = {
     "vf_env_step": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, _vp]),
     "vf_env_step_n": (C.c_int, [_vp, C.POINTER(EnvRollout), _vp]),
     "vf_env_ring_phase": (C.c_int32, [_vp]),
+    "vf_env_set_ring_phase": (C.c_int, [_vp, C.c_int32]),
+    "vf_dyn_ring_phase": (C.c_int32, [_vp]),
+    "vf_dyn_set_ring_phase": (C.c_int, [_vp, C.c_int32]),
     "vf_env_rollout_fused": (C.c_int, [_vp, C.POINTER(EnvRollout), _vp]),
     "vf_env_graph_create": (C.c_int, [_vp, C.POINTER(EnvRollout), C.POINTER(_vp)]),
     "vf_env_graph_launch": (C.c_int, [_vp, _vp]),

@@ -233,7 +233,16 @@ int vf_dyn_step(vf_dyn* h, const float* action, float* state_out, vf_stream_t st
 {
     if (!h || !action) return vf::fail(VF_EINVAL, "vf_dyn_step: null handle or action");
     if (!h->S) return vf::fail(VF_ESTATE, "vf_dyn_step: vf_dyn_bind has not been called");
+    if (int rc = vf::refuse_capture(h, vf::as_stream(stream), "vf_dyn_step")) return rc;
     return launch_step(h, action, state_out, vf::as_stream(stream));
+}
+
+int32_t vf_dyn_ring_phase(const vf_dyn* h) { return h ? vf::ring_head(h) : 0; }
+
+int vf_dyn_set_ring_phase(vf_dyn* h, int32_t phase)
+{
+    if (!h) return vf::fail(VF_EINVAL, "vf_dyn_set_ring_phase: null handle");
+    return vf::set_ring_phase(h, phase, "vf_dyn_set_ring_phase");
 }
 
 int vf_dyn_reset(vf_dyn* h, const int32_t* idx, int32_t k, const float* pos, const float* quat, const float* vel,

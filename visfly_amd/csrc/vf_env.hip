@@ -591,6 +591,7 @@ int vf_env_step(vf_env* h, const float* action, const vf_env_out* out, int32_t a
     if (!h || !action || !out) return vf::fail(VF_EINVAL, "vf_env_step: null argument");
     if (!out->obs || !out->reward || !out->done) return vf::fail(VF_EINVAL, "vf_env_step: obs, reward and done outputs are required");
     if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_step: vf_env_bind has not been called");
+    if (int rc = vf::refuse_capture(&h->dyn, vf::as_stream(stream), "vf_env_step")) return rc;
     if (int rc = launch_env_step(h, action, out, auto_reset, vf::as_stream(stream))) return rc;
     h->dyn.tick += 1;
     return VF_OK;
@@ -636,6 +637,12 @@ int vf_env_step_n(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
 }
 
 int32_t vf_env_ring_phase(const vf_env* h) { return h ? vf::ring_head(&h->dyn) : 0; }
+
+int vf_env_set_ring_phase(vf_env* h, int32_t phase)
+{
+    if (!h) return vf::fail(VF_EINVAL, "vf_env_set_ring_phase: null handle");
+    return vf::set_ring_phase(&h->dyn, phase, "vf_env_set_ring_phase");
+}
 
 int vf_env_rollout_fused(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
 {

@@ -574,6 +574,9 @@ extern "C" int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* a, vf_stream_t 
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: unknown integrator");
     if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: the HoverEnv2 / NavigationEnv2 observation and reward variants have no adjoint");
+    if (h->dyn.wind)
+        return vf::fail(VF_EUNSUPPORTED, "vf_env_step_bwd: per-agent wind rows are set (vf_dyn_set_wind); the adjoint replays the "
+                                         "interval with the constant vf_dyn_cfg.wind and would differentiate another trajectory");
     const int S = h->dyn.cfg.interval_steps;
     if (S > 10) return vf::fail(VF_EINVAL, "vf_env_step_bwd: at most 10 sub-steps per control interval (LDS budget)");
     const size_t lds = (size_t)S * vf::kSave * vf::kBlock * sizeof(float);

@@ -76,4 +76,28 @@ inline int ring_head(const vf_dyn* h, int ahead = 0)
     return h->cfg.delay_steps > 0 ? (int)((h->tick + ahead) % h->cfg.delay_steps) : 0;
 }
 
+// vf_dyn_step / vf_env_step inside somebody else's stream capture: the launch would bake one ring slot into the graph
+inline int refuse_capture(const vf_dyn* h, hipStream_t st, const char* who)
+{
+    if (h->cfg.delay_steps <= 1) return VF_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return VF_OK;
+    }
+    if (cs != hipStreamCaptureStatusNone)
+        return fail(VF_ESTATE, "%s: the stream is capturing and delay_steps = %d: a captured launch bakes ONE delay-ring slot "
+                               "into the graph (every replay would reuse it).  Use vf_env_graph_create / vf_env_graph_launch",
+                    who, h->cfg.delay_steps);
+    return VF_OK;
+}
+
+inline int set_ring_phase(vf_dyn* h, int phase, const char* who)
+{
+    const int D = h->cfg.delay_steps;
+    if (phase < 0 || (D > 0 ? phase >= D : phase != 0)) return fail(VF_EINVAL, "%s: phase %d outside [0, %d)", who, phase, D > 0 ? D : 1);
+    h->tick = phase;
+    return VF_OK;
+}
+
 }  // namespace vf

@@ -399,6 +399,11 @@ class DroneGymEnvsBase:
         the env's obs_mode); envs that assemble their observation on the host override this"""
         return tobs[i]
 
+    def _terminal_state_rows(self):
+        """(N, w) "state" rows of the terminal observations in the env's own observation map, valid where `done` was set by the
+        last step (what a trainer values for the TimeLimit bootstrap); the step kernel writes them in obs_mode already"""
+        return self._terminal_obs
+
     def _state_obs(self, raw_state):
         """observation "state" from the raw (N,13) dynamics state; the step kernel applies the same map on the
         device (vf_env_cfg.obs_mode), this host version only runs after resets"""

@@ -227,5 +227,8 @@ class RacingEnv2(RacingEnv):
         raw = tobs[i].reshape(1, 13).to(self.device)
         return self._race_state(raw, self._terminal_gate[i].reshape(1))[0]
 
+    def _terminal_state_rows(self):
+        return self._race_state(self._terminal_obs, self._terminal_gate)
+
     def _terminal_static_obs(self, i):
         return {"gate": self._terminal_gate[i].reshape(1)}

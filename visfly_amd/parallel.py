@@ -101,26 +101,65 @@ def native_comm(force: bool = False):
     except Exception as e:  # noqa: BLE001
         why = e
     if agreed(why is None):
-        try:                                # phase 2, collective: id to everybody, ncclCommInitRank
+        try:                                # phase 2, collective: the id goes to everybody ...
             if w > 1:
                 box = [bytes(ident)]
                 dist.broadcast_object_list(box, src=0)
                 ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
-            h = _lib._vp()
-            _lib.check(L.vf_comm_init(ident, w, rank(), C.byref(h)))
+                if not any(ident):
+                    raise RuntimeError("rank 0 sent an empty ncclUniqueId")
         except Exception as e:  # noqa: BLE001
-            why, h = e, None
-        if not agreed(h is not None):
-            if h is not None:
-                L.vf_comm_destroy(h)
-            h, why = None, why or RuntimeError("another rank could not create its communicator")
+            why = e
+        # ... and only when EVERY rank holds it does anybody enter ncclCommInitRank (a rank that raised above would leave the
+        # others blocked inside the init for ever); the init itself runs under a watchdog for the same reason
+        if agreed(why is None):
+            import threading
+            box2 = {}
+            dev_index = th.cuda.current_device()
+
+            def init():
+                try:
+                    th.cuda.set_device(dev_index)
+                    hh = _lib._vp()
+                    _lib.check(L.vf_comm_init(ident, w, rank(), C.byref(hh)))
+                    box2["h"] = hh
+                except Exception as e:  # noqa: BLE001
+                    box2["why"] = e
+
+            t = threading.Thread(target=init, daemon=True)
+            t.start()
+            t.join(float(os.environ.get("VISFLY_AMD_COMM_INIT_TIMEOUT", "180")))
+            if t.is_alive():
+                why = RuntimeError("ncclCommInitRank did not return (another rank never entered it?)")
+            else:
+                h, why = box2.get("h"), box2.get("why")
+            if not agreed(h is not None):
+                if h is not None:
+                    L.vf_comm_destroy(h)
+                h, why = None, why or RuntimeError("another rank could not create its communicator")
+        else:
+            why = why or RuntimeError("another rank did not receive the communicator id")
     else:
         why = why or RuntimeError("another rank could not load RCCL")
     if h is None:
         warnings.warn(f"visfly_amd: native RCCL communicator unavailable ({why}); gradient all-reduce goes through "
                       "torch.distributed (same RCCL collective, Python dispatch)")
     _native["comm"] = h
+    if h is not None and not _native.get("atexit"):
+        import atexit
+        _native["atexit"] = True
+        atexit.register(_destroy_native)
     return _native["comm"]
+
+
+def _destroy_native():
+    h, _native["comm"] = _native["comm"], None
+    if h is not None:
+        try:
+            from . import _lib
+            _lib.lib().vf_comm_destroy(h)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def allreduce_sum_(t: th.Tensor) -> th.Tensor:

@@ -714,7 +714,9 @@ class PPO:
         self.lr, self.weight_decay, self.adam_eps, self.betas = learning_rate, weight_decay, adam_eps, betas
         self.normalize_advantage, self.target_kl, self.seed = normalize_advantage, target_kl, seed
         self.clip_range_vf = clip_range_vf                          # PPO.py:237-243; None = no value clipping
-        self.defer_bootstrap, self._boot = True, None                # TimeLimit bootstrap valued once per rollout (collect_rollouts)
+        # TimeLimit bootstrap valued once per rollout (collect_rollouts) from the terminal rows the step kernel wrote; envs that
+        # assemble their observation on the host (RacingEnv2: 16 gate-relative columns) have no such kernel rows -> valued per step
+        self.defer_bootstrap, self._boot = not getattr(env, "_HOST_OBS", False), None
         self._last_obs = None
         if not getattr(env, "_is_initial", False):
             self._last_obs = env.reset()
@@ -764,7 +766,8 @@ class PPO:
             cap = (N * per_agent + 8191) // 8192 * 8192
             w1 = self.policy.obs_dims.get("target", 0) if "target" in self.obs_keys else 0
             self._boot = {"cap": cap, "cursor": th.zeros(1, dtype=th.int32, device=dev), "idx": th.zeros(cap, dtype=th.int32, device=dev),
-                          "rows0": th.zeros((cap, 13), device=dev), "rows1": th.zeros((cap, w1), device=dev) if w1 else None,
+                          "rows0": th.zeros((cap, self.policy.obs_dims["state"]), device=dev),
+                          "rows1": th.zeros((cap, w1), device=dev) if w1 else None,
                           "stat": th.zeros((N, 4), device=dev)}
         self._boot["cursor"].zero_()
         self._boot["stat"].zero_()
@@ -832,15 +835,17 @@ class PPO:
             # TimeLimit.truncated bootstrap: SB3 adds gamma * V(terminal_observation) where the info says truncated.  Deferred:
             # the few truncated rows of this step are appended to a compact list, valued once after the loop
             nxt = buf.episode_starts[t + 1] if t + 1 < self.n_steps else self._last_starts
+            trows = env._terminal_state_rows()               # (N, w) in the env's observation map, w = the policy's row width
+            assert trows.shape[1] == pol.obs_dims["state"], (trows.shape, pol.obs_dims)
             if self.defer_bootstrap:
                 o1 = obs["target"] if "target" in self.obs_keys else None
                 _lib.check(L.vf_rollout_post_collect(_ptr(reward), done.data_ptr(), _ptr(env._ep_flags), _ptr(buf.rewards[t]), _ptr(nxt),
-                                                     _ptr(env._terminal_obs), _ptr(o1), 13, 0 if o1 is None else o1.shape[1],
+                                                     _ptr(trows), _ptr(o1), trows.shape[1], 0 if o1 is None else o1.shape[1],
                                                      bs["cursor"].data_ptr(), bs["cap"], bs["idx"].data_ptr(), _ptr(bs["rows0"]),
                                                      _ptr(bs["rows1"]), t * N, N, _ptr(env._ep_return), env._ep_length.data_ptr(),
                                                      _ptr(bs["stat"]), self._stream()))
             else:
-                tobs = {"state": env._terminal_obs}
+                tobs = {"state": trows.contiguous()}
                 if "target" in self.obs_keys:
                     tobs["target"] = obs["target"]
                 _, tv = pol.forward(tobs, save_activations=False)
