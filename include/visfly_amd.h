@@ -31,7 +31,7 @@ extern "C" {
                                  vf_bptt_accumulate_checkpoint, vf_ppo_loss_cfg.old_value /
                                  clip_range_vf, vf_comm_* / vf_allreduce_grads (RCCL);
                               5: vf_dyn_ring_phase / vf_dyn_set_ring_phase / vf_env_set_ring_phase, capture guard on
-                                 vf_dyn_step / vf_env_step */
+                                 vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update */
 
 typedef void* vf_stream_t;
 
@@ -410,7 +410,11 @@ int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, 
  * the weights come from the packed copy below as the MFMA B operand (two workgroups per CU), fp32 MFMA.
  * Buffers are numbered: 0..3 = the observation inputs (global, row-major, width in_dim[i]);
  * 4.. = LDS activation regions laid out by the host (offset / row stride in floats, stride odd);
- * VF_MLP_OUT0 / VF_MLP_OUT1 = the global outputs (mean (M,4), value (M,1)). */
+ * VF_MLP_OUT0 / VF_MLP_OUT1 = the global outputs (row-major (M, No) of the layer that writes them: mean (M,4) and value (M,1)
+ * for the actor-critic policy, mu / log_std (M,4) for the SHAC actor, Q1 / Q2 (M,1) for the twin critic).
+ * A layer whose K is not a multiple of 16 and whose source is an LDS buffer (a concatenation such as features (+) action,
+ * td_policies.py:137) must read the TAIL of that buffer (src_col + K = its width): the kernel zero-fills the columns
+ * [src_col + K, src_col + round16(K)) of the LDS copy, which the 16-step MFMA sweep reads against zero weights. */
 #define VF_MLP_MAX_LAYERS 16
 #define VF_MLP_MAX_BUFS 12
 enum { VF_MLP_OUT0 = 100, VF_MLP_OUT1 = 101 };
@@ -674,6 +678,38 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * already maps (PyTorch ships its own copy).
  * ===================================================================================== */
 #define VF_COMM_ID_BYTES 128
+/* ---- SHAC (utils/algorithms/shac.py:215-278; actor / twin critic of utils/policies/td_policies.py:82-252) -----------------
+ * The networks are vf_mlp_desc layer tables like the PPO policy's (actor: two 4-wide heads mu / log_std over one extractor;
+ * critic: features (+) action -> two Q trunks, the action columns entering through a frozen identity layer); the env step and
+ * its adjoint are vf_env_step / vf_env_step_bwd; TD-lambda is vf_td_returns.  What is left of one iteration:
+ *   vf_shac_head_fwd    action = tanh(mu + eps * exp(clamp(log_std, min, max)))   rows (N,4)   (td_policies.py:230-243 +
+ *                       SB3 SquashedDiagGaussianDistribution.sample: Normal(mu, exp(log_std)).rsample(), tanh)
+ *   vf_shac_head_bwd    its reverse: d_mu = d_action (1 - action^2), d_log_std = d_mu eps exp(log_std) inside the clamp
+ *                       interval (closed, like torch.clamp), 0 outside
+ *   vf_shac_accumulate  one horizon step of the actor objective INCLUDING the bootstrap term (shac.py:247-257):
+ *                       next_value = min(q0, q1); loss -= reward disc; loss -= next_value disc gamma [(done | last_step) &
+ *                       ~episode_done]; d_reward = -disc scale; disc = disc gamma ~done + done; writes the buffer rows
+ *                       next_value_row (N,) and ep_done_row (N,) = done & (ep_flags & VF_EP_EPISODE_DONE) (shac.py:231-232)
+ *   vf_twin_q_loss      loss_out[0] = sum((min(q0, q1) - target)^2) / M_global (mse_loss(target, values), :269) and its
+ *                       gradient: dq_k = 2 (values - target) / M_global for the head that is the minimum (ties: q0), else 0;
+ *                       scratch: vf_twin_q_loss_scratch_doubles(M) doubles.  M_global = rows summed over all ranks
+ *   vf_polyak_update    target = target (1 - tau) + tau param   (SB3 polyak_update as shac.py:274 calls it) */
+int vf_shac_head_fwd(const float* mu, const float* log_std, const float* eps, float* action, int32_t N, float log_std_min,
+                     float log_std_max, vf_stream_t stream);
+int vf_shac_head_bwd(const float* d_action, const float* action, const float* log_std, const float* eps, float* d_mu,
+                     float* d_log_std, int32_t N, float log_std_min, float log_std_max, vf_stream_t stream);
+int vf_shac_accumulate(const float* reward, const uint8_t* done, const uint8_t* ep_flags, const float* q0, const float* q1,
+                       float* disc, float* loss, float* d_reward, float* next_value_row, uint8_t* ep_done_row, float gamma,
+                       float scale, int32_t last_step, int32_t N, vf_stream_t stream);
+int64_t vf_twin_q_loss_scratch_doubles(int32_t M);
+int vf_twin_q_loss(const float* q0, const float* q1, const float* target, float* dq0, float* dq1, float* loss_out,
+                   double* scratch, int32_t M, int64_t M_global, vf_stream_t stream);
+int vf_polyak_update(float* target, const float* param, int64_t n, double tau, vf_stream_t stream);
+
+/* test hook: fills the LDS of every CU with NaNs (tests/test_shac_gpu.py: layer tables with widths that are not multiples of
+ * the 16-step MFMA chunk must not depend on what a previous kernel left in LDS) */
+int vf_debug_poison_lds(vf_stream_t stream);
+
 typedef struct vf_comm vf_comm;
 int vf_comm_library(const char* path);
 int vf_comm_unique_id(uint8_t* id /* VF_COMM_ID_BYTES, host */);

@@ -1,0 +1,87 @@
+"""CPU side of the SHAC golden (tests/golden/shac_hover.npz from the reference's own learn() loop, oracle/gen_shac.py):
+the oracle's TD-lambda is bit-identical to the buffer's returns, the actor-loss recurrence incl. the bootstrap term
+(shac.py:247-257) and the twin-Q objective (:267-270) restated in a few lines of numpy / torch reproduce the recorded
+scalars and the recorded critic gradient from the recorded parameters -- i.e. the fixture's parameter layout and every
+quantity the GPU test (tests/test_shac_gpu.py) compares against mean what that test assumes."""
+import numpy as np
+import torch
+
+import oracle
+from _golden import load
+
+
+def test_oracle_td_lambda_is_the_buffers_returns():
+    fx = load("shac_hover")
+    ret = oracle.td_returns(fx["buf_reward"], fx["buf_done"], fx["buf_next_value"], fx["buf_episode_done"], 0.99, float(fx["lamda"]))
+    assert np.array_equal(ret.view(np.uint32), fx["buf_returns"].view(np.uint32))
+    assert fx["buf_done"].sum() > fx["buf_episode_done"].sum() > 0            # truncations AND true episode ends in the horizon
+
+
+def test_actor_loss_recurrence_with_bootstrap():
+    fx = load("shac_hover")
+    H, N = fx["buf_reward"].shape
+    g = np.float32(float(fx["gamma"]))
+    loss, disc = np.zeros(N, np.float32), np.ones(N, np.float32)
+    for t in range(H):
+        done, epd = fx["buf_done"][t].astype(bool), fx["buf_episode_done"][t].astype(bool)
+        loss = loss - fx["buf_reward"][t] * disc
+        cut = (done | (t == H - 1)) & ~epd
+        loss = loss - fx["buf_next_value"][t] * disc * g * cut.astype(np.float32)
+        disc = disc * g * (~done).astype(np.float32) + done.astype(np.float32)
+    assert abs(float(loss.mean()) - float(fx["actor_loss"])) <= 1e-6
+    # without the bootstrap term the value is a different one: the recorded scalar DOES include it
+    plain = -(fx["buf_reward"] * 1.0).sum(0).mean()
+    assert abs(float(plain) - float(fx["actor_loss"])) > 1e-3
+
+
+def _critic(params, obs, act):
+    """extractor 13 -> 128 -> 64, cat action, two Q MLPs 68 -> 64 -> 64 -> 1; layout: per layer weight [No][K] then bias"""
+    p, off = torch.from_numpy(params).double().requires_grad_(True), 0
+
+    def lin(x, K, No, relu=True):
+        nonlocal off
+        w, b = p[off:off + K * No].view(No, K), p[off + K * No:off + K * No + No]
+        off += K * No + No
+        y = x @ w.T + b
+        return torch.relu(y) if relu else y
+
+    f = lin(lin(obs, 13, 128), 128, 64)
+    x = torch.cat([f, act], dim=1)
+    qs = []
+    for _ in range(2):
+        qs.append(lin(lin(lin(x, 68, 64), 64, 64), 64, 1, relu=False))
+    assert off == params.size
+    return p, qs
+
+
+def test_twin_q_objective_and_gradient_from_recorded_parameters():
+    fx = load("shac_hover")
+    H, N = fx["buf_reward"].shape
+    obs = torch.from_numpy(fx["buf_obs"].reshape(H * N, 13)).double()
+    act = torch.from_numpy(fx["buf_action"].reshape(H * N, 4)).double()
+    target = torch.from_numpy(fx["buf_returns"].reshape(-1)).double()
+    for i in range(int(fx["gradient_steps"])):
+        params = fx["critic_params0"] if i == 0 else fx["critic_params"][i - 1]
+        p, (q0, q1) = _critic(params, obs, act)
+        values = torch.cat([q0, q1], dim=1).min(dim=1)[0]
+        loss = torch.nn.functional.mse_loss(target, values)
+        assert abs(float(loss.detach()) - float(fx["critic_loss"][i])) <= 2e-6
+        loss.backward()
+        want = fx["critic_grad"][i]
+        assert np.abs(p.grad.numpy() - want).max() <= 2e-5 * np.abs(want).max()
+    # Polyak: target_i = (1 - tau) target_{i-1} + tau critic_i
+    tau = float(fx["tau"])
+    t = fx["critic_params0"].astype(np.float64)
+    for i in range(int(fx["gradient_steps"])):
+        t = (1 - tau) * t + tau * fx["critic_params"][i]
+        assert np.abs(t - fx["target_params"][i]).max() <= 2e-7
+
+
+def test_adam_step_of_the_actor_from_the_recorded_gradient():
+    fx = load("shac_hover")
+    g = fx["actor_grad"].astype(np.float64)
+    norm = np.linalg.norm(g)
+    g = g * min(1.0, 0.5 / (norm + 1e-6))                                   # clip_grad_norm_(0.5)
+    m, v = 0.1 * g, 0.001 * g * g
+    step = float(fx["lr"]) * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)
+    assert np.abs(fx["actor_params0"] - step - fx["actor_params1"]).max() <= 2e-7

@@ -204,6 +204,13 @@ SIGNATURES = {
     "vf_env_reset": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     "vf_env_step": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, _vp]),
     "vf_env_step_n": (C.c_int, [_vp, C.POINTER(EnvRollout), _vp]),
+    "vf_shac_head_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_float, C.c_float, _vp]),
+    "vf_shac_head_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_float, C.c_float, _vp]),
+    "vf_shac_accumulate": (C.c_int, [_vp] * 10 + [C.c_float, C.c_float, C.c_int32, C.c_int32, _vp]),
+    "vf_twin_q_loss_scratch_doubles": (C.c_int64, [C.c_int32]),
+    "vf_twin_q_loss": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int64, _vp]),
+    "vf_polyak_update": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, _vp]),
+    "vf_debug_poison_lds": (C.c_int, [_vp]),
     "vf_env_ring_phase": (C.c_int32, [_vp]),
     "vf_env_set_ring_phase": (C.c_int, [_vp, C.c_int32]),
     "vf_dyn_ring_phase": (C.c_int32, [_vp]),

@@ -75,12 +75,7 @@ class BPTT:
         self.obs_keys = [k for k in obs.keys() if k in ("state", "target")]
         if hasattr(env, "obs_gate_exact"):       # RacingEnv: the policy does not read "gate"; skip its per-step bookkeeping launches
             env.obs_gate_exact = False
-        pk = checkpoint.policy_kwargs_from_reference(policy_kwargs, self.obs_keys)
-        self.weight_decay = pk.get("weight_decay", self.weight_decay)
-        self.policy = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},
-                                pk.get("extractor", {k: [128, 64] for k in self.obs_keys}), pk.get("pi", [64, 64]),
-                                pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed,
-                                ortho_init=pk.get("ortho_init", True))
+        self.policy = self._make_policy(obs, policy_kwargs, seed)
         self.policy.lazy_pack = True        # this trainer calls mark_updated() after every optimiser step
         self.world, self.rank = parallel.world_size(), parallel.rank()
         # same initial parameters on every rank (only gradients are exchanged afterwards), different exploration noise
@@ -96,6 +91,15 @@ class BPTT:
         self._opt_step = 0
         self.num_timesteps = 0
         self.logs: Dict[str, float] = {}
+
+    def _make_policy(self, obs, policy_kwargs, seed):
+        """the actor network (subclasses with another actor shape override this; SHAC: state-dependent log_std head)"""
+        pk = checkpoint.policy_kwargs_from_reference(policy_kwargs, self.obs_keys)
+        self.weight_decay = pk.get("weight_decay", self.weight_decay)
+        return MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},
+                         pk.get("extractor", {k: [128, 64] for k in self.obs_keys}), pk.get("pi", [64, 64]),
+                         pk.get("vf", [64, 64]), self.device, log_std_init=pk.get("log_std_init", -1.0), seed=seed,
+                         ortho_init=pk.get("ortho_init", True))
 
     def _update(self):
         """one horizon: roll out, back-propagate through simulator and policy, clip + Adam (BPTT.py:100-134)"""
@@ -133,10 +137,8 @@ class BPTT:
             if not (defer and pol.forward_act(o, epss[t], action, slot=t)):      # action head fused into the forward launch
                 mean, _ = pol.forward(o, slot=t, need_value=False)
                 _lib.check(L.vf_reparam_fwd(_ptr(mean), _ptr(log_std), _ptr(epss[t]), _ptr(action), N, st))
-            pre_obs = obs
             obs, reward, done, _ = env._step_no_grad(action, False, record=True, borrow=True,   # acts[t] outlives the reverse sweep
                                                      prefilled=ckpt_done)
-            self._on_step(t, pre_obs, action, obs, reward, done, disc)
             # loss / discount bookkeeping, fused with the state checkpoint of step t + 1 (one launch instead of two)
             ckpt_done = t + 1 < H and env._tape_t < env._tape.shape[0]
             if ckpt_done:
@@ -161,9 +163,6 @@ class BPTT:
             pol.weight_grad_slots(N, H, d_means, accumulate=True)
         pol.grad[pol.log_std_off:] = g_ls.sum(dim=0)
         return loss_vec.mean() / self.world
-
-    def _on_step(self, t, pre_obs, action, obs, reward, done, disc):
-        """hook for subclasses (SHAC collects its critic buffer here); disc is the discount BEFORE this step's update"""
 
     def _grad_autograd(self):
         """the same gradient with torch.autograd as the scheduler (two custom Functions wrap the kernels); kept as the

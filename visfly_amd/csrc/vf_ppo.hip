@@ -263,6 +263,12 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
                 }
             }
         }
+#ifndef VF_TEST_NO_PAD_ZERO
+        if (redp > red) {      // a vector-loadable row that is not a whole MFMA chunk (4- or 8-wide: the action columns of a
+            const int np = redp - red;                     // critic): the pad columns must be zeros, not what LDS held before
+            for (int i = tid; i < nrows * np; i += NT) As[(i / np) * sa + red + (i % np)] = 0.0f;
+        }
+#endif
     } else {
         const int total = nrows * redp;
         for (int base = tid; base < total; base += 4 * NT) {     // 4 independent loads in flight per thread
@@ -601,6 +607,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, 
             const int nacc = c0 + 2 < ct ? 2 : (c0 < ct ? 1 : 0);
             const float* bg = packed + L.wt_off;            // wave-uniform base, 32-bit lane offsets
             const int off0 = lk * ldb + c0 * 32 + lr, off1 = off0 + 64;
+#ifndef VF_TEST_NO_PAD_ZERO                                 // (tools/exp_pad_poison.py: shows that the poison test fails without)
+            if (L.src >= 4 && (L.K & 15)) {
+                // a hidden source whose width is not a multiple of the 16-step MFMA chunk (a concatenation such as
+                // features (+) action = 68 columns): the sweep reads [K, round16(K)) as well.  The packed weights are zero
+                // there, but 0 x (whatever the recycled LDS region holds) is NaN for NaN / Inf bit patterns, which the ReLU
+                // then turns into a silent 0.  Nobody else writes those columns: zero them (rows 64 x < 16 columns).
+                float* pad = lds + d.lds_off[L.src] + L.src_col + L.K;
+                const int np = red16 - L.K, ss = d.lds_stride[L.src];
+                for (int i = tid; i < kRows * np; i += kBlock) pad[(i / np) * ss + (i % np)] = 0.0f;
+            }
+#endif
             __syncthreads();                               // inputs of this layer are in LDS
             VF_PROBE_AT(2);
             const float* As = lds + d.lds_off[L.src] + L.src_col;

@@ -33,6 +33,7 @@ class _Linear:
         self.K, self.No, self.relu = K, No, relu
         self.src, self.sc, self.dst, self.dc = src, sc, dst, dc
         self.w_off, self.b_off, self.first = w_off, b_off, first
+        self.frozen = False       # identity pass-through (MlpPolicy ``passthrough``): no gradient, not in the backward tables
 
 
 class MlpPolicy:
@@ -46,11 +47,20 @@ class MlpPolicy:
     """
 
     def __init__(self, obs_dims: Dict[str, int], extractor: Dict[str, List[int]], pi: List[int], vf: List[int],
-                 device, action_dim: int = 4, log_std_init: float = 0.0, seed: int = 0, ortho_init: bool = True):
+                 device, action_dim: int = 4, log_std_init: float = 0.0, seed: int = 0, ortho_init: bool = True,
+                 head_dims=None, passthrough=(), log_std_param: bool = True):
+        """``head_dims`` (default (action_dim, 1)): widths of the two heads "mean" / "value" -- the SHAC actor of the reference
+        has two 4-wide heads (mu and a state-dependent log_std, utils/policies/td_policies.py:230-243), its twin critic two
+        1-wide ones.  ``passthrough``: input keys whose columns are appended to the features unchanged, after the extractor
+        outputs -- ``th.cat([features, actions], dim=-1)`` of ContinuousCritic.forward (:137); realised as a frozen identity
+        layer (W = I, b = 0: exact in fp32) whose parameters sit BEHIND the trainable ones in ``flat`` and never receive a
+        gradient.  ``log_std_param`` False: no state-independent log_std parameter."""
         assert action_dim == 4, "the head kernels are written for the 4-d drone action"
         self.device = th.device(device)
-        self.obs_keys = list(extractor.keys())
+        self.passthrough = [k for k in passthrough]
+        self.obs_keys = list(extractor.keys()) + self.passthrough
         self.obs_dims = {k: int(obs_dims[k]) for k in self.obs_keys}
+        self.head_dims = tuple(head_dims) if head_dims is not None else (action_dim, 1)
         self.spec = dict(extractor={k: list(v) for k, v in extractor.items()}, pi=list(pi), vf=list(vf))
         # ---- activation buffers (name -> width) and the layer schedule ----
         self.widths: Dict[str, int] = {}
@@ -62,7 +72,7 @@ class MlpPolicy:
             self.layers.append(_Linear(K, No, relu, src, sc, dst, dc, off, off + K * No, first))
             off += K * No + No
 
-        feat_w = sum((v[-1] if v else self.obs_dims[k]) for k, v in extractor.items())
+        feat_w = sum((v[-1] if v else self.obs_dims[k]) for k, v in extractor.items()) + sum(self.obs_dims[k] for k in self.passthrough)
         self.widths["feat"] = feat_w
         col = 0
         for k, hidden in extractor.items():
@@ -78,7 +88,11 @@ class MlpPolicy:
                 add(K, h, True, src, sc, dst, dc, first=(li == 0))
                 src, sc, K = dst, dc, h
             col += hidden[-1]
-        for trunk, hidden, head_dim, head in (("pi", pi, action_dim, "mean"), ("vf", vf, 1, "value")):
+        pass_cols = []
+        for k in self.passthrough:
+            pass_cols.append((k, col))
+            col += self.obs_dims[k]
+        for trunk, hidden, head_dim, head in (("pi", pi, self.head_dims[0], "mean"), ("vf", vf, self.head_dims[1], "value")):
             src, sc, K = "feat", 0, feat_w
             for li, h in enumerate(hidden):
                 dst = f"{trunk}:{li}"
@@ -88,7 +102,17 @@ class MlpPolicy:
             self.widths[head] = head_dim
             add(K, head_dim, False, src, sc, head, 0)
         self.log_std_off = off
-        self.n_params = off + action_dim
+        self.n_params = off + (action_dim if log_std_param else 0)      # trainable parameters (what Adam / the all-reduce see)
+        # frozen identity layers of the pass-through inputs: executed with the extractors, parameters behind the trainable ones
+        off = self.n_params
+        n_ext = sum(len(v) for v in extractor.values())
+        for j, (k, c) in enumerate(pass_cols):
+            d = self.obs_dims[k]
+            ly = _Linear(d, d, False, "obs:" + k, 0, "feat", c, off, off + d * d, True)
+            ly.frozen = True
+            self.layers.insert(n_ext + j, ly)
+            off += d * d + d
+        self.n_total = off
         for ly in self.layers:
             if ly.K > 128 or ly.No > 128:
                 raise ValueError("layer widths up to 128 are supported by the MFMA linear kernels")
@@ -96,9 +120,12 @@ class MlpPolicy:
         # ActorCriticPolicy._build -- orthogonal weights with gain sqrt(2) for the extractor and trunk layers, 0.01 for
         # action_net, 1 for value_net, zero biases; otherwise nn.Linear's default (kaiming-uniform) ----
         g = th.Generator().manual_seed(seed)
-        flat = th.zeros(self.n_params)
+        flat = th.zeros(self.n_total)
         self.ortho_init = bool(ortho_init)
         for ly in self.layers:
+            if ly.frozen:
+                flat[ly.w_off:ly.w_off + ly.K * ly.No] = th.eye(ly.K).reshape(-1)
+                continue
             if ortho_init:
                 gain = {"mean": 0.01, "value": 1.0}.get(ly.dst, float(np.sqrt(2.0)))
                 w = th.empty(ly.No, ly.K)
@@ -108,9 +135,9 @@ class MlpPolicy:
                 bound = 1.0 / np.sqrt(ly.K)
                 flat[ly.w_off:ly.w_off + ly.K * ly.No] = (th.rand(ly.K * ly.No, generator=g) * 2 - 1) * bound
                 flat[ly.b_off:ly.b_off + ly.No] = (th.rand(ly.No, generator=g) * 2 - 1) * bound
-        flat[self.log_std_off:] = log_std_init
+        flat[self.log_std_off:self.n_params] = log_std_init
         self.flat = flat.to(self.device)
-        self.grad = th.zeros_like(self.flat)
+        self.grad = th.zeros(self.n_params, device=self.device)
         self._bufs: Dict[tuple, Dict[str, th.Tensor]] = {}
         self._gbufs: Dict[int, Dict[str, th.Tensor]] = {}
         self._scratch = None
@@ -248,7 +275,7 @@ class MlpPolicy:
             return None, None
         if self._pack_map is None:
             import numpy as np
-            m = np.full((self.n_params, 4), -1, np.int32)
+            m = np.full((self.n_total, 4), -1, np.int32)
             for li, ly in enumerate(self.layers):
                 n, k = np.meshgrid(np.arange(ly.No), np.arange(ly.K), indexing="ij")
                 flat = ly.w_off + n * ly.K + k
@@ -286,7 +313,7 @@ class MlpPolicy:
 
     @property
     def log_std(self):
-        return self.flat[self.log_std_off:]
+        return self.flat[self.log_std_off:self.n_params]
 
     def _buffers(self, M, slot=0):
         """activation buffers of one forward pass (kept for backward).  ``slot`` selects one of several resident
@@ -373,7 +400,7 @@ class MlpPolicy:
             if rc:
                 _lib.check(rc)
         if out_value is not None:
-            out_value.copy_(b["value"].view(-1))
+            out_value.copy_(b["value"].view(out_value.shape))
             return b["mean"], out_value
         return b["mean"], b["value"]
 
@@ -393,11 +420,13 @@ class MlpPolicy:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
         gbuf = {} if d_mean is None else {"mean": d_mean}
         if d_value is not None:
-            gbuf["value"] = d_value.view(M, 1)
+            gbuf["value"] = d_value.view(M, self.head_dims[1])
         wgrad = L.vf_linear_bwd_weight_acc if accumulate else L.vf_linear_bwd_weight
         touched = set()
         d_in = {}
         for ly in reversed(self.layers):
+            if ly.frozen:
+                continue
             if d_value is None and (ly.dst == "value" or ly.dst.startswith("vf:")):
                 continue
             if d_mean is None and (ly.dst == "mean" or ly.dst.startswith("pi:")):
@@ -423,9 +452,9 @@ class MlpPolicy:
             touched.add(key)
         if d_log_std is not None:
             if accumulate:
-                self.grad[self.log_std_off:] += d_log_std
+                self.grad[self.log_std_off:self.n_params] += d_log_std
             else:
-                self.grad[self.log_std_off:] = d_log_std
+                self.grad[self.log_std_off:self.n_params] = d_log_std
         return d_in
 
     def _bwd_desc(self, b, M, d_mean, d_value, need_input_grad):
@@ -433,11 +462,13 @@ class MlpPolicy:
         gradient skipped -> (desc, {obs key: dLoss/d obs tensor})"""
         gbuf = {} if d_mean is None else {"mean": d_mean}
         if d_value is not None:
-            gbuf["value"] = d_value.view(-1, 1)
+            gbuf["value"] = d_value.view(-1, self.head_dims[1])
         d = _lib.MlpBwdDesc()
         d.n_fold = self.log_std_off
         touched, d_in, n = set(), {}, 0
         for ly in reversed(self.layers):
+            if ly.frozen:
+                continue
             if d_value is None and (ly.dst == "value" or ly.dst.startswith("vf:")):
                 continue
             if d_mean is None and (ly.dst == "mean" or ly.dst.startswith("pi:")):
@@ -630,9 +661,9 @@ class MlpPolicy:
                                      1 if accumulate else 0, st))
         if d_log_std is not None:
             if accumulate:
-                self.grad[self.log_std_off:] += d_log_std
+                self.grad[self.log_std_off:self.n_params] += d_log_std
             else:
-                self.grad[self.log_std_off:] = d_log_std
+                self.grad[self.log_std_off:self.n_params] = d_log_std
         return d_in
 
     # -------------------------------------------------------------------------------------------
@@ -671,9 +702,12 @@ class MlpPolicy:
             def flat_grad(s):
                 g = th.zeros(pol.n_params)
                 for ly, m in zip(pol.layers, s.lin):
+                    if ly.frozen or m.weight.grad is None:
+                        continue
                     g[ly.w_off:ly.w_off + ly.K * ly.No] = m.weight.grad.reshape(-1)
                     g[ly.b_off:ly.b_off + ly.No] = m.bias.grad
-                g[pol.log_std_off:] = s.log_std.grad
+                if s.log_std.grad is not None and pol.n_params > pol.log_std_off:
+                    g[pol.log_std_off:] = s.log_std.grad
                 return g
 
         return Ref()

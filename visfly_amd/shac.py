@@ -1,144 +1,251 @@
-"""EXPERIMENTAL (parity unpinned, network shapes NOT the reference's -- see "Parity status" below).
+"""SHAC: short-horizon actor-critic through the differentiable simulator.
 
-SHAC as the reference runs it (utils/algorithms/shac.py:215-278): a short-horizon first-order actor update through
-the differentiable simulator plus twin Q critics regressed onto TD-lambda returns.
+Restates ``TemporalDifferBase.learn`` of the reference (utils/algorithms/shac.py:185-326) with the reference's network shapes
+(utils/policies/td_policies.py):
 
-What the reference's ``learn`` loop does per iteration, and where each piece runs here:
+* **Actor** (:146-252): features extractor -> two trunks of identical shape, ``latent_pi -> mu`` (4) and ``log_latent_pi ->
+  log_std`` (4, clamped to [-10, 2], :31-32,241-243); action = tanh(mu + eps * exp(log_std)) (SB3's squashed Gaussian).  One
+  ``MlpPolicy`` layer table with two 4-wide heads; ``log_latent_pi`` starts as a copy of ``latent_pi`` (:205).
+* **Critic** (:82-143): its OWN features extractor (``share_features_extractor=False``, trained by the critic loss),
+  ``th.cat([features, actions])`` -> two Q MLPs ``qf0`` / ``qf1`` -> 1.  One layer table: extractor branch + a frozen identity
+  branch that appends the 4 action columns to the features, two trunks with 1-wide heads; a second instance is the target.
 
-* H env steps with the stochastic actor, ``actor_loss = -sum_t reward_t * disc_t`` minus the bootstrap
-  ``next_value * disc * gamma`` where a horizon or an episode is cut (:251-257).  ``next_value`` comes from the TARGET
-  critics on detached observations and detached next actions (:247), so it is a constant of the actor objective: the
-  actor gradient is exactly the BPTT gradient -> ``BPTT._grad_reverse_sweep`` (adjoint env kernel + one-launch network
-  backward); the bootstrap only enters the logged loss value.
-* ``compute_td_returns`` (utils/algorithms/common.py:893-923) -> ``vf_td_returns`` (bit-identical to the reference on
-  the golden vectors).  The reference's buffer calls it with the literal gamma 0.99 (common.py:1232-1239), mirrored.
-* ``gradient_steps`` critic updates on the whole horizon buffer: ``mse(returns, min(Q1, Q2))`` (:267-270), joint
-  grad-norm clip 0.5 over both Q networks, Adam, Polyak update of the target critics (:274).
+Per iteration (shac.py:215-278):
 
-Parity status: UNPINNED -- the reference's SHAC needs stable-baselines3 (SACPolicy / ContinuousCritic), which is not
-importable in the build container, so no golden vectors exist for the loop itself.  Network shapes differ from SB3's
-where the MFMA kernels' layer model requires it: the actor keeps a state-independent log_std (SB3's Actor has a
-log_std head), and each Q network is an ``MlpPolicy`` value trunk over the concatenated (observation, action) row
-instead of SB3's features extractor -> concat(features, action) -> Q MLP (utils/policies/td_policies.py:146-252; it would
-need an identity extractor branch for the action columns, which the fused MLP layer tables do not have).  What IS pinned:
-the actor gradient (= the BPTT reverse sweep, gradient fixtures from the reference's autograd) and ``vf_td_returns``
-(bit-identical to the reference's compute_td_returns).  Treat learning curves from this class as indicative only.
+1. H env steps with the stochastic actor; ``actor_loss = mean_i sum_t [-reward_t disc_t - next_value_t disc_t gamma cut_t]``,
+   ``cut = (done | t == H-1) & ~episode_done``, ``next_value = min(Q1', Q2')`` of the TARGET critic on the detached next
+   observation and a freshly sampled, detached next action (:242-257) -- a constant of the actor objective, so the actor
+   gradient is the BPTT reverse sweep (adjoint env kernel ``vf_env_step_bwd`` + MLP backward) while the loss VALUE carries the
+   bootstrap term (``vf_shac_accumulate``).
+2. clip_grad_norm_(0.5) + Adam on the actor (:271-276 of the actor part), ``env.detach()``.
+3. TD-lambda returns of the horizon buffer (``vf_td_returns``; the buffer passes the literal gamma 0.99,
+   utils/algorithms/common.py:1232-1239).
+4. ``gradient_steps`` x: ``mse_loss(returns, min(Q1, Q2))`` over the whole buffer (``vf_twin_q_loss``), backward through both Q
+   trunks and the critic's extractor, clip 0.5, Adam, Polyak update of the target (``vf_polyak_update``).
+
+Parity: pinned by ``tests/golden/shac_hover.npz`` -- ONE iteration of the reference's own ``learn()`` loop with its own Actor /
+ContinuousCritic / StateExtractor / create_mlp / SimpleRolloutBuffer / compute_td_returns over the differentiable HoverEnv
+(``oracle/gen_shac.py``; SB3's base classes restated there, reference defect C-10 repaired: the buffer's observations are
+flattened like its actions): horizon buffer, next values, actor loss incl. bootstrap, flat actor gradient, actor parameters after
+the step, returns, and per critic step loss / gradient / parameters / target parameters (``tests/test_shac_gpu.py``).
 """
 import ctypes as C
 from typing import Optional
 
 import torch as th
 
-from . import _lib, parallel
+from . import _lib, checkpoint, parallel
 from .bptt import BPTT
 from .ppo import MlpPolicy, _ptr
 
-EP_EPISODE_DONE = 8      # VF_EP_EPISODE_DONE
-
-
-class _Critic:
-    """one Q network + its Adam state"""
-
-    def __init__(self, in_dim, arch, device, seed):
-        self.net = MlpPolicy({"sa": in_dim}, {"sa": list(arch[:1])}, [1], list(arch[1:]) or [arch[-1]], device, seed=seed)
-        self.net.lazy_pack = True
-        n = self.net.n_params
-        self.m, self.v = th.zeros(n, device=device), th.zeros(n, device=device)
-        self.sumsq = th.zeros(1, device=device)
-
-    def q(self, sa, save=False, slot=0):
-        _, value = self.net.forward({"sa": sa}, save_activations=save, slot=slot)
-        return value.view(-1)
+LOG_STD_MAX, LOG_STD_MIN = 2.0, -10.0        # td_policies.py:31-32
 
 
 class SHAC(BPTT):
-    def __init__(self, env, horizon: int = 32, tau: float = 0.005, gamma: float = 0.99, gradient_steps: int = 5,
-                 learning_rate: float = 1e-3, critic_arch=(128, 64, 64), lamda: float = 0.95, seed: int = 42, **kw):
-        super().__init__(env, horizon=horizon, gamma=gamma, learning_rate=learning_rate, seed=seed, **kw)
+    def __init__(self, env, policy=None, policy_kwargs: Optional[dict] = None, learning_rate: float = 1e-3, logger_kwargs=None,
+                 comment=None, save_path=None, dump_step=1e4, horizon: int = 32, tau: float = 0.005, gamma: float = 0.99,
+                 gradient_steps: int = 5, buffer_size: int = int(1e6), batch_size: int = int(2e5), clip_range_vf: float = 0.1,
+                 pre_stop: float = 0.1, policy_noise: float = 0.0, device=None, seed: int = 42, lamda: float = 0.95,
+                 max_grad_norm: float = 0.5, **kw):
+        # argument list of TemporalDifferBase.__init__ (shac.py:50-72); buffer_size / batch_size / clip_range_vf / pre_stop /
+        # policy_noise are stored but unused by the reference's loop as well
+        if policy not in (None, "MultiInputPolicy", "MlpPolicy", "MTDPolicy"):
+            raise NotImplementedError(f"policy {policy}: vector-observation MTDPolicy only")
+        self._critic_arch = None
         self.tau, self.gradient_steps, self.lamda = tau, gradient_steps, lamda
-        dev = self.device
-        in_dim = sum(self.policy.obs_dims[k] for k in self.obs_keys) + 4
-        self.critics = [_Critic(in_dim, critic_arch, dev, seed + 101 + i) for i in range(2)]
-        self.targets = [_Critic(in_dim, critic_arch, dev, seed + 101 + i) for i in range(2)]
-        for c, t in zip(self.critics, self.targets):
-            t.net.flat.copy_(c.net.flat)
-            t.net.mark_updated()
+        super().__init__(env, horizon=horizon, gamma=gamma, learning_rate=learning_rate, max_grad_norm=max_grad_norm,
+                         policy_kwargs=policy_kwargs, seed=seed, **kw)
+        pol, dev = self.policy, self.device
+        obs_dims = {k: pol.obs_dims[k] for k in self._ext_keys}
+        mk = lambda s: MlpPolicy({**obs_dims, "action": 4}, self._extractor, self._critic_arch, self._critic_arch, dev, seed=s,
+                                 ortho_init=False, head_dims=(1, 1), passthrough=("action",), log_std_param=False)
+        self.critic, self.critic_target = mk(seed + 101), mk(seed + 101)
+        parallel.broadcast_(self.critic.flat)
+        self.critic_target.flat.copy_(self.critic.flat)                              # critic_target.load_state_dict(critic.state_dict())
+        for net in (self.critic, self.critic_target):
+            net.lazy_pack = True
+            net.mark_updated()
+        n = self.critic.n_params
+        self.c_exp_avg, self.c_exp_avg_sq = th.zeros(n, device=dev), th.zeros(n, device=dev)
+        self._c_sumsq = th.zeros(1, device=dev)
         self._critic_step = 0
         self._buf = None
+        self._eps_override = None            # tests: (2H, N, 4) noise feed, [2t] = action of step t, [2t+1] = next action
 
-    # ---- rollout bookkeeping (called from BPTT._grad_reverse_sweep) ------------------------------------------------
-    def _sa(self, obs, action):
-        return th.cat([obs[k].detach() for k in self.obs_keys] + [action.detach()], dim=1).contiguous()
+    # ---- networks ---------------------------------------------------------------------------------------------------------
+    def _make_policy(self, obs, policy_kwargs, seed):
+        """the Actor: extractor -> (latent_pi -> mu | log_latent_pi -> log_std); nn.Linear default initialisation (SB3's SAC
+        policies do not use orthogonal init), log_latent_pi = deepcopy(latent_pi) (td_policies.py:205)"""
+        pk = dict(policy_kwargs or {})
+        na = pk.get("net_arch")
+        if isinstance(na, dict) and "qf" in na:                       # SB3 get_actor_critic_arch: dict(pi=..., qf=...)
+            self._critic_arch = list(na["qf"])
+            pk["net_arch"] = dict(pi=list(na["pi"]), vf=list(na["pi"]))
+        if pk.get("share_features_extractor"):
+            raise NotImplementedError("share_features_extractor=True: the critic here owns its extractor (the reference default)")
+        pk.pop("share_features_extractor", None)
+        if any(k in pk for k in ("features_extractor_class", "net_arch", "features_extractor_kwargs", "activation_fn")):
+            pk.setdefault("activation_fn", "relu")                    # MTDPolicy's default activation IS ReLU (td_policies.py:297)
+        pk = checkpoint.policy_kwargs_from_reference(pk, self.obs_keys)
+        self._extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
+        self._ext_keys = list(self._extractor.keys())
+        arch = list(pk.get("pi", [64, 64]))
+        if self._critic_arch is None:
+            self._critic_arch = list(arch)
+        pol = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys}, self._extractor, arch, arch, self.device, seed=seed,
+                        ortho_init=False, head_dims=(4, 4), log_std_param=False)
+        hidden = lambda trunk: [ly for ly in pol.layers if ly.dst.startswith(trunk + ":")]
+        for a, b in zip(hidden("pi"), hidden("vf")):                  # log_latent_pi starts as a copy of latent_pi
+            pol.weight(b).copy_(pol.weight(a))
+            pol.bias(b).copy_(pol.bias(a))
+        return pol
 
-    def _on_step(self, t, pre_obs, action, obs, reward, done, disc):
-        env, N, dev = self.env, self.env.num_envs, self.device
-        if t == 0:
-            H = self.H
-            self._buf = dict(sa=[], reward=th.empty((H, N), device=dev), done=th.empty((H, N), dtype=th.uint8, device=dev),
-                             ep_done=th.empty((H, N), dtype=th.uint8, device=dev), next_value=th.empty((H, N), device=dev),
-                             boot=th.zeros(N, device=dev))
-        b = self._buf
-        # next action of the (stochastic) actor on the new observation, Q-target on (obs', a') -- all detached (:242-247)
-        mean, _ = self.policy.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, save_activations=False,
-                                      slot=self.H, need_value=False)      # a slot of its own: the horizon's activations stay intact
-        eps = th.randn((N, 4), device=dev, generator=self._gen)
-        nxt = th.empty((N, 4), device=dev)
-        _lib.check(_lib.lib().vf_reparam_fwd(_ptr(mean), _ptr(self.policy.log_std), _ptr(eps), _ptr(nxt), N,
-                                             _lib.current_stream(dev)))
-        sa_next = self._sa(obs, nxt)
-        nv = th.minimum(self.targets[0].q(sa_next).clone(), self.targets[1].q(sa_next))
-        ep_done = done & ((env._ep_flags & EP_EPISODE_DONE) != 0)
-        b["sa"].append(self._sa(pre_obs, action))
-        b["reward"][t].copy_(reward)
-        b["done"][t].copy_(done)
-        b["ep_done"][t].copy_(ep_done)
-        b["next_value"][t].copy_(nv)
-        cut = (done | (t == self.H - 1)) & ~ep_done                                   # :254
-        b["boot"] += nv * disc * self.gamma * cut                                      # :256 (logged loss only)
+    def _head_fwd(self, mu, log_std, eps, action):
+        _lib.check(_lib.lib().vf_shac_head_fwd(_ptr(mu), _ptr(log_std), _ptr(eps), _ptr(action), mu.shape[0], LOG_STD_MIN,
+                                               LOG_STD_MAX, _lib.current_stream(self.device)))
 
-    # ---- one iteration ----------------------------------------------------------------------------------------------
+    def _q(self, net, obs, action, save=False, slot=0):
+        q0, q1 = net.forward({**{k: obs[k] for k in self._ext_keys}, "action": action}, save_activations=save, slot=slot)
+        return q0.view(-1), q1.view(-1)
+
+    # ---- actor: horizon roll-out + reverse sweep ------------------------------------------------------------------------------
+    def _grad_reverse_sweep(self):
+        """shac.py:215-266 forward, then the reverse sweep t = H-1 .. 0: adjoint env step -> action head -> both actor trunks
+        (parameter gradients accumulate) -> gradient w.r.t. the observation of step t, which step t-1 returned"""
+        env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
+        L, st, dev = _lib.lib(), _lib.current_stream(self.device), self.device
+        keys = self.obs_keys
+        pol.grad.zero_()
+        disc, loss_vec = th.ones(N, device=dev), th.zeros(N, device=dev)
+        f = dict(dtype=th.float32, device=dev)
+        u8 = dict(dtype=th.uint8, device=dev)
+        b = self._buf = dict(obs={k: th.empty((H, N, pol.obs_dims[k]), **f) for k in keys}, action=th.empty((H, N, 4), **f),
+                             reward=th.empty((H, N), **f), done=th.empty((H, N), **u8), ep_done=th.empty((H, N), **u8),
+                             next_value=th.empty((H, N), **f))
+        eps = self._eps_override if self._eps_override is not None else th.randn((2 * H, N, 4), device=dev, generator=self._gen)
+        assert eps.shape == (2 * H, N, 4)
+        drews, ls_rows = th.empty((H, N), **f), []
+        nxt = th.empty((N, 4), **f)
+        t0 = env._tape_t
+        obs = env.get_observation()
+        for t in range(H):
+            for k in keys:
+                b["obs"][k][t].copy_(obs[k].detach())                                  # rollout_buffer.add(obs=pre_obs ...) :259
+            o = {k: b["obs"][k][t] for k in keys}                                      # rows that outlive the reverse sweep
+            mu, ls = pol.forward(o, slot=t)                                            # actor.action_log_prob(obs) :219
+            ls_rows.append(ls)                                                         # slot t's head buffer
+            action = b["action"][t]
+            self._head_fwd(mu, ls, eps[2 * t], action)
+            obs, reward, done, _ = env._step_no_grad(action, False, record=True, borrow=True)      # :225
+            # next action of the stochastic actor on the new observation, target critics on (obs', a'), all detached :234-239
+            o2 = {k: obs[k].detach().contiguous() for k in keys}
+            mu2, ls2 = pol.forward(o2, save_activations=False, slot=H)
+            self._head_fwd(mu2, ls2, eps[2 * t + 1], nxt)
+            q0, q1 = self._q(self.critic_target, o2, nxt, slot=0)
+            b["reward"][t].copy_(reward)
+            b["done"][t].copy_(done)
+            _lib.check(L.vf_shac_accumulate(_ptr(reward), done.data_ptr(), env._ep_flags.data_ptr(), _ptr(q0), _ptr(q1), _ptr(disc),
+                                            _ptr(loss_vec), _ptr(drews[t]), _ptr(b["next_value"][t]), b["ep_done"][t].data_ptr(),
+                                            float(self.gamma), 1.0 / (N * self.world), 1 if t == H - 1 else 0, N, st))
+        g_obs = None
+        d_mu, d_ls = th.empty((N, 4), **f), th.empty((N, 4), **f)
+        for t in reversed(range(H)):
+            d_action = env.backward_step(t0 + t, g_obs, drews[t])
+            _lib.check(L.vf_shac_head_bwd(_ptr(d_action), _ptr(b["action"][t]), _ptr(ls_rows[t]), _ptr(eps[2 * t]), _ptr(d_mu),
+                                          _ptr(d_ls), N, LOG_STD_MIN, LOG_STD_MAX, st))
+            d_in = pol.backward(d_mu, d_ls, None, accumulate=True, need_input_grad=t > 0, slot=t)
+            g_obs = d_in.get("state") if t > 0 else None
+        return loss_vec.mean() / self.world
+
+    # ---- one iteration ------------------------------------------------------------------------------------------------------
     def _update(self):
         loss = self._grad_reverse_sweep()
+        out = self._apply(loss)                                                        # clip 0.5 + Adam + env.detach() :271-277
         b, N, H = self._buf, self.env.num_envs, self.H
-        actor_loss = loss - b["boot"].mean() / self.world
-        out = self._apply(actor_loss)
         L, st = _lib.lib(), _lib.current_stream(self.device)
         returns = th.empty((H, N), device=self.device)
         # SimpleRolloutBuffer.compute_returns passes the literal 0.99 (common.py:1232-1239)
         _lib.check(L.vf_td_returns(_ptr(b["reward"]), b["done"].data_ptr(), b["ep_done"].data_ptr(), _ptr(b["next_value"]),
                                    _ptr(returns), H, N, 0.99, float(self.lamda), st))
-        sa, target = th.cat(b["sa"], dim=0), returns.view(-1)
-        self.logs["train/critic_loss"] = float(self._train_critics(sa, target))
-        self.logs["train/actor_loss_with_bootstrap"] = float(out)
+        b["returns"] = returns
+        obs = {k: v.view(H * N, -1) for k, v in b["obs"].items()}
+        self._last_losses = (out, self._train_critics(obs, b["action"].view(H * N, 4), returns.view(-1)))
         return out
 
-    def _train_critics(self, sa, target):
-        L, st, M = _lib.lib(), _lib.current_stream(self.device), sa.shape[0]
-        gM = M * self.world
-        loss = None
+    def flush_logs(self):
+        """device scalars of the last iteration -> self.logs (one host sync; the loop itself never waits for the GPU)"""
+        if getattr(self, "_last_losses", None) is not None:
+            a, c = self._last_losses
+            c = c.clone()
+            parallel.allreduce_sum_(c)
+            self.logs["train/actor_loss"], self.logs["train/critic_loss"] = float(a), float(c)
+        return self.logs
+
+    def learn(self, total_timesteps: int, log_interval: Optional[int] = None):
+        out = super().learn(total_timesteps, log_interval)
+        self.flush_logs()
+        return out
+
+    def _critic_step_once(self, obs, action, target):
+        """one critic update (shac.py:267-274) -> loss (0-dim device tensor, this rank's share of the global mean)"""
+        L, st, M = _lib.lib(), _lib.current_stream(self.device), action.shape[0]
+        c, dev = self.critic, self.device
+        q0, q1 = self._q(c, obs, action, save=True)
+        if getattr(self, "_dq", None) is None or self._dq[0].numel() != M:
+            self._dq = (th.empty(M, device=dev), th.empty(M, device=dev), th.empty(1, device=dev),
+                        th.empty(int(L.vf_twin_q_loss_scratch_doubles(M)), dtype=th.float64, device=dev))
+        dq0, dq1, loss, scr = self._dq
+        _lib.check(L.vf_twin_q_loss(_ptr(q0), _ptr(q1), _ptr(target), _ptr(dq0), _ptr(dq1), _ptr(loss), scr.data_ptr(), M,
+                                    M * self.world, st))
+        c.backward(dq0.view(M, 1), dq1.view(M, 1), None)
+        parallel.allreduce_sum_(c.grad)
+        self._last_critic_grad = c.grad
+        _lib.check(L.vf_sumsq(_ptr(c.grad), c.n_params, _ptr(self._c_sumsq), _ptr(self._scratch), st))
+        self._critic_step += 1
+        pmap, packed = c.pack_map()
+        cfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, 0.0, self.max_grad_norm, self._critic_step, 0,
+                           _ptr(pmap), _ptr(packed))
+        _lib.check(L.vf_adam_step(_ptr(c.flat), _ptr(c.grad), _ptr(self.c_exp_avg), _ptr(self.c_exp_avg_sq), c.n_params,
+                                  _ptr(self._c_sumsq), C.byref(cfg), st))
+        c.mark_updated(packed_current=pmap is not None)
+        tg = self.critic_target
+        _lib.check(L.vf_polyak_update(_ptr(tg.flat), _ptr(c.flat), c.n_params, float(self.tau), st))    # trainable part only
+        tg.mark_updated()
+        return loss[0]
+
+    def _train_critics(self, obs, action, target):
+        loss = th.full((), float("nan"), device=self.device)
         for _ in range(self.gradient_steps):
-            q = [c.q(sa, save=True) for c in self.critics]
-            values = th.minimum(q[0], q[1])
-            diff = values - target
-            loss = (diff * diff).mean()                                               # mse_loss(target, values) :269
-            coef = diff * (2.0 / gM)
-            first = q[0] <= q[1]                                                      # th.min routes the gradient to one net
-            total = th.zeros(1, device=self.device)
-            for i, c in enumerate(self.critics):
-                dv = th.where(first if i == 0 else ~first, coef, th.zeros_like(coef)).contiguous()
-                c.net.backward(None, dv, None)
-                c.net.grad[c.net.log_std_off:] = 0.0
-                parallel.allreduce_sum_(c.net.grad)
-                _lib.check(L.vf_sumsq(_ptr(c.net.grad), c.net.n_params, _ptr(c.sumsq), _ptr(self._scratch), st))
-                total += c.sumsq
-            self._critic_step += 1
-            for c, t in zip(self.critics, self.targets):                              # joint clip over both nets (:272)
-                pmap, packed = c.net.pack_map()
-                cfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, 0.0, 0.5, self._critic_step, 0,
-                                   _ptr(pmap), _ptr(packed))
-                _lib.check(L.vf_adam_step(_ptr(c.net.flat), _ptr(c.net.grad), _ptr(c.m), _ptr(c.v), c.net.n_params,
-                                          _ptr(total), C.byref(cfg), st))
-                c.net.mark_updated(packed_current=pmap is not None)
-                t.net.flat.lerp_(c.net.flat, self.tau)                                # polyak_update :274
-                t.net.mark_updated()
+            loss = self._critic_step_once(obs, action, target)
         return loss
+
+    # ---- inference -------------------------------------------------------------------------------------------------------------
+    def predict(self, obs, state=None, episode_start=None, deterministic: bool = False):
+        """shac.py:334-343 / MTDPolicy.predict: -> (action, None); deterministic: tanh(mu)"""
+        N = obs[self.obs_keys[0]].shape[0]
+        mu, ls = self.policy.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, save_activations=False, slot=self.H + 1)
+        if deterministic:
+            return th.tanh(mu), None
+        eps = th.randn((N, 4), device=self.device, generator=self._gen)
+        action = th.empty((N, 4), device=self.device)
+        self._head_fwd(mu, ls.contiguous(), eps, action)
+        return action, None
+
+    def save(self, path: str):
+        """the reference pickles the whole SB3 policy object (shac.py:328-332), which cannot exist here; this writes the flat
+        parameter buffers and the layer tables' shapes as a plain torch archive"""
+        th.save({"actor": self.policy.flat.cpu(), "critic": self.critic.flat.cpu(), "critic_target": self.critic_target.flat.cpu(),
+                 "spec": dict(extractor=self._extractor, pi=self.policy.spec["pi"], qf=self._critic_arch, horizon=self.H)},
+                path if path.endswith(".pth") else path + ".pth")
+
+    def set_parameters(self, path: str, load_optimizer: bool = True):
+        d = th.load(path if path.endswith(".pth") else path + ".pth", map_location="cpu")
+        for net, key in ((self.policy, "actor"), (self.critic, "critic"), (self.critic_target, "critic_target")):
+            assert d[key].numel() == net.flat.numel(), f"{key}: archive holds a different network"
+            net.flat.copy_(d[key])
+            net.mark_updated()
+        return self
+
+    @classmethod
+    def load(cls, path: str, env, **kwargs):
+        return cls(env, **kwargs).set_parameters(path)
