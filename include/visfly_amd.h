@@ -31,7 +31,8 @@ extern "C" {
                                  vf_bptt_accumulate_checkpoint, vf_ppo_loss_cfg.old_value /
                                  clip_range_vf, vf_comm_* / vf_allreduce_grads (RCCL);
                               5: vf_dyn_ring_phase / vf_dyn_set_ring_phase / vf_env_set_ring_phase, capture guard on
-                                 vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update */
+                                 vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update,
+                                 vf_dyn_cfg.trig_mode (was pad0) */
 
 typedef void* vf_stream_t;
 
@@ -68,6 +69,14 @@ enum {
 enum { VF_ACT_THRUST = 0, VF_ACT_BODYRATE = 1, VF_ACT_VELOCITY = 2, VF_ACT_POSITION = 3 };   /* utils/type.py:14-18 */
 enum { VF_INT_EULER = 0, VF_INT_RK4 = 1 };         /* utils/maths.py:331,353 */
 
+/* sin / cos / acos on the path.  torch's CPU fp32 routines for these three are closed-source MKL VML, which cannot be restated;
+ *   VF_TRIG_CR    fp64 evaluation rounded once to fp32 -- what the golden-vector generator patches torch.sin / cos / acos to,
+ *                 so that the fixtures pin these paths to the bit (default of the Python classes);
+ *   VF_TRIG_SLEEF SLEEF's u10 fp32 routines (the closest published algorithm to torch's results: one ulp away for 2 - 8 % of
+ *                 the arguments), no fp64 arithmetic.
+ * atan2 is SLEEF's atan2f_u10 in both modes (that IS torch's atan2, bit for bit).  csrc/vf_xmath.hpp. */
+enum { VF_TRIG_SLEEF = 0, VF_TRIG_CR = 1 };
+
 /* Constants derived once on the host (envs/base/dynamics.py:26-130,562-689).
  * Matrices are row-major.  These bits are part of the parity contract. */
 typedef struct vf_dyn_cfg {
@@ -76,7 +85,8 @@ typedef struct vf_dyn_cfg {
     int32_t interval_steps;   /* int(ctrl_dt/dt)                 dynamics.py:74  */
     int32_t delay_steps;      /* int(comm_delay/ctrl_dt)         dynamics.py:75  */
     int32_t ctrl_delay;       /* first-order rotor model on/off  dynamics.py:510 */
-    int32_t pad0;
+    int32_t trig_mode;        /* VF_TRIG_*: how sin / cos / acos of the velocity / position controllers (dynamics.py:432,438,
+                                 467,473) and of NavigationEnv's view-angle term (NavigationEnv.py:91) are evaluated */
     float dt, ctrl_dt;
     float m;                  /* mass                                            */
     float g_z;                /* -9.81                           dynamics.py:15  */

@@ -21,7 +21,7 @@ class Consts(C.Structure):
     _fields_ = [
         ("action_type", C.c_int32), ("integrator", C.c_int32),
         ("interval_steps", C.c_int32), ("delay_steps", C.c_int32),
-        ("ctrl_delay", C.c_int32), ("pad0", C.c_int32),
+        ("ctrl_delay", C.c_int32), ("trig_mode", C.c_int32),
         ("dt", C.c_float), ("ctrl_dt", C.c_float),
         ("m", C.c_float), ("g_z", C.c_float),
         ("J", C.c_float * 9), ("Jinv", C.c_float * 9),
@@ -70,11 +70,12 @@ class EnvState(C.Structure):
 # name -> (ctypes field, is_array) ; constants are passed around as a dict of
 # float32 numpy scalars/arrays (bit patterns are the parity contract)
 GEOMETRIC_FIELDS = ("vel_half", "vel_mean", "yaw_half", "yaw_mean", "vel_p", "vel_d", "pos_d", "Pm", "P12")
-CONST_FIELDS = [f[0] for f in Consts._fields_ if f[0] != "pad0"]
+CONST_FIELDS = [f[0] for f in Consts._fields_ if f[0] != "trig_mode"]
 
 
 def consts_from_dict(d):
     c = Consts()
+    c.trig_mode = int(d.get("trig_mode", 1))
     for name in CONST_FIELDS:
         if name not in d and name in GEOMETRIC_FIELDS:
             continue      # fixtures of the bodyrate/thrust cases predate the geometric-controller constants
@@ -317,8 +318,9 @@ class OracleEnv:
 
 
 def xmath(kind, a, b=None):
-    """vf_sleef.h (SLEEF u10 routines restated) over arrays: kind in atan2 | sin | cos | acos"""
-    k = {"atan2": 0, "sin": 1, "cos": 2, "acos": 3}[kind]
+    """vf_sleef.h over arrays: kind in atan2 | sin | cos | acos (SLEEF u10 routines restated) | sin_cr | cos_cr | acos_cr (fp64
+    evaluation rounded once: what the golden generator patches torch.sin / cos / acos to)"""
+    k = {"atan2": 0, "sin": 1, "cos": 2, "acos": 3, "sin_cr": 4, "cos_cr": 5, "acos_cr": 6, "atan2_glibc": 7}[kind]
     a = np.ascontiguousarray(a, np.float32)
     b = a if b is None else np.ascontiguousarray(b, np.float32)
     out = np.empty_like(a)

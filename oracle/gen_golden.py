@@ -37,8 +37,34 @@ def cr_sqrt(x):
     return _orig_sqrt(x.double()).float() if x.dtype == th.float32 else _orig_sqrt(x)
 
 
+_orig_unary = {n: (getattr(th, n), getattr(th.Tensor, n)) for n in ("sin", "cos", "acos")}
+
+
+def _cr_unary(orig):
+    """fp32 tensor -> the fp64 result rounded once to fp32 (differentiable: autograd sees double ops between two casts)"""
+    def f(x, *a, **k):
+        if isinstance(x, th.Tensor) and x.dtype == th.float32 and not a and not k:
+            return orig(x.double()).float()
+        return orig(x, *a, **k)
+    return f
+
+
+def use_cr_trig(on=True):
+    """"CR-trig oracle" (r03, same precedent as CR-sqrt): this torch build's CPU fp32 sin / cos / acos are Intel MKL VML (closed
+    source, not correctly rounded: 4.8 % / 5.0 % / 6.5 % of random arguments differ from the rounded fp64 result) and cannot be
+    restated.  The generator patches the three -- module functions and Tensor methods, every call form the reference uses
+    (envs/base/dynamics.py:432,438,467,473; utils/maths.py:256-276; envs/NavigationEnv.py:91) -- to fp64 evaluation rounded once
+    to fp32, which the oracle and the HIP kernels reproduce bit for bit in their "cr" transcendental mode (oracle/vf_sleef.h).
+    torch.atan2 stays torch's: it is SLEEF's atan2f_u10, restated bit for bit."""
+    for n, (fn, meth) in _orig_unary.items():
+        setattr(th, n, _cr_unary(fn) if on else fn)
+        setattr(th.Tensor, n, _cr_unary(meth) if on else meth)
+
+
 def use_cr_sqrt(on=True):
+    """the CR oracle: sqrt AND sin / cos / acos (use_cr_trig) patched together; off = the reference exactly as torch runs it"""
     th.sqrt = cr_sqrt if on else _orig_sqrt
+    use_cr_trig(on)
 
 
 # ----------------------------------------------------------------------------------
@@ -100,6 +126,7 @@ def extract_consts(d):
         "yaw_mean": f32(npar["yaw"].mean.reshape(-1)[0]) if geometric else np.float32(0),
         "vel_p": f32(d._VELOCITY_PID.p), "vel_d": f32(d._VELOCITY_PID.d), "pos_d": f32(d._POSITION_PID.d),
         "Pm": f32(d._BODYRATE_PID.p), "P12": f32(1.2 * d._BODYRATE_PID.p),
+        "trig_mode": np.int32(1),          # the fixtures are generated under use_cr_trig (VF_TRIG_CR)
     }
     return {k: np.asarray(v) for k, v in c.items()}
 
@@ -668,11 +695,7 @@ def gen_bptt(name, N=64, seed=42):
 def gen_td(name="td_lambda", H=24, N=40, seed=3):
     """compute_td_returns of the reference (utils/algorithms/common.py:893-923), imported through the stubs"""
     import_envs()
-    for n in ("stable_baselines3.common.buffers", "stable_baselines3.common.type_aliases",
-              "stable_baselines3.common.preprocessing", "stable_baselines3.common.utils", "stable_baselines3.common.vec_env.base_vec_env"):
-        if n not in sys.modules:
-            _auto(n)
-    sys.modules["stable_baselines3.common.buffers"].BaseBuffer = type("BaseBuffer", (), {})
+    _sb3_stubs()       # the same stand-ins as gen_ppo: utils/algorithms/common.py is imported once per process
     from VisFly.utils.algorithms.common import compute_td_returns
     rng = np.random.default_rng(seed)
     r = rng.normal(size=(H, N)).astype(np.float32)

@@ -137,7 +137,7 @@ static inline void cross_helper(const float* a, const float* b, float* o)
 }
 
 static void geometric_controller(const vfo_consts* c, const float* a, const float* p, quat q,
-                                 const float* v, const float* w, const float* al, float* Td)
+                                 const float* v, const float* w, const float* al, float* Td, int strided_v)
 {
     const int pos_mode = c->action_type == VFO_ACT_POSITION;
     /* _de_normalize :716-730 -> [yaw, x, y, z] */
@@ -163,11 +163,13 @@ static void geometric_controller(const vfo_consts* c, const float* a, const floa
         gain = c->pos_d;                                       /* :468 */
     } else {
         float vn = sqrtf(fmaf(v[1], v[1], v[0] * v[0]));       /* :421 */
-        yaw_des = vn > 0.1f ? vfs_atan2f_u10(v[1], v[0]) : yaw_cur;    /* :423-427 */
+        /* :423-427; torch.atan2 on strided velocity rows = glibc's atan2f, on contiguous ones SLEEF's (vf_sleef.h) */
+        yaw_des = vn > 0.1f ? (strided_v ? vfs_atan2f_glibc(v[1], v[0]) : vfs_atan2f_u10(v[1], v[0])) : yaw_cur;
         gain = c->vel_d;                                       /* :433 */
     }
     float ye = yaw_des - yaw_cur;
-    ye = vfs_atan2f_u10(vfs_sinf_u10(ye), vfs_cosf_u10(ye));                           /* :432,467 */
+    const int crm = c->trig_mode == 1;
+    ye = crm ? vfs_atan2f_u10(vfs_sinf_cr(ye), vfs_cosf_cr(ye)) : vfs_atan2f_u10(vfs_sinf_u10(ye), vfs_cosf_u10(ye));   /* :432,467 */
     float yaw_spd = ye * gain * 2.0f;
     /* gross thrust = (conj(q) * (0,F) * q).imag[2]            :435, maths.py:49,103 */
     quat fq = { 0.0f, F[0], F[1], F[2] };
@@ -181,7 +183,7 @@ static void geometric_controller(const vfo_consts* c, const float* a, const floa
     /* desired frame :437-442 */
     float fn = sqrtf(fmaf(F[2], F[2], fmaf(F[1], F[1], F[0] * F[0])));
     float b3[3] = { F[0] / fn, F[1] / fn, F[2] / fn };
-    float c1[3] = { vfs_cosf_u10(yaw_des), vfs_sinf_u10(yaw_des), 0.0f };
+    float c1[3] = { crm ? vfs_cosf_cr(yaw_des) : vfs_cosf_u10(yaw_des), crm ? vfs_sinf_cr(yaw_des) : vfs_sinf_u10(yaw_des), 0.0f };
     float b2[3], b1[3];
     cross_helper(b3, c1, b2);
     float bn = sqrtf(fmaf(b2[2], b2[2], fmaf(b2[1], b2[1], b2[0] * b2[0])));
@@ -228,12 +230,18 @@ static void geometric_controller(const vfo_consts* c, const float* a, const floa
 
 /* ---------- Dynamics.step ---------- */
 
-static void dyn_step_range(const vfo_consts* c, int N, float* S, float* Q, int slot,
+/* bit 30 of *tick (the ring head itself is *tick & ~VFO_TICK_VSTRIDED): the reference's `_velocity` tensor is a strided view,
+ * i.e. the last full reset was given velocities (dynamics.py:236 stores vel.T; in-place updates and clamp() keep the layout).
+ * It decides which atan2 torch runs for the velocity action type's auto-yaw: glibc's (strided operands) or SLEEF's. */
+#define VFO_TICK_VSTRIDED (1 << 30)
+
+static void dyn_step_range(const vfo_consts* c, int N, float* S, float* Q, int slot_vstr,
                            const float* klin, const float* kquad,
                            const float* action, float* obs, int i0, int i1)
 {
     const int D = c->delay_steps;
     const float dt = c->dt;
+    const int slot = slot_vstr & ~VFO_TICK_VSTRIDED, vstr = (slot_vstr & VFO_TICK_VSTRIDED) != 0;
 
     for (int i = i0; i < i1; ++i) {
 #define ROW(r) S[(size_t)(r) * N + i]
@@ -287,7 +295,7 @@ static void dyn_step_range(const vfo_consts* c, int N, float* S, float* Q, int s
             for (int k = 0; k < 3; ++k) u[k + 1] = (t1[k] + cr[k]) - t3[k];
             mat4_chain(c->Binv, u, Td);
         } else if (c->action_type == VFO_ACT_VELOCITY || c->action_type == VFO_ACT_POSITION) {
-            geometric_controller(c, a, p, q, v, w, al, Td);
+            geometric_controller(c, a, p, q, v, w, al, Td, vstr);
         } else {
             /* THRUST: dynamics.py:712-714,398-399 */
             for (int k = 0; k < 4; ++k) Td[k] = c->m * (a[k] * c->acc_half + c->acc_mean);
@@ -425,14 +433,15 @@ void vfo_dyn_step(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick,
                   const float* action, float* obs)
 {
     const int D = c->delay_steps;
-    const int slot = D > 0 ? (int)((*tick) % D) : 0;
+    const int t0 = *tick & ~VFO_TICK_VSTRIDED;
+    const int slot = (D > 0 ? t0 % D : 0) | (*tick & VFO_TICK_VSTRIDED);
 #pragma omp parallel if (N >= 4096)
     {
         int i0, i1;
         thread_range(N, &i0, &i1);
         dyn_step_range(c, N, S, Q, slot, klin, kquad, action, obs, i0, i1);
     }
-    if (D > 0) *tick = (*tick + 1) % D;
+    *tick = (D > 0 ? (t0 + 1) % D : 0) | (*tick & VFO_TICK_VSTRIDED);
 }
 
 /* ---------- Dynamics.reset ---------- */
@@ -462,7 +471,7 @@ void vfo_dyn_reset(const vfo_consts* c, int N, float* S, float* Q, int32_t* tick
         if (Q) /* dynamics.py:243,262-263 */
             for (int s = 0; s < c->delay_steps * 4; ++s) Q[(size_t)s * N + i] = 0.0f;
     }
-    if (full && tick) *tick = 0;
+    if (full && tick) *tick = vel ? VFO_TICK_VSTRIDED : 0;
 }
 
 /* ---------- env layer ---------- */
@@ -620,7 +629,7 @@ static void env_post_step_range(const vfo_consts* c, const vfo_env_consts* e, in
             const float thrd = (float)(3.14159265358979323846 / 18.0);
             float cs = dot3_sum(dir, v) / (1e-6f + norm3(v[0], v[1], v[2])) / 1.0f;
             cs = clampf(cs, -1.0f, 1.0f);
-            float ang = vfs_acosf_u10(cs);
+            float ang = c->trig_mode == 1 ? vfs_acosf_cr(cs) : vfs_acosf_u10(cs);
             ang = ang < thrd ? thrd : ang;
             float t2 = (ang - thrd) * -0.01f;
             float t3 = norm4(q[0] - 1.0f, q[1] - 0.0f, q[2] - 0.0f, q[3] - 0.0f) * (float)-0.00001;
@@ -683,20 +692,20 @@ void vfo_env_run_steps(const vfo_consts* c, const vfo_env_consts* e, int N, floa
                        vfo_env_state* es, int steps)
 {
     const int D = c->delay_steps;
-    const int tick0 = *tick;
+    const int tick0 = *tick & ~VFO_TICK_VSTRIDED, vstr0 = *tick & VFO_TICK_VSTRIDED;
 #pragma omp parallel
     {
         int i0, i1;
         thread_range(N, &i0, &i1);
         for (int s = 0; s < steps; ++s) {
-            const int slot = D > 0 ? (tick0 + s) % D : 0;
+            const int slot = (D > 0 ? (tick0 + s) % D : 0) | vstr0;
             dyn_step_range(c, N, S, Q, slot, klin, kquad, actions + (size_t)(s % n_actions) * 4 * N, NULL, i0, i1);
             collision_point_range(e, N, S, es, NULL, i0, i1);
             collision_flags_range(e, N, S, es, i0, i1);
             env_post_step_range(c, e, N, S, es, i0, i1);
         }
     }
-    if (D > 0) *tick = (tick0 + steps) % D;
+    *tick = (D > 0 ? (tick0 + steps) % D : 0) | vstr0;
 }
 
 void vfo_env_reset_attr(int N, vfo_env_state* es, const int32_t* idx, int k)
@@ -770,7 +779,11 @@ void vfo_xmath(int kind, const float* a, const float* b, float* out, int64_t n)
         case 0: out[i] = vfs_atan2f_u10(a[i], b[i]); break;
         case 1: out[i] = vfs_sinf_u10(a[i]); break;
         case 2: out[i] = vfs_cosf_u10(a[i]); break;
-        default: out[i] = vfs_acosf_u10(a[i]); break;
+        case 3: out[i] = vfs_acosf_u10(a[i]); break;
+        case 4: out[i] = vfs_sinf_cr(a[i]); break;
+        case 5: out[i] = vfs_cosf_cr(a[i]); break;
+        case 6: out[i] = vfs_acosf_cr(a[i]); break;
+        default: out[i] = vfs_atan2f_glibc(a[i], b[i]); break;
         }
     }
 }

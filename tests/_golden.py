@@ -37,27 +37,10 @@ def assert_bits_equal(a, b, what=""):
                              f"{a[tuple(idx)]!r} vs {b[tuple(idx)]!r}; max|diff|={np.nanmax(np.abs(a - b)):.3e}")
 
 
+# velocity / position action types.  Their controller evaluates sin / cos (torch: closed-source MKL VML); the
+# fixtures are generated with those patched to the fp64 result rounded once (oracle/gen_golden.py::use_cr_trig), which the
+# oracle and the kernels reproduce in their "cr" transcendental mode -> held to the bit like every other fixture
 GEOMETRIC = ["dyn_velocity_euler", "dyn_position_euler"]
-
-
-def assert_geometric_close(got, want_all, want, what=""):
-    """velocity / position action types: the controller evaluates sin / cos / atan2.  torch.atan2 is SLEEF's
-    atan2f_u10 and is restated bit for bit; torch.sin / torch.cos run Intel MKL VML (closed source), so the oracle and
-    the kernels use SLEEF's sinf_u10 / cosf_u10 (restated bit for bit, the closest published algorithms), which differ
-    from MKL by one ulp in ~2 % of the calls (oracle/vf_sleef.h, tests/test_sleef_restatement.py).  After ONE control
-    step >= 98 % of the state words are bit-identical; the closed attitude loop then amplifies the one-ulp
-    differences.  Tolerance per extend_state column: |diff| <= 5e-5 * max|column| over the 256-step fixture -- looser
-    than north_star's 1e-5, which these two action types cannot meet without MKL's algorithm."""
-    got = np.asarray(got, np.float32)
-    scale = np.abs(want_all).reshape(-1, want_all.shape[-1]).max(0)
-    lim = 5e-5 * np.maximum(scale, 1e-3)
-    d = np.abs(got - want)
-    bad = d > lim
-    if bad.any():
-        i = np.argwhere(bad)[0]
-        raise AssertionError(f"{what}: {int(bad.sum())} components beyond tolerance; first at {tuple(i)}: "
-                             f"{got[tuple(i)]!r} vs {want[tuple(i)]!r} (limit {lim[i[-1]]:.2e})")
-    return float((d / lim).max())
 
 
 # constructor kwargs of the env fixtures (same as oracle/gen_golden.py::ENV_CASES)

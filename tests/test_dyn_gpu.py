@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from _golden import GEOMETRIC, assert_bits_equal, assert_geometric_close, consts_of, decode_actions, load
+from _golden import GEOMETRIC, assert_bits_equal, consts_of, decode_actions, load
 
 pytestmark = pytest.mark.gpu
 
@@ -52,32 +52,64 @@ def test_golden_bit_exact(name):
 
 @pytest.mark.parametrize("name", GEOMETRIC)
 def test_geometric_controller_golden(name):
-    """velocity / position action types: the reference's per-agent Python loop
-    (dynamics.py:446-450) as one fused launch; tolerance-level parity against the reference (its sin / cos are MKL VML,
-    closed source -- oracle/vf_sleef.h), bit-level parity against the oracle in the next test"""
+    """velocity / position action types: the reference's per-agent Python loop (dynamics.py:446-450) as one fused
+    launch, BIT-IDENTICAL to the CR-trig reference (sin / cos = fp64 result rounded once, oracle/gen_golden.py::use_cr_trig;
+    atan2 = SLEEF's, which is torch's) for all 256 steps x 28 state components -- the r02 tolerance (5e-5 of the column scale,
+    MKL's closed-source sin / cos on the reference side) is gone; the drift of the unpatched reference is printed"""
     fx = load(name)
     consts = consts_of(fx)
+    assert int(consts["trig_mode"]) == 1
     acts = decode_actions(fx)
     N = fx["fs0"].shape[0]
     dyn = make_dyn(consts, N)
     set_full_state(dyn, fx["fs0"])
     cps = list(fx["checkpoints"])
     acts_d = torch.from_numpy(acts).cuda()
-    worst = 0.0
     for k in range(acts.shape[0]):
         obs = dyn.step(acts_d[k])
         if (k + 1) in cps:
             j = cps.index(k + 1)
-            worst = max(worst, assert_geometric_close(dyn.extend_state.cpu().numpy(), fx["ext"], fx["ext"][j],
-                                                      f"{name} extend_state @ {k + 1}"))
-            assert_geometric_close(obs.cpu().numpy(), fx["obs"], fx["obs"][j], f"{name} step() return @ {k + 1}")
-    print(f"{name}: worst deviation = {worst:.3f} of the tolerance")
+            assert_bits_equal(dyn.extend_state.cpu().numpy(), fx["ext"][j], f"{name} extend_state @ {k + 1}")
+            assert_bits_equal(obs.cpu().numpy(), fx["obs"][j], f"{name} step() return @ {k + 1}")
+    drift = np.abs(dyn.extend_state.cpu().numpy()[:, :13] - fx["raw_ext_last"][:, :13])
+    scale = np.abs(fx["ext"][..., :13]).reshape(-1, 13).max(0)
+    print(f"{name}: |HIP - unpatched reference (MKL sin / cos, non-IEEE sqrt)| @ {acts.shape[0]} steps = {drift.max():.3e} "
+          f"({(drift.max(0) / np.maximum(scale, 1e-3)).max():.2e} of the column scale)")
+
+
+@pytest.mark.parametrize("name", GEOMETRIC)
+def test_geometric_sleef_mode_stays_within_its_stated_tolerance(name):
+    """transcendentals="sleef" (VF_TRIG_SLEEF: SLEEF's u10 sin / cos, no fp64 arithmetic) on the same fixture: one ulp away
+    from the CR results on a few per cent of the calls, which the closed attitude loop amplifies -- <= 5e-5 of the column
+    scale at 256 steps (what r02 measured against the MKL reference); and HIP == oracle to the bit in this mode too"""
+    fx = load(name)
+    consts = dict(consts_of(fx), trig_mode=np.int32(0))
+    acts = decode_actions(fx)
+    N = fx["fs0"].shape[0]
+    dyn = make_dyn(consts, N)
+    set_full_state(dyn, fx["fs0"])
+    od = oracle.OracleDynamics(consts, N)
+    od.set_full_state(fx["fs0"])
+    acts_d = torch.from_numpy(acts).cuda()
+    cps = list(fx["checkpoints"])
+    scale = np.maximum(np.abs(fx["ext"]).reshape(-1, fx["ext"].shape[-1]).max(0), 1e-3)
+    differs = False
+    for k in range(acts.shape[0]):
+        dyn.step(acts_d[k])
+        od.step(acts[k])
+        if (k + 1) in cps:
+            got = dyn.extend_state.cpu().numpy()
+            assert_bits_equal(got, od.extend_state, f"{name} sleef mode, HIP vs oracle @ {k + 1}")
+            assert (np.abs(got - fx["ext"][cps.index(k + 1)]) <= 5e-5 * scale).all(), f"{name} sleef mode @ {k + 1}"
+            differs = differs or not np.array_equal(got, fx["ext"][cps.index(k + 1)])
+    assert differs, "the two transcendental modes must not be the same code path"
 
 
 @pytest.mark.parametrize("mode", ["velocity", "position"])
 def test_geometric_vs_oracle_one_step(mode):
     """control steps from identical states: HIP and the C oracle share the restated transcendentals (oracle/vf_sleef.h ==
-    csrc/vf_xmath.hpp: SLEEF's u10 atan2 / sin / cos), so these two action types are bit-identical too"""
+    csrc/vf_xmath.hpp: SLEEF's atan2, fp64-evaluated sin / cos of the default "cr" mode), so these two action types are
+    bit-identical too"""
     from visfly_amd import Dynamics
     N = 1000
     kw = dict(action_type=mode, dt=0.0025, ctrl_dt=0.02, ctrl_delay=True, comm_delay=0.0)
@@ -106,8 +138,7 @@ def test_geometric_vs_oracle_one_step(mode):
 
 @pytest.mark.parametrize("name", GEOMETRIC)
 def test_geometric_fixture_bit_identical_to_oracle(name):
-    """the whole 256-step fixture run: HIP == CPU oracle, bit for bit, at every checkpoint (the tolerance of
-    test_geometric_controller_golden is entirely between the oracle and torch's closed-source MKL sin / cos)"""
+    """the whole 256-step fixture run: HIP == CPU oracle, bit for bit, at every checkpoint"""
     fx = load(name)
     acts = decode_actions(fx)
     N = fx["fs0"].shape[0]

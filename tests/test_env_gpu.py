@@ -60,14 +60,10 @@ def test_env_replay_mode_matches_reference_run(name):
     if str(fx["kind"]) == "racing":
         assert np.array_equal(obs0["gate"].cpu().numpy(), fx["obs0_gate"][:, 0]), f"{name} reset() gate entry (the stale one)"
     keep = list(fx["keep_steps"])
-    is_nav = str(fx["kind"]) == "nav"
     for k in range(acts.shape[0]):
         obs, reward, done, info = env.step(torch.from_numpy(acts[k]).cuda())
         r = reward.cpu().numpy()
-        if is_nav:
-            assert (np.abs(r - fx["reward"][k]) <= 5e-8 + 1.2e-7 * np.abs(fx["reward"][k])).all(), f"reward @ {k}"
-        else:
-            assert_bits_equal(r, fx["reward"][k], f"{name} reward @ {k}")
+        assert_bits_equal(r, fx["reward"][k], f"{name} reward @ {k}")      # Navigation incl.: acos in "cr" mode vs the CR-trig reference
         d = done.cpu().numpy()
         assert np.array_equal(d.astype(np.uint8), fx["done"][k]), f"{name} done @ {k}"
         sel = fx["ev_step"] == k
@@ -81,10 +77,7 @@ def test_env_replay_mode_matches_reference_run(name):
             for j in np.nonzero(sel)[0]:
                 d = info[int(fx["ev_agent"][j])]
                 ep = d["episode"]
-                if is_nav:      # the episode return sums rewards that carry the acos tolerance
-                    assert abs(float(ep["r"]) - float(fx["ev_r"][j])) <= 2e-6 + 2e-6 * abs(float(fx["ev_r"][j])), f"{name} episode r @ {k}"
-                else:
-                    assert_bits_equal(np.float32(ep["r"]), fx["ev_r"][j], f"{name} episode r @ {k}")
+                assert_bits_equal(np.float32(ep["r"]), fx["ev_r"][j], f"{name} episode r @ {k}")
                 assert int(ep["l"]) == int(fx["ev_l"][j])
                 assert_bits_equal(np.float32(ep["t"]), fx["ev_t"][j], f"{name} episode t @ {k}")
                 got = (int(bool(d["is_success"])) | (int(bool(d["TimeLimit.truncated"])) << 1) | (int(bool(d["episode_done"])) << 2)

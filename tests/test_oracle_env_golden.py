@@ -19,16 +19,8 @@ def run_env_fixture(name, make_env, step_fn, reset_fn, state_fn, gates_fn=None):
     keep = list(fx["keep_steps"])
     for k in range(steps):
         out = step_fn(env, acts[k])
-        if str(fx["kind"]) == "nav":
-            # NavigationEnv's reward goes through acos (NavigationEnv.py:88): torch's CPU acos is Intel MKL VML
-            # (closed source; oracle/probe_torch_transcendentals.py); the closest published algorithm, SLEEF's acosf_u10
-            # (restated in oracle/vf_sleef.h), differs from it by one ulp for ~8 % of the arguments.  1 ulp of acos (<=2.4e-7) * 0.01 -> a few 1e-9 absolute through the partial sums (bound used: 5e-8), plus one final-rounding
-            # ulp (2^-23 relative) when that perturbation crosses a rounding boundary of the summed reward;
-            # everything that feeds done / counters / state stays bit-exact below.
-            tol = 5e-8 + 1.2e-7 * np.abs(fx["reward"][k])
-            assert (np.abs(out["reward"] - fx["reward"][k]) <= tol).all(), f"{name} reward @ {k}"
-        else:
-            assert_bits_equal(out["reward"], fx["reward"][k], f"{name} reward @ {k}")
+        # NavigationEnv's reward goes through acos (NavigationEnv.py:91): CR-trig reference, "cr" mode of the oracle -> bit level
+        assert_bits_equal(out["reward"], fx["reward"][k], f"{name} reward @ {k}")
         assert np.array_equal(out["done"].astype(np.uint8), fx["done"][k]), f"{name} done @ {k}"
         assert np.array_equal(out["step_count"], fx["step_count"][k]), f"{name} step_count @ {k}"
         assert np.array_equal(out["is_collision"].astype(np.uint8), fx["is_collision"][k]), f"{name} is_collision @ {k}"

@@ -73,3 +73,53 @@ def test_sin_cos_acos_one_ulp_from_torch():
     e = np.array([0.0, 3.14159265, -3.14159265, 1.5707964, 6.2831855, -6.2831855, 100, 124.99, 1e-20, -1e-20], np.float32)
     assert np.abs(oracle.xmath("sin", e).astype(np.float64) - np.sin(e.astype(np.float64))).max() < 1.2e-7
     assert np.abs(oracle.xmath("cos", e).astype(np.float64) - np.cos(e.astype(np.float64))).max() < 1.2e-7
+
+
+def test_cr_mode_is_the_rounded_fp64_result():
+    """sin_cr / cos_cr / acos_cr (fdlibm's fp64 kernels restated, rounded once to fp32: the "cr" transcendental mode) ==
+    torch.f(x.double()).float() -- what oracle/gen_golden.py::use_cr_trig patches the reference's sin / cos / acos to -- for
+    every argument tried (8 M incl. the edges); and they are NOT what torch's fp32 routines return (MKL VML: ~5 % differ),
+    which is why the reference has to be patched to be pinnable at all"""
+    rng = np.random.default_rng(2)
+    n = 1 << 21
+    ang = np.concatenate([rng.uniform(-7, 7, n), rng.uniform(-124, 124, n // 2), rng.uniform(-1e4, 1e4, n // 2),
+                          np.array([0.0, -0.0, 3.14159265, -3.14159265, 1.5707964, 6.2831855, 1e-20, -1e-20, 1e-40, 0.78539816], np.float32)]).astype(np.float32)
+    unit = np.concatenate([rng.uniform(-1, 1, n), 1 - np.exp(rng.uniform(-20, 0, n // 2)), -1 + np.exp(rng.uniform(-20, 0, n // 2)),
+                           np.array([1, -1, 0.5, -0.5, 0, -0.0, 0.99999994, -0.99999994, 1e-20, -1e-30], np.float32)]).astype(np.float32)
+    for kind, x, tfn in (("sin_cr", ang, torch.sin), ("cos_cr", ang, torch.cos), ("acos_cr", unit, torch.acos)):
+        got = oracle.xmath(kind, x)
+        want = tfn(torch.from_numpy(x).double()).float().numpy()
+        assert np.array_equal(bits(got), bits(want)), f"{kind}: {(bits(got) != bits(want)).sum()} mismatches"
+        t32 = tfn(torch.from_numpy(x)).numpy()
+        assert 0.01 < (bits(t32) != bits(got)).mean() < 0.12, kind
+    assert bits(oracle.xmath("sin_cr", np.array([-0.0], np.float32)))[0] == 0x80000000
+    assert np.isnan(oracle.xmath("acos_cr", np.array([1.5, np.nan], np.float32))).all()
+    assert np.isnan(oracle.xmath("sin_cr", np.array([np.inf, np.nan], np.float32))).all()
+
+
+def test_strided_atan2_is_glibc_atan2f():
+    """torch.atan2 runs SLEEF only in its vectorised loop (contiguous operands); strided operands -- the velocity rows of the
+    velocity action type's auto-yaw whenever Dynamics.reset stored `vel.T` (dynamics.py:236,423-427) -- go through glibc's
+    atan2f, restated as vfs_atan2f_glibc (fdlibm's e_atan2f.c / s_atanf.c, as glibc 2.35 ships them)"""
+    rng = np.random.default_rng(3)
+    n = 1 << 20
+
+    def strided_atan2(y, x):
+        a = torch.from_numpy(np.stack([x, y], 1).copy()).T
+        assert not a[1].is_contiguous()
+        return torch.atan2(a[1], a[0]).numpy()
+    mag = lambda: (np.exp(rng.uniform(-80, 80, n)) * rng.choice([-1, 1], n)).astype(np.float32)
+    y0 = mag()
+    e = np.array([0.0, -0.0, 1, -1, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-39, 3e38, 0.5, 7.0, 0.4375, 0.6875, 1.1875, 2.4375,
+                  2.0 ** 25, 2.0 ** -29], np.float32)
+    Y, X = np.meshgrid(e, e)
+    cases = [(rng.normal(0, 3, n), rng.normal(0, 3, n)), (mag(), mag()), (y0, y0 * rng.uniform(0.3, 3, n)),
+             (rng.uniform(-1, 1, n), np.ones(n)), (Y.ravel(), X.ravel())]
+    differs = 0
+    for y, x in cases:
+        y, x = np.asarray(y, np.float32), np.asarray(x, np.float32)
+        want, got = strided_atan2(y, x), oracle.xmath("atan2_glibc", y, x)
+        same = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (y[~same][:4], x[~same][:4], got[~same][:4], want[~same][:4])
+        differs += int((bits(got) != bits(oracle.xmath("atan2", y, x))).sum())
+    assert differs > 1000          # and it is NOT the SLEEF routine of the contiguous path

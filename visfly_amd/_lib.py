@@ -24,7 +24,7 @@ class DynCfg(C.Structure):
     _fields_ = [
         ("action_type", C.c_int32), ("integrator", C.c_int32),
         ("interval_steps", C.c_int32), ("delay_steps", C.c_int32),
-        ("ctrl_delay", C.c_int32), ("pad0", C.c_int32),
+        ("ctrl_delay", C.c_int32), ("trig_mode", C.c_int32),
         ("dt", C.c_float), ("ctrl_dt", C.c_float),
         ("m", C.c_float), ("g_z", C.c_float),
         ("J", C.c_float * 9), ("Jinv", C.c_float * 9),
@@ -52,7 +52,8 @@ class DynCfg(C.Structure):
     def from_dict(cls, d):
         c = cls()
         for name, _ in cls._fields_:
-            if name == "pad0":
+            if name == "trig_mode":       # VF_TRIG_CR unless the constants say otherwise (fixtures older than the field: no trig calls)
+                c.trig_mode = int(d.get("trig_mode", 1))
                 continue
             if name not in d and name in GEOMETRIC_FIELDS:
                 continue                     # constants of the velocity/position controller: zero when unused

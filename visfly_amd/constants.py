@@ -37,7 +37,14 @@ def derive_constants(
         integrator: str = "euler",
         cfg: Union[str, dict] = "drone_state",
         wind_settings=(0, 0, 0),
+        transcendentals: str = "cr",
 ) -> Dict[str, np.ndarray]:
+    """``transcendentals``: "cr" -- sin / cos / acos on the path are evaluated in fp64 and rounded once to fp32 (what the golden
+    generator patches torch.sin / cos / acos to: the velocity / position controllers and NavigationEnv's view-angle term are
+    then bit-identical to that reference); "sleef" -- SLEEF's u10 fp32 routines, the closest published algorithm to torch's
+    closed-source MKL results (one ulp away for 2 - 8 % of the arguments), no fp64 arithmetic (include/visfly_amd.h VF_TRIG_*)"""
+    if transcendentals not in ("cr", "sleef"):
+        raise ValueError("transcendentals should be 'cr' or 'sleef'")
     if action_type not in ACTION_TYPES:
         raise AssertionError(f"action_type should be one of {list(ACTION_TYPES)}")
     if integrator not in INTEGRATORS:
@@ -134,5 +141,6 @@ def derive_constants(
         "vel_p": _f(th.tensor(vel_pid["p"])), "vel_d": _f(th.tensor(vel_pid["d"])),
         "pos_d": _f(th.tensor(pos_pid["d"])),
         "Pm": _f(P), "P12": _f(1.2 * P),                                       # :451,491
+        "trig_mode": np.int32(1 if transcendentals == "cr" else 0),
     }
     return {k: np.asarray(v) for k, v in c.items()}

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg* __restric
     if (c.delay_steps > 0) sp.vel = head_bits;
     float kl[3], kq[3];
     drag_of(c, g, i, kl, kq);
-    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
+    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.vstrided != 0);
     store_agent(g.S, g.G, i, s, sp);
     if (g.obs) {
         float o[13];
@@ -178,7 +178,7 @@ StepKernel pick_step_kernel(const vf_dyn_cfg& c)
 int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st)
 {
     vf::DynArgs g{h->N, h->G, h->g_drag, h->S, reinterpret_cast<const float4*>(action), state_out, vf::ring_head(h),
-                  reinterpret_cast<const float4*>(h->wind)};
+                  reinterpret_cast<const float4*>(h->wind), h->vel_strided};
     h->tick += 1;
     if (vf::use_split(h->Npad, h->cfg))
         hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->d_cfg, g);
@@ -258,6 +258,7 @@ int vf_dyn_reset(vf_dyn* h, const int32_t* idx, int32_t k, const float* pos, con
     hipStream_t st = vf::as_stream(stream);
     if (n == 0) return VF_OK;
     if (!idx) h->tick = 0;   // full reset: every head word goes to 0 (k_dyn_reset), and so does the launch-uniform phase
+    if (!idx) h->vel_strided = vel ? 1 : 0;   // reset(vel=...) stores the strided view vel.T, reset() contiguous zeros (dynamics.py:236)
     vf::ResetArgs r{h->N, h->Npad, n, h->G, h->g_drag, h->S, idx, pos, quat, vel, omg, mot, thr, t, t_rand, klin, kquad};
     hipLaunchKernelGGL(vf::k_dyn_reset, dim3(vf::blocks_for(n)), dim3(vf::kBlock), 0, st, h->cfg, r);
     VF_HIP(hipGetLastError());

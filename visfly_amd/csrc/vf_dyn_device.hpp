@@ -159,7 +159,7 @@ __device__ __forceinline__ void cross_helper(const float* a, const float* b, flo
 // closed-source MKL VML there; one ulp apart for ~2 % of the arguments), see vf_xmath.hpp: bit-identical to the CPU oracle,
 // and held to a stated tolerance against the reference for these two action types (tests/test_dyn_gpu.py).
 template <bool POSITION>
-__device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const Agent& s, const float* a, float* Td)
+__device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const Agent& s, const float* a, float* Td, bool strided_v)
 {
     float cmd[4];   // _de_normalize :716-730 -> [yaw, x, y, z]
     cmd[0] = a[0] * c.yaw_half + c.yaw_mean;
@@ -185,11 +185,14 @@ __device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const 
         gain = c.pos_d;                                            // :468
     } else {
         const float vn = sqrtf(__builtin_fmaf(s.v[1], s.v[1], s.v[0] * s.v[0]));   // :421
-        yaw_des = vn > 0.1f ? vfs_atan2f_u10(s.v[1], s.v[0]) : yaw_cur;                     // :423-427
+        // :423-427.  torch.atan2 = SLEEF for contiguous operands, glibc's atan2f for strided ones; the velocity rows are strided
+        // whenever the last full reset was given velocities (vf_xmath.hpp, vfs_atan2f_glibc; DynArgs.vstrided), wave-uniform
+        yaw_des = vn > 0.1f ? (strided_v ? vfs_atan2f_glibc(s.v[1], s.v[0]) : vfs_atan2f_u10(s.v[1], s.v[0])) : yaw_cur;
         gain = c.vel_d;                                            // :433
     }
     float ye = yaw_des - yaw_cur;
-    ye = vfs_atan2f_u10(vfs_sinf_u10(ye), vfs_cosf_u10(ye));                               // :432,467
+    const bool crm = c.trig_mode == VF_TRIG_CR;       // wave-uniform: fp64-evaluated sin / cos rounded once, or SLEEF u10
+    ye = crm ? vfs_atan2f_u10(vfs_sinf_cr(ye), vfs_cosf_cr(ye)) : vfs_atan2f_u10(vfs_sinf_u10(ye), vfs_cosf_u10(ye));   // :432,467
     const float yaw_spd = ye * gain * 2.0f;
     // gross thrust = (conj(q) * (0, F) * q).imag[2]               :435, maths.py:49,103
     const Quat fb = qmul(qmul(Quat{q.w, -q.x, -q.y, -q.z}, Quat{0.0f, F[0], F[1], F[2]}), q);
@@ -200,7 +203,7 @@ __device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const 
     // desired frame :437-442
     const float fn = sqrtf(__builtin_fmaf(F[2], F[2], __builtin_fmaf(F[1], F[1], F[0] * F[0])));
     const float b3[3] = {F[0] / fn, F[1] / fn, F[2] / fn};
-    const float c1[3] = {vfs_cosf_u10(yaw_des), vfs_sinf_u10(yaw_des), 0.0f};
+    const float c1[3] = {crm ? vfs_cosf_cr(yaw_des) : vfs_cosf_u10(yaw_des), crm ? vfs_sinf_cr(yaw_des) : vfs_sinf_u10(yaw_des), 0.0f};
     float b2[3], b1[3];
     cross_helper(b3, c1, b2);
     const float bn = sqrtf(__builtin_fmaf(b2[2], b2[2], __builtin_fmaf(b2[1], b2[1], b2[0] * b2[0])));
@@ -247,7 +250,7 @@ __device__ __forceinline__ void geometric_controller(const vf_dyn_cfg& c, const 
 // De-normalise the (delayed) action and run the low-level controller once per control
 // interval -> clamped desired rotor thrusts (dynamics.py:692-714,389-413,501).
 template <int ACT>
-__device__ __forceinline__ void desired_thrusts(const vf_dyn_cfg& c, const Agent& s, const float* a, float* Td)
+__device__ __forceinline__ void desired_thrusts(const vf_dyn_cfg& c, const Agent& s, const float* a, float* Td, bool vstrided = false)
 {
     if constexpr (ACT == VF_ACT_BODYRATE) {
         const float Fc = (a[0] * c.acc_half + c.acc_mean) * c.m;
@@ -270,7 +273,7 @@ __device__ __forceinline__ void desired_thrusts(const vf_dyn_cfg& c, const Agent
         for (int k = 0; k < 3; ++k) u[k + 1] = (t1[k] + cr[k]) - t3[k];
         mat4(c.Binv, u, Td);
     } else if constexpr (ACT == VF_ACT_VELOCITY || ACT == VF_ACT_POSITION) {
-        geometric_controller<ACT == VF_ACT_POSITION>(c, s, a, Td);
+        geometric_controller<ACT == VF_ACT_POSITION>(c, s, a, Td, vstrided);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) Td[k] = c.m * (a[k] * c.acc_half + c.acc_mean);
@@ -467,10 +470,10 @@ __device__ __forceinline__ void finish_interval(const vf_dyn_cfg& c, Agent& s)
 // All sub-steps of one control interval in ONE thread (dynamics.py:335-382).  kl/kq: this agent's drag.
 template <int ACT, int INTEG, bool CTRL_DELAY>
 __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, const float* a,
-                                                 const float* kl, const float* kq)
+                                                 const float* kl, const float* kq, bool vstrided = false)
 {
     float Td[4], wd[4];
-    desired_thrusts<ACT>(c, s, a, Td);
+    desired_thrusts<ACT>(c, s, a, Td, vstrided);
     rotor_setpoint<CTRL_DELAY>(c, Td, wd);
 #if VF_SUBSTEP_UNROLL == 2
 #pragma unroll 2
@@ -588,6 +591,7 @@ struct DynArgs {
     float* obs;            // (N,13) or null
     int head;              // delay-ring slot of this launch (= every agent's head word; vf_handles.hpp)
     const float4* wind = nullptr;   // per-agent wind of this control interval (N rows x,y,z,-; vf_*_set_wind) or null = vf_dyn_cfg.wind
+    int vstrided = 0;               // 1: the reference's velocity tensor is a strided view (vf_dyn::vel_strided; geometric_controller)
 };
 
 // wind velocity of the interval (dynamics.py:320,384-388: update_wind() runs first in step(), the value holds for all sub-steps)

@@ -94,7 +94,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
             failure = col.hit;
             reward = nav2_reward(e, s.p, vel, s.w, success);
         } else {
-            reward = nav_reward(e, s.p, s.q, vel, s.w, col, success, er.step_count);
+            reward = nav_reward(e, s.p, s.q, vel, s.w, col, success, er.step_count, c.trig_mode);
         }
     } else {  // RacingEnv.get_success / get_reward (RacingEnv.py:142-148,199-215)
         race = *granule(g.d.S, g.d.G, i, g.g_race);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     if (c.delay_steps > 0) sp.vel = head_bits;
     float kl[3], kq[3];
     drag_of(c, g.d, i, kl, kq);
-    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
+    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
     const int wave = threadIdx.x >> 6;
     env_epilogue<KIND>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
 }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_env_rollout(const vf_dyn_cfg* __rest
         if (c.delay_steps > 0) sp.vel = head_bits;
         float kl[3], kq[3];
         drag_of(c, g.d, i, kl, kq);
-        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq);
+        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
         env_epilogue<KIND, false>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
         if (++k >= g.K) break;
         g.d.action += g.action_stride;            // float4 units
@@ -503,7 +503,7 @@ EnvKernel pick_env_kernel(const vf_env* h)
 vf::DynArgs dyn_args(const vf_env* h, const float* action, float* obs, int ahead = 0)
 {
     return vf::DynArgs{h->dyn.N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(action), obs,
-                       vf::ring_head(&h->dyn, ahead), reinterpret_cast<const float4*>(h->dyn.wind)};
+                       vf::ring_head(&h->dyn, ahead), reinterpret_cast<const float4*>(h->dyn.wind), h->dyn.vel_strided};
 }
 
 // `ahead`: position of this launch in a sequence enqueued (or captured) before the handle's step counter advances
@@ -574,6 +574,7 @@ int vf_env_reset(vf_env* h, const int32_t* idx, int32_t k, const float* full_sta
     if (n < 0) return vf::fail(VF_EINVAL, "vf_env_reset: k < 0");
     if (n == 0) return VF_OK;
     if (!idx) h->dyn.tick = 0;   // full reset: head words go to 0 (k_env_reset) and so does the launch-uniform phase
+    if (!idx) h->dyn.vel_strided = 1;   // DroneEnvsBase.reset always passes the randomizer's velocities (droneEnv.py:282)
     vf::EnvResetArgs r{dyn_args(h, nullptr, nullptr), n, h->g_race, idx, full_state};
     hipStream_t st = vf::as_stream(stream);
     const dim3 grid(vf::blocks_for(n)), block(vf::kBlock);

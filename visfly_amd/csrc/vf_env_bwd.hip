@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg* __res
         const float vn = norm3(vv[0], vv[1], vv[2]), den2 = 1e-6f + vn, dot2 = dot3(dir, vv);
         const float cs0 = dot2 / den2;
         const float thrd = (float)(3.14159265358979323846 / 18.0);
-        if (cs0 >= -1.0f && cs0 <= 1.0f && vfs_acosf_u10(cs0) >= thrd) {
+        if (cs0 >= -1.0f && cs0 <= 1.0f && (c.trig_mode == VF_TRIG_CR ? vfs_acosf_cr(cs0) : vfs_acosf_u10(cs0)) >= thrd) {
             const float gcs = dr * -0.01f * (-1.0f / sqrtf(1.0f - cs0 * cs0));
             float ldir[3];
 #pragma unroll

@@ -66,7 +66,7 @@ __device__ __forceinline__ float hover_reward(const float* p, const float* tgt, 
 
 // NavigationEnv.get_reward (envs/NavigationEnv.py:84-99); step_count already incremented
 __device__ __forceinline__ float nav_reward(const vf_env_cfg& e, const float* p, const Quat& q, const float* v,
-                                            const float* w, const Collision& col, bool success, int step_count)
+                                            const float* w, const Collision& col, bool success, int step_count, int trig_mode)
 {
     const float tp[3] = {e.target[0] - p[0], e.target[1] - p[1], e.target[2] - p[2]};
     float t1 = dot3(v, tp) / (1e-6f + norm3(tp[0], tp[1], tp[2]));
@@ -79,7 +79,7 @@ __device__ __forceinline__ float nav_reward(const vf_env_cfg& e, const float* p,
     const float vn = norm3(v[0], v[1], v[2]);
     float cs = dot3(dir, v) / (1e-6f + vn) / 1.0f;
     cs = clampf(cs, -1.0f, 1.0f);
-    float ang = vfs_acosf_u10(cs);
+    float ang = trig_mode == VF_TRIG_CR ? vfs_acosf_cr(cs) : vfs_acosf_u10(cs);
     ang = ang < thrd ? thrd : ang;
     const float t2 = (ang - thrd) * -0.01f;
     const float t3 = norm4(q.w - 1.0f, q.x, q.y, q.z) * (float)-0.00001;

@@ -11,6 +11,11 @@ struct vf_dyn {
     // kernels take the slot index from the launch arguments -- the ring-slot load no longer waits for the velocity granule
     // that carries the per-agent copy (still written: the adjoint kernel reads it from its tape).
     long long tick = 0;
+    // Layout of the reference's `_velocity` tensor, which decides WHICH atan2 torch runs for the velocity action type's auto-yaw
+    // (dynamics.py:423-427): Dynamics.reset stores `vel.T` -- a strided view -- when velocities are passed (:236; every env
+    // reset does) and contiguous zeros otherwise; in-place updates and clamp() keep that layout until the next full reset.
+    // Strided operands take torch's scalar loop = glibc's atan2f, contiguous ones the SLEEF loop (vf_xmath.hpp).
+    int vel_strided = 0;
     // device copy of cfg (vf_dyn_create / vf_env_create): the step kernels read their ~600 B of constants through this pointer
     // instead of by-value kernel arguments.  A by-value block lives at a fresh kernarg address every launch, so each wave's
     // scalar loads miss all the way to HBM; the persistent copy stays in the XCD L2s from launch to launch (65 536 agents:
@@ -53,6 +58,7 @@ inline void init_dyn_handle(vf_dyn* h, const vf_dyn_cfg* cfg, int N, int per_age
     h->G = h->g_extra + extra;
     h->S = nullptr;
     h->tick = 0;
+    h->vel_strided = 0;
 }
 
 // device copies of the constant blocks (current HIP device); freed by release_cfg

@@ -26,6 +26,10 @@ __device__ __forceinline__ int vfs_isinf32(float x) { return __builtin_isinf(x);
 __device__ __forceinline__ int vfs_isnan32(float x) { return __builtin_isnan(x); }
 __device__ __forceinline__ uint32_t vfs_bits(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float vfs_float(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ double vfs_rint64(double x) { return __builtin_rint(x); }
+__device__ __forceinline__ double vfs_sqrt64(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ uint64_t vfs_dbits(double f) { return (uint64_t)__double_as_longlong(f); }
+__device__ __forceinline__ double vfs_double(uint64_t u) { return __longlong_as_double((long long)u); }
 
 /* ==== shared text: identical in oracle/vf_sleef.h and visfly_amd/csrc/vf_xmath.hpp (tests/test_sleef_restatement.py) ==== */
 VFS_INLINE float vfs_mla(float x, float y, float z) { return vfs_fma32(x, y, z); }        /* x*y + z */
@@ -206,6 +210,171 @@ VFS_INLINE float vfs_acosf_u10(float d)
     if (!o) y = vfs_scale(x, 2.0f);
     if (!o && d < 0.0f) y = vfs_sub_f2_f2(vfs_f2_(3.1415927410125732422f, -8.7422776573475857731e-08f), y);
     return y.x + y.y;
+}
+
+/* ---- "cr" mode (vf_dyn_cfg.trig_mode = 1): sin / cos / acos evaluated in fp64 and rounded ONCE to fp32 -----------------------
+ * What the golden-vector generator patches torch.sin / cos / acos to (x.double() -> f -> .float(), oracle/gen_golden.py:
+ * the precedent is its correctly rounded sqrt): torch's own fp32 routines here are closed-source MKL
+ * VML, which nothing can restate, so the reference is run with these three replaced by a fully specified definition and the
+ * velocity / position controllers and NavigationEnv's view-angle term are pinned to the BIT instead of to a tolerance.
+ * The fp64 evaluation restates Sun's fdlibm (k_sin.c, k_cos.c in the FreeBSD msun form, e_rem_pio2.c's medium-size path with
+ * its second iteration applied unconditionally -- 118 bits of pi/2 --, e_acos.c; "Copyright (C) 1993 by Sun Microsystems,
+ * Inc. All rights reserved.  Developed at SunSoft, a Sun Microsystems, Inc. business.  Permission to use, copy, modify, and
+ * distribute this software is freely granted, provided that this notice is preserved."): error < 1 ulp of fp64, so the fp32
+ * result equals round(torch's fp64 result) except when that fp64 value lies within ~1e-16 relative of a rounding boundary
+ * (probability ~2e-9 per call; tests/test_sleef_restatement.py measures 0 mismatches in 8 M arguments).  |x| < 1e5 rad. */
+VFS_INLINE double vfs_ksin64(double x, double y)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x, w = z * z;
+    const double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    const double v = z * x;
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+VFS_INLINE double vfs_kcos64(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x, w0 = z * z;
+    const double r = z * (C1 + z * (C2 + z * C3)) + (w0 * w0) * (C4 + z * (C5 + z * C6));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+/* x = n pi/2 + (y0 + y1), |y0 + y1| <= pi/4 (+ 1 ulp); returns n mod 4 */
+VFS_INLINE int vfs_rem_pio2_64(double x, double* y0, double* y1)
+{
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+                 pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
+    const double fn = vfs_rint64(x * invpio2);
+    const double t = x - fn * pio2_1;                  /* exact; with pio2_1t this would be fdlibm's 1st round (85 bits) */
+    double w = fn * pio2_2;                            /* 2nd round: good to 118 bits (fdlibm applies it on cancellation only) */
+    const double r = t - w;
+    w = fn * pio2_2t - ((t - r) - w);
+    *y0 = r - w;
+    *y1 = (r - *y0) - w;
+    return (int)((long long)fn & 3);
+}
+VFS_INLINE float vfs_sinf_cr(float d)
+{
+    double y0, y1;
+    if (vfs_isinf32(d) || vfs_isnan32(d)) return VFS_NAN;
+    if (d == 0.0f) return d;                                       /* keeps -0 */
+    const int n = vfs_rem_pio2_64((double)d, &y0, &y1);
+    const double s = vfs_ksin64(y0, y1), c = vfs_kcos64(y0, y1);
+    const double v = (n & 1) ? c : s;
+    return (float)((n & 2) ? -v : v);
+}
+VFS_INLINE float vfs_cosf_cr(float d)
+{
+    double y0, y1;
+    if (vfs_isinf32(d) || vfs_isnan32(d)) return VFS_NAN;
+    const int n = vfs_rem_pio2_64((double)d, &y0, &y1);
+    const double s = vfs_ksin64(y0, y1), c = vfs_kcos64(y0, y1);
+    const double v = (n & 1) ? s : c;
+    return (float)(((n + 1) & 2) ? -v : v);
+}
+VFS_INLINE double vfs_acos_pq(double z)
+{
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+                 pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+                 qS4 = 7.70381505559019352791e-02;
+    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    return p / q;
+}
+VFS_INLINE float vfs_acosf_cr(float d)
+{
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
+    const double x = (double)d;
+    if (vfs_isnan32(d) || d > 1.0f || d < -1.0f) return VFS_NAN;
+    if (d == 1.0f) return 0.0f;
+    if (d == -1.0f) return (float)(pi + 2.0 * pio2_lo);
+    if (d < 0.5f && d > -0.5f) {
+        if (vfs_abs32(d) <= 6.938893903907228e-18f) return (float)(pio2_hi + pio2_lo);           /* |x| <= 2^-57 */
+        const double r = vfs_acos_pq(x * x);
+        return (float)(pio2_hi - (x - (pio2_lo - x * r)));
+    }
+    if (d < 0.0f) {
+        const double z = (1.0 + x) * 0.5, s = vfs_sqrt64(z);
+        const double w = vfs_acos_pq(z) * s - pio2_lo;
+        return (float)(pi - 2.0 * (s + w));
+    }
+    const double z = (1.0 - x) * 0.5, s = vfs_sqrt64(z);
+    const double df = vfs_double(vfs_dbits(s) & 0xffffffff00000000ull);
+    const double c = (z - df * df) / (s + df);
+    const double w = vfs_acos_pq(z) * s + c;
+    return (float)(2.0 * (df + w));
+}
+
+/* ---- glibc 2.35 atan2f (sysdeps/ieee754/flt-32/e_atan2f.c + s_atanf.c: the fdlibm single-precision routines, "Copyright (C)
+ * 1993 by Sun Microsystems, Inc. ... Permission to use, copy, modify, and distribute this software is freely granted, provided
+ * that this notice is preserved"; plain separately rounded fp32 operations) --------------------------------------------------
+ * torch.atan2 runs SLEEF only through its vectorised loop, i.e. for contiguous operands; STRIDED operands go element by element
+ * through std::atan2 = this routine [probe: 0 mismatches in 4096 + all special values, glibc 2.35].  One call on the path sees
+ * strided operands: the auto-yaw `th.atan2(velocity_horizontal[1], velocity_horizontal[0])` of the velocity action type
+ * (envs/base/dynamics.py:423-427) whenever `_velocity` is the transposed view `vel.T` that Dynamics.reset stores when it is
+ * given velocities (:236; every env reset is) -- the in-place integrator updates (utils/maths.py:344) and clamp() (:381) keep
+ * that layout until the next full reset; after a reset() without velocities the tensor is contiguous and SLEEF runs. */
+VFS_INLINE float vfs_atanf_glibc(float x)
+{
+    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const uint32_t hx = vfs_bits(x), ix = hx & 0x7fffffffu;
+    const int neg = (hx >> 31) != 0;
+    int id;
+    if (ix >= 0x4c000000u) {                                        /* |x| >= 2^25 */
+        if (ix > 0x7f800000u) return x + x;                         /* NaN */
+        return neg ? -hi3 - lo3 : hi3 + lo3;
+    }
+    if (ix < 0x3ee00000u) {                                         /* |x| < 0.4375 */
+        if (ix < 0x31000000u) return x;                             /* |x| < 2^-29 */
+        id = -1;
+    } else {
+        x = vfs_abs32(x);
+        if (ix < 0x3f980000u) {                                     /* |x| < 1.1875 */
+            if (ix < 0x3f300000u) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }       /* 7/16 <= |x| < 11/16 */
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }                                /* 11/16 <= |x| < 19/16 */
+        } else {
+            if (ix < 0x401c0000u) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }       /* |x| < 2.4375 */
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float hi = id == 0 ? hi0 : (id == 1 ? hi1 : (id == 2 ? hi2 : hi3)), lo = id == 0 ? lo0 : (id == 1 ? lo1 : (id == 2 ? lo2 : lo3));
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return neg ? -r : r;
+}
+VFS_INLINE float vfs_atan2f_glibc(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const uint32_t hx = vfs_bits(x), hy = vfs_bits(y), ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    if (ix > 0x7f800000u || iy > 0x7f800000u) return x + y;        /* NaN */
+    if (hx == 0x3f800000u) return vfs_atanf_glibc(y);               /* x = 1 */
+    const int m = (int)((hy >> 31) & 1u) | (int)((hx >> 30) & 2u);  /* 2 sign(x) + sign(y) */
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return (hy >> 31) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000u) {
+        if (iy == 0x7f800000u) return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+        return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+    }
+    if (iy == 0x7f800000u) return (hy >> 31) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = ((int)iy - (int)ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                          /* |y / x| > 2^60 */
+    else if ((hx >> 31) && k < -60) z = 0.0f;                       /* |y| / x < -2^60 */
+    else z = vfs_atanf_glibc(vfs_abs32(y / x));
+    if (m == 0) return z;
+    if (m == 1) return vfs_float(vfs_bits(z) ^ 0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
 }
 
 /* ==== end of shared text ==== */

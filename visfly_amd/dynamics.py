@@ -49,6 +49,7 @@ class Dynamics:
             cfg: Union[str, dict] = "drone_state",
             wind_settings: Optional[List] = (0, 0, 0),
             rotor_sim: bool = True,
+            transcendentals: str = "cr",
             constants: Optional[dict] = None,
             _attach=None,
     ):
@@ -72,7 +73,8 @@ class Dynamics:
         # `constants` lets parity tests inject the golden fixture's constant bits verbatim
         self.constants = dict(constants) if constants is not None else derive_constants(
             action_type=action_type, dt=dt, ctrl_dt=ctrl_dt, ctrl_delay=ctrl_delay, comm_delay=comm_delay,
-            action_space=action_space, integrator=integrator, cfg=cfg, wind_settings=wind_settings)
+            action_space=action_space, integrator=integrator, cfg=cfg, wind_settings=wind_settings,
+            transcendentals=transcendentals)
         c = self.constants
         self._interval_steps = int(c["interval_steps"])
         self._comm_delay_steps = int(c["delay_steps"])

@@ -260,7 +260,7 @@ class DroneGymEnvsBase:
         drag_random = dkw.get("drag_random", 0)
         consts = constants if constants is not None else derive_constants(
             **{k: v for k, v in dkw.items() if k in ("action_type", "dt", "ctrl_dt", "ctrl_delay", "comm_delay",
-                                                     "action_space", "integrator", "cfg", "wind_settings")})
+                                                     "action_space", "integrator", "cfg", "wind_settings", "transcendentals")})
         self._boxes = spawn_boxes(random_kwargs)
         self._imu_noise = _imu_noise_model(random_kwargs)
         _reject_unsupported(scene_kwargs, sensor_kwargs)     # warns
@@ -308,7 +308,7 @@ class DroneGymEnvsBase:
             dyn = Dynamics(num=N, seed=seed, device=self.device, constants=consts,
                            **{k: v for k, v in dkw.items() if k != "constants"}, _attach=(hd, self._slab, G))
             self.envs = DroneEnvsBase(self, dyn)
-            self._spawner = ReplaySpawner(self._boxes, dyn.rng)
+            self._spawner = ReplaySpawner(self._boxes, dyn.rng, cr_trig=int(consts.get("trig_mode", 1)) == 1)
             # step outputs (re-used every step; the returned tensors are fresh clones only where the
             # reference returns fresh tensors to the caller)
             f32 = dict(dtype=th.float32, device=self.device)

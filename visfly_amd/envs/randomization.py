@@ -44,11 +44,14 @@ def spawn_boxes(random_kwargs: Optional[Dict]) -> List[Dict]:
                               "(Normal / TargetUniform need features outside SURVEY.md 8)")
 
 
-def _from_euler(roll, pitch, yaw):
-    """Quaternion.from_euler, zyx (utils/maths.py:256-269); same torch CPU ops -> same bits"""
-    cy, sy = th.cos(yaw * 0.5), th.sin(yaw * 0.5)
-    cp, sp = th.cos(pitch * 0.5), th.sin(pitch * 0.5)
-    cr, sr = th.cos(roll * 0.5), th.sin(roll * 0.5)
+def _from_euler(roll, pitch, yaw, cr_trig=True):
+    """Quaternion.from_euler, zyx (utils/maths.py:256-269); same torch CPU ops -> same bits.  cr_trig (the "cr" transcendental
+    mode, constants.derive_constants): sin / cos evaluated in fp64 and rounded once, as the golden generator patches torch's"""
+    cos = (lambda x: th.cos(x.double()).float()) if cr_trig else th.cos
+    sin = (lambda x: th.sin(x.double()).float()) if cr_trig else th.sin
+    cy, sy = cos(yaw * 0.5), sin(yaw * 0.5)
+    cp, sp = cos(pitch * 0.5), sin(pitch * 0.5)
+    cr, sr = cos(roll * 0.5), sin(roll * 0.5)
     return th.stack([cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy,
                      cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy], dim=1)
 
@@ -56,8 +59,8 @@ def _from_euler(roll, pitch, yaw):
 class ReplaySpawner:
     """Host-side replay of the reference's spawn draws on a shared torch CPU generator."""
 
-    def __init__(self, boxes: List[Dict], rng: th.Generator):
-        self.rng = rng
+    def __init__(self, boxes: List[Dict], rng: th.Generator, cr_trig: bool = True):
+        self.rng, self.cr_trig = rng, cr_trig
         self.boxes = [{f: (th.tensor(b[f]["mean"]), th.tensor(b[f]["half"])) for f in _FIELDS} for b in boxes]
 
     def _uniform(self, box, num):
@@ -85,12 +88,12 @@ class ReplaySpawner:
             o = u[:, 1] * oh.unsqueeze(0) + om.unsqueeze(0)
             v = u[:, 2] * vh.unsqueeze(0) + vm.unsqueeze(0)
             w = u[:, 3] * wh.unsqueeze(0) + wm.unsqueeze(0)
-            return p, _from_euler(o[:, 0], o[:, 1], o[:, 2]), v, w
+            return p, _from_euler(o[:, 0], o[:, 1], o[:, 2], self.cr_trig), v, w
         rows = []
         for _ in range(num):  # UnionRandomizer._generate (:284-296): every member draws, then randint picks
             members = [self._uniform(b, 1) for b in self.boxes]
             sel = int(th.randint(0, len(self.boxes), (1,), generator=self.rng))
             p, o, v, w = members[sel]
-            rows.append((p, _from_euler(o[:, 0], o[:, 1], o[:, 2]), v, w))
+            rows.append((p, _from_euler(o[:, 0], o[:, 1], o[:, 2], self.cr_trig), v, w))
         cat = lambda k: th.cat([r[k] for r in rows]) if rows else th.zeros((0, (3, 4, 3, 3)[k]))
         return cat(0), cat(1), cat(2), cat(3)
