@@ -16,6 +16,9 @@ cases = [
     ("configs[4] RacingEnv thrust euler (BPTT shard)", RacingEnv, 16384, dict(base, action_type="thrust", integrator="euler"), {}, [-0.8333] * 4),
     ("f1 HoverEnv velocity euler", HoverEnv, 65536, dict(base, action_type="velocity", integrator="euler"), {}, [0, 0, 0, 0]),
     ("f1 HoverEnv position euler", HoverEnv, 65536, dict(base, action_type="position", integrator="euler"), {}, [0, 0.1, 0, 0.15]),
+    ("configs[3] shape, transcendentals=sleef", NavigationEnv, 32768, dict(base, action_type="bodyrate", integrator="euler", transcendentals="sleef"),
+     dict(random_kwargs=spawn), [-1 / 3, 0, 0, 0]),
+    ("f1 velocity, transcendentals=sleef", HoverEnv, 65536, dict(base, action_type="velocity", integrator="euler", transcendentals="sleef"), {}, [0, 0, 0, 0]),
     ("1M agents HoverEnv bodyrate euler", HoverEnv, 1 << 20, dict(base, action_type="bodyrate", integrator="euler"), {}, [-1 / 3, 0, 0, 0]),
 ]
 for name, cls, N, dkw, kw, hover in cases:
