@@ -205,9 +205,27 @@ def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
     torch.cuda.synchronize()
     parallel.barrier()
     el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    # rooflines of the loop as a whole (it is a chain of 10-20 us launches at 256-1024 waves, i.e. latency-bound: both fractions are
+    # small by construction and are reported so that they can be tracked).  MFMA: policy trunk forward + data gradient + weight
+    # gradient = 6 flops per weight per agent-step.  HBM: algorithmic bytes per agent-step = the forward env step (350 B, SURVEY
+    # 8d) + the state checkpoint written to the tape and read back by the adjoint (2 slabs) + the adjoint slab in / out (2 slabs)
+    pol = algo.policy
+    w_pi = sum(ly.K * ly.No + ly.No for ly in pol.layers if not (ly.dst == "value" or ly.dst.startswith("vf:")))
+    steps_total = 64 * N * iters                      # this rank
+    tfs = 6.0 * w_pi * steps_total / el / 1e12
+    slab_bytes = env._slab.numel() * 4 / N
+    hbm_bytes = BYTES_PER_ENV_STEP + 4 * slab_bytes
+    gbs = hbm_bytes * steps_total / el / 1e9
+    roof = {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
+            "kernel": "whole update: policy forward chain + env step + adjoint env step + reverse chain + one weight-gradient launch per horizon",
+            "flops_per_agent_step": 6.0 * w_pi,
+            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_agent_step": hbm_bytes,
+                    "note": "env step 350 B + 4 slabs (tape write / read, adjoint in / out)"},
+            "note": "loop-level figures over the timed updates (wall clock, not one kernel): the loop is latency-bound -- "
+                    "profiles/r02_bptt_kernel_stats.txt lists the per-kernel times"}
     out = {"metric": "BPTT env-steps/s (H=64 rollout + adjoint + actor update, RacingEnv)",
            "value": 64 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
-           "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
+           "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic", "roofline": roof,
            "config": {"workload": f"RacingEnv {N} agents/GPU, thrust actions, horizon 64 (BASELINE configs[4] shard)",
                       "logs": {k: float(v) for k, v in algo.logs.items()}}}
     if cpu_ref and rank == 0:
@@ -347,13 +365,27 @@ def main():
     # ~20 ms of load to leave its idle state (a 20-step region right after process start runs at 12.85 us per step, the same region
     # after 2 000 untimed steps at 12.1 -- `--spinup-ms 0` switches this off).  Untimed, before the W warm-up steps; the timed
     # regions below still consist of exactly K steps each.
+    # The contract read literally -- W untimed warm-up steps, then exactly K timed steps, nothing else before them -- measured once,
+    # right after process start and BEFORE the spin-up: reported as value_without_spinup next to the headline
+    run_steps(min(K, seq.shape[0]), seq)                  # first use of the K-step output buffers is an allocation (untimed)
+    if W > 0:
+        run_steps(W, wseq)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(K, seq)
+    torch.cuda.synchronize()
+    cold_el = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([cold_el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cold_el = float(t.item())
     spin = int(args.spinup_ms * 1e3 / 11.0)
     if spin > 0:
         run_steps(spin, seq)
         torch.cuda.synchronize()
     if W > 0:
         run_steps(W, wseq)
-    run_steps(min(K, 64), seq)                            # first use of the K-step output buffers is an allocation
     walls, hosts, events, done_at = [], [], [], []
     for _ in range(max(1, args.repeats)):          # wall clock: nothing but the K launches between the two barriers
         barrier()
@@ -430,47 +462,68 @@ def main():
     if not args.no_reset_leg:
         rseq = (torch.rand((seq.shape[0], N, 4), device=dev, generator=g) * 2 - 1).contiguous()
         run_steps(max(256, seq.shape[0]), rseq)         # let the crashes spread over the episode phase
-        rwalls = []
-        for _ in range(3):
+        rwalls, revents = [], []
+        for _ in range(max(1, args.repeats)):           # the same clock as the headline: stops when the synchronize returns
             barrier()
             t0 = time.perf_counter()
             run_steps(K, rseq)
-            barrier()
+            torch.cuda.synchronize()
             rwalls.append(time.perf_counter() - t0)
+            barrier()
+        for _ in range(3):                              # and the same device-clock figure (HIP events over the K launches / K)
+            barrier()
+            e0.record()
+            run_steps(K, rseq)
+            e1.record()
+            barrier()
+            revents.append(e0.elapsed_time(e1) * 1e-3)
         rel = statistics.median(rwalls)
         dn = env._rollouts[rseq.shape[0]]["done"]
         with_resets = {"value": world * N * K / rel, "unit": "agent-steps/s", "us_per_step": rel / K * 1e6,
-                       "kernel_us": env.time_steps(rseq[0], iters=300),
+                       "kernel_us": statistics.median(revents) / K * 1e6,
+                       "vs_headline": el / rel, "kernel_us_vs_headline": (statistics.median(revents) / K * 1e6) / kern_us,
                        "episode_end_rate": float(dn.float().mean()), "steps_with_a_reset": float(dn.any(dim=1).float().mean()),
-                       "actions": "U(-1,1) (SURVEY 8(d) input 2, second run): per rank, not max-reduced over ranks"}
+                       "timing": "median of the repeated --steps regions, clock as for the headline; kernel_us = HIP events over "
+                                 "the K launches / K (median of 3)",
+                       "actions": "U(-1,1) (SURVEY 8(d) input 2, second run): per rank, not max-reduced over ranks",
+                       "spawn_prefetch": bool(env._ecfg.spawn_prefetch)}
 
     out = None
     if rank == 0:
         value = world * N * K / el
         achieved = BYTES_PER_ENV_STEP * N / (kern_us * 1e-6) / 1e9
-        traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (per-agent figure x N)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            traffic = (pmc["fetch_bytes_per_agent"] + pmc["write_bytes_per_agent"]) * N
-        except Exception:
-            pass
+        # HBM bytes per launch: NOT measured in this run -- read from the PMC pass committed under profiles/ (rocprofv3 --pmc in its
+        # own run, as MI355X_MICROARCH.md prescribes; per-agent figure x N), and labelled as such (roofline.traffic_source)
+        traffic, traffic_src = None, None
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                traffic = (pmc["fetch_bytes_per_agent"] + pmc["write_bytes_per_agent"]) * N
+                traffic_src = f"profiles/{name} (builder's rocprofv3 --pmc pass on the same kernel; not measured in this run)"
+                break
+            except Exception:
+                continue
         # the unit that is actually busy: fp32 VALU ISSUE of a single wave per SIMD.  Instruction count per wave
         # from the PMC pass committed under profiles/, 4.1 cycles per wave64 VALU instruction for a lone wave
         # (profiles/r02_valu_cost_probe.txt), 2.4 GHz.  Reported next to the HBM roofline the contract asks for.
         valu = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_env_sq.json")))["k_env_step"]
+            sq_name = "r03_pmc_env_sq.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_env_sq.json")) else "r02_pmc_env_sq.json"
+            sq = json.load(open(os.path.join(ROOT, "profiles", sq_name)))["k_env_step"]
             per_wave = sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]
             waves_per_simd = -(-(-(-N // 64)) // 1024)                 # ceil(waves / (256 CUs x 4 SIMDs))
             floor_us = waves_per_simd * per_wave * 4.1 / 2.4e3
             valu = {"valu_instr_per_wave": per_wave, "waves_per_simd": waves_per_simd, "cycles_per_instr_single_wave": 4.1,
-                    "floor_us": floor_us, "frac": floor_us / kern_us}
+                    "floor_us": floor_us, "frac": floor_us / kern_us,
+                    "source": f"instruction count from profiles/{sq_name} (builder's PMC pass, not measured in this run); "
+                              "kernel time from this run"}
         except Exception:
             pass
         out = {
             "metric": "agent-steps/sec (dynamics.step, visual=False)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value_without_spinup": world * N * K / cold_el,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"HoverEnv.step (fused dynamics + collision + reward + done + on-device auto-reset), "
                                    f"{N} agents/GPU, visual=False, bodyrate+euler, dt=0.0025/ctrl_dt=0.02, ctrl_delay, "
@@ -491,14 +544,17 @@ def main():
                                           "completion, i.e. without the ~20 us torch.cuda.synchronize() takes to return on an already "
                                           "idle device (1 us per step at --steps 20); rank 0's figure",
                        "spinup_steps": spin, "spinup_note": "untimed env steps before the W warm-up steps so that the device is at "
-                                                            "its sustained clocks (--spinup-ms, default 25 ms)"},
+                                                            "its sustained clocks (--spinup-ms, default 25 ms); value_without_spinup "
+                                                            "= the first K-step region of the process, timed right after W warm-up "
+                                                            "steps and before any spin-up (one region, max over ranks)",
+                       "ms_per_step_without_spinup": cold_el / K * 1e3},
             "with_resets": with_resets,
             "rollout_fused": {"value": world * N * K / fused_el, "unit": "agent-steps/s", "us_per_step": fused_el / K * 1e6,
                               "driver": "env.step_n(fused=True): the K steps of the region in ONE launch (vf_env_rollout_fused), agents "
                                         "held in registers between the steps; open-loop only (actions known up front), bit-identical "
                                         "outputs (tests/test_env_multistep_gpu.py); per rank, not max-reduced over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_env_step<hover,bodyrate,euler,ctrl_delay>", "kernel_us": kern_us,
                          "kernel_us_source": "HIP events on the launch stream over the timed K-step regions / K (median of 3)",
                          "kernel_us_300_launches_one_action": kern_us_300,

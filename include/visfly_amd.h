@@ -182,6 +182,20 @@ int vf_dyn_time_steps(vf_dyn* h, const float* action, float* state_out, int32_t 
  *   VF_G_AACC.c0 = _rewards running sum (fp32)         droneGymEnv.py:121
  *   VF_G_ACC.c0  = flag word (int32 bits): VF_F_* | episode counter << 8
  * RacingEnv adds one granule after the dynamics ones: (next gate, passed gates, is_pass_next, -).
+ *
+ * Prefetched re-spawn (vf_env_cfg.spawn_prefetch, r03).  The on-device auto-reset (examine() -> reset_agent_by_id,
+ * droneGymEnv.py:339-349,420-423) draws the new state from Philox keyed by (agent, episode) -- a pure function, so it can be
+ * evaluated BEFORE the episode ends.  With one wave per SIMD a launch lasts as long as its slowest wave, and one re-spawning
+ * agent made its whole wave ~1.2 us late (three Philox blocks + Euler -> quaternion).  With spawn_prefetch the slab holds two
+ * copies (A / B) of "the state agent i re-spawns into next": 2 x 4 granules after the racing granule,
+ *   (episode tag, p) (q) (t, v) (-, w);
+ * vf_env_step launches twice the blocks: the second half are HELPER blocks that look at their 64 agents' episode counter and
+ * refill stale copies (tag != episode + 1) of the buffer this launch does NOT read -- they share the SIMDs with the main waves,
+ * which leave three of four issue slots idle -- while a main wave that ends an episode takes the 4 granules of the OTHER buffer
+ * (loaded with its state burst) if their tag is the episode it needs, and falls back to drawing in place otherwise (first
+ * episodes after a reset, episodes of length one).  Buffers alternate with the step parity, so a copy is never read and
+ * written in the same launch; results are bit-identical to the in-place draw (tests/test_env_gpu.py).
+ * vf_env_rollout_fused, the two-wave split kernels (<= 32 768 agents) and vf_env_finish_step always draw in place.
  * ===================================================================================== */
 enum { VF_ENV_HOVER = 0, VF_ENV_NAV = 1, VF_ENV_RACING = 2 };
 enum {
@@ -220,6 +234,8 @@ typedef struct vf_env_cfg {
     /* observation / reward variants */
     int32_t obs_mode;             /* VF_OBS_*: raw state | HoverEnv2 (HoverEnv.py:136-152) | NavigationEnv2 (NavigationEnv.py:163-183) */
     int32_t reward_mode;          /* VF_REWARD_*: the kind's own reward | NavigationEnv2 reward + failure = is_collision (:155-224) */
+    int32_t spawn_prefetch;       /* != 0: the next re-spawn state of every agent is kept ready in the slab (see "Prefetched re-spawn") */
+    int32_t pad1;
 } vf_env_cfg;
 
 /* Outputs of one env step; obs/reward/done are required, the rest may be NULL. */

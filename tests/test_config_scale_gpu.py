@@ -116,5 +116,5 @@ def test_headline_size_properties_65536():
         count = torch.where(d, torch.zeros_like(count), count + 1)
         assert torch.equal(a._step_count, count), f"step counters @ {k}"
         assert bool((d | (count < 8)).all())
-    assert torch.equal(a._slab, b._slab)
+    assert torch.equal(a.state_slab, b.state_slab)
     assert int(done.sum()) >= N                       # every agent hit the 8-step time limit at least once

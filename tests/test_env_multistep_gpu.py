@@ -47,7 +47,7 @@ def test_step_n_equals_k_steps(cls_name, N):
         same(obs[k], outs[k][0]["state"], f"obs @ {k}")
         same(reward[k], outs[k][1], f"reward @ {k}")
         same(done[k], outs[k][2], f"done @ {k}")
-    same(env._slab, ref._slab, "slab after the rollout")
+    same(env.state_slab, ref.state_slab, "slab after the rollout")
     same(env._ep_return, ref._ep_return, "episode returns")
     same(env._ep_length, ref._ep_length, "episode lengths")
     same(env.get_observation()["state"], outs[-1][0]["state"], "get_observation() after step_n")
@@ -59,7 +59,7 @@ def test_step_n_equals_k_steps(cls_name, N):
     outs2 = [ref.step(B[k]) for k in range(K)]
     obs2, reward2, done2 = env.step_n(B)
     same(obs2[K - 1], outs2[-1][0]["state"], "second rollout: last obs")
-    same(env._slab, ref._slab, "slab after the second rollout")
+    same(env.state_slab, ref.state_slab, "slab after the second rollout")
 
 
 @pytest.mark.parametrize("cls_name,N", [("HoverEnv", 1000), ("NavigationEnv", 4099), ("RacingEnv", 777), ("HoverEnv", 70000)])
@@ -77,7 +77,7 @@ def test_fused_rollout_equals_k_steps(cls_name, N):
         same(obs[k], outs[k][0]["state"], f"obs @ {k}")
         same(reward[k], outs[k][1], f"reward @ {k}")
         same(done[k], outs[k][2], f"done @ {k}")
-    same(env._slab, ref._slab, "slab after the fused rollout")
+    same(env.state_slab, ref.state_slab, "slab after the fused rollout")
     same(env._ep_return, ref._ep_return, "episode returns")
     same(env._terminal_obs, ref._terminal_obs, "terminal observations")
     if cls_name == "RacingEnv":
@@ -88,7 +88,7 @@ def test_fused_rollout_equals_k_steps(cls_name, N):
     same(obs2[6], outs2[-1][0]["state"], "second fused rollout")
     x = actions(N, 1, seed=2)[0]
     same(env.step(x)[0]["state"], ref.step(x)[0]["state"], "step() after fused rollouts (ring phase, counters)")
-    same(env._slab, ref._slab, "slab")
+    same(env.state_slab, ref.state_slab, "slab")
 
 
 def test_fused_rollout_rk4_drag_randomisation():
@@ -105,7 +105,7 @@ def test_fused_rollout_rk4_drag_randomisation():
     for k in range(K):
         same(obs[k], outs[k][0]["state"], f"obs @ {k}")
         same(reward[k], outs[k][1], f"reward @ {k}")
-    same(env._slab, ref._slab, "slab (re-drawn per-agent drag granules included)")
+    same(env.state_slab, ref.state_slab, "slab (re-drawn per-agent drag granules included)")
 
 
 def test_step_n_is_test_keeps_done_agents():
@@ -117,7 +117,7 @@ def test_step_n_is_test_keeps_done_agents():
     for k in (0, 11, 12, K - 1):
         same(obs[k], outs[k][0]["state"], f"obs @ {k}")
         same(done[k], outs[k][2], f"done @ {k}")
-    same(env._slab, ref._slab, "slab")
+    same(env.state_slab, ref.state_slab, "slab")
 
 
 def test_graph_replay_equals_k_steps():
@@ -133,7 +133,7 @@ def test_graph_replay_equals_k_steps():
             same(obs[k], outs[k][0]["state"], f"round {rnd} obs @ {k}")
             same(reward[k], outs[k][1], f"round {rnd} reward @ {k}")
             same(done[k], outs[k][2], f"round {rnd} done @ {k}")
-        same(env._slab, ref._slab, f"round {rnd} slab")
+        same(env.state_slab, ref.state_slab, f"round {rnd} slab")
     assert len(env._rollouts[K]["graphs"]) == 1          # K is a multiple of the 3-slot delay ring: one graph serves every replay
     env.close()
 
@@ -152,7 +152,7 @@ def test_graph_replay_ring_phases_and_interleaved_steps():
         obs, reward, done = env.step_n(buf, graph=True)
         for k in (0, 1, 2, K - 1):
             same(obs[k], outs[k][0]["state"], f"round {rnd} obs @ {k}")
-        same(env._slab, ref._slab, f"round {rnd} slab")
+        same(env.state_slab, ref.state_slab, f"round {rnd} slab")
         if rnd == 2:
             extra = actions(N, 1, seed=99)[0]
             same(env.step(extra)[0]["state"], ref.step(extra)[0]["state"], "interleaved step()")
@@ -161,7 +161,7 @@ def test_graph_replay_ring_phases_and_interleaved_steps():
     phase = int(L.vf_env_ring_phase(env._h))
     wrong = next(g for key, g in env._rollouts[K]["graphs"].items() if key[2] != phase)
     assert L.vf_env_graph_launch(wrong, _lib.current_stream(env.device)) == -3 and b"phase" in L.vf_last_error()
-    same(env._slab, ref._slab, "a refused replay leaves the env untouched")
+    same(env.state_slab, ref.state_slab, "a refused replay leaves the env untouched")
 
 
 def test_output_ring_equals_fresh_tensors():
@@ -218,7 +218,7 @@ def test_step_n_c_abi_strides_and_errors():
     _lib.check(L.vf_env_step_n(env._h, C.byref(ro), _lib.current_stream(env.device)))
     same(obs, o["state"], "last obs")
     same(rew, r, "last reward")
-    same(env._slab, ref._slab, "slab")
+    same(env.state_slab, ref.state_slab, "slab")
     ro.K = 0
     assert L.vf_env_step_n(env._h, C.byref(ro), None) == -1 and b"K must be > 0" in L.vf_last_error()
     ro.K, ro.actions = 2, None
@@ -272,3 +272,50 @@ def test_export_pose_wind_and_partial_outputs():
     same(vel, obs["state"][:, 7:10].contiguous(), "velocity includes the wind (dynamics.py:751-752)")
     same(vel, env.velocity.contiguous(), "Dynamics.velocity")
     assert _lib.lib().vf_env_export_pose(None, None, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("kind", ["hover", "nav_dr", "racing"])
+def test_prefetched_respawn_is_bit_identical(kind):
+    """spawn_prefetch (helper blocks of the step launch draw every agent's NEXT re-spawn state ahead of time into the slab; a
+    wave that ends an episode only loads it) against the in-place draw: same Philox keys, so every output of every step --
+    observations after auto-reset, rewards, done flags, terminal rows, the full state -- is bit-identical; short episodes and
+    U(-1,1) actions, so that re-spawns happen in every step, incl. episodes of length one (which fall back to the in-place draw)"""
+    import visfly_amd.envs as E
+    N, steps = 65536 + 192, 70
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 0.6], "half": [1., 1., 0.58]},
+                                                                "orientation": {"mean": [0., 0., 0.], "half": [0.3, 0.3, 3.0]},
+                                                                "velocity": {"mean": [0., 0., 0.], "half": [1., 1., 1.]}}]}}
+    dkw = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+    cls, kw = E.HoverEnv, dict(random_kwargs=spawn)
+    if kind == "nav_dr":
+        cls, dkw = E.NavigationEnv, dict(dkw, drag_random=0.1)
+    elif kind == "racing":
+        cls, kw, dkw = E.RacingEnv, {}, dict(dkw, action_type="thrust")
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    acts = torch.rand((steps, N, 4), device="cuda:0", generator=g) * 2 - 1
+    outs = []
+    for pf in (True, False):
+        env = cls(num_agent_per_scene=N, seed=11, dynamics_kwargs=dict(dkw), device="cuda:0", max_episode_steps=7, tensor_output=True,
+                  spawn_prefetch=pf, **kw)
+        assert bool(env._ecfg.spawn_prefetch) == pf
+        env.reset()
+        rec = []
+        for t in range(steps):
+            obs, r, d, _ = env.step(acts[t])
+            rec.append((obs["state"].clone(), r.clone(), d.clone(), env._terminal_obs.clone(), env._ep_return.clone()))
+        rec.append((env.full_state.clone(),))
+        # step_n (the launch loop in C) takes the same path
+        o2, r2, d2 = env.step_n(acts[:16].contiguous())
+        rec.append((o2.clone(), r2.clone(), d2.clone(), env.full_state.clone()))
+        outs.append(rec)
+        env.close()
+    n_done = 0
+    for t, (a, b) in enumerate(zip(*outs)):
+        for x, y in zip(a, b):
+            if x.dtype == torch.bool or x.dtype == torch.uint8:
+                assert torch.equal(x, y), f"step {t}"
+            else:
+                assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"step {t}"
+        if t < steps:
+            n_done += int(a[2].sum())
+    assert n_done > N * steps // 8           # every agent ends an episode at least every 7 steps

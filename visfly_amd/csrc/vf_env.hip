@@ -27,6 +27,9 @@ struct EnvArgs {
     // scene manager computed for the pose the dynamics interval produced (droneEnv.py:330-342); null = the bbox query
     const float* ext_point = nullptr;
     const unsigned char* ext_oob = nullptr;
+    // prefetched re-spawn (include/visfly_amd.h): granule index of the copy this launch READS (main waves) and of the copy its
+    // helper blocks REFILL, or -1; helper != 0: the second half of the grid are helper blocks
+    int g_spawn_rd = -1, g_spawn_wr = -1, helper = 0;
 };
 
 // env counters <-> spare slots
@@ -61,6 +64,27 @@ __device__ __forceinline__ int collision_flags(int flags, const Collision& col)
 // Everything of DroneGymEnvsBase.step that follows the dynamics interval, for ONE agent held in
 // registers: bbox collision, counters, success / reward, done masks, episode outputs, auto-reset,
 // stores (envs/base/droneGymEnv.py:161-218,339-423; envs/base/droneEnv.py:345-371).
+// one copy of an agent's prefetched re-spawn state (include/visfly_amd.h "Prefetched re-spawn"): (episode tag, p) (q) (t, v) (-, w)
+struct SpawnSlot {
+    float4 g0, g1, g2, g3;
+};
+
+// helper blocks of k_env_step: refill the copy this launch does not read for every agent whose copy is stale
+__device__ __forceinline__ void spawn_helper(const vf_env_cfg& e, const EnvArgs& g, int i)
+{
+    if (i >= g.d.N) return;
+    const unsigned need = ((unsigned)__float_as_int(granule(g.d.S, g.d.G, i, VF_G_ACC)->x) >> 8) + 1u;   // episode counter + 1
+    float4* dst = granule(g.d.S, g.d.G, i, g.g_spawn_wr);
+    if (__float_as_uint(dst->x) == need) return;
+    Agent s;
+    spawn_agent(e, i, need, true, s);
+    const int gs = 64;                                   // float4 between two granules of one agent (wave-tile AoSoA)
+    dst[0] = make_float4(__uint_as_float(need), s.p[0], s.p[1], s.p[2]);
+    dst[gs] = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
+    dst[2 * gs] = make_float4(s.t, s.v[0], s.v[1], s.v[2]);
+    dst[3 * gs] = make_float4(0.0f, s.w[0], s.w[1], s.w[2]);
+}
+
 template <int KIND, bool STORE_STATE = true, bool EXT = false>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile)
@@ -121,6 +145,15 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     er.flags = set_flag(er.flags, VF_F_FAILURE, failure);
     er.flags = set_flag(er.flags, VF_F_DONE, done);
 
+    // prefetched re-spawn: only a wave that ends an episode touches the copy -- four exec-masked 16-byte loads, issued as soon as
+    // `done` is known so that they travel under the terminal-row stores (loading them with the state burst of EVERY wave cost
+    // the no-reset launch 0.45 us: profiles/r03_reset_prefetch.txt)
+    SpawnSlot slot;
+    const bool use_slot = done && g.auto_reset && g.g_spawn_rd >= 0;
+    if (use_slot) {
+        const float4* src = granule(g.d.S, g.d.G, i, g.g_spawn_rd);
+        slot.g0 = src[0]; slot.g1 = src[64]; slot.g2 = src[128]; slot.g3 = src[192];
+    }
     float o[13];
     obs_row(c, s, o);
     obs_variant(e, o);
@@ -154,7 +187,15 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
             passed = 0;
             race.z = __int_as_float(0);
         }
-        spawn_agent(e, i, episode, true, s);
+        if (use_slot && __float_as_uint(slot.g0.x) == episode) {   // the state this episode starts from was drawn ahead of time
+            s.p[0] = slot.g0.y; s.p[1] = slot.g0.z; s.p[2] = slot.g0.w;
+            s.q = Quat{slot.g1.x, slot.g1.y, slot.g1.z, slot.g1.w};
+            s.t = slot.g2.x;
+            s.v[0] = slot.g2.y; s.v[1] = slot.g2.z; s.v[2] = slot.g2.w;
+            s.w[0] = slot.g3.y; s.w[1] = slot.g3.z; s.w[2] = slot.g3.w;
+        } else {
+            spawn_agent(e, i, episode, true, s);
+        }
         reset_rotors(c, s);
         for (int q = 0; q < c.delay_steps; ++q)
             *granule(g.d.S, g.d.G, i, VF_G_RING + q) = make_float4(0.f, 0.f, 0.f, 0.f);     // dynamics.py:262-263
@@ -190,6 +231,13 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     const vf_dyn_cfg& c = *cp;   // persistent device copies (vf_handles.hpp): L2-resident from launch to launch
     const vf_env_cfg& e = *ep;
     __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
+    if (g.helper) {                                  // second half of the grid: helper blocks (prefetched re-spawn)
+        const int nbm = (int)(gridDim.x >> 1);
+        if ((int)blockIdx.x >= nbm) {
+            spawn_helper(e, g, ((int)blockIdx.x - nbm) * kBlock + (int)threadIdx.x);
+            return;
+        }
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.d.N;
     Agent s;
@@ -510,10 +558,19 @@ vf::DynArgs dyn_args(const vf_env* h, const float* action, float* obs, int ahead
 int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int auto_reset, hipStream_t st, int ahead = 0)
 {
     vf::EnvArgs g{dyn_args(h, action, out->obs, ahead), *out, h->g_race, auto_reset};
-    if (vf::use_split(h->dyn.Npad, h->dyn.cfg))
+    if (vf::use_split(h->dyn.Npad, h->dyn.cfg)) {
         hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
-    else
-        hipLaunchKernelGGL(pick_env_kernel(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
+    } else {
+        unsigned nb = h->dyn.Npad / vf::kBlock;
+        if (h->g_spawn >= 0 && auto_reset) {     // prefetched re-spawn: main blocks read copy `par`, helper blocks refill the other
+            const int par = (int)((h->dyn.tick + ahead) & 1);
+            static const int mode = [] { const char* e = getenv("VISFLY_AMD_PREFETCH_MODE"); return e ? atoi(e) : 3; }();   // A/B: 1 = slot loads only, 2 = helper only
+            if (mode & 1) g.g_spawn_rd = h->g_spawn + 4 * par;
+            g.g_spawn_wr = h->g_spawn + 4 * (1 - par);
+            if (mode & 2) { g.helper = 1; nb *= 2; }
+        }
+        hipLaunchKernelGGL(pick_env_kernel(h), dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
+    }
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
@@ -532,10 +589,11 @@ int vf_env_create(const vf_dyn_cfg* dyn, const vf_env_cfg* env, int32_t N, int32
         return vf::fail(VF_EINVAL, "vf_env_create: n_gates must be 1..%d", VF_MAX_GATES);
     if (env->max_episode_steps <= 0) return vf::fail(VF_EINVAL, "vf_env_create: max_episode_steps must be > 0");
     vf_env* h = new vf_env;
-    const int extra = env->kind == VF_ENV_RACING ? 1 : 0;
+    const int racing = env->kind == VF_ENV_RACING ? 1 : 0, extra = racing + (env->spawn_prefetch ? 8 : 0);
     vf::init_dyn_handle(&h->dyn, dyn, N, per_agent_drag, extra);
     h->cfg = *env;
-    h->g_race = extra ? h->dyn.g_extra : -1;
+    h->g_race = racing ? h->dyn.g_extra : -1;
+    h->g_spawn = env->spawn_prefetch ? h->dyn.g_extra + racing : -1;
     int rc = vf::upload_cfg(h->dyn.cfg, &h->dyn.d_cfg);
     if (rc == VF_OK) rc = vf::upload_cfg(h->cfg, &h->d_cfg);
     if (rc != VF_OK) {

@@ -29,6 +29,7 @@ struct vf_env {
     vf_dyn dyn;
     vf_env_cfg cfg;
     int g_race;  // racing granule or -1
+    int g_spawn = -1;  // first of the 2 x 4 prefetched re-spawn granules or -1 (vf_env_cfg.spawn_prefetch)
     vf_env_cfg* d_cfg = nullptr;   // device copy of cfg, see vf_dyn::d_cfg
 };
 

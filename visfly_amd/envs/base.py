@@ -230,10 +230,14 @@ class DroneGymEnvsBase:
             gates=None,
             constants: Optional[dict] = None,
             out_buffers: int = 0,
+            spawn_prefetch: Optional[bool] = None,
     ):
         """out_buffers = R > 0: step() writes into a ring of R pre-allocated (obs, reward, done) sets instead of fresh tensors
         -- no allocation and no Python object construction on the hot path; what step t returned stays valid until step
-        t + R.  0 (default) returns fresh tensors every step like the reference."""
+        t + R.  0 (default) returns fresh tensors every step like the reference.
+        spawn_prefetch (default: on for spawn="device" without requires_grad): the state an agent re-spawns into is drawn ahead of
+        its episode end by helper blocks of the step launch and kept in the slab (8 granules per agent; include/visfly_amd.h
+        "Prefetched re-spawn") -- bit-identical results, the re-spawning wave no longer holds up the launch."""
         if visual:
             raise NotImplementedError("visual=True needs the external Habitat-sim renderer; the MI355X engine "
                                       "covers the visual=False path (SURVEY.md 8)")
@@ -292,6 +296,9 @@ class DroneGymEnvsBase:
                     getattr(sb, name + "_mean")[d] = b[f]["mean"][d]
                     getattr(sb, name + "_half")[d] = b[f]["half"][d]
         e.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if spawn_prefetch is None:       # the tape of a requires_grad env copies the slab every step: keep it small there
+            spawn_prefetch = spawn == "device" and not requires_grad
+        e.spawn_prefetch = int(bool(spawn_prefetch))
         self._ecfg = e
 
         L = _lib.lib()
@@ -398,6 +405,11 @@ class DroneGymEnvsBase:
         """ "state" entry of agent i's terminal observation from the (N,13) rows the step kernel wrote where done (already in
         the env's obs_mode); envs that assemble their observation on the host override this"""
         return tobs[i]
+
+    @property
+    def state_slab(self):
+        """the slab without the prefetched re-spawn copies (which launch path refilled them last is not part of the env's state)"""
+        return self._slab[:, :self._slab.shape[1] - (8 if self._ecfg.spawn_prefetch else 0)]
 
     def _terminal_state_rows(self):
         """(N, w) "state" rows of the terminal observations in the env's own observation map, valid where `done` was set by the
