@@ -32,7 +32,8 @@ extern "C" {
                                  clip_range_vf, vf_comm_* / vf_allreduce_grads (RCCL);
                               5: vf_dyn_ring_phase / vf_dyn_set_ring_phase / vf_env_set_ring_phase, capture guard on
                                  vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update,
-                                 vf_dyn_cfg.trig_mode (was pad0) */
+                                 vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
+                                 vf_dyn_step_bwd, vf_debug_poison_lds */
 
 typedef void* vf_stream_t;
 
@@ -250,6 +251,11 @@ typedef struct vf_env_out {
     int32_t* gate;        /* (N,)   RacingEnv next-gate observation after auto-reset            */
     int32_t* ep_past_gates; /* (N,) RacingEnv gates passed in the finished episode, written where done (RacingEnv.py:113-116) */
     int32_t* terminal_gate; /* (N,) RacingEnv "gate" entry of the terminal observation (pre-reset), written where done */
+    /* compacted done list: the indices of the agents whose `done` this step set, in no particular order (one
+     * atomic per wave), and their number.  vf_env_step zeroes *done_count before the launch; capacity N.  Optional (both or
+     * neither); the multi-step entry points (vf_env_step_n, vf_env_rollout_fused, vf_env_graph_*) ignore them. */
+    int32_t* done_list;
+    int32_t* done_count;
 } vf_env_out;
 
 /* Dense per-agent view of the env state for the reference's properties (droneGymEnv.py:477-571,
@@ -376,6 +382,16 @@ typedef struct vf_env_bwd_args {
     const uint8_t* done; float* adj_slab; float* d_action;
 } vf_env_bwd_args;
 int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* args, vf_stream_t stream);
+/* Dynamics.step's own reverse pass: the same kernel on a bare vf_dyn handle -- no reward term, no episode ends.
+ *   tape_slab copy of the slab taken BEFORE the vf_dyn_step call, action what that call was given, d_state (N,13) dLoss/d(state it
+ *   returned) or NULL, adj_slab in/out as above, d_action (N,4) out.  Thrust / bodyrate actions, Euler / RK4. */
+int vf_dyn_step_bwd(vf_dyn* h, const float* tape_slab, const float* action, const float* d_state, float* adj_slab,
+                    float* d_action, vf_stream_t stream);
+/* SURVEY 8b.4 also lists `*_cpu` twins of these entry points in the CPU restatement library.  The restatement (oracle/
+ * vf_oracle.h, test infrastructure) keeps an ABI of its own instead -- vfo_dyn_step, vfo_env_post_step, vfo_gae, vfo_td_returns ...
+ * on the reference's (C, N) row layout with host pointers -- because it restates the REFERENCE's data layout and call
+ * structure (one function per reference method), not this library's fused launches; the parity tests drive both through their
+ * Python wrappers (oracle.OracleDynamics / OracleEnv vs visfly_amd.Dynamics / envs). */
 
 /* =====================================================================================
  * PPO inner loop on the device (utils/algorithms/PPO.py:177-337; SB3 2.2.1 RolloutBuffer /

@@ -319,3 +319,22 @@ def test_prefetched_respawn_is_bit_identical(kind):
         if t < steps:
             n_done += int(a[2].sum())
     assert n_done > N * steps // 8           # every agent ends an episode at least every 7 steps
+
+
+def test_compacted_done_list_matches_the_done_flags():
+    """vf_env_out.done_list / done_count: the unordered set of indices equals where(done), through resets"""
+    env = make("HoverEnv", 70000)
+    env.enable_done_list()
+    A = actions(70000, 30, seed=5, wide=1.0)
+    seen = 0
+    for t in range(30):
+        _, _, done, _ = env.step(A[t])
+        idx = env.done_indices()
+        want = torch.where(done)[0].to(torch.int32)
+        assert idx.numel() == want.numel() and torch.equal(torch.sort(idx).values, want), f"step {t}"
+        seen += int(want.numel())
+    assert seen > 70000
+    ref = make("HoverEnv", 70000)
+    for t in range(30):
+        ref.step(A[t])
+    same(env.state_slab, ref.state_slab, "the list is an extra output: the state does not depend on it")

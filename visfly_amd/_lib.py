@@ -100,7 +100,7 @@ class EnvCfg(C.Structure):
 class EnvOut(C.Structure):
     """mirror of vf_env_out (device pointers)"""
     _fields_ = [(n, C.c_void_p) for n in ("obs", "reward", "done", "ep_return", "ep_length", "ep_flags",
-                                          "terminal_obs", "gate", "ep_past_gates", "terminal_gate")]
+                                          "terminal_obs", "gate", "ep_past_gates", "terminal_gate", "done_list", "done_count")]
 
 
 class EnvRollout(C.Structure):
@@ -213,6 +213,7 @@ SIGNATURES = {
     "vf_twin_q_loss": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int64, _vp]),
     "vf_polyak_update": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, _vp]),
     "vf_debug_poison_lds": (C.c_int, [_vp]),
+    "vf_dyn_step_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vf_env_ring_phase": (C.c_int32, [_vp]),
     "vf_env_set_ring_phase": (C.c_int, [_vp, C.c_int32]),
     "vf_dyn_ring_phase": (C.c_int32, [_vp]),

@@ -214,6 +214,7 @@ void vf_dyn_destroy(vf_dyn* h)
 {
     if (!h) return;
     vf::release_cfg(&h->d_cfg);
+    vf::release_cfg(&h->d_env_dummy);
     delete h;
 }
 

@@ -145,6 +145,16 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     er.flags = set_flag(er.flags, VF_F_FAILURE, failure);
     er.flags = set_flag(er.flags, VF_F_DONE, done);
 
+    if (g.out.done_list) {                       // compacted done list: one atomic per wave that has an ending agent
+        const unsigned long long m = __ballot(live && done);
+        if (m) {
+            const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(g.out.done_count, __popcll(m));
+            base = __shfl(base, first);
+            if (live && done) g.out.done_list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
+    }
     // prefetched re-spawn: only a wave that ends an episode touches the copy -- four exec-masked 16-byte loads, issued as soon as
     // `done` is known so that they travel under the terminal-row stores (loading them with the state burst of EVERY wave cost
     // the no-reset launch 0.45 us: profiles/r03_reset_prefetch.txt)
@@ -608,6 +618,7 @@ void vf_env_destroy(vf_env* h)
 {
     if (!h) return;
     vf::release_cfg(&h->dyn.d_cfg);
+    vf::release_cfg(&h->dyn.d_env_dummy);
     vf::release_cfg(&h->d_cfg);
     delete h;
 }
@@ -651,6 +662,9 @@ int vf_env_step(vf_env* h, const float* action, const vf_env_out* out, int32_t a
     if (!out->obs || !out->reward || !out->done) return vf::fail(VF_EINVAL, "vf_env_step: obs, reward and done outputs are required");
     if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_env_step: vf_env_bind has not been called");
     if (int rc = vf::refuse_capture(&h->dyn, vf::as_stream(stream), "vf_env_step")) return rc;
+    if ((out->done_list == nullptr) != (out->done_count == nullptr))
+        return vf::fail(VF_EINVAL, "vf_env_step: done_list and done_count come together");
+    if (out->done_count) VF_HIP(hipMemsetAsync(out->done_count, 0, sizeof(int32_t), vf::as_stream(stream)));
     if (int rc = launch_env_step(h, action, out, auto_reset, vf::as_stream(stream))) return rc;
     h->dyn.tick += 1;
     return VF_OK;
@@ -674,6 +688,7 @@ int check_rollout(const vf_env* h, const vf_env_rollout* r, const char* who)
 int enqueue_rollout(vf_env* h, const vf_env_rollout* r, hipStream_t st)
 {
     vf_env_out o = r->out;
+    o.done_list = o.done_count = nullptr;          // per-step outputs of vf_env_step only
     const float* a = r->actions;
     for (int k = 0; k < r->K; ++k) {
         if (int rc = launch_env_step(h, a, &o, r->auto_reset, st, k)) return rc;
@@ -708,6 +723,7 @@ int vf_env_rollout_fused(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
     if (int rc = check_rollout(h, r, "vf_env_rollout_fused")) return rc;
     if (r->action_stride % 4) return vf::fail(VF_EINVAL, "vf_env_rollout_fused: action_stride must be a multiple of 4 floats");
     vf::EnvArgs g{dyn_args(h, r->actions, r->out.obs), r->out, h->g_race, r->auto_reset};
+    g.out.done_list = g.out.done_count = nullptr;
     g.K = r->K;
     g.action_stride = r->action_stride / 4;
     g.obs_stride = r->obs_stride;

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg* __res
     for (int k = 0; k < 3; ++k) { s.v[k] = clampf(s.v[k], -c.vel_lim, c.vel_lim); s.w[k] = clampf(s.w[k], -c.omg_lim, c.omg_lim); }
 
     // ---- incoming adjoints of the post-step state (zero for agents reset at the end of this step) ----
-    const bool cut = live ? (g.done[i] != 0) : true;
+    const bool cut = live ? (g.done != nullptr && g.done[i] != 0) : true;
     float lp[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lw[3] = {0, 0, 0}, lwm[4] = {0, 0, 0, 0}, laa[3] = {0, 0, 0};
     Quat lq{0, 0, 0, 0};
     if (!cut) {
@@ -587,6 +587,36 @@ extern "C" int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* a, vf_stream_t 
     vf::BwdArgs g{h->dyn.N, h->dyn.G, h->dyn.g_drag, h->g_race, a->tape_slab, reinterpret_cast<const float4*>(a->action),
                   a->d_obs, a->d_reward, a->done, a->adj_slab, reinterpret_cast<float4*>(a->d_action)};
     hipLaunchKernelGGL(k, dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, g);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+// Dynamics.step's own reverse pass (SURVEY 8b.4 `vf_dyn_step_bwd`): what autograd does for a loss on the states a bare
+// `Dynamics` object returns (no env layer, hence no reward term and no episode ends) -- the env adjoint above with d_reward = NULL
+// and nobody done, on a vf_dyn handle.  The kernel wants an env constant block: a zeroed one, uploaded once per handle.
+extern "C" int vf_dyn_step_bwd(vf_dyn* h, const float* tape_slab, const float* action, const float* d_state, float* adj_slab,
+                               float* d_action, vf_stream_t stream)
+{
+    if (!h || !tape_slab || !action || !adj_slab || !d_action) return vf::fail(VF_EINVAL, "vf_dyn_step_bwd: null argument");
+    if (h->cfg.action_type != VF_ACT_THRUST && h->cfg.action_type != VF_ACT_BODYRATE)
+        return vf::fail(VF_EINVAL, "vf_dyn_step_bwd: the adjoint covers the thrust and bodyrate action types only");
+    if (h->wind)
+        return vf::fail(VF_EUNSUPPORTED, "vf_dyn_step_bwd: per-agent wind rows are set (vf_dyn_set_wind): see vf_env_step_bwd");
+    const int S = h->cfg.interval_steps;
+    if (S > 10) return vf::fail(VF_EINVAL, "vf_dyn_step_bwd: at most 10 sub-steps per control interval (LDS budget)");
+    if (!h->d_cfg) return vf::fail(VF_ESTATE, "vf_dyn_step_bwd: the handle has no device constant block");
+    if (!h->d_env_dummy) {
+        vf_env_cfg z{};
+        z.kind = VF_ENV_HOVER;
+        if (int rc = vf::upload_cfg(z, &h->d_env_dummy)) return rc;
+    }
+    const size_t lds = (size_t)S * vf::kSave * vf::kBlock * sizeof(float);
+    BwdKernel k = pick_bwd<VF_ENV_HOVER>(h->cfg);
+    if (lds > 64 * 1024)
+        VF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    vf::BwdArgs g{h->N, h->G, h->g_drag, -1, tape_slab, reinterpret_cast<const float4*>(action), d_state, nullptr, nullptr, adj_slab,
+                  reinterpret_cast<float4*>(d_action)};
+    hipLaunchKernelGGL(k, dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), lds, vf::as_stream(stream), h->d_cfg, h->d_env_dummy, g);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -21,6 +21,7 @@ struct vf_dyn {
     // scalar loads miss all the way to HBM; the persistent copy stays in the XCD L2s from launch to launch (65 536 agents:
     // 11.5 -> 10.7 us per step, tools/env_step_probe.hip; a lone 64-agent wave pays ~1 us for the extra dependent load).
     vf_dyn_cfg* d_cfg = nullptr;
+    struct vf_env_cfg* d_env_dummy = nullptr;   // vf_dyn_step_bwd only: the adjoint kernel's (unused) env constant block
     // per-agent wind rows (N x 4 floats, caller-owned device memory; vf_dyn_set_wind / vf_env_set_wind) or null = cfg.wind
     const float* wind = nullptr;
 };

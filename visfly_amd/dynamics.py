@@ -223,6 +223,19 @@ class Dynamics:
             self._last_action = a
         return out
 
+    def backward_step(self, tape_slab, action, d_state, adj_slab):
+        """reverse pass of ONE step() of a bare Dynamics object (vf_dyn_step_bwd; what autograd does through
+        dynamics.py:319-372 when the loss reads the returned state): ``tape_slab`` = a clone of ``self._slab`` taken before
+        that step, ``action`` what it was given, ``d_state`` (N,13) dLoss/d(returned state) or None, ``adj_slab`` the adjoint
+        of the persistent state (same shape as the slab, in/out: zeros after the last step of the horizon).  -> dLoss/d action"""
+        with th.cuda.device(self.device):
+            a = _as_device_f32(action, self.device, 4)
+            d_action = th.empty((self.num, 4), dtype=th.float32, device=self.device)
+            ds = None if d_state is None else d_state.to(self.device, dtype=th.float32).reshape(self.num, 13).contiguous()
+            _lib.check(_lib.lib().vf_dyn_step_bwd(self._h, _lib.ptr(tape_slab), _lib.ptr(a), _lib.ptr(ds), _lib.ptr(adj_slab),
+                                                  _lib.ptr(d_action), self._stream()))
+        return d_action
+
     # ------------------------------------------------------------------ properties
     def _vec(self, g):
         """(N,3) copy of the xyz components of granule g"""

@@ -369,7 +369,31 @@ class DroneGymEnvsBase:
         o.gate = _lib.ptr(self._gate)
         o.ep_past_gates = _lib.ptr(self._ep_past_gates)
         o.terminal_gate = _lib.ptr(self._terminal_gate)
+        dl = getattr(self, "_done_list", None)
+        if dl is not None:
+            o.done_list, o.done_count = dl[0].data_ptr(), dl[1].data_ptr()
         return o
+
+    def enable_done_list(self, on: bool = True):
+        """every step() additionally leaves the compacted list of the agents it finished (vf_env_out.done_list / done_count):
+        ``done_indices()`` -> int32 tensor (unordered), what ``th.where(done)[0]`` costs a full pass over `done` for"""
+        if on:
+            self._done_list = (th.zeros(self.num_agent, dtype=th.int32, device=self.device), th.zeros(1, dtype=th.int32, device=self.device))
+        else:
+            self._done_list = None
+        self._outs = self._out(self._terminal_obs, self._ep_return, self._ep_flags)
+        self._outs_ref = C.byref(self._outs)
+        if self._ring:
+            with th.cuda.device(self.device):
+                self._ring = [_OutSlot(self) for _ in self._ring]
+        return self
+
+    def done_indices(self):
+        """indices of the agents the LAST step() finished (needs enable_done_list(); one host sync for the count)"""
+        if getattr(self, "_done_list", None) is None:
+            raise VisflyError("done_indices(): call enable_done_list() first")
+        lst, cnt = self._done_list
+        return lst[:int(cnt.item())]
 
     def _query(self):
         if self._qcache is None:
