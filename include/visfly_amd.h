@@ -33,7 +33,7 @@ extern "C" {
                               5: vf_dyn_ring_phase / vf_dyn_set_ring_phase / vf_env_set_ring_phase, capture guard on
                                  vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update,
                                  vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
-                                 vf_dyn_step_bwd, vf_debug_poison_lds */
+                                 vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout */
 
 typedef void* vf_stream_t;
 
@@ -720,6 +720,25 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * already maps (PyTorch ships its own copy).
  * ===================================================================================== */
 #define VF_COMM_ID_BYTES 128
+/* The forward half of a BPTT horizon as ONE persistent launch (BPTT.py:107-124 is a closed loop: policy(obs_t) -> action_t ->
+ * env.step -> obs_{t+1}): a wave owns 16 agents for all H steps -- 16-rows-per-wave policy chain + action head, state
+ * checkpoint for the adjoint, fused env step with the agent in registers, loss / discount recurrence -- and leaves exactly what
+ * H rounds of vf_mlp_forward_act + vf_env_step + vf_bptt_accumulate_checkpoint leave (bit-identical):
+ *   desc          the policy's layer table with the `save` pointers of slot 0; the slots of the horizon are stored back to back
+ *                 ([H][N][w] per buffer), so row t N + i addresses slot t (as for vf_mlp_weight_grad over a horizon)
+ *   obs_slots0/1  [H][N][w] observation copies of the slots; slot 0 holds the current observation, slot t + 1 is written by
+ *                 step t (obs_slots1 = the constant "target" rows of NavigationEnv, filled by the caller, or NULL)
+ *   eps, actions  [H][N][4]: reparameterisation noise in, actions out (the tape's action rows)
+ *   out           episode outputs as for vf_env_step; out->reward = N floats of scratch; obs / done are ignored
+ *   obs_final     (N,13) observation after the last step;  tape [H] rows of tape_stride floats;  tape_done [H][N]
+ *   d_reward      [H][N] = -disc_t * scale;  loss / disc (N,) in/out as for vf_bptt_accumulate
+ * VF_EUNSUPPORTED unless: policy-only network of the register-chained classes, Hover / Racing / Navigation env with the
+ * raw-state observation, thrust / bodyrate actions, Euler, ctrl_delay, constant wind. */
+int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const float* obs_slots0,
+                    const float* obs_slots1, const float* log_std, const float* eps, float* actions, const vf_env_out* out,
+                    float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done, float* d_reward, float* loss,
+                    float* disc, float gamma, float scale, int32_t H, vf_stream_t stream);
+
 /* ---- SHAC (utils/algorithms/shac.py:215-278; actor / twin critic of utils/policies/td_policies.py:82-252) -----------------
  * The networks are vf_mlp_desc layer tables like the PPO policy's (actor: two 4-wide heads mu / log_std over one extractor;
  * critic: features (+) action -> two Q trunks, the action columns entering through a frozen identity layer); the env step and

@@ -82,6 +82,7 @@ class BPTT:
         parallel.broadcast_(self.policy.flat)
         self.policy.mark_updated()
         self.use_autograd = False           # True: torch.autograd schedules the same kernels (cross-check path)
+        self.fused_rollout = True           # forward half of a horizon as one persistent launch where the library has the kernel
         self._defer_wgrad = None            # decided at the first update (MlpPolicy.backward_data_supported)
         n = self.policy.n_params
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=self.device), th.zeros(n, device=self.device)
@@ -131,7 +132,11 @@ class BPTT:
         acts, drews = th.empty((H, N, 4), device=dev), th.empty((H, N), device=dev)
         epss = th.randn((H, N, 4), device=dev, generator=self._gen)
         ckpt_done = False
-        for t in range(H):
+        fused = False
+        if defer and self.fused_rollout and pol._act_fused is not False:
+            # the whole forward half as one persistent launch (vf_bptt_rollout): same kernels' arithmetic, same buffers
+            fused = env.rollout_policy(pol, self.obs_keys, epss, acts, drews, loss_vec, disc, float(self.gamma), 1.0 / (N * self.world))
+        for t in range(0 if not fused else H, H):
             action = acts[t]
             o = {k: obs[k].detach().contiguous() for k in self.obs_keys}
             if not (defer and pol.forward_act(o, epss[t], action, slot=t)):      # action head fused into the forward launch

@@ -1,0 +1,170 @@
+// vf_bptt_rollout.hip -- the forward half of a BPTT horizon as ONE persistent launch (gfx950).
+//
+// BPTT.learn's inner loop (utils/algorithms/BPTT.py:107-124) is closed: policy(obs_t) -> action_t -> env.step -> obs_{t+1}.
+// As separate launches that is, per control step, the register-chained policy forward + action head, the fused env step and
+// the loss / discount bookkeeping + state checkpoint: three launches of 256-1024 waves each, every one of them latency-bound
+// (~4 us of launch boundary, first-touch misses on kernel arguments and weights, the state round trip through HBM), 32-35 us per
+// step at 16 384 agents for ~17 us of work.  Here a wave owns 16 agents for the whole horizon:
+//   * the policy forward is the 16-rows-per-wave chain of vf_mlp_chain.hpp (v_mfma_f32_16x16x4_f32, activations in accumulator
+//     registers, weights straight from the row-major parameter buffer -- L2-resident after the first step);
+//   * the env step is the same per-agent code as k_env_step (control_interval + env_epilogue), the agent's state staying in
+//     registers from step to step like in k_env_rollout.  One lane per agent: lanes 16..63 replicate the agent of lane & 15
+//     (same loads, same arithmetic, same stores of the same values) -- the step is bound by single-wave instruction issue,
+//     not by lanes, so the idle three quarters of the wave cost nothing, and no code path needs a 16-lane special case;
+//   * observation rows and actions travel through the per-step slot buffers the reverse sweep needs anyway (the observation
+//     copy of slot t + 1 IS what step t's epilogue writes; the action row IS the tape's action), so nothing is copied;
+//   * per step the wave also writes the adjoint's checkpoint (its agents' granules of tape row t) and advances the loss /
+//     discount recurrence in registers.
+// Everything the per-step path leaves behind -- saved activations of every slot, actions, tape rows, done flags, d_reward
+// rows, loss, episode outputs, final slab -- is bit-identical (tests/test_bptt_gpu.py), so the reverse sweep is unchanged.
+#include "vf_env_epilogue.hpp"
+#include "vf_mlp_chain.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vf {
+
+struct RollArgs {
+    int H;                     // control steps
+    int N;                     // agents = policy rows per step
+    float* tape;               // [H][slab floats]: row t = the slab before step t (what vf_env_step_bwd reads)
+    long long tape_stride;     // floats between two tape rows
+    unsigned char* tape_done;  // [H][N]
+    float* d_reward;           // [H][N]  -disc_t * scale
+    float* loss;               // [N] in/out
+    float* disc;               // [N] in/out
+    float* obs_slots;          // [H][N][13]: slot t = the observation the policy sees at step t (slot 0 filled by the caller)
+    float* obs_final;          // (N,13): the observation after the last step
+    float gamma, scale;
+};
+
+template <class Net, int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs ge,
+                                                     const ChainArgs gc, const RollArgs r)
+{
+    prefetch_kernarg<sizeof(EnvArgs) + sizeof(ChainArgs) + sizeof(RollArgs) + 16>();
+    const vf_dyn_cfg& c = *cp;
+    const vf_env_cfg& e = *ep;
+    __shared__ __attribute__((aligned(16))) float tile[64 * 13];
+    const int lane = threadIdx.x, m = lane & 15;
+    const int wave_first = blockIdx.x * 16;
+    // agent = policy row of this lane.  Lanes 16..63 -- and the lanes past the last agent -- are REPLICAS of a live lane: same
+    // index, same loads, same arithmetic, same stores of the same values
+    const int i = min(wave_first + m, r.N - 1), ic = i;
+    const bool live = true;
+    EnvArgs g = ge;
+    g.d.N = min(r.N, wave_first + 16);                   // the wave's observation tile holds 16 rows
+    Agent s;
+    Spares sp;
+    load_agent<true>(g.d.S, g.d.G, ic, s, sp);
+    load_wind(c, g.d, ic, live, s);
+    float disc = r.disc[ic], loss = r.loss[ic];
+    const int Gx = g.d.G;
+    for (int t = 0; t < r.H; ++t) {
+        // ---- policy forward + action head: rows t N + i of the slot buffers, action row of step t ----
+        {
+            const int row = t * r.N + i, rc = row, gq = lane >> 4;
+            const bool lrow = true;
+            ChainState16<Net> st;
+            chain16_prologue<Net, 0>(gc, st, lane);
+#pragma unroll
+            for (int b = 0; b < Net::NB; ++b) {
+                const int w = gc.d.in_dim[b];
+                const float* x = gc.io.in[b] + (size_t)rc * w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * gq + j;
+                    const float v = x[k < w ? k : w - 1];
+                    st.x[b][j] = k < w ? v : 0.0f;
+                }
+            }
+            chain16_items<Net, 0>(gc, st, lane, row, lrow);
+        }
+        // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
+        // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // ---- checkpoint for the adjoint: this agent's granules of tape row t = the slab before the step ----
+        float* T = r.tape + (size_t)t * r.tape_stride;
+        store_agent(T, Gx, ic, s, sp);
+        for (int q = VF_G_FIXED; q < Gx; ++q) *granule(T, Gx, ic, q) = *granule(g.d.S, Gx, ic, q);
+        // ---- env step (k_env_rollout's body) ----
+        float a[4], head_bits = 0.0f;
+        ring_exchange(c, g.d, ic, live, head_bits, a);
+        if (c.delay_steps > 0) sp.vel = head_bits;
+        float kl[3], kq[3];
+        drag_of(c, g.d, ic, kl, kq);
+        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
+        float reward = 0.0f;
+        bool done = false;
+        env_epilogue<KIND, false>(c, e, g, ic, live, s, sp, wave_first, tile, &reward, &done);
+        // ---- loss / discount recurrence (BPTT.py:123-124; k_bptt_accumulate) ----
+        r.d_reward[(size_t)t * r.N + i] = -disc * r.scale;
+        loss = loss + -1.0f * reward * disc;
+        const float dn = done ? 1.0f : 0.0f;
+        disc = disc * r.gamma * (1.0f - dn) + dn;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the observation rows of slot t + 1 are read by the next forward
+        // ---- next step ----
+        g.d.action += r.N;                               // float4 units
+        g.out.done += r.N;
+        g.out.obs = t + 2 < r.H ? r.obs_slots + (size_t)(t + 2) * r.N * 13 : r.obs_final;   // the last one: the env's own buffer
+        g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
+    }
+    store_agent(g.d.S, Gx, ic, s, sp);
+    r.disc[i] = disc;
+    r.loss[i] = loss;
+}
+
+}  // namespace vf
+
+namespace {
+
+using RollKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvArgs, const vf::ChainArgs, const vf::RollArgs);
+
+template <class Net, int KIND>
+RollKernel pick_roll(const vf_dyn_cfg& c)
+{
+    if (c.integrator != VF_INT_EULER || !c.ctrl_delay) return nullptr;
+    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const float* obs_slots0,
+                               const float* obs_slots1, const float* log_std, const float* eps, float* actions,
+                               const vf_env_out* out, float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done,
+                               float* d_reward, float* loss, float* disc, float gamma, float scale, int32_t H, vf_stream_t stream)
+{
+    if (!h || !desc || !params || !obs_slots0 || !log_std || !eps || !actions || !out || !obs_final || !tape || !tape_done || !d_reward ||
+        !loss || !disc || H <= 0)
+        return vf::fail(VF_EINVAL, "vf_bptt_rollout: bad argument");
+    if (!out->reward) return vf::fail(VF_EINVAL, "vf_bptt_rollout: out->reward (N floats of scratch) is required");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_bptt_rollout: vf_env_bind has not been called");
+    if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: per-agent wind rows are set");
+    if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
+        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: observation / reward variants have no adjoint");
+    if (tape_stride < (int64_t)h->dyn.Npad * h->dyn.G * 4) return vf::fail(VF_EINVAL, "vf_bptt_rollout: tape rows are shorter than the slab");
+    const int cls = vf::chain16_policy_class(desc, params);
+    RollKernel k = nullptr;
+    if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = pick_roll<vf::NetHoverPi, VF_ENV_HOVER>(h->dyn.cfg);
+    else if (cls == 1 && h->cfg.kind == VF_ENV_RACING) k = pick_roll<vf::NetHoverPi, VF_ENV_RACING>(h->dyn.cfg);
+    else if (cls == 2 && h->cfg.kind == VF_ENV_NAV && obs_slots1) k = pick_roll<vf::NetNavPi, VF_ENV_NAV>(h->dyn.cfg);
+    if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: no persistent roll-out for this network class / env kind / dynamics "
+                                             "configuration (policy-only [128, 64] x [64, 64] networks, thrust / bodyrate, Euler, ctrl_delay)");
+    const int N = h->dyn.N;
+    vf::EnvArgs ge{vf::DynArgs{N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(actions), nullptr,
+                               vf::ring_head(&h->dyn), nullptr, h->dyn.vel_strided},
+                   *out, h->g_race, 1};
+    ge.out.done = tape_done;
+    ge.out.done_list = ge.out.done_count = nullptr;
+    // slot t + 1's observation rows are what step t writes; slot 0 holds the current observation (caller)
+    ge.out.obs = H > 1 ? const_cast<float*>(obs_slots0) + (size_t)N * 13 : obs_final;
+    vf::ChainArgs gc{*desc, params, packed, vf::ChainIo{{obs_slots0, obs_slots1}, nullptr, nullptr}, H * N, log_std,
+                     reinterpret_cast<const float4*>(eps), reinterpret_cast<float4*>(actions), {nullptr, nullptr}};
+    vf::RollArgs r{H, N, tape, tape_stride, tape_done, d_reward, loss, disc, const_cast<float*>(obs_slots0), obs_final, gamma, scale};
+    hipLaunchKernelGGL(k, dim3((N + 15) / 16), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
+    VF_HIP(hipGetLastError());
+    h->dyn.tick += H;
+    return VF_OK;
+}

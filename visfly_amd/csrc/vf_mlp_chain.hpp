@@ -1,0 +1,334 @@
+// vf_mlp_chain.hpp -- shared definitions of the register-chained MLP kernels (network classes, launch arguments) and the
+// 16-rows-per-wave forward chain as device code, so that other translation units can run the policy forward inside their own
+// kernels (vf_bptt_rollout.hip: policy forward + env step of a whole BPTT horizon in one persistent launch).  The kernels
+// themselves, the 32-row chains and the reverse chains live in vf_mlp_chain.hip.
+#pragma once
+#include "vf_common.hpp"
+#include "vf_ppo_device.hpp"
+
+#include <type_traits>
+
+#ifndef VF_CHAIN16_DEPTH
+#define VF_CHAIN16_DEPTH 24
+#endif
+
+namespace vf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct __attribute__((packed, aligned(4))) f32x4u {   // 4 consecutive floats at dword alignment (bias vectors)
+    float x, y, z, w;
+};
+
+struct ChainIo {
+    const float* in[2];
+    float* mean;
+    float* value;
+};
+
+// compile-time description of one layer of the chain
+struct ChainLayer {
+    int desc;      // index in vf_mlp_desc.layer
+    int obs;       // >= 0: reads observation `obs` (natural k order), -1: reads activation tiles
+    int in0, nin;  // first input tile, number of input tiles (obs: nin = number of 8-wide k groups)
+    int out0, nout;
+    int relu;
+};
+
+// NB branches (KA / KB = first-layer widths padded to 8), hidden widths in 32-feature tiles
+// VF_ = false: the value trunk is not executed (first-order policy optimisation only needs the action mean)
+template <int NB_, int KA_, int KB_, int E1_, int E2_, int P1_, int P2_, int V1_, int V2_, bool VF_ = true>
+struct ChainNet {
+    static constexpr int NB = NB_, E1 = E1_, E2 = E2_, P1 = P1_, P2 = P2_, V1 = V1_, V2 = V2_;
+    static constexpr bool VF = VF_;
+    static constexpr int kin(int b) { return b == 0 ? KA_ : KB_; }
+    static constexpr int n_layers = 2 * NB + 6;              // layers of the vf_mlp_desc this class matches
+    static constexpr int n_exec = 2 * NB + (VF ? 6 : 3);     // layers the kernel runs
+    static constexpr int L_mean = 2 * NB + 2, L_value = 2 * NB + 5;   // desc indices of the heads
+    // tiles: [branch L1 outputs][feat][pi1][pi2][mean][vf1][vf2][value]
+    static constexpr int t_e1(int b) { return b * E1; }
+    static constexpr int t_feat = NB * E1;
+    static constexpr int t_p1 = t_feat + NB * E2, t_p2 = t_p1 + P1, t_mean = t_p2 + P2;
+    static constexpr int t_v1 = t_mean + 1, t_v2 = t_v1 + V1, t_val = t_v2 + V2;
+    static constexpr int n_tiles = t_val + 1;
+    // execution order alternates between independent chains so that one chain's epilogue (VALU) can sit in the
+    // shadow of the other's MFMAs
+    static constexpr ChainLayer layer(int i)
+    {
+        if (i < NB) return ChainLayer{2 * i, i, 0, kin(i) / 8, t_e1(i), E1, 1};
+        if (i < 2 * NB) return ChainLayer{2 * (i - NB) + 1, -1, t_e1(i - NB), E1, t_feat + (i - NB) * E2, E2, 1};
+        const int base = 2 * NB;
+        if (!VF) {
+            switch (i - base) {
+            case 0: return ChainLayer{base + 0, -1, t_feat, NB * E2, t_p1, P1, 1};
+            case 1: return ChainLayer{base + 1, -1, t_p1, P1, t_p2, P2, 1};
+            default: return ChainLayer{base + 2, -1, t_p2, P2, t_mean, 1, 0};
+            }
+        }
+        switch (i - base) {
+        case 0: return ChainLayer{base + 0, -1, t_feat, NB * E2, t_p1, P1, 1};
+        case 1: return ChainLayer{base + 3, -1, t_feat, NB * E2, t_v1, V1, 1};
+        case 2: return ChainLayer{base + 1, -1, t_p1, P1, t_p2, P2, 1};
+        case 3: return ChainLayer{base + 4, -1, t_v1, V1, t_v2, V2, 1};
+        case 4: return ChainLayer{base + 2, -1, t_p2, P2, t_mean, 1, 0};
+        default: return ChainLayer{base + 5, -1, t_v2, V2, t_val, 1, 0};
+        }
+    }
+    static constexpr int groups(int i) { return layer(i).obs >= 0 ? layer(i).nin : layer(i).nin * 4; }   // float4 k groups
+    static constexpr int items(int i) { return groups(i) * layer(i).nout; }
+    static constexpr int n_items()
+    {
+        int n = 0;
+        for (int i = 0; i < n_exec; ++i) n += items(i);
+        return n;
+    }
+    static constexpr bool is_head(int i) { return layer(i).desc == L_mean || layer(i).desc == L_value; }
+    // first output tile of desc layer fl (MlpPolicy order)
+    static constexpr int tile_of_layer(int fl)
+    {
+        if (fl < 2 * NB) return (fl & 1) ? t_feat + (fl >> 1) * E2 : t_e1(fl >> 1);
+        switch (fl - 2 * NB) {
+        case 0: return t_p1;
+        case 1: return t_p2;
+        case 2: return t_mean;
+        case 3: return t_v1;
+        case 4: return t_v2;
+        default: return t_val;
+        }
+    }
+    static constexpr int layer_of(int item)
+    {
+        int i = 0;
+        while (item >= items(i)) { item -= items(i); ++i; }
+        return i;
+    }
+    static constexpr int first_item(int li)
+    {
+        int n = 0;
+        for (int i = 0; i < li; ++i) n += items(i);
+        return n;
+    }
+};
+
+constexpr int kChainDepth = 8;   // weight blocks in flight: 8 x 4 MFMAs x 64 cycles = 2 k cycles of cover
+
+template <class N>
+struct ChainState {
+    f32x16 t[N::n_tiles];
+    float x[2][16];              // observation fragments: x[b][s] = X[m][2 s + h] (K padded to <= 32)
+    float4 ring[kChainDepth];
+    float4 bias[4][4];           // bias of the layer in flight: [out tile][g] -> features 32 a + 8 g + 4 h .. + 3
+};
+
+struct ChainArgs {
+    vf_mlp_desc d;
+    const float* params;
+    const float* packed;
+    ChainIo io;
+    int M;
+    // optional action head (vf_mlp_forward_act): action = tanh(mean + exp(log_std) * eps) instead of the mean
+    const float* rp_log_std;
+    const float4* rp_eps;
+    float4* rp_action;
+    float* obs_copy[2];      // optional: the observation rows are also written here (a trainer's contiguous per-slot copy)
+};
+
+using NetHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2>;   // StateExtractor [128, 64], pi / vf [64, 64]
+using NetNav = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2>;     // StateTargetExtractor [128, 64] x 2, pi / vf [64, 64]
+using NetHoverPi = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, false>;
+using NetNavPi = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2, false>;
+
+
+// ------------------------------------------------------------------------------------------------
+// The same forward with 16 rows per wave (v_mfma_f32_16x16x4_f32) for SMALL row counts.  The 32-row chain puts M / 32 waves on
+// 1 024 SIMDs and lasts as long as one wave needs for the whole network whatever M is; at the BPTT shard (16 384 rows = 512
+// waves) half of the chip idles.  With 16 rows a wave does half the work and twice as many waves run (probe, same skeleton:
+// 47 -> 28 us at 16 384 rows; no gain once the chip is full -- profiles/r02_mfma_chain_probe.txt), so vf_mlp_forward picks
+// this kernel for M <= 16 384.
+//     A operand = weights   A[i = n][k]    lane = n + 16 kq
+//     B operand = X^T       B[k][j = m]    lane = m + 16 kq
+//     C / D     = Y^T       D[i = n][j = m] lane (m, gq = lane >> 4) holds n = 4 gq + r, r = 0..3
+// An accumulator lane holds features 4 gq .. 4 gq + 3 of its own row: as the B operand of step r of the next layer it supplies
+// k = (feature 4 gq + r of that 16-feature tile), so step r's A fragment is W[n][16 T + 4 gq + r] -- the four steps of an
+// (output tile, input tile) pair are ONE float4 of the row-major weight matrix itself.  No packed image at all.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+#ifdef VF_CHAIN_TRACE
+__device__ long long vf_chain_trace[2][32];
+#define VF_TRACE(k) do { if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 0) vf_chain_trace[blockIdx.x ? 1 : 0][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VF_TRACE(k) do { } while (0)
+#endif
+
+// weight fragments in flight: an item is 4 MFMAs x 32 cycles here, so the same ~2 k cycles of cover need more slots than the
+// 32-row chain's 8 (measured: 8 slots 17.9 us, i.e. load-latency bound)
+constexpr int kChain16Depth = VF_CHAIN16_DEPTH;
+
+template <class N>
+struct Chain16 {
+    static constexpr int nin(int i) { return N::layer(i).obs >= 0 ? 1 : 2 * N::layer(i).nin; }       // 16-feature input tiles
+    static constexpr int nout(int i) { return N::is_head(i) ? 1 : 2 * N::layer(i).nout; }
+    static constexpr int items(int i) { return nin(i) * nout(i); }
+    static constexpr int n_items()
+    {
+        int n = 0;
+        for (int i = 0; i < N::n_exec; ++i) n += items(i);
+        return n;
+    }
+    static constexpr int layer_of(int item)
+    {
+        int i = 0;
+        while (item >= items(i)) { item -= items(i); ++i; }
+        return i;
+    }
+    static constexpr int first_item(int li)
+    {
+        int n = 0;
+        for (int i = 0; i < li; ++i) n += items(i);
+        return n;
+    }
+};
+
+template <class N>
+struct ChainState16 {
+    f32x4 t[2 * N::n_tiles];
+    float x[2][4];               // observation fragment: x[b][j] = X[m][4 gq + j] (K <= 16)
+    float4 ring[kChain16Depth];
+    float4 bias[8];              // bias of the layer in flight: [out tile] -> features 16 a + 4 gq .. + 3
+};
+
+template <class N, int I>
+__device__ __forceinline__ float4 chain16_load(const ChainArgs& g, int lane)
+{
+    using C = Chain16<N>;
+    constexpr int li = C::layer_of(I), local = I - C::first_item(li);
+    constexpr ChainLayer L = N::layer(li);
+    constexpr int T = local / C::nout(li), a = local % C::nout(li);
+    const vf_mlp_layer& D = g.d.layer[L.desc];
+    const int n = 16 * a + (lane & 15), gq = lane >> 4;
+    const float* w = g.params + D.w_off;
+    if constexpr (L.obs >= 0) {          // K = in_dim <= 16, rows not 16-byte aligned: guarded scalar loads
+        const float* r = w + (size_t)n * D.K;
+        const int k = 4 * gq;
+        return make_float4(k < D.K ? r[k] : 0.0f, k + 1 < D.K ? r[k + 1] : 0.0f, k + 2 < D.K ? r[k + 2] : 0.0f, k + 3 < D.K ? r[k + 3] : 0.0f);
+    } else {
+        const int nc = n < D.No ? n : D.No - 1;      // heads: rows past No repeat the last one (their outputs are never read)
+        return *reinterpret_cast<const float4*>(w + (size_t)nc * D.K + 16 * T + 4 * gq);
+    }
+}
+
+template <class N, int LI>
+__device__ __forceinline__ void chain16_bias_load(const ChainArgs& g, ChainState16<N>& st, int gq)
+{
+    constexpr ChainLayer L = N::layer(LI);
+    const float* b = g.params + g.d.layer[L.desc].b_off;    // b_off is only dword aligned
+    if constexpr (L.desc == N::L_value) {
+        st.bias[0] = make_float4(b[0], 0.0f, 0.0f, 0.0f);
+    } else if constexpr (L.desc == N::L_mean) {
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(b);
+        st.bias[0] = make_float4(v.x, v.y, v.z, v.w);
+    } else {
+#pragma unroll
+        for (int a = 0; a < Chain16<N>::nout(LI); ++a) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(b + 16 * a + 4 * gq);
+            st.bias[a] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
+template <class N, int LI>
+__device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState16<N>& st, int row, int gq, bool live)
+{
+    constexpr ChainLayer L = N::layer(LI);
+    if constexpr (N::is_head(LI)) {                    // heads: mean (M,4) / value (M,1); lane group 0 holds them
+        f32x4& y = st.t[2 * L.out0];
+        const float4 bq = st.bias[0];
+        y[0] += bq.x; y[1] += bq.y; y[2] += bq.z; y[3] += bq.w;
+        if (live && gq == 0) {
+            if constexpr (L.desc == N::L_mean) {
+                if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
+                if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers (as chain_epilogue)
+                    const float4 e = g.rp_eps[row];
+                    g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
+                                                   tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                }
+            } else {
+                if (g.io.value) g.io.value[row] = y[0];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < Chain16<N>::nout(LI); ++a) {
+            f32x4& y = st.t[2 * L.out0 + a];
+            const float4 bq = st.bias[a];
+            y[0] = fmaxf(y[0] + bq.x, 0.0f); y[1] = fmaxf(y[1] + bq.y, 0.0f);
+            y[2] = fmaxf(y[2] + bq.z, 0.0f); y[3] = fmaxf(y[3] + bq.w, 0.0f);
+        }
+    }
+}
+
+// saved copies of the previous layer's output, trickled out under this layer's items (see chain_deferred_store)
+template <class N, int LI, int LOCAL>
+__device__ __forceinline__ void chain16_deferred_store(const ChainArgs& g, const ChainState16<N>& st, int row, int gq, bool live)
+{
+    if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
+        using C = Chain16<N>;
+        constexpr ChainLayer P = N::layer(LI - 1);
+        constexpr int S = C::nout(LI - 1), per = (S + C::items(LI) - 1) / C::items(LI);
+        constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
+        if constexpr (s0 < s1) {
+            const vf_mlp_layer& D = g.d.layer[P.desc];
+            if (D.save && live) {
+                const unsigned off = (unsigned)row * (unsigned)D.save_ld + 4u * gq;
+#pragma unroll
+                for (int a = s0; a < s1; ++a) {
+                    const f32x4& y = st.t[2 * P.out0 + a];
+                    *reinterpret_cast<float4*>(D.save + D.dst_col + 16 * a + off) = make_float4(y[0], y[1], y[2], y[3]);
+                }
+            }
+        }
+    }
+}
+
+template <class N, int I>
+__device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N>& st, int lane, int row, bool live)
+{
+    using C = Chain16<N>;
+    if constexpr (I < C::n_items()) {
+        constexpr int li = C::layer_of(I), local = I - C::first_item(li);
+        constexpr ChainLayer L = N::layer(li);
+        constexpr int T = local / C::nout(li), a = local % C::nout(li);
+        const int gq = lane >> 4;
+        const float4 w = st.ring[I % kChain16Depth];
+        if constexpr (I + kChain16Depth < C::n_items()) st.ring[I % kChain16Depth] = chain16_load<N, I + kChain16Depth>(g, lane);
+        if constexpr (local == 0) chain16_bias_load<N, li>(g, st, gq);
+        f32x4& acc = st.t[2 * L.out0 + a];
+        if constexpr (T == 0) acc = f32x4{0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float b;
+            if constexpr (L.obs >= 0) b = st.x[L.obs][j];
+            else b = st.t[2 * L.in0 + T][j];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
+        }
+        chain16_deferred_store<N, li, local>(g, st, row, gq, live);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (local == 0) VF_TRACE(2 + 2 * li);
+        if constexpr (local == C::items(li) - 1) {
+            chain16_epilogue<N, li>(g, st, row, gq, live);
+            VF_TRACE(3 + 2 * li);
+        }
+        chain16_items<N, I + 1>(g, st, lane, row, live);
+    }
+}
+
+template <class N, int I>
+__device__ __forceinline__ void chain16_prologue(const ChainArgs& g, ChainState16<N>& st, int lane)
+{
+    if constexpr (I < kChain16Depth && I < Chain16<N>::n_items()) {
+        st.ring[I] = chain16_load<N, I>(g, lane);
+        chain16_prologue<N, I + 1>(g, st, lane);
+    }
+}
+
+}  // namespace vf

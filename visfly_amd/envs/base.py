@@ -819,6 +819,60 @@ class DroneGymEnvsBase:
         self._tape_t = 0
         self._record_all = True      # manual mode: every step() is recorded until clear_tape()/detach()
 
+    def rollout_policy(self, policy, obs_keys, eps, actions, d_reward, loss, disc, gamma, scale):
+        """H = eps.shape[0] closed-loop control steps -- policy forward (slots 0..H-1 of `policy`, reserved back to back), action
+        head, state checkpoint on the tape, fused env step, loss / discount recurrence -- in ONE persistent launch
+        (vf_bptt_rollout).  Leaves exactly what H rounds of policy.forward_act + _step_no_grad(record=True) +
+        vf_bptt_accumulate leave.  -> False when the library has no roll-out kernel for this env / network / dynamics
+        configuration (the caller then steps launch by launch)."""
+        if (self._tape is None or self.spawn_mode != "device" or self._imu_noise is not None or self._half_step
+                or self.envs.dynamics._wind_fn is not None or getattr(self, "_HOST_OBS", False) or not self.tensor_output
+                or getattr(self, "obs_gate_exact", False)):
+            return False
+        H, N, dev = eps.shape[0], self.num_agent, self.device
+        t0 = self._tape_t
+        if t0 + H > self._tape.shape[0]:
+            raise VisflyError("tape is full: call env.detach() (BPTT horizon exceeded)")
+        nblk, blk = policy._slot_blocks.get(N, (0, None))
+        if nblk < H or any(k not in ("state", "target") for k in obs_keys):
+            return False
+        obs = self.get_observation()
+        blk["obs:state"][0].copy_(obs["state"].detach())
+        o1 = None
+        if "target" in obs_keys:
+            blk["obs:target"][:H].copy_(obs["target"].detach().unsqueeze(0).expand(H, N, -1))     # constant per env
+            o1 = blk["obs:target"]
+        b0 = policy._buffers(N, 0)
+        key = (N, 0, True)
+        d = policy._descs.get(key)
+        if d is None:
+            d = policy._descs[key] = policy._fused_desc(b0, True)
+        policy._pack()
+        if getattr(self, "_roll_out", None) is None:
+            self._roll_scratch = (th.empty((N, 13), dtype=th.float32, device=dev), th.empty(N, dtype=th.float32, device=dev),
+                                  th.empty(N, dtype=th.bool, device=dev))
+            self._roll_out = self._out(*self._roll_scratch)
+        final = th.empty((N, 13), dtype=th.float32, device=dev)
+        L = _lib.lib()
+        with th.cuda.device(dev):
+            rc = L.vf_bptt_rollout(self._h, C.byref(d), _lib.ptr(policy.flat), _lib.ptr(policy._packed), _lib.ptr(blk["obs:state"]),
+                                   _lib.ptr(o1), _lib.ptr(policy.log_std), _lib.ptr(eps), _lib.ptr(actions), C.byref(self._roll_out),
+                                   _lib.ptr(final), _lib.ptr(self._tape[t0]), self._slab.numel(), self._tape_done[t0].data_ptr(),
+                                   _lib.ptr(d_reward), _lib.ptr(loss), _lib.ptr(disc), float(gamma), float(scale), H, self._stream())
+        if rc == _lib.EUNSUPPORTED:
+            return False
+        if rc:
+            _lib.check(rc)
+        for t in range(H):
+            self._tape_action_ref[t0 + t] = actions[t]
+        self._tape_t = t0 + H
+        self._qcache = self._imu_cache = self._ext_col = None
+        self._action = actions[H - 1]
+        self._reward, self._done = self._roll_scratch[1], self._tape_done[t0 + H - 1]
+        self._observations = self._full_obs(final)
+        policy._last_M, policy._last_slot = N, H - 1
+        return True
+
     def clear_tape(self):
         """env.detach() of the reference (droneGymEnv.py:286-300): cut the graph at the current state"""
         if self._tape is not None:
