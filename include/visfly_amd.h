@@ -33,7 +33,7 @@ extern "C" {
                               5: vf_dyn_ring_phase / vf_dyn_set_ring_phase / vf_env_set_ring_phase, capture guard on
                                  vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update,
                                  vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
-                                 vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout */
+                                 vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse */
 
 typedef void* vf_stream_t;
 
@@ -738,6 +738,17 @@ int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, con
                     const float* obs_slots1, const float* log_std, const float* eps, float* actions, const vf_env_out* out,
                     float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done, float* d_reward, float* loss,
                     float* disc, float gamma, float scale, int32_t H, vf_stream_t stream);
+
+/* ... and the reverse half (loss.backward() over the horizon, BPTT.py:127-129): for t = H-1 .. 0 the adjoint of env step t and the
+ * policy's action-head reverse + reverse chain of step t, a wave owning 32 agents for the whole sweep; leaves what H rounds of
+ * vf_env_step_bwd + vf_mlp_backward_data_act leave (bit-identical): the masked layer gradients of every slot (for ONE
+ * vf_mlp_weight_grad over H N rows afterwards), d_mean rows, the per-row log_std gradient terms and the adjoint slab.
+ *   desc       reverse layer table over the FLATTENED slots (H N rows; layer[0].dY = d_mean (H N, 4), the first-layer dX of the
+ *              "state" branch = g_obs, (H N, 13) observation gradients);  d_action [H][N][4] scratch;  g_log_std [H][N][4] zeroed
+ * Same restrictions as vf_bptt_rollout. */
+int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const float* packed, const float* log_std, const float* eps,
+                    const float* actions, const float* tape, int64_t tape_stride, const uint8_t* tape_done, const float* d_reward,
+                    float* adj_slab, float* d_action, const float* g_obs, float* g_log_std, int32_t H, vf_stream_t stream);
 
 /* ---- SHAC (utils/algorithms/shac.py:215-278; actor / twin critic of utils/policies/td_policies.py:82-252) -----------------
  * The networks are vf_mlp_desc layer tables like the PPO policy's (actor: two 4-wide heads mu / log_std over one extractor;

@@ -83,6 +83,7 @@ class BPTT:
         self.policy.mark_updated()
         self.use_autograd = False           # True: torch.autograd schedules the same kernels (cross-check path)
         self.fused_rollout = True           # forward half of a horizon as one persistent launch where the library has the kernel
+        self.fused_reverse = True           # ... and the reverse half (only after a fused forward: same tape / slot buffers)
         self._defer_wgrad = None            # decided at the first update (MlpPolicy.backward_data_supported)
         n = self.policy.n_params
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=self.device), th.zeros(n, device=self.device)
@@ -155,18 +156,23 @@ class BPTT:
                                                 float(self.gamma), 1.0 / (N * self.world), N, st))
         g_obs = None
         d_means = th.empty((H, N, 4), device=dev)
-        for t in reversed(range(H)):
+        g_ls_rows = th.zeros((H, N, 4), device=dev) if defer else None     # log_std gradient terms, one row per (step, agent)
+        rev = False
+        if fused and self.fused_reverse:
+            # the whole reverse half as one persistent launch (vf_bptt_reverse)
+            rev = env.reverse_policy(pol, H, epss, acts, drews, d_means, g_ls_rows)
+        for t in reversed(range(0 if not rev else H, H)):
             d_action = env.backward_step(t0 + t, g_obs, drews[t])
             d_mean = d_means[t]
             if defer:       # action head's reverse + reverse chain in one launch (step 0's observation gradient is unused)
-                d_in = pol.backward_data_act(d_action, acts[t], epss[t], g_ls, d_mean, slot=t)
+                d_in = pol.backward_data_act(d_action, acts[t], epss[t], g_ls_rows[t], d_mean, slot=t)
             else:
                 _lib.check(L.vf_reparam_bwd(_ptr(d_action), _ptr(acts[t]), _ptr(log_std), _ptr(epss[t]), _ptr(d_mean), _ptr(g_ls), N, st))
                 d_in = pol.backward(d_mean, None, None, accumulate=True, need_input_grad=t > 0, slot=t)
             g_obs = d_in.get("state") if t > 0 else None
         if defer:
             pol.weight_grad_slots(N, H, d_means, accumulate=True)
-        pol.grad[pol.log_std_off:] = g_ls.sum(dim=0)
+        pol.grad[pol.log_std_off:] = g_ls_rows.sum(dim=(0, 1)) if defer else g_ls.sum(dim=0)
         return loss_vec.mean() / self.world
 
     def _grad_autograd(self):

@@ -1,0 +1,105 @@
+// vf_bptt_reverse.hip -- the reverse half of a BPTT horizon as ONE persistent launch (gfx950).
+//
+// loss.backward() over a horizon (utils/algorithms/BPTT.py:127-129) is a strictly serial chain: the adjoint of env step t needs
+// dLoss/d obs_{t+1} from the policy's reverse pass of step t + 1, which needs dLoss/d action_{t+1} from the adjoint of step
+// t + 1.  As separate launches that is 2 H launches of 256-512 waves, each latency-bound (~20 us at 16 384 agents).  Agents are
+// independent, so here a wave owns 32 agents for the whole sweep t = H-1 .. 0:
+//   * adjoint of the control interval + env epilogue for its agents (env_step_bwd_agent, one lane per agent; lanes 32..63
+//     replicate lane & 31 -- same loads, same arithmetic, same stores of the same values, so no 32-lane special case);
+//   * action head reverse + reverse register chain for the same 32 rows (vf_mlp_chain_bwd.hpp): masked layer gradients into
+//     the slot's dZ buffers for the horizon-wide weight-gradient launch, dLoss/d observation for the next adjoint step;
+// d_action and the observation gradient travel through per-step rows of scratch (the same wave reads what it wrote).
+// Bit-identical to the launch-by-launch sweep (tests/test_bptt_gpu.py).
+#include "vf_env_bwd_body.hpp"
+#include "vf_mlp_chain_bwd.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vf {
+
+struct RevArgs {
+    int H, N, G, g_drag, g_race;
+    const float* tape;             // [H] rows of tape_stride floats: the slab before step t
+    long long tape_stride;
+    const float4* actions;         // [H][N]: the action step t was given
+    const unsigned char* done;     // [H][N]
+    const float* d_reward;         // [H][N]
+    float* adj;                    // adjoint of the persistent state (slab layout), in / out
+    float4* d_action;              // [H][N] scratch: dLoss / d action_t, read by the head reverse of step t
+    const float* g_obs;            // [H][N][13]: row t N + i = dLoss / d (observation of slot t), written by the reverse chain
+};
+
+template <class P, int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const BwdArgsChain gb,
+                                                     const RevArgs r)
+{
+    prefetch_kernarg<sizeof(BwdArgsChain) + sizeof(RevArgs) + 16>();
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [S * kSave][64]
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int i = min((int)blockIdx.x * 32 + m, r.N - 1);            // lanes past the last agent replicate it as well
+    for (int t = r.H - 1; t >= 0; --t) {
+        const BwdArgs g{r.N, r.G, r.g_drag, r.g_race, r.tape + (size_t)t * r.tape_stride, r.actions + (size_t)t * r.N,
+                        t + 1 < r.H ? r.g_obs + (size_t)(t + 1) * r.N * 13 : nullptr, r.d_reward + (size_t)t * r.N,
+                        r.done + (size_t)t * r.N, r.adj, r.d_action + (size_t)t * r.N};
+        env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64>(*cp, *ep, g, i, true, lds + lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // d_action_t: written above, read by the head reverse below
+        const int row = t * r.N + i;
+        BwdState<P> st;
+        bwd_prologue<P, 0>(gb, st, lane);
+        bwd_head_prologue<P, 0>(gb, st, row, h, true);
+        bwd_items<P, NoFwd, 0>(gb, st, NoFwd{}, lane, row, row, true);
+        bwd_tail_store<P>(gb, st, row, h, true);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // dLoss / d obs_t: read by the adjoint of step t - 1
+    }
+}
+
+}  // namespace vf
+
+namespace {
+
+using RevKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::BwdArgsChain, const vf::RevArgs);
+
+template <class Net, int KIND>
+RevKernel pick_rev(const vf_dyn_cfg& c)
+{
+    using P = vf::BwdProg<Net, true, false, true>;
+    if (c.integrator != VF_INT_EULER || !c.ctrl_delay) return nullptr;
+    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const float* packed, const float* log_std, const float* eps,
+                               const float* actions, const float* tape, int64_t tape_stride, const uint8_t* tape_done,
+                               const float* d_reward, float* adj_slab, float* d_action, const float* g_obs, float* g_log_std, int32_t H,
+                               vf_stream_t stream)
+{
+    if (!h || !desc || !packed || !log_std || !eps || !actions || !tape || !tape_done || !d_reward || !adj_slab || !d_action || !g_obs ||
+        !g_log_std || H <= 0)
+        return vf::fail(VF_EINVAL, "vf_bptt_reverse: bad argument");
+    if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: per-agent wind rows are set");
+    if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
+        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: observation / reward variants have no adjoint");
+    const int S = h->dyn.cfg.interval_steps;
+    if (S > 10) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: at most 10 sub-steps per control interval");
+    const int N = h->dyn.N;
+    const int cls = vf::bwd_chain_policy_class(desc);
+    RevKernel k = nullptr;
+    if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = pick_rev<vf::NetHover, VF_ENV_HOVER>(h->dyn.cfg);
+    else if (cls == 1 && h->cfg.kind == VF_ENV_RACING) k = pick_rev<vf::NetHover, VF_ENV_RACING>(h->dyn.cfg);
+    else if (cls == 2 && h->cfg.kind == VF_ENV_NAV) k = pick_rev<vf::NetNav, VF_ENV_NAV>(h->dyn.cfg);
+    if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: no persistent reverse sweep for this network class / env kind / dynamics configuration");
+    bool found = false;        // g_obs must be the (rows, 13) buffer the "state" branch's first layer writes its data gradient to
+    for (int l = 0; l < desc->n_layers; ++l) found = found || (desc->layer[l].need_dx && desc->layer[l].dX == g_obs && desc->layer[l].ld_dx == 13);
+    if (!found) return vf::fail(VF_EINVAL, "vf_bptt_reverse: g_obs is not the (rows, 13) observation-gradient buffer of the layer table");
+    vf::BwdArgsChain gb{*desc, packed, H * N, reinterpret_cast<const float4*>(d_action), reinterpret_cast<const float4*>(actions), log_std,
+                        reinterpret_cast<const float4*>(eps), reinterpret_cast<float4*>(g_log_std)};
+    vf::RevArgs r{H, N, h->dyn.G, h->dyn.g_drag, h->g_race, tape, tape_stride, reinterpret_cast<const float4*>(actions), tape_done, d_reward,
+                  adj_slab, reinterpret_cast<float4*>(d_action), g_obs};
+    const size_t lds = (size_t)S * vf::kSave * 64 * sizeof(float);
+    hipLaunchKernelGGL(k, dim3((N + 31) / 32), dim3(64), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, gb, r);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}

@@ -10,534 +10,17 @@
 // quaternion products are differentiated as the polynomial expressions the reference evaluates
 // (d(a*b): lam_a = lam * conj(b), lam_b = conj(a) * lam), comparisons / done masks carry no gradient,
 // agents reset at the end of a step stop the gradient there.
-#include "vf_env_device.hpp"
-#include "vf_handles.hpp"
+#include "vf_env_bwd_body.hpp"
 
 namespace vf {
-
-struct BwdArgs {
-    int N, G, g_drag, g_race;
-    const float* tape;
-    const float4* action;
-    const float* d_obs;
-    const float* d_reward;
-    const unsigned char* done;
-    float* adj;
-    float4* d_action;
-};
-
-__device__ __forceinline__ Quat qscale(const Quat& a, float s) { return Quat{a.w * s, a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ void qacc(Quat& a, const Quat& b) { a.w += b.w; a.x += b.x; a.y += b.y; a.z += b.z; }
-__device__ __forceinline__ void cross3(const float* a, const float* b, float* o)
-{
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-}
-// o += A^T x  (3x3 row-major)
-__device__ __forceinline__ void mat3T_acc(const float* A, const float* x, float* o)
-{
-#pragma unroll
-    for (int j = 0; j < 3; ++j) o[j] += A[j] * x[0] + A[3 + j] * x[1] + A[6 + j] * x[2];
-}
-__device__ __forceinline__ float in_closed(float x, float lo, float hi) { return (x >= lo && x <= hi) ? 1.0f : 0.0f; }
-
-// adjoint of r = imag(conj(q) * (0,x) * q)  [inv_rotate]  (utils/maths.py:40-49)
-__device__ __forceinline__ void inv_rotate_bwd(const Quat& q, const float* x, const float* lr, Quat& lq, float* lx)
-{
-    const Quat X{0.0f, x[0], x[1], x[2]}, L{0.0f, lr[0], lr[1], lr[2]};
-    const Quat qc = qconj(q);
-    const Quat A = qmul(qc, X);                 // r = A * q
-    const Quat lA = qmul(L, qconj(q));
-    qacc(lq, qmul(qconj(A), L));
-    const Quat lqc = qmul(lA, qconj(X));        // A = conj(q) * X
-    qacc(lq, qconj(lqc));
-    const Quat lX = qmul(q, lA);                // conj(conj(q)) * lA
-    lx[0] += lX.x; lx[1] += lX.y; lx[2] += lX.z;
-}
-// adjoint of r = imag(q * (0,x) * conj(q))  [rotate]  (utils/maths.py:32-38)
-__device__ __forceinline__ void rotate_bwd(const Quat& q, const float* x, const float* lr, Quat& lq, float* lx)
-{
-    const Quat X{0.0f, x[0], x[1], x[2]}, L{0.0f, lr[0], lr[1], lr[2]};
-    const Quat A = qmul(q, X);                  // r = A * conj(q)
-    const Quat lA = qmul(L, q);                 // L * conj(conj(q))
-    const Quat lqc = qmul(qconj(A), L);
-    qacc(lq, qconj(lqc));
-    qacc(lq, qmul(lA, qconj(X)));               // A = q * X
-    const Quat lX = qmul(qconj(q), lA);
-    lx[0] += lX.x; lx[1] += lX.y; lx[2] += lX.z;
-}
-
-constexpr int kSave = 14;  // per sub-step: q(4) v(3) w(3) wm(4)
-
-// adjoint of (dq, dw) = derivs(q, w, tau)  (utils/maths.py:311,314): dq = 0.5 q (0,w), dw = Jinv (tau - w x (J w))
-__device__ __forceinline__ void derivs_bwd(const vf_dyn_cfg& c, const Quat& q, const float* w, const Quat& ldq, const float* ldw,
-                                           Quat& lq, float* lw, float* ltau)
-{
-    float lr[3] = {0, 0, 0};
-    mat3T_acc(c.Jinv, ldw, lr);
-    const float lc[3] = {-lr[0], -lr[1], -lr[2]};
-    float Jw[3], t0[3], t1[3];
-    mat3(c.J, w[0], w[1], w[2], Jw);
-    cross3(Jw, lc, t0);        // lam_w += (Jw) x lc
-    cross3(lc, w, t1);         // lam_(Jw) = lc x w
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { ltau[k] += lr[k]; lw[k] += t0[k]; }
-    mat3T_acc(c.J, t1, lw);
-    const Quat L = qscale(ldq, 0.5f), W{0.0f, w[0], w[1], w[2]};
-    qacc(lq, qmul(L, qconj(W)));
-    const Quat lW = qmul(qconj(q), L);
-    lw[0] += lW.x; lw[1] += lW.y; lw[2] += lW.z;
-}
 
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
 __global__ __launch_bounds__(kBlock) void k_env_step_bwd(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const BwdArgs g)
 {
-    const vf_dyn_cfg& c = *cp;   // persistent device copies of the constant blocks (vf_handles.hpp)
-    const vf_env_cfg& e = *ep;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [S*kSave][kBlock]
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int tx = threadIdx.x;
     if (i >= ((g.N + kBlock - 1) / kBlock) * kBlock) return;
-    const bool live = i < g.N;
-    float* T = const_cast<float*>(g.tape);
-    Agent s;
-    Spares sp;
-    load_agent(T, g.G, i, s, sp);
-    // ---- the action this step consumed (oldest ring slot) and the head it used ----
-    int head = 0;
-    float a[4];
-    {
-        float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) an = g.action[i];
-        if (c.delay_steps > 0) {
-            head = __float_as_int(sp.vel);
-            head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
-            an = *granule(T, g.G, i, VF_G_RING + head);
-        }
-        a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
-    }
-    float kl[3], kq[3];
-    if (g.g_drag >= 0) {
-        const float4 x = *granule(T, g.G, i, g.g_drag), y = *granule(T, g.G, i, g.g_drag + 1);
-        kl[0] = x.y; kl[1] = x.z; kl[2] = x.w; kq[0] = y.y; kq[1] = y.z; kq[2] = y.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
-    }
-    const float w0[3] = {s.w[0], s.w[1], s.w[2]}, al0[3] = {s.aa[0], s.aa[1], s.aa[2]};
-
-    // ---- forward replay (same arithmetic as control_interval), parking sub-step inputs ----
-    float Traw[4], Td[4], wd[4], disc[4];
-    if constexpr (ACT == VF_ACT_BODYRATE) {
-        const float Fc = (a[0] * c.acc_half + c.acc_mean) * c.m;
-        float ev[3], t1[3], Jw[3], t3[3], cr[3], u[4];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ev[k] = (a[k + 1] * c.rate_half + c.rate_mean) - s.w[k];
-        mat3(c.JP, ev[0], ev[1], ev[2], t1);
-        mat3(c.J, s.w[0], s.w[1], s.w[2], Jw);
-        cross3(s.w, Jw, cr);
-        mat3(c.Dm, s.aa[0], s.aa[1], s.aa[2], t3);
-        u[0] = Fc;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) u[k + 1] = (t1[k] + cr[k]) - t3[k];
-        mat4(c.Binv, u, Traw);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) Traw[k] = c.m * (a[k] * c.acc_half + c.acc_mean);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        Td[k] = clampf(Traw[k], c.T_min, c.T_max);
-        disc[k] = c.rot_tm1sq - c.rot_4tm0 * (c.tm2 - Td[k]);
-        wd[k] = c.rot_scale * (c.rot_neg_tm1 + sqrtf(disc[k]));
-    }
-    const float dt = c.dt;
-    const int S = c.interval_steps;
-    for (int sub = 0; sub < S; ++sub) {
-        float* sv = lds + (size_t)sub * kSave * kBlock + tx;
-        sv[0 * kBlock] = s.q.w; sv[1 * kBlock] = s.q.x; sv[2 * kBlock] = s.q.y; sv[3 * kBlock] = s.q.z;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { sv[(4 + k) * kBlock] = s.v[k]; sv[(7 + k) * kBlock] = s.w[k]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sv[(10 + k) * kBlock] = s.wm[k];
-        if constexpr (CTRL_DELAY) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s.wm[k] = c.c_motor * s.wm[k] + c.one_minus_c * wd[k];
-                s.T[k] = (c.tm0 * (s.wm[k] * s.wm[k]) + c.tm1 * s.wm[k]) + c.tm2;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s.T[k] = Td[k];
-        }
-        float ft[4];
-        mat4(c.B, s.T, ft);
-        const Quat vq{0.0f, s.v[0], s.v[1], s.v[2]};
-        const Quat vb = qmul(qmul(qconj(s.q), vq), s.q);
-        const float vbv[3] = {vb.x, vb.y, vb.z};
-        float u[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) u[k] = (k == 2 ? ft[0] : 0.0f) - (kl[k] * vbv[k] + (kq[k] * vbv[k]) * fabsf(vbv[k]));
-        const Quat uq{0.0f, u[0], u[1], u[2]};
-        const Quat ra = qmul(qmul(s.q, uq), qconj(s.q));
-        s.acc[0] = ra.x / c.m; s.acc[1] = ra.y / c.m; s.acc[2] = ra.z / c.m + c.g_z;
-        if constexpr (INTEG == VF_INT_EULER) {
-            float dq[4], dw[3];
-            derivs(c, s.q, s.w, ft + 1, dq, dw);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s.p[k] += (s.v[k] + c.wind[k]) * dt;
-            s.q.w += dq[0] * dt; s.q.x += dq[1] * dt; s.q.y += dq[2] * dt; s.q.z += dq[3] * dt;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { s.v[k] += s.acc[k] * dt; s.w[k] += dw[k] * dt; }
-            const float nn = sqrtf(((s.q.w * s.q.w + s.q.x * s.q.x) + s.q.y * s.q.y) + s.q.z * s.q.z);
-            s.q = qscale(s.q, 1.0f / nn);
-        } else {   // repaired RK4: the forward kernels' own sub-step functions
-            trans_substep<VF_INT_RK4>(c, s.q, ft[0], kl, kq, c.wind, s.p, s.v, s.acc);
-            rot_substep<VF_INT_RK4>(c, ft + 1, s.q, s.w, s.aa);
-        }
-    }
-    // pre-clamp values decide the clamp masks; clamped values are the step's outputs
-    const float pm[3] = {in_closed(s.p[0], -c.pos_xy_lim, c.pos_xy_lim), in_closed(s.p[1], -c.pos_xy_lim, c.pos_xy_lim),
-                         in_closed(s.p[2], c.pos_z_lo, c.pos_z_hi)};
-    float vm[3], wmk[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        vm[k] = in_closed(s.v[k], -c.vel_lim, c.vel_lim);
-        wmk[k] = in_closed(s.w[k], -c.omg_lim, c.omg_lim);
-    }
-    s.p[0] = clampf(s.p[0], -c.pos_xy_lim, c.pos_xy_lim);
-    s.p[1] = clampf(s.p[1], -c.pos_xy_lim, c.pos_xy_lim);
-    s.p[2] = clampf(s.p[2], c.pos_z_lo, c.pos_z_hi);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { s.v[k] = clampf(s.v[k], -c.vel_lim, c.vel_lim); s.w[k] = clampf(s.w[k], -c.omg_lim, c.omg_lim); }
-
-    // ---- incoming adjoints of the post-step state (zero for agents reset at the end of this step) ----
-    const bool cut = live ? (g.done != nullptr && g.done[i] != 0) : true;
-    float lp[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lw[3] = {0, 0, 0}, lwm[4] = {0, 0, 0, 0}, laa[3] = {0, 0, 0};
-    Quat lq{0, 0, 0, 0};
-    if (!cut) {
-        const float4 g0 = *granule(g.adj, g.G, i, VF_G_POS), g1 = *granule(g.adj, g.G, i, VF_G_QUAT);
-        const float4 g2 = *granule(g.adj, g.G, i, VF_G_VEL), g3 = *granule(g.adj, g.G, i, VF_G_OMG);
-        const float4 g4 = *granule(g.adj, g.G, i, VF_G_MOT), g6 = *granule(g.adj, g.G, i, VF_G_AACC);
-        lp[0] = g0.y; lp[1] = g0.z; lp[2] = g0.w;
-        lq = Quat{g1.x, g1.y, g1.z, g1.w};
-        lv[0] = g2.y; lv[1] = g2.z; lv[2] = g2.w;
-        lw[0] = g3.y; lw[1] = g3.z; lw[2] = g3.w;
-        lwm[0] = g4.x; lwm[1] = g4.y; lwm[2] = g4.z; lwm[3] = g4.w;
-        laa[0] = g6.y; laa[1] = g6.z; laa[2] = g6.w;
-        if (g.d_obs) {  // observation = [p, q, v + wind, w] of the post-step state (dynamics.py:779-786)
-            const float* d = g.d_obs + 13 * (size_t)i;
-            lp[0] += d[0]; lp[1] += d[1]; lp[2] += d[2];
-            lq.w += d[3]; lq.x += d[4]; lq.y += d[5]; lq.z += d[6];
-            lv[0] += d[7]; lv[1] += d[8]; lv[2] += d[9];
-            lw[0] += d[10]; lw[1] += d[11]; lw[2] += d[12];
-        }
-    }
-    // reward gradient (computed on the pre-reset post-step state, so it survives a reset)
-    if (live && g.d_reward && KIND == VF_ENV_NAV) {
-        // NavigationEnv.get_reward (envs/NavigationEnv.py:84-99).  What autograd differentiates there: position, orientation,
-        // velocity, angular velocity and -- through collision_vector = collision_point.detach() - position
-        // (droneEnv.py:345-366) -- the distance / direction to the closest bbox face; success and the step counter are
-        // constants.  clamp / clamp_max / clamp_min pass the gradient on the closed side, relu'(0) = 0, norm'(0) = 0.
-        const float dr = g.d_reward[i];
-        const float vv[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};
-        const Collision col = bbox_collision(e, s.p);
-        const bool success = norm3(s.p[0] - e.target[0], s.p[1] - e.target[1], s.p[2] - e.target[2]) <= e.success_radius;
-        const int step_count = __float_as_int(sp.omg) + 1;        // counter of THIS step (the tape holds the pre-step slab)
-        float ltp[3] = {0.f, 0.f, 0.f}, lcv[3] = {0.f, 0.f, 0.f}, ldis = 0.0f;
-        // t1 = clamp_max(<v, tp> / (1e-6 + |tp|), 10) * 0.01,  tp = target - p
-        const float tp[3] = {e.target[0] - s.p[0], e.target[1] - s.p[1], e.target[2] - s.p[2]};
-        const float ntp = norm3(tp[0], tp[1], tp[2]), den1 = 1e-6f + ntp, dot1 = dot3(vv, tp);
-        if (dot1 / den1 <= 10.0f) {
-            const float gq = dr * 0.01f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                lv[k] += gq * tp[k] / den1;
-                ltp[k] += gq * (vv[k] / den1 - (ntp > 0.0f ? dot1 / (den1 * den1) * tp[k] / ntp : 0.0f));
-            }
-        }
-        // t2 = (clamp_min(acos(clamp(<dir, v> / (1e-6 + |v|), -1, 1)), pi/18) - pi/18) * -0.01,  dir = x_axis(q)
-        const Quat& q = s.q;
-        const float dir[3] = {1.0f - 2.0f * (q.y * q.y + q.z * q.z), 2.0f * (q.x * q.y + q.z * q.w), 2.0f * (q.x * q.z - q.y * q.w)};
-        const float vn = norm3(vv[0], vv[1], vv[2]), den2 = 1e-6f + vn, dot2 = dot3(dir, vv);
-        const float cs0 = dot2 / den2;
-        const float thrd = (float)(3.14159265358979323846 / 18.0);
-        if (cs0 >= -1.0f && cs0 <= 1.0f && (c.trig_mode == VF_TRIG_CR ? vfs_acosf_cr(cs0) : vfs_acosf_u10(cs0)) >= thrd) {
-            const float gcs = dr * -0.01f * (-1.0f / sqrtf(1.0f - cs0 * cs0));
-            float ldir[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                ldir[k] = gcs * vv[k] / den2;
-                lv[k] += gcs * (dir[k] / den2 - (vn > 0.0f ? dot2 / (den2 * den2) * vv[k] / vn : 0.0f));
-            }
-            lq.w += ldir[1] * 2.0f * q.z - ldir[2] * 2.0f * q.y;
-            lq.x += ldir[1] * 2.0f * q.y + ldir[2] * 2.0f * q.z;
-            lq.y += ldir[0] * -4.0f * q.y + ldir[1] * 2.0f * q.x - ldir[2] * 2.0f * q.w;
-            lq.z += ldir[0] * -4.0f * q.z + ldir[1] * 2.0f * q.w + ldir[2] * 2.0f * q.x;
-        }
-        // t3 .. t5: -1e-5 |q - 1|, -0.002 |v|, -0.002 |w|
-        const float dqv[4] = {q.w - 1.0f, q.x, q.y, q.z};
-        const float nq = norm4(dqv[0], dqv[1], dqv[2], dqv[3]), nw = norm3(s.w[0], s.w[1], s.w[2]);
-        if (nq > 0.0f) {
-            const float gq = dr * (float)-0.00001 / nq;
-            lq.w += gq * dqv[0]; lq.x += gq * dqv[1]; lq.y += gq * dqv[2]; lq.z += gq * dqv[3];
-        }
-        // t8 = success * (max_steps - step) * 0.1 * (0.2 + 0.8 / (1 + |v|)): the only other |v| term
-        const float sterm = (float)(success ? e.max_episode_steps - step_count : 0);
-        const float lvn = dr * (-0.002f + sterm * 0.1f * 0.8f * (-1.0f / ((1.0f + vn) * (1.0f + vn))));
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (vn > 0.0f) lv[k] += lvn * vv[k] / vn;
-            if (nw > 0.0f) lw[k] += dr * -0.002f * s.w[k] / nw;
-        }
-        // t6 = -0.01 / (dis + 0.2);  t7 = relu(1 - dis) * relu(<cv, v> / (1e-6 + dis)) * -0.005
-        ldis += dr * 0.01f / ((col.dis + 0.2f) * (col.dis + 0.2f));
-        const float relu1 = 1.0f - col.dis > 0.0f ? 1.0f - col.dis : 0.0f;
-        const float den7 = 1e-6f + col.dis, dot7 = dot3(col.vec, vv), ap = dot7 / den7;
-        const float g7 = dr * -0.005f;
-        if (1.0f - col.dis > 0.0f) ldis -= g7 * (ap > 0.0f ? ap : 0.0f);
-        if (ap > 0.0f) {
-            const float lap = g7 * relu1;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { lcv[k] += lap * vv[k] / den7; lv[k] += lap * col.vec[k] / den7; }
-            ldis -= lap * dot7 / (den7 * den7);
-        }
-        if (col.dis > 0.0f) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) lcv[k] += ldis * col.vec[k] / col.dis;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) lp[k] -= ltp[k] + lcv[k];     // tp = target - p,  cv = const - p
-    } else if (live && g.d_reward) {
-        const float dr = g.d_reward[i];
-        const float* tgt = e.target;
-        if constexpr (KIND == VF_ENV_RACING) {
-            const float4 race = *granule(T, g.G, i, g.g_race);
-            int gate = __float_as_int(race.x);
-            gate = (unsigned)gate < (unsigned)e.n_gates ? gate : 0;
-            const float* gt = e.gates[gate];
-            const bool pass = norm3(s.p[0] - gt[0], s.p[1] - gt[1], s.p[2] - gt[2]) <= e.success_radius;
-            gate = gate + (pass ? 1 : 0);
-            gate = gate == e.n_gates ? 0 : gate;
-            tgt = e.gates[gate];
-        }
-        const float c1 = (float)(-0.1 * 1 / 9), c2 = (float)-0.00001, c3 = (float)-0.002;
-        const float dp[3] = {s.p[0] - tgt[0], s.p[1] - tgt[1], s.p[2] - tgt[2]};
-        const float np_ = norm3(dp[0], dp[1], dp[2]);
-        const float dqv[4] = {s.q.w - 1.0f, s.q.x, s.q.y, s.q.z};
-        const float nq = norm4(dqv[0], dqv[1], dqv[2], dqv[3]);
-        const float vv[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};
-        const float nv = norm3(vv[0], vv[1], vv[2]), nw = norm3(s.w[0], s.w[1], s.w[2]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (np_ > 0.0f) lp[k] += dr * c1 * dp[k] / np_;
-            if (nv > 0.0f) lv[k] += dr * c3 * vv[k] / nv;
-            if (nw > 0.0f) lw[k] += dr * c3 * s.w[k] / nw;
-        }
-        if (nq > 0.0f) {
-            lq.w += dr * c2 * dqv[0] / nq; lq.x += dr * c2 * dqv[1] / nq;
-            lq.y += dr * c2 * dqv[2] / nq; lq.z += dr * c2 * dqv[3] / nq;
-        }
-    }
-    // _ugly_fix clamps
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { lp[k] *= pm[k]; lv[k] *= vm[k]; lw[k] *= wmk[k]; }
-
-    // ---- reverse sweep over the sub-steps ----
-    float lwd[4] = {0, 0, 0, 0}, lTd[4] = {0, 0, 0, 0};
-    float ldw_in[3] = {laa[0], laa[1], laa[2]};  // aa state = dw of the LAST sub-step
-    for (int sub = S - 1; sub >= 0; --sub) {
-        const float* sv = lds + (size_t)sub * kSave * kBlock + tx;
-        const Quat q{sv[0 * kBlock], sv[1 * kBlock], sv[2 * kBlock], sv[3 * kBlock]};
-        float v[3], w[3], wm0[4];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { v[k] = sv[(4 + k) * kBlock]; w[k] = sv[(7 + k) * kBlock]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wm0[k] = sv[(10 + k) * kBlock];
-        // recompute this sub-step's intermediates
-        float wm1[4], Tt[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            wm1[k] = CTRL_DELAY ? c.c_motor * wm0[k] + c.one_minus_c * wd[k] : wm0[k];
-            Tt[k] = CTRL_DELAY ? (c.tm0 * (wm1[k] * wm1[k]) + c.tm1 * wm1[k]) + c.tm2 : Td[k];
-        }
-        float ft[4];
-        mat4(c.B, Tt, ft);
-        const Quat vq{0.0f, v[0], v[1], v[2]};
-        const Quat vb = qmul(qmul(qconj(q), vq), q);
-        const float vbv[3] = {vb.x, vb.y, vb.z};
-        float u[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) u[k] = (k == 2 ? ft[0] : 0.0f) - (kl[k] * vbv[k] + (kq[k] * vbv[k]) * fabsf(vbv[k]));
-        float lacc[3], ltau[3] = {0, 0, 0};
-        Quat lq_in;
-        if constexpr (INTEG == VF_INT_EULER) {
-            float dq[4], dw[3];
-            derivs(c, q, w, ft + 1, dq, dw);
-            const Quat qt{q.w + dq[0] * dt, q.x + dq[1] * dt, q.y + dq[2] * dt, q.z + dq[3] * dt};
-            const float nn = sqrtf(((qt.w * qt.w + qt.x * qt.x) + qt.y * qt.y) + qt.z * qt.z);
-            const Quat qn = qscale(qt, 1.0f / nn);
-            // normalise: q' = qt / |qt|
-            const float dotl = qn.w * lq.w + qn.x * lq.x + qn.y * lq.y + qn.z * lq.z;
-            const Quat lqt{(lq.w - qn.w * dotl) / nn, (lq.x - qn.x * dotl) / nn, (lq.y - qn.y * dotl) / nn,
-                           (lq.z - qn.z * dotl) / nn};
-            // Euler update
-            float ldw[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                ldw[k] = lw[k] * dt + ldw_in[k];
-                lacc[k] = lv[k] * dt;
-                lv[k] += lp[k] * dt;   // p' = p + (v + wind) dt ; lp, lw, lv carry through (identity part)
-                ldw_in[k] = 0.0f;
-            }
-            lq_in = lqt;               // q~ = q + dq dt
-            derivs_bwd(c, q, w, qscale(lqt, dt), ldw, lq_in, lw, ltau);
-        } else {
-            // RK4 over (q, w) with tau frozen: stage st sees q + dq_{st-1} h dt, w + dw_{st-1} h dt (h = .5, .5, 1);
-            // q~ = q + dt sum ks dq_st, w' = w + dt sum ks dw_st, aa = sum ks dw_st
-            const float ks[4] = {1.0f / 6.0f, 2.0f / 6.0f, 2.0f / 6.0f, 1.0f / 6.0f}, hs[4] = {0.0f, 0.5f, 0.5f, 1.0f};
-            Quat qs[4];
-            float ws[4][3], dq[4], dw[3], sq[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                if (st == 0) {
-                    qs[0] = q;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) ws[0][k] = w[k];
-                } else {
-                    const float h = hs[st] * dt;
-                    qs[st] = Quat{q.w + dq[0] * h, q.x + dq[1] * h, q.y + dq[2] * h, q.z + dq[3] * h};
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) ws[st][k] = w[k] + dw[k] * h;
-                }
-                derivs(c, qs[st], ws[st], ft + 1, dq, dw);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sq[k] += dq[k] * ks[st];
-            }
-            const Quat qt{q.w + sq[0] * dt, q.x + sq[1] * dt, q.y + sq[2] * dt, q.z + sq[3] * dt};
-            const float nn = sqrtf(((qt.w * qt.w + qt.x * qt.x) + qt.y * qt.y) + qt.z * qt.z);
-            const Quat qn = qscale(qt, 1.0f / nn);
-            const float dotl = qn.w * lq.w + qn.x * lq.x + qn.y * lq.y + qn.z * lq.z;
-            const Quat lqt{(lq.w - qn.w * dotl) / nn, (lq.x - qn.x * dotl) / nn, (lq.y - qn.y * dotl) / nn,
-                           (lq.z - qn.z * dotl) / nn};
-            float lsw[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                lsw[k] = lw[k] * dt + ldw_in[k];
-                ldw_in[k] = 0.0f;
-                // translation: p' = p + dt sum ks (v + acc h dt + wind), v' = v + dt sum ks acc  (sum ks = 1, sum ks h = 1/2)
-                lacc[k] = lv[k] * dt + lp[k] * dt * (0.5f * dt);
-                lv[k] += lp[k] * dt;
-            }
-            const Quat lsq = qscale(lqt, dt);
-            lq_in = lqt;
-            Quat ldq_c = qscale(lsq, ks[3]);                 // adjoint of the stage derivative currently being unwound
-            float ldw_c[3] = {lsw[0] * ks[3], lsw[1] * ks[3], lsw[2] * ks[3]};
-#pragma unroll
-            for (int st = 3; st >= 0; --st) {
-                Quat lqc{0, 0, 0, 0};
-                float lwc[3] = {0, 0, 0};
-                derivs_bwd(c, qs[st], ws[st], ldq_c, ldw_c, lqc, lwc, ltau);
-                qacc(lq_in, lqc);                               // every stage state contains q and w once
-#pragma unroll
-                for (int k = 0; k < 3; ++k) lw[k] += lwc[k];
-                if (st > 0) {                                   // ... and the previous stage's derivative times h dt
-                    const float h = hs[st] * dt;
-                    ldq_c = qscale(lsq, ks[st - 1]);
-                    qacc(ldq_c, qscale(lqc, h));
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) ldw_c[k] = lsw[k] * ks[st - 1] + lwc[k] * h;
-                }
-            }
-        }
-        // acc = rotate(q, u) / m + g
-        float lra[3] = {lacc[0] / c.m, lacc[1] / c.m, lacc[2] / c.m}, lu[3] = {0, 0, 0};
-        rotate_bwd(q, u, lra, lq_in, lu);
-        float lF = lu[2];
-        // u = z F - drag ; drag = kl vb + kq vb |vb|
-        float lvb[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) lvb[k] = -lu[k] * (kl[k] + 2.0f * kq[k] * fabsf(vbv[k]));
-        inv_rotate_bwd(q, v, lvb, lq_in, lv);
-        // [F; tau] = B T
-        const float lft[4] = {lF, ltau[0], ltau[1], ltau[2]};
-        float lT[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lT[k] = c.B[k] * lft[0] + c.B[4 + k] * lft[1] + c.B[8 + k] * lft[2] + c.B[12 + k] * lft[3];
-        if constexpr (CTRL_DELAY) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float l1 = lwm[k] + lT[k] * (2.0f * c.tm0 * wm1[k] + c.tm1);
-                lwd[k] += c.one_minus_c * l1;
-                lwm[k] = c.c_motor * l1;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) lTd[k] += lT[k];
-        }
-        lq = lq_in;
-    }
-    // ---- rotor set-point, clamp, controller, de-normalisation ----
-    float lTraw[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (CTRL_DELAY) lTd[k] += lwd[k] / sqrtf(disc[k]);  // d wd / d Td = 1 / sqrt(tm1^2 - 4 tm0 (tm2 - Td))
-        lTraw[k] = lTd[k] * in_closed(Traw[k], c.T_min, c.T_max);
-    }
-    float la[4];
-    if constexpr (ACT == VF_ACT_BODYRATE) {
-        float lu4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            lu4[k] = c.Binv[k] * lTraw[0] + c.Binv[4 + k] * lTraw[1] + c.Binv[8 + k] * lTraw[2] + c.Binv[12 + k] * lTraw[3];
-        la[0] = lu4[0] * c.m * c.acc_half;
-        const float ltd[3] = {lu4[1], lu4[2], lu4[3]};
-        float le[3] = {0, 0, 0};
-        mat3T_acc(c.JP, ltd, le);
-        float Jw[3], t0[3], t1[3];
-        mat3(c.J, w0[0], w0[1], w0[2], Jw);
-        cross3(Jw, ltd, t0);
-        cross3(ltd, w0, t1);
-        float nd[3] = {-ltd[0], -ltd[1], -ltd[2]};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            la[k + 1] = le[k] * c.rate_half;
-            lw[k] += t0[k] - le[k];
-        }
-        mat3T_acc(c.J, t1, lw);
-        float laa0[3] = {0, 0, 0};
-        mat3T_acc(c.Dm, nd, laa0);
-        laa[0] = laa0[0]; laa[1] = laa0[1]; laa[2] = laa0[2];
-        (void)al0;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) la[k] = lTraw[k] * c.m * c.acc_half;
-        laa[0] = laa[1] = laa[2] = 0.0f;
-    }
-
-    // ---- write the adjoint of the pre-step state; hand the action gradient out ----
-    float4 dact = make_float4(la[0], la[1], la[2], la[3]);
-    if (c.delay_steps > 0) {
-        // the consumed action sat in ring[head]; the action passed to this step was pushed into the same
-        // slot, so ITS gradient is whatever later steps accumulated on that slot
-        float4* slot = granule(g.adj, g.G, i, VF_G_RING + head);
-        const float4 pushed = cut ? make_float4(0.f, 0.f, 0.f, 0.f) : *slot;
-        *slot = dact;
-        dact = pushed;
-        if (cut)
-            for (int q = 0; q < c.delay_steps; ++q)
-                if (q != head) *granule(g.adj, g.G, i, VF_G_RING + q) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    *granule(g.adj, g.G, i, VF_G_POS) = make_float4(0.f, lp[0], lp[1], lp[2]);
-    *granule(g.adj, g.G, i, VF_G_QUAT) = make_float4(lq.w, lq.x, lq.y, lq.z);
-    *granule(g.adj, g.G, i, VF_G_VEL) = make_float4(0.f, lv[0], lv[1], lv[2]);
-    *granule(g.adj, g.G, i, VF_G_OMG) = make_float4(0.f, lw[0], lw[1], lw[2]);
-    *granule(g.adj, g.G, i, VF_G_MOT) = make_float4(lwm[0], lwm[1], lwm[2], lwm[3]);
-    *granule(g.adj, g.G, i, VF_G_THR) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *granule(g.adj, g.G, i, VF_G_AACC) = make_float4(0.f, laa[0], laa[1], laa[2]);
-    *granule(g.adj, g.G, i, VF_G_ACC) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) g.d_action[i] = dact;
+    env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, kBlock>(*cp, *ep, g, i, i < g.N, lds + threadIdx.x);
 }
 
 }  // namespace vf

@@ -19,7 +19,7 @@
 // policies.py:18-49): NB extractor branches of two ReLU layers, concatenated, then policy / value trunks of two
 // ReLU layers with a 4-wide / 1-wide head.  vf_mlp_forward picks it when the layer table matches an instantiated
 // shape and falls back to the LDS kernel (k_mlp_forward) otherwise.
-#include "vf_mlp_chain.hpp"
+#include "vf_mlp_chain_bwd.hpp"
 
 namespace vf {
 
@@ -208,304 +208,6 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
     VF_TRACE(1);
     chain16_items<N, 0>(g, st, lane, row, live);
     VF_TRACE(31);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Reverse chain: data gradients of the whole network for 32 rows per wave, again in registers.
-// dA^T[k][m] = sum_n W[n][k] dZ^T[n][m] has the same shape as the forward step (A operand = W^T blocks in the order an
-// accumulator lane holds its row's features: image at vf_mlp_layer.wq_off; B operand = the masked gradient tiles),
-// so the gradient tiles are fed back exactly like the activations.  After a layer's gradient w.r.t. the previous
-// activation is complete it is masked with that activation (> 0, read back from the copy the forward saved) and
-// stored to the buffer the weight-gradient kernel (vf_mlp_wgrad.hip) reads as dZ; the stores trickle out through the
-// items of the next op like the forward's.  The weight / bias gradients are NOT formed here: they reduce over rows,
-// i.e. across waves, and have their own kernel with row-slab partials.
-// ------------------------------------------------------------------------------------------------
-struct BwdFin {     // mask tiles [t0, t0 + nt) with the saved output of forward layer fl and store them as its dZ
-    int fl, t0, nt, ym0;
-};
-struct BwdOp {
-    int fl;         // forward layer whose weights are applied (MlpPolicy order)
-    int in_kind;    // 0: gradient tiles, 1: d_mean (M,4), 2: d_value (M,)
-    int in0, G;     // first input tile, number of 8-feature groups of the input gradient
-    int out0, nout; // output tiles = ceil(K / 32)
-    int accum;      // 1: keep accumulating into the output tiles
-    int obs;        // >= 0: the output is dLoss/d observation `obs` (stored directly, no mask)
-    int nfin;
-    BwdFin fin[2];
-};
-
-template <class N, bool PI, bool VF, bool IG>
-struct BwdProg {
-    using Net = N;
-    static constexpr int NB = N::NB;
-    static constexpr int L_pi0 = 2 * NB, L_pi1 = 2 * NB + 1, L_mean = 2 * NB + 2, L_vf0 = 2 * NB + 3, L_vf1 = 2 * NB + 4, L_val = 2 * NB + 5;
-    // gradient tiles
-    static constexpr int g_p2 = 0, g_v2 = g_p2 + N::P2, g_p1 = g_v2 + N::V2, g_v1 = g_p1 + N::P1, g_feat = g_v1 + N::V1;
-    static constexpr int g_e1(int b) { return g_feat + NB * N::E2 + b * N::E1; }
-    static constexpr int g_in(int b) { return g_e1(NB) + b; }
-    static constexpr int n_tiles = g_in(NB);
-    static constexpr int n_ops = (PI ? 3 : 0) + (VF ? 3 : 0) + NB + (IG ? NB : 0);
-    static constexpr bool included(int l) { return l < 2 * NB || (l >= L_pi0 && l <= L_mean && PI) || (l >= L_vf0 && VF); }
-    static constexpr int entry(int fl)      // index of forward layer fl in the (reversed, trunk-skipping) vf_mlp_bwd_desc
-    {
-        int e = 0;
-        for (int l = fl + 1; l < 2 * NB + 6; ++l) e += included(l) ? 1 : 0;
-        return e;
-    }
-    static constexpr BwdOp feat_fins(BwdOp o)
-    {
-        o.nfin = NB;
-        for (int b = 0; b < NB; ++b) o.fin[b] = BwdFin{2 * b + 1, g_feat + b * N::E2, N::E2, b * N::E2};
-        return o;
-    }
-    static constexpr BwdOp op(int i)
-    {
-        // order: heads, second trunk layers, first trunk layers (-> feat), extractor L2 layers, [extractor L1 layers]
-        int k = 0;
-        if (PI) { if (i == k) return BwdOp{L_mean, 1, 0, 1, g_p2, N::P2, 0, -1, 1, {BwdFin{L_pi1, g_p2, N::P2, 0}, {}}}; ++k; }
-        if (VF) { if (i == k) return BwdOp{L_val, 2, 0, 1, g_v2, N::V2, 0, -1, 1, {BwdFin{L_vf1, g_v2, N::V2, 2}, {}}}; ++k; }
-        if (PI) { if (i == k) return BwdOp{L_pi1, 0, g_p2, N::P2 * 4, g_p1, N::P1, 0, -1, 1, {BwdFin{L_pi0, g_p1, N::P1, 0}, {}}}; ++k; }
-        if (VF) { if (i == k) return BwdOp{L_vf1, 0, g_v2, N::V2 * 4, g_v1, N::V1, 0, -1, 1, {BwdFin{L_vf0, g_v1, N::V1, 2}, {}}}; ++k; }
-        if (PI) {
-            if (i == k) {
-                BwdOp o{L_pi0, 0, g_p1, N::P1 * 4, g_feat, NB * N::E2, 0, -1, 0, {}};
-                return VF ? o : feat_fins(o);
-            }
-            ++k;
-        }
-        if (VF) {
-            if (i == k) return feat_fins(BwdOp{L_vf0, 0, g_v1, N::V1 * 4, g_feat, NB * N::E2, PI ? 1 : 0, -1, 0, {}});
-            ++k;
-        }
-        for (int b = 0; b < NB; ++b) {
-            if (i == k) return BwdOp{2 * b + 1, 0, g_feat + b * N::E2, N::E2 * 4, g_e1(b), N::E1, 0, -1, 1, {BwdFin{2 * b, g_e1(b), N::E1, 0}, {}}};
-            ++k;
-        }
-        for (int b = 0; b < NB; ++b) {
-            if (i == k) return BwdOp{2 * b, 0, g_e1(b), N::E1 * 4, g_in(b), 1, 0, b, 0, {}};
-            ++k;
-        }
-        return BwdOp{};
-    }
-    static constexpr int items(int i) { return op(i).G * op(i).nout; }
-    static constexpr int n_items()
-    {
-        int n = 0;
-        for (int i = 0; i < n_ops; ++i) n += items(i);
-        return n;
-    }
-    static constexpr int op_of(int item)
-    {
-        int i = 0;
-        while (item >= items(i)) { item -= items(i); ++i; }
-        return i;
-    }
-    static constexpr int first_item(int oi)
-    {
-        int n = 0;
-        for (int i = 0; i < oi; ++i) n += items(i);
-        return n;
-    }
-};
-
-struct BwdArgsChain {
-    vf_mlp_bwd_desc d;
-    const float* packed;
-    int M;
-    // optional action head (vf_mlp_backward_data_act): the head gradient is formed here from d_action
-    const float4* rp_d_action;
-    const float4* rp_action;
-    const float* rp_log_std;
-    const float4* rp_eps;
-    float4* rp_g_log_std;
-};
-
-template <class P>
-struct BwdState {
-    f32x16 t[P::n_tiles];
-    float4 ring[kChainDepth];
-    float4 ym[4][4];             // saved activations (mask source) of the tiles being finalised
-    float hin[2][4];             // head gradients of this lane's row: d_mean[0..3] / d_value (lane half 0), else 0
-};
-
-template <class P, int I>
-__device__ __forceinline__ float4 bwd_load(const BwdArgsChain& g, int lane)
-{
-    constexpr int oi = P::op_of(I), local = I - P::first_item(oi);
-    constexpr BwdOp O = P::op(oi);
-    constexpr int gq = local / O.nout, a = local % O.nout;
-    const char* base = reinterpret_cast<const char*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off) + (a * O.G + gq) * 1024;
-    return *reinterpret_cast<const float4*>(base + (unsigned)lane * 16u);
-}
-
-template <class P, int OI>
-__device__ __forceinline__ void bwd_mask_load(const BwdArgsChain& g, BwdState<P>& st, int rc, int h)
-{
-    constexpr BwdOp O = P::op(OI);
-#pragma unroll
-    for (int f = 0; f < O.nfin; ++f) {
-        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fin[f].fl)];
-        const float* y = E.Y + (size_t)rc * E.ld_y + 4 * h;
-#pragma unroll
-        for (int a = 0; a < O.fin[f].nt; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) st.ym[O.fin[f].ym0 + a][q] = *reinterpret_cast<const float4*>(y + 32 * a + 8 * q);
-    }
-}
-
-struct NoFwd {};     // FS of the stand-alone reverse chain: masks are read back from HBM
-
-template <class P, class FS, int OI>
-__device__ __forceinline__ void bwd_finalize(const BwdArgsChain& g, BwdState<P>& st, const FS& fs, int row, int h, bool live)
-{
-    constexpr BwdOp O = P::op(OI);
-#pragma unroll
-    for (int f = 0; f < O.nfin; ++f)
-#pragma unroll
-        for (int a = 0; a < O.fin[f].nt; ++a) {
-            f32x16& v = st.t[O.fin[f].t0 + a];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 y;
-                if constexpr (std::is_same<FS, NoFwd>::value) y = st.ym[O.fin[f].ym0 + a][q];
-                else {      // fused kernel: the forward's own accumulator tile of that layer is still in registers
-                    const f32x16& t = fs.t[P::Net::tile_of_layer(O.fin[f].fl) + a];
-                    y = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
-                }
-                v[4 * q + 0] = y.x > 0.0f ? v[4 * q + 0] : 0.0f;
-                v[4 * q + 1] = y.y > 0.0f ? v[4 * q + 1] : 0.0f;
-                v[4 * q + 2] = y.z > 0.0f ? v[4 * q + 2] : 0.0f;
-                v[4 * q + 3] = y.w > 0.0f ? v[4 * q + 3] : 0.0f;
-            }
-        }
-    if constexpr (O.obs >= 0) {        // dLoss/d observation: features 4 h + (r & 3) + 8 (r >> 2) of this lane's row
-        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];
-        if (live) {
-            const f32x16& v = st.t[O.out0];
-            float* dx = E.dX + (size_t)row * E.ld_dx;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = 4 * h + (r & 3) + 8 * (r >> 2);
-                if (k < E.K) dx[k] = v[r];
-            }
-        }
-    }
-}
-
-// stores of the tiles the PREVIOUS op finalised, spread over this op's items
-template <class P, int OI, int LOCAL>
-__device__ __forceinline__ void bwd_deferred_store(const BwdArgsChain& g, const BwdState<P>& st, int row, int h, bool live)
-{
-    if constexpr (OI >= 1) {
-        constexpr BwdOp Q = P::op(OI - 1);
-        constexpr int S0 = Q.nfin > 0 ? Q.fin[0].nt * 4 : 0, S = S0 + (Q.nfin > 1 ? Q.fin[1].nt * 4 : 0);
-        constexpr int n_it = P::items(OI), per = (S + n_it - 1) / n_it;
-        constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
-        if constexpr (s0 < s1) {
-            if (live) {
-#pragma unroll
-                for (int i = s0; i < s1; ++i) {
-                    const int f = i < S0 ? 0 : 1, ii = i - (f ? S0 : 0), a = ii / 4, q = ii % 4;
-                    const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
-                    float* base = const_cast<float*>(E.dY) + 32 * a + 8 * q;            // wave-uniform
-                    const unsigned off = (unsigned)row * (unsigned)E.ld_dy + 4u * h;
-                    const f32x16& v = st.t[Q.fin[f].t0 + a];
-                    *reinterpret_cast<float4*>(base + off) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                }
-            }
-        }
-    }
-}
-
-template <class P, class FS, int I>
-__device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st, const FS& fs, int lane, int row, int rc, bool live)
-{
-    if constexpr (I < P::n_items()) {
-        constexpr int oi = P::op_of(I), local = I - P::first_item(oi);
-        constexpr BwdOp O = P::op(oi);
-        constexpr int gq = local / O.nout, a = local % O.nout;
-        const int h = lane >> 5;
-        const float4 w = st.ring[I % kChainDepth];
-        if constexpr (I + kChainDepth < P::n_items()) st.ring[I % kChainDepth] = bwd_load<P, I + kChainDepth>(g, lane);
-        if constexpr (local == 0 && O.in_kind == 0 && std::is_same<FS, NoFwd>::value) bwd_mask_load<P, oi>(g, st, rc, h);   // head ops: in the prologue
-        f32x16& acc = st.t[O.out0 + a];
-        if constexpr (gq == 0 && !O.accum) acc = f32x16{0};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float b;
-            if constexpr (O.in_kind == 0) b = st.t[O.in0 + gq / 4][4 * (gq % 4) + j];
-            else b = st.hin[O.in_kind - 1][j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
-        }
-        bwd_deferred_store<P, oi, local>(g, st, row, h, live);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (local == P::items(oi) - 1) bwd_finalize<P, FS, oi>(g, st, fs, row, h, live);
-        bwd_items<P, FS, I + 1>(g, st, fs, lane, row, rc, live);
-    }
-}
-
-template <class P, int I>
-__device__ __forceinline__ void bwd_prologue(const BwdArgsChain& g, BwdState<P>& st, int lane)
-{
-    if constexpr (I < kChainDepth && I < P::n_items()) {
-        st.ring[I] = bwd_load<P, I>(g, lane);
-        bwd_prologue<P, I + 1>(g, st, lane);
-    }
-}
-
-template <class P, int OI>
-__device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdState<P>& st, int rc, int h, bool live)
-{
-    if constexpr (OI < P::n_ops) {
-        constexpr BwdOp O = P::op(OI);
-        if constexpr (O.in_kind != 0) {
-            const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];
-            const float* dy = E.dY + (size_t)rc * E.ld_dy;
-            if constexpr (O.in_kind == 1) {
-                if (g.rp_d_action) {       // k_reparam_bwd's arithmetic; lane half 0 of a live row writes d_mean / g_log_std
-                    const float4 da = g.rp_d_action[rc], a = g.rp_action[rc], e = g.rp_eps[rc];
-                    const float4 dm = make_float4(da.x * (1.0f - a.x * a.x), da.y * (1.0f - a.y * a.y), da.z * (1.0f - a.z * a.z),
-                                                  da.w * (1.0f - a.w * a.w));
-                    if (live && h == 0) {
-                        *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
-                        float4 gl = g.rp_g_log_std[rc];
-                        gl.x += dm.x * expf(g.rp_log_std[0]) * e.x; gl.y += dm.y * expf(g.rp_log_std[1]) * e.y;
-                        gl.z += dm.z * expf(g.rp_log_std[2]) * e.z; gl.w += dm.w * expf(g.rp_log_std[3]) * e.w;
-                        g.rp_g_log_std[rc] = gl;
-                    }
-                    st.hin[0][0] = h == 0 ? dm.x : 0.0f; st.hin[0][1] = h == 0 ? dm.y : 0.0f;
-                    st.hin[0][2] = h == 0 ? dm.z : 0.0f; st.hin[0][3] = h == 0 ? dm.w : 0.0f;
-                } else {
-                    st.hin[0][0] = h == 0 ? dy[0] : 0.0f; st.hin[0][1] = h == 0 ? dy[1] : 0.0f;
-                    st.hin[0][2] = h == 0 ? dy[2] : 0.0f; st.hin[0][3] = h == 0 ? dy[3] : 0.0f;
-                }
-            } else {
-                st.hin[1][0] = h == 0 ? dy[0] : 0.0f; st.hin[1][1] = 0.0f; st.hin[1][2] = 0.0f; st.hin[1][3] = 0.0f;
-            }
-            bwd_mask_load<P, OI>(g, st, rc, h);
-            bwd_head_prologue<P, OI + 1>(g, st, rc, h, live);
-        }
-    }
-}
-
-// the last op's finalised tiles have no following items to carry their stores
-template <class P>
-__device__ __forceinline__ void bwd_tail_store(const BwdArgsChain& g, const BwdState<P>& st, int row, int h, bool live)
-{
-    constexpr BwdOp Q = P::op(P::n_ops - 1);
-    if (!live) return;
-#pragma unroll
-    for (int f = 0; f < Q.nfin; ++f) {
-        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
-        float* base = const_cast<float*>(E.dY) + (size_t)row * E.ld_dy + 4 * h;
-#pragma unroll
-        for (int a = 0; a < Q.fin[f].nt; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x16& v = st.t[Q.fin[f].t0 + a];
-                *reinterpret_cast<float4*>(base + 32 * a + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-            }
-    }
 }
 
 template <class P>
@@ -773,6 +475,16 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     }
     if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
     if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
+    return 0;
+}
+
+// the policy-trunk-only reverse chain with observation gradient (first-order policy optimisation): 0 none, 1 NetHover, 2 NetNav
+int bwd_chain_policy_class(const vf_mlp_bwd_desc* d)
+{
+    static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
+    if (off) return 0;
+    if (bwd_chain_matches<NetHover, true, false, true>(*d)) return 1;
+    if (bwd_chain_matches<NetNav, true, false, true>(*d)) return 2;
     return 0;
 }
 

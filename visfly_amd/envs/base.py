@@ -873,6 +873,35 @@ class DroneGymEnvsBase:
         policy._last_M, policy._last_slot = N, H - 1
         return True
 
+    def reverse_policy(self, policy, H, eps, actions, d_reward, d_means, g_log_std):
+        """the reverse half of the last H recorded steps in ONE persistent launch (vf_bptt_reverse): for t = H-1 .. 0 the adjoint of
+        env step t and the policy's action-head reverse + reverse chain of slot t.  -> False when the library has no kernel for
+        this configuration (the caller then sweeps launch by launch).  d_means (H,N,4) out, g_log_std (H,N,4) zeroed in / out."""
+        N, dev = self.num_agent, self.device
+        t0 = self._tape_t - H
+        nblk, blk = policy._slot_blocks.get(N, (0, None))
+        if self._tape is None or t0 < 0 or nblk < H:
+            return False
+        key = ("bwd_flat", N, H)
+        cached = policy._descs.get(key)
+        if cached is None:
+            b = {name: t[:H].reshape(-1, t.shape[-1]) for name, t in blk.items()}
+            d, d_in = policy._bwd_desc(b, H * N, d_means.view(-1, 4), None, True)
+            cached = policy._descs[key] = (d, d_in, th.empty((H, N, 4), dtype=th.float32, device=dev))
+        d, d_in, d_action = cached
+        d.layer[0].dY = _lib.ptr(d_means)
+        policy._pack()
+        with th.cuda.device(dev):
+            rc = _lib.lib().vf_bptt_reverse(self._h, C.byref(d), _lib.ptr(policy._packed), _lib.ptr(policy.log_std), _lib.ptr(eps),
+                                            _lib.ptr(actions), _lib.ptr(self._tape[t0]), self._slab.numel(), self._tape_done[t0].data_ptr(),
+                                            _lib.ptr(d_reward), _lib.ptr(self._adj), _lib.ptr(d_action), _lib.ptr(d_in["state"]),
+                                            _lib.ptr(g_log_std), H, self._stream())
+        if rc == _lib.EUNSUPPORTED:
+            return False
+        if rc:
+            _lib.check(rc)
+        return True
+
     def clear_tape(self):
         """env.detach() of the reference (droneGymEnv.py:286-300): cut the graph at the current state"""
         if self._tape is not None:
