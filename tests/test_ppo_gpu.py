@@ -662,3 +662,28 @@ def test_ppo_on_a_host_observation_env_values_its_own_terminal_rows():
     ppo.train()
     assert torch.isfinite(ppo.policy.flat).all()
     env.close()
+
+
+@pytest.mark.parametrize("keys", [("state",), ("state", "target")])
+def test_chain16_and_chain32_agree_to_a_stated_bound(keys):
+    """the 16-rows-per-wave forward (v_mfma_f32_16x16x4_f32, picked for M <= 16 384: roll-outs, BPTT) and the 32-row chain
+    (v_mfma_f32_32x32x2_f32: larger M, and what vf_ppo_update recomputes a minibatch with) accumulate the same products in a different
+    order.  Same rows through both: heads within 2e-6 relative of the output scale (a handful of fp32 ulps; measured ~4e-7) --
+    so the log-prob recomputed by the first PPO minibatch differs from the rollout's by rounding only (ratio = 1 +- 1e-6)"""
+    from visfly_amd.ppo import MlpPolicy
+    dims = {"state": 13, "target": 3}
+    pol = MlpPolicy({k: dims[k] for k in keys}, {k: [128, 64] for k in keys}, [64, 64], [64, 64], DEV, seed=6)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    M16, M32 = 16384, 16384 + 4096
+    obs32 = {k: torch.randn((M32, dims[k]), device=DEV, generator=g) for k in keys}
+    obs16 = {k: v[:M16].contiguous() for k, v in obs32.items()}
+    m16, v16 = [x.clone() for x in pol.forward(obs16, save_activations=False)]
+    m32, v32 = [x.clone() for x in pol.forward(obs32, save_activations=False)]
+    for a, b in ((m16, m32[:M16]), (v16.view(-1), v32.view(-1)[:M16])):
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        assert err <= 2e-6 * scale, (err, scale)
+    ref = pol.to_torch().to(DEV).double()
+    with torch.no_grad():
+        m0, _ = ref({k: v.double() for k, v in obs16.items()})
+    assert float((m16.double() - m0).abs().max()) <= 2e-6 * float(m0.abs().max())        # and both sit that close to fp64

@@ -3,6 +3,9 @@ same number of steps as ONE vf_env_rollout_fused launch per 8 steps instead"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get('VF_ALT_LIB'):
+    from visfly_amd import _build, _lib
+    _build.LIB = _lib.LIB = os.environ['VF_ALT_LIB']
 from visfly_amd.envs import HoverEnv
 N = int(sys.argv[1]); iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 fused = len(sys.argv) > 3 and sys.argv[3] == "fused"

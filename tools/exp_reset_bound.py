@@ -14,9 +14,9 @@ if sys.argv[1:] == ["build"]:
     _build.build(force=True, extra_flags=["-DVF_EXP_CHEAP_SPAWN"], out=ALT)
     print("built", ALT)
     sys.exit(0)
-if sys.argv[1:] == ["alt"]:
+if sys.argv[1:] == ["alt"] or os.environ.get("VF_ALT_LIB"):
     from visfly_amd import _build, _lib
-    _build.LIB = _lib.LIB = ALT
+    _build.LIB = _lib.LIB = os.environ.get("VF_ALT_LIB") or ALT
 import torch
 from visfly_amd.envs import HoverEnv
 N = 65536
@@ -40,7 +40,7 @@ def timed(seq, reps=60):
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / (reps * seq.shape[0]))
     return best
-print(f"{'alt' if sys.argv[1:] == ['alt'] else 'real'}: no-reset regime {timed(calm):.2f} us/step", end="; ")
+print(f"{os.path.basename(os.environ.get('VF_ALT_LIB', '')) or ('alt' if sys.argv[1:] == ['alt'] else 'real')}: no-reset regime {timed(calm):.2f} us/step", end="; ")
 for _ in range(40):
     env.step_n(wild)
 dn = env._rollouts[16]["done"]

@@ -19,13 +19,17 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     const vf_dyn_cfg& c = *cp;   // persistent device copies (vf_handles.hpp): L2-resident from launch to launch
     const vf_env_cfg& e = *ep;
     __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
-    if (g.helper) {                                  // second half of the grid: helper blocks (prefetched re-spawn)
-        const int nbm = (int)(gridDim.x >> 1);
+#ifndef VF_EXP_NO_HELPER
+    if (g.helper) {                                  // the blocks behind the g.helper main blocks: helper blocks (prefetched re-spawn),
+        const int nbm = g.helper;                    // kHelperSpan agents per thread (a workgroup dispatch costs more than their checks)
         if ((int)blockIdx.x >= nbm) {
-            spawn_helper(e, g, ((int)blockIdx.x - nbm) * kBlock + (int)threadIdx.x);
+            const int base = ((int)blockIdx.x - nbm) * kHelperSpan * kBlock + (int)threadIdx.x;
+#pragma unroll 1
+            for (int k = 0; k < kHelperSpan; ++k) spawn_helper(e, g, base + k * kBlock);
             return;
         }
     }
+#endif
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.d.N;
     Agent s;
@@ -355,7 +359,7 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
             static const int mode = [] { const char* e = getenv("VISFLY_AMD_PREFETCH_MODE"); return e ? atoi(e) : 3; }();   // A/B: 1 = slot loads only, 2 = helper only
             if (mode & 1) g.g_spawn_rd = h->g_spawn + 4 * par;
             g.g_spawn_wr = h->g_spawn + 4 * (1 - par);
-            if (mode & 2) { g.helper = 1; nb *= 2; }
+            if (mode & 2) { g.helper = (int)nb; nb += (nb + vf::kHelperSpan - 1) / vf::kHelperSpan; }
         }
         hipLaunchKernelGGL(pick_env_kernel(h), dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
     }

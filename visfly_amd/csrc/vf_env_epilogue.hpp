@@ -64,6 +64,13 @@ struct SpawnSlot {
     float4 g0, g1, g2, g3;
 };
 
+#ifndef VF_HELPER_SPAN
+#define VF_HELPER_SPAN 1
+#endif
+// agents per helper thread.  1: as many helper blocks as main blocks.  Fewer, longer helper blocks were measured and lose: their
+// serial refills end up on the launch's critical path (reset regime at 65 536 agents: span 1 11.2 us, 4 11.5, 8 17.6, 16 29.3)
+constexpr int kHelperSpan = VF_HELPER_SPAN;
+
 // helper blocks of k_env_step: refill the copy this launch does not read for every agent whose copy is stale
 __device__ __forceinline__ void spawn_helper(const vf_env_cfg& e, const EnvArgs& g, int i)
 {
@@ -141,6 +148,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     er.flags = set_flag(er.flags, VF_F_FAILURE, failure);
     er.flags = set_flag(er.flags, VF_F_DONE, done);
 
+#ifndef VF_EXP_NO_DONE_LIST
     if (g.out.done_list) {                       // compacted done list: one atomic per wave that has an ending agent
         const unsigned long long m = __ballot(live && done);
         if (m) {
@@ -151,11 +159,16 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
             if (live && done) g.out.done_list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
         }
     }
+#endif
     // prefetched re-spawn: only a wave that ends an episode touches the copy -- four exec-masked 16-byte loads, issued as soon as
     // `done` is known so that they travel under the terminal-row stores (loading them with the state burst of EVERY wave cost
     // the no-reset launch 0.45 us: profiles/r03_reset_prefetch.txt)
     SpawnSlot slot;
+#ifdef VF_EXP_NO_SLOT
+    const bool use_slot = false;
+#else
     const bool use_slot = done && g.auto_reset && g.g_spawn_rd >= 0;
+#endif
     if (use_slot) {
         const float4* src = granule(g.d.S, g.d.G, i, g.g_spawn_rd);
         slot.g0 = src[0]; slot.g1 = src[64]; slot.g2 = src[128]; slot.g3 = src[192];
