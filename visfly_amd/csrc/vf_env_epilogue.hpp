@@ -23,7 +23,7 @@ struct EnvArgs {
     const float* ext_point = nullptr;
     const unsigned char* ext_oob = nullptr;
     // prefetched re-spawn (include/visfly_amd.h): granule index of the copy this launch READS (main waves) and of the copy its
-    // helper blocks REFILL, or -1; helper != 0: the second half of the grid are helper blocks
+    // helper blocks REFILL, or -1; helper = number of main blocks when helper blocks follow them in the grid, else 0
     int g_spawn_rd = -1, g_spawn_wr = -1, helper = 0;
 };
 

@@ -664,7 +664,9 @@ class DroneGymEnvsBase:
     def step_n(self, actions, is_test=False, graph=False, fused=False):
         """K consecutive step() calls with the launch loop in C (vf_env_step_n): `actions` is a (K,N,4) device tensor.
         Returns (obs (K,N,13), reward (K,N), done (K,N)) -- row k is what the k-th step()
-        would have returned (obs after auto-reset, reward / done before); bit-identical to K step() calls.  The output
+        would have returned (obs after auto-reset, reward / done before); bit-identical to K step() calls.  No info dicts: the
+        episode outputs (ep_return / ep_length / ep_flags / terminal_obs) are ONE buffer per env, so an agent that finishes twice
+        within the K steps keeps only its last episode's entries -- trainers that need every episode's info use step().  The output
         buffers are cached per K and re-used by the next step_n call of the same K.  graph=True replays the K launches from
         a hipGraph captured on the first call for this (K, actions buffer): the caller refills that SAME actions tensor
         between calls.  fused=True runs the K steps inside ONE launch with the agents held in registers between the steps
