@@ -33,7 +33,7 @@ extern "C" {
                               5: vf_dyn_ring_phase / vf_dyn_set_ring_phase / vf_env_set_ring_phase, capture guard on
                                  vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update,
                                  vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
-                                 vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse */
+                                 vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout */
 
 typedef void* vf_stream_t;
 
@@ -749,6 +749,39 @@ int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, con
 int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const float* packed, const float* log_std, const float* eps,
                     const float* actions, const float* tape, int64_t tape_stride, const uint8_t* tape_done, const float* d_reward,
                     float* adj_slab, float* d_action, const float* g_obs, float* g_log_std, int32_t H, vf_stream_t stream);
+
+/* The same construction for PPO's collect_rollouts (SB3 OnPolicyAlgorithm.collect_rollouts, run by utils/algorithms/PPO.py:146;
+ * n_steps rounds of policy.forward -> distribution.sample / log_prob -> env.step -> RolloutBuffer.add): T steps in ONE
+ * persistent launch, a wave owning 16 agents.  Leaves what T rounds of vf_mlp_forward (both heads) + vf_head_sample (Philox
+ * counter sample_step + 1 + t) + vf_env_step + vf_rollout_post_collect leave: the rollout-buffer rows, the compact
+ * TimeLimit-bootstrap list (rows in arbitrary order, as from the per-step calls), the per-agent episode statistics, the
+ * episode outputs of the last step and the slab.  Bit-identical wherever vf_mlp_forward itself runs the 16-rows-per-wave chain
+ * (N <= 16 384); above that the per-step forward is the 32-row chain, whose heads differ from the 16-row chain's in the last
+ * bits (different fp32 summation order inside a dot product; tests/test_ppo_gpu.py bounds it). */
+typedef struct vf_ppo_rollout_args {
+    int32_t T, w1, capacity, pad0;
+    float* obs_state;           /* [T][N][13] RolloutBuffer "state" rows; row 0 = the current observation (caller), row t + 1 by step t */
+    const float* obs_target;    /* [T][N][w1] "target" rows filled by the caller (NavigationEnv: constant), or NULL */
+    const float* obs_target_row;/* (N,w1) the same for the bootstrap list, or NULL */
+    float* obs_final;           /* (N,13) the observation after the last step */
+    float* mean_scratch;        /* [T][N][4] */
+    float* values;              /* [T][N] */
+    float* actions;             /* [T][N][4] */
+    float* log_probs;           /* [T][N] */
+    float* rewards;             /* [T][N] (before the bootstrap scatter) */
+    float* episode_starts;      /* [T][N]: rows 1.. are written (row 0 = the caller's last episode starts) */
+    float* last_starts;         /* (N,) episode starts after the last step */
+    const float* log_std;       /* (4,) */
+    uint64_t noise_key, sample_step;
+    int32_t* cursor;            /* as for vf_rollout_post_collect */
+    int32_t* idx_list;
+    float* rows0;               /* [capacity][13] */
+    float* rows1;               /* [capacity][w1] or NULL */
+    float* stat;                /* (N,4) */
+    const vf_env_out* out;      /* episode outputs; reward / done = N elements of scratch; obs ignored */
+} vf_ppo_rollout_args;
+int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const vf_ppo_rollout_args* a,
+                   vf_stream_t stream);
 
 /* ---- SHAC (utils/algorithms/shac.py:215-278; actor / twin critic of utils/policies/td_policies.py:82-252) -----------------
  * The networks are vf_mlp_desc layer tables like the PPO policy's (actor: two 4-wide heads mu / log_std over one extractor;

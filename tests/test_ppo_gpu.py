@@ -644,6 +644,55 @@ def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
     assert float((bufs[0]["rewards"].abs() > 0).float().mean()) > 0.5
 
 
+@pytest.mark.parametrize("env_name,N", [("NavigationEnv", 3000), ("HoverEnv", 1000), ("NavigationEnv", 16500), ("HoverEnv", 16401)])
+def test_persistent_rollout_equals_the_per_step_loop(env_name, N):
+    """collect_rollouts as ONE launch (vf_ppo_rollout: 16 / 32 agents per wave for all n_steps, the same rows-per-wave chain
+    vf_mlp_forward picks for N rows) leaves the rollout buffer, the TimeLimit list, the episode statistics, the episode
+    outputs and the slab of the launch-by-launch loop, bit for bit -- over two consecutive rollouts with a training pass
+    between them (Philox counters, delay-ring phase and spawn counters carry over)"""
+    import visfly_amd.envs as E
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    res = []
+    for fused in (True, False):
+        kw = {}
+        if env_name == "NavigationEnv":
+            kw["random_kwargs"] = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+        env = getattr(E, env_name)(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=7,
+                                   tensor_output=True, **kw)
+        ppo = PPO(env, n_steps=20, batch_size=N * 20 // (4 if N < 16000 else 20), n_epochs=1, seed=2)
+        ppo.fused_rollout = fused
+        out = {}
+        for rnd in range(2):
+            ppo.collect_rollouts()
+            torch.cuda.synchronize()
+            assert ppo.fused_rollout is fused                 # the kernel was not refused
+            for k in ("rewards", "values", "advantages", "returns", "episode_starts", "log_probs", "actions"):
+                out[f"{rnd}:{k}"] = getattr(ppo.buf, k).clone()
+            for k in ppo.obs_keys:
+                out[f"{rnd}:obs:{k}"] = ppo.buf.obs[k].clone()
+                out[f"{rnd}:last:{k}"] = ppo._last_obs[k].clone()
+            cnt = int(ppo._boot["cursor"].item())
+            order = torch.argsort(ppo._boot["idx"][:cnt])
+            out[f"{rnd}:boot_idx"] = ppo._boot["idx"][:cnt][order].clone()
+            out[f"{rnd}:boot_rows"] = ppo._boot["rows0"][:cnt][order].clone()
+            assert cnt >= N * 2
+            out[f"{rnd}:stat"] = ppo._boot["stat"].clone()
+            sl = env.state_slab                               # padded to whole workgroups; pad agents are nobody's state
+            out[f"{rnd}:slab"] = sl.transpose(-3, -4).reshape(sl.shape[-3], -1, 4)[:, :N].clone()
+            out[f"{rnd}:starts"] = ppo._last_starts.clone()
+            out[f"{rnd}:ep"] = torch.stack([env._ep_return, env._ep_length.float(), env._ep_flags.float()]).clone()
+            out[f"{rnd}:terminal"] = env._terminal_obs.clone()
+            if rnd == 0:
+                ppo.train()
+        out["params"] = ppo.policy.flat.clone()
+        res.append(out)
+        env.close()
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert float((res[0]["1:rewards"].abs() > 0).float().mean()) > 0.5
+
+
 def test_ppo_on_a_host_observation_env_values_its_own_terminal_rows():
     """RacingEnv2 hands the policy 16 gate-relative columns assembled on the host: the TimeLimit bootstrap must value THOSE rows
     (env._terminal_state_rows()), not the kernel's raw 13-column terminal state (the width was hard-coded)"""

@@ -103,6 +103,15 @@ class EnvOut(C.Structure):
                                           "terminal_obs", "gate", "ep_past_gates", "terminal_gate", "done_list", "done_count")]
 
 
+class PpoRolloutArgs(C.Structure):
+    """mirror of vf_ppo_rollout_args"""
+    _fields_ = ([("T", C.c_int32), ("w1", C.c_int32), ("capacity", C.c_int32), ("pad0", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("obs_state", "obs_target", "obs_target_row", "obs_final", "mean_scratch", "values", "actions",
+                                           "log_probs", "rewards", "episode_starts", "last_starts", "log_std")] +
+                [("noise_key", C.c_uint64), ("sample_step", C.c_uint64)] +
+                [(n, C.c_void_p) for n in ("cursor", "idx_list", "rows0", "rows1", "stat", "out")])
+
+
 class EnvRollout(C.Structure):
     """mirror of vf_env_rollout"""
     _fields_ = [("actions", C.c_void_p), ("action_stride", C.c_int64), ("out", EnvOut),
@@ -216,6 +225,7 @@ SIGNATURES = {
     "vf_bptt_reverse": (C.c_int, [_vp, C.POINTER(MlpBwdDesc)] + [_vp] * 5 + [C.c_int64] + [_vp] * 6 + [C.c_int32, _vp]),
     "vf_bptt_rollout": (C.c_int, [_vp, C.POINTER(MlpDesc)] + [_vp] * 7 + [C.POINTER(EnvOut), _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                   C.c_float, C.c_float, C.c_int32, _vp]),
+    "vf_ppo_rollout": (C.c_int, [_vp, C.POINTER(MlpDesc), _vp, _vp, C.POINTER(PpoRolloutArgs), _vp]),
     "vf_dyn_step_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vf_env_ring_phase": (C.c_int32, [_vp]),
     "vf_env_set_ring_phase": (C.c_int, [_vp, C.c_int32]),

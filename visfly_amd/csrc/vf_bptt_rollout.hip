@@ -63,10 +63,14 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
     for (int t = 0; t < r.H; ++t) {
         // ---- policy forward + action head: rows t N + i of the slot buffers, action row of step t ----
         {
-            const int row = t * r.N + i, rc = row, gq = lane >> 4;
+            // (an opaque copy of the lane id per iteration: the chain's per-item load offsets are loop-invariant and would be
+            // hoisted out of the t loop -- dozens of live VGPRs, scratch spills in the two-branch network)
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            const int row = t * r.N + i, rc = row, gq = lane_t >> 4;
             const bool lrow = true;
             ChainState16<Net> st;
-            chain16_prologue<Net, 0>(gc, st, lane);
+            chain16_prologue<Net, 0>(gc, st, lane_t);
 #pragma unroll
             for (int b = 0; b < Net::NB; ++b) {
                 const int w = gc.d.in_dim[b];
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
                     st.x[b][j] = k < w ? v : 0.0f;
                 }
             }
-            chain16_items<Net, 0>(gc, st, lane, row, lrow);
+            chain16_items<Net, 0>(gc, st, lane_t, row, lrow);
         }
         // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
         // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)

@@ -51,6 +51,26 @@ inline bool use_split(int agents_padded, const vf_dyn_cfg& cfg)
 }
 
 #ifdef __HIPCC__
+// ---- Philox4x32-10 counter RNG (on-device spawner, exploration noise of the policy head) ----
+struct U4 {
+    unsigned x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 ctr, unsigned k0, unsigned k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = U4{hi1 ^ ctr.y ^ k0, lo1, hi0 ^ ctr.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f); }
+
 // Pull the whole kernel-argument block into the scalar cache with one batch of loads (24 lines per batch).  The chain kernels
 // take their layer tables by value (1.2 - 2.8 KB of kernel arguments at a fresh address every launch) and the compiler fetches a
 // field where it is first used: k_ppo_update_chain had 314 s_load / 216 s_waitcnt lgkmcnt in its body, ~44 of them first touches
@@ -94,6 +114,7 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
 
 int bwd_chain_policy_class(const vf_mlp_bwd_desc* d);                  // vf_mlp_chain.hip: 0 none, 1 NetHover, 2 NetNav (policy trunk, obs gradient)
 int chain16_policy_class(const vf_mlp_desc* d, const float* params);   // vf_mlp_chain.hip: 0 none, 1 NetHoverPi, 2 NetNavPi
+int chain_full_class(const vf_mlp_desc* d, const float* params, int M);   // 0 none, 1 NetHover, 2 NetNav (both trunks); + 16: M rows run on the 16-row chain
 // reverse chain (data gradients) for the same network classes: 1 launched, 0 no match, < 0 error
 int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp = nullptr);
 int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,

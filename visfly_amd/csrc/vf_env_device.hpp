@@ -6,6 +6,7 @@
 // sqrt(fma(z,z,fma(y,y,x*x))) (4 columns: one more fma), (a*b).sum(dim=1) = (a0*b0 + a1*b1) + a2*b2, python scalars cast
 // to fp32 at the op, `scalar / tensor` = reciprocal(tensor) * scalar.
 #pragma once
+#include "vf_common.hpp"
 #include "vf_dyn_device.hpp"
 
 #pragma clang fp contract(off)
@@ -126,25 +127,8 @@ __device__ __forceinline__ void obs_variant(const vf_env_cfg& e, float* o)
     }
 }
 
-// ---- Philox4x32-10 counter RNG for the on-device spawner ----
-struct U4 {
-    unsigned x, y, z, w;
-};
+// (Philox4x32-10 and u01: vf_common.hpp)
 
-__device__ __forceinline__ U4 philox4x32_10(U4 ctr, unsigned k0, unsigned k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
-        ctr = U4{hi1 ^ ctr.y ^ k0, lo1, hi0 ^ ctr.w ^ k1, lo0};
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return ctr;
-}
-
-__device__ __forceinline__ float u01(unsigned x) { return (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f); }
 
 // sin and cos of one angle with ONE range reduction (Cody-Waite on pi/2, cephes-style minimax polynomials on
 // [-pi/4, pi/4]; ~1 ulp for the |x| < 1e3 a spawn half-angle can take).  The spawner sits on the step's critical path

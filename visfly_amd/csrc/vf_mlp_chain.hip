@@ -24,136 +24,7 @@
 namespace vf {
 
 
-template <class N, int I>
-__device__ __forceinline__ float4 chain_load(const ChainArgs& g, int lane)
-{
-    constexpr int li = N::layer_of(I), local = I - N::first_item(li);
-    constexpr ChainLayer L = N::layer(li);
-    constexpr int G = N::groups(li), gq = local / L.nout, a = local % L.nout;
-    // wave-uniform base (scalar registers) + 32-bit lane offset: no 64-bit VGPR address arithmetic per load
-    const char* base = reinterpret_cast<const char*>(g.packed + g.d.layer[L.desc].wr_off) + (a * G + gq) * 1024;
-    return *reinterpret_cast<const float4*>(base + (unsigned)lane * 16u);
-}
-
-// widths are compile-time (hidden layers: whole tiles; heads: 4 / 1 features in lane half 0, q = 0), so the bias loads
-// and the epilogue carry no guards
-template <class N, int LI>
-__device__ __forceinline__ void chain_bias_load(const ChainArgs& g, ChainState<N>& st, int h)
-{
-    constexpr ChainLayer L = N::layer(LI);
-    const float* b = g.params + g.d.layer[L.desc].b_off;    // b_off is only dword aligned
-    if constexpr (L.desc == N::L_value) {
-        st.bias[0][0] = make_float4(b[0], 0.0f, 0.0f, 0.0f);
-    } else if constexpr (L.desc == N::L_mean) {
-        const f32x4u v = *reinterpret_cast<const f32x4u*>(b);
-        st.bias[0][0] = make_float4(v.x, v.y, v.z, v.w);
-    } else {
-#pragma unroll
-        for (int a = 0; a < L.nout; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4u v = *reinterpret_cast<const f32x4u*>(b + 32 * a + 8 * q + 4 * h);
-                st.bias[a][q] = make_float4(v.x, v.y, v.z, v.w);
-            }
-    }
-}
-
-template <class N, int LI>
-__device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>& st, int row, int h, bool live)
-{
-    constexpr ChainLayer L = N::layer(LI);
-    if constexpr (N::is_head(LI)) {                    // heads: mean (M,4) / value (M,1); only lane half 0 holds them
-        f32x16& y = st.t[L.out0];
-        const float4 bq = st.bias[0][0];
-        y[0] += bq.x; y[1] += bq.y; y[2] += bq.z; y[3] += bq.w;
-        if (live && h == 0) {                          // (the fused PPO kernel keeps the heads in registers: no pointers)
-            if constexpr (L.desc == N::L_mean) {
-                if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
-                if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers
-                    const float4 e = g.rp_eps[row];
-                    g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
-                                                   tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
-                }
-            } else {
-                if (g.io.value) g.io.value[row] = y[0];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int a = 0; a < L.nout; ++a) {
-            f32x16& y = st.t[L.out0 + a];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bq = st.bias[a][q];
-                y[4 * q + 0] += bq.x; y[4 * q + 1] += bq.y; y[4 * q + 2] += bq.z; y[4 * q + 3] += bq.w;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = fmaxf(y[r], 0.0f);
-        }
-    }
-}
-
-// The copies of a layer's output that the backward reads are not stored in the epilogue (a 16 KiB burst per wave, all
-// waves in lock-step, behind which the weight loads of the following items would queue: loads and stores retire in
-// order on gfx9's vmcnt) but trickled out, a float4 or two per item of the NEXT layer in execution order.
-template <class N, int LI, int LOCAL>
-__device__ __forceinline__ void chain_deferred_store(const ChainArgs& g, const ChainState<N>& st, int row, int h, bool live)
-{
-    if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
-        constexpr ChainLayer P = N::layer(LI - 1);
-        constexpr int S = P.nout * 4, per = (S + N::items(LI) - 1) / N::items(LI);
-        constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
-        if constexpr (s0 < s1) {
-            const vf_mlp_layer& D = g.d.layer[P.desc];
-            if (D.save && live) {
-                const unsigned off = (unsigned)row * (unsigned)D.save_ld + 4u * h;     // lane offset, elements
-#pragma unroll
-                for (int i = s0; i < s1; ++i) {
-                    const int a = i / 4, q = i % 4;
-                    const f32x16& y = st.t[P.out0 + a];
-                    float* base = D.save + D.dst_col + 32 * a + 8 * q;               // wave-uniform
-                    *reinterpret_cast<float4*>(base + off) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-                }
-            }
-        }
-    }
-}
-
-template <class N, int I>
-__device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& st, int lane, int row, bool live)
-{
-    if constexpr (I < N::n_items()) {
-        constexpr int li = N::layer_of(I), local = I - N::first_item(li);
-        constexpr ChainLayer L = N::layer(li);
-        constexpr int gq = local / L.nout, a = local % L.nout;
-        const int h = lane >> 5;
-        const float4 w = st.ring[I % kChainDepth];       // the slot being refilled is the one this item consumes: read it first
-        if constexpr (I + kChainDepth < N::n_items()) st.ring[I % kChainDepth] = chain_load<N, I + kChainDepth>(g, lane);
-        if constexpr (local == 0) chain_bias_load<N, li>(g, st, h);
-        f32x16& acc = st.t[L.out0 + a];
-        if constexpr (gq == 0) acc = f32x16{0};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float b;
-            if constexpr (L.obs >= 0) b = st.x[L.obs][4 * gq + j];
-            else b = st.t[L.in0 + gq / 4][4 * (gq % 4) + j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
-        }
-        chain_deferred_store<N, li, local>(g, st, row, h, live);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (local == N::items(li) - 1) chain_epilogue<N, li>(g, st, row, h, live);
-        chain_items<N, I + 1>(g, st, lane, row, live);
-    }
-}
-
-template <class N, int I>
-__device__ __forceinline__ void chain_prologue(const ChainArgs& g, ChainState<N>& st, int lane)
-{
-    if constexpr (I < kChainDepth && I < N::n_items()) {
-        st.ring[I] = chain_load<N, I>(g, lane);
-        chain_prologue<N, I + 1>(g, st, lane);
-    }
-}
+// (the 32-row forward's device code -- chain_load .. chain_prologue -- lives in vf_mlp_chain.hpp: vf_ppo_rollout.hip runs it too)
 
 template <class N>
 __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
@@ -496,6 +367,17 @@ int chain16_policy_class(const vf_mlp_desc* d, const float* params)
     if (off) return 0;
     if (chain_matches<NetHoverPi>(*d) && chain16_ok<NetHoverPi>(*d, params, 1)) return 1;
     if (chain_matches<NetNavPi>(*d) && chain16_ok<NetNavPi>(*d, params, 1)) return 2;
+    return 0;
+}
+
+// the actor-critic class of a layer table run on M rows (vf_ppo_rollout.hip): 0 none, 1 NetHover, 2 NetNav; + 16 when
+// vf_mlp_forward would run those M rows on the 16-rows-per-wave chain
+int chain_full_class(const vf_mlp_desc* d, const float* params, int M)
+{
+    static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
+    if (off) return 0;
+    if (chain_matches<NetHover>(*d)) return 1 + (chain16_ok<NetHover>(*d, params, M) ? 16 : 0);
+    if (chain_matches<NetNav>(*d)) return 2 + (chain16_ok<NetNav>(*d, params, M) ? 16 : 0);
     return 0;
 }
 

@@ -1066,27 +1066,9 @@ __global__ __launch_bounds__(kBlock) void k_head_sample(const float4* __restrict
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= M) return;
-    const float4 m4 = mean[i];
-    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
-    const float ls[4] = {log_std[0], log_std[1], log_std[2], log_std[3]};
-    float a[4];
-    if (deterministic) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) a[d] = tanhf(mu[d]);
-    } else {
-        const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)step, (unsigned)(step >> 32), 0xac7u}, (unsigned)seed,
-                                   (unsigned)(seed >> 32));
-        const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
-        const float u3 = ((float)(r.z >> 8) + 1.0f) * (1.0f / 16777216.0f), u4 = (float)(r.w >> 8) * (1.0f / 16777216.0f);
-        const float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
-        const float two_pi = 6.28318530717958647692f;
-        const float e[4] = {ra * cosf(two_pi * u2), ra * sinf(two_pi * u2), rb * cosf(two_pi * u4), rb * sinf(two_pi * u4)};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) a[d] = tanhf(mu[d] + expf(ls[d]) * e[d]);
-    }
-    float g[4];
-    logp[i] = squashed_log_prob(mu, ls, a, g);
-    action[i] = make_float4(a[0], a[1], a[2], a[3]);
+    float4 a;
+    logp[i] = head_sample_row(mean[i], log_std, i, seed, step, deterministic, a);
+    action[i] = a;
 }
 
 // PPO clipped surrogate + value MSE + "entropy" (= mean log-prob for the squashed head), PPO.py:210-263

@@ -30,6 +30,35 @@ __device__ __forceinline__ float squashed_log_prob(const float* mu, const float*
     return lp;
 }
 
+// Squashed diagonal Gaussian head for row i (policies.py:177-181, SB3 SquashedDiagGaussianDistribution): action = tanh(mean +
+// exp(log_std) eps), eps = Box-Muller over Philox(row, step; seed); -> log-prob of the action.  k_head_sample (vf_ppo.hip) and
+// the persistent PPO roll-out (vf_bptt_rollout.hip) share it.
+__device__ __forceinline__ float head_sample_row(const float4 m4, const float* __restrict__ log_std, int i, unsigned long long seed,
+                                                 unsigned long long step, int deterministic, float4& action)
+{
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+    const float ls[4] = {log_std[0], log_std[1], log_std[2], log_std[3]};
+    float a[4];
+    if (deterministic) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) a[d] = tanhf(mu[d]);
+    } else {
+        const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)step, (unsigned)(step >> 32), 0xac7u}, (unsigned)seed,
+                                   (unsigned)(seed >> 32));
+        const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+        const float u3 = ((float)(r.z >> 8) + 1.0f) * (1.0f / 16777216.0f), u4 = (float)(r.w >> 8) * (1.0f / 16777216.0f);
+        const float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+        const float two_pi = 6.28318530717958647692f;
+        const float e[4] = {ra * cosf(two_pi * u2), ra * sinf(two_pi * u2), rb * cosf(two_pi * u4), rb * sinf(two_pi * u4)};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) a[d] = tanhf(mu[d] + expf(ls[d]) * e[d]);
+    }
+    float g[4];
+    const float lp = squashed_log_prob(mu, ls, a, g);
+    action = make_float4(a[0], a[1], a[2], a[3]);
+    return lp;
+}
+
 // one row of the clipped-surrogate loss: gradients w.r.t. the head outputs and the 9 statistics
 // st = {policy loss, value loss, log prob, approx kl, clipped?, d_log_std[4]}
 // `row`: index of this row in the call's arrays (for cfg.old_value)

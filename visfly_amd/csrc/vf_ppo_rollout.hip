@@ -1,0 +1,227 @@
+// vf_ppo_rollout.hip -- PPO's collect_rollouts as ONE persistent launch (gfx950).
+//
+// SB3 OnPolicyAlgorithm.collect_rollouts (run by utils/algorithms/PPO.py:146) is the closed loop policy.forward(obs_t) ->
+// distribution.sample / log_prob -> env.step -> RolloutBuffer.add, n_steps times.  Launch by launch that is, per control step
+// at 32 768 agents: the register-chained forward (30 us), the head sampler (5 us), two observation copies (2 x 5 us), the env
+// step (11 us) and the TimeLimit bookkeeping (4 us) -- 60 us, of which the launch boundaries and the cold first touches of
+// every launch are a third (profiles/r03_ppo_kernel_stats.txt).  Here, as in vf_bptt_rollout.hip, a wave owns its agents for
+// all n_steps:
+//   * ROWS = 32 agents per wave with the 32-row chain (v_mfma_f32_32x32x2_f32) or 16 with the 16-row chain -- the SAME choice
+//     vf_mlp_forward makes from the row count (chain16_ok), so heads, values, actions and log-probs are the per-step path's
+//     to the bit.  Lanes ROWS..63 replicate lane & (ROWS - 1) outside the chain (k_bptt_rollout's construction);
+//   * the head outputs go through one 16-byte scratch row per agent (the accumulator lane that holds them is not the lane that
+//     steps the agent), everything else of the step stays in registers: the sampled action feeds the env step directly, the
+//     reward / done of the epilogue feed the buffer rows and the TimeLimit list;
+//   * the observation row of step t + 1 is written by step t's epilogue straight into RolloutBuffer.obs["state"][t + 1].
+#include "vf_env_epilogue.hpp"
+#include "vf_mlp_chain.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vf {
+
+struct PpoRollArgs {
+    int T, N;
+    float* mean_scratch;            // [T][N][4]
+    float4* actions;                // [T][N]
+    float* log_probs;               // [T][N]
+    float* rewards;                 // [T][N]
+    float* episode_starts;          // [T][N]; row 0 is filled by the caller
+    float* last_starts;             // (N,): episode_starts of the step after the last one
+    float* obs_slots;               // [T][N][13] = RolloutBuffer.obs["state"]
+    float* obs_final;               // (N,13)
+    const float* log_std;
+    unsigned long long noise_key, sample_step;      // step t samples with Philox counter sample_step + 1 + t (k_head_sample)
+    // deferred TimeLimit bootstrap list + per-agent episode statistics (k_rollout_post_collect)
+    const float* obs1;              // (N,w1) constant "target" rows or null
+    int w1, capacity;
+    int* cursor;
+    int* idx_list;
+    float* rows0;                   // [capacity][13]
+    float* rows1;                   // [capacity][w1]
+    float* stat;                    // (N,4)
+};
+
+// one forward of rows `row` (lane & (ROWS - 1) of the wave): mean -> g.io.mean, value -> g.io.value
+template <class Net, int ROWS>
+__device__ __forceinline__ void policy_rows(const ChainArgs& gc, int lane, int row)
+{
+    if constexpr (ROWS == 16) {
+        const int gq = lane >> 4;
+        ChainState16<Net> st;
+        chain16_prologue<Net, 0>(gc, st, lane);
+#pragma unroll
+        for (int b = 0; b < Net::NB; ++b) {
+            const int w = gc.d.in_dim[b];
+            const float* x = gc.io.in[b] + (size_t)row * w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * gq + j;
+                const float v = x[k < w ? k : w - 1];
+                st.x[b][j] = k < w ? v : 0.0f;
+            }
+        }
+        chain16_items<Net, 0>(gc, st, lane, row, true);
+    } else {
+        const int h = lane >> 5;
+        ChainState<Net> st;
+        chain_prologue<Net, 0>(gc, st, lane);
+#pragma unroll
+        for (int b = 0; b < Net::NB; ++b) {
+            const int w = gc.d.in_dim[b];
+            const float* x = gc.io.in[b] + (size_t)row * w;
+#pragma unroll
+            for (int s = 0; s < Net::kin(b) / 2; ++s) {
+                const int k = 2 * s + h;
+                const float v = x[k < w ? k : w - 1];
+                st.x[b][s] = k < w ? v : 0.0f;
+            }
+        }
+        chain_items<Net, 0>(gc, st, lane, row, true);
+    }
+}
+
+template <class Net, int ROWS, int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs ge,
+                                                    const ChainArgs gc, const PpoRollArgs r)
+{
+    prefetch_kernarg<sizeof(EnvArgs) + sizeof(ChainArgs) + sizeof(PpoRollArgs) + 16>();
+    const vf_dyn_cfg& c = *cp;
+    const vf_env_cfg& e = *ep;
+    __shared__ __attribute__((aligned(16))) float tile[64 * 13];
+    const int lane = threadIdx.x, m = lane & (ROWS - 1);
+    const int wave_first = blockIdx.x * ROWS;
+    // lanes ROWS..63 and the lanes past the last agent are REPLICAS of a live lane (same index, loads, arithmetic, stores of the
+    // same values); what must happen once per agent -- the read-modify-write of the statistics, the list append -- is the owner's
+    const int i = min(wave_first + m, r.N - 1);
+    const bool owner = lane < ROWS && wave_first + lane < r.N;
+    EnvArgs g = ge;
+    g.d.N = min(r.N, wave_first + ROWS);                  // the wave's observation tile holds ROWS rows
+    Agent s;
+    Spares sp;
+    load_agent<true>(g.d.S, g.d.G, i, s, sp);
+    load_wind(c, g.d, i, true, s);
+    const int Gx = g.d.G;
+    for (int t = 0; t < r.T; ++t) {
+        const int row = t * r.N + i;
+        // the chain's per-item load offsets (lane * 16 + item * 1 KiB) are loop-invariant: hoisted out of the t loop they are
+        // ~100 live VGPRs and 1.1 KB of scratch per lane.  An opaque copy of the lane id per iteration keeps them just-in-time
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        policy_rows<Net, ROWS>(gc, lane_t, row);
+        // the head row another lane of this wave just wrote (program order through the one TCP; workgroup scope = s_waitcnt)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        float4 act;
+        const float lp = head_sample_row(*reinterpret_cast<const float4*>(r.mean_scratch + (size_t)row * 4), r.log_std, i, r.noise_key,
+                                         r.sample_step + 1ull + (unsigned long long)t, 0, act);
+        r.actions[row] = act;
+        r.log_probs[row] = lp;
+        // ---- env step (k_env_rollout's body; ring_exchange with the action already in registers) ----
+        float a[4];
+        {
+            float4 an = act;
+            if (c.delay_steps > 0) {
+                const int head = g.d.head;
+                float4* slot = granule(g.d.S, Gx, i, VF_G_RING + head);
+                const float4 old = *slot;
+                st4(slot, an);
+                an = old;
+                sp.vel = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
+            }
+            a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
+        }
+        float kl[3], kq[3];
+        drag_of(c, g.d, i, kl, kq);
+        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
+        float reward = 0.0f;
+        bool done = false;
+        env_epilogue<KIND, false>(c, e, g, i, true, s, sp, wave_first, tile, &reward, &done);
+        // ---- RolloutBuffer.add + the TimeLimit bookkeeping (k_rollout_post_collect) ----
+        r.rewards[row] = reward;
+        (t + 1 < r.T ? r.episode_starts + (size_t)(t + 1) * r.N : r.last_starts)[i] = done ? 1.0f : 0.0f;
+        if (done && owner) {
+            // ep_return / ep_length / ep_flags / terminal row: this lane's own stores of the epilogue
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            const unsigned char fl = g.out.ep_flags[i];
+            float4* sa = reinterpret_cast<float4*>(r.stat) + i;
+            float4 v = *sa;
+            v.x += 1.0f;
+            v.y += g.out.ep_return[i];
+            v.z += (float)g.out.ep_length[i];
+            v.w += (fl & VF_EP_SUCCESS) ? 1.0f : 0.0f;
+            *sa = v;
+            if (fl & VF_EP_TRUNCATED) {
+                const int slot = atomicAdd(r.cursor, 1);
+                if (slot < r.capacity) {
+                    r.idx_list[slot] = row;
+                    const float* to = g.out.terminal_obs + 13 * (size_t)i;
+                    for (int k = 0; k < 13; ++k) r.rows0[(size_t)slot * 13 + k] = to[k];
+                    for (int k = 0; k < r.w1; ++k) r.rows1[(size_t)slot * r.w1 + k] = r.obs1[(size_t)i * r.w1 + k];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the observation rows of slot t + 1 are read by the next forward
+        g.out.obs = t + 2 < r.T ? r.obs_slots + (size_t)(t + 2) * r.N * 13 : r.obs_final;
+        g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
+    }
+    store_agent(g.d.S, Gx, i, s, sp);
+}
+
+}  // namespace vf
+
+namespace {
+
+using PpoRollKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvArgs, const vf::ChainArgs, const vf::PpoRollArgs);
+
+template <class Net, int ROWS, int KIND>
+PpoRollKernel pick_ppo_roll(const vf_dyn_cfg& c)
+{
+    if (c.integrator != VF_INT_EULER || !c.ctrl_delay) return nullptr;
+    if (c.action_type == VF_ACT_THRUST) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const vf_ppo_rollout_args* a,
+                              vf_stream_t stream)
+{
+    if (!h || !desc || !params || !packed || !a || !a->out || !a->obs_state || !a->values || !a->actions || !a->log_probs || !a->rewards ||
+        !a->episode_starts || !a->last_starts || !a->obs_final || !a->mean_scratch || !a->log_std || !a->cursor || !a->idx_list || !a->rows0 ||
+        !a->stat || a->T <= 0 || a->w1 < 0 || (a->w1 > 0 && (!a->rows1 || !a->obs_target_row)))
+        return vf::fail(VF_EINVAL, "vf_ppo_rollout: bad argument");
+    const vf_env_out* out = a->out;
+    if (!out->reward || !out->done || !out->ep_return || !out->ep_length || !out->ep_flags || !out->terminal_obs)
+        return vf::fail(VF_EINVAL, "vf_ppo_rollout: out needs reward / done scratch and the episode outputs");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_ppo_rollout: vf_env_bind has not been called");
+    if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: per-agent wind rows are set");
+    if (h->cfg.obs_mode != VF_OBS_STATE) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: raw-state observation only");
+    if ((reinterpret_cast<uintptr_t>(a->mean_scratch) | reinterpret_cast<uintptr_t>(a->actions) | reinterpret_cast<uintptr_t>(a->stat)) & 15)
+        return vf::fail(VF_EINVAL, "vf_ppo_rollout: mean_scratch / actions / stat must be 16-byte aligned");
+    const int N = h->dyn.N, T = a->T;
+    // the rows-per-wave choice of vf_mlp_forward for N rows (chain16_ok), so that the heads are the per-step path's to the bit
+    const int cls = vf::chain_full_class(desc, params, N);        // 0 none; 1 NetHover, 2 NetNav; + 16 when the 16-row chain runs N rows
+    const bool r16 = (cls & 16) != 0;
+    PpoRollKernel k = nullptr;
+    if ((cls & 15) == 1 && h->cfg.kind == VF_ENV_HOVER)
+        k = r16 ? pick_ppo_roll<vf::NetHover, 16, VF_ENV_HOVER>(h->dyn.cfg) : pick_ppo_roll<vf::NetHover, 32, VF_ENV_HOVER>(h->dyn.cfg);
+    else if ((cls & 15) == 2 && h->cfg.kind == VF_ENV_NAV && a->obs_target)
+        k = r16 ? pick_ppo_roll<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_ppo_roll<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg);
+    if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: no persistent roll-out for this network class / env kind / dynamics "
+                                             "configuration ([128, 64] x [64, 64] actor-critic, Hover / Navigation, thrust / bodyrate, Euler, ctrl_delay)");
+    const int rows = r16 ? 16 : 32;
+    vf::EnvArgs ge{vf::DynArgs{N, h->dyn.G, h->dyn.g_drag, h->dyn.S, nullptr, nullptr, vf::ring_head(&h->dyn), nullptr, h->dyn.vel_strided},
+                   *out, h->g_race, 1};
+    ge.out.done_list = ge.out.done_count = nullptr;
+    ge.out.obs = T > 1 ? a->obs_state + (size_t)N * 13 : a->obs_final;
+    vf::ChainArgs gc{*desc, params, packed, vf::ChainIo{{a->obs_state, a->obs_target}, a->mean_scratch, a->values}, T * N, nullptr, nullptr, nullptr,
+                     {nullptr, nullptr}};
+    vf::PpoRollArgs r{T, N, a->mean_scratch, reinterpret_cast<float4*>(a->actions), a->log_probs, a->rewards, a->episode_starts, a->last_starts,
+                      a->obs_state, a->obs_final, a->log_std, a->noise_key, a->sample_step, a->obs_target_row, a->w1, a->capacity, a->cursor,
+                      a->idx_list, a->rows0, a->rows1, a->stat};
+    hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
+    VF_HIP(hipGetLastError());
+    h->dyn.tick += T;
+    return VF_OK;
+}

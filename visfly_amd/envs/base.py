@@ -875,6 +875,58 @@ class DroneGymEnvsBase:
         policy._last_M, policy._last_slot = N, H - 1
         return True
 
+    def collect_policy(self, policy, obs_keys, buf, boot, noise_key, sample_step, last_starts):
+        """T = buf.actions.shape[0] rounds of PPO's collect_rollouts loop -- policy.forward (both heads), squashed-Gaussian
+        sample + log-prob (Philox counters sample_step + 1 ..), env.step, RolloutBuffer rows, TimeLimit list / episode
+        statistics -- in ONE persistent launch (vf_ppo_rollout).  buf.obs["state"][0] (and every row of buf.obs["target"])
+        and buf.episode_starts[0] are the caller's.  -> the final observation TensorDict, or False when the library has no
+        roll-out kernel for this env / network / dynamics configuration (the caller then steps launch by launch)."""
+        if (self._tape is not None or self.spawn_mode != "device" or self._imu_noise is not None or self._half_step
+                or self.envs.dynamics._wind_fn is not None or getattr(self, "_HOST_OBS", False) or not self.tensor_output
+                or getattr(self, "obs_gate_exact", False) or not self._STATIC_OBS_CONST
+                or self._terminal_state_rows() is not self._terminal_obs
+                or any(k not in ("state", "target") for k in obs_keys) or policy._plan is None or not policy.fused):
+            return False
+        assert self._is_initial, "You should call reset() before step()"
+        T, N, dev = buf.actions.shape[0], self.num_agent, self.device
+        b0 = policy._buffers(N, 0)
+        key = (N, 0, False)
+        d = policy._descs.get(key)
+        if d is None:
+            d = policy._descs[key] = policy._fused_desc(b0, False)
+        policy._pack()
+        sc = getattr(self, "_collect_scratch", None)
+        if sc is None or sc["mean"].shape[0] != T:
+            sc = self._collect_scratch = {"mean": th.empty((T, N, 4), dtype=th.float32, device=dev),
+                                          "reward": th.empty(N, dtype=th.float32, device=dev),
+                                          "done": th.empty(N, dtype=th.bool, device=dev),
+                                          "state": th.empty((N, 13), dtype=th.float32, device=dev)}
+            sc["out"] = self._out(sc["state"], sc["reward"], sc["done"])
+        final = th.empty((N, 13), dtype=th.float32, device=dev)
+        o1 = buf.obs["target"] if "target" in obs_keys else None
+        a = _lib.PpoRolloutArgs()
+        a.T, a.w1, a.capacity = T, 0 if o1 is None else o1.shape[-1], boot["cap"]
+        a.obs_state, a.obs_target = _lib.ptr(buf.obs["state"]), _lib.ptr(o1)
+        a.obs_target_row = None if o1 is None else _lib.ptr(o1[0])
+        a.obs_final, a.mean_scratch, a.values = _lib.ptr(final), _lib.ptr(sc["mean"]), _lib.ptr(buf.values)
+        a.actions, a.log_probs, a.rewards = _lib.ptr(buf.actions), _lib.ptr(buf.log_probs), _lib.ptr(buf.rewards)
+        a.episode_starts, a.last_starts, a.log_std = _lib.ptr(buf.episode_starts), _lib.ptr(last_starts), _lib.ptr(policy.log_std)
+        a.noise_key, a.sample_step = noise_key, sample_step
+        a.cursor, a.idx_list, a.rows0 = boot["cursor"].data_ptr(), boot["idx"].data_ptr(), _lib.ptr(boot["rows0"])
+        a.rows1, a.stat = _lib.ptr(boot["rows1"]), _lib.ptr(boot["stat"])
+        a.out = C.addressof(sc["out"])
+        with th.cuda.device(dev):
+            rc = _lib.lib().vf_ppo_rollout(self._h, C.byref(d), _lib.ptr(policy.flat), _lib.ptr(policy._packed), C.byref(a), self._stream())
+        if rc == _lib.EUNSUPPORTED:
+            return False
+        if rc:
+            _lib.check(rc)
+        self._qcache = self._imu_cache = self._ext_col = None
+        self._action = buf.actions[T - 1]
+        self._reward, self._done = sc["reward"], sc["done"]
+        self._observations = obs = self._full_obs(final)
+        return obs
+
     def reverse_policy(self, policy, H, eps, actions, d_reward, d_means, g_log_std):
         """the reverse half of the last H recorded steps in ONE persistent launch (vf_bptt_reverse): for t = H-1 .. 0 the adjoint of
         env step t and the policy's action-head reverse + reverse chain of slot t.  -> False when the library has no kernel for

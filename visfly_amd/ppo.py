@@ -751,6 +751,7 @@ class PPO:
         # TimeLimit bootstrap valued once per rollout (collect_rollouts) from the terminal rows the step kernel wrote; envs that
         # assemble their observation on the host (RacingEnv2: 16 gate-relative columns) have no such kernel rows -> valued per step
         self.defer_bootstrap, self._boot = not getattr(env, "_HOST_OBS", False), None
+        self.fused_rollout = True           # collect_rollouts as one persistent launch where the library has the kernel (vf_ppo_rollout)
         self._last_obs = None
         if not getattr(env, "_is_initial", False):
             self._last_obs = env.reset()
@@ -853,7 +854,21 @@ class PPO:
         L, pol, N = _lib.lib(), self.policy, self.n_envs
         buf.episode_starts[0].copy_(self._last_starts)
         bs = self._bootstrap_list() if self.defer_bootstrap else None
-        for t in range(self.n_steps):
+        fused = False
+        if self.fused_rollout and self.defer_bootstrap and hasattr(env, "collect_policy"):
+            # the whole loop below as one persistent launch (vf_ppo_rollout); same buffer rows, same Philox counters
+            for k in self.obs_keys:
+                if k == "state":
+                    buf.obs[k][0].copy_(obs[k])
+                else:
+                    buf.obs[k].copy_(obs[k].unsqueeze(0).expand_as(buf.obs[k]))        # constant per env ("target")
+            fused = env.collect_policy(pol, self.obs_keys, buf, bs, self._noise_key, self._sample_step, self._last_starts)
+            if fused is not False:
+                obs = fused
+                self._sample_step += self.n_steps
+            else:
+                self.fused_rollout = False
+        for t in range(self.n_steps if fused is False else 0):
             # policy.forward (policies.py:195-226) straight into row t of the buffer: value head, sampled action, log-prob
             action, logp = buf.actions[t], buf.log_probs[t]
             mean, _ = pol.forward({k: obs[k] for k in self.obs_keys}, save_activations=False, out_value=buf.values[t])
