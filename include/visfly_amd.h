@@ -764,7 +764,7 @@ typedef struct vf_ppo_rollout_args {
     const float* obs_target;    /* [T][N][w1] "target" rows filled by the caller (NavigationEnv: constant), or NULL */
     const float* obs_target_row;/* (N,w1) the same for the bootstrap list, or NULL */
     float* obs_final;           /* (N,13) the observation after the last step */
-    float* mean_scratch;        /* [T][N][4] */
+    float* means;               /* [T][N][4] the head means (what the per-step vf_mlp_forward leaves), or NULL */
     float* values;              /* [T][N] */
     float* actions;             /* [T][N][4] */
     float* log_probs;           /* [T][N] */

@@ -106,7 +106,7 @@ class EnvOut(C.Structure):
 class PpoRolloutArgs(C.Structure):
     """mirror of vf_ppo_rollout_args"""
     _fields_ = ([("T", C.c_int32), ("w1", C.c_int32), ("capacity", C.c_int32), ("pad0", C.c_int32)] +
-                [(n, C.c_void_p) for n in ("obs_state", "obs_target", "obs_target_row", "obs_final", "mean_scratch", "values", "actions",
+                [(n, C.c_void_p) for n in ("obs_state", "obs_target", "obs_target_row", "obs_final", "means", "values", "actions",
                                            "log_probs", "rewards", "episode_starts", "last_starts", "log_std")] +
                 [("noise_key", C.c_uint64), ("sample_step", C.c_uint64)] +
                 [(n, C.c_void_p) for n in ("cursor", "idx_list", "rows0", "rows1", "stat", "out")])

@@ -9,10 +9,10 @@
 //   * ROWS = 32 agents per wave with the 32-row chain (v_mfma_f32_32x32x2_f32) or 16 with the 16-row chain -- the SAME choice
 //     vf_mlp_forward makes from the row count (chain16_ok), so heads, values, actions and log-probs are the per-step path's
 //     to the bit.  Lanes ROWS..63 replicate lane & (ROWS - 1) outside the chain (k_bptt_rollout's construction);
-//   * the head outputs go through one 16-byte scratch row per agent (the accumulator lane that holds them is not the lane that
-//     steps the agent), everything else of the step stays in registers: the sampled action feeds the env step directly, the
-//     reward / done of the epilogue feed the buffer rows and the TimeLimit list;
-//   * the observation row of step t + 1 is written by step t's epilogue straight into RolloutBuffer.obs["state"][t + 1].
+//   * nothing of a step travels through memory: the accumulator lane that holds the heads of row m IS lane m (replicas take
+//     them by ds_bpermute), the sampled action feeds the env step in registers, the reward / done of the epilogue feed the buffer
+//     rows and the TimeLimit list, and the next forward reads its "state" row from the LDS tile the epilogue staged it through
+//     on its way to RolloutBuffer.obs["state"][t + 1].  Global memory sees only the buffer rows, written once, never re-read.
 #include "vf_env_epilogue.hpp"
 #include "vf_mlp_chain.hpp"
 
@@ -22,7 +22,6 @@ namespace vf {
 
 struct PpoRollArgs {
     int T, N;
-    float* mean_scratch;            // [T][N][4]
     float4* actions;                // [T][N]
     float* log_probs;               // [T][N]
     float* rewards;                 // [T][N]
@@ -42,10 +41,13 @@ struct PpoRollArgs {
     float* stat;                    // (N,4)
 };
 
-// one forward of rows `row` (lane & (ROWS - 1) of the wave): mean -> g.io.mean, value -> g.io.value
+// one forward of rows `row` (lane & (ROWS - 1) of the wave): value -> g.io.value; -> the mean row, valid in the lanes < ROWS
+// (the accumulator lanes of group 0 hold heads of their own row: chain_epilogue / chain16_epilogue).  The "state" row comes from
+// the wave's LDS tile (13 floats per agent, where the env epilogue of the previous step left it), other branches from memory.
 template <class Net, int ROWS>
-__device__ __forceinline__ void policy_rows(const ChainArgs& gc, int lane, int row)
+__device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int row, const float* tile)
 {
+    const int m = lane & (ROWS - 1);
     if constexpr (ROWS == 16) {
         const int gq = lane >> 4;
         ChainState16<Net> st;
@@ -53,7 +55,7 @@ __device__ __forceinline__ void policy_rows(const ChainArgs& gc, int lane, int r
 #pragma unroll
         for (int b = 0; b < Net::NB; ++b) {
             const int w = gc.d.in_dim[b];
-            const float* x = gc.io.in[b] + (size_t)row * w;
+            const float* x = b == 0 ? tile + m * 13 : gc.io.in[b] + (size_t)row * w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * gq + j;
@@ -62,6 +64,8 @@ __device__ __forceinline__ void policy_rows(const ChainArgs& gc, int lane, int r
             }
         }
         chain16_items<Net, 0>(gc, st, lane, row, true);
+        const f32x4& y = st.t[2 * Net::t_mean];
+        return make_float4(y[0], y[1], y[2], y[3]);
     } else {
         const int h = lane >> 5;
         ChainState<Net> st;
@@ -69,7 +73,7 @@ __device__ __forceinline__ void policy_rows(const ChainArgs& gc, int lane, int r
 #pragma unroll
         for (int b = 0; b < Net::NB; ++b) {
             const int w = gc.d.in_dim[b];
-            const float* x = gc.io.in[b] + (size_t)row * w;
+            const float* x = b == 0 ? tile + m * 13 : gc.io.in[b] + (size_t)row * w;
 #pragma unroll
             for (int s = 0; s < Net::kin(b) / 2; ++s) {
                 const int k = 2 * s + h;
@@ -78,6 +82,8 @@ __device__ __forceinline__ void policy_rows(const ChainArgs& gc, int lane, int r
             }
         }
         chain_items<Net, 0>(gc, st, lane, row, true);
+        const f32x16& y = st.t[Net::t_mean];
+        return make_float4(y[0], y[1], y[2], y[3]);
     }
 }
 
@@ -102,18 +108,22 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
     load_agent<true>(g.d.S, g.d.G, i, s, sp);
     load_wind(c, g.d, i, true, s);
     const int Gx = g.d.G;
+    // the wave's observation tile: row l = the "state" observation of lane l's agent.  The env epilogue of step t leaves the rows
+    // of step t + 1 there (store_rows_coalesced stages them through it on their way to RolloutBuffer.obs[t + 1]); step 0's come
+    // from the caller's row 0.  One wave's LDS operations execute in order: no barrier.
+    for (int k = 0; k < 13; ++k) tile[lane * 13 + k] = r.obs_slots[(size_t)i * 13 + k];
+    __builtin_amdgcn_wave_barrier();
     for (int t = 0; t < r.T; ++t) {
         const int row = t * r.N + i;
         // the chain's per-item load offsets (lane * 16 + item * 1 KiB) are loop-invariant: hoisted out of the t loop they are
         // ~100 live VGPRs and 1.1 KB of scratch per lane.  An opaque copy of the lane id per iteration keeps them just-in-time
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
-        policy_rows<Net, ROWS>(gc, lane_t, row);
-        // the head row another lane of this wave just wrote (program order through the one TCP; workgroup scope = s_waitcnt)
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        float4 mean = policy_rows<Net, ROWS>(gc, lane_t, row, tile);
+        // lane m < ROWS holds the head of its own agent; the replica lanes take it from there
+        mean.x = __shfl(mean.x, m); mean.y = __shfl(mean.y, m); mean.z = __shfl(mean.z, m); mean.w = __shfl(mean.w, m);
         float4 act;
-        const float lp = head_sample_row(*reinterpret_cast<const float4*>(r.mean_scratch + (size_t)row * 4), r.log_std, i, r.noise_key,
-                                         r.sample_step + 1ull + (unsigned long long)t, 0, act);
+        const float lp = head_sample_row(mean, r.log_std, i, r.noise_key, r.sample_step + 1ull + (unsigned long long)t, 0, act);
         r.actions[row] = act;
         r.log_probs[row] = lp;
         // ---- env step (k_env_rollout's body; ring_exchange with the action already in registers) ----
@@ -160,7 +170,6 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the observation rows of slot t + 1 are read by the next forward
         g.out.obs = t + 2 < r.T ? r.obs_slots + (size_t)(t + 2) * r.N * 13 : r.obs_final;
         g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
     }
@@ -188,7 +197,7 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
                               vf_stream_t stream)
 {
     if (!h || !desc || !params || !packed || !a || !a->out || !a->obs_state || !a->values || !a->actions || !a->log_probs || !a->rewards ||
-        !a->episode_starts || !a->last_starts || !a->obs_final || !a->mean_scratch || !a->log_std || !a->cursor || !a->idx_list || !a->rows0 ||
+        !a->episode_starts || !a->last_starts || !a->obs_final || !a->log_std || !a->cursor || !a->idx_list || !a->rows0 ||
         !a->stat || a->T <= 0 || a->w1 < 0 || (a->w1 > 0 && (!a->rows1 || !a->obs_target_row)))
         return vf::fail(VF_EINVAL, "vf_ppo_rollout: bad argument");
     const vf_env_out* out = a->out;
@@ -197,8 +206,8 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
     if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_ppo_rollout: vf_env_bind has not been called");
     if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: per-agent wind rows are set");
     if (h->cfg.obs_mode != VF_OBS_STATE) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: raw-state observation only");
-    if ((reinterpret_cast<uintptr_t>(a->mean_scratch) | reinterpret_cast<uintptr_t>(a->actions) | reinterpret_cast<uintptr_t>(a->stat)) & 15)
-        return vf::fail(VF_EINVAL, "vf_ppo_rollout: mean_scratch / actions / stat must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(a->means) | reinterpret_cast<uintptr_t>(a->actions) | reinterpret_cast<uintptr_t>(a->stat)) & 15)
+        return vf::fail(VF_EINVAL, "vf_ppo_rollout: means / actions / stat must be 16-byte aligned");
     const int N = h->dyn.N, T = a->T;
     // the rows-per-wave choice of vf_mlp_forward for N rows (chain16_ok), so that the heads are the per-step path's to the bit
     const int cls = vf::chain_full_class(desc, params, N);        // 0 none; 1 NetHover, 2 NetNav; + 16 when the 16-row chain runs N rows
@@ -215,9 +224,9 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
                    *out, h->g_race, 1};
     ge.out.done_list = ge.out.done_count = nullptr;
     ge.out.obs = T > 1 ? a->obs_state + (size_t)N * 13 : a->obs_final;
-    vf::ChainArgs gc{*desc, params, packed, vf::ChainIo{{a->obs_state, a->obs_target}, a->mean_scratch, a->values}, T * N, nullptr, nullptr, nullptr,
+    vf::ChainArgs gc{*desc, params, packed, vf::ChainIo{{a->obs_state, a->obs_target}, a->means, a->values}, T * N, nullptr, nullptr, nullptr,
                      {nullptr, nullptr}};
-    vf::PpoRollArgs r{T, N, a->mean_scratch, reinterpret_cast<float4*>(a->actions), a->log_probs, a->rewards, a->episode_starts, a->last_starts,
+    vf::PpoRollArgs r{T, N, reinterpret_cast<float4*>(a->actions), a->log_probs, a->rewards, a->episode_starts, a->last_starts,
                       a->obs_state, a->obs_final, a->log_std, a->noise_key, a->sample_step, a->obs_target_row, a->w1, a->capacity, a->cursor,
                       a->idx_list, a->rows0, a->rows1, a->stat};
     hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);

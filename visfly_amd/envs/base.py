@@ -896,9 +896,8 @@ class DroneGymEnvsBase:
             d = policy._descs[key] = policy._fused_desc(b0, False)
         policy._pack()
         sc = getattr(self, "_collect_scratch", None)
-        if sc is None or sc["mean"].shape[0] != T:
-            sc = self._collect_scratch = {"mean": th.empty((T, N, 4), dtype=th.float32, device=dev),
-                                          "reward": th.empty(N, dtype=th.float32, device=dev),
+        if sc is None:
+            sc = self._collect_scratch = {"reward": th.empty(N, dtype=th.float32, device=dev),
                                           "done": th.empty(N, dtype=th.bool, device=dev),
                                           "state": th.empty((N, 13), dtype=th.float32, device=dev)}
             sc["out"] = self._out(sc["state"], sc["reward"], sc["done"])
@@ -908,7 +907,7 @@ class DroneGymEnvsBase:
         a.T, a.w1, a.capacity = T, 0 if o1 is None else o1.shape[-1], boot["cap"]
         a.obs_state, a.obs_target = _lib.ptr(buf.obs["state"]), _lib.ptr(o1)
         a.obs_target_row = None if o1 is None else _lib.ptr(o1[0])
-        a.obs_final, a.mean_scratch, a.values = _lib.ptr(final), _lib.ptr(sc["mean"]), _lib.ptr(buf.values)
+        a.obs_final, a.means, a.values = _lib.ptr(final), None, _lib.ptr(buf.values)
         a.actions, a.log_probs, a.rewards = _lib.ptr(buf.actions), _lib.ptr(buf.log_probs), _lib.ptr(buf.rewards)
         a.episode_starts, a.last_starts, a.log_std = _lib.ptr(buf.episode_starts), _lib.ptr(last_starts), _lib.ptr(policy.log_std)
         a.noise_key, a.sample_step = noise_key, sample_step
