@@ -736,3 +736,41 @@ def test_chain16_and_chain32_agree_to_a_stated_bound(keys):
     with torch.no_grad():
         m0, _ = ref({k: v.double() for k, v in obs16.items()})
     assert float((m16.double() - m0).abs().max()) <= 2e-6 * float(m0.abs().max())        # and both sit that close to fp64
+
+
+@pytest.mark.parametrize("keys", [("state",), ("state", "target")])
+def test_reverse_chain16_and_chain32_agree_to_a_stated_bound(keys):
+    """the 16-rows-per-wave reverse chain (policy trunk + observation gradient, picked for M <= 16 384: BPTT shards) and the
+    32-row one form the same sums in a different order: same rows through both -> observation gradients within 2e-6 of the
+    output scale of each other and of torch's fp64 autograd (rows whose ReLU masks differ between the two forwards -- a
+    pre-activation within rounding of zero -- excepted: fewer than 1 in 10 000)"""
+    from visfly_amd.ppo import MlpPolicy
+    dims = {"state": 13, "target": 3}
+    pol = MlpPolicy({k: dims[k] for k in keys}, {k: [128, 64] for k in keys}, [64, 64], [64, 64], DEV, seed=8)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    M16, M32 = 8192, 16384 + 2048
+    obs32 = {k: torch.randn((M32, dims[k]), device=DEV, generator=g) for k in keys}
+    obs16 = {k: v[:M16].contiguous() for k, v in obs32.items()}
+    dm32 = torch.randn((M32, 4), device=DEV, generator=g)
+    dm16 = dm32[:M16].contiguous()
+    pol.reserve_slots(M32, 1)
+    pol.reserve_slots(M16, 1)
+    pol.forward(obs32, slot=0, need_value=False)
+    if not pol.backward_data_supported(M32):
+        pytest.skip("register-chained reverse pass switched off")
+    g32 = {k: v.clone() for k, v in pol.backward_data(dm32, slot=0).items()}
+    pol.forward(obs16, slot=0, need_value=False)
+    g16 = {k: v.clone() for k, v in pol.backward_data(dm16, slot=0).items()}
+    ref = pol.to_torch().to(DEV).double()
+    x = {k: v.double().requires_grad_(True) for k, v in obs16.items()}
+    mean, _ = ref(x)
+    (mean * dm16.double()).sum().backward()
+    for k in keys:
+        want = x[k].grad
+        scale = float(want.abs().max())
+        for got in (g16[k], g32[k][:M16]):
+            bad = ((got.double() - want).abs().amax(dim=1) > 2e-6 * scale).float().mean()
+            assert float(bad) < 1e-4, (k, float(bad))
+        bad = ((g16[k] - g32[k][:M16]).abs().amax(dim=1) > 2e-6 * scale).float().mean()
+        assert float(bad) < 1e-4, (k, float(bad))
+

@@ -3,10 +3,11 @@
 // loss.backward() over a horizon (utils/algorithms/BPTT.py:127-129) is a strictly serial chain: the adjoint of env step t needs
 // dLoss/d obs_{t+1} from the policy's reverse pass of step t + 1, which needs dLoss/d action_{t+1} from the adjoint of step
 // t + 1.  As separate launches that is 2 H launches of 256-512 waves, each latency-bound (~20 us at 16 384 agents).  Agents are
-// independent, so here a wave owns 32 agents for the whole sweep t = H-1 .. 0:
-//   * adjoint of the control interval + env epilogue for its agents (env_step_bwd_agent, one lane per agent; lanes 32..63
-//     replicate lane & 31 -- same loads, same arithmetic, same stores of the same values, so no 32-lane special case);
-//   * action head reverse + reverse register chain for the same 32 rows (vf_mlp_chain_bwd.hpp): masked layer gradients into
+// independent, so here a wave owns ROWS = 16 or 32 agents (the rows-per-wave choice of vf_mlp_backward_data for N rows) for the
+// whole sweep t = H-1 .. 0:
+//   * adjoint of the control interval + env epilogue for its agents (env_step_bwd_agent, one lane per agent; lanes ROWS..63
+//     replicate lane & (ROWS - 1) -- same loads, same arithmetic, same stores of the same values, so no special case);
+//   * action head reverse + reverse register chain for the same rows (vf_mlp_chain_bwd.hpp): masked layer gradients into
 //     the slot's dZ buffers for the horizon-wide weight-gradient launch, dLoss/d observation for the next adjoint step;
 // d_action and the observation gradient travel through per-step rows of scratch (the same wave reads what it wrote).
 // Bit-identical to the launch-by-launch sweep (tests/test_bptt_gpu.py).
@@ -29,14 +30,14 @@ struct RevArgs {
     const float* g_obs;            // [H][N][13]: row t N + i = dLoss / d (observation of slot t), written by the reverse chain
 };
 
-template <class P, int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+template <class P, int ROWS, int KIND, int ACT, int INTEG, bool CTRL_DELAY>
 __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const BwdArgsChain gb,
                                                      const RevArgs r)
 {
     prefetch_kernarg<sizeof(BwdArgsChain) + sizeof(RevArgs) + 16>();
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [S * kSave][64]
-    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
-    const int i = min((int)blockIdx.x * 32 + m, r.N - 1);            // lanes past the last agent replicate it as well
+    const int lane = threadIdx.x, m = lane & (ROWS - 1);
+    const int i = min((int)blockIdx.x * ROWS + m, r.N - 1);          // lanes past the last agent replicate it as well
     for (int t = r.H - 1; t >= 0; --t) {
         const BwdArgs g{r.N, r.G, r.g_drag, r.g_race, r.tape + (size_t)t * r.tape_stride, r.actions + (size_t)t * r.N,
                         t + 1 < r.H ? r.g_obs + (size_t)(t + 1) * r.N * 13 : nullptr, r.d_reward + (size_t)t * r.N,
@@ -44,11 +45,11 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64>(*cp, *ep, g, i, true, lds + lane);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // d_action_t: written above, read by the head reverse below
         const int row = t * r.N + i;
-        BwdState<P> st;
-        bwd_prologue<P, 0>(gb, st, lane);
-        bwd_head_prologue<P, 0>(gb, st, row, h, true);
-        bwd_items<P, NoFwd, 0>(gb, st, NoFwd{}, lane, row, row, true);
-        bwd_tail_store<P>(gb, st, row, h, true);
+        // (an opaque copy of the lane id per iteration: the chain's loop-invariant per-item load offsets stay just-in-time instead
+        // of being hoisted out of the t loop into ~100 live registers -- see k_ppo_rollout)
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        bwd_rows<P, ROWS>(gb, lane_t, row, row, true);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // dLoss / d obs_t: read by the adjoint of step t - 1
     }
 }
@@ -59,13 +60,13 @@ namespace {
 
 using RevKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::BwdArgsChain, const vf::RevArgs);
 
-template <class Net, int KIND>
+template <class Net, int ROWS, int KIND>
 RevKernel pick_rev(const vf_dyn_cfg& c)
 {
     using P = vf::BwdProg<Net, true, false, true>;
     if (c.integrator != VF_INT_EULER || !c.ctrl_delay) return nullptr;
-    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
-    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
     return nullptr;
 }
 
@@ -85,11 +86,13 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     const int S = h->dyn.cfg.interval_steps;
     if (S > 10) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: at most 10 sub-steps per control interval");
     const int N = h->dyn.N;
-    const int cls = vf::bwd_chain_policy_class(desc);
+    // rows per wave: the choice vf_mlp_backward_data makes for N rows, so that the sweep equals the launch-by-launch one to the bit
+    const int cls = vf::bwd_chain_policy_class(desc, N), net = cls & 15;
+    const bool r16 = (cls & 16) != 0;
     RevKernel k = nullptr;
-    if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = pick_rev<vf::NetHover, VF_ENV_HOVER>(h->dyn.cfg);
-    else if (cls == 1 && h->cfg.kind == VF_ENV_RACING) k = pick_rev<vf::NetHover, VF_ENV_RACING>(h->dyn.cfg);
-    else if (cls == 2 && h->cfg.kind == VF_ENV_NAV) k = pick_rev<vf::NetNav, VF_ENV_NAV>(h->dyn.cfg);
+    if (net == 1 && h->cfg.kind == VF_ENV_HOVER) k = r16 ? pick_rev<vf::NetHover, 16, VF_ENV_HOVER>(h->dyn.cfg) : pick_rev<vf::NetHover, 32, VF_ENV_HOVER>(h->dyn.cfg);
+    else if (net == 1 && h->cfg.kind == VF_ENV_RACING) k = r16 ? pick_rev<vf::NetHover, 16, VF_ENV_RACING>(h->dyn.cfg) : pick_rev<vf::NetHover, 32, VF_ENV_RACING>(h->dyn.cfg);
+    else if (net == 2 && h->cfg.kind == VF_ENV_NAV) k = r16 ? pick_rev<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_rev<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg);
     if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: no persistent reverse sweep for this network class / env kind / dynamics configuration");
     bool found = false;        // g_obs must be the (rows, 13) buffer the "state" branch's first layer writes its data gradient to
     for (int l = 0; l < desc->n_layers; ++l) found = found || (desc->layer[l].need_dx && desc->layer[l].dX == g_obs && desc->layer[l].ld_dx == 13);
@@ -99,7 +102,8 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     vf::RevArgs r{H, N, h->dyn.G, h->dyn.g_drag, h->g_race, tape, tape_stride, reinterpret_cast<const float4*>(actions), tape_done, d_reward,
                   adj_slab, reinterpret_cast<float4*>(d_action), g_obs};
     const size_t lds = (size_t)S * vf::kSave * 64 * sizeof(float);
-    hipLaunchKernelGGL(k, dim3((N + 31) / 32), dim3(64), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, gb, r);
+    const int rows = r16 ? 16 : 32;
+    hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, gb, r);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -81,19 +81,15 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
     VF_TRACE(31);
 }
 
-template <class P>
+template <class P, int ROWS = 32>
 __global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
 {
     prefetch_kernarg<sizeof(BwdArgsChain)>();
-    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
-    const int row = blockIdx.x * 32 + m;
+    const int lane = threadIdx.x, m = lane & (ROWS - 1);
+    const int row = blockIdx.x * ROWS + m;
     const bool live = row < g.M;
     const int rc = live ? row : g.M - 1;
-    BwdState<P> st;
-    bwd_prologue<P, 0>(g, st, lane);
-    bwd_head_prologue<P, 0>(g, st, rc, h, live);
-    bwd_items<P, NoFwd, 0>(g, st, NoFwd{}, lane, row, rc, live);
-    bwd_tail_store<P>(g, st, row, h, live);
+    bwd_rows<P, ROWS>(g, lane, row, rc, live);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -281,11 +277,36 @@ bool bwd_chain_matches(const vf_mlp_bwd_desc& d)
     return true;
 }
 
+// 16 rows per wave for the reverse chain?  The forward's rule (chain16_ok): a small row count leaves half of the SIMDs without a
+// wave; only the policy-trunk variant with observation gradient (first-order policy optimisation, whose shards are small) is
+// instantiated.  Needs the row-major data-gradient image (wb_off) and observation widths <= 16.  VISFLY_AMD_MLP_CHAIN16=0/1
+// forces the choice (A/B) together with the forward's.
+template <class N, bool PI, bool VF, bool IG>
+bool bwd16_ok(const vf_mlp_bwd_desc& d, int M)
+{
+    if constexpr (!(PI && !VF && IG)) return false;
+    using P = BwdProg<N, PI, VF, IG>;
+    static const int forced = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN16"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || (forced < 0 && M > 16384)) return false;
+    for (int l = 0; l < d.n_layers; ++l)
+        if (d.layer[l].wb_off < 0) return false;
+    for (int b = 0; b < N::NB; ++b)
+        if (d.layer[P::entry(2 * b)].K > 16) return false;
+    return true;
+}
+
 template <class N, bool PI, bool VF, bool IG>
 int bwd_chain_launch(const vf_mlp_bwd_desc& d, const float* packed, int M, hipStream_t st, const ReparamBwd& rp)
 {
     BwdArgsChain g{d, packed, M, reinterpret_cast<const float4*>(rp.d_action), reinterpret_cast<const float4*>(rp.action), rp.log_std,
                    reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.g_log_std)};
+    if constexpr (PI && !VF && IG) {
+        if (bwd16_ok<N, PI, VF, IG>(d, M)) {
+            hipLaunchKernelGGL((k_mlp_backward_chain<BwdProg<N, PI, VF, IG>, 16>), dim3((M + 15) / 16), dim3(64), 0, st, g);
+            VF_HIP(hipGetLastError());
+            return 1;
+        }
+    }
     hipLaunchKernelGGL((k_mlp_backward_chain<BwdProg<N, PI, VF, IG>>), dim3((M + 31) / 32), dim3(64), 0, st, g);
     VF_HIP(hipGetLastError());
     return 1;
@@ -349,13 +370,14 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     return 0;
 }
 
-// the policy-trunk-only reverse chain with observation gradient (first-order policy optimisation): 0 none, 1 NetHover, 2 NetNav
-int bwd_chain_policy_class(const vf_mlp_bwd_desc* d)
+// the policy-trunk-only reverse chain with observation gradient (first-order policy optimisation): 0 none, 1 NetHover, 2 NetNav;
+// + 16 when M rows per pass run on the 16-rows-per-wave chain
+int bwd_chain_policy_class(const vf_mlp_bwd_desc* d, int M)
 {
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
     if (off) return 0;
-    if (bwd_chain_matches<NetHover, true, false, true>(*d)) return 1;
-    if (bwd_chain_matches<NetNav, true, false, true>(*d)) return 2;
+    if (bwd_chain_matches<NetHover, true, false, true>(*d)) return 1 + (bwd16_ok<NetHover, true, false, true>(*d, M) ? 16 : 0);
+    if (bwd_chain_matches<NetNav, true, false, true>(*d)) return 2 + (bwd16_ok<NetNav, true, false, true>(*d, M) ? 16 : 0);
     return 0;
 }
 

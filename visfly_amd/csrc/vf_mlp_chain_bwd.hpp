@@ -303,4 +303,245 @@ __device__ __forceinline__ void bwd_tail_store(const BwdArgsChain& g, const BwdS
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same reverse chain with 16 rows per wave (v_mfma_f32_16x16x4_f32) for SMALL row counts, the counterpart of the 16-row
+// forward (vf_mlp_chain.hpp): at the BPTT shard (16 384 rows) the 32-row reverse chain puts 512 waves on 1 024 SIMDs and lasts as
+// long as one wave needs for the whole network; 16 rows per wave halve that.
+//     A operand = W^T     A[i = k][kk = n]   lane = k + 16 kq
+//     B operand = dZ^T    B[kk = n][j = m]   lane = m + 16 kq
+//     C / D     = dX^T    D[i = k][j = m]    lane (m, gq = lane >> 4) holds k = 4 gq + r, r = 0..3
+// A gradient-tile lane holds features 4 gq + r of its own row; as the B operand of step r it supplies n = 16 T + 4 kq + r, so step
+// r's A fragment is W[16 T + 4 kq + r][16 a + i]: read from the zero-padded row-major data-gradient image the block-tile
+// kernel uses (vf_mlp_layer.wb_off: round16(No) rows of round32(K) floats), four dwords per (input tile T, output tile a)
+// item; no image of its own.  Heads (4 / 1 input features) are ONE MFMA per output tile: B = the lane's kq-th head gradient.
+// Summation order inside a dot product differs from the 32-row chain's (4 products per MFMA instead of 2), so the two agree to
+// rounding, not to the bit: callers pick ONE of them per row count (bwd16_ok, the forward's rule) on every path.
+// ------------------------------------------------------------------------------------------------
+template <class P>
+struct Bwd16 {
+    static constexpr int nin(int oi) { return P::op(oi).in_kind == 0 ? P::op(oi).G / 2 : 1; }       // 16-feature input tiles
+    static constexpr int nout(int oi) { return P::op(oi).obs >= 0 ? 1 : 2 * P::op(oi).nout; }       // 16-feature output tiles
+    static constexpr int k32(int oi) { return P::op(oi).obs >= 0 ? 32 : 32 * P::op(oi).nout; }      // row length of the wb image
+    static constexpr int items(int oi) { return nin(oi) * nout(oi); }
+    static constexpr int n_items()
+    {
+        int n = 0;
+        for (int i = 0; i < P::n_ops; ++i) n += items(i);
+        return n;
+    }
+    static constexpr int op_of(int item)
+    {
+        int i = 0;
+        while (item >= items(i)) { item -= items(i); ++i; }
+        return i;
+    }
+    static constexpr int first_item(int oi)
+    {
+        int n = 0;
+        for (int i = 0; i < oi; ++i) n += items(i);
+        return n;
+    }
+};
+
+template <class P>
+struct BwdState16 {
+    f32x4 t[2 * P::n_tiles];
+    float4 ring[kChain16Depth];  // the four A fragments of an item
+    float4 ym[8];                // saved activations (mask source) of the 16-tiles being finalised
+    float hin[2];                // this lane's element of the head gradients: d_mean[kq] / d_value (kq = 0), else 0
+};
+
+template <class P, int I>
+__device__ __forceinline__ float4 bwd16_load(const BwdArgsChain& g, int lane)
+{
+    using B = Bwd16<P>;
+    constexpr int oi = B::op_of(I), local = I - B::first_item(oi);
+    constexpr BwdOp O = P::op(oi);
+    constexpr int T = local / B::nout(oi), a = local % B::nout(oi), K32 = B::k32(oi);
+    const float* base = g.packed + g.d.layer[P::entry(O.fl)].wb_off;             // wave-uniform
+    if constexpr (O.in_kind == 0) {
+        const float* p = base + (16 * T * K32 + 16 * a) + ((unsigned)(lane >> 4) * (4u * K32) + (unsigned)(lane & 15));
+        return make_float4(p[0], p[K32], p[2 * K32], p[3 * K32]);
+    } else {
+        const float* p = base + 16 * a + ((unsigned)(lane >> 4) * (unsigned)K32 + (unsigned)(lane & 15));
+        return make_float4(p[0], 0.0f, 0.0f, 0.0f);
+    }
+}
+
+template <class P, int OI>
+__device__ __forceinline__ void bwd16_mask_load(const BwdArgsChain& g, BwdState16<P>& st, int rc, int gq)
+{
+    constexpr BwdOp O = P::op(OI);
+#pragma unroll
+    for (int f = 0; f < O.nfin; ++f) {
+        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fin[f].fl)];
+        const float* y = E.Y + (size_t)rc * E.ld_y + 4 * gq;
+#pragma unroll
+        for (int a = 0; a < 2 * O.fin[f].nt; ++a) st.ym[2 * O.fin[f].ym0 + a] = *reinterpret_cast<const float4*>(y + 16 * a);
+    }
+}
+
+template <class P, int OI>
+__device__ __forceinline__ void bwd16_finalize(const BwdArgsChain& g, BwdState16<P>& st, int row, int gq, bool live)
+{
+    constexpr BwdOp O = P::op(OI);
+#pragma unroll
+    for (int f = 0; f < O.nfin; ++f)
+#pragma unroll
+        for (int a = 0; a < 2 * O.fin[f].nt; ++a) {
+            f32x4& v = st.t[2 * O.fin[f].t0 + a];
+            const float4 y = st.ym[2 * O.fin[f].ym0 + a];
+            v[0] = y.x > 0.0f ? v[0] : 0.0f;
+            v[1] = y.y > 0.0f ? v[1] : 0.0f;
+            v[2] = y.z > 0.0f ? v[2] : 0.0f;
+            v[3] = y.w > 0.0f ? v[3] : 0.0f;
+        }
+    if constexpr (O.obs >= 0) {        // dLoss/d observation: features 4 gq + r of this lane's row
+        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];
+        if (live) {
+            const f32x4& v = st.t[2 * O.out0];
+            float* dx = E.dX + (size_t)row * E.ld_dx;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * gq + r;
+                if (k < E.K) dx[k] = v[r];
+            }
+        }
+    }
+}
+
+// stores of the tiles the PREVIOUS op finalised, spread over this op's items
+template <class P, int OI, int LOCAL>
+__device__ __forceinline__ void bwd16_deferred_store(const BwdArgsChain& g, const BwdState16<P>& st, int row, int gq, bool live)
+{
+    if constexpr (OI >= 1) {
+        constexpr BwdOp Q = P::op(OI - 1);
+        constexpr int S0 = Q.nfin > 0 ? Q.fin[0].nt * 2 : 0, S = S0 + (Q.nfin > 1 ? Q.fin[1].nt * 2 : 0);
+        constexpr int n_it = Bwd16<P>::items(OI), per = (S + n_it - 1) / n_it;
+        constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
+        if constexpr (s0 < s1) {
+            if (live) {
+#pragma unroll
+                for (int i = s0; i < s1; ++i) {
+                    const int f = i < S0 ? 0 : 1, a = i - (f ? S0 : 0);
+                    const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
+                    float* base = const_cast<float*>(E.dY) + 16 * a;                    // wave-uniform
+                    const unsigned off = (unsigned)row * (unsigned)E.ld_dy + 4u * gq;
+                    const f32x4& v = st.t[2 * Q.fin[f].t0 + a];
+                    *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+template <class P, int I>
+__device__ __forceinline__ void bwd16_items(const BwdArgsChain& g, BwdState16<P>& st, int lane, int row, int rc, bool live)
+{
+    using B = Bwd16<P>;
+    if constexpr (I < B::n_items()) {
+        constexpr int oi = B::op_of(I), local = I - B::first_item(oi);
+        constexpr BwdOp O = P::op(oi);
+        constexpr int T = local / B::nout(oi), a = local % B::nout(oi);
+        const int gq = lane >> 4;
+        const float4 w = st.ring[I % kChain16Depth];
+        if constexpr (I + kChain16Depth < B::n_items()) st.ring[I % kChain16Depth] = bwd16_load<P, I + kChain16Depth>(g, lane);
+        if constexpr (local == 0 && O.in_kind == 0) bwd16_mask_load<P, oi>(g, st, rc, gq);            // head ops: in the prologue
+        f32x4& acc = st.t[2 * O.out0 + a];
+        if constexpr (T == 0 && !O.accum) acc = f32x4{0};
+        if constexpr (O.in_kind == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, st.t[2 * O.in0 + T][j], acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, st.hin[O.in_kind - 1], acc, 0, 0, 0);
+        }
+        bwd16_deferred_store<P, oi, local>(g, st, row, gq, live);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (local == B::items(oi) - 1) bwd16_finalize<P, oi>(g, st, row, gq, live);
+        bwd16_items<P, I + 1>(g, st, lane, row, rc, live);
+    }
+}
+
+template <class P, int I>
+__device__ __forceinline__ void bwd16_prologue(const BwdArgsChain& g, BwdState16<P>& st, int lane)
+{
+    if constexpr (I < kChain16Depth && I < Bwd16<P>::n_items()) {
+        st.ring[I] = bwd16_load<P, I>(g, lane);
+        bwd16_prologue<P, I + 1>(g, st, lane);
+    }
+}
+
+template <class P, int OI>
+__device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdState16<P>& st, int rc, int gq, bool live)
+{
+    if constexpr (OI < P::n_ops) {
+        constexpr BwdOp O = P::op(OI);
+        if constexpr (O.in_kind != 0) {
+            const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];
+            const float* dy = E.dY + (size_t)rc * E.ld_dy;
+            if constexpr (O.in_kind == 1) {
+                float4 dm;
+                if (g.rp_d_action) {       // k_reparam_bwd's arithmetic; lane group 0 of a live row writes d_mean / g_log_std
+                    const float4 da = g.rp_d_action[rc], a = g.rp_action[rc], e = g.rp_eps[rc];
+                    dm = make_float4(da.x * (1.0f - a.x * a.x), da.y * (1.0f - a.y * a.y), da.z * (1.0f - a.z * a.z), da.w * (1.0f - a.w * a.w));
+                    if (live && gq == 0) {
+                        *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
+                        float4 gl = g.rp_g_log_std[rc];
+                        gl.x += dm.x * expf(g.rp_log_std[0]) * e.x; gl.y += dm.y * expf(g.rp_log_std[1]) * e.y;
+                        gl.z += dm.z * expf(g.rp_log_std[2]) * e.z; gl.w += dm.w * expf(g.rp_log_std[3]) * e.w;
+                        g.rp_g_log_std[rc] = gl;
+                    }
+                } else {
+                    dm = make_float4(dy[0], dy[1], dy[2], dy[3]);
+                }
+                st.hin[0] = gq == 0 ? dm.x : gq == 1 ? dm.y : gq == 2 ? dm.z : dm.w;
+            } else {
+                st.hin[1] = gq == 0 ? dy[0] : 0.0f;
+            }
+            bwd16_mask_load<P, OI>(g, st, rc, gq);
+            bwd16_head_prologue<P, OI + 1>(g, st, rc, gq, live);
+        }
+    }
+}
+
+// the last op's finalised tiles have no following items to carry their stores
+template <class P>
+__device__ __forceinline__ void bwd16_tail_store(const BwdArgsChain& g, const BwdState16<P>& st, int row, int gq, bool live)
+{
+    constexpr BwdOp Q = P::op(P::n_ops - 1);
+    if (!live) return;
+#pragma unroll
+    for (int f = 0; f < Q.nfin; ++f) {
+        const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
+        float* base = const_cast<float*>(E.dY) + (size_t)row * E.ld_dy + 4 * gq;
+#pragma unroll
+        for (int a = 0; a < 2 * Q.fin[f].nt; ++a) {
+            const f32x4& v = st.t[2 * Q.fin[f].t0 + a];
+            *reinterpret_cast<float4*>(base + 16 * a) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// one reverse pass of the rows `row` (lane & (ROWS - 1) of the wave), ROWS = 32 or 16
+template <class P, int ROWS>
+__device__ __forceinline__ void bwd_rows(const BwdArgsChain& g, int lane, int row, int rc, bool live)
+{
+    if constexpr (ROWS == 32) {
+        const int h = lane >> 5;
+        BwdState<P> st;
+        bwd_prologue<P, 0>(g, st, lane);
+        bwd_head_prologue<P, 0>(g, st, rc, h, live);
+        bwd_items<P, NoFwd, 0>(g, st, NoFwd{}, lane, row, rc, live);
+        bwd_tail_store<P>(g, st, row, h, live);
+    } else {
+        const int gq = lane >> 4;
+        BwdState16<P> st;
+        bwd16_prologue<P, 0>(g, st, lane);
+        bwd16_head_prologue<P, 0>(g, st, rc, gq, live);
+        bwd16_items<P, 0>(g, st, lane, row, rc, live);
+        bwd16_tail_store<P>(g, st, row, gq, live);
+    }
+}
+
 }  // namespace vf
