@@ -545,7 +545,8 @@ int vf_mlp_backward(const vf_mlp_bwd_desc* desc, const float* packed, float* par
                     int32_t accumulate, vf_stream_t stream);
 /* The two halves of the register-chained backward, for callers that reduce the weight gradient over several batches
  * at once (BPTT: one weight-gradient launch per horizon instead of one per step, BPTT.py:107-129):
- *   vf_mlp_backward_data   reverse chain only: leaves the ReLU-masked gradient of every hidden layer in its dY buffer and
+ *   vf_mlp_backward_data   reverse chain only (M <= 16 384 rows: 16 rows per wave, else 32 -- the two agree to rounding, ~1e-6 of
+ *                          the output scale, not to the bit): leaves the ReLU-masked gradient of every hidden layer in its dY buffer and
  *                          (need_dx on the first layers) dLoss/d observation in dX; VF_EUNSUPPORTED if the layer table is
  *                          not an instantiated network class / variant (vf_mlp_backward_data_supported: 1 / 0)
  *   vf_mlp_weight_grad     dW / db of every listed layer from dY (masked, as left by vf_mlp_backward_data) and X over M
@@ -740,7 +741,8 @@ int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, con
                     float* disc, float gamma, float scale, int32_t H, vf_stream_t stream);
 
 /* ... and the reverse half (loss.backward() over the horizon, BPTT.py:127-129): for t = H-1 .. 0 the adjoint of env step t and the
- * policy's action-head reverse + reverse chain of step t, a wave owning 32 agents for the whole sweep; leaves what H rounds of
+ * policy's action-head reverse + reverse chain of step t, a wave owning 16 or 32 agents (the rows-per-wave choice
+ * vf_mlp_backward_data makes for N rows) for the whole sweep; leaves what H rounds of
  * vf_env_step_bwd + vf_mlp_backward_data_act leave (bit-identical): the masked layer gradients of every slot (for ONE
  * vf_mlp_weight_grad over H N rows afterwards), d_mean rows, the per-row log_std gradient terms and the adjoint slab.
  *   desc       reverse layer table over the FLATTENED slots (H N rows; layer[0].dY = d_mean (H N, 4), the first-layer dX of the
