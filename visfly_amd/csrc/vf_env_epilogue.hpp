@@ -87,6 +87,22 @@ __device__ __forceinline__ void spawn_helper(const vf_env_cfg& e, const EnvArgs&
     dst[3 * gs] = make_float4(0.0f, s.w[0], s.w[1], s.w[2]);
 }
 
+#ifndef VF_EXP_SLOT_MODE
+#define VF_EXP_SLOT_MODE 1       // 0: the loads under `if (done)` (A/B, profiles/r03_reset_prefetch.txt)
+#endif
+
+// the prefetched spawn copy of agent i (granules g_spawn_rd .. + 3 of its tile).  Loaded by EVERY lane, ending an episode or not
+// (granule 0 when the feature is off: a valid address whose value nobody looks at): a load under `if (done)` joins a path on which
+// the registers are undefined, and the copies the join needs are placed -- with their s_waitcnt -- right behind the loads
+// (profiles/r03_reset_prefetch.txt); loads nobody waits for cost an ending-free wave four issue slots
+__device__ __forceinline__ SpawnSlot load_spawn_slot(const EnvArgs& g, int i)
+{
+    const float4* src = granule(g.d.S, g.d.G, i, g.g_spawn_rd >= 0 ? g.g_spawn_rd : 0);
+    SpawnSlot slot;
+    slot.g0 = src[0]; slot.g1 = src[64]; slot.g2 = src[128]; slot.g3 = src[192];
+    return slot;
+}
+
 template <int KIND, bool STORE_STATE = true, bool EXT = false>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile, float* reward_reg = nullptr,
@@ -108,7 +124,32 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     er.flags = collision_flags(er.flags, col);
     er.step_count += 1;                                                                  // droneGymEnv.py:163
 
+    // ---- is this the agent's last step?  Decided BEFORE the reward: nothing of it depends on the reward, and a wave that ends
+    // an episode wants its prefetched spawn copy on the way as early as possible (below) ----
     bool success = false, failure = false;
+    if constexpr (KIND == VF_ENV_NAV) {
+        success = norm3(s.p[0] - e.target[0], s.p[1] - e.target[1], s.p[2] - e.target[2]) <= e.success_radius;
+        if (e.reward_mode == VF_REWARD_NAV2) failure = col.hit;   // NavigationEnv2: failure = is_collision (NavigationEnv.py:159-160)
+    }
+    bool ep_done = (er.flags & VF_F_EPISODE_DONE) || success || failure || (er.flags & VF_F_OUT_BOUNDS);   // :188
+    if (e.is_collision_reset) ep_done = ep_done || (er.flags & VF_F_COLLISION);          // :189-190
+    const bool truncated = er.step_count >= e.max_episode_steps;
+    const bool done = ep_done || truncated;                                              // :193
+    // prefetched re-spawn: the copy an ending agent starts its next episode from (load_spawn_slot)
+    SpawnSlot slot;
+#ifdef VF_EXP_NO_SLOT
+    const bool use_slot = false;
+#else
+    const bool use_slot = done && g.auto_reset && g.g_spawn_rd >= 0;
+#endif
+#if VF_EXP_SLOT_MODE == 1
+    slot = load_spawn_slot(g, i);     // (issuing them ahead of the dynamics interval instead: same times, 16 registers more)
+#else
+    if (use_slot) {
+        const float4* src = granule(g.d.S, g.d.G, i, g.g_spawn_rd);
+        slot.g0 = src[0]; slot.g1 = src[64]; slot.g2 = src[128]; slot.g3 = src[192];
+    }
+#endif
     float reward;
     int gate = 0, passed = 0, gate_pre = 0;   // gate_pre: the index the terminal observation carries -- the observation is
                                               // refreshed before get_success() advances it (droneGymEnv.py:161-166,197-208)
@@ -116,9 +157,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     if constexpr (KIND == VF_ENV_HOVER) {
         reward = hover_reward(s.p, e.target, s.q, vel, s.w);
     } else if constexpr (KIND == VF_ENV_NAV) {
-        success = norm3(s.p[0] - e.target[0], s.p[1] - e.target[1], s.p[2] - e.target[2]) <= e.success_radius;
-        if (e.reward_mode == VF_REWARD_NAV2) {   // NavigationEnv2: failure = is_collision (NavigationEnv.py:159-160)
-            failure = col.hit;
+        if (e.reward_mode == VF_REWARD_NAV2) {
             reward = nav2_reward(e, s.p, vel, s.w, success);
         } else {
             reward = nav_reward(e, s.p, s.q, vel, s.w, col, success, er.step_count, c.trig_mode);
@@ -139,15 +178,10 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         race.z = __int_as_float(pass ? 1 : 0);
     }
     er.rewards = er.rewards + reward;                                                    // :185
-    bool ep_done = (er.flags & VF_F_EPISODE_DONE) || success || failure || (er.flags & VF_F_OUT_BOUNDS);   // :188
-    if (e.is_collision_reset) ep_done = ep_done || (er.flags & VF_F_COLLISION);          // :189-190
-    const bool truncated = er.step_count >= e.max_episode_steps;
-    const bool done = ep_done || truncated;                                              // :193
     er.flags = set_flag(er.flags, VF_F_EPISODE_DONE, ep_done);
     er.flags = set_flag(er.flags, VF_F_SUCCESS, success);
     er.flags = set_flag(er.flags, VF_F_FAILURE, failure);
     er.flags = set_flag(er.flags, VF_F_DONE, done);
-
 #ifndef VF_EXP_NO_DONE_LIST
     if (g.out.done_list) {                       // compacted done list: one atomic per wave that has an ending agent
         const unsigned long long m = __ballot(live && done);
@@ -160,19 +194,6 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         }
     }
 #endif
-    // prefetched re-spawn: only a wave that ends an episode touches the copy -- four exec-masked 16-byte loads, issued as soon as
-    // `done` is known so that they travel under the terminal-row stores (loading them with the state burst of EVERY wave cost
-    // the no-reset launch 0.45 us: profiles/r03_reset_prefetch.txt)
-    SpawnSlot slot;
-#ifdef VF_EXP_NO_SLOT
-    const bool use_slot = false;
-#else
-    const bool use_slot = done && g.auto_reset && g.g_spawn_rd >= 0;
-#endif
-    if (use_slot) {
-        const float4* src = granule(g.d.S, g.d.G, i, g.g_spawn_rd);
-        slot.g0 = src[0]; slot.g1 = src[64]; slot.g2 = src[128]; slot.g3 = src[192];
-    }
     float o[13];
     obs_row(c, s, o);
     obs_variant(e, o);
