@@ -422,6 +422,10 @@ __device__ __forceinline__ void chain16_deferred_store(const ChainArgs& g, const
     }
 }
 
+// Items (T, a) and (T, a + 1) -- same input tile, neighbouring output tiles -- run as ONE step with their MFMAs interleaved:
+// v_mfma_f32_16x16x4_f32 issues every 32 cycles but a MFMA that accumulates into the result of the one before it waits 40
+// (MI355X_MICROARCH.md, per-instruction constants), so four back-to-back MFMAs on one accumulator run at 80 % of the pipe; two
+// accumulators alternating do not wait.  Every accumulator still sees its products in the same order: same bits.
 template <class N, int I>
 __device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N>& st, int lane, int row, bool live)
 {
@@ -430,27 +434,40 @@ __device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N
         constexpr int li = C::layer_of(I), local = I - C::first_item(li);
         constexpr ChainLayer L = N::layer(li);
         constexpr int T = local / C::nout(li), a = local % C::nout(li);
+        constexpr bool pair = (a % 2 == 0) && (a + 1 < C::nout(li));
+        constexpr int step = pair ? 2 : 1;
         const int gq = lane >> 4;
         const float4 w = st.ring[I % kChain16Depth];
         if constexpr (I + kChain16Depth < C::n_items()) st.ring[I % kChain16Depth] = chain16_load<N, I + kChain16Depth>(g, lane);
+        float4 w1 = w;
+        if constexpr (pair) {
+            w1 = st.ring[(I + 1) % kChain16Depth];
+            if constexpr (I + 1 + kChain16Depth < C::n_items()) st.ring[(I + 1) % kChain16Depth] = chain16_load<N, I + 1 + kChain16Depth>(g, lane);
+        }
         if constexpr (local == 0) chain16_bias_load<N, li>(g, st, gq);
         f32x4& acc = st.t[2 * L.out0 + a];
-        if constexpr (T == 0) acc = f32x4{0};
+        f32x4& acc1 = st.t[2 * L.out0 + a + (pair ? 1 : 0)];
+        if constexpr (T == 0) {
+            acc = f32x4{0};
+            if constexpr (pair) acc1 = f32x4{0};
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float b;
             if constexpr (L.obs >= 0) b = st.x[L.obs][j];
             else b = st.t[2 * L.in0 + T][j];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
+            if constexpr (pair) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w1.x : j == 1 ? w1.y : j == 2 ? w1.z : w1.w, b, acc1, 0, 0, 0);
         }
         chain16_deferred_store<N, li, local>(g, st, row, gq, live);
+        if constexpr (pair) chain16_deferred_store<N, li, local + 1>(g, st, row, gq, live);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (local == 0) VF_TRACE(2 + 2 * li);
-        if constexpr (local == C::items(li) - 1) {
+        if constexpr (local + step - 1 == C::items(li) - 1) {
             chain16_epilogue<N, li>(g, st, row, gq, live);
             VF_TRACE(3 + 2 * li);
         }
-        chain16_items<N, I + 1>(g, st, lane, row, live);
+        chain16_items<N, I + step>(g, st, lane, row, live);
     }
 }
 

@@ -435,6 +435,7 @@ __device__ __forceinline__ void bwd16_deferred_store(const BwdArgsChain& g, cons
     }
 }
 
+// (items (T, a), (T, a + 1) as one step with their MFMAs interleaved: see chain16_items)
 template <class P, int I>
 __device__ __forceinline__ void bwd16_items(const BwdArgsChain& g, BwdState16<P>& st, int lane, int row, int rc, bool live)
 {
@@ -443,23 +444,38 @@ __device__ __forceinline__ void bwd16_items(const BwdArgsChain& g, BwdState16<P>
         constexpr int oi = B::op_of(I), local = I - B::first_item(oi);
         constexpr BwdOp O = P::op(oi);
         constexpr int T = local / B::nout(oi), a = local % B::nout(oi);
+        constexpr bool pair = O.in_kind == 0 && (a % 2 == 0) && (a + 1 < B::nout(oi));
+        constexpr int step = pair ? 2 : 1;
         const int gq = lane >> 4;
         const float4 w = st.ring[I % kChain16Depth];
         if constexpr (I + kChain16Depth < B::n_items()) st.ring[I % kChain16Depth] = bwd16_load<P, I + kChain16Depth>(g, lane);
+        float4 w1 = w;
+        if constexpr (pair) {
+            w1 = st.ring[(I + 1) % kChain16Depth];
+            if constexpr (I + 1 + kChain16Depth < B::n_items()) st.ring[(I + 1) % kChain16Depth] = bwd16_load<P, I + 1 + kChain16Depth>(g, lane);
+        }
         if constexpr (local == 0 && O.in_kind == 0) bwd16_mask_load<P, oi>(g, st, rc, gq);            // head ops: in the prologue
         f32x4& acc = st.t[2 * O.out0 + a];
-        if constexpr (T == 0 && !O.accum) acc = f32x4{0};
+        f32x4& acc1 = st.t[2 * O.out0 + a + (pair ? 1 : 0)];
+        if constexpr (T == 0 && !O.accum) {
+            acc = f32x4{0};
+            if constexpr (pair) acc1 = f32x4{0};
+        }
         if constexpr (O.in_kind == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, st.t[2 * O.in0 + T][j], acc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const float b = st.t[2 * O.in0 + T][j];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
+                if constexpr (pair) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w1.x : j == 1 ? w1.y : j == 2 ? w1.z : w1.w, b, acc1, 0, 0, 0);
+            }
         } else {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, st.hin[O.in_kind - 1], acc, 0, 0, 0);
         }
         bwd16_deferred_store<P, oi, local>(g, st, row, gq, live);
+        if constexpr (pair) bwd16_deferred_store<P, oi, local + 1>(g, st, row, gq, live);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (local == B::items(oi) - 1) bwd16_finalize<P, oi>(g, st, row, gq, live);
-        bwd16_items<P, I + 1>(g, st, lane, row, rc, live);
+        if constexpr (local + step - 1 == B::items(oi) - 1) bwd16_finalize<P, oi>(g, st, row, gq, live);
+        bwd16_items<P, I + step>(g, st, lane, row, rc, live);
     }
 }
 

@@ -20,6 +20,10 @@
 
 namespace vf {
 
+#ifdef VF_PPO_TRACE
+__device__ long long vf_ppo_trace[8];
+#endif
+
 struct PpoRollArgs {
     int T, N;
     float4* actions;                // [T][N]
@@ -113,6 +117,12 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
     // from the caller's row 0.  One wave's LDS operations execute in order: no barrier.
     for (int k = 0; k < 13; ++k) tile[lane * 13 + k] = r.obs_slots[(size_t)i * 13 + k];
     __builtin_amdgcn_wave_barrier();
+#ifdef VF_PPO_TRACE
+    long long tr[5] = {0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define VF_PT(k) do { const long long n_ = __builtin_readcyclecounter(); tr[k] += n_ - tc; tc = n_; } while (0)
+#else
+#define VF_PT(k) do { } while (0)
+#endif
     for (int t = 0; t < r.T; ++t) {
         const int row = t * r.N + i;
         // the chain's per-item load offsets (lane * 16 + item * 1 KiB) are loop-invariant: hoisted out of the t loop they are
@@ -122,6 +132,7 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
         float4 mean = policy_rows<Net, ROWS>(gc, lane_t, row, tile);
         // lane m < ROWS holds the head of its own agent; the replica lanes take it from there
         mean.x = __shfl(mean.x, m); mean.y = __shfl(mean.y, m); mean.z = __shfl(mean.z, m); mean.w = __shfl(mean.w, m);
+        VF_PT(0);
         float4 act;
         const float lp = head_sample_row(mean, r.log_std, i, r.noise_key, r.sample_step + 1ull + (unsigned long long)t, 0, act);
         r.actions[row] = act;
@@ -142,10 +153,13 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
         }
         float kl[3], kq[3];
         drag_of(c, g.d, i, kl, kq);
+        VF_PT(1);
         control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
+        VF_PT(2);
         float reward = 0.0f;
         bool done = false;
         env_epilogue<KIND, false>(c, e, g, i, true, s, sp, wave_first, tile, &reward, &done);
+        VF_PT(3);
         // ---- RolloutBuffer.add + the TimeLimit bookkeeping (k_rollout_post_collect) ----
         r.rewards[row] = reward;
         (t + 1 < r.T ? r.episode_starts + (size_t)(t + 1) * r.N : r.last_starts)[i] = done ? 1.0f : 0.0f;
@@ -172,8 +186,12 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
         }
         g.out.obs = t + 2 < r.T ? r.obs_slots + (size_t)(t + 2) * r.N * 13 : r.obs_final;
         g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
+        VF_PT(4);
     }
     store_agent(g.d.S, Gx, i, s, sp);
+#ifdef VF_PPO_TRACE
+    if (blockIdx.x == 7 && lane == 0) for (int k = 0; k < 5; ++k) vf_ppo_trace[k] = tr[k];
+#endif
 }
 
 }  // namespace vf
@@ -234,3 +252,10 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
     h->dyn.tick += T;
     return VF_OK;
 }
+
+#ifdef VF_PPO_TRACE
+extern "C" int vf_debug_ppo_trace(long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vf::vf_ppo_trace), sizeof(long long) * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
