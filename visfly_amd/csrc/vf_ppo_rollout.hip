@@ -129,6 +129,10 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
         // ~100 live VGPRs and 1.1 KB of scratch per lane.  An opaque copy of the lane id per iteration keeps them just-in-time
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
+        // the delay-ring slot this step swaps its action with: address known now, value needed right after the sampler -- loaded
+        // ahead of the forward (by every lane, from a valid granule when there is no ring: a load under `if` would be waited for
+        // on the spot, see load_spawn_slot)
+        const float4 ring_old = *granule(g.d.S, Gx, i, c.delay_steps > 0 ? VF_G_RING + g.d.head : 0);
         float4 mean = policy_rows<Net, ROWS>(gc, lane_t, row, tile);
         // lane m < ROWS holds the head of its own agent; the replica lanes take it from there
         mean.x = __shfl(mean.x, m); mean.y = __shfl(mean.y, m); mean.z = __shfl(mean.z, m); mean.w = __shfl(mean.w, m);
@@ -143,10 +147,8 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
             float4 an = act;
             if (c.delay_steps > 0) {
                 const int head = g.d.head;
-                float4* slot = granule(g.d.S, Gx, i, VF_G_RING + head);
-                const float4 old = *slot;
-                st4(slot, an);
-                an = old;
+                st4(granule(g.d.S, Gx, i, VF_G_RING + head), an);
+                an = ring_old;
                 sp.vel = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
             }
             a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
