@@ -754,12 +754,14 @@ int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const float* packed,
 
 /* The same construction for PPO's collect_rollouts (SB3 OnPolicyAlgorithm.collect_rollouts, run by utils/algorithms/PPO.py:146;
  * n_steps rounds of policy.forward -> distribution.sample / log_prob -> env.step -> RolloutBuffer.add): T steps in ONE
- * persistent launch, a wave owning 16 agents.  Leaves what T rounds of vf_mlp_forward (both heads) + vf_head_sample (Philox
- * counter sample_step + 1 + t) + vf_env_step + vf_rollout_post_collect leave: the rollout-buffer rows, the compact
- * TimeLimit-bootstrap list (rows in arbitrary order, as from the per-step calls), the per-agent episode statistics, the
- * episode outputs of the last step and the slab.  Bit-identical wherever vf_mlp_forward itself runs the 16-rows-per-wave chain
- * (N <= 16 384); above that the per-step forward is the 32-row chain, whose heads differ from the 16-row chain's in the last
- * bits (different fp32 summation order inside a dot product; tests/test_ppo_gpu.py bounds it). */
+ * persistent launch, a wave owning 16 or 32 agents (the rows-per-wave chain vf_mlp_forward runs N rows on, so that the heads are
+ * the per-step path's to the bit).  Leaves what T rounds of vf_mlp_forward (both heads) + vf_head_sample (Philox counter
+ * sample_step + 1 + t) + vf_env_step + vf_rollout_post_collect leave, bit for bit (tests/test_ppo_gpu.py): the rollout-buffer
+ * rows, the compact TimeLimit-bootstrap list (rows in arbitrary order, as from the per-step calls), the per-agent episode
+ * statistics, the episode outputs of the last step and the slab.  VF_EUNSUPPORTED unless: actor-critic network of the
+ * register-chained classes, Hover / Navigation env with the raw-state observation, thrust / bodyrate actions, Euler, ctrl_delay,
+ * constant wind.
+ * desc: the policy's layer table WITHOUT activation copies (every layer's `save` NULL: inference only). */
 typedef struct vf_ppo_rollout_args {
     int32_t T, w1, capacity, pad0;
     float* obs_state;           /* [T][N][13] RolloutBuffer "state" rows; row 0 = the current observation (caller), row t + 1 by step t */

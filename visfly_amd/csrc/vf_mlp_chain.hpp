@@ -235,7 +235,9 @@ __device__ __forceinline__ void chain_deferred_store(const ChainArgs& g, const C
     }
 }
 
-template <class N, int I>
+// SAVE = false: the caller's layer table keeps no activation copies (inference inside a persistent launch): the trickled stores
+// and their per-item `save != null` branches are not compiled in (2.5 k cycles of 62 k per forward in k_ppo_rollout)
+template <class N, int I, bool SAVE = true>
 __device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& st, int lane, int row, bool live)
 {
     if constexpr (I < N::n_items()) {
@@ -248,6 +250,12 @@ __device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& s
         if constexpr (local == 0) chain_bias_load<N, li>(g, st, h);
         f32x16& acc = st.t[L.out0 + a];
         if constexpr (gq == 0) acc = f32x16{0};
+#ifndef VF_EXP_NO_ITEM_FENCE
+        // the refill load and its address arithmetic issue HERE, between the previous item's MFMAs and this item's (different
+        // accumulators), not between two MFMAs of this item: an extra issue slot between MFMAs on the SAME accumulator costs
+        // ~43 cycles (MI355X_MICROARCH.md, per-instruction constants), and the scheduler liked to put them behind the first one
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float b;
@@ -255,10 +263,10 @@ __device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& s
             else b = st.t[L.in0 + gq / 4][4 * (gq % 4) + j];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
         }
-        chain_deferred_store<N, li, local>(g, st, row, h, live);
+        if constexpr (SAVE) chain_deferred_store<N, li, local>(g, st, row, h, live);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (local == N::items(li) - 1) chain_epilogue<N, li>(g, st, row, h, live);
-        chain_items<N, I + 1>(g, st, lane, row, live);
+        chain_items<N, I + 1, SAVE>(g, st, lane, row, live);
     }
 }
 
@@ -426,7 +434,7 @@ __device__ __forceinline__ void chain16_deferred_store(const ChainArgs& g, const
 // v_mfma_f32_16x16x4_f32 issues every 32 cycles but a MFMA that accumulates into the result of the one before it waits 40
 // (MI355X_MICROARCH.md, per-instruction constants), so four back-to-back MFMAs on one accumulator run at 80 % of the pipe; two
 // accumulators alternating do not wait.  Every accumulator still sees its products in the same order: same bits.
-template <class N, int I>
+template <class N, int I, bool SAVE = true>
 __device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N>& st, int lane, int row, bool live)
 {
     using C = Chain16<N>;
@@ -459,15 +467,15 @@ __device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
             if constexpr (pair) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w1.x : j == 1 ? w1.y : j == 2 ? w1.z : w1.w, b, acc1, 0, 0, 0);
         }
-        chain16_deferred_store<N, li, local>(g, st, row, gq, live);
-        if constexpr (pair) chain16_deferred_store<N, li, local + 1>(g, st, row, gq, live);
+        if constexpr (SAVE) chain16_deferred_store<N, li, local>(g, st, row, gq, live);
+        if constexpr (SAVE && pair) chain16_deferred_store<N, li, local + 1>(g, st, row, gq, live);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (local == 0) VF_TRACE(2 + 2 * li);
         if constexpr (local + step - 1 == C::items(li) - 1) {
             chain16_epilogue<N, li>(g, st, row, gq, live);
             VF_TRACE(3 + 2 * li);
         }
-        chain16_items<N, I + step>(g, st, lane, row, live);
+        chain16_items<N, I + step, SAVE>(g, st, lane, row, live);
     }
 }
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int
                 st.x[b][j] = k < w ? v : 0.0f;
             }
         }
-        chain16_items<Net, 0>(gc, st, lane, row, true);
+        chain16_items<Net, 0, false>(gc, st, lane, row, true);
         const f32x4& y = st.t[2 * Net::t_mean];
         return make_float4(y[0], y[1], y[2], y[3]);
     } else {
@@ -85,7 +85,7 @@ __device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int
                 st.x[b][s] = k < w ? v : 0.0f;
             }
         }
-        chain_items<Net, 0>(gc, st, lane, row, true);
+        chain_items<Net, 0, false>(gc, st, lane, row, true);
         const f32x16& y = st.t[Net::t_mean];
         return make_float4(y[0], y[1], y[2], y[3]);
     }
@@ -133,7 +133,14 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
         // ahead of the forward (by every lane, from a valid granule when there is no ring: a load under `if` would be waited for
         // on the spot, see load_spawn_slot)
         const float4 ring_old = *granule(g.d.S, Gx, i, c.delay_steps > 0 ? VF_G_RING + g.d.head : 0);
-        float4 mean = policy_rows<Net, ROWS>(gc, lane_t, row, tile);
+        // ... and an opaque zero in the weight pointers: the ~170 per-item base addresses (SGPR pairs) are loop-invariant as
+        // well, hoisted they are spilled to VGPR lanes and cost two v_readlane per item
+        long zero_t = 0;
+        asm volatile("" : "+s"(zero_t));
+        ChainArgs gct = gc;
+        gct.packed = gc.packed + zero_t;
+        gct.params = gc.params + zero_t;
+        float4 mean = policy_rows<Net, ROWS>(gct, lane_t, row, tile);
         // lane m < ROWS holds the head of its own agent; the replica lanes take it from there
         mean.x = __shfl(mean.x, m); mean.y = __shfl(mean.y, m); mean.z = __shfl(mean.z, m); mean.w = __shfl(mean.w, m);
         VF_PT(0);
@@ -223,6 +230,8 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
     const vf_env_out* out = a->out;
     if (!out->reward || !out->done || !out->ep_return || !out->ep_length || !out->ep_flags || !out->terminal_obs)
         return vf::fail(VF_EINVAL, "vf_ppo_rollout: out needs reward / done scratch and the episode outputs");
+    for (int l = 0; l < desc->n_layers; ++l)
+        if (desc->layer[l].save) return vf::fail(VF_EINVAL, "vf_ppo_rollout: the layer table must not keep activation copies (layer %d has a save pointer)", l);
     if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_ppo_rollout: vf_env_bind has not been called");
     if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: per-agent wind rows are set");
     if (h->cfg.obs_mode != VF_OBS_STATE) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: raw-state observation only");
