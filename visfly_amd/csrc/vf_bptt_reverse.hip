@@ -49,7 +49,11 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         // of being hoisted out of the t loop into ~100 live registers -- see k_ppo_rollout)
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
-        bwd_rows<P, ROWS>(gb, lane_t, row, row, true);
+        long zero_t = 0;                                             // (likewise for the per-item weight base addresses)
+        asm volatile("" : "+s"(zero_t));
+        BwdArgsChain gbt = gb;
+        gbt.packed = gb.packed + zero_t;
+        bwd_rows<P, ROWS>(gbt, lane_t, row, row, true);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // dLoss / d obs_t: read by the adjoint of step t - 1
     }
 }

@@ -69,12 +69,19 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
             asm volatile("" : "+v"(lane_t));
             const int row = t * r.N + i, rc = row, gq = lane_t >> 4;
             const bool lrow = true;
+            // (... and an opaque zero in the weight pointers: the per-item base addresses are loop-invariant too; hoisted, the SGPR
+            // pairs are spilled to VGPR lanes and read back with two v_readlane per item)
+            long zero_t = 0;
+            asm volatile("" : "+s"(zero_t));
+            ChainArgs gct = gc;
+            gct.packed = gc.packed + zero_t;
+            gct.params = gc.params + zero_t;
             ChainState16<Net> st;
-            chain16_prologue<Net, 0>(gc, st, lane_t);
+            chain16_prologue<Net, 0>(gct, st, lane_t);
 #pragma unroll
             for (int b = 0; b < Net::NB; ++b) {
-                const int w = gc.d.in_dim[b];
-                const float* x = gc.io.in[b] + (size_t)rc * w;
+                const int w = gct.d.in_dim[b];
+                const float* x = gct.io.in[b] + (size_t)rc * w;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * gq + j;
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
                     st.x[b][j] = k < w ? v : 0.0f;
                 }
             }
-            chain16_items<Net, 0>(gc, st, lane_t, row, lrow);
+            chain16_items<Net, 0>(gct, st, lane_t, row, lrow);
         }
         // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
         // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)
