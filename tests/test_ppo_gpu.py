@@ -693,6 +693,44 @@ def test_persistent_rollout_equals_the_per_step_loop(env_name, N):
     assert float((res[0]["1:rewards"].abs() > 0).float().mean()) > 0.5
 
 
+@pytest.mark.parametrize("n_steps", [1, 2])
+def test_persistent_rollout_shortest_horizons(n_steps):
+    """n_steps = 1 / 2: the observation row of the last step goes to the env's own buffer, not to a buffer row"""
+    from visfly_amd.envs import HoverEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    res = []
+    for fused in (True, False):
+        env = HoverEnv(num_agent_per_scene=777, seed=3, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=3, tensor_output=True)
+        ppo = PPO(env, n_steps=n_steps, batch_size=777 * n_steps, n_epochs=1, seed=2)
+        ppo.fused_rollout = fused
+        for _ in range(5):
+            ppo.collect_rollouts()
+        torch.cuda.synchronize()
+        assert ppo.fused_rollout is fused
+        res.append({k: getattr(ppo.buf, k).clone() for k in ("rewards", "values", "advantages", "returns", "episode_starts", "log_probs", "actions")})
+        res[-1]["obs"], res[-1]["last"] = ppo.buf.obs["state"].clone(), ppo._last_obs["state"].clone()
+        env.close()
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
+def test_persistent_rollout_declines_what_it_has_no_kernel_for():
+    """RK4 dynamics: vf_ppo_rollout answers VF_EUNSUPPORTED, collect_rollouts steps launch by launch (and stops asking)"""
+    from visfly_amd.envs import HoverEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    env = HoverEnv(num_agent_per_scene=512, seed=3, dynamics_kwargs=dict(ENV_DYN, integrator="rk4"), device=DEV, max_episode_steps=5,
+                   tensor_output=True)
+    ppo = PPO(env, n_steps=8, batch_size=2048, n_epochs=1, seed=2)
+    assert ppo.fused_rollout is True
+    ppo.collect_rollouts()
+    torch.cuda.synchronize()
+    assert ppo.fused_rollout is False
+    assert torch.isfinite(ppo.buf.advantages).all() and float(ppo._ep_stats[0]) >= 512
+    env.close()
+
+
 def test_ppo_on_a_host_observation_env_values_its_own_terminal_rows():
     """RacingEnv2 hands the policy 16 gate-relative columns assembled on the host: the TimeLimit bootstrap must value THOSE rows
     (env._terminal_state_rows()), not the kernel's raw 13-column terminal state (the width was hard-coded)"""

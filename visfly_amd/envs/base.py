@@ -885,7 +885,8 @@ class DroneGymEnvsBase:
                 or self.envs.dynamics._wind_fn is not None or getattr(self, "_HOST_OBS", False) or not self.tensor_output
                 or getattr(self, "obs_gate_exact", False) or not self._STATIC_OBS_CONST
                 or self._terminal_state_rows() is not self._terminal_obs
-                or any(k not in ("state", "target") for k in obs_keys) or policy._plan is None or not policy.fused):
+                or any(k not in ("state", "target") for k in obs_keys) or policy._plan is None or not policy.fused
+                or policy.obs_dims.get("state") != 13 or buf.obs["state"].shape[-1] != 13):
             return False
         assert self._is_initial, "You should call reset() before step()"
         T, N, dev = buf.actions.shape[0], self.num_agent, self.device
