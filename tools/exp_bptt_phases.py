@@ -41,3 +41,15 @@ for fwd, rev in ((True, True), (True, False), (False, False)):
         ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
         print(f"   {k:24s} {ms:7.3f} ms" + (f"  = {ms / H * 1e3:6.1f} us per step" if "persistent" in k else ""))
     env.close()
+
+# phase split inside the persistent reverse sweep (needs a -DVF_PPO_TRACE build; silently skipped otherwise)
+try:
+    import ctypes as _C
+    from visfly_amd import _lib as _l
+    _L = _C.CDLL(_l.lib()._name)
+    _o = (_C.c_longlong * 8)()
+    _L.vf_debug_rev_trace(_o)
+    print("k_bptt_reverse, one wave, cycles per step: adjoint of the env step %.0f, reverse chain %.0f" % (_o[0] / 64.0, _o[1] / 64.0))
+except AttributeError:
+    pass
+

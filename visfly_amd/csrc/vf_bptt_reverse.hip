@@ -18,6 +18,10 @@
 
 namespace vf {
 
+#ifdef VF_PPO_TRACE
+__device__ long long vf_rev_trace[8];
+#endif
+
 struct RevArgs {
     int H, N, G, g_drag, g_race;
     const float* tape;             // [H] rows of tape_stride floats: the slab before step t
@@ -38,12 +42,19 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [S * kSave][64]
     const int lane = threadIdx.x, m = lane & (ROWS - 1);
     const int i = min((int)blockIdx.x * ROWS + m, r.N - 1);          // lanes past the last agent replicate it as well
+#ifdef VF_PPO_TRACE
+    long long tr[2] = {0, 0}, tc = __builtin_readcyclecounter();
+#define VF_RT(k) do { const long long n_ = __builtin_readcyclecounter(); tr[k] += n_ - tc; tc = n_; } while (0)
+#else
+#define VF_RT(k) do { } while (0)
+#endif
     for (int t = r.H - 1; t >= 0; --t) {
         const BwdArgs g{r.N, r.G, r.g_drag, r.g_race, r.tape + (size_t)t * r.tape_stride, r.actions + (size_t)t * r.N,
                         t + 1 < r.H ? r.g_obs + (size_t)(t + 1) * r.N * 13 : nullptr, r.d_reward + (size_t)t * r.N,
                         r.done + (size_t)t * r.N, r.adj, r.d_action + (size_t)t * r.N};
         env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64>(*cp, *ep, g, i, true, lds + lane);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // d_action_t: written above, read by the head reverse below
+        VF_RT(0);
         const int row = t * r.N + i;
         // (an opaque copy of the lane id per iteration: the chain's loop-invariant per-item load offsets stay just-in-time instead
         // of being hoisted out of the t loop into ~100 live registers -- see k_ppo_rollout)
@@ -55,7 +66,11 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         gbt.packed = gb.packed + zero_t;
         bwd_rows<P, ROWS>(gbt, lane_t, row, row, true);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // dLoss / d obs_t: read by the adjoint of step t - 1
+        VF_RT(1);
     }
+#ifdef VF_PPO_TRACE
+    if (blockIdx.x == 7 && lane == 0) { vf_rev_trace[0] = tr[0]; vf_rev_trace[1] = tr[1]; }
+#endif
 }
 
 }  // namespace vf
@@ -111,3 +126,10 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
+
+#ifdef VF_PPO_TRACE
+extern "C" int vf_debug_rev_trace(long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vf::vf_rev_trace), sizeof(long long) * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
