@@ -134,9 +134,25 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
     # data gradient and weight gradient
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     n0 = ppo._opt_step
+    # the 256 policy -> sample -> env.step -> buffer rounds on their own clock (one persistent launch, vf_ppo_rollout, where the
+    # library has the kernel): events around env.collect_policy
+    roll_ev, inner = [torch.cuda.Event(enable_timing=True) for _ in range(2)], getattr(env, "collect_policy", None)
+    roll = {"fused": False}
+
+    def timed_collect(*a, **k):
+        roll_ev[0].record()
+        r = inner(*a, **k)
+        roll_ev[1].record()
+        roll["fused"] = r is not False
+        return r
+
+    if inner is not None:
+        env.collect_policy = timed_collect
     ev[0].record()
     ppo.collect_rollouts()
     ev[1].record()
+    if inner is not None:
+        del env.collect_policy
     ppo.train()
     ev[2].record()
     torch.cuda.synchronize()
@@ -170,6 +186,8 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
            "value": 256 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
            "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
            "split_ms": {"collect_rollouts": ev[0].elapsed_time(ev[1]), "train": ev[1].elapsed_time(ev[2]),
+                        "rollout_256_steps": roll_ev[0].elapsed_time(roll_ev[1]) if roll["fused"] else None,
+                        "rollout_persistent_launch": roll["fused"],
                         "optimiser_steps": n_upd, "note": "rank 0's device clock: env + policy rollout (no collective) vs "
                                                             "the optimiser steps (one all-reduce each)"},
            "exchange": exchange,
