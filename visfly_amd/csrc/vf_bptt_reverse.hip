@@ -105,6 +105,8 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     const int S = h->dyn.cfg.interval_steps;
     if (S > 10) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: at most 10 sub-steps per control interval");
     const int N = h->dyn.N;
+    if ((int64_t)H * N * 128 * 4 >= (1ll << 32))             // the reverse chain addresses its dZ stores with 32-bit byte offsets
+        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: H x N rows of layer gradients pass 4 GiB per buffer");
     // rows per wave: the choice vf_mlp_backward_data makes for N rows, so that the sweep equals the launch-by-launch one to the bit
     const int cls = vf::bwd_chain_policy_class(desc, N), net = cls & 15;
     const bool r16 = (cls & 16) != 0;

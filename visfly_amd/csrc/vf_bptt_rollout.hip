@@ -156,6 +156,8 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: observation / reward variants have no adjoint");
     if (tape_stride < (int64_t)h->dyn.Npad * h->dyn.G * 4) return vf::fail(VF_EINVAL, "vf_bptt_rollout: tape rows are shorter than the slab");
+    if ((int64_t)H * h->dyn.N * 128 * 4 >= (1ll << 32))      // the chain addresses its activation copies with 32-bit byte offsets
+        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: H x N rows of activation copies pass 4 GiB per buffer");
     const int cls = vf::chain16_policy_class(desc, params);
     RollKernel k = nullptr;
     if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = pick_roll<vf::NetHoverPi, VF_ENV_HOVER>(h->dyn.cfg);

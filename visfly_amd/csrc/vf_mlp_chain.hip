@@ -315,8 +315,13 @@ int bwd_chain_launch(const vf_mlp_bwd_desc& d, const float* packed, int M, hipSt
 // data gradients of the whole network (masked dZ of every hidden layer left in the dY buffers, optional observation
 // gradients): 1 launched, 0 not an instantiated class / variant, < 0 error.  Variants: PPO update (both trunks, no
 // observation gradient) and first-order policy optimisation (policy trunk only, observation gradient).
+// the chains address their activation / gradient stores with 32-bit BYTE offsets (row * ld * 4): rows x widest row < 4 GiB
+static bool rows_fit_u32(int M, int ld_max) { return (unsigned long long)M * (unsigned long long)ld_max * 4ull < (1ull << 32); }
+
 int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rpp)
 {
+    for (int l = 0; l < d->n_layers; ++l)
+        if (!rows_fit_u32(M, d->layer[l].ld_dy)) return 0;
     const ReparamBwd rp = rpp ? *rpp : ReparamBwd{};
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
     if (off) return 0;
@@ -338,6 +343,10 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
     if (off) return 0;
     for (int i = 0; i < d->n_layers; ++i)
         if (d->layer[i].dst < VF_MLP_OUT0 && !d->layer[i].save) return 0;          // the weight gradients need every layer input
+    for (int i = 0; i < d->n_layers; ++i)
+        if (d->layer[i].save && !rows_fit_u32(M, d->layer[i].save_ld)) return 0;
+    for (int l = 0; l < bd->n_layers; ++l)
+        if (!rows_fit_u32(M, bd->layer[l].ld_dy)) return 0;
     ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M, nullptr, nullptr, nullptr, {nullptr, nullptr}};
     BwdArgsChain gb{*bd, packed, M, nullptr, nullptr, nullptr, nullptr, nullptr};
     PpoRowArgs pr{log_std, reinterpret_cast<const float4*>(action), old_lp, adv, ret, part, *cfg};
@@ -360,6 +369,8 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
     const ReparamFwd rp = rpp ? *rpp : ReparamFwd{};
     if (off || (!out0 && !rp.action) || (reinterpret_cast<uintptr_t>(out0) & 15) || (reinterpret_cast<uintptr_t>(rp.action) & 15)) return 0;
+    for (int i = 0; i < d->n_layers; ++i)
+        if (d->layer[i].save && !rows_fit_u32(M, d->layer[i].save_ld)) return 0;
     if (!out1) {      // no value requested: the value trunk is skipped
         if (chain_matches<NetNavPi>(*d) && in1) return chain_launch<NetNavPi>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
         if (chain_matches<NetHoverPi>(*d)) return chain_launch<NetHoverPi>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);

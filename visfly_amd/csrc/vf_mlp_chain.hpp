@@ -222,12 +222,14 @@ __device__ __forceinline__ void chain_deferred_store(const ChainArgs& g, const C
         if constexpr (s0 < s1) {
             const vf_mlp_layer& D = g.d.layer[P.desc];
             if (D.save && live) {
-                const unsigned off = (unsigned)row * (unsigned)D.save_ld + 4u * h;     // lane offset, elements
+                // lane offset in BYTES, 32 bit (the hosts refuse row counts whose buffers pass 4 GiB): scalar base + 32-bit offset
+                // is an addressing mode, a 64-bit element offset is three VALU instructions per store
+                const unsigned off = ((unsigned)row * (unsigned)D.save_ld + 4u * h) * 4u;
 #pragma unroll
                 for (int i = s0; i < s1; ++i) {
                     const int a = i / 4, q = i % 4;
                     const f32x16& y = st.t[P.out0 + a];
-                    float* base = D.save + D.dst_col + 32 * a + 8 * q;               // wave-uniform
+                    char* base = reinterpret_cast<char*>(D.save + D.dst_col + 32 * a + 8 * q);               // wave-uniform
                     *reinterpret_cast<float4*>(base + off) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
                 }
             }
@@ -419,11 +421,11 @@ __device__ __forceinline__ void chain16_deferred_store(const ChainArgs& g, const
         if constexpr (s0 < s1) {
             const vf_mlp_layer& D = g.d.layer[P.desc];
             if (D.save && live) {
-                const unsigned off = (unsigned)row * (unsigned)D.save_ld + 4u * gq;
+                const unsigned off = ((unsigned)row * (unsigned)D.save_ld + 4u * gq) * 4u;        // bytes (chain_deferred_store)
 #pragma unroll
                 for (int a = s0; a < s1; ++a) {
                     const f32x4& y = st.t[2 * P.out0 + a];
-                    *reinterpret_cast<float4*>(D.save + D.dst_col + 16 * a + off) = make_float4(y[0], y[1], y[2], y[3]);
+                    *reinterpret_cast<float4*>(reinterpret_cast<char*>(D.save + D.dst_col + 16 * a) + off) = make_float4(y[0], y[1], y[2], y[3]);
                 }
             }
         }

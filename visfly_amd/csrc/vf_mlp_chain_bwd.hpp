@@ -202,8 +202,8 @@ __device__ __forceinline__ void bwd_deferred_store(const BwdArgsChain& g, const 
                 for (int i = s0; i < s1; ++i) {
                     const int f = i < S0 ? 0 : 1, ii = i - (f ? S0 : 0), a = ii / 4, q = ii % 4;
                     const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
-                    float* base = const_cast<float*>(E.dY) + 32 * a + 8 * q;            // wave-uniform
-                    const unsigned off = (unsigned)row * (unsigned)E.ld_dy + 4u * h;
+                    char* base = reinterpret_cast<char*>(const_cast<float*>(E.dY) + 32 * a + 8 * q);            // wave-uniform
+                    const unsigned off = ((unsigned)row * (unsigned)E.ld_dy + 4u * h) * 4u;                    // bytes (chain_deferred_store)
                     const f32x16& v = st.t[Q.fin[f].t0 + a];
                     *reinterpret_cast<float4*>(base + off) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 }
@@ -428,8 +428,8 @@ __device__ __forceinline__ void bwd16_deferred_store(const BwdArgsChain& g, cons
                 for (int i = s0; i < s1; ++i) {
                     const int f = i < S0 ? 0 : 1, a = i - (f ? S0 : 0);
                     const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
-                    float* base = const_cast<float*>(E.dY) + 16 * a;                    // wave-uniform
-                    const unsigned off = (unsigned)row * (unsigned)E.ld_dy + 4u * gq;
+                    char* base = reinterpret_cast<char*>(const_cast<float*>(E.dY) + 16 * a);                    // wave-uniform
+                    const unsigned off = ((unsigned)row * (unsigned)E.ld_dy + 4u * gq) * 4u;                   // bytes
                     const f32x4& v = st.t[2 * Q.fin[f].t0 + a];
                     *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
                 }
