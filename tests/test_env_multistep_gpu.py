@@ -274,7 +274,7 @@ def test_export_pose_wind_and_partial_outputs():
     assert _lib.lib().vf_env_export_pose(None, None, None, None, None, None) == -1
 
 
-@pytest.mark.parametrize("kind", ["hover", "nav_dr", "racing"])
+@pytest.mark.parametrize("kind", ["hover", "nav_dr", "racing", "hover_many"])
 def test_prefetched_respawn_is_bit_identical(kind):
     """spawn_prefetch (helper blocks of the step launch draw every agent's NEXT re-spawn state ahead of time into the slab; a
     wave that ends an episode only loads it) against the in-place draw: same Philox keys, so every output of every step --
@@ -282,6 +282,8 @@ def test_prefetched_respawn_is_bit_identical(kind):
     U(-1,1) actions, so that re-spawns happen in every step, incl. episodes of length one (which fall back to the in-place draw)"""
     import visfly_amd.envs as E
     N, steps = 65536 + 192, 70
+    if kind == "hover_many":     # more than two waves per SIMD: the kernel variant whose ending lanes load the copy lazily (k_env_step LAZY_SLOT)
+        N, steps = 2 * 65536 + 320, 24
     spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 0.6], "half": [1., 1., 0.58]},
                                                                 "orientation": {"mean": [0., 0., 0.], "half": [0.3, 0.3, 3.0]},
                                                                 "velocity": {"mean": [0., 0., 0.], "half": [1., 1., 1.]}}]}}

@@ -13,7 +13,11 @@
 
 namespace vf {
 
-template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+// LAZY_SLOT: the prefetched re-spawn copy is loaded only by the lanes that end an episode instead of by every lane
+// (load_spawn_slot).  One wave per SIMD: an ending wave must not sit out the load latency -> every lane loads.  More than two waves
+// per SIMD: the step is bandwidth-bound, a stalled wave costs nothing and 64 B per agent of loads nobody looks at cost 7 %
+// (1 M agents: 99 vs 92.5 us) -> lazily.  Two kernels, not a branch: both epilogues in one kernel cost the small launch 0.1 us.
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY, bool LAZY_SLOT = false>
 __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g)
 {
     const vf_dyn_cfg& c = *cp;   // persistent device copies (vf_handles.hpp): L2-resident from launch to launch
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     drag_of(c, g.d, i, kl, kq);
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
     const int wave = threadIdx.x >> 6;
-    env_epilogue<KIND>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+    env_epilogue<KIND, true, false, LAZY_SLOT>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
 }
 
 // The part of the step that follows the dynamics interval, as a launch of its own (vf_env_finish_step): the dynamics ran
@@ -250,27 +254,33 @@ namespace {
 
 using EnvKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvArgs);
 
-template <int KIND, int ACT>
+template <int KIND, int ACT, bool LAZY>
 EnvKernel pick_env_kernel_ka(const vf_dyn_cfg& c)
 {
     const int key = (c.integrator == VF_INT_RK4 ? 2 : 0) | (c.ctrl_delay ? 1 : 0);
     switch (key) {
-    case 0: return vf::k_env_step<KIND, ACT, VF_INT_EULER, false>;
-    case 1: return vf::k_env_step<KIND, ACT, VF_INT_EULER, true>;
-    case 2: return vf::k_env_step<KIND, ACT, VF_INT_RK4, false>;
-    default: return vf::k_env_step<KIND, ACT, VF_INT_RK4, true>;
+    case 0: return vf::k_env_step<KIND, ACT, VF_INT_EULER, false, LAZY>;
+    case 1: return vf::k_env_step<KIND, ACT, VF_INT_EULER, true, LAZY>;
+    case 2: return vf::k_env_step<KIND, ACT, VF_INT_RK4, false, LAZY>;
+    default: return vf::k_env_step<KIND, ACT, VF_INT_RK4, true, LAZY>;
+    }
+}
+
+template <int KIND, bool LAZY>
+EnvKernel pick_env_kernel_kl(const vf_dyn_cfg& c)
+{
+    switch (c.action_type) {
+    case VF_ACT_THRUST: return pick_env_kernel_ka<KIND, VF_ACT_THRUST, LAZY>(c);
+    case VF_ACT_BODYRATE: return pick_env_kernel_ka<KIND, VF_ACT_BODYRATE, LAZY>(c);
+    case VF_ACT_VELOCITY: return pick_env_kernel_ka<KIND, VF_ACT_VELOCITY, LAZY>(c);
+    default: return pick_env_kernel_ka<KIND, VF_ACT_POSITION, LAZY>(c);
     }
 }
 
 template <int KIND>
-EnvKernel pick_env_kernel_k(const vf_dyn_cfg& c)
+EnvKernel pick_env_kernel_k(const vf_dyn_cfg& c, bool lazy)
 {
-    switch (c.action_type) {
-    case VF_ACT_THRUST: return pick_env_kernel_ka<KIND, VF_ACT_THRUST>(c);
-    case VF_ACT_BODYRATE: return pick_env_kernel_ka<KIND, VF_ACT_BODYRATE>(c);
-    case VF_ACT_VELOCITY: return pick_env_kernel_ka<KIND, VF_ACT_VELOCITY>(c);
-    default: return pick_env_kernel_ka<KIND, VF_ACT_POSITION>(c);
-    }
+    return lazy ? pick_env_kernel_kl<KIND, true>(c) : pick_env_kernel_kl<KIND, false>(c);
 }
 
 template <int KIND, int ACT>
@@ -333,10 +343,11 @@ EnvKernel pick_env_split(const vf_env* h)
 
 EnvKernel pick_env_kernel(const vf_env* h)
 {
+    const bool lazy = h->dyn.Npad > 2 * 65536;          // more than two waves per SIMD (k_env_step, LAZY_SLOT)
     switch (h->cfg.kind) {
-    case VF_ENV_HOVER: return pick_env_kernel_k<VF_ENV_HOVER>(h->dyn.cfg);
-    case VF_ENV_NAV: return pick_env_kernel_k<VF_ENV_NAV>(h->dyn.cfg);
-    default: return pick_env_kernel_k<VF_ENV_RACING>(h->dyn.cfg);
+    case VF_ENV_HOVER: return pick_env_kernel_k<VF_ENV_HOVER>(h->dyn.cfg, lazy);
+    case VF_ENV_NAV: return pick_env_kernel_k<VF_ENV_NAV>(h->dyn.cfg, lazy);
+    default: return pick_env_kernel_k<VF_ENV_RACING>(h->dyn.cfg, lazy);
     }
 }
 

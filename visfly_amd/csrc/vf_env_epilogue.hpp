@@ -103,7 +103,7 @@ __device__ __forceinline__ SpawnSlot load_spawn_slot(const EnvArgs& g, int i)
     return slot;
 }
 
-template <int KIND, bool STORE_STATE = true, bool EXT = false>
+template <int KIND, bool STORE_STATE = true, bool EXT = false, bool LAZY_SLOT = false>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile, float* reward_reg = nullptr,
                                              bool* done_reg = nullptr)
@@ -142,14 +142,11 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
 #else
     const bool use_slot = done && g.auto_reset && g.g_spawn_rd >= 0;
 #endif
-#if VF_EXP_SLOT_MODE == 1
-    slot = load_spawn_slot(g, i);     // (issuing them ahead of the dynamics interval instead: same times, 16 registers more)
-#else
-    if (use_slot) {
-        const float4* src = granule(g.d.S, g.d.G, i, g.g_spawn_rd);
-        slot.g0 = src[0]; slot.g1 = src[64]; slot.g2 = src[128]; slot.g3 = src[192];
+    if constexpr (VF_EXP_SLOT_MODE == 1 && !LAZY_SLOT) {
+        slot = load_spawn_slot(g, i);     // (issuing them ahead of the dynamics interval instead: same times, 16 registers more)
+    } else {
+        if (use_slot) slot = load_spawn_slot(g, i);
     }
-#endif
     float reward;
     int gate = 0, passed = 0, gate_pre = 0;   // gate_pre: the index the terminal observation carries -- the observation is
                                               // refreshed before get_success() advances it (droneGymEnv.py:161-166,197-208)
