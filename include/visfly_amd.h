@@ -193,7 +193,8 @@ int vf_dyn_time_steps(vf_dyn* h, const float* action, float* state_out, int32_t 
  * vf_env_step launches twice the blocks: the second half are HELPER blocks that look at their 64 agents' episode counter and
  * refill stale copies (tag != episode + 1) of the buffer this launch does NOT read -- they share the SIMDs with the main waves,
  * which leave three of four issue slots idle -- while a main wave that ends an episode takes the 4 granules of the OTHER buffer
- * (loaded by every lane in the step's epilogue, looked at only by an ending agent) if their tag is the episode it needs, and falls back to drawing in place otherwise (first
+ * (up to two waves per SIMD: loaded by every lane in the step's epilogue, looked at only by an ending agent; above: loaded by
+ * the ending lanes) if their tag is the episode it needs, and falls back to drawing in place otherwise (first
  * episodes after a reset, episodes of length one).  Buffers alternate with the step parity, so a copy is never read and
  * written in the same launch; results are bit-identical to the in-place draw (tests/test_env_gpu.py).
  * vf_env_rollout_fused, the two-wave split kernels (<= 32 768 agents) and vf_env_finish_step always draw in place.
