@@ -6,7 +6,7 @@
 // (~4 us of launch boundary, first-touch misses on kernel arguments and weights, the state round trip through HBM), 32-35 us per
 // step at 16 384 agents for ~17 us of work.  Here a wave owns 16 agents for the whole horizon:
 //   * the policy forward is the 16-rows-per-wave chain of vf_mlp_chain.hpp (v_mfma_f32_16x16x4_f32, activations in accumulator
-//     registers, weights straight from the row-major parameter buffer -- L2-resident after the first step);
+//     registers, weights from the transposed image of the packed buffer -- L2-resident after the first step);
 //   * the env step is the same per-agent code as k_env_step (control_interval + env_epilogue), the agent's state staying in
 //     registers from step to step like in k_env_rollout.  One lane per agent: lanes 16..63 replicate the agent of lane & 15
 //     (same loads, same arithmetic, same stores of the same values) -- the step is bound by single-wave instruction issue,

@@ -220,6 +220,7 @@ bool chain16_ok(const vf_mlp_desc& d, const float* params, int M)
     for (int i = 0; i < N::n_exec; ++i) {
         const vf_mlp_layer& L = d.layer[N::layer(i).desc];
         if (N::layer(i).obs < 0 && ((L.w_off & 3) || (L.K & 15))) return false;
+        if (L.wt_off < 0) return false;               // the transposed image the A fragments come from (chain16_load)
     }
     return true;
 }

@@ -8,6 +8,9 @@
 
 #include <type_traits>
 
+#ifndef VF_CHAIN16_WT
+#define VF_CHAIN16_WT 1      // 0: A fragments of the 16-row forward as float4 of the row-major parameter buffer (A/B)
+#endif
 #ifndef VF_CHAIN16_DEPTH
 #define VF_CHAIN16_DEPTH 24
 #endif
@@ -292,7 +295,10 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs& g, ChainState<N>
 //     C / D     = Y^T       D[i = n][j = m] lane (m, gq = lane >> 4) holds n = 4 gq + r, r = 0..3
 // An accumulator lane holds features 4 gq .. 4 gq + 3 of its own row: as the B operand of step r of the next layer it supplies
 // k = (feature 4 gq + r of that 16-feature tile), so step r's A fragment is W[n][16 T + 4 gq + r] -- the four steps of an
-// (output tile, input tile) pair are ONE float4 of the row-major weight matrix itself.  No packed image at all.
+// (output tile, input tile) pair are ONE float4 of the row-major weight matrix itself -- which is how they were read until a
+// look at the access pattern: a quarter-wave of that load is 16 lanes n with 16 different rows, 16 B out of each of 16 lines.
+// They are now four dwords of the TRANSPOSED image the block-tile forward keeps anyway (Wt[k][n], vf_mlp_layer.wt_off), whose
+// quarter-waves read 64 contiguous bytes: a quarter of the L1 line accesses, -2.5 us per step in k_bptt_rollout (chain16_load).
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 #ifdef VF_CHAIN_TRACE
@@ -347,6 +353,16 @@ __device__ __forceinline__ float4 chain16_load(const ChainArgs& g, int lane)
     constexpr ChainLayer L = N::layer(li);
     constexpr int T = local / C::nout(li), a = local % C::nout(li);
     const vf_mlp_layer& D = g.d.layer[L.desc];
+#if VF_CHAIN16_WT
+    {   // four dwords of the zero-padded TRANSPOSED image (vf_mlp_layer.wt_off: Wt[k][n], rows of N32 floats): a quarter-wave (16
+        // lanes n, one k) reads 64 contiguous bytes.  The float4 W[n][16 T + 4 gq ..] of the row-major parameters is one
+        // instruction instead of four, but its quarter-waves touch 16 rows each: 64 line accesses per item instead of 16
+        constexpr int N32 = N::is_head(li) ? 32 : 32 * L.nout;
+        const char* base = reinterpret_cast<const char*>(g.packed + D.wt_off + (16 * T * N32 + 16 * a));     // wave-uniform
+        const float* p = reinterpret_cast<const float*>(base + ((unsigned)(lane >> 4) * (4u * N32) + (unsigned)(lane & 15)) * 4u);
+        return make_float4(p[0], p[N32], p[2 * N32], p[3 * N32]);
+    }
+#endif
     const int n = 16 * a + (lane & 15), gq = lane >> 4;
     const float* w = g.params + D.w_off;
     if constexpr (L.obs >= 0) {          // K = in_dim <= 16, rows not 16-byte aligned: guarded scalar loads
