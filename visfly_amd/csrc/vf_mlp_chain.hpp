@@ -9,7 +9,8 @@
 #include <type_traits>
 
 #ifndef VF_CHAIN16_WT
-#define VF_CHAIN16_WT 1      // 0: A fragments of the 16-row forward as float4 of the row-major parameter buffer (A/B)
+#define VF_CHAIN16_WT 2      // A fragments of the 16-row forward: 2 = float4 of the 32-row chain's image (hidden layers), 1 = four dwords of the
+                             // transposed image, 0 = float4 of the row-major parameter buffer (A/B)
 #endif
 #ifndef VF_CHAIN16_DEPTH
 #define VF_CHAIN16_DEPTH 24
@@ -297,8 +298,10 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs& g, ChainState<N>
 // k = (feature 4 gq + r of that 16-feature tile), so step r's A fragment is W[n][16 T + 4 gq + r] -- the four steps of an
 // (output tile, input tile) pair are ONE float4 of the row-major weight matrix itself -- which is how they were read until a
 // look at the access pattern: a quarter-wave of that load is 16 lanes n with 16 different rows, 16 B out of each of 16 lines.
-// They are now four dwords of the TRANSPOSED image the block-tile forward keeps anyway (Wt[k][n], vf_mlp_layer.wt_off), whose
-// quarter-waves read 64 contiguous bytes: a quarter of the L1 line accesses, -2.5 us per step in k_bptt_rollout (chain16_load).
+// Hidden layers now take the float4 from the 32-row chain's own image, where the same four values of lane (n, kq) sit in lane
+// order (chain16_load: quarter-waves of 256 contiguous bytes); observation layers four dwords of the transposed image of the
+// block-tile forward (Wt[k][n], vf_mlp_layer.wt_off; quarter-waves of 64 contiguous bytes).  A quarter of the L1 line accesses:
+// -3.2 us per step in k_bptt_rollout.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 #ifdef VF_CHAIN_TRACE
@@ -353,6 +356,18 @@ __device__ __forceinline__ float4 chain16_load(const ChainArgs& g, int lane)
     constexpr ChainLayer L = N::layer(li);
     constexpr int T = local / C::nout(li), a = local % C::nout(li);
     const vf_mlp_layer& D = g.d.layer[L.desc];
+#if VF_CHAIN16_WT == 2
+    if constexpr (L.obs < 0) {
+        // ONE float4 of the 32-row chain's own image (vf_mlp_layer.wr_off, block (a, g) = 1 KiB, lane l = n + 32 h holds
+        // W[32 a + n][32 (g >> 2) + 8 (g & 3) + 4 h .. + 3]): the fragment of lane (i, kq) for output 16-tile a16, input 16-tile T is the
+        // float4 of lane 16 (a16 & 1) + i + 32 (kq & 1) in block (a16 / 2, 4 (T >> 1) + 2 (T & 1) + (kq >> 1)); a quarter-wave reads
+        // 256 contiguous bytes
+        constexpr int G = N::groups(li), blk = (a >> 1) * G + 4 * (T >> 1) + 2 * (T & 1);
+        const char* base = reinterpret_cast<const char*>(g.packed + D.wr_off) + (blk * 1024 + 256 * (a & 1));       // wave-uniform
+        const unsigned kq = lane >> 4;
+        return *reinterpret_cast<const float4*>(base + ((kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u));
+    }
+#endif
 #if VF_CHAIN16_WT
     {   // four dwords of the zero-padded TRANSPOSED image (vf_mlp_layer.wt_off: Wt[k][n], rows of N32 floats): a quarter-wave (16
         // lanes n, one k) reads 64 contiguous bytes.  The float4 W[n][16 T + 4 gq ..] of the row-major parameters is one

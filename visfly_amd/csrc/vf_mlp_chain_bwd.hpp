@@ -314,9 +314,9 @@ __device__ __forceinline__ void bwd_tail_store(const BwdArgsChain& g, const BwdS
 //     B operand = dZ^T    B[kk = n][j = m]   lane = m + 16 kq
 //     C / D     = dX^T    D[i = k][j = m]    lane (m, gq = lane >> 4) holds k = 4 gq + r, r = 0..3
 // A gradient-tile lane holds features 4 gq + r of its own row; as the B operand of step r it supplies n = 16 T + 4 kq + r, so step
-// r's A fragment is W[16 T + 4 kq + r][16 a + i]: read from the zero-padded row-major data-gradient image the block-tile
-// kernel uses (vf_mlp_layer.wb_off: round16(No) rows of round32(K) floats), four dwords per (input tile T, output tile a)
-// item; no image of its own.  Heads (4 / 1 input features) are ONE MFMA per output tile: B = the lane's kq-th head gradient.
+// r's A fragment is W[16 T + 4 kq + r][16 a + i]: the four steps of an (input tile T, output tile a) item are one float4 of the
+// 32-row reverse chain's image (vf_mlp_layer.wq_off, bwd16_load), in lane order; no image of its own.  (Four dwords of the
+// zero-padded row-major data-gradient image, vf_mlp_layer.wb_off, are the A/B alternative: same time.)  Heads (4 / 1 input features) are ONE MFMA per output tile: B = the lane's kq-th head gradient.
 // Summation order inside a dot product differs from the 32-row chain's (4 products per MFMA instead of 2), so the two agree to
 // rounding, not to the bit: callers pick ONE of them per row count (bwd16_ok, the forward's rule) on every path.
 // ------------------------------------------------------------------------------------------------
@@ -361,6 +361,21 @@ __device__ __forceinline__ float4 bwd16_load(const BwdArgsChain& g, int lane)
     constexpr int oi = B::op_of(I), local = I - B::first_item(oi);
     constexpr BwdOp O = P::op(oi);
     constexpr int T = local / B::nout(oi), a = local % B::nout(oi), K32 = B::k32(oi);
+#if VF_CHAIN16_WT == 2
+    {   // ONE float4 of the 32-row reverse chain's own image (vf_mlp_layer.wq_off, block (a, g) = 1 KiB, lane l = k + 32 h holds
+        // W[32 (g >> 2) + 8 (g & 3) + 4 h .. + 3][32 a + k]): the fragment of lane (i, kq) for output 16-tile a16, input 16-tile T is
+        // the float4 of lane 16 (a16 & 1) + i + 32 (kq & 1) in block (a16 / 2, 4 (T >> 1) + 2 (T & 1) + (kq >> 1)); quarter-waves of
+        // 256 contiguous bytes, one instruction per item (chain16_load).  Heads: component kq of lane k's float4 in block (a, 0)
+        constexpr int GQ = O.in_kind == 0 ? O.G : 1;
+        constexpr int blk = (a >> 1) * GQ + (O.in_kind == 0 ? 4 * (T >> 1) + 2 * (T & 1) : 0);
+        const char* qb = reinterpret_cast<const char*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off) + (blk * 1024 + 256 * (a & 1));
+        const unsigned kq = lane >> 4;
+        if constexpr (O.in_kind == 0)
+            return *reinterpret_cast<const float4*>(qb + ((kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u));
+        else
+            return make_float4(*reinterpret_cast<const float*>(qb + ((unsigned)(lane & 15) * 16u + kq * 4u)), 0.0f, 0.0f, 0.0f);
+    }
+#endif
     const float* base = g.packed + g.d.layer[P::entry(O.fl)].wb_off;             // wave-uniform
     if constexpr (O.in_kind == 0) {
         const float* p = base + (16 * T * K32 + 16 * a) + ((unsigned)(lane >> 4) * (4u * K32) + (unsigned)(lane & 15));
