@@ -52,10 +52,15 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         const BwdArgs g{r.N, r.G, r.g_drag, r.g_race, r.tape + (size_t)t * r.tape_stride, r.actions + (size_t)t * r.N,
                         t + 1 < r.H ? r.g_obs + (size_t)(t + 1) * r.N * 13 : nullptr, r.d_reward + (size_t)t * r.N,
                         r.done + (size_t)t * r.N, r.adj, r.d_action + (size_t)t * r.N};
+        const int row = t * r.N + i;
+        // the masks of this step's reverse chain (saved activations of slot t: written a forward sweep ago, HBM by now) are loaded
+        // HERE, ahead of the adjoint, which covers their latency; issued inside the chain, whose ops are over long before their
+        // own loads are back, they cost 5 of the step's 31 us
+        BwdState16<P> st16;
+        if constexpr (ROWS == 16) bwd16_mask_preload<P, 0>(gb, st16, row, lane >> 4);
         env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64>(*cp, *ep, g, i, true, lds + lane);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // d_action_t: written above, read by the head reverse below
         VF_RT(0);
-        const int row = t * r.N + i;
         // (an opaque copy of the lane id per iteration: the chain's loop-invariant per-item load offsets stay just-in-time instead
         // of being hoisted out of the t loop into ~100 live registers -- see k_ppo_rollout)
         int lane_t = lane;
@@ -64,7 +69,15 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         asm volatile("" : "+s"(zero_t));
         BwdArgsChain gbt = gb;
         gbt.packed = gb.packed + zero_t;
-        bwd_rows<P, ROWS>(gbt, lane_t, row, row, true);
+        if constexpr (ROWS == 16) {
+            const int gq = lane_t >> 4;
+            bwd16_prologue<P, 0>(gbt, st16, lane_t);
+            bwd16_head_prologue<P, 0, true>(gbt, st16, row, gq, true);
+            bwd16_items<P, 0, true>(gbt, st16, lane_t, row, row, true);
+            bwd16_tail_store<P>(gbt, st16, row, gq, true);
+        } else {
+            bwd_rows<P, ROWS>(gbt, lane_t, row, row, true);
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // dLoss / d obs_t: read by the adjoint of step t - 1
         VF_RT(1);
     }

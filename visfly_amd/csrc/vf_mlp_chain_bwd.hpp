@@ -326,6 +326,20 @@ struct Bwd16 {
     static constexpr int nout(int oi) { return P::op(oi).obs >= 0 ? 1 : 2 * P::op(oi).nout; }       // 16-feature output tiles
     static constexpr int k32(int oi) { return P::op(oi).obs >= 0 ? 32 : 32 * P::op(oi).nout; }      // row length of the wb image
     static constexpr int items(int oi) { return nin(oi) * nout(oi); }
+    // mask float4s (saved activations of the 16-tiles an op finalises) live in ONE register array, op oi's at mask0(oi) ..
+    static constexpr int nmask(int oi)
+    {
+        int n = 0;
+        for (int f = 0; f < P::op(oi).nfin; ++f) n += 2 * P::op(oi).fin[f].nt;
+        return n;
+    }
+    static constexpr int mask0(int oi)
+    {
+        int n = 0;
+        for (int i = 0; i < oi; ++i) n += nmask(i);
+        return n;
+    }
+    static constexpr int n_masks() { return mask0(P::n_ops); }
     static constexpr int n_items()
     {
         int n = 0;
@@ -350,8 +364,9 @@ template <class P>
 struct BwdState16 {
     f32x4 t[2 * P::n_tiles];
     float4 ring[kChain16Depth];  // the four A fragments of an item
-    float4 ym[8];                // saved activations (mask source) of the 16-tiles being finalised
+    float4 ym[Bwd16<P>::n_masks() > 0 ? Bwd16<P>::n_masks() : 1];   // saved activations (mask source) of the 16-tiles every op finalises
     float hin[2];                // this lane's element of the head gradients: d_mean[kq] / d_value (kq = 0), else 0
+    float4 pa, pe, pg;           // preloaded action / noise / log_std-gradient rows of the action head's reverse (bwd16_mask_preload)
 };
 
 template <class P, int I>
@@ -390,12 +405,28 @@ template <class P, int OI>
 __device__ __forceinline__ void bwd16_mask_load(const BwdArgsChain& g, BwdState16<P>& st, int rc, int gq)
 {
     constexpr BwdOp O = P::op(OI);
+    constexpr int m0 = Bwd16<P>::mask0(OI);
 #pragma unroll
     for (int f = 0; f < O.nfin; ++f) {
         const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fin[f].fl)];
         const float* y = E.Y + (size_t)rc * E.ld_y + 4 * gq;
+        const int f0 = f == 0 ? 0 : 2 * O.fin[0].nt;
 #pragma unroll
-        for (int a = 0; a < 2 * O.fin[f].nt; ++a) st.ym[2 * O.fin[f].ym0 + a] = *reinterpret_cast<const float4*>(y + 16 * a);
+        for (int a = 0; a < 2 * O.fin[f].nt; ++a) st.ym[m0 + f0 + a] = *reinterpret_cast<const float4*>(y + 16 * a);
+    }
+}
+
+// every op's masks at once (a persistent sweep issues them ahead of the step's adjoint: the saved activations of a slot were
+// written a whole forward sweep ago, HBM by now, and an op is over long before its own loads would be back)
+template <class P, int OI>
+__device__ __forceinline__ void bwd16_mask_preload(const BwdArgsChain& g, BwdState16<P>& st, int rc, int gq)
+{
+    if constexpr (OI == 0) {       // ... and the rows of the action head's reverse that do not depend on the adjoint
+        if (g.rp_d_action) { st.pa = g.rp_action[rc]; st.pe = g.rp_eps[rc]; st.pg = g.rp_g_log_std[rc]; }
+    }
+    if constexpr (OI < P::n_ops) {
+        bwd16_mask_load<P, OI>(g, st, rc, gq);
+        bwd16_mask_preload<P, OI + 1>(g, st, rc, gq);
     }
 }
 
@@ -408,7 +439,7 @@ __device__ __forceinline__ void bwd16_finalize(const BwdArgsChain& g, BwdState16
 #pragma unroll
         for (int a = 0; a < 2 * O.fin[f].nt; ++a) {
             f32x4& v = st.t[2 * O.fin[f].t0 + a];
-            const float4 y = st.ym[2 * O.fin[f].ym0 + a];
+            const float4 y = st.ym[Bwd16<P>::mask0(OI) + (f == 0 ? 0 : 2 * O.fin[0].nt) + a];
             v[0] = y.x > 0.0f ? v[0] : 0.0f;
             v[1] = y.y > 0.0f ? v[1] : 0.0f;
             v[2] = y.z > 0.0f ? v[2] : 0.0f;
@@ -454,7 +485,7 @@ __device__ __forceinline__ void bwd16_deferred_store(const BwdArgsChain& g, cons
 }
 
 // (items (T, a), (T, a + 1) as one step with their MFMAs interleaved: see chain16_items)
-template <class P, int I>
+template <class P, int I, bool PRE = false>
 __device__ __forceinline__ void bwd16_items(const BwdArgsChain& g, BwdState16<P>& st, int lane, int row, int rc, bool live)
 {
     using B = Bwd16<P>;
@@ -472,7 +503,7 @@ __device__ __forceinline__ void bwd16_items(const BwdArgsChain& g, BwdState16<P>
             w1 = st.ring[(I + 1) % kChain16Depth];
             if constexpr (I + 1 + kChain16Depth < B::n_items()) st.ring[(I + 1) % kChain16Depth] = bwd16_load<P, I + 1 + kChain16Depth>(g, lane);
         }
-        if constexpr (local == 0 && O.in_kind == 0) bwd16_mask_load<P, oi>(g, st, rc, gq);            // head ops: in the prologue
+        if constexpr (local == 0 && O.in_kind == 0 && !PRE) bwd16_mask_load<P, oi>(g, st, rc, gq);    // head ops: in the prologue
         f32x4& acc = st.t[2 * O.out0 + a];
         f32x4& acc1 = st.t[2 * O.out0 + a + (pair ? 1 : 0)];
         if constexpr (T == 0 && !O.accum) {
@@ -493,7 +524,7 @@ __device__ __forceinline__ void bwd16_items(const BwdArgsChain& g, BwdState16<P>
         if constexpr (pair) bwd16_deferred_store<P, oi, local + 1>(g, st, row, gq, live);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (local + step - 1 == B::items(oi) - 1) bwd16_finalize<P, oi>(g, st, row, gq, live);
-        bwd16_items<P, I + step>(g, st, lane, row, rc, live);
+        bwd16_items<P, I + step, PRE>(g, st, lane, row, rc, live);
     }
 }
 
@@ -506,7 +537,7 @@ __device__ __forceinline__ void bwd16_prologue(const BwdArgsChain& g, BwdState16
     }
 }
 
-template <class P, int OI>
+template <class P, int OI, bool PRE = false>
 __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdState16<P>& st, int rc, int gq, bool live)
 {
     if constexpr (OI < P::n_ops) {
@@ -517,11 +548,11 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
             if constexpr (O.in_kind == 1) {
                 float4 dm;
                 if (g.rp_d_action) {       // k_reparam_bwd's arithmetic; lane group 0 of a live row writes d_mean / g_log_std
-                    const float4 da = g.rp_d_action[rc], a = g.rp_action[rc], e = g.rp_eps[rc];
+                    const float4 da = g.rp_d_action[rc], a = PRE ? st.pa : g.rp_action[rc], e = PRE ? st.pe : g.rp_eps[rc];
                     dm = make_float4(da.x * (1.0f - a.x * a.x), da.y * (1.0f - a.y * a.y), da.z * (1.0f - a.z * a.z), da.w * (1.0f - a.w * a.w));
                     if (live && gq == 0) {
                         *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
-                        float4 gl = g.rp_g_log_std[rc];
+                        float4 gl = PRE ? st.pg : g.rp_g_log_std[rc];
                         gl.x += dm.x * expf(g.rp_log_std[0]) * e.x; gl.y += dm.y * expf(g.rp_log_std[1]) * e.y;
                         gl.z += dm.z * expf(g.rp_log_std[2]) * e.z; gl.w += dm.w * expf(g.rp_log_std[3]) * e.w;
                         g.rp_g_log_std[rc] = gl;
@@ -533,8 +564,8 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
             } else {
                 st.hin[1] = gq == 0 ? dy[0] : 0.0f;
             }
-            bwd16_mask_load<P, OI>(g, st, rc, gq);
-            bwd16_head_prologue<P, OI + 1>(g, st, rc, gq, live);
+            if constexpr (!PRE) bwd16_mask_load<P, OI>(g, st, rc, gq);
+            bwd16_head_prologue<P, OI + 1, PRE>(g, st, rc, gq, live);
         }
     }
 }
