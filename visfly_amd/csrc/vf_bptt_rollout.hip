@@ -104,7 +104,11 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         if (c.delay_steps > 0) sp.vel = head_bits;
         float kl[3], kq[3];
         drag_of(c, g.d, ic, kl, kq);
+        // the noise row of the NEXT step's action head (drawn before the launch: HBM-cold) is touched here, under the dynamics
+        // interval; the head's own load at the end of the next forward then finds it in the cache instead of waiting for HBM
+        const float4 eps_touch = gc.rp_eps[(size_t)(t + 1 < r.H ? t + 1 : t) * r.N + i];
         control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
+        asm volatile("" :: "v"(eps_touch.x), "v"(eps_touch.y), "v"(eps_touch.z), "v"(eps_touch.w));
         float reward = 0.0f;
         bool done = false;
         env_epilogue<KIND, false>(c, e, g, ic, live, s, sp, wave_first, tile, &reward, &done);
