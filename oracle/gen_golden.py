@@ -428,25 +428,25 @@ RACING_TEST_GATES = [[2.1, 0.1, 1.0], [6., 2., 1.45], [6.1, -2., 1.5], [2., 2.1,
 
 ENV_CASES = {
     # name: (env, ctor kwargs, hover, scale, steps)
-    "env_hover": ("hover", dict(max_episode_steps=64), [-1 / 3, 0, 0, 0], 0.5, 200),
+    "env_hover": ("hover", dict(max_episode_steps=64), [-1 / 3, 0, 0, 0], 0.5, 256),
     "env_hover_256": ("hover", dict(max_episode_steps=256), [-1 / 3, 0, 0, 0], 0.3, 256),
     "env_nav": ("nav", dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [
-        {"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}), [-0.2, 0, 0, 0], 0.6, 200),
-    "env_racing": ("racing", dict(max_episode_steps=48), [-0.8333] * 4, 0.08, 160),
-    "env_racing2": ("racing2", dict(max_episode_steps=48), [-0.8333] * 4, 0.08, 120),
+        {"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}), [-0.2, 0, 0, 0], 0.6, 256),
+    "env_racing": ("racing", dict(max_episode_steps=48), [-0.8333] * 4, 0.08, 256),
+    "env_racing2": ("racing2", dict(max_episode_steps=48), [-0.8333] * 4, 0.08, 256),
     "env_nav_close": ("nav", dict(max_episode_steps=96, target=[2.5, 0., 1.5], random_kwargs={"state_generator": {
         "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
                                         "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
                                         "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}),
-                      [-0.3, 0, 0, 0], 0.5, 200),
+                      [-0.3, 0, 0, 0], 0.5, 256),
     # observation / reward variants
     "env_hover2": ("hover2", dict(max_episode_steps=64, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [
-        {"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]}}), [-1 / 3, 0, 0, 0], 0.5, 160),
+        {"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]}}), [-1 / 3, 0, 0, 0], 0.5, 256),
     "env_nav2": ("nav2", dict(max_episode_steps=96, target=[2.5, 0., 1.5], random_kwargs={"state_generator": {
         "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
                                         "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
                                         "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}),
-                 [-0.3, 0, 0, 0], 0.5, 200),
+                 [-0.3, 0, 0, 0], 0.5, 256),
 }
 
 
@@ -463,16 +463,32 @@ def gen_env(name, N=128, seed=42):
     kw = dict(kw)
     if "target" in kw:
         kw["target"] = th.tensor(kw["target"])
-    env = cls(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False,
-              dynamics_kwargs=dict(RACING_DYN if kind == "racing" else ENV_DYN),
-              device="cpu", **({"tensor_output": True} if kind in ("hover", "hover2", "nav2") else {}), **kw)
-    env.tensor_output = True
-    if kind == "racing":
-        env.targets = th.as_tensor(RACING_TEST_GATES)
-    consts = extract_consts(env.envs.dynamics)
+    def make_env():
+        e = cls(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False,
+                dynamics_kwargs=dict(RACING_DYN if kind == "racing" else ENV_DYN),
+                device="cpu", **({"tensor_output": True} if kind in ("hover", "hover2", "nav2") else {}), **kw)
+        e.tensor_output = True
+        if kind == "racing":
+            e.targets = th.as_tensor(RACING_TEST_GATES)
+        return e
+
     rng = np.random.default_rng(seed + 1)
     q = rng.integers(-127, 128, size=(steps, N, 4), dtype=np.int8)
     actions = decode_actions(q, hover, scale)
+    # the same run with the reference EXACTLY as torch runs it (MKL sin / cos / acos, this build's sqrt): reward / done of every step,
+    # so that the tests can bound what the CR patches cost in faithfulness (the bit-level pins are against the patched
+    # reference; this is the distance to the unpatched one)
+    use_cr_sqrt(False)
+    raw_env = make_env()
+    raw_env.reset()
+    raw_reward, raw_done = [], []
+    for k in range(steps):
+        _, r, d, _ = raw_env.step(th.from_numpy(actions[k].copy()))
+        raw_reward.append(f32(r)); raw_done.append(d.numpy().astype(np.uint8))
+    del raw_env
+    use_cr_sqrt(True)
+    env = make_env()
+    consts = extract_consts(env.envs.dynamics)
     obs0 = env.reset()
     env_gate0 = env._next_target_i.clone().numpy().astype(np.int32) if kind == "racing" else None
     dyn = env.envs.dynamics
@@ -535,7 +551,7 @@ def gen_env(name, N=128, seed=42):
     print(f"{name}: N={N} steps={steps} resets={len(ev_step)} "
           f"(collisions {int(np.sum(rec['is_collision']))}, success {int(np.sum(rec['success']))})")
     # keep the fixture small: full pre-reset state only at sparse steps
-    keep = sorted(set([0, 1, 2, 3, 7, 15, 31, 63, 64, 65, 127, 128, steps - 1]) & set(range(steps)))
+    keep = sorted(set([0, 1, 2, 3, 7, 15, 31, 63, 64, 65, 127, 128, 191, 255, steps - 1]) & set(range(steps)))
     save = {
         "kind": np.asarray(kind), "max_episode_steps": np.int32(kw["max_episode_steps"]),
         "target": f32(env.target[0]) if kind != "racing" else np.zeros(3, np.float32), "seed": np.int32(seed),
@@ -552,6 +568,7 @@ def gen_env(name, N=128, seed=42):
         "ev_fs": np.stack(ev_fs) if ev_fs else np.zeros((0, 22), np.float32),
         "spawn": np.asarray(repr(kw.get("random_kwargs", "hover-default"))),
         "label": np.asarray("repaired-oracle" if kind == "racing" else "cr-sqrt-oracle"),
+        "raw_reward": np.stack(raw_reward), "raw_done": np.stack(raw_done),
     }
     if "ev_r" in rec:
         save.update(ev_r=np.asarray(rec["ev_r"], np.float32), ev_l=np.asarray(rec["ev_l"], np.int32), ev_t=np.asarray(rec["ev_t"], np.float32),

@@ -43,6 +43,39 @@ def assert_bits_equal(a, b, what=""):
 GEOMETRIC = ["dyn_velocity_euler", "dyn_position_euler"]
 
 
+# Distance of the CR-patched reference (= what the fixtures pin to the bit) to the reference EXACTLY as this torch build runs it
+# (MKL sin / cos / acos, its not-correctly-rounded sqrt), max abs over the 13 state components after all 256 steps: the fixtures
+# store the unpatched run's final state (`raw_ext_last`).  Measured (oracle/gen_golden.py prints them): bodyrate 5.3e-5, dt=0.005
+# 1.1e-4, wide actions 9.2e-5, no ctrl_delay 0, RK4 6.1e-5, thrust 2.5e-4 (0.25 m/s^2-scale motion over 5 s), velocity 6.2e-5,
+# position 1.5e-5, wind functions 4.6e-5.  north_star's 1e-5 is below the fp32 noise floor of a 256-step closed loop;
+# these bounds are what a regression must not exceed -- asserted by the oracle test on the CPU and by the HIP test on the GPU.
+RAW_DRIFT_ABS = {"dyn_bodyrate_euler": 1.0e-4, "dyn_bodyrate_euler_wide": 1.5e-4, "dyn_thrust_euler": 4.0e-4, "dyn_bodyrate_nodelay": 1.0e-6,
+                 "dyn_bodyrate_dt005": 2.0e-4, "dyn_bodyrate_rk4": 1.0e-4, "dyn_velocity_euler": 1.0e-4, "dyn_position_euler": 5.0e-5,
+                 "dyn_wind_functions": 1.0e-4}
+RAW_DRIFT_REL = 3.0e-5        # ... and relative to the largest magnitude the column reaches in the fixture
+
+
+def assert_close_to_unpatched_reference(name, fx, ext_last, what="HIP"):
+    """|state - unpatched reference's state| after the fixture's last step: within the stated bounds"""
+    d = np.abs(np.asarray(ext_last)[:, :13] - fx["raw_ext_last"][:, :13])
+    scale = np.maximum(np.abs(fx["ext"][..., :13]).reshape(-1, 13).max(0), 1e-3)
+    rel = float((d.max(0) / scale).max())
+    assert d.max() <= RAW_DRIFT_ABS[name], f"{name}: |{what} - unpatched reference| = {d.max():.3e} > {RAW_DRIFT_ABS[name]:.1e}"
+    assert rel <= RAW_DRIFT_REL, f"{name}: |{what} - unpatched reference| = {rel:.3e} of the column scale > {RAW_DRIFT_REL:.1e}"
+    return float(d.max()), rel
+
+
+def assert_env_trace_close_to_unpatched_reference(name, fx, reward, done):
+    """env fixtures also store the UNPATCHED reference's reward / done of every step (`raw_reward`, `raw_done`): the done flags of all
+    256 steps must be identical (measured: 0 mismatches in all eight fixtures) and the rewards within 5e-7 (measured <= 1.4e-7)"""
+    reward, done = np.asarray(reward), np.asarray(done).astype(np.uint8)
+    assert reward.shape == fx["raw_reward"].shape
+    assert np.array_equal(done, fx["raw_done"]), f"{name}: done flags differ from the unpatched reference's in {int((done != fx['raw_done']).sum())} places"
+    err = float(np.abs(reward - fx["raw_reward"]).max())
+    assert err <= 5e-7, f"{name}: |reward - unpatched reference's| = {err:.3e}"
+    return err
+
+
 # constructor kwargs of the env fixtures (same as oracle/gen_golden.py::ENV_CASES)
 ENV_DYN = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
 RACING_DYN = dict(action_type="thrust", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import ENV_DYN, ENV_KW, RACING_DYN, assert_bits_equal, consts_of, decode_actions, load
+from _golden import (ENV_DYN, ENV_KW, RACING_DYN, assert_bits_equal, assert_env_trace_close_to_unpatched_reference, consts_of,
+                     decode_actions, load)
 from test_oracle_env_golden import ENVS, run_env_fixture
 
 pytestmark = pytest.mark.gpu
@@ -51,7 +52,7 @@ def test_env_trace_scripted_resets(name):
 def test_env_replay_mode_matches_reference_run(name):
     fx = load(name)
     acts = decode_actions(fx)
-    env = make(name, fx, spawn="replay")
+    env = make(name, fx, spawn="replay", replay_trig="cr")
     obs0 = env.reset()
     assert_bits_equal(env.full_state.cpu().numpy(), fx["fs_init"], f"{name} spawn states")
     assert_bits_equal(obs0["state"].cpu().numpy(), fx["obs0_state"], f"{name} reset() observation")
@@ -60,12 +61,15 @@ def test_env_replay_mode_matches_reference_run(name):
     if str(fx["kind"]) == "racing":
         assert np.array_equal(obs0["gate"].cpu().numpy(), fx["obs0_gate"][:, 0]), f"{name} reset() gate entry (the stale one)"
     keep = list(fx["keep_steps"])
+    trace_r, trace_d = [], []
     for k in range(acts.shape[0]):
         obs, reward, done, info = env.step(torch.from_numpy(acts[k]).cuda())
         r = reward.cpu().numpy()
         assert_bits_equal(r, fx["reward"][k], f"{name} reward @ {k}")      # Navigation incl.: acos in "cr" mode vs the CR-trig reference
         d = done.cpu().numpy()
         assert np.array_equal(d.astype(np.uint8), fx["done"][k]), f"{name} done @ {k}"
+        trace_r.append(r)
+        trace_d.append(d.astype(np.uint8))
         sel = fx["ev_step"] == k
         if sel.any():
             idx = fx["ev_agent"][sel]
@@ -97,6 +101,9 @@ def test_env_replay_mode_matches_reference_run(name):
             if sel.any():
                 tg = [int(info[int(i)]["terminal_observation"]["gate"]) for i in fx["ev_agent"][sel]]
                 assert tg == list(fx["ev_tgate"][np.nonzero(sel)[0]]), f"{name} terminal gate @ {k}"
+    # the whole 256-step run against the reference EXACTLY as torch runs it (no CR patches): done flags identical, rewards <= 5e-7
+    assert acts.shape[0] == 256
+    assert_env_trace_close_to_unpatched_reference(name, fx, np.stack(trace_r), np.stack(trace_d))
 
 
 def test_racing2_replay_matches_reference_run():
@@ -107,7 +114,7 @@ def test_racing2_replay_matches_reference_run():
     acts = decode_actions(fx)
     env = RacingEnv2(num_agent_per_scene=fx["fs_init"].shape[0], num_scene=1, seed=int(fx["seed"]), visual=False,
                      dynamics_kwargs=dict(RACING_DYN), device="cuda:0", tensor_output=True, constants=consts_of(fx),
-                     gates=fx["gates"].tolist(), spawn="replay", **ENV_KW["env_racing2"])
+                     gates=fx["gates"].tolist(), spawn="replay", replay_trig="cr", **ENV_KW["env_racing2"])
     assert env.observation_space["state"].shape == (16,)
     obs0 = env.reset()
     assert_bits_equal(env.full_state.cpu().numpy(), fx["fs_init"], "racing2 spawn states")
@@ -399,7 +406,7 @@ def test_imu_noise_replay_mode_matches_reference():
     rk = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]},
           "noise_kwargs": noise}
     env = HoverEnv(num_agent_per_scene=N, seed=int(fx["seed"]), dynamics_kwargs=dict(ENV_DYN), device="cuda:0", tensor_output=True,
-                   max_episode_steps=int(fx["max_episode_steps"]), random_kwargs=rk, spawn="replay", constants=consts_of(fx))
+                   max_episode_steps=int(fx["max_episode_steps"]), random_kwargs=rk, spawn="replay", replay_trig="cr", constants=consts_of(fx))
     env.reset()
     keep = list(fx["keep"])
     for k in range(acts.shape[0] + 1):

@@ -191,7 +191,7 @@ def test_output_ring_equals_fresh_tensors():
 
 def test_step_n_rejects_replay_and_tape():
     from visfly_amd._lib import VisflyError
-    env = make("HoverEnv", 128, spawn="replay")
+    env = make("HoverEnv", 128, spawn="replay", replay_trig="cr")
     with pytest.raises(VisflyError):
         env.step_n(actions(128, 2))
     env2 = make("HoverEnv", 128, requires_grad=True)

@@ -40,6 +40,24 @@ def test_replay_spawner_draw_order_uniform():
     assert torch.equal(torch.rand(3, generator=g1), torch.rand(3, generator=g2))      # streams stay aligned
 
 
+def test_replay_spawner_orientation_uses_torch_trig_by_default():
+    """the replay mode reproduces the reference AS TORCH RUNS IT, so the spawned quaternion is formed with torch's own
+    CPU sin / cos (utils/maths.py:256-269) unless the caller asks for the CR evaluation of the patched golden generator"""
+    from visfly_amd.envs.randomization import _from_euler
+    g = torch.Generator().manual_seed(3)
+    r, p, y = (2 * torch.rand(20000, generator=g) - 1 for _ in range(3))
+
+    def quat(cos, sin):
+        cy, sy, cp, sp, cr, sr = cos(y * 0.5), sin(y * 0.5), cos(p * 0.5), sin(p * 0.5), cos(r * 0.5), sin(r * 0.5)
+        return torch.stack([cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy], dim=1)
+
+    assert torch.equal(_from_euler(r, p, y), quat(torch.cos, torch.sin))
+    q_cr = quat(lambda x: torch.cos(x.double()).float(), lambda x: torch.sin(x.double()).float())
+    assert torch.equal(_from_euler(r, p, y, cr_trig=True), q_cr)
+    assert not torch.equal(q_cr, _from_euler(r, p, y)), "the two evaluations differ by an ulp on a few per cent of the arguments"
+    assert (q_cr - _from_euler(r, p, y)).abs().max() < 3e-7
+
+
 def test_replay_spawner_union_draw_order():
     boxes = spawn_boxes({"state_generator": {"class": "Union", "kwargs": [{"randomizers_kwargs": [
         {"class": "Uniform", "kwargs": {"position": {"mean": [2., 2., 1.], "half": [.2, .2, .2]}}},

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle
-from _golden import assert_bits_equal, consts_of, decode_actions, load
+from _golden import assert_bits_equal, assert_env_trace_close_to_unpatched_reference, consts_of, decode_actions, load
 
 ENVS = ["env_hover", "env_hover_256", "env_nav", "env_nav_close", "env_racing", "env_hover2", "env_nav2"]
 
@@ -64,6 +64,15 @@ def test_oracle_env_trace(name):
 
     run_env_fixture(name, make_env, step_fn, lambda env, idx, fs: env.reset_agents(idx, fs), state_fn,
                     lambda env: (env.a["next_gate"], env.a["past_gates"]))
+
+
+@pytest.mark.parametrize("name", ENVS + ["env_racing2"])
+def test_env_fixture_stays_close_to_the_unpatched_reference(name):
+    """what the CR patches cost at the env level: the fixture's reward / done trace (CR-patched reference, pinned to the bit above)
+    against the reference run exactly as torch runs it, all 256 steps"""
+    fx = load(name)
+    assert fx["reward"].shape[0] == 256
+    assert_env_trace_close_to_unpatched_reference(name, fx, fx["reward"], fx["done"])
 
 
 def test_run_steps_equals_step_loop():

@@ -32,7 +32,7 @@ def make(fx, **kw):
     N = fx["fs_init"].shape[0]
     env = HoverEnv(num_agent_per_scene=N, seed=int(fx["seed"]), dynamics_kwargs=ast.literal_eval(str(fx["dyn_kw"])), device=DEV,
                    tensor_output=True, requires_grad=True, max_episode_steps=int(fx["max_episode_steps"]),
-                   random_kwargs=ast.literal_eval(str(fx["spawn"])), spawn="replay", constants=consts_of(fx))
+                   random_kwargs=ast.literal_eval(str(fx["spawn"])), spawn="replay", replay_trig="cr", constants=consts_of(fx))
     env.reset()
     assert_bits_equal(env.full_state.cpu().numpy(), fx["fs_init"], "spawn states of the replayed stream")
     algo = SHAC(env, policy_kwargs=dict(PK), horizon=int(fx["H"]), tau=float(fx["tau"]), gamma=float(fx["gamma"]),

@@ -325,6 +325,19 @@ def check(rc):
         raise VisflyError(f"libvisfly_amd error {rc}: {lib().vf_last_error().decode()}")
 
 
+_warned = set()
+
+
+def warn_unsupported(what: str):
+    """a persistent launch answered VF_EUNSUPPORTED and the caller falls back to its launch-by-launch path (same results, roughly
+    twice the time per step): say so ONCE per entry point, with the library's reason, instead of silently"""
+    if what not in _warned:
+        _warned.add(what)
+        import warnings
+        warnings.warn(f"visfly_amd: {what} is not available for this configuration ({lib().vf_last_error().decode()}); "
+                      "falling back to one launch per step (same results, about half the rate)", stacklevel=3)
+
+
 def ptr(t):
     """device pointer of a contiguous CUDA(ROCm) tensor, or NULL"""
     if t is None:

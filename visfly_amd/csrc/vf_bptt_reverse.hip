@@ -112,6 +112,13 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     if (!h || !desc || !packed || !log_std || !eps || !actions || !tape || !tape_done || !d_reward || !adj_slab || !d_action || !g_obs ||
         !g_log_std || H <= 0)
         return vf::fail(VF_EINVAL, "vf_bptt_reverse: bad argument");
+    if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_bptt_reverse: vf_env_bind has not been called");
+    if (tape_stride < (int64_t)h->dyn.Npad * h->dyn.G * 4) return vf::fail(VF_EINVAL, "vf_bptt_reverse: tape rows are shorter than the slab");
+    // rows the kernel reads / writes as float4
+    auto misaligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+    if (misaligned(actions) || misaligned(d_action) || misaligned(eps) || misaligned(g_log_std) || misaligned(tape) || misaligned(adj_slab) ||
+        (tape_stride & 3))
+        return vf::fail(VF_EINVAL, "vf_bptt_reverse: actions / d_action / eps / g_log_std / tape / adj_slab must be 16-byte aligned (float4 rows)");
     if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: per-agent wind rows are set");
     if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: observation / reward variants have no adjoint");

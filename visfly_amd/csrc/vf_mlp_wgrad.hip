@@ -18,9 +18,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // row pairs in flight per wave.  The kernel streams 2 rows x (No + K) floats per step and is bandwidth-bound: by
 // Little's law the chip needs ~16 KiB in flight per wave (1024 waves x 16 KiB / ~2.5 us = 6.5 TB/s), i.e.
 // 64 / (NT + KT) steps of 256 (NT + KT) bytes
-constexpr int wg_depth(int nt, int kt)
+constexpr int wg_depth(int nt, int kt, bool small)
 {
-    const int d = 64 / (nt + kt);
+    const int d = (small ? 40 : 64) / (nt + kt);      // small: two waves per SIMD share its 512 registers
     return d > 16 ? 16 : (d < 4 ? 4 : d);
 }
 
@@ -35,10 +35,29 @@ struct WgradTable {
 // (KT) CONSECUTIVE columns of its row with one vector load (32 lanes = one contiguous 128 NT bytes) and feeds component
 // i to tile i -- the (tile, lane) -> column assignment is a free choice, it only permutes where dW lands in the
 // accumulators: n = NT lane + i instead of 32 i + lane.
-template <int NT, int KT, bool VA, bool VB>
+template <int W>
+__device__ __forceinline__ void wgrad_load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&f)[W])
+{
+    if constexpr (W == 4) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);      // (__builtin_bit_cast of a vector ELEMENT reads element 0)
+    } else {
+        static_assert(W == 2, "vector operand loads: 2 or 4 tiles");
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+        f[0] = __uint_as_float(v[0]);
+        f[1] = __uint_as_float(v[1]);
+    }
+}
+
+// Operand rows through BUFFER loads whose descriptors cover exactly the wave's slab [r0, r1): a row past the slab reads as zeros
+// (hardware range check), so the steps that overhang the slab need neither clamped row indices nor `live` multipliers, and an
+// address is a 32-bit lane offset + one add per step instead of a 64-bit multiply-add per operand (r03: ~27 VALU instructions per
+// step next to its NT x KT MFMAs, and hipcc piled the address arithmetic of a whole unrolled body ahead of its MFMAs).
+template <int NT, int KT, bool VA, bool VB, bool SMALL>
 __device__ __forceinline__ void wgrad_slab(const vf_mlp_bwd_layer& L, int r0, int r1, float* __restrict__ part)
 {
-    constexpr int kWgDepth = wg_depth(NT, KT);
+    constexpr int kWgDepth = wg_depth(NT, KT, SMALL);
     const int lane = threadIdx.x & 63, c = lane & 31, kk = lane >> 5;
     f32x16 acc[NT][KT];
 #pragma unroll
@@ -48,51 +67,51 @@ __device__ __forceinline__ void wgrad_slab(const vf_mlp_bwd_layer& L, int r0, in
     float bsum[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) bsum[i] = 0.0f;
+    const int rows = r1 - r0;
+    float* pa = const_cast<float*>(L.dY) + (size_t)r0 * L.ld_dy;
+    float* pb = const_cast<float*>(L.X) + (size_t)r0 * L.ld_x;
+    const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(pa, 0, ((rows - 1) * L.ld_dy + L.No) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(pb, 0, ((rows - 1) * L.ld_x + L.K) * 4, 0x00020000);
     // scalar mode: column guards hoisted (clamped column + multiplier 0 / 1)
-    int an[NT], bk[KT];
+    unsigned an[NT], bk[KT];
     float am[NT], bm[KT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { const int n = 32 * i + c; an[i] = n < L.No ? n : L.No - 1; am[i] = n < L.No ? 1.0f : 0.0f; }
+    for (int i = 0; i < NT; ++i) { const int n = 32 * i + c; an[i] = 4u * (unsigned)(n < L.No ? n : L.No - 1); am[i] = n < L.No ? 1.0f : 0.0f; }
 #pragma unroll
-    for (int j = 0; j < KT; ++j) { const int k = 32 * j + c; bk[j] = k < L.K ? k : L.K - 1; bm[j] = k < L.K ? 1.0f : 0.0f; }
+    for (int j = 0; j < KT; ++j) { const int k = 32 * j + c; bk[j] = 4u * (unsigned)(k < L.K ? k : L.K - 1); bm[j] = k < L.K ? 1.0f : 0.0f; }
     float ra[kWgDepth][NT], rb[kWgDepth][KT];
-    const int steps = (r1 - r0 + 1) >> 1;
-    auto issue = [&](int s, float (&fa)[NT], float (&fb)[KT]) {
-        const int m = r0 + 2 * s + kk, mc = m < r1 ? m : r1 - 1;
-        const float* dz = L.dY + (size_t)mc * L.ld_dy;
-        const float* x = L.X + (size_t)mc * L.ld_x;
+    const int steps = (rows + 1) >> 1;
+    // byte offsets of this lane's row of the step being issued (row 2 s + kk of the slab); + 2 rows per step
+    unsigned oa = (unsigned)kk * (unsigned)L.ld_dy * 4u + (VA ? (unsigned)(NT * c) * 4u : 0u);
+    unsigned ob = (unsigned)kk * (unsigned)L.ld_x * 4u + (VB ? (unsigned)(KT * c) * 4u : 0u);
+    const unsigned da = 8u * (unsigned)L.ld_dy, db = 8u * (unsigned)L.ld_x;
+    auto issue = [&](float (&fa)[NT], float (&fb)[KT]) {
         if constexpr (VA) {
-            using vec = __attribute__((ext_vector_type(NT))) float;
-            const vec v = *reinterpret_cast<const vec*>(dz + NT * c);
-#pragma unroll
-            for (int i = 0; i < NT; ++i) fa[i] = v[i];
+            wgrad_load<NT>(ra_src, oa, fa);
         } else {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) fa[i] = dz[an[i]];
+            for (int i = 0; i < NT; ++i) fa[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra_src, (int)(oa + an[i]), 0, 0));
         }
         if constexpr (VB) {
-            using vec = __attribute__((ext_vector_type(KT))) float;
-            const vec v = *reinterpret_cast<const vec*>(x + KT * c);
-#pragma unroll
-            for (int j = 0; j < KT; ++j) fb[j] = v[j];
+            wgrad_load<KT>(rb_src, ob, fb);
         } else {
 #pragma unroll
-            for (int j = 0; j < KT; ++j) fb[j] = x[bk[j]];
+            for (int j = 0; j < KT; ++j) fb[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb_src, (int)(ob + bk[j]), 0, 0));
         }
+        oa += da;
+        ob += db;
     };
 #pragma unroll
-    for (int p = 0; p < kWgDepth; ++p) issue(p, ra[p], rb[p]);      // rows past the slab are clamped inside
-    for (int s0 = 0; s0 < steps; s0 += kWgDepth) {     // branch-free body: steps past the slab run with live = 0
+    for (int p = 0; p < kWgDepth; ++p) issue(ra[p], rb[p]);      // rows past the slab: zeros
+    for (int s0 = 0; s0 < steps; s0 += kWgDepth) {     // branch-free body: steps past the slab multiply zeros
 #pragma unroll
         for (int p = 0; p < kWgDepth; ++p) {
-            const int s = s0 + p;
-            const float live = (r0 + 2 * s + kk) < r1 ? 1.0f : 0.0f;
             float fa[NT], fb[KT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) { fa[i] = ra[p][i] * (VA ? live : am[i] * live); bsum[i] += fa[i]; }
+            for (int i = 0; i < NT; ++i) { fa[i] = VA ? ra[p][i] : ra[p][i] * am[i]; bsum[i] += fa[i]; }
 #pragma unroll
             for (int j = 0; j < KT; ++j) fb[j] = VB ? rb[p][j] : rb[p][j] * bm[j];
-            issue(s + kWgDepth, ra[p], rb[p]);
+            issue(ra[p], rb[p]);
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -144,23 +163,26 @@ __device__ __forceinline__ int wgrad_param_of(const vf_mlp_bwd_layer& L, int e)
     return (n < L.No && k < L.K) ? n * L.K + k : -1;
 }
 
-template <int NT, int KT>
+template <int NT, int KT, bool SMALL>
 __device__ __forceinline__ void wgrad_slab_pick(const vf_mlp_bwd_layer& L, int r0, int r1, float* __restrict__ part)
 {
     const bool va = wgrad_vec_ok(L.dY, L.ld_dy, L.No, NT), vb = wgrad_vec_ok(L.X, L.ld_x, L.K, KT);
     if constexpr ((NT == 2 || NT == 4) && (KT == 2 || KT == 4)) {
-        if (va && vb) return wgrad_slab<NT, KT, true, true>(L, r0, r1, part);
+        if (va && vb) return wgrad_slab<NT, KT, true, true, SMALL>(L, r0, r1, part);
     }
     if constexpr (NT == 2 || NT == 4) {
-        if (va) return wgrad_slab<NT, KT, true, false>(L, r0, r1, part);
+        if (va) return wgrad_slab<NT, KT, true, false, SMALL>(L, r0, r1, part);
     }
     if constexpr (KT == 2 || KT == 4) {
-        if (vb) return wgrad_slab<NT, KT, false, true>(L, r0, r1, part);
+        if (vb) return wgrad_slab<NT, KT, false, true, SMALL>(L, r0, r1, part);
     }
-    wgrad_slab<NT, KT, false, false>(L, r0, r1, part);
+    wgrad_slab<NT, KT, false, false, SMALL>(L, r0, r1, part);
 }
 
-__global__ __launch_bounds__(64) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const WgradTable t, float* __restrict__ partials, int M)
+// SMALL: every layer of the table has at most 8 accumulator tiles (the reference-default policies: 128 -> 64 is the largest layer), so
+// a wave fits 256 VGPRs and TWO waves share a SIMD -- the launch streams X / dZ and is bound by how much of that is in flight
+template <bool SMALL>
+__global__ __launch_bounds__(64, SMALL ? 2 : 1) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const WgradTable t, float* __restrict__ partials, int M)
 {
     prefetch_kernarg<sizeof(vf_mlp_bwd_desc) + sizeof(WgradTable) + 16>();
     const int w = blockIdx.x;
@@ -176,22 +198,28 @@ __global__ __launch_bounds__(64) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const
         return;
     }
     switch (NT * 4 + KT - 5) {
-    case 0: wgrad_slab_pick<1, 1>(L, r0, r1, part); break;
-    case 1: wgrad_slab_pick<1, 2>(L, r0, r1, part); break;
-    case 2: wgrad_slab_pick<1, 3>(L, r0, r1, part); break;
-    case 3: wgrad_slab_pick<1, 4>(L, r0, r1, part); break;
-    case 4: wgrad_slab_pick<2, 1>(L, r0, r1, part); break;
-    case 5: wgrad_slab_pick<2, 2>(L, r0, r1, part); break;
-    case 6: wgrad_slab_pick<2, 3>(L, r0, r1, part); break;
-    case 7: wgrad_slab_pick<2, 4>(L, r0, r1, part); break;
-    case 8: wgrad_slab_pick<3, 1>(L, r0, r1, part); break;
-    case 9: wgrad_slab_pick<3, 2>(L, r0, r1, part); break;
-    case 10: wgrad_slab_pick<3, 3>(L, r0, r1, part); break;
-    case 11: wgrad_slab_pick<3, 4>(L, r0, r1, part); break;
-    case 12: wgrad_slab_pick<4, 1>(L, r0, r1, part); break;
-    case 13: wgrad_slab_pick<4, 2>(L, r0, r1, part); break;
-    case 14: wgrad_slab_pick<4, 3>(L, r0, r1, part); break;
-    default: wgrad_slab_pick<4, 4>(L, r0, r1, part); break;
+    case 0: wgrad_slab_pick<1, 1, SMALL>(L, r0, r1, part); break;
+    case 1: wgrad_slab_pick<1, 2, SMALL>(L, r0, r1, part); break;
+    case 2: wgrad_slab_pick<1, 3, SMALL>(L, r0, r1, part); break;
+    case 3: wgrad_slab_pick<1, 4, SMALL>(L, r0, r1, part); break;
+    case 4: wgrad_slab_pick<2, 1, SMALL>(L, r0, r1, part); break;
+    case 5: wgrad_slab_pick<2, 2, SMALL>(L, r0, r1, part); break;
+    case 6: wgrad_slab_pick<2, 3, SMALL>(L, r0, r1, part); break;
+    case 7: wgrad_slab_pick<2, 4, SMALL>(L, r0, r1, part); break;
+    case 8: wgrad_slab_pick<3, 1, SMALL>(L, r0, r1, part); break;
+    case 9: wgrad_slab_pick<3, 2, SMALL>(L, r0, r1, part); break;
+    case 12: wgrad_slab_pick<4, 1, SMALL>(L, r0, r1, part); break;
+    case 13: wgrad_slab_pick<4, 2, SMALL>(L, r0, r1, part); break;
+    default:
+        if constexpr (!SMALL) {
+            switch (NT * 4 + KT - 5) {
+            case 10: wgrad_slab_pick<3, 3, SMALL>(L, r0, r1, part); break;
+            case 11: wgrad_slab_pick<3, 4, SMALL>(L, r0, r1, part); break;
+            case 14: wgrad_slab_pick<4, 3, SMALL>(L, r0, r1, part); break;
+            default: wgrad_slab_pick<4, 4, SMALL>(L, r0, r1, part); break;
+            }
+        }
+        break;
     }
 }
 
@@ -271,6 +299,16 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, 
 }
 
 // waves per layer proportional to its MFMA count per row pair; -> total waves, partial floats
+// two waves per SIMD?  Only when no layer needs more than 8 accumulator tiles (k_mlp_wgrad<true>); VISFLY_AMD_WGRAD_WPS=1/2 forces it (A/B)
+bool wgrad_small(const vf_mlp_bwd_desc& d)
+{
+    static const int forced = [] { const char* e = getenv("VISFLY_AMD_WGRAD_WPS"); return e ? atoi(e) : 0; }();
+    if (forced != 2) return false;       // measured slower (profiles/r04_ppo_wgrad.txt): off unless asked for
+    for (int l = 0; l < d.n_layers; ++l)
+        if (((d.layer[l].No + 31) >> 5) * ((d.layer[l].K + 31) >> 5) > 8) return false;
+    return true;
+}
+
 int64_t wgrad_plan(const vf_mlp_bwd_desc& d, int M, WgradTable& t, int* total_waves)
 {
     int tiles[VF_MLP_MAX_LAYERS], sum = 0;
@@ -278,7 +316,7 @@ int64_t wgrad_plan(const vf_mlp_bwd_desc& d, int M, WgradTable& t, int* total_wa
         tiles[l] = ((d.layer[l].No + 31) >> 5) * ((d.layer[l].K + 31) >> 5) + 2;   // + per-row-pair overhead (loads, guards) in MFMA units
         sum += tiles[l];
     }
-    const int budget = 1024;                       // one wave per SIMD
+    const int budget = wgrad_small(d) ? 2048 : 1024;   // waves per SIMD x 1024 SIMDs
     t.n_layers = d.n_layers;
     int w = 0;
     int64_t off = 0;
@@ -320,7 +358,8 @@ int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int
     WgradTable t;
     int waves = 0;
     wgrad_plan(*d, M, t, &waves);
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
+    if (wgrad_small(*d)) hipLaunchKernelGGL(k_mlp_wgrad<true>, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
+    else hipLaunchKernelGGL(k_mlp_wgrad<false>, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
     const int nb = mlp_wgrad_fold_blocks(d);
     const vf_stats_fold ls = loss_stats ? *loss_stats : vf_stats_fold{};
     hipLaunchKernelGGL(k_wgrad_fold, dim3(nb + (loss_stats ? 1 : 0)), dim3(kBlock), 0, st, *d, t, (const float*)partials, grad, accumulate,

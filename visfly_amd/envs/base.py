@@ -12,7 +12,11 @@ Two spawn modes:
   ``spawn="replay"``: parity mode.  The reference's global-RNG draw order is
       replayed on the host generator shared with ``Dynamics`` and the drawn states are scattered
       by ``vf_env_reset``; reset states, counters and done flags are then bit-identical to the
-      reference on the same seed (one host sync per step).
+      reference on the same seed (one host sync per step).  The spawned orientation goes through ``Quaternion.from_euler``
+      (sin / cos): ``replay_trig="torch"`` (default) evaluates it with this torch build's own CPU sin / cos, i.e. draws what the
+      reference AS TORCH RUNS IT draws; ``replay_trig="cr"`` evaluates it the way the golden generator's CR-trig patch does (fp64
+      result rounded once) and is what the tests pass to reproduce the CR-patched fixtures (1 ulp apart on a few per cent of the
+      arguments).
 """
 import ctypes as C
 from typing import Dict, List, Optional
@@ -231,6 +235,7 @@ class DroneGymEnvsBase:
             constants: Optional[dict] = None,
             out_buffers: int = 0,
             spawn_prefetch: Optional[bool] = None,
+            replay_trig: str = "torch",
     ):
         """out_buffers = R > 0: step() writes into a ring of R pre-allocated (obs, reward, done) sets instead of fresh tensors
         -- no allocation and no Python object construction on the hot path; what step t returned stays valid until step
@@ -243,6 +248,8 @@ class DroneGymEnvsBase:
                                       "covers the visual=False path (SURVEY.md 8)")
         if spawn not in ("device", "replay"):
             raise ValueError("spawn must be 'device' or 'replay'")
+        if replay_trig not in ("torch", "cr"):
+            raise ValueError("replay_trig must be 'torch' or 'cr'")
         self.device = th.device(device)
         if self.device.type != "cuda":
             raise VisflyError(f"visfly_amd envs run on an MI355X only (device='{device}'); there is no CPU fallback")
@@ -315,7 +322,7 @@ class DroneGymEnvsBase:
             dyn = Dynamics(num=N, seed=seed, device=self.device, constants=consts,
                            **{k: v for k, v in dkw.items() if k != "constants"}, _attach=(hd, self._slab, G))
             self.envs = DroneEnvsBase(self, dyn)
-            self._spawner = ReplaySpawner(self._boxes, dyn.rng, cr_trig=int(consts.get("trig_mode", 1)) == 1)
+            self._spawner = ReplaySpawner(self._boxes, dyn.rng, cr_trig=replay_trig == "cr")
             # step outputs (re-used every step; the returned tensors are fresh clones only where the
             # reference returns fresh tensors to the caller)
             f32 = dict(dtype=th.float32, device=self.device)
@@ -862,6 +869,7 @@ class DroneGymEnvsBase:
                                    _lib.ptr(final), _lib.ptr(self._tape[t0]), self._slab.numel(), self._tape_done[t0].data_ptr(),
                                    _lib.ptr(d_reward), _lib.ptr(loss), _lib.ptr(disc), float(gamma), float(scale), H, self._stream())
         if rc == _lib.EUNSUPPORTED:
+            _lib.warn_unsupported("vf_bptt_rollout")
             return False
         if rc:
             _lib.check(rc)
@@ -918,6 +926,7 @@ class DroneGymEnvsBase:
         with th.cuda.device(dev):
             rc = _lib.lib().vf_ppo_rollout(self._h, C.byref(d), _lib.ptr(policy.flat), _lib.ptr(policy._packed), C.byref(a), self._stream())
         if rc == _lib.EUNSUPPORTED:
+            _lib.warn_unsupported("vf_ppo_rollout")
             return False
         if rc:
             _lib.check(rc)
@@ -951,6 +960,7 @@ class DroneGymEnvsBase:
                                             _lib.ptr(d_reward), _lib.ptr(self._adj), _lib.ptr(d_action), _lib.ptr(d_in["state"]),
                                             _lib.ptr(g_log_std), H, self._stream())
         if rc == _lib.EUNSUPPORTED:
+            _lib.warn_unsupported("vf_bptt_reverse")
             return False
         if rc:
             _lib.check(rc)

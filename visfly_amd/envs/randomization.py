@@ -44,9 +44,11 @@ def spawn_boxes(random_kwargs: Optional[Dict]) -> List[Dict]:
                               "(Normal / TargetUniform need features outside SURVEY.md 8)")
 
 
-def _from_euler(roll, pitch, yaw, cr_trig=True):
-    """Quaternion.from_euler, zyx (utils/maths.py:256-269); same torch CPU ops -> same bits.  cr_trig (the "cr" transcendental
-    mode, constants.derive_constants): sin / cos evaluated in fp64 and rounded once, as the golden generator patches torch's"""
+def _from_euler(roll, pitch, yaw, cr_trig=False):
+    """Quaternion.from_euler, zyx (utils/maths.py:256-269); same torch CPU ops -> same bits as the reference run by this torch
+    build.  cr_trig: sin / cos evaluated in fp64 and rounded once instead, as the golden generator's CR-trig patch evaluates them
+    (oracle/gen_golden.py::use_cr_trig) -- only for reproducing the CR-patched fixtures; differs from torch's own sin / cos by one
+    ulp on a few per cent of the arguments"""
     cos = (lambda x: th.cos(x.double()).float()) if cr_trig else th.cos
     sin = (lambda x: th.sin(x.double()).float()) if cr_trig else th.sin
     cy, sy = cos(yaw * 0.5), sin(yaw * 0.5)
@@ -59,7 +61,7 @@ def _from_euler(roll, pitch, yaw, cr_trig=True):
 class ReplaySpawner:
     """Host-side replay of the reference's spawn draws on a shared torch CPU generator."""
 
-    def __init__(self, boxes: List[Dict], rng: th.Generator, cr_trig: bool = True):
+    def __init__(self, boxes: List[Dict], rng: th.Generator, cr_trig: bool = False):
         self.rng, self.cr_trig = rng, cr_trig
         self.boxes = [{f: (th.tensor(b[f]["mean"]), th.tensor(b[f]["half"])) for f in _FIELDS} for b in boxes]
 
