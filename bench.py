@@ -53,7 +53,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline_env(consts, kind, N, seconds_target=15.0, threads=None, note=None):
+def cpu_baseline_env(consts, kind, N, seconds_target=5.0, threads=None, note=None):
     """TEST/BENCH INFRASTRUCTURE: time the CPU oracle (C restatement of the reference's env.step: dynamics interval + bbox
     collision + reward / counters / done masks) on the host cores of this box on a bounded sample of the same workload.
     The sample runs inside ONE OpenMP region per block of 64 steps (oracle.OracleEnv.run_steps: every thread walks its own
@@ -102,7 +102,42 @@ REFERENCE_RECORDED = {"where": "build container, 8-core Xeon 2.1 GHz, torch 2.10
                       "Dynamics.step_agent_steps_per_s@N=65536": 1.21e6, "HoverEnv.step_agent_steps_per_s@N=65536": 2.92e5}
 
 
-def cpu_baseline(consts, seconds_target=15.0, threads=None):
+def exchange_block(gbuf, n_upd, s_per_iteration, us_per_update, world, dev):
+    """the one exchange step of the path, timed on its own: 50 all-reduces of the trainer's gradient + statistics buffer on this stream
+    (vf_allreduce_grads = ncclAllReduce from C on the nccl backend), per rank and as a share of the optimiser step / iteration.
+    `native_rccl` false = the native communicator could not be created and the all-reduce went through torch.distributed (same RCCL
+    collective, Python dispatch): visible in the JSON line, with the reason, not only as a warning."""
+    from visfly_amd import parallel
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    scratch = torch.zeros_like(gbuf)
+    parallel.allreduce_sum_(scratch)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    ev2[0].record()
+    for _ in range(50):
+        parallel.allreduce_sum_(scratch)
+    ev2[1].record()
+    torch.cuda.synchronize()
+    mine = ev2[0].elapsed_time(ev2[1]) * 1e3 / 50
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, float(mine))
+    ar_us = max(per_rank)
+    native = parallel.native_comm() is not None
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(native))
+    out = {"allreduce_us": ar_us, "allreduce_us_per_rank": per_rank, "floats": int(scratch.numel()), "bytes": int(scratch.numel() * scratch.element_size()),
+           "per_iteration_ms": ar_us * n_upd * 1e-3, "share_of_iteration": ar_us * n_upd * 1e-6 / s_per_iteration,
+           "share_of_optimiser_step": (ar_us / us_per_update) if us_per_update else None,
+           "native_rccl": all(flags), "native_rccl_per_rank": flags, "backend": dist.get_backend()}
+    if not all(flags):
+        out["native_rccl_fallback_reason"] = parallel.native_comm_error() or "another rank could not create its communicator"
+    return out
+
+
+def cpu_baseline(consts, seconds_target=5.0, threads=None):
     out = cpu_baseline_env(consts, "hover", AGENTS_PER_GPU, seconds_target, threads)
     out["reference_recorded"] = REFERENCE_RECORDED
     return out
@@ -164,24 +199,7 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
     roof = {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
             "kernel": "optimiser step: k_ppo_update_chain + k_mlp_wgrad + fold + Adam", "us_per_update": us_upd,
             "rows": rows, "note": "fp32 v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)"}
-    # the one exchange step of the path, timed on its own: 50 all-reduces of the gradient + statistics buffer on this stream
-    # (vf_allreduce_grads on the nccl backend), as a share of the optimiser steps of one iteration
-    exchange = None
-    if world > 1:
-        ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        scratch = torch.zeros_like(ppo._gbuf)
-        parallel.allreduce_sum_(scratch)
-        torch.cuda.synchronize()
-        parallel.barrier()
-        ev2[0].record()
-        for _ in range(50):
-            parallel.allreduce_sum_(scratch)
-        ev2[1].record()
-        torch.cuda.synchronize()
-        ar_us = parallel.max_over_ranks(ev2[0].elapsed_time(ev2[1]) * 1e3 / 50, dev)
-        exchange = {"allreduce_us": ar_us, "floats": int(scratch.numel()), "per_iteration_ms": ar_us * n_upd * 1e-3,
-                    "share_of_iteration": ar_us * n_upd * 1e-6 / (el / iters),
-                    "native_rccl": parallel.native_comm() is not None}
+    exchange = exchange_block(ppo._gbuf, n_upd, el / iters, us_upd, world, dev)
     out = {"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
            "value": 256 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
            "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
@@ -196,7 +214,7 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
                       "logs": {k: float(v) for k, v in ppo.logs.items()}},
            "roofline": roof}
     if cpu_ref and rank == 0:
-        out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "nav", 32768, seconds_target=6.0,
+        out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "nav", 32768, seconds_target=3.0,
                                                note="env.step part of the loop only (the reference's PPO runs its MLP on "
                                                     "torch CPU; not ported to C)")
     env.close()
@@ -248,10 +266,11 @@ def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
     out = {"metric": "BPTT env-steps/s (H=64 rollout + adjoint + actor update, RacingEnv)",
            "value": 64 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
            "iterations": iters, "regions": len(els), "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic", "roofline": roof,
+           "exchange": exchange_block(algo.policy.grad, 1, el / iters, el / iters * 1e6, world, dev),     # one all-reduce of the flat gradient per update
            "config": {"workload": f"RacingEnv {N} agents/GPU, thrust actions, horizon 64 (BASELINE configs[4] shard)",
                       "logs": {k: float(v) for k, v in algo.logs.items()}}}
     if cpu_ref and rank == 0:
-        out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "racing", 16384, seconds_target=4.0,
+        out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "racing", 16384, seconds_target=3.0,
                                                note="forward env.step only (no adjoint on the CPU side)")
     env.close()
     return out
@@ -304,7 +323,7 @@ def main():
     ap.add_argument("--no-reset-leg", action="store_true", help="skip the U(-1,1) reset-heavy leg (kernel-trace profiles of the headline regime)")
     ap.add_argument("--spinup-ms", type=float, default=25.0, help="untimed device spin-up before the warm-up steps (clock governor); 0 = off")
     ap.add_argument("--repeats", type=int, default=7, help="the timed --steps region is repeated; the median is reported")
-    ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back stepping reported as `sustained` (the driver's "
+    ap.add_argument("--sustain-s", type=float, default=6.0, help="seconds of back-to-back stepping reported as `sustained` (the driver's "
                     "gpu_busy samples see the GPU working; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
@@ -611,7 +630,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dyn.constants)
-            out["cpu_baseline_1core"] = cpu_baseline(dyn.constants, seconds_target=5.0, threads=1)
+            out["cpu_baseline_1core"] = cpu_baseline(dyn.constants, seconds_target=3.0, threads=1)
     env.close()
 
     # configs[3] / configs[4] under the same clock: ONE PPO iteration and three regions of FOUR BPTT updates (median; after one warm-up each)

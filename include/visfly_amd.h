@@ -735,7 +735,8 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  *   obs_final     (N,13) observation after the last step;  tape [H] rows of tape_stride floats;  tape_done [H][N]
  *   d_reward      [H][N] = -disc_t * scale;  loss / disc (N,) in/out as for vf_bptt_accumulate
  * VF_EUNSUPPORTED unless: policy-only network of the register-chained classes, Hover / Racing / Navigation env with the
- * raw-state observation, thrust / bodyrate actions, Euler, ctrl_delay, constant wind. */
+ * raw-state observation, thrust / bodyrate actions, Euler or (repaired, utils/maths.py:353-386) RK4, ctrl_delay, constant wind;
+ * per-agent drag randomisation (dynamics.py:244-267) is carried in the slab's drag granules. */
 int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const float* obs_slots0,
                     const float* obs_slots1, const float* log_std, const float* eps, float* actions, const vf_env_out* out,
                     float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done, float* d_reward, float* loss,
@@ -760,8 +761,8 @@ int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const float* packed,
  * sample_step + 1 + t) + vf_env_step + vf_rollout_post_collect leave, bit for bit (tests/test_ppo_gpu.py): the rollout-buffer
  * rows, the compact TimeLimit-bootstrap list (rows in arbitrary order, as from the per-step calls), the per-agent episode
  * statistics, the episode outputs of the last step and the slab.  VF_EUNSUPPORTED unless: actor-critic network of the
- * register-chained classes, Hover / Navigation env with the raw-state observation, thrust / bodyrate actions, Euler, ctrl_delay,
- * constant wind.
+ * register-chained classes, Hover / Navigation env with the raw-state observation, thrust / bodyrate actions, Euler or RK4
+ * (BASELINE configs[2]'s dynamics incl. drag randomisation), ctrl_delay, constant wind.
  * desc: the policy's layer table WITHOUT activation copies (every layer's `save` NULL: inference only). */
 typedef struct vf_ppo_rollout_args {
     int32_t T, w1, capacity, pad0;

@@ -644,21 +644,28 @@ def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
     assert float((bufs[0]["rewards"].abs() > 0).float().mean()) > 0.5
 
 
-@pytest.mark.parametrize("env_name,N", [("NavigationEnv", 3000), ("HoverEnv", 1000), ("NavigationEnv", 16500), ("HoverEnv", 16401)])
-def test_persistent_rollout_equals_the_per_step_loop(env_name, N):
+@pytest.mark.parametrize("env_name,N,dyn", [("NavigationEnv", 3000, "euler"), ("HoverEnv", 1000, "euler"), ("NavigationEnv", 16500, "euler"),
+                                            ("HoverEnv", 16401, "euler"), ("NavigationEnv", 3000, "rk4_drag"), ("HoverEnv", 16401, "rk4")])
+def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
     """collect_rollouts as ONE launch (vf_ppo_rollout: 16 / 32 agents per wave for all n_steps, the same rows-per-wave chain
     vf_mlp_forward picks for N rows) leaves the rollout buffer, the TimeLimit list, the episode statistics, the episode
     outputs and the slab of the launch-by-launch loop, bit for bit -- over two consecutive rollouts with a training pass
-    between them (Philox counters, delay-ring phase and spawn counters carry over)"""
+    between them (Philox counters, delay-ring phase and spawn counters carry over).  r04: also with the RK4 integrator and per-agent
+    drag randomisation re-drawn at every re-spawn (BASELINE configs[2]'s dynamics, utils/maths.py:353-386, dynamics.py:244-267)"""
     import visfly_amd.envs as E
     from visfly_amd.ppo import PPO
     from _golden import ENV_DYN
+    dkw = dict(ENV_DYN)
+    if dyn.startswith("rk4"):
+        dkw["integrator"] = "rk4"
+    if dyn.endswith("drag"):
+        dkw["drag_random"] = 0.5
     res = []
     for fused in (True, False):
         kw = {}
         if env_name == "NavigationEnv":
             kw["random_kwargs"] = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
-        env = getattr(E, env_name)(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=7,
+        env = getattr(E, env_name)(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(dkw), device=DEV, max_episode_steps=7,
                                    tensor_output=True, **kw)
         ppo = PPO(env, n_steps=20, batch_size=N * 20 // (4 if N < 16000 else 20), n_epochs=1, seed=2)
         ppo.fused_rollout = fused
@@ -716,16 +723,24 @@ def test_persistent_rollout_shortest_horizons(n_steps):
 
 
 def test_persistent_rollout_declines_what_it_has_no_kernel_for():
-    """RK4 dynamics: vf_ppo_rollout answers VF_EUNSUPPORTED, collect_rollouts steps launch by launch (and stops asking)"""
+    """no motor lag (ctrl_delay=False, not the reference's default): vf_ppo_rollout answers VF_EUNSUPPORTED, collect_rollouts warns
+    ONCE with the library's reason, steps launch by launch and stops asking.  (RK4, declined until r03, has its instances now.)"""
+    import warnings
     from visfly_amd.envs import HoverEnv
     from visfly_amd.ppo import PPO
     from _golden import ENV_DYN
-    env = HoverEnv(num_agent_per_scene=512, seed=3, dynamics_kwargs=dict(ENV_DYN, integrator="rk4"), device=DEV, max_episode_steps=5,
-                   tensor_output=True)
+    env = HoverEnv(num_agent_per_scene=512, seed=3, dynamics_kwargs=dict(ENV_DYN, ctrl_delay=False, comm_delay=0.0), device=DEV,
+                   max_episode_steps=5, tensor_output=True)
     ppo = PPO(env, n_steps=8, batch_size=2048, n_epochs=1, seed=2)
     assert ppo.fused_rollout is True
-    ppo.collect_rollouts()
+    from visfly_amd import _lib
+    _lib._warned.discard("vf_ppo_rollout")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        ppo.collect_rollouts()
+        ppo.collect_rollouts()
     torch.cuda.synchronize()
+    assert sum("vf_ppo_rollout" in str(w.message) for w in caught) == 1
     assert ppo.fused_rollout is False
     assert torch.isfinite(ppo.buf.advantages).all() and float(ppo._ep_stats[0]) >= 512
     env.close()

@@ -96,7 +96,12 @@ template <class Net, int ROWS, int KIND>
 RevKernel pick_rev(const vf_dyn_cfg& c)
 {
     using P = vf::BwdProg<Net, true, false, true>;
-    if (c.integrator != VF_INT_EULER || !c.ctrl_delay) return nullptr;
+    if (!c.ctrl_delay) return nullptr;
+    if (c.integrator == VF_INT_RK4) {
+        if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
+        if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
+        return nullptr;
+    }
     if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
     if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
     return nullptr;

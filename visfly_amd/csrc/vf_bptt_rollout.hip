@@ -36,6 +36,35 @@ struct RollArgs {
     float* obs_slots;          // [H][N][13]: slot t = the observation the policy sees at step t (slot 0 filled by the caller)
     float* obs_final;          // (N,13): the observation after the last step
     float gamma, scale;
+    float4* ck;                // optional sub-step tape [H][4 S + 4][N] float4 (include/visfly_amd.h, vf_bptt_rollout) or null
+};
+
+// control_interval observer: the agent at the head of every sub-step -- (q) (v, 0) (w, 0) (rotor speeds) -- and the state after the
+// last one before the clamps -- (p, 0) (q) (v, 0) (w, 0) --, what the adjoint of the interval otherwise obtains by replaying it
+struct TapeCheckpoint {
+    float4* p;                 // record of (step, agent), or null (replica lanes, no tape)
+    size_t n;                  // float4 between two entries of a record = agents
+    int S;
+    __device__ __forceinline__ void head(int sub, const Agent& s) const
+    {
+        if (p) {
+            float4* o = p + (size_t)(4 * sub) * n;
+            o[0] = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
+            o[n] = make_float4(s.v[0], s.v[1], s.v[2], 0.0f);
+            o[2 * n] = make_float4(s.w[0], s.w[1], s.w[2], 0.0f);
+            o[3 * n] = make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]);
+        }
+    }
+    __device__ __forceinline__ void end(const Agent& s) const
+    {
+        if (p) {
+            float4* o = p + (size_t)(4 * S) * n;
+            o[0] = make_float4(s.p[0], s.p[1], s.p[2], 0.0f);
+            o[n] = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
+            o[2 * n] = make_float4(s.v[0], s.v[1], s.v[2], 0.0f);
+            o[3 * n] = make_float4(s.w[0], s.w[1], s.w[2], 0.0f);
+        }
+    }
 };
 
 template <class Net, int KIND, int ACT, int INTEG, bool CTRL_DELAY>
@@ -107,7 +136,11 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         // the noise row of the NEXT step's action head (drawn before the launch: HBM-cold) is touched here, under the dynamics
         // interval; the head's own load at the end of the next forward then finds it in the cache instead of waiting for HBM
         const float4 eps_touch = gc.rp_eps[(size_t)(t + 1 < r.H ? t + 1 : t) * r.N + i];
-        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
+        // sub-step tape of this (step, agent): written by the agent's own lane only (the replica lanes hold the same values)
+        const int cks = 4 * c.interval_steps + 4;
+        const TapeCheckpoint ck{(r.ck && lane < 16 && wave_first + lane < r.N) ? r.ck + (size_t)t * cks * r.N + i : nullptr, (size_t)r.N,
+                                c.interval_steps};
+        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0, ck);
         asm volatile("" :: "v"(eps_touch.x), "v"(eps_touch.y), "v"(eps_touch.z), "v"(eps_touch.w));
         float reward = 0.0f;
         bool done = false;
@@ -138,7 +171,12 @@ using RollKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvA
 template <class Net, int KIND>
 RollKernel pick_roll(const vf_dyn_cfg& c)
 {
-    if (c.integrator != VF_INT_EULER || !c.ctrl_delay) return nullptr;
+    if (!c.ctrl_delay) return nullptr;
+    if (c.integrator == VF_INT_RK4) {
+        if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
+        if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
+        return nullptr;
+    }
     if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
     if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
     return nullptr;
@@ -149,7 +187,8 @@ RollKernel pick_roll(const vf_dyn_cfg& c)
 extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const float* obs_slots0,
                                const float* obs_slots1, const float* log_std, const float* eps, float* actions,
                                const vf_env_out* out, float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done,
-                               float* d_reward, float* loss, float* disc, float gamma, float scale, int32_t H, vf_stream_t stream)
+                               float* d_reward, float* loss, float* disc, float gamma, float scale, int32_t H, float* substep_tape,
+                               vf_stream_t stream)
 {
     if (!h || !desc || !params || !obs_slots0 || !log_std || !eps || !actions || !out || !obs_final || !tape || !tape_done || !d_reward ||
         !loss || !disc || H <= 0)
@@ -160,6 +199,7 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: observation / reward variants have no adjoint");
     if (tape_stride < (int64_t)h->dyn.Npad * h->dyn.G * 4) return vf::fail(VF_EINVAL, "vf_bptt_rollout: tape rows are shorter than the slab");
+    if (reinterpret_cast<uintptr_t>(substep_tape) & 15) return vf::fail(VF_EINVAL, "vf_bptt_rollout: substep_tape must be 16-byte aligned");
     if ((int64_t)H * h->dyn.N * 128 * 4 >= (1ll << 32))      // the chain addresses its activation copies with 32-bit byte offsets
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: H x N rows of activation copies pass 4 GiB per buffer");
     const int cls = vf::chain16_policy_class(desc, params);
@@ -168,7 +208,7 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     else if (cls == 1 && h->cfg.kind == VF_ENV_RACING) k = pick_roll<vf::NetHoverPi, VF_ENV_RACING>(h->dyn.cfg);
     else if (cls == 2 && h->cfg.kind == VF_ENV_NAV && obs_slots1) k = pick_roll<vf::NetNavPi, VF_ENV_NAV>(h->dyn.cfg);
     if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: no persistent roll-out for this network class / env kind / dynamics "
-                                             "configuration (policy-only [128, 64] x [64, 64] networks, thrust / bodyrate, Euler, ctrl_delay)");
+                                             "configuration (policy-only [128, 64] x [64, 64] networks, thrust / bodyrate, Euler / RK4, ctrl_delay)");
     const int N = h->dyn.N;
     vf::EnvArgs ge{vf::DynArgs{N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(actions), nullptr,
                                vf::ring_head(&h->dyn), nullptr, h->dyn.vel_strided},
@@ -179,7 +219,7 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     ge.out.obs = H > 1 ? const_cast<float*>(obs_slots0) + (size_t)N * 13 : obs_final;
     vf::ChainArgs gc{*desc, params, packed, vf::ChainIo{{obs_slots0, obs_slots1}, nullptr, nullptr}, H * N, log_std,
                      reinterpret_cast<const float4*>(eps), reinterpret_cast<float4*>(actions), {nullptr, nullptr}};
-    vf::RollArgs r{H, N, tape, tape_stride, tape_done, d_reward, loss, disc, const_cast<float*>(obs_slots0), obs_final, gamma, scale};
+    vf::RollArgs r{H, N, tape, tape_stride, tape_done, d_reward, loss, disc, const_cast<float*>(obs_slots0), obs_final, gamma, scale, reinterpret_cast<float4*>(substep_tape)};
     hipLaunchKernelGGL(k, dim3((N + 15) / 16), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
     VF_HIP(hipGetLastError());
     h->dyn.tick += H;

@@ -467,10 +467,18 @@ __device__ __forceinline__ void finish_interval(const vf_dyn_cfg& c, Agent& s)
     for (int k = 0; k < 3; ++k) s.w[k] = clampf(s.w[k], -c.omg_lim, c.omg_lim);
 }
 
+// Optional observer of a control interval: head(sub, s) sees the agent at the head of every sub-step, end(s) the state after the last
+// one BEFORE finish_interval clamps it.  k_bptt_rollout (vf_bptt_rollout.hip) writes them to the sub-step tape that lets the
+// persistent reverse sweep skip its replay of the interval (vf_env_bwd_body.hpp).
+struct NoCheckpoint {
+    __device__ __forceinline__ void head(int, const Agent&) const {}
+    __device__ __forceinline__ void end(const Agent&) const {}
+};
+
 // All sub-steps of one control interval in ONE thread (dynamics.py:335-382).  kl/kq: this agent's drag.
-template <int ACT, int INTEG, bool CTRL_DELAY>
+template <int ACT, int INTEG, bool CTRL_DELAY, class CK = NoCheckpoint>
 __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, const float* a,
-                                                 const float* kl, const float* kq, bool vstrided = false)
+                                                 const float* kl, const float* kq, bool vstrided = false, const CK& ck = CK{})
 {
     float Td[4], wd[4];
     desired_thrusts<ACT>(c, s, a, Td, vstrided);
@@ -485,11 +493,13 @@ __device__ __forceinline__ void control_interval(const vf_dyn_cfg& c, Agent& s, 
 #pragma unroll 1
 #endif
     for (int sub = 0; sub < c.interval_steps; ++sub) {
+        ck.head(sub, s);
         float ft[4];
         motor_substep<CTRL_DELAY>(c, Td, wd, s.wm, s.T, ft);
         trans_substep<INTEG>(c, s.q, ft[0], kl, kq, s.wnd, s.p, s.v, s.acc);   // uses q of the sub-step start
         rot_substep<INTEG>(c, ft + 1, s.q, s.w, s.aa);
     }
+    ck.end(s);
     finish_interval(c, s);
 }
 

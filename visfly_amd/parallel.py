@@ -141,6 +141,7 @@ def native_comm(force: bool = False):
             why = why or RuntimeError("another rank did not receive the communicator id")
     else:
         why = why or RuntimeError("another rank could not load RCCL")
+    _native["why"] = None if h is not None else f"{type(why).__name__}: {why}" if why is not None else "unknown"
     if h is None:
         warnings.warn(f"visfly_amd: native RCCL communicator unavailable ({why}); gradient all-reduce goes through "
                       "torch.distributed (same RCCL collective, Python dispatch)")
@@ -150,6 +151,11 @@ def native_comm(force: bool = False):
         _native["atexit"] = True
         atexit.register(_destroy_native)
     return _native["comm"]
+
+
+def native_comm_error():
+    """why the last native_comm() attempt fell back to torch.distributed (None: it did not, or it was never tried / not applicable)"""
+    return _native.get("why")
 
 
 def _destroy_native():
