@@ -276,6 +276,48 @@ def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
     return out
 
 
+def bench_shac(args, rank, world, dev, iters=None, cpu_ref=False):
+    """SHAC (utils/algorithms/shac.py:215-278) in the reference's network shapes -- HoverEnv, bodyrate, 16 384 agents per GPU,
+    horizon 32, 5 critic steps per iteration (the reference's defaults), agents sharded by rank, one all-reduce of the actor gradient
+    and one of the critic gradient per critic step."""
+    from visfly_amd import parallel
+    from visfly_amd.envs import HoverEnv
+    from visfly_amd.shac import SHAC
+    N, H = (args.agents if args.agents != AGENTS_PER_GPU else 16384), 32
+    env = HoverEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dict(DYN_KW), device=dev, max_episode_steps=256,
+                   requires_grad=True, tensor_output=True)
+    algo = SHAC(env, horizon=H, gamma=0.99, learning_rate=1e-3, gradient_steps=5, seed=0)
+    algo.learn(H * N * world)       # warm-up iteration
+    torch.cuda.synchronize()
+    parallel.barrier()
+    iters = iters or max(1, args.steps // H)
+    els = []
+    for _ in range(3 if iters < 16 else 1):
+        t0 = time.perf_counter()
+        algo.learn(H * N * world * iters)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        els.append(parallel.max_over_ranks(time.perf_counter() - t0, dev))
+    el = sorted(els)[len(els) // 2]
+    # MFMA work of one iteration per (step, agent) row: actor forward + data gradient + weight gradient (6 flops per weight), the next
+    # action's actor forward (2), the target critics' forward (2), and gradient_steps critic updates over the horizon buffer (6 each)
+    wa = algo.policy.n_params
+    wc = algo.critic.n_params
+    flops_row = 6.0 * wa + 2.0 * wa + 2.0 * wc + algo.gradient_steps * 6.0 * wc
+    tfs = flops_row * H * N * iters / el / 1e12
+    out = {"metric": "SHAC env-steps/s (H=32 rollout + adjoint + actor update + 5 critic updates, HoverEnv)",
+           "value": H * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world, "iterations": iters, "regions": len(els),
+           "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",
+           "roofline": {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
+                        "kernel": "whole iteration: actor chain forward / reverse + env step + adjoint, target critics, 5 critic updates",
+                        "flops_per_agent_step": flops_row, "actor_params": int(wa), "critic_params": int(wc),
+                        "note": "loop-level figure over the timed iterations (wall clock, not one kernel)"},
+           "config": {"workload": f"HoverEnv {N} agents/GPU, bodyrate, horizon {H}, 5 critic steps (SURVEY 8f-2; the reference's SHAC defaults)",
+                      "logs": {k: float(v) for k, v in algo.logs.items()}}}
+    env.close()
+    return out
+
+
 def _with_watchdog(fn, seconds, what):
     """secondary measurements must never cost the primary line: run fn() and give up after `seconds`"""
     import threading
@@ -327,8 +369,8 @@ def main():
                     "gpu_busy samples see the GPU working; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
-    ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt"],
-                    help="env: fused HoverEnv.step (the BASELINE metric, default); ppo / bptt: that loop only")
+    ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt", "shac"],
+                    help="env: fused HoverEnv.step (the BASELINE metric, default); ppo / bptt / shac: that loop only")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins the process group, one barrier, rank 0 prints the world size "
                          "(no GPU work; tests/test_parallel_gloo.py runs the plain `--gpus 2` command through it on CPU)")
@@ -358,8 +400,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-    if args.workload in ("ppo", "bptt"):
-        out = (bench_ppo if args.workload == "ppo" else bench_bptt)(args, rank, world, dev, cpu_ref=world == 1)
+    if args.workload in ("ppo", "bptt", "shac"):
+        out = {"ppo": bench_ppo, "bptt": bench_bptt, "shac": bench_shac}[args.workload](args, rank, world, dev, cpu_ref=world == 1)
         if rank == 0:
             print(json.dumps(out), flush=True)
         if dist is not None:
@@ -633,10 +675,10 @@ def main():
             out["cpu_baseline_1core"] = cpu_baseline(dyn.constants, seconds_target=3.0, threads=1)
     env.close()
 
-    # configs[3] / configs[4] under the same clock: ONE PPO iteration and three regions of FOUR BPTT updates (median; after one warm-up each)
+    # configs[3] / configs[4] / SHAC under the same clock: ONE PPO iteration, three regions of FOUR BPTT updates and of TWO SHAC iterations (median; after one warm-up each)
     if not args.no_secondary and os.environ.get("VISFLY_BENCH_SECONDARY", "1") != "0":
         sec, dead = {}, False
-        for name, fn, iters in (("ppo", bench_ppo, 1), ("bptt", bench_bptt, 4)):
+        for name, fn, iters in (("ppo", bench_ppo, 1), ("bptt", bench_bptt, 4), ("shac", bench_shac, 2)):
             res, dead = _with_watchdog(lambda fn=fn, iters=iters: fn(args, rank, world, dev, iters=iters, cpu_ref=world == 1),
                                        240, name)
             sec[name] = res

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 5   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
+#define VF_ABI_VERSION 6   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
                               4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_dyn_set_wind,
@@ -33,7 +33,8 @@ extern "C" {
                               5: vf_dyn_ring_phase / vf_dyn_set_ring_phase / vf_env_set_ring_phase, capture guard on
                                  vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update,
                                  vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
-                                 vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout */
+                                 vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout;
+                              6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse */
 
 typedef void* vf_stream_t;
 
@@ -736,11 +737,17 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  *   d_reward      [H][N] = -disc_t * scale;  loss / disc (N,) in/out as for vf_bptt_accumulate
  * VF_EUNSUPPORTED unless: policy-only network of the register-chained classes, Hover / Racing / Navigation env with the
  * raw-state observation, thrust / bodyrate actions, Euler or (repaired, utils/maths.py:353-386) RK4, ctrl_delay, constant wind;
- * per-agent drag randomisation (dynamics.py:244-267) is carried in the slab's drag granules. */
+ * per-agent drag randomisation (dynamics.py:244-267) is carried in the slab's drag granules.
+ *   substep_tape  optional (NULL: off), [H][S + 1][W][64] float4 with S = interval_steps and W = ceil(N / 16) waves: for every
+ *                 (step, wave of 16 agents) S + 1 rows of 1 KiB, entry k of agent slot m at float4 [k * 16 + m] of a row -- rows
+ *                 0 .. S-1 the state at the head of each integrator sub-step: (q) (v, 0) (w, 0) (rotor speeds); row S the state
+ *                 after the last one before the clamps: (p, 0) (q) (v, 0) (w, 0).  What autograd's tape keeps of
+ *                 dynamics.py:335-382; handed to vf_bptt_reverse, whose adjoint of the interval then reads it (LDS-DMA, one step
+ *                 ahead) instead of replaying the S sub-steps (a third of its instruction stream).  16-byte aligned. */
 int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const float* obs_slots0,
                     const float* obs_slots1, const float* log_std, const float* eps, float* actions, const vf_env_out* out,
                     float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done, float* d_reward, float* loss,
-                    float* disc, float gamma, float scale, int32_t H, vf_stream_t stream);
+                    float* disc, float gamma, float scale, int32_t H, float* substep_tape, vf_stream_t stream);
 
 /* ... and the reverse half (loss.backward() over the horizon, BPTT.py:127-129): for t = H-1 .. 0 the adjoint of env step t and the
  * policy's action-head reverse + reverse chain of step t, a wave owning 16 or 32 agents (the rows-per-wave choice
@@ -749,10 +756,13 @@ int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, con
  * vf_mlp_weight_grad over H N rows afterwards), d_mean rows, the per-row log_std gradient terms and the adjoint slab.
  *   desc       reverse layer table over the FLATTENED slots (H N rows; layer[0].dY = d_mean (H N, 4), the first-layer dX of the
  *              "state" branch = g_obs, (H N, 13) observation gradients);  d_action [H][N][4] scratch;  g_log_std [H][N][4] zeroed
+ *   substep_tape  what vf_bptt_rollout wrote for the same H steps, or NULL (the interval is replayed; same results to the bit).
+ *                 Read by the 16-agents-per-wave sweep only (N <= 16 384 per launch); ignored otherwise
  * Same restrictions as vf_bptt_rollout. */
 int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const float* packed, const float* log_std, const float* eps,
                     const float* actions, const float* tape, int64_t tape_stride, const uint8_t* tape_done, const float* d_reward,
-                    float* adj_slab, float* d_action, const float* g_obs, float* g_log_std, int32_t H, vf_stream_t stream);
+                    float* adj_slab, float* d_action, const float* g_obs, float* g_log_std, int32_t H, const float* substep_tape,
+                    vf_stream_t stream);
 
 /* The same construction for PPO's collect_rollouts (SB3 OnPolicyAlgorithm.collect_rollouts, run by utils/algorithms/PPO.py:146;
  * n_steps rounds of policy.forward -> distribution.sample / log_prob -> env.step -> RolloutBuffer.add): T steps in ONE

@@ -428,5 +428,144 @@ def gen_shac(name="shac_hover", N=64, H=8, seed=42, gradient_steps=3, lr=1e-3, t
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def gen_bptt_loop(name="bptt_loop_hover", N=64, H=8, seed=42, lr=1e-3):
+    """ONE iteration of the reference's own ``BPTT.learn`` (utils/algorithms/BPTT.py:77-134) with its own ``MTDPolicy.actor`` -- the
+    SAC-style ``Actor`` with the state-dependent ``log_std`` head (utils/policies/td_policies.py:146-252), which is what
+    ``self.policy.actor.action_log_prob(obs)`` (:113) runs -- over the differentiable HoverEnv (CR oracle), exploration noise fed
+    from the fixture.  Recorded: the (clipped) actions, rewards and done flags of the H steps, ``actor_loss`` (:127), its flat
+    gradient as ``clip_grad_norm_(.., 0.5)`` sees it (:130), the actor parameters after ``optimizer.step()`` (:133).  5-step
+    episodes and a spawn box that reaches the floor, so that the discount recurrence (:124) sees truncations and true episode ends
+    inside the horizon."""
+    _install_sb3()
+    HoverEnvShim, _, _ = G.import_envs()
+    G.use_cr_sqrt(True)
+    import VisFly.utils.algorithms.shac as S
+    import VisFly.utils.algorithms.BPTT as B
+    from VisFly.utils.policies.td_policies import MTDPolicy
+    import VisFly.utils.policies.extractors as E
+
+    rng = np.random.default_rng(seed + 19)
+    eps_all = rng.standard_normal((H, N, 4)).astype(np.float32)
+    feed = {"i": 0}
+    import torch.distributions.normal as TDN
+
+    def fed_standard_normal(shape, dtype, device):
+        assert tuple(shape) == (N, 4), shape
+        e = th.from_numpy(eps_all[feed["i"]].copy())
+        feed["i"] += 1
+        return e
+    TDN._standard_normal = fed_standard_normal
+
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 0.65], "half": [1.0, 1.0, 0.6]}}]}}
+    max_steps = 5
+    env = HoverEnvShim(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False, dynamics_kwargs=dict(G.ENV_DYN), device="cpu",
+                       requires_grad=True, tensor_output=True, max_episode_steps=max_steps, random_kwargs=spawn)
+    consts = G.extract_consts(env.envs.dynamics)
+    policy_kwargs = dict(features_extractor_class=E.StateExtractor,
+                         features_extractor_kwargs={"net_arch": {"state": {"layer": [128, 64]}}},
+                         net_arch=dict(pi=[64, 64], qf=[64, 64]), activation_fn=nn.ReLU, share_features_extractor=False)
+    th.manual_seed(seed + 1)
+    import copy as _copy
+    real_deepcopy = _copy.deepcopy
+    S.deepcopy = lambda e: e if isinstance(e, HoverEnvShim) else real_deepcopy(e)
+    B.deepcopy = S.deepcopy
+    # BPTT.learn wraps its loop in tqdm; a transparent stand-in keeps the generator's output clean (pbar.n / pbar.update only)
+
+    class _Bar:
+        def __init__(self, total=None):
+            self.n = 0
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def update(self, k):
+            self.n += k
+    B.tqdm = _Bar
+    algo = B.BPTT(env, MTDPolicy, policy_kwargs=policy_kwargs, learning_rate=lr, horizon=H, gamma=0.99, device="cpu", seed=seed,
+                  save_path="/tmp/vf_bptt_gen", dump_step=1e12)
+    algo._create_logger = lambda **kw: types.SimpleNamespace(record=lambda *a, **k: None, dump=lambda *a, **k: None)
+    actor = algo.policy.actor
+    assert type(actor).__module__.endswith("td_policies") and type(actor).__name__ == "Actor"
+    with th.no_grad():                                            # de-correlate the two trunks and the heads (as gen_shac)
+        g = th.Generator().manual_seed(seed + 2)
+        for l in _linears(actor.log_latent_pi, actor.log_std):
+            l.weight.add_(th.randn(l.weight.shape, generator=g) * 0.05)
+        actor.log_std.bias.fill_(-1.0)
+        actor.mu.weight.mul_(0.5)
+    a_lin = _linears(actor.features_extractor.state_extractor, actor.latent_pi) + [actor.mu] + _linears(actor.log_latent_pi) + [actor.log_std]
+    assert len(list(actor.parameters())) == 2 * len(a_lin)
+    save = {"actor_params0": _flat(a_lin)}
+    th.manual_seed(seed)
+    env.reset()
+    fs_init = G.f32(env.envs.dynamics.full_state)
+
+    rec = {"action": [], "reward": [], "done": [], "clip": [], "loss": [], "params": []}
+    real_step_env = env.step
+
+    def step_rec(a, *aa, **kk):
+        rec["action"].append(G.f32(a))
+        o, r, d, info = real_step_env(a, *aa, **kk)
+        rec["reward"].append(G.f32(r))
+        rec["done"].append(d.numpy().astype(np.uint8))
+        return o, r, d, info
+    env.step = step_rec
+    real_clip = th.nn.utils.clip_grad_norm_
+
+    def clip_rec(params, max_norm, *a, **k):
+        params = list(params)
+        rec["clip"].append((_flat(a_lin, grad=True), float(max_norm)))
+        return real_clip(params, max_norm, *a, **k)
+    th.nn.utils.clip_grad_norm_ = clip_rec
+    opt = actor.optimizer
+    real_opt_step = opt.step
+
+    def opt_step_rec(*a, **k):
+        r = real_opt_step(*a, **k)
+        rec["params"].append(_flat(a_lin))
+        return r
+    opt.step = opt_step_rec
+    real_backward = th.Tensor.backward
+
+    def backward_rec(self, *a, **k):
+        if not rec["loss"]:
+            rec["loss"].append(float(self.detach()))
+        return real_backward(self, *a, **k)
+    th.Tensor.backward = backward_rec
+    try:
+        algo.learn(total_timesteps=H * N)
+    finally:
+        th.Tensor.backward = real_backward
+        th.nn.utils.clip_grad_norm_ = real_clip
+    assert feed["i"] == H and len(rec["action"]) == H and len(rec["clip"]) == 1 and len(rec["params"]) == 1, (feed, len(rec["action"]))
+    done = np.stack(rec["done"]).astype(bool)
+    gnorm = float(np.linalg.norm(rec["clip"][0][0]))
+    print(f"{name}: N={N} H={H} dones={int(done.sum())} actor_loss={rec['loss'][0]:.6f} |g|={gnorm:.4f} (clip {rec['clip'][0][1]})")
+    assert done.sum() > 0 and rec["clip"][0][1] == 0.5
+    save.update(
+        eps=eps_all, fs_init=fs_init, seed=np.int32(seed), max_episode_steps=np.int32(max_steps), spawn=np.asarray(repr(spawn)),
+        dyn_kw=np.asarray(repr(dict(G.ENV_DYN))), H=np.int32(H), gamma=np.float64(0.99), lr=np.float64(lr), max_grad_norm=np.float64(0.5),
+        log_std_min=np.float32(-10), log_std_max=np.float32(2),
+        action=np.stack(rec["action"]), reward=np.stack(rec["reward"]), done=np.stack(rec["done"]),
+        actor_loss=np.float64(rec["loss"][0]), actor_grad=rec["clip"][0][0], actor_params1=rec["params"][0],
+        label=np.asarray("cr-oracle; the reference's own BPTT.learn loop (BPTT.py:100-134), MTDPolicy.actor = td_policies.Actor, StateExtractor, "
+                         "create_mlp; SB3 base classes restated (oracle/gen_shac.py)"),
+        **{"c_" + k: v for k, v in consts.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 if __name__ == "__main__":
-    gen_shac()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None, choices=[None, "shac_hover", "bptt_loop_hover"])
+    a = ap.parse_args()
+    if a.only == "bptt_loop_hover":
+        gen_bptt_loop()
+    elif a.only == "shac_hover":
+        gen_shac()
+    else:          # separate interpreters: both patch module-level state of the imported reference
+        import subprocess
+        for n in ("shac_hover", "bptt_loop_hover"):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--only", n])

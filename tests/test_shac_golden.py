@@ -85,3 +85,48 @@ def test_adam_step_of_the_actor_from_the_recorded_gradient():
     m, v = 0.1 * g, 0.001 * g * g
     step = float(fx["lr"]) * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)
     assert np.abs(fx["actor_params0"] - step - fx["actor_params1"]).max() <= 2e-7
+
+
+# ---- tests/golden/bptt_loop_hover.npz: ONE iteration of the reference's own BPTT.learn with its own actor (gen_shac.py::gen_bptt_loop) ----
+def test_bptt_loop_fixture_first_episodes_are_the_oracle_envs():
+    """the recorded (clipped) actions driven through the CPU oracle's HoverEnv from the recorded spawn states: reward and done of
+    every agent's FIRST episode (5 steps; the re-spawns that follow come from the reference's RNG stream, which only the replay
+    mode on the GPU reproduces) are the fixture's, bit for bit -- the env side of the loop is the pinned env"""
+    from _golden import assert_bits_equal, consts_of
+    fx = load("bptt_loop_hover")
+    H, N = fx["reward"].shape
+    env = oracle.OracleEnv(consts_of(fx), N, "hover", int(fx["max_episode_steps"]))
+    env.reset_full_state(fx["fs_init"])
+    alive = np.ones(N, bool)
+    checked = 0
+    for t in range(H):
+        env.step(fx["action"][t])
+        assert_bits_equal(env.a["reward"][alive], fx["reward"][t][alive], f"reward of the first episodes @ {t}")
+        assert np.array_equal(env.a["done"][alive], fx["done"][t][alive]), f"done of the first episodes @ {t}"
+        checked += int(alive.sum())
+        alive &= fx["done"][t] == 0
+        if not alive.any():
+            break
+    assert t == int(fx["max_episode_steps"]) - 1 and checked >= 4 * N          # everybody is truncated at step 5 at the latest
+    assert (np.abs(fx["action"]) <= 1.0).all()                                   # tanh-squashed: the clip of BPTT.py:114-116 is the identity
+
+
+def test_bptt_loop_loss_recurrence_and_adam_step():
+    """actor_loss = mean_i sum_t -reward_t disc_t, disc <- disc gamma ~done + done (BPTT.py:123-127) from the recorded rewards / done
+    flags; the recorded parameters after the step = clip_grad_norm_(0.5) + Adam(lr) from the recorded gradient (:130-133)"""
+    fx = load("bptt_loop_hover")
+    H, N = fx["reward"].shape
+    g = np.float32(float(fx["gamma"]))
+    loss, disc = np.zeros(N, np.float32), np.ones(N, np.float32)
+    for t in range(H):
+        done = fx["done"][t].astype(bool)
+        loss = loss + np.float32(-1) * fx["reward"][t] * disc
+        disc = disc * g * (~done).astype(np.float32) + done.astype(np.float32)
+    assert abs(float(loss.mean()) - float(fx["actor_loss"])) <= 1e-6
+    assert fx["done"].sum() > N                                                   # truncations of everybody + true episode ends
+    gr = fx["actor_grad"].astype(np.float64)
+    gr = gr * min(1.0, 0.5 / (np.linalg.norm(gr) + 1e-6))
+    m, v = 0.1 * gr, 0.001 * gr * gr
+    step = float(fx["lr"]) * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)
+    assert np.abs(fx["actor_params0"] - step - fx["actor_params1"]).max() <= 2e-7
+    assert fx["actor_params0"].size == 13 * 128 + 128 + 128 * 64 + 64 + 2 * (64 * 64 + 64) * 2 + 2 * (64 * 4 + 4)

@@ -11,6 +11,7 @@ step) and the policy's is the MFMA linear-layer kernels; ``torch.autograd`` is o
 that orders those launches (two custom Functions), so any torch policy can be dropped in as well.
 """
 import ctypes as C
+import os
 import time
 from typing import Dict, Optional
 
@@ -60,10 +61,24 @@ class PolicyFunction(th.autograd.Function):
         return (None, None, None) + tuple(d_in.get(k) for k in ctx.keys)
 
 
+# the reference constructs ``BPTT(env, policy, policy_kwargs, ...)`` with one of utils/policies/td_policies.py's policies (BPTT.py:13,
+# 29-49); its loop then runs ``self.policy.actor.action_log_prob(obs)`` (:113), i.e. the SAC-style Actor with the state-dependent
+# log_std head (td_policies.py:146-252).  These names select that actor here; None keeps the MlpPolicy with a state-independent log_std
+REFERENCE_ACTOR_POLICIES = ("MultiInputPolicy", "MTDPolicy", "CnnPolicy", "MlpPolicy")
+LOG_STD_MAX, LOG_STD_MIN = 2.0, -10.0        # td_policies.py:31-32
+
+
 class BPTT:
     def __init__(self, env, horizon: int = 32, gamma: float = 0.99, learning_rate: float = 1e-3,
                  max_grad_norm: float = 0.5, weight_decay: float = 0.0, policy_kwargs: Optional[dict] = None,
-                 seed: int = 0, betas=(0.9, 0.999), adam_eps: float = 1e-8):
+                 seed: int = 0, betas=(0.9, 0.999), adam_eps: float = 1e-8, policy=None):
+        if policy is not None and not isinstance(policy, str):
+            policy = getattr(policy, "__name__", str(policy))
+        if policy is not None and policy not in REFERENCE_ACTOR_POLICIES:
+            raise NotImplementedError(f"policy {policy}: one of {REFERENCE_ACTOR_POLICIES} (vector observations) or None")
+        # True: the reference's own actor (two trunks, mu / clamped state-dependent log_std heads); SHAC always uses it
+        self.reference_actor = policy is not None or getattr(self, "reference_actor", False)
+        self._eps_override = None            # tests: the exploration noise of the next horizon(s), fed instead of drawn
         self.env, self.H, self.gamma = env, horizon, gamma
         self.lr, self.max_grad_norm, self.weight_decay, self.betas, self.adam_eps = learning_rate, max_grad_norm, weight_decay, betas, adam_eps
         self.device = env.device
@@ -94,8 +109,45 @@ class BPTT:
         self.num_timesteps = 0
         self.logs: Dict[str, float] = {}
 
+    def _make_reference_actor(self, obs, policy_kwargs, seed):
+        """td_policies.Actor (:146-252): extractor -> (latent_pi -> mu | log_latent_pi -> log_std); nn.Linear default initialisation
+        (SB3's SAC policies do not use orthogonal init), log_latent_pi = deepcopy(latent_pi) (:205).  One MlpPolicy layer table with
+        two 4-wide heads; sets self._extractor / _ext_keys / _critic_arch (SHAC builds its critics from them)."""
+        pk = dict(policy_kwargs or {})
+        na = pk.get("net_arch")
+        self._critic_arch = getattr(self, "_critic_arch", None)
+        if isinstance(na, dict) and "qf" in na:                       # SB3 get_actor_critic_arch: dict(pi=..., qf=...)
+            self._critic_arch = list(na["qf"])
+            pk["net_arch"] = dict(pi=list(na["pi"]), vf=list(na["pi"]))
+        if pk.get("share_features_extractor"):
+            raise NotImplementedError("share_features_extractor=True: the critic here owns its extractor (the reference default)")
+        pk.pop("share_features_extractor", None)
+        if any(k in pk for k in ("features_extractor_class", "net_arch", "features_extractor_kwargs", "activation_fn")):
+            pk.setdefault("activation_fn", "relu")                    # MTDPolicy's default activation IS ReLU (td_policies.py:297)
+        pk = checkpoint.policy_kwargs_from_reference(pk, self.obs_keys)
+        self._extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
+        self._ext_keys = list(self._extractor.keys())
+        arch = list(pk.get("pi", [64, 64]))
+        if self._critic_arch is None:
+            self._critic_arch = list(arch)
+        pol = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys}, self._extractor, arch, arch, self.device, seed=seed,
+                        ortho_init=False, head_dims=(4, 4), log_std_param=False)
+        hidden = lambda trunk: [ly for ly in pol.layers if ly.dst.startswith(trunk + ":")]
+        for a, b in zip(hidden("pi"), hidden("vf")):                  # log_latent_pi starts as a copy of latent_pi
+            pol.weight(b).copy_(pol.weight(a))
+            pol.bias(b).copy_(pol.bias(a))
+        return pol
+
+    def _head_fwd(self, mu, log_std, eps, action):
+        """action = tanh(mu + eps exp(clamp(log_std))) -- Actor.action_log_prob's sample (SB3 squashed Gaussian)"""
+        _lib.check(_lib.lib().vf_shac_head_fwd(_ptr(mu), _ptr(log_std), _ptr(eps), _ptr(action), mu.shape[0], LOG_STD_MIN,
+                                               LOG_STD_MAX, _lib.current_stream(self.device)))
+
     def _make_policy(self, obs, policy_kwargs, seed):
-        """the actor network (subclasses with another actor shape override this; SHAC: state-dependent log_std head)"""
+        """the actor network: the reference's Actor when a td_policies policy was named (or by SHAC), else the MlpPolicy with a
+        state-independent log_std"""
+        if self.reference_actor:
+            return self._make_reference_actor(obs, policy_kwargs, seed)
         pk = checkpoint.policy_kwargs_from_reference(policy_kwargs, self.obs_keys)
         self.weight_decay = pk.get("weight_decay", self.weight_decay)
         return MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},
@@ -108,12 +160,51 @@ class BPTT:
         loss = self._grad_autograd() if self.use_autograd else self._grad_reverse_sweep()
         return self._apply(loss)
 
+    def _grad_reverse_sweep_reference_actor(self):
+        """BPTT.py:107-134 with the reference's actor: per step actor.action_log_prob(obs) (both trunks, clamped log_std, squashed
+        reparameterised sample; the log-prob it also returns is discarded by the loop) -> env.step -> loss / discount recurrence
+        (:123-124); reverse, t = H-1 .. 0: adjoint env step -> action head reverse (d mu, d log_std) -> both trunks + extractor
+        (parameter gradients accumulate) -> gradient w.r.t. the observation of step t, which step t-1 returned"""
+        env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
+        L, st, dev = _lib.lib(), _lib.current_stream(self.device), self.device
+        keys = self.obs_keys
+        pol.grad.zero_()
+        f = dict(dtype=th.float32, device=dev)
+        disc, loss_vec = th.ones(N, **f), th.zeros(N, **f)
+        eps = self._eps_override if self._eps_override is not None else th.randn((H, N, 4), device=dev, generator=self._gen)
+        assert eps.shape == (H, N, 4)
+        acts, drews, ls_rows = th.empty((H, N, 4), **f), th.empty((H, N), **f), []
+        self._last_rollout = dict(action=acts, reward=th.empty((H, N), **f), done=th.empty((H, N), dtype=th.bool, device=dev))
+        t0 = env._tape_t
+        obs = env.get_observation()
+        for t in range(H):
+            o = {k: obs[k].detach().contiguous() for k in keys}
+            mu, ls = pol.forward(o, slot=t)                                            # actor.action_log_prob(obs) :113
+            ls_rows.append(ls)
+            self._head_fwd(mu, ls, eps[t], acts[t])                                    # tanh output: the clip of :114-116 is the identity
+            obs, reward, done, _ = env._step_no_grad(acts[t], False, record=True, borrow=True)      # :119
+            self._last_rollout["reward"][t].copy_(reward)
+            self._last_rollout["done"][t].copy_(done)
+            _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(drews[t]),
+                                            float(self.gamma), 1.0 / (N * self.world), N, st))     # :123-124
+        g_obs = None
+        d_mu, d_ls = th.empty((N, 4), **f), th.empty((N, 4), **f)
+        for t in reversed(range(H)):
+            d_action = env.backward_step(t0 + t, g_obs, drews[t])
+            _lib.check(L.vf_shac_head_bwd(_ptr(d_action), _ptr(acts[t]), _ptr(ls_rows[t]), _ptr(eps[t]), _ptr(d_mu), _ptr(d_ls), N,
+                                          LOG_STD_MIN, LOG_STD_MAX, st))
+            d_in = pol.backward(d_mu, d_ls, None, accumulate=True, need_input_grad=t > 0, slot=t)
+            g_obs = d_in.get("state") if t > 0 else None
+        return loss_vec.mean() / self.world
+
     def _grad_reverse_sweep(self):
         """explicit reverse sweep: no autograd tape.  Forward: policy (activations of every step stay resident in their
         own slot) -> reparameterised action -> fused env step (state checkpoint on the tape) -> loss / discount
         bookkeeping, one launch each.  Reverse, t = H-1 .. 0: adjoint env step -> action head -> whole-network backward
         (parameter gradients accumulate in MFMA partials + fold) -> gradient w.r.t. the observation of step t, which
         is what step t-1 returned.  dLoss/d reward_t = -disc_t / N is known in the forward pass (:123)."""
+        if self.reference_actor:
+            return self._grad_reverse_sweep_reference_actor()
         env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
         L, st, dev = _lib.lib(), _lib.current_stream(self.device), self.device
         pol.grad.zero_()
@@ -216,6 +307,14 @@ class BPTT:
     def predict(self, obs, state=None, episode_start=None, deterministic: bool = False):
         """SB3-style predict (utils/evaluate.py:94): -> (action, None); deterministic: a = tanh(mean)"""
         N = obs[self.obs_keys[0]].shape[0]
+        if self.reference_actor:         # shac.py:334-343 / MTDPolicy.predict
+            mu, ls = self.policy.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, save_activations=False, slot=self.H + 1)
+            if deterministic:
+                return th.tanh(mu), None
+            eps = th.randn((N, 4), device=self.device, generator=self._gen)
+            action = th.empty((N, 4), device=self.device)
+            self._head_fwd(mu, ls.contiguous(), eps, action)
+            return action, None
         mean, _ = self.policy.forward({k: obs[k].detach().contiguous() for k in self.obs_keys}, save_activations=False,
                                       slot=self.H + 1, need_value=False)
         if deterministic:
@@ -223,14 +322,56 @@ class BPTT:
         eps = th.randn((N, 4), device=self.device, generator=self._gen)
         return th.tanh(mean + self.policy.log_std.exp() * eps), None
 
+    # ---- checkpoints ----
+    # MlpPolicy actor: the SB3-layout zip of checkpoint.py.  Reference actor (and SHAC): the reference pickles the whole SB3 policy
+    # object (shac.py:328-332), which cannot exist here; a plain torch archive of the flat parameter buffers, the Adam moments and
+    # step counters, the generator state and the spec the networks are rebuilt from.
+    def _state(self):
+        return {"actor": self.policy.flat.cpu(), "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
+                "opt_step": int(self._opt_step), "num_timesteps": int(self.num_timesteps), "rng": self._gen.get_state().cpu(),
+                "spec": dict(extractor=self._extractor, pi=self.policy.spec["pi"], qf=self._critic_arch, horizon=self.H,
+                             gamma=self.gamma, learning_rate=self.lr, algo=type(self).__name__)}
+
+    def _load_state(self, d, load_optimizer=True):
+        assert d["actor"].numel() == self.policy.flat.numel(), "actor: the archive holds a different network (pass the same policy_kwargs, or use load())"
+        self.policy.flat.copy_(d["actor"])
+        self.policy.mark_updated()
+        if load_optimizer and "exp_avg" in d:
+            self.exp_avg.copy_(d["exp_avg"])
+            self.exp_avg_sq.copy_(d["exp_avg_sq"])
+            self._opt_step, self.num_timesteps = int(d["opt_step"]), int(d.get("num_timesteps", 0))
+            self._gen.set_state(d["rng"])
+
     def save(self, path: str):
-        return checkpoint.save(self, path)
+        if not self.reference_actor:
+            return checkpoint.save(self, path)
+        th.save(self._state(), path if path.endswith(".pth") else path + ".pth")
 
     def set_parameters(self, path: str, load_optimizer: bool = True):
-        return checkpoint.load_into(self, path, load_optimizer)
+        if not self.reference_actor:
+            return checkpoint.load_into(self, path, load_optimizer)
+        self._load_state(th.load(path if path.endswith(".pth") else path + ".pth", map_location="cpu"), load_optimizer)
+        return self
+
+    @staticmethod
+    def _policy_kwargs_from_spec(spec):
+        """the stored network shapes as SB3-style policy_kwargs (what _make_reference_actor parses)"""
+        return dict(features_extractor_class="StateTargetExtractor" if len(spec["extractor"]) > 1 else "StateExtractor",
+                    features_extractor_kwargs={"net_arch": {k: {"layer": list(v)} for k, v in spec["extractor"].items()}},
+                    net_arch=dict(pi=list(spec["pi"]), qf=list(spec["qf"])), activation_fn="relu")
 
     @classmethod
     def load(cls, path: str, env, **kwargs):
+        if path.endswith(".pth") or (not path.endswith(".zip") and os.path.exists(path + ".pth")):
+            d = th.load(path if path.endswith(".pth") else path + ".pth", map_location="cpu")
+            spec, load_opt = d["spec"], kwargs.pop("load_optimizer", True)
+            kwargs.setdefault("policy_kwargs", cls._policy_kwargs_from_spec(spec))
+            kwargs.setdefault("horizon", spec["horizon"])
+            if cls is BPTT:
+                kwargs.setdefault("policy", "MultiInputPolicy")
+            algo = cls(env, **kwargs)
+            algo._load_state(d, load_opt)
+            return algo
         return checkpoint.load_into(cls(env, **checkpoint.ctor_kwargs_from_archive(path, kwargs)), path)
 
     def learn(self, total_timesteps: int, log_interval: Optional[int] = None):

@@ -36,34 +36,38 @@ struct RollArgs {
     float* obs_slots;          // [H][N][13]: slot t = the observation the policy sees at step t (slot 0 filled by the caller)
     float* obs_final;          // (N,13): the observation after the last step
     float gamma, scale;
-    float4* ck;                // optional sub-step tape [H][4 S + 4][N] float4 (include/visfly_amd.h, vf_bptt_rollout) or null
+    float4* ck;                // optional sub-step tape [H][S + 1][waves][64] float4 (include/visfly_amd.h, vf_bptt_rollout) or null
 };
 
 // control_interval observer: the agent at the head of every sub-step -- (q) (v, 0) (w, 0) (rotor speeds) -- and the state after the
-// last one before the clamps -- (p, 0) (q) (v, 0) (w, 0) --, what the adjoint of the interval otherwise obtains by replaying it
+// last one before the clamps -- (p, 0) (q) (v, 0) (w, 0) --, what the adjoint of the interval otherwise obtains by replaying it.
+// One record row = ONE store instruction of the whole wave: the four lane groups (which hold the same 16 agents) store one entry
+// each, [entry k = lane >> 4][agent slot = lane & 15] float4 = 1 KiB contiguous; k_bptt_reverse fetches a row back with one LDS-DMA.
 struct TapeCheckpoint {
-    float4* p;                 // record of (step, agent), or null (replica lanes, no tape)
-    size_t n;                  // float4 between two entries of a record = agents
-    int S;
+    float4* p;                 // row 0 of this (step, wave) + lane, or null (no tape)
+    size_t rs;                 // float4 between two rows of a record = 64 x waves
+    int S, k;                  // sub-steps per interval; this lane's entry (lane >> 4)
+    // two-level selects on the bits of k (a chain `k == 0 ? .. : k == 1 ? ..` is compiled into a scratch array + indexed load)
+    __device__ __forceinline__ float sel(float a, float b, float c2, float d) const
+    {
+        const float lo = (k & 1) ? b : a, hi = (k & 1) ? d : c2;
+        return (k & 2) ? hi : lo;
+    }
+    __device__ __forceinline__ float4 pick(const float4& e0, const float4& e1, const float4& e2, const float4& e3) const
+    {
+        return make_float4(sel(e0.x, e1.x, e2.x, e3.x), sel(e0.y, e1.y, e2.y, e3.y), sel(e0.z, e1.z, e2.z, e3.z), sel(e0.w, e1.w, e2.w, e3.w));
+    }
     __device__ __forceinline__ void head(int sub, const Agent& s) const
     {
-        if (p) {
-            float4* o = p + (size_t)(4 * sub) * n;
-            o[0] = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
-            o[n] = make_float4(s.v[0], s.v[1], s.v[2], 0.0f);
-            o[2 * n] = make_float4(s.w[0], s.w[1], s.w[2], 0.0f);
-            o[3 * n] = make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]);
-        }
+        if (p)
+            p[(size_t)sub * rs] = pick(make_float4(s.q.w, s.q.x, s.q.y, s.q.z), make_float4(s.v[0], s.v[1], s.v[2], 0.0f),
+                                       make_float4(s.w[0], s.w[1], s.w[2], 0.0f), make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]));
     }
     __device__ __forceinline__ void end(const Agent& s) const
     {
-        if (p) {
-            float4* o = p + (size_t)(4 * S) * n;
-            o[0] = make_float4(s.p[0], s.p[1], s.p[2], 0.0f);
-            o[n] = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
-            o[2 * n] = make_float4(s.v[0], s.v[1], s.v[2], 0.0f);
-            o[3 * n] = make_float4(s.w[0], s.w[1], s.w[2], 0.0f);
-        }
+        if (p)
+            p[(size_t)S * rs] = pick(make_float4(s.p[0], s.p[1], s.p[2], 0.0f), make_float4(s.q.w, s.q.x, s.q.y, s.q.z),
+                                     make_float4(s.v[0], s.v[1], s.v[2], 0.0f), make_float4(s.w[0], s.w[1], s.w[2], 0.0f));
     }
 };
 
@@ -136,10 +140,10 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         // the noise row of the NEXT step's action head (drawn before the launch: HBM-cold) is touched here, under the dynamics
         // interval; the head's own load at the end of the next forward then finds it in the cache instead of waiting for HBM
         const float4 eps_touch = gc.rp_eps[(size_t)(t + 1 < r.H ? t + 1 : t) * r.N + i];
-        // sub-step tape of this (step, agent): written by the agent's own lane only (the replica lanes hold the same values)
-        const int cks = 4 * c.interval_steps + 4;
-        const TapeCheckpoint ck{(r.ck && lane < 16 && wave_first + lane < r.N) ? r.ck + (size_t)t * cks * r.N + i : nullptr, (size_t)r.N,
-                                c.interval_steps};
+        // sub-step tape of this (step, wave): [H][S + 1 rows][waves][64] float4 (wave-uniform pointer test: no divergence)
+        const size_t ck_rs = (size_t)gridDim.x * 64;
+        const TapeCheckpoint ck{r.ck ? r.ck + ((size_t)t * (c.interval_steps + 1) * gridDim.x + blockIdx.x) * 64 + lane : nullptr, ck_rs,
+                                c.interval_steps, lane >> 4};
         control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0, ck);
         asm volatile("" :: "v"(eps_touch.x), "v"(eps_touch.y), "v"(eps_touch.z), "v"(eps_touch.w));
         float reward = 0.0f;

@@ -85,8 +85,16 @@ __device__ __forceinline__ void derivs_bwd(const vf_dyn_cfg& c, const Quat& q, c
 
 // Reverse pass of ONE control interval for agent i (see the kernel below for what it computes).  `lds_col` = this thread's column
 // of the [S * kSave][STRIDE] parking area (STRIDE = threads per workgroup).
-template <int KIND, int ACT, int INTEG, bool CTRL_DELAY, int STRIDE>
-__device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf_env_cfg& e, const BwdArgs& g, int i, bool live, float* lds_col)
+//
+// CKPT: the forward kernel left the interval's sub-step tape (k_bptt_rollout's TapeCheckpoint) and the caller has brought this
+// wave's record of the step into LDS (k_bptt_reverse: LDS-DMA one step ahead, double-buffered): `rec` = lane-group-interleaved rows
+// of 64 float4, row r = sub-step r (r < S) or the pre-clamp end state (r = S), entry k of agent slot m at rec[r * 64 + k * 16 + m]
+// -- sub-step rows: (q) (v, 0) (w, 0) (rotor speeds); end row: (p, 0) (q) (v, 0) (w, 0).  The replay of the interval -- a third of
+// this function's instruction stream -- is skipped.  Same values as the replay computes (it runs the forward kernels' own
+// sub-step functions), so the adjoint is bit-identical either way.  16 agents per wave (lane & 15 = agent slot).
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY, int STRIDE, bool CKPT = false>
+__device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf_env_cfg& e, const BwdArgs& g, int i, bool live, float* lds_col,
+                                                   const float4* rec = nullptr)
 {
     float* T = const_cast<float*>(g.tape);
     Agent s;
@@ -142,47 +150,30 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     }
     const float dt = c.dt;
     const int S = c.interval_steps;
-    for (int sub = 0; sub < S; ++sub) {
-        float* sv = lds_col + (size_t)sub * kSave * STRIDE;
-        sv[0 * STRIDE] = s.q.w; sv[1 * STRIDE] = s.q.x; sv[2 * STRIDE] = s.q.y; sv[3 * STRIDE] = s.q.z;
+    const int mslot = threadIdx.x & 15;
+    if constexpr (CKPT) {
+        const float4 ep = rec[S * 64 + mslot], eq = rec[S * 64 + 16 + mslot], ev = rec[S * 64 + 32 + mslot], ew = rec[S * 64 + 48 + mslot];
+        s.p[0] = ep.x; s.p[1] = ep.y; s.p[2] = ep.z;
+        s.q = Quat{eq.x, eq.y, eq.z, eq.w};
+        s.v[0] = ev.x; s.v[1] = ev.y; s.v[2] = ev.z;
+        s.w[0] = ew.x; s.w[1] = ew.y; s.w[2] = ew.z;
+    } else {
+        // the forward kernels' own sub-step functions (control_interval's loop body): the replayed states ARE the forward's, bit for
+        // bit (r03 restated the Euler sub-step here and normalised q with a reciprocal product where the forward divides: 1 ulp)
+        float wdp[4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { sv[(4 + k) * STRIDE] = s.v[k]; sv[(7 + k) * STRIDE] = s.w[k]; }
+        for (int k = 0; k < 4; ++k) wdp[k] = c.one_minus_c * wd[k];           // rotor_setpoint's pre-multiplied set-point
+        for (int sub = 0; sub < S; ++sub) {
+            float* sv = lds_col + (size_t)sub * kSave * STRIDE;
+            sv[0 * STRIDE] = s.q.w; sv[1 * STRIDE] = s.q.x; sv[2 * STRIDE] = s.q.y; sv[3 * STRIDE] = s.q.z;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sv[(10 + k) * STRIDE] = s.wm[k];
-        if constexpr (CTRL_DELAY) {
+            for (int k = 0; k < 3; ++k) { sv[(4 + k) * STRIDE] = s.v[k]; sv[(7 + k) * STRIDE] = s.w[k]; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s.wm[k] = c.c_motor * s.wm[k] + c.one_minus_c * wd[k];
-                s.T[k] = (c.tm0 * (s.wm[k] * s.wm[k]) + c.tm1 * s.wm[k]) + c.tm2;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s.T[k] = Td[k];
-        }
-        float ft[4];
-        mat4(c.B, s.T, ft);
-        const Quat vq{0.0f, s.v[0], s.v[1], s.v[2]};
-        const Quat vb = qmul(qmul(qconj(s.q), vq), s.q);
-        const float vbv[3] = {vb.x, vb.y, vb.z};
-        float u[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) u[k] = (k == 2 ? ft[0] : 0.0f) - (kl[k] * vbv[k] + (kq[k] * vbv[k]) * fabsf(vbv[k]));
-        const Quat uq{0.0f, u[0], u[1], u[2]};
-        const Quat ra = qmul(qmul(s.q, uq), qconj(s.q));
-        s.acc[0] = ra.x / c.m; s.acc[1] = ra.y / c.m; s.acc[2] = ra.z / c.m + c.g_z;
-        if constexpr (INTEG == VF_INT_EULER) {
-            float dq[4], dw[3];
-            derivs(c, s.q, s.w, ft + 1, dq, dw);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s.p[k] += (s.v[k] + c.wind[k]) * dt;
-            s.q.w += dq[0] * dt; s.q.x += dq[1] * dt; s.q.y += dq[2] * dt; s.q.z += dq[3] * dt;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { s.v[k] += s.acc[k] * dt; s.w[k] += dw[k] * dt; }
-            const float nn = sqrtf(((s.q.w * s.q.w + s.q.x * s.q.x) + s.q.y * s.q.y) + s.q.z * s.q.z);
-            s.q = qscale(s.q, 1.0f / nn);
-        } else {   // repaired RK4: the forward kernels' own sub-step functions
-            trans_substep<VF_INT_RK4>(c, s.q, ft[0], kl, kq, c.wind, s.p, s.v, s.acc);
-            rot_substep<VF_INT_RK4>(c, ft + 1, s.q, s.w, s.aa);
+            for (int k = 0; k < 4; ++k) sv[(10 + k) * STRIDE] = s.wm[k];
+            float ft[4];
+            motor_substep<CTRL_DELAY>(c, Td, wdp, s.wm, s.T, ft);
+            trans_substep<INTEG>(c, s.q, ft[0], kl, kq, c.wind, s.p, s.v, s.acc);
+            rot_substep<INTEG>(c, ft + 1, s.q, s.w, s.aa);
         }
     }
     // pre-clamp values decide the clamp masks; clamped values are the step's outputs
@@ -336,13 +327,22 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     float lwd[4] = {0, 0, 0, 0}, lTd[4] = {0, 0, 0, 0};
     float ldw_in[3] = {laa[0], laa[1], laa[2]};  // aa state = dw of the LAST sub-step
     for (int sub = S - 1; sub >= 0; --sub) {
-        const float* sv = lds_col + (size_t)sub * kSave * STRIDE;
-        const Quat q{sv[0 * STRIDE], sv[1 * STRIDE], sv[2 * STRIDE], sv[3 * STRIDE]};
+        Quat q;
         float v[3], w[3], wm0[4];
+        if constexpr (CKPT) {
+            const float4 hq = rec[sub * 64 + mslot], hv = rec[sub * 64 + 16 + mslot], hw = rec[sub * 64 + 32 + mslot], hm = rec[sub * 64 + 48 + mslot];
+            q = Quat{hq.x, hq.y, hq.z, hq.w};
+            v[0] = hv.x; v[1] = hv.y; v[2] = hv.z;
+            w[0] = hw.x; w[1] = hw.y; w[2] = hw.z;
+            wm0[0] = hm.x; wm0[1] = hm.y; wm0[2] = hm.z; wm0[3] = hm.w;
+        } else {
+            const float* sv = lds_col + (size_t)sub * kSave * STRIDE;
+            q = Quat{sv[0 * STRIDE], sv[1 * STRIDE], sv[2 * STRIDE], sv[3 * STRIDE]};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { v[k] = sv[(4 + k) * STRIDE]; w[k] = sv[(7 + k) * STRIDE]; }
+            for (int k = 0; k < 3; ++k) { v[k] = sv[(4 + k) * STRIDE]; w[k] = sv[(7 + k) * STRIDE]; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wm0[k] = sv[(10 + k) * STRIDE];
+            for (int k = 0; k < 4; ++k) wm0[k] = sv[(10 + k) * STRIDE];
+        }
         // recompute this sub-step's intermediates
         float wm1[4], Tt[4];
 #pragma unroll

@@ -19,6 +19,7 @@ Two spawn modes:
       arguments).
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -263,6 +264,8 @@ class DroneGymEnvsBase:
         self.max_episode_steps = int(max_episode_steps)
         self.max_sense_radius = 10
         self.spawn_mode = spawn
+        # persistent BPTT roll-outs also record the integrator sub-steps for the reverse launch (VISFLY_AMD_SUBSTEP_TAPE=0: A/B switch)
+        self.substep_tape = os.environ.get("VISFLY_AMD_SUBSTEP_TAPE", "1") != "0"
         self.validate_actions = (spawn == "replay") if validate_actions is None else validate_actions
         self.seed = seed
         N = self.num_agent
@@ -640,6 +643,7 @@ class DroneGymEnvsBase:
                 self._tape_action_ref[tape_t] = None
                 self._tape_actions[tape_t].copy_(a)
             self._tape_t += 1
+            self._substep_range = None        # a step recorded launch by launch: the sub-step tape no longer covers the horizon
         borrow_done = borrow and tape_t >= 0
         done = self._tape_done[tape_t] if borrow_done else th.empty(N, dtype=th.bool, device=dev)      # the kernel writes 0/1 bytes
         o = self._outs
@@ -863,16 +867,28 @@ class DroneGymEnvsBase:
             self._roll_out = self._out(*self._roll_scratch)
         final = th.empty((N, 13), dtype=th.float32, device=dev)
         L = _lib.lib()
+        # sub-step tape (include/visfly_amd.h, vf_bptt_rollout): what the reverse launch reads instead of replaying every interval;
+        # one (S + 1 rows, waves of 16 agents, 64) float4 record block per tape row, allocated with the first persistent roll-out
+        sub = None
+        if self.substep_tape:
+            if getattr(self, "_substep", None) is None:
+                S = int(self.envs.dynamics.constants["interval_steps"])
+                self._substep = th.empty((self._tape.shape[0], S + 1, (N + 15) // 16, 64, 4), dtype=th.float32, device=dev)
+            sub = self._substep[t0]
+        self._substep_range = None
         with th.cuda.device(dev):
             rc = L.vf_bptt_rollout(self._h, C.byref(d), _lib.ptr(policy.flat), _lib.ptr(policy._packed), _lib.ptr(blk["obs:state"]),
                                    _lib.ptr(o1), _lib.ptr(policy.log_std), _lib.ptr(eps), _lib.ptr(actions), C.byref(self._roll_out),
                                    _lib.ptr(final), _lib.ptr(self._tape[t0]), self._slab.numel(), self._tape_done[t0].data_ptr(),
-                                   _lib.ptr(d_reward), _lib.ptr(loss), _lib.ptr(disc), float(gamma), float(scale), H, self._stream())
+                                   _lib.ptr(d_reward), _lib.ptr(loss), _lib.ptr(disc), float(gamma), float(scale), H, _lib.ptr(sub),
+                                   self._stream())
         if rc == _lib.EUNSUPPORTED:
             _lib.warn_unsupported("vf_bptt_rollout")
             return False
         if rc:
             _lib.check(rc)
+        if sub is not None:
+            self._substep_range = (t0, t0 + H)
         for t in range(H):
             self._tape_action_ref[t0 + t] = actions[t]
         self._tape_t = t0 + H
@@ -954,11 +970,13 @@ class DroneGymEnvsBase:
         d, d_in, d_action = cached
         d.layer[0].dY = _lib.ptr(d_means)
         policy._pack()
+        # the sub-step tape only if exactly these H steps were recorded by ONE persistent roll-out with the tape on
+        sub = self._substep[t0] if getattr(self, "_substep_range", None) == (t0, t0 + H) else None
         with th.cuda.device(dev):
             rc = _lib.lib().vf_bptt_reverse(self._h, C.byref(d), _lib.ptr(policy._packed), _lib.ptr(policy.log_std), _lib.ptr(eps),
                                             _lib.ptr(actions), _lib.ptr(self._tape[t0]), self._slab.numel(), self._tape_done[t0].data_ptr(),
                                             _lib.ptr(d_reward), _lib.ptr(self._adj), _lib.ptr(d_action), _lib.ptr(d_in["state"]),
-                                            _lib.ptr(g_log_std), H, self._stream())
+                                            _lib.ptr(g_log_std), H, _lib.ptr(sub), self._stream())
         if rc == _lib.EUNSUPPORTED:
             _lib.warn_unsupported("vf_bptt_reverse")
             return False
@@ -970,6 +988,7 @@ class DroneGymEnvsBase:
         """env.detach() of the reference (droneGymEnv.py:286-300): cut the graph at the current state"""
         if self._tape is not None:
             self._tape_t = 0
+            self._substep_range = None
             self._adj.zero_()
             self._token = th.zeros(1, device=self.device, requires_grad=True)
 

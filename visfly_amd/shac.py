@@ -35,10 +35,8 @@ from typing import Optional
 import torch as th
 
 from . import _lib, checkpoint, parallel
-from .bptt import BPTT
+from .bptt import BPTT, LOG_STD_MAX, LOG_STD_MIN
 from .ppo import MlpPolicy, _ptr
-
-LOG_STD_MAX, LOG_STD_MIN = 2.0, -10.0        # td_policies.py:31-32
 
 
 class SHAC(BPTT):
@@ -53,6 +51,7 @@ class SHAC(BPTT):
             raise NotImplementedError(f"policy {policy}: vector-observation MTDPolicy only")
         self._critic_arch = None
         self.tau, self.gradient_steps, self.lamda = tau, gradient_steps, lamda
+        kw.pop("policy", None)
         super().__init__(env, horizon=horizon, gamma=gamma, learning_rate=learning_rate, max_grad_norm=max_grad_norm,
                          policy_kwargs=policy_kwargs, seed=seed, **kw)
         pol, dev = self.policy, self.device
@@ -70,39 +69,12 @@ class SHAC(BPTT):
         self._c_sumsq = th.zeros(1, device=dev)
         self._critic_step = 0
         self._buf = None
-        self._eps_override = None            # tests: (2H, N, 4) noise feed, [2t] = action of step t, [2t+1] = next action
+        # _eps_override (tests): (2H, N, 4) noise feed, [2t] = action of step t, [2t+1] = next action
 
     # ---- networks ---------------------------------------------------------------------------------------------------------
-    def _make_policy(self, obs, policy_kwargs, seed):
-        """the Actor: extractor -> (latent_pi -> mu | log_latent_pi -> log_std); nn.Linear default initialisation (SB3's SAC
-        policies do not use orthogonal init), log_latent_pi = deepcopy(latent_pi) (td_policies.py:205)"""
-        pk = dict(policy_kwargs or {})
-        na = pk.get("net_arch")
-        if isinstance(na, dict) and "qf" in na:                       # SB3 get_actor_critic_arch: dict(pi=..., qf=...)
-            self._critic_arch = list(na["qf"])
-            pk["net_arch"] = dict(pi=list(na["pi"]), vf=list(na["pi"]))
-        if pk.get("share_features_extractor"):
-            raise NotImplementedError("share_features_extractor=True: the critic here owns its extractor (the reference default)")
-        pk.pop("share_features_extractor", None)
-        if any(k in pk for k in ("features_extractor_class", "net_arch", "features_extractor_kwargs", "activation_fn")):
-            pk.setdefault("activation_fn", "relu")                    # MTDPolicy's default activation IS ReLU (td_policies.py:297)
-        pk = checkpoint.policy_kwargs_from_reference(pk, self.obs_keys)
-        self._extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
-        self._ext_keys = list(self._extractor.keys())
-        arch = list(pk.get("pi", [64, 64]))
-        if self._critic_arch is None:
-            self._critic_arch = list(arch)
-        pol = MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys}, self._extractor, arch, arch, self.device, seed=seed,
-                        ortho_init=False, head_dims=(4, 4), log_std_param=False)
-        hidden = lambda trunk: [ly for ly in pol.layers if ly.dst.startswith(trunk + ":")]
-        for a, b in zip(hidden("pi"), hidden("vf")):                  # log_latent_pi starts as a copy of latent_pi
-            pol.weight(b).copy_(pol.weight(a))
-            pol.bias(b).copy_(pol.bias(a))
-        return pol
-
-    def _head_fwd(self, mu, log_std, eps, action):
-        _lib.check(_lib.lib().vf_shac_head_fwd(_ptr(mu), _ptr(log_std), _ptr(eps), _ptr(action), mu.shape[0], LOG_STD_MIN,
-                                               LOG_STD_MAX, _lib.current_stream(self.device)))
+    # the Actor (extractor -> latent_pi -> mu | log_latent_pi -> log_std) and its action head are BPTT's reference-actor path
+    # (bptt.py::_make_reference_actor / _head_fwd): the reference's BPTT and SHAC share td_policies.Actor
+    reference_actor = True
 
     def _q(self, net, obs, action, save=False, slot=0):
         q0, q1 = net.forward({**{k: obs[k] for k in self._ext_keys}, "action": action}, save_activations=save, slot=slot)
@@ -231,21 +203,20 @@ class SHAC(BPTT):
         self._head_fwd(mu, ls.contiguous(), eps, action)
         return action, None
 
-    def save(self, path: str):
-        """the reference pickles the whole SB3 policy object (shac.py:328-332), which cannot exist here; this writes the flat
-        parameter buffers and the layer tables' shapes as a plain torch archive"""
-        th.save({"actor": self.policy.flat.cpu(), "critic": self.critic.flat.cpu(), "critic_target": self.critic_target.flat.cpu(),
-                 "spec": dict(extractor=self._extractor, pi=self.policy.spec["pi"], qf=self._critic_arch, horizon=self.H)},
-                path if path.endswith(".pth") else path + ".pth")
+    def _state(self):
+        d = super()._state()
+        d.update({"critic": self.critic.flat.cpu(), "critic_target": self.critic_target.flat.cpu(), "c_exp_avg": self.c_exp_avg.cpu(),
+                  "c_exp_avg_sq": self.c_exp_avg_sq.cpu(), "critic_step": int(self._critic_step)})
+        d["spec"].update(tau=self.tau, gradient_steps=self.gradient_steps, lamda=self.lamda)
+        return d
 
-    def set_parameters(self, path: str, load_optimizer: bool = True):
-        d = th.load(path if path.endswith(".pth") else path + ".pth", map_location="cpu")
-        for net, key in ((self.policy, "actor"), (self.critic, "critic"), (self.critic_target, "critic_target")):
-            assert d[key].numel() == net.flat.numel(), f"{key}: archive holds a different network"
+    def _load_state(self, d, load_optimizer=True):
+        super()._load_state(d, load_optimizer)
+        for net, key in ((self.critic, "critic"), (self.critic_target, "critic_target")):
+            assert d[key].numel() == net.flat.numel(), f"{key}: the archive holds a different network"
             net.flat.copy_(d[key])
             net.mark_updated()
-        return self
-
-    @classmethod
-    def load(cls, path: str, env, **kwargs):
-        return cls(env, **kwargs).set_parameters(path)
+        if load_optimizer and "c_exp_avg" in d:
+            self.c_exp_avg.copy_(d["c_exp_avg"])
+            self.c_exp_avg_sq.copy_(d["c_exp_avg_sq"])
+            self._critic_step = int(d["critic_step"])
