@@ -435,6 +435,63 @@ def test_chain_backward_vs_torch_and_block_tile_kernel(M, net, mode):
     assert torch.allclose(pol.grad, 2 * res[True][0], rtol=1e-5, atol=1e-6 * scale)
 
 
+@pytest.mark.parametrize("M", [1, 33, 777, 16384, 25600])
+@pytest.mark.parametrize("net", ["nav", "hover"])
+@pytest.mark.parametrize("ig", [True, False])
+def test_sac_actor_chain_vs_torch_and_block_tile_kernel(M, net, ig):
+    """r04: the reference's SAC-style Actor (td_policies.py:146-252: latent_pi -> mu, log_latent_pi -> log_std, two 4-wide heads; the
+    actor of its BPTT and SHAC loops) on the register-chained kernels (vf_mlp_chain_sac.hip: forward in 32- and 16-row form, reverse
+    chain of both trunks with and without the observation gradient) against torch on the same weights and against the block-tile
+    kernels it ran on until r03; deterministic"""
+    from visfly_amd import _lib
+    from visfly_amd.ppo import MlpPolicy
+    import ctypes as C
+    dims = {"state": 13, "target": 3} if net == "nav" else {"state": 13}
+    pol = MlpPolicy(dims, {k: [128, 64] for k in dims}, [64, 64], [64, 64], DEV, seed=9, ortho_init=False, head_dims=(4, 4), log_std_param=False)
+    g = torch.Generator(device=DEV).manual_seed(M + 5)
+    obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+    d_mu = torch.randn((M, 4), device=DEV, generator=g) / M
+    d_ls = torch.randn((M, 4), device=DEV, generator=g) / M
+    ref = pol.to_torch().double().to(DEV)          # fp64 reference: the bound below is this path's own rounding
+    xs = {k: v.double().requires_grad_(ig) for k, v in obs.items()}
+    m0, v0 = ref(xs)
+    ((m0 * d_mu.double()).sum() + (v0 * d_ls.double()).sum()).backward()
+    gref = ref.flat_grad().to(DEV).float()
+    m0, v0 = m0.float(), v0.float()
+    mu, ls = pol.forward(obs)
+    assert mu.shape == ls.shape == (M, 4)
+    sc = max(m0.abs().max().item(), v0.abs().max().item())
+    assert (mu - m0).abs().max().item() <= 2e-6 * sc and (ls - v0).abs().max().item() <= 2e-6 * sc
+    # the chain classes ARE what ran: the library's capability query answers for this layer table
+    b = pol._buffers(M, 0)
+    bd = pol._bwd_desc(b, M, d_mu, d_ls, ig)[0]
+    assert _lib.lib().vf_mlp_backward_data_supported(C.byref(bd)) == 1
+    res = {}
+    for fused in (True, False, True):
+        pol.fused_backward = fused
+        pol.grad.fill_(0.0)
+        pol.forward(obs)
+        d_in = pol.backward(d_mu, d_ls, None, need_input_grad=ig)
+        if fused and fused in res:
+            assert torch.equal(res[True][0], pol.grad)
+        res[fused] = (pol.grad.clone(), {k: v.clone() for k, v in d_in.items()})
+    scale = gref.abs().max().item()
+    # the two backward implementations start from the SAME saved activations (one forward kernel): they must agree to rounding ...
+    assert (res[True][0] - res[False][0]).abs().max().item() <= 5e-6 * scale
+    for fused in (True, False):
+        # ... while against the fp64 network a ReLU mask can flip where a pre-activation is within fp32 rounding of zero: one flipped
+        # unit in one row moves a gradient entry by ~|d| |w x| ~ 1 / M -- measured 1.5e-5 .. 2e-4 of the largest entry at M >= 16 384
+        # (identically for both implementations), < 2e-7 below
+        err = (res[fused][0] - gref).abs().max().item()
+        assert err <= (1e-3 if M >= 16384 else 2e-6) * scale, (fused, err, scale)
+        for k, v in res[fused][1].items():
+            assert torch.allclose(v, xs[k].grad.float(), rtol=1e-3, atol=(1e-3 if M >= 16384 else 1e-5) * xs[k].grad.abs().max().item())
+    pol.fused_backward = True
+    pol.forward(obs)
+    pol.backward(d_mu, d_ls, None, accumulate=True, need_input_grad=ig)
+    assert torch.allclose(pol.grad, 2 * res[True][0], rtol=1e-5, atol=1e-6 * scale)
+
+
 @pytest.mark.parametrize("shape", ["reference", "other"])
 def test_policy_only_forward_and_split_backward(shape):
     """need_value=False: same action mean (the register-chained kernel skips the value trunk, other layer tables fall

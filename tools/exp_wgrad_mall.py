@@ -9,7 +9,12 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if len(sys.argv) > 3:            # A/B: another build of the library (python -c "from visfly_amd import _build; _build.build(force=True, extra_flags=[..], out=..)")
+    from visfly_amd import _build
+    _build.LIB = sys.argv[3]
 from visfly_amd import _lib
+if len(sys.argv) > 3:
+    _lib.LIB = sys.argv[3]
 from visfly_amd.ppo import MlpPolicy, _ptr
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 25600

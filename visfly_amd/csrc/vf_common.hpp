@@ -117,6 +117,10 @@ int chain16_policy_class(const vf_mlp_desc* d, const float* params);   // vf_mlp
 int chain_full_class(const vf_mlp_desc* d, const float* params, int M);   // 0 none, 1 NetHover, 2 NetNav (both trunks); + 16: M rows run on the 16-row chain
 // reverse chain (data gradients) for the same network classes: 1 launched, 0 no match, < 0 error
 int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp = nullptr);
+// the same for the SAC-style Actor's network classes (vf_mlp_chain_sac.hip); called by the two functions above as their last resort
+int mlp_forward_chain_try_sac(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
+                              float* out0, float* out1, int M, hipStream_t st);
+int mlp_backward_chain_try_sac(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st);
 int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,
                          const float* in1, const float* log_std, const float* action, const float* old_lp, const float* adv,
                          const float* ret, float* part, const vf_ppo_loss_cfg* cfg, int M, hipStream_t st);

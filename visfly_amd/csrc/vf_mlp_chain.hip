@@ -19,78 +19,12 @@
 // policies.py:18-49): NB extractor branches of two ReLU layers, concatenated, then policy / value trunks of two
 // ReLU layers with a 4-wide / 1-wide head.  vf_mlp_forward picks it when the layer table matches an instantiated
 // shape and falls back to the LDS kernel (k_mlp_forward) otherwise.
-#include "vf_mlp_chain_bwd.hpp"
+#include "vf_mlp_chain_kernels.hpp"
 
 namespace vf {
 
 
 // (the 32-row forward's device code -- chain_load .. chain_prologue -- lives in vf_mlp_chain.hpp: vf_ppo_rollout.hip runs it too)
-
-template <class N>
-__global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
-{
-    prefetch_kernarg<sizeof(ChainArgs)>();
-    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
-    const int row = blockIdx.x * 32 + m;
-    const bool live = row < g.M;
-    const int rc = live ? row : g.M - 1;
-    ChainState<N> st;
-    chain_prologue<N, 0>(g, st, lane);
-#pragma unroll
-    for (int b = 0; b < N::NB; ++b) {
-        const int w = g.d.in_dim[b];
-        const float* x = g.io.in[b] + (size_t)rc * w;
-        float* xc = g.obs_copy[b] ? g.obs_copy[b] + (size_t)rc * w : nullptr;
-#pragma unroll
-        for (int s = 0; s < N::kin(b) / 2; ++s) {
-            const int k = 2 * s + h;
-            const float v = x[k < w ? k : w - 1];
-            st.x[b][s] = k < w ? v : 0.0f;
-            if (xc && live && k < w) xc[k] = v;
-        }
-    }
-    chain_items<N, 0>(g, st, lane, row, live);
-}
-
-template <class N>
-__global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
-{
-    VF_TRACE(0);
-    prefetch_kernarg<sizeof(ChainArgs)>();
-    const int lane = threadIdx.x, m = lane & 15, gq = lane >> 4;
-    const int row = blockIdx.x * 16 + m;
-    const bool live = row < g.M;
-    const int rc = live ? row : g.M - 1;
-    ChainState16<N> st;
-    chain16_prologue<N, 0>(g, st, lane);
-#pragma unroll
-    for (int b = 0; b < N::NB; ++b) {
-        const int w = g.d.in_dim[b];
-        const float* x = g.io.in[b] + (size_t)rc * w;
-        float* xc = g.obs_copy[b] ? g.obs_copy[b] + (size_t)rc * w : nullptr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = 4 * gq + j;
-            const float v = x[k < w ? k : w - 1];
-            st.x[b][j] = k < w ? v : 0.0f;
-            if (xc && live && k < w) xc[k] = v;
-        }
-    }
-    VF_TRACE(1);
-    chain16_items<N, 0>(g, st, lane, row, live);
-    VF_TRACE(31);
-}
-
-template <class P, int ROWS = 32>
-__global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
-{
-    prefetch_kernarg<sizeof(BwdArgsChain)>();
-    const int lane = threadIdx.x, m = lane & (ROWS - 1);
-    const int row = blockIdx.x * ROWS + m;
-    const bool live = row < g.M;
-    const int rc = live ? row : g.M - 1;
-    bwd_rows<P, ROWS>(g, lane, row, rc, live);
-}
 
 // ------------------------------------------------------------------------------------------------
 // PPO minibatch step, everything that is per-row in ONE launch: forward chain -> clipped-surrogate loss of the wave's
@@ -173,151 +107,6 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
 }
 
 
-// does the layer table describe network class N (shapes, wiring, execution order of MlpPolicy)?
-template <class N>
-bool chain_matches(const vf_mlp_desc& d)
-{
-    if (d.n_layers != N::n_layers || d.n_inputs != N::NB) return false;
-    for (int b = 0; b < N::NB; ++b)
-        if (d.in_dim[b] < 1 || d.in_dim[b] > N::kin(b)) return false;
-    auto is = [&](int li, int K, int No, int relu) {
-        const vf_mlp_layer& L = d.layer[li];
-        return L.K == K && L.No == No && (L.relu != 0) == (relu != 0) && L.wr_off >= 0 && (L.wr_off & 3) == 0;
-    };
-    const int feat = N::NB * N::E2 * 32;
-    for (int b = 0; b < N::NB; ++b) {
-        if (!is(2 * b, d.in_dim[b], N::E1 * 32, 1) || !is(2 * b + 1, N::E1 * 32, N::E2 * 32, 1)) return false;
-        const vf_mlp_layer &l1 = d.layer[2 * b], &l2 = d.layer[2 * b + 1];
-        if (l1.src != b || l1.src_col != 0 || l2.src != l1.dst || l2.src_col != l1.dst_col) return false;
-        if (l2.dst_col != b * N::E2 * 32 || l2.dst != d.layer[1].dst) return false;
-    }
-    const int base = 2 * N::NB, fid = d.layer[1].dst;
-    const int w1[2] = {N::P1 * 32, N::V1 * 32}, w2[2] = {N::P2 * 32, N::V2 * 32}, wo[2] = {4, 1};
-    for (int t = 0; t < 2; ++t) {
-        const int l = base + 3 * t;
-        if (!is(l, feat, w1[t], 1) || !is(l + 1, w1[t], w2[t], 1) || !is(l + 2, w2[t], wo[t], 0)) return false;
-        if (d.layer[l].src != fid || d.layer[l].src_col != 0) return false;
-        if (d.layer[l + 1].src != d.layer[l].dst || d.layer[l + 2].src != d.layer[l + 1].dst) return false;
-        if (d.layer[l + 2].dst != VF_MLP_OUT0 + t) return false;
-    }
-    for (int i = 0; i < d.n_layers; ++i) {
-        const vf_mlp_layer& L = d.layer[i];
-        if (L.save && ((L.save_ld & 3) || (L.dst_col & 3) || (reinterpret_cast<uintptr_t>(L.save) & 15))) return false;
-    }
-    return true;
-}
-
-// 16 rows per wave: only while it doubles the waves without exceeding one per SIMD (M <= 16 384), K <= 16 observation rows,
-// and the weight rows the kernel reads as float4 are 16-byte aligned.  VISFLY_AMD_MLP_CHAIN16=0/1 forces the choice (A/B).
-template <class N>
-bool chain16_ok(const vf_mlp_desc& d, const float* params, int M)
-{
-    static const int forced = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN16"); return e ? atoi(e) : -1; }();
-    if (forced == 0 || (forced < 0 && M > 16384)) return false;
-    if (reinterpret_cast<uintptr_t>(params) & 15) return false;
-    for (int b = 0; b < N::NB; ++b)
-        if (d.in_dim[b] > 16) return false;
-    for (int i = 0; i < N::n_exec; ++i) {
-        const vf_mlp_layer& L = d.layer[N::layer(i).desc];
-        if (N::layer(i).obs < 0 && ((L.w_off & 3) || (L.K & 15))) return false;
-        if (L.wt_off < 0) return false;               // the transposed image the A fragments come from (chain16_load)
-    }
-    return true;
-}
-
-template <class N>
-int chain_launch(const vf_mlp_desc& d, const float* params, const float* packed, const float* in0, const float* in1, float* out0,
-                 float* out1, int M, hipStream_t st, const ReparamFwd& rp)
-{
-    ChainArgs g{d, params, packed, ChainIo{{in0, in1}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.action),
-                {rp.obs_copy[0], rp.obs_copy[1]}};
-    if (chain16_ok<N>(d, params, M))
-        hipLaunchKernelGGL(k_mlp_forward_chain16<N>, dim3((M + 15) / 16), dim3(64), 0, st, g);
-    else
-        hipLaunchKernelGGL(k_mlp_forward_chain<N>, dim3((M + 31) / 32), dim3(64), 0, st, g);
-    VF_HIP(hipGetLastError());
-    return 1;
-}
-
-template <class N, bool PI, bool VF, bool IG>
-bool bwd_chain_matches(const vf_mlp_bwd_desc& d)
-{
-    using P = BwdProg<N, PI, VF, IG>;
-    if (d.n_layers != 2 * N::NB + 3 * ((PI ? 1 : 0) + (VF ? 1 : 0))) return false;
-    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    auto is = [&](int fl, int K, int No, bool relu, bool first) {
-        const vf_mlp_bwd_layer& E = d.layer[P::entry(fl)];
-        if (E.K != K || E.No != No || (E.Y != nullptr) != relu || E.wq_off < 0 || (E.wq_off & 3)) return false;
-        if (relu && (!al16(E.Y) || (E.ld_y & 3) || !al16(E.dY) || (E.ld_dy & 3))) return false;   // float4 mask loads / dZ stores
-        if (first ? (E.need_dx != 0) != IG : E.need_dx == 0) return false;
-        return true;
-    };
-    for (int b = 0; b < N::NB; ++b) {
-        const int K0 = d.layer[P::entry(2 * b)].K;
-        if (K0 < 1 || K0 > N::kin(b) || K0 > 32) return false;
-        if (!is(2 * b, K0, N::E1 * 32, true, true) || !is(2 * b + 1, N::E1 * 32, N::E2 * 32, true, false)) return false;
-    }
-    const int feat = N::NB * N::E2 * 32;
-    if (PI && (!is(P::L_pi0, feat, N::P1 * 32, true, false) || !is(P::L_pi1, N::P1 * 32, N::P2 * 32, true, false) ||
-               !is(P::L_mean, N::P2 * 32, 4, false, false)))
-        return false;
-    if (VF && (!is(P::L_vf0, feat, N::V1 * 32, true, false) || !is(P::L_vf1, N::V1 * 32, N::V2 * 32, true, false) ||
-               !is(P::L_val, N::V2 * 32, 1, false, false)))
-        return false;
-    // wiring: the gradient a layer's consumer produces is that layer's dY buffer (incl. the feature concat)
-    for (int b = 0; b < N::NB; ++b) {
-        if (d.layer[P::entry(2 * b + 1)].dX != d.layer[P::entry(2 * b)].dY) return false;
-        const vf_mlp_bwd_layer& first_trunk = d.layer[P::entry(PI ? P::L_pi0 : P::L_vf0)];
-        if (d.layer[P::entry(2 * b + 1)].dY != first_trunk.dX + b * N::E2 * 32 || d.layer[P::entry(2 * b + 1)].ld_dy != first_trunk.ld_dx) return false;
-    }
-    if (PI && (d.layer[P::entry(P::L_pi1)].dX != d.layer[P::entry(P::L_pi0)].dY || d.layer[P::entry(P::L_mean)].dX != d.layer[P::entry(P::L_pi1)].dY))
-        return false;
-    if (VF && (d.layer[P::entry(P::L_vf1)].dX != d.layer[P::entry(P::L_vf0)].dY || d.layer[P::entry(P::L_val)].dX != d.layer[P::entry(P::L_vf1)].dY))
-        return false;
-    if (PI && VF && d.layer[P::entry(P::L_pi0)].dX != d.layer[P::entry(P::L_vf0)].dX) return false;
-    return true;
-}
-
-// 16 rows per wave for the reverse chain?  The forward's rule (chain16_ok): a small row count leaves half of the SIMDs without a
-// wave; only the policy-trunk variant with observation gradient (first-order policy optimisation, whose shards are small) is
-// instantiated.  Needs the row-major data-gradient image (wb_off) and observation widths <= 16.  VISFLY_AMD_MLP_CHAIN16=0/1
-// forces the choice (A/B) together with the forward's.
-template <class N, bool PI, bool VF, bool IG>
-bool bwd16_ok(const vf_mlp_bwd_desc& d, int M)
-{
-    if constexpr (!(PI && !VF && IG)) return false;
-    using P = BwdProg<N, PI, VF, IG>;
-    static const int forced = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN16"); return e ? atoi(e) : -1; }();
-    if (forced == 0 || (forced < 0 && M > 16384)) return false;
-    for (int l = 0; l < d.n_layers; ++l)
-        if (d.layer[l].wb_off < 0) return false;
-    for (int b = 0; b < N::NB; ++b)
-        if (d.layer[P::entry(2 * b)].K > 16) return false;
-    return true;
-}
-
-template <class N, bool PI, bool VF, bool IG>
-int bwd_chain_launch(const vf_mlp_bwd_desc& d, const float* packed, int M, hipStream_t st, const ReparamBwd& rp)
-{
-    BwdArgsChain g{d, packed, M, reinterpret_cast<const float4*>(rp.d_action), reinterpret_cast<const float4*>(rp.action), rp.log_std,
-                   reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.g_log_std)};
-    if constexpr (PI && !VF && IG) {
-        if (bwd16_ok<N, PI, VF, IG>(d, M)) {
-            hipLaunchKernelGGL((k_mlp_backward_chain<BwdProg<N, PI, VF, IG>, 16>), dim3((M + 15) / 16), dim3(64), 0, st, g);
-            VF_HIP(hipGetLastError());
-            return 1;
-        }
-    }
-    hipLaunchKernelGGL((k_mlp_backward_chain<BwdProg<N, PI, VF, IG>>), dim3((M + 31) / 32), dim3(64), 0, st, g);
-    VF_HIP(hipGetLastError());
-    return 1;
-}
-
-// data gradients of the whole network (masked dZ of every hidden layer left in the dY buffers, optional observation
-// gradients): 1 launched, 0 not an instantiated class / variant, < 0 error.  Variants: PPO update (both trunks, no
-// observation gradient) and first-order policy optimisation (policy trunk only, observation gradient).
-// the chains address their activation / gradient stores with 32-bit BYTE offsets (row * ld * 4): rows x widest row < 4 GiB
-static bool rows_fit_u32(int M, int ld_max) { return (unsigned long long)M * (unsigned long long)ld_max * 4ull < (1ull << 32); }
 
 int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rpp)
 {
@@ -331,6 +120,7 @@ int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M,
     if (bwd_chain_matches<NetNav, true, false, true>(*d)) return launch ? bwd_chain_launch<NetNav, true, false, true>(*d, packed, M, st, rp) : 1;
     if (bwd_chain_matches<NetHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetHover, true, true, false>(*d, packed, M, st, rp) : 1;
     if (bwd_chain_matches<NetHover, true, false, true>(*d)) return launch ? bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st, rp) : 1;
+    if (!rpp) return mlp_backward_chain_try_sac(d, packed, M, st);       // the SAC-style Actor's classes (vf_mlp_chain_sac.hip)
     return 0;
 }
 
@@ -379,6 +169,7 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     }
     if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
     if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
+    if (!rpp) return mlp_forward_chain_try_sac(d, params, packed, in0, in1, out0, out1, M, st);    // SAC-style Actor (vf_mlp_chain_sac.hip)
     return 0;
 }
 

@@ -41,10 +41,13 @@ struct ChainLayer {
 
 // NB branches (KA / KB = first-layer widths padded to 8), hidden widths in 32-feature tiles
 // VF_ = false: the value trunk is not executed (first-order policy optimisation only needs the action mean)
-template <int NB_, int KA_, int KB_, int E1_, int E2_, int P1_, int P2_, int V1_, int V2_, bool VF_ = true>
+// HV_: width of the second trunk's head -- 1 = the critic's value (policies.py:18-49), 4 = the state-dependent log_std head of the
+// reference's SAC-style Actor (utils/policies/td_policies.py:146-252: latent_pi -> mu, log_latent_pi -> log_std), output (M, 4)
+template <int NB_, int KA_, int KB_, int E1_, int E2_, int P1_, int P2_, int V1_, int V2_, bool VF_ = true, int HV_ = 1>
 struct ChainNet {
-    static constexpr int NB = NB_, E1 = E1_, E2 = E2_, P1 = P1_, P2 = P2_, V1 = V1_, V2 = V2_;
+    static constexpr int NB = NB_, E1 = E1_, E2 = E2_, P1 = P1_, P2 = P2_, V1 = V1_, V2 = V2_, HV = HV_;
     static constexpr bool VF = VF_;
+    static_assert(HV_ == 1 || HV_ == 4, "second head: 1 (value) or 4 (log_std) wide");
     static constexpr int kin(int b) { return b == 0 ? KA_ : KB_; }
     static constexpr int n_layers = 2 * NB + 6;              // layers of the vf_mlp_desc this class matches
     static constexpr int n_exec = 2 * NB + (VF ? 6 : 3);     // layers the kernel runs
@@ -141,6 +144,8 @@ using NetHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2>;   // StateExtractor [128,
 using NetNav = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2>;     // StateTargetExtractor [128, 64] x 2, pi / vf [64, 64]
 using NetHoverPi = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, false>;
 using NetNavPi = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2, false>;
+using NetSacHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, true, 4>;   // td_policies.Actor over StateExtractor: mu / log_std heads
+using NetSacNav = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2, true, 4>;     // ... over StateTargetExtractor
 
 
 // ---- the 32-rows-per-wave forward (the scheme at the head of vf_mlp_chain.hip) ----
@@ -162,9 +167,9 @@ __device__ __forceinline__ void chain_bias_load(const ChainArgs& g, ChainState<N
 {
     constexpr ChainLayer L = N::layer(LI);
     const float* b = g.params + g.d.layer[L.desc].b_off;    // b_off is only dword aligned
-    if constexpr (L.desc == N::L_value) {
+    if constexpr (L.desc == N::L_value && N::HV == 1) {
         st.bias[0][0] = make_float4(b[0], 0.0f, 0.0f, 0.0f);
-    } else if constexpr (L.desc == N::L_mean) {
+    } else if constexpr (L.desc == N::L_mean || L.desc == N::L_value) {
         const f32x4u v = *reinterpret_cast<const f32x4u*>(b);
         st.bias[0][0] = make_float4(v.x, v.y, v.z, v.w);
     } else {
@@ -194,6 +199,8 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>
                     g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
                                                    tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
                 }
+            } else if constexpr (N::HV == 4) {
+                if (g.io.value) *reinterpret_cast<float4*>(g.io.value + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
             } else {
                 if (g.io.value) g.io.value[row] = y[0];
             }
@@ -395,9 +402,9 @@ __device__ __forceinline__ void chain16_bias_load(const ChainArgs& g, ChainState
 {
     constexpr ChainLayer L = N::layer(LI);
     const float* b = g.params + g.d.layer[L.desc].b_off;    // b_off is only dword aligned
-    if constexpr (L.desc == N::L_value) {
+    if constexpr (L.desc == N::L_value && N::HV == 1) {
         st.bias[0] = make_float4(b[0], 0.0f, 0.0f, 0.0f);
-    } else if constexpr (L.desc == N::L_mean) {
+    } else if constexpr (L.desc == N::L_mean || L.desc == N::L_value) {
         const f32x4u v = *reinterpret_cast<const f32x4u*>(b);
         st.bias[0] = make_float4(v.x, v.y, v.z, v.w);
     } else {
@@ -425,6 +432,8 @@ __device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState1
                     g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
                                                    tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
                 }
+            } else if constexpr (N::HV == 4) {
+                if (g.io.value) *reinterpret_cast<float4*>(g.io.value + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
             } else {
                 if (g.io.value) g.io.value[row] = y[0];
             }

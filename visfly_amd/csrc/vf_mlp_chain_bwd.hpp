@@ -277,6 +277,9 @@ __device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdStat
                     st.hin[0][0] = h == 0 ? dy[0] : 0.0f; st.hin[0][1] = h == 0 ? dy[1] : 0.0f;
                     st.hin[0][2] = h == 0 ? dy[2] : 0.0f; st.hin[0][3] = h == 0 ? dy[3] : 0.0f;
                 }
+            } else if constexpr (P::Net::HV == 4) {      // second head 4 wide (the SAC actor's log_std head): d_log_std (M,4)
+                st.hin[1][0] = h == 0 ? dy[0] : 0.0f; st.hin[1][1] = h == 0 ? dy[1] : 0.0f;
+                st.hin[1][2] = h == 0 ? dy[2] : 0.0f; st.hin[1][3] = h == 0 ? dy[3] : 0.0f;
             } else {
                 st.hin[1][0] = h == 0 ? dy[0] : 0.0f; st.hin[1][1] = 0.0f; st.hin[1][2] = 0.0f; st.hin[1][3] = 0.0f;
             }
@@ -561,6 +564,8 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
                     dm = make_float4(dy[0], dy[1], dy[2], dy[3]);
                 }
                 st.hin[0] = gq == 0 ? dm.x : gq == 1 ? dm.y : gq == 2 ? dm.z : dm.w;
+            } else if constexpr (P::Net::HV == 4) {
+                st.hin[1] = dy[gq];
             } else {
                 st.hin[1] = gq == 0 ? dy[0] : 0.0f;
             }

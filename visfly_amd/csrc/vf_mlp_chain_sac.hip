@@ -1,0 +1,43 @@
+// vf_mlp_chain_sac.hip -- register-chained kernels for the reference's SAC-style Actor (utils/policies/td_policies.py:146-252):
+// features extractor -> two trunks of one shape, latent_pi -> mu (4) and log_latent_pi -> log_std (4), i.e. the actor-critic class
+// with a 4-wide second head (ChainNet<.., HV = 4>).  It is the actor of the reference's BPTT (utils/algorithms/BPTT.py:113) and SHAC
+// (utils/algorithms/shac.py:219) loops; until r04 it ran on the block-tile kernels (k_mlp_forward / k_mlp_backward).
+//   forward            k_mlp_forward_chain / _chain16 <NetSacHover | NetSacNav>: mu -> out0 (M,4), log_std -> out1 (M,4)
+//   reverse            k_mlp_backward_chain <BwdProg<Net, pi, vf, IG>> from d_mu / d_log_std (M,4): both trunks, with and without the
+//                      observation gradient (the first step of a horizon does not need it); masked layer gradients for k_mlp_wgrad
+// A translation unit of its own so that its instances compile next to vf_mlp_chain.hip's, not after them.
+#include "vf_mlp_chain_kernels.hpp"
+
+namespace vf {
+
+static bool sac_off()
+{
+    static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
+    return off;
+}
+
+// 1: launched, 0: not one of the SAC actor classes (or no second output), < 0: error
+int mlp_forward_chain_try_sac(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
+                              float* out0, float* out1, int M, hipStream_t st)
+{
+    if (sac_off() || !out0 || !out1 || ((reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1)) & 15)) return 0;
+    const ReparamFwd rp{};
+    if (chain_matches<NetSacNav>(*d) && in1) return chain_launch<NetSacNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
+    if (chain_matches<NetSacHover>(*d)) return chain_launch<NetSacHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
+    return 0;
+}
+
+// packed == nullptr: capability query only
+int mlp_backward_chain_try_sac(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st)
+{
+    if (sac_off()) return 0;
+    const bool launch = packed != nullptr;
+    const ReparamBwd rp{};
+    if (bwd_chain_matches<NetSacNav, true, true, true>(*d)) return launch ? bwd_chain_launch<NetSacNav, true, true, true>(*d, packed, M, st, rp) : 1;
+    if (bwd_chain_matches<NetSacNav, true, true, false>(*d)) return launch ? bwd_chain_launch<NetSacNav, true, true, false>(*d, packed, M, st, rp) : 1;
+    if (bwd_chain_matches<NetSacHover, true, true, true>(*d)) return launch ? bwd_chain_launch<NetSacHover, true, true, true>(*d, packed, M, st, rp) : 1;
+    if (bwd_chain_matches<NetSacHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetSacHover, true, true, false>(*d, packed, M, st, rp) : 1;
+    return 0;
+}
+
+}  // namespace vf

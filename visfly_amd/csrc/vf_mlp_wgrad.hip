@@ -18,9 +18,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // row pairs in flight per wave.  The kernel streams 2 rows x (No + K) floats per step and is bandwidth-bound: by
 // Little's law the chip needs ~16 KiB in flight per wave (1024 waves x 16 KiB / ~2.5 us = 6.5 TB/s), i.e.
 // 64 / (NT + KT) steps of 256 (NT + KT) bytes
+#ifndef VF_WGRAD_BUDGET
+#define VF_WGRAD_BUDGET 64       // operand registers of the prefetch ring (A/B knob: profiles/r04_ppo_wgrad.txt)
+#endif
 constexpr int wg_depth(int nt, int kt, bool small)
 {
-    const int d = (small ? 40 : 64) / (nt + kt);      // small: two waves per SIMD share its 512 registers
+    const int d = (small ? 40 : VF_WGRAD_BUDGET) / (nt + kt);      // small: two waves per SIMD share its 512 registers
     return d > 16 ? 16 : (d < 4 ? 4 : d);
 }
 
