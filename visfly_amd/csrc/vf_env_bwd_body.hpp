@@ -326,6 +326,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     // ---- reverse sweep over the sub-steps ----
     float lwd[4] = {0, 0, 0, 0}, lTd[4] = {0, 0, 0, 0};
     float ldw_in[3] = {laa[0], laa[1], laa[2]};  // aa state = dw of the LAST sub-step
+    const float inv_m = 1.0f / c.m;              // acc = rotate(q, u) / m: its adjoint multiplies by 1 / m (one division per step, see above)
     for (int sub = S - 1; sub >= 0; --sub) {
         Quat q;
         float v[3], w[3], wm0[4];
@@ -365,11 +366,13 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
             derivs(c, q, w, ft + 1, dq, dw);
             const Quat qt{q.w + dq[0] * dt, q.x + dq[1] * dt, q.y + dq[2] * dt, q.z + dq[3] * dt};
             const float nn = sqrtf(((qt.w * qt.w + qt.x * qt.x) + qt.y * qt.y) + qt.z * qt.z);
-            const Quat qn = qscale(qt, 1.0f / nn);
+            // (the adjoint is held to 1e-5 of the reference's autograd, not to its bits: ONE IEEE division per normalisation, the
+            // four quotients by |qt| are products with its reciprocal -- an IEEE fp32 division is 48 cycles of a lone wave's issue)
+            const float rnn = 1.0f / nn;
+            const Quat qn = qscale(qt, rnn);
             // normalise: q' = qt / |qt|
             const float dotl = qn.w * lq.w + qn.x * lq.x + qn.y * lq.y + qn.z * lq.z;
-            const Quat lqt{(lq.w - qn.w * dotl) / nn, (lq.x - qn.x * dotl) / nn, (lq.y - qn.y * dotl) / nn,
-                           (lq.z - qn.z * dotl) / nn};
+            const Quat lqt{(lq.w - qn.w * dotl) * rnn, (lq.x - qn.x * dotl) * rnn, (lq.y - qn.y * dotl) * rnn, (lq.z - qn.z * dotl) * rnn};
             // Euler update
             float ldw[3];
 #pragma unroll
@@ -405,10 +408,10 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
             }
             const Quat qt{q.w + sq[0] * dt, q.x + sq[1] * dt, q.y + sq[2] * dt, q.z + sq[3] * dt};
             const float nn = sqrtf(((qt.w * qt.w + qt.x * qt.x) + qt.y * qt.y) + qt.z * qt.z);
-            const Quat qn = qscale(qt, 1.0f / nn);
+            const float rnn = 1.0f / nn;
+            const Quat qn = qscale(qt, rnn);
             const float dotl = qn.w * lq.w + qn.x * lq.x + qn.y * lq.y + qn.z * lq.z;
-            const Quat lqt{(lq.w - qn.w * dotl) / nn, (lq.x - qn.x * dotl) / nn, (lq.y - qn.y * dotl) / nn,
-                           (lq.z - qn.z * dotl) / nn};
+            const Quat lqt{(lq.w - qn.w * dotl) * rnn, (lq.x - qn.x * dotl) * rnn, (lq.y - qn.y * dotl) * rnn, (lq.z - qn.z * dotl) * rnn};
             float lsw[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -440,7 +443,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
             }
         }
         // acc = rotate(q, u) / m + g
-        float lra[3] = {lacc[0] / c.m, lacc[1] / c.m, lacc[2] / c.m}, lu[3] = {0, 0, 0};
+        float lra[3] = {lacc[0] * inv_m, lacc[1] * inv_m, lacc[2] * inv_m}, lu[3] = {0, 0, 0};
         rotate_bwd(q, u, lra, lq_in, lu);
         float lF = lu[2];
         // u = z F - drag ; drag = kl vb + kq vb |vb|
