@@ -34,7 +34,7 @@ extern "C" {
                                  vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update,
                                  vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
                                  vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout;
-                              6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse */
+                              6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse, vf_mlp_desc.identity_mask (was pad0) */
 
 typedef void* vf_stream_t;
 
@@ -479,7 +479,11 @@ typedef struct vf_mlp_desc {
     int32_t in_dim[4];
     int32_t lds_off[VF_MLP_MAX_BUFS], lds_stride[VF_MLP_MAX_BUFS];   /* indexed by buffer id (ids < 4: staged inputs) */
     int32_t lds_floats;          /* total dynamic LDS, floats (activations only; <= 80 KiB lets two workgroups share a CU) */
-    int32_t pad0;
+    int32_t identity_mask;       /* bit i: layer i is a frozen identity (W = I, b = 0, no ReLU) that appends an input's columns to a
+                                  * concatenation -- th.cat([features, actions]) of ContinuousCritic.forward (td_policies.py:137).  The
+                                  * block-tile kernels run it like any layer; the register-chained classes with a pass-through input
+                                  * (vf_mlp_chain_sac.hip) copy the columns instead and REQUIRE the bit, so that a trainable layer of
+                                  * the same shape is never mistaken for one.  0 = none (was pad0 before ABI 6) */
     vf_mlp_layer layer[VF_MLP_MAX_LAYERS];
 } vf_mlp_desc;
 /* The forward reads its MFMA B operand straight from global memory: `packed` holds, per layer at float offset

@@ -496,6 +496,54 @@ def test_sac_actor_chain_vs_torch_and_block_tile_kernel(M, net, ig):
     assert torch.allclose(pol.grad, 2 * res[True][0], rtol=1e-5, atol=1e-6 * scale)
 
 
+@pytest.mark.parametrize("M", [1, 33, 777, 16384, 40000])
+@pytest.mark.parametrize("net", ["hover"])        # (over the two-branch extractor the concatenation is 132 wide: beyond the layer kernels' 128)
+def test_twin_critic_chain_vs_torch_and_block_tile_kernel(M, net):
+    """r04: the reference's twin ContinuousCritic (td_policies.py:82-143: own extractor, th.cat([features, actions]) -> qf0 / qf1 -> Q;
+    68-wide first trunk layers, two 1-wide heads) on the register-chained kernels (vf_mlp_chain_sac.hip, ChainNet<.., PASS = 1>: the
+    action columns are one more input tile, the frozen identity layer of the table is not executed) against torch on the same weights
+    and against the block-tile kernels it ran on until r03; the saved feature rows carry the action columns (the weight gradients of
+    the 68-wide layers read them); deterministic"""
+    from visfly_amd import _lib
+    from visfly_amd.ppo import MlpPolicy
+    import ctypes as C
+    dims = {"state": 13, "target": 3, "action": 4} if net == "nav" else {"state": 13, "action": 4}
+    ext = {k: [128, 64] for k in dims if k != "action"}
+    pol = MlpPolicy(dims, ext, [64, 64], [64, 64], DEV, seed=11, ortho_init=False, head_dims=(1, 1), passthrough=("action",), log_std_param=False)
+    g = torch.Generator(device=DEV).manual_seed(M + 7)
+    obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+    obs["action"] = torch.tanh(obs["action"])
+    d_q0 = torch.randn((M, 1), device=DEV, generator=g) / M
+    d_q1 = torch.randn((M, 1), device=DEV, generator=g) / M
+    ref = pol.to_torch().double().to(DEV)
+    q0r, q1r = ref({k: v.double() for k, v in obs.items()})
+    ((q0r * d_q0.double()).sum() + (q1r * d_q1.double()).sum()).backward()
+    gref = ref.flat_grad().to(DEV).float()[:pol.n_params]
+    q0, q1 = pol.forward(obs)
+    assert q0.shape == q1.shape == (M, 1)
+    sc = max(q0r.abs().max().item(), q1r.abs().max().item())
+    assert (q0 - q0r.float()).abs().max().item() <= 2e-6 * sc and (q1 - q1r.float()).abs().max().item() <= 2e-6 * sc
+    nfeat = 64 * len(ext)
+    assert torch.equal(pol._buffers(M, 0)["feat"][:, nfeat:], obs["action"])          # pass-through columns of the saved feature rows
+    b = pol._buffers(M, 0)
+    bd = pol._bwd_desc(b, M, d_q0, d_q1, False)[0]
+    assert _lib.lib().vf_mlp_backward_data_supported(C.byref(bd)) == 1                # the chain class IS what runs
+    res = {}
+    for fused in (True, False, True):
+        pol.fused_backward = fused
+        pol.grad.fill_(0.0)
+        pol.forward(obs)
+        pol.backward(d_q0, d_q1, None)
+        if fused and fused in res:
+            assert torch.equal(res[True], pol.grad)
+        res[fused] = pol.grad.clone()
+    scale = gref.abs().max().item()
+    assert (res[True] - res[False]).abs().max().item() <= 5e-6 * scale
+    for fused in (True, False):                      # vs fp64: ReLU-mask flips at large M (test_sac_actor_chain_vs_torch_and_block_tile_kernel)
+        err = (res[fused] - gref).abs().max().item()
+        assert err <= (1e-3 if M >= 16384 else 2e-6) * scale, (fused, err, scale)
+
+
 @pytest.mark.parametrize("shape", ["reference", "other"])
 def test_policy_only_forward_and_split_backward(shape):
     """need_value=False: same action mean (the register-chained kernel skips the value trunk, other layer tables fall

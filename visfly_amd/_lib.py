@@ -145,7 +145,7 @@ class MlpDesc(C.Structure):
     """mirror of vf_mlp_desc"""
     _fields_ = [("n_layers", C.c_int32), ("n_inputs", C.c_int32), ("in_dim", C.c_int32 * 4),
                 ("lds_off", C.c_int32 * MLP_MAX_BUFS), ("lds_stride", C.c_int32 * MLP_MAX_BUFS),
-                ("lds_floats", C.c_int32), ("pad0", C.c_int32), ("layer", MlpLayer * MLP_MAX_LAYERS)]
+                ("lds_floats", C.c_int32), ("identity_mask", C.c_int32), ("layer", MlpLayer * MLP_MAX_LAYERS)]
 
 
 class StatsFold(C.Structure):

@@ -110,7 +110,7 @@ struct ReparamBwd {
 };
 // vf_mlp_chain.hip: register-chained forward for the reference-default network shapes (1: launched, 0: no match)
 int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rp = nullptr);
+                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rp = nullptr, const float* in2 = nullptr);
 
 int bwd_chain_policy_class(const vf_mlp_bwd_desc* d, int M);           // vf_mlp_chain.hip: 0 none, 1 NetHover, 2 NetNav (policy trunk, obs gradient); + 16: M rows per pass run 16 rows per wave
 int chain16_policy_class(const vf_mlp_desc* d, const float* params);   // vf_mlp_chain.hip: 0 none, 1 NetHoverPi, 2 NetNavPi
@@ -119,7 +119,7 @@ int chain_full_class(const vf_mlp_desc* d, const float* params, int M);   // 0 n
 int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp = nullptr);
 // the same for the SAC-style Actor's network classes (vf_mlp_chain_sac.hip); called by the two functions above as their last resort
 int mlp_forward_chain_try_sac(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                              float* out0, float* out1, int M, hipStream_t st);
+                              const float* in2, float* out0, float* out1, int M, hipStream_t st);
 int mlp_backward_chain_try_sac(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st);
 int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,
                          const float* in1, const float* log_std, const float* action, const float* old_lp, const float* adv,

@@ -155,7 +155,7 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
 
 // 1: launched, 0: the layer table is not one of the instantiated network classes, < 0: error
 int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rpp)
+                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rpp, const float* in2)
 {
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
     const ReparamFwd rp = rpp ? *rpp : ReparamFwd{};
@@ -169,7 +169,7 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     }
     if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
     if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
-    if (!rpp) return mlp_forward_chain_try_sac(d, params, packed, in0, in1, out0, out1, M, st);    // SAC-style Actor (vf_mlp_chain_sac.hip)
+    if (!rpp) return mlp_forward_chain_try_sac(d, params, packed, in0, in1, in2, out0, out1, M, st);    // SAC-style Actor / twin critic (vf_mlp_chain_sac.hip)
     return 0;
 }
 

@@ -25,7 +25,7 @@ struct __attribute__((packed, aligned(4))) f32x4u {   // 4 consecutive floats at
 };
 
 struct ChainIo {
-    const float* in[2];
+    const float* in[3];          // observation inputs of the extractor branches, then the pass-through input (if the class has one)
     float* mean;
     float* value;
 };
@@ -41,40 +41,48 @@ struct ChainLayer {
 
 // NB branches (KA / KB = first-layer widths padded to 8), hidden widths in 32-feature tiles
 // VF_ = false: the value trunk is not executed (first-order policy optimisation only needs the action mean)
-// HV_: width of the second trunk's head -- 1 = the critic's value (policies.py:18-49), 4 = the state-dependent log_std head of the
-// reference's SAC-style Actor (utils/policies/td_policies.py:146-252: latent_pi -> mu, log_latent_pi -> log_std), output (M, 4)
-template <int NB_, int KA_, int KB_, int E1_, int E2_, int P1_, int P2_, int V1_, int V2_, bool VF_ = true, int HV_ = 1>
+// HV_ / HM_: widths of the second / first trunk's head -- (HM, HV) = (4, 1): actor-critic of the PPO policies (policies.py:18-49);
+//   (4, 4): the reference's SAC-style Actor (utils/policies/td_policies.py:146-252: latent_pi -> mu, log_latent_pi -> log_std);
+//   (1, 1): its twin ContinuousCritic (:82-143: qf0 / qf1 -> Q)
+// PASS_ = 1: one more input (<= 8 wide; the critic's action) is appended to the features unchanged -- th.cat([features, actions])
+//   (:137).  In the layer table it is a frozen identity layer between the extractor layers and the trunks (vf_mlp_desc.identity_mask);
+//   here it is one more 32-feature input tile of the trunks' first layers whose first registers hold the input's columns
+template <int NB_, int KA_, int KB_, int E1_, int E2_, int P1_, int P2_, int V1_, int V2_, bool VF_ = true, int HV_ = 1, int HM_ = 4,
+          int PASS_ = 0>
 struct ChainNet {
-    static constexpr int NB = NB_, E1 = E1_, E2 = E2_, P1 = P1_, P2 = P2_, V1 = V1_, V2 = V2_, HV = HV_;
+    static constexpr int NB = NB_, E1 = E1_, E2 = E2_, P1 = P1_, P2 = P2_, V1 = V1_, V2 = V2_, HV = HV_, HM = HM_, PASS = PASS_;
     static constexpr bool VF = VF_;
-    static_assert(HV_ == 1 || HV_ == 4, "second head: 1 (value) or 4 (log_std) wide");
+    static_assert((HV_ == 1 || HV_ == 4) && (HM_ == 1 || HM_ == 4), "heads: 1 or 4 wide");
+    static_assert(PASS_ == 0 || PASS_ == 1, "at most one pass-through input");
     static constexpr int kin(int b) { return b == 0 ? KA_ : KB_; }
-    static constexpr int n_layers = 2 * NB + 6;              // layers of the vf_mlp_desc this class matches
-    static constexpr int n_exec = 2 * NB + (VF ? 6 : 3);     // layers the kernel runs
-    static constexpr int L_mean = 2 * NB + 2, L_value = 2 * NB + 5;   // desc indices of the heads
-    // tiles: [branch L1 outputs][feat][pi1][pi2][mean][vf1][vf2][value]
+    static constexpr int base = 2 * NB + PASS;               // desc index of the first trunk layer
+    static constexpr int n_layers = base + 6;                // layers of the vf_mlp_desc this class matches
+    static constexpr int n_exec = 2 * NB + (VF ? 6 : 3);     // layers the kernel runs (the identity layer is not one of them)
+    static constexpr int L_mean = base + 2, L_value = base + 5;   // desc indices of the heads
+    // tiles: [branch L1 outputs][feat][pass][pi1][pi2][mean][vf1][vf2][value]
     static constexpr int t_e1(int b) { return b * E1; }
     static constexpr int t_feat = NB * E1;
-    static constexpr int t_p1 = t_feat + NB * E2, t_p2 = t_p1 + P1, t_mean = t_p2 + P2;
+    static constexpr int t_pass = t_feat + NB * E2;
+    static constexpr int t_p1 = t_pass + PASS, t_p2 = t_p1 + P1, t_mean = t_p2 + P2;
     static constexpr int t_v1 = t_mean + 1, t_v2 = t_v1 + V1, t_val = t_v2 + V2;
     static constexpr int n_tiles = t_val + 1;
+    static constexpr int n_feat = NB * E2 + PASS;            // input tiles of the trunks' first layers
     // execution order alternates between independent chains so that one chain's epilogue (VALU) can sit in the
     // shadow of the other's MFMAs
     static constexpr ChainLayer layer(int i)
     {
         if (i < NB) return ChainLayer{2 * i, i, 0, kin(i) / 8, t_e1(i), E1, 1};
         if (i < 2 * NB) return ChainLayer{2 * (i - NB) + 1, -1, t_e1(i - NB), E1, t_feat + (i - NB) * E2, E2, 1};
-        const int base = 2 * NB;
         if (!VF) {
-            switch (i - base) {
-            case 0: return ChainLayer{base + 0, -1, t_feat, NB * E2, t_p1, P1, 1};
+            switch (i - 2 * NB) {
+            case 0: return ChainLayer{base + 0, -1, t_feat, n_feat, t_p1, P1, 1};
             case 1: return ChainLayer{base + 1, -1, t_p1, P1, t_p2, P2, 1};
             default: return ChainLayer{base + 2, -1, t_p2, P2, t_mean, 1, 0};
             }
         }
-        switch (i - base) {
-        case 0: return ChainLayer{base + 0, -1, t_feat, NB * E2, t_p1, P1, 1};
-        case 1: return ChainLayer{base + 3, -1, t_feat, NB * E2, t_v1, V1, 1};
+        switch (i - 2 * NB) {
+        case 0: return ChainLayer{base + 0, -1, t_feat, n_feat, t_p1, P1, 1};
+        case 1: return ChainLayer{base + 3, -1, t_feat, n_feat, t_v1, V1, 1};
         case 2: return ChainLayer{base + 1, -1, t_p1, P1, t_p2, P2, 1};
         case 3: return ChainLayer{base + 4, -1, t_v1, V1, t_v2, V2, 1};
         case 4: return ChainLayer{base + 2, -1, t_p2, P2, t_mean, 1, 0};
@@ -90,7 +98,7 @@ struct ChainNet {
         return n;
     }
     static constexpr bool is_head(int i) { return layer(i).desc == L_mean || layer(i).desc == L_value; }
-    // first output tile of desc layer fl (MlpPolicy order)
+    // first output tile of forward layer fl in MlpPolicy order WITHOUT the identity layer (the numbering of BwdProg)
     static constexpr int tile_of_layer(int fl)
     {
         if (fl < 2 * NB) return (fl & 1) ? t_feat + (fl >> 1) * E2 : t_e1(fl >> 1);
@@ -146,6 +154,7 @@ using NetHoverPi = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, false>;
 using NetNavPi = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2, false>;
 using NetSacHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, true, 4>;   // td_policies.Actor over StateExtractor: mu / log_std heads
 using NetSacNav = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2, true, 4>;     // ... over StateTargetExtractor
+using NetCriticHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, true, 1, 1, 1>;   // td_policies.ContinuousCritic: extractor, (+) action, qf0 / qf1
 
 
 // ---- the 32-rows-per-wave forward (the scheme at the head of vf_mlp_chain.hip) ----
@@ -167,7 +176,7 @@ __device__ __forceinline__ void chain_bias_load(const ChainArgs& g, ChainState<N
 {
     constexpr ChainLayer L = N::layer(LI);
     const float* b = g.params + g.d.layer[L.desc].b_off;    // b_off is only dword aligned
-    if constexpr (L.desc == N::L_value && N::HV == 1) {
+    if constexpr ((L.desc == N::L_value && N::HV == 1) || (L.desc == N::L_mean && N::HM == 1)) {
         st.bias[0][0] = make_float4(b[0], 0.0f, 0.0f, 0.0f);
     } else if constexpr (L.desc == N::L_mean || L.desc == N::L_value) {
         const f32x4u v = *reinterpret_cast<const f32x4u*>(b);
@@ -192,7 +201,9 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>
         const float4 bq = st.bias[0][0];
         y[0] += bq.x; y[1] += bq.y; y[2] += bq.z; y[3] += bq.w;
         if (live && h == 0) {                          // (the fused PPO kernel keeps the heads in registers: no pointers)
-            if constexpr (L.desc == N::L_mean) {
+            if constexpr (L.desc == N::L_mean && N::HM == 1) {
+                if (g.io.mean) g.io.mean[row] = y[0];
+            } else if constexpr (L.desc == N::L_mean) {
                 if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
                 if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers
                     const float4 e = g.rp_eps[row];
@@ -289,6 +300,32 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs& g, ChainState<N>
     if constexpr (I < kChainDepth && I < N::n_items()) {
         st.ring[I] = chain_load<N, I>(g, lane);
         chain_prologue<N, I + 1>(g, st, lane);
+    }
+}
+
+// the pass-through input as one more activation tile (ChainNet::PASS): columns 0 .. pw-1 of row `rc` of the extra input are features
+// 0 .. pw-1 of tile t_pass -- an accumulator lane (m, h) holds features 4 h + (r & 3) + 8 (r >> 2) in register r, i.e. the half
+// h = 0 holds them in registers 0 .. 3 (pw <= 4) and 8 .. 11 of h = 0 would be features 8 ..; everything else is zero.  Also the copy
+// the weight gradients of the trunks' first layers read: the identity layer's columns of the saved feature rows
+template <class N>
+__device__ __forceinline__ void chain_pass_tile(const ChainArgs& g, ChainState<N>& st, int row, int rc, int h, bool live)
+{
+    if constexpr (N::PASS) {
+        const int pw = g.d.in_dim[N::NB];
+        const float* x = g.io.in[N::NB] + (size_t)rc * pw;
+        f32x16& t = st.t[N::t_pass];
+        t = f32x16{0};
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (h == 0 && k < pw) ? x[k < pw ? k : pw - 1] : 0.0f;
+        t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+        const vf_mlp_layer& D = g.d.layer[2 * N::NB];
+        if (D.save && live && h == 0) {
+            float* o = D.save + (size_t)row * D.save_ld + D.dst_col;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < pw) o[k] = v[k];
+        }
     }
 }
 
@@ -402,7 +439,7 @@ __device__ __forceinline__ void chain16_bias_load(const ChainArgs& g, ChainState
 {
     constexpr ChainLayer L = N::layer(LI);
     const float* b = g.params + g.d.layer[L.desc].b_off;    // b_off is only dword aligned
-    if constexpr (L.desc == N::L_value && N::HV == 1) {
+    if constexpr ((L.desc == N::L_value && N::HV == 1) || (L.desc == N::L_mean && N::HM == 1)) {
         st.bias[0] = make_float4(b[0], 0.0f, 0.0f, 0.0f);
     } else if constexpr (L.desc == N::L_mean || L.desc == N::L_value) {
         const f32x4u v = *reinterpret_cast<const f32x4u*>(b);
@@ -425,7 +462,9 @@ __device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState1
         const float4 bq = st.bias[0];
         y[0] += bq.x; y[1] += bq.y; y[2] += bq.z; y[3] += bq.w;
         if (live && gq == 0) {
-            if constexpr (L.desc == N::L_mean) {
+            if constexpr (L.desc == N::L_mean && N::HM == 1) {
+                if (g.io.mean) g.io.mean[row] = y[0];
+            } else if constexpr (L.desc == N::L_mean) {
                 if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
                 if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers (as chain_epilogue)
                     const float4 e = g.rp_eps[row];
@@ -445,6 +484,28 @@ __device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState1
             const float4 bq = st.bias[a];
             y[0] = fmaxf(y[0] + bq.x, 0.0f); y[1] = fmaxf(y[1] + bq.y, 0.0f);
             y[2] = fmaxf(y[2] + bq.z, 0.0f); y[3] = fmaxf(y[3] + bq.w, 0.0f);
+        }
+    }
+}
+
+// 16-row form of chain_pass_tile: lane (m, gq) holds features 4 gq + r of a 16-feature tile -> group gq = 0 holds the input's columns
+template <class N>
+__device__ __forceinline__ void chain16_pass_tile(const ChainArgs& g, ChainState16<N>& st, int row, int rc, int gq, bool live)
+{
+    if constexpr (N::PASS) {
+        const int pw = g.d.in_dim[N::NB];
+        const float* x = g.io.in[N::NB] + (size_t)rc * pw;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (gq == 0 && k < pw) ? x[k < pw ? k : pw - 1] : 0.0f;
+        st.t[2 * N::t_pass] = f32x4{v[0], v[1], v[2], v[3]};
+        st.t[2 * N::t_pass + 1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const vf_mlp_layer& D = g.d.layer[2 * N::NB];
+        if (D.save && live && gq == 0) {
+            float* o = D.save + (size_t)row * D.save_ld + D.dst_col;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < pw) o[k] = v[k];
         }
     }
 }

@@ -273,6 +273,8 @@ __device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdStat
                     }
                     st.hin[0][0] = h == 0 ? dm.x : 0.0f; st.hin[0][1] = h == 0 ? dm.y : 0.0f;
                     st.hin[0][2] = h == 0 ? dm.z : 0.0f; st.hin[0][3] = h == 0 ? dm.w : 0.0f;
+                } else if constexpr (P::Net::HM == 1) {      // first head 1 wide (the twin critic's Q1): d_q (M,)
+                    st.hin[0][0] = h == 0 ? dy[0] : 0.0f; st.hin[0][1] = 0.0f; st.hin[0][2] = 0.0f; st.hin[0][3] = 0.0f;
                 } else {
                     st.hin[0][0] = h == 0 ? dy[0] : 0.0f; st.hin[0][1] = h == 0 ? dy[1] : 0.0f;
                     st.hin[0][2] = h == 0 ? dy[2] : 0.0f; st.hin[0][3] = h == 0 ? dy[3] : 0.0f;
@@ -560,6 +562,8 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
                         gl.z += dm.z * expf(g.rp_log_std[2]) * e.z; gl.w += dm.w * expf(g.rp_log_std[3]) * e.w;
                         g.rp_g_log_std[rc] = gl;
                     }
+                } else if constexpr (P::Net::HM == 1) {
+                    dm = make_float4(dy[0], 0.0f, 0.0f, 0.0f);
                 } else {
                     dm = make_float4(dy[0], dy[1], dy[2], dy[3]);
                 }

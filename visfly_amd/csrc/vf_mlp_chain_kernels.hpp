@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
             if (xc && live && k < w) xc[k] = v;
         }
     }
+    chain_pass_tile<N>(g, st, row, rc, h, live);
     chain_items<N, 0>(g, st, lane, row, live);
 }
 
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
             if (xc && live && k < w) xc[k] = v;
         }
     }
+    chain16_pass_tile<N>(g, st, row, rc, gq, live);
     VF_TRACE(1);
     chain16_items<N, 0>(g, st, lane, row, live);
     VF_TRACE(31);
@@ -77,24 +79,34 @@ __global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
 template <class N>
 bool chain_matches(const vf_mlp_desc& d)
 {
-    if (d.n_layers != N::n_layers || d.n_inputs != N::NB) return false;
+    if (d.n_layers != N::n_layers || d.n_inputs != N::NB + N::PASS) return false;
     for (int b = 0; b < N::NB; ++b)
         if (d.in_dim[b] < 1 || d.in_dim[b] > N::kin(b)) return false;
     auto is = [&](int li, int K, int No, int relu) {
         const vf_mlp_layer& L = d.layer[li];
         return L.K == K && L.No == No && (L.relu != 0) == (relu != 0) && L.wr_off >= 0 && (L.wr_off & 3) == 0;
     };
-    const int feat = N::NB * N::E2 * 32;
+    int feat = N::NB * N::E2 * 32;
     for (int b = 0; b < N::NB; ++b) {
         if (!is(2 * b, d.in_dim[b], N::E1 * 32, 1) || !is(2 * b + 1, N::E1 * 32, N::E2 * 32, 1)) return false;
         const vf_mlp_layer &l1 = d.layer[2 * b], &l2 = d.layer[2 * b + 1];
         if (l1.src != b || l1.src_col != 0 || l2.src != l1.dst || l2.src_col != l1.dst_col) return false;
         if (l2.dst_col != b * N::E2 * 32 || l2.dst != d.layer[1].dst) return false;
     }
-    const int base = 2 * N::NB, fid = d.layer[1].dst;
-    const int w1[2] = {N::P1 * 32, N::V1 * 32}, w2[2] = {N::P2 * 32, N::V2 * 32}, wo[2] = {4, N::HV};
+    const int fid = d.layer[1].dst;
+    if constexpr (N::PASS) {      // the frozen identity layer: input NB, <= 4 columns, appended to the features, declared in identity_mask
+        const vf_mlp_layer& I = d.layer[2 * N::NB];
+        const int pw = d.in_dim[N::NB];
+        if (pw < 1 || pw > 4 || I.K != pw || I.No != pw || I.relu || I.src != N::NB || I.src_col != 0 || I.dst != fid || I.dst_col != feat) return false;
+        if (!((d.identity_mask >> (2 * N::NB)) & 1)) return false;
+        if (I.save && ((I.save_ld & 3) || (I.dst_col & 3))) return false;
+        feat += pw;
+    } else if (d.identity_mask) {
+        return false;
+    }
+    const int w1[2] = {N::P1 * 32, N::V1 * 32}, w2[2] = {N::P2 * 32, N::V2 * 32}, wo[2] = {N::HM, N::HV};
     for (int t = 0; t < 2; ++t) {
-        const int l = base + 3 * t;
+        const int l = N::base + 3 * t;
         if (!is(l, feat, w1[t], 1) || !is(l + 1, w1[t], w2[t], 1) || !is(l + 2, w2[t], wo[t], 0)) return false;
         if (d.layer[l].src != fid || d.layer[l].src_col != 0) return false;
         if (d.layer[l + 1].src != d.layer[l].dst || d.layer[l + 2].src != d.layer[l + 1].dst) return false;
@@ -127,9 +139,9 @@ bool chain16_ok(const vf_mlp_desc& d, const float* params, int M)
 
 template <class N>
 int chain_launch(const vf_mlp_desc& d, const float* params, const float* packed, const float* in0, const float* in1, float* out0,
-                 float* out1, int M, hipStream_t st, const ReparamFwd& rp)
+                 float* out1, int M, hipStream_t st, const ReparamFwd& rp, const float* in2 = nullptr)
 {
-    ChainArgs g{d, params, packed, ChainIo{{in0, in1}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.action),
+    ChainArgs g{d, params, packed, ChainIo{{in0, in1, in2}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.action),
                 {rp.obs_copy[0], rp.obs_copy[1]}};
     if (chain16_ok<N>(d, params, M))
         hipLaunchKernelGGL(k_mlp_forward_chain16<N>, dim3((M + 15) / 16), dim3(64), 0, st, g);
@@ -157,9 +169,14 @@ bool bwd_chain_matches(const vf_mlp_bwd_desc& d)
         if (K0 < 1 || K0 > N::kin(b) || K0 > 32) return false;
         if (!is(2 * b, K0, N::E1 * 32, true, true) || !is(2 * b + 1, N::E1 * 32, N::E2 * 32, true, false)) return false;
     }
-    const int feat = N::NB * N::E2 * 32;
+    int feat = N::NB * N::E2 * 32;
+    if constexpr (N::PASS) {       // features (+) pass-through columns: the trunks' first layers are K = feat + pw wide, pw = 1 .. 4
+        const int K0 = d.layer[P::entry(PI ? P::L_pi0 : P::L_vf0)].K;
+        if (K0 <= feat || K0 > feat + 4) return false;
+        feat = K0;
+    }
     if (PI && (!is(P::L_pi0, feat, N::P1 * 32, true, false) || !is(P::L_pi1, N::P1 * 32, N::P2 * 32, true, false) ||
-               !is(P::L_mean, N::P2 * 32, 4, false, false)))
+               !is(P::L_mean, N::P2 * 32, N::HM, false, false)))
         return false;
     if (VF && (!is(P::L_vf0, feat, N::V1 * 32, true, false) || !is(P::L_vf1, N::V1 * 32, N::V2 * 32, true, false) ||
                !is(P::L_val, N::V2 * 32, N::HV, false, false)))

@@ -5,6 +5,12 @@
 //   forward            k_mlp_forward_chain / _chain16 <NetSacHover | NetSacNav>: mu -> out0 (M,4), log_std -> out1 (M,4)
 //   reverse            k_mlp_backward_chain <BwdProg<Net, pi, vf, IG>> from d_mu / d_log_std (M,4): both trunks, with and without the
 //                      observation gradient (the first step of a horizon does not need it); masked layer gradients for k_mlp_wgrad
+// ... and for its twin ContinuousCritic (:82-143): the critic's own extractor, th.cat([features, actions]) (:137) -> qf0 / qf1 -> Q, i.e.
+// the class with a pass-through input and two 1-wide heads (ChainNet<.., HV = 1, HM = 1, PASS = 1>): the action columns are one more
+// input tile of the trunks' first layers (68 = 64 + 4 wide), the layer table's frozen identity layer (vf_mlp_desc.identity_mask) is
+// not executed.  5 critic updates over the H N rows of the horizon buffer are 2/3 of a SHAC iteration.
+//   forward            <NetCriticHover>: Q1 -> out0 (M,), Q2 -> out1 (M,); inputs: the extractor's observation, then the action
+//   reverse            BwdProg<Net, pi, vf, no observation gradient> from dQ1 / dQ2
 // A translation unit of its own so that its instances compile next to vf_mlp_chain.hip's, not after them.
 #include "vf_mlp_chain_kernels.hpp"
 
@@ -18,10 +24,14 @@ static bool sac_off()
 
 // 1: launched, 0: not one of the SAC actor classes (or no second output), < 0: error
 int mlp_forward_chain_try_sac(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                              float* out0, float* out1, int M, hipStream_t st)
+                              const float* in2, float* out0, float* out1, int M, hipStream_t st)
 {
-    if (sac_off() || !out0 || !out1 || ((reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1)) & 15)) return 0;
+    if (sac_off() || !out0 || !out1) return 0;
     const ReparamFwd rp{};
+    // twin critic: 1-wide heads (no alignment requirement on the outputs); the action is the input behind the extractor's
+    // (over a StateTarget extractor the concatenation would be 132 wide: beyond the 128 columns every layer kernel here is built for)
+    if (chain_matches<NetCriticHover>(*d) && in1) return chain_launch<NetCriticHover>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
+    if ((reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1)) & 15) return 0;
     if (chain_matches<NetSacNav>(*d) && in1) return chain_launch<NetSacNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
     if (chain_matches<NetSacHover>(*d)) return chain_launch<NetSacHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
     return 0;
@@ -37,6 +47,7 @@ int mlp_backward_chain_try_sac(const vf_mlp_bwd_desc* d, const float* packed, in
     if (bwd_chain_matches<NetSacNav, true, true, false>(*d)) return launch ? bwd_chain_launch<NetSacNav, true, true, false>(*d, packed, M, st, rp) : 1;
     if (bwd_chain_matches<NetSacHover, true, true, true>(*d)) return launch ? bwd_chain_launch<NetSacHover, true, true, true>(*d, packed, M, st, rp) : 1;
     if (bwd_chain_matches<NetSacHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetSacHover, true, true, false>(*d, packed, M, st, rp) : 1;
+    if (bwd_chain_matches<NetCriticHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetCriticHover, true, true, false>(*d, packed, M, st, rp) : 1;
     return 0;
 }
 

@@ -1587,7 +1587,7 @@ int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* pa
     }
     // reference-default network shapes: activations chained through MFMA accumulator registers (vf_mlp_chain.hip);
     // out1 == NULL there means "skip the value trunk"
-    if (int rc = vf::mlp_forward_chain_try(desc, params, packed, in0, in1, out0, out1, M, vf::as_stream(stream))) return rc < 0 ? rc : VF_OK;
+    if (int rc = vf::mlp_forward_chain_try(desc, params, packed, in0, in1, out0, out1, M, vf::as_stream(stream), nullptr, in2)) return rc < 0 ? rc : VF_OK;
     for (int i = 0; i < desc->n_layers; ++i) {
         const vf_mlp_layer& L = desc->layer[i];
         if (L.dst >= VF_MLP_OUT0 && !(L.dst == VF_MLP_OUT0 ? out0 : out1))

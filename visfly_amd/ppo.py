@@ -243,6 +243,7 @@ class MlpPolicy:
         p = self._plan
         d = _lib.MlpDesc()
         d.n_layers, d.n_inputs = len(self.layers), len(self.obs_keys)
+        d.identity_mask = sum(1 << i for i, ly in enumerate(self.layers) if ly.frozen)
         for i, k in enumerate(self.obs_keys):
             d.in_dim[i] = self.obs_dims[k]
         for n, bid in p["ids"].items():
