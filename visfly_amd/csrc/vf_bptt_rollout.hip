@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
                     st.x[b][j] = k < w ? v : 0.0f;
                 }
             }
-            chain16_items<Net, 0>(gct, st, lane_t, row, lrow);
+            chain16_items<Net, 0>(gct, st, lane_t, row, lrow, rc);
         }
         // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
         // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)

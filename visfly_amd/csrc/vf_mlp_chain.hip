@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
     const float4 a4 = pr.action[rc];
     const float old_lp = pr.old_lp[rc], adv = pr.adv[rc], ret = pr.ret[rc];
     const float ls[4] = {pr.log_std[0], pr.log_std[1], pr.log_std[2], pr.log_std[3]};
-    chain_items<N, 0>(g, fs, lane, row, live);
+    chain_items<N, 0>(g, fs, lane, row, live, rc);
     BwdState<P> bs;
     bwd_prologue<P, 0>(gb, bs, lane);                  // first weight blocks of the reverse chain: in flight during the loss arithmetic
     // ---- loss of this lane's row (lane half 0 holds mean[0..3] / value in registers 0..3 / 0 of the head tiles) ----
@@ -82,9 +82,12 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
         const bool on = live && h == 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) stt[k] = on ? st1[k] : 0.0f;
+        // head gradients: lane half 0 of EVERY lane -- the lanes past the last row are replicas of row M - 1 (they loaded its inputs)
+        // and must stay replicas through the reverse chain, whose dZ stores are unguarded (bwd_store_setup): they rewrite that row's
+        // values, they do not zero them.  Only the statistics above and the head rows below exclude them.
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dm[k] = on ? dm1[k] : 0.0f;
-        dvl = on ? dv1 : 0.0f;
+        for (int k = 0; k < 4; ++k) dm[k] = h == 0 ? dm1[k] : 0.0f;
+        dvl = h == 0 ? dv1 : 0.0f;
         if (on) {         // head gradients: dZ of the head layers for the weight-gradient kernel
             const vf_mlp_bwd_layer& Em = gb.d.layer[P::entry(P::L_mean)];
             const vf_mlp_bwd_layer& Ev = gb.d.layer[P::entry(P::L_val)];

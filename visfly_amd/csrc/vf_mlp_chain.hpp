@@ -24,6 +24,12 @@ struct __attribute__((packed, aligned(4))) f32x4u {   // 4 consecutive floats at
     float x, y, z, w;
 };
 
+// pointers that went through an opaque register copy (chain_store_setup) lose the compiler's "this is global memory" inference and
+// would be dereferenced with flat_* instructions (64-bit VGPR addresses, lgkmcnt as well as vmcnt): say it in the type
+typedef __attribute__((address_space(1))) char* vf_gptr;
+typedef float vf_st4 __attribute__((ext_vector_type(4)));              // (float4 is a class: no assignment operator for address space 1)
+typedef __attribute__((address_space(1))) vf_st4 vf_gfloat4;
+
 struct ChainIo {
     const float* in[3];          // observation inputs of the extractor branches, then the pass-through input (if the class has one)
     float* mean;
@@ -133,6 +139,9 @@ struct ChainState {
     float x[2][16];              // observation fragments: x[b][s] = X[m][2 s + h] (K padded to <= 32)
     float4 ring[kChainDepth];
     float4 bias[4][4];           // bias of the layer in flight: [out tile][g] -> features 32 a + 8 g + 4 h .. + 3
+    // where the saved copy of the PREVIOUS layer's output goes (chain_store_setup): wave-uniform base (null: not kept) + this lane's byte offset
+    vf_gptr sv_base;
+    unsigned sv_off;
 };
 
 struct ChainArgs {
@@ -234,25 +243,43 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>
 // The copies of a layer's output that the backward reads are not stored in the epilogue (a 16 KiB burst per wave, all
 // waves in lock-step, behind which the weight loads of the following items would queue: loads and stores retire in
 // order on gfx9's vmcnt) but trickled out, a float4 or two per item of the NEXT layer in execution order.
+//
+// r04: what a store needs of the layer table -- base pointer, row stride -- is read ONCE per layer (chain_store_setup at the layer's
+// first item) and pinned in registers.  Read per store, hipcc re-loaded the two fields from the kernel-argument segment in front of
+// every store (s_load_dword x 2 + s_waitcnt lgkmcnt(0) + v_mul_lo_u32: the scalar-cache round trip fully exposed, ~100 cycles of a
+// lone wave per store; 357 s_load in k_ppo_update_chain), and the `row < M` guard made every store an exec-masked branch.  The lanes
+// past the last row are exact replicas of row M - 1 (they load THAT row's inputs), so they store the same values to the same
+// addresses and need no guard.
+template <class N, int LI>
+__device__ __forceinline__ void chain_store_setup(const ChainArgs& g, ChainState<N>& st, int rc, int h)
+{
+    if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
+        constexpr ChainLayer P = N::layer(LI - 1);
+        const vf_mlp_layer& D = g.d.layer[P.desc];
+        unsigned long b = D.save ? reinterpret_cast<unsigned long>(D.save + D.dst_col) : 0ul;
+        asm volatile("" : "+s"(b));          // opaque: the compiler cannot re-derive it from the kernel arguments at every use
+        st.sv_base = (vf_gptr)b;
+        // lane offset in BYTES, 32 bit (the hosts refuse row counts whose buffers pass 4 GiB): scalar base + 32-bit offset
+        // is an addressing mode, a 64-bit element offset is three VALU instructions per store
+        st.sv_off = ((unsigned)rc * (unsigned)D.save_ld + 4u * h) * 4u;
+    }
+}
+
 template <class N, int LI, int LOCAL>
-__device__ __forceinline__ void chain_deferred_store(const ChainArgs& g, const ChainState<N>& st, int row, int h, bool live)
+__device__ __forceinline__ void chain_deferred_store(const ChainState<N>& st)
 {
     if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
         constexpr ChainLayer P = N::layer(LI - 1);
         constexpr int S = P.nout * 4, per = (S + N::items(LI) - 1) / N::items(LI);
         constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
         if constexpr (s0 < s1) {
-            const vf_mlp_layer& D = g.d.layer[P.desc];
-            if (D.save && live) {
-                // lane offset in BYTES, 32 bit (the hosts refuse row counts whose buffers pass 4 GiB): scalar base + 32-bit offset
-                // is an addressing mode, a 64-bit element offset is three VALU instructions per store
-                const unsigned off = ((unsigned)row * (unsigned)D.save_ld + 4u * h) * 4u;
+            if (st.sv_base) {
+                const vf_gptr base = st.sv_base + st.sv_off;
 #pragma unroll
                 for (int i = s0; i < s1; ++i) {
                     const int a = i / 4, q = i % 4;
                     const f32x16& y = st.t[P.out0 + a];
-                    char* base = reinterpret_cast<char*>(D.save + D.dst_col + 32 * a + 8 * q);               // wave-uniform
-                    *reinterpret_cast<float4*>(base + off) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                    *(vf_gfloat4*)(base + (32 * a + 8 * q) * 4) = vf_st4{y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
                 }
             }
         }
@@ -261,8 +288,9 @@ __device__ __forceinline__ void chain_deferred_store(const ChainArgs& g, const C
 
 // SAVE = false: the caller's layer table keeps no activation copies (inference inside a persistent launch): the trickled stores
 // and their per-item `save != null` branches are not compiled in (2.5 k cycles of 62 k per forward in k_ppo_rollout)
+// rc = the row this lane LOADS (min(row, M - 1): lanes past the last row replicate it), row = the row it would own
 template <class N, int I, bool SAVE = true>
-__device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& st, int lane, int row, bool live)
+__device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& st, int lane, int row, bool live, int rc)
 {
     if constexpr (I < N::n_items()) {
         constexpr int li = N::layer_of(I), local = I - N::first_item(li);
@@ -287,10 +315,11 @@ __device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& s
             else b = st.t[L.in0 + gq / 4][4 * (gq % 4) + j];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
         }
-        if constexpr (SAVE) chain_deferred_store<N, li, local>(g, st, row, h, live);
+        if constexpr (SAVE && local == 0) chain_store_setup<N, li>(g, st, rc, h);
+        if constexpr (SAVE) chain_deferred_store<N, li, local>(st);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (local == N::items(li) - 1) chain_epilogue<N, li>(g, st, row, h, live);
-        chain_items<N, I + 1, SAVE>(g, st, lane, row, live);
+        chain_items<N, I + 1, SAVE>(g, st, lane, row, live, rc);
     }
 }
 
@@ -390,6 +419,8 @@ struct ChainState16 {
     float x[2][4];               // observation fragment: x[b][j] = X[m][4 gq + j] (K <= 16)
     float4 ring[kChain16Depth];
     float4 bias[8];              // bias of the layer in flight: [out tile] -> features 16 a + 4 gq .. + 3
+    vf_gptr sv_base;         // saved copy of the previous layer's output (chain16_store_setup): uniform base (null: not kept) + lane byte offset
+    unsigned sv_off;
 };
 
 template <class N, int I>
@@ -510,9 +541,22 @@ __device__ __forceinline__ void chain16_pass_tile(const ChainArgs& g, ChainState
     }
 }
 
-// saved copies of the previous layer's output, trickled out under this layer's items (see chain_deferred_store)
+// saved copies of the previous layer's output, trickled out under this layer's items (see chain_store_setup / chain_deferred_store)
+template <class N, int LI>
+__device__ __forceinline__ void chain16_store_setup(const ChainArgs& g, ChainState16<N>& st, int rc, int gq)
+{
+    if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
+        constexpr ChainLayer P = N::layer(LI - 1);
+        const vf_mlp_layer& D = g.d.layer[P.desc];
+        unsigned long b = D.save ? reinterpret_cast<unsigned long>(D.save + D.dst_col) : 0ul;
+        asm volatile("" : "+s"(b));
+        st.sv_base = (vf_gptr)b;
+        st.sv_off = ((unsigned)rc * (unsigned)D.save_ld + 4u * gq) * 4u;        // bytes
+    }
+}
+
 template <class N, int LI, int LOCAL>
-__device__ __forceinline__ void chain16_deferred_store(const ChainArgs& g, const ChainState16<N>& st, int row, int gq, bool live)
+__device__ __forceinline__ void chain16_deferred_store(const ChainState16<N>& st)
 {
     if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
         using C = Chain16<N>;
@@ -520,13 +564,12 @@ __device__ __forceinline__ void chain16_deferred_store(const ChainArgs& g, const
         constexpr int S = C::nout(LI - 1), per = (S + C::items(LI) - 1) / C::items(LI);
         constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
         if constexpr (s0 < s1) {
-            const vf_mlp_layer& D = g.d.layer[P.desc];
-            if (D.save && live) {
-                const unsigned off = ((unsigned)row * (unsigned)D.save_ld + 4u * gq) * 4u;        // bytes (chain_deferred_store)
+            if (st.sv_base) {
+                const vf_gptr base = st.sv_base + st.sv_off;
 #pragma unroll
                 for (int a = s0; a < s1; ++a) {
                     const f32x4& y = st.t[2 * P.out0 + a];
-                    *reinterpret_cast<float4*>(reinterpret_cast<char*>(D.save + D.dst_col + 16 * a) + off) = make_float4(y[0], y[1], y[2], y[3]);
+                    *(vf_gfloat4*)(base + 16 * a * 4) = vf_st4{y[0], y[1], y[2], y[3]};
                 }
             }
         }
@@ -538,7 +581,7 @@ __device__ __forceinline__ void chain16_deferred_store(const ChainArgs& g, const
 // (MI355X_MICROARCH.md, per-instruction constants), so four back-to-back MFMAs on one accumulator run at 80 % of the pipe; two
 // accumulators alternating do not wait.  Every accumulator still sees its products in the same order: same bits.
 template <class N, int I, bool SAVE = true>
-__device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N>& st, int lane, int row, bool live)
+__device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N>& st, int lane, int row, bool live, int rc)
 {
     using C = Chain16<N>;
     if constexpr (I < C::n_items()) {
@@ -570,15 +613,16 @@ __device__ __forceinline__ void chain16_items(const ChainArgs& g, ChainState16<N
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
             if constexpr (pair) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(j == 0 ? w1.x : j == 1 ? w1.y : j == 2 ? w1.z : w1.w, b, acc1, 0, 0, 0);
         }
-        if constexpr (SAVE) chain16_deferred_store<N, li, local>(g, st, row, gq, live);
-        if constexpr (SAVE && pair) chain16_deferred_store<N, li, local + 1>(g, st, row, gq, live);
+        if constexpr (SAVE && local == 0) chain16_store_setup<N, li>(g, st, rc, gq);
+        if constexpr (SAVE) chain16_deferred_store<N, li, local>(st);
+        if constexpr (SAVE && pair) chain16_deferred_store<N, li, local + 1>(st);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (local == 0) VF_TRACE(2 + 2 * li);
         if constexpr (local + step - 1 == C::items(li) - 1) {
             chain16_epilogue<N, li>(g, st, row, gq, live);
             VF_TRACE(3 + 2 * li);
         }
-        chain16_items<N, I + step, SAVE>(g, st, lane, row, live);
+        chain16_items<N, I + step, SAVE>(g, st, lane, row, live, rc);
     }
 }
 

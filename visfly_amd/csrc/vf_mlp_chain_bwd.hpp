@@ -121,6 +121,8 @@ struct BwdState {
     float4 ring[kChainDepth];
     float4 ym[4][4];             // saved activations (mask source) of the tiles being finalised
     float hin[2][4];             // head gradients of this lane's row: d_mean[0..3] / d_value (lane half 0), else 0
+    vf_gptr sv_base[2];      // dZ buffers of the (up to two) layers the PREVIOUS op finalised (bwd_store_setup): uniform bases ...
+    unsigned sv_off[2];          // ... + this lane's byte offsets
 };
 
 template <class P, int I>
@@ -187,9 +189,26 @@ __device__ __forceinline__ void bwd_finalize(const BwdArgsChain& g, BwdState<P>&
     }
 }
 
-// stores of the tiles the PREVIOUS op finalised, spread over this op's items
+// stores of the tiles the PREVIOUS op finalised, spread over this op's items.  Base pointers / row strides are read from the layer
+// table once per op and pinned (chain_store_setup, vf_mlp_chain.hpp, says why); lanes past the last row replicate row M - 1: no guard
+template <class P, int OI>
+__device__ __forceinline__ void bwd_store_setup(const BwdArgsChain& g, BwdState<P>& st, int rc, int h)
+{
+    if constexpr (OI >= 1) {
+        constexpr BwdOp Q = P::op(OI - 1);
+#pragma unroll
+        for (int f = 0; f < Q.nfin; ++f) {
+            const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
+            unsigned long b = reinterpret_cast<unsigned long>(E.dY);
+            asm volatile("" : "+s"(b));
+            st.sv_base[f] = (vf_gptr)b;
+            st.sv_off[f] = ((unsigned)rc * (unsigned)E.ld_dy + 4u * h) * 4u;                    // bytes
+        }
+    }
+}
+
 template <class P, int OI, int LOCAL>
-__device__ __forceinline__ void bwd_deferred_store(const BwdArgsChain& g, const BwdState<P>& st, int row, int h, bool live)
+__device__ __forceinline__ void bwd_deferred_store(const BwdState<P>& st)
 {
     if constexpr (OI >= 1) {
         constexpr BwdOp Q = P::op(OI - 1);
@@ -197,16 +216,11 @@ __device__ __forceinline__ void bwd_deferred_store(const BwdArgsChain& g, const 
         constexpr int n_it = P::items(OI), per = (S + n_it - 1) / n_it;
         constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
         if constexpr (s0 < s1) {
-            if (live) {
 #pragma unroll
-                for (int i = s0; i < s1; ++i) {
-                    const int f = i < S0 ? 0 : 1, ii = i - (f ? S0 : 0), a = ii / 4, q = ii % 4;
-                    const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
-                    char* base = reinterpret_cast<char*>(const_cast<float*>(E.dY) + 32 * a + 8 * q);            // wave-uniform
-                    const unsigned off = ((unsigned)row * (unsigned)E.ld_dy + 4u * h) * 4u;                    // bytes (chain_deferred_store)
-                    const f32x16& v = st.t[Q.fin[f].t0 + a];
-                    *reinterpret_cast<float4*>(base + off) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                }
+            for (int i = s0; i < s1; ++i) {
+                const int f = i < S0 ? 0 : 1, ii = i - (f ? S0 : 0), a = ii / 4, q = ii % 4;
+                const f32x16& v = st.t[Q.fin[f].t0 + a];
+                *(vf_gfloat4*)(st.sv_base[f] + st.sv_off[f] + (32 * a + 8 * q) * 4) = vf_st4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
             }
         }
     }
@@ -235,7 +249,8 @@ __device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st
             else b = st.hin[O.in_kind - 1][j];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, b, acc, 0, 0, 0);
         }
-        bwd_deferred_store<P, oi, local>(g, st, row, h, live);
+        if constexpr (local == 0) bwd_store_setup<P, oi>(g, st, rc, h);
+        bwd_deferred_store<P, oi, local>(st);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (local == P::items(oi) - 1) bwd_finalize<P, FS, oi>(g, st, fs, row, h, live);
         bwd_items<P, FS, I + 1>(g, st, fs, lane, row, rc, live);
@@ -372,6 +387,8 @@ struct BwdState16 {
     float4 ym[Bwd16<P>::n_masks() > 0 ? Bwd16<P>::n_masks() : 1];   // saved activations (mask source) of the 16-tiles every op finalises
     float hin[2];                // this lane's element of the head gradients: d_mean[kq] / d_value (kq = 0), else 0
     float4 pa, pe, pg;           // preloaded action / noise / log_std-gradient rows of the action head's reverse (bwd16_mask_preload)
+    vf_gptr sv_base[2];      // dZ buffers of the layers the previous op finalised (bwd16_store_setup) + this lane's byte offsets
+    unsigned sv_off[2];
 };
 
 template <class P, int I>
@@ -464,9 +481,25 @@ __device__ __forceinline__ void bwd16_finalize(const BwdArgsChain& g, BwdState16
     }
 }
 
-// stores of the tiles the PREVIOUS op finalised, spread over this op's items
+// stores of the tiles the PREVIOUS op finalised, spread over this op's items (bases pinned per op: bwd_store_setup)
+template <class P, int OI>
+__device__ __forceinline__ void bwd16_store_setup(const BwdArgsChain& g, BwdState16<P>& st, int rc, int gq)
+{
+    if constexpr (OI >= 1) {
+        constexpr BwdOp Q = P::op(OI - 1);
+#pragma unroll
+        for (int f = 0; f < Q.nfin; ++f) {
+            const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
+            unsigned long b = reinterpret_cast<unsigned long>(E.dY);
+            asm volatile("" : "+s"(b));
+            st.sv_base[f] = (vf_gptr)b;
+            st.sv_off[f] = ((unsigned)rc * (unsigned)E.ld_dy + 4u * gq) * 4u;                   // bytes
+        }
+    }
+}
+
 template <class P, int OI, int LOCAL>
-__device__ __forceinline__ void bwd16_deferred_store(const BwdArgsChain& g, const BwdState16<P>& st, int row, int gq, bool live)
+__device__ __forceinline__ void bwd16_deferred_store(const BwdState16<P>& st)
 {
     if constexpr (OI >= 1) {
         constexpr BwdOp Q = P::op(OI - 1);
@@ -474,16 +507,11 @@ __device__ __forceinline__ void bwd16_deferred_store(const BwdArgsChain& g, cons
         constexpr int n_it = Bwd16<P>::items(OI), per = (S + n_it - 1) / n_it;
         constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
         if constexpr (s0 < s1) {
-            if (live) {
 #pragma unroll
-                for (int i = s0; i < s1; ++i) {
-                    const int f = i < S0 ? 0 : 1, a = i - (f ? S0 : 0);
-                    const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
-                    char* base = reinterpret_cast<char*>(const_cast<float*>(E.dY) + 16 * a);                    // wave-uniform
-                    const unsigned off = ((unsigned)row * (unsigned)E.ld_dy + 4u * gq) * 4u;                   // bytes
-                    const f32x4& v = st.t[2 * Q.fin[f].t0 + a];
-                    *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
-                }
+            for (int i = s0; i < s1; ++i) {
+                const int f = i < S0 ? 0 : 1, a = i - (f ? S0 : 0);
+                const f32x4& v = st.t[2 * Q.fin[f].t0 + a];
+                *(vf_gfloat4*)(st.sv_base[f] + st.sv_off[f] + 16 * a * 4) = vf_st4{v[0], v[1], v[2], v[3]};
             }
         }
     }
@@ -525,8 +553,9 @@ __device__ __forceinline__ void bwd16_items(const BwdArgsChain& g, BwdState16<P>
         } else {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, st.hin[O.in_kind - 1], acc, 0, 0, 0);
         }
-        bwd16_deferred_store<P, oi, local>(g, st, row, gq, live);
-        if constexpr (pair) bwd16_deferred_store<P, oi, local + 1>(g, st, row, gq, live);
+        if constexpr (local == 0) bwd16_store_setup<P, oi>(g, st, rc, gq);
+        bwd16_deferred_store<P, oi, local>(st);
+        if constexpr (pair) bwd16_deferred_store<P, oi, local + 1>(st);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (local + step - 1 == B::items(oi) - 1) bwd16_finalize<P, oi>(g, st, row, gq, live);
         bwd16_items<P, I + step, PRE>(g, st, lane, row, rc, live);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
         }
     }
     chain_pass_tile<N>(g, st, row, rc, h, live);
-    chain_items<N, 0>(g, st, lane, row, live);
+    chain_items<N, 0>(g, st, lane, row, live, rc);
 }
 
 template <class N>
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void k_mlp_forward_chain16(const ChainArgs g)
     }
     chain16_pass_tile<N>(g, st, row, rc, gq, live);
     VF_TRACE(1);
-    chain16_items<N, 0>(g, st, lane, row, live);
+    chain16_items<N, 0>(g, st, lane, row, live, rc);
     VF_TRACE(31);
 }
 

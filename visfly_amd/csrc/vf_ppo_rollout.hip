@@ -67,7 +67,7 @@ __device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int
                 st.x[b][j] = k < w ? v : 0.0f;
             }
         }
-        chain16_items<Net, 0, false>(gc, st, lane, row, true);
+        chain16_items<Net, 0, false>(gc, st, lane, row, true, row);
         const f32x4& y = st.t[2 * Net::t_mean];
         return make_float4(y[0], y[1], y[2], y[3]);
     } else {
@@ -85,7 +85,7 @@ __device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int
                 st.x[b][s] = k < w ? v : 0.0f;
             }
         }
-        chain_items<Net, 0, false>(gc, st, lane, row, true);
+        chain_items<Net, 0, false>(gc, st, lane, row, true, row);
         const f32x16& y = st.t[Net::t_mean];
         return make_float4(y[0], y[1], y[2], y[3]);
     }
