@@ -83,13 +83,27 @@ def native_comm(force: bool = False):
     from . import _lib
     L = _lib.lib()
 
+    # the agreement rounds run over a gloo (CPU) side group: after a timed-out ncclCommInitRank the NCCL backend's own stream may be
+    # blocked behind the stuck init on this device, and an all-reduce on it would hang the very ranks the watchdog is protecting
+    # (ADVICE r03).  new_group is itself collective: every rank reaches this line (local failures above are caught, not raised)
+    side = None
+    if w > 1:
+        try:
+            side = dist.new_group(backend="gloo")
+        except Exception:  # noqa: BLE001   (gloo not built: fall back to the default group)
+            side = None
+
     def agreed(ok: bool) -> bool:
         """every rank must take the same path (one rank on torch.distributed and the others on the native communicator would
         hang in their first all-reduce): logical AND over the ranks through the bootstrap process group"""
         if w == 1:
             return ok
-        flag = th.tensor([1 if ok else 0], dtype=th.int32, device=th.device("cuda", th.cuda.current_device()))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if side is not None:
+            flag = th.tensor([1 if ok else 0], dtype=th.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=side)
+        else:
+            flag = th.tensor([1 if ok else 0], dtype=th.int32, device=th.device("cuda", th.cuda.current_device()))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
     why, h = None, None
@@ -122,7 +136,10 @@ def native_comm(force: bool = False):
                     th.cuda.set_device(dev_index)
                     hh = _lib._vp()
                     _lib.check(L.vf_comm_init(ident, w, rank(), C.byref(hh)))
-                    box2["h"] = hh
+                    if box2.get("abandoned"):        # the watchdog gave up on this thread: nobody will use the communicator it got
+                        L.vf_comm_destroy(hh)
+                    else:
+                        box2["h"] = hh
                 except Exception as e:  # noqa: BLE001
                     box2["why"] = e
 
@@ -130,12 +147,13 @@ def native_comm(force: bool = False):
             t.start()
             t.join(float(os.environ.get("VISFLY_AMD_COMM_INIT_TIMEOUT", "180")))
             if t.is_alive():
+                box2["abandoned"] = True     # if the init ever returns, its thread destroys the handle itself
                 why = RuntimeError("ncclCommInitRank did not return (another rank never entered it?)")
             else:
                 h, why = box2.get("h"), box2.get("why")
             if not agreed(h is not None):
-                if h is not None:
-                    L.vf_comm_destroy(h)
+                # a peer is still inside (or never entered) ncclCommInitRank: destroying OUR communicator now would wait for it.
+                # The handle is abandoned instead (a few MB until the process exits; no atexit destroy is registered for it)
                 h, why = None, why or RuntimeError("another rank could not create its communicator")
         else:
             why = why or RuntimeError("another rank did not receive the communicator id")
