@@ -227,5 +227,6 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     hipLaunchKernelGGL(k, dim3((N + 15) / 16), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
     VF_HIP(hipGetLastError());
     h->dyn.tick += H;
+    h->stale_all = 1;       // agents re-spawned inside the launch: the prefetched copies' stale bits no longer cover them
     return VF_OK;
 }

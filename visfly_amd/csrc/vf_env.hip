@@ -363,6 +363,7 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
     vf::EnvArgs g{dyn_args(h, action, out->obs, ahead), *out, h->g_race, auto_reset};
     if (vf::use_split(h->dyn.Npad, h->dyn.cfg)) {
         hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
+        h->stale_all = 1;
     } else {
         unsigned nb = h->dyn.Npad / vf::kBlock;
         if (h->g_spawn >= 0 && auto_reset) {     // prefetched re-spawn: main blocks read copy `par`, helper blocks refill the other
@@ -371,6 +372,27 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
             if (mode & 1) g.g_spawn_rd = h->g_spawn + 4 * par;
             g.g_spawn_wr = h->g_spawn + 4 * (1 - par);
             if (mode & 2) { g.helper = (int)nb; nb += (nb + vf::kHelperSpan - 1) / vf::kHelperSpan; }
+            // stale bits: (re)armed here when something re-spawned agents without maintaining them; not inside a stream capture
+            // (the memset would replay with the graph) -- those launches run the helper's per-agent tag compare instead
+            // OFF by default: they take the helper's reads from 16 to 3 B per agent-step but cost the reset regime 0.3 us per launch (two
+            // atomics in every ending wave, a dependent load more in front of the helper's refills): profiles/r04_env_quad.txt
+            static const bool bits_off = [] { const char* e = getenv("VISFLY_AMD_STALE_BITS"); return !(e && atoi(e) == 1); }();
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cap);
+            if (h->d_stale && !bits_off && (mode & 2) && cap == hipStreamCaptureStatusNone) {
+                const int tiles = h->dyn.Npad / 64;
+                if (h->stale_all) {
+                    VF_HIP(hipMemsetAsync(h->d_stale, 0xFF, (size_t)2 * tiles * sizeof(unsigned long long), st));
+                    h->stale_all = 0;
+                }
+                g.stale = h->d_stale;
+                g.n_tiles = tiles;
+                g.stale_wr = 1 - par;
+            } else {
+                h->stale_all = 1;        // these launches re-spawn agents behind the bits' back
+            }
+        } else {
+            h->stale_all = 1;
         }
         hipLaunchKernelGGL(pick_env_kernel(h), dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
     }
@@ -399,6 +421,11 @@ int vf_env_create(const vf_dyn_cfg* dyn, const vf_env_cfg* env, int32_t N, int32
     h->g_spawn = env->spawn_prefetch ? h->dyn.g_extra + racing : -1;
     int rc = vf::upload_cfg(h->dyn.cfg, &h->dyn.d_cfg);
     if (rc == VF_OK) rc = vf::upload_cfg(h->cfg, &h->d_cfg);
+    if (rc == VF_OK && h->g_spawn >= 0 &&
+        hipMalloc(reinterpret_cast<void**>(&h->d_stale), (size_t)2 * (h->dyn.Npad / 64) * sizeof(unsigned long long)) != hipSuccess) {
+        h->d_stale = nullptr;            // no bits: the helper compares every tag, as before
+        (void)hipGetLastError();
+    }
     if (rc != VF_OK) {
         vf_env_destroy(h);
         return rc;
@@ -413,6 +440,7 @@ void vf_env_destroy(vf_env* h)
     vf::release_cfg(&h->dyn.d_cfg);
     vf::release_cfg(&h->dyn.d_env_dummy);
     vf::release_cfg(&h->d_cfg);
+    if (h->d_stale) (void)hipFree(h->d_stale);
     delete h;
 }
 
@@ -435,6 +463,7 @@ int vf_env_reset(vf_env* h, const int32_t* idx, int32_t k, const float* full_sta
     const int n = idx ? k : h->dyn.Npad;
     if (n < 0) return vf::fail(VF_EINVAL, "vf_env_reset: k < 0");
     if (n == 0) return VF_OK;
+    h->stale_all = 1;            // episode counters / spawn copies change behind the stale bits' back
     if (!idx) h->dyn.tick = 0;   // full reset: head words go to 0 (k_env_reset) and so does the launch-uniform phase
     if (!idx) h->dyn.vel_strided = 1;   // DroneEnvsBase.reset always passes the randomizer's velocities (droneEnv.py:282)
     vf::EnvResetArgs r{dyn_args(h, nullptr, nullptr), n, h->g_race, idx, full_state};
@@ -525,6 +554,7 @@ int vf_env_rollout_fused(vf_env* h, const vf_env_rollout* r, vf_stream_t stream)
     hipLaunchKernelGGL(pick_env_rollout(h), dim3(h->dyn.Npad / vf::kBlock), dim3(vf::kBlock), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, g);
     VF_HIP(hipGetLastError());
     h->dyn.tick += r->K;
+    h->stale_all = 1;        // re-spawns inside the fused launch are not reflected in the stale bits
     return VF_OK;
 }
 
@@ -603,6 +633,7 @@ int vf_env_finish_step(vf_env* h, const float* ext_collision_point, const uint8_
     default: hipLaunchKernelGGL(vf::k_env_finish<VF_ENV_RACING>, grid, block, 0, st, h->dyn.d_cfg, h->d_cfg, g); break;
     }
     VF_HIP(hipGetLastError());
+    h->stale_all = 1;        // re-spawns of the split step are not reflected in the stale bits
     return VF_OK;
 }
 

@@ -25,6 +25,10 @@ struct EnvArgs {
     // prefetched re-spawn (include/visfly_amd.h): granule index of the copy this launch READS (main waves) and of the copy its
     // helper blocks REFILL, or -1; helper = number of main blocks when helper blocks follow them in the grid, else 0
     int g_spawn_rd = -1, g_spawn_wr = -1, helper = 0;
+    // stale bits of the two spawn copies (vf_env::d_stale): [2][n_tiles] words, or null (the helper then checks every agent's tag);
+    // stale_wr = index (0 / 1) of the copy the helper blocks refill
+    unsigned long long* stale = nullptr;
+    int n_tiles = 0, stale_wr = 0;
 };
 
 // env counters <-> spare slots
@@ -71,33 +75,47 @@ struct SpawnSlot {
 // serial refills end up on the launch's critical path (reset regime at 65 536 agents: span 1 11.2 us, 4 11.5, 8 17.6, 16 29.3)
 constexpr int kHelperSpan = VF_HELPER_SPAN;
 
-// helper blocks of k_env_step: refill the copy this launch does not read for every agent whose copy is stale
+// helper blocks of k_env_step: refill the copy this launch does not read for every agent whose copy is stale.  With the stale bits
+// (EnvArgs::stale) a wave reads ONE 64-bit word and is done unless a bit is set; without them it compares every agent's tag.
 __device__ __forceinline__ void spawn_helper(const vf_env_cfg& e, const EnvArgs& g, int i)
 {
     if (i >= g.d.N) return;
+    unsigned long long* word = nullptr;
+    if (g.stale) {
+        word = g.stale + (size_t)g.stale_wr * g.n_tiles + (i >> 6);
+        if (!((*word >> (i & 63)) & 1ull)) return;
+    }
     const unsigned need = ((unsigned)__float_as_int(granule(g.d.S, g.d.G, i, VF_G_ACC)->x) >> 8) + 1u;   // episode counter + 1
     float4* dst = granule(g.d.S, g.d.G, i, g.g_spawn_wr);
-    if (__float_as_uint(dst->x) == need) return;
-    Agent s;
-    spawn_agent(e, i, need, true, s);
-    const int gs = 64;                                   // float4 between two granules of one agent (wave-tile AoSoA)
-    dst[0] = make_float4(__uint_as_float(need), s.p[0], s.p[1], s.p[2]);
-    dst[gs] = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
-    dst[2 * gs] = make_float4(s.t, s.v[0], s.v[1], s.v[2]);
-    dst[3 * gs] = make_float4(0.0f, s.w[0], s.w[1], s.w[2]);
+    if (__float_as_uint(dst->x) != need) {
+        Agent s;
+        spawn_agent(e, i, need, true, s);
+        const int gs = 64;                                   // float4 between two granules of one agent (wave-tile AoSoA)
+        dst[0] = make_float4(__uint_as_float(need), s.p[0], s.p[1], s.p[2]);
+        dst[gs] = make_float4(s.q.w, s.q.x, s.q.y, s.q.z);
+        dst[2 * gs] = make_float4(s.t, s.v[0], s.v[1], s.v[2]);
+        dst[3 * gs] = make_float4(0.0f, s.w[0], s.w[1], s.w[2]);
+    }
+    // this copy now holds the state of episode `need`.  (An agent that ends an episode in THIS launch sets the bit again -- before
+    // or after this clear; if before, the bit is lost and the copy looks valid while it is one episode behind: the tag compare at
+    // consumption catches it, the in-place draw runs once, and that re-spawn sets the bit again.)
+    if (word) atomicAnd(word, ~(1ull << (i & 63)));
 }
 
 #ifndef VF_EXP_SLOT_MODE
 #define VF_EXP_SLOT_MODE 1       // 0: the loads under `if (done)` (A/B, profiles/r03_reset_prefetch.txt)
+#endif
+#ifndef VF_EXP_SLOT_ALWAYS
+#define VF_EXP_SLOT_ALWAYS 0     // 1: the r03 form -- every lane of every wave loads its spawn copy (A/B, profiles/r04_env_quad.txt)
 #endif
 
 // the prefetched spawn copy of agent i (granules g_spawn_rd .. + 3 of its tile).  Loaded by EVERY lane, ending an episode or not
 // (granule 0 when the feature is off: a valid address whose value nobody looks at): a load under `if (done)` joins a path on which
 // the registers are undefined, and the copies the join needs are placed -- with their s_waitcnt -- right behind the loads
 // (profiles/r03_reset_prefetch.txt); loads nobody waits for cost an ending-free wave four issue slots
-__device__ __forceinline__ SpawnSlot load_spawn_slot(const EnvArgs& g, int i)
+__device__ __forceinline__ SpawnSlot load_spawn_slot(const EnvArgs& g, int i, bool wanted = true)
 {
-    const float4* src = granule(g.d.S, g.d.G, i, g.g_spawn_rd >= 0 ? g.g_spawn_rd : 0);
+    const float4* src = granule(g.d.S, g.d.G, i, (wanted && g.g_spawn_rd >= 0) ? g.g_spawn_rd : 0);
     SpawnSlot slot;
     slot.g0 = src[0]; slot.g1 = src[64]; slot.g2 = src[128]; slot.g3 = src[192];
     return slot;
@@ -143,7 +161,13 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     const bool use_slot = done && g.auto_reset && g.g_spawn_rd >= 0;
 #endif
     if constexpr (VF_EXP_SLOT_MODE == 1 && !LAZY_SLOT) {
-        slot = load_spawn_slot(g, i);     // (issuing them ahead of the dynamics interval instead: same times, 16 registers more)
+        // Issued by every lane, consumed only by an ending one (a load under `if (done)` is waited for on the spot:
+        // profiles/r03_reset_prefetch.txt).  r04: in a wave in which NO agent ends its episode the four loads read the agent's own
+        // state granules instead (fetched at the head of the launch: L2 hits) -- a wave-uniform SELECT of the granule index, not a
+        // branch, so there is no join whose copies wait for the loads.  r03 read the spawn copy in every wave: 64 B of HBM traffic per
+        // agent-step that nobody looks at in the headline regime, where nobody ends an episode (1.25 x the algorithmic bytes)
+        const bool wave_ends = VF_EXP_SLOT_ALWAYS || __builtin_amdgcn_ballot_w64(use_slot) != 0;
+        slot = load_spawn_slot(g, i, wave_ends);
     } else {
         if (use_slot) slot = load_spawn_slot(g, i);
     }
@@ -215,6 +239,13 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
 #pragma unroll
                 for (int k = 0; k < 13; ++k) to[k] = o[k];
             }
+        }
+    }
+    if (g.stale) {       // both spawn copies of an agent that starts a new episode are one episode behind from now on
+        const unsigned long long ending = __builtin_amdgcn_ballot_w64(done && g.auto_reset != 0 && live);
+        if (ending && (threadIdx.x & 63) == 0) {
+            atomicOr(g.stale + (i >> 6), ending);
+            atomicOr(g.stale + g.n_tiles + (i >> 6), ending);
         }
     }
     if (done && g.auto_reset) {  // examine() -> reset_agent_by_id (:339-349,420-423)

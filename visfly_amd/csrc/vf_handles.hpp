@@ -31,6 +31,13 @@ struct vf_env {
     vf_env_cfg cfg;
     int g_race;  // racing granule or -1
     int g_spawn = -1;  // first of the 2 x 4 prefetched re-spawn granules or -1 (vf_env_cfg.spawn_prefetch)
+    // prefetched re-spawn, r04: one "may be stale" bit per (spawn copy, agent), a 64-bit word per wave tile -- [2][Npad / 64], owned by the
+    // handle.  The helper blocks of a step launch read ONE word per 64 agents and look at an agent's episode counter / copy tag only
+    // where its bit is set (r03: two words per agent per launch, 32 B of line traffic per agent-step); an ending agent sets its bit
+    // in both copies.  A hint only: the tag compare at consumption decides validity.  stale_all: every bit must be set before the
+    // next helper pass (after a reset, or after launches that re-spawn agents without maintaining the bits)
+    unsigned long long* d_stale = nullptr;
+    int stale_all = 1;
     vf_env_cfg* d_cfg = nullptr;   // device copy of cfg, see vf_dyn::d_cfg
 };
 

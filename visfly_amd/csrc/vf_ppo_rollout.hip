@@ -266,6 +266,7 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
     hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
     VF_HIP(hipGetLastError());
     h->dyn.tick += T;
+    h->stale_all = 1;       // agents re-spawned inside the launch: the prefetched copies' stale bits no longer cover them
     return VF_OK;
 }
 
