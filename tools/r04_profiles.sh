@@ -1,6 +1,6 @@
 #!/bin/bash
 # r04 evidence for profiles/: rocprofv3 kernel-trace stats of the four bench workloads (the commands the bench line's figures come from)
-O=$GRAFT_REPO_ROOT/gpurun_out/r04p; mkdir -p $O; R=$GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r04f; mkdir -p $O; R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 RP="rocprofv3 --output-format csv"
 timeout 600 $RP --kernel-trace --stats -d /tmp/p_env -- python $R/bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline --no-reset-leg --sustain-s 1 > $O/bench_env_profiled.log 2>&1
