@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 6   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
+#define VF_ABI_VERSION 7   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
                               4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_dyn_set_wind,
@@ -34,7 +34,12 @@ extern "C" {
                                  vf_dyn_step / vf_env_step, vf_shac_* / vf_twin_q_loss / vf_polyak_update,
                                  vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
                                  vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout;
-                              6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse, vf_mlp_desc.identity_mask (was pad0) */
+                              6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse, vf_mlp_desc.identity_mask (was pad0);
+                              7: mean_rows / log_std_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes) */
+
+/* clamp interval of the state-dependent log_std head of the reference's Actor (utils/policies/td_policies.py:31-32,241-243) */
+#define VF_SAC_LOG_STD_MIN (-10.0f)
+#define VF_SAC_LOG_STD_MAX 2.0f
 
 typedef void* vf_stream_t;
 
@@ -747,11 +752,18 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  *                 0 .. S-1 the state at the head of each integrator sub-step: (q) (v, 0) (w, 0) (rotor speeds); row S the state
  *                 after the last one before the clamps: (p, 0) (q) (v, 0) (w, 0).  What autograd's tape keeps of
  *                 dynamics.py:335-382; handed to vf_bptt_reverse, whose adjoint of the interval then reads it (LDS-DMA, one step
- *                 ahead) instead of replaying the S sub-steps (a third of its instruction stream).  16-byte aligned. */
+ *                 ahead) instead of replaying the S sub-steps (a third of its instruction stream).  16-byte aligned.
+ * Actor classes: (a) the policy trunk of an actor-critic layer table with the state-independent `log_std` (4,) parameter
+ * (policies.py:18-49; action = tanh(mean + exp(log_std) eps)); (b) the reference's own actor, utils/policies/td_policies.py:146-252
+ * (what BPTT.py:113 / shac.py:219 call per step): a layer table with TWO 4-wide heads, latent_pi -> mu and log_latent_pi -> log_std,
+ * action = tanh(mu + eps exp(clamp(log_std, VF_SAC_LOG_STD_MIN, VF_SAC_LOG_STD_MAX))) -- `log_std` is ignored (may be NULL) and
+ *   log_std_rows  (H N, 4) out, required for (b): the second head of every step (vf_bptt_reverse's head reverse reads it)
+ *   mean_rows     (H N, 4) out, optional (NULL: not kept): the first head of every step.  Both 16-byte aligned. */
 int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const float* obs_slots0,
                     const float* obs_slots1, const float* log_std, const float* eps, float* actions, const vf_env_out* out,
                     float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done, float* d_reward, float* loss,
-                    float* disc, float gamma, float scale, int32_t H, float* substep_tape, vf_stream_t stream);
+                    float* disc, float gamma, float scale, int32_t H, float* substep_tape, float* mean_rows, float* log_std_rows,
+                    vf_stream_t stream);
 
 /* ... and the reverse half (loss.backward() over the horizon, BPTT.py:127-129): for t = H-1 .. 0 the adjoint of env step t and the
  * policy's action-head reverse + reverse chain of step t, a wave owning 16 or 32 agents (the rows-per-wave choice
@@ -762,11 +774,15 @@ int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, con
  *              "state" branch = g_obs, (H N, 13) observation gradients);  d_action [H][N][4] scratch;  g_log_std [H][N][4] zeroed
  *   substep_tape  what vf_bptt_rollout wrote for the same H steps, or NULL (the interval is replayed; same results to the bit).
  *                 Read by the 16-agents-per-wave sweep only (N <= 16 384 per launch); ignored otherwise
+ * Actor class (b) of vf_bptt_rollout: the table holds both trunks (layer[0] = the log_std head, dY = d_log_std (H N, 4) out; the
+ * mean head's dY = d_mu (H N, 4) out), `log_std_rows` = what the forward launch saved; log_std / g_log_std are ignored (NULL);
+ * what it leaves equals H rounds of vf_env_step_bwd + vf_shac_head_bwd + vf_mlp_backward_data.  16 agents per wave only
+ * (N <= 16 384 per launch), VF_EUNSUPPORTED beyond.
  * Same restrictions as vf_bptt_rollout. */
 int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const float* packed, const float* log_std, const float* eps,
                     const float* actions, const float* tape, int64_t tape_stride, const uint8_t* tape_done, const float* d_reward,
                     float* adj_slab, float* d_action, const float* g_obs, float* g_log_std, int32_t H, const float* substep_tape,
-                    vf_stream_t stream);
+                    const float* log_std_rows, vf_stream_t stream);
 
 /* The same construction for PPO's collect_rollouts (SB3 OnPolicyAlgorithm.collect_rollouts, run by utils/algorithms/PPO.py:146;
  * n_steps rounds of policy.forward -> distribution.sample / log_prob -> env.step -> RolloutBuffer.add): T steps in ONE

@@ -164,23 +164,36 @@ class BPTT:
         """BPTT.py:107-134 with the reference's actor: per step actor.action_log_prob(obs) (both trunks, clamped log_std, squashed
         reparameterised sample; the log-prob it also returns is discarded by the loop) -> env.step -> loss / discount recurrence
         (:123-124); reverse, t = H-1 .. 0: adjoint env step -> action head reverse (d mu, d log_std) -> both trunks + extractor
-        (parameter gradients accumulate) -> gradient w.r.t. the observation of step t, which step t-1 returned"""
+        -> gradient w.r.t. the observation of step t, which step t-1 returned.  Like the MlpPolicy sweep: the activations of every
+        step stay in their slot, the weight gradient is reduced once over the rows of all H steps, and where the library has the
+        kernels each half is ONE persistent launch (vf_bptt_rollout / vf_bptt_reverse, actor class (b)) that leaves what the
+        launch-by-launch loop below leaves, bit for bit."""
         env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
         L, st, dev = _lib.lib(), _lib.current_stream(self.device), self.device
         keys = self.obs_keys
         pol.grad.zero_()
+        pol.reserve_slots(N, H)
+        if self._defer_wgrad is None:
+            self._defer_wgrad = pol.backward_data_supported(N, both_heads=True)
+        defer = self._defer_wgrad
         f = dict(dtype=th.float32, device=dev)
         disc, loss_vec = th.ones(N, **f), th.zeros(N, **f)
         eps = self._eps_override if self._eps_override is not None else th.randn((H, N, 4), device=dev, generator=self._gen)
         assert eps.shape == (H, N, 4)
-        acts, drews, ls_rows = th.empty((H, N, 4), **f), th.empty((H, N), **f), []
-        self._last_rollout = dict(action=acts, reward=th.empty((H, N), **f), done=th.empty((H, N), dtype=th.bool, device=dev))
+        acts, drews = th.empty((H, N, 4), **f), th.empty((H, N), **f)
+        ls_rows = pol._slot_blocks[N][1]["value"]                                      # (slots, N, 4): slot t's log_std head
         t0 = env._tape_t
-        obs = env.get_observation()
-        for t in range(H):
+        fused = False
+        if defer and self.fused_rollout:
+            fused = env.rollout_policy(pol, keys, eps, acts, drews, loss_vec, disc, float(self.gamma), 1.0 / (N * self.world))
+        if fused:
+            self._last_rollout = dict(action=acts, done=env._tape_done[t0:t0 + H])
+        else:
+            self._last_rollout = dict(action=acts, reward=th.empty((H, N), **f), done=th.empty((H, N), dtype=th.bool, device=dev))
+            obs = env.get_observation()
+        for t in range(0 if not fused else H, H):
             o = {k: obs[k].detach().contiguous() for k in keys}
             mu, ls = pol.forward(o, slot=t)                                            # actor.action_log_prob(obs) :113
-            ls_rows.append(ls)
             self._head_fwd(mu, ls, eps[t], acts[t])                                    # tanh output: the clip of :114-116 is the identity
             obs, reward, done, _ = env._step_no_grad(acts[t], False, record=True, borrow=True)      # :119
             self._last_rollout["reward"][t].copy_(reward)
@@ -188,13 +201,21 @@ class BPTT:
             _lib.check(L.vf_bptt_accumulate(_ptr(reward), done.data_ptr(), _ptr(disc), _ptr(loss_vec), _ptr(drews[t]),
                                             float(self.gamma), 1.0 / (N * self.world), N, st))     # :123-124
         g_obs = None
-        d_mu, d_ls = th.empty((N, 4), **f), th.empty((N, 4), **f)
-        for t in reversed(range(H)):
+        d_mus, d_lss = th.empty((H, N, 4), **f), th.empty((H, N, 4), **f)
+        rev = False
+        if fused and self.fused_reverse:
+            rev = env.reverse_policy(pol, H, eps, acts, drews, d_mus, None, d_log_stds=d_lss)
+        for t in reversed(range(0 if not rev else H, H)):
             d_action = env.backward_step(t0 + t, g_obs, drews[t])
-            _lib.check(L.vf_shac_head_bwd(_ptr(d_action), _ptr(acts[t]), _ptr(ls_rows[t]), _ptr(eps[t]), _ptr(d_mu), _ptr(d_ls), N,
+            _lib.check(L.vf_shac_head_bwd(_ptr(d_action), _ptr(acts[t]), _ptr(ls_rows[t]), _ptr(eps[t]), _ptr(d_mus[t]), _ptr(d_lss[t]), N,
                                           LOG_STD_MIN, LOG_STD_MAX, st))
-            d_in = pol.backward(d_mu, d_ls, None, accumulate=True, need_input_grad=t > 0, slot=t)
+            if defer:
+                d_in = pol.backward_data(d_mus[t], t, d_value=d_lss[t])
+            else:
+                d_in = pol.backward(d_mus[t], d_lss[t], None, accumulate=True, need_input_grad=t > 0, slot=t)
             g_obs = d_in.get("state") if t > 0 else None
+        if defer:
+            pol.weight_grad_slots(N, H, d_mus, accumulate=True, d_value_all=d_lss)
         return loss_vec.mean() / self.world
 
     def _grad_reverse_sweep(self):

@@ -1,0 +1,140 @@
+// vf_bptt_reverse_kernel.hpp -- k_bptt_reverse (the reverse half of a BPTT horizon as one persistent launch; scheme at the head of
+// vf_bptt_reverse.hip) + its instance table, shared by vf_bptt_reverse.hip (MlpPolicy classes) and vf_bptt_reverse_sac.hip
+// (td_policies.Actor), two translation units so that their instances compile side by side.
+#pragma once
+#include "vf_env_bwd_body.hpp"
+#include "vf_mlp_chain_bwd.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vf {
+
+#ifdef VF_PPO_TRACE
+__device__ long long vf_rev_trace[8];
+#endif
+
+struct RevArgs {
+    int H, N, G, g_drag, g_race;
+    const float* tape;             // [H] rows of tape_stride floats: the slab before step t
+    long long tape_stride;
+    const float4* actions;         // [H][N]: the action step t was given
+    const unsigned char* done;     // [H][N]
+    const float* d_reward;         // [H][N]
+    float* adj;                    // adjoint of the persistent state (slab layout), in / out
+    float4* d_action;              // [H][N] scratch: dLoss / d action_t, read by the head reverse of step t
+    const float* g_obs;            // [H][N][13]: row t N + i = dLoss / d (observation of slot t), written by the reverse chain
+    const float4* ck;              // the forward launch's sub-step tape [H][S + 1][waves of 16 agents][64] float4 (CKPT instances), else null
+};
+
+template <class P, int ROWS, int KIND, int ACT, int INTEG, bool CTRL_DELAY, bool CKPT>
+__global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const BwdArgsChain gb,
+                                                     const RevArgs r)
+{
+    prefetch_kernarg<sizeof(BwdArgsChain) + sizeof(RevArgs) + 16>();
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [S * kSave][64]
+    const int lane = threadIdx.x, m = lane & (ROWS - 1);
+    const int i = min((int)blockIdx.x * ROWS + m, r.N - 1);          // lanes past the last agent replicate it as well
+#ifdef VF_PPO_TRACE
+    long long tr[2] = {0, 0}, tc = __builtin_readcyclecounter();
+#define VF_RT(k) do { const long long n_ = __builtin_readcyclecounter(); tr[k] += n_ - tc; tc = n_; } while (0)
+#else
+#define VF_RT(k) do { } while (0)
+#endif
+    // CKPT: this wave's record of step t travels global -> LDS by LDS-DMA (no registers; one 1 KiB row per instruction) a whole
+    // step AHEAD of its use, into the half of the LDS area the current step does not read: issued at the head of step t + 1, it has
+    // ~28 us to arrive from HBM (the tape was written a forward sweep ago) and nothing ever waits for it -- fetched by the step
+    // that needs it, it cost as much latency as the replay it replaces (r04: reverse half 28.4 -> 28.6 us per step)
+    const int rows_ck = cp->interval_steps + 1;
+    float4* lds4 = reinterpret_cast<float4*>(lds);
+    auto fetch_record = [&](int t) {
+        const float4* src = r.ck + ((size_t)t * rows_ck * gridDim.x + blockIdx.x) * 64 + lane;
+        float4* dst = lds4 + (size_t)(t & 1) * rows_ck * 64;
+        for (int j = 0; j < rows_ck; ++j)
+            __builtin_amdgcn_global_load_lds(src + (size_t)j * gridDim.x * 64, (__attribute__((address_space(3))) void*)(dst + (size_t)j * 64), 16, 0, 0);
+    };
+    if constexpr (CKPT) {
+        fetch_record(r.H - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int t = r.H - 1; t >= 0; --t) {
+        const BwdArgs g{r.N, r.G, r.g_drag, r.g_race, r.tape + (size_t)t * r.tape_stride, r.actions + (size_t)t * r.N,
+                        t + 1 < r.H ? r.g_obs + (size_t)(t + 1) * r.N * 13 : nullptr, r.d_reward + (size_t)t * r.N,
+                        r.done + (size_t)t * r.N, r.adj, r.d_action + (size_t)t * r.N};
+        const int row = t * r.N + i;
+        // the masks of this step's reverse chain (saved activations of slot t: written a forward sweep ago, HBM by now) are loaded
+        // HERE, ahead of the adjoint, which covers their latency; issued inside the chain, whose ops are over long before their
+        // own loads are back, they cost 5 of the step's 31 us
+        BwdState16<P> st16;
+        if constexpr (ROWS == 16) bwd16_mask_preload<P, 0>(gb, st16, row, lane >> 4);
+        if constexpr (CKPT) {
+            if (t > 0) fetch_record(t - 1);
+            env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64, true>(*cp, *ep, g, i, true, lds + lane, lds4 + (size_t)(t & 1) * rows_ck * 64);
+        } else {
+            env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64>(*cp, *ep, g, i, true, lds + lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // d_action_t: written above, read by the head reverse below
+        VF_RT(0);
+        // (an opaque copy of the lane id per iteration: the chain's loop-invariant per-item load offsets stay just-in-time instead
+        // of being hoisted out of the t loop into ~100 live registers -- see k_ppo_rollout)
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        long zero_t = 0;                                             // (likewise for the per-item weight base addresses)
+        asm volatile("" : "+s"(zero_t));
+        BwdArgsChain gbt = gb;
+        gbt.packed = gb.packed + zero_t;
+        if constexpr (ROWS == 16) {
+            const int gq = lane_t >> 4;
+            bwd16_prologue<P, 0>(gbt, st16, lane_t);
+            bwd16_head_prologue<P, 0, true>(gbt, st16, row, gq, true);
+            bwd16_items<P, 0, true>(gbt, st16, lane_t, row, row, true);
+            bwd16_tail_store<P>(gbt, st16, row, gq, true);
+        } else {
+            bwd_rows<P, ROWS>(gbt, lane_t, row, row, true);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // dLoss / d obs_t: read by the adjoint of step t - 1
+        // the record of step t - 1 (issued a whole step ago) is in LDS before the next adjoint reads it; every other load of this step
+        // has been consumed by now, so this never waits
+        if constexpr (CKPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VF_RT(1);
+    }
+#ifdef VF_PPO_TRACE
+    if (blockIdx.x == 7 && lane == 0) { vf_rev_trace[0] = tr[0]; vf_rev_trace[1] = tr[1]; }
+#endif
+}
+
+}  // namespace vf
+
+namespace vf {
+
+using RevKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::BwdArgsChain, const vf::RevArgs);
+
+template <class Net, int ROWS, int KIND, bool CKPT>
+static RevKernel pick_rev2(const vf_dyn_cfg& c)
+{
+    using P = vf::BwdProg<Net, true, Net::HV == 4, true>;      // HV == 4: td_policies.Actor, both trunks
+    if (!c.ctrl_delay) return nullptr;
+    if (c.integrator == VF_INT_RK4) {
+        if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_RK4, true, CKPT>;
+        if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_RK4, true, CKPT>;
+        return nullptr;
+    }
+    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_EULER, true, CKPT>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true, CKPT>;
+    return nullptr;
+}
+
+// ckpt: the forward launch wrote the sub-step tape -> the instances that read it instead of replaying the interval
+template <class Net, int ROWS, int KIND>
+static RevKernel pick_rev(const vf_dyn_cfg& c, bool ckpt)
+{
+    if constexpr (ROWS == 16) {          // the tape's records are the forward launch's waves: 16 agents each
+        if (ckpt) return pick_rev2<Net, ROWS, KIND, true>(c);
+    }
+    return pick_rev2<Net, ROWS, KIND, false>(c);
+}
+
+// vf_bptt_reverse_sac.hip: net = 3 NetSacHover (Hover / Racing env), 4 NetSacNav (Navigation env), 16 rows per wave only
+RevKernel pick_rev_sac(int net, int kind, const vf_dyn_cfg& c, bool ckpt);
+
+}  // namespace vf
+

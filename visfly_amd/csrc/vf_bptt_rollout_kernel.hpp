@@ -1,0 +1,178 @@
+// vf_bptt_rollout_kernel.hpp -- k_bptt_rollout (the forward half of a BPTT horizon as one persistent launch; scheme at the head of
+// vf_bptt_rollout.hip) + its instance table, shared by vf_bptt_rollout.hip (state-independent log_std: the MlpPolicy classes) and
+// vf_bptt_rollout_sac.hip (td_policies.Actor: state-dependent log_std), two translation units so that their instances compile side by side.
+#pragma once
+#include "vf_env_epilogue.hpp"
+#include "vf_mlp_chain.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vf {
+
+struct RollArgs {
+    int H;                     // control steps
+    int N;                     // agents = policy rows per step
+    float* tape;               // [H][slab floats]: row t = the slab before step t (what vf_env_step_bwd reads)
+    long long tape_stride;     // floats between two tape rows
+    unsigned char* tape_done;  // [H][N]
+    float* d_reward;           // [H][N]  -disc_t * scale
+    float* loss;               // [N] in/out
+    float* disc;               // [N] in/out
+    float* obs_slots;          // [H][N][13]: slot t = the observation the policy sees at step t (slot 0 filled by the caller)
+    float* obs_final;          // (N,13): the observation after the last step
+    float gamma, scale;
+    float4* ck;                // optional sub-step tape [H][S + 1][waves][64] float4 (include/visfly_amd.h, vf_bptt_rollout) or null
+};
+
+// control_interval observer: the agent at the head of every sub-step -- (q) (v, 0) (w, 0) (rotor speeds) -- and the state after the
+// last one before the clamps -- (p, 0) (q) (v, 0) (w, 0) --, what the adjoint of the interval otherwise obtains by replaying it.
+// One record row = ONE store instruction of the whole wave: the four lane groups (which hold the same 16 agents) store one entry
+// each, [entry k = lane >> 4][agent slot = lane & 15] float4 = 1 KiB contiguous; k_bptt_reverse fetches a row back with one LDS-DMA.
+struct TapeCheckpoint {
+    float4* p;                 // row 0 of this (step, wave) + lane, or null (no tape)
+    size_t rs;                 // float4 between two rows of a record = 64 x waves
+    int S, k;                  // sub-steps per interval; this lane's entry (lane >> 4)
+    // two-level selects on the bits of k (a chain `k == 0 ? .. : k == 1 ? ..` is compiled into a scratch array + indexed load)
+    __device__ __forceinline__ float sel(float a, float b, float c2, float d) const
+    {
+        const float lo = (k & 1) ? b : a, hi = (k & 1) ? d : c2;
+        return (k & 2) ? hi : lo;
+    }
+    __device__ __forceinline__ float4 pick(const float4& e0, const float4& e1, const float4& e2, const float4& e3) const
+    {
+        return make_float4(sel(e0.x, e1.x, e2.x, e3.x), sel(e0.y, e1.y, e2.y, e3.y), sel(e0.z, e1.z, e2.z, e3.z), sel(e0.w, e1.w, e2.w, e3.w));
+    }
+    __device__ __forceinline__ void head(int sub, const Agent& s) const
+    {
+        if (p)
+            p[(size_t)sub * rs] = pick(make_float4(s.q.w, s.q.x, s.q.y, s.q.z), make_float4(s.v[0], s.v[1], s.v[2], 0.0f),
+                                       make_float4(s.w[0], s.w[1], s.w[2], 0.0f), make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]));
+    }
+    __device__ __forceinline__ void end(const Agent& s) const
+    {
+        if (p)
+            p[(size_t)S * rs] = pick(make_float4(s.p[0], s.p[1], s.p[2], 0.0f), make_float4(s.q.w, s.q.x, s.q.y, s.q.z),
+                                     make_float4(s.v[0], s.v[1], s.v[2], 0.0f), make_float4(s.w[0], s.w[1], s.w[2], 0.0f));
+    }
+};
+
+template <class Net, int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs ge,
+                                                     const ChainArgs gc, const RollArgs r)
+{
+    prefetch_kernarg<sizeof(EnvArgs) + sizeof(ChainArgs) + sizeof(RollArgs) + 16>();
+    const vf_dyn_cfg& c = *cp;
+    const vf_env_cfg& e = *ep;
+    __shared__ __attribute__((aligned(16))) float tile[64 * 13];
+    const int lane = threadIdx.x, m = lane & 15;
+    const int wave_first = blockIdx.x * 16;
+    // agent = policy row of this lane.  Lanes 16..63 -- and the lanes past the last agent -- are REPLICAS of a live lane: same
+    // index, same loads, same arithmetic, same stores of the same values
+    const int i = min(wave_first + m, r.N - 1), ic = i;
+    const bool live = true;
+    EnvArgs g = ge;
+    g.d.N = min(r.N, wave_first + 16);                   // the wave's observation tile holds 16 rows
+    Agent s;
+    Spares sp;
+    load_agent<true>(g.d.S, g.d.G, ic, s, sp);
+    load_wind(c, g.d, ic, live, s);
+    float disc = r.disc[ic], loss = r.loss[ic];
+    const int Gx = g.d.G;
+    for (int t = 0; t < r.H; ++t) {
+        // ---- policy forward + action head: rows t N + i of the slot buffers, action row of step t ----
+        {
+            // (an opaque copy of the lane id per iteration: the chain's per-item load offsets are loop-invariant and would be
+            // hoisted out of the t loop -- dozens of live VGPRs, scratch spills in the two-branch network)
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            const int row = t * r.N + i, rc = row, gq = lane_t >> 4;
+            const bool lrow = true;
+            // (... and an opaque zero in the weight pointers: the per-item base addresses are loop-invariant too; hoisted, the SGPR
+            // pairs are spilled to VGPR lanes and read back with two v_readlane per item)
+            long zero_t = 0;
+            asm volatile("" : "+s"(zero_t));
+            ChainArgs gct = gc;
+            gct.packed = gc.packed + zero_t;
+            gct.params = gc.params + zero_t;
+            ChainState16<Net> st;
+            chain16_prologue<Net, 0>(gct, st, lane_t);
+#pragma unroll
+            for (int b = 0; b < Net::NB; ++b) {
+                const int w = gct.d.in_dim[b];
+                const float* x = gct.io.in[b] + (size_t)rc * w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * gq + j;
+                    const float v = x[k < w ? k : w - 1];
+                    st.x[b][j] = k < w ? v : 0.0f;
+                }
+            }
+            chain16_items<Net, 0>(gct, st, lane_t, row, lrow, rc);
+        }
+        // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
+        // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // ---- checkpoint for the adjoint: this agent's granules of tape row t = the slab before the step ----
+        float* T = r.tape + (size_t)t * r.tape_stride;
+        store_agent(T, Gx, ic, s, sp);
+        for (int q = VF_G_FIXED; q < Gx; ++q) *granule(T, Gx, ic, q) = *granule(g.d.S, Gx, ic, q);
+        // ---- env step (k_env_rollout's body) ----
+        float a[4], head_bits = 0.0f;
+        ring_exchange(c, g.d, ic, live, head_bits, a);
+        if (c.delay_steps > 0) sp.vel = head_bits;
+        float kl[3], kq[3];
+        drag_of(c, g.d, ic, kl, kq);
+        // the noise row of the NEXT step's action head (drawn before the launch: HBM-cold) is touched here, under the dynamics
+        // interval; the head's own load at the end of the next forward then finds it in the cache instead of waiting for HBM
+        const float4 eps_touch = gc.rp_eps[(size_t)(t + 1 < r.H ? t + 1 : t) * r.N + i];
+        // sub-step tape of this (step, wave): [H][S + 1 rows][waves][64] float4 (wave-uniform pointer test: no divergence)
+        const size_t ck_rs = (size_t)gridDim.x * 64;
+        const TapeCheckpoint ck{r.ck ? r.ck + ((size_t)t * (c.interval_steps + 1) * gridDim.x + blockIdx.x) * 64 + lane : nullptr, ck_rs,
+                                c.interval_steps, lane >> 4};
+        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0, ck);
+        asm volatile("" :: "v"(eps_touch.x), "v"(eps_touch.y), "v"(eps_touch.z), "v"(eps_touch.w));
+        float reward = 0.0f;
+        bool done = false;
+        env_epilogue<KIND, false>(c, e, g, ic, live, s, sp, wave_first, tile, &reward, &done);
+        // ---- loss / discount recurrence (BPTT.py:123-124; k_bptt_accumulate) ----
+        r.d_reward[(size_t)t * r.N + i] = -disc * r.scale;
+        loss = loss + -1.0f * reward * disc;
+        const float dn = done ? 1.0f : 0.0f;
+        disc = disc * r.gamma * (1.0f - dn) + dn;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the observation rows of slot t + 1 are read by the next forward
+        // ---- next step ----
+        g.d.action += r.N;                               // float4 units
+        g.out.done += r.N;
+        g.out.obs = t + 2 < r.H ? r.obs_slots + (size_t)(t + 2) * r.N * 13 : r.obs_final;   // the last one: the env's own buffer
+        g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
+    }
+    store_agent(g.d.S, Gx, ic, s, sp);
+    r.disc[i] = disc;
+    r.loss[i] = loss;
+}
+
+}  // namespace vf
+
+namespace vf {
+
+using RollKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvArgs, const vf::ChainArgs, const vf::RollArgs);
+
+template <class Net, int KIND>
+static RollKernel pick_roll(const vf_dyn_cfg& c)
+{
+    if (!c.ctrl_delay) return nullptr;
+    if (c.integrator == VF_INT_RK4) {
+        if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
+        if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
+        return nullptr;
+    }
+    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    return nullptr;
+}
+
+// vf_bptt_rollout_sac.hip: net = 3 NetSacHover (Hover / Racing env), 4 NetSacNav (Navigation env); nullptr: no instance
+RollKernel pick_roll_sac(int net, int kind, const vf_dyn_cfg& c);
+
+}  // namespace vf
+

@@ -112,8 +112,8 @@ struct ReparamBwd {
 int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
                           float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rp = nullptr, const float* in2 = nullptr);
 
-int bwd_chain_policy_class(const vf_mlp_bwd_desc* d, int M);           // vf_mlp_chain.hip: 0 none, 1 NetHover, 2 NetNav (policy trunk, obs gradient); + 16: M rows per pass run 16 rows per wave
-int chain16_policy_class(const vf_mlp_desc* d, const float* params);   // vf_mlp_chain.hip: 0 none, 1 NetHoverPi, 2 NetNavPi
+int bwd_chain_policy_class(const vf_mlp_bwd_desc* d, int M);           // vf_mlp_chain.hip: 0 none, 1 NetHover, 2 NetNav (policy trunk, obs gradient), 3 / 4 NetSacHover / NetSacNav (both trunks); + 16: M rows per pass run 16 rows per wave
+int chain16_policy_class(const vf_mlp_desc* d, const float* params);   // vf_mlp_chain.hip: 0 none, 1 NetHoverPi, 2 NetNavPi, 3 NetSacHover, 4 NetSacNav
 int chain_full_class(const vf_mlp_desc* d, const float* params, int M);   // 0 none, 1 NetHover, 2 NetNav (both trunks); + 16: M rows run on the 16-row chain
 // reverse chain (data gradients) for the same network classes: 1 launched, 0 no match, < 0 error
 int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp = nullptr);

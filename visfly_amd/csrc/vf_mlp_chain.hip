@@ -176,7 +176,8 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     return 0;
 }
 
-// the policy-trunk-only reverse chain with observation gradient (first-order policy optimisation): 0 none, 1 NetHover, 2 NetNav;
+// the reverse chain with observation gradient a BPTT sweep runs per step: 0 none, 1 NetHover, 2 NetNav (policy trunk only), 3 NetSacHover,
+// 4 NetSacNav (td_policies.Actor: both trunks);
 // + 16 when M rows per pass run on the 16-rows-per-wave chain
 int bwd_chain_policy_class(const vf_mlp_bwd_desc* d, int M)
 {
@@ -184,17 +185,22 @@ int bwd_chain_policy_class(const vf_mlp_bwd_desc* d, int M)
     if (off) return 0;
     if (bwd_chain_matches<NetHover, true, false, true>(*d)) return 1 + (bwd16_ok<NetHover, true, false, true>(*d, M) ? 16 : 0);
     if (bwd_chain_matches<NetNav, true, false, true>(*d)) return 2 + (bwd16_ok<NetNav, true, false, true>(*d, M) ? 16 : 0);
+    if (bwd_chain_matches<NetSacHover, true, true, true>(*d)) return 3 + (bwd16_ok<NetSacHover, true, true, true>(*d, M) ? 16 : 0);
+    if (bwd_chain_matches<NetSacNav, true, true, true>(*d)) return 4 + (bwd16_ok<NetSacNav, true, true, true>(*d, M) ? 16 : 0);
     return 0;
 }
 
 // which 16-rows-per-wave policy-only class does this layer table belong to (vf_bptt_rollout.hip)?  0: none, 1: NetHoverPi
-// (one observation), 2: NetNavPi (state + target).  The conditions of chain16_ok apart from the row count.
+// (one observation), 2: NetNavPi (state + target), 3 / 4: NetSacHover / NetSacNav (both trunks, two 4-wide heads).  The conditions of
+// chain16_ok apart from the row count.
 int chain16_policy_class(const vf_mlp_desc* d, const float* params)
 {
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
     if (off) return 0;
     if (chain_matches<NetHoverPi>(*d) && chain16_ok<NetHoverPi>(*d, params, 1)) return 1;
     if (chain_matches<NetNavPi>(*d) && chain16_ok<NetNavPi>(*d, params, 1)) return 2;
+    if (chain_matches<NetSacHover>(*d) && chain16_ok<NetSacHover>(*d, params, 1)) return 3;     // td_policies.Actor: mu / log_std heads
+    if (chain_matches<NetSacNav>(*d) && chain16_ok<NetSacNav>(*d, params, 1)) return 4;
     return 0;
 }
 

@@ -155,7 +155,12 @@ struct ChainArgs {
     const float4* rp_eps;
     float4* rp_action;
     float* obs_copy[2];      // optional: the observation rows are also written here (a trainer's contiguous per-slot copy)
+    // HV == 4 classes (td_policies.Actor: the second head IS log_std, rp_log_std unused): clamp bounds of the state-dependent
+    // log_std in action = tanh(mean + eps exp(clamp(log_std, lo, hi))) (k_shac_head_fwd's arithmetic)
+    float rp_ls_lo, rp_ls_hi;
 };
+
+__device__ __forceinline__ float chain_clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 using NetHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2>;   // StateExtractor [128, 64], pi / vf [64, 64]
 using NetNav = ChainNet<2, 16, 8, 4, 2, 2, 2, 2, 2>;     // StateTargetExtractor [128, 64] x 2, pi / vf [64, 64]
@@ -214,13 +219,22 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>
                 if (g.io.mean) g.io.mean[row] = y[0];
             } else if constexpr (L.desc == N::L_mean) {
                 if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
-                if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers
-                    const float4 e = g.rp_eps[row];
-                    g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
-                                                   tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                if constexpr (N::HV != 4) {
+                    if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers
+                        const float4 e = g.rp_eps[row];
+                        g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
+                                                       tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                    }
                 }
             } else if constexpr (N::HV == 4) {
                 if (g.io.value) *reinterpret_cast<float4*>(g.io.value + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
+                if (g.rp_action) {         // k_shac_head_fwd's arithmetic: the mean head (run before this one) is still in its tile
+                    const f32x16& mu = st.t[N::t_mean];
+                    const float4 e = g.rp_eps[row];
+                    const float lo = g.rp_ls_lo, hi = g.rp_ls_hi;
+                    g.rp_action[row] = make_float4(tanhf(mu[0] + e.x * expf(chain_clampf(y[0], lo, hi))), tanhf(mu[1] + e.y * expf(chain_clampf(y[1], lo, hi))),
+                                                   tanhf(mu[2] + e.z * expf(chain_clampf(y[2], lo, hi))), tanhf(mu[3] + e.w * expf(chain_clampf(y[3], lo, hi))));
+                }
             } else {
                 if (g.io.value) g.io.value[row] = y[0];
             }
@@ -497,13 +511,22 @@ __device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState1
                 if (g.io.mean) g.io.mean[row] = y[0];
             } else if constexpr (L.desc == N::L_mean) {
                 if (g.io.mean) *reinterpret_cast<float4*>(g.io.mean + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
-                if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers (as chain_epilogue)
-                    const float4 e = g.rp_eps[row];
-                    g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
-                                                   tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                if constexpr (N::HV != 4) {
+                    if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers (as chain_epilogue)
+                        const float4 e = g.rp_eps[row];
+                        g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
+                                                       tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                    }
                 }
             } else if constexpr (N::HV == 4) {
                 if (g.io.value) *reinterpret_cast<float4*>(g.io.value + (size_t)row * 4) = make_float4(y[0], y[1], y[2], y[3]);
+                if (g.rp_action) {         // k_shac_head_fwd's arithmetic (as chain_epilogue)
+                    const f32x4& mu = st.t[2 * N::t_mean];
+                    const float4 e = g.rp_eps[row];
+                    const float lo = g.rp_ls_lo, hi = g.rp_ls_hi;
+                    g.rp_action[row] = make_float4(tanhf(mu[0] + e.x * expf(chain_clampf(y[0], lo, hi))), tanhf(mu[1] + e.y * expf(chain_clampf(y[1], lo, hi))),
+                                                   tanhf(mu[2] + e.z * expf(chain_clampf(y[2], lo, hi))), tanhf(mu[3] + e.w * expf(chain_clampf(y[3], lo, hi))));
+                }
             } else {
                 if (g.io.value) g.io.value[row] = y[0];
             }

@@ -33,6 +33,7 @@ template <class N, bool PI, bool VF, bool IG>
 struct BwdProg {
     using Net = N;
     static constexpr int NB = N::NB;
+    static constexpr bool sac_head = PI && VF && N::HV == 4 && N::HM == 4;     // td_policies.Actor: mu / log_std heads of ONE action
     static constexpr int L_pi0 = 2 * NB, L_pi1 = 2 * NB + 1, L_mean = 2 * NB + 2, L_vf0 = 2 * NB + 3, L_vf1 = 2 * NB + 4, L_val = 2 * NB + 5;
     // gradient tiles
     static constexpr int g_p2 = 0, g_v2 = g_p2 + N::P2, g_p1 = g_v2 + N::V2, g_v1 = g_p1 + N::P1, g_feat = g_v1 + N::V1;
@@ -113,7 +114,14 @@ struct BwdArgsChain {
     const float* rp_log_std;
     const float4* rp_eps;
     float4* rp_g_log_std;
+    // sac_head classes: the log_std rows the forward saved (its second head; rp_log_std / rp_g_log_std unused) and the clamp bounds of
+    // action = tanh(mean + eps exp(clamp(log_std, lo, hi))); both head gradients are formed from d_action (k_shac_head_bwd's arithmetic)
+    const float4* rp_ls_rows;
+    float rp_ls_lo, rp_ls_hi;
 };
+
+// d log_std of one component: torch.clamp passes the gradient on the closed interval (k_shac_head_bwd)
+__device__ __forceinline__ float sac_dls(float dp, float e, float s, float lo, float hi) { return (s >= lo && s <= hi) ? dp * e * expf(s) : 0.0f; }
 
 template <class P>
 struct BwdState {
@@ -279,7 +287,19 @@ __device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdStat
                     const float4 da = g.rp_d_action[rc], a = g.rp_action[rc], e = g.rp_eps[rc];
                     const float4 dm = make_float4(da.x * (1.0f - a.x * a.x), da.y * (1.0f - a.y * a.y), da.z * (1.0f - a.z * a.z),
                                                   da.w * (1.0f - a.w * a.w));
-                    if (live && h == 0) {
+                    if constexpr (P::sac_head) {       // ... k_shac_head_bwd's: d_mu = dm, d_log_std (the second head's gradient) from the saved row
+                        const vf_mlp_bwd_layer& EV = g.d.layer[P::entry(P::L_val)];
+                        const float4 s = g.rp_ls_rows[rc];
+                        const float lo = g.rp_ls_lo, hi = g.rp_ls_hi;
+                        const float4 dl = make_float4(sac_dls(dm.x, e.x, s.x, lo, hi), sac_dls(dm.y, e.y, s.y, lo, hi),
+                                                      sac_dls(dm.z, e.z, s.z, lo, hi), sac_dls(dm.w, e.w, s.w, lo, hi));
+                        if (live && h == 0) {
+                            *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
+                            *reinterpret_cast<float4*>(const_cast<float*>(EV.dY) + (size_t)rc * EV.ld_dy) = dl;
+                        }
+                        st.hin[1][0] = h == 0 ? dl.x : 0.0f; st.hin[1][1] = h == 0 ? dl.y : 0.0f;
+                        st.hin[1][2] = h == 0 ? dl.z : 0.0f; st.hin[1][3] = h == 0 ? dl.w : 0.0f;
+                    } else if (live && h == 0) {
                         *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
                         float4 gl = g.rp_g_log_std[rc];
                         gl.x += dm.x * expf(g.rp_log_std[0]) * e.x; gl.y += dm.y * expf(g.rp_log_std[1]) * e.y;
@@ -295,8 +315,10 @@ __device__ __forceinline__ void bwd_head_prologue(const BwdArgsChain& g, BwdStat
                     st.hin[0][2] = h == 0 ? dy[2] : 0.0f; st.hin[0][3] = h == 0 ? dy[3] : 0.0f;
                 }
             } else if constexpr (P::Net::HV == 4) {      // second head 4 wide (the SAC actor's log_std head): d_log_std (M,4)
-                st.hin[1][0] = h == 0 ? dy[0] : 0.0f; st.hin[1][1] = h == 0 ? dy[1] : 0.0f;
-                st.hin[1][2] = h == 0 ? dy[2] : 0.0f; st.hin[1][3] = h == 0 ? dy[3] : 0.0f;
+                if (!(P::sac_head && g.rp_d_action)) {   // (else: formed by the first head's branch above)
+                    st.hin[1][0] = h == 0 ? dy[0] : 0.0f; st.hin[1][1] = h == 0 ? dy[1] : 0.0f;
+                    st.hin[1][2] = h == 0 ? dy[2] : 0.0f; st.hin[1][3] = h == 0 ? dy[3] : 0.0f;
+                }
             } else {
                 st.hin[1][0] = h == 0 ? dy[0] : 0.0f; st.hin[1][1] = 0.0f; st.hin[1][2] = 0.0f; st.hin[1][3] = 0.0f;
             }
@@ -444,7 +466,12 @@ template <class P, int OI>
 __device__ __forceinline__ void bwd16_mask_preload(const BwdArgsChain& g, BwdState16<P>& st, int rc, int gq)
 {
     if constexpr (OI == 0) {       // ... and the rows of the action head's reverse that do not depend on the adjoint
-        if (g.rp_d_action) { st.pa = g.rp_action[rc]; st.pe = g.rp_eps[rc]; st.pg = g.rp_g_log_std[rc]; }
+        if (g.rp_d_action) {
+            st.pa = g.rp_action[rc];
+            st.pe = g.rp_eps[rc];
+            if constexpr (P::sac_head) st.pg = g.rp_ls_rows[rc];
+            else st.pg = g.rp_g_log_std[rc];
+        }
     }
     if constexpr (OI < P::n_ops) {
         bwd16_mask_load<P, OI>(g, st, rc, gq);
@@ -456,12 +483,13 @@ template <class P, int OI>
 __device__ __forceinline__ void bwd16_finalize(const BwdArgsChain& g, BwdState16<P>& st, int row, int gq, bool live)
 {
     constexpr BwdOp O = P::op(OI);
+    constexpr int m0 = Bwd16<P>::mask0(OI);     // (constexpr local: called in a runtime expression, the op table is walked at run time -- r04: the two-trunk Nav class)
 #pragma unroll
     for (int f = 0; f < O.nfin; ++f)
 #pragma unroll
         for (int a = 0; a < 2 * O.fin[f].nt; ++a) {
             f32x4& v = st.t[2 * O.fin[f].t0 + a];
-            const float4 y = st.ym[Bwd16<P>::mask0(OI) + (f == 0 ? 0 : 2 * O.fin[0].nt) + a];
+            const float4 y = st.ym[m0 + (f == 0 ? 0 : 2 * O.fin[0].nt) + a];
             v[0] = y.x > 0.0f ? v[0] : 0.0f;
             v[1] = y.y > 0.0f ? v[1] : 0.0f;
             v[2] = y.z > 0.0f ? v[2] : 0.0f;
@@ -584,7 +612,18 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
                 if (g.rp_d_action) {       // k_reparam_bwd's arithmetic; lane group 0 of a live row writes d_mean / g_log_std
                     const float4 da = g.rp_d_action[rc], a = PRE ? st.pa : g.rp_action[rc], e = PRE ? st.pe : g.rp_eps[rc];
                     dm = make_float4(da.x * (1.0f - a.x * a.x), da.y * (1.0f - a.y * a.y), da.z * (1.0f - a.z * a.z), da.w * (1.0f - a.w * a.w));
-                    if (live && gq == 0) {
+                    if constexpr (P::sac_head) {       // k_shac_head_bwd's: d_mu = dm, d_log_std (the second head's gradient) from the saved row
+                        const vf_mlp_bwd_layer& EV = g.d.layer[P::entry(P::L_val)];
+                        const float4 s = PRE ? st.pg : g.rp_ls_rows[rc];
+                        const float lo = g.rp_ls_lo, hi = g.rp_ls_hi;
+                        const float4 dl = make_float4(sac_dls(dm.x, e.x, s.x, lo, hi), sac_dls(dm.y, e.y, s.y, lo, hi),
+                                                      sac_dls(dm.z, e.z, s.z, lo, hi), sac_dls(dm.w, e.w, s.w, lo, hi));
+                        if (live && gq == 0) {
+                            *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
+                            *reinterpret_cast<float4*>(const_cast<float*>(EV.dY) + (size_t)rc * EV.ld_dy) = dl;
+                        }
+                        st.hin[1] = gq == 0 ? dl.x : gq == 1 ? dl.y : gq == 2 ? dl.z : dl.w;
+                    } else if (live && gq == 0) {
                         *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
                         float4 gl = PRE ? st.pg : g.rp_g_log_std[rc];
                         gl.x += dm.x * expf(g.rp_log_std[0]) * e.x; gl.y += dm.y * expf(g.rp_log_std[1]) * e.y;
@@ -598,7 +637,7 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
                 }
                 st.hin[0] = gq == 0 ? dm.x : gq == 1 ? dm.y : gq == 2 ? dm.z : dm.w;
             } else if constexpr (P::Net::HV == 4) {
-                st.hin[1] = dy[gq];
+                if (!(P::sac_head && g.rp_d_action)) st.hin[1] = dy[gq];      // (else: formed by the first head's branch above)
             } else {
                 st.hin[1] = gq == 0 ? dy[0] : 0.0f;
             }

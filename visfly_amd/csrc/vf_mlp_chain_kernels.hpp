@@ -202,8 +202,8 @@ bool bwd_chain_matches(const vf_mlp_bwd_desc& d)
 template <class N, bool PI, bool VF, bool IG>
 bool bwd16_ok(const vf_mlp_bwd_desc& d, int M)
 {
-    if constexpr (!(PI && !VF && IG)) return false;
     using P = BwdProg<N, PI, VF, IG>;
+    if constexpr (!(IG && ((PI && !VF) || P::sac_head))) return false;      // the classes a BPTT sweep runs per step (observation gradient)
     static const int forced = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN16"); return e ? atoi(e) : -1; }();
     if (forced == 0 || (forced < 0 && M > 16384)) return false;
     for (int l = 0; l < d.n_layers; ++l)
@@ -218,7 +218,7 @@ int bwd_chain_launch(const vf_mlp_bwd_desc& d, const float* packed, int M, hipSt
 {
     BwdArgsChain g{d, packed, M, reinterpret_cast<const float4*>(rp.d_action), reinterpret_cast<const float4*>(rp.action), rp.log_std,
                    reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.g_log_std)};
-    if constexpr (PI && !VF && IG) {
+    if constexpr (IG && ((PI && !VF) || BwdProg<N, PI, VF, IG>::sac_head)) {
         if (bwd16_ok<N, PI, VF, IG>(d, M)) {
             hipLaunchKernelGGL((k_mlp_backward_chain<BwdProg<N, PI, VF, IG>, 16>), dim3((M + 15) / 16), dim3(64), 0, st, g);
             VF_HIP(hipGetLastError());

@@ -836,8 +836,10 @@ class DroneGymEnvsBase:
         """H = eps.shape[0] closed-loop control steps -- policy forward (slots 0..H-1 of `policy`, reserved back to back), action
         head, state checkpoint on the tape, fused env step, loss / discount recurrence -- in ONE persistent launch
         (vf_bptt_rollout).  Leaves exactly what H rounds of policy.forward_act + _step_no_grad(record=True) +
-        vf_bptt_accumulate leave.  -> False when the library has no roll-out kernel for this env / network / dynamics
-        configuration (the caller then steps launch by launch)."""
+        vf_bptt_accumulate leave.  A policy with two 4-wide heads and no log_std parameter is the reference's own Actor
+        (td_policies.py:146-252): state-dependent log_std, what H rounds of policy.forward + vf_shac_head_fwd leave, the heads of
+        every step in the slots' "mean" / "value" buffers.  -> False when the library has no roll-out kernel for this env / network
+        / dynamics configuration (the caller then steps launch by launch)."""
         if (self._tape is None or self.spawn_mode != "device" or self._imu_noise is not None or self._half_step
                 or self.envs.dynamics._wind_fn is not None or getattr(self, "_HOST_OBS", False) or not self.tensor_output
                 or getattr(self, "obs_gate_exact", False)):
@@ -876,12 +878,14 @@ class DroneGymEnvsBase:
                 self._substep = th.empty((self._tape.shape[0], S + 1, (N + 15) // 16, 64, 4), dtype=th.float32, device=dev)
             sub = self._substep[t0]
         self._substep_range = None
+        two_heads = tuple(policy.head_dims) == (4, 4) and policy.log_std.numel() == 0
         with th.cuda.device(dev):
             rc = L.vf_bptt_rollout(self._h, C.byref(d), _lib.ptr(policy.flat), _lib.ptr(policy._packed), _lib.ptr(blk["obs:state"]),
-                                   _lib.ptr(o1), _lib.ptr(policy.log_std), _lib.ptr(eps), _lib.ptr(actions), C.byref(self._roll_out),
-                                   _lib.ptr(final), _lib.ptr(self._tape[t0]), self._slab.numel(), self._tape_done[t0].data_ptr(),
-                                   _lib.ptr(d_reward), _lib.ptr(loss), _lib.ptr(disc), float(gamma), float(scale), H, _lib.ptr(sub),
-                                   self._stream())
+                                   _lib.ptr(o1), None if two_heads else _lib.ptr(policy.log_std), _lib.ptr(eps), _lib.ptr(actions),
+                                   C.byref(self._roll_out), _lib.ptr(final), _lib.ptr(self._tape[t0]), self._slab.numel(),
+                                   self._tape_done[t0].data_ptr(), _lib.ptr(d_reward), _lib.ptr(loss), _lib.ptr(disc), float(gamma),
+                                   float(scale), H, _lib.ptr(sub), _lib.ptr(blk["mean"]) if two_heads else None,
+                                   _lib.ptr(blk["value"]) if two_heads else None, self._stream())
         if rc == _lib.EUNSUPPORTED:
             _lib.warn_unsupported("vf_bptt_rollout")
             return False
@@ -952,31 +956,38 @@ class DroneGymEnvsBase:
         self._observations = obs = self._full_obs(final)
         return obs
 
-    def reverse_policy(self, policy, H, eps, actions, d_reward, d_means, g_log_std):
+    def reverse_policy(self, policy, H, eps, actions, d_reward, d_means, g_log_std, d_log_stds=None):
         """the reverse half of the last H recorded steps in ONE persistent launch (vf_bptt_reverse): for t = H-1 .. 0 the adjoint of
         env step t and the policy's action-head reverse + reverse chain of slot t.  -> False when the library has no kernel for
-        this configuration (the caller then sweeps launch by launch).  d_means (H,N,4) out, g_log_std (H,N,4) zeroed in / out."""
+        this configuration (the caller then sweeps launch by launch).  d_means (H,N,4) out, g_log_std (H,N,4) zeroed in / out.
+        ``d_log_stds`` (H,N,4) out instead of g_log_std: the reference's Actor (two heads, see rollout_policy) -- both trunks are
+        swept, the head gradients of every step land in d_means / d_log_stds."""
         N, dev = self.num_agent, self.device
         t0 = self._tape_t - H
         nblk, blk = policy._slot_blocks.get(N, (0, None))
         if self._tape is None or t0 < 0 or nblk < H:
             return False
-        key = ("bwd_flat", N, H)
+        two_heads = d_log_stds is not None
+        key = ("bwd_flat", N, H, two_heads)
         cached = policy._descs.get(key)
         if cached is None:
             b = {name: t[:H].reshape(-1, t.shape[-1]) for name, t in blk.items()}
-            d, d_in = policy._bwd_desc(b, H * N, d_means.view(-1, 4), None, True)
+            d, d_in = policy._bwd_desc(b, H * N, d_means.view(-1, 4), d_log_stds.view(-1, 4) if two_heads else None, True)
             cached = policy._descs[key] = (d, d_in, th.empty((H, N, 4), dtype=th.float32, device=dev))
         d, d_in, d_action = cached
-        d.layer[0].dY = _lib.ptr(d_means)
+        im, iv = policy._head_entries(two_heads)
+        d.layer[im].dY = _lib.ptr(d_means)
+        if two_heads:
+            d.layer[iv].dY = _lib.ptr(d_log_stds)
         policy._pack()
         # the sub-step tape only if exactly these H steps were recorded by ONE persistent roll-out with the tape on
         sub = self._substep[t0] if getattr(self, "_substep_range", None) == (t0, t0 + H) else None
         with th.cuda.device(dev):
-            rc = _lib.lib().vf_bptt_reverse(self._h, C.byref(d), _lib.ptr(policy._packed), _lib.ptr(policy.log_std), _lib.ptr(eps),
-                                            _lib.ptr(actions), _lib.ptr(self._tape[t0]), self._slab.numel(), self._tape_done[t0].data_ptr(),
-                                            _lib.ptr(d_reward), _lib.ptr(self._adj), _lib.ptr(d_action), _lib.ptr(d_in["state"]),
-                                            _lib.ptr(g_log_std), H, _lib.ptr(sub), self._stream())
+            rc = _lib.lib().vf_bptt_reverse(self._h, C.byref(d), _lib.ptr(policy._packed), None if two_heads else _lib.ptr(policy.log_std),
+                                            _lib.ptr(eps), _lib.ptr(actions), _lib.ptr(self._tape[t0]), self._slab.numel(),
+                                            self._tape_done[t0].data_ptr(), _lib.ptr(d_reward), _lib.ptr(self._adj), _lib.ptr(d_action),
+                                            _lib.ptr(d_in["state"]), None if two_heads else _lib.ptr(g_log_std), H, _lib.ptr(sub),
+                                            _lib.ptr(blk["value"]) if two_heads else None, self._stream())
         if rc == _lib.EUNSUPPORTED:
             _lib.warn_unsupported("vf_bptt_reverse")
             return False

@@ -549,40 +549,54 @@ class MlpPolicy:
                                                        _ptr(eps), _ptr(g_log_std), M, self._stream()))
         return d_in
 
-    def backward_data_supported(self, M, slot=0):
-        """can ``backward_data`` (policy trunk + observation gradient) run for this network?"""
+    def backward_data_supported(self, M, slot=0, both_heads=False):
+        """can ``backward_data`` (policy trunk [+ second trunk: ``both_heads``] + observation gradient) run for this network?"""
         if self._plan is None or not self.fused_backward:
             return False
         b = self._buffers(M, slot)
-        dm = th.empty((M, 4), dtype=th.float32, device=self.device)
-        d, _ = self._bwd_desc(b, M, dm, None, True)
+        dm = th.empty((M, self.head_dims[0]), dtype=th.float32, device=self.device)
+        dv = th.empty((M, self.head_dims[1]), dtype=th.float32, device=self.device) if both_heads else None
+        d, _ = self._bwd_desc(b, M, dm, dv, True)
         return bool(_lib.lib().vf_mlp_backward_data_supported(C.byref(d)))
 
-    def backward_data(self, d_mean, slot):
-        """reverse chain of slot `slot` only (policy trunk): masked layer gradients stay in the slot's g: buffers for
-        ``weight_grad_slots``; -> {obs key: dLoss/d obs} (for reserved slots the returned tensors are reused by the next
-        call on the same slot)"""
+    def _head_entries(self, both_heads):
+        """indices of the (mean, value) head layers in the reverse layer table ``_bwd_desc`` builds (reversed layer order, a
+        trunk without head gradient skipped)"""
+        order = [ly.dst for ly in reversed(self.layers)
+                 if not ly.frozen and (both_heads or not (ly.dst == "value" or ly.dst.startswith("vf:")))]
+        return order.index("mean"), (order.index("value") if both_heads else None)
+
+    def backward_data(self, d_mean, slot, d_value=None):
+        """reverse chain of slot `slot` only (policy trunk; with ``d_value`` both trunks -- the reference's Actor, whose second
+        head is log_std): masked layer gradients stay in the slot's g: buffers for ``weight_grad_slots``; -> {obs key: dLoss/d obs}
+        (for reserved slots the returned tensors are reused by the next call on the same slot)"""
         M = d_mean.shape[0]
         b = self._buffers(M, slot)
-        cached = self._descs.get(("bwd_data", M, slot)) if b.get("_contig") else None    # reserved slots: fixed buffers
+        key = ("bwd_data", M, slot, d_value is not None)
+        cached = self._descs.get(key) if b.get("_contig") else None    # reserved slots: fixed buffers
         if cached is None:
-            d, d_in = self._bwd_desc(b, M, d_mean, None, True)
+            d, d_in = self._bwd_desc(b, M, d_mean, d_value, True)
             if b.get("_contig"):
-                self._descs[("bwd_data", M, slot)] = (d, d_in)
+                self._descs[key] = (d, d_in)
         else:
             d, d_in = cached
-            d.layer[0].dY = _ptr(d_mean)           # entry 0 = action head: its gradient is the caller's tensor
+            im, iv = self._head_entries(d_value is not None)
+            d.layer[im].dY = _ptr(d_mean)          # the heads' gradients are the caller's tensors
+            if iv is not None:
+                d.layer[iv].dY = _ptr(d_value)
         self._pack()
         _lib.check(_lib.lib().vf_mlp_backward_data(C.byref(d), _ptr(self._packed), M, self._stream()))
         return d_in
 
-    def weight_grad_slots(self, M, n, d_mean_all, accumulate=False):
-        """weight / bias gradients of the policy trunk + extractors summed over slots 0..n-1 (reserved with
-        ``reserve_slots``; d_mean_all (n, M, 4) holds the head gradients the ``backward_data`` calls were given)"""
+    def weight_grad_slots(self, M, n, d_mean_all, accumulate=False, d_value_all=None):
+        """weight / bias gradients of the policy trunk (+ the second trunk when ``d_value_all`` is given) + extractors summed over
+        slots 0..n-1 (reserved with ``reserve_slots``; d_mean_all (n, M, 4) [d_value_all (n, M, w)] hold the head gradients the
+        ``backward_data`` calls were given)"""
         nblk, blk = self._slot_blocks[M]
         assert n <= nblk and d_mean_all.shape == (n, M, 4) and d_mean_all.is_contiguous()
-        b = {name: t.view(-1, t.shape[-1]) for name, t in blk.items()}
-        d, _ = self._bwd_desc(b, n * M, d_mean_all.view(-1, 4), None, False)
+        assert d_value_all is None or (d_value_all.shape == (n, M, self.head_dims[1]) and d_value_all.is_contiguous())
+        b = {name: t[:n].reshape(-1, t.shape[-1]) for name, t in blk.items()}
+        d, _ = self._bwd_desc(b, n * M, d_mean_all.view(-1, 4), None if d_value_all is None else d_value_all.view(n * M, -1), False)
         L = _lib.lib()
         need = int(L.vf_mlp_backward_partial_floats(C.byref(d), n * M))
         if self._scratch is None or self._scratch.numel() < need:
