@@ -35,7 +35,7 @@ extern "C" {
                                  vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
                                  vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout;
                               6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse, vf_mlp_desc.identity_mask (was pad0);
-                              7: mean_rows / log_std_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes) */
+                              7: mean_rows / log_std_rows / reward_rows / ep_flag_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes) */
 
 /* clamp interval of the state-dependent log_std head of the reference's Actor (utils/policies/td_policies.py:31-32,241-243) */
 #define VF_SAC_LOG_STD_MIN (-10.0f)
@@ -758,12 +758,15 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * (what BPTT.py:113 / shac.py:219 call per step): a layer table with TWO 4-wide heads, latent_pi -> mu and log_latent_pi -> log_std,
  * action = tanh(mu + eps exp(clamp(log_std, VF_SAC_LOG_STD_MIN, VF_SAC_LOG_STD_MAX))) -- `log_std` is ignored (may be NULL) and
  *   log_std_rows  (H N, 4) out, required for (b): the second head of every step (vf_bptt_reverse's head reverse reads it)
- *   mean_rows     (H N, 4) out, optional (NULL: not kept): the first head of every step.  Both 16-byte aligned. */
+ *   mean_rows     (H N, 4) out, optional (NULL: not kept): the first head of every step.  Both 16-byte aligned.
+ * SHAC's horizon buffer (shac.py:259-266) additionally keeps, per step (both optional, NULL: not kept):
+ *   reward_rows   [H][N] the reward of every step;  ep_flag_rows [H][N] bytes = out->ep_flags of the step, written where done
+ *                 (needs out->ep_flags; shac.py:231-232 reads `episode_done` only there) */
 int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const float* obs_slots0,
                     const float* obs_slots1, const float* log_std, const float* eps, float* actions, const vf_env_out* out,
                     float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done, float* d_reward, float* loss,
                     float* disc, float gamma, float scale, int32_t H, float* substep_tape, float* mean_rows, float* log_std_rows,
-                    vf_stream_t stream);
+                    float* reward_rows, uint8_t* ep_flag_rows, vf_stream_t stream);
 
 /* ... and the reverse half (loss.backward() over the horizon, BPTT.py:127-129): for t = H-1 .. 0 the adjoint of env step t and the
  * policy's action-head reverse + reverse chain of step t, a wave owning 16 or 32 agents (the rows-per-wave choice

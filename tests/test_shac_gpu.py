@@ -170,6 +170,52 @@ def test_learn_runs_and_is_reproducible():
         assert torch.equal(x, y)
 
 
+FAST_SPAWN = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [1., 1., 1.]},
+                                                                   "velocity": {"mean": [0., 0., 0.], "half": [9., 9., 9.]}}]}}
+
+
+@pytest.mark.parametrize("N,H,steps,spawn", [(2048, 16, 20, None), (1000, 8, 5, None), (7, 6, 4, None), (3000, 12, 30, FAST_SPAWN)])
+def test_persistent_launches_equal_the_loop(N, H, steps, spawn):
+    """SHAC's horizon on vf_bptt_rollout / vf_bptt_reverse (actor class (b)) + the next-action / target-critic terms evaluated over the
+    recorded horizon, against the launch-by-launch loop: horizon buffer (observations, actions, rewards, done / episode_done, next
+    values, returns), actor loss and gradient, and actor / critic / target parameters after three iterations are bit-identical;
+    short episodes, so that agents end episodes (terminations and truncations) inside the horizon"""
+    from visfly_amd.envs import HoverEnv
+    from visfly_amd.shac import SHAC
+    from _golden import ENV_DYN
+    res = []
+    for fused in (True, False):
+        env = HoverEnv(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(ENV_DYN), device=DEV, tensor_output=True, requires_grad=True,
+                       max_episode_steps=steps, **({} if spawn is None else {"random_kwargs": spawn}))
+        algo = SHAC(env, policy_kwargs=dict(PK), horizon=H, gradient_steps=2, learning_rate=1e-3, seed=7)
+        algo.fused_rollout = algo.fused_reverse = fused
+        used = []
+        orig = env.rollout_policy
+        env.rollout_policy = lambda *a, **k: used.append(orig(*a, **k)) or used[-1]
+        out = {}
+        for it in range(3):
+            algo._update()
+            b = algo._buf
+            for k in ("action", "reward", "done", "ep_done", "next_value", "returns"):
+                out[f"{k}{it}"] = b[k].clone()
+            out[f"obs{it}"] = b["obs"]["state"].clone()
+            out[f"grad{it}"] = algo.policy.grad.clone()
+            out[f"loss{it}"] = algo._last_losses[0].clone().reshape(1)
+        out["actor"], out["critic"], out["target"] = algo.policy.flat.clone(), algo.critic.flat.clone(), algo.critic_target.flat.clone()
+        out["state"] = env.get_observation()["state"].clone()
+        assert used == ([True] * 3 if fused else []), used
+        res.append(out)
+        env.close()
+    n_done = sum(int(res[0][f"done{it}"].sum()) for it in range(3))
+    n_ep = sum(int(res[0][f"ep_done{it}"].sum()) for it in range(3))
+    print(f"done flags in the three horizons: {n_done}, of them episode_done: {n_ep}")
+    assert n_done > 0 and (spawn is None or n_ep > 0)      # fast spawns: agents leave the bounding box = episode_done
+    for k in res[0]:
+        a, b = res[0][k], res[1][k]
+        same = torch.equal(a, b) if a.dtype != torch.float32 else torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert same, f"{k} differs (max abs {float((a.float() - b.float()).abs().max()):.3e})"
+
+
 def test_default_kwargs_iterations_lower_the_critic_loss():
     """no policy_kwargs (extractor [128, 64], trunks [64, 64]): the critic targets of OUR horizon buffer are the oracle's
     TD-lambda returns bit for bit, and regressing the twin critics onto them lowers the critic loss; save / load round trip"""

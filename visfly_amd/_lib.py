@@ -224,7 +224,7 @@ SIGNATURES = {
     "vf_debug_poison_lds": (C.c_int, [_vp]),
     "vf_bptt_reverse": (C.c_int, [_vp, C.POINTER(MlpBwdDesc)] + [_vp] * 5 + [C.c_int64] + [_vp] * 6 + [C.c_int32, _vp, _vp, _vp]),
     "vf_bptt_rollout": (C.c_int, [_vp, C.POINTER(MlpDesc)] + [_vp] * 7 + [C.POINTER(EnvOut), _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
-                                  C.c_float, C.c_float, C.c_int32, _vp, _vp, _vp, _vp]),
+                                  C.c_float, C.c_float, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vf_ppo_rollout": (C.c_int, [_vp, C.POINTER(MlpDesc), _vp, _vp, C.POINTER(PpoRolloutArgs), _vp]),
     "vf_dyn_step_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vf_env_ring_phase": (C.c_int32, [_vp]),

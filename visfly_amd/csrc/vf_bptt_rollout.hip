@@ -23,7 +23,7 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
                                const float* obs_slots1, const float* log_std, const float* eps, float* actions,
                                const vf_env_out* out, float* obs_final, float* tape, int64_t tape_stride, uint8_t* tape_done,
                                float* d_reward, float* loss, float* disc, float gamma, float scale, int32_t H, float* substep_tape,
-                               float* mean_rows, float* log_std_rows, vf_stream_t stream)
+                               float* mean_rows, float* log_std_rows, float* reward_rows, uint8_t* ep_flag_rows, vf_stream_t stream)
 {
     if (!h || !desc || !params || !obs_slots0 || !eps || !actions || !out || !obs_final || !tape || !tape_done || !d_reward ||
         !loss || !disc || H <= 0)
@@ -63,7 +63,8 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     vf::ChainArgs gc{*desc, params, packed, vf::ChainIo{{obs_slots0, obs_slots1}, mean_rows, sac ? log_std_rows : nullptr}, H * N, log_std,
                      reinterpret_cast<const float4*>(eps), reinterpret_cast<float4*>(actions), {nullptr, nullptr}, VF_SAC_LOG_STD_MIN,
                      VF_SAC_LOG_STD_MAX};
-    vf::RollArgs r{H, N, tape, tape_stride, tape_done, d_reward, loss, disc, const_cast<float*>(obs_slots0), obs_final, gamma, scale, reinterpret_cast<float4*>(substep_tape)};
+    vf::RollArgs r{H, N, tape, tape_stride, tape_done, d_reward, loss, disc, const_cast<float*>(obs_slots0), obs_final, gamma, scale, reinterpret_cast<float4*>(substep_tape), reward_rows,
+                   ep_flag_rows};
     hipLaunchKernelGGL(k, dim3((N + 15) / 16), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
     VF_HIP(hipGetLastError());
     h->dyn.tick += H;

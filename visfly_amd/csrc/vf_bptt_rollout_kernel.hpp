@@ -22,6 +22,8 @@ struct RollArgs {
     float* obs_final;          // (N,13): the observation after the last step
     float gamma, scale;
     float4* ck;                // optional sub-step tape [H][S + 1][waves][64] float4 (include/visfly_amd.h, vf_bptt_rollout) or null
+    float* reward_rows;        // optional [H][N]: the reward of every step (SHAC's horizon buffer, shac.py:259-266)
+    unsigned char* ep_flag_rows;   // optional [H][N]: out->ep_flags of the step, written where done (shac.py:231-232 reads episode_done there)
 };
 
 // control_interval observer: the agent at the head of every sub-step -- (q) (v, 0) (w, 0) (rotor speeds) -- and the state after the
@@ -134,6 +136,8 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         float reward = 0.0f;
         bool done = false;
         env_epilogue<KIND, false>(c, e, g, ic, live, s, sp, wave_first, tile, &reward, &done);
+        if (r.reward_rows) r.reward_rows[(size_t)t * r.N + i] = reward;
+        if (r.ep_flag_rows && done && g.out.ep_flags) r.ep_flag_rows[(size_t)t * r.N + i] = g.out.ep_flags[ic];   // (this lane's own store above)
         // ---- loss / discount recurrence (BPTT.py:123-124; k_bptt_accumulate) ----
         r.d_reward[(size_t)t * r.N + i] = -disc * r.scale;
         loss = loss + -1.0f * reward * disc;

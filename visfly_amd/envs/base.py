@@ -832,14 +832,15 @@ class DroneGymEnvsBase:
         self._tape_t = 0
         self._record_all = True      # manual mode: every step() is recorded until clear_tape()/detach()
 
-    def rollout_policy(self, policy, obs_keys, eps, actions, d_reward, loss, disc, gamma, scale):
+    def rollout_policy(self, policy, obs_keys, eps, actions, d_reward, loss, disc, gamma, scale, reward_rows=None, ep_flag_rows=None):
         """H = eps.shape[0] closed-loop control steps -- policy forward (slots 0..H-1 of `policy`, reserved back to back), action
         head, state checkpoint on the tape, fused env step, loss / discount recurrence -- in ONE persistent launch
         (vf_bptt_rollout).  Leaves exactly what H rounds of policy.forward_act + _step_no_grad(record=True) +
         vf_bptt_accumulate leave.  A policy with two 4-wide heads and no log_std parameter is the reference's own Actor
         (td_policies.py:146-252): state-dependent log_std, what H rounds of policy.forward + vf_shac_head_fwd leave, the heads of
         every step in the slots' "mean" / "value" buffers.  -> False when the library has no roll-out kernel for this env / network
-        / dynamics configuration (the caller then steps launch by launch)."""
+        / dynamics configuration (the caller then steps launch by launch).  ``reward_rows`` (H,N) / ``ep_flag_rows`` (H,N) uint8:
+        optional per-step copies of the reward and of the episode flags (valid where done) -- SHAC's horizon buffer."""
         if (self._tape is None or self.spawn_mode != "device" or self._imu_noise is not None or self._half_step
                 or self.envs.dynamics._wind_fn is not None or getattr(self, "_HOST_OBS", False) or not self.tensor_output
                 or getattr(self, "obs_gate_exact", False)):
@@ -885,7 +886,8 @@ class DroneGymEnvsBase:
                                    C.byref(self._roll_out), _lib.ptr(final), _lib.ptr(self._tape[t0]), self._slab.numel(),
                                    self._tape_done[t0].data_ptr(), _lib.ptr(d_reward), _lib.ptr(loss), _lib.ptr(disc), float(gamma),
                                    float(scale), H, _lib.ptr(sub), _lib.ptr(blk["mean"]) if two_heads else None,
-                                   _lib.ptr(blk["value"]) if two_heads else None, self._stream())
+                                   _lib.ptr(blk["value"]) if two_heads else None, _lib.ptr(reward_rows),
+                                   None if ep_flag_rows is None else ep_flag_rows.data_ptr(), self._stream())
         if rc == _lib.EUNSUPPORTED:
             _lib.warn_unsupported("vf_bptt_rollout")
             return False

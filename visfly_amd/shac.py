@@ -82,12 +82,23 @@ class SHAC(BPTT):
 
     # ---- actor: horizon roll-out + reverse sweep ------------------------------------------------------------------------------
     def _grad_reverse_sweep(self):
-        """shac.py:215-266 forward, then the reverse sweep t = H-1 .. 0: adjoint env step -> action head -> both actor trunks
-        (parameter gradients accumulate) -> gradient w.r.t. the observation of step t, which step t-1 returned"""
+        """shac.py:215-266 forward, then the reverse sweep t = H-1 .. 0: adjoint env step -> action head -> both actor trunks ->
+        gradient w.r.t. the observation of step t, which step t-1 returned.  Like BPTT's reference-actor sweep the activations of
+        every step stay in their slot and the actor's weight gradient is reduced once over the H N rows of the horizon.  Where the
+        library has the kernels (vf_bptt_rollout / vf_bptt_reverse, actor class (b)) the closed loop policy -> env -> policy and its
+        reverse are ONE persistent launch each; the terms of the loss VALUE that are constants of the actor objective -- next action
+        and target critics on the detached next observation (:234-239) -- follow over the recorded horizon: the next observation of
+        step t IS the input of slot t + 1, so its actor heads are already there (same weights), only the last step's are computed.
+        Leaves what the launch-by-launch loop leaves, bit for bit (tests/test_shac_gpu.py)."""
         env, pol, N, H = self.env, self.policy, self.env.num_envs, self.H
         L, st, dev = _lib.lib(), _lib.current_stream(self.device), self.device
         keys = self.obs_keys
         pol.grad.zero_()
+        pol.reserve_slots(N, H)
+        if self._defer_wgrad is None:
+            self._defer_wgrad = pol.backward_data_supported(N, both_heads=True)
+        defer = self._defer_wgrad
+        blk = pol._slot_blocks[N][1]
         disc, loss_vec = th.ones(N, device=dev), th.zeros(N, device=dev)
         f = dict(dtype=th.float32, device=dev)
         u8 = dict(dtype=th.uint8, device=dev)
@@ -96,18 +107,45 @@ class SHAC(BPTT):
                              next_value=th.empty((H, N), **f))
         eps = self._eps_override if self._eps_override is not None else th.randn((2 * H, N, 4), device=dev, generator=self._gen)
         assert eps.shape == (2 * H, N, 4)
-        drews, ls_rows = th.empty((H, N), **f), []
-        nxt = th.empty((N, 4), **f)
+        eps_a = eps[0::2].contiguous()                                                 # [t] = noise of the action of step t
+        drews, ls_rows = th.empty((H, N), **f), blk["value"]
+        scale = 1.0 / (N * self.world)
         t0 = env._tape_t
-        obs = env.get_observation()
-        for t in range(H):
+        fused = False
+        if defer and self.fused_rollout:
+            flag_rows = th.empty((H, N), **u8)
+            fused = env.rollout_policy(pol, keys, eps_a, b["action"], drews, th.zeros(N, **f), th.ones(N, **f), float(self.gamma), scale,
+                                       reward_rows=b["reward"], ep_flag_rows=flag_rows)
+        if fused:
+            for k in keys:
+                b["obs"][k].copy_(blk["obs:" + k][:H])                                 # rollout_buffer.add(obs=pre_obs ...) :259
+            b["done"].copy_(env._tape_done[t0:t0 + H])
+            last = env.get_observation()
+            o_last = {k: last[k].detach().contiguous() for k in keys}
+            mu2, ls2, nxt = th.empty((H, N, 4), **f), th.empty((H, N, 4), **f), th.empty((H, N, 4), **f)
+            if H > 1:
+                mu2[:H - 1].copy_(blk["mean"][1:H])
+                ls2[:H - 1].copy_(blk["value"][1:H])
+            m, l = pol.forward(o_last, save_activations=False, slot=H)
+            mu2[H - 1].copy_(m)
+            ls2[H - 1].copy_(l)
+            self._head_fwd(mu2.view(-1, 4), ls2.view(-1, 4), eps[1::2].contiguous().view(-1, 4), nxt.view(-1, 4))
+            for t in range(H):      # target critics per step: N rows per launch, the row count (-> kernel choice) of the loop
+                o2 = {k: blk["obs:" + k][t + 1] for k in keys} if t + 1 < H else o_last
+                q0, q1 = self._q(self.critic_target, o2, nxt[t], slot=0)
+                _lib.check(L.vf_shac_accumulate(_ptr(b["reward"][t]), b["done"][t].data_ptr(), flag_rows[t].data_ptr(), _ptr(q0), _ptr(q1),
+                                                _ptr(disc), _ptr(loss_vec), _ptr(drews[t]), _ptr(b["next_value"][t]),
+                                                b["ep_done"][t].data_ptr(), float(self.gamma), scale, 1 if t == H - 1 else 0, N, st))
+        else:
+            nxt = th.empty((N, 4), **f)
+            obs = env.get_observation()
+        for t in range(0 if not fused else H, H):
             for k in keys:
                 b["obs"][k][t].copy_(obs[k].detach())                                  # rollout_buffer.add(obs=pre_obs ...) :259
             o = {k: b["obs"][k][t] for k in keys}                                      # rows that outlive the reverse sweep
             mu, ls = pol.forward(o, slot=t)                                            # actor.action_log_prob(obs) :219
-            ls_rows.append(ls)                                                         # slot t's head buffer
             action = b["action"][t]
-            self._head_fwd(mu, ls, eps[2 * t], action)
+            self._head_fwd(mu, ls, eps_a[t], action)
             obs, reward, done, _ = env._step_no_grad(action, False, record=True, borrow=True)      # :225
             # next action of the stochastic actor on the new observation, target critics on (obs', a'), all detached :234-239
             o2 = {k: obs[k].detach().contiguous() for k in keys}
@@ -118,15 +156,23 @@ class SHAC(BPTT):
             b["done"][t].copy_(done)
             _lib.check(L.vf_shac_accumulate(_ptr(reward), done.data_ptr(), env._ep_flags.data_ptr(), _ptr(q0), _ptr(q1), _ptr(disc),
                                             _ptr(loss_vec), _ptr(drews[t]), _ptr(b["next_value"][t]), b["ep_done"][t].data_ptr(),
-                                            float(self.gamma), 1.0 / (N * self.world), 1 if t == H - 1 else 0, N, st))
+                                            float(self.gamma), scale, 1 if t == H - 1 else 0, N, st))
         g_obs = None
-        d_mu, d_ls = th.empty((N, 4), **f), th.empty((N, 4), **f)
-        for t in reversed(range(H)):
+        d_mus, d_lss = th.empty((H, N, 4), **f), th.empty((H, N, 4), **f)
+        rev = False
+        if fused and self.fused_reverse:
+            rev = env.reverse_policy(pol, H, eps_a, b["action"], drews, d_mus, None, d_log_stds=d_lss)
+        for t in reversed(range(0 if not rev else H, H)):
             d_action = env.backward_step(t0 + t, g_obs, drews[t])
-            _lib.check(L.vf_shac_head_bwd(_ptr(d_action), _ptr(b["action"][t]), _ptr(ls_rows[t]), _ptr(eps[2 * t]), _ptr(d_mu),
-                                          _ptr(d_ls), N, LOG_STD_MIN, LOG_STD_MAX, st))
-            d_in = pol.backward(d_mu, d_ls, None, accumulate=True, need_input_grad=t > 0, slot=t)
+            _lib.check(L.vf_shac_head_bwd(_ptr(d_action), _ptr(b["action"][t]), _ptr(ls_rows[t]), _ptr(eps_a[t]), _ptr(d_mus[t]),
+                                          _ptr(d_lss[t]), N, LOG_STD_MIN, LOG_STD_MAX, st))
+            if defer:
+                d_in = pol.backward_data(d_mus[t], t, d_value=d_lss[t])
+            else:
+                d_in = pol.backward(d_mus[t], d_lss[t], None, accumulate=True, need_input_grad=t > 0, slot=t)
             g_obs = d_in.get("state") if t > 0 else None
+        if defer:
+            pol.weight_grad_slots(N, H, d_mus, accumulate=True, d_value_all=d_lss)
         return loss_vec.mean() / self.world
 
     # ---- one iteration ------------------------------------------------------------------------------------------------------
