@@ -273,6 +273,27 @@ def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
         out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "racing", 16384, seconds_target=3.0,
                                                note="forward env.step only (no adjoint on the CPU side)")
     env.close()
+    # the same loop with the reference's own actor (utils/policies/td_policies.py:146-252, what BPTT.py:113 calls: two trunks, state-dependent
+    # clamped log_std head) instead of the MlpPolicy actor above (one trunk, log_std parameter): 2 x the policy MFMA work per agent-step
+    env = RacingEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dkw, device=dev, max_episode_steps=256,
+                    requires_grad=True, tensor_output=True)
+    algo = BPTT(env, policy="MultiInputPolicy", horizon=64, gamma=0.99, learning_rate=1e-3, seed=0)
+    algo.learn(64 * N * world)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    els = []
+    for _ in range(3 if iters < 16 else 1):
+        t0 = time.perf_counter()
+        algo.learn(64 * N * world * iters)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        els.append(parallel.max_over_ranks(time.perf_counter() - t0, dev))
+    el2 = sorted(els)[len(els) // 2]
+    w_a = algo.policy.n_params
+    out["reference_actor"] = {"value": 64 * N * world * iters / el2, "unit": "agent-steps/s", "s_per_iteration": el2 / iters,
+                              "policy": "td_policies.Actor (MultiInputPolicy): extractor [128, 64], latent_pi / log_latent_pi [64, 64], mu / log_std heads",
+                              "mfma_frac": 6.0 * w_a * 64 * N * iters / el2 / 1e12 / 157.3, "actor_params": int(w_a)}
+    env.close()
     return out
 
 
