@@ -301,17 +301,22 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, 
     }
 }
 
-// waves per layer proportional to its MFMA count per row pair; -> total waves, partial floats
-// two waves per SIMD?  Only when no layer needs more than 8 accumulator tiles (k_mlp_wgrad<true>); VISFLY_AMD_WGRAD_WPS=1/2 forces it (A/B)
-bool wgrad_small(const vf_mlp_bwd_desc& d)
+// two waves per SIMD (k_mlp_wgrad<true>: no layer needs more than 8 accumulator tiles)?  At row counts whose operands fit the 256 MiB
+// Infinity Cache (the PPO minibatch: 25 600 rows x 5.7 KB) the launch is bound by MFMA issue + load latency and a second wave per SIMD
+// only doubles the partials (slower: profiles/r04_ppo_wgrad.txt).  Past it -- SHAC's critic over the 524 288 rows of the horizon buffer,
+// 2 GB of X / dZ per launch -- a lone wave per SIMD keeps too few bytes in flight (2.9 TB/s); two waves: 0.70 -> 0.41 ms
+// (profiles/r04_shac.txt).  VISFLY_AMD_WGRAD_WPS=1/2 forces the choice (A/B).
+constexpr int kWgradStreamRows = 131072;
+bool wgrad_small(const vf_mlp_bwd_desc& d, int M)
 {
     static const int forced = [] { const char* e = getenv("VISFLY_AMD_WGRAD_WPS"); return e ? atoi(e) : 0; }();
-    if (forced != 2) return false;       // measured slower (profiles/r04_ppo_wgrad.txt): off unless asked for
+    if (forced == 1 || (forced != 2 && M < kWgradStreamRows)) return false;
     for (int l = 0; l < d.n_layers; ++l)
         if (((d.layer[l].No + 31) >> 5) * ((d.layer[l].K + 31) >> 5) > 8) return false;
     return true;
 }
 
+// waves per layer proportional to its MFMA count per row pair; -> total waves, partial floats
 int64_t wgrad_plan(const vf_mlp_bwd_desc& d, int M, WgradTable& t, int* total_waves)
 {
     int tiles[VF_MLP_MAX_LAYERS], sum = 0;
@@ -319,7 +324,7 @@ int64_t wgrad_plan(const vf_mlp_bwd_desc& d, int M, WgradTable& t, int* total_wa
         tiles[l] = ((d.layer[l].No + 31) >> 5) * ((d.layer[l].K + 31) >> 5) + 2;   // + per-row-pair overhead (loads, guards) in MFMA units
         sum += tiles[l];
     }
-    const int budget = wgrad_small(d) ? 2048 : 1024;   // waves per SIMD x 1024 SIMDs
+    const int budget = wgrad_small(d, M) ? 2048 : 1024;   // waves per SIMD x 1024 SIMDs
     t.n_layers = d.n_layers;
     int w = 0;
     int64_t off = 0;
@@ -361,7 +366,7 @@ int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int
     WgradTable t;
     int waves = 0;
     wgrad_plan(*d, M, t, &waves);
-    if (wgrad_small(*d)) hipLaunchKernelGGL(k_mlp_wgrad<true>, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
+    if (wgrad_small(*d, M)) hipLaunchKernelGGL(k_mlp_wgrad<true>, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
     else hipLaunchKernelGGL(k_mlp_wgrad<false>, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
     const int nb = mlp_wgrad_fold_blocks(d);
     const vf_stats_fold ls = loss_stats ? *loss_stats : vf_stats_fold{};
