@@ -68,7 +68,9 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         if constexpr (ROWS == 16) bwd16_mask_preload<P, 0>(gb, st16, row, lane >> 4);
         if constexpr (CKPT) {
             if (t > 0) fetch_record(t - 1);
-            env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64, true>(*cp, *ep, g, i, true, lds + lane, lds4 + (size_t)(t & 1) * rows_ck * 64);
+            // four lanes per agent: the quads (lanes 4 m .. 4 m + 3) hold the agent the chain below keeps in lanes m, m + 16, m + 32, m + 48
+            const int iq = min((int)blockIdx.x * ROWS + (lane >> 2), r.N - 1);
+            env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64, true, true>(*cp, *ep, g, iq, true, lds + lane, lds4 + (size_t)(t & 1) * rows_ck * 64);
         } else {
             env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64>(*cp, *ep, g, i, true, lds + lane);
         }

@@ -2,6 +2,7 @@
 // (vf_env_bwd.hip) and the persistent reverse sweep of vf_bptt_reverse.hip.
 #pragma once
 #include "vf_env_device.hpp"
+#include "vf_env_bwd_quad.hpp"
 #include "vf_handles.hpp"
 
 #pragma clang fp contract(off)
@@ -92,10 +93,15 @@ __device__ __forceinline__ void derivs_bwd(const vf_dyn_cfg& c, const Quat& q, c
 // -- sub-step rows: (q) (v, 0) (w, 0) (rotor speeds); end row: (p, 0) (q) (v, 0) (w, 0).  The replay of the interval -- a third of
 // this function's instruction stream -- is skipped.  Same values as the replay computes (it runs the forward kernels' own
 // sub-step functions), so the adjoint is bit-identical either way.  16 agents per wave (lane & 15 = agent slot).
-template <int KIND, int ACT, int INTEG, bool CTRL_DELAY, int STRIDE, bool CKPT = false>
+//
+// QUAD (with CKPT): four lanes per agent -- the wave's 16 agents sit in QUADS (lanes 4 m .. 4 m + 3 = agent slot m; the caller passes the
+// same `i` to the four lanes of a quad) and the sub-step loop, two thirds of this function, runs in component layout
+// (vf_env_bwd_quad.hpp).  Everything outside the loop is per agent, not per component, and stays replicated.  Bit-identical.
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY, int STRIDE, bool CKPT = false, bool QUAD = false>
 __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf_env_cfg& e, const BwdArgs& g, int i, bool live, float* lds_col,
                                                    const float4* rec = nullptr)
 {
+    static_assert(!QUAD || CKPT, "the component layout reads the sub-step tape");
     float* T = const_cast<float*>(g.tape);
     Agent s;
     Spares sp;
@@ -142,15 +148,23 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
 #pragma unroll
         for (int k = 0; k < 4; ++k) Traw[k] = c.m * (a[k] * c.acc_half + c.acc_mean);
     }
+    const int qk = threadIdx.x & 3;
+    // QUAD: rotor qk's clamp / set-point only (one sqrt per lane instead of four)
+    const float Traw_c = q_sel4(qk, Traw[0], Traw[1], Traw[2], Traw[3]);
+    const float Td_c = clampf(Traw_c, c.T_min, c.T_max);
+    const float disc_c = c.rot_tm1sq - c.rot_4tm0 * (c.tm2 - Td_c);
+    const float wd_c = c.rot_scale * (c.rot_neg_tm1 + sqrtf(disc_c));
+    if constexpr (!QUAD) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        Td[k] = clampf(Traw[k], c.T_min, c.T_max);
-        disc[k] = c.rot_tm1sq - c.rot_4tm0 * (c.tm2 - Td[k]);
-        wd[k] = c.rot_scale * (c.rot_neg_tm1 + sqrtf(disc[k]));
+        for (int k = 0; k < 4; ++k) {
+            Td[k] = clampf(Traw[k], c.T_min, c.T_max);
+            disc[k] = c.rot_tm1sq - c.rot_4tm0 * (c.tm2 - Td[k]);
+            wd[k] = c.rot_scale * (c.rot_neg_tm1 + sqrtf(disc[k]));
+        }
     }
     const float dt = c.dt;
     const int S = c.interval_steps;
-    const int mslot = threadIdx.x & 15;
+    const int mslot = QUAD ? (threadIdx.x >> 2) & 15 : threadIdx.x & 15;
     if constexpr (CKPT) {
         const float4 ep = rec[S * 64 + mslot], eq = rec[S * 64 + 16 + mslot], ev = rec[S * 64 + 32 + mslot], ew = rec[S * 64 + 48 + mslot];
         s.p[0] = ep.x; s.p[1] = ep.y; s.p[2] = ep.z;
@@ -327,6 +341,30 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     float lwd[4] = {0, 0, 0, 0}, lTd[4] = {0, 0, 0, 0};
     float ldw_in[3] = {laa[0], laa[1], laa[2]};  // aa state = dw of the LAST sub-step
     const float inv_m = 1.0f / c.m;              // acc = rotate(q, u) / m: its adjoint multiplies by 1 / m (one division per step, see above)
+    float lTraw_q = 0.0f;                        // QUAD: rotor qk's component of lTraw
+    if constexpr (QUAD) {
+        const QuadLane QL = quad_lane(c, threadIdx.x);
+        QuadAdj qa{q_sel4(qk, lq.w, lq.x, lq.y, lq.z), q_sel3(qk, lv), q_sel3(qk, lw), q_sel3(qk, lp),
+                   q_sel4(qk, lwm[0], lwm[1], lwm[2], lwm[3]), 0.0f, 0.0f, q_sel3(qk, ldw_in)};
+        const float kl_c = q_sel3(qk, kl), kq_c = q_sel3(qk, kq);
+        // this lane's component of the sub-step records: entries (q) (v, 0) (w, 0) (rotor speeds) of agent slot mslot; the vectors'
+        // component qk - 1 (lane 0 reads the stored 0)
+        const float* rf = reinterpret_cast<const float*>(rec);
+        const int oq = (0 * 16 + mslot) * 4 + qk, ov = (1 * 16 + mslot) * 4 + ((qk + 3) & 3), ow = (2 * 16 + mslot) * 4 + ((qk + 3) & 3),
+                  om = (3 * 16 + mslot) * 4 + qk;
+        for (int sub = S - 1; sub >= 0; --sub) {
+            const float* r = rf + sub * 256;
+            substep_bwd_c<INTEG, CTRL_DELAY>(c, QL, r[oq], r[ov], r[ow], r[om], kl_c, kq_c, wd_c, Td_c, dt, inv_m, qa);
+        }
+        lq = Quat{qb<0>(qa.lq), qb<1>(qa.lq), qb<2>(qa.lq), qb<3>(qa.lq)};
+        lv[0] = qb<1>(qa.lv); lv[1] = qb<2>(qa.lv); lv[2] = qb<3>(qa.lv);
+        lw[0] = qb<1>(qa.lw); lw[1] = qb<2>(qa.lw); lw[2] = qb<3>(qa.lw);
+        lwm[0] = qb<0>(qa.lwm); lwm[1] = qb<1>(qa.lwm); lwm[2] = qb<2>(qa.lwm); lwm[3] = qb<3>(qa.lwm);
+        float lTd_c = qa.lTd;
+        if (CTRL_DELAY) lTd_c += qa.lwd / sqrtf(disc_c);
+        lTraw_q = lTd_c * in_closed(Traw_c, c.T_min, c.T_max);
+    }
+    if constexpr (!QUAD)
     for (int sub = S - 1; sub >= 0; --sub) {
         Quat q;
         float v[3], w[3], wm0[4];
@@ -471,10 +509,14 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     }
     // ---- rotor set-point, clamp, controller, de-normalisation ----
     float lTraw[4];
+    if constexpr (QUAD) {
+        lTraw[0] = qb<0>(lTraw_q); lTraw[1] = qb<1>(lTraw_q); lTraw[2] = qb<2>(lTraw_q); lTraw[3] = qb<3>(lTraw_q);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (CTRL_DELAY) lTd[k] += lwd[k] / sqrtf(disc[k]);  // d wd / d Td = 1 / sqrt(tm1^2 - 4 tm0 (tm2 - Td))
-        lTraw[k] = lTd[k] * in_closed(Traw[k], c.T_min, c.T_max);
+        for (int k = 0; k < 4; ++k) {
+            if (CTRL_DELAY) lTd[k] += lwd[k] / sqrtf(disc[k]);  // d wd / d Td = 1 / sqrt(tm1^2 - 4 tm0 (tm2 - Td))
+            lTraw[k] = lTd[k] * in_closed(Traw[k], c.T_min, c.T_max);
+        }
     }
     float la[4];
     if constexpr (ACT == VF_ACT_BODYRATE) {
