@@ -747,12 +747,16 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * VF_EUNSUPPORTED unless: policy-only network of the register-chained classes, Hover / Racing / Navigation env with the
  * raw-state observation, thrust / bodyrate actions, Euler or (repaired, utils/maths.py:353-386) RK4, ctrl_delay, constant wind;
  * per-agent drag randomisation (dynamics.py:244-267) is carried in the slab's drag granules.
- *   substep_tape  optional (NULL: off), [H][S + 1][W][64] float4 with S = interval_steps and W = ceil(N / 16) waves: for every
- *                 (step, wave of 16 agents) S + 1 rows of 1 KiB, entry k of agent slot m at float4 [k * 16 + m] of a row -- rows
+ *   substep_tape  optional (NULL: off), [H][S + 3][W][64] float4 with S = interval_steps and W = ceil(N / 16) waves: for every
+ *                 (step, wave of 16 agents) S + 3 rows of 1 KiB, entry k of agent slot m at float4 [k * 16 + m] of a row -- rows
  *                 0 .. S-1 the state at the head of each integrator sub-step: (q) (v, 0) (w, 0) (rotor speeds); row S the state
- *                 after the last one before the clamps: (p, 0) (q) (v, 0) (w, 0).  What autograd's tape keeps of
- *                 dynamics.py:335-382; handed to vf_bptt_reverse, whose adjoint of the interval then reads it (LDS-DMA, one step
- *                 ahead) instead of replaying the S sub-steps (a third of its instruction stream).  16-byte aligned.
+ *                 after the last one before the clamps: (p, 0) (q) (v, 0) (w, 0); row S + 1 the step's other inputs and its
+ *                 outcome: (body rates, ring-head bits) (angular acceleration, step-counter bits) (the action the interval
+ *                 consumed) (done, d_reward, pre-step gate bits, 0); row S + 2, entries 0 / 1: the agent's drag granules (drag
+ *                 randomisation only).  What autograd's tape keeps of dynamics.py:335-382; handed to vf_bptt_reverse, whose
+ *                 adjoint then reads it (LDS-DMA, one step ahead) instead of replaying the S sub-steps (a third of its
+ *                 instruction stream) and instead of the tape slab / done / d_reward rows (HBM-cold by then: two dependent
+ *                 round trips at the head of every step).  16-byte aligned.
  * Actor classes: (a) the policy trunk of an actor-critic layer table with the state-independent `log_std` (4,) parameter
  * (policies.py:18-49; action = tanh(mean + exp(log_std) eps)); (b) the reference's own actor, utils/policies/td_policies.py:146-252
  * (what BPTT.py:113 / shac.py:219 call per step): a layer table with TWO 4-wide heads, latent_pi -> mu and log_latent_pi -> log_std,

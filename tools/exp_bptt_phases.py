@@ -4,10 +4,13 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if len(sys.argv) > 2:            # another build of the library (e.g. -DVF_PPO_TRACE: python -c "from visfly_amd import _build; _build.build(force=True, extra_flags=['-DVF_PPO_TRACE'], out='/path/x.so')")
+    from visfly_amd import _build, _lib
+    _build.LIB = _lib.LIB = sys.argv[2]
 from visfly_amd.bptt import BPTT
 from visfly_amd.envs import RacingEnv
 N, H = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, 64
-dkw = dict(action_type="thrust", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
+dkw = dict(action_type="thrust", integrator=os.environ.get("VF_EXP_INTEG", "euler"), dt=float(os.environ.get("VF_EXP_DT", "0.0025")), ctrl_dt=0.02, ctrl_delay=True)   # VF_EXP_DT=0.005 / 0.01: 4 / 2 sub-steps per interval
 
 
 def timed(fn, acc, key):

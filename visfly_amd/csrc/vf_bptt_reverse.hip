@@ -60,7 +60,7 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
                         VF_SAC_LOG_STD_MIN, VF_SAC_LOG_STD_MAX};
     vf::RevArgs r{H, N, h->dyn.G, h->dyn.g_drag, h->g_race, tape, tape_stride, reinterpret_cast<const float4*>(actions), tape_done, d_reward,
                   adj_slab, reinterpret_cast<float4*>(d_action), g_obs, reinterpret_cast<const float4*>(substep_tape)};
-    const size_t lds = ckpt ? (size_t)2 * (S + 1) * 64 * sizeof(float4) : (size_t)S * vf::kSave * 64 * sizeof(float);
+    const size_t lds = ckpt ? (size_t)2 * (S + 3) * 64 * sizeof(float4) : (size_t)S * vf::kSave * 64 * sizeof(float);
     const int rows = r16 ? 16 : 32;
     hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, gb, r);
     VF_HIP(hipGetLastError());

@@ -23,7 +23,7 @@ struct RevArgs {
     float* adj;                    // adjoint of the persistent state (slab layout), in / out
     float4* d_action;              // [H][N] scratch: dLoss / d action_t, read by the head reverse of step t
     const float* g_obs;            // [H][N][13]: row t N + i = dLoss / d (observation of slot t), written by the reverse chain
-    const float4* ck;              // the forward launch's sub-step tape [H][S + 1][waves of 16 agents][64] float4 (CKPT instances), else null
+    const float4* ck;              // the forward launch's sub-step tape [H][S + 3][waves of 16 agents][64] float4 (CKPT instances), else null
 };
 
 template <class P, int ROWS, int KIND, int ACT, int INTEG, bool CTRL_DELAY, bool CKPT>
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
     // step AHEAD of its use, into the half of the LDS area the current step does not read: issued at the head of step t + 1, it has
     // ~28 us to arrive from HBM (the tape was written a forward sweep ago) and nothing ever waits for it -- fetched by the step
     // that needs it, it cost as much latency as the replay it replaces (r04: reverse half 28.4 -> 28.6 us per step)
-    const int rows_ck = cp->interval_steps + 1;
+    const int rows_ck = cp->interval_steps + 3;      // S sub-step heads, the pre-clamp end state, the step's inputs, its drag granules
     float4* lds4 = reinterpret_cast<float4*>(lds);
     auto fetch_record = [&](int t) {
         const float4* src = r.ck + ((size_t)t * rows_ck * gridDim.x + blockIdx.x) * 64 + lane;

@@ -21,7 +21,7 @@ struct RollArgs {
     float* obs_slots;          // [H][N][13]: slot t = the observation the policy sees at step t (slot 0 filled by the caller)
     float* obs_final;          // (N,13): the observation after the last step
     float gamma, scale;
-    float4* ck;                // optional sub-step tape [H][S + 1][waves][64] float4 (include/visfly_amd.h, vf_bptt_rollout) or null
+    float4* ck;                // optional sub-step tape [H][S + 3][waves][64] float4 (include/visfly_amd.h, vf_bptt_rollout) or null
     float* reward_rows;        // optional [H][N]: the reward of every step (SHAC's horizon buffer, shac.py:259-266)
     unsigned char* ep_flag_rows;   // optional [H][N]: out->ep_flags of the step, written where done (shac.py:231-232 reads episode_done there)
 };
@@ -55,6 +55,24 @@ struct TapeCheckpoint {
         if (p)
             p[(size_t)S * rs] = pick(make_float4(s.p[0], s.p[1], s.p[2], 0.0f), make_float4(s.q.w, s.q.x, s.q.y, s.q.z),
                                      make_float4(s.v[0], s.v[1], s.v[2], 0.0f), make_float4(s.w[0], s.w[1], s.w[2], 0.0f));
+    }
+    // row S + 1 -- what else the adjoint of the step reads of the step's INPUTS, so that it never touches the (HBM-cold) tape slab:
+    // (body rates, ring head bits) (angular acceleration, step-counter bits) (the action the interval consumed) before the
+    // interval, by lane groups 0..2; (done, d_reward, pre-step gate bits, 0) after the epilogue, by lane group 3
+    __device__ __forceinline__ void inputs(const Agent& s, float head_bits, float counter_bits, const float* a) const
+    {
+        if (p && k < 3)
+            p[(size_t)(S + 1) * rs] = pick(make_float4(s.w[0], s.w[1], s.w[2], head_bits), make_float4(s.aa[0], s.aa[1], s.aa[2], counter_bits),
+                                           make_float4(a[0], a[1], a[2], a[3]), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    }
+    __device__ __forceinline__ void outcome(bool done, float d_reward, float gate_bits) const
+    {
+        if (p && k == 3) p[(size_t)(S + 1) * rs] = make_float4(done ? 1.0f : 0.0f, d_reward, gate_bits, 0.0f);
+    }
+    // row S + 2, entries 0 / 1: the agent's two drag granules (per-agent drag randomisation only)
+    __device__ __forceinline__ void drag(const float* S_, int G, int i, int g_drag) const
+    {
+        if (p && g_drag >= 0 && k < 2) p[(size_t)(S + 2) * rs] = *granule(const_cast<float*>(S_), G, i, g_drag + k);
     }
 };
 
@@ -120,6 +138,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         for (int q = VF_G_FIXED; q < Gx; ++q) *granule(T, Gx, ic, q) = *granule(g.d.S, Gx, ic, q);
         // ---- env step (k_env_rollout's body) ----
         float a[4], head_bits = 0.0f;
+        const float head_pre = sp.vel, counter_pre = sp.omg;
         ring_exchange(c, g.d, ic, live, head_bits, a);
         if (c.delay_steps > 0) sp.vel = head_bits;
         float kl[3], kq[3];
@@ -127,15 +146,20 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         // the noise row of the NEXT step's action head (drawn before the launch: HBM-cold) is touched here, under the dynamics
         // interval; the head's own load at the end of the next forward then finds it in the cache instead of waiting for HBM
         const float4 eps_touch = gc.rp_eps[(size_t)(t + 1 < r.H ? t + 1 : t) * r.N + i];
-        // sub-step tape of this (step, wave): [H][S + 1 rows][waves][64] float4 (wave-uniform pointer test: no divergence)
+        // sub-step tape of this (step, wave): [H][S + 3 rows][waves][64] float4 (wave-uniform pointer test: no divergence)
         const size_t ck_rs = (size_t)gridDim.x * 64;
-        const TapeCheckpoint ck{r.ck ? r.ck + ((size_t)t * (c.interval_steps + 1) * gridDim.x + blockIdx.x) * 64 + lane : nullptr, ck_rs,
+        const TapeCheckpoint ck{r.ck ? r.ck + ((size_t)t * (c.interval_steps + 3) * gridDim.x + blockIdx.x) * 64 + lane : nullptr, ck_rs,
                                 c.interval_steps, lane >> 4};
+        ck.inputs(s, head_pre, counter_pre, a);
+        ck.drag(g.d.S, Gx, ic, g.d.g_drag);
+        float gate_pre = 0.0f;
+        if constexpr (KIND == VF_ENV_RACING) gate_pre = granule(g.d.S, Gx, ic, g.g_race)->x;
         control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0, ck);
         asm volatile("" :: "v"(eps_touch.x), "v"(eps_touch.y), "v"(eps_touch.z), "v"(eps_touch.w));
         float reward = 0.0f;
         bool done = false;
         env_epilogue<KIND, false>(c, e, g, ic, live, s, sp, wave_first, tile, &reward, &done);
+        ck.outcome(done, -disc * r.scale, gate_pre);
         if (r.reward_rows) r.reward_rows[(size_t)t * r.N + i] = reward;
         if (r.ep_flag_rows && done && g.out.ep_flags) r.ep_flag_rows[(size_t)t * r.N + i] = g.out.ep_flags[ic];   // (this lane's own store above)
         // ---- loss / discount recurrence (BPTT.py:123-124; k_bptt_accumulate) ----

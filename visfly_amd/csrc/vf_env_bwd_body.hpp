@@ -105,11 +105,37 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     float* T = const_cast<float*>(g.tape);
     Agent s;
     Spares sp;
-    load_agent(T, g.G, i, s, sp);
-    // ---- the action this step consumed (oldest ring slot) and the head it used ----
+    const int rec_slot = QUAD ? (threadIdx.x >> 2) & 15 : threadIdx.x & 15;
+    // ---- the step's inputs: pre-step body rates / angular acceleration / counters, the action this step consumed (oldest ring slot)
+    // and the head it used, done / d_reward, drag coefficients.  CKPT: from rows S + 1, S + 2 of the record (k_bptt_rollout's
+    // TapeCheckpoint::inputs / outcome / drag) -- in LDS since the previous step; else from the tape slab and the per-step rows
     int head = 0;
     float a[4];
-    {
+    float kl[3], kq[3];
+    bool done_in;
+    float dr_in = 0.0f, gate_bits = 0.0f;
+    if constexpr (CKPT) {
+        const float4* rin = rec + (c.interval_steps + 1) * 64;
+        const float4 e0 = rin[rec_slot], e1 = rin[16 + rec_slot], e2 = rin[32 + rec_slot], e3 = rin[48 + rec_slot];
+        s.w[0] = e0.x; s.w[1] = e0.y; s.w[2] = e0.z; sp.vel = e0.w;
+        s.aa[0] = e1.x; s.aa[1] = e1.y; s.aa[2] = e1.z; sp.omg = e1.w;
+        a[0] = e2.x; a[1] = e2.y; a[2] = e2.z; a[3] = e2.w;
+        done_in = e3.x != 0.0f;
+        dr_in = e3.y;
+        gate_bits = e3.z;
+        if (c.delay_steps > 0) {
+            head = __float_as_int(sp.vel);
+            head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
+        }
+        if (g.g_drag >= 0) {
+            const float4 x = rin[64 + rec_slot], y = rin[64 + 16 + rec_slot];
+            kl[0] = x.y; kl[1] = x.z; kl[2] = x.w; kq[0] = y.y; kq[1] = y.z; kq[2] = y.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
+        }
+    } else {
+        load_agent(T, g.G, i, s, sp);
         float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) an = g.action[i];
         if (c.delay_steps > 0) {
@@ -118,14 +144,18 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
             an = *granule(T, g.G, i, VF_G_RING + head);
         }
         a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
-    }
-    float kl[3], kq[3];
-    if (g.g_drag >= 0) {
-        const float4 x = *granule(T, g.G, i, g.g_drag), y = *granule(T, g.G, i, g.g_drag + 1);
-        kl[0] = x.y; kl[1] = x.z; kl[2] = x.w; kq[0] = y.y; kq[1] = y.z; kq[2] = y.w;
-    } else {
+        if (g.g_drag >= 0) {
+            const float4 x = *granule(T, g.G, i, g.g_drag), y = *granule(T, g.G, i, g.g_drag + 1);
+            kl[0] = x.y; kl[1] = x.z; kl[2] = x.w; kq[0] = y.y; kq[1] = y.z; kq[2] = y.w;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
+            for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
+        }
+        done_in = live && g.done != nullptr && g.done[i] != 0;
+        if (live && g.d_reward) dr_in = g.d_reward[i];
+        if constexpr (KIND == VF_ENV_RACING) {
+            if (live) gate_bits = granule(T, g.G, i, g.g_race)->x;
+        }
     }
     const float w0[3] = {s.w[0], s.w[1], s.w[2]}, al0[3] = {s.aa[0], s.aa[1], s.aa[2]};
 
@@ -164,7 +194,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     }
     const float dt = c.dt;
     const int S = c.interval_steps;
-    const int mslot = QUAD ? (threadIdx.x >> 2) & 15 : threadIdx.x & 15;
+    const int mslot = rec_slot;
     if constexpr (CKPT) {
         const float4 ep = rec[S * 64 + mslot], eq = rec[S * 64 + 16 + mslot], ev = rec[S * 64 + 32 + mslot], ew = rec[S * 64 + 48 + mslot];
         s.p[0] = ep.x; s.p[1] = ep.y; s.p[2] = ep.z;
@@ -206,7 +236,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     for (int k = 0; k < 3; ++k) { s.v[k] = clampf(s.v[k], -c.vel_lim, c.vel_lim); s.w[k] = clampf(s.w[k], -c.omg_lim, c.omg_lim); }
 
     // ---- incoming adjoints of the post-step state (zero for agents reset at the end of this step) ----
-    const bool cut = live ? (g.done != nullptr && g.done[i] != 0) : true;
+    const bool cut = live ? done_in : true;
     float lp[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lw[3] = {0, 0, 0}, lwm[4] = {0, 0, 0, 0}, laa[3] = {0, 0, 0};
     Quat lq{0, 0, 0, 0};
     if (!cut) {
@@ -233,7 +263,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
         // velocity, angular velocity and -- through collision_vector = collision_point.detach() - position
         // (droneEnv.py:345-366) -- the distance / direction to the closest bbox face; success and the step counter are
         // constants.  clamp / clamp_max / clamp_min pass the gradient on the closed side, relu'(0) = 0, norm'(0) = 0.
-        const float dr = g.d_reward[i];
+        const float dr = dr_in;
         const float vv[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};
         const Collision col = bbox_collision(e, s.p);
         const bool success = norm3(s.p[0] - e.target[0], s.p[1] - e.target[1], s.p[2] - e.target[2]) <= e.success_radius;
@@ -303,11 +333,10 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
 #pragma unroll
         for (int k = 0; k < 3; ++k) lp[k] -= ltp[k] + lcv[k];     // tp = target - p,  cv = const - p
     } else if (live && g.d_reward) {
-        const float dr = g.d_reward[i];
+        const float dr = dr_in;
         const float* tgt = e.target;
         if constexpr (KIND == VF_ENV_RACING) {
-            const float4 race = *granule(T, g.G, i, g.g_race);
-            int gate = __float_as_int(race.x);
+            int gate = __float_as_int(gate_bits);
             gate = (unsigned)gate < (unsigned)e.n_gates ? gate : 0;
             const float* gt = e.gates[gate];
             const bool pass = norm3(s.p[0] - gt[0], s.p[1] - gt[1], s.p[2] - gt[2]) <= e.success_radius;

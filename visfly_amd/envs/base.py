@@ -871,12 +871,12 @@ class DroneGymEnvsBase:
         final = th.empty((N, 13), dtype=th.float32, device=dev)
         L = _lib.lib()
         # sub-step tape (include/visfly_amd.h, vf_bptt_rollout): what the reverse launch reads instead of replaying every interval;
-        # one (S + 1 rows, waves of 16 agents, 64) float4 record block per tape row, allocated with the first persistent roll-out
+        # one (S + 3 rows, waves of 16 agents, 64) float4 record block per tape row, allocated with the first persistent roll-out
         sub = None
         if self.substep_tape:
             if getattr(self, "_substep", None) is None:
                 S = int(self.envs.dynamics.constants["interval_steps"])
-                self._substep = th.empty((self._tape.shape[0], S + 1, (N + 15) // 16, 64, 4), dtype=th.float32, device=dev)
+                self._substep = th.empty((self._tape.shape[0], S + 3, (N + 15) // 16, 64, 4), dtype=th.float32, device=dev)
             sub = self._substep[t0]
         self._substep_range = None
         two_heads = tuple(policy.head_dims) == (4, 4) and policy.log_std.numel() == 0
