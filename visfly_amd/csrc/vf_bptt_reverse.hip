@@ -44,7 +44,8 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
                                        : "vf_bptt_reverse: log_std / g_log_std are required for the state-independent-log_std classes");
     // the tape is read only by the 16-agents-per-wave sweep (its records are the forward launch's waves); with 32 agents per wave
     // (N > 16 384 per launch) the interval is replayed -- same results to the bit
-    const bool ckpt = substep_tape != nullptr && r16;
+    // ... and with at most kRingRegs delay-ring slots (the sweep keeps the ring's adjoints in registers)
+    const bool ckpt = substep_tape != nullptr && r16 && h->dyn.cfg.delay_steps <= vf::kRingRegs;
     if (reinterpret_cast<uintptr_t>(substep_tape) & 15) return vf::fail(VF_EINVAL, "vf_bptt_reverse: substep_tape must be 16-byte aligned");
     vf::RevKernel k = nullptr;
     if (sac) k = r16 ? vf::pick_rev_sac(net, h->cfg.kind, h->dyn.cfg, ckpt) : nullptr;
@@ -60,7 +61,7 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
                         VF_SAC_LOG_STD_MIN, VF_SAC_LOG_STD_MAX};
     vf::RevArgs r{H, N, h->dyn.G, h->dyn.g_drag, h->g_race, tape, tape_stride, reinterpret_cast<const float4*>(actions), tape_done, d_reward,
                   adj_slab, reinterpret_cast<float4*>(d_action), g_obs, reinterpret_cast<const float4*>(substep_tape)};
-    const size_t lds = ckpt ? (size_t)2 * (S + 3) * 64 * sizeof(float4) : (size_t)S * vf::kSave * 64 * sizeof(float);
+    const size_t lds = ckpt ? (size_t)2 * (S + 3) * 64 * sizeof(float4) + (64 + 256) * sizeof(float) : (size_t)S * vf::kSave * 64 * sizeof(float);
     const int rows = r16 ? 16 : 32;
     hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, gb, r);
     VF_HIP(hipGetLastError());

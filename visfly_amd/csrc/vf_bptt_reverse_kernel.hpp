@@ -52,8 +52,32 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         for (int j = 0; j < rows_ck; ++j)
             __builtin_amdgcn_global_load_lds(src + (size_t)j * gridDim.x * 64, (__attribute__((address_space(3))) void*)(dst + (size_t)j * 64), 16, 0, 0);
     };
+    // CKPT (four lanes per agent, vf_env_bwd_quad.hpp): the adjoint of the persistent state stays in registers for the whole sweep
+    // (component layout: 6 + delay_steps registers), d_action_t and dLoss / d obs_t travel between the adjoint and the chain through
+    // LDS -- no slab round trip, no global hand-over, hence no fence that waits for the step's stores to be acknowledged
+    const int iq = min((int)blockIdx.x * ROWS + (lane >> 2), r.N - 1);      // the quads (lanes 4 m .. 4 m + 3) hold the agent the chain keeps in lanes m + 16 kq
+    float* da_lds = lds + (size_t)2 * rows_ck * 256;                         // [16 slots] float4
+    float* obs_lds = da_lds + 64;                                            // [16 slots][16] floats
+    QuadCarry cy;
     if constexpr (CKPT) {
         fetch_record(r.H - 1);
+        const int k = lane & 3;
+        const float4 g0 = *granule(r.adj, r.G, iq, VF_G_POS), g1 = *granule(r.adj, r.G, iq, VF_G_QUAT), g2 = *granule(r.adj, r.G, iq, VF_G_VEL);
+        const float4 g3 = *granule(r.adj, r.G, iq, VF_G_OMG), g4 = *granule(r.adj, r.G, iq, VF_G_MOT), g6 = *granule(r.adj, r.G, iq, VF_G_AACC);
+        cy.lp = q_sel4(k, 0.0f, g0.y, g0.z, g0.w);
+        cy.lq = q_sel4(k, g1.x, g1.y, g1.z, g1.w);
+        cy.lv = q_sel4(k, 0.0f, g2.y, g2.z, g2.w);
+        cy.lw = q_sel4(k, 0.0f, g3.y, g3.z, g3.w);
+        cy.lwm = q_sel4(k, g4.x, g4.y, g4.z, g4.w);
+        cy.laa = q_sel4(k, 0.0f, g6.y, g6.z, g6.w);
+#pragma unroll
+        for (int q = 0; q < kRingRegs; ++q) {
+            cy.ring[q] = 0.0f;
+            if (q < cp->delay_steps) {
+                const float4 gr = *granule(r.adj, r.G, iq, VF_G_RING + q);
+                cy.ring[q] = q_sel4(k, gr.x, gr.y, gr.z, gr.w);
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     for (int t = r.H - 1; t >= 0; --t) {
@@ -68,13 +92,18 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         if constexpr (ROWS == 16) bwd16_mask_preload<P, 0>(gb, st16, row, lane >> 4);
         if constexpr (CKPT) {
             if (t > 0) fetch_record(t - 1);
-            // four lanes per agent: the quads (lanes 4 m .. 4 m + 3) hold the agent the chain below keeps in lanes m, m + 16, m + 32, m + 48
-            const int iq = min((int)blockIdx.x * ROWS + (lane >> 2), r.N - 1);
-            env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64, true, true>(*cp, *ep, g, iq, true, lds + lane, lds4 + (size_t)(t & 1) * rows_ck * 64);
+            env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64, true, true>(*cp, *ep, g, iq, true, lds + lane, lds4 + (size_t)(t & 1) * rows_ck * 64, &cy,
+                                                                             obs_lds, da_lds);
+            // the record of step t - 1 and this step's masks were issued at the head of the step and the adjoint issued no other
+            // vector-memory operation: they are back by now (on gfx9 vmcnt also counts STORES: waiting here, not behind the chain,
+            // keeps the chain's 40-odd dZ stores out of the wait).  LDS operations of a wave execute in order.
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            st16.pda = reinterpret_cast<const float4*>(da_lds)[lane & 15];
         } else {
             env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64>(*cp, *ep, g, i, true, lds + lane);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // d_action_t: written above, read by the head reverse below
+            if constexpr (ROWS == 16) st16.pda = r.d_action[(size_t)t * r.N + i];
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // d_action_t: written above, read by the head reverse below
         VF_RT(0);
         // (an opaque copy of the lane id per iteration: the chain's loop-invariant per-item load offsets stay just-in-time instead
         // of being hoisted out of the t loop into ~100 live registers -- see k_ppo_rollout)
@@ -90,14 +119,30 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
             bwd16_head_prologue<P, 0, true>(gbt, st16, row, gq, true);
             bwd16_items<P, 0, true>(gbt, st16, lane_t, row, row, true);
             bwd16_tail_store<P>(gbt, st16, row, gq, true);
+            if constexpr (CKPT) {      // dLoss / d obs_t for the adjoint of step t - 1: features 4 gq .. 4 gq + 3 of row lane & 15
+                const f32x4& v = bwd16_obs_tile<P>(st16);
+                *reinterpret_cast<float4*>(obs_lds + (lane_t & 15) * 16 + 4 * gq) = make_float4(v[0], v[1], v[2], v[3]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         } else {
             bwd_rows<P, ROWS>(gbt, lane_t, row, row, true);
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // dLoss / d obs_t: read by the adjoint of step t - 1
-        // the record of step t - 1 (issued a whole step ago) is in LDS before the next adjoint reads it; every other load of this step
-        // has been consumed by now, so this never waits
-        if constexpr (CKPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!CKPT) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // dLoss / d obs_t: read by the adjoint of step t - 1
         VF_RT(1);
+    }
+    if constexpr (CKPT) {      // the adjoint of the state before the first step of the horizon, back into the slab
+        *granule(r.adj, r.G, iq, VF_G_POS) = make_float4(0.f, qb<1>(cy.lp), qb<2>(cy.lp), qb<3>(cy.lp));
+        *granule(r.adj, r.G, iq, VF_G_QUAT) = make_float4(qb<0>(cy.lq), qb<1>(cy.lq), qb<2>(cy.lq), qb<3>(cy.lq));
+        *granule(r.adj, r.G, iq, VF_G_VEL) = make_float4(0.f, qb<1>(cy.lv), qb<2>(cy.lv), qb<3>(cy.lv));
+        *granule(r.adj, r.G, iq, VF_G_OMG) = make_float4(0.f, qb<1>(cy.lw), qb<2>(cy.lw), qb<3>(cy.lw));
+        *granule(r.adj, r.G, iq, VF_G_MOT) = make_float4(qb<0>(cy.lwm), qb<1>(cy.lwm), qb<2>(cy.lwm), qb<3>(cy.lwm));
+        *granule(r.adj, r.G, iq, VF_G_THR) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *granule(r.adj, r.G, iq, VF_G_AACC) = make_float4(0.f, qb<1>(cy.laa), qb<2>(cy.laa), qb<3>(cy.laa));
+        *granule(r.adj, r.G, iq, VF_G_ACC) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < kRingRegs; ++q)
+            if (q < cp->delay_steps)
+                *granule(r.adj, r.G, iq, VF_G_RING + q) = make_float4(qb<0>(cy.ring[q]), qb<1>(cy.ring[q]), qb<2>(cy.ring[q]), qb<3>(cy.ring[q]));
     }
 #ifdef VF_PPO_TRACE
     if (blockIdx.x == 7 && lane == 0) { vf_rev_trace[0] = tr[0]; vf_rev_trace[1] = tr[1]; }

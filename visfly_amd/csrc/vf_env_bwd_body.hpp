@@ -99,8 +99,12 @@ __device__ __forceinline__ void derivs_bwd(const vf_dyn_cfg& c, const Quat& q, c
 // (vf_env_bwd_quad.hpp).  Everything outside the loop is per agent, not per component, and stays replicated.  Bit-identical.
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY, int STRIDE, bool CKPT = false, bool QUAD = false>
 __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf_env_cfg& e, const BwdArgs& g, int i, bool live, float* lds_col,
-                                                   const float4* rec = nullptr)
+                                                   const float4* rec = nullptr, QuadCarry* carry = nullptr, const float* d_obs_lds = nullptr,
+                                                   float* d_action_lds = nullptr)
 {
+    // QUAD: `carry` holds the adjoint of the persistent state from step to step (g.adj is not touched), the observation gradient of
+    // the wave's agents comes from d_obs_lds ([16 slots][16] floats, LDS; read iff g.d_obs != nullptr), the action gradient goes to
+    // d_action_lds ([16 slots] float4, LDS; g.d_action is not written)
     static_assert(!QUAD || CKPT, "the component layout reads the sub-step tape");
     float* T = const_cast<float*>(g.tape);
     Agent s;
@@ -239,7 +243,31 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     const bool cut = live ? done_in : true;
     float lp[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lw[3] = {0, 0, 0}, lwm[4] = {0, 0, 0, 0}, laa[3] = {0, 0, 0};
     Quat lq{0, 0, 0, 0};
-    if (!cut) {
+    if constexpr (QUAD) {
+        // (cross-lane reads first, selects afterwards: vf_env_bwd_quad.hpp)
+        const float cp1 = qb<1>(carry->lp), cp2 = qb<2>(carry->lp), cp3 = qb<3>(carry->lp);
+        const float cq0 = qb<0>(carry->lq), cq1 = qb<1>(carry->lq), cq2 = qb<2>(carry->lq), cq3 = qb<3>(carry->lq);
+        const float cv1 = qb<1>(carry->lv), cv2 = qb<2>(carry->lv), cv3 = qb<3>(carry->lv);
+        const float cw1 = qb<1>(carry->lw), cw2 = qb<2>(carry->lw), cw3 = qb<3>(carry->lw);
+        const float cm0 = qb<0>(carry->lwm), cm1 = qb<1>(carry->lwm), cm2 = qb<2>(carry->lwm), cm3 = qb<3>(carry->lwm);
+        const float ca1 = qb<1>(carry->laa), ca2 = qb<2>(carry->laa), ca3 = qb<3>(carry->laa);
+        if (!cut) {
+            lp[0] = cp1; lp[1] = cp2; lp[2] = cp3;
+            lq = Quat{cq0, cq1, cq2, cq3};
+            lv[0] = cv1; lv[1] = cv2; lv[2] = cv3;
+            lw[0] = cw1; lw[1] = cw2; lw[2] = cw3;
+            lwm[0] = cm0; lwm[1] = cm1; lwm[2] = cm2; lwm[3] = cm3;
+            laa[0] = ca1; laa[1] = ca2; laa[2] = ca3;
+            if (g.d_obs) {  // observation = [p, q, v + wind, w] of the post-step state (dynamics.py:779-786)
+                const float4* d4 = reinterpret_cast<const float4*>(d_obs_lds + 16 * rec_slot);
+                const float4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
+                lp[0] += d0.x; lp[1] += d0.y; lp[2] += d0.z;
+                lq.w += d0.w; lq.x += d1.x; lq.y += d1.y; lq.z += d1.z;
+                lv[0] += d1.w; lv[1] += d2.x; lv[2] += d2.y;
+                lw[0] += d2.z; lw[1] += d2.w; lw[2] += d3.x;
+            }
+        }
+    } else if (!cut) {
         const float4 g0 = *granule(g.adj, g.G, i, VF_G_POS), g1 = *granule(g.adj, g.G, i, VF_G_QUAT);
         const float4 g2 = *granule(g.adj, g.G, i, VF_G_VEL), g3 = *granule(g.adj, g.G, i, VF_G_OMG);
         const float4 g4 = *granule(g.adj, g.G, i, VF_G_MOT), g6 = *granule(g.adj, g.G, i, VF_G_AACC);
@@ -579,6 +607,29 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     }
 
     // ---- write the adjoint of the pre-step state; hand the action gradient out ----
+    if constexpr (QUAD) {
+        carry->lp = q_sel3(qk, lp);
+        carry->lq = q_sel4(qk, lq.w, lq.x, lq.y, lq.z);
+        carry->lv = q_sel3(qk, lv);
+        carry->lw = q_sel3(qk, lw);
+        carry->lwm = q_sel4(qk, lwm[0], lwm[1], lwm[2], lwm[3]);
+        carry->laa = q_sel3(qk, laa);
+        float dact_c = q_sel4(qk, la[0], la[1], la[2], la[3]);
+        if (c.delay_steps > 0) {       // the ring slot logic of the slab form below, on registers (head is launch-uniform)
+#pragma unroll
+            for (int q = 0; q < kRingRegs; ++q) {
+                if (q == head) {
+                    const float pushed = cut ? 0.0f : carry->ring[q];
+                    carry->ring[q] = dact_c;
+                    dact_c = pushed;
+                } else if (cut) {
+                    carry->ring[q] = 0.0f;
+                }
+            }
+        }
+        d_action_lds[rec_slot * 4 + qk] = dact_c;
+        return;
+    }
     float4 dact = make_float4(la[0], la[1], la[2], la[3]);
     if (c.delay_steps > 0) {
         // the consumed action sat in ring[head]; the action passed to this step was pushed into the same

@@ -173,6 +173,16 @@ __device__ __forceinline__ float inv_rotate_bwd_c(const QuadLane& L, float q, fl
     return qmul_c(L, q, lA);
 }
 
+// The adjoint of the persistent state BETWEEN two steps of a persistent reverse sweep, one register per quantity (component layout):
+// k_bptt_reverse loads it from the adjoint slab before the sweep and stores it after -- per step the slab round trip (8 granule
+// stores, a fence, 6 + 1 dependent loads at the head of the next step) is gone.  ring: the delay ring's action adjoints (a float4
+// per slot, lane k = component k); at most kRingRegs slots (else the sweep keeps the slab in the loop).
+constexpr int kRingRegs = 4;
+struct QuadCarry {
+    float lp, lq, lv, lw, lwm, laa;
+    float ring[kRingRegs];
+};
+
 // adjoint state carried through the sub-steps, one register each (component layout)
 struct QuadAdj {
     float lq, lv, lw, lp;       // quaternion; vectors in lanes 1..3

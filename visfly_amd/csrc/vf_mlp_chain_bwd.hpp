@@ -409,6 +409,7 @@ struct BwdState16 {
     float4 ym[Bwd16<P>::n_masks() > 0 ? Bwd16<P>::n_masks() : 1];   // saved activations (mask source) of the 16-tiles every op finalises
     float hin[2];                // this lane's element of the head gradients: d_mean[kq] / d_value (kq = 0), else 0
     float4 pa, pe, pg;           // preloaded action / noise / log_std-gradient rows of the action head's reverse (bwd16_mask_preload)
+    float4 pda;                  // PRE callers: the row's d_action (k_bptt_reverse hands it over through LDS, not through rp_d_action)
     vf_gptr sv_base[2];      // dZ buffers of the layers the previous op finalised (bwd16_store_setup) + this lane's byte offsets
     unsigned sv_off[2];
 };
@@ -610,7 +611,7 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
             if constexpr (O.in_kind == 1) {
                 float4 dm;
                 if (g.rp_d_action) {       // k_reparam_bwd's arithmetic; lane group 0 of a live row writes d_mean / g_log_std
-                    const float4 da = g.rp_d_action[rc], a = PRE ? st.pa : g.rp_action[rc], e = PRE ? st.pe : g.rp_eps[rc];
+                    const float4 da = PRE ? st.pda : g.rp_d_action[rc], a = PRE ? st.pa : g.rp_action[rc], e = PRE ? st.pe : g.rp_eps[rc];
                     dm = make_float4(da.x * (1.0f - a.x * a.x), da.y * (1.0f - a.y * a.y), da.z * (1.0f - a.z * a.z), da.w * (1.0f - a.w * a.w));
                     if constexpr (P::sac_head) {       // k_shac_head_bwd's: d_mu = dm, d_log_std (the second head's gradient) from the saved row
                         const vf_mlp_bwd_layer& EV = g.d.layer[P::entry(P::L_val)];
@@ -645,6 +646,15 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
             bwd16_head_prologue<P, OI + 1, PRE>(g, st, rc, gq, live);
         }
     }
+}
+
+// the tile that holds dLoss / d observation 0 (the "state" branch) after the sweep: lane (m, gq) = features 4 gq .. 4 gq + 3 of row m
+template <class P>
+__device__ __forceinline__ const f32x4& bwd16_obs_tile(const BwdState16<P>& st)
+{
+    constexpr int oi = [] { for (int i = 0; i < P::n_ops; ++i) if (P::op(i).obs == 0) return i; return -1; }();
+    static_assert(oi >= 0, "the program has no observation-gradient op");
+    return st.t[2 * P::op(oi).out0];
 }
 
 // the last op's finalised tiles have no following items to carry their stores
