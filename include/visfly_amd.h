@@ -748,12 +748,14 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * raw-state observation, thrust / bodyrate actions, Euler or (repaired, utils/maths.py:353-386) RK4, ctrl_delay, constant wind;
  * per-agent drag randomisation (dynamics.py:244-267) is carried in the slab's drag granules.
  *   substep_tape  optional (NULL: off), [H][S + 3][W][64] float4 with S = interval_steps and W = ceil(N / 16) waves: for every
- *                 (step, wave of 16 agents) S + 3 rows of 1 KiB, entry k of agent slot m at float4 [k * 16 + m] of a row -- rows
- *                 0 .. S-1 the state at the head of each integrator sub-step: (q) (v, 0) (w, 0) (rotor speeds); row S the state
- *                 after the last one before the clamps: (p, 0) (q) (v, 0) (w, 0); row S + 1 the step's other inputs and its
- *                 outcome: (body rates, ring-head bits) (angular acceleration, step-counter bits) (the action the interval
- *                 consumed) (done, d_reward, pre-step gate bits, 0); row S + 2, entries 0 / 1: the agent's drag granules (drag
- *                 randomisation only).  What autograd's tape keeps of dynamics.py:335-382; handed to vf_bptt_reverse, whose
+ *                 (step, wave of 16 agents) S + 3 rows of 1 KiB.  Rows 0 .. S are component-major: the float4 at [k * 16 + m] of
+ *                 a row holds component k (of w x y z; vectors as pure quaternions (0, x, y, z); rotor k) of four quantities of
+ *                 agent slot m -- rows 0 .. S-1 the state at the head of each integrator sub-step: (q_k, v_k, w_k, rotor speed k);
+ *                 row S the state after the last one before the clamps: (p_k, q_k, v_k, w_k) -- the layout both persistent
+ *                 launches compute in (four lanes per agent).  Row S + 1, entry k of slot m at [k * 16 + m]: the step's other
+ *                 inputs and its outcome: (body rates, ring-head bits) (angular acceleration, step-counter bits) (the action the
+ *                 interval consumed) (done, d_reward, pre-step gate bits, 0); row S + 2, entries 0 / 1: the agent's drag
+ *                 granules (drag randomisation only).  What autograd's tape keeps of dynamics.py:335-382; handed to vf_bptt_reverse, whose
  *                 adjoint then reads it (LDS-DMA, one step ahead) instead of replaying the S sub-steps (a third of its
  *                 instruction stream) and instead of the tape slab / done / d_reward rows (HBM-cold by then: two dependent
  *                 round trips at the head of every step).  16-byte aligned.

@@ -3,6 +3,7 @@
 // vf_bptt_rollout_sac.hip (td_policies.Actor: state-dependent log_std), two translation units so that their instances compile side by side.
 #pragma once
 #include "vf_env_epilogue.hpp"
+#include "vf_dyn_quad.hpp"
 #include "vf_mlp_chain.hpp"
 
 #pragma clang fp contract(off)
@@ -26,14 +27,16 @@ struct RollArgs {
     unsigned char* ep_flag_rows;   // optional [H][N]: out->ep_flags of the step, written where done (shac.py:231-232 reads episode_done there)
 };
 
-// control_interval observer: the agent at the head of every sub-step -- (q) (v, 0) (w, 0) (rotor speeds) -- and the state after the
-// last one before the clamps -- (p, 0) (q) (v, 0) (w, 0) --, what the adjoint of the interval otherwise obtains by replaying it.
-// One record row = ONE store instruction of the whole wave: the four lane groups (which hold the same 16 agents) store one entry
-// each, [entry k = lane >> 4][agent slot = lane & 15] float4 = 1 KiB contiguous; k_bptt_reverse fetches a row back with one LDS-DMA.
+// control_interval_quad observer (component layout: lane 4 m + k holds component k of agent slot m's quantities): the agent at the
+// head of every sub-step and the state after the last one before the clamps -- what the adjoint of the interval otherwise obtains by
+// replaying it.  One record row = ONE store instruction of the whole wave, 1 KiB contiguous: the float4 at [k * 16 + m] of a row holds
+// component k of four quantities of slot m, vectors as pure quaternions (0, x, y, z):
+//     sub-step rows   (q_k, v_k, w_k, rotor speed k)        end row   (p_k, q_k, v_k, w_k)
+// so that the reverse sweep, in the same layout, reads ONE float4 per lane and sub-step; k_bptt_reverse fetches a row with one LDS-DMA.
 struct TapeCheckpoint {
-    float4* p;                 // row 0 of this (step, wave) + lane, or null (no tape)
+    float4* p;                 // row 0 of this (step, wave) + this lane's position (lane & 3) * 16 + (lane >> 2), or null (no tape)
     size_t rs;                 // float4 between two rows of a record = 64 x waves
-    int S, k;                  // sub-steps per interval; this lane's entry (lane >> 4)
+    int S, k;                  // sub-steps per interval; this lane's component / entry (lane & 3)
     // two-level selects on the bits of k (a chain `k == 0 ? .. : k == 1 ? ..` is compiled into a scratch array + indexed load)
     __device__ __forceinline__ float sel(float a, float b, float c2, float d) const
     {
@@ -44,17 +47,13 @@ struct TapeCheckpoint {
     {
         return make_float4(sel(e0.x, e1.x, e2.x, e3.x), sel(e0.y, e1.y, e2.y, e3.y), sel(e0.z, e1.z, e2.z, e3.z), sel(e0.w, e1.w, e2.w, e3.w));
     }
-    __device__ __forceinline__ void head(int sub, const Agent& s) const
+    __device__ __forceinline__ void head_c(int sub, float q, float v, float w, float wm) const
     {
-        if (p)
-            p[(size_t)sub * rs] = pick(make_float4(s.q.w, s.q.x, s.q.y, s.q.z), make_float4(s.v[0], s.v[1], s.v[2], 0.0f),
-                                       make_float4(s.w[0], s.w[1], s.w[2], 0.0f), make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]));
+        if (p) p[(size_t)sub * rs] = make_float4(q, v, w, wm);
     }
-    __device__ __forceinline__ void end(const Agent& s) const
+    __device__ __forceinline__ void end_c(float pp, float q, float v, float w) const
     {
-        if (p)
-            p[(size_t)S * rs] = pick(make_float4(s.p[0], s.p[1], s.p[2], 0.0f), make_float4(s.q.w, s.q.x, s.q.y, s.q.z),
-                                     make_float4(s.v[0], s.v[1], s.v[2], 0.0f), make_float4(s.w[0], s.w[1], s.w[2], 0.0f));
+        if (p) p[(size_t)S * rs] = make_float4(pp, q, v, w);
     }
     // row S + 1 -- what else the adjoint of the step reads of the step's INPUTS, so that it never touches the (HBM-cold) tape slab:
     // (body rates, ring head bits) (angular acceleration, step-counter bits) (the action the interval consumed) before the
@@ -86,9 +85,10 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
     __shared__ __attribute__((aligned(16))) float tile[64 * 13];
     const int lane = threadIdx.x, m = lane & 15;
     const int wave_first = blockIdx.x * 16;
-    // agent = policy row of this lane.  Lanes 16..63 -- and the lanes past the last agent -- are REPLICAS of a live lane: same
-    // index, same loads, same arithmetic, same stores of the same values
-    const int i = min(wave_first + m, r.N - 1), ic = i;
+    // policy rows: lane (m, gq = lane >> 4) works on row m of the wave (MFMA layout).  Env step: the QUAD of lanes 4 m .. 4 m + 3
+    // holds agent slot m -- replicas outside the sub-step loop (same index, same loads, same arithmetic, same stores of the same
+    // values), the four components of the agent's quantities inside it (vf_dyn_quad.hpp).  Lanes past the last agent replicate it.
+    const int i = min(wave_first + m, r.N - 1), ic = min(wave_first + (lane >> 2), r.N - 1);
     const bool live = true;
     EnvArgs g = ge;
     g.d.N = min(r.N, wave_first + 16);                   // the wave's observation tile holds 16 rows
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         }
         // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
         // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)
+#ifndef VF_EXP_NO_FWD_FENCE
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
         // ---- checkpoint for the adjoint: this agent's granules of tape row t = the slab before the step ----
         float* T = r.tape + (size_t)t * r.tape_stride;
         store_agent(T, Gx, ic, s, sp);
@@ -148,26 +150,28 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         const float4 eps_touch = gc.rp_eps[(size_t)(t + 1 < r.H ? t + 1 : t) * r.N + i];
         // sub-step tape of this (step, wave): [H][S + 3 rows][waves][64] float4 (wave-uniform pointer test: no divergence)
         const size_t ck_rs = (size_t)gridDim.x * 64;
-        const TapeCheckpoint ck{r.ck ? r.ck + ((size_t)t * (c.interval_steps + 3) * gridDim.x + blockIdx.x) * 64 + lane : nullptr, ck_rs,
-                                c.interval_steps, lane >> 4};
+        const TapeCheckpoint ck{r.ck ? r.ck + ((size_t)t * (c.interval_steps + 3) * gridDim.x + blockIdx.x) * 64 + ((lane & 3) * 16 + (lane >> 2)) : nullptr,
+                                ck_rs, c.interval_steps, lane & 3};
         ck.inputs(s, head_pre, counter_pre, a);
         ck.drag(g.d.S, Gx, ic, g.d.g_drag);
         float gate_pre = 0.0f;
         if constexpr (KIND == VF_ENV_RACING) gate_pre = granule(g.d.S, Gx, ic, g.g_race)->x;
-        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0, ck);
+        control_interval_quad<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0, ck);
         asm volatile("" :: "v"(eps_touch.x), "v"(eps_touch.y), "v"(eps_touch.z), "v"(eps_touch.w));
         float reward = 0.0f;
         bool done = false;
-        env_epilogue<KIND, false>(c, e, g, ic, live, s, sp, wave_first, tile, &reward, &done);
+        env_epilogue<KIND, false, 4>(c, e, g, ic, live, s, sp, wave_first, tile, &reward, &done);
         ck.outcome(done, -disc * r.scale, gate_pre);
-        if (r.reward_rows) r.reward_rows[(size_t)t * r.N + i] = reward;
-        if (r.ep_flag_rows && done && g.out.ep_flags) r.ep_flag_rows[(size_t)t * r.N + i] = g.out.ep_flags[ic];   // (this lane's own store above)
+        if (r.reward_rows) r.reward_rows[(size_t)t * r.N + ic] = reward;
+        if (r.ep_flag_rows && done && g.out.ep_flags) r.ep_flag_rows[(size_t)t * r.N + ic] = g.out.ep_flags[ic];   // (this lane's own store above)
         // ---- loss / discount recurrence (BPTT.py:123-124; k_bptt_accumulate) ----
-        r.d_reward[(size_t)t * r.N + i] = -disc * r.scale;
+        r.d_reward[(size_t)t * r.N + ic] = -disc * r.scale;
         loss = loss + -1.0f * reward * disc;
         const float dn = done ? 1.0f : 0.0f;
         disc = disc * r.gamma * (1.0f - dn) + dn;
+#ifndef VF_EXP_NO_FWD_FENCE
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the observation rows of slot t + 1 are read by the next forward
+#endif
         // ---- next step ----
         g.d.action += r.N;                               // float4 units
         g.out.done += r.N;
@@ -175,8 +179,8 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
     }
     store_agent(g.d.S, Gx, ic, s, sp);
-    r.disc[i] = disc;
-    r.loss[i] = loss;
+    r.disc[ic] = disc;
+    r.loss[ic] = loss;
 }
 
 }  // namespace vf

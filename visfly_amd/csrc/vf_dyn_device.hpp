@@ -690,6 +690,25 @@ __device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, in
     }
 }
 
+// ... for a wave whose QUADS of lanes hold one agent each (16 rows per wave): lane 4 m + k parks row m (the four lanes of a quad hold the
+// same row: same values to the same addresses), then the wave streams its <= 16 rows out
+template <int C>
+__device__ __forceinline__ void store_rows_quads(float* __restrict__ out, int N, int wave_first, const float* row, float* tile)
+{
+    const int l = threadIdx.x & 63, m = l >> 2;
+#pragma unroll
+    for (int k = 0; k < C; ++k) tile[m * C + k] = row[k];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    const int total = min(16, N - wave_first) * C;
+    float* dst = out + (size_t)wave_first * C;
+#pragma unroll
+    for (int k = 0; k < (16 * C + 63) / 64; ++k) {
+        const int j = k * 64 + l;
+        if (j < total) st1(dst + j, tile[j]);
+    }
+}
+
 // ---- two-wave split of the control interval --------------------------------------------------------
 // One wave per SIMD cannot hide its own dependent-issue latency (measured 4.6 cycles / instruction,
 // 2.5 with four waves per SIMD).  Rotation (motors -> torque -> q, w) never reads the translational

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     drag_of(c, g.d, i, kl, kq);
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
     const int wave = threadIdx.x >> 6;
-    env_epilogue<KIND, true, false, LAZY_SLOT>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+    env_epilogue<KIND, true, 1, false, LAZY_SLOT>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
 }
 
 // The part of the step that follows the dynamics interval, as a launch of its own (vf_env_finish_step): the dynamics ran
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_env_finish(const vf_dyn_cfg* __restr
     load_agent<false>(g.d.S, g.d.G, i, s, sp);
     load_wind(c, g.d, i, live, s);
     const int wave = threadIdx.x >> 6;
-    env_epilogue<KIND, true, true>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+    env_epilogue<KIND, true, 1, true>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
 }
 
 // K consecutive steps in one launch: see vf_env_rollout_fused (include/visfly_amd.h)

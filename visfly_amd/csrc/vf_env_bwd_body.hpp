@@ -88,11 +88,12 @@ __device__ __forceinline__ void derivs_bwd(const vf_dyn_cfg& c, const Quat& q, c
 // of the [S * kSave][STRIDE] parking area (STRIDE = threads per workgroup).
 //
 // CKPT: the forward kernel left the interval's sub-step tape (k_bptt_rollout's TapeCheckpoint) and the caller has brought this
-// wave's record of the step into LDS (k_bptt_reverse: LDS-DMA one step ahead, double-buffered): `rec` = lane-group-interleaved rows
-// of 64 float4, row r = sub-step r (r < S) or the pre-clamp end state (r = S), entry k of agent slot m at rec[r * 64 + k * 16 + m]
-// -- sub-step rows: (q) (v, 0) (w, 0) (rotor speeds); end row: (p, 0) (q) (v, 0) (w, 0).  The replay of the interval -- a third of
-// this function's instruction stream -- is skipped.  Same values as the replay computes (it runs the forward kernels' own
-// sub-step functions), so the adjoint is bit-identical either way.  16 agents per wave (lane & 15 = agent slot).
+// wave's record of the step into LDS (k_bptt_reverse: LDS-DMA one step ahead, double-buffered): `rec` = rows of 64 float4, row r =
+// sub-step r (r < S), the pre-clamp end state (r = S), the step's inputs / outcome (S + 1), its drag granules (S + 2).  Rows 0 .. S are
+// component-major -- the float4 at [k * 16 + m] holds component k of four quantities of agent slot m, vectors as (0, x, y, z):
+// (q_k, v_k, w_k, rotor speed k) / (p_k, q_k, v_k, w_k) --, rows S + 1, S + 2 entry-major (entry k of slot m at [k * 16 + m]).  The
+// replay of the interval -- a third of this function's instruction stream -- is skipped; same values as the replay computes (it
+// runs the forward kernels' own sub-step functions), so the adjoint is bit-identical either way.  16 agents per wave.
 //
 // QUAD (with CKPT): four lanes per agent -- the wave's 16 agents sit in QUADS (lanes 4 m .. 4 m + 3 = agent slot m; the caller passes the
 // same `i` to the four lanes of a quad) and the sub-step loop, two thirds of this function, runs in component layout
@@ -200,11 +201,12 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     const int S = c.interval_steps;
     const int mslot = rec_slot;
     if constexpr (CKPT) {
-        const float4 ep = rec[S * 64 + mslot], eq = rec[S * 64 + 16 + mslot], ev = rec[S * 64 + 32 + mslot], ew = rec[S * 64 + 48 + mslot];
-        s.p[0] = ep.x; s.p[1] = ep.y; s.p[2] = ep.z;
-        s.q = Quat{eq.x, eq.y, eq.z, eq.w};
-        s.v[0] = ev.x; s.v[1] = ev.y; s.v[2] = ev.z;
-        s.w[0] = ew.x; s.w[1] = ew.y; s.w[2] = ew.z;
+        // end row, component-major (TapeCheckpoint::end_c): the float4 at [k * 16 + slot] = (p_k, q_k, v_k, w_k), vectors as (0, x, y, z)
+        const float4 c0 = rec[S * 64 + mslot], c1 = rec[S * 64 + 16 + mslot], c2 = rec[S * 64 + 32 + mslot], c3 = rec[S * 64 + 48 + mslot];
+        s.p[0] = c1.x; s.p[1] = c2.x; s.p[2] = c3.x;
+        s.q = Quat{c0.y, c1.y, c2.y, c3.y};
+        s.v[0] = c1.z; s.v[1] = c2.z; s.v[2] = c3.z;
+        s.w[0] = c1.w; s.w[1] = c2.w; s.w[2] = c3.w;
     } else {
         // the forward kernels' own sub-step functions (control_interval's loop body): the replayed states ARE the forward's, bit for
         // bit (r03 restated the Euler sub-step here and normalised q with a reciprocal product where the forward divides: 1 ulp)
@@ -404,14 +406,12 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
         QuadAdj qa{q_sel4(qk, lq.w, lq.x, lq.y, lq.z), q_sel3(qk, lv), q_sel3(qk, lw), q_sel3(qk, lp),
                    q_sel4(qk, lwm[0], lwm[1], lwm[2], lwm[3]), 0.0f, 0.0f, q_sel3(qk, ldw_in)};
         const float kl_c = q_sel3(qk, kl), kq_c = q_sel3(qk, kq);
-        // this lane's component of the sub-step records: entries (q) (v, 0) (w, 0) (rotor speeds) of agent slot mslot; the vectors'
-        // component qk - 1 (lane 0 reads the stored 0)
-        const float* rf = reinterpret_cast<const float*>(rec);
-        const int oq = (0 * 16 + mslot) * 4 + qk, ov = (1 * 16 + mslot) * 4 + ((qk + 3) & 3), ow = (2 * 16 + mslot) * 4 + ((qk + 3) & 3),
-                  om = (3 * 16 + mslot) * 4 + qk;
+        // this lane's component of the sub-step records (component-major rows, TapeCheckpoint::head_c): ONE float4 per sub-step =
+        // (q_k, v_k, w_k, rotor speed k) of agent slot mslot
+        const float4* rq = rec + qk * 16 + mslot;
         for (int sub = S - 1; sub >= 0; --sub) {
-            const float* r = rf + sub * 256;
-            substep_bwd_c<INTEG, CTRL_DELAY>(c, QL, r[oq], r[ov], r[ow], r[om], kl_c, kq_c, wd_c, Td_c, dt, inv_m, qa);
+            const float4 h = rq[sub * 64];
+            substep_bwd_c<INTEG, CTRL_DELAY>(c, QL, h.x, h.y, h.z, h.w, kl_c, kq_c, wd_c, Td_c, dt, inv_m, qa);
         }
         lq = Quat{qb<0>(qa.lq), qb<1>(qa.lq), qb<2>(qa.lq), qb<3>(qa.lq)};
         lv[0] = qb<1>(qa.lv); lv[1] = qb<2>(qa.lv); lv[2] = qb<3>(qa.lv);
@@ -425,12 +425,12 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     for (int sub = S - 1; sub >= 0; --sub) {
         Quat q;
         float v[3], w[3], wm0[4];
-        if constexpr (CKPT) {
-            const float4 hq = rec[sub * 64 + mslot], hv = rec[sub * 64 + 16 + mslot], hw = rec[sub * 64 + 32 + mslot], hm = rec[sub * 64 + 48 + mslot];
-            q = Quat{hq.x, hq.y, hq.z, hq.w};
-            v[0] = hv.x; v[1] = hv.y; v[2] = hv.z;
-            w[0] = hw.x; w[1] = hw.y; w[2] = hw.z;
-            wm0[0] = hm.x; wm0[1] = hm.y; wm0[2] = hm.z; wm0[3] = hm.w;
+        if constexpr (CKPT) {      // (one lane per agent on the component-major rows: transposed reads)
+            const float4 h0 = rec[sub * 64 + mslot], h1 = rec[sub * 64 + 16 + mslot], h2 = rec[sub * 64 + 32 + mslot], h3 = rec[sub * 64 + 48 + mslot];
+            q = Quat{h0.x, h1.x, h2.x, h3.x};
+            v[0] = h1.y; v[1] = h2.y; v[2] = h3.y;
+            w[0] = h1.z; w[1] = h2.z; w[2] = h3.z;
+            wm0[0] = h0.w; wm0[1] = h1.w; wm0[2] = h2.w; wm0[3] = h3.w;
         } else {
             const float* sv = lds_col + (size_t)sub * kSave * STRIDE;
             q = Quat{sv[0 * STRIDE], sv[1 * STRIDE], sv[2 * STRIDE], sv[3 * STRIDE]};

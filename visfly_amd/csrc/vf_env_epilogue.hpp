@@ -121,7 +121,9 @@ __device__ __forceinline__ SpawnSlot load_spawn_slot(const EnvArgs& g, int i, bo
     return slot;
 }
 
-template <int KIND, bool STORE_STATE = true, bool EXT = false, bool LAZY_SLOT = false>
+// LANES = 4: the agent is held by the four lanes of a quad (lanes 4 m .. 4 m + 3 = row m of the wave's 16, k_bptt_rollout): only the
+// row hand-over at the end depends on the lane <-> agent map
+template <int KIND, bool STORE_STATE = true, int LANES = 1, bool EXT = false, bool LAZY_SLOT = false>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile, float* reward_reg = nullptr,
                                              bool* done_reg = nullptr)
@@ -292,7 +294,8 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     }
     pack_env(er, sp);
     if constexpr (STORE_STATE) store_agent(g.d.S, g.d.G, i, s, sp);
-    store_rows_coalesced<13>(g.out.obs, g.d.N, wave_first, o, tile);
+    if constexpr (LANES == 4) store_rows_quads<13>(g.out.obs, g.d.N, wave_first, o, tile);
+    else store_rows_coalesced<13>(g.out.obs, g.d.N, wave_first, o, tile);
 }
 
 }  // namespace vf
