@@ -37,6 +37,7 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if (reinterpret_cast<uintptr_t>(substep_tape) & 15) return vf::fail(VF_EINVAL, "vf_bptt_rollout: substep_tape must be 16-byte aligned");
     if ((int64_t)H * h->dyn.N * 128 * 4 >= (1ll << 32))      // the chain addresses its activation copies with 32-bit byte offsets
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: H x N rows of activation copies pass 4 GiB per buffer");
+    if (desc->in_dim[0] != 13) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the first observation must be the 13-wide state row");
     const int cls = vf::chain16_policy_class(desc, params);
     const bool sac = cls >= 3;          // td_policies.Actor: the second head is the state-dependent log_std
     if (sac ? !log_std_rows : !log_std)

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
     const vf_dyn_cfg& c = *cp;
     const vf_env_cfg& e = *ep;
     __shared__ __attribute__((aligned(16))) float tile[64 * 13];
+    __shared__ float4 act_lds[16];      // the action rows of the step: chain lanes (m, gq = 0) -> the quad of agent slot m
     const int lane = threadIdx.x, m = lane & 15;
     const int wave_first = blockIdx.x * 16;
     // policy rows: lane (m, gq = lane >> 4) works on row m of the wave (MFMA layout).  Env step: the QUAD of lanes 4 m .. 4 m + 3
@@ -120,14 +121,19 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
             for (int b = 0; b < Net::NB; ++b) {
                 const int w = gct.d.in_dim[b];
                 const float* x = gct.io.in[b] + (size_t)rc * w;
+                // the state observation of step t > 0 is the row the env epilogue of step t - 1 left in the LDS tile (it also wrote it to
+                // slot t: the weight gradients' X); read back from the slot it would be an L2 round trip behind the store
+                const float* xl = tile + (lane_t & 15) * 13;
+                const bool from_lds = b == 0 && t > 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * gq + j;
-                    const float v = x[k < w ? k : w - 1];
+                    const float v = from_lds ? xl[k < w ? k : w - 1] : x[k < w ? k : w - 1];
                     st.x[b][j] = k < w ? v : 0.0f;
                 }
             }
             chain16_items<Net, 0>(gct, st, lane_t, row, lrow, rc);
+            if (gq == 0) act_lds[lane_t & 15] = st.act;
         }
         // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
         // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)
@@ -141,7 +147,8 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         // ---- env step (k_env_rollout's body) ----
         float a[4], head_bits = 0.0f;
         const float head_pre = sp.vel, counter_pre = sp.omg;
-        ring_exchange(c, g.d, ic, live, head_bits, a);
+        const float4 act_new = act_lds[lane >> 2];       // (LDS operations of a wave execute in order)
+        ring_exchange(c, g.d, ic, live, head_bits, a, &act_new);
         if (c.delay_steps > 0) sp.vel = head_bits;
         float kl[3], kq[3];
         drag_of(c, g.d, ic, kl, kq);

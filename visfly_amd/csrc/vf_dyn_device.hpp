@@ -619,11 +619,13 @@ __device__ __forceinline__ void load_wind(const vf_dyn_cfg& c, const DynArgs& g,
 // known before any state arrives, so the slot load travels with the first burst instead of waiting for the velocity
 // granule.  The per-agent head word in that granule's spare component is still advanced -- the adjoint kernel reads it
 // from its tape -- and a reset zeroes all slots, after which any head position is equivalent.
+// an_reg: the new action in a register (a persistent launch that just computed it) instead of g.action[i]
 __device__ __forceinline__ void ring_exchange(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, float& head_bits,
-                                              float* a)
+                                              float* a, const float4* an_reg = nullptr)
 {
     float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) an = g.action[i];
+    if (an_reg) an = *an_reg;
+    else if (live) an = g.action[i];
     if (c.delay_steps > 0) {
         const int head = g.head;
         float4* slot = granule(g.S, g.G, i, VF_G_RING + head);

@@ -435,6 +435,7 @@ struct ChainState16 {
     float4 bias[8];              // bias of the layer in flight: [out tile] -> features 16 a + 4 gq .. + 3
     vf_gptr sv_base;         // saved copy of the previous layer's output (chain16_store_setup): uniform base (null: not kept) + lane byte offset
     unsigned sv_off;
+    float4 act;              // the action the head epilogue wrote to rp_action (lane group 0; k_bptt_rollout hands it on through LDS)
 };
 
 template <class N, int I>
@@ -514,8 +515,9 @@ __device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState1
                 if constexpr (N::HV != 4) {
                     if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers (as chain_epilogue)
                         const float4 e = g.rp_eps[row];
-                        g.rp_action[row] = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
-                                                       tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                        st.act = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
+                                             tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                        g.rp_action[row] = st.act;
                     }
                 }
             } else if constexpr (N::HV == 4) {
@@ -524,8 +526,9 @@ __device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState1
                     const f32x4& mu = st.t[2 * N::t_mean];
                     const float4 e = g.rp_eps[row];
                     const float lo = g.rp_ls_lo, hi = g.rp_ls_hi;
-                    g.rp_action[row] = make_float4(tanhf(mu[0] + e.x * expf(chain_clampf(y[0], lo, hi))), tanhf(mu[1] + e.y * expf(chain_clampf(y[1], lo, hi))),
-                                                   tanhf(mu[2] + e.z * expf(chain_clampf(y[2], lo, hi))), tanhf(mu[3] + e.w * expf(chain_clampf(y[3], lo, hi))));
+                    st.act = make_float4(tanhf(mu[0] + e.x * expf(chain_clampf(y[0], lo, hi))), tanhf(mu[1] + e.y * expf(chain_clampf(y[1], lo, hi))),
+                                         tanhf(mu[2] + e.z * expf(chain_clampf(y[2], lo, hi))), tanhf(mu[3] + e.w * expf(chain_clampf(y[3], lo, hi))));
+                    g.rp_action[row] = st.act;
                 }
             } else {
                 if (g.io.value) g.io.value[row] = y[0];
