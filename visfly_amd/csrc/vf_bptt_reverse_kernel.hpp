@@ -59,7 +59,9 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
     float* da_lds = lds + (size_t)2 * rows_ck * 256;                         // [16 slots] float4
     float* obs_lds = da_lds + 64;                                            // [16 slots][16] floats
     QuadCarry cy;
+    QuadLane ql;
     if constexpr (CKPT) {
+        ql = quad_lane(*cp, lane);
         fetch_record(r.H - 1);
         const int k = lane & 3;
         const float4 g0 = *granule(r.adj, r.G, iq, VF_G_POS), g1 = *granule(r.adj, r.G, iq, VF_G_QUAT), g2 = *granule(r.adj, r.G, iq, VF_G_VEL);
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         if constexpr (CKPT) {
             if (t > 0) fetch_record(t - 1);
             env_step_bwd_agent<KIND, ACT, INTEG, CTRL_DELAY, 64, true, true>(*cp, *ep, g, iq, true, lds + lane, lds4 + (size_t)(t & 1) * rows_ck * 64, &cy,
-                                                                             obs_lds, da_lds);
+                                                                             obs_lds, da_lds, &ql);
             // the record of step t - 1 and this step's masks were issued at the head of the step and the adjoint issued no other
             // vector-memory operation: they are back by now (on gfx9 vmcnt also counts STORES: waiting here, not behind the chain,
             // keeps the chain's 40-odd dZ stores out of the wait).  LDS operations of a wave execute in order.

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
     load_agent<true>(g.d.S, g.d.G, ic, s, sp);
     load_wind(c, g.d, ic, live, s);
     float disc = r.disc[ic], loss = r.loss[ic];
+    const QuadLane ql = quad_lane(c, lane);
     const int Gx = g.d.G;
     for (int t = 0; t < r.H; ++t) {
         // ---- policy forward + action head: rows t N + i of the slot buffers, action row of step t ----
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         ck.drag(g.d.S, Gx, ic, g.d.g_drag);
         float gate_pre = 0.0f;
         if constexpr (KIND == VF_ENV_RACING) gate_pre = granule(g.d.S, Gx, ic, g.g_race)->x;
-        control_interval_quad<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0, ck);
+        control_interval_quad<ACT, INTEG, CTRL_DELAY>(c, ql, s, a, kl, kq, g.d.vstrided != 0, ck);
         asm volatile("" :: "v"(eps_touch.x), "v"(eps_touch.y), "v"(eps_touch.z), "v"(eps_touch.w));
         float reward = 0.0f;
         bool done = false;

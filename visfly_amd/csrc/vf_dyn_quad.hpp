@@ -93,12 +93,12 @@ __device__ __forceinline__ void substep_c(const vf_dyn_cfg& c, const QuadLane& L
 // control_interval (vf_dyn_device.hpp) for an agent held by the four lanes of a quad: `s` is replicated in the quad on entry and on exit.
 // CK: head_c(sub, q, v, w, wm) / end_c(p, q, v, w) see this lane's components (vectors: lane 0 = 0)
 template <int ACT, int INTEG, bool CTRL_DELAY, class CK>
-__device__ __forceinline__ void control_interval_quad(const vf_dyn_cfg& c, Agent& s, const float* a, const float* kl, const float* kq, bool vstrided,
-                                                      const CK& ck)
+// L: quad_lane(c, lane), made once per launch by the caller (lane-dependent loads of the cfg matrices)
+__device__ __forceinline__ void control_interval_quad(const vf_dyn_cfg& c, const QuadLane& L, Agent& s, const float* a, const float* kl, const float* kq,
+                                                      bool vstrided, const CK& ck)
 {
     float Td[4];
     desired_thrusts<ACT>(c, s, a, Td, vstrided);
-    const QuadLane L = quad_lane(c, threadIdx.x);
     const int k = L.k;
     const float Td_c = q_sel4(k, Td[0], Td[1], Td[2], Td[3]);
     float wd_c = 0.0f;

@@ -101,7 +101,7 @@ __device__ __forceinline__ void derivs_bwd(const vf_dyn_cfg& c, const Quat& q, c
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY, int STRIDE, bool CKPT = false, bool QUAD = false>
 __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf_env_cfg& e, const BwdArgs& g, int i, bool live, float* lds_col,
                                                    const float4* rec = nullptr, QuadCarry* carry = nullptr, const float* d_obs_lds = nullptr,
-                                                   float* d_action_lds = nullptr)
+                                                   float* d_action_lds = nullptr, const QuadLane* quad = nullptr)
 {
     // QUAD: `carry` holds the adjoint of the persistent state from step to step (g.adj is not touched), the observation gradient of
     // the wave's agents comes from d_obs_lds ([16 slots][16] floats, LDS; read iff g.d_obs != nullptr), the action gradient goes to
@@ -121,7 +121,8 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     float dr_in = 0.0f, gate_bits = 0.0f;
     if constexpr (CKPT) {
         const float4* rin = rec + (c.interval_steps + 1) * 64;
-        const float4 e0 = rin[rec_slot], e1 = rin[16 + rec_slot], e2 = rin[32 + rec_slot], e3 = rin[48 + rec_slot];
+        float4 e0, e1, e2, e3;       // (reads the compiler does not order behind the LDS-DMA in flight: vf_quad.hpp)
+        lds_read4_opaque<256>(rin + rec_slot, e0, e1, e2, e3);
         s.w[0] = e0.x; s.w[1] = e0.y; s.w[2] = e0.z; sp.vel = e0.w;
         s.aa[0] = e1.x; s.aa[1] = e1.y; s.aa[2] = e1.z; sp.omg = e1.w;
         a[0] = e2.x; a[1] = e2.y; a[2] = e2.z; a[3] = e2.w;
@@ -133,7 +134,8 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
             head = (unsigned)head < (unsigned)c.delay_steps ? head : 0;
         }
         if (g.g_drag >= 0) {
-            const float4 x = rin[64 + rec_slot], y = rin[64 + 16 + rec_slot];
+            float4 x, y;
+            lds_read2_opaque(rin + 64 + rec_slot, x, y);
             kl[0] = x.y; kl[1] = x.z; kl[2] = x.w; kq[0] = y.y; kq[1] = y.z; kq[2] = y.w;
         } else {
 #pragma unroll
@@ -202,7 +204,8 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     const int mslot = rec_slot;
     if constexpr (CKPT) {
         // end row, component-major (TapeCheckpoint::end_c): the float4 at [k * 16 + slot] = (p_k, q_k, v_k, w_k), vectors as (0, x, y, z)
-        const float4 c0 = rec[S * 64 + mslot], c1 = rec[S * 64 + 16 + mslot], c2 = rec[S * 64 + 32 + mslot], c3 = rec[S * 64 + 48 + mslot];
+        float4 c0, c1, c2, c3;
+        lds_read4_opaque<256>(rec + S * 64 + mslot, c0, c1, c2, c3);
         s.p[0] = c1.x; s.p[1] = c2.x; s.p[2] = c3.x;
         s.q = Quat{c0.y, c1.y, c2.y, c3.y};
         s.v[0] = c1.z; s.v[1] = c2.z; s.v[2] = c3.z;
@@ -262,7 +265,8 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
             laa[0] = ca1; laa[1] = ca2; laa[2] = ca3;
             if (g.d_obs) {  // observation = [p, q, v + wind, w] of the post-step state (dynamics.py:779-786)
                 const float4* d4 = reinterpret_cast<const float4*>(d_obs_lds + 16 * rec_slot);
-                const float4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
+                float4 d0, d1, d2, d3;
+                lds_read4_opaque<16>(d4, d0, d1, d2, d3);
                 lp[0] += d0.x; lp[1] += d0.y; lp[2] += d0.z;
                 lq.w += d0.w; lq.x += d1.x; lq.y += d1.y; lq.z += d1.z;
                 lv[0] += d1.w; lv[1] += d2.x; lv[2] += d2.y;
@@ -368,11 +372,24 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
         if constexpr (KIND == VF_ENV_RACING) {
             int gate = __float_as_int(gate_bits);
             gate = (unsigned)gate < (unsigned)e.n_gates ? gate : 0;
+            // CKPT (persistent sweep): a per-lane indexed load of the gate table would be a vector load queued behind the step's
+            // HBM-cold mask / record fetches (vmcnt is one in-order counter); the table is 8 x 3 launch-uniform scalars: select
+            float gsel[3];
+            auto gate_pos = [&](int gi) {
+                gsel[0] = e.gates[0][0]; gsel[1] = e.gates[0][1]; gsel[2] = e.gates[0][2];
+#pragma unroll
+                for (int q = 1; q < VF_MAX_GATES; ++q) {
+                    const bool is = gi == q;
+                    gsel[0] = is ? e.gates[q][0] : gsel[0]; gsel[1] = is ? e.gates[q][1] : gsel[1]; gsel[2] = is ? e.gates[q][2] : gsel[2];
+                }
+            };
             const float* gt = e.gates[gate];
+            if constexpr (CKPT) { gate_pos(gate); gt = gsel; }
             const bool pass = norm3(s.p[0] - gt[0], s.p[1] - gt[1], s.p[2] - gt[2]) <= e.success_radius;
             gate = gate + (pass ? 1 : 0);
             gate = gate == e.n_gates ? 0 : gate;
             tgt = e.gates[gate];
+            if constexpr (CKPT) { gate_pos(gate); tgt = gsel; }
         }
         const float c1 = (float)(-0.1 * 1 / 9), c2 = (float)-0.00001, c3 = (float)-0.002;
         const float dp[3] = {s.p[0] - tgt[0], s.p[1] - tgt[1], s.p[2] - tgt[2]};
@@ -402,7 +419,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     const float inv_m = 1.0f / c.m;              // acc = rotate(q, u) / m: its adjoint multiplies by 1 / m (one division per step, see above)
     float lTraw_q = 0.0f;                        // QUAD: rotor qk's component of lTraw
     if constexpr (QUAD) {
-        const QuadLane QL = quad_lane(c, threadIdx.x);
+        const QuadLane& QL = *quad;      // (the caller's, made once per launch: 20 lane-dependent loads of cfg matrices otherwise sit in every step)
         QuadAdj qa{q_sel4(qk, lq.w, lq.x, lq.y, lq.z), q_sel3(qk, lv), q_sel3(qk, lw), q_sel3(qk, lp),
                    q_sel4(qk, lwm[0], lwm[1], lwm[2], lwm[3]), 0.0f, 0.0f, q_sel3(qk, ldw_in)};
         const float kl_c = q_sel3(qk, kl), kq_c = q_sel3(qk, kq);
@@ -410,7 +427,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
         // (q_k, v_k, w_k, rotor speed k) of agent slot mslot
         const float4* rq = rec + qk * 16 + mslot;
         for (int sub = S - 1; sub >= 0; --sub) {
-            const float4 h = rq[sub * 64];
+            const float4 h = lds_read1_opaque(rq + sub * 64);
             substep_bwd_c<INTEG, CTRL_DELAY>(c, QL, h.x, h.y, h.z, h.w, kl_c, kq_c, wd_c, Td_c, dt, inv_m, qa);
         }
         lq = Quat{qb<0>(qa.lq), qb<1>(qa.lq), qb<2>(qa.lq), qb<3>(qa.lq)};

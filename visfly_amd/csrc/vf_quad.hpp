@@ -36,6 +36,41 @@ __device__ __forceinline__ float q_nxt(float x) { return qdpp<VF_QP(0, 2, 3, 1)>
 __device__ __forceinline__ float q_prv(float x) { return qdpp<VF_QP(0, 3, 1, 2)>(x); }               // vector lanes: x <- z, y <- x, z <- y
 __device__ __forceinline__ float q_sx(float x, unsigned m) { return __uint_as_float(__float_as_uint(x) ^ m); }
 
+// LDS reads the compiler's wait-count insertion does not see.  k_bptt_reverse brings the NEXT step's record into the other half of an LDS
+// area with global_load_lds while the current step reads its own half; hipcc cannot tell the halves apart and orders every LDS read it
+// emits behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0) in front of the first read of a step = the HBM latency of the fetch it was
+// meant to hide, 2-3 us per step).  The kernel waits for a fetch explicitly, a whole step after issuing it.  stride: 256 B = 16 float4.
+typedef float vf_q4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr(const void* p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ float4 lds_read1_opaque(const float4* p)
+{
+    vf_q4 a;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(lds_addr(p)) : "memory");
+    return make_float4(a.x, a.y, a.z, a.w);
+}
+__device__ __forceinline__ void lds_read2_opaque(const float4* p, float4& r0, float4& r1)      // p[0], p[16]
+{
+    vf_q4 a, b;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(lds_addr(p)) : "memory");
+    r0 = make_float4(a.x, a.y, a.z, a.w); r1 = make_float4(b.x, b.y, b.z, b.w);
+}
+template <int STRIDE_BYTES>
+__device__ __forceinline__ void lds_read4_opaque(const float4* p, float4& r0, float4& r1, float4& r2, float4& r3)      // p[0], p[s], p[2 s], p[3 s]
+{
+    vf_q4 a, b, c2, d;
+    if constexpr (STRIDE_BYTES == 256)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:256\n\tds_read_b128 %2, %4 offset:512\n\tds_read_b128 %3, %4 offset:768\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b), "=&v"(c2), "=&v"(d) : "v"(lds_addr(p)) : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b), "=&v"(c2), "=&v"(d) : "v"(lds_addr(p)) : "memory");
+    r0 = make_float4(a.x, a.y, a.z, a.w); r1 = make_float4(b.x, b.y, b.z, b.w);
+    r2 = make_float4(c2.x, c2.y, c2.z, c2.w); r3 = make_float4(d.x, d.y, d.z, d.w);
+}
+
 struct QuadLane {
     int k;                               // lane & 3
     unsigned m1, m2, m3, mc;             // sign masks of qmul's terms 1..3 and of qconj for this lane
