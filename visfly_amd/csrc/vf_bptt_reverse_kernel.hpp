@@ -58,6 +58,11 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
     const int iq = min((int)blockIdx.x * ROWS + (lane >> 2), r.N - 1);      // the quads (lanes 4 m .. 4 m + 3) hold the agent the chain keeps in lanes m + 16 kq
     float* da_lds = lds + (size_t)2 * rows_ck * 256;                         // [16 slots] float4
     float* obs_lds = da_lds + 64;                                            // [16 slots][16] floats
+    float std_reg[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // exp(log_std) of the state-independent head, once per launch (see k_bptt_rollout)
+    if constexpr (!P::sac_head) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) std_reg[k] = expf(gb.rp_log_std[k]);
+    }
     QuadCarry cy;
     QuadLane ql;
     if constexpr (CKPT) {
@@ -115,6 +120,9 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
         asm volatile("" : "+s"(zero_t));
         BwdArgsChain gbt = gb;
         gbt.packed = gb.packed + zero_t;
+        gbt.rp_std_valid = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gbt.rp_std[k] = std_reg[k];
         if constexpr (ROWS == 16) {
             const int gq = lane_t >> 4;
             bwd16_prologue<P, 0>(gbt, st16, lane_t);

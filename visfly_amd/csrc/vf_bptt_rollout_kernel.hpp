@@ -99,6 +99,13 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
     load_wind(c, g.d, ic, live, s);
     float disc = r.disc[ic], loss = r.loss[ic];
     const QuadLane ql = quad_lane(c, lane);
+    // exp(log_std) of the state-independent head once per launch (the head epilogue loaded the four parameters one by one, each an
+    // L2 round trip in front of its expf: 2 us per step)
+    float std_reg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (Net::HV != 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) std_reg[k] = expf(gc.rp_log_std[k]);
+    }
     const int Gx = g.d.G;
     for (int t = 0; t < r.H; ++t) {
         // ---- policy forward + action head: rows t N + i of the slot buffers, action row of step t ----
@@ -116,6 +123,9 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
             ChainArgs gct = gc;
             gct.packed = gc.packed + zero_t;
             gct.params = gc.params + zero_t;
+            gct.rp_std_valid = 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gct.rp_std[k] = std_reg[k];
             ChainState16<Net> st;
             chain16_prologue<Net, 0>(gct, st, lane_t);
 #pragma unroll
@@ -144,7 +154,16 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         // ---- checkpoint for the adjoint: this agent's granules of tape row t = the slab before the step ----
         float* T = r.tape + (size_t)t * r.tape_stride;
         store_agent(T, Gx, ic, s, sp);
-        for (int q = VF_G_FIXED; q < Gx; ++q) *granule(T, Gx, ic, q) = *granule(g.d.S, Gx, ic, q);
+        // (the other granules -- delay ring, drag, race, spawn copies --, four loads per wait: one by one, every copy is an L2 round
+        // trip behind the stores above, 3-4 us per step at 11 granules)
+        for (int q0 = VF_G_FIXED; q0 < Gx; q0 += 4) {
+            float4 cp4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cp4[j] = *granule(g.d.S, Gx, ic, min(q0 + j, Gx - 1));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q0 + j < Gx) *granule(T, Gx, ic, q0 + j) = cp4[j];
+        }
         // ---- env step (k_env_rollout's body) ----
         float a[4], head_bits = 0.0f;
         const float head_pre = sp.vel, counter_pre = sp.omg;

@@ -158,6 +158,9 @@ struct ChainArgs {
     // HV == 4 classes (td_policies.Actor: the second head IS log_std, rp_log_std unused): clamp bounds of the state-dependent
     // log_std in action = tanh(mean + eps exp(clamp(log_std, lo, hi))) (k_shac_head_fwd's arithmetic)
     float rp_ls_lo, rp_ls_hi;
+    // a persistent caller's exp(rp_log_std[k]), computed once per launch (rp_std_valid != 0), instead of four loads + expf per pass
+    int rp_std_valid;
+    float rp_std[4];
 };
 
 __device__ __forceinline__ float chain_clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -515,8 +518,10 @@ __device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState1
                 if constexpr (N::HV != 4) {
                     if (g.rp_action) {     // k_reparam_fwd's arithmetic on the head still in registers (as chain_epilogue)
                         const float4 e = g.rp_eps[row];
-                        st.act = make_float4(tanhf(y[0] + expf(g.rp_log_std[0]) * e.x), tanhf(y[1] + expf(g.rp_log_std[1]) * e.y),
-                                             tanhf(y[2] + expf(g.rp_log_std[2]) * e.z), tanhf(y[3] + expf(g.rp_log_std[3]) * e.w));
+                        float sd[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sd[k] = g.rp_std_valid ? g.rp_std[k] : expf(g.rp_log_std[k]);
+                        st.act = make_float4(tanhf(y[0] + sd[0] * e.x), tanhf(y[1] + sd[1] * e.y), tanhf(y[2] + sd[2] * e.z), tanhf(y[3] + sd[3] * e.w));
                         g.rp_action[row] = st.act;
                     }
                 }

@@ -118,6 +118,9 @@ struct BwdArgsChain {
     // action = tanh(mean + eps exp(clamp(log_std, lo, hi))); both head gradients are formed from d_action (k_shac_head_bwd's arithmetic)
     const float4* rp_ls_rows;
     float rp_ls_lo, rp_ls_hi;
+    // a persistent caller's exp(rp_log_std[k]), computed once per launch (rp_std_valid != 0), instead of four loads + expf per pass
+    int rp_std_valid;
+    float rp_std[4];
 };
 
 // d log_std of one component: torch.clamp passes the gradient on the closed interval (k_shac_head_bwd)
@@ -627,8 +630,11 @@ __device__ __forceinline__ void bwd16_head_prologue(const BwdArgsChain& g, BwdSt
                     } else if (live && gq == 0) {
                         *reinterpret_cast<float4*>(const_cast<float*>(E.dY) + (size_t)rc * E.ld_dy) = dm;
                         float4 gl = PRE ? st.pg : g.rp_g_log_std[rc];
-                        gl.x += dm.x * expf(g.rp_log_std[0]) * e.x; gl.y += dm.y * expf(g.rp_log_std[1]) * e.y;
-                        gl.z += dm.z * expf(g.rp_log_std[2]) * e.z; gl.w += dm.w * expf(g.rp_log_std[3]) * e.w;
+                        float sd[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sd[k] = g.rp_std_valid ? g.rp_std[k] : expf(g.rp_log_std[k]);
+                        gl.x += dm.x * sd[0] * e.x; gl.y += dm.y * sd[1] * e.y;
+                        gl.z += dm.z * sd[2] * e.z; gl.w += dm.w * sd[3] * e.w;
                         g.rp_g_log_std[rc] = gl;
                     }
                 } else if constexpr (P::Net::HM == 1) {
