@@ -107,6 +107,8 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         for (int k = 0; k < 4; ++k) std_reg[k] = expf(gc.rp_log_std[k]);
     }
     const int Gx = g.d.G;
+    ChainState16<Net> st;
+    chain16_prologue<Net, 0>(gc, st, lane);
     for (int t = 0; t < r.H; ++t) {
         // ---- policy forward + action head: rows t N + i of the slot buffers, action row of step t ----
         {
@@ -126,8 +128,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
             gct.rp_std_valid = 1;
 #pragma unroll
             for (int k = 0; k < 4; ++k) gct.rp_std[k] = std_reg[k];
-            ChainState16<Net> st;
-            chain16_prologue<Net, 0>(gct, st, lane_t);
+            // (the first weight fragments of this step were requested at the end of the previous step's chain, see below)
 #pragma unroll
             for (int b = 0; b < Net::NB; ++b) {
                 const int w = gct.d.in_dim[b];
@@ -145,6 +146,18 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
             }
             chain16_items<Net, 0>(gct, st, lane_t, row, lrow, rc);
             if (gq == 0) act_lds[lane_t & 15] = st.act;
+            // the weight fragments the NEXT step's chain starts with (the same every step), requested here, in front of the env step's
+            // ~35 stores: vmcnt is ONE in-order counter of loads and stores on gfx9 -- requested at the head of the next chain they
+            // would return behind those stores' acknowledgements
+            if (t + 1 < r.H) {
+                int lane_n = lane;
+                asm volatile("" : "+v"(lane_n));
+                long zero_n = 0;
+                asm volatile("" : "+s"(zero_n));
+                ChainArgs gcn = gc;
+                gcn.packed = gc.packed + zero_n;
+                chain16_prologue<Net, 0>(gcn, st, lane_n);
+            }
         }
         // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
         // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)
@@ -156,13 +169,14 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         store_agent(T, Gx, ic, s, sp);
         // (the other granules -- delay ring, drag, race, spawn copies --, four loads per wait: one by one, every copy is an L2 round
         // trip behind the stores above, 3-4 us per step at 11 granules)
-        for (int q0 = VF_G_FIXED; q0 < Gx; q0 += 4) {
-            float4 cp4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cp4[j] = *granule(g.d.S, Gx, ic, min(q0 + j, Gx - 1));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (q0 + j < Gx) *granule(T, Gx, ic, q0 + j) = cp4[j];
+        for (int q0 = VF_G_FIXED; q0 < Gx; q0 += 4) {       // (indices past the last granule repeat it: same value to the same address)
+            const int q1 = min(q0 + 1, Gx - 1), q2 = min(q0 + 2, Gx - 1), q3 = min(q0 + 3, Gx - 1);
+            const float4 v0 = *granule(g.d.S, Gx, ic, q0), v1 = *granule(g.d.S, Gx, ic, q1), v2 = *granule(g.d.S, Gx, ic, q2),
+                         v3 = *granule(g.d.S, Gx, ic, q3);
+            *granule(T, Gx, ic, q0) = v0;
+            *granule(T, Gx, ic, q1) = v1;
+            *granule(T, Gx, ic, q2) = v2;
+            *granule(T, Gx, ic, q3) = v3;
         }
         // ---- env step (k_env_rollout's body) ----
         float a[4], head_bits = 0.0f;
