@@ -90,6 +90,11 @@ __device__ __forceinline__ void substep_c(const vf_dyn_cfg& c, const QuadLane& L
     x.q = x.q / nn;
 }
 
+struct NoCheckpointQuad {
+    __device__ __forceinline__ void head_c(int, float, float, float, float) const {}
+    __device__ __forceinline__ void end_c(float, float, float, float) const {}
+};
+
 // control_interval (vf_dyn_device.hpp) for an agent held by the four lanes of a quad: `s` is replicated in the quad on entry and on exit.
 // CK: head_c(sub, q, v, w, wm) / end_c(p, q, v, w) see this lane's components (vectors: lane 0 = 0)
 template <int ACT, int INTEG, bool CTRL_DELAY, class CK>

@@ -8,6 +8,9 @@
 // env counters ride in the spare components of the dynamics granules, so the env step
 // moves the same bytes as the bare dynamics step plus its outputs.
 #include "vf_env_epilogue.hpp"
+#ifdef VF_EXP_ENV_QUAD
+#include "vf_dyn_quad.hpp"
+#endif
 
 #pragma clang fp contract(off)
 
@@ -49,6 +52,45 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     const int wave = threadIdx.x >> 6;
     env_epilogue<KIND, true, 1, false, LAZY_SLOT>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
 }
+
+
+#ifdef VF_EXP_ENV_QUAD
+// Measurement build only (-DVF_EXP_ENV_QUAD, run with VISFLY_AMD_ENV_QUAD=1; profiles/r04_env_quad.txt): the env step with FOUR LANES PER
+// AGENT -- 16 agents per wave, 4 waves per SIMD at 65 536 agents, the sub-step loop in component layout (vf_dyn_quad.hpp, the loop the
+// persistent BPTT launches run), controller / epilogue / loads / stores replicated in the four lanes of a quad.  Bit-identical to
+// k_env_step (tests/test_env_gpu.py passes on it) and 1.5 x slower: the component-layout sub-step costs 1.03 us where the one-lane
+// form costs 0.55 (four waves of 166 instructions, a third of them DPP moves, issue at 3.7 cycles per instruction per SIMD).
+template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
+__global__ __launch_bounds__(kBlock) void k_env_step_quadrep(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g)
+{
+    const vf_dyn_cfg& c = *cp;
+    const vf_env_cfg& e = *ep;
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
+    if (g.helper) {
+        const int nbm = g.helper;
+        if ((int)blockIdx.x >= nbm) {
+            spawn_helper(e, g, ((int)blockIdx.x - nbm) * kBlock + (int)threadIdx.x);
+            return;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_first = blockIdx.x * 64 + wave * 16;
+    const int i = wave_first + (lane >> 2);
+    const bool live = i < g.d.N;
+    Agent s;
+    Spares sp;
+    float a[4], head_bits = 0.0f;
+    ring_exchange(c, g.d, i, live, head_bits, a);
+    load_agent<false>(g.d.S, g.d.G, i, s, sp);
+    load_wind(c, g.d, i, live, s);
+    if (c.delay_steps > 0) sp.vel = head_bits;
+    float kl[3], kq[3];
+    drag_of(c, g.d, i, kl, kq);
+    const QuadLane ql = quad_lane(c, lane);
+    control_interval_quad<ACT, INTEG, CTRL_DELAY>(c, ql, s, a, kl, kq, g.d.vstrided != 0, NoCheckpointQuad{});
+    env_epilogue<KIND, true, 4, false, false>(c, e, g, i, live, s, sp, wave_first, tile + wave * 64 * 13);
+}
+#endif
 
 // The part of the step that follows the dynamics interval, as a launch of its own (vf_env_finish_step): the dynamics ran
 // in vf_dyn_step on the same slab, an external scene manager then answered the collision query for the new poses
@@ -341,6 +383,28 @@ EnvKernel pick_env_split(const vf_env* h)
     }
 }
 
+#ifdef VF_EXP_ENV_QUAD
+template <int KIND>
+EnvKernel pick_env_quadrep_k(const vf_dyn_cfg& c)
+{
+    if (!c.ctrl_delay || c.integrator != VF_INT_EULER) return nullptr;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_env_step_quadrep<KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    if (c.action_type == VF_ACT_THRUST) return vf::k_env_step_quadrep<KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
+    return nullptr;
+}
+EnvKernel pick_env_quadrep(const vf_env* h)
+{
+    static const int on = [] { const char* e = getenv("VISFLY_AMD_ENV_QUAD"); return e ? atoi(e) : 0; }();
+    if (on != 1) return nullptr;
+    switch (h->cfg.kind) {
+    case VF_ENV_HOVER: return pick_env_quadrep_k<VF_ENV_HOVER>(h->dyn.cfg);
+    default: return nullptr;
+    }
+}
+#else
+EnvKernel pick_env_quadrep(const vf_env*) { return nullptr; }
+#endif
+
 EnvKernel pick_env_kernel(const vf_env* h)
 {
     const bool lazy = h->dyn.Npad > 2 * 65536;          // more than two waves per SIMD (k_env_step, LAZY_SLOT)
@@ -394,6 +458,13 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
         } else {
             h->stale_all = 1;
         }
+        EnvKernel kq = g.stale ? nullptr : pick_env_quadrep(h);
+        if (kq) {                                // 64 agents per main block
+            const unsigned nbm = h->dyn.Npad / 64;
+            if (g.helper) g.helper = (int)nbm;
+            nb = nbm + (g.helper ? h->dyn.Npad / vf::kBlock : 0);
+            hipLaunchKernelGGL(kq, dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
+        } else
         hipLaunchKernelGGL(pick_env_kernel(h), dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
     }
     VF_HIP(hipGetLastError());

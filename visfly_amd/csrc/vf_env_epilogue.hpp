@@ -207,13 +207,14 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     er.flags = set_flag(er.flags, VF_F_DONE, done);
 #ifndef VF_EXP_NO_DONE_LIST
     if (g.out.done_list) {                       // compacted done list: one atomic per wave that has an ending agent
-        const unsigned long long m = __ballot(live && done);
+        const bool mine = live && done && (LANES == 1 || (threadIdx.x & (LANES - 1)) == 0);   // (a quad: its first lane speaks for the agent)
+        const unsigned long long m = __ballot(mine);
         if (m) {
             const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
             int base = 0;
             if (lane == first) base = atomicAdd(g.out.done_count, __popcll(m));
             base = __shfl(base, first);
-            if (live && done) g.out.done_list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+            if (mine) g.out.done_list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
         }
     }
 #endif
