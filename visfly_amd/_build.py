@@ -15,6 +15,11 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Wall", "-Wno-unused-function"]
 
 
+# per-source extra flags.  The single-step kernels: the dispatcher preloads the leading kernel arguments into SGPRs (gfx940+), see k_env_step
+_PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+PER_SOURCE_FLAGS = {"vf_env.hip": _PRELOAD, "vf_dyn.hip": _PRELOAD}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -41,7 +46,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + cflags + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

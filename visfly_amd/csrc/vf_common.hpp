@@ -92,6 +92,46 @@ __device__ __forceinline__ void prefetch_kernarg()
                      "s"(x[19]), "s"(x[20]), "s"(x[21]), "s"(x[22]), "s"(x[23]));
     }
 }
+
+// The same for a constant block behind a kernel-argument POINTER (the persistent device copies of vf_dyn_cfg / vf_env_cfg the step kernels
+// read their constants through): one dword of each of the first LINES_A / LINES_B 64-byte lines of two blocks (+ one more word), all
+// requested in one batch and waited for once.
+// Without it the compiler fetches a field where it is first used, and every first touch of a line is a scalar-cache miss that a lone wave
+// sits out in full (L2 round trip): the env step touched ~12 lines one after the other between its loads and its stores.
+template <int LINES_A, int LINES_B>
+__device__ __forceinline__ void prefetch_const_lines(const void* __restrict__ a, const void* __restrict__ b, const void* __restrict__ c1)
+{
+    static_assert(LINES_A + LINES_B + 1 <= 16, "one batch");
+    const unsigned* wa = reinterpret_cast<const unsigned*>(a);
+    const unsigned* wb = reinterpret_cast<const unsigned*>(b);
+    unsigned x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        x[k] = k < LINES_A ? wa[16 * k] : k < LINES_A + LINES_B ? wb[16 * (k - LINES_A)] : k == LINES_A + LINES_B ? *reinterpret_cast<const unsigned*>(c1) : 0u;
+    asm volatile("" ::"s"(x[0]), "s"(x[1]), "s"(x[2]), "s"(x[3]), "s"(x[4]), "s"(x[5]), "s"(x[6]), "s"(x[7]), "s"(x[8]), "s"(x[9]),
+                 "s"(x[10]), "s"(x[11]), "s"(x[12]), "s"(x[13]), "s"(x[14]), "s"(x[15]));
+}
+
+// Both in ONE batch, for a kernel whose pointers to the constant blocks are preloaded kernel arguments (k_env_step): the remaining
+// kernel-argument lines do not have to arrive before the constant blocks can be asked for
+template <int KBYTES, int LINES_A, int LINES_B>
+__device__ __forceinline__ void prefetch_kernarg_and_const_lines(const void* __restrict__ a, const void* __restrict__ b, const void* __restrict__ c1)
+{
+    typedef const unsigned __attribute__((address_space(4))) * kptr;
+    const kptr wk = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int LK = (KBYTES + 63) / 64;
+    static_assert(LK + LINES_A + LINES_B + 1 <= 24, "one batch");
+    const unsigned* wa = reinterpret_cast<const unsigned*>(a);
+    const unsigned* wb = reinterpret_cast<const unsigned*>(b);
+    unsigned x[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k)
+        x[k] = k < LK ? wk[16 * k] : k < LK + LINES_A ? wa[16 * (k - LK)] : k < LK + LINES_A + LINES_B ? wb[16 * (k - LK - LINES_A)]
+             : k == LK + LINES_A + LINES_B ? *reinterpret_cast<const unsigned*>(c1) : 0u;
+    asm volatile("" ::"s"(x[0]), "s"(x[1]), "s"(x[2]), "s"(x[3]), "s"(x[4]), "s"(x[5]), "s"(x[6]), "s"(x[7]), "s"(x[8]), "s"(x[9]),
+                 "s"(x[10]), "s"(x[11]), "s"(x[12]), "s"(x[13]), "s"(x[14]), "s"(x[15]), "s"(x[16]), "s"(x[17]), "s"(x[18]),
+                 "s"(x[19]), "s"(x[20]), "s"(x[21]), "s"(x[22]), "s"(x[23]));
+}
 #endif
 
 // action head fused into the chain kernels (vf_mlp_forward_act / vf_mlp_backward_data_act); all-null: off

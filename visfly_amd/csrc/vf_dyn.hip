@@ -22,21 +22,36 @@ char* err_buf()
 
 // grid covers the padded agent count (multiple of 64); pad lanes integrate an inert hover state
 template <int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg* __restrict__ cp, const DynArgs g)
+__global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg* __restrict__ cp, float* S, const float4* action, float* obs, int N, int G,
+                                                     int g_drag, int head, int delay_steps, const DynArgs g0)
 {
+    // leading scalar arguments = fields of g0 + vf_dyn_cfg::delay_steps, preloaded into SGPRs by the dispatcher (this file is compiled with
+    // -mllvm -amdgpu-kernarg-preload-count=16): the first burst of loads is issued without a scalar-memory round trip, the remaining
+    // kernel-argument lines and the constant block arrive in one batch behind it (k_env_step, vf_env.hip)
     const vf_dyn_cfg& c = *cp;   // persistent device copy (vf_handles.hpp): stays L2-resident from launch to launch
     __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
+    DynArgs g = g0;
+    g.S = S; g.action = action; g.obs = obs; g.N = N; g.G = G; g.g_drag = g_drag; g.head = head;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.N;
     Agent s;
     Spares sp;
     float a[4], head_bits = 0.0f;
-    ring_exchange(c, g, i, live, head_bits, a);   // issued first: its two loads are the first values the controller needs
+    ring_exchange_d(g, i, live, head_bits, a, nullptr, delay_steps);   // issued first: its two loads are the first values the controller needs
     load_agent<false>(g.S, g.G, i, s, sp);
+    float4 dk0 = make_float4(0.f, 0.f, 0.f, 0.f), dk1 = dk0;
+    if (g.g_drag >= 0) { dk0 = *granule(g.S, g.G, i, g.g_drag); dk1 = *granule(g.S, g.G, i, g.g_drag + 1); }
+    prefetch_kernarg_and_const_lines<sizeof(DynArgs) + 56, (sizeof(vf_dyn_cfg) + 63) / 64, 0>(cp, cp, cp);
     load_wind(c, g, i, live, s);
-    if (c.delay_steps > 0) sp.vel = head_bits;
-    float kl[3], kq[3];
-    drag_of(c, g, i, kl, kq);
+    if (delay_steps > 0) sp.vel = head_bits;
+    float kl[3], kq[3];                                                // drag_of
+    if (g.g_drag >= 0) {
+        kl[0] = dk0.y; kl[1] = dk0.z; kl[2] = dk0.w;
+        kq[0] = dk1.y; kq[1] = dk1.z; kq[2] = dk1.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
+    }
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.vstrided != 0);
     store_agent(g.S, g.G, i, s, sp);
     if (g.obs) {
@@ -136,6 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_dyn_reset(const vf_dyn_cfg c, const 
 namespace {
 
 using StepKernel = void (*)(const vf_dyn_cfg*, const vf::DynArgs);
+using StepKernel1 = void (*)(const vf_dyn_cfg*, float*, const float4*, float*, int, int, int, int, int, const vf::DynArgs);
 
 StepKernel pick_split_kernel(const vf_dyn_cfg& c)
 {
@@ -154,7 +170,7 @@ StepKernel pick_split_kernel(const vf_dyn_cfg& c)
 }
 
 template <int ACT>
-StepKernel pick_step_kernel_a(const vf_dyn_cfg& c)
+StepKernel1 pick_step_kernel_a(const vf_dyn_cfg& c)
 {
     const int key = (c.integrator == VF_INT_RK4 ? 2 : 0) | (c.ctrl_delay ? 1 : 0);
     switch (key) {
@@ -165,7 +181,7 @@ StepKernel pick_step_kernel_a(const vf_dyn_cfg& c)
     }
 }
 
-StepKernel pick_step_kernel(const vf_dyn_cfg& c)
+StepKernel1 pick_step_kernel(const vf_dyn_cfg& c)
 {
     switch (c.action_type) {
     case VF_ACT_THRUST: return pick_step_kernel_a<VF_ACT_THRUST>(c);
@@ -183,7 +199,8 @@ int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st
     if (vf::use_split(h->Npad, h->cfg))
         hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->d_cfg, g);
     else
-        hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->d_cfg, g);
+        hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->d_cfg, g.S, g.action, g.obs, g.N, g.G,
+                           g.g_drag, g.head, h->cfg.delay_steps, g);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

@@ -620,21 +620,27 @@ __device__ __forceinline__ void load_wind(const vf_dyn_cfg& c, const DynArgs& g,
 // granule.  The per-agent head word in that granule's spare component is still advanced -- the adjoint kernel reads it
 // from its tape -- and a reset zeroes all slots, after which any head position is equivalent.
 // an_reg: the new action in a register (a persistent launch that just computed it) instead of g.action[i]
-__device__ __forceinline__ void ring_exchange(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, float& head_bits,
-                                              float* a, const float4* an_reg = nullptr)
+// D: c.delay_steps -- a parameter of its own for k_env_step, which has it as a preloaded kernel argument (the slot load then does not
+// wait for the constant block)
+__device__ __forceinline__ void ring_exchange_d(const DynArgs& g, int i, bool live, float& head_bits, float* a, const float4* an_reg, int D)
 {
     float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
     if (an_reg) an = *an_reg;
     else if (live) an = g.action[i];
-    if (c.delay_steps > 0) {
+    if (D > 0) {
         const int head = g.head;
         float4* slot = granule(g.S, g.G, i, VF_G_RING + head);
         const float4 old = *slot;
         st4(slot, an);
         an = old;
-        head_bits = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
+        head_bits = __int_as_float(head + 1 == D ? 0 : head + 1);
     }
     a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
+}
+__device__ __forceinline__ void ring_exchange(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, float& head_bits,
+                                              float* a, const float4* an_reg = nullptr)
+{
+    ring_exchange_d(g, i, live, head_bits, a, an_reg, c.delay_steps);
 }
 
 __device__ __forceinline__ void drag_of(const vf_dyn_cfg& c, const DynArgs& g, int i, float* kl, float* kq)

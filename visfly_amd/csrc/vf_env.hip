@@ -14,43 +14,132 @@
 
 #pragma clang fp contract(off)
 
+#ifdef VF_ENV_TRACE   // measurement build only (tools/exp_env_timeline.py): wall-clock (100 MHz) stamps of every main wave of k_env_step
+__device__ unsigned long long* vf_env_trace_buf = nullptr;
+__device__ unsigned vf_env_trace_cnt = 0, vf_env_trace_cap = 0;
+extern "C" int vf_debug_env_trace(unsigned long long* buf, unsigned cap)
+{
+    unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vf_env_trace_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vf_env_trace_cnt), &zero, sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vf_env_trace_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+    return 0;
+}
+#define VF_TR(i) tr[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define VF_TR(i)
+#endif
+
 namespace vf {
 
 // LAZY_SLOT: the prefetched re-spawn copy is loaded only by the lanes that end an episode instead of by every lane
 // (load_spawn_slot).  One wave per SIMD: an ending wave must not sit out the load latency -> every lane loads.  More than two waves
 // per SIMD: the step is bandwidth-bound, a stalled wave costs nothing and 64 B per agent of loads nobody looks at cost 7 %
 // (1 M agents: 99 vs 92.5 us) -> lazily.  Two kernels, not a branch: both epilogues in one kernel cost the small launch 0.1 us.
+// The leading scalar arguments repeat fields of `g0` (and vf_dyn_cfg::delay_steps): this file is compiled with
+// -mllvm -amdgpu-kernarg-preload-count=16, which has the dispatcher place the first 14 dwords of the kernel-argument segment in SGPRs
+// before the wave starts (16 user SGPRs less the segment pointer; scalar arguments only -- a by-value struct is not preloaded).
+// Everything the first burst of loads needs (slab, action rows, N, G, ring slot, drag granule) is among them, so the burst is issued without a single scalar-memory round trip;
+// the rest of the kernel arguments and the two constant blocks arrive, in ONE batch, while it is in flight.  Before: kernel arguments
+// (0.4 us), then the constant block for delay_steps (0.4 us), then the loads (timeline: profiles/r04_env_timeline.txt).
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY, bool LAZY_SLOT = false>
-__global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g)
+__global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, float* S,
+                                                     const float4* action, int N, int G, int head, int helper, int delay_steps,
+                                                     int g_drag, const EnvArgs g0)
 {
     const vf_dyn_cfg& c = *cp;   // persistent device copies (vf_handles.hpp): L2-resident from launch to launch
     const vf_env_cfg& e = *ep;
     __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
+    EnvArgs g = g0;
+    g.d.S = S; g.d.action = action; g.d.N = N; g.d.G = G; g.d.head = head; g.helper = helper; g.d.g_drag = g_drag;
 #ifndef VF_EXP_NO_HELPER
-    if (g.helper) {                                  // the blocks behind the g.helper main blocks: helper blocks (prefetched re-spawn),
-        const int nbm = g.helper;                    // kHelperSpan agents per thread (a workgroup dispatch costs more than their checks)
-        if ((int)blockIdx.x >= nbm) {
-            const int base = ((int)blockIdx.x - nbm) * kHelperSpan * kBlock + (int)threadIdx.x;
+    // the blocks behind the g.helper main blocks: helper blocks (prefetched re-spawn), kHelperSpan agents per thread (a workgroup dispatch
+    // costs more than their checks).  Marked unlikely: the instruction cache is cold at every launch, and a main wave whose first
+    // instruction is a taken branch over the helper's code starts with a miss (timeline: 0.3 us from entry to the first load)
+    if (__builtin_expect(g.helper != 0 && (int)blockIdx.x >= g.helper, 0)) {
+        const int nbm = g.helper;
+        const int base = ((int)blockIdx.x - nbm) * kHelperSpan * kBlock + (int)threadIdx.x;
 #pragma unroll 1
-            for (int k = 0; k < kHelperSpan; ++k) spawn_helper(e, g, base + k * kBlock);
-            return;
-        }
+        for (int k = 0; k < kHelperSpan; ++k) spawn_helper(e, g, base + k * kBlock);
+        return;
     }
 #endif
+#ifdef VF_ENV_TRACE
+    unsigned long long tr[13];
+#endif
+    VF_TR(0);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < g.d.N;
     Agent s;
     Spares sp;
     float a[4], head_bits = 0.0f;
-    ring_exchange(c, g.d, i, live, head_bits, a);   // issued first: its two loads are the first values the controller needs
+    ring_exchange_d(g.d, i, live, head_bits, a, nullptr, delay_steps);   // issued first: its two loads are the first values the controller needs
     load_agent<false>(g.d.S, g.d.G, i, s, sp);
+    float4 dk0 = make_float4(0.f, 0.f, 0.f, 0.f), dk1 = dk0;
+    if (g.d.g_drag >= 0) { dk0 = *granule(g.d.S, g.d.G, i, g.d.g_drag); dk1 = *granule(g.d.S, g.d.G, i, g.d.g_drag + 1); }
+#ifndef VF_EXP_NO_CFG_PREFETCH
+    // ... and behind the burst ONE batch of scalar loads: the remaining kernel-argument lines and the lines of the two constant blocks
+    // (first touched one after the other on the way, each was a round trip a lone wave sits out in full)
+#ifdef VF_ENV_TRACE
+    VF_TR(1);                                        // vector loads issued
+    prefetch_const_lines<(sizeof(vf_dyn_cfg) + 63) / 64, 2>(cp, ep, &ep->obs_mode);
+    VF_TR(2);                                        // constant-block lines arrived
+    prefetch_kernarg<sizeof(EnvArgs) + 64>();
+    VF_TR(3);                                        // kernel-argument lines arrived
+#else
+    prefetch_kernarg_and_const_lines<sizeof(EnvArgs) + 64, (sizeof(vf_dyn_cfg) + 63) / 64, 2>(cp, ep, &ep->obs_mode);
+#endif
+#endif
     load_wind(c, g.d, i, live, s);
-    if (c.delay_steps > 0) sp.vel = head_bits;
-    float kl[3], kq[3];
-    drag_of(c, g.d, i, kl, kq);
+    if (delay_steps > 0) sp.vel = head_bits;
+    float kl[3], kq[3];                                                       // drag_of
+    if (g.d.g_drag >= 0) {
+        kl[0] = dk0.y; kl[1] = dk0.z; kl[2] = dk0.w;
+        kq[0] = dk1.y; kq[1] = dk1.z; kq[2] = dk1.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { kl[k] = c.k_lin[k]; kq[k] = c.k_quad[k]; }
+    }
+#ifdef VF_ENV_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VF_TR(4);                                        // loads arrived
+    struct TraceCk {
+        unsigned long long* tr;
+        __device__ __forceinline__ void head(int sub, const Agent& s) const
+        {
+            if (sub < 2) { asm volatile("" :: "v"(s.wm[0]), "v"(s.q.w) : "memory"); tr[5 + sub] = __builtin_amdgcn_s_memrealtime(); }
+        }
+        __device__ __forceinline__ void end(const Agent&) const {}
+    };
+    control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0, TraceCk{tr});
+    asm volatile("" :: "v"(s.p[0]), "v"(s.q.w), "v"(s.v[0]), "v"(s.w[0]) : "memory");
+    VF_TR(7);                                        // interval done
+#else
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
+#endif
     const int wave = threadIdx.x >> 6;
+#ifdef VF_ENV_TRACE
+    env_epilogue<KIND, true, 1, false, LAZY_SLOT>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13, nullptr, nullptr, tr);
+    asm volatile("" ::: "memory");
+    VF_TR(11);                                       // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VF_TR(12);                                       // stores acknowledged
+    if ((threadIdx.x & 63) == 0 && vf_env_trace_buf) {
+        const unsigned slot = atomicAdd(&vf_env_trace_cnt, 1u);
+        if (slot < vf_env_trace_cap) {
+            unsigned long long* o = vf_env_trace_buf + (size_t)slot * 16;
+            for (int k = 0; k < 13; ++k) o[k] = tr[k];
+            o[13] = ((unsigned long long)blockIdx.x << 8) | wave;
+            unsigned xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned hwid = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            o[14] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+#else
     env_epilogue<KIND, true, 1, false, LAZY_SLOT>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+#endif
 }
 
 
@@ -295,9 +384,10 @@ struct vf_env_graph {
 namespace {
 
 using EnvKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvArgs);
+using EnvStepKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, float*, const float4*, int, int, int, int, int, int, const vf::EnvArgs);
 
 template <int KIND, int ACT, bool LAZY>
-EnvKernel pick_env_kernel_ka(const vf_dyn_cfg& c)
+EnvStepKernel pick_env_kernel_ka(const vf_dyn_cfg& c)
 {
     const int key = (c.integrator == VF_INT_RK4 ? 2 : 0) | (c.ctrl_delay ? 1 : 0);
     switch (key) {
@@ -309,7 +399,7 @@ EnvKernel pick_env_kernel_ka(const vf_dyn_cfg& c)
 }
 
 template <int KIND, bool LAZY>
-EnvKernel pick_env_kernel_kl(const vf_dyn_cfg& c)
+EnvStepKernel pick_env_kernel_kl(const vf_dyn_cfg& c)
 {
     switch (c.action_type) {
     case VF_ACT_THRUST: return pick_env_kernel_ka<KIND, VF_ACT_THRUST, LAZY>(c);
@@ -320,7 +410,7 @@ EnvKernel pick_env_kernel_kl(const vf_dyn_cfg& c)
 }
 
 template <int KIND>
-EnvKernel pick_env_kernel_k(const vf_dyn_cfg& c, bool lazy)
+EnvStepKernel pick_env_kernel_k(const vf_dyn_cfg& c, bool lazy)
 {
     return lazy ? pick_env_kernel_kl<KIND, true>(c) : pick_env_kernel_kl<KIND, false>(c);
 }
@@ -405,7 +495,7 @@ EnvKernel pick_env_quadrep(const vf_env* h)
 EnvKernel pick_env_quadrep(const vf_env*) { return nullptr; }
 #endif
 
-EnvKernel pick_env_kernel(const vf_env* h)
+EnvStepKernel pick_env_kernel(const vf_env* h)
 {
     const bool lazy = h->dyn.Npad > 2 * 65536;          // more than two waves per SIMD (k_env_step, LAZY_SLOT)
     switch (h->cfg.kind) {
@@ -465,7 +555,8 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
             nb = nbm + (g.helper ? h->dyn.Npad / vf::kBlock : 0);
             hipLaunchKernelGGL(kq, dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
         } else
-        hipLaunchKernelGGL(pick_env_kernel(h), dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
+        hipLaunchKernelGGL(pick_env_kernel(h), dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g.d.S, g.d.action, g.d.N, g.d.G,
+                           g.d.head, g.helper, h->dyn.cfg.delay_steps, g.d.g_drag, g);
     }
     VF_HIP(hipGetLastError());
     return VF_OK;

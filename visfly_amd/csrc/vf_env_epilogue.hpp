@@ -126,8 +126,13 @@ __device__ __forceinline__ SpawnSlot load_spawn_slot(const EnvArgs& g, int i, bo
 template <int KIND, bool STORE_STATE = true, int LANES = 1, bool EXT = false, bool LAZY_SLOT = false>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile, float* reward_reg = nullptr,
-                                             bool* done_reg = nullptr)
+                                             bool* done_reg = nullptr, unsigned long long* tr = nullptr)   // tr: -DVF_ENV_TRACE builds only
 {
+#ifdef VF_ENV_TRACE
+#define VF_EPI_TR(k, x) do { if (tr) { asm volatile("" :: "v"(x) : "memory"); tr[k] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define VF_EPI_TR(k, x)
+#endif
     EnvRegs er = unpack_env(sp);
     const float vel[3] = {s.v[0] + s.wnd[0], s.v[1] + s.wnd[1], s.v[2] + s.wnd[2]};  // dynamics.py:751-752
     Collision col = bbox_collision(e, s.p);
@@ -200,6 +205,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         reward = reward + (pass ? 1.0f : 0.0f) * 20.0f;
         race.z = __int_as_float(pass ? 1 : 0);
     }
+    VF_EPI_TR(8, reward);                                                                // collision, done decision, reward
     er.rewards = er.rewards + reward;                                                    // :185
     er.flags = set_flag(er.flags, VF_F_EPISODE_DONE, ep_done);
     er.flags = set_flag(er.flags, VF_F_SUCCESS, success);
@@ -226,7 +232,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         if (reward_reg) *reward_reg = reward;       // (callers that keep going with the agent in registers: vf_bptt_rollout.hip)
         if (done_reg) *done_reg = done;
         g.out.done[i] = done ? 1 : 0;
-        if (done) {  // collect_info (:238-275)
+        if (__builtin_expect(done, 0)) {  // collect_info (:238-275)
             if (g.out.ep_return) g.out.ep_return[i] = er.rewards;
             if (g.out.ep_length) g.out.ep_length[i] = er.step_count;
             if (g.out.ep_flags)
@@ -251,7 +257,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
             atomicOr(g.stale + g.n_tiles + (i >> 6), ending);
         }
     }
-    if (done && g.auto_reset) {  // examine() -> reset_agent_by_id (:339-349,420-423)
+    if (__builtin_expect(done && g.auto_reset, 0)) {  // examine() -> reset_agent_by_id (:339-349,420-423); unlikely: laid out behind the hot path (cold instruction cache at every launch)
         unsigned episode = ((unsigned)er.flags >> 8) + 1u;
         if constexpr (KIND == VF_ENV_RACING) {
             // RacingEnv.reset_agent_by_id (RacingEnv.py:150-163) picks the next gate BEFORE the base class
@@ -294,7 +300,9 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         if (live && g.out.gate) g.out.gate[i] = gate;
     }
     pack_env(er, sp);
+    VF_EPI_TR(9, sp.acc);                                                                // outputs written, re-spawn decided
     if constexpr (STORE_STATE) store_agent(g.d.S, g.d.G, i, s, sp);
+    VF_EPI_TR(10, sp.acc);                                                               // state stores issued
     if constexpr (LANES == 4) store_rows_quads<13>(g.out.obs, g.d.N, wave_first, o, tile);
     else store_rows_coalesced<13>(g.out.obs, g.d.N, wave_first, o, tile);
 }
