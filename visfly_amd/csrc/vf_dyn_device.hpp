@@ -540,6 +540,28 @@ __device__ __forceinline__ void st1(float* p, const float v)
 #endif
 }
 
+// store with an explicit cache policy (A/B experiments: -DVF_EXP_EARLY): 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1
+template <int MODE>
+__device__ __forceinline__ void st4_mode(float4* p, const float4 v)
+{
+    if constexpr (MODE == 0) {
+        st4(p, v);
+    } else {
+        const vf_f4 x = {v.x, v.y, v.z, v.w};
+        if constexpr (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+        else if constexpr (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void st1_mode(float* p, const float v)
+{
+    if constexpr (MODE == 0) st1(p, v);
+    else if constexpr (MODE == 1) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    else if constexpr (MODE == 2) asm volatile("global_store_dword %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 // ---- slab I/O: wave-tile AoSoA, one 16-byte granule per lane per access ----
 // float4 address of (agent i, granule g): see include/visfly_amd.h
 __device__ __forceinline__ float4* granule(float* __restrict__ S, int G, int i, int g)
@@ -667,7 +689,7 @@ __device__ __forceinline__ void obs_row(const vf_dyn_cfg& c, const Agent& s, flo
 // AoS (N,C) output through LDS so that the global stores are coalesced dwords.  Wave-local: lane l parks
 // its C-float row at tile[l*C..] (C odd -> conflict-free), then the wave streams its 64 rows out linearly.
 // No workgroup barrier: one wave's LDS operations execute in order.  `tile` holds 64*C floats per wave.
-template <int C>
+template <int C, int MODE = 0>
 __device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, int N, int wave_first, const float* row,
                                                      float* tile)
 {
@@ -686,7 +708,7 @@ __device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, in
 #pragma unroll
         for (int k = 0; k < (Q + 63) / 64; ++k) {
             const int j = k * 64 + l;
-            if (j < Q) st4(reinterpret_cast<float4*>(dst) + j, *reinterpret_cast<const float4*>(tile + 4 * j));
+            if (j < Q) st4_mode<MODE>(reinterpret_cast<float4*>(dst) + j, *reinterpret_cast<const float4*>(tile + 4 * j));
         }
         return;
     }
@@ -694,7 +716,7 @@ __device__ __forceinline__ void store_rows_coalesced(float* __restrict__ out, in
 #pragma unroll
     for (int k = 0; k < C; ++k) {
         const int j = k * 64 + l;
-        if (j < total) st1(dst + j, tile[j]);
+        if (j < total) st1_mode<MODE>(dst + j, tile[j]);
     }
 }
 

@@ -118,6 +118,23 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
 #endif
     const int wave = threadIdx.x >> 6;
+#ifdef VF_EXP_EARLY
+    {   // A/B experiment: what the interval finalised goes out BEFORE collision / reward / counters, with cache policy VF_EXP_EARLY - 1
+        constexpr int EM = VF_EXP_EARLY - 1;
+        float* S_ = g.d.S;
+        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_POS), make_float4(s.t, s.p[0], s.p[1], s.p[2]));
+        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_QUAT), make_float4(s.q.w, s.q.x, s.q.y, s.q.z));
+        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_VEL), make_float4(sp.vel, s.v[0], s.v[1], s.v[2]));
+        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_MOT), make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]));
+        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_THR), make_float4(s.T[0], s.T[1], s.T[2], s.T[3]));
+        float o[13];
+        obs_row(c, s, o);
+        obs_variant(e, o);
+        store_rows_coalesced<13, EM>(g.out.obs, g.d.N, blockIdx.x * kBlock + wave * 64, o, tile + wave * 64 * 13);
+    }
+    env_epilogue<KIND, true, 1, false, LAZY_SLOT, VF_EXP_EARLY>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
+    return;
+#endif
 #ifdef VF_ENV_TRACE
     env_epilogue<KIND, true, 1, false, LAZY_SLOT>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13, nullptr, nullptr, tr);
     asm volatile("" ::: "memory");

@@ -123,7 +123,10 @@ __device__ __forceinline__ SpawnSlot load_spawn_slot(const EnvArgs& g, int i, bo
 
 // LANES = 4: the agent is held by the four lanes of a quad (lanes 4 m .. 4 m + 3 = row m of the wave's 16, k_bptt_rollout): only the
 // row hand-over at the end depends on the lane <-> agent map
-template <int KIND, bool STORE_STATE = true, int LANES = 1, bool EXT = false, bool LAZY_SLOT = false>
+// EARLY (A/B experiment -DVF_EXP_EARLY, k_env_step only): 0 = off; 1 + m = the caller has already stored, with cache policy m (st4_mode), the
+// granules the interval finalises (POS, QUAT, VEL, MOT, THR) and the observation row; the epilogue then stores the three granules that
+// carry the env counters and, for an agent that re-spawns, those five and its row once more
+template <int KIND, bool STORE_STATE = true, int LANES = 1, bool EXT = false, bool LAZY_SLOT = false, int EARLY = 0>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile, float* reward_reg = nullptr,
                                              bool* done_reg = nullptr, unsigned long long* tr = nullptr)   // tr: -DVF_ENV_TRACE builds only
@@ -292,6 +295,19 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         er.rewards = 0.0f;
         obs_row(c, s, o);
         obs_variant(e, o);
+        if constexpr (EARLY != 0) {
+            if (live) {
+                float* to = g.out.obs + 13 * (size_t)i;
+#pragma unroll
+                for (int k = 0; k < 13; ++k) st1_mode<EARLY - 1>(to + k, o[k]);
+            }
+            float* S_ = g.d.S;
+            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_POS), make_float4(s.t, s.p[0], s.p[1], s.p[2]));
+            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_QUAT), make_float4(s.q.w, s.q.x, s.q.y, s.q.z));
+            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_VEL), make_float4(sp.vel, s.v[0], s.v[1], s.v[2]));
+            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_MOT), make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]));
+            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_THR), make_float4(s.T[0], s.T[1], s.T[2], s.T[3]));
+        }
     }
     if constexpr (KIND == VF_ENV_RACING) {
         race.x = __int_as_float(gate);
@@ -301,6 +317,12 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     }
     pack_env(er, sp);
     VF_EPI_TR(9, sp.acc);                                                                // outputs written, re-spawn decided
+    if constexpr (EARLY != 0) {
+        st4(granule(g.d.S, g.d.G, i, VF_G_OMG), make_float4(sp.omg, s.w[0], s.w[1], s.w[2]));
+        st4(granule(g.d.S, g.d.G, i, VF_G_AACC), make_float4(sp.aacc, s.aa[0], s.aa[1], s.aa[2]));
+        st4(granule(g.d.S, g.d.G, i, VF_G_ACC), make_float4(sp.acc, s.acc[0], s.acc[1], s.acc[2]));
+        return;
+    }
     if constexpr (STORE_STATE) store_agent(g.d.S, g.d.G, i, s, sp);
     VF_EPI_TR(10, sp.acc);                                                               // state stores issued
     if constexpr (LANES == 4) store_rows_quads<13>(g.out.obs, g.d.N, wave_first, o, tile);
