@@ -685,8 +685,8 @@ def main():
                          "kernel_us_300_launches_one_action": kern_us_300,
                          "bytes_per_agent_step": BYTES_PER_ENV_STEP, "valu_issue": valu,
                          "note": "bound by the contract's definition (algorithmic HBM bytes / launch time); the launch is in fact "
-                                 "limited by single-wave VALU issue (valu_issue) plus ~4 us of launch boundary and state round "
-                                 "trip per step -- profiles/r02_env_step_ablation.txt, DESIGN.md 4",
+                                 "limited by single-wave VALU issue (valu_issue: ~7.5 us of wave life, all but its first 0.7 us VALU) plus "
+                                 "~2.5 us of dispatch ramp and completion per launch -- wave timeline in profiles/r04_env_timeline.txt, DESIGN.md 4",
                          "dyn_only": {"kernel": "k_dyn_step<bodyrate,euler,ctrl_delay>", "kernel_us": dyn_us,
                                       "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
                                       "achieved": BYTES_PER_AGENT_STEP * N / (dyn_us * 1e-6) / 1e9}},
