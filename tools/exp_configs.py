@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get('VF_ALT_LIB'):     # another build of the library (A/B)
+    from visfly_amd import _build, _lib
+    _build.LIB = _lib.LIB = os.environ['VF_ALT_LIB']
 from visfly_amd.envs import HoverEnv, NavigationEnv, RacingEnv
 DEV = "cuda:0"
 base = dict(dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)

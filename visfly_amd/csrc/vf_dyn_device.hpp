@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "vf_common.hpp"
 #include "vf_xmath.hpp"
 #include "visfly_amd.h"
 
@@ -757,8 +758,12 @@ __device__ __forceinline__ void lds_publish_barrier()
 }
 
 // rotation wave: everything that does not need p / v.  Returns after the final hand-off.
-template <int ACT, int INTEG, bool CTRL_DELAY>
-__device__ __forceinline__ void split_rotation_wave(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, SplitShared& sh)
+// D: c.delay_steps when the caller has it as a preloaded kernel argument (k_env_step_split), else -1
+// PFK > 0: behind the first loads, one batch of scalar loads touches the PFK bytes of kernel arguments and the lines of the constant
+// blocks pf_a (vf_dyn_cfg) / pf_b (first two lines) + the word at pf_c (prefetch_kernarg_and_const_lines, vf_common.hpp)
+template <int ACT, int INTEG, bool CTRL_DELAY, int PFK = 0>
+__device__ __forceinline__ void split_rotation_wave(const vf_dyn_cfg& c, const DynArgs& g, int i, bool live, SplitShared& sh, int D = -1,
+                                                    const void* pf_b = nullptr, const void* pf_c = nullptr)
 {
     const int l = threadIdx.x & 63;
     const float4 g1 = *granule(g.S, g.G, i, VF_G_QUAT), g3 = *granule(g.S, g.G, i, VF_G_OMG);
@@ -772,7 +777,9 @@ __device__ __forceinline__ void split_rotation_wave(const vf_dyn_cfg& c, const D
     s.T[0] = g5.x; s.T[1] = g5.y; s.T[2] = g5.z; s.T[3] = g5.w;
     s.aa[0] = g6.y; s.aa[1] = g6.z; s.aa[2] = g6.w;
     float a[4];
-    ring_exchange(c, g, i, live, head_bits, a);   // pushes the new action; the translation wave advances the head word
+    if (D >= 0) ring_exchange_d(g, i, live, head_bits, a, nullptr, D);   // pushes the new action; the translation wave advances the head word
+    else ring_exchange(c, g, i, live, head_bits, a);
+    if constexpr (PFK > 0) prefetch_kernarg_and_const_lines<PFK, (sizeof(vf_dyn_cfg) + 63) / 64, 2>(&c, pf_b, pf_c);
     float Td[4], wd[4];
     desired_thrusts<ACT>(c, s, a, Td);
     rotor_setpoint<CTRL_DELAY>(c, Td, wd);
@@ -797,13 +804,14 @@ __device__ __forceinline__ void split_rotation_wave(const vf_dyn_cfg& c, const D
 }
 
 // translation wave: p, v, acc through the sub-steps, then assembles the full agent state (clamped, t advanced)
-template <int INTEG>
+template <int INTEG, int PFK = 0>
 __device__ __forceinline__ void split_translation_wave(const vf_dyn_cfg& c, const DynArgs& g, int i, SplitShared& sh, Agent& s,
-                                                       Spares& sp)
+                                                       Spares& sp, int D = -1, const void* pf_b = nullptr, const void* pf_c = nullptr)
 {
     const int l = threadIdx.x & 63;
     const float4 g0 = *granule(g.S, g.G, i, VF_G_POS), g2 = *granule(g.S, g.G, i, VF_G_VEL);
     const float4 g7 = *granule(g.S, g.G, i, VF_G_ACC);
+    if constexpr (PFK > 0) prefetch_kernarg_and_const_lines<PFK, (sizeof(vf_dyn_cfg) + 63) / 64, 2>(&c, pf_b, pf_c);
     float kl[3], kq[3];
     drag_of(c, g, i, kl, kq);
     load_wind(c, g, i, i < g.N, s);
@@ -812,8 +820,9 @@ __device__ __forceinline__ void split_translation_wave(const vf_dyn_cfg& c, cons
     s.acc[0] = g7.y; s.acc[1] = g7.z; s.acc[2] = g7.w;
     sp.acc = g7.x;
     sp.vel = g2.x;
-    if (c.delay_steps > 0)    // same head update ring_exchange applies (the rotation wave did the exchange itself)
-        sp.vel = __int_as_float(g.head + 1 == c.delay_steps ? 0 : g.head + 1);
+    const int Dd = D >= 0 ? D : c.delay_steps;
+    if (Dd > 0)    // same head update ring_exchange applies (the rotation wave did the exchange itself)
+        sp.vel = __int_as_float(g.head + 1 == Dd ? 0 : g.head + 1);
     for (int sub = 0; sub < c.interval_steps; ++sub) {
         __builtin_amdgcn_s_barrier();
         const float(*x)[64] = sh.xq[sub & 1];

@@ -259,23 +259,28 @@ __global__ __launch_bounds__(kBlock) void k_env_rollout(const vf_dyn_cfg* __rest
 // waves for 128 agents (one wave per SIMD of the CU); the translation waves own the env epilogue and
 // every store.
 template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_env_step_split(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g)
+__global__ __launch_bounds__(kBlock) void k_env_step_split(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, float* S,
+                                                           const float4* action, int N, int G, int head, int helper, int delay_steps,
+                                                           int g_drag, const EnvArgs g0)
 {
+    // (leading scalar arguments: preloaded into SGPRs, see k_env_step; `helper` unused here, kept for one launch signature)
     const vf_dyn_cfg& c = *cp;
     const vf_env_cfg& e = *ep;
     __shared__ __attribute__((aligned(16))) SplitShared shs[2];
+    EnvArgs g = g0;
+    g.d.S = S; g.d.action = action; g.d.N = N; g.d.G = G; g.d.head = head; g.d.g_drag = g_drag;
     const int grp = (threadIdx.x >> 6) & 1;
     SplitShared& sh = shs[grp];
     const int first = blockIdx.x * 128 + grp * 64;
     const int i = first + (threadIdx.x & 63);
     const bool live = i < g.d.N;
     if (threadIdx.x < 128) {
-        split_rotation_wave<ACT, INTEG, CTRL_DELAY>(c, g.d, i, live, sh);
+        split_rotation_wave<ACT, INTEG, CTRL_DELAY, sizeof(EnvArgs) + 64>(c, g.d, i, live, sh, delay_steps, ep, &ep->obs_mode);
         return;
     }
     Agent s;
     Spares sp;
-    split_translation_wave<INTEG>(c, g.d, i, sh, s, sp);
+    split_translation_wave<INTEG, sizeof(EnvArgs) + 64>(c, g.d, i, sh, s, sp, delay_steps, ep, &ep->obs_mode);
     env_epilogue<KIND>(c, e, g, i, live, s, sp, first, sh.tile);
 }
 
@@ -465,7 +470,7 @@ EnvKernel pick_env_rollout(const vf_env* h)
 }
 
 template <int KIND>
-EnvKernel pick_env_split_k(const vf_dyn_cfg& c)
+EnvStepKernel pick_env_split_k(const vf_dyn_cfg& c)
 {
     const int key = (c.action_type == VF_ACT_BODYRATE ? 4 : 0) | (c.integrator == VF_INT_RK4 ? 2 : 0) |
                     (c.ctrl_delay ? 1 : 0);
@@ -481,7 +486,7 @@ EnvKernel pick_env_split_k(const vf_dyn_cfg& c)
     }
 }
 
-EnvKernel pick_env_split(const vf_env* h)
+EnvStepKernel pick_env_split(const vf_env* h)
 {
     switch (h->cfg.kind) {
     case VF_ENV_HOVER: return pick_env_split_k<VF_ENV_HOVER>(h->dyn.cfg);
@@ -533,7 +538,8 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
 {
     vf::EnvArgs g{dyn_args(h, action, out->obs, ahead), *out, h->g_race, auto_reset};
     if (vf::use_split(h->dyn.Npad, h->dyn.cfg)) {
-        hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
+        hipLaunchKernelGGL(pick_env_split(h), dim3(h->dyn.Npad / 128), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g.d.S, g.d.action, g.d.N, g.d.G,
+                           g.d.head, 0, h->dyn.cfg.delay_steps, g.d.g_drag, g);
         h->stale_all = 1;
     } else {
         unsigned nb = h->dyn.Npad / vf::kBlock;
