@@ -65,22 +65,25 @@ __global__ __launch_bounds__(kBlock) void k_dyn_step(const vf_dyn_cfg* __restric
 // Two-wave variant (see SplitShared): 256-thread workgroups = 2 rotation + 2 translation waves for 128
 // agents, so that every workgroup puts exactly one wave on each SIMD of its CU.
 template <int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_dyn_step_split(const vf_dyn_cfg* __restrict__ cp, const DynArgs g)
+__global__ __launch_bounds__(kBlock) void k_dyn_step_split(const vf_dyn_cfg* __restrict__ cp, float* S, const float4* action, float* obs, int N, int G,
+                                                           int g_drag, int head, int delay_steps, const DynArgs g0)
 {
-    const vf_dyn_cfg& c = *cp;
+    const vf_dyn_cfg& c = *cp;   // (leading scalar arguments: preloaded into SGPRs, see k_dyn_step)
     __shared__ __attribute__((aligned(16))) SplitShared shs[2];
+    DynArgs g = g0;
+    g.S = S; g.action = action; g.obs = obs; g.N = N; g.G = G; g.g_drag = g_drag; g.head = head;
     const int grp = (threadIdx.x >> 6) & 1;
     SplitShared& sh = shs[grp];
     const int first = blockIdx.x * 128 + grp * 64;
     const int i = first + (threadIdx.x & 63);
     const bool live = i < g.N;
     if (threadIdx.x < 128) {
-        split_rotation_wave<ACT, INTEG, CTRL_DELAY>(c, g, i, live, sh);
+        split_rotation_wave<ACT, INTEG, CTRL_DELAY>(c, g, i, live, sh, delay_steps);
         return;
     }
     Agent s;
     Spares sp;
-    split_translation_wave<INTEG>(c, g, i, sh, s, sp);
+    split_translation_wave<INTEG>(c, g, i, sh, s, sp, delay_steps);
     store_agent(g.S, g.G, i, s, sp);
     if (g.obs) {
         float o[13];
@@ -153,7 +156,7 @@ namespace {
 using StepKernel = void (*)(const vf_dyn_cfg*, const vf::DynArgs);
 using StepKernel1 = void (*)(const vf_dyn_cfg*, float*, const float4*, float*, int, int, int, int, int, const vf::DynArgs);
 
-StepKernel pick_split_kernel(const vf_dyn_cfg& c)
+StepKernel1 pick_split_kernel(const vf_dyn_cfg& c)
 {
     const int key = (c.action_type == VF_ACT_BODYRATE ? 4 : 0) | (c.integrator == VF_INT_RK4 ? 2 : 0) |
                     (c.ctrl_delay ? 1 : 0);
@@ -197,7 +200,8 @@ int launch_step(vf_dyn* h, const float* action, float* state_out, hipStream_t st
                   reinterpret_cast<const float4*>(h->wind), h->vel_strided};
     h->tick += 1;
     if (vf::use_split(h->Npad, h->cfg))
-        hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->d_cfg, g);
+        hipLaunchKernelGGL(pick_split_kernel(h->cfg), dim3(h->Npad / 128), dim3(vf::kBlock), 0, st, h->d_cfg, g.S, g.action, g.obs, g.N, g.G,
+                           g.g_drag, g.head, h->cfg.delay_steps, g);
     else
         hipLaunchKernelGGL(pick_step_kernel(h->cfg), dim3(h->Npad / vf::kBlock), dim3(vf::kBlock), 0, st, h->d_cfg, g.S, g.action, g.obs, g.N, g.G,
                            g.g_drag, g.head, h->cfg.delay_steps, g);
