@@ -84,10 +84,10 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     VF_TR(1);                                        // vector loads issued
     prefetch_const_lines<(sizeof(vf_dyn_cfg) + 63) / 64, 2>(cp, ep, &ep->obs_mode);
     VF_TR(2);                                        // constant-block lines arrived
-    prefetch_kernarg<sizeof(EnvArgs) + 64>();
+    prefetch_kernarg<sizeof(EnvArgs) + 56>();
     VF_TR(3);                                        // kernel-argument lines arrived
 #else
-    prefetch_kernarg_and_const_lines<sizeof(EnvArgs) + 64, (sizeof(vf_dyn_cfg) + 63) / 64, 2>(cp, ep, &ep->obs_mode);
+    prefetch_kernarg_and_const_lines<sizeof(EnvArgs) + 56, (sizeof(vf_dyn_cfg) + 63) / 64, 2>(cp, ep, &ep->obs_mode);
 #endif
 #endif
     load_wind(c, g.d, i, live, s);
@@ -275,12 +275,12 @@ __global__ __launch_bounds__(kBlock) void k_env_step_split(const vf_dyn_cfg* __r
     const int i = first + (threadIdx.x & 63);
     const bool live = i < g.d.N;
     if (threadIdx.x < 128) {
-        split_rotation_wave<ACT, INTEG, CTRL_DELAY, sizeof(EnvArgs) + 64>(c, g.d, i, live, sh, delay_steps, ep, &ep->obs_mode);
+        split_rotation_wave<ACT, INTEG, CTRL_DELAY, sizeof(EnvArgs) + 56>(c, g.d, i, live, sh, delay_steps, ep, &ep->obs_mode);
         return;
     }
     Agent s;
     Spares sp;
-    split_translation_wave<INTEG, sizeof(EnvArgs) + 64>(c, g.d, i, sh, s, sp, delay_steps, ep, &ep->obs_mode);
+    split_translation_wave<INTEG, sizeof(EnvArgs) + 56>(c, g.d, i, sh, s, sp, delay_steps, ep, &ep->obs_mode);
     env_epilogue<KIND>(c, e, g, i, live, s, sp, first, sh.tile);
 }
 
