@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 7   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
+#define VF_ABI_VERSION 8   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
                               4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_dyn_set_wind,
@@ -35,7 +35,8 @@ extern "C" {
                                  vf_dyn_cfg.trig_mode (was pad0), vf_env_cfg.spawn_prefetch, vf_env_out.done_list / done_count,
                                  vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout;
                               6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse, vf_mlp_desc.identity_mask (was pad0);
-                              7: mean_rows / log_std_rows / reward_rows / ep_flag_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes) */
+                              7: mean_rows / log_std_rows / reward_rows / ep_flag_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes);
+                              8: vf_twin_q_update (fused critic step of SHAC) */
 
 /* clamp interval of the state-dependent log_std head of the reference's Actor (utils/policies/td_policies.py:31-32,241-243) */
 #define VF_SAC_LOG_STD_MIN (-10.0f)
@@ -854,6 +855,19 @@ int vf_shac_accumulate(const float* reward, const uint8_t* done, const uint8_t* 
 int64_t vf_twin_q_loss_scratch_doubles(int32_t M);
 int vf_twin_q_loss(const float* q0, const float* q1, const float* target, float* dq0, float* dq1, float* loss_out,
                    double* scratch, int32_t M, int64_t M_global, vf_stream_t stream);
+/* vf_twin_q_update     one critic update's per-row part in ONE launch (shac.py:267-270: values = critic(obs, action); mse_loss(returns,
+ *                       min(Q1, Q2)); backward through both Q trunks and the critic's extractor): forward chain of the twin critic ->
+ *                       vf_twin_q_loss's arithmetic on the head outputs still in registers -> reverse chain with the forward's own
+ *                       activations as ReLU masks.  fwd / bwd: the critic's layer tables as for vf_mlp_forward (every layer input saved)
+ *                       / vf_mlp_backward_data (no input gradient); in0 = the extractor's observation rows, in1 = the action rows;
+ *                       leaves the saved inputs X, the masked gradients dZ and dQ1 / dQ2 (the head entries' dY) for
+ *                       vf_mlp_weight_grad, loss_out[0] as vf_twin_q_loss.  scratch: vf_twin_q_update_scratch_doubles(M) doubles.
+ *                       VF_EUNSUPPORTED when the tables are not the instantiated class (td_policies.ContinuousCritic over a
+ *                       StateExtractor): the caller then runs vf_mlp_forward / vf_twin_q_loss / vf_mlp_backward_data. */
+int64_t vf_twin_q_update_scratch_doubles(int32_t M);
+int vf_twin_q_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const float* params, const float* packed, const float* in0,
+                     const float* in1, const float* target, float* loss_out, double* scratch, int32_t M, int64_t M_global,
+                     vf_stream_t stream);
 int vf_polyak_update(float* target, const float* param, int64_t n, double tau, vf_stream_t stream);
 
 /* test hook: fills the LDS of every CU with NaNs (tests/test_shac_gpu.py: layer tables with widths that are not multiples of

@@ -148,6 +148,34 @@ def test_one_iteration_matches_the_reference_loop():
     env2.close()
 
 
+@pytest.mark.parametrize("M", [1000, 4096 + 17])
+def test_fused_critic_step_equals_the_three_launch_step(M):
+    """vf_twin_q_update (forward + twin-Q loss + reverse chain in one launch) leaves the loss and the flat gradient of the
+    forward / vf_twin_q_loss / backward path (same chain arithmetic; the masks come from registers instead of the saved activations) --
+    row counts that are not multiples of the 32-row tile included"""
+    fx = load("shac_hover")
+    env, algo = make(fx)
+    c = algo.critic
+    g = torch.Generator(device=DEV).manual_seed(5)
+    obs = {"state": torch.randn((M, 13), device=DEV, generator=g)}
+    act = torch.tanh(torch.randn((M, 4), device=DEV, generator=g))
+    target = torch.randn(M, device=DEV, generator=g)
+    out = {}
+    for fused in (False, True):
+        c.flat[:c.n_params].copy_(torch.from_numpy(fx["critic_params0"]))
+        c.mark_updated()
+        algo.fused_critic = fused
+        algo._dq = None
+        loss = algo._critic_step_once(obs, act, target)
+        out[fused] = (float(loss), c.grad[:c.n_params].cpu().numpy().copy())
+    assert c._fused_twin_q is not False, "the reference's critic shape must run on vf_twin_q_update"
+    (l0, g0), (l1, g1) = out[False], out[True]
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0)), (l0, l1)
+    rel = blocks_close(g1, g0, c, 2e-6, 1e-4, "fused critic gradient")
+    print(f"M={M}: loss {l1:.7f} vs {l0:.7f}, gradient rel err {rel:.2e}")
+    env.close()
+
+
 def test_learn_runs_and_is_reproducible():
     """a few full iterations at a larger batch: finite, the critic loss falls, two runs from the same seed are bit-identical"""
     from visfly_amd.envs import HoverEnv

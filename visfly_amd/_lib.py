@@ -71,7 +71,7 @@ class DynCfg(C.Structure):
 
 
 EUNSUPPORTED = -4         # VF_EUNSUPPORTED
-ABI_VERSION = 7          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
+ABI_VERSION = 8          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
 MAX_GATES, MAX_SPAWN = 8, 4
 
 
@@ -220,6 +220,8 @@ SIGNATURES = {
     "vf_shac_accumulate": (C.c_int, [_vp] * 10 + [C.c_float, C.c_float, C.c_int32, C.c_int32, _vp]),
     "vf_twin_q_loss_scratch_doubles": (C.c_int64, [C.c_int32]),
     "vf_twin_q_loss": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int64, _vp]),
+    "vf_twin_q_update_scratch_doubles": (C.c_int64, [C.c_int32]),
+    "vf_twin_q_update": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpBwdDesc)] + [_vp] * 7 + [C.c_int32, C.c_int64, _vp]),
     "vf_polyak_update": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, _vp]),
     "vf_debug_poison_lds": (C.c_int, [_vp]),
     "vf_bptt_reverse": (C.c_int, [_vp, C.POINTER(MlpBwdDesc)] + [_vp] * 5 + [C.c_int64] + [_vp] * 6 + [C.c_int32, _vp, _vp, _vp]),

@@ -161,6 +161,9 @@ int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M,
 int mlp_forward_chain_try_sac(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
                               const float* in2, float* out0, float* out1, int M, hipStream_t st);
 int mlp_backward_chain_try_sac(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st);
+// vf_mlp_chain_sac.hip: fused critic step of SHAC (forward + twin-Q loss + reverse chain) for the ContinuousCritic class: 1 launched, 0 no match
+int twin_q_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,
+                            const float* in1, const float* target, double* part, float scale, int M, hipStream_t st);
 int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,
                          const float* in1, const float* log_std, const float* action, const float* old_lp, const float* adv,
                          const float* ret, float* part, const vf_ppo_loss_cfg* cfg, int M, hipStream_t st);

@@ -111,6 +111,23 @@ __global__ __launch_bounds__(64) void k_twin_q_fold(const double* __restrict__ p
     if (threadIdx.x == 0) loss_out[0] = (float)(s * inv_m);
 }
 
+// the same sum over many partials (the fused critic step leaves one per wave of 32 rows: 16 384 at the SHAC horizon buffer), fixed order
+__global__ __launch_bounds__(1024) void k_twin_q_fold_wide(const double* __restrict__ partial, int nblk, float* __restrict__ loss_out,
+                                                           double inv_m)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 1024) s += partial[b];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        loss_out[0] = (float)(t * inv_m);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_polyak(float* __restrict__ target, const float* __restrict__ param, long long n,
                                                    float one_minus_tau, float tau)
 {
@@ -187,6 +204,25 @@ int vf_twin_q_loss(const float* q0, const float* q1, const float* target, float*
     hipLaunchKernelGGL(vf::k_twin_q_loss, dim3(nb), dim3(vf::kBlock), 0, vf::as_stream(stream), q0, q1, target, dq0, dq1, scratch, M,
                        (float)(1.0 / (double)M_global));
     hipLaunchKernelGGL(vf::k_twin_q_fold, dim3(1), dim3(64), 0, vf::as_stream(stream), scratch, nb, loss_out, 1.0 / (double)M_global);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int64_t vf_twin_q_update_scratch_doubles(int32_t M) { return M > 0 ? (M + 31) / 32 : 0; }
+
+int vf_twin_q_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const float* params, const float* packed, const float* in0,
+                     const float* in1, const float* target, float* loss_out, double* scratch, int32_t M, int64_t M_global,
+                     vf_stream_t stream)
+{
+    if (!fwd || !bwd || !params || !packed || !in0 || !in1 || !target || !loss_out || !scratch || M <= 0 || M_global < M)
+        return vf::fail(VF_EINVAL, "vf_twin_q_update: bad argument");
+    if (fwd->n_layers < 1 || fwd->n_layers > VF_MLP_MAX_LAYERS || bwd->n_layers < 1 || bwd->n_layers > VF_MLP_MAX_LAYERS)
+        return vf::fail(VF_EINVAL, "vf_twin_q_update: bad layer count");
+    hipStream_t st = vf::as_stream(stream);
+    const int rc = vf::twin_q_update_chain_try(fwd, bwd, params, packed, in0, in1, target, scratch, (float)(1.0 / (double)M_global), M, st);
+    if (rc < 0) return rc;
+    if (rc == 0) return vf::fail(VF_EUNSUPPORTED, "vf_twin_q_update: the layer tables are not the instantiated twin-critic class");
+    hipLaunchKernelGGL(vf::k_twin_q_fold_wide, dim3(1), dim3(1024), 0, st, scratch, (M + 31) / 32, loss_out, 1.0 / (double)M_global);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

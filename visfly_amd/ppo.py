@@ -149,6 +149,7 @@ class MlpPolicy:
         self._pack_map = None
         self._pi_only_ok = True
         self._fused_ppo = None             # None: untried, False: vf_ppo_update does not support this network
+        self._fused_twin_q = None          # the same for vf_twin_q_update (a twin critic's fused update step)
         self._act_fused = None             # likewise for vf_mlp_forward_act
         self._sq_part = None
         self._slot_blocks: Dict[int, tuple] = {}
@@ -659,6 +660,55 @@ class MlpPolicy:
             _lib.check(L.vf_mlp_weight_grad_sumsq(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, self._sq_part.data_ptr(),
                                                   C.byref(ls), st))
             return self._sq_part, nb
+        _lib.check(L.vf_mlp_weight_grad(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, st))
+        return True
+
+    def twin_q_update(self, obs, target, loss_out, m_global):
+        """a twin critic's update step up to the flat gradient (shac.py:267-270): forward + mse_loss(target, min(Q1, Q2)) + reverse
+        chain in one launch (vf_twin_q_update), then the weight gradients into ``self.grad``.  ``obs``: the extractor's observations
+        + the pass-through "action" rows; ``loss_out`` (1,) device tensor.  -> False when the network is not the register-chained
+        critic class (the caller then runs forward / vf_twin_q_loss / backward)."""
+        if self._fused_twin_q is False or self._plan is None or not (self.fused and self.fused_backward) or len(self.obs_keys) != 2:
+            return False
+        M = target.shape[0]
+        b = self._buffers(M, 0)
+        L, st = _lib.lib(), self._stream()
+        for k in self.obs_keys:
+            t = obs[k]
+            assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
+            if b.get("_contig"):
+                b["obs:" + k].copy_(t)
+            else:
+                b["obs:" + k] = t
+        self._last_M, self._last_slot = M, 0
+        key = (M, 0, True)
+        d = self._descs.get(key)
+        if d is None:
+            d = self._descs[key] = self._fused_desc(b, True)
+        if "d:q0" not in b:
+            b["d:q0"] = th.empty((M, self.head_dims[0]), dtype=th.float32, device=self.device)
+            b["d:q1"] = th.empty((M, self.head_dims[1]), dtype=th.float32, device=self.device)
+        cached = self._descs.get(("twin_q_bwd", M))
+        if cached is None:
+            bd = self._bwd_desc(b, M, b["d:q0"], b["d:q1"], False)[0]
+            firsts = [(i, ly.src) for i, ly in enumerate(l for l in reversed(self.layers) if not l.frozen) if ly.first]
+            need = int(L.vf_twin_q_update_scratch_doubles(M))
+            cached = self._descs[("twin_q_bwd", M)] = (bd, firsts, th.empty(need, dtype=th.float64, device=self.device))
+        bd, firsts, scr = cached
+        for i, src in firsts:                 # entries whose X is an observation: the caller's tensor, may change from call to call
+            bd.layer[i].X = _ptr(b[src])
+        self._pack()
+        rc = L.vf_twin_q_update(C.byref(d), C.byref(bd), _ptr(self.flat), _ptr(self._packed), _ptr(b["obs:" + self.obs_keys[0]]),
+                                _ptr(b["obs:" + self.obs_keys[1]]), _ptr(target), _ptr(loss_out), scr.data_ptr(), M, int(m_global), st)
+        if rc == _lib.EUNSUPPORTED:
+            self._fused_twin_q = False
+            self._warn_fallback("vf_twin_q_update")
+            return False
+        if rc:
+            _lib.check(rc)
+        need = int(L.vf_mlp_backward_partial_floats(C.byref(bd), M))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = th.empty(need, dtype=th.float32, device=self.device)
         _lib.check(L.vf_mlp_weight_grad(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, st))
         return True
 

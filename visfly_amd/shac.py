@@ -29,6 +29,7 @@ ContinuousCritic / StateExtractor / create_mlp / SimpleRolloutBuffer / compute_t
 flattened like its actions): horizon buffer, next values, actor loss incl. bootstrap, flat actor gradient, actor parameters after
 the step, returns, and per critic step loss / gradient / parameters / target parameters (``tests/test_shac_gpu.py``).
 """
+import os
 import ctypes as C
 from typing import Optional
 
@@ -51,6 +52,7 @@ class SHAC(BPTT):
             raise NotImplementedError(f"policy {policy}: vector-observation MTDPolicy only")
         self._critic_arch = None
         self.tau, self.gradient_steps, self.lamda = tau, gradient_steps, lamda
+        self.fused_critic = os.environ.get("VISFLY_AMD_FUSED_CRITIC", "1") != "0"   # a critic update's per-row part as one launch (vf_twin_q_update); A/B
         kw.pop("policy", None)
         super().__init__(env, horizon=horizon, gamma=gamma, learning_rate=learning_rate, max_grad_norm=max_grad_norm,
                          policy_kwargs=policy_kwargs, seed=seed, **kw)
@@ -208,14 +210,17 @@ class SHAC(BPTT):
         """one critic update (shac.py:267-274) -> loss (0-dim device tensor, this rank's share of the global mean)"""
         L, st, M = _lib.lib(), _lib.current_stream(self.device), action.shape[0]
         c, dev = self.critic, self.device
-        q0, q1 = self._q(c, obs, action, save=True)
         if getattr(self, "_dq", None) is None or self._dq[0].numel() != M:
             self._dq = (th.empty(M, device=dev), th.empty(M, device=dev), th.empty(1, device=dev),
                         th.empty(int(L.vf_twin_q_loss_scratch_doubles(M)), dtype=th.float64, device=dev))
         dq0, dq1, loss, scr = self._dq
-        _lib.check(L.vf_twin_q_loss(_ptr(q0), _ptr(q1), _ptr(target), _ptr(dq0), _ptr(dq1), _ptr(loss), scr.data_ptr(), M,
-                                    M * self.world, st))
-        c.backward(dq0.view(M, 1), dq1.view(M, 1), None)
+        # forward + loss + reverse chain of the update as ONE launch where the library has the class (vf_twin_q_update), else three
+        if not (self.fused_critic and c.twin_q_update({**{k: obs[k] for k in self._ext_keys}, "action": action}, target, loss,
+                                                      M * self.world)):
+            q0, q1 = self._q(c, obs, action, save=True)
+            _lib.check(L.vf_twin_q_loss(_ptr(q0), _ptr(q1), _ptr(target), _ptr(dq0), _ptr(dq1), _ptr(loss), scr.data_ptr(), M,
+                                        M * self.world, st))
+            c.backward(dq0.view(M, 1), dq1.view(M, 1), None)
         parallel.allreduce_sum_(c.grad)
         self._last_critic_grad = c.grad
         _lib.check(L.vf_sumsq(_ptr(c.grad), c.n_params, _ptr(self._c_sumsq), _ptr(self._scratch), st))
