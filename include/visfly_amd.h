@@ -36,7 +36,7 @@ extern "C" {
                                  vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout;
                               6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse, vf_mlp_desc.identity_mask (was pad0);
                               7: mean_rows / log_std_rows / reward_rows / ep_flag_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes);
-                              8: vf_twin_q_update (fused critic step of SHAC) */
+                              8: vf_twin_q_update (fused critic step of SHAC), vf_mlp_forward_steps, vf_shac_accumulate_horizon */
 
 /* clamp interval of the state-dependent log_std head of the reference's Actor (utils/policies/td_policies.py:31-32,241-243) */
 #define VF_SAC_LOG_STD_MIN (-10.0f)
@@ -516,6 +516,13 @@ int vf_mlp_pack_weights(const vf_mlp_desc* desc, const float* params, float* pac
  * (its saved activations are left untouched); layer tables that run on the LDS kernel return VF_EUNSUPPORTED. */
 int vf_mlp_forward(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
                    const float* in2, const float* in3, float* out0, float* out1, int32_t M, vf_stream_t stream);
+/* The forward of n_steps consecutive blocks of M_step rows (inputs / outputs (n_steps M_step, w)) in ONE launch, every row computed
+ * exactly as vf_mlp_forward computes it in a launch over its block alone (the rows-per-wave choice is made for M_step rows): the
+ * per-step inference passes of a recorded horizon -- SHAC's target critics on (obs', a') of every step, shac.py:234-239 -- without H
+ * latency-bound launches.  Inference only (no layer saves); M_step a multiple of 32; register-chained network classes only
+ * (VF_EUNSUPPORTED otherwise: the caller loops vf_mlp_forward). */
+int vf_mlp_forward_steps(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
+                         const float* in2, float* out0, float* out1, int32_t M_step, int32_t n_steps, vf_stream_t stream);
 
 /* Whole-network backward in ONE launch (+ one fold): what loss.backward() does for the actor-critic MLP
  * (PPO.py:286-287, BPTT.py:127-129).  Layers are listed in execution (reverse) order.  A 64-row tile
@@ -852,6 +859,11 @@ int vf_shac_head_bwd(const float* d_action, const float* action, const float* lo
 int vf_shac_accumulate(const float* reward, const uint8_t* done, const uint8_t* ep_flags, const float* q0, const float* q1,
                        float* disc, float* loss, float* d_reward, float* next_value_row, uint8_t* ep_done_row, float gamma,
                        float scale, int32_t last_step, int32_t N, vf_stream_t stream);
+/* vf_shac_accumulate for the H steps of a recorded horizon in one launch: rows (H, N) of reward / done / ep_flags / q0 / q1 in, d_reward /
+ * next_value / ep_done rows out, disc / loss (N,) carried through the steps in order -- the same operations as H calls */
+int vf_shac_accumulate_horizon(const float* reward, const uint8_t* done, const uint8_t* ep_flags, const float* q0, const float* q1,
+                               float* disc, float* loss, float* d_reward, float* next_value, uint8_t* ep_done, float gamma, float scale,
+                               int32_t H, int32_t N, vf_stream_t stream);
 int64_t vf_twin_q_loss_scratch_doubles(int32_t M);
 int vf_twin_q_loss(const float* q0, const float* q1, const float* target, float* dq0, float* dq1, float* loss_out,
                    double* scratch, int32_t M, int64_t M_global, vf_stream_t stream);

@@ -220,6 +220,8 @@ SIGNATURES = {
     "vf_shac_accumulate": (C.c_int, [_vp] * 10 + [C.c_float, C.c_float, C.c_int32, C.c_int32, _vp]),
     "vf_twin_q_loss_scratch_doubles": (C.c_int64, [C.c_int32]),
     "vf_twin_q_loss": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int64, _vp]),
+    "vf_shac_accumulate_horizon": (C.c_int, [_vp] * 10 + [C.c_float, C.c_float, C.c_int32, C.c_int32, _vp]),
+    "vf_mlp_forward_steps": (C.c_int, [C.POINTER(MlpDesc)] + [_vp] * 7 + [C.c_int32, C.c_int32, _vp]),
     "vf_twin_q_update_scratch_doubles": (C.c_int64, [C.c_int32]),
     "vf_twin_q_update": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpBwdDesc)] + [_vp] * 7 + [C.c_int32, C.c_int64, _vp]),
     "vf_polyak_update": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, _vp]),

@@ -150,7 +150,8 @@ struct ReparamBwd {
 };
 // vf_mlp_chain.hip: register-chained forward for the reference-default network shapes (1: launched, 0: no match)
 int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rp = nullptr, const float* in2 = nullptr);
+                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rp = nullptr, const float* in2 = nullptr,
+                          int M_choice = 0);      // M_choice > 0: rows-per-wave choice as for M_choice rows (vf_mlp_forward_steps)
 
 int bwd_chain_policy_class(const vf_mlp_bwd_desc* d, int M);           // vf_mlp_chain.hip: 0 none, 1 NetHover, 2 NetNav (policy trunk, obs gradient), 3 / 4 NetSacHover / NetSacNav (both trunks); + 16: M rows per pass run 16 rows per wave
 int chain16_policy_class(const vf_mlp_desc* d, const float* params);   // vf_mlp_chain.hip: 0 none, 1 NetHoverPi, 2 NetNavPi, 3 NetSacHover, 4 NetSacNav
@@ -159,7 +160,7 @@ int chain_full_class(const vf_mlp_desc* d, const float* params, int M);   // 0 n
 int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp = nullptr);
 // the same for the SAC-style Actor's network classes (vf_mlp_chain_sac.hip); called by the two functions above as their last resort
 int mlp_forward_chain_try_sac(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                              const float* in2, float* out0, float* out1, int M, hipStream_t st);
+                              const float* in2, float* out0, float* out1, int M, hipStream_t st, int M_choice = 0);
 int mlp_backward_chain_try_sac(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st);
 // vf_mlp_chain_sac.hip: fused critic step of SHAC (forward + twin-Q loss + reverse chain) for the ContinuousCritic class: 1 launched, 0 no match
 int twin_q_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const float* params, const float* packed, const float* in0,

@@ -158,7 +158,7 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
 
 // 1: launched, 0: the layer table is not one of the instantiated network classes, < 0: error
 int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rpp, const float* in2)
+                          float* out0, float* out1, int M, hipStream_t st, const ReparamFwd* rpp, const float* in2, int M_choice)
 {
     static const bool off = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN"); return e && atoi(e) == 0; }();
     const ReparamFwd rp = rpp ? *rpp : ReparamFwd{};
@@ -166,13 +166,13 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     for (int i = 0; i < d->n_layers; ++i)
         if (d->layer[i].save && !rows_fit_u32(M, d->layer[i].save_ld)) return 0;
     if (!out1) {      // no value requested: the value trunk is skipped
-        if (chain_matches<NetNavPi>(*d) && in1) return chain_launch<NetNavPi>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
-        if (chain_matches<NetHoverPi>(*d)) return chain_launch<NetHoverPi>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
+        if (chain_matches<NetNavPi>(*d) && in1) return chain_launch<NetNavPi>(*d, params, packed, in0, in1, out0, out1, M, st, rp, nullptr, M_choice);
+        if (chain_matches<NetHoverPi>(*d)) return chain_launch<NetHoverPi>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp, nullptr, M_choice);
         return 0;
     }
-    if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
-    if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
-    if (!rpp) return mlp_forward_chain_try_sac(d, params, packed, in0, in1, in2, out0, out1, M, st);    // SAC-style Actor / twin critic (vf_mlp_chain_sac.hip)
+    if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp, nullptr, M_choice);
+    if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp, nullptr, M_choice);
+    if (!rpp) return mlp_forward_chain_try_sac(d, params, packed, in0, in1, in2, out0, out1, M, st, M_choice);    // SAC-style Actor / twin critic (vf_mlp_chain_sac.hip)
     return 0;
 }
 

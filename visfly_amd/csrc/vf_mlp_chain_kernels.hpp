@@ -137,13 +137,15 @@ bool chain16_ok(const vf_mlp_desc& d, const float* params, int M)
     return true;
 }
 
+// M_choice > 0: the rows-per-wave choice is made for M_choice rows (vf_mlp_forward_steps: n consecutive blocks of M_choice rows in one
+// launch, each row computed exactly as a launch over its block alone would)
 template <class N>
 int chain_launch(const vf_mlp_desc& d, const float* params, const float* packed, const float* in0, const float* in1, float* out0,
-                 float* out1, int M, hipStream_t st, const ReparamFwd& rp, const float* in2 = nullptr)
+                 float* out1, int M, hipStream_t st, const ReparamFwd& rp, const float* in2 = nullptr, int M_choice = 0)
 {
     ChainArgs g{d, params, packed, ChainIo{{in0, in1, in2}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.action),
                 {rp.obs_copy[0], rp.obs_copy[1]}};
-    if (chain16_ok<N>(d, params, M))
+    if (chain16_ok<N>(d, params, M_choice > 0 ? M_choice : M))
         hipLaunchKernelGGL(k_mlp_forward_chain16<N>, dim3((M + 15) / 16), dim3(64), 0, st, g);
     else
         hipLaunchKernelGGL(k_mlp_forward_chain<N>, dim3((M + 31) / 32), dim3(64), 0, st, g);

@@ -24,16 +24,16 @@ static bool sac_off()
 
 // 1: launched, 0: not one of the SAC actor classes (or no second output), < 0: error
 int mlp_forward_chain_try_sac(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,
-                              const float* in2, float* out0, float* out1, int M, hipStream_t st)
+                              const float* in2, float* out0, float* out1, int M, hipStream_t st, int M_choice)
 {
     if (sac_off() || !out0 || !out1) return 0;
     const ReparamFwd rp{};
     // twin critic: 1-wide heads (no alignment requirement on the outputs); the action is the input behind the extractor's
     // (over a StateTarget extractor the concatenation would be 132 wide: beyond the 128 columns every layer kernel here is built for)
-    if (chain_matches<NetCriticHover>(*d) && in1) return chain_launch<NetCriticHover>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
+    if (chain_matches<NetCriticHover>(*d) && in1) return chain_launch<NetCriticHover>(*d, params, packed, in0, in1, out0, out1, M, st, rp, nullptr, M_choice);
     if ((reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1)) & 15) return 0;
-    if (chain_matches<NetSacNav>(*d) && in1) return chain_launch<NetSacNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp);
-    if (chain_matches<NetSacHover>(*d)) return chain_launch<NetSacHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp);
+    if (chain_matches<NetSacNav>(*d) && in1) return chain_launch<NetSacNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp, nullptr, M_choice);
+    if (chain_matches<NetSacHover>(*d)) return chain_launch<NetSacHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp, nullptr, M_choice);
     return 0;
 }
 

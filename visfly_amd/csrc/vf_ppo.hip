@@ -1712,6 +1712,22 @@ int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32
     return VF_OK;
 }
 
+int vf_mlp_forward_steps(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
+                         const float* in2, float* out0, float* out1, int32_t M_step, int32_t n_steps, vf_stream_t stream)
+{
+    if (!desc || !params || !packed || !in0 || !out0 || M_step <= 0 || n_steps <= 0) return vf::fail(VF_EINVAL, "vf_mlp_forward_steps: bad argument");
+    if (desc->n_layers < 1 || desc->n_layers > VF_MLP_MAX_LAYERS || desc->n_inputs < 1 || desc->n_inputs > 4)
+        return vf::fail(VF_EINVAL, "vf_mlp_forward_steps: bad layer / input count");
+    if (M_step & 31) return vf::fail(VF_EUNSUPPORTED, "vf_mlp_forward_steps: M_step must be a multiple of 32 (whole row tiles per step)");
+    if ((int64_t)M_step * n_steps > 0x7fffffff) return vf::fail(VF_EINVAL, "vf_mlp_forward_steps: M_step x n_steps passes 2^31 rows");
+    for (int i = 0; i < desc->n_layers; ++i)
+        if (desc->layer[i].save) return vf::fail(VF_EINVAL, "vf_mlp_forward_steps: inference only (no saved activations)");
+    const int rc = vf::mlp_forward_chain_try(desc, params, packed, in0, in1, out0, out1, M_step * n_steps, vf::as_stream(stream), nullptr, in2, M_step);
+    if (rc < 0) return rc;
+    if (rc == 0) return vf::fail(VF_EUNSUPPORTED, "vf_mlp_forward_steps: the layer table is not an instantiated network class");
+    return VF_OK;
+}
+
 int vf_mlp_forward_act(const vf_mlp_desc* desc, const float* params, const float* packed, const float* in0, const float* in1,
                        const float* log_std, const float* eps, float* action, float* obs_copy0, float* obs_copy1, int32_t M,
                        vf_stream_t stream)

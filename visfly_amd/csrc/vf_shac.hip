@@ -74,6 +74,36 @@ __global__ __launch_bounds__(kBlock) void k_shac_accumulate(const float* __restr
     ep_done_row[i] = epd ? 1 : 0;
 }
 
+// k_shac_accumulate for the H steps of a recorded horizon in one launch: a thread walks its agent's rows t = 0 .. H-1 in order (the
+// discount / loss recurrence is per agent), rows (H, N); the same operations on the same values as H launches
+__global__ __launch_bounds__(kBlock) void k_shac_accumulate_horizon(const float* __restrict__ reward, const uint8_t* __restrict__ done,
+                                                                    const uint8_t* __restrict__ ep_flags, const float* __restrict__ q0,
+                                                                    const float* __restrict__ q1, float* __restrict__ disc,
+                                                                    float* __restrict__ loss, float* __restrict__ d_reward,
+                                                                    float* __restrict__ next_value, uint8_t* __restrict__ ep_done,
+                                                                    float gamma, float scale, int H, int N)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    float d = disc[i], l = loss[i];
+    for (int t = 0; t < H; ++t) {
+        const size_t j = (size_t)t * N + i;
+        const float r = reward[j];
+        const bool dn = done[j] != 0;
+        const bool epd = dn && (ep_flags[j] & VF_EP_EPISODE_DONE) != 0;
+        const float nv = fminf(q0[j], q1[j]);
+        l = l - r * d;
+        const bool cut = (dn || t == H - 1) && !epd;
+        l = l - nv * d * gamma * (cut ? 1.0f : 0.0f);
+        d_reward[j] = -d * scale;
+        d = d * gamma * (dn ? 0.0f : 1.0f) + (dn ? 1.0f : 0.0f);
+        next_value[j] = nv;
+        ep_done[j] = epd ? 1 : 0;
+    }
+    disc[i] = d;
+    loss[i] = l;
+}
+
 // values = min(Q1, Q2) (ties: the first, like torch.min over dim 1); loss = mean((returns - values)^2);
 // dQ_k = 2 (values - returns) / M_global where Q_k is the minimum, else 0.  Per-block fp64 partial sums of the squared error.
 __global__ __launch_bounds__(kBlock) void k_twin_q_loss(const float* __restrict__ q0, const float* __restrict__ q1,
@@ -189,6 +219,18 @@ int vf_shac_accumulate(const float* reward, const uint8_t* done, const uint8_t* 
         return vf::fail(VF_EINVAL, "vf_shac_accumulate: bad argument");
     hipLaunchKernelGGL(vf::k_shac_accumulate, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done,
                        ep_flags, q0, q1, disc, loss, d_reward, next_value_row, ep_done_row, gamma, scale, last_step, N);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_shac_accumulate_horizon(const float* reward, const uint8_t* done, const uint8_t* ep_flags, const float* q0, const float* q1,
+                               float* disc, float* loss, float* d_reward, float* next_value, uint8_t* ep_done, float gamma, float scale,
+                               int32_t H, int32_t N, vf_stream_t stream)
+{
+    if (!reward || !done || !ep_flags || !q0 || !q1 || !disc || !loss || !d_reward || !next_value || !ep_done || N <= 0 || H <= 0)
+        return vf::fail(VF_EINVAL, "vf_shac_accumulate_horizon: bad argument");
+    hipLaunchKernelGGL(vf::k_shac_accumulate_horizon, dim3(vf::blocks_for(N)), dim3(vf::kBlock), 0, vf::as_stream(stream), reward, done,
+                       ep_flags, q0, q1, disc, loss, d_reward, next_value, ep_done, gamma, scale, H, N);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

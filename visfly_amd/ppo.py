@@ -150,6 +150,7 @@ class MlpPolicy:
         self._pi_only_ok = True
         self._fused_ppo = None             # None: untried, False: vf_ppo_update does not support this network
         self._fused_twin_q = None          # the same for vf_twin_q_update (a twin critic's fused update step)
+        self._steps_ok, self._steps_out = None, {}      # vf_mlp_forward_steps (forward_steps)
         self._act_fused = None             # likewise for vf_mlp_forward_act
         self._sq_part = None
         self._slot_blocks: Dict[int, tuple] = {}
@@ -662,6 +663,33 @@ class MlpPolicy:
             return self._sq_part, nb
         _lib.check(L.vf_mlp_weight_grad(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, st))
         return True
+
+    def forward_steps(self, obs, m_step, n_steps):
+        """inference forward of ``n_steps`` consecutive blocks of ``m_step`` rows in one launch, every row as ``forward`` computes it
+        in a launch over its block alone (vf_mlp_forward_steps) -> (mean, value) of (n_steps m_step) rows, or None when the library
+        has no register-chained class for this network / row count (the caller loops ``forward``)"""
+        if self._steps_ok is False or self._plan is None or not self.fused or m_step % 32:
+            return None
+        M = m_step * n_steps
+        for k in self.obs_keys:
+            t = obs[k]
+            assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
+        if self._pack_desc is None:
+            self._pack_desc = self._fused_desc(None, False)
+        out = self._steps_out.get(M)
+        if out is None:
+            f = dict(dtype=th.float32, device=self.device)
+            out = self._steps_out[M] = (th.empty((M, self.head_dims[0]), **f), th.empty((M, self.head_dims[1]), **f))
+        ins = [_ptr(obs[k]) for k in self.obs_keys] + [None] * (3 - len(self.obs_keys))
+        self._pack()
+        rc = _lib.lib().vf_mlp_forward_steps(C.byref(self._pack_desc), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], ins[2],
+                                             _ptr(out[0]), _ptr(out[1]), int(m_step), int(n_steps), self._stream())
+        if rc == _lib.EUNSUPPORTED:
+            self._steps_ok = False
+            return None
+        if rc:
+            _lib.check(rc)
+        return out
 
     def twin_q_update(self, obs, target, loss_out, m_global):
         """a twin critic's update step up to the flat gradient (shac.py:267-270): forward + mse_loss(target, min(Q1, Q2)) + reverse

@@ -53,6 +53,7 @@ class SHAC(BPTT):
         self._critic_arch = None
         self.tau, self.gradient_steps, self.lamda = tau, gradient_steps, lamda
         self.fused_critic = os.environ.get("VISFLY_AMD_FUSED_CRITIC", "1") != "0"   # a critic update's per-row part as one launch (vf_twin_q_update); A/B
+        self.batch_targets = os.environ.get("VISFLY_AMD_BATCH_TARGETS", "1") != "0"  # the horizon's target-critic passes as one launch (vf_mlp_forward_steps); A/B
         kw.pop("policy", None)
         super().__init__(env, horizon=horizon, gamma=gamma, learning_rate=learning_rate, max_grad_norm=max_grad_norm,
                          policy_kwargs=policy_kwargs, seed=seed, **kw)
@@ -132,7 +133,24 @@ class SHAC(BPTT):
             mu2[H - 1].copy_(m)
             ls2[H - 1].copy_(l)
             self._head_fwd(mu2.view(-1, 4), ls2.view(-1, 4), eps[1::2].contiguous().view(-1, 4), nxt.view(-1, 4))
-            for t in range(H):      # target critics per step: N rows per launch, the row count (-> kernel choice) of the loop
+            # target critics on (obs', a') of every step and the loss / discount recurrence: ONE forward launch over the H N rows with the
+            # rows-per-wave choice of an N-row launch (vf_mlp_forward_steps: every row as the per-step launch computes it) + ONE
+            # accumulate launch, where the library has them; else H launches of each
+            qs = None
+            if self.batch_targets:
+                if getattr(self, "_obs2", None) is None or self._obs2[keys[0]].shape[:2] != (H, N):
+                    self._obs2 = {k: th.empty((H, N, pol.obs_dims[k]), **f) for k in keys}
+                for k in keys:
+                    if H > 1:
+                        self._obs2[k][:H - 1].copy_(blk["obs:" + k][1:H])
+                    self._obs2[k][H - 1].copy_(o_last[k])
+                tg = self.critic_target
+                qs = tg.forward_steps({**{k: self._obs2[k].view(H * N, -1) for k in self._ext_keys}, "action": nxt.view(H * N, 4)}, N, H)
+            if qs is not None:
+                _lib.check(L.vf_shac_accumulate_horizon(_ptr(b["reward"]), b["done"].data_ptr(), flag_rows.data_ptr(), _ptr(qs[0]), _ptr(qs[1]),
+                                                        _ptr(disc), _ptr(loss_vec), _ptr(drews), _ptr(b["next_value"]),
+                                                        b["ep_done"].data_ptr(), float(self.gamma), scale, H, N, st))
+            for t in range(H if qs is not None else 0, H):      # target critics per step: N rows per launch, the row count (-> kernel choice) of the loop
                 o2 = {k: blk["obs:" + k][t + 1] for k in keys} if t + 1 < H else o_last
                 q0, q1 = self._q(self.critic_target, o2, nxt[t], slot=0)
                 _lib.check(L.vf_shac_accumulate(_ptr(b["reward"][t]), b["done"][t].data_ptr(), flag_rows[t].data_ptr(), _ptr(q0), _ptr(q1),
