@@ -226,21 +226,17 @@ __global__ __launch_bounds__(64, SMALL ? 2 : 1) void k_mlp_wgrad(const vf_mlp_bw
     }
 }
 
-// grad (+)= sum over the layer's waves of partial[wave][e]; 64 consecutive partial elements per block, the kFoldWaves waves of
+// grad (+)= sum over the layer's waves of partial[wave][e]; 64 consecutive partial elements per block, the 4 waves of
 // the block split the partial rows (8 loads in flight each) and combine through LDS in a fixed order
-#ifndef VF_FOLD_WAVES
-#define VF_FOLD_WAVES 4
-#endif
-constexpr int kFoldWaves = VF_FOLD_WAVES;
-__global__ __launch_bounds__(64 * kFoldWaves) void k_wgrad_fold(const vf_mlp_bwd_desc d, const WgradTable t, const float* __restrict__ partials,
+__global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, const WgradTable t, const float* __restrict__ partials,
                                                        float* __restrict__ grad, int accumulate, double* __restrict__ sq_part,
                                                        const vf_stats_fold ls, int n_param_blocks)
 {
     prefetch_kernarg<sizeof(vf_mlp_bwd_desc) + sizeof(WgradTable) + 40 + sizeof(vf_stats_fold)>();
-    __shared__ float red[kFoldWaves][64];
+    __shared__ float red[4][64];
     if ((int)blockIdx.x >= n_param_blocks) {     // the extra block: loss-statistic partial rows (vf_ppo_update) -> stats
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        for (int k = w; k < 16; k += kFoldWaves) {         // 64 lanes stride over the rows, shuffle tree: the order of k_fold_stats
+        for (int k = w; k < 16; k += 4) {         // 64 lanes stride over the rows, shuffle tree: the order of k_fold_stats
             float s = 0.0f;
             if (k < 9) {
                 // rows are at most 1024 (vf_ppo_update's contract): all of a lane's loads are issued before the first add
@@ -280,20 +276,18 @@ __global__ __launch_bounds__(64 * kFoldWaves) void k_wgrad_fold(const vf_mlp_bwd
         const float* p = partials + t.part_off[l] + e;
         float s4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int w = q;
-        for (; w + 7 * kFoldWaves < waves; w += 8 * kFoldWaves) {
+        for (; w + 28 < waves; w += 32) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s4[u] += p[(size_t)(w + kFoldWaves * u) * tot];
+            for (int u = 0; u < 8; ++u) s4[u] += p[(size_t)(w + 4 * u) * tot];
         }
-        for (; w < waves; w += kFoldWaves) s4[0] += p[(size_t)w * tot];
+        for (; w < waves; w += 4) s4[0] += p[(size_t)w * tot];
         s = ((s4[0] + s4[1]) + (s4[2] + s4[3])) + ((s4[4] + s4[5]) + (s4[6] + s4[7]));
     }
     red[q][lane] = s;
     __syncthreads();
     double sq = 0.0;
     if (q == 0 && prm >= 0) {
-        float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-#pragma unroll
-        for (int k = 4; k < kFoldWaves; ++k) v += red[k][lane];
+        const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
         const int nw = L.K * L.No;
         float* g = grad + (prm < nw ? L.w_off + prm : L.b_off + (prm - nw));
         const float nv = accumulate ? *g + v : v;
@@ -376,7 +370,7 @@ int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int
     else hipLaunchKernelGGL(k_mlp_wgrad<false>, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
     const int nb = mlp_wgrad_fold_blocks(d);
     const vf_stats_fold ls = loss_stats ? *loss_stats : vf_stats_fold{};
-    hipLaunchKernelGGL(k_wgrad_fold, dim3(nb + (loss_stats ? 1 : 0)), dim3(64 * kFoldWaves), 0, st, *d, t, (const float*)partials, grad, accumulate,
+    hipLaunchKernelGGL(k_wgrad_fold, dim3(nb + (loss_stats ? 1 : 0)), dim3(kBlock), 0, st, *d, t, (const float*)partials, grad, accumulate,
                        sq_part, ls, nb);
     VF_HIP(hipGetLastError());
     return VF_OK;
