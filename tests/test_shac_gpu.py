@@ -176,6 +176,57 @@ def test_fused_critic_step_equals_the_three_launch_step(M):
     env.close()
 
 
+def test_forward_steps_equals_the_per_step_forwards():
+    """vf_mlp_forward_steps: n blocks of M rows in one launch == n vf_mlp_forward launches of M rows, bit for bit (the rows-per-wave choice is
+    made for M rows), for the twin critic and for the actor; vf_shac_accumulate_horizon == H vf_shac_accumulate launches"""
+    from visfly_amd import _lib
+    fx = load("shac_hover")
+    env, algo = make(fx)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, n = 256, 5
+    obs = torch.randn((n, M, 13), device=DEV, generator=g)
+    act = torch.tanh(torch.randn((n, M, 4), device=DEV, generator=g))
+    tg = algo.critic_target
+    got = tg.forward_steps({"state": obs.view(n * M, 13), "action": act.view(n * M, 4)}, M, n)
+    assert got is not None, "the reference's critic shape must run on vf_mlp_forward_steps"
+    q0s, q1s = got[0].view(n, M).clone(), got[1].view(n, M).clone()
+    for t in range(n):
+        q0, q1 = algo._q(tg, {"state": obs[t]}, act[t])
+        assert_bits_equal(q0s[t].cpu().numpy(), q0.cpu().numpy(), f"Q1 of block {t}")
+        assert_bits_equal(q1s[t].cpu().numpy(), q1.cpu().numpy(), f"Q2 of block {t}")
+    pol = algo.policy
+    ga = pol.forward_steps({"state": obs.view(n * M, 13)}, M, n)
+    assert ga is not None
+    mus, lss = ga[0].view(n, M, 4).clone(), ga[1].view(n, M, 4).clone()
+    for t in range(n):
+        mu, ls = pol.forward({"state": obs[t].contiguous()}, save_activations=False, slot=0)
+        assert_bits_equal(mus[t].cpu().numpy(), mu.cpu().numpy(), f"mu of block {t}")
+        assert_bits_equal(lss[t].cpu().numpy(), ls.cpu().numpy(), f"log_std of block {t}")
+    # the loss / discount recurrence of a horizon in one launch
+    L, st = _lib.lib(), _lib.current_stream(torch.device(DEV))
+    from visfly_amd.ppo import _ptr
+    H, N = 7, 300
+    f = dict(device=DEV)
+    rew, qa, qb = (torch.randn((H, N), generator=g, **f) for _ in range(3))
+    done = (torch.rand((H, N), generator=g, **f) < 0.2).to(torch.uint8)
+    flags = (torch.randint(0, 16, (H, N), generator=g, **f)).to(torch.uint8)
+    outs = []
+    for batched in (False, True):
+        disc, loss = torch.ones(N, **f), torch.zeros(N, **f)
+        dr, nv, epd = torch.empty((H, N), **f), torch.empty((H, N), **f), torch.empty((H, N), dtype=torch.uint8, **f)
+        if batched:
+            _lib.check(L.vf_shac_accumulate_horizon(_ptr(rew), done.data_ptr(), flags.data_ptr(), _ptr(qa), _ptr(qb), _ptr(disc), _ptr(loss),
+                                                    _ptr(dr), _ptr(nv), epd.data_ptr(), 0.99, 1.0 / N, H, N, st))
+        else:
+            for t in range(H):
+                _lib.check(L.vf_shac_accumulate(_ptr(rew[t]), done[t].data_ptr(), flags[t].data_ptr(), _ptr(qa[t]), _ptr(qb[t]), _ptr(disc),
+                                                _ptr(loss), _ptr(dr[t]), _ptr(nv[t]), epd[t].data_ptr(), 0.99, 1.0 / N, 1 if t == H - 1 else 0, N, st))
+        outs.append([x.cpu().numpy() for x in (disc, loss, dr, nv, epd)])
+    for a, b, what in zip(outs[0], outs[1], ("disc", "loss", "d_reward", "next_value", "ep_done")):
+        assert_bits_equal(b, a, what)
+    env.close()
+
+
 def test_learn_runs_and_is_reproducible():
     """a few full iterations at a larger batch: finite, the critic loss falls, two runs from the same seed are bit-identical"""
     from visfly_amd.envs import HoverEnv
