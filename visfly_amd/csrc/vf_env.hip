@@ -54,9 +54,9 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     g.d.S = S; g.d.action = action; g.d.N = N; g.d.G = G; g.d.head = head; g.helper = helper; g.d.g_drag = g_drag;
 #ifndef VF_EXP_NO_HELPER
     // the blocks behind the g.helper main blocks: helper blocks (prefetched re-spawn), kHelperSpan agents per thread (a workgroup dispatch
-    // costs more than their checks).  Marked unlikely so that the main waves' path is the fall-through from the kernel's entry (the
-    // instruction cache is cold at every launch); measured: no change in the 0.3 us from entry to the first load -- kept for the layout
-    if (__builtin_expect(g.helper != 0 && (int)blockIdx.x >= g.helper, 0)) {
+    // costs more than their checks).  (Laying the helper's code and the episode-end blocks out behind the hot path with __builtin_expect --
+    // the instruction cache is cold at every launch -- was measured in both regimes: no difference, profiles/r04_env_timeline.txt)
+    if (g.helper != 0 && (int)blockIdx.x >= g.helper) {
         const int nbm = g.helper;
         const int base = ((int)blockIdx.x - nbm) * kHelperSpan * kBlock + (int)threadIdx.x;
 #pragma unroll 1

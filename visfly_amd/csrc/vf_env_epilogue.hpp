@@ -235,7 +235,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         if (reward_reg) *reward_reg = reward;       // (callers that keep going with the agent in registers: vf_bptt_rollout.hip)
         if (done_reg) *done_reg = done;
         g.out.done[i] = done ? 1 : 0;
-        if (__builtin_expect(done, 0)) {  // collect_info (:238-275)
+        if (done) {  // collect_info (:238-275)
             if (g.out.ep_return) g.out.ep_return[i] = er.rewards;
             if (g.out.ep_length) g.out.ep_length[i] = er.step_count;
             if (g.out.ep_flags)
@@ -260,7 +260,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
             atomicOr(g.stale + g.n_tiles + (i >> 6), ending);
         }
     }
-    if (__builtin_expect(done && g.auto_reset, 0)) {  // examine() -> reset_agent_by_id (:339-349,420-423); unlikely: laid out behind the hot path (cold instruction cache at every launch)
+    if (done && g.auto_reset) {  // examine() -> reset_agent_by_id (:339-349,420-423)
         unsigned episode = ((unsigned)er.flags >> 8) + 1u;
         if constexpr (KIND == VF_ENV_RACING) {
             // RacingEnv.reset_agent_by_id (RacingEnv.py:150-163) picks the next gate BEFORE the base class
