@@ -29,6 +29,13 @@ def _worker(rank, world, port, q, algo, backend="gloo"):
                        tensor_output=True)
         tr = PPO(env, n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3 + 17 * rank)   # rank-dependent seed: the ctor broadcasts rank 0's weights
         tr.learn(16 * 1024 * world * 2)
+    elif algo == "shac":
+        from visfly_amd.envs import HoverEnv
+        from visfly_amd.shac import SHAC
+        env = HoverEnv(num_agent_per_scene=512, seed=10 + rank, dynamics_kwargs=dict(ENV_DYN), device=dev, max_episode_steps=64,
+                       tensor_output=True, requires_grad=True)
+        tr = SHAC(env, horizon=8, learning_rate=1e-3, gradient_steps=2, seed=3 + 17 * rank)
+        tr.learn(8 * 512 * world * 3)
     else:
         from visfly_amd.bptt import BPTT
         from visfly_amd.envs import HoverEnv
@@ -36,7 +43,10 @@ def _worker(rank, world, port, q, algo, backend="gloo"):
                        tensor_output=True)
         tr = BPTT(env, horizon=8, learning_rate=1e-3, seed=3 + 17 * rank)
         tr.learn(8 * 512 * world * 3)
-    flat = tr.policy.flat.detach() if backend == "nccl" else tr.policy.flat.detach().cpu()
+    flat = tr.policy.flat.detach()
+    if algo == "shac":       # the critic (fused update step, its own all-reduce) must stay in lockstep too
+        flat = torch.cat([flat, tr.critic.flat.detach(), tr.critic_target.flat.detach()])
+    flat = flat if backend == "nccl" else flat.cpu()
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     ok = bool(torch.isfinite(flat).all()) and all(torch.equal(both[0], b) for b in both)
@@ -46,11 +56,11 @@ def _worker(rank, world, port, q, algo, backend="gloo"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("algo", ["ppo", "bptt"])
+@pytest.mark.parametrize("algo", ["ppo", "bptt", "shac"])
 def test_two_ranks_stay_in_lockstep(algo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 200 + (0 if algo == "ppo" else 1)
+    port = 29700 + os.getpid() % 200 + {"ppo": 0, "bptt": 1, "shac": 2}[algo]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo)) for r in range(2)]
     for p in procs:
         p.start()
