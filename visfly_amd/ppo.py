@@ -667,7 +667,8 @@ class MlpPolicy:
     def forward_steps(self, obs, m_step, n_steps):
         """inference forward of ``n_steps`` consecutive blocks of ``m_step`` rows in one launch, every row as ``forward`` computes it
         in a launch over its block alone (vf_mlp_forward_steps) -> (mean, value) of (n_steps m_step) rows, or None when the library
-        has no register-chained class for this network / row count (the caller loops ``forward``)"""
+        has no register-chained class for this network / row count (the caller loops ``forward``).  The returned tensors are the
+        policy's own output buffers for this row count: the next call with the same (m_step, n_steps) overwrites them."""
         if self._steps_ok is False or self._plan is None or not self.fused or m_step % 32:
             return None
         M = m_step * n_steps
