@@ -17,7 +17,12 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 # per-source extra flags.  The single-step kernels: the dispatcher preloads the leading kernel arguments into SGPRs (gfx940+), see k_env_step
 _PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
-PER_SOURCE_FLAGS = {"vf_env.hip": _PRELOAD, "vf_dyn.hip": _PRELOAD}
+# ... and -slp-threshold=8: hipcc's SLP vectoriser pairs scalar fp32 operations into v_pk_* instructions; a lone wave issues a packed
+# instruction in the slot of a scalar one, but every pair whose operands are not in adjacent registers costs v_mov's.  At the default
+# threshold the sub-step loop of k_env_step is 315 instructions (126 packed, 36 moves); at 8 only the pairs that pay are formed: 301
+# (82 packed, 8 moves) -- the minimum of a scan over 2 .. 24 (profiles/r04_env_timeline.txt).  Same IEEE operations: bit-identical.
+_STEP = _PRELOAD + ["-mllvm", "-slp-threshold=8"]
+PER_SOURCE_FLAGS = {"vf_env.hip": _STEP, "vf_dyn.hip": _STEP}
 
 
 def sources():
