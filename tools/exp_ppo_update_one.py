@@ -1,8 +1,10 @@
 """a few fused PPO minibatch steps (vf_ppo_update + vf_mlp_weight_grad) of the Nav actor-critic at M rows, for rocprofv3 passes"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visfly_amd import _build, _lib
+if os.environ.get('VF_ALT_LIB'):     # another build of the library (A/B)
+    _build.LIB = _lib.LIB = os.environ['VF_ALT_LIB']
 import torch
-from visfly_amd import _lib
 from visfly_amd.ppo import MlpPolicy
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 25600
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10

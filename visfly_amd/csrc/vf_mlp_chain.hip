@@ -33,16 +33,6 @@ namespace vf {
 // inputs X (forward's saved copies), the masked gradients dZ, d_mean / d_value; per wave one row of loss-statistic
 // partials (folded by the loss kernel's k_fold_stats).
 // ------------------------------------------------------------------------------------------------
-struct PpoRowArgs {
-    const float* log_std;
-    const float4* action;
-    const float* old_lp;
-    const float* adv;
-    const float* ret;
-    float* part;             // [n_waves][kStats]
-    vf_ppo_loss_cfg cfg;
-};
-
 template <class N>
 __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, const BwdArgsChain gb, const PpoRowArgs pr)
 {
@@ -52,6 +42,10 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
     const int row = blockIdx.x * 32 + m;
     const bool live = row < g.M;
     const int rc = live ? row : g.M - 1;
+    // per-row loss inputs first: the action-only part of the loss (ppo_row_pre) runs while the weight fragments are on their way
+    const float4 a4 = pr.action[rc];
+    const float ls[4] = {pr.log_std[0], pr.log_std[1], pr.log_std[2], pr.log_std[3]};
+    const float old_lp = pr.old_lp[rc], adv = pr.adv[rc], ret = pr.ret[rc];
     ChainState<N> fs;
     chain_prologue<N, 0>(g, fs, lane);
 #pragma unroll
@@ -65,10 +59,11 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
             fs.x[b][s] = k < w ? v : 0.0f;
         }
     }
-    // per-row loss inputs: issued before the forward so that they have arrived when it ends
-    const float4 a4 = pr.action[rc];
-    const float old_lp = pr.old_lp[rc], adv = pr.adv[rc], ret = pr.ret[rc];
-    const float ls[4] = {pr.log_std[0], pr.log_std[1], pr.log_std[2], pr.log_std[3]};
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+    PpoRowPre pre = ppo_row_pre(a);
+#pragma unroll
+    for (int d = 0; d < 4; ++d)     // pinned here: left alone the compiler sinks the arithmetic to its use behind the forward chain
+        asm volatile("" : "+v"(pre.g[d]), "+v"(pre.corr[d]));
     chain_items<N, 0>(g, fs, lane, row, live, rc);
     BwdState<P> bs;
     bwd_prologue<P, 0>(gb, bs, lane);                  // first weight blocks of the reverse chain: in flight during the loss arithmetic
@@ -76,9 +71,9 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
     float stt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dm[4] = {0, 0, 0, 0}, dvl = 0.0f;
     {
         const f32x16& mt = fs.t[N::t_mean];
-        const float mu[4] = {mt[0], mt[1], mt[2], mt[3]}, a[4] = {a4.x, a4.y, a4.z, a4.w};
+        const float mu[4] = {mt[0], mt[1], mt[2], mt[3]};
         float st1[9], dm1[4], dv1;
-        ppo_row(mu, fs.t[N::t_val][0], ls, a, old_lp, adv, ret, pr.cfg, dm1, dv1, st1, rc);
+        ppo_row_post(pre, mu, fs.t[N::t_val][0], ls, old_lp, adv, ret, pr.cfg, dm1, dv1, st1, rc);
         const bool on = live && h == 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) stt[k] = on ? st1[k] : 0.0f;
@@ -145,13 +140,14 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
     BwdArgsChain gb{*bd, packed, M, nullptr, nullptr, nullptr, nullptr, nullptr};
     PpoRowArgs pr{log_std, reinterpret_cast<const float4*>(action), old_lp, adv, ret, part, *cfg};
     const dim3 grid((M + 31) / 32);
-    if (chain_matches<NetNav>(*d) && in1 && bwd_chain_matches<NetNav, true, true, false>(*bd)) {
-        hipLaunchKernelGGL(k_ppo_update_chain<NetNav>, grid, dim3(64), 0, st, g, gb, pr);
-    } else if (chain_matches<NetHover>(*d) && bwd_chain_matches<NetHover, true, true, false>(*bd)) {
-        hipLaunchKernelGGL(k_ppo_update_chain<NetHover>, grid, dim3(64), 0, st, g, gb, pr);
-    } else {
-        return 0;
-    }
+    const int which = (chain_matches<NetNav>(*d) && in1 && bwd_chain_matches<NetNav, true, true, false>(*bd)) ? 2
+                    : (chain_matches<NetHover>(*d) && bwd_chain_matches<NetHover, true, true, false>(*bd)) ? 1 : 0;
+    if (!which) return 0;
+    // two waves per row tile, each walking half of the network (vf_mlp_chain_split.hip); 0: switched off -> the one-wave kernel
+    const int sp = ppo_update_split_try(g, gb, &pr, which, M, st);
+    if (sp) return sp;
+    if (which == 2) hipLaunchKernelGGL(k_ppo_update_chain<NetNav>, grid, dim3(64), 0, st, g, gb, pr);
+    else hipLaunchKernelGGL(k_ppo_update_chain<NetHover>, grid, dim3(64), 0, st, g, gb, pr);
     VF_HIP(hipGetLastError());
     return 1;
 }

@@ -16,6 +16,10 @@
 #define VF_CHAIN16_DEPTH 24
 #endif
 
+#ifndef VF_CHAIN_HOOK
+#define VF_CHAIN_HOOK(kind, idx) do { } while (0)     // trace builds: a cycle stamp at the end of layer / op idx (kind 0 / 1: forward before / after the epilogue, 2 / 3: reverse)
+#endif
+
 namespace vf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -43,6 +47,12 @@ struct ChainLayer {
     int in0, nin;  // first input tile, number of input tiles (obs: nin = number of 8-wide k groups)
     int out0, nout;
     int relu;
+    // ---- slices (vf_mlp_chain_split.hpp: two waves share a row tile, each walks half of the network); defaults = a whole layer ----
+    int a0 = 0;            // the layer's output tiles [a0, a0 + nout) are computed here (weight image / bias / saved-copy columns)
+    int s0 = 0, sn = -1;   // of those, tiles [s0, s0 + sn) are the ones THIS wave stores for the weight gradients (-1: all)
+    int xsn = 0, xr0 = 0;  // > 0: after the epilogue the output tiles go to the partner wave through LDS and its xsn tiles arrive at xr0
+    int pk0 = -1;          // >= 0: at the end of this layer its INPUT tiles are reduced to one bit per value (> 0?) at bit tiles pk0 .. of
+                           // ChainState::mb -- all the fused kernels' reverse chain wants of them -- and the 16 registers per tile are free
 };
 
 // NB branches (KA / KB = first-layer widths padded to 8), hidden widths in 32-feature tiles
@@ -129,18 +139,24 @@ struct ChainNet {
         for (int i = 0; i < li; ++i) n += items(i);
         return n;
     }
+    static constexpr int mask_bits(int /*fl*/) { return -1; }     // first bit tile of forward layer fl's ReLU mask (ChainLayer::pk0), -1: the tiles stay
 };
 
-constexpr int kChainDepth = 8;   // weight blocks in flight: 8 x 4 MFMAs x 64 cycles = 2 k cycles of cover
+#ifndef VF_CHAIN_DEPTH
+#define VF_CHAIN_DEPTH 8
+#endif
+constexpr int kChainDepth = VF_CHAIN_DEPTH;   // weight blocks in flight: 8 x 4 MFMAs x 64 cycles = 2 k cycles of cover (the split kernels: their own choice)
 
 template <class N>
 struct ChainState {
+    using Net = N;
     f32x16 t[N::n_tiles];
+    unsigned mb[8];              // ReLU masks kept as bits (ChainLayer::pk0): bit tile j = bits [16 (j & 1), +16) of word j >> 1, bit r = register r
     float x[2][16];              // observation fragments: x[b][s] = X[m][2 s + h] (K padded to <= 32)
     float4 ring[kChainDepth];
     float4 bias[4][4];           // bias of the layer in flight: [out tile][g] -> features 32 a + 8 g + 4 h .. + 3
     // where the saved copy of the PREVIOUS layer's output goes (chain_store_setup): wave-uniform base (null: not kept) + this lane's byte offset
-    vf_gptr sv_base;
+    unsigned long sv_base;       // (0: not kept)
     unsigned sv_off;
 };
 
@@ -175,15 +191,52 @@ using NetCriticHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, true, 1, 1, 1>;   //
 
 
 // ---- the 32-rows-per-wave forward (the scheme at the head of vf_mlp_chain.hip) ----
+// The weight fragments are BUFFER loads: descriptor over the packed image (4 SGPRs, made once) + this lane's constant 16-byte slot +
+// a scalar block offset.  r05 (tools/mfma_occupancy_probe.hip, profiles/r05_chain_split.txt): what a load costs a lone wave is its
+// ISSUE, during which the wave's dependent MFMAs cannot go -- 49 cycles per global_load with a 64-bit VGPR address (what the pointer
+// form below compiled to, plus two VALU adds), 71 with scalar base + VGPR offset, 30 as a buffer load, per item of 4 MFMAs = 256 cycles
+#ifndef VF_CHAIN_BUFFER_LOADS
+#define VF_CHAIN_BUFFER_LOADS 1
+#endif
+typedef unsigned vf_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_weight_rsrc(const float* packed)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float4 chain_buffer_float4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned block_off)
+{
+    const vf_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)block_off, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
+// ... and the trickled copies are BUFFER stores: a global_store with scalar base + lane offset costs a lone wave 26 cycles of issue, with a
+// 64-bit VGPR address 32, a buffer_store 2 (same probe).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_store_rsrc(unsigned long base)
+{
+    // (readfirstlane: the pinned base went through an inline asm, whose result the compiler takes for divergent -- it would wrap every
+    // store in a waterfall loop over "different" descriptors.  For the same reason the descriptor has a constant size and a buffer that
+    // is not kept is skipped by a scalar branch: `base ? 2^32 - 1 : 0` becomes a v_cndmask however it is written)
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi << 32) | lo), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ void chain_buffer_store(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned col_off, float a, float b, float c, float d)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(vf_u4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, (int)lane_off, (int)col_off, 0);
+}
+
 template <class N, int I>
 __device__ __forceinline__ float4 chain_load(const ChainArgs& g, int lane)
 {
     constexpr int li = N::layer_of(I), local = I - N::first_item(li);
     constexpr ChainLayer L = N::layer(li);
     constexpr int G = N::groups(li), gq = local / L.nout, a = local % L.nout;
+#if VF_CHAIN_BUFFER_LOADS
+    return chain_buffer_float4(chain_weight_rsrc(g.packed), (unsigned)lane * 16u, (unsigned)g.d.layer[L.desc].wr_off * 4u + ((L.a0 + a) * G + gq) * 1024u);
+#else
     // wave-uniform base (scalar registers) + 32-bit lane offset: no 64-bit VGPR address arithmetic per load
-    const char* base = reinterpret_cast<const char*>(g.packed + g.d.layer[L.desc].wr_off) + (a * G + gq) * 1024;
+    const char* base = reinterpret_cast<const char*>(g.packed + g.d.layer[L.desc].wr_off) + ((L.a0 + a) * G + gq) * 1024;
     return *reinterpret_cast<const float4*>(base + (unsigned)lane * 16u);
+#endif
 }
 
 // widths are compile-time (hidden layers: whole tiles; heads: 4 / 1 features in lane half 0, q = 0), so the bias loads
@@ -203,7 +256,7 @@ __device__ __forceinline__ void chain_bias_load(const ChainArgs& g, ChainState<N
         for (int a = 0; a < L.nout; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4u v = *reinterpret_cast<const f32x4u*>(b + 32 * a + 8 * q + 4 * h);
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(b + 32 * (L.a0 + a) + 8 * q + 4 * h);
                 st.bias[a][q] = make_float4(v.x, v.y, v.z, v.w);
             }
     }
@@ -275,9 +328,8 @@ __device__ __forceinline__ void chain_store_setup(const ChainArgs& g, ChainState
         const vf_mlp_layer& D = g.d.layer[P.desc];
         unsigned long b = D.save ? reinterpret_cast<unsigned long>(D.save + D.dst_col) : 0ul;
         asm volatile("" : "+s"(b));          // opaque: the compiler cannot re-derive it from the kernel arguments at every use
-        st.sv_base = (vf_gptr)b;
-        // lane offset in BYTES, 32 bit (the hosts refuse row counts whose buffers pass 4 GiB): scalar base + 32-bit offset
-        // is an addressing mode, a 64-bit element offset is three VALU instructions per store
+        st.sv_base = b;
+        // lane offset in BYTES, 32 bit (the hosts refuse row counts whose buffers pass 4 GiB)
         st.sv_off = ((unsigned)rc * (unsigned)D.save_ld + 4u * h) * 4u;
     }
 }
@@ -287,18 +339,78 @@ __device__ __forceinline__ void chain_deferred_store(const ChainState<N>& st)
 {
     if constexpr (LI >= 1 && !N::is_head(LI >= 1 ? LI - 1 : 0)) {
         constexpr ChainLayer P = N::layer(LI - 1);
-        constexpr int S = P.nout * 4, per = (S + N::items(LI) - 1) / N::items(LI);
+        constexpr int S = (P.sn < 0 ? P.nout : P.sn) * 4, per = (S + N::items(LI) - 1) / N::items(LI);
         constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
         if constexpr (s0 < s1) {
             if (st.sv_base) {
-                const vf_gptr base = st.sv_base + st.sv_off;
+                const __amdgpu_buffer_rsrc_t r = chain_store_rsrc(st.sv_base);
 #pragma unroll
                 for (int i = s0; i < s1; ++i) {
-                    const int a = i / 4, q = i % 4;
+                    const int a = P.s0 + i / 4, q = i % 4;
                     const f32x16& y = st.t[P.out0 + a];
-                    *(vf_gfloat4*)(base + (32 * a + 8 * q) * 4) = vf_st4{y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+                    chain_buffer_store(r, st.sv_off, (32 * (P.a0 + a) + 8 * q) * 4, y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
                 }
             }
+        }
+    }
+}
+
+// ---- hand-over between the two waves of a split row tile (vf_mlp_chain_split.hpp): same lane -> same lane, one float4 per (tile, q) ----
+constexpr int kXchTiles = 2;
+__shared__ vf_st4 vf_xch_fwd[2][kXchTiles][4][64];     // [writer role][tile][q][lane]: 16 KiB, allocated only for kernels that exchange
+__shared__ vf_st4 vf_xch_bwd[2][kXchTiles][4][64];
+
+// LDS writes of this wave done, then the workgroup barrier.  NOT __syncthreads(): its fence also waits for every global load / store
+// in flight (vmcnt(0)), i.e. for the weight ring and the trickled stores
+__device__ __forceinline__ void xch_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <class N, int LI>
+__device__ __forceinline__ void chain_exchange(ChainState<N>& st, int lane)
+{
+    constexpr ChainLayer L = N::layer(LI);
+    if constexpr (L.xsn > 0) {
+        static_assert(L.xsn <= kXchTiles, "exchange buffer");
+        constexpr int R = N::role;
+#pragma unroll
+        for (int a = 0; a < L.xsn; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x16& y = st.t[L.out0 + a];
+                vf_xch_fwd[R][a][q][lane] = vf_st4{y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+            }
+        xch_barrier();
+#pragma unroll
+        for (int a = 0; a < L.xsn; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const vf_st4 v = vf_xch_fwd[1 - R][a][q][lane];
+                f32x16& y = st.t[L.xr0 + a];
+                y[4 * q] = v[0]; y[4 * q + 1] = v[1]; y[4 * q + 2] = v[2]; y[4 * q + 3] = v[3];
+            }
+    }
+}
+
+// y > 0 of a ReLU output (>= 0, so: bits != 0) as one bit per accumulator register: 2 VALU per value to pack, 2 to apply (bwd_finalize)
+template <class N, int LI>
+__device__ __forceinline__ void chain_pack_input(ChainState<N>& st)
+{
+    constexpr ChainLayer L = N::layer(LI);
+    if constexpr (L.pk0 >= 0) {
+#pragma unroll
+        for (int a = 0; a < L.nin; ++a) {
+            const int j = L.pk0 + a;
+            unsigned bits = (j & 1) ? st.mb[j >> 1] : 0u;
+            const f32x16& y = st.t[L.in0 + a];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float yr = y[r];          // (a copy: __builtin_bit_cast applied to a vector element reads element 0 whatever r is)
+                const unsigned nz = __float_as_uint(yr) != 0u ? 1u : 0u;
+                bits |= nz << (16 * (j & 1) + r);
+            }
+            // pinned HERE: left to itself the compiler sinks the 2 x 16 instructions to the first use of the word -- the reverse chain's
+            // finalize, a forward trunk and a loss later -- and the tile's 16 registers stay live all the way (measured: 64 VGPRs)
+            asm volatile("" : "+v"(bits));
+            st.mb[j >> 1] = bits;
         }
     }
 }
@@ -335,7 +447,13 @@ __device__ __forceinline__ void chain_items(const ChainArgs& g, ChainState<N>& s
         if constexpr (SAVE && local == 0) chain_store_setup<N, li>(g, st, rc, h);
         if constexpr (SAVE) chain_deferred_store<N, li, local>(st);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (local == N::items(li) - 1) chain_epilogue<N, li>(g, st, row, h, live);
+        if constexpr (local == N::items(li) - 1) {
+            VF_CHAIN_HOOK(0, li);
+            chain_epilogue<N, li>(g, st, row, h, live);
+            chain_exchange<N, li>(st, lane);
+            chain_pack_input<N, li>(st);
+            VF_CHAIN_HOOK(1, li);
+        }
         chain_items<N, I + 1, SAVE>(g, st, lane, row, live, rc);
     }
 }
@@ -353,7 +471,7 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs& g, ChainState<N>
 // 0 .. pw-1 of tile t_pass -- an accumulator lane (m, h) holds features 4 h + (r & 3) + 8 (r >> 2) in register r, i.e. the half
 // h = 0 holds them in registers 0 .. 3 (pw <= 4) and 8 .. 11 of h = 0 would be features 8 ..; everything else is zero.  Also the copy
 // the weight gradients of the trunks' first layers read: the identity layer's columns of the saved feature rows
-template <class N>
+template <class N, bool STORE = true>
 __device__ __forceinline__ void chain_pass_tile(const ChainArgs& g, ChainState<N>& st, int row, int rc, int h, bool live)
 {
     if constexpr (N::PASS) {
@@ -366,7 +484,7 @@ __device__ __forceinline__ void chain_pass_tile(const ChainArgs& g, ChainState<N
         for (int k = 0; k < 4; ++k) v[k] = (h == 0 && k < pw) ? x[k < pw ? k : pw - 1] : 0.0f;
         t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
         const vf_mlp_layer& D = g.d.layer[2 * N::NB];
-        if (D.save && live && h == 0) {
+        if (STORE && D.save && live && h == 0) {
             float* o = D.save + (size_t)row * D.save_ld + D.dst_col;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -456,9 +574,14 @@ __device__ __forceinline__ float4 chain16_load(const ChainArgs& g, int lane)
         // float4 of lane 16 (a16 & 1) + i + 32 (kq & 1) in block (a16 / 2, 4 (T >> 1) + 2 (T & 1) + (kq >> 1)); a quarter-wave reads
         // 256 contiguous bytes
         constexpr int G = N::groups(li), blk = (a >> 1) * G + 4 * (T >> 1) + 2 * (T & 1);
-        const char* base = reinterpret_cast<const char*>(g.packed + D.wr_off) + (blk * 1024 + 256 * (a & 1));       // wave-uniform
         const unsigned kq = lane >> 4;
+#if VF_CHAIN_BUFFER_LOADS
+        return chain_buffer_float4(chain_weight_rsrc(g.packed), (kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u,
+                                   (unsigned)D.wr_off * 4u + (blk * 1024 + 256 * (a & 1)));       // (buffer load: see chain_load)
+#else
+        const char* base = reinterpret_cast<const char*>(g.packed + D.wr_off) + (blk * 1024 + 256 * (a & 1));       // wave-uniform
         return *reinterpret_cast<const float4*>(base + ((kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u));
+#endif
     }
 #endif
 #if VF_CHAIN16_WT

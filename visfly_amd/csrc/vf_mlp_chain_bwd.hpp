@@ -17,6 +17,9 @@ namespace vf {
 // ------------------------------------------------------------------------------------------------
 struct BwdFin {     // mask tiles [t0, t0 + nt) with the saved output of forward layer fl and store them as its dZ
     int fl, t0, nt, ym0;
+    // slices (vf_mlp_chain_split.hpp); defaults = the whole layer
+    int c0 = 0;            // the tiles are tiles [c0, c0 + nt) of layer fl's output (mask source, dZ columns)
+    int s0 = 0, sn = -1;   // of those, [s0, s0 + sn) are stored by THIS wave (-1: all)
 };
 struct BwdOp {
     int fl;         // forward layer whose weights are applied (MlpPolicy order)
@@ -27,6 +30,9 @@ struct BwdOp {
     int obs;        // >= 0: the output is dLoss/d observation `obs` (stored directly, no mask)
     int nfin;
     BwdFin fin[2];
+    // slices (vf_mlp_chain_split.hpp); defaults = the whole op
+    int a0 = 0;            // the op's output tiles [a0, a0 + nout) are computed here (weight image)
+    int xsn = 0, xs0 = 0, xr0 = 0;   // > 0: before the op is finalised, tiles [xs0, xs0 + xsn) go to the partner wave through LDS and its xsn tiles are ADDED to [xr0, ..)
 };
 
 template <class N, bool PI, bool VF, bool IG>
@@ -132,7 +138,7 @@ struct BwdState {
     float4 ring[kChainDepth];
     float4 ym[4][4];             // saved activations (mask source) of the tiles being finalised
     float hin[2][4];             // head gradients of this lane's row: d_mean[0..3] / d_value (lane half 0), else 0
-    vf_gptr sv_base[2];      // dZ buffers of the (up to two) layers the PREVIOUS op finalised (bwd_store_setup): uniform bases ...
+    unsigned long sv_base[2];    // dZ buffers of the (up to two) layers the PREVIOUS op finalised (bwd_store_setup): uniform bases ...
     unsigned sv_off[2];          // ... + this lane's byte offsets
 };
 
@@ -142,8 +148,12 @@ __device__ __forceinline__ float4 bwd_load(const BwdArgsChain& g, int lane)
     constexpr int oi = P::op_of(I), local = I - P::first_item(oi);
     constexpr BwdOp O = P::op(oi);
     constexpr int gq = local / O.nout, a = local % O.nout;
-    const char* base = reinterpret_cast<const char*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off) + (a * O.G + gq) * 1024;
+#if VF_CHAIN_BUFFER_LOADS
+    return chain_buffer_float4(chain_weight_rsrc(g.packed), (unsigned)lane * 16u, (unsigned)g.d.layer[P::entry(O.fl)].wq_off * 4u + ((O.a0 + a) * O.G + gq) * 1024u);
+#else
+    const char* base = reinterpret_cast<const char*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off) + ((O.a0 + a) * O.G + gq) * 1024;
     return *reinterpret_cast<const float4*>(base + (unsigned)lane * 16u);
+#endif
 }
 
 template <class P, int OI>
@@ -157,35 +167,58 @@ __device__ __forceinline__ void bwd_mask_load(const BwdArgsChain& g, BwdState<P>
 #pragma unroll
         for (int a = 0; a < O.fin[f].nt; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) st.ym[O.fin[f].ym0 + a][q] = *reinterpret_cast<const float4*>(y + 32 * a + 8 * q);
+            for (int q = 0; q < 4; ++q) st.ym[O.fin[f].ym0 + a][q] = *reinterpret_cast<const float4*>(y + 32 * (O.fin[f].c0 + a) + 8 * q);
     }
 }
 
 struct NoFwd {};     // FS of the stand-alone reverse chain: masks are read back from HBM
 
+// ReLU mask of the tiles of fin F of op OI: from the saved copy (NoFwd), from the fused kernel's own forward tiles, or from what a
+// fused kernel kept of them -- one bit per value (ChainLayer::pk0)
+template <class P, class FS, int OI, int F>
+__device__ __forceinline__ void bwd_mask_fin(BwdState<P>& st, const FS& fs)
+{
+    constexpr BwdOp O = P::op(OI);
+    if constexpr (F < O.nfin) {
+        constexpr BwdFin fin = O.fin[F];
+        constexpr int bits0 = [] { if constexpr (std::is_same<FS, NoFwd>::value) return -1; else return FS::Net::mask_bits(fin.fl); }();
+#pragma unroll
+        for (int a = 0; a < fin.nt; ++a) {
+            f32x16& v = st.t[fin.t0 + a];
+            if constexpr (bits0 >= 0) {
+                const int j = bits0 + fin.c0 + a;
+                const unsigned w = fs.mb[j >> 1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int keep = (int)(w << (31 - (16 * (j & 1) + r))) >> 31;      // 0 / -1
+                    const float vr = v[r];      // (a copy: see chain_pack_input)
+                    v[r] = __uint_as_float(__float_as_uint(vr) & (unsigned)keep);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 y;
+                    if constexpr (std::is_same<FS, NoFwd>::value) y = st.ym[fin.ym0 + a][q];
+                    else {      // fused kernel: the forward's own accumulator tile of that layer is still in registers
+                        const f32x16& t = fs.t[P::Net::tile_of_layer(fin.fl) + fin.c0 + a];
+                        y = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+                    }
+                    v[4 * q + 0] = y.x > 0.0f ? v[4 * q + 0] : 0.0f;
+                    v[4 * q + 1] = y.y > 0.0f ? v[4 * q + 1] : 0.0f;
+                    v[4 * q + 2] = y.z > 0.0f ? v[4 * q + 2] : 0.0f;
+                    v[4 * q + 3] = y.w > 0.0f ? v[4 * q + 3] : 0.0f;
+                }
+            }
+        }
+    }
+}
+
 template <class P, class FS, int OI>
 __device__ __forceinline__ void bwd_finalize(const BwdArgsChain& g, BwdState<P>& st, const FS& fs, int row, int h, bool live)
 {
     constexpr BwdOp O = P::op(OI);
-#pragma unroll
-    for (int f = 0; f < O.nfin; ++f)
-#pragma unroll
-        for (int a = 0; a < O.fin[f].nt; ++a) {
-            f32x16& v = st.t[O.fin[f].t0 + a];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 y;
-                if constexpr (std::is_same<FS, NoFwd>::value) y = st.ym[O.fin[f].ym0 + a][q];
-                else {      // fused kernel: the forward's own accumulator tile of that layer is still in registers
-                    const f32x16& t = fs.t[P::Net::tile_of_layer(O.fin[f].fl) + a];
-                    y = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
-                }
-                v[4 * q + 0] = y.x > 0.0f ? v[4 * q + 0] : 0.0f;
-                v[4 * q + 1] = y.y > 0.0f ? v[4 * q + 1] : 0.0f;
-                v[4 * q + 2] = y.z > 0.0f ? v[4 * q + 2] : 0.0f;
-                v[4 * q + 3] = y.w > 0.0f ? v[4 * q + 3] : 0.0f;
-            }
-        }
+    bwd_mask_fin<P, FS, OI, 0>(st, fs);
+    bwd_mask_fin<P, FS, OI, 1>(st, fs);
     if constexpr (O.obs >= 0) {        // dLoss/d observation: features 4 h + (r & 3) + 8 (r >> 2) of this lane's row
         const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];
         if (live) {
@@ -200,6 +233,8 @@ __device__ __forceinline__ void bwd_finalize(const BwdArgsChain& g, BwdState<P>&
     }
 }
 
+constexpr int bwd_fin_stored(const BwdFin& f) { return f.sn < 0 ? f.nt : f.sn; }
+
 // stores of the tiles the PREVIOUS op finalised, spread over this op's items.  Base pointers / row strides are read from the layer
 // table once per op and pinned (chain_store_setup, vf_mlp_chain.hpp, says why); lanes past the last row replicate row M - 1: no guard
 template <class P, int OI>
@@ -212,7 +247,7 @@ __device__ __forceinline__ void bwd_store_setup(const BwdArgsChain& g, BwdState<
             const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
             unsigned long b = reinterpret_cast<unsigned long>(E.dY);
             asm volatile("" : "+s"(b));
-            st.sv_base[f] = (vf_gptr)b;
+            st.sv_base[f] = b;
             st.sv_off[f] = ((unsigned)rc * (unsigned)E.ld_dy + 4u * h) * 4u;                    // bytes
         }
     }
@@ -223,17 +258,44 @@ __device__ __forceinline__ void bwd_deferred_store(const BwdState<P>& st)
 {
     if constexpr (OI >= 1) {
         constexpr BwdOp Q = P::op(OI - 1);
-        constexpr int S0 = Q.nfin > 0 ? Q.fin[0].nt * 4 : 0, S = S0 + (Q.nfin > 1 ? Q.fin[1].nt * 4 : 0);
+        constexpr int S0 = Q.nfin > 0 ? bwd_fin_stored(Q.fin[0]) * 4 : 0, S = S0 + (Q.nfin > 1 ? bwd_fin_stored(Q.fin[1]) * 4 : 0);
         constexpr int n_it = P::items(OI), per = (S + n_it - 1) / n_it;
         constexpr int s0 = LOCAL * per, s1 = (LOCAL + 1) * per < S ? (LOCAL + 1) * per : S;
         if constexpr (s0 < s1) {
 #pragma unroll
             for (int i = s0; i < s1; ++i) {
-                const int f = i < S0 ? 0 : 1, ii = i - (f ? S0 : 0), a = ii / 4, q = ii % 4;
+                const int f = i < S0 ? 0 : 1, ii = i - (f ? S0 : 0), a = Q.fin[f].s0 + ii / 4, q = ii % 4;
                 const f32x16& v = st.t[Q.fin[f].t0 + a];
-                *(vf_gfloat4*)(st.sv_base[f] + st.sv_off[f] + (32 * a + 8 * q) * 4) = vf_st4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                chain_buffer_store(chain_store_rsrc(st.sv_base[f]), st.sv_off[f], (32 * (Q.fin[f].c0 + a) + 8 * q) * 4, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
             }
         }
+    }
+}
+
+// partial gradients of the two halves of a split row tile meet (vf_mlp_chain_split.hpp): send, barrier, add the partner's
+template <class P, int OI>
+__device__ __forceinline__ void bwd_exchange(BwdState<P>& st, int lane)
+{
+    constexpr BwdOp O = P::op(OI);
+    if constexpr (O.xsn > 0) {
+        static_assert(O.xsn <= kXchTiles, "exchange buffer");
+        constexpr int R = P::role;
+#pragma unroll
+        for (int a = 0; a < O.xsn; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x16& v = st.t[O.xs0 + a];
+                vf_xch_bwd[R][a][q][lane] = vf_st4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            }
+        xch_barrier();
+#pragma unroll
+        for (int a = 0; a < O.xsn; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const vf_st4 u = vf_xch_bwd[1 - R][a][q][lane];
+                f32x16& v = st.t[O.xr0 + a];
+                v[4 * q] += u[0]; v[4 * q + 1] += u[1]; v[4 * q + 2] += u[2]; v[4 * q + 3] += u[3];
+            }
     }
 }
 
@@ -263,7 +325,12 @@ __device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st
         if constexpr (local == 0) bwd_store_setup<P, oi>(g, st, rc, h);
         bwd_deferred_store<P, oi, local>(st);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (local == P::items(oi) - 1) bwd_finalize<P, FS, oi>(g, st, fs, row, h, live);
+        if constexpr (local == P::items(oi) - 1) {
+            VF_CHAIN_HOOK(2, oi);
+            bwd_exchange<P, oi>(st, lane);
+            bwd_finalize<P, FS, oi>(g, st, fs, row, h, live);
+            VF_CHAIN_HOOK(3, oi);
+        }
         bwd_items<P, FS, I + 1>(g, st, fs, lane, row, rc, live);
     }
 }
@@ -342,11 +409,12 @@ __device__ __forceinline__ void bwd_tail_store(const BwdArgsChain& g, const BwdS
         const vf_mlp_bwd_layer& E = g.d.layer[P::entry(Q.fin[f].fl)];
         float* base = const_cast<float*>(E.dY) + (size_t)row * E.ld_dy + 4 * h;
 #pragma unroll
-        for (int a = 0; a < Q.fin[f].nt; ++a)
+        for (int i = 0; i < bwd_fin_stored(Q.fin[f]); ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                const int a = Q.fin[f].s0 + i;
                 const f32x16& v = st.t[Q.fin[f].t0 + a];
-                *reinterpret_cast<float4*>(base + 32 * a + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                *reinterpret_cast<float4*>(base + 32 * (Q.fin[f].c0 + a) + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
             }
     }
 }
@@ -431,12 +499,21 @@ __device__ __forceinline__ float4 bwd16_load(const BwdArgsChain& g, int lane)
         // 256 contiguous bytes, one instruction per item (chain16_load).  Heads: component kq of lane k's float4 in block (a, 0)
         constexpr int GQ = O.in_kind == 0 ? O.G : 1;
         constexpr int blk = (a >> 1) * GQ + (O.in_kind == 0 ? 4 * (T >> 1) + 2 * (T & 1) : 0);
-        const char* qb = reinterpret_cast<const char*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off) + (blk * 1024 + 256 * (a & 1));
         const unsigned kq = lane >> 4;
+#if VF_CHAIN_BUFFER_LOADS
+        const unsigned block_off = (unsigned)g.d.layer[P::entry(O.fl)].wq_off * 4u + (blk * 1024 + 256 * (a & 1));     // (buffer loads: see chain_load)
+        if constexpr (O.in_kind == 0)
+            return chain_buffer_float4(chain_weight_rsrc(g.packed), (kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u, block_off);
+        else
+            return make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(chain_weight_rsrc(g.packed), (int)((unsigned)(lane & 15) * 16u + kq * 4u), (int)block_off, 0)),
+                               0.0f, 0.0f, 0.0f);
+#else
+        const char* qb = reinterpret_cast<const char*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off) + (blk * 1024 + 256 * (a & 1));
         if constexpr (O.in_kind == 0)
             return *reinterpret_cast<const float4*>(qb + ((kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u));
         else
             return make_float4(*reinterpret_cast<const float*>(qb + ((unsigned)(lane & 15) * 16u + kq * 4u)), 0.0f, 0.0f, 0.0f);
+#endif
     }
 #endif
     const float* base = g.packed + g.d.layer[P::entry(O.fl)].wb_off;             // wave-uniform

@@ -7,6 +7,20 @@
 
 namespace vf {
 
+struct PpoRowArgs {          // per-row inputs of the fused PPO minibatch step (k_ppo_update_chain / k_ppo_update_split)
+    const float* log_std;
+    const float4* action;
+    const float* old_lp;
+    const float* adv;
+    const float* ret;
+    float* part;             // [n_tiles][kStats]
+    vf_ppo_loss_cfg cfg;
+};
+
+// vf_mlp_chain_split.hip: the fused update kernels with two waves per row tile; 1 launched, 0 not taken, < 0 error
+int ppo_update_split_try(const ChainArgs& g, const BwdArgsChain& gb, const void* pr, int which, int M, hipStream_t st);
+int twin_q_update_split_try(const ChainArgs& g, const BwdArgsChain& gb, const float* target, double* part, float scale, int M, hipStream_t st);
+
 template <class N>
 __global__ __launch_bounds__(64) void k_mlp_forward_chain(const ChainArgs g)
 {

@@ -124,6 +124,8 @@ int twin_q_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, con
     if (!(chain_matches<NetCriticHover>(*d) && in1 && bwd_chain_matches<NetCriticHover, true, true, false>(*bd))) return 0;
     ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M, nullptr, nullptr, nullptr, {nullptr, nullptr}};
     BwdArgsChain gb{*bd, packed, M, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int sp = twin_q_update_split_try(g, gb, target, part, scale, M, st);     // two waves per row tile (vf_mlp_chain_split.hip)
+    if (sp) return sp;
     hipLaunchKernelGGL(k_twin_q_update_chain<NetCriticHover>, dim3((M + 31) / 32), dim3(64), 0, st, g, gb, target, part, scale);
     VF_HIP(hipGetLastError());
     return 1;

@@ -59,14 +59,40 @@ __device__ __forceinline__ float head_sample_row(const float4 m4, const float* _
     return lp;
 }
 
+// The part of a row's loss that needs the ACTION only (SquashedDiagGaussianDistribution.log_prob: gaussian_actions = atanh(clamp(a)),
+// the tanh correction log(1 - a^2 + 1e-6)): 12 of the row's ~26 transcendental evaluations.  The fused
+// update kernels run it BEFORE the forward chain, while the wave waits for its first weight fragments anyway, instead of between the
+// forward and the reverse chain where the matrix pipe idles for it (r05: 8.9 k of a wave's 136 k cycles, profiles/r05_chain_split.txt).
+struct PpoRowPre {
+    float g[4], corr[4];
+};
+
+__device__ __forceinline__ PpoRowPre ppo_row_pre(const float* a)
+{
+    PpoRowPre p;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        p.g[d] = atanh_clamped(a[d]);
+        p.corr[d] = logf(1.0f - a[d] * a[d] + 1e-6f);
+    }
+    return p;
+}
+
 // one row of the clipped-surrogate loss: gradients w.r.t. the head outputs and the 9 statistics
 // st = {policy loss, value loss, log prob, approx kl, clipped?, d_log_std[4]}
 // `row`: index of this row in the call's arrays (for cfg.old_value)
-__device__ __forceinline__ void ppo_row(const float* mu, float v, const float* ls, const float* a, float old_lp, float A, float R,
-                                        const vf_ppo_loss_cfg& cfg, float* dm, float& d_value, float* st, int row = 0)
+// (the same operations in the same order as squashed_log_prob + the former single-piece ppo_row: same bits)
+__device__ __forceinline__ void ppo_row_post(const PpoRowPre& p, const float* mu, float v, const float* ls, float old_lp, float A, float R,
+                                             const vf_ppo_loss_cfg& cfg, float* dm, float& d_value, float* st, int row = 0)
 {
-    float g[4];
-    const float lp = squashed_log_prob(mu, ls, a, g);
+    float lp = 0.0f, sd[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        sd[d] = expf(ls[d]);            // (wave-uniform: not worth four registers across the forward chain)
+        const float z = (p.g[d] - mu[d]) / sd[d];
+        lp += -0.5f * z * z - ls[d] - 0.91893853320467274178f;
+        lp -= p.corr[d];
+    }
     const float log_ratio = lp - old_lp;
     const float ratio = expf(log_ratio);
     const float lo = 1.0f - cfg.clip_range, hi = 1.0f + cfg.clip_range;
@@ -86,9 +112,8 @@ __device__ __forceinline__ void ppo_row(const float* mu, float v, const float* l
     const float dl_dlp = (dl_dratio * ratio + cfg.ent_coef) * cfg.inv_batch;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const float sd = expf(ls[d]);
-        const float z = (g[d] - mu[d]) / sd;
-        dm[d] = dl_dlp * z / sd;
+        const float z = (p.g[d] - mu[d]) / sd[d];
+        dm[d] = dl_dlp * z / sd[d];
         st[5 + d] = dl_dlp * (z * z - 1.0f);
     }
     d_value = cfg.vf_coef * 2.0f * dv * cfg.inv_batch * vgate;
@@ -97,6 +122,13 @@ __device__ __forceinline__ void ppo_row(const float* mu, float v, const float* l
     st[2] = lp;
     st[3] = (ratio - 1.0f) - log_ratio;
     st[4] = fabsf(ratio - 1.0f) > cfg.clip_range ? 1.0f : 0.0f;
+}
+
+__device__ __forceinline__ void ppo_row(const float* mu, float v, const float* ls, const float* a, float old_lp, float A, float R,
+                                        const vf_ppo_loss_cfg& cfg, float* dm, float& d_value, float* st, int row = 0)
+{
+    const PpoRowPre p = ppo_row_pre(a);
+    ppo_row_post(p, mu, v, ls, old_lp, A, R, cfg, dm, d_value, st, row);
 }
 
 }  // namespace vf
