@@ -583,11 +583,14 @@ def test_policy_only_forward_and_split_backward(shape):
     assert (pol.grad - want).abs().max().item() <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("form", ["split", "one-wave"])
 @pytest.mark.parametrize("net", ["nav", "hover"])
 @pytest.mark.parametrize("B", [25600, 1000, 33])
-def test_fused_ppo_update_equals_separate_launches(net, B):
+def test_fused_ppo_update_equals_separate_launches(net, B, form, monkeypatch):
     """vf_ppo_update (forward + loss + reverse chain in one launch, masks from the live forward registers) + vf_mlp_weight_grad
-    vs forward / vf_ppo_loss / backward: same statistics, same gradient (up to fp32 summation order)"""
+    vs forward / vf_ppo_loss / backward: same statistics, same gradient (up to fp32 summation order) -- in both forms of the fused
+    kernel: two half-network waves per row tile (k_ppo_update_split, the default) and one wave per tile (k_ppo_update_chain)"""
+    monkeypatch.setenv("VISFLY_AMD_CHAIN_SPLIT", "1" if form == "split" else "0")     # read by the library per call
     from visfly_amd.ppo import MlpPolicy
     _lib, lib = L()
     dims = {"state": 13, "target": 3} if net == "nav" else {"state": 13}

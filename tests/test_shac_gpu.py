@@ -148,11 +148,14 @@ def test_one_iteration_matches_the_reference_loop():
     env2.close()
 
 
+@pytest.mark.parametrize("form", ["split", "one-wave"])
 @pytest.mark.parametrize("M", [1000, 4096 + 17])
-def test_fused_critic_step_equals_the_three_launch_step(M):
+def test_fused_critic_step_equals_the_three_launch_step(M, form, monkeypatch):
     """vf_twin_q_update (forward + twin-Q loss + reverse chain in one launch) leaves the loss and the flat gradient of the
     forward / vf_twin_q_loss / backward path (same chain arithmetic; the masks come from registers instead of the saved activations) --
-    row counts that are not multiples of the 32-row tile included"""
+    row counts that are not multiples of the 32-row tile included; in both forms of the fused kernel: two half-network waves per row tile
+    (k_twin_q_update_split, the default up to 32 768 rows) and one wave per tile (k_twin_q_update_chain)"""
+    monkeypatch.setenv("VISFLY_AMD_CHAIN_SPLIT", "1" if form == "split" else "0")     # read by the library per call
     fx = load("shac_hover")
     env, algo = make(fx)
     c = algo.critic

@@ -117,6 +117,22 @@ for w in ("ppo", "shac"):
 d = json.loads(open("$O/bench_bptt.json").read()); print("bptt", d.get("value"), d.get("reference_actor", {}))
 PY
     ;;
+full2)    # whole suite + threshold scan of the split form + the three trainer benches
+    timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest.txt
+    for M in 20480 25600 32768 49152; do for sp in 0 1; do
+        VISFLY_AMD_CHAIN_SPLIT=$sp prof m${M}_$sp timeout 300 python $R/tools/exp_ppo_update_one.py $M 200 > /dev/null
+        echo "M=$M split=$sp: $(grep k_ppo_update $O/m${M}_${sp}_stats.txt | awk '{print $(NF-4), $(NF-3), $(NF-2)}')" | tee -a $O/ab.txt
+    done; done
+    for w in ppo bptt shac; do
+        timeout 600 python bench.py --workload $w --no-cpu-baseline 2>&1 | tail -1 > $O/bench_$w.json
+    done
+    python - <<PY
+import json
+for w in ("ppo", "bptt", "shac"):
+    d = json.loads(open("$O/bench_%s.json" % w).read())
+    print(w, d.get("value"), d.get("roofline", {}).get("frac"), d.get("roofline", {}).get("us_per_update"), d.get("reference_actor", {}).get("value"), d.get("split_ms"))
+PY
+    ;;
 avail)    # counter names this rocprofv3 knows on gfx950
     (cd /tmp && rocprofv3 --list-avail > $O/avail.txt 2>&1); grep -c . $O/avail.txt
     ;;

@@ -142,10 +142,7 @@ struct ChainNet {
     static constexpr int mask_bits(int /*fl*/) { return -1; }     // first bit tile of forward layer fl's ReLU mask (ChainLayer::pk0), -1: the tiles stay
 };
 
-#ifndef VF_CHAIN_DEPTH
-#define VF_CHAIN_DEPTH 8
-#endif
-constexpr int kChainDepth = VF_CHAIN_DEPTH;   // weight blocks in flight: 8 x 4 MFMAs x 64 cycles = 2 k cycles of cover (the split kernels: their own choice)
+constexpr int kChainDepth = 8;   // weight blocks in flight: 8 x 4 MFMAs x 64 cycles = 2 k cycles of cover (4 deep measured the same in the split kernels)
 
 template <class N>
 struct ChainState {
@@ -198,6 +195,7 @@ using NetCriticHover = ChainNet<1, 16, 8, 4, 2, 2, 2, 2, 2, true, 1, 1, 1>;   //
 #ifndef VF_CHAIN_BUFFER_LOADS
 #define VF_CHAIN_BUFFER_LOADS 1
 #endif
+
 typedef unsigned vf_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_weight_rsrc(const float* packed)
 {
@@ -575,13 +573,9 @@ __device__ __forceinline__ float4 chain16_load(const ChainArgs& g, int lane)
         // 256 contiguous bytes
         constexpr int G = N::groups(li), blk = (a >> 1) * G + 4 * (T >> 1) + 2 * (T & 1);
         const unsigned kq = lane >> 4;
-#if VF_CHAIN_BUFFER_LOADS
-        return chain_buffer_float4(chain_weight_rsrc(g.packed), (kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u,
-                                   (unsigned)D.wr_off * 4u + (blk * 1024 + 256 * (a & 1)));       // (buffer load: see chain_load)
-#else
+        // (plain loads: as buffer loads these measured no gain in the persistent launches -- profiles/r05_chain_split.txt section 5)
         const char* base = reinterpret_cast<const char*>(g.packed + D.wr_off) + (blk * 1024 + 256 * (a & 1));       // wave-uniform
         return *reinterpret_cast<const float4*>(base + ((kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u));
-#endif
     }
 #endif
 #if VF_CHAIN16_WT

@@ -500,20 +500,11 @@ __device__ __forceinline__ float4 bwd16_load(const BwdArgsChain& g, int lane)
         constexpr int GQ = O.in_kind == 0 ? O.G : 1;
         constexpr int blk = (a >> 1) * GQ + (O.in_kind == 0 ? 4 * (T >> 1) + 2 * (T & 1) : 0);
         const unsigned kq = lane >> 4;
-#if VF_CHAIN_BUFFER_LOADS
-        const unsigned block_off = (unsigned)g.d.layer[P::entry(O.fl)].wq_off * 4u + (blk * 1024 + 256 * (a & 1));     // (buffer loads: see chain_load)
-        if constexpr (O.in_kind == 0)
-            return chain_buffer_float4(chain_weight_rsrc(g.packed), (kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u, block_off);
-        else
-            return make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(chain_weight_rsrc(g.packed), (int)((unsigned)(lane & 15) * 16u + kq * 4u), (int)block_off, 0)),
-                               0.0f, 0.0f, 0.0f);
-#else
         const char* qb = reinterpret_cast<const char*>(g.packed + g.d.layer[P::entry(O.fl)].wq_off) + (blk * 1024 + 256 * (a & 1));
         if constexpr (O.in_kind == 0)
             return *reinterpret_cast<const float4*>(qb + ((kq >> 1) * 1024u + (kq & 1u) * 512u + (unsigned)(lane & 15) * 16u));
         else
             return make_float4(*reinterpret_cast<const float*>(qb + ((unsigned)(lane & 15) * 16u + kq * 4u)), 0.0f, 0.0f, 0.0f);
-#endif
     }
 #endif
     const float* base = g.packed + g.d.layer[P::entry(O.fl)].wb_off;             // wave-uniform

@@ -25,14 +25,15 @@ __shared__ float vf_xch_q[2][64];     // the twin critic's two heads meet for mi
 #endif
 
 // Which form runs M rows?  Two half-chain waves per tile finish a tile in about 0.6 of the one-wave time while every wave still has a SIMD
-// to itself (tiles <= 512: 35.6 vs 57.5 us at 8 192 rows, 56.7 vs 60.1 at 16 384); from two waves per SIMD on they lose what they
-// gained to their second prologue, to the hand-over barriers and to a lower clock (25 600 rows: 70.5 vs 66.3 us under rocprofv3) --
-// profiles/r05_chain_split.txt.  VISFLY_AMD_CHAIN_SPLIT=0/1 forces a form (A/B, tests); read per call.
+// to itself (34.0 vs 55.1 us at 8 192 rows, 53.7 vs 56.6 at 16 384); with two waves per SIMD most of that goes to the second prologue,
+// the hand-over barriers and a lower clock (25 600 rows 59.3 vs 60.5, 32 768 rows 62.3 vs 65.5 us under rocprofv3), and over the
+// 524 288 rows of a SHAC critic update -- many tiles per SIMD either way -- the one-wave form is 2 % ahead: profiles/r05_chain_split.txt.
+// VISFLY_AMD_CHAIN_SPLIT=0/1 forces a form (A/B, tests); read per call.
 static bool chain_split_for(int M)
 {
     const char* e = getenv("VISFLY_AMD_CHAIN_SPLIT");
     if (e && *e) return atoi(e) != 0;
-    return M <= 16384;
+    return M <= 32768;
 }
 
 template <class N, int R>
