@@ -1064,15 +1064,19 @@ class PPO:
         pol.mark_updated(packed_current=pmap is not None)
         return self._stats
 
-    def train(self):
+    def train(self, permutations=None):
         """PPO.train (PPO.py:177-337): n_epochs passes over random minibatches (SB3 RolloutBuffer.get: the trailing
-        partial minibatch of an epoch is trained on too)"""
+        partial minibatch of an epoch is trained on too).  `permutations`: one row permutation per epoch (rows = step * n_envs + env)
+        instead of the trainer's own draws -- how tests replay the minibatches of a recorded run of the reference's train()
+        (tests/test_ppo_loop_gpu.py)"""
         total = self.n_steps * self.n_envs
         bs = min(self.batch_size, total)
         g = th.Generator(device=self.device)
         g.manual_seed(self.seed + 7919 * (self._opt_step + 1))
-        stats_acc = th.zeros(16, device=self.device)
-        rows_done = 0
+        # loss statistics per epoch: the reference logs approx_kl of the LAST epoch it started (the list is reset per epoch,
+        # PPO.py:197) and everything else over all minibatches of the call
+        stats_epoch = th.zeros((self.n_epochs, 16), device=self.device)
+        rows_epoch = [0] * self.n_epochs
         stop = False
         buf = self.buf
         flat = {"actions": buf.actions.view(-1, 4), "old_lp": buf.log_probs.view(-1), "adv": buf.advantages.view(-1),
@@ -1082,9 +1086,14 @@ class PPO:
         flat.update({"obs:" + k: buf.obs[k].view(-1, buf.obs[k].shape[-1]) for k in self.obs_keys})
         n_seg, rem = divmod(total, bs)
         for _epoch in range(self.n_epochs):
+            stats_acc = stats_epoch[_epoch]
             # one gather per epoch instead of one per minibatch: the shuffled copy makes every minibatch a
             # contiguous slice (same rows, same order as indexing the buffer with perm[s:s+bs])
-            perm = th.randperm(total, device=self.device, generator=g)
+            if permutations is not None:
+                perm = th.as_tensor(permutations[_epoch], dtype=th.int64, device=self.device).contiguous()
+                assert perm.numel() == total
+            else:
+                perm = th.randperm(total, device=self.device, generator=g)
             shuf = self._gather(flat, perm)
             if self.normalize_advantage and bs * self.world > 1:
                 # PPO.py:215-220 normalises per minibatch; all minibatches of the epoch in one launch (+ one
@@ -1111,15 +1120,17 @@ class PPO:
             for s in range(0, total, bs):
                 e = min(s + bs, total)
                 st = self._minibatch_update({k: v[s:e] for k, v in shuf.items()}, stats_acc)
-                rows_done += e - s
+                rows_epoch[_epoch] += e - s
                 if st is None:
                     stop = True
                     break
             if stop:
                 break
         if self.world > 1:
-            parallel.allreduce_sum_(stats_acc)                       # log the global means, like a single-process run would
-        s = (stats_acc / float(max(rows_done, 1) * self.world)).tolist()
+            parallel.allreduce_sum_(stats_epoch)                     # log the global means, like a single-process run would
+        rows_done, last = sum(rows_epoch), max(e for e in range(self.n_epochs) if rows_epoch[e] > 0 or e == 0)
+        s = (stats_epoch.sum(0) / float(max(rows_done, 1) * self.world)).tolist()
+        s[3] = float(stats_epoch[last, 3].item()) / float(max(rows_epoch[last], 1) * self.world)      # approx_kl: the last epoch's
         ep = parallel.allreduce_sum_(self._ep_stats.clone()).tolist()          # rollout statistics of this iteration (:398-414)
         self._ep_stats.zero_()
         if ep[0] > 0:
