@@ -223,49 +223,58 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
 
 def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
     """BASELINE configs[4] shape: RacingEnv, thrust actions, BPTT H=64 through the adjoint kernel, 16 384 agents per GPU
-    (131 072 / 8), agents sharded by rank, one all-reduce of the flat gradient per update."""
+    (131 072 / 8), agents sharded by rank, one all-reduce of the flat gradient per update.  The leg's `value` is the loop with the
+    actor the reference's own BPTT.learn runs (utils/algorithms/BPTT.py:113: MTDPolicy.actor = td_policies.Actor, two trunks and a
+    state-dependent clamped log_std head: `policy="MultiInputPolicy"`); the one-trunk MlpPolicy actor (a log_std parameter, half the
+    policy MFMA work per agent-step) is reported next to it as `mlp_policy_actor`."""
     from visfly_amd import parallel
     from visfly_amd.bptt import BPTT
     from visfly_amd.envs import RacingEnv
     N = args.agents if args.agents != AGENTS_PER_GPU else 16384
     dkw = dict(DYN_KW, action_type="thrust")
-    env = RacingEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dkw, device=dev, max_episode_steps=256,
-                    requires_grad=True, tensor_output=True)
-    algo = BPTT(env, horizon=64, gamma=0.99, learning_rate=1e-3, seed=0)
-    algo.learn(64 * N * world)     # warm-up update
-    torch.cuda.synchronize()
-    parallel.barrier()
     iters = iters or max(1, args.steps // 64)
-    # short regions (a few updates of 4 ms) are at the mercy of one host hiccup: three of them, the median
-    els = []
-    for _ in range(3 if iters < 16 else 1):
-        t0 = time.perf_counter()
-        algo.learn(64 * N * world * iters)
+
+    def run(policy):
+        env = RacingEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dkw, device=dev, max_episode_steps=256,
+                        requires_grad=True, tensor_output=True)
+        algo = BPTT(env, horizon=64, gamma=0.99, learning_rate=1e-3, seed=0, **({"policy": policy} if policy else {}))
+        algo.learn(64 * N * world)     # warm-up update
         torch.cuda.synchronize()
         parallel.barrier()
-        els.append(parallel.max_over_ranks(time.perf_counter() - t0, dev))
-    el = sorted(els)[len(els) // 2]
-    # rooflines of the loop as a whole (it is a chain of 10-20 us launches at 256-1024 waves, i.e. latency-bound: both fractions are
-    # small by construction and are reported so that they can be tracked).  MFMA: policy trunk forward + data gradient + weight
-    # gradient = 6 flops per weight per agent-step.  HBM: algorithmic bytes per agent-step = the forward env step (350 B, SURVEY
-    # 8d) + the state checkpoint written to the tape and read back by the adjoint (2 slabs) + the adjoint slab in / out (2 slabs)
-    pol = algo.policy
-    w_pi = sum(ly.K * ly.No + ly.No for ly in pol.layers if not (ly.dst == "value" or ly.dst.startswith("vf:")))
+        # short regions (a few updates of 4 ms) are at the mercy of one host hiccup: three of them, the median
+        els = []
+        for _ in range(3 if iters < 16 else 1):
+            t0 = time.perf_counter()
+            algo.learn(64 * N * world * iters)
+            torch.cuda.synchronize()
+            parallel.barrier()
+            els.append(parallel.max_over_ranks(time.perf_counter() - t0, dev))
+        return env, algo, sorted(els)[len(els) // 2], len(els)
+
+    env, algo, el, regions = run("MultiInputPolicy")
+    # rooflines of the loop as a whole (it is a chain of persistent launches at 1024 waves whose waves alternate between a 16-row MFMA
+    # chain and the env step's VALU stream: both fractions are small by construction and are reported so that they can be tracked).
+    # MFMA: actor forward + data gradient + weight gradient = 6 flops per weight per agent-step.  HBM: algorithmic bytes per
+    # agent-step = the forward env step (350 B, SURVEY 8d) + the state checkpoint written to the tape and read back by the adjoint
+    # (2 slabs) + the adjoint slab in / out (2 slabs)
+    w_a = int(algo.policy.n_params)
     steps_total = 64 * N * iters                      # this rank
-    tfs = 6.0 * w_pi * steps_total / el / 1e12
+    tfs = 6.0 * w_a * steps_total / el / 1e12
     slab_bytes = env._slab.numel() * 4 / N
     hbm_bytes = BYTES_PER_ENV_STEP + 4 * slab_bytes
     gbs = hbm_bytes * steps_total / el / 1e9
     roof = {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
-            "kernel": "whole update: policy forward chain + env step + adjoint env step + reverse chain + one weight-gradient launch per horizon",
-            "flops_per_agent_step": 6.0 * w_pi,
+            "kernel": "whole update: k_bptt_rollout (actor chain + env step, 64 x) + k_bptt_reverse (adjoint env step + reverse chain, 64 x) "
+                      "+ one weight-gradient launch per horizon",
+            "flops_per_agent_step": 6.0 * w_a, "actor_params": w_a,
             "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_agent_step": hbm_bytes,
                     "note": "env step 350 B + 4 slabs (tape write / read, adjoint in / out)"},
-            "note": "loop-level figures over the timed updates (wall clock, not one kernel): the loop is latency-bound -- "
-                    "profiles/r02_bptt_kernel_stats.txt lists the per-kernel times"}
-    out = {"metric": "BPTT env-steps/s (H=64 rollout + adjoint + actor update, RacingEnv)",
+            "note": "loop-level figures over the timed updates (wall clock, not one kernel) -- profiles/r04_bptt_kernel_stats.txt lists "
+                    "the per-kernel times, profiles/r04_pmc_mfma.txt the MFMA-busy share of a wave's life"}
+    out = {"metric": "BPTT env-steps/s (H=64 rollout + adjoint + actor update, RacingEnv, the reference's td_policies.Actor)",
            "value": 64 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
-           "iterations": iters, "regions": len(els), "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic", "roofline": roof,
+           "iterations": iters, "regions": regions, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic", "roofline": roof,
+           "policy": "td_policies.Actor (policy=\"MultiInputPolicy\"): extractor [128, 64], latent_pi / log_latent_pi [64, 64], mu / log_std heads",
            "exchange": exchange_block(algo.policy.grad, 1, el / iters, el / iters * 1e6, world, dev),     # one all-reduce of the flat gradient per update
            "config": {"workload": f"RacingEnv {N} agents/GPU, thrust actions, horizon 64 (BASELINE configs[4] shard)",
                       "logs": {k: float(v) for k, v in algo.logs.items()}}}
@@ -273,26 +282,12 @@ def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
         out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "racing", 16384, seconds_target=3.0,
                                                note="forward env.step only (no adjoint on the CPU side)")
     env.close()
-    # the same loop with the reference's own actor (utils/policies/td_policies.py:146-252, what BPTT.py:113 calls: two trunks, state-dependent
-    # clamped log_std head) instead of the MlpPolicy actor above (one trunk, log_std parameter): 2 x the policy MFMA work per agent-step
-    env = RacingEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dkw, device=dev, max_episode_steps=256,
-                    requires_grad=True, tensor_output=True)
-    algo = BPTT(env, policy="MultiInputPolicy", horizon=64, gamma=0.99, learning_rate=1e-3, seed=0)
-    algo.learn(64 * N * world)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    els = []
-    for _ in range(3 if iters < 16 else 1):
-        t0 = time.perf_counter()
-        algo.learn(64 * N * world * iters)
-        torch.cuda.synchronize()
-        parallel.barrier()
-        els.append(parallel.max_over_ranks(time.perf_counter() - t0, dev))
-    el2 = sorted(els)[len(els) // 2]
-    w_a = algo.policy.n_params
-    out["reference_actor"] = {"value": 64 * N * world * iters / el2, "unit": "agent-steps/s", "s_per_iteration": el2 / iters,
-                              "policy": "td_policies.Actor (MultiInputPolicy): extractor [128, 64], latent_pi / log_latent_pi [64, 64], mu / log_std heads",
-                              "mfma_frac": 6.0 * w_a * 64 * N * iters / el2 / 1e12 / 157.3, "actor_params": int(w_a)}
+    env, algo, el2, _ = run(None)
+    pol = algo.policy
+    w_pi = sum(ly.K * ly.No + ly.No for ly in pol.layers if not (ly.dst == "value" or ly.dst.startswith("vf:")))
+    out["mlp_policy_actor"] = {"value": 64 * N * world * iters / el2, "unit": "agent-steps/s", "s_per_iteration": el2 / iters,
+                               "policy": "MlpPolicy actor (one trunk, log_std parameter): extractor [128, 64], pi [64, 64], 4-wide head",
+                               "mfma_frac": 6.0 * w_pi * 64 * N * iters / el2 / 1e12 / 157.3, "actor_params": int(w_pi)}
     env.close()
     return out
 
@@ -335,6 +330,71 @@ def bench_shac(args, rank, world, dev, iters=None, cpu_ref=False):
                         "note": "loop-level figure over the timed iterations (wall clock, not one kernel)"},
            "config": {"workload": f"HoverEnv {N} agents/GPU, bodyrate, horizon {H}, 5 critic steps (SURVEY 8f-2; the reference's SHAC defaults)",
                       "logs": {k: float(v) for k, v in algo.logs.items()}}}
+    env.close()
+    return out
+
+
+def bench_nav_rk4_dr(args, rank, world, dev, iters=None, cpu_ref=False):
+    """BASELINE configs[2] (SURVEY 8d input 3): NavigationEnv.step, 65 536 agents per GPU, RK4 integrator + ctrl_delay + domain
+    randomisation of the drag coefficients (drag_random = 0.1: two 16-byte per-agent granules read every step, re-drawn by the on-device
+    spawner at every reset) -- the same fused launch as the headline, driven and timed the same way (env.step_n, regions of `steps`
+    launches between barriers, HIP events on the launch stream for the kernel time)."""
+    from visfly_amd import parallel
+    from visfly_amd.envs import NavigationEnv
+    N = args.agents
+    K = iters or max(20, min(args.steps, 2000))
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+    dkw = dict(DYN_KW, integrator="rk4", drag_random=0.1)
+    env = NavigationEnv(num_agent_per_scene=N, num_scene=1, seed=42 + rank, visual=False, dynamics_kwargs=dkw, random_kwargs=spawn,
+                        device=dev, max_episode_steps=256, tensor_output=True, out_buffers=4)
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    hover = torch.tensor([-1 / 3, 0, 0, 0], device=dev)
+    Kc = min(K, args.chunk)
+    seq = (hover + (torch.rand((Kc, N, 4), device=dev, generator=g) * 2 - 1) * 0.02).clamp(-1, 1).contiguous()
+
+    def run_steps(n):
+        done = 0
+        while done < n:
+            k = min(n - done, Kc)
+            env.step_n(seq if k == Kc else seq[:k])
+            done += k
+    run_steps(max(256, 4 * Kc))          # allocation of the output ring + clocks
+    torch.cuda.synchronize()
+    walls, events = [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        parallel.barrier()
+        t0 = time.perf_counter()
+        run_steps(K)
+        torch.cuda.synchronize()
+        walls.append(parallel.max_over_ranks(time.perf_counter() - t0, dev))
+    for _ in range(3):
+        parallel.barrier()
+        e0.record()
+        run_steps(K)
+        e1.record()
+        torch.cuda.synchronize()
+        events.append(e0.elapsed_time(e1) * 1e-3)
+    el, kern_us = statistics.median(walls), statistics.median(events) / K * 1e6
+    dn = env._rollouts[Kc]["done"]
+    bytes_step = BYTES_PER_ENV_STEP + 32             # + the two drag granules (16 B each) every step reads
+    achieved = bytes_step * N / (kern_us * 1e-6) / 1e9
+    out = {"metric": "agent-steps/sec (NavigationEnv.step, RK4 + ctrl_delay + drag domain randomisation)",
+           "value": world * N * K / el, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "us_per_step": el / K * 1e6,
+           "dtype": "f32", "data": "synthetic", "episode_end_rate": float(dn.float().mean()),
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "k_env_step<navigation,bodyrate,rk4,ctrl_delay> (per-agent drag granules)",
+                        "kernel_us": kern_us, "bytes_per_agent_step": bytes_step,
+                        "kernel_us_source": "HIP events on the launch stream over the timed regions / steps (median of 3)",
+                        "note": "bound by the contract's definition; like the headline launch it is limited by a lone wave's VALU issue "
+                                "(RK4 = four derivative evaluations per sub-step: ~1.5 x the Euler launch), DESIGN.md 4"},
+           "config": {"workload": f"NavigationEnv.step, {N} agents/GPU, visual=False, bodyrate + RK4, dt=0.0025/ctrl_dt=0.02, ctrl_delay, "
+                                  "drag_random=0.1, max_episode_steps=256 (BASELINE configs[2])"}}
+    if cpu_ref and rank == 0:
+        out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "nav", N, seconds_target=3.0,
+                                               note="oracle env.step with the RK4 integrator and the nominal drag coefficients (the per-agent "
+                                                    "draw changes values, not the arithmetic)")
     env.close()
     return out
 
@@ -390,8 +450,8 @@ def main():
                     "gpu_busy samples see the GPU working; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
-    ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt", "shac"],
-                    help="env: fused HoverEnv.step (the BASELINE metric, default); ppo / bptt / shac: that loop only")
+    ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt", "shac", "nav_rk4_dr"],
+                    help="env: fused HoverEnv.step (the BASELINE metric, default); ppo / bptt / shac / nav_rk4_dr (BASELINE configs[2]): that leg only")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins the process group, one barrier, rank 0 prints the world size "
                          "(no GPU work; tests/test_parallel_gloo.py runs the plain `--gpus 2` command through it on CPU)")
@@ -400,6 +460,15 @@ def main():
         sys.exit(_self_launch(args.gpus))
 
     from visfly_amd import parallel
+    build_info = None
+    if not args.launch_check:
+        # did THIS process compile the library or reuse the .so that travelled with the tree?  (recorded in the JSON line)
+        from visfly_amd import _build
+        stale = _build._stale()
+        t_b = time.time()
+        _build.build()
+        build_info = {"rebuilt": bool(stale), "so_mtime": os.path.getmtime(_build.LIB), "so_bytes": os.path.getsize(_build.LIB),
+                      "build_s": round(time.time() - t_b, 1) if stale else 0.0}
     if args.launch_check:
         import torch.distributed as dist
         dist.init_process_group(os.environ.get("VISFLY_AMD_DIST_BACKEND", "gloo"))
@@ -421,9 +490,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-    if args.workload in ("ppo", "bptt", "shac"):
-        out = {"ppo": bench_ppo, "bptt": bench_bptt, "shac": bench_shac}[args.workload](args, rank, world, dev, cpu_ref=world == 1)
+    if args.workload in ("ppo", "bptt", "shac", "nav_rk4_dr"):
+        out = {"ppo": bench_ppo, "bptt": bench_bptt, "shac": bench_shac, "nav_rk4_dr": bench_nav_rk4_dr}[args.workload](args, rank, world, dev, cpu_ref=world == 1)
         if rank == 0:
+            out["build"] = build_info
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -672,6 +742,7 @@ def main():
                                                             "= the first K-step region of the process, timed right after W warm-up "
                                                             "steps and before any spin-up (one region, max over ranks)",
                        "ms_per_step_without_spinup": cold_el / K * 1e3},
+            "build": build_info,
             "sustained": sustained,
             "with_resets": with_resets,
             "rollout_fused": {"value": world * N * K / fused_el, "unit": "agent-steps/s", "us_per_step": fused_el / K * 1e6,
@@ -699,7 +770,7 @@ def main():
     # configs[3] / configs[4] / SHAC under the same clock: ONE PPO iteration, three regions of FOUR BPTT updates and of TWO SHAC iterations (median; after one warm-up each)
     if not args.no_secondary and os.environ.get("VISFLY_BENCH_SECONDARY", "1") != "0":
         sec, dead = {}, False
-        for name, fn, iters in (("ppo", bench_ppo, 1), ("bptt", bench_bptt, 4), ("shac", bench_shac, 2)):
+        for name, fn, iters in (("nav_rk4_dr", bench_nav_rk4_dr, K), ("ppo", bench_ppo, 1), ("bptt", bench_bptt, 4), ("shac", bench_shac, 2)):
             res, dead = _with_watchdog(lambda fn=fn, iters=iters: fn(args, rank, world, dev, iters=iters, cpu_ref=world == 1),
                                        240, name)
             sec[name] = res
