@@ -291,6 +291,9 @@ class BPTT:
         """the same gradient with torch.autograd as the scheduler (two custom Functions wrap the kernels); kept as the
         cross-check of the reverse sweep and as the template for dropping in an arbitrary torch policy"""
         env, pol, N = self.env, self.policy, self.env.num_envs
+        if self.reference_actor:
+            raise NotImplementedError("use_autograd=True drives the one-head MlpPolicy actor (log_std parameter); the reference's "
+                                      "two-head actor runs on the reverse sweep only")
         pol.grad.zero_()
         log_std = pol.log_std.detach().clone().requires_grad_(True)
         anchor = th.zeros(1, device=self.device, requires_grad=True)
@@ -388,6 +391,11 @@ class BPTT:
             spec, load_opt = d["spec"], kwargs.pop("load_optimizer", True)
             kwargs.setdefault("policy_kwargs", cls._policy_kwargs_from_spec(spec))
             kwargs.setdefault("horizon", spec["horizon"])
+            # the hyper-parameters the archive was trained with (a resumed run silently trained with the constructor's
+            # defaults next to the restored Adam moments); an explicit keyword argument still wins
+            for k in ("gamma", "learning_rate", "tau", "gradient_steps", "lamda"):
+                if k in spec:
+                    kwargs.setdefault(k, spec[k])
             if cls is BPTT:
                 kwargs.setdefault("policy", "MultiInputPolicy")
             algo = cls(env, **kwargs)

@@ -161,9 +161,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         }
         // the action row this wave just wrote is what it reads next (other lanes of the SAME wave: program order through the one
         // TCP; a workgroup-scope fence = s_waitcnt only -- an agent-scope __threadfence() adds an L2 write-back per step)
-#ifndef VF_EXP_NO_FWD_FENCE
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#endif
         // ---- checkpoint for the adjoint: this agent's granules of tape row t = the slab before the step ----
         float* T = r.tape + (size_t)t * r.tape_stride;
         store_agent(T, Gx, ic, s, sp);
@@ -210,9 +208,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         loss = loss + -1.0f * reward * disc;
         const float dn = done ? 1.0f : 0.0f;
         disc = disc * r.gamma * (1.0f - dn) + dn;
-#ifndef VF_EXP_NO_FWD_FENCE
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the observation rows of slot t + 1 are read by the next forward
-#endif
         // ---- next step ----
         g.d.action += r.N;                               // float4 units
         g.out.done += r.N;

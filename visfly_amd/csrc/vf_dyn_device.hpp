@@ -541,7 +541,7 @@ __device__ __forceinline__ void st1(float* p, const float v)
 #endif
 }
 
-// store with an explicit cache policy (A/B experiments: -DVF_EXP_EARLY): 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1
+// store with an explicit cache policy (store_rows_coalesced's MODE; measured in profiles/r04_env_quad.txt): 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1
 template <int MODE>
 __device__ __forceinline__ void st4_mode(float4* p, const float4 v)
 {

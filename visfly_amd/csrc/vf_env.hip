@@ -8,9 +8,6 @@
 // env counters ride in the spare components of the dynamics granules, so the env step
 // moves the same bytes as the bare dynamics step plus its outputs.
 #include "vf_env_epilogue.hpp"
-#ifdef VF_EXP_ENV_QUAD
-#include "vf_dyn_quad.hpp"
-#endif
 
 #pragma clang fp contract(off)
 
@@ -52,7 +49,6 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
     EnvArgs g = g0;
     g.d.S = S; g.d.action = action; g.d.N = N; g.d.G = G; g.d.head = head; g.helper = helper; g.d.g_drag = g_drag;
-#ifndef VF_EXP_NO_HELPER
     // the blocks behind the g.helper main blocks: helper blocks (prefetched re-spawn), kHelperSpan agents per thread (a workgroup dispatch
     // costs more than their checks).  (Laying the helper's code and the episode-end blocks out behind the hot path with __builtin_expect --
     // the instruction cache is cold at every launch -- was measured in both regimes: no difference, profiles/r04_env_timeline.txt)
@@ -63,7 +59,6 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
         for (int k = 0; k < kHelperSpan; ++k) spawn_helper(e, g, base + k * kBlock);
         return;
     }
-#endif
 #ifdef VF_ENV_TRACE
     unsigned long long tr[13];
 #endif
@@ -77,7 +72,6 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     load_agent<false>(g.d.S, g.d.G, i, s, sp);
     float4 dk0 = make_float4(0.f, 0.f, 0.f, 0.f), dk1 = dk0;
     if (g.d.g_drag >= 0) { dk0 = *granule(g.d.S, g.d.G, i, g.d.g_drag); dk1 = *granule(g.d.S, g.d.G, i, g.d.g_drag + 1); }
-#ifndef VF_EXP_NO_CFG_PREFETCH
     // ... and behind the burst ONE batch of scalar loads: the remaining kernel-argument lines and the lines of the two constant blocks
     // (first touched one after the other on the way, each was a round trip a lone wave sits out in full)
 #ifdef VF_ENV_TRACE
@@ -88,7 +82,6 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     VF_TR(3);                                        // kernel-argument lines arrived
 #else
     prefetch_kernarg_and_const_lines<sizeof(EnvArgs) + 56, (sizeof(vf_dyn_cfg) + 63) / 64, 2>(cp, ep, &ep->obs_mode);
-#endif
 #endif
     load_wind(c, g.d, i, live, s);
     if (delay_steps > 0) sp.vel = head_bits;
@@ -118,23 +111,6 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
     control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
 #endif
     const int wave = threadIdx.x >> 6;
-#ifdef VF_EXP_EARLY
-    {   // A/B experiment: what the interval finalised goes out BEFORE collision / reward / counters, with cache policy VF_EXP_EARLY - 1
-        constexpr int EM = VF_EXP_EARLY - 1;
-        float* S_ = g.d.S;
-        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_POS), make_float4(s.t, s.p[0], s.p[1], s.p[2]));
-        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_QUAT), make_float4(s.q.w, s.q.x, s.q.y, s.q.z));
-        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_VEL), make_float4(sp.vel, s.v[0], s.v[1], s.v[2]));
-        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_MOT), make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]));
-        st4_mode<EM>(granule(S_, g.d.G, i, VF_G_THR), make_float4(s.T[0], s.T[1], s.T[2], s.T[3]));
-        float o[13];
-        obs_row(c, s, o);
-        obs_variant(e, o);
-        store_rows_coalesced<13, EM>(g.out.obs, g.d.N, blockIdx.x * kBlock + wave * 64, o, tile + wave * 64 * 13);
-    }
-    env_epilogue<KIND, true, 1, false, LAZY_SLOT, VF_EXP_EARLY>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13);
-    return;
-#endif
 #ifdef VF_ENV_TRACE
     env_epilogue<KIND, true, 1, false, LAZY_SLOT>(c, e, g, i, live, s, sp, blockIdx.x * kBlock + wave * 64, tile + wave * 64 * 13, nullptr, nullptr, tr);
     asm volatile("" ::: "memory");
@@ -160,43 +136,6 @@ __global__ __launch_bounds__(kBlock) void k_env_step(const vf_dyn_cfg* __restric
 }
 
 
-#ifdef VF_EXP_ENV_QUAD
-// Measurement build only (-DVF_EXP_ENV_QUAD, run with VISFLY_AMD_ENV_QUAD=1; profiles/r04_env_quad.txt): the env step with FOUR LANES PER
-// AGENT -- 16 agents per wave, 4 waves per SIMD at 65 536 agents, the sub-step loop in component layout (vf_dyn_quad.hpp, the loop the
-// persistent BPTT launches run), controller / epilogue / loads / stores replicated in the four lanes of a quad.  Bit-identical to
-// k_env_step (tests/test_env_gpu.py passes on it) and 1.5 x slower: the component-layout sub-step costs 1.03 us where the one-lane
-// form costs 0.55 (four waves of 166 instructions, a third of them DPP moves, issue at 3.7 cycles per instruction per SIMD).
-template <int KIND, int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(kBlock) void k_env_step_quadrep(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs g)
-{
-    const vf_dyn_cfg& c = *cp;
-    const vf_env_cfg& e = *ep;
-    __shared__ __attribute__((aligned(16))) float tile[kBlock * 13];
-    if (g.helper) {
-        const int nbm = g.helper;
-        if ((int)blockIdx.x >= nbm) {
-            spawn_helper(e, g, ((int)blockIdx.x - nbm) * kBlock + (int)threadIdx.x);
-            return;
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_first = blockIdx.x * 64 + wave * 16;
-    const int i = wave_first + (lane >> 2);
-    const bool live = i < g.d.N;
-    Agent s;
-    Spares sp;
-    float a[4], head_bits = 0.0f;
-    ring_exchange(c, g.d, i, live, head_bits, a);
-    load_agent<false>(g.d.S, g.d.G, i, s, sp);
-    load_wind(c, g.d, i, live, s);
-    if (c.delay_steps > 0) sp.vel = head_bits;
-    float kl[3], kq[3];
-    drag_of(c, g.d, i, kl, kq);
-    const QuadLane ql = quad_lane(c, lane);
-    control_interval_quad<ACT, INTEG, CTRL_DELAY>(c, ql, s, a, kl, kq, g.d.vstrided != 0, NoCheckpointQuad{});
-    env_epilogue<KIND, true, 4, false, false>(c, e, g, i, live, s, sp, wave_first, tile + wave * 64 * 13);
-}
-#endif
 
 // The part of the step that follows the dynamics interval, as a launch of its own (vf_env_finish_step): the dynamics ran
 // in vf_dyn_step on the same slab, an external scene manager then answered the collision query for the new poses
@@ -495,27 +434,6 @@ EnvStepKernel pick_env_split(const vf_env* h)
     }
 }
 
-#ifdef VF_EXP_ENV_QUAD
-template <int KIND>
-EnvKernel pick_env_quadrep_k(const vf_dyn_cfg& c)
-{
-    if (!c.ctrl_delay || c.integrator != VF_INT_EULER) return nullptr;
-    if (c.action_type == VF_ACT_BODYRATE) return vf::k_env_step_quadrep<KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
-    if (c.action_type == VF_ACT_THRUST) return vf::k_env_step_quadrep<KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
-    return nullptr;
-}
-EnvKernel pick_env_quadrep(const vf_env* h)
-{
-    static const int on = [] { const char* e = getenv("VISFLY_AMD_ENV_QUAD"); return e ? atoi(e) : 0; }();
-    if (on != 1) return nullptr;
-    switch (h->cfg.kind) {
-    case VF_ENV_HOVER: return pick_env_quadrep_k<VF_ENV_HOVER>(h->dyn.cfg);
-    default: return nullptr;
-    }
-}
-#else
-EnvKernel pick_env_quadrep(const vf_env*) { return nullptr; }
-#endif
 
 EnvStepKernel pick_env_kernel(const vf_env* h)
 {
@@ -555,8 +473,9 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
             // atomics in every ending wave, a dependent load more in front of the helper's refills): profiles/r04_env_quad.txt
             static const bool bits_off = [] { const char* e = getenv("VISFLY_AMD_STALE_BITS"); return !(e && atoi(e) == 1); }();
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(st, &cap);
-            if (h->d_stale && !bits_off && (mode & 2) && cap == hipStreamCaptureStatusNone) {
+            const bool bits_wanted = h->d_stale && !bits_off && (mode & 2);
+            if (bits_wanted) (void)hipStreamIsCapturing(st, &cap);        // (a runtime call per launch: only when the bits are on)
+            if (bits_wanted && cap == hipStreamCaptureStatusNone) {
                 const int tiles = h->dyn.Npad / 64;
                 if (h->stale_all) {
                     VF_HIP(hipMemsetAsync(h->d_stale, 0xFF, (size_t)2 * tiles * sizeof(unsigned long long), st));
@@ -571,13 +490,6 @@ int launch_env_step(vf_env* h, const float* action, const vf_env_out* out, int a
         } else {
             h->stale_all = 1;
         }
-        EnvKernel kq = g.stale ? nullptr : pick_env_quadrep(h);
-        if (kq) {                                // 64 agents per main block
-            const unsigned nbm = h->dyn.Npad / 64;
-            if (g.helper) g.helper = (int)nbm;
-            nb = nbm + (g.helper ? h->dyn.Npad / vf::kBlock : 0);
-            hipLaunchKernelGGL(kq, dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g);
-        } else
         hipLaunchKernelGGL(pick_env_kernel(h), dim3(nb), dim3(vf::kBlock), 0, st, h->dyn.d_cfg, h->d_cfg, g.d.S, g.d.action, g.d.N, g.d.G,
                            g.d.head, g.helper, h->dyn.cfg.delay_steps, g.d.g_drag, g);
     }

@@ -158,15 +158,6 @@ __device__ __forceinline__ void sincos_spawn(float x, float& sn, float& cs)
 // indexed reset's t take the twelve spare top bytes (Philox output bits are independent; a fourth block was 90 instructions).
 __device__ __forceinline__ void spawn_agent(const vf_env_cfg& e, int agent, unsigned episode, bool indexed, Agent& s)
 {
-#ifdef VF_EXP_CHEAP_SPAWN      // tools/exp_reset_bound.py: what the launch would cost if the draw + Euler conversion were free
-    {
-        const vf_spawn_box& sb0 = e.spawn[0];
-        for (int d = 0; d < 3; ++d) { s.p[d] = sb0.pos_mean[d] + 0.001f * (float)((agent + (int)episode) & 255) * sb0.pos_half[d]; s.v[d] = sb0.vel_mean[d]; s.w[d] = sb0.omg_mean[d]; }
-        s.q = Quat{1.0f, 0.0f, 0.0f, 0.0f};
-        s.t = 0.0f;
-        return;
-    }
-#endif
     const unsigned k0 = (unsigned)e.seed, k1 = (unsigned)(e.seed >> 32);
     const U4 r0 = philox4x32_10(U4{(unsigned)agent, episode, 0u, 0x5eedu}, k0, k1);
     const U4 r1 = philox4x32_10(U4{(unsigned)agent, episode, 1u, 0x5eedu}, k0, k1);

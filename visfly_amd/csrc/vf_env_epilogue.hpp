@@ -102,13 +102,6 @@ __device__ __forceinline__ void spawn_helper(const vf_env_cfg& e, const EnvArgs&
     if (word) atomicAnd(word, ~(1ull << (i & 63)));
 }
 
-#ifndef VF_EXP_SLOT_MODE
-#define VF_EXP_SLOT_MODE 1       // 0: the loads under `if (done)` (A/B, profiles/r03_reset_prefetch.txt)
-#endif
-#ifndef VF_EXP_SLOT_ALWAYS
-#define VF_EXP_SLOT_ALWAYS 0     // 1: the r03 form -- every lane of every wave loads its spawn copy (A/B, profiles/r04_env_quad.txt)
-#endif
-
 // the prefetched spawn copy of agent i (granules g_spawn_rd .. + 3 of its tile).  Loaded by EVERY lane, ending an episode or not
 // (granule 0 when the feature is off: a valid address whose value nobody looks at): a load under `if (done)` joins a path on which
 // the registers are undefined, and the copies the join needs are placed -- with their s_waitcnt -- right behind the loads
@@ -123,10 +116,9 @@ __device__ __forceinline__ SpawnSlot load_spawn_slot(const EnvArgs& g, int i, bo
 
 // LANES = 4: the agent is held by the four lanes of a quad (lanes 4 m .. 4 m + 3 = row m of the wave's 16, k_bptt_rollout): only the
 // row hand-over at the end depends on the lane <-> agent map
-// EARLY (A/B experiment -DVF_EXP_EARLY, k_env_step only): 0 = off; 1 + m = the caller has already stored, with cache policy m (st4_mode), the
-// granules the interval finalises (POS, QUAT, VEL, MOT, THR) and the observation row; the epilogue then stores the three granules that
-// carry the env counters and, for an agent that re-spawns, those five and its row once more
-template <int KIND, bool STORE_STATE = true, int LANES = 1, bool EXT = false, bool LAZY_SLOT = false, int EARLY = 0>
+// (storing what the interval finalises BEFORE collision / reward / counters, with write-through or non-temporal policies, was measured:
+// 0.3 us off the headline regime only, profiles/r04_env_quad.txt; not kept)
+template <int KIND, bool STORE_STATE = true, int LANES = 1, bool EXT = false, bool LAZY_SLOT = false>
 __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_cfg& e, const EnvArgs& g, int i, bool live,
                                              Agent& s, Spares& sp, int wave_first, float* tile, float* reward_reg = nullptr,
                                              bool* done_reg = nullptr, unsigned long long* tr = nullptr)   // tr: -DVF_ENV_TRACE builds only
@@ -165,18 +157,14 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     const bool done = ep_done || truncated;                                              // :193
     // prefetched re-spawn: the copy an ending agent starts its next episode from (load_spawn_slot)
     SpawnSlot slot;
-#ifdef VF_EXP_NO_SLOT
-    const bool use_slot = false;
-#else
     const bool use_slot = done && g.auto_reset && g.g_spawn_rd >= 0;
-#endif
-    if constexpr (VF_EXP_SLOT_MODE == 1 && !LAZY_SLOT) {
+    if constexpr (!LAZY_SLOT) {
         // Issued by every lane, consumed only by an ending one (a load under `if (done)` is waited for on the spot:
         // profiles/r03_reset_prefetch.txt).  r04: in a wave in which NO agent ends its episode the four loads read the agent's own
         // state granules instead (fetched at the head of the launch: L2 hits) -- a wave-uniform SELECT of the granule index, not a
         // branch, so there is no join whose copies wait for the loads.  r03 read the spawn copy in every wave: 64 B of HBM traffic per
         // agent-step that nobody looks at in the headline regime, where nobody ends an episode (1.25 x the algorithmic bytes)
-        const bool wave_ends = VF_EXP_SLOT_ALWAYS || __builtin_amdgcn_ballot_w64(use_slot) != 0;
+        const bool wave_ends = __builtin_amdgcn_ballot_w64(use_slot) != 0;
         slot = load_spawn_slot(g, i, wave_ends);
     } else {
         if (use_slot) slot = load_spawn_slot(g, i);
@@ -214,7 +202,6 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     er.flags = set_flag(er.flags, VF_F_SUCCESS, success);
     er.flags = set_flag(er.flags, VF_F_FAILURE, failure);
     er.flags = set_flag(er.flags, VF_F_DONE, done);
-#ifndef VF_EXP_NO_DONE_LIST
     if (g.out.done_list) {                       // compacted done list: one atomic per wave that has an ending agent
         const bool mine = live && done && (LANES == 1 || (threadIdx.x & (LANES - 1)) == 0);   // (a quad: its first lane speaks for the agent)
         const unsigned long long m = __ballot(mine);
@@ -226,7 +213,6 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
             if (mine) g.out.done_list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
         }
     }
-#endif
     float o[13];
     obs_row(c, s, o);
     obs_variant(e, o);
@@ -295,19 +281,6 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         er.rewards = 0.0f;
         obs_row(c, s, o);
         obs_variant(e, o);
-        if constexpr (EARLY != 0) {
-            if (live) {
-                float* to = g.out.obs + 13 * (size_t)i;
-#pragma unroll
-                for (int k = 0; k < 13; ++k) st1_mode<EARLY - 1>(to + k, o[k]);
-            }
-            float* S_ = g.d.S;
-            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_POS), make_float4(s.t, s.p[0], s.p[1], s.p[2]));
-            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_QUAT), make_float4(s.q.w, s.q.x, s.q.y, s.q.z));
-            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_VEL), make_float4(sp.vel, s.v[0], s.v[1], s.v[2]));
-            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_MOT), make_float4(s.wm[0], s.wm[1], s.wm[2], s.wm[3]));
-            st4_mode<EARLY - 1>(granule(S_, g.d.G, i, VF_G_THR), make_float4(s.T[0], s.T[1], s.T[2], s.T[3]));
-        }
     }
     if constexpr (KIND == VF_ENV_RACING) {
         race.x = __int_as_float(gate);
@@ -317,12 +290,6 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     }
     pack_env(er, sp);
     VF_EPI_TR(9, sp.acc);                                                                // outputs written, re-spawn decided
-    if constexpr (EARLY != 0) {
-        st4(granule(g.d.S, g.d.G, i, VF_G_OMG), make_float4(sp.omg, s.w[0], s.w[1], s.w[2]));
-        st4(granule(g.d.S, g.d.G, i, VF_G_AACC), make_float4(sp.aacc, s.aa[0], s.aa[1], s.aa[2]));
-        st4(granule(g.d.S, g.d.G, i, VF_G_ACC), make_float4(sp.acc, s.acc[0], s.acc[1], s.acc[2]));
-        return;
-    }
     if constexpr (STORE_STATE) store_agent(g.d.S, g.d.G, i, s, sp);
     VF_EPI_TR(10, sp.acc);                                                               // state stores issued
     if constexpr (LANES == 4) store_rows_quads<13>(g.out.obs, g.d.N, wave_first, o, tile);

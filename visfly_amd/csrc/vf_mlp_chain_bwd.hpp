@@ -312,9 +312,7 @@ __device__ __forceinline__ void bwd_items(const BwdArgsChain& g, BwdState<P>& st
         if constexpr (local == 0 && O.in_kind == 0 && std::is_same<FS, NoFwd>::value) bwd_mask_load<P, oi>(g, st, rc, h);   // head ops: in the prologue
         f32x16& acc = st.t[O.out0 + a];
         if constexpr (gq == 0 && !O.accum) acc = f32x16{0};
-#ifndef VF_EXP_NO_ITEM_FENCE
         __builtin_amdgcn_sched_barrier(0);      // refill load + address arithmetic before the item's MFMAs, not among them (chain_items)
-#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float b;

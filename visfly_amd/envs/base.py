@@ -831,6 +831,9 @@ class DroneGymEnvsBase:
         self._adj = th.zeros_like(self._slab)
         self._tape_t = 0
         self._record_all = True      # manual mode: every step() is recorded until clear_tape()/detach()
+        # the sub-step tape is sized by the tape: a new horizon gets a new one (a second trainer with a longer horizon on
+        # the same env handed vf_bptt_rollout the first trainer's rows)
+        self._substep, self._substep_range = None, None
 
     def rollout_policy(self, policy, obs_keys, eps, actions, d_reward, loss, disc, gamma, scale, reward_rows=None, ep_flag_rows=None):
         """H = eps.shape[0] closed-loop control steps -- policy forward (slots 0..H-1 of `policy`, reserved back to back), action
@@ -872,11 +875,14 @@ class DroneGymEnvsBase:
         L = _lib.lib()
         # sub-step tape (include/visfly_amd.h, vf_bptt_rollout): what the reverse launch reads instead of replaying every interval;
         # one (S + 3 rows, waves of 16 agents, 64) float4 record block per tape row, allocated with the first persistent roll-out
+        # ... and only where the reverse launch reads it (vf_bptt_reverse: 16 agents per wave, i.e. N <= 16 384 per launch, and a
+        # delay ring of at most 4 slots): elsewhere it would be (S + 3) KiB per wave-step of stores nobody loads
         sub = None
-        if self.substep_tape:
-            if getattr(self, "_substep", None) is None:
-                S = int(self.envs.dynamics.constants["interval_steps"])
-                self._substep = th.empty((self._tape.shape[0], S + 3, (N + 15) // 16, 64, 4), dtype=th.float32, device=dev)
+        if self.substep_tape and N <= 16384 and self.envs.dynamics._comm_delay_steps <= 4:
+            S = int(self.envs.dynamics.constants["interval_steps"])
+            shape = (self._tape.shape[0], S + 3, (N + 15) // 16, 64, 4)
+            if getattr(self, "_substep", None) is None or tuple(self._substep.shape) != shape:
+                self._substep = th.empty(shape, dtype=th.float32, device=dev)
             sub = self._substep[t0]
         self._substep_range = None
         two_heads = tuple(policy.head_dims) == (4, 4) and policy.log_std.numel() == 0
