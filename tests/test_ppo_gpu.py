@@ -757,7 +757,8 @@ def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
 
 
 @pytest.mark.parametrize("env_name,N,dyn", [("NavigationEnv", 3000, "euler"), ("HoverEnv", 1000, "euler"), ("NavigationEnv", 16500, "euler"),
-                                            ("HoverEnv", 16401, "euler"), ("NavigationEnv", 3000, "rk4_drag"), ("HoverEnv", 16401, "rk4")])
+                                            ("HoverEnv", 16401, "euler"), ("NavigationEnv", 3000, "rk4_drag"), ("HoverEnv", 16401, "rk4"),
+                                            ("HoverEnv", 1000, "euler_nodelay"), ("NavigationEnv", 16500, "rk4_nodelay")])
 def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
     """collect_rollouts as ONE launch (vf_ppo_rollout: 16 / 32 agents per wave for all n_steps, the same rows-per-wave chain
     vf_mlp_forward picks for N rows) leaves the rollout buffer, the TimeLimit list, the episode statistics, the episode
@@ -772,6 +773,8 @@ def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
         dkw["integrator"] = "rk4"
     if dyn.endswith("drag"):
         dkw["drag_random"] = 0.5
+    if dyn.endswith("nodelay"):            # r05: no motor lag (envs/base/dynamics.py:534-554) has its persistent instances too
+        dkw["ctrl_delay"] = False
     res = []
     for fused in (True, False):
         kw = {}
@@ -835,25 +838,21 @@ def test_persistent_rollout_shortest_horizons(n_steps):
 
 
 def test_persistent_rollout_declines_what_it_has_no_kernel_for():
-    """no motor lag (ctrl_delay=False, not the reference's default): vf_ppo_rollout answers VF_EUNSUPPORTED, collect_rollouts warns
-    ONCE with the library's reason, steps launch by launch and stops asking.  (RK4, declined until r03, has its instances now.)"""
-    import warnings
+    """what is left without a persistent instance after r05: per-agent wind rows (a host-side wind function, dynamics.py:270-317).
+    vf_ppo_rollout answers VF_EUNSUPPORTED / collect_rollouts does not ask, the loop steps launch by launch and keeps working."""
     from visfly_amd.envs import HoverEnv
     from visfly_amd.ppo import PPO
     from _golden import ENV_DYN
-    env = HoverEnv(num_agent_per_scene=512, seed=3, dynamics_kwargs=dict(ENV_DYN, ctrl_delay=False, comm_delay=0.0), device=DEV,
+    env = HoverEnv(num_agent_per_scene=512, seed=3, dynamics_kwargs=dict(ENV_DYN, wind_settings=["0.3 - 0.05*x", "0.02*x*x", "0.5*y + 0.1", "0*x + 0.125", "-0.01*x", "0.25*y - 0.05"]), device=DEV,
                    max_episode_steps=5, tensor_output=True)
     ppo = PPO(env, n_steps=8, batch_size=2048, n_epochs=1, seed=2)
-    assert ppo.fused_rollout is True
-    from visfly_amd import _lib
-    _lib._warned.discard("vf_ppo_rollout")
-    with warnings.catch_warnings(record=True) as caught:
-        warnings.simplefilter("always")
-        ppo.collect_rollouts()
-        ppo.collect_rollouts()
+    used = []
+    inner = env.collect_policy
+    env.collect_policy = lambda *a, **k: used.append(inner(*a, **k)) or used[-1]
+    ppo.collect_rollouts()
+    ppo.collect_rollouts()
     torch.cuda.synchronize()
-    assert sum("vf_ppo_rollout" in str(w.message) for w in caught) == 1
-    assert ppo.fused_rollout is False
+    assert used and all(u is False for u in used), used
     assert torch.isfinite(ppo.buf.advantages).all() and float(ppo._ep_stats[0]) >= 512
     env.close()
 

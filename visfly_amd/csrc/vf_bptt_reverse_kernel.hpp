@@ -165,30 +165,35 @@ namespace vf {
 
 using RevKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::BwdArgsChain, const vf::RevArgs);
 
-template <class Net, int ROWS, int KIND, bool CKPT>
+// DELAY: the motor-lag form of the interval or the direct one (pick_roll, vf_bptt_rollout_kernel.hpp); the direct instances live in
+// vf_bptt_reverse_nodelay.hip
+template <class Net, int ROWS, int KIND, bool CKPT, bool DELAY>
 static RevKernel pick_rev2(const vf_dyn_cfg& c)
 {
     using P = vf::BwdProg<Net, true, Net::HV == 4, true>;      // HV == 4: td_policies.Actor, both trunks
-    if (!c.ctrl_delay) return nullptr;
+    if ((c.ctrl_delay != 0) != DELAY) return nullptr;
     if (c.integrator == VF_INT_RK4) {
-        if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_RK4, true, CKPT>;
-        if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_RK4, true, CKPT>;
+        if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_RK4, DELAY, CKPT>;
+        if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_RK4, DELAY, CKPT>;
         return nullptr;
     }
-    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_EULER, true, CKPT>;
-    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true, CKPT>;
+    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_THRUST, VF_INT_EULER, DELAY, CKPT>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_reverse<P, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_EULER, DELAY, CKPT>;
     return nullptr;
 }
 
 // ckpt: the forward launch wrote the sub-step tape -> the instances that read it instead of replaying the interval
-template <class Net, int ROWS, int KIND>
+template <class Net, int ROWS, int KIND, bool DELAY = true>
 static RevKernel pick_rev(const vf_dyn_cfg& c, bool ckpt)
 {
     if constexpr (ROWS == 16) {          // the tape's records are the forward launch's waves: 16 agents each
-        if (ckpt) return pick_rev2<Net, ROWS, KIND, true>(c);
+        if (ckpt) return pick_rev2<Net, ROWS, KIND, true, DELAY>(c);
     }
-    return pick_rev2<Net, ROWS, KIND, false>(c);
+    return pick_rev2<Net, ROWS, KIND, false, DELAY>(c);
 }
+
+// vf_bptt_reverse_nodelay.hip: every class with ctrl_delay = false (net: bwd_chain_policy_class's 1 .. 4; r16: 16 rows per wave)
+RevKernel pick_rev_nodelay(int net, bool r16, int kind, const vf_dyn_cfg& c, bool ckpt);
 
 // vf_bptt_reverse_sac.hip: net = 3 NetSacHover (Hover / Racing env), 4 NetSacNav (Navigation env), 16 rows per wave only
 RevKernel pick_rev_sac(int net, int kind, const vf_dyn_cfg& c, bool ckpt);

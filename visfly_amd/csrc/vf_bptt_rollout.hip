@@ -46,12 +46,13 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if ((reinterpret_cast<uintptr_t>(mean_rows) | reinterpret_cast<uintptr_t>(log_std_rows)) & 15)
         return vf::fail(VF_EINVAL, "vf_bptt_rollout: mean_rows / log_std_rows must be 16-byte aligned");
     vf::RollKernel k = nullptr;
-    if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_HOVER>(h->dyn.cfg);
+    if (!h->dyn.cfg.ctrl_delay) k = (cls == 2 || cls == 4) && !obs_slots1 ? nullptr : vf::pick_roll_nodelay(cls, h->cfg.kind, h->dyn.cfg);
+    else if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_HOVER>(h->dyn.cfg);
     else if (cls == 1 && h->cfg.kind == VF_ENV_RACING) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_RACING>(h->dyn.cfg);
     else if (cls == 2 && h->cfg.kind == VF_ENV_NAV && obs_slots1) k = vf::pick_roll<vf::NetNavPi, VF_ENV_NAV>(h->dyn.cfg);
     else if (sac && (cls == 3 || obs_slots1)) k = vf::pick_roll_sac(cls, h->cfg.kind, h->dyn.cfg);
     if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: no persistent roll-out for this network class / env kind / dynamics "
-                                             "configuration (policy trunk or td_policies.Actor over [128, 64] x [64, 64], thrust / bodyrate, Euler / RK4, ctrl_delay)");
+                                             "configuration (policy trunk or td_policies.Actor over [128, 64] x [64, 64], thrust / bodyrate, Euler / RK4)");
     const int N = h->dyn.N;
     vf::EnvArgs ge{vf::DynArgs{N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(actions), nullptr,
                                vf::ring_head(&h->dyn), nullptr, h->dyn.vel_strided},

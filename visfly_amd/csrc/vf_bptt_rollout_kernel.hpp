@@ -226,19 +226,24 @@ namespace vf {
 
 using RollKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvArgs, const vf::ChainArgs, const vf::RollArgs);
 
-template <class Net, int KIND>
+// DELAY: the motor-lag form of the interval (ctrl_delay, the reference's default: envs/base/dynamics.py:510-533) or the direct one
+// (:534-554); the direct instances live in vf_bptt_rollout_nodelay.hip
+template <class Net, int KIND, bool DELAY = true>
 static RollKernel pick_roll(const vf_dyn_cfg& c)
 {
-    if (!c.ctrl_delay) return nullptr;
+    if ((c.ctrl_delay != 0) != DELAY) return nullptr;
     if (c.integrator == VF_INT_RK4) {
-        if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
-        if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
+        if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_RK4, DELAY>;
+        if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_RK4, DELAY>;
         return nullptr;
     }
-    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
-    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
+    if (c.action_type == VF_ACT_THRUST) return vf::k_bptt_rollout<Net, KIND, VF_ACT_THRUST, VF_INT_EULER, DELAY>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_bptt_rollout<Net, KIND, VF_ACT_BODYRATE, VF_INT_EULER, DELAY>;
     return nullptr;
 }
+
+// vf_bptt_rollout_nodelay.hip: every class below with ctrl_delay = false (cls: chain16_policy_class's 1 .. 4)
+RollKernel pick_roll_nodelay(int cls, int kind, const vf_dyn_cfg& c);
 
 // vf_bptt_rollout_sac.hip: net = 3 NetSacHover (Hover / Racing env), 4 NetSacNav (Navigation env); nullptr: no instance
 RollKernel pick_roll_sac(int net, int kind, const vf_dyn_cfg& c);

@@ -209,18 +209,24 @@ namespace {
 
 using PpoRollKernel = void (*)(const vf_dyn_cfg*, const vf_env_cfg*, const vf::EnvArgs, const vf::ChainArgs, const vf::PpoRollArgs);
 
+template <class Net, int ROWS, int KIND, bool DELAY>
+PpoRollKernel pick_ppo_roll2(const vf_dyn_cfg& c)
+{
+    if (c.integrator == VF_INT_RK4) {      // BASELINE configs[2]'s dynamics (utils/maths.py:353-386, repaired): bodyrate; thrust too
+        if (c.action_type == VF_ACT_THRUST) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_THRUST, VF_INT_RK4, DELAY>;
+        if (c.action_type == VF_ACT_BODYRATE) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_RK4, DELAY>;
+        return nullptr;
+    }
+    if (c.action_type == VF_ACT_THRUST) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_THRUST, VF_INT_EULER, DELAY>;
+    if (c.action_type == VF_ACT_BODYRATE) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_EULER, DELAY>;
+    return nullptr;
+}
+
+// motor lag (ctrl_delay, the reference's default) or the direct form of the interval (envs/base/dynamics.py:510-554; r05)
 template <class Net, int ROWS, int KIND>
 PpoRollKernel pick_ppo_roll(const vf_dyn_cfg& c)
 {
-    if (!c.ctrl_delay) return nullptr;
-    if (c.integrator == VF_INT_RK4) {      // BASELINE configs[2]'s dynamics (utils/maths.py:353-386, repaired): bodyrate; thrust too
-        if (c.action_type == VF_ACT_THRUST) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_THRUST, VF_INT_RK4, true>;
-        if (c.action_type == VF_ACT_BODYRATE) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_RK4, true>;
-        return nullptr;
-    }
-    if (c.action_type == VF_ACT_THRUST) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_THRUST, VF_INT_EULER, true>;
-    if (c.action_type == VF_ACT_BODYRATE) return vf::k_ppo_rollout<Net, ROWS, KIND, VF_ACT_BODYRATE, VF_INT_EULER, true>;
-    return nullptr;
+    return c.ctrl_delay ? pick_ppo_roll2<Net, ROWS, KIND, true>(c) : pick_ppo_roll2<Net, ROWS, KIND, false>(c);
 }
 
 }  // namespace
@@ -252,7 +258,7 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
     else if ((cls & 15) == 2 && h->cfg.kind == VF_ENV_NAV && a->obs_target)
         k = r16 ? pick_ppo_roll<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_ppo_roll<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg);
     if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: no persistent roll-out for this network class / env kind / dynamics "
-                                             "configuration ([128, 64] x [64, 64] actor-critic, Hover / Navigation, thrust / bodyrate, Euler / RK4, ctrl_delay)");
+                                             "configuration ([128, 64] x [64, 64] actor-critic, Hover / Navigation, thrust / bodyrate, Euler / RK4)");
     const int rows = r16 ? 16 : 32;
     vf::EnvArgs ge{vf::DynArgs{N, h->dyn.G, h->dyn.g_drag, h->dyn.S, nullptr, nullptr, vf::ring_head(&h->dyn), nullptr, h->dyn.vel_strided},
                    *out, h->g_race, 1};
