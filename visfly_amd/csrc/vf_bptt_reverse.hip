@@ -49,7 +49,7 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     if (reinterpret_cast<uintptr_t>(substep_tape) & 15) return vf::fail(VF_EINVAL, "vf_bptt_reverse: substep_tape must be 16-byte aligned");
     vf::RevKernel k = nullptr;
     if (!h->dyn.cfg.ctrl_delay) k = vf::pick_rev_nodelay(net, r16, h->cfg.kind, h->dyn.cfg, ckpt);
-    else if (sac) k = r16 ? vf::pick_rev_sac(net, h->cfg.kind, h->dyn.cfg, ckpt) : nullptr;
+    else if (sac) k = r16 ? vf::pick_rev_sac(net, h->cfg.kind, h->dyn.cfg, ckpt) : vf::pick_rev_sac32(net, h->cfg.kind, h->dyn.cfg);
     else if (net == 1 && h->cfg.kind == VF_ENV_HOVER) k = r16 ? vf::pick_rev<vf::NetHover, 16, VF_ENV_HOVER>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetHover, 32, VF_ENV_HOVER>(h->dyn.cfg, ckpt);
     else if (net == 1 && h->cfg.kind == VF_ENV_RACING) k = r16 ? vf::pick_rev<vf::NetHover, 16, VF_ENV_RACING>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetHover, 32, VF_ENV_RACING>(h->dyn.cfg, ckpt);
     else if (net == 2 && h->cfg.kind == VF_ENV_NAV) k = r16 ? vf::pick_rev<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg, ckpt);

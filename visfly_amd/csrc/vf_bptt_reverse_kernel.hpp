@@ -195,8 +195,10 @@ static RevKernel pick_rev(const vf_dyn_cfg& c, bool ckpt)
 // vf_bptt_reverse_nodelay.hip: every class with ctrl_delay = false (net: bwd_chain_policy_class's 1 .. 4; r16: 16 rows per wave)
 RevKernel pick_rev_nodelay(int net, bool r16, int kind, const vf_dyn_cfg& c, bool ckpt);
 
-// vf_bptt_reverse_sac.hip: net = 3 NetSacHover (Hover / Racing env), 4 NetSacNav (Navigation env), 16 rows per wave only
+// vf_bptt_reverse_sac.hip: net = 3 NetSacHover (Hover / Racing env), 4 NetSacNav (Navigation env); 16 rows per wave, and (r05) 32 for
+// N > 16 384 agents per launch
 RevKernel pick_rev_sac(int net, int kind, const vf_dyn_cfg& c, bool ckpt);
+RevKernel pick_rev_sac32(int net, int kind, const vf_dyn_cfg& c);
 
 }  // namespace vf
 

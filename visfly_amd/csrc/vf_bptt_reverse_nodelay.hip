@@ -10,10 +10,9 @@ RevKernel pick_rev_nodelay(int net, bool r16, int kind, const vf_dyn_cfg& c, boo
     if (net == 1 && kind == VF_ENV_HOVER) return r16 ? pick_rev<NetHover, 16, VF_ENV_HOVER, false>(c, ckpt) : pick_rev<NetHover, 32, VF_ENV_HOVER, false>(c, ckpt);
     if (net == 1 && kind == VF_ENV_RACING) return r16 ? pick_rev<NetHover, 16, VF_ENV_RACING, false>(c, ckpt) : pick_rev<NetHover, 32, VF_ENV_RACING, false>(c, ckpt);
     if (net == 2 && kind == VF_ENV_NAV) return r16 ? pick_rev<NetNav, 16, VF_ENV_NAV, false>(c, ckpt) : pick_rev<NetNav, 32, VF_ENV_NAV, false>(c, ckpt);
-    if (!r16) return nullptr;          // td_policies.Actor: 16 rows per wave only (vf_bptt_reverse_sac.hip)
-    if (net == 3 && kind == VF_ENV_HOVER) return pick_rev<NetSacHover, 16, VF_ENV_HOVER, false>(c, ckpt);
-    if (net == 3 && kind == VF_ENV_RACING) return pick_rev<NetSacHover, 16, VF_ENV_RACING, false>(c, ckpt);
-    if (net == 4 && kind == VF_ENV_NAV) return pick_rev<NetSacNav, 16, VF_ENV_NAV, false>(c, ckpt);
+    if (net == 3 && kind == VF_ENV_HOVER) return r16 ? pick_rev<NetSacHover, 16, VF_ENV_HOVER, false>(c, ckpt) : pick_rev<NetSacHover, 32, VF_ENV_HOVER, false>(c, false);
+    if (net == 3 && kind == VF_ENV_RACING) return r16 ? pick_rev<NetSacHover, 16, VF_ENV_RACING, false>(c, ckpt) : pick_rev<NetSacHover, 32, VF_ENV_RACING, false>(c, false);
+    if (net == 4 && kind == VF_ENV_NAV) return r16 ? pick_rev<NetSacNav, 16, VF_ENV_NAV, false>(c, ckpt) : pick_rev<NetSacNav, 32, VF_ENV_NAV, false>(c, false);
     return nullptr;
 }
 
