@@ -716,7 +716,7 @@ typedef struct vf_adam_cfg {
  * fold.  fwd: the forward layer table with every `save` pointer set; bwd: the backward table (both trunks, no observation
  * gradient) whose head entries' dY buffers receive d_mean (M,4) / d_value (M,).  Afterwards the dY buffers hold the masked
  * layer gradients: call vf_mlp_weight_grad(bwd, ...) for dW / db.  stats / cfg / scratch as in vf_ppo_loss (scratch >=
- * 16 * ceil(M / 32) floats, M <= 32768); stats == NULL: the partial rows stay in scratch for vf_mlp_weight_grad_sumsq's
+ * 16 * ceil(M / 32) floats: one row of partial loss statistics per 32-row tile; until r05 M was capped at 32 768); stats == NULL: the partial rows stay in scratch for vf_mlp_weight_grad_sumsq's
  * loss_stats.  VF_EUNSUPPORTED: not an instantiated class -> use vf_mlp_forward, vf_ppo_loss,
  * vf_mlp_backward. */
 int vf_ppo_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const float* params, const float* packed,

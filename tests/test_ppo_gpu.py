@@ -585,7 +585,7 @@ def test_policy_only_forward_and_split_backward(shape):
 
 @pytest.mark.parametrize("form", ["split", "one-wave"])
 @pytest.mark.parametrize("net", ["nav", "hover"])
-@pytest.mark.parametrize("B", [25600, 1000, 33])
+@pytest.mark.parametrize("B", [25600, 1000, 33, 40000])
 def test_fused_ppo_update_equals_separate_launches(net, B, form, monkeypatch):
     """vf_ppo_update (forward + loss + reverse chain in one launch, masks from the live forward registers) + vf_mlp_weight_grad
     vs forward / vf_ppo_loss / backward: same statistics, same gradient (up to fp32 summation order) -- in both forms of the fused
@@ -601,7 +601,7 @@ def test_fused_ppo_update_equals_separate_launches(net, B, form, monkeypatch):
     actions = torch.tanh(mean + 0.7 * torch.randn((B, 4), device=DEV, generator=g)).contiguous()
     old_lp = sb3_squashed_log_prob(mean, pol.log_std, actions) + 0.3 * torch.randn(B, device=DEV, generator=g)
     adv, ret = torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g)
-    scratch = torch.zeros(16 * 1024, device=DEV)
+    scratch = torch.zeros(16 * max(1024, (B + 31) // 32), device=DEV)     # one row of 16 partial statistics per 32-row tile (r05: any B)
     res = {}
     for fused in (True, False):
         stats = torch.zeros(16, device=DEV)
@@ -758,7 +758,8 @@ def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
 
 @pytest.mark.parametrize("env_name,N,dyn", [("NavigationEnv", 3000, "euler"), ("HoverEnv", 1000, "euler"), ("NavigationEnv", 16500, "euler"),
                                             ("HoverEnv", 16401, "euler"), ("NavigationEnv", 3000, "rk4_drag"), ("HoverEnv", 16401, "rk4"),
-                                            ("HoverEnv", 1000, "euler_nodelay"), ("NavigationEnv", 16500, "rk4_nodelay")])
+                                            ("HoverEnv", 1000, "euler_nodelay"), ("NavigationEnv", 16500, "rk4_nodelay"),
+                                            ("HoverEnv2", 3000, "euler"), ("NavigationEnv2", 3000, "euler"), ("NavigationEnv2", 16500, "rk4")])
 def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
     """collect_rollouts as ONE launch (vf_ppo_rollout: 16 / 32 agents per wave for all n_steps, the same rows-per-wave chain
     vf_mlp_forward picks for N rows) leaves the rollout buffer, the TimeLimit list, the episode statistics, the episode
@@ -780,6 +781,7 @@ def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
         kw = {}
         if env_name == "NavigationEnv":
             kw["random_kwargs"] = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+        # r05: the *2 variants (relative-position observation rows, NavigationEnv2's reward) run on the persistent launch too
         env = getattr(E, env_name)(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(dkw), device=DEV, max_episode_steps=7,
                                    tensor_output=True, **kw)
         ppo = PPO(env, n_steps=20, batch_size=N * 20 // (4 if N < 16000 else 20), n_epochs=1, seed=2)

@@ -1931,8 +1931,7 @@ int vf_ppo_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const floa
         return vf::fail(VF_EINVAL, "vf_ppo_update: bad argument");
     if (fwd->n_layers < 1 || fwd->n_layers > VF_MLP_MAX_LAYERS) return vf::fail(VF_EINVAL, "vf_ppo_update: bad layer count");
     if (int rc = check_bwd_desc(bwd, "vf_ppo_update")) return rc;
-    const int nwaves = (M + 31) / 32;
-    if (nwaves > 1024) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_update: at most 32768 rows per call (scratch contract)");
+    const int nwaves = (M + 31) / 32;        // = partial rows of loss statistics in scratch (16 floats each; any count: k_fold_stats strides over them)
     hipStream_t st = vf::as_stream(stream);
     const int rc = vf::ppo_update_chain_try(fwd, bwd, params, packed, in0, in1, log_std, action, old_log_prob, adv, ret, scratch, cfg, M, st);
     if (rc < 0) return rc;

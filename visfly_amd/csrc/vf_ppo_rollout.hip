@@ -245,7 +245,8 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
         if (desc->layer[l].save) return vf::fail(VF_EINVAL, "vf_ppo_rollout: the layer table must not keep activation copies (layer %d has a save pointer)", l);
     if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_ppo_rollout: vf_env_bind has not been called");
     if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: per-agent wind rows are set");
-    if (h->cfg.obs_mode != VF_OBS_STATE) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: raw-state observation only");
+    // (observation / reward variants -- HoverEnv2, NavigationEnv2 -- are the epilogue's own: the rows it stages through the wave's
+    // tile for the next forward are already in the env's obs_mode, the terminal rows too; r05)
     if ((reinterpret_cast<uintptr_t>(a->means) | reinterpret_cast<uintptr_t>(a->actions) | reinterpret_cast<uintptr_t>(a->stat)) & 15)
         return vf::fail(VF_EINVAL, "vf_ppo_rollout: means / actions / stat must be 16-byte aligned");
     const int N = h->dyn.N, T = a->T;
@@ -257,6 +258,8 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
         k = r16 ? pick_ppo_roll<vf::NetHover, 16, VF_ENV_HOVER>(h->dyn.cfg) : pick_ppo_roll<vf::NetHover, 32, VF_ENV_HOVER>(h->dyn.cfg);
     else if ((cls & 15) == 2 && h->cfg.kind == VF_ENV_NAV && a->obs_target)
         k = r16 ? pick_ppo_roll<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_ppo_roll<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg);
+    else if ((cls & 15) == 1 && h->cfg.kind == VF_ENV_NAV && !a->obs_target)      // NavigationEnv2: the target is inside the "state" row
+        k = r16 ? pick_ppo_roll<vf::NetHover, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_ppo_roll<vf::NetHover, 32, VF_ENV_NAV>(h->dyn.cfg);
     if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: no persistent roll-out for this network class / env kind / dynamics "
                                              "configuration ([128, 64] x [64, 64] actor-critic, Hover / Navigation, thrust / bodyrate, Euler / RK4)");
     const int rows = r16 ? 16 : 32;

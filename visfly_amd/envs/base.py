@@ -919,7 +919,7 @@ class DroneGymEnvsBase:
         roll-out kernel for this env / network / dynamics configuration (the caller then steps launch by launch)."""
         if (self._tape is not None or self.spawn_mode != "device" or self._imu_noise is not None or self._half_step
                 or self.envs.dynamics._wind_fn is not None or getattr(self, "_HOST_OBS", False) or not self.tensor_output
-                or getattr(self, "obs_gate_exact", False) or not self._STATIC_OBS_CONST
+                or getattr(self, "obs_gate_exact", False)
                 or self._terminal_state_rows() is not self._terminal_obs
                 or any(k not in ("state", "target") for k in obs_keys) or policy._plan is None or not policy.fused
                 or policy.obs_dims.get("state") != 13 or buf.obs["state"].shape[-1] != 13):

@@ -868,7 +868,8 @@ class PPO:
         n = self.policy.n_params
         dev = self.device
         self.exp_avg, self.exp_avg_sq = th.zeros(n, device=dev), th.zeros(n, device=dev)
-        self._scratch = th.zeros(16 * 1024 + 4096, device=dev)
+        # loss-statistic partial rows of a minibatch (16 floats per 32-row tile; vf_ppo_loss / vf_ppo_update) + 4096 floats of reduction scratch
+        self._scratch = th.zeros(16 * max(1024, (min(batch_size, n_steps * self.n_envs) + 31) // 32) + 4096, device=dev)
         # flat gradient and the 16 loss statistics in ONE buffer: an optimiser step on several GPUs is exactly one all-reduce
         self._gbuf = th.zeros(n + 16, device=dev)
         self.policy.grad = self._gbuf[:n]
