@@ -647,6 +647,15 @@ BPTT_CASES = {
                                         "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
                                         "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}),
                           [-0.3, 0, 0, 0], 0.5, 12),
+    # r05: the observation / reward variants (HoverEnv2: scaled relative-position rows; NavigationEnv2: relative position + the
+    # along / across-velocity reward of get_along_vertical_vector) take requires_grad in the reference like every env
+    "bptt_hover2": ("hover2", ENV_DYN, dict(max_episode_steps=1000, random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [
+        {"position": {"mean": [1., 0., 1.5], "half": [1.0, 1.0, 0.5]}}]}}), [-1 / 3, 0, 0, 0], 0.3, 12),
+    "bptt_nav2": ("nav2", ENV_DYN, dict(max_episode_steps=1000, target=[1.6, 0., 1.5], random_kwargs={"state_generator": {
+        "class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]},
+                                        "orientation": {"mean": [0., 0., 0.], "half": [0.2, 0.2, 1.0]},
+                                        "velocity": {"mean": [1., 0., 0.], "half": [1., .5, .5]}}]}}),
+                  [-0.3, 0, 0, 0], 0.5, 12),
     # velocity / position action types have no BPTT fixture: the reference's autograd raises on them ("one of the variables
     # needed for gradient computation has been modified by an inplace operation": the per-agent loop of dynamics.py:446-450
     # / 481-488 writes pose_err[:, i] / ang_vel_err[:, i] in place while earlier slices are saved for backward), tried
@@ -662,12 +671,15 @@ def gen_bptt(name, N=64, seed=42):
     if dkw.get("integrator") == "rk4":
         repair_rk4("VisFly.utils.maths")
     use_cr_sqrt(True)
-    cls = {"hover": HoverEnvShim, "racing": RacingEnv, "nav": NavigationEnv}[kind]
+    cls = {"hover": HoverEnvShim, "racing": RacingEnv, "nav": NavigationEnv}.get(kind)
+    if cls is None:
+        H2, N2 = import_envs2()
+        cls = {"hover2": H2, "nav2": N2}[kind]
     kw = dict(kw)
     if "target" in kw:
         kw["target"] = th.tensor(kw["target"])
     env = cls(num_agent_per_scene=N, num_scene=1, seed=seed, visual=False, dynamics_kwargs=dict(dkw), device="cpu",
-              requires_grad=True, **({"tensor_output": True} if kind == "hover" else {}), **kw)
+              requires_grad=True, **({"tensor_output": True} if kind.startswith("hover") else {}), **kw)
     env.tensor_output = True
     if kind == "racing":
         env.targets = th.as_tensor(RACING_TEST_GATES)

@@ -256,19 +256,23 @@ FAST_SPAWN = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"
                                                                    "velocity": {"mean": [0., 0., 0.], "half": [9., 9., 9.]}}]}}
 
 
-@pytest.mark.parametrize("N,H,steps,spawn", [(2048, 16, 20, None), (1000, 8, 5, None), (7, 6, 4, None), (3000, 12, 30, FAST_SPAWN)])
+@pytest.mark.parametrize("N,H,steps,spawn", [(2048, 16, 20, None), (1000, 8, 5, None), (7, 6, 4, None), (3000, 12, 30, FAST_SPAWN),
+                                             (1500, 8, 6, "NavigationEnv2"), (900, 8, 6, "HoverEnv2")])
 def test_persistent_launches_equal_the_loop(N, H, steps, spawn):
     """SHAC's horizon on vf_bptt_rollout / vf_bptt_reverse (actor class (b)) + the next-action / target-critic terms evaluated over the
     recorded horizon, against the launch-by-launch loop: horizon buffer (observations, actions, rewards, done / episode_done, next
     values, returns), actor loss and gradient, and actor / critic / target parameters after three iterations are bit-identical;
     short episodes, so that agents end episodes (terminations and truncations) inside the horizon"""
-    from visfly_amd.envs import HoverEnv
+    import visfly_amd.envs as E
     from visfly_amd.shac import SHAC
     from _golden import ENV_DYN
+    # r05: the observation / reward variants (their adjoint is obs_variant_bwd + the NAV2 reward gradient) run SHAC on the persistent
+    # launches too -- NavigationEnv2 = the Navigation env kind under the one-observation actor (vf_bptt_*_nav2.hip)
+    cls, spawn = (getattr(E, spawn), None) if isinstance(spawn, str) else (E.HoverEnv, spawn)
     res = []
     for fused in (True, False):
-        env = HoverEnv(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(ENV_DYN), device=DEV, tensor_output=True, requires_grad=True,
-                       max_episode_steps=steps, **({} if spawn is None else {"random_kwargs": spawn}))
+        env = cls(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(ENV_DYN), device=DEV, tensor_output=True, requires_grad=True,
+                  max_episode_steps=steps, **({} if spawn is None else {"random_kwargs": spawn}))
         algo = SHAC(env, policy_kwargs=dict(PK), horizon=H, gradient_steps=2, learning_rate=1e-3, seed=7)
         algo.fused_rollout = algo.fused_reverse = fused
         used = []

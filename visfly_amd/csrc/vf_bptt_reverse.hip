@@ -28,8 +28,6 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
         misaligned(adj_slab) || (tape_stride & 3))
         return vf::fail(VF_EINVAL, "vf_bptt_reverse: actions / d_action / eps / g_log_std / log_std_rows / tape / adj_slab must be 16-byte aligned (float4 rows)");
     if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: per-agent wind rows are set");
-    if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
-        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: observation / reward variants have no adjoint");
     const int S = h->dyn.cfg.interval_steps;
     if (S > 10) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: at most 10 sub-steps per control interval");
     const int N = h->dyn.N;
@@ -48,7 +46,8 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     const bool ckpt = substep_tape != nullptr && r16 && h->dyn.cfg.delay_steps <= vf::kRingRegs;
     if (reinterpret_cast<uintptr_t>(substep_tape) & 15) return vf::fail(VF_EINVAL, "vf_bptt_reverse: substep_tape must be 16-byte aligned");
     vf::RevKernel k = nullptr;
-    if (!h->dyn.cfg.ctrl_delay) k = vf::pick_rev_nodelay(net, r16, h->cfg.kind, h->dyn.cfg, ckpt);
+    if ((net == 1 || net == 3) && h->cfg.kind == VF_ENV_NAV) k = vf::pick_rev_nav2(net, r16, h->dyn.cfg, ckpt);
+    else if (!h->dyn.cfg.ctrl_delay) k = vf::pick_rev_nodelay(net, r16, h->cfg.kind, h->dyn.cfg, ckpt);
     else if (sac) k = r16 ? vf::pick_rev_sac(net, h->cfg.kind, h->dyn.cfg, ckpt) : vf::pick_rev_sac32(net, h->cfg.kind, h->dyn.cfg);
     else if (net == 1 && h->cfg.kind == VF_ENV_HOVER) k = r16 ? vf::pick_rev<vf::NetHover, 16, VF_ENV_HOVER>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetHover, 32, VF_ENV_HOVER>(h->dyn.cfg, ckpt);
     else if (net == 1 && h->cfg.kind == VF_ENV_RACING) k = r16 ? vf::pick_rev<vf::NetHover, 16, VF_ENV_RACING>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetHover, 32, VF_ENV_RACING>(h->dyn.cfg, ckpt);

@@ -192,6 +192,8 @@ static RevKernel pick_rev(const vf_dyn_cfg& c, bool ckpt)
     return pick_rev2<Net, ROWS, KIND, false, DELAY>(c);
 }
 
+// vf_bptt_reverse_nav2.hip: the one-observation classes (net 1, 3) over the Navigation env kind (NavigationEnv2); both forms of the interval
+RevKernel pick_rev_nav2(int net, bool r16, const vf_dyn_cfg& c, bool ckpt);
 // vf_bptt_reverse_nodelay.hip: every class with ctrl_delay = false (net: bwd_chain_policy_class's 1 .. 4; r16: 16 rows per wave)
 RevKernel pick_rev_nodelay(int net, bool r16, int kind, const vf_dyn_cfg& c, bool ckpt);
 

@@ -31,8 +31,6 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if (!out->reward) return vf::fail(VF_EINVAL, "vf_bptt_rollout: out->reward (N floats of scratch) is required");
     if (!h->dyn.S) return vf::fail(VF_ESTATE, "vf_bptt_rollout: vf_env_bind has not been called");
     if (h->dyn.wind) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: per-agent wind rows are set");
-    if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
-        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: observation / reward variants have no adjoint");
     if (tape_stride < (int64_t)h->dyn.Npad * h->dyn.G * 4) return vf::fail(VF_EINVAL, "vf_bptt_rollout: tape rows are shorter than the slab");
     if (reinterpret_cast<uintptr_t>(substep_tape) & 15) return vf::fail(VF_EINVAL, "vf_bptt_rollout: substep_tape must be 16-byte aligned");
     if ((int64_t)H * h->dyn.N * 128 * 4 >= (1ll << 32))      // the chain addresses its activation copies with 32-bit byte offsets
@@ -46,7 +44,8 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if ((reinterpret_cast<uintptr_t>(mean_rows) | reinterpret_cast<uintptr_t>(log_std_rows)) & 15)
         return vf::fail(VF_EINVAL, "vf_bptt_rollout: mean_rows / log_std_rows must be 16-byte aligned");
     vf::RollKernel k = nullptr;
-    if (!h->dyn.cfg.ctrl_delay) k = (cls == 2 || cls == 4) && !obs_slots1 ? nullptr : vf::pick_roll_nodelay(cls, h->cfg.kind, h->dyn.cfg);
+    if ((cls == 1 || cls == 3) && h->cfg.kind == VF_ENV_NAV) k = obs_slots1 ? nullptr : vf::pick_roll_nav2(cls, h->dyn.cfg);
+    else if (!h->dyn.cfg.ctrl_delay) k = (cls == 2 || cls == 4) && !obs_slots1 ? nullptr : vf::pick_roll_nodelay(cls, h->cfg.kind, h->dyn.cfg);
     else if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_HOVER>(h->dyn.cfg);
     else if (cls == 1 && h->cfg.kind == VF_ENV_RACING) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_RACING>(h->dyn.cfg);
     else if (cls == 2 && h->cfg.kind == VF_ENV_NAV && obs_slots1) k = vf::pick_roll<vf::NetNavPi, VF_ENV_NAV>(h->dyn.cfg);

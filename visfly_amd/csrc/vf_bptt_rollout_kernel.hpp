@@ -244,6 +244,9 @@ static RollKernel pick_roll(const vf_dyn_cfg& c)
 
 // vf_bptt_rollout_nodelay.hip: every class below with ctrl_delay = false (cls: chain16_policy_class's 1 .. 4)
 RollKernel pick_roll_nodelay(int cls, int kind, const vf_dyn_cfg& c);
+// vf_bptt_rollout_nav2.hip: the one-observation classes (1, 3) over the Navigation env kind = NavigationEnv2, whose target is inside its
+// "state" row (envs/NavigationEnv.py:163-183); both forms of the interval
+RollKernel pick_roll_nav2(int cls, const vf_dyn_cfg& c);
 
 // vf_bptt_rollout_sac.hip: net = 3 NetSacHover (Hover / Racing env), 4 NetSacNav (Navigation env); nullptr: no instance
 RollKernel pick_roll_sac(int net, int kind, const vf_dyn_cfg& c);

@@ -55,8 +55,6 @@ extern "C" int vf_env_step_bwd(vf_env* h, const vf_env_bwd_args* a, vf_stream_t 
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: the adjoint covers the thrust and bodyrate action types only");
     if (h->dyn.cfg.integrator != VF_INT_EULER && h->dyn.cfg.integrator != VF_INT_RK4)
         return vf::fail(VF_EINVAL, "vf_env_step_bwd: unknown integrator");
-    if (h->cfg.obs_mode != VF_OBS_STATE || h->cfg.reward_mode != VF_REWARD_DEFAULT)
-        return vf::fail(VF_EINVAL, "vf_env_step_bwd: the HoverEnv2 / NavigationEnv2 observation and reward variants have no adjoint");
     if (h->dyn.wind)
         return vf::fail(VF_EUNSUPPORTED, "vf_env_step_bwd: per-agent wind rows are set (vf_dyn_set_wind); the adjoint replays the "
                                          "interval with the constant vf_dyn_cfg.wind and would differentiate another trajectory");

@@ -263,14 +263,16 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
             lw[0] = cw1; lw[1] = cw2; lw[2] = cw3;
             lwm[0] = cm0; lwm[1] = cm1; lwm[2] = cm2; lwm[3] = cm3;
             laa[0] = ca1; laa[1] = ca2; laa[2] = ca3;
-            if (g.d_obs) {  // observation = [p, q, v + wind, w] of the post-step state (dynamics.py:779-786)
+            if (g.d_obs) {  // observation = [p, q, v + wind, w] of the post-step state (dynamics.py:779-786), in the env's obs_mode
                 const float4* d4 = reinterpret_cast<const float4*>(d_obs_lds + 16 * rec_slot);
                 float4 d0, d1, d2, d3;
                 lds_read4_opaque<16>(d4, d0, d1, d2, d3);
-                lp[0] += d0.x; lp[1] += d0.y; lp[2] += d0.z;
-                lq.w += d0.w; lq.x += d1.x; lq.y += d1.y; lq.z += d1.z;
-                lv[0] += d1.w; lv[1] += d2.x; lv[2] += d2.y;
-                lw[0] += d2.z; lw[1] += d2.w; lw[2] += d3.x;
+                float dd[13] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x};
+                obs_variant_bwd(e, dd);
+                lp[0] += dd[0]; lp[1] += dd[1]; lp[2] += dd[2];
+                lq.w += dd[3]; lq.x += dd[4]; lq.y += dd[5]; lq.z += dd[6];
+                lv[0] += dd[7]; lv[1] += dd[8]; lv[2] += dd[9];
+                lw[0] += dd[10]; lw[1] += dd[11]; lw[2] += dd[12];
             }
         }
     } else if (!cut) {
@@ -283,16 +285,52 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
         lw[0] = g3.y; lw[1] = g3.z; lw[2] = g3.w;
         lwm[0] = g4.x; lwm[1] = g4.y; lwm[2] = g4.z; lwm[3] = g4.w;
         laa[0] = g6.y; laa[1] = g6.z; laa[2] = g6.w;
-        if (g.d_obs) {  // observation = [p, q, v + wind, w] of the post-step state (dynamics.py:779-786)
+        if (g.d_obs) {  // observation = [p, q, v + wind, w] of the post-step state (dynamics.py:779-786), in the env's obs_mode
             const float* d = g.d_obs + 13 * (size_t)i;
-            lp[0] += d[0]; lp[1] += d[1]; lp[2] += d[2];
-            lq.w += d[3]; lq.x += d[4]; lq.y += d[5]; lq.z += d[6];
-            lv[0] += d[7]; lv[1] += d[8]; lv[2] += d[9];
-            lw[0] += d[10]; lw[1] += d[11]; lw[2] += d[12];
+            float dd[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) dd[k] = d[k];
+            obs_variant_bwd(e, dd);
+            lp[0] += dd[0]; lp[1] += dd[1]; lp[2] += dd[2];
+            lq.w += dd[3]; lq.x += dd[4]; lq.y += dd[5]; lq.z += dd[6];
+            lv[0] += dd[7]; lv[1] += dd[8]; lv[2] += dd[9];
+            lw[0] += dd[10]; lw[1] += dd[11]; lw[2] += dd[12];
         }
     }
     // reward gradient (computed on the pre-reset post-step state, so it survives a reset)
-    if (live && g.d_reward && KIND == VF_ENV_NAV) {
+    if (live && g.d_reward && KIND == VF_ENV_NAV && e.reward_mode == VF_REWARD_NAV2) {
+        // NavigationEnv2.get_reward (envs/NavigationEnv.py:185-224): 0.02 (v_along - |v_across|) toward the target - 0.001 |w| + success,
+        // get_along_vertical_vector (:16-24): bn = base / (|base| + 1e-8), along = <v, bn>, across = v - bn along.  success is a constant.
+        const float dr = dr_in;
+        const float vv[3] = {s.v[0] + c.wind[0], s.v[1] + c.wind[1], s.v[2] + c.wind[2]};
+        const float base[3] = {e.target[0] - s.p[0], e.target[1] - s.p[1], e.target[2] - s.p[2]};
+        const float nb = norm3(base[0], base[1], base[2]), den = nb + 1e-8f;
+        const float bn[3] = {base[0] / den, base[1] / den, base[2] / den};
+        const float along = dot3(vv, bn);
+        const float vert[3] = {vv[0] - bn[0] * along, vv[1] - bn[1] * along, vv[2] - bn[2] * along};
+        const float away = norm3(vert[0], vert[1], vert[2]);
+        const float g_away = dr * -0.02f;
+        float lvert[3] = {0.f, 0.f, 0.f};
+        if (away > 0.0f) { lvert[0] = g_away * vert[0] / away; lvert[1] = g_away * vert[1] / away; lvert[2] = g_away * vert[2] / away; }
+        const float l_along = dr * 0.02f - dot3(lvert, bn);          // along enters directly and through across = v - bn along
+        float lbn[3], lbase[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lv[k] += lvert[k] + l_along * bn[k];
+            lbn[k] = l_along * vv[k] - lvert[k] * along;
+        }
+        const float proj = dot3(lbn, base);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lbase[k] = lbn[k] / den - (nb > 0.0f ? proj / (den * den) * base[k] / nb : 0.0f);
+            lp[k] -= lbase[k];                                        // base = target - p
+        }
+        const float nw = norm3(s.w[0], s.w[1], s.w[2]);
+        if (nw > 0.0f) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lw[k] += dr * -0.001f * s.w[k] / nw;
+        }
+    } else if (live && g.d_reward && KIND == VF_ENV_NAV) {
         // NavigationEnv.get_reward (envs/NavigationEnv.py:84-99).  What autograd differentiates there: position, orientation,
         // velocity, angular velocity and -- through collision_vector = collision_point.detach() - position
         // (droneEnv.py:345-366) -- the distance / direction to the closest bbox face; success and the step counter are

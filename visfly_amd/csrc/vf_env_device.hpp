@@ -127,6 +127,19 @@ __device__ __forceinline__ void obs_variant(const vf_env_cfg& e, float* o)
     }
 }
 
+// ... and their adjoint: the gradient w.r.t. an observation row in the env's obs_mode -> the gradient w.r.t. the raw state row
+// (HoverEnv2 / NavigationEnv2 take requires_grad like every env of the reference: HoverEnv.py:105,125, NavigationEnv.py:109,137; r05)
+__device__ __forceinline__ void obs_variant_bwd(const vf_env_cfg& e, float* d)
+{
+    if (e.obs_mode == VF_OBS_HOVER2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { d[k] = -(d[k] / 10.0f); d[7 + k] = d[7 + k] / 10.0f; d[10 + k] = d[10 + k] / 10.0f; }
+    } else if (e.obs_mode == VF_OBS_NAV2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = -d[k];
+    }
+}
+
 // (Philox4x32-10 and u01: vf_common.hpp)
 
 

@@ -1089,9 +1089,6 @@ class DroneGymEnvsBase:
     def set_requires_grad(self, requires_grad: bool, horizon: int = 64):
         """droneGymEnv.py:628-633.  True: record the per-step checkpoints the adjoint kernel needs (up to
         `horizon` steps between two detach() calls) and return graph-attached obs / reward from step()."""
-        if requires_grad and (self.OBS_MODE or self.REWARD_MODE):
-            raise NotImplementedError("the adjoint kernel differentiates the raw-state observation and the Hover / "
-                                      "Racing rewards; the HoverEnv2 / NavigationEnv2 variants run forward only")
         self.requires_grad = bool(requires_grad)
         if requires_grad:
             if self._tape is None or self._tape.shape[0] < horizon:
