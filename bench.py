@@ -689,7 +689,7 @@ def main():
         # HBM bytes per launch: NOT measured in this run -- read from the PMC pass committed under profiles/ (rocprofv3 --pmc in its
         # own run, as MI355X_MICROARCH.md prescribes; per-agent figure x N), and labelled as such (roofline.traffic_source)
         traffic, traffic_src = None, None
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = (pmc["fetch_bytes_per_agent"] + pmc["write_bytes_per_agent"]) * N
