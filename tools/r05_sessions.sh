@@ -158,6 +158,12 @@ evidence) # r05 evidence for profiles/: the driver's bench command, kernel stats
     done
     cat $O/pmc_traffic.txt $O/pmc_env_sq.txt; head -8 $O/r05_*_kernel_stats.txt
     ;;
+prefetch) # next epoch's gather + advantage normalisation on a side stream under the optimiser steps
+    timeout 600 python -m pytest tests/test_ppo_gpu.py tests/test_ppo_loop_gpu.py -x -q -m gpu 2>&1 | tail -5 | tee $O/pytest.txt
+    timeout 900 python tools/exp_ppo_prefetch.py 6 2>&1 | grep -v amdgpu.ids | tee $O/ab.txt
+    (cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace -d /tmp/prof_pf -- python $R/tools/exp_ppo_prefetch.py 1 only > $O/prof.log 2>&1)
+    python tools/trace_overlap.py /tmp/prof_pf k_gather_rows | tee $O/overlap.txt
+    ;;
 avail)    # counter names this rocprofv3 knows on gfx950
     (cd /tmp && rocprofv3 --list-avail > $O/avail.txt 2>&1); grep -c . $O/avail.txt
     ;;

@@ -1085,39 +1085,16 @@ class PPO:
         if self.clip_range_vf is not None:
             flat["old_v"] = buf.values.view(-1)
         flat.update({"obs:" + k: buf.obs[k].view(-1, buf.obs[k].shape[-1]) for k in self.obs_keys})
-        n_seg, rem = divmod(total, bs)
         for _epoch in range(self.n_epochs):
             stats_acc = stats_epoch[_epoch]
-            # one gather per epoch instead of one per minibatch: the shuffled copy makes every minibatch a
-            # contiguous slice (same rows, same order as indexing the buffer with perm[s:s+bs])
             if permutations is not None:
                 perm = th.as_tensor(permutations[_epoch], dtype=th.int64, device=self.device).contiguous()
                 assert perm.numel() == total
             else:
                 perm = th.randperm(total, device=self.device, generator=g)
-            shuf = self._gather(flat, perm)
-            if self.normalize_advantage and bs * self.world > 1:
-                # PPO.py:215-220 normalises per minibatch; all minibatches of the epoch in one launch (+ one
-                # all-reduce of the per-minibatch sums when the minibatch spans several GPUs)
-                advn = th.empty_like(shuf["adv"])
-                sums = th.empty((n_seg + 1, 2), dtype=th.float64, device=self.device)
-                L, stv = _lib.lib(), self._stream()
-                calls = [(_ptr(shuf["adv"]), _ptr(advn), n_seg, bs, bs * self.world, sums.data_ptr())]
-                if rem > 1 or (rem == 1 and self.world > 1):       # PPO.py:216: only `if len(advantages) > 1`
-                    calls.append((_ptr(shuf["adv"], n_seg * bs), _ptr(advn, n_seg * bs), 1, rem, rem * self.world,
-                                  sums.data_ptr() + 16 * n_seg))
-                elif rem == 1:
-                    advn[n_seg * bs:] = shuf["adv"][n_seg * bs:]
-                if self.world > 1:
-                    for args in calls:
-                        _lib.check(L.vf_adv_normalize_segments(*args, 0, stv))
-                    parallel.allreduce_sum_(sums)
-                    for args in calls:
-                        _lib.check(L.vf_adv_normalize_segments(*args, 1, stv))
-                else:
-                    for args in calls:
-                        _lib.check(L.vf_adv_normalize_segments(*args, 2, stv))
-                shuf["adv"] = advn
+            # (preparing epoch e + 1's copy on a side stream under epoch e's optimiser steps gains nothing: the gather takes the HBM
+            # bandwidth the weight-gradient kernel runs on -- profiles/r05_side_streams.txt, tools/exp_ppo_prefetch.py)
+            shuf = self._prepare_epoch(flat, perm, bs)
             for s in range(0, total, bs):
                 e = min(s + bs, total)
                 st = self._minibatch_update({k: v[s:e] for k, v in shuf.items()}, stats_acc)
@@ -1141,17 +1118,54 @@ class PPO:
                           "train/approx_kl": s[3], "train/clip_fraction": s[4], "train/n_updates": self._opt_step,
                           "train/early_stop": float(stop)})
 
-    def _gather(self, flat, perm):
+    def _prepare_epoch(self, flat, perm, bs, slot=0):
+        """the epoch's shuffled copy of the rollout (buffer set `slot`), advantages normalised per minibatch"""
+        total = perm.numel()
+        n_seg, rem = divmod(total, bs)
+        # one gather per epoch instead of one per minibatch: the shuffled copy makes every minibatch a
+        # contiguous slice (same rows, same order as indexing the buffer with perm[s:s+bs])
+        shuf = self._gather(flat, perm, slot)
+        if self.normalize_advantage and bs * self.world > 1:
+            # PPO.py:215-220 normalises per minibatch; all minibatches of the epoch in one launch (+ one
+            # all-reduce of the per-minibatch sums when the minibatch spans several GPUs)
+            scr = self._shuf.setdefault(("advn", slot), {})
+            if scr.get("advn") is None or scr["advn"].shape != shuf["adv"].shape or scr["sums"].shape[0] != n_seg + 1:
+                scr["advn"] = th.empty_like(shuf["adv"])
+                scr["sums"] = th.empty((n_seg + 1, 2), dtype=th.float64, device=self.device)
+            advn, sums = scr["advn"], scr["sums"]
+            L, stv = _lib.lib(), self._stream()
+            calls = [(_ptr(shuf["adv"]), _ptr(advn), n_seg, bs, bs * self.world, sums.data_ptr())]
+            if rem > 1 or (rem == 1 and self.world > 1):       # PPO.py:216: only `if len(advantages) > 1`
+                calls.append((_ptr(shuf["adv"], n_seg * bs), _ptr(advn, n_seg * bs), 1, rem, rem * self.world,
+                              sums.data_ptr() + 16 * n_seg))
+            elif rem == 1:
+                advn[n_seg * bs:] = shuf["adv"][n_seg * bs:]
+            if self.world > 1:
+                for args in calls:
+                    _lib.check(L.vf_adv_normalize_segments(*args, 0, stv))
+                parallel.allreduce_sum_(sums)
+                for args in calls:
+                    _lib.check(L.vf_adv_normalize_segments(*args, 1, stv))
+            else:
+                for args in calls:
+                    _lib.check(L.vf_adv_normalize_segments(*args, 2, stv))
+            shuf["adv"] = advn
+        return shuf
+
+    def _gather(self, flat, perm, slot=0):
         """{name: rows of flat[name] in the order of perm} -- all fields in one launch (vf_gather_rows); the destination
-        buffers are kept between epochs"""
-        if self._shuf is None or any(self._shuf[k].shape != v.shape for k, v in flat.items()):
-            self._shuf = {k: th.empty_like(v) for k, v in flat.items()}
+        buffers (set `slot`) are kept between epochs"""
+        if self._shuf is None:
+            self._shuf = {}
+        dst = self._shuf.get(slot)
+        if dst is None or any(k not in dst or dst[k].shape != v.shape for k, v in flat.items()):
+            dst = self._shuf[slot] = {k: th.empty_like(v) for k, v in flat.items()}
         gf = _lib.GatherFields()
         gf.n_fields = len(flat)
         for i, (k, v) in enumerate(flat.items()):
-            gf.width[i], gf.src[i], gf.dst[i] = (v.shape[1] if v.dim() == 2 else 1), _ptr(v), _ptr(self._shuf[k])
+            gf.width[i], gf.src[i], gf.dst[i] = (v.shape[1] if v.dim() == 2 else 1), _ptr(v), _ptr(dst[k])
         _lib.check(_lib.lib().vf_gather_rows(C.byref(gf), perm.data_ptr(), perm.numel(), self._stream()))
-        return dict(self._shuf)
+        return dict(dst)
 
     def learn(self, total_timesteps: int, log_interval: Optional[int] = None):
         """PPO.learn (PPO.py:116-175): alternate rollout collection and training"""
