@@ -511,6 +511,17 @@ typedef struct vf_mlp_desc {
  * vf_adam_step do it through vf_adam_cfg.pack_map); vf_mlp_packed_floats = size of the packed buffer the layer
  * table implies. */
 int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc);
+/* Register-chained kernels for layer tables the library holds no instance of (any depth / width of the reference's
+ * `features_extractor_kwargs.net_arch` and `net_arch=dict(pi=.., vf=..)`: utils/policies/extractors.py:376-449, widths in multiples of 32
+ * up to 128): the host side generates a translation unit that names the shape (csrc/vf_mlp_chain_gen.hpp), compiles it with hipcc on
+ * first use into a shared object next to the library (visfly_amd/_jit.py) and registers it here.  vf_mlp_forward, vf_mlp_backward_data,
+ * vf_ppo_update and their relatives then ask the loaded plugins after the built-in classes.  A plugin compiled against other struct
+ * layouts is refused (VF_EINVAL).  Loading the same path twice is a no-op. */
+int vf_chain_plugin_load(const char* path);
+int vf_chain_plugin_count(void);
+const char* vf_chain_plugin_name(int32_t i);
+int vf_chain_plugin_set_enabled(int on); /* 0: the loaded plugins are not asked (A/B against the block-tile kernels); returns the previous setting */
+int64_t vf_chain_plugin_launches(void); /* launches (queries included) the plugins have served since the library was loaded */
 int vf_mlp_pack_weights(const vf_mlp_desc* desc, const float* params, float* packed, vf_stream_t stream);
 /* out1 == NULL: the caller does not need the value head -- the register-chained kernel then skips the value trunk
  * (its saved activations are left untouched); layer tables that run on the LDS kernel return VF_EUNSUPPORTED. */

@@ -1,0 +1,255 @@
+"""Register-chained kernels for ANY layer list of the reference's policies (utils/policies/extractors.py:376-449 `create_mlp` of any depth per
+observation key; `net_arch=dict(pi=[..], vf=[..])` of any depth): shapes libvisfly_amd.so holds no instance of are compiled on first use
+(visfly_amd/_jit.py -> csrc/vf_mlp_chain_gen.hpp -> a plugin registered with vf_chain_plugin_load).  CPU: the shape rules, the generated
+source, that the plugin builds, loads and is refused when it is not one.  GPU: forward / reverse chain / fused PPO step of generated
+classes against torch autograd on the same weights and against the block-tile kernels, as test_chain_backward_vs_torch_and_block_tile_kernel
+does for the built-in classes -- and that it IS the plugin that ran (vf_chain_plugin_launches)."""
+import ctypes as C
+import os
+import warnings
+
+import pytest
+import torch
+
+DEV = "cuda:0"
+from visfly_amd._jit import PREBUILD as SHAPES      # name -> (observation widths, extractor layers, pi, vf); __graft_entry__.build() compiles them
+
+
+def test_shape_rules_and_generated_source():
+    from visfly_amd import _jit
+    dims, ext, pi, vf = SHAPES["verdict"]
+    sh = _jit.shape_of(dims, ext, pi, vf)
+    assert sh == ((16, 8), ((4, 2), (4, 2)), (4, 4), (1,)) and not _jit.is_builtin(sh)
+    assert _jit.name_of(sh) == "in16[128,64] in8[128,64] pi[128,128] vf[32]"
+    # the YAML-default shapes are the library's own classes: nothing to compile
+    assert _jit.is_builtin(_jit.shape_of(dims, ext, [64, 64], [64, 64]))
+    assert _jit.is_builtin(_jit.shape_of({"state": 13}, {"state": [128, 64]}, [64, 64], [64, 64]))
+    # what stays on the block-tile kernels: widths off the 32 grid or above 128, empty trunks, > 4 layers, SAC heads, pass-through inputs
+    assert _jit.shape_of(dims, ext, [48], [32]) is None and _jit.shape_of(dims, ext, [160], [32]) is None
+    assert _jit.shape_of(dims, ext, [], [32]) is None and _jit.shape_of(dims, ext, [32] * 5, [32]) is None
+    assert _jit.shape_of(dims, ext, pi, vf, head_dims=(4, 4)) is None and _jit.shape_of(dims, ext, pi, vf, passthrough=("action",)) is None
+    assert _jit.shape_of({"state": 40}, {"state": [64]}, [32], [32]) is None
+    src = _jit.source(sh)
+    assert "static constexpr int EW[2][4] = {{4, 2, 0, 0}, {4, 2, 0, 0}};" in src and "static constexpr int PW[4] = {4, 4, 0, 0};" in src
+    assert "VF_CHAIN_PLUGIN_DEFINE(Net, NetPi" in src
+    assert _jit.path_of(sh) == _jit.path_of(_jit.shape_of(dims, ext, pi, vf)) and _jit.path_of(sh) != _jit.path_of(_jit.shape_of(dims, ext, pi, [64]))
+
+
+def test_plugin_builds_loads_and_is_checked(tmp_path):
+    """hipcc cross-compiles the plugin without a GPU (cached: __graft_entry__.build() made it); the registry takes it once, refuses a
+    shared object that is not a plugin"""
+    from visfly_amd import _jit, _lib
+    lib = _lib.lib()
+    sh = _jit.shape_of(*SHAPES["verdict"])
+    path = _jit.build(sh)
+    assert os.path.exists(path) and os.path.dirname(path) == _jit.JIT_DIR
+    n0 = lib.vf_chain_plugin_count()
+    names0 = [lib.vf_chain_plugin_name(i) for i in range(n0)]
+    _lib.check(lib.vf_chain_plugin_load(path.encode()))
+    _lib.check(lib.vf_chain_plugin_load(path.encode()))
+    n1 = lib.vf_chain_plugin_count()
+    assert n1 == n0 + (0 if _jit.name_of(sh).encode() in names0 else 1)
+    assert _jit.name_of(sh).encode() in [lib.vf_chain_plugin_name(i) for i in range(n1)]
+    assert lib.vf_chain_plugin_name(n1) is None
+    assert lib.vf_chain_plugin_load(str(tmp_path / "missing.so").encode()) != 0 and b"vf_chain_plugin_load" in lib.vf_last_error()
+    assert lib.vf_chain_plugin_load(_lib.LIB.encode()) != 0 and b"not a chain plugin" in lib.vf_last_error()
+    assert lib.vf_chain_plugin_count() == n1
+
+
+def make(name, **kw):
+    from visfly_amd.ppo import MlpPolicy
+    dims, ext, pi, vf = SHAPES[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        pol = MlpPolicy(dims, ext, pi, vf, DEV, seed=9, **kw)
+    assert pol.chain_jit, "the shape has a generated chain class"
+    return pol, dims
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 33, 777, 25600])
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_generated_forward_vs_torch_and_block_tile_kernel(name, M):
+    from visfly_amd import _lib
+    lib = _lib.lib()
+    pol, dims = make(name)
+    g = torch.Generator(device=DEV).manual_seed(M)
+    obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+    ref = pol.to_torch().double().to(DEV)
+    m0, v0 = ref({k: v.double() for k, v in obs.items()})
+    n0 = lib.vf_chain_plugin_launches()
+    mean, value = pol.forward(obs)
+    mean, value = mean.clone(), value.clone()
+    assert lib.vf_chain_plugin_launches() == n0 + 1, "the plugin served the forward"
+    mean_pi, none = pol.forward(obs, save_activations=False, need_value=False)
+    assert none is None and lib.vf_chain_plugin_launches() == n0 + 2 and torch.equal(mean_pi, mean), "policy-only class: same mean, bit for bit"
+    sc = max(m0.abs().max().item(), v0.abs().max().item(), 1e-3)
+    assert (mean.double() - m0).abs().max().item() <= 2e-6 * sc and (value.view(-1).double() - v0.view(-1)).abs().max().item() <= 2e-6 * sc
+    pol.fused = False                               # layer by layer on the block-tile kernels
+    m1, v1 = pol.forward(obs)
+    assert lib.vf_chain_plugin_launches() == n0 + 2
+    assert (m1 - mean).abs().max().item() <= 4e-6 * sc and (v1.view(-1) - value.view(-1)).abs().max().item() <= 4e-6 * sc
+    # every saved activation (what the weight gradients read) equals the layer-by-layer path's
+    b1 = {k: v.clone() for k, v in pol._buffers(M, 0).items() if isinstance(v, torch.Tensor) and k.split(":")[0] in ("x", "pi", "vf", "feat")}
+    pol.fused = True
+    pol.forward(obs)
+    b2 = pol._buffers(M, 0)
+    assert b1, "hidden activations are kept"
+    for k, v in b1.items():
+        assert (b2[k] - v).abs().max().item() <= 4e-6 * max(v.abs().max().item(), 1e-3), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 33, 777, 25600])
+@pytest.mark.parametrize("mode", ["ppo", "bptt"])
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_generated_backward_vs_torch_and_block_tile_kernel(name, mode, M):
+    """the reverse chain of a generated class, the two variants the trainers use (both trunks without / policy trunk with the observation
+    gradient) + the row-slab weight gradients, against torch autograd and the layer-by-layer kernels; deterministic; accumulate mode"""
+    from visfly_amd import _lib
+    lib = _lib.lib()
+    pol, dims = make(name)
+    g = torch.Generator(device=DEV).manual_seed(M)
+    obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+    d_mean = torch.randn((M, 4), device=DEV, generator=g) / M
+    d_value = torch.randn(M, device=DEV, generator=g) / M if mode == "ppo" else None
+    ig = mode == "bptt"
+    ref = pol.to_torch().to(DEV)
+    xs = {k: v.clone().requires_grad_(ig) for k, v in obs.items()}
+    m0, v0 = ref(xs)
+    loss = (m0 * d_mean).sum() + ((v0.view(-1) * d_value).sum() if d_value is not None else 0.0) + 0.0 * ref.log_std.sum()
+    loss.backward()
+    for mod in ref.lin:
+        for prm in mod.parameters():
+            if prm.grad is None:
+                prm.grad = torch.zeros_like(prm)
+    gref = ref.flat_grad().to(DEV)
+    res = {}
+    for fused in (True, False, True):
+        pol.fused_backward = fused
+        pol.grad.fill_(0.0)
+        pol.forward(obs)
+        n0 = lib.vf_chain_plugin_launches()
+        d_in = pol.backward(d_mean, d_value, None, need_input_grad=ig)
+        assert (lib.vf_chain_plugin_launches() > n0) == fused, "the plugin's reverse chain ran (and only when asked)"
+        if fused and fused in res:
+            assert torch.equal(res[True][0], pol.grad)
+        res[fused] = (pol.grad.clone(), {k: v.clone() for k, v in d_in.items()})
+    scale = gref.abs().max().item()
+    for fused in (True, False):
+        gk = res[fused][0].clone()
+        gk[pol.log_std_off:] = 0
+        assert (gk - gref).abs().max().item() <= 5e-6 * scale, (fused, (gk - gref).abs().max().item(), scale)
+        for k, v in res[fused][1].items():
+            assert torch.allclose(v, xs[k].grad, rtol=1e-4, atol=1e-6 * xs[k].grad.abs().max().item())
+    pol.fused_backward = True
+    pol.forward(obs)
+    pol.backward(d_mean, d_value, None, accumulate=True, need_input_grad=ig)
+    assert torch.allclose(pol.grad, 2 * res[True][0], rtol=1e-5, atol=1e-6 * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [25600, 1000, 33])
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_generated_fused_ppo_update_equals_separate_launches(name, B):
+    """vf_ppo_update on a generated class (k_ppo_update_chain<ChainNetG<..>>: forward + loss + reverse chain in one launch) vs forward /
+    vf_ppo_loss / backward"""
+    from visfly_amd import _lib
+    from test_ppo_gpu import sb3_squashed_log_prob
+    lib = _lib.lib()
+    pol, dims = make(name, log_std_init=-0.3)
+    g = torch.Generator(device=DEV).manual_seed(B)
+    obs = {k: torch.randn((B, d), device=DEV, generator=g) for k, d in dims.items()}
+    mean, value = pol.forward(obs)
+    actions = torch.tanh(mean + 0.7 * torch.randn((B, 4), device=DEV, generator=g)).contiguous()
+    old_lp = sb3_squashed_log_prob(mean, pol.log_std, actions) + 0.3 * torch.randn(B, device=DEV, generator=g)
+    adv, ret = torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g)
+    scratch = torch.zeros(16 * max(1024, (B + 31) // 32), device=DEV)
+    st = _lib.current_stream(torch.device(DEV))
+    res = {}
+    for fused in (True, False):
+        stats = torch.zeros(16, device=DEV)
+        pol.grad.fill_(3.0)
+        cfg = _lib.PpoLossCfg(0.2, 0.01, 0.5, 1.0 / B, pol.grad.data_ptr() + 4 * pol.log_std_off, None)
+        if fused:
+            n0 = lib.vf_chain_plugin_launches()
+            assert pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch)
+            assert lib.vf_chain_plugin_launches() > n0
+        else:
+            m, v = pol.forward(obs)
+            d_mean, d_value = torch.empty((B, 4), device=DEV), torch.empty(B, device=DEV)
+            _lib.check(lib.vf_ppo_loss(m.data_ptr(), v.data_ptr(), pol.log_std.data_ptr(), actions.data_ptr(), old_lp.data_ptr(),
+                                       adv.data_ptr(), ret.data_ptr(), d_mean.data_ptr(), d_value.data_ptr(), stats.data_ptr(), B,
+                                       C.byref(cfg), scratch.data_ptr(), st))
+            pol.backward(d_mean, d_value, None)
+        res[fused] = (pol.grad.clone(), stats.clone())
+    (g1, s1), (g0, s0) = res[True], res[False]
+    assert torch.allclose(s1[:9], s0[:9], rtol=2e-5, atol=1e-6 * max(1.0, s0[:9].abs().max().item())), (s1, s0)
+    scale = g0.abs().max().item()
+    assert (g1 - g0).abs().max().item() <= 5e-6 * scale, ((g1 - g0).abs().max().item(), scale)
+    assert torch.allclose(g1[pol.log_std_off:], g0[pol.log_std_off:], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_ppo_trains_a_non_default_net_arch_on_chain_kernels(monkeypatch):
+    """`PPO(net_arch=dict(pi=[128, 128], vf=[32]))` trains without the block-tile warning, on the plugin's kernels;
+    the same run with the compilation switched off (VISFLY_AMD_JIT=0: block-tile kernels, with the warning) ends at the same parameters
+    up to fp32 summation order"""
+    from visfly_amd import _lib
+    from visfly_amd.envs import NavigationEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    lib = _lib.lib()
+    kw = dict(n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3,
+              policy_kwargs=dict(features_extractor_class="StateTargetExtractor",
+                                 features_extractor_kwargs=dict(net_arch=dict(state=dict(layer=[128, 64]), target=dict(layer=[128, 64]))),
+                                 net_arch=dict(pi=[128, 128], vf=[32]), activation_fn="ReLU"))
+    flats = []
+    for jit in (True, False):
+        monkeypatch.setenv("VISFLY_AMD_JIT", "1" if jit else "0")
+        lib.vf_chain_plugin_set_enabled(1 if jit else 0)       # (the registry is per process: the first run's plugin would serve the second)
+        env = NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64, tensor_output=True)
+        n0 = lib.vf_chain_plugin_launches()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ppo = PPO(env, **kw)
+            assert ppo.policy.spec["pi"] == [128, 128] and ppo.policy.spec["vf"] == [32] and ppo.policy.chain_jit == jit
+            ppo.learn(16 * 1024 * 2)
+        torch.cuda.synchronize()
+        tile = [x for x in w if "block-tile" in str(x.message)]
+        if jit:
+            assert not tile, [str(x.message) for x in tile]
+            # 2 iterations x (16 rollout forwards + 2 epochs x 4 fused minibatch steps)
+            assert lib.vf_chain_plugin_launches() - n0 >= 2 * (16 + 8)
+        else:
+            assert tile and lib.vf_chain_plugin_launches() == n0
+        flats.append(ppo.policy.flat.clone())
+        env.close()
+    lib.vf_chain_plugin_set_enabled(1)
+    d = (flats[0] - flats[1]).abs().max().item()
+    assert d <= 2e-5, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ragged", "builtin_nav"])
+def test_saved_activations_of_cold_launches(name):
+    """r05 regression: the copies of the hidden activations that the chain kernels trickle out as 128-bit buffer stores.  With the column
+    offset in the store's soffset SGPR the compiler let the next epilogue overwrite the data registers in the slot after the store, and
+    on a COLD launch (freshly mapped buffers: the store's issue stalls) one float of 8 rows went out as the new register value -- once in
+    ~3 launches of this shape (csrc/vf_mlp_chain.hpp: chain_buffer_store).  Fresh allocations every repetition."""
+    from visfly_amd.ppo import MlpPolicy
+    dims, ext, pi, vf = SHAPES[name] if name in SHAPES else ({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64])
+    M = 25600
+    for rep in range(12):
+        torch.cuda.empty_cache()
+        pol = MlpPolicy(dims, ext, pi, vf, DEV, seed=9)
+        g = torch.Generator(device=DEV).manual_seed(M + rep)
+        obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+        pol.forward(obs)
+        b0 = {k: v.clone() for k, v in pol._buffers(M, 0).items() if isinstance(v, torch.Tensor) and k.split(":")[0] in ("x", "pi", "vf", "feat")}
+        pol.fused = False
+        pol.forward(obs)
+        b1 = pol._buffers(M, 0)
+        for k, v in b0.items():
+            assert (v - b1[k]).abs().max().item() <= 4e-6 * max(b1[k].abs().max().item(), 1e-3), (rep, k)
+        del pol, b0, b1

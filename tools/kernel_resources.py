@@ -1,9 +1,9 @@
 """VGPR / AGPR / spill / LDS figures of the kernels inside libvisfly_amd.so (the gfx950 code objects of the offload bundles, llvm-readelf
---notes).  python tools/kernel_resources.py [regex]"""
+--notes).  python tools/kernel_resources.py [regex] [shared object]"""
 import os, re, shutil, struct, subprocess, sys, tempfile
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-so = open(os.path.join(root, "visfly_amd", "csrc", "libvisfly_amd.so"), "rb").read()
+so = open(sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "visfly_amd", "csrc", "libvisfly_amd.so"), "rb").read()
 pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else ".")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 rows, pos, tmp = [], so.find(MAGIC), tempfile.mkdtemp()

@@ -164,6 +164,10 @@ prefetch) # next epoch's gather + advantage normalisation on
     (cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace -d /tmp/prof_pf -- python $R/tools/exp_ppo_prefetch.py 1 only > $O/prof.log 2>&1)
     python tools/trace_overlap.py /tmp/prof_pf k_gather_rows | tee $O/overlap.txt
     ;;
+jit)      # chain kernels compiled on first use for any net_arch -- parity, then the optimiser step with / without the plugin
+    timeout 1200 python -m pytest tests/test_chain_jit_gpu.py -x -q 2>&1 | tail -5 | tee $O/pytest.txt
+    timeout 900 python tools/exp_chain_jit.py 2>&1 | grep -v amdgpu.ids | tee $O/table.txt
+    ;;
 avail)    # counter names this rocprofv3 knows on gfx950
     (cd /tmp && rocprofv3 --list-avail > $O/avail.txt 2>&1); grep -c . $O/avail.txt
     ;;

@@ -1,0 +1,124 @@
+// vf_chain_plugin.hpp -- the interface between libvisfly_amd.so and a chain plugin: a shared object, compiled on first use for one network
+// shape (visfly_amd/_jit.py), that holds the register-chained kernels of that shape (vf_mlp_chain_gen.hpp) and the three host functions
+// below.  libvisfly_amd.so loads it with vf_chain_plugin_load (include/visfly_amd.h) and asks every loaded plugin after its own classes
+// (mlp_forward_chain_try, mlp_backward_chain_try, ppo_update_chain_try).  Return values as those functions': 1 launched (or, for a
+// query, "would launch"), 0 not this plugin's shape, < 0 error (-1000 - hipError_t).
+#pragma once
+#include "vf_mlp_chain_kernels.hpp"
+#ifdef VF_CHAIN_PLUGIN
+#include "vf_mlp_chain_gen.hpp"
+#endif
+
+namespace vf {
+
+// layout stamp: both sides are compiled from the same headers; a plugin built against other struct layouts is refused
+constexpr unsigned kChainPluginAbi = 0x56460001u ^ (unsigned)(sizeof(vf_mlp_desc) * 31u + sizeof(vf_mlp_bwd_desc) * 17u + sizeof(ChainArgs) * 7u +
+                                                            sizeof(BwdArgsChain) * 5u + sizeof(PpoRowArgs) * 3u + sizeof(ReparamFwd) + sizeof(ReparamBwd));
+
+struct ChainPlugin {
+    unsigned abi;
+    const char* name;      // the shape, for messages
+    // out1 == null: the policy-only class (no value trunk)
+    int (*forward)(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1, float* out0, float* out1,
+                   int M, hipStream_t st, const ReparamFwd* rp);
+    // packed == null: capability query
+    int (*backward)(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp);
+    int (*ppo_update)(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowArgs* pr, int M, hipStream_t st);
+};
+
+// the registry (vf_chain_plugin.hip)
+int chain_plugin_count();
+const ChainPlugin* chain_plugin(int i);
+void chain_plugin_count_launch();      // vf_chain_plugin_launches(): how tests see that a plugin, not the block-tile kernels, served a call
+
+}  // namespace vf
+
+#ifdef VF_CHAIN_PLUGIN
+// ---- the plugin side: VF_CHAIN_PLUGIN_PART selects what this translation unit compiles (the parts compile in parallel) ----
+//   1: forward kernels, 2: reverse chains, 3: fused PPO step, 0: the table
+namespace vf {
+
+template <class Net, class NetPi>
+int plugin_forward(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1, float* out0, float* out1, int M,
+                   hipStream_t st, const ReparamFwd* rpp)
+{
+    if (Net::NB == 2 && !in1) return 0;
+    const ReparamFwd rp = rpp ? *rpp : ReparamFwd{};
+    ChainArgs g{*d, params, packed, ChainIo{{in0, in1, nullptr}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps),
+                reinterpret_cast<float4*>(rp.action), {rp.obs_copy[0], rp.obs_copy[1]}};
+    if (!out1) {
+        if (!chain_matches_gen<NetPi>(*d)) return 0;
+        hipLaunchKernelGGL(k_mlp_forward_chain<NetPi>, dim3((M + 31) / 32), dim3(64), 0, st, g);
+    } else {
+        if (!chain_matches_gen<Net>(*d)) return 0;
+        hipLaunchKernelGGL(k_mlp_forward_chain<Net>, dim3((M + 31) / 32), dim3(64), 0, st, g);
+    }
+    VF_HIP(hipGetLastError());
+    return 1;
+}
+
+template <class Net>
+int plugin_backward(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rpp)
+{
+    using PU = typename Net::template Bwd<true, true, false>;      // PPO update: both trunks, no observation gradient
+    using PG = typename Net::template Bwd<true, false, true>;      // first-order policy optimisation: policy trunk, observation gradient
+    const ReparamBwd rp = rpp ? *rpp : ReparamBwd{};
+    BwdArgsChain g{*d, packed, M, reinterpret_cast<const float4*>(rp.d_action), reinterpret_cast<const float4*>(rp.action), rp.log_std,
+                   reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.g_log_std)};
+    const dim3 grid((M + 31) / 32);
+    if (bwd_chain_matches_gen<PU>(*d, false)) {
+        if (packed) hipLaunchKernelGGL(k_mlp_backward_chain<PU>, grid, dim3(64), 0, st, g);
+    } else if (bwd_chain_matches_gen<PG>(*d, true)) {
+        if (packed) hipLaunchKernelGGL(k_mlp_backward_chain<PG>, grid, dim3(64), 0, st, g);
+    } else {
+        return 0;
+    }
+    VF_HIP(hipGetLastError());
+    return 1;
+}
+
+template <class Net0>
+int plugin_ppo_update(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowArgs* pr, int M, hipStream_t st)
+{
+    // more forward tiles than stay live beside the reverse chain: the variant that keeps the ReLU masks as bits (vf_mlp_chain_gen.hpp)
+    using Net = std::conditional_t<(Net0::n_tiles > kGenLiveTiles), ChainNetG<typename Net0::Spec, true>, Net0>;
+    using PU = typename Net::template Bwd<true, true, false>;
+    if (Net::NB == 2 && !g->io.in[1]) return 0;
+    if (!chain_matches_gen<Net>(g->d) || !bwd_chain_matches_gen<PU>(gb->d, false)) return 0;
+    hipLaunchKernelGGL(k_ppo_update_chain<Net>, dim3((M + 31) / 32), dim3(64), 0, st, *g, *gb, *pr);
+    VF_HIP(hipGetLastError());
+    return 1;
+}
+
+}  // namespace vf
+
+extern "C" {
+int vf_plugin_forward(const vf_mlp_desc*, const float*, const float*, const float*, const float*, float*, float*, int, hipStream_t, const vf::ReparamFwd*);
+int vf_plugin_backward(const vf_mlp_bwd_desc*, const float*, int, hipStream_t, const vf::ReparamBwd*);
+int vf_plugin_ppo_update(const vf::ChainArgs*, const vf::BwdArgsChain*, const vf::PpoRowArgs*, int, hipStream_t);
+const vf::ChainPlugin* vf_chain_plugin();
+}
+
+// VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, "name"): the part of the plugin this translation unit holds
+#if VF_CHAIN_PLUGIN_PART == 1
+#define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
+    extern "C" int vf_plugin_forward(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,    \
+                                     float* out0, float* out1, int M, hipStream_t st, const vf::ReparamFwd* rp)                              \
+    { return vf::plugin_forward<Net, NetPi>(d, params, packed, in0, in1, out0, out1, M, st, rp); }
+#elif VF_CHAIN_PLUGIN_PART == 2
+#define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
+    extern "C" int vf_plugin_backward(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const vf::ReparamBwd* rp)        \
+    { return vf::plugin_backward<Net>(d, packed, M, st, rp); }
+#elif VF_CHAIN_PLUGIN_PART == 3
+#define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
+    extern "C" int vf_plugin_ppo_update(const vf::ChainArgs* g, const vf::BwdArgsChain* gb, const vf::PpoRowArgs* pr, int M, hipStream_t st) \
+    { return vf::plugin_ppo_update<Net>(g, gb, pr, M, st); }
+#else
+#define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
+    extern "C" const vf::ChainPlugin* vf_chain_plugin()                                                                                      \
+    {                                                                                                                                        \
+        static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, vf_plugin_forward, vf_plugin_backward, vf_plugin_ppo_update};              \
+        return &p;                                                                                                                           \
+    }
+#endif
+#endif

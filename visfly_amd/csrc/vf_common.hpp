@@ -21,6 +21,14 @@ inline int fail(int code, const char* fmt, ...)
     return code;
 }
 
+#ifdef VF_CHAIN_PLUGIN
+// a chain plugin (vf_chain_plugin.hpp) is a shared object of its own: it calls nothing of libvisfly_amd.so, the library words the error
+#define VF_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return -1000 - (int)e_;                                       \
+    } while (0)
+#else
 #define VF_HIP(expr)                                                                        \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
@@ -28,6 +36,7 @@ inline int fail(int code, const char* fmt, ...)
             return vf::fail(VF_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                             __FILE__, __LINE__);                                            \
     } while (0)
+#endif
 
 inline hipStream_t as_stream(vf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -63,9 +63,14 @@ struct ChainLayer {
 // PASS_ = 1: one more input (<= 8 wide; the critic's action) is appended to the features unchanged -- th.cat([features, actions])
 //   (:137).  In the layer table it is a frozen identity layer between the extractor layers and the trunks (vf_mlp_desc.identity_mask);
 //   here it is one more 32-feature input tile of the trunks' first layers whose first registers hold the input's columns
+template <class N, bool PI, bool VF, bool IG>
+struct BwdProg;      // vf_mlp_chain_bwd.hpp
+
 template <int NB_, int KA_, int KB_, int E1_, int E2_, int P1_, int P2_, int V1_, int V2_, bool VF_ = true, int HV_ = 1, int HM_ = 4,
           int PASS_ = 0>
 struct ChainNet {
+    template <bool PI, bool VF2, bool IG>
+    using Bwd = BwdProg<ChainNet, PI, VF2, IG>;      // the class's reverse-chain program (a generated class names its own: vf_mlp_chain_gen.hpp)
     static constexpr int NB = NB_, E1 = E1_, E2 = E2_, P1 = P1_, P2 = P2_, V1 = V1_, V2 = V2_, HV = HV_, HM = HM_, PASS = PASS_;
     static constexpr bool VF = VF_;
     static_assert((HV_ == 1 || HV_ == 4) && (HM_ == 1 || HM_ == 4), "heads: 1 or 4 wide");
@@ -140,6 +145,8 @@ struct ChainNet {
         return n;
     }
     static constexpr int mask_bits(int /*fl*/) { return -1; }     // first bit tile of forward layer fl's ReLU mask (ChainLayer::pk0), -1: the tiles stay
+    static constexpr int n_mb = 8;              // words of ChainState::mb
+    static constexpr bool pack_or = false;      // true: bit tiles are packed in any order into words the kernel zeroed (vf_mlp_chain_gen.hpp)
 };
 
 constexpr int kChainDepth = 8;   // weight blocks in flight: 8 x 4 MFMAs x 64 cycles = 2 k cycles of cover (4 deep measured the same in the split kernels)
@@ -148,7 +155,7 @@ template <class N>
 struct ChainState {
     using Net = N;
     f32x16 t[N::n_tiles];
-    unsigned mb[8];              // ReLU masks kept as bits (ChainLayer::pk0): bit tile j = bits [16 (j & 1), +16) of word j >> 1, bit r = register r
+    unsigned mb[N::n_mb];        // ReLU masks kept as bits (ChainLayer::pk0): bit tile j = bits [16 (j & 1), +16) of word j >> 1, bit r = register r
     float x[2][16];              // observation fragments: x[b][s] = X[m][2 s + h] (K padded to <= 32)
     float4 ring[kChainDepth];
     float4 bias[4][4];           // bias of the layer in flight: [out tile][g] -> features 32 a + 8 g + 4 h .. + 3
@@ -217,9 +224,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_store_rsrc(unsigned long
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi << 32) | lo), 0, 0xFFFFFFFFu, 0x00020000);
 }
+// The column offset (a compile-time constant < 4096) goes into the instruction's IMMEDIATE offset field (voffset + constant, soffset = 0),
+// NOT into soffset.  r05, found on a generated class: with the constant in soffset, offsets above 64 (no inline constant) become
+// `s_movk_i32 sN, 0xc0; buffer_store_dwordx4 v[6:9], v122, s[28:31], sN offen; v_add_f32 v6, ..` -- the compiler's hazard rule for
+// 128-bit store data ("a VALU write of the data registers needs 2 wait states after the store") exempts stores whose soffset is an SGPR,
+// and the next layer's epilogue overwrote v6 in the very next slot.  On gfx950 the exemption does not hold when the store's issue stalls
+// (first touch of freshly allocated pages): element 0 of the float4 of the last-read lanes (12-15 of every 16) went out as the NEW value
+// of v6, a pre-ReLU sum -- 8 rows x 2 floats of one saved activation wrong, once in ~3 cold launches.  With the immediate form the
+// compiler sees a store without soffset register and inserts the `s_nop 1` itself.
 __device__ __forceinline__ void chain_buffer_store(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned col_off, float a, float b, float c, float d)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(vf_u4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, (int)lane_off, (int)col_off, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(vf_u4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, (int)(lane_off + col_off), 0, 0);
 }
 
 template <class N, int I>
@@ -397,7 +412,7 @@ __device__ __forceinline__ void chain_pack_input(ChainState<N>& st)
 #pragma unroll
         for (int a = 0; a < L.nin; ++a) {
             const int j = L.pk0 + a;
-            unsigned bits = (j & 1) ? st.mb[j >> 1] : 0u;
+            unsigned bits = (N::pack_or || (j & 1)) ? st.mb[j >> 1] : 0u;
             const f32x16& y = st.t[L.in0 + a];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -46,6 +46,7 @@ struct BwdProg {
     static constexpr int g_e1(int b) { return g_feat + NB * N::E2 + b * N::E1; }
     static constexpr int g_in(int b) { return g_e1(NB) + b; }
     static constexpr int n_tiles = g_in(NB);
+    static constexpr int n_ym = 4;          // BwdFin::ym0 + nt of every op fits: mask slots of the stand-alone reverse chain
     static constexpr int n_ops = (PI ? 3 : 0) + (VF ? 3 : 0) + NB + (IG ? NB : 0);
     static constexpr bool included(int l) { return l < 2 * NB || (l >= L_pi0 && l <= L_mean && PI) || (l >= L_vf0 && VF); }
     static constexpr int entry(int fl)      // index of forward layer fl in the (reversed, trunk-skipping) vf_mlp_bwd_desc
@@ -136,7 +137,7 @@ template <class P>
 struct BwdState {
     f32x16 t[P::n_tiles];
     float4 ring[kChainDepth];
-    float4 ym[4][4];             // saved activations (mask source) of the tiles being finalised
+    float4 ym[P::n_ym][4];       // saved activations (mask source) of the tiles being finalised
     float hin[2][4];             // head gradients of this lane's row: d_mean[0..3] / d_value (lane half 0), else 0
     unsigned long sv_base[2];    // dZ buffers of the (up to two) layers the PREVIOUS op finalised (bwd_store_setup): uniform bases ...
     unsigned sv_off[2];          // ... + this lane's byte offsets

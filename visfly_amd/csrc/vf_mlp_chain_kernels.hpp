@@ -89,6 +89,88 @@ __global__ __launch_bounds__(64) void k_mlp_backward_chain(const BwdArgsChain g)
     bwd_rows<P, ROWS>(g, lane, row, rc, live);
 }
 
+// ------------------------------------------------------------------------------------------------
+// PPO minibatch step, everything that is per-row in ONE launch: forward chain -> clipped-surrogate loss of the wave's
+// 32 rows (their head outputs never leave the registers) -> reverse chain, whose ReLU masks are the forward's own
+// accumulator tiles (still live), so nothing is read back.  Left in HBM for the weight-gradient kernel: the layer
+// inputs X (forward's saved copies), the masked gradients dZ, d_mean / d_value; per wave one row of loss-statistic
+// partials (folded by the loss kernel's k_fold_stats).
+// ------------------------------------------------------------------------------------------------
+template <class N>
+__global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, const BwdArgsChain gb, const PpoRowArgs pr)
+{
+    using P = typename N::template Bwd<true, true, false>;
+    prefetch_kernarg<sizeof(ChainArgs) + sizeof(BwdArgsChain) + sizeof(PpoRowArgs)>();
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int row = blockIdx.x * 32 + m;
+    const bool live = row < g.M;
+    const int rc = live ? row : g.M - 1;
+    // per-row loss inputs first: the action-only part of the loss (ppo_row_pre) runs while the weight fragments are on their way
+    const float4 a4 = pr.action[rc];
+    const float ls[4] = {pr.log_std[0], pr.log_std[1], pr.log_std[2], pr.log_std[3]};
+    const float old_lp = pr.old_lp[rc], adv = pr.adv[rc], ret = pr.ret[rc];
+    ChainState<N> fs;
+    if constexpr (N::pack_or) {
+#pragma unroll
+        for (int i = 0; i < N::n_mb; ++i) fs.mb[i] = 0u;
+    }
+    chain_prologue<N, 0>(g, fs, lane);
+#pragma unroll
+    for (int b = 0; b < N::NB; ++b) {
+        const int w = g.d.in_dim[b];
+        const float* x = g.io.in[b] + (size_t)rc * w;
+#pragma unroll
+        for (int s = 0; s < N::kin(b) / 2; ++s) {
+            const int k = 2 * s + h;
+            const float v = x[k < w ? k : w - 1];
+            fs.x[b][s] = k < w ? v : 0.0f;
+        }
+    }
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+    PpoRowPre pre = ppo_row_pre(a);
+#pragma unroll
+    for (int d = 0; d < 4; ++d)     // pinned here: left alone the compiler sinks the arithmetic to its use behind the forward chain
+        asm volatile("" : "+v"(pre.g[d]), "+v"(pre.corr[d]));
+    chain_items<N, 0>(g, fs, lane, row, live, rc);
+    BwdState<P> bs;
+    bwd_prologue<P, 0>(gb, bs, lane);                  // first weight blocks of the reverse chain: in flight during the loss arithmetic
+    // ---- loss of this lane's row (lane half 0 holds mean[0..3] / value in registers 0..3 / 0 of the head tiles) ----
+    float stt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dm[4] = {0, 0, 0, 0}, dvl = 0.0f;
+    {
+        const f32x16& mt = fs.t[N::t_mean];
+        const float mu[4] = {mt[0], mt[1], mt[2], mt[3]};
+        float st1[9], dm1[4], dv1;
+        ppo_row_post(pre, mu, fs.t[N::t_val][0], ls, old_lp, adv, ret, pr.cfg, dm1, dv1, st1, rc);
+        const bool on = live && h == 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) stt[k] = on ? st1[k] : 0.0f;
+        // head gradients: lane half 0 of EVERY lane -- the lanes past the last row are replicas of row M - 1 (they loaded its inputs)
+        // and must stay replicas through the reverse chain, whose dZ stores are unguarded (bwd_store_setup): they rewrite that row's
+        // values, they do not zero them.  Only the statistics above and the head rows below exclude them.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dm[k] = h == 0 ? dm1[k] : 0.0f;
+        dvl = h == 0 ? dv1 : 0.0f;
+        if (on) {         // head gradients: dZ of the head layers for the weight-gradient kernel
+            const vf_mlp_bwd_layer& Em = gb.d.layer[P::entry(P::L_mean)];
+            const vf_mlp_bwd_layer& Ev = gb.d.layer[P::entry(P::L_val)];
+            *reinterpret_cast<float4*>(const_cast<float*>(Em.dY) + (size_t)row * Em.ld_dy) = make_float4(dm[0], dm[1], dm[2], dm[3]);
+            const_cast<float*>(Ev.dY)[(size_t)row * Ev.ld_dy] = dvl;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float s = stt[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) pr.part[(size_t)blockIdx.x * kStats + k] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bs.hin[0][k] = dm[k];
+    bs.hin[1][0] = dvl; bs.hin[1][1] = 0.0f; bs.hin[1][2] = 0.0f; bs.hin[1][3] = 0.0f;
+    bwd_items<P, ChainState<N>, 0>(gb, bs, fs, lane, row, rc, live);
+    bwd_tail_store<P>(gb, bs, row, h, live);
+}
+
 // does the layer table describe network class N (shapes, wiring, execution order of MlpPolicy)?
 template <class N>
 bool chain_matches(const vf_mlp_desc& d)

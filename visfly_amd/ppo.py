@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch as th
 
-from . import _lib, checkpoint, parallel
+from . import _jit, _lib, checkpoint, parallel
 
 
 def _ptr(t, off=0):
@@ -143,6 +143,17 @@ class MlpPolicy:
         self._scratch = None
         self._plan = self._plan_fused()
         self._descs = {}
+        # chain kernels of a shape the library holds no instance of: compiled on first use (visfly_amd/_jit.py)
+        self.chain_shape = _jit.shape_of(self.obs_dims, extractor, pi, vf, self.head_dims, self.passthrough) if log_std_param else None
+        self.chain_jit = False
+        if self._plan is None:          # more activation buffers than a vf_mlp_desc names (VF_MLP_MAX_BUFS): layer-by-layer launches
+            self.chain_shape = None
+        if self.chain_shape is not None and not _jit.is_builtin(self.chain_shape) and self.device.type == "cuda":
+            try:
+                self.chain_jit = _jit.ensure(self.chain_shape)
+            except Exception as e:      # no hipcc on this machine, a shape the compiler rejects, ...: the block-tile kernels run it
+                import warnings
+                warnings.warn(f"visfly_amd: no chain kernels for {_jit.name_of(self.chain_shape)} ({e})")
         self.fused = True
         self.fused_backward = True
         self._packed, self._pack_desc, self._stamp, self._packed_stamp, self.lazy_pack = None, None, 0, -1, False
@@ -156,9 +167,10 @@ class MlpPolicy:
         self._slot_blocks: Dict[int, tuple] = {}
 
     def _warn_fallback(self, what):
-        """the register-chained kernels are instantiated for the reference-default shapes only (one or two [128, 64] extractor
-        branches, [64, 64] trunks); any other net_arch runs on the general block-tile / per-layer kernels -- correct, but
-        at roughly half the MFMA throughput.  Say so once instead of silently."""
+        """the register-chained kernels exist for the reference-default shapes (instantiated in the library) and for every shape
+        visfly_amd/_jit.py can generate an instance of (1-2 observation branches, 1-4 layers per branch / trunk, widths in multiples
+        of 32 up to 128: compiled on first use); any other net_arch runs on the general block-tile / per-layer kernels -- correct,
+        but at roughly half the MFMA throughput.  Say so once instead of silently."""
         if not getattr(self, "_warned_fallback", False):
             self._warned_fallback = True
             import warnings
