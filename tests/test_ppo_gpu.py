@@ -178,7 +178,7 @@ def test_fused_forward_equals_layerwise(M, shape):
     to the per-layer kernels; the reference-default shape runs the register-chained kernel (vf_mlp_chain.hip), whose
     reduction order over k differs -- equal to fp32 rounding"""
     from visfly_amd.ppo import MlpPolicy
-    ext = {"state": [128, 64], "target": [128, 64]} if shape == "reference" else {"state": [128, 32], "target": [96, 64]}
+    ext = {"state": [128, 64], "target": [128, 64]} if shape == "reference" else {"state": [128, 40], "target": [96, 64]}      # (40: off the 32 grid, so no generated chain class either)
     pol = MlpPolicy({"state": 13, "target": 3}, ext, [64, 64], [64, 64], DEV, seed=9)
     assert pol._plan is not None and pol._plan["total"] * 4 <= 160 * 1024
     g = torch.Generator(device=DEV).manual_seed(M)
@@ -549,7 +549,7 @@ def test_policy_only_forward_and_split_backward(shape):
     """need_value=False: same action mean (the register-chained kernel skips the value trunk, other layer tables fall
     back to the full forward); backward_data + weight_grad_slots over reserved slots == per-slot backward, summed"""
     from visfly_amd.ppo import MlpPolicy
-    ext = {"state": [128, 64]} if shape == "reference" else {"state": [96, 64]}
+    ext = {"state": [128, 64]} if shape == "reference" else {"state": [100, 64]}      # (100: no built-in and no generated chain class)
     pol = MlpPolicy({"state": 13}, ext, [64, 64], [64, 64], DEV, seed=21)
     M, n = 777, 3
     g = torch.Generator(device=DEV).manual_seed(5)
