@@ -86,12 +86,23 @@ def native_comm(force: bool = False):
     # the agreement rounds run over a gloo (CPU) side group: after a timed-out ncclCommInitRank the NCCL backend's own stream may be
     # blocked behind the stuck init on this device, and an all-reduce on it would hang the very ranks the watchdog is protecting
     # (ADVICE r03).  new_group is itself collective: every rank reaches this line (local failures above are caught, not raised)
+    # The side group is made once per process (a forced retry reuses it) and used only if EVERY rank got one: new_group can fail on
+    # some ranks only, and agreement rounds on different groups would hang -- that availability vote is the one
+    # all-reduce that has to run on the default group, before anything was handed to RCCL
     side = None
     if w > 1:
-        try:
-            side = dist.new_group(backend="gloo")
-        except Exception:  # noqa: BLE001   (gloo not built: fall back to the default group)
-            side = None
+        if "side" not in _native:
+            try:
+                _native["side"] = dist.new_group(backend="gloo")
+            except Exception:  # noqa: BLE001   (gloo not built)
+                _native["side"] = None
+            got = th.tensor([1 if _native["side"] is not None else 0], dtype=th.int32)
+            if dist.get_backend() == "nccl":
+                got = got.to(th.device("cuda", th.cuda.current_device()))
+            dist.all_reduce(got, op=dist.ReduceOp.MIN)
+            if not bool(got.item()):
+                _native["side"] = None
+        side = _native["side"]
 
     def agreed(ok: bool) -> bool:
         """every rank must take the same path (one rank on torch.distributed and the others on the native communicator would
@@ -128,29 +139,32 @@ def native_comm(force: bool = False):
         # others blocked inside the init for ever); the init itself runs under a watchdog for the same reason
         if agreed(why is None):
             import threading
-            box2 = {}
-            dev_index = th.cuda.current_device()
+            box2, box_lock = {}, threading.Lock()      # "abandoned" is checked and "h" stored under the lock: a late init either
+            dev_index = th.cuda.current_device()       # sees the flag and destroys its handle, or its handle is seen below
 
             def init():
                 try:
                     th.cuda.set_device(dev_index)
                     hh = _lib._vp()
                     _lib.check(L.vf_comm_init(ident, w, rank(), C.byref(hh)))
-                    if box2.get("abandoned"):        # the watchdog gave up on this thread: nobody will use the communicator it got
+                    with box_lock:
+                        late = box2.get("abandoned", False)
+                        if not late:
+                            box2["h"] = hh
+                    if late:                         # the watchdog gave up on this thread: nobody will use the communicator it got
                         L.vf_comm_destroy(hh)
-                    else:
-                        box2["h"] = hh
                 except Exception as e:  # noqa: BLE001
                     box2["why"] = e
 
             t = threading.Thread(target=init, daemon=True)
             t.start()
             t.join(float(os.environ.get("VISFLY_AMD_COMM_INIT_TIMEOUT", "180")))
-            if t.is_alive():
-                box2["abandoned"] = True     # if the init ever returns, its thread destroys the handle itself
-                why = RuntimeError("ncclCommInitRank did not return (another rank never entered it?)")
-            else:
-                h, why = box2.get("h"), box2.get("why")
+            with box_lock:
+                h = box2.get("h")
+                if h is None and "why" not in box2:
+                    box2["abandoned"] = True         # if the init ever returns, its thread destroys the handle itself
+            if h is None:
+                why = box2.get("why") or RuntimeError("ncclCommInitRank did not return (another rank never entered it?)")
             if not agreed(h is not None):
                 # a peer is still inside (or never entered) ncclCommInitRank: destroying OUR communicator now would wait for it.
                 # The handle is abandoned instead (a few MB until the process exits; no atexit destroy is registered for it)
