@@ -638,6 +638,8 @@ BPTT_CASES = {
     "bptt_hover_nodelay": ("hover", dict(ENV_DYN, ctrl_delay=False, comm_delay=0.0), dict(max_episode_steps=1000),
                            [-1 / 3, 0, 0, 0], 0.3, 8),
     "bptt_racing_thrust": ("racing", RACING_DYN, dict(max_episode_steps=1000), [-0.8333] * 4, 0.08, 12),
+    # RacingEnv2 (envs/RacingEnv.py:218-267): the 16-column gate-relative observation under the loss's obs weights (Wo (H, N, 16))
+    "bptt_racing2_thrust": ("racing2", RACING_DYN, dict(max_episode_steps=1000), [-0.8333] * 4, 0.08, 12),
     # repaired RK4: stages chained through the (q, omega) derivatives, acc / tau frozen over the sub-step
     "bptt_hover_rk4": ("hover", dict(ENV_DYN, integrator="rk4"), dict(max_episode_steps=1000), [-1 / 3, 0, 0, 0], 0.3, 12),
     # NavigationEnv reward (progress, view angle through acos, obstacle terms, success bonus): close target so that
@@ -672,6 +674,9 @@ def gen_bptt(name, N=64, seed=42):
         repair_rk4("VisFly.utils.maths")
     use_cr_sqrt(True)
     cls = {"hover": HoverEnvShim, "racing": RacingEnv, "nav": NavigationEnv}.get(kind)
+    obs_w = 13
+    if kind == "racing2":
+        cls, kind, obs_w = import_racing2(), "racing", 16       # everything but the observation is RacingEnv
     if cls is None:
         H2, N2 = import_envs2()
         cls = {"hover2": H2, "nav2": N2}[kind]
@@ -688,7 +693,7 @@ def gen_bptt(name, N=64, seed=42):
     acts = th.tensor(decode_actions(rng.integers(-127, 128, size=(H, N, 4), dtype=np.int8), hover, scale),
                      requires_grad=True)
     Wr = th.tensor(rng.normal(size=(H, N)).astype(np.float32))
-    Wo = th.tensor((rng.normal(size=(H, N, 13)) * 0.1).astype(np.float32))
+    Wo = th.tensor((rng.normal(size=(H, N, obs_w)) * 0.1).astype(np.float32))
     env.reset()
     dyn = env.envs.dynamics
     fs_init = f32(dyn.full_state)
@@ -707,7 +712,7 @@ def gen_bptt(name, N=64, seed=42):
     loss.backward()
     g = f32(acts.grad)
     print(f"{name}: N={N} H={H} resets={len(ev_step)} |dL/da| max {np.abs(g).max():.3e} loss {float(loss):.4f}")
-    save = {"kind": np.asarray(kind), "max_episode_steps": np.int32(kw["max_episode_steps"]), "seed": np.int32(seed),
+    save = {"kind": np.asarray("racing2" if obs_w == 16 else kind), "max_episode_steps": np.int32(kw["max_episode_steps"]), "seed": np.int32(seed),
             "fs_init": fs_init, "actions": f32(acts), "Wr": f32(Wr), "Wo": f32(Wo), "d_actions": g, "loss": np.float64(float(loss)),
             "done": np.stack(dones), "reward": np.stack(rewards),
             "ev_step": np.asarray(ev_step, np.int32), "ev_agent": np.asarray(ev_agent, np.int32),

@@ -197,14 +197,15 @@ class RacingEnv2(RacingEnv):
     """RacingEnv with the gate-relative observation (envs/RacingEnv.py:218-267): "state" = [(next `_next_target_num` gates -
     p) / max_sense_radius (6), q (4), v / 10 (3), w / 10 (3)] = 16 columns, "gate" = next-gate index as (N,1).  Dynamics, reward,
     gate bookkeeping and re-spawn are RacingEnv's (the step kernel); the observation is assembled from the kernel's raw state rows
-    with the reference's own torch expressions, one small launch sequence per step (NEXT tier; forward only --
-    requires_grad=True raises, and step_n() is refused)."""
+    with the reference's own torch expressions, one small launch sequence per step (NEXT tier; step_n() is refused).
+    requires_grad=True (r05): the observation is linear in the raw state row for a given gate index (which carries no gradient), so
+    its adjoint is four column operations in front of the step kernel's adjoint (``backward_step``); pinned by the gradient fixture
+    ``bptt_racing2_thrust`` (the reference's autograd over its own RacingEnv2.get_observation).  The trainers' persistent launches
+    do not cover a host-side observation: BPTT / SHAC on this env step launch by launch."""
     _HOST_OBS = True
 
-    def __init__(self, *a, requires_grad: bool = False, **kw):
-        if requires_grad:
-            raise NotImplementedError("RacingEnv2: the host-side observation has no adjoint; use RacingEnv for BPTT / SHAC")
-        super().__init__(*a, requires_grad=False, **kw)
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
         self.max_sense_radius = 10                                                     # droneGymEnv.py:69
         g = kw.get("gates")
         self.targets = th.as_tensor(_RACING_GATES if g is None else g, dtype=th.float32, device=self.device)
@@ -218,9 +219,20 @@ class RacingEnv2(RacingEnv):
         return th.hstack([rel / th.full((1,), float(self.max_sense_radius), device=raw.device), raw[:, 3:7],
                           raw[:, 7:10] / ten, raw[:, 10:13] / ten])                                    # :257-262
 
+    def backward_step(self, t: int, d_obs=None, d_reward=None):
+        """d_obs (N, 16): gradient w.r.t. the observation rows step t returned -> the raw state row's (N, 13), then RacingEnv's adjoint.
+        obs = [(g0 - p) / R, (g1 - p) / R, q, v / 10, w / 10] (RacingEnv.py:254-262): dp = -(d[0:3] + d[3:6]) / R, dq = d[6:10],
+        dv = d[10:13] / 10, dw = d[13:16] / 10"""
+        if d_obs is not None:
+            d = d_obs.to(self.device, dtype=th.float32).reshape(self.num_agent, 16)
+            d_obs = th.cat([-(d[:, 0:3] + d[:, 3:6]) / float(self.max_sense_radius), d[:, 6:10], d[:, 10:13] / 10.0, d[:, 13:16] / 10.0], dim=1)
+        return super().backward_step(t, d_obs, d_reward)
+
     def _full_obs(self, state, raw=False):          # RacingEnv's rules for WHICH gate index the returned rows use apply unchanged
-        self._last_raw = state
         g = self._gate if self._g_obs is None else self._g_obs
+        if state.shape[-1] == 16:      # already the observation rows (step() with requires_grad: the graph-attached copy of what
+            return TensorDict({"state": state, "gate": g.unsqueeze(1).clone()})      # _step_no_grad built from the raw rows)
+        self._last_raw = state
         return TensorDict({"state": self._race_state(state, g), "gate": g.unsqueeze(1).clone()})      # :264-267
 
     def _terminal_state_obs(self, tobs, i):
