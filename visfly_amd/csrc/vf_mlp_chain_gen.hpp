@@ -136,7 +136,10 @@ struct GenLayers {
 // they are reduced to one bit per value (ChainLayer::pk0, bit tile = tile number) and their 16 registers each are free again.  The fused
 // PPO step of a shape with more than kGenLiveTiles forward tiles runs this variant: with every tile live it spills (26 tiles: 64
 // spilled registers, 38 tiles: 283), as bits the whole forward is 0.5 register per tile.
-constexpr int kGenLiveTiles = 24;
+#ifndef VF_GEN_LIVE_TILES
+#define VF_GEN_LIVE_TILES 24
+#endif
+constexpr int kGenLiveTiles = VF_GEN_LIVE_TILES;
 
 template <class S, bool VF, bool PACK = false>
 struct GenLayerTable {
