@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 8   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
+#define VF_ABI_VERSION 9   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
                               4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_dyn_set_wind,
@@ -36,7 +36,8 @@ extern "C" {
                                  vf_dyn_step_bwd, vf_debug_poison_lds, vf_bptt_rollout, vf_bptt_reverse, vf_ppo_rollout;
                               6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse, vf_mlp_desc.identity_mask (was pad0);
                               7: mean_rows / log_std_rows / reward_rows / ep_flag_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes);
-                              8: vf_twin_q_update (fused critic step of SHAC), vf_mlp_forward_steps, vf_shac_accumulate_horizon */
+                              8: vf_twin_q_update (fused critic step of SHAC), vf_mlp_forward_steps, vf_shac_accumulate_horizon 
+                              9: vf_ppo_loss_cfg.row_index / obs_copy0 / obs_copy1 (vf_ppo_update on an indexed minibatch), vf_chain_plugin_* */
 
 /* clamp interval of the state-dependent log_std head of the reference's Actor (utils/policies/td_policies.py:31-32,241-243) */
 #define VF_SAC_LOG_STD_MIN (-10.0f)
@@ -690,6 +691,15 @@ typedef struct vf_ppo_loss_cfg {
     const float* old_value;
     float clip_range_vf;
     int32_t pad0;
+    /* ABI 9, vf_ppo_update only (vf_ppo_loss ignores them): row_index != NULL -- row m of the call is row row_index[m] of in0 / in1 /
+     * action / old_log_prob / ret / old_value, i.e. those pointers are the rollout buffer itself and no shuffled copy of it is made
+     * (SB3's RolloutBuffer.get indexes the buffer with a permutation slice: buffers.py [SB3 2.2.1] :get/_get_samples).  adv stays in
+     * call order: it is normalised per minibatch (PPO.py:215-220).  obs_copy0 / obs_copy1 (required with row_index): (M, in_dim)
+     * buffers that receive the call's observation rows in call order -- the X operand of the first layers' weight gradients, i.e. what
+     * bwd's first-layer entries must point to. */
+    const int64_t* row_index;
+    float* obs_copy0;
+    float* obs_copy1;
 } vf_ppo_loss_cfg;
 
 /* Clipped-surrogate PPO loss and its gradient w.r.t. the head outputs (PPO.py:210-263;

@@ -628,6 +628,67 @@ def test_fused_ppo_update_equals_separate_launches(net, B, form, monkeypatch):
     assert torch.allclose(g1[pol.log_std_off:], g0[pol.log_std_off:], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("form", ["split", "one-wave"])
+@pytest.mark.parametrize("net,vclip", [("nav", False), ("hover", True)])
+@pytest.mark.parametrize("B", [25600, 1000, 33])
+def test_fused_ppo_update_on_an_indexed_minibatch(net, vclip, B, form, monkeypatch):
+    """r05 (ABI 9): vf_ppo_update reads its minibatch through row indices into the whole rollout buffer (vf_ppo_loss_cfg.row_index: no
+    shuffled copy of the buffer per epoch) and leaves the observation rows in minibatch order for the weight gradients -- the same
+    statistics and gradient, bit for bit, as the call on the gathered rows; with value clipping (old_value indexed too)"""
+    monkeypatch.setenv("VISFLY_AMD_CHAIN_SPLIT", "1" if form == "split" else "0")
+    from visfly_amd.ppo import MlpPolicy
+    _lib, lib = L()
+    dims = {"state": 13, "target": 3} if net == "nav" else {"state": 13}
+    pol = MlpPolicy(dims, {k: [128, 64] for k in dims}, [64, 64], [64, 64], DEV, seed=5, log_std_init=-0.3)
+    T = 3 * B + 17                                   # rows of the "rollout buffer"
+    g = torch.Generator(device=DEV).manual_seed(B)
+    obs = {k: torch.randn((T, d), device=DEV, generator=g) for k, d in dims.items()}
+    actions = torch.tanh(torch.randn((T, 4), device=DEV, generator=g)).contiguous()
+    old_lp, ret, old_v = (torch.randn(T, device=DEV, generator=g) for _ in range(3))
+    rows = torch.randperm(T, device=DEV, generator=g)[:B].contiguous()
+    adv = torch.randn(B, device=DEV, generator=g)                      # minibatch order (normalised per minibatch)
+    scratch = torch.zeros(16 * max(1024, (B + 31) // 32), device=DEV)
+    res = {}
+    for indexed in (True, False):
+        stats = torch.zeros(16, device=DEV)
+        pol.grad.fill_(3.0)
+        cfg = _lib.PpoLossCfg(0.2, 0.01, 0.5, 1.0 / B, pol.grad.data_ptr() + 4 * pol.log_std_off, None)
+        if indexed:
+            if vclip:
+                cfg.old_value, cfg.clip_range_vf = old_v.data_ptr(), 0.3
+            assert pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch, row_index=rows)
+            copies = {k: pol._buffers(B, 0)["obs:" + k].clone() for k in dims}
+        else:
+            ov = old_v[rows].contiguous()
+            if vclip:
+                cfg.old_value, cfg.clip_range_vf = ov.data_ptr(), 0.3
+            o = {k: v[rows].contiguous() for k, v in obs.items()}
+            assert pol.ppo_update(o, actions[rows].contiguous(), old_lp[rows].contiguous(), adv, ret[rows].contiguous(), cfg, stats, scratch)
+            for k in dims:
+                assert torch.equal(copies[k], o[k]), "the observation rows the indexed launch left for the weight gradients"
+        res[indexed] = (pol.grad.clone(), stats.clone())
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][0], res[False][0])
+
+
+def test_ppo_training_with_indexed_minibatches_equals_the_shuffled_copy():
+    """PPO.train with the minibatches read through the permutation slice (the default on the chain kernels) ends at the same
+    parameters, bit for bit, as with the per-epoch shuffled copy of the rollout buffer (index_minibatches = False); trailing partial
+    minibatch, value clipping"""
+    from visfly_amd.envs import NavigationEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    flats = []
+    for flag in (True, False):
+        env = NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64, tensor_output=True)
+        ppo = PPO(env, n_steps=16, batch_size=6000, n_epochs=3, learning_rate=3e-4, seed=3, clip_range_vf=0.3)
+        ppo.index_minibatches = flag
+        ppo.learn(16 * 1024 * 3)
+        torch.cuda.synchronize()
+        flats.append(ppo.policy.flat.clone())
+        env.close()
+    assert torch.equal(flats[0], flats[1])
+
+
 def test_predict_is_deterministic_and_bounded():
     """SB3 ``predict(obs, deterministic=True)`` as evaluation harnesses call it (utils/evaluate.py:94): a = tanh(mean)"""
     from visfly_amd.envs import HoverEnv

@@ -71,7 +71,7 @@ class DynCfg(C.Structure):
 
 
 EUNSUPPORTED = -4         # VF_EUNSUPPORTED
-ABI_VERSION = 8          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
+ABI_VERSION = 9          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
 MAX_GATES, MAX_SPAWN = 8, 4
 
 
@@ -176,7 +176,8 @@ class PpoLossCfg(C.Structure):
     """mirror of vf_ppo_loss_cfg"""
     _fields_ = [("clip_range", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("inv_batch", C.c_float),
                 ("d_log_std_out", C.c_void_p), ("stats_accum", C.c_void_p),
-                ("old_value", C.c_void_p), ("clip_range_vf", C.c_float), ("pad0", C.c_int32)]
+                ("old_value", C.c_void_p), ("clip_range_vf", C.c_float), ("pad0", C.c_int32),
+                ("row_index", C.c_void_p), ("obs_copy0", C.c_void_p), ("obs_copy1", C.c_void_p)]
 
 
 class AdamCfg(C.Structure):

@@ -67,7 +67,10 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
         if (d->layer[i].save && !rows_fit_u32(M, d->layer[i].save_ld)) return 0;
     for (int l = 0; l < bd->n_layers; ++l)
         if (!rows_fit_u32(M, bd->layer[l].ld_dy)) return 0;
-    ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M, nullptr, nullptr, nullptr, {nullptr, nullptr}};
+    if (cfg->row_index && (!cfg->obs_copy0 || (in1 && !cfg->obs_copy1)))
+        return fail(VF_EINVAL, "vf_ppo_update: row_index needs obs_copy0 / obs_copy1 (the weight gradients read the observation rows in call order)");
+    ChainArgs g{*d, params, packed, ChainIo{{in0, in1}, nullptr, nullptr}, M, nullptr, nullptr, nullptr,
+                {cfg->row_index ? cfg->obs_copy0 : nullptr, cfg->row_index ? cfg->obs_copy1 : nullptr}};
     BwdArgsChain gb{*bd, packed, M, nullptr, nullptr, nullptr, nullptr, nullptr};
     PpoRowArgs pr{log_std, reinterpret_cast<const float4*>(action), old_lp, adv, ret, part, *cfg};
     const dim3 grid((M + 31) / 32);

@@ -14,8 +14,11 @@ struct PpoRowArgs {          // per-row inputs of the fused PPO minibatch step (
     const float* adv;
     const float* ret;
     float* part;             // [n_tiles][kStats]
-    vf_ppo_loss_cfg cfg;
+    vf_ppo_loss_cfg cfg;     // cfg.row_index: the call's row m is row row_index[m] of the observation / action / old_lp / ret / old_value buffers
 };
+
+// the buffer row a lane's row comes from (vf_ppo_loss_cfg.row_index; one dependent load at the head of the kernel)
+__device__ __forceinline__ int ppo_source_row(const PpoRowArgs& pr, int rc) { return pr.cfg.row_index ? (int)pr.cfg.row_index[rc] : rc; }
 
 // vf_mlp_chain_split.hip: the fused update kernels with two waves per row tile; 1 launched, 0 not taken, < 0 error
 int ppo_update_split_try(const ChainArgs& g, const BwdArgsChain& gb, const void* pr, int which, int M, hipStream_t st);
@@ -106,9 +109,10 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
     const bool live = row < g.M;
     const int rc = live ? row : g.M - 1;
     // per-row loss inputs first: the action-only part of the loss (ppo_row_pre) runs while the weight fragments are on their way
-    const float4 a4 = pr.action[rc];
+    const int rs = ppo_source_row(pr, rc);
+    const float4 a4 = pr.action[rs];
     const float ls[4] = {pr.log_std[0], pr.log_std[1], pr.log_std[2], pr.log_std[3]};
-    const float old_lp = pr.old_lp[rc], adv = pr.adv[rc], ret = pr.ret[rc];
+    const float old_lp = pr.old_lp[rs], adv = pr.adv[rc], ret = pr.ret[rs];
     ChainState<N> fs;
     if constexpr (N::pack_or) {
 #pragma unroll
@@ -118,12 +122,14 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
 #pragma unroll
     for (int b = 0; b < N::NB; ++b) {
         const int w = g.d.in_dim[b];
-        const float* x = g.io.in[b] + (size_t)rc * w;
+        const float* x = g.io.in[b] + (size_t)rs * w;
+        float* xc = g.obs_copy[b] ? g.obs_copy[b] + (size_t)rc * w : nullptr;      // (row_index: the rows in call order, for the weight gradients)
 #pragma unroll
         for (int s = 0; s < N::kin(b) / 2; ++s) {
             const int k = 2 * s + h;
             const float v = x[k < w ? k : w - 1];
             fs.x[b][s] = k < w ? v : 0.0f;
+            if (xc && live && k < w) xc[k] = v;
         }
     }
     const float a[4] = {a4.x, a4.y, a4.z, a4.w};
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
         const f32x16& mt = fs.t[N::t_mean];
         const float mu[4] = {mt[0], mt[1], mt[2], mt[3]};
         float st1[9], dm1[4], dv1;
-        ppo_row_post(pre, mu, fs.t[N::t_val][0], ls, old_lp, adv, ret, pr.cfg, dm1, dv1, st1, rc);
+        ppo_row_post(pre, mu, fs.t[N::t_val][0], ls, old_lp, adv, ret, pr.cfg, dm1, dv1, st1, rs);
         const bool on = live && h == 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) stt[k] = on ? st1[k] : 0.0f;

@@ -56,18 +56,19 @@ __device__ __forceinline__ void ppo_update_role(const ChainArgs& g, const BwdArg
     // per-row loss inputs first: the action-only part of the loss (ppo_row_pre) runs while the weight fragments are on their way
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float old_lp = 0.0f, adv = 0.0f, ret = 0.0f, ls[4] = {0.f, 0.f, 0.f, 0.f};
+    const int rs = ppo_source_row(pr, rc);
     if constexpr (R == 0) {
-        a4 = pr.action[rc];
+        a4 = pr.action[rs];
 #pragma unroll
         for (int k = 0; k < 4; ++k) ls[k] = pr.log_std[k];
-        old_lp = pr.old_lp[rc];
+        old_lp = pr.old_lp[rs];
         adv = pr.adv[rc];
     } else {
-        ret = pr.ret[rc];
+        ret = pr.ret[rs];
     }
     ChainState<S> fs;
     chain_prologue<S, 0>(g, fs, lane);
-    split_load_obs<N, R>(g, fs, rc, h);
+    split_load_obs<N, R>(g, fs, rs, h, rc, live);
     PpoRowPre pre{};
     if constexpr (R == 0) {
         const float a[4] = {a4.x, a4.y, a4.z, a4.w};
@@ -106,7 +107,7 @@ __device__ __forceinline__ void ppo_update_role(const ChainArgs& g, const BwdArg
     } else {
         const float mu[4] = {0.f, 0.f, 0.f, 0.f};
         float st1[9], dm1[4], dv1;
-        ppo_row_post(pre, mu, fs.t[N::t_val][0], ls, 0.0f, 0.0f, ret, pr.cfg, dm1, dv1, st1, rc);     // (only the value terms are used)
+        ppo_row_post(pre, mu, fs.t[N::t_val][0], ls, 0.0f, 0.0f, ret, pr.cfg, dm1, dv1, st1, rs);     // (only the value terms are used)
         const float dvl = h == 0 ? dv1 : 0.0f;
         bs.hin[1][0] = dvl; bs.hin[1][1] = 0.0f; bs.hin[1][2] = 0.0f; bs.hin[1][3] = 0.0f;
         if (on) {

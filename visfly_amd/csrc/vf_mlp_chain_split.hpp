@@ -131,18 +131,22 @@ struct SplitBwd : BwdProg<N, true, true, false> {
 
 // observation fragments of the branches role R reads (NB = 2: its own branch only)
 template <class N, int R>
-__device__ __forceinline__ void split_load_obs(const ChainArgs& g, ChainState<SplitNet<N, R>>& fs, int rc, int h)
+// rs: the buffer row the lane loads; rc_copy / live: where (and whether) the row is also written in call order (ChainArgs::obs_copy: the
+// fused PPO step on an indexed minibatch, vf_ppo_loss_cfg.row_index).  One extractor: both roles load the row, role 0 writes the copy
+__device__ __forceinline__ void split_load_obs(const ChainArgs& g, ChainState<SplitNet<N, R>>& fs, int rs, int h, int rc_copy = 0, bool live = false)
 {
 #pragma unroll
     for (int b = 0; b < N::NB; ++b) {
         if (N::NB == 2 && b != R) continue;
         const int w = g.d.in_dim[b];
-        const float* x = g.io.in[b] + (size_t)rc * w;
+        const float* x = g.io.in[b] + (size_t)rs * w;
+        float* xc = (g.obs_copy[b] && live && (N::NB == 2 || R == 0)) ? g.obs_copy[b] + (size_t)rc_copy * w : nullptr;
 #pragma unroll
         for (int s = 0; s < N::kin(b) / 2; ++s) {
             const int k = 2 * s + h;
             const float v = x[k < w ? k : w - 1];
             fs.x[b][s] = k < w ? v : 0.0f;
+            if (xc && k < w) xc[k] = v;
         }
     }
 }

@@ -617,23 +617,41 @@ class MlpPolicy:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
         _lib.check(L.vf_mlp_weight_grad(C.byref(d), _ptr(self._scratch), _ptr(self.grad), n * M, 1 if accumulate else 0, self._stream()))
 
-    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch, want_sumsq=False):
+    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch, want_sumsq=False, row_index=None):
         """forward + PPO loss + reverse chain in one launch, then the weight gradients into ``self.grad`` (vf_ppo_update +
         vf_mlp_weight_grad).  -> False when the network is not one of the register-chained classes (the caller then
         runs forward / vf_ppo_loss / backward).  ``want_sumsq``: -> (fp64 partials tensor, count) of the squared norm of the
-        gradient the fold wrote, for vf_adam_cfg.sumsq_partials (no separate grad-norm launch)."""
+        gradient the fold wrote, for vf_adam_cfg.sumsq_partials (no separate grad-norm launch).
+        ``row_index`` (int64, M entries; vf_ppo_loss_cfg.row_index): obs / actions / old_lp / ret (and loss_cfg.old_value) are the
+        WHOLE rollout buffer and row m of the minibatch is their row row_index[m] -- no shuffled copy; ``adv`` stays in minibatch order."""
         if self._fused_ppo is False or self._plan is None or not (self.fused and self.fused_backward):
             return False
-        M = actions.shape[0]
+        M = actions.shape[0] if row_index is None else row_index.numel()
         b = self._buffers(M, 0)
         L, st = _lib.lib(), self._stream()
+        whole = {}
         for k in self.obs_keys:
             t = obs[k]
-            assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape == (M, self.obs_dims[k])
+            assert t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.shape[1:] == (self.obs_dims[k],)
+            if row_index is not None:
+                # the launch leaves the minibatch's observation rows, in minibatch order, where the weight gradients read them
+                whole[k] = t
+                if not b.get("_contig"):        # (reserved slots own their observation rows already)
+                    own = b.get("_own:" + k)
+                    if own is None:
+                        own = b["_own:" + k] = th.empty((M, self.obs_dims[k]), dtype=th.float32, device=self.device)
+                    b["obs:" + k] = own
+                continue
+            assert t.shape[0] == M
             if b.get("_contig"):
                 b["obs:" + k].copy_(t)
             else:
                 b["obs:" + k] = t
+        if row_index is not None:
+            assert row_index.dtype == th.int64 and row_index.is_contiguous() and adv.numel() == M
+            loss_cfg.row_index = row_index.data_ptr()
+            loss_cfg.obs_copy0 = _ptr(b["obs:" + self.obs_keys[0]])
+            loss_cfg.obs_copy1 = _ptr(b["obs:" + self.obs_keys[1]]) if len(self.obs_keys) > 1 else None
         self._last_M, self._last_slot = M, 0
         key = (M, 0, True)
         d = self._descs.get(key)
@@ -650,7 +668,7 @@ class MlpPolicy:
         bd, firsts = cached
         for i, src in firsts:
             bd.layer[i].X = _ptr(b[src])
-        ins = [_ptr(b["obs:" + k]) for k in self.obs_keys] + [None] * (2 - len(self.obs_keys))
+        ins = [_ptr(whole[k] if row_index is not None else b["obs:" + k]) for k in self.obs_keys] + [None] * (2 - len(self.obs_keys))
         self._pack()
         # want_sumsq: the loss-statistic rows are folded by the weight-gradient fold launch (one launch less)
         rc = L.vf_ppo_update(C.byref(d), C.byref(bd), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], _ptr(self.log_std),
@@ -894,6 +912,7 @@ class PPO:
         self.num_timesteps = 0
         self._last_starts = th.ones(self.n_envs, device=dev)
         self._shuf = None
+        self.index_minibatches = False     # True: train() reads its minibatches through the permutation slice (vf_ppo_loss_cfg.row_index) instead of a shuffled copy -- measured 2 % slower, see train()
         self.logs: Dict[str, float] = {}
 
     def _stream(self):
@@ -1034,6 +1053,7 @@ class PPO:
         Returns the loss statistics of the (global) minibatch, or None when target_kl stopped the update BEFORE the
         optimiser step (PPO.py:269-282)."""
         L, st, pol = _lib.lib(), self._stream(), self.policy
+        rows = mb.get("rows")        # indexed minibatch: the fields are the whole rollout buffer, `rows` the minibatch's row indices
         obs = {k: mb["obs:" + k] for k in self.obs_keys}
         actions, old_lp, adv, ret = mb["actions"], mb["old_lp"], mb["adv"], mb["ret"]
         B = adv.numel()
@@ -1046,8 +1066,14 @@ class PPO:
                               _ptr(mb["old_v"]) if vclip else None, float(self.clip_range_vf) if vclip else 0.0, 0)
         # reference-default policy shapes: forward + loss + reverse chain are one launch (vf_ppo_update)
         # single GPU: the weight-gradient fold also leaves the squared gradient norm as partial sums, which Adam adds up itself
-        res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch, want_sumsq=self.world == 1)
+        res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch, want_sumsq=self.world == 1, row_index=rows)
         sq = res if isinstance(res, tuple) else None
+        if res is False and rows is not None:       # no fused step for this network: materialise the minibatch (what the gather did)
+            obs = {k: v.index_select(0, rows) for k, v in obs.items()}
+            actions, old_lp, ret = actions.index_select(0, rows), old_lp.index_select(0, rows), ret.index_select(0, rows)
+            if vclip:
+                cfg.old_value = _ptr(mb["old_v"].index_select(0, rows))
+            cfg.row_index, cfg.obs_copy0, cfg.obs_copy1 = None, None, None
         if res is False:
             mean, value = pol.forward(obs)
             d_mean, d_value = th.empty((B, 4), device=self.device), th.empty(B, device=self.device)
@@ -1106,10 +1132,21 @@ class PPO:
                 perm = th.randperm(total, device=self.device, generator=g)
             # (preparing epoch e + 1's copy on a side stream under epoch e's optimiser steps gains nothing: the gather takes the HBM
             # bandwidth the weight-gradient kernel runs on -- profiles/r05_side_streams.txt, tools/exp_ppo_prefetch.py)
-            shuf = self._prepare_epoch(flat, perm, bs)
+            # r05 (ABI 9), `index_minibatches`: the fused step can read its minibatch through the permutation slice
+            # (vf_ppo_loss_cfg.row_index), like SB3's RolloutBuffer.get indexes the buffer -- only the advantages are gathered then.
+            # Bit-identical, and SLOWER: 145.3 vs 142.5 ms per train() of 1280 steps (tools/exp_ppo_indexed.py) -- the 1.14 ms-per-epoch
+            # streaming gather (5.7 ms) is replaced by 25 600 random 100-byte rows behind a dependent index load at the head of every
+            # fused launch, +6.6 us of a lone wave's latency each (8.5 ms).  Off by default; the shuffled copy stays
+            pol = self.policy
+            indexed = (self.index_minibatches and pol._fused_ppo is not False and pol._plan is not None and pol.fused and pol.fused_backward)
+            shuf = self._prepare_epoch({"adv": flat["adv"]} if indexed else flat, perm, bs)
             for s in range(0, total, bs):
                 e = min(s + bs, total)
-                st = self._minibatch_update({k: v[s:e] for k, v in shuf.items()}, stats_acc)
+                if indexed:
+                    mb = dict(flat, adv=shuf["adv"][s:e], rows=perm[s:e])
+                else:
+                    mb = {k: v[s:e] for k, v in shuf.items()}
+                st = self._minibatch_update(mb, stats_acc)
                 rows_epoch[_epoch] += e - s
                 if st is None:
                     stop = True
