@@ -365,6 +365,16 @@ int vf_env_finish_step(vf_env* h, const float* ext_collision_point, const uint8_
 
 int vf_env_query(vf_env* h, const vf_env_view* view, vf_stream_t stream);
 
+/* RacingEnv2's observation (envs/RacingEnv.py:218-267) from the step kernel's raw state rows: state (N, 3 n_next + 10) =
+ * [(gates[(g + k) % n_gates] - p) / radius for k < n_next, q, v / 10, w / 10], gate_out (N,) = g (may be NULL).  Which index g the
+ * rows that step() RETURNS use depends on the whole batch (droneGymEnv.py:161-166,347: the observation is refreshed before the gate of
+ * an agent that just passed one advances -- unless some agent ended its episode in the step, which rebuilds every observation with the
+ * advanced gates): mode 0: g = gate[i]; 1: g = gate_prev[i] (the index at the start of the step); 2: gate[i] if *done_count > 0
+ * (vf_env_out.done_count of the step just launched on the same stream) else gate_prev[i].  gates: HOST array (n_gates, 3). */
+int vf_race_obs(const float* raw, const int32_t* gate, const int32_t* gate_prev, const int32_t* done_count, int32_t mode,
+                const float* gates, int32_t n_gates, int32_t n_next, float radius, float* state, int32_t* gate_out, int32_t N,
+                vf_stream_t stream);
+
 /* mean device microseconds per vf_env_step launch over `iters` back-to-back launches (HIP events) */
 int vf_env_time_steps(vf_env* h, const float* action, const vf_env_out* out, int32_t auto_reset, int32_t iters,
                       vf_stream_t stream, float* mean_us);

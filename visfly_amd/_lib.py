@@ -265,6 +265,7 @@ SIGNATURES = {
     "vf_bptt_accumulate_checkpoint": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_int32, _vp, _vp, C.c_int64, _vp]),
     "vf_mlp_packed_floats": (C.c_int64, [C.POINTER(MlpDesc)]),
     "vf_mlp_pack_weights": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp]),
+    "vf_race_obs": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_float, _vp, _vp, C.c_int32, _vp]),
     "vf_chain_plugin_load": (C.c_int, [C.c_char_p]),
     "vf_chain_plugin_count": (C.c_int, []),
     "vf_chain_plugin_name": (C.c_char_p, [C.c_int32]),

@@ -4,12 +4,14 @@ Constructor kwargs follow the reference (envs/HoverEnv.py:15-30, envs/Navigation
 envs/RacingEnv.py:17-31); observation / reward / success definitions live in the fused kernel
 (visfly_amd/csrc/vf_env_device.hpp) and are listed next to each class.
 """
+import ctypes as C
 from typing import Optional
 
 import numpy as np
 import torch as th
 
 from . import spaces
+from .. import _lib
 from ..type import TensorDict
 from .base import HOVER, NAV, RACING, DroneGymEnvsBase
 
@@ -196,8 +198,9 @@ class RacingEnv(DroneGymEnvsBase):
 class RacingEnv2(RacingEnv):
     """RacingEnv with the gate-relative observation (envs/RacingEnv.py:218-267): "state" = [(next `_next_target_num` gates -
     p) / max_sense_radius (6), q (4), v / 10 (3), w / 10 (3)] = 16 columns, "gate" = next-gate index as (N,1).  Dynamics, reward,
-    gate bookkeeping and re-spawn are RacingEnv's (the step kernel); the observation is assembled from the kernel's raw state rows
-    with the reference's own torch expressions, one small launch sequence per step (NEXT tier; step_n() is refused).
+    gate bookkeeping and re-spawn are RacingEnv's (the step kernel); the observation rows are formed from the kernel's raw state rows
+    by ONE launch behind it (vf_race_obs, csrc/vf_obs.hip; the reference's torch expressions remain as the host path for single
+    terminal rows) (NEXT tier; step_n() is refused).
     requires_grad=True (r05): the observation is linear in the raw state row for a given gate index (which carries no gradient), so
     its adjoint is four column operations in front of the step kernel's adjoint (``backward_step``); pinned by the gradient fixture
     ``bptt_racing2_thrust`` (the reference's autograd over its own RacingEnv2.get_observation).  The trainers' persistent launches
@@ -209,8 +212,44 @@ class RacingEnv2(RacingEnv):
         self.max_sense_radius = 10                                                     # droneGymEnv.py:69
         g = kw.get("gates")
         self.targets = th.as_tensor(_RACING_GATES if g is None else g, dtype=th.float32, device=self.device)
+        self._gates_host = (C.c_float * (3 * len(self.targets)))(*[float(x) for x in self.targets.cpu().reshape(-1).tolist()])
+        self._gate_prev = th.zeros_like(self._gate)
+        self.enable_done_list()        # vf_race_obs reads the step's done count (which gate index the returned rows use)
+
+    def _race_rows(self, raw, gate, gate_prev=None, mode=0, gate_out=None):
+        """vf_race_obs: the observation rows in one launch -> (N, 16) tensor (mode: include/visfly_amd.h)"""
+        N = raw.shape[0]
+        out = th.empty((N, 3 * self._next_target_num + 10), dtype=th.float32, device=raw.device)
+        dl = getattr(self, "_done_list", None)
+        with th.cuda.device(raw.device):
+            _lib.check(_lib.lib().vf_race_obs(raw.data_ptr(), gate.data_ptr(), None if gate_prev is None else gate_prev.data_ptr(),
+                                              None if dl is None else dl[1].data_ptr(), mode, self._gates_host, len(self.targets),
+                                              self._next_target_num, float(self.max_sense_radius), out.data_ptr(),
+                                              None if gate_out is None else gate_out.data_ptr(), N, self._stream()))
+        return out
+
+    def _step_no_grad(self, _action, is_test=False, **kw):
+        """RacingEnv's step with the returned rows formed by ONE launch behind the step kernel (vf_race_obs picks the gate index by
+        RacingEnv's rule from the step's done count) instead of a clone, an any(), a where() and the dozen launches of _race_state"""
+        if not self.obs_gate_exact or not self.tensor_output:
+            return super()._step_no_grad(_action, is_test=is_test, **kw)
+        self._g_obs = None
+        self._gate_prev.copy_(self._gate)
+        self._defer_rows = True                    # the base step's own _full_obs call only records the raw rows
+        try:
+            _, reward, done, info = super(RacingEnv, self)._step_no_grad(_action, is_test=is_test, **kw)
+        finally:
+            self._defer_rows = False
+        g = th.empty_like(self._gate)
+        state = self._race_rows(self._last_raw, self._gate, self._gate_prev, 1 if is_test else 2, g)
+        self._g_obs = g
+        self._observations = obs = TensorDict({"state": state, "gate": g.unsqueeze(1)})
+        return obs, reward, done, info
 
     def _race_state(self, raw, gate):
+        if (raw.is_cuda and raw.dtype == th.float32 and raw.dim() == 2 and raw.shape[1] == 13 and raw.is_contiguous() and raw.shape[0] > 1
+                and gate.dtype == th.int32 and gate.is_contiguous() and gate.shape[0] == raw.shape[0]):
+            return self._race_rows(raw, gate)
         idx = th.stack([gate + i for i in range(self._next_target_num)]).T % len(self.targets)    # RacingEnv.py:254
         rel = (self.targets[idx.long()] - raw[:, 0:3].unsqueeze(1)).reshape(raw.shape[0], -1)       # :255-256
         # divisors as device tensors: torch's GPU kernels turn `x / python_scalar` into x * (1 / scalar), one ulp off the CPU
@@ -229,6 +268,9 @@ class RacingEnv2(RacingEnv):
         return super().backward_step(t, d_obs, d_reward)
 
     def _full_obs(self, state, raw=False):          # RacingEnv's rules for WHICH gate index the returned rows use apply unchanged
+        if getattr(self, "_defer_rows", False):        # inside _step_no_grad: the rows are formed after the step kernel, from these
+            self._last_raw = state
+            return TensorDict({"state": state, "gate": self._gate.unsqueeze(1)})
         g = self._gate if self._g_obs is None else self._g_obs
         if state.shape[-1] == 16:      # already the observation rows (step() with requires_grad: the graph-attached copy of what
             return TensorDict({"state": state, "gate": g.unsqueeze(1).clone()})      # _step_no_grad built from the raw rows)
