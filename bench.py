@@ -197,7 +197,7 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
     flops = 6.0 * ppo.policy.log_std_off * rows          # log_std_off = number of weights + biases of the network
     tfs = flops / (us_upd * 1e-6) / 1e12
     roof = {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
-            "kernel": "optimiser step: k_ppo_update_chain + k_mlp_wgrad + fold + Adam", "us_per_update": us_upd,
+            "kernel": "optimiser step: k_ppo_update_split (k_ppo_update_chain above 32 768 rows) + k_mlp_wgrad + fold + Adam", "us_per_update": us_upd,
             "rows": rows, "note": "fp32 v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)"}
     exchange = exchange_block(ppo._gbuf, n_upd, el / iters, us_upd, world, dev)
     out = {"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
