@@ -40,6 +40,53 @@ def test_config2_rk4_drag_65536_bit_identical_to_oracle():
     assert_bits_equal(env.extend_state.cpu().numpy(), ref.dyn.extend_state, "extend_state after 6 steps")
 
 
+def test_config2_rk4_drag_65536_with_auto_resets_and_redraws():
+    """configs[2] at full size WITH episode ends (r05; the r04 verdict noted that the 6-step test above runs is_test=True): 40 steps
+    with max_episode_steps = 12, so every agent is re-spawned by the device (Philox) three times and its drag coefficients are re-drawn
+    each time.  Reward / done of every step and the observation of every agent that did not end are bit-identical to the oracle; for the
+    agents that ended, the oracle is handed the state and the coefficients the device drew (the draw itself cannot be pinned: the
+    reference's drag_random raises on indexed resets) -- it is property-checked: inside nominal x (1 +- 0.1), and new --
+    and everything after the re-spawn is compared bit for bit again"""
+    import oracle
+    from visfly_amd.envs import NavigationEnv
+    N, T = 65536, 12
+    dkw = dict(DYN, integrator="rk4", drag_random=0.1)
+    env = NavigationEnv(num_agent_per_scene=N, seed=23, dynamics_kwargs=dkw, random_kwargs=NAV_SPAWN, device="cuda:0",
+                        max_episode_steps=T, tensor_output=True)
+    env.reset()
+    dyn = env.envs.dynamics
+    kl, kq = (x.cpu().numpy() for x in dyn.drag_coefficients)
+    nominal_l, nominal_q = np.asarray(dyn.constants["k_lin"], np.float32), np.asarray(dyn.constants["k_quad"], np.float32)
+    ref = oracle.OracleEnv(dyn.constants, N, "nav", T, target=[9., 0., 1.])
+    ref.dyn.klin, ref.dyn.kquad = np.ascontiguousarray(kl.T), np.ascontiguousarray(kq.T)
+    ref.reset_full_state(env.full_state.cpu().numpy())
+    g = torch.Generator().manual_seed(5)
+    ended = 0
+    for k in range(40):
+        a = ((torch.rand((N, 4), generator=g) * 2 - 1) * 0.6 + torch.tensor([-0.3, 0, 0, 0])).clamp(-1, 1)
+        o, r, d, _ = env.step(a.cuda())
+        ro, rr, rd = ref.step(a.numpy())
+        dn = d.cpu().numpy().astype(bool)
+        assert_bits_equal(r.cpu().numpy(), rr, f"reward @ {k}")
+        assert np.array_equal(dn.astype(np.uint8), rd), f"done @ {k}"
+        assert_bits_equal(o["state"].cpu().numpy()[~dn], ro[~dn], f"state of the agents that go on @ {k}")
+        idx = np.nonzero(dn)[0]
+        if len(idx):
+            ended += len(idx)
+            fs = env.full_state.cpu().numpy()
+            kl2, kq2 = (x.cpu().numpy() for x in dyn.drag_coefficients)
+            assert np.array_equal(kl2[~dn], kl[~dn]) and np.array_equal(kq2[~dn], kq[~dn]), "only re-spawned agents get new coefficients"
+            for new, old, nom in ((kl2, kl, nominal_l), (kq2, kq, nominal_q)):
+                assert np.all(np.abs(new[idx] - nom) <= 0.1 * np.abs(nom) * (1 + 1e-6)), "draw inside nominal x (1 +- drag_random)"
+                assert np.mean(np.any(new[idx] != old[idx], axis=1)) > 0.99, "re-drawn"
+            kl, kq = kl2, kq2
+            ref.dyn.klin[:, idx], ref.dyn.kquad[:, idx] = kl[idx].T, kq[idx].T
+            ref.reset_agents(idx, fs[idx])
+            assert_bits_equal(o["state"].cpu().numpy()[dn], fs[idx][:, :13], f"returned rows of re-spawned agents = their new state @ {k}")
+    assert ended >= 3 * N, "every agent went through three episode ends"
+    assert_bits_equal(env.extend_state.cpu().numpy(), ref.dyn.extend_state, "extend_state after 40 steps with re-spawns")
+
+
 def _ppo_iteration(seed):
     from visfly_amd.envs import NavigationEnv
     from visfly_amd.ppo import PPO
