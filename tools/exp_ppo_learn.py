@@ -8,7 +8,14 @@ N = 8192
 spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0.5, 1., 0.5]}}]}}
 env = NavigationEnv(num_agent_per_scene=N, seed=1, dynamics_kwargs=dict(action_type="bodyrate", integrator="euler", dt=0.0025,
                     ctrl_dt=0.02, ctrl_delay=True), random_kwargs=spawn, device="cuda:0", max_episode_steps=128, target=[4., 0., 1.5])
-ppo = PPO(env, n_steps=128, batch_size=25600, n_epochs=5, learning_rate=3e-4, seed=0)
+# third argument "pi=128,128:vf=32": a net_arch without a built-in chain class (compiled on first use, visfly_amd/_jit.py)
+kw = {}
+if len(sys.argv) > 2:
+    arch = {k: [int(x) for x in v.split(",")] for k, v in (p.split("=") for p in sys.argv[2].split(":"))}
+    kw = dict(policy_kwargs=dict(features_extractor_class="StateTargetExtractor", activation_fn="ReLU", net_arch=arch,
+                                 features_extractor_kwargs=dict(net_arch=dict(state=dict(layer=[128, 64]), target=dict(layer=[128, 64])))))
+ppo = PPO(env, n_steps=128, batch_size=25600, n_epochs=5, learning_rate=3e-4, seed=0, **kw)
+print("policy:", ppo.policy.spec, "generated chain class" if ppo.policy.chain_jit else "built-in chain class")
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     ppo.learn(128 * N)
     l = ppo.logs

@@ -168,6 +168,11 @@ jit)      # chain kernels compiled on first use for any net_
     timeout 1200 python -m pytest tests/test_chain_jit_gpu.py -x -q 2>&1 | tail -5 | tee $O/pytest.txt
     timeout 900 python tools/exp_chain_jit.py 2>&1 | grep -v amdgpu.ids | tee $O/table.txt
     ;;
+functional) # end of the round: soak of the step kernels, PPO learning curve (built-in class) and on a generated class
+    timeout 1500 python tools/soak_envs.py 50000 2>&1 | grep -v amdgpu.ids | tee $O/soak.txt
+    timeout 900 python tools/exp_ppo_learn.py 40 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve.txt
+    timeout 900 python tools/exp_ppo_learn.py 40 pi=128,128:vf=32 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve_generated.txt
+    ;;
 avail)    # counter names this rocprofv3 knows on gfx950
     (cd /tmp && rocprofv3 --list-avail > $O/avail.txt 2>&1); grep -c . $O/avail.txt
     ;;
