@@ -219,8 +219,9 @@ def test_ppo_trains_a_non_default_net_arch_on_chain_kernels(monkeypatch):
         tile = [x for x in w if "block-tile" in str(x.message)]
         if jit:
             assert not tile, [str(x.message) for x in tile]
-            # 2 iterations x (16 rollout forwards + 2 epochs x 4 fused minibatch steps)
-            assert lib.vf_chain_plugin_launches() - n0 >= 2 * (16 + 8)
+            # 2 iterations x (the roll-out as ONE launch of the class's roll-out plugin + 2 epochs x 4 fused minibatch steps)
+            assert lib.vf_chain_plugin_launches() - n0 >= 2 * (1 + 8)
+            assert not [x for x in w if "vf_ppo_rollout" in str(x.message)], "no launch-by-launch fallback of the roll-out either"
         else:
             assert tile and lib.vf_chain_plugin_launches() == n0
         flats.append(ppo.policy.flat.clone())

@@ -822,6 +822,27 @@ def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
                                             ("HoverEnv", 1000, "euler_nodelay"), ("NavigationEnv", 16500, "rk4_nodelay"),
                                             ("HoverEnv2", 3000, "euler"), ("NavigationEnv2", 3000, "euler"), ("NavigationEnv2", 16500, "rk4")])
 def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
+    _persistent_rollout_vs_loop(env_name, N, dyn)
+
+
+@pytest.mark.parametrize("env_name,N,dyn,net", [("NavigationEnv", 3000, "euler", "verdict"), ("HoverEnv", 16401, "rk4_nodelay", "one_layer_extractor")])
+def test_persistent_rollout_of_a_generated_class_equals_the_per_step_loop(env_name, N, dyn, net):
+    """r05: a network shape without a built-in chain class gets its roll-out launch as one more plugin, compiled on first use for the env
+    kind / action type / integrator / motor-lag setting (visfly_amd/_jit.py: ensure_rollout; csrc/vf_ppo_rollout_kernel.hpp) -- the same
+    bit-for-bit comparison with the launch-by-launch loop as for the built-in classes, and no fallback warning"""
+    import warnings
+    from visfly_amd import _jit, _lib
+    _, ext, pi, vf = _jit.PREBUILD[net]
+    pk = dict(features_extractor_class="StateTargetExtractor" if "target" in ext else "StateExtractor", activation_fn="ReLU",
+              features_extractor_kwargs=dict(net_arch={k: dict(layer=v) for k, v in ext.items()}), net_arch=dict(pi=pi, vf=vf))
+    n0 = _lib.lib().vf_chain_plugin_launches()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _persistent_rollout_vs_loop(env_name, N, dyn, policy_kwargs=pk)
+    assert _lib.lib().vf_chain_plugin_launches() > n0
+
+
+def _persistent_rollout_vs_loop(env_name, N, dyn, policy_kwargs=None):
     """collect_rollouts as ONE launch (vf_ppo_rollout: 16 / 32 agents per wave for all n_steps, the same rows-per-wave chain
     vf_mlp_forward picks for N rows) leaves the rollout buffer, the TimeLimit list, the episode statistics, the episode
     outputs and the slab of the launch-by-launch loop, bit for bit -- over two consecutive rollouts with a training pass
@@ -845,7 +866,8 @@ def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
         # r05: the *2 variants (relative-position observation rows, NavigationEnv2's reward) run on the persistent launch too
         env = getattr(E, env_name)(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(dkw), device=DEV, max_episode_steps=7,
                                    tensor_output=True, **kw)
-        ppo = PPO(env, n_steps=20, batch_size=N * 20 // (4 if N < 16000 else 20), n_epochs=1, seed=2)
+        ppo = PPO(env, n_steps=20, batch_size=N * 20 // (4 if N < 16000 else 20), n_epochs=1, seed=2,
+                  **({"policy_kwargs": policy_kwargs} if policy_kwargs else {}))
         ppo.fused_rollout = fused
         out = {}
         for rnd in range(2):

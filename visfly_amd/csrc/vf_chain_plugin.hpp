@@ -24,6 +24,12 @@ struct ChainPlugin {
     // packed == null: capability query
     int (*backward)(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp);
     int (*ppo_update)(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowArgs* pr, int M, hipStream_t st);
+    // a ROLL-OUT plugin (one more shared object per shape AND env kind / action type / integrator / ctrl_delay: the persistent
+    // launch of vf_ppo_rollout.hip is a template over all of them) sets only this one; env_args / roll_args: vf::EnvArgs /
+    // vf::PpoRollArgs (vf_ppo_rollout_kernel.hpp; rollout_abi stamps their layout), c: the host copy of the dynamics constants
+    unsigned rollout_abi;
+    int (*ppo_rollout)(const vf_mlp_desc* d, int env_kind, const vf_dyn_cfg* c, int has_target, const vf_dyn_cfg* d_dyn, const vf_env_cfg* d_env,
+                       const void* env_args, const ChainArgs* gc, const void* roll_args, int N, hipStream_t st);
 };
 
 // the registry (vf_chain_plugin.hip)
@@ -113,11 +119,14 @@ const vf::ChainPlugin* vf_chain_plugin();
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
     extern "C" int vf_plugin_ppo_update(const vf::ChainArgs* g, const vf::BwdArgsChain* gb, const vf::PpoRowArgs* pr, int M, hipStream_t st) \
     { return vf::plugin_ppo_update<Net>(g, gb, pr, M, st); }
+#elif VF_CHAIN_PLUGIN_PART == 4
+// the roll-out plugin: one translation unit, one kernel instance (vf_ppo_rollout_kernel.hpp defines VF_CHAIN_PLUGIN_ROLLOUT_DEFINE)
+#define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)
 #else
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
     extern "C" const vf::ChainPlugin* vf_chain_plugin()                                                                                      \
     {                                                                                                                                        \
-        static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, vf_plugin_forward, vf_plugin_backward, vf_plugin_ppo_update};              \
+        static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, vf_plugin_forward, vf_plugin_backward, vf_plugin_ppo_update, 0u, nullptr}; \
         return &p;                                                                                                                           \
     }
 #endif

@@ -48,7 +48,8 @@ int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M,
     if (bwd_chain_matches<NetHover, true, true, false>(*d)) return launch ? bwd_chain_launch<NetHover, true, true, false>(*d, packed, M, st, rp) : 1;
     if (bwd_chain_matches<NetHover, true, false, true>(*d)) return launch ? bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st, rp) : 1;
     for (int i = 0; i < chain_plugin_count(); ++i)      // shapes compiled on first use (vf_mlp_chain_gen.hpp)
-        if (int rc = chain_plugin(i)->backward(d, launch ? packed : nullptr, M, st, rpp)) return plugin_rc(rc, "vf_mlp_backward_data");
+        if (chain_plugin(i)->backward)
+            if (int rc = chain_plugin(i)->backward(d, launch ? packed : nullptr, M, st, rpp)) return plugin_rc(rc, "vf_mlp_backward_data");
     if (!rpp) return mlp_backward_chain_try_sac(d, packed, M, st);       // the SAC-style Actor's classes (vf_mlp_chain_sac.hip)
     return 0;
 }
@@ -78,7 +79,8 @@ int ppo_update_chain_try(const vf_mlp_desc* d, const vf_mlp_bwd_desc* bd, const 
                     : (chain_matches<NetHover>(*d) && bwd_chain_matches<NetHover, true, true, false>(*bd)) ? 1 : 0;
     if (!which) {
         for (int i = 0; i < chain_plugin_count(); ++i)      // shapes compiled on first use (vf_mlp_chain_gen.hpp)
-            if (int rc = chain_plugin(i)->ppo_update(&g, &gb, &pr, M, st)) return plugin_rc(rc, "vf_ppo_update");
+            if (chain_plugin(i)->ppo_update)
+                if (int rc = chain_plugin(i)->ppo_update(&g, &gb, &pr, M, st)) return plugin_rc(rc, "vf_ppo_update");
         return 0;
     }
     // two waves per row tile, each walking half of the network (vf_mlp_chain_split.hip); 0: switched off -> the one-wave kernel
@@ -108,7 +110,8 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp, nullptr, M_choice);
     if (!in2)
         for (int i = 0; i < chain_plugin_count(); ++i)      // shapes compiled on first use (vf_mlp_chain_gen.hpp); 32 rows per wave at every M
-            if (int rc = chain_plugin(i)->forward(d, params, packed, in0, in1, out0, out1, M, st, rpp)) return plugin_rc(rc, "vf_mlp_forward");
+            if (chain_plugin(i)->forward)
+                if (int rc = chain_plugin(i)->forward(d, params, packed, in0, in1, out0, out1, M, st, rpp)) return plugin_rc(rc, "vf_mlp_forward");
     if (!rpp) return mlp_forward_chain_try_sac(d, params, packed, in0, in1, in2, out0, out1, M, st, M_choice);    // SAC-style Actor / twin critic (vf_mlp_chain_sac.hip)
     return 0;
 }

@@ -13,197 +13,8 @@
 //     them by ds_bpermute), the sampled action feeds the env step in registers, the reward / done of the epilogue feed the buffer
 //     rows and the TimeLimit list, and the next forward reads its "state" row from the LDS tile the epilogue staged it through
 //     on its way to RolloutBuffer.obs["state"][t + 1].  Global memory sees only the buffer rows, written once, never re-read.
-#include "vf_env_epilogue.hpp"
-#include "vf_mlp_chain.hpp"
-
-#pragma clang fp contract(off)
-
-namespace vf {
-
-#ifdef VF_PPO_TRACE
-__device__ long long vf_ppo_trace[8];
-#endif
-
-struct PpoRollArgs {
-    int T, N;
-    float4* actions;                // [T][N]
-    float* log_probs;               // [T][N]
-    float* rewards;                 // [T][N]
-    float* episode_starts;          // [T][N]; row 0 is filled by the caller
-    float* last_starts;             // (N,): episode_starts of the step after the last one
-    float* obs_slots;               // [T][N][13] = RolloutBuffer.obs["state"]
-    float* obs_final;               // (N,13)
-    const float* log_std;
-    unsigned long long noise_key, sample_step;      // step t samples with Philox counter sample_step + 1 + t (k_head_sample)
-    // deferred TimeLimit bootstrap list + per-agent episode statistics (k_rollout_post_collect)
-    const float* obs1;              // (N,w1) constant "target" rows or null
-    int w1, capacity;
-    int* cursor;
-    int* idx_list;
-    float* rows0;                   // [capacity][13]
-    float* rows1;                   // [capacity][w1]
-    float* stat;                    // (N,4)
-};
-
-// one forward of rows `row` (lane & (ROWS - 1) of the wave): value -> g.io.value; -> the mean row, valid in the lanes < ROWS
-// (the accumulator lanes of group 0 hold heads of their own row: chain_epilogue / chain16_epilogue).  The "state" row comes from
-// the wave's LDS tile (13 floats per agent, where the env epilogue of the previous step left it), other branches from memory.
-template <class Net, int ROWS>
-__device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int row, const float* tile)
-{
-    const int m = lane & (ROWS - 1);
-    if constexpr (ROWS == 16) {
-        const int gq = lane >> 4;
-        ChainState16<Net> st;
-        chain16_prologue<Net, 0>(gc, st, lane);
-#pragma unroll
-        for (int b = 0; b < Net::NB; ++b) {
-            const int w = gc.d.in_dim[b];
-            const float* x = b == 0 ? tile + m * 13 : gc.io.in[b] + (size_t)row * w;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 4 * gq + j;
-                const float v = x[k < w ? k : w - 1];
-                st.x[b][j] = k < w ? v : 0.0f;
-            }
-        }
-        chain16_items<Net, 0, false>(gc, st, lane, row, true, row);
-        const f32x4& y = st.t[2 * Net::t_mean];
-        return make_float4(y[0], y[1], y[2], y[3]);
-    } else {
-        const int h = lane >> 5;
-        ChainState<Net> st;
-        chain_prologue<Net, 0>(gc, st, lane);
-#pragma unroll
-        for (int b = 0; b < Net::NB; ++b) {
-            const int w = gc.d.in_dim[b];
-            const float* x = b == 0 ? tile + m * 13 : gc.io.in[b] + (size_t)row * w;
-#pragma unroll
-            for (int s = 0; s < Net::kin(b) / 2; ++s) {
-                const int k = 2 * s + h;
-                const float v = x[k < w ? k : w - 1];
-                st.x[b][s] = k < w ? v : 0.0f;
-            }
-        }
-        chain_items<Net, 0, false>(gc, st, lane, row, true, row);
-        const f32x16& y = st.t[Net::t_mean];
-        return make_float4(y[0], y[1], y[2], y[3]);
-    }
-}
-
-template <class Net, int ROWS, int KIND, int ACT, int INTEG, bool CTRL_DELAY>
-__global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict__ cp, const vf_env_cfg* __restrict__ ep, const EnvArgs ge,
-                                                    const ChainArgs gc, const PpoRollArgs r)
-{
-    prefetch_kernarg<sizeof(EnvArgs) + sizeof(ChainArgs) + sizeof(PpoRollArgs) + 16>();
-    const vf_dyn_cfg& c = *cp;
-    const vf_env_cfg& e = *ep;
-    __shared__ __attribute__((aligned(16))) float tile[64 * 13];
-    const int lane = threadIdx.x, m = lane & (ROWS - 1);
-    const int wave_first = blockIdx.x * ROWS;
-    // lanes ROWS..63 and the lanes past the last agent are REPLICAS of a live lane (same index, loads, arithmetic, stores of the
-    // same values); what must happen once per agent -- the read-modify-write of the statistics, the list append -- is the owner's
-    const int i = min(wave_first + m, r.N - 1);
-    const bool owner = lane < ROWS && wave_first + lane < r.N;
-    EnvArgs g = ge;
-    g.d.N = min(r.N, wave_first + ROWS);                  // the wave's observation tile holds ROWS rows
-    Agent s;
-    Spares sp;
-    load_agent<true>(g.d.S, g.d.G, i, s, sp);
-    load_wind(c, g.d, i, true, s);
-    const int Gx = g.d.G;
-    // the wave's observation tile: row l = the "state" observation of lane l's agent.  The env epilogue of step t leaves the rows
-    // of step t + 1 there (store_rows_coalesced stages them through it on their way to RolloutBuffer.obs[t + 1]); step 0's come
-    // from the caller's row 0.  One wave's LDS operations execute in order: no barrier.
-    for (int k = 0; k < 13; ++k) tile[lane * 13 + k] = r.obs_slots[(size_t)i * 13 + k];
-    __builtin_amdgcn_wave_barrier();
-#ifdef VF_PPO_TRACE
-    long long tr[5] = {0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
-#define VF_PT(k) do { const long long n_ = __builtin_readcyclecounter(); tr[k] += n_ - tc; tc = n_; } while (0)
-#else
-#define VF_PT(k) do { } while (0)
-#endif
-    for (int t = 0; t < r.T; ++t) {
-        const int row = t * r.N + i;
-        // the chain's per-item load offsets (lane * 16 + item * 1 KiB) are loop-invariant: hoisted out of the t loop they are
-        // ~100 live VGPRs and 1.1 KB of scratch per lane.  An opaque copy of the lane id per iteration keeps them just-in-time
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        // the delay-ring slot this step swaps its action with: address known now, value needed right after the sampler -- loaded
-        // ahead of the forward (by every lane, from a valid granule when there is no ring: a load under `if` would be waited for
-        // on the spot, see load_spawn_slot)
-        const float4 ring_old = *granule(g.d.S, Gx, i, c.delay_steps > 0 ? VF_G_RING + g.d.head : 0);
-        // ... and an opaque zero in the weight pointers: the ~170 per-item base addresses (SGPR pairs) are loop-invariant as
-        // well, hoisted they are spilled to VGPR lanes and cost two v_readlane per item
-        long zero_t = 0;
-        asm volatile("" : "+s"(zero_t));
-        ChainArgs gct = gc;
-        gct.packed = gc.packed + zero_t;
-        gct.params = gc.params + zero_t;
-        float4 mean = policy_rows<Net, ROWS>(gct, lane_t, row, tile);
-        // lane m < ROWS holds the head of its own agent; the replica lanes take it from there
-        mean.x = __shfl(mean.x, m); mean.y = __shfl(mean.y, m); mean.z = __shfl(mean.z, m); mean.w = __shfl(mean.w, m);
-        VF_PT(0);
-        float4 act;
-        const float lp = head_sample_row(mean, r.log_std, i, r.noise_key, r.sample_step + 1ull + (unsigned long long)t, 0, act);
-        r.actions[row] = act;
-        r.log_probs[row] = lp;
-        // ---- env step (k_env_rollout's body; ring_exchange with the action already in registers) ----
-        float a[4];
-        {
-            float4 an = act;
-            if (c.delay_steps > 0) {
-                const int head = g.d.head;
-                st4(granule(g.d.S, Gx, i, VF_G_RING + head), an);
-                an = ring_old;
-                sp.vel = __int_as_float(head + 1 == c.delay_steps ? 0 : head + 1);
-            }
-            a[0] = an.x; a[1] = an.y; a[2] = an.z; a[3] = an.w;
-        }
-        float kl[3], kq[3];
-        drag_of(c, g.d, i, kl, kq);
-        VF_PT(1);
-        control_interval<ACT, INTEG, CTRL_DELAY>(c, s, a, kl, kq, g.d.vstrided != 0);
-        VF_PT(2);
-        float reward = 0.0f;
-        bool done = false;
-        env_epilogue<KIND, false>(c, e, g, i, true, s, sp, wave_first, tile, &reward, &done);
-        VF_PT(3);
-        // ---- RolloutBuffer.add + the TimeLimit bookkeeping (k_rollout_post_collect) ----
-        r.rewards[row] = reward;
-        (t + 1 < r.T ? r.episode_starts + (size_t)(t + 1) * r.N : r.last_starts)[i] = done ? 1.0f : 0.0f;
-        if (done && owner) {
-            // ep_return / ep_length / ep_flags / terminal row: this lane's own stores of the epilogue
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            const unsigned char fl = g.out.ep_flags[i];
-            float4* sa = reinterpret_cast<float4*>(r.stat) + i;
-            float4 v = *sa;
-            v.x += 1.0f;
-            v.y += g.out.ep_return[i];
-            v.z += (float)g.out.ep_length[i];
-            v.w += (fl & VF_EP_SUCCESS) ? 1.0f : 0.0f;
-            *sa = v;
-            if (fl & VF_EP_TRUNCATED) {
-                const int slot = atomicAdd(r.cursor, 1);
-                if (slot < r.capacity) {
-                    r.idx_list[slot] = row;
-                    const float* to = g.out.terminal_obs + 13 * (size_t)i;
-                    for (int k = 0; k < 13; ++k) r.rows0[(size_t)slot * 13 + k] = to[k];
-                    for (int k = 0; k < r.w1; ++k) r.rows1[(size_t)slot * r.w1 + k] = r.obs1[(size_t)i * r.w1 + k];
-                }
-            }
-        }
-        g.out.obs = t + 2 < r.T ? r.obs_slots + (size_t)(t + 2) * r.N * 13 : r.obs_final;
-        g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
-        VF_PT(4);
-    }
-    store_agent(g.d.S, Gx, i, s, sp);
-#ifdef VF_PPO_TRACE
-    if (blockIdx.x == 7 && lane == 0) for (int k = 0; k < 5; ++k) vf_ppo_trace[k] = tr[k];
-#endif
-}
-
-}  // namespace vf
+#include "vf_chain_plugin.hpp"
+#include "vf_ppo_rollout_kernel.hpp"
 
 namespace {
 
@@ -260,8 +71,6 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
         k = r16 ? pick_ppo_roll<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_ppo_roll<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg);
     else if ((cls & 15) == 1 && h->cfg.kind == VF_ENV_NAV && !a->obs_target)      // NavigationEnv2: the target is inside the "state" row
         k = r16 ? pick_ppo_roll<vf::NetHover, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_ppo_roll<vf::NetHover, 32, VF_ENV_NAV>(h->dyn.cfg);
-    if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: no persistent roll-out for this network class / env kind / dynamics "
-                                             "configuration ([128, 64] x [64, 64] actor-critic, Hover / Navigation, thrust / bodyrate, Euler / RK4)");
     const int rows = r16 ? 16 : 32;
     vf::EnvArgs ge{vf::DynArgs{N, h->dyn.G, h->dyn.g_drag, h->dyn.S, nullptr, nullptr, vf::ring_head(&h->dyn), nullptr, h->dyn.vel_strided},
                    *out, h->g_race, 1};
@@ -272,8 +81,25 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
     vf::PpoRollArgs r{T, N, reinterpret_cast<float4*>(a->actions), a->log_probs, a->rewards, a->episode_starts, a->last_starts,
                       a->obs_state, a->obs_final, a->log_std, a->noise_key, a->sample_step, a->obs_target_row, a->w1, a->capacity, a->cursor,
                       a->idx_list, a->rows0, a->rows1, a->stat};
-    hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
-    VF_HIP(hipGetLastError());
+    if (k) {
+        hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
+        VF_HIP(hipGetLastError());
+    } else {
+        // a generated class: its roll-out plugin, compiled on first use for this env kind / dynamics configuration (visfly_amd/_jit.py)
+        int rc = 0;
+        for (int i = 0; i < vf::chain_plugin_count() && rc == 0; ++i) {
+            const vf::ChainPlugin* p = vf::chain_plugin(i);
+            if (p->ppo_rollout && p->rollout_abi == vf::kRolloutPluginAbi)
+                rc = p->ppo_rollout(desc, h->cfg.kind, &h->dyn.cfg, a->obs_target != nullptr, h->dyn.d_cfg, h->d_cfg, &ge, &gc, &r, N,
+                                    vf::as_stream(stream));
+        }
+        if (rc <= -1000) return vf::fail(VF_EHIP, "vf_ppo_rollout (chain plugin) failed: %s", hipGetErrorString((hipError_t)(-rc - 1000)));
+        if (rc == 0)
+            return vf::fail(VF_EUNSUPPORTED, "vf_ppo_rollout: no persistent roll-out for this network class / env kind / dynamics "
+                                             "configuration (built in: [128, 64] x [64, 64] actor-critic, Hover / Navigation, thrust / bodyrate, "
+                                             "Euler / RK4; generated classes: through their roll-out plugin)");
+        vf::chain_plugin_count_launch();
+    }
     h->dyn.tick += T;
     h->stale_all = 1;       // agents re-spawned inside the launch: the prefetched copies' stale bits no longer cover them
     return VF_OK;

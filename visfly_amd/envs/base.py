@@ -951,6 +951,16 @@ class DroneGymEnvsBase:
         a.cursor, a.idx_list, a.rows0 = boot["cursor"].data_ptr(), boot["idx"].data_ptr(), _lib.ptr(boot["rows0"])
         a.rows1, a.stat = _lib.ptr(boot["rows1"]), _lib.ptr(boot["stat"])
         a.out = C.addressof(sc["out"])
+        if getattr(policy, "chain_jit", False):
+            # a generated chain class: its roll-out launch is one more plugin, per env kind / action type / integrator / motor lag
+            # (visfly_amd/_jit.py; ~15 s of hipcc on first use)
+            try:
+                from .. import _jit
+                c = self.envs.dynamics.constants
+                _jit.ensure_rollout(policy.chain_shape, (self.KIND, int(c["action_type"]), int(c["integrator"]), bool(c["ctrl_delay"])))
+            except Exception as e:          # no hipcc, ...: launch by launch, with the warning below
+                import warnings
+                warnings.warn(f"visfly_amd: no roll-out plugin for this network ({e})")
         with th.cuda.device(dev):
             rc = _lib.lib().vf_ppo_rollout(self._h, C.byref(d), _lib.ptr(policy.flat), _lib.ptr(policy._packed), C.byref(a), self._stream())
         if rc == _lib.EUNSUPPORTED:
