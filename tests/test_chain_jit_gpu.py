@@ -27,7 +27,11 @@ def test_shape_rules_and_generated_source():
     # what stays on the block-tile kernels: widths off the 32 grid or above 128, empty trunks, > 4 layers, SAC heads, pass-through inputs
     assert _jit.shape_of(dims, ext, [48], [32]) is None and _jit.shape_of(dims, ext, [160], [32]) is None
     assert _jit.shape_of(dims, ext, [], [32]) is None and _jit.shape_of(dims, ext, [32] * 5, [32]) is None
-    assert _jit.shape_of(dims, ext, pi, vf, head_dims=(4, 4)) is None and _jit.shape_of(dims, ext, pi, vf, passthrough=("action",)) is None
+    assert _jit.shape_of(dims, ext, pi, vf, head_dims=(1, 1)) is None and _jit.shape_of(dims, ext, pi, vf, passthrough=("action",)) is None
+    # the SAC-style Actor (two 4-wide heads): a class of its own, the default widths built in
+    assert _jit.shape_of(dims, ext, pi, vf, head_dims=(4, 4)) == sh + ((4, 4),) and "heads 4/4" in _jit.name_of(sh + ((4, 4),))
+    assert "static constexpr int HM = 4, HV = 4;" in _jit.source(sh + ((4, 4),)) and "static constexpr int HM = 4, HV = 1;" in _jit.source(sh)
+    assert _jit.is_builtin(_jit.shape_of(dims, ext, [64, 64], [64, 64], head_dims=(4, 4)))
     assert _jit.shape_of({"state": 40}, {"state": [64]}, [32], [32]) is None
     src = _jit.source(sh)
     assert "static constexpr int EW[2][4] = {{4, 2, 0, 0}, {4, 2, 0, 0}};" in src and "static constexpr int PW[4] = {4, 4, 0, 0};" in src
@@ -254,3 +258,87 @@ def test_saved_activations_of_cold_launches(name):
         for k, v in b0.items():
             assert (v - b1[k]).abs().max().item() <= 4e-6 * max(b1[k].abs().max().item(), 1e-3), (rep, k)
         del pol, b0, b1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 33, 777, 16384])
+@pytest.mark.parametrize("ig", [True, False])
+@pytest.mark.parametrize("name", ["sac_nav", "sac_hover"])
+def test_generated_sac_actor_vs_torch_and_block_tile_kernel(name, ig, M):
+    """the reference's SAC-style Actor (utils/policies/td_policies.py:146-252: latent_pi -> mu, log_latent_pi -> log_std, two 4-wide heads; the
+    actor of its BPTT and SHAC loops) on a NON-default shape: generated class, forward + reverse chain of both trunks with / without the
+    observation gradient against an fp64 torch network on the same weights and against the block-tile kernels
+    (test_sac_actor_chain_vs_torch_and_block_tile_kernel's checks for the built-in classes)"""
+    from visfly_amd import _jit, _lib
+    from visfly_amd.ppo import MlpPolicy
+    lib = _lib.lib()
+    dims, ext, pi, vf, heads = _jit.PREBUILD_SAC[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        pol = MlpPolicy(dims, ext, pi, vf, DEV, seed=9, ortho_init=False, head_dims=heads, log_std_param=False)
+    assert pol.chain_jit
+    g = torch.Generator(device=DEV).manual_seed(M + 5)
+    obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+    d_mu = torch.randn((M, 4), device=DEV, generator=g) / M
+    d_ls = torch.randn((M, 4), device=DEV, generator=g) / M
+    ref = pol.to_torch().double().to(DEV)
+    xs = {k: v.double().requires_grad_(ig) for k, v in obs.items()}
+    m0, v0 = ref(xs)
+    ((m0 * d_mu.double()).sum() + (v0 * d_ls.double()).sum()).backward()
+    gref = ref.flat_grad().to(DEV).float()
+    n0 = lib.vf_chain_plugin_launches()
+    mu, ls = pol.forward(obs)
+    assert lib.vf_chain_plugin_launches() == n0 + 1 and mu.shape == ls.shape == (M, 4)
+    sc = max(m0.abs().max().item(), v0.abs().max().item())
+    assert (mu - m0.float()).abs().max().item() <= 2e-6 * sc and (ls - v0.float()).abs().max().item() <= 2e-6 * sc
+    res = {}
+    for fused in (True, False, True):
+        pol.fused_backward = fused
+        pol.grad.fill_(0.0)
+        pol.forward(obs)
+        n1 = lib.vf_chain_plugin_launches()
+        d_in = pol.backward(d_mu, d_ls, None, need_input_grad=ig)
+        assert (lib.vf_chain_plugin_launches() > n1) == fused
+        if fused and fused in res:
+            assert torch.equal(res[True][0], pol.grad)
+        res[fused] = (pol.grad.clone(), {k: v.clone() for k, v in d_in.items()})
+    scale = gref.abs().max().item()
+    assert (res[True][0] - res[False][0]).abs().max().item() <= 5e-6 * scale
+    for fused in (True, False):
+        err = (res[fused][0] - gref).abs().max().item()
+        assert err <= (1e-3 if M >= 16384 else 2e-6) * scale, (fused, err, scale)      # (a ReLU unit within rounding of 0 may flip vs fp64)
+    for k in res[True][1]:
+        assert torch.allclose(res[True][1][k], res[False][1][k], rtol=1e-4, atol=1e-6 * res[False][1][k].abs().max().item())
+        want = xs[k].grad.float()
+        bad = ((res[True][1][k] - want).abs() > 1e-4 * want.abs() + 1e-5 * want.abs().max()).any(dim=1)
+        assert int(bad.sum()) <= (8 if M >= 16384 else 0), (k, int(bad.sum()))
+
+
+@pytest.mark.gpu
+def test_bptt_with_the_reference_actor_on_a_non_default_shape_runs_on_chain_kernels():
+    """BPTT(policy="MultiInputPolicy") -- the reference's own actor -- with a non-default `net_arch`: the per-step forward / reverse chains
+    come from the generated class (the persistent launches are built-in classes only: one warning says so), and one update's gradient
+    equals the block-tile kernels' (plugins switched off) to fp32 summation order"""
+    from visfly_amd import _lib
+    from visfly_amd.bptt import BPTT
+    from visfly_amd.envs import HoverEnv
+    from _golden import ENV_DYN
+    lib = _lib.lib()
+    pk = dict(features_extractor_class="StateExtractor", features_extractor_kwargs={"net_arch": {"state": {"layer": [64, 64, 32]}}},
+              net_arch=dict(pi=[32], qf=[96, 32]), activation_fn="relu", share_features_extractor=False)
+    grads = []
+    for on in (1, 0):
+        lib.vf_chain_plugin_set_enabled(on)
+        env = HoverEnv(num_agent_per_scene=2048, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, tensor_output=True, max_episode_steps=64)
+        n0 = lib.vf_chain_plugin_launches()
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            algo = BPTT(env, policy="MultiInputPolicy", policy_kwargs=pk, horizon=8, learning_rate=1e-3, seed=1)
+            algo._grad_reverse_sweep()
+        torch.cuda.synchronize()
+        assert (lib.vf_chain_plugin_launches() - n0 >= 16) == bool(on), "8 forwards + 8 reverse chains from the plugin"
+        grads.append(algo.policy.grad.clone())
+        env.close()
+    lib.vf_chain_plugin_set_enabled(1)
+    scale = grads[1].abs().max().item()
+    assert scale > 0 and (grads[0] - grads[1]).abs().max().item() <= 2e-5 * scale

@@ -9,7 +9,7 @@ flags) and registers it with the library (vf_chain_plugin_load).  ``__graft_entr
 the GPU box finds them in the snapshot.
 
 Shapes that qualify: 1-2 observation branches of <= 32 columns, 1-4 layers per branch / trunk, widths in multiples of 32 up to 128,
-the actor-critic heads (4, 1), no pass-through input.  Everything else keeps running on the block-tile kernels (MlpPolicy warns once).
+the actor-critic heads (4, 1) or the SAC-style Actor's (4, 4), no pass-through input.  Everything else keeps running on the block-tile kernels (MlpPolicy warns once).
 ``VISFLY_AMD_JIT=0`` switches the compilation off.
 """
 import hashlib
@@ -24,7 +24,8 @@ from ._build import CSRC, HIPCC_FLAGS, INCLUDE
 JIT_DIR = os.path.join(CSRC, "jit")
 MAX_DEPTH = 4
 # the shapes libvisfly_amd.so itself instantiates (NetHover / NetNav and their policy-only classes)
-_BUILTIN = {((16,), ((4, 2),), (2, 2), (2, 2)), ((16, 8), ((4, 2), (4, 2)), (2, 2), (2, 2))}
+_BUILTIN = {((16,), ((4, 2),), (2, 2), (2, 2)), ((16, 8), ((4, 2), (4, 2)), (2, 2), (2, 2)),
+            ((16,), ((4, 2),), (2, 2), (2, 2), (4, 4)), ((16, 8), ((4, 2), (4, 2)), (2, 2), (2, 2), (4, 4))}      # (.., (4, 4)): the SAC-style Actor
 _HEADERS = ("vf_mlp_chain.hpp", "vf_mlp_chain_bwd.hpp", "vf_mlp_chain_kernels.hpp", "vf_mlp_chain_gen.hpp", "vf_chain_plugin.hpp",
             "vf_common.hpp", "vf_ppo_device.hpp")
 _ROLLOUT_HEADERS = ("vf_ppo_rollout_kernel.hpp", "vf_env_epilogue.hpp", "vf_env_device.hpp", "vf_dyn_device.hpp", "vf_xmath.hpp",
@@ -39,13 +40,19 @@ PREBUILD = {
     # 30 forward tiles: the fused PPO step keeps the ReLU masks as bits (csrc/vf_mlp_chain_gen.hpp: kGenLiveTiles)
     "wide": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [128, 128], [128, 128]),
 }
+# the SAC-style Actor (heads (4, 4); td_policies.Actor: `pi` = latent_pi, `vf` = log_latent_pi) on a non-default shape: (.., head_dims)
+PREBUILD_SAC = {
+    "sac_nav": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [64]}, [128, 64], [64], (4, 4)),
+    "sac_hover": ({"state": 13}, {"state": [64, 64, 32]}, [32], [32], (4, 4)),      # (the Actor BPTT builds for pi=[32]: log_latent_pi mirrors latent_pi)
+}
 # ... and their roll-out plugins for the configurations tests/test_ppo_gpu.py runs: (shape name, (VF_ENV_*, VF_ACT_*, VF_INT_*, ctrl_delay))
 PREBUILD_ROLLOUT = [("verdict", (1, 1, 0, True)), ("one_layer_extractor", (0, 1, 1, False))]
 
 
 def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=()):
-    """(KIN, extractor widths in tiles, pi tiles, vf tiles) of a network the generated chain classes cover, else None"""
-    if passthrough or tuple(head_dims) != (4, 1) or not 1 <= len(extractor) <= 2:
+    """(KIN, extractor widths in tiles, pi tiles, vf tiles[, (4, 4)]) of a network the generated chain classes cover, else None.
+    Heads (4, 1): the actor-critic of the PPO policies; (4, 4): the SAC-style Actor of BPTT / SHAC (mu / log_std heads; fifth element)"""
+    if passthrough or tuple(head_dims) not in ((4, 1), (4, 4)) or not 1 <= len(extractor) <= 2:
         return None
     kin, ew = [], []
     for k, hidden in extractor.items():
@@ -61,22 +68,27 @@ def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=()):
     if any(h % 32 or not 32 <= h <= 128 for h in widths):
         return None
     tiles = lambda t: tuple(h // 32 for h in t)
-    return tuple(kin), tuple(tiles(e) for e in ew), tiles(trunks[0]), tiles(trunks[1])
+    sh = tuple(kin), tuple(tiles(e) for e in ew), tiles(trunks[0]), tiles(trunks[1])
+    return sh if tuple(head_dims) == (4, 1) else sh + ((4, 4),)
 
 
 def is_builtin(shape):
     return shape in _BUILTIN
 
 
+def _heads(shape):
+    return shape[4] if len(shape) > 4 else (4, 1)
+
+
 def name_of(shape):
-    kin, ew, pw, vw = shape
+    kin, ew, pw, vw = shape[:4]
     f = lambda t: "[" + ",".join(str(32 * x) for x in t) + "]"
-    return " ".join(f"in{k}{f(e)}" for k, e in zip(kin, ew)) + f" pi{f(pw)} vf{f(vw)}"
+    return " ".join(f"in{k}{f(e)}" for k, e in zip(kin, ew)) + f" pi{f(pw)} vf{f(vw)}" + (" heads 4/4" if _heads(shape) == (4, 4) else "")
 
 
 def source(shape):
     """the generated translation unit: a Spec (csrc/vf_mlp_chain_gen.hpp) and the plugin's entry points"""
-    kin, ew, pw, vw = shape
+    kin, ew, pw, vw = shape[:4]
     pad = lambda t, n=MAX_DEPTH: ", ".join(str(x) for x in (tuple(t) + (0,) * n)[:n])
     nb = len(kin)
     return f"""// generated by visfly_amd/_jit.py -- chain plugin for: {name_of(shape)}
@@ -93,6 +105,7 @@ struct Spec {{
     static constexpr int PW[{MAX_DEPTH}] = {{{pad(pw)}}};
     static constexpr int VW[{MAX_DEPTH}] = {{{pad(vw)}}};
     static constexpr bool VF = true;
+    static constexpr int HM = {_heads(shape)[0]}, HV = {_heads(shape)[1]};
 }};
 struct SpecPi : Spec {{
     static constexpr bool VF = false;
@@ -130,9 +143,9 @@ def _key(shape, rollout=None):
 
 
 def _slug(shape, rollout=None):
-    kin, ew, pw, vw = shape
+    kin, ew, pw, vw = shape[:4]
     t = lambda x: "".join(str(v) for v in x)
-    s = "e" + "_".join(f"{k}x{t(e)}" for k, e in zip(kin, ew)) + f"_p{t(pw)}_v{t(vw)}"
+    s = "e" + "_".join(f"{k}x{t(e)}" for k, e in zip(kin, ew)) + f"_p{t(pw)}_v{t(vw)}" + ("_h44" if _heads(shape) == (4, 4) else "")
     return s if rollout is None else s + "_roll" + "".join(str(int(x)) for x in rollout)
 
 
@@ -221,7 +234,8 @@ def ensure_rollout(shape, cfg):
 
 def prebuild(verbose=False):
     """compile the PREBUILD shapes (in parallel) -> paths"""
-    jobs = [(shape_of(*v), None) for v in PREBUILD.values()] + [(shape_of(*PREBUILD[n]), cfg) for n, cfg in PREBUILD_ROLLOUT]
+    jobs = ([(shape_of(*v), None) for v in list(PREBUILD.values()) + list(PREBUILD_SAC.values())] +
+            [(shape_of(*PREBUILD[n]), cfg) for n, cfg in PREBUILD_ROLLOUT])
     with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
         paths = list(pool.map(lambda j: build(j[0], verbose, rollout=j[1]), jobs))
     return paths

@@ -35,6 +35,7 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: H x N rows of layer gradients pass 4 GiB per buffer");
     // rows per wave: the choice vf_mlp_backward_data makes for N rows, so that the sweep equals the launch-by-launch one to the bit
     const int cls = vf::bwd_chain_policy_class(desc, N), net = cls & 15;
+    if (net == 0) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: the policy's layer table is not one of the built-in register-chained classes");
     const bool r16 = (cls & 16) != 0;
     const bool sac = net >= 3;          // td_policies.Actor: both head gradients come from d_action and the saved log_std rows
     if (sac ? !log_std_rows : (!log_std || !g_log_std))

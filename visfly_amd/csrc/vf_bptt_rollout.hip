@@ -37,6 +37,8 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: H x N rows of activation copies pass 4 GiB per buffer");
     if (desc->in_dim[0] != 13) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the first observation must be the 13-wide state row");
     const int cls = vf::chain16_policy_class(desc, params);
+    if (cls == 0)          // (before the per-class argument checks: a caller with another network -- a generated class -- steps launch by launch)
+        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the policy's layer table is not one of the built-in register-chained classes");
     const bool sac = cls >= 3;          // td_policies.Actor: the second head is the state-dependent log_std
     if (sac ? !log_std_rows : !log_std)
         return vf::fail(VF_EINVAL, sac ? "vf_bptt_rollout: log_std_rows (H N, 4) is required for the two-headed actor classes"

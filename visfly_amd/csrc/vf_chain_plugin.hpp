@@ -53,8 +53,12 @@ int plugin_forward(const vf_mlp_desc* d, const float* params, const float* packe
     ChainArgs g{*d, params, packed, ChainIo{{in0, in1, nullptr}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps),
                 reinterpret_cast<float4*>(rp.action), {rp.obs_copy[0], rp.obs_copy[1]}};
     if (!out1) {
-        if (!chain_matches_gen<NetPi>(*d)) return 0;
-        hipLaunchKernelGGL(k_mlp_forward_chain<NetPi>, dim3((M + 31) / 32), dim3(64), 0, st, g);
+        if constexpr (Net::HV != 1) {
+            return 0;             // (the SAC-style Actor always runs both trunks)
+        } else {
+            if (!chain_matches_gen<NetPi>(*d)) return 0;
+            hipLaunchKernelGGL(k_mlp_forward_chain<NetPi>, dim3((M + 31) / 32), dim3(64), 0, st, g);
+        }
     } else {
         if (!chain_matches_gen<Net>(*d)) return 0;
         hipLaunchKernelGGL(k_mlp_forward_chain<Net>, dim3((M + 31) / 32), dim3(64), 0, st, g);
@@ -66,8 +70,10 @@ int plugin_forward(const vf_mlp_desc* d, const float* params, const float* packe
 template <class Net>
 int plugin_backward(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rpp)
 {
-    using PU = typename Net::template Bwd<true, true, false>;      // PPO update: both trunks, no observation gradient
-    using PG = typename Net::template Bwd<true, false, true>;      // first-order policy optimisation: policy trunk, observation gradient
+    using PU = typename Net::template Bwd<true, true, false>;      // PPO update / SHAC actor: both trunks, no observation gradient
+    // with observation gradient: the policy trunk alone (first-order optimisation of an actor-critic's policy) or, for the SAC-style
+    // Actor, both trunks (mu and log_std heads both carry gradient)
+    using PG = typename Net::template Bwd<true, Net::HV == 4, true>;
     const ReparamBwd rp = rpp ? *rpp : ReparamBwd{};
     BwdArgsChain g{*d, packed, M, reinterpret_cast<const float4*>(rp.d_action), reinterpret_cast<const float4*>(rp.action), rp.log_std,
                    reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.g_log_std)};
@@ -88,12 +94,16 @@ int plugin_ppo_update(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowAr
 {
     // more forward tiles than stay live beside the reverse chain: the variant that keeps the ReLU masks as bits (vf_mlp_chain_gen.hpp)
     using Net = std::conditional_t<(Net0::n_tiles > kGenLiveTiles), ChainNetG<typename Net0::Spec, true>, Net0>;
-    using PU = typename Net::template Bwd<true, true, false>;
-    if (Net::NB == 2 && !g->io.in[1]) return 0;
-    if (!chain_matches_gen<Net>(g->d) || !bwd_chain_matches_gen<PU>(gb->d, false)) return 0;
-    hipLaunchKernelGGL(k_ppo_update_chain<Net>, dim3((M + 31) / 32), dim3(64), 0, st, *g, *gb, *pr);
-    VF_HIP(hipGetLastError());
-    return 1;
+    if constexpr (Net::HV != 1) {
+        return 0;                 // (no PPO step on the SAC-style Actor: the kernel is not instantiated)
+    } else {
+        using PU = typename Net::template Bwd<true, true, false>;
+        if (Net::NB == 2 && !g->io.in[1]) return 0;
+        if (!chain_matches_gen<Net>(g->d) || !bwd_chain_matches_gen<PU>(gb->d, false)) return 0;
+        hipLaunchKernelGGL(k_ppo_update_chain<Net>, dim3((M + 31) / 32), dim3(64), 0, st, *g, *gb, *pr);
+        VF_HIP(hipGetLastError());
+        return 1;
+    }
 }
 
 }  // namespace vf

@@ -10,6 +10,8 @@
 //     DE[b], EW[b][l]   layers of branch b's extractor and their widths in 32-feature tiles (<= 4 tiles = 128 features)
 //     DP, PW[j]     hidden layers of the policy trunk (>= 1), widths in tiles;   DV, VW[j]: the value trunk's
 //     VF            false: the class runs extractors + policy trunk only
+//     HM, HV        widths of the two heads: (4, 1) the PPO policies' action mean / value; (4, 4) the SAC-style Actor's mu / log_std
+//                   (utils/policies/td_policies.py:146-252: `pi` = latent_pi, `vf` = log_latent_pi)
 // ChainNetG<Spec> / BwdProgG<..> derive from it the same layer / op tables that ChainNet / BwdProg spell out for the two-layer shapes;
 // the device code (vf_mlp_chain.hpp, vf_mlp_chain_bwd.hpp) is the same.
 #pragma once
@@ -175,7 +177,8 @@ struct ChainNetG {
     using Spec = S;
     template <bool PI, bool VF2, bool IG>
     using Bwd = BwdProgG<ChainNetG, PI, VF2, IG>;
-    static constexpr int NB = S::NB, HV = 1, HM = 4, PASS = 0;
+    static constexpr int NB = S::NB, HV = S::HV, HM = S::HM, PASS = 0;       // heads (4, 1): actor-critic; (4, 4): the SAC-style Actor (mu / log_std)
+    static_assert(HM == 4 && (HV == 1 || HV == 4), "heads");
     static constexpr bool VF = S::VF;
     static_assert(NB >= 1 && NB <= 2 && S::DP >= 1 && S::DV >= 1 && S::DP <= kGenMaxDepth && S::DV <= kGenMaxDepth, "shape");
     static constexpr int kin(int b) { return S::KIN[b]; }
@@ -309,7 +312,7 @@ struct BwdProgG {
     using Sh = typename N::Shape;
     static_assert(PI || VF, "a reverse chain needs a head gradient");
     static constexpr int NB = N::NB;
-    static constexpr bool sac_head = false;
+    static constexpr bool sac_head = PI && VF && N::HV == 4 && N::HM == 4;     // td_policies.Actor: both heads' gradients can come from d_action (BwdProg)
     static constexpr int L_mean = N::L_mean, L_val = N::L_value;
     static constexpr int n_tiles = N::n_tiles + NB;
     static constexpr GenOps tab = Tab::make();

@@ -144,7 +144,9 @@ class MlpPolicy:
         self._plan = self._plan_fused()
         self._descs = {}
         # chain kernels of a shape the library holds no instance of: compiled on first use (visfly_amd/_jit.py)
-        self.chain_shape = _jit.shape_of(self.obs_dims, extractor, pi, vf, self.head_dims, self.passthrough) if log_std_param else None
+        # (heads (4, 1) with the log_std parameter: the PPO policies' actor-critic; (4, 4) without: the SAC-style Actor of BPTT / SHAC)
+        self.chain_shape = (_jit.shape_of(self.obs_dims, extractor, pi, vf, self.head_dims, self.passthrough)
+                            if bool(log_std_param) == (self.head_dims == (4, 1)) else None)
         self.chain_jit = False
         if self._plan is None:          # more activation buffers than a vf_mlp_desc names (VF_MLP_MAX_BUFS): layer-by-layer launches
             self.chain_shape = None
