@@ -154,7 +154,12 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
     spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
     env = NavigationEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dict(DYN_KW), random_kwargs=spawn,
                         device=dev, max_episode_steps=256)
-    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=0)
+    kw = {}
+    if getattr(args, "net_arch", None):
+        arch = {k: [int(x) for x in v.split(",")] for k, v in (p.split("=") for p in args.net_arch.split(":"))}
+        kw = dict(policy_kwargs=dict(features_extractor_class="StateTargetExtractor", activation_fn="ReLU", net_arch=arch,
+                                     features_extractor_kwargs=dict(net_arch=dict(state=dict(layer=[128, 64]), target=dict(layer=[128, 64])))))
+    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=0, **kw)
     ppo.learn(256 * N * world)   # warm-up iteration
     torch.cuda.synchronize()
     parallel.barrier()
@@ -197,7 +202,8 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
     flops = 6.0 * ppo.policy.log_std_off * rows          # log_std_off = number of weights + biases of the network
     tfs = flops / (us_upd * 1e-6) / 1e12
     roof = {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3, "traffic": None,
-            "kernel": "optimiser step: k_ppo_update_split (k_ppo_update_chain above 32 768 rows) + k_mlp_wgrad + fold + Adam", "us_per_update": us_upd,
+            "kernel": ("optimiser step: k_ppo_update_chain<generated class> + k_mlp_wgrad + fold + Adam" if kw else
+                       "optimiser step: k_ppo_update_split (k_ppo_update_chain above 32 768 rows) + k_mlp_wgrad + fold + Adam"), "us_per_update": us_upd,
             "rows": rows, "note": "fp32 v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)"}
     exchange = exchange_block(ppo._gbuf, n_upd, el / iters, us_upd, world, dev)
     out = {"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
@@ -210,7 +216,7 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
                                                             "the optimiser steps (one all-reduce each)"},
            "exchange": exchange,
            "config": {"workload": f"NavigationEnv {N} agents/GPU, n_steps=256, batch 25600/GPU, 5 epochs "
-                                  "(BASELINE configs[3] shard)",
+                                  "(BASELINE configs[3] shard)" + (f", net_arch {args.net_arch} (generated chain class)" if kw else ""),
                       "logs": {k: float(v) for k, v in ppo.logs.items()}},
            "roofline": roof}
     if cpu_ref and rank == 0:
@@ -449,6 +455,8 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=6.0, help="seconds of back-to-back stepping reported as `sustained` (the driver's "
                     "gpu_busy samples see the GPU working; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--net-arch", default=None, help="--workload ppo only: `pi=128,128:vf=32` -- a net_arch without a built-in chain class "
+                                                     "(kernels compiled on first use, visfly_amd/_jit.py); the default is the reference's [64, 64] / [64, 64]")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
     ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt", "shac", "nav_rk4_dr"],
                     help="env: fused HoverEnv.step (the BASELINE metric, default); ppo / bptt / shac / nav_rk4_dr (BASELINE configs[2]): that leg only")
