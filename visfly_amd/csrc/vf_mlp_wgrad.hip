@@ -21,9 +21,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #ifndef VF_WGRAD_BUDGET
 #define VF_WGRAD_BUDGET 64       // operand registers of the prefetch ring (A/B knob: profiles/r04_ppo_wgrad.txt)
 #endif
+#ifndef VF_WGRAD_BUDGET_SMALL
+#define VF_WGRAD_BUDGET_SMALL 40
+#endif
 constexpr int wg_depth(int nt, int kt, bool small)
 {
-    const int d = (small ? 40 : VF_WGRAD_BUDGET) / (nt + kt);      // small: two waves per SIMD share its 512 registers
+    const int d = (small ? VF_WGRAD_BUDGET_SMALL : VF_WGRAD_BUDGET) / (nt + kt);      // small: two waves per SIMD share its 512 registers
     return d > 16 ? 16 : (d < 4 ? 4 : d);
 }
 
