@@ -46,7 +46,7 @@ PREBUILD_SAC = {
     "sac_hover": ({"state": 13}, {"state": [64, 64, 32]}, [32], [32], (4, 4)),      # (the Actor BPTT builds for pi=[32]: log_latent_pi mirrors latent_pi)
 }
 # ... and their roll-out plugins for the configurations tests/test_ppo_gpu.py runs: (shape name, (VF_ENV_*, VF_ACT_*, VF_INT_*, ctrl_delay))
-PREBUILD_ROLLOUT = [("verdict", (1, 1, 0, True)), ("one_layer_extractor", (0, 1, 1, False))]
+PREBUILD_ROLLOUT = [("verdict", (1, 1, 0, True)), ("one_layer_extractor", (0, 1, 1, False)), ("one_layer_extractor", (1, 1, 0, True))]
 
 
 def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=()):
