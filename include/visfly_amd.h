@@ -477,7 +477,7 @@ int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, 
  * td_policies.py:137) must read the TAIL of that buffer (src_col + K = its width): the kernel zero-fills the columns
  * [src_col + K, src_col + round16(K)) of the LDS copy, which the 16-step MFMA sweep reads against zero weights. */
 #define VF_MLP_MAX_LAYERS 16
-#define VF_MLP_MAX_BUFS 12
+#define VF_MLP_MAX_BUFS 16
 enum { VF_MLP_OUT0 = 100, VF_MLP_OUT1 = 101 };
 typedef struct vf_mlp_layer {
     int32_t K, No, relu;

@@ -130,7 +130,7 @@ class EnvBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("tape_slab", "action", "d_obs", "d_reward", "done", "adj_slab", "d_action")]
 
 
-MLP_MAX_LAYERS, MLP_MAX_BUFS, MLP_OUT0, MLP_OUT1 = 16, 12, 100, 101
+MLP_MAX_LAYERS, MLP_MAX_BUFS, MLP_OUT0, MLP_OUT1 = 16, 16, 100, 101
 
 
 class MlpLayer(C.Structure):
