@@ -226,10 +226,11 @@ def ensure_rollout(shape, cfg):
     key = (shape, tuple(int(x) for x in cfg))
     if key not in _loaded:
         from . import _lib
+        _loaded[key] = None                  # (a failed build is not retried on every roll-out: the caller warns once and falls back)
         path = build(shape, rollout=key[1])
         _lib.check(_lib.lib().vf_chain_plugin_load(path.encode()))
         _loaded[key] = path
-    return True
+    return _loaded[key] is not None
 
 
 def prebuild(verbose=False):
