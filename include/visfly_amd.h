@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 9   /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
+#define VF_ABI_VERSION 10  /* 2: geometric-controller constants, env obs/reward modes, packed MLP weights, fused backward;
                               3: register-chain weight images (vf_mlp_layer.wr_off / wq_off, four-column pack_map),
                                  vf_mlp_backward_partial_floats;
                               4: vf_env_step_n / vf_env_graph_* (multi-step launch), vf_env_export_pose, vf_env_finish_step, vf_dyn_set_wind,
@@ -37,7 +37,8 @@ extern "C" {
                               6: substep_tape argument of vf_bptt_rollout / vf_bptt_reverse, vf_mlp_desc.identity_mask (was pad0);
                               7: mean_rows / log_std_rows / reward_rows / ep_flag_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes);
                               8: vf_twin_q_update (fused critic step of SHAC), vf_mlp_forward_steps, vf_shac_accumulate_horizon 
-                              9: vf_ppo_loss_cfg.row_index / obs_copy0 / obs_copy1 (vf_ppo_update on an indexed minibatch), vf_chain_plugin_* */
+                              9: vf_ppo_loss_cfg.row_index / obs_copy0 / obs_copy1 (vf_ppo_update on an indexed minibatch), vf_chain_plugin_*
+                              10: vf_mlp_weight_grad_adam / vf_wgrad_tail (fold + norm + clip + Adam inside the weight-gradient launch) */
 
 /* clamp interval of the state-dependent log_std head of the reference's Actor (utils/policies/td_policies.py:31-32,241-243) */
 #define VF_SAC_LOG_STD_MIN (-10.0f)
@@ -739,6 +740,37 @@ typedef struct vf_adam_cfg {
     int32_t n_sumsq_partials;
     int32_t sumsq_tail_from;
 } vf_adam_cfg;
+
+/* ABI 10.  The tail of an optimiser step inside the weight-gradient launch (utils/algorithms/PPO.py:284-292: loss.backward()'s weight
+ * gradients, clip_grad_norm_, optimizer.step()): vf_mlp_weight_grad_sumsq + vf_adam_step as ONE launch instead of three (weight
+ * gradients, fold, Adam).  The waves of the weight-gradient kernel meet at device counters once their partials are out, fold the
+ * partials chip-wide, form the squared gradient norm and run clip + Adam (+ the packed-weight refresh) on the elements they hold --
+ * the same reduction orders and the same arithmetic as the separate launches: identical bits.
+ *   tail->param / exp_avg / exp_avg_sq  the flat buffers of n parameters (as vf_adam_step)
+ *   tail->adam                          as vf_adam_step; sumsq_partials = vf_mlp_weight_grad_fold_blocks(desc) doubles of workspace the
+ *                                       launch writes and reads (n_sumsq_partials is ignored); sumsq_tail_from = first parameter the
+ *                                       layer table does not cover (log_std): those take their gradient from grad[] as the caller /
+ *                                       loss_stats->d_log_std_out left it
+ *   tail->sync                          VF_WGRAD_SYNC_WORDS uint32, zeroed ONCE by the caller and then reused launch after launch by
+ *                                       launches of one stream (the kernel leaves the counters at zero)
+ *   loss_stats                          as vf_mlp_weight_grad_sumsq (part rows 16-byte aligned)
+ * Needs every wave of the launch resident at once: VF_EUNSUPPORTED (reason in vf_last_error) when the plan for (desc, M) exceeds
+ * what this device holds of the kernel, for streaming row counts (>= 131 072 with narrow layers), or with VISFLY_AMD_FUSED_TAIL=0 --
+ * the caller then issues vf_mlp_weight_grad_sumsq + vf_adam_step.  A wave that waits longer than VISFLY_AMD_FUSED_TAIL_TIMEOUT_MS
+ * (default 2000) sets sync[VF_WGRAD_SYNC_ABORT] and every waiter leaves WITHOUT the update: a caller polls that word at its
+ * next host synchronisation and treats non-zero as a hard error (the counters are then stale: zero sync[] before reuse). */
+#define VF_WGRAD_SYNC_WORDS 32
+#define VF_WGRAD_SYNC_ABORT 2
+typedef struct vf_wgrad_tail {
+    float* param;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    vf_adam_cfg adam;
+    uint32_t* sync;
+} vf_wgrad_tail;
+int vf_mlp_weight_grad_adam(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
+                            const vf_stats_fold* loss_stats, const vf_wgrad_tail* tail, vf_stream_t stream);
 
 /* One PPO minibatch step up to the weight gradients (utils/algorithms/PPO.py:203-287: evaluate_actions, the clipped-surrogate
  * loss, loss.backward()), for the network classes of the register-chained kernels: forward +

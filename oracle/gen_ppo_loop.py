@@ -239,8 +239,18 @@ def _flat(policy, grad=False):
     return np.concatenate(parts)
 
 
+# the schedules of the `ppo_loop_nav_sched` case, as functions of SB3's progress_remaining (tests/test_ppo_loop_gpu.py passes the same
+# callables to visfly_amd.ppo.PPO): linear learning rate, clip ranges shrinking to half
+def sched_lr(lr):
+    return lambda p: lr * p
+
+
+def sched_clip(c):
+    return lambda p: c * (0.5 + 0.5 * p)
+
+
 def gen_ppo_loop(name, T=8, N=64, batch_size=160, n_epochs=2, seed=21, lr=1e-3, ent_coef=0.0, clip_range_vf=None, target_kl=None,
-                 adv_scale=1.0):
+                 adv_scale=1.0, progress=1.0, sched=False):
     sp = _install_ppo_sb3()
     import VisFly.utils.algorithms.PPO as RP
     import VisFly.utils.algorithms.common as RC
@@ -267,7 +277,7 @@ def gen_ppo_loop(name, T=8, N=64, batch_size=160, n_epochs=2, seed=21, lr=1e-3, 
     act_space = sp.Box(-1, 1, (4,))
     # the YAMLs' policy_kwargs (exps/examples/alg_cfgs/*/PPO.yaml) with the state-vector extractor
     policy = RPOL.CustomMultiInputActorCriticPolicy(
-        obs_space, act_space, lr_schedule=lambda _: lr, net_arch=dict(pi=[64, 64], vf=[64, 64]), activation_fn=nn.ReLU, ortho_init=False,
+        obs_space, act_space, lr_schedule=(sched_lr(lr) if sched else (lambda _: lr)), net_arch=dict(pi=[64, 64], vf=[64, 64]), activation_fn=nn.ReLU, ortho_init=False,
         log_std_init=-0.5, features_extractor_class=E.StateTargetExtractor,
         features_extractor_kwargs={"net_arch": {"state": {"layer": [128, 64]}, "target": {"layer": [128, 64]}}, "activation_fn": nn.ReLU},
         optimizer_kwargs={"weight_decay": weight_decay})
@@ -324,10 +334,11 @@ def gen_ppo_loop(name, T=8, N=64, batch_size=160, n_epochs=2, seed=21, lr=1e-3, 
     # explained-variance log line (np.var) -- what SB3's own buffer holds; the tensor port's are tensors
     algo.policy = policy
     algo.rollout_buffer = types.SimpleNamespace(get=buf.get, values=G.f32(buf.values), returns=G.f32(buf.returns))
-    algo.lr_schedule = lambda _: lr
-    algo.clip_range = lambda _: clip_range
-    algo.clip_range_vf = None if clip_range_vf is None else (lambda _: clip_range_vf)
-    algo._current_progress_remaining = 1.0
+    # SB3's get_schedule_fn (common/utils.py [SB3 2.2.1]) turns a float into a constant callable and passes a callable through
+    algo.lr_schedule = sched_lr(lr) if sched else (lambda _: lr)
+    algo.clip_range = sched_clip(clip_range) if sched else (lambda _: clip_range)
+    algo.clip_range_vf = None if clip_range_vf is None else (sched_clip(clip_range_vf) if sched else (lambda _: clip_range_vf))
+    algo._current_progress_remaining = progress       # what learn() sets before train() (PPO.py:150-152)
     algo.n_epochs, algo.batch_size, algo.action_space, algo.use_sde = n_epochs, batch_size, act_space, False
     algo.normalize_advantage, algo.ent_coef, algo.vf_coef, algo.max_grad_norm = True, ent_coef, vf_coef, max_grad_norm
     algo.target_kl, algo.verbose, algo._n_updates = target_kl, 0, 0
@@ -389,6 +400,9 @@ def gen_ppo_loop(name, T=8, N=64, batch_size=160, n_epochs=2, seed=21, lr=1e-3, 
         log_value_loss=np.float64(logs["train/value_loss"]), log_approx_kl=np.float64(logs["train/approx_kl"]),
         log_clip_fraction=np.float64(logs["train/clip_fraction"]), log_loss=np.float64(logs["train/loss"]),
         log_std_mean=np.float64(logs["train/std"]), log_explained_variance=np.float64(logs["train/explained_variance"]),
+        log_learning_rate=np.float64(logs["train/learning_rate"]), log_clip_range=np.float64(logs["train/clip_range"]),
+        log_clip_range_vf=np.float64(logs.get("train/clip_range_vf", -1.0)), log_n_updates=np.int32(logs["train/n_updates"]),
+        progress_remaining=np.float64(progress), sched=np.bool_(sched),
         T=np.int32(T), N=np.int32(N), batch_size=np.int32(batch_size), n_epochs=np.int32(n_epochs), lr=np.float64(lr),
         gamma=np.float64(gamma), gae_lambda=np.float64(lam), clip_range=np.float64(clip_range), ent_coef=np.float64(ent_coef),
         vf_coef=np.float64(vf_coef), max_grad_norm=np.float64(max_grad_norm), weight_decay=np.float64(weight_decay),
@@ -402,6 +416,8 @@ def gen_ppo_loop(name, T=8, N=64, batch_size=160, n_epochs=2, seed=21, lr=1e-3, 
 CASES = {
     "ppo_loop_nav": dict(),
     "ppo_loop_nav_kl": dict(seed=22, ent_coef=0.01, clip_range_vf=0.3, target_kl=None, lr=3e-3),      # target_kl filled in below
+    # learning_rate / clip_range / clip_range_vf as callables of progress_remaining, train() entered at 40 % of the run remaining
+    "ppo_loop_nav_sched": dict(seed=23, ent_coef=0.005, clip_range_vf=0.4, lr=2e-3, progress=0.4, sched=True),
 }
 
 if __name__ == "__main__":

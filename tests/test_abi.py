@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/ but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in visfly_amd/_lib.py"
-    assert L.vf_abi_version() == _lib.ABI_VERSION == 9
+    assert L.vf_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_cfg_struct_size_matches_header():

@@ -689,6 +689,74 @@ def test_ppo_training_with_indexed_minibatches_equals_the_shuffled_copy():
     assert torch.equal(flats[0], flats[1])
 
 
+@pytest.mark.parametrize("keys,B", [(("state", "target"), 25600), (("state",), 4096), (("state", "target"), 1000), (("state", "target"), 70)])
+def test_fused_optimiser_tail_equals_separate_launches(keys, B):
+    """vf_mlp_weight_grad_adam (weight gradients + fold + gradient norm + clip + Adam + packed-weight refresh in ONE launch, the waves
+    meeting at device counters) leaves, bit for bit, what vf_mlp_weight_grad_sumsq + vf_adam_step leave: gradient, loss statistics,
+    their epoch accumulator, the per-block squared-norm partials, parameters, both Adam moments and the packed MFMA weight images --
+    over several consecutive steps on the same sync words (the kernel leaves its counters at zero)"""
+    from visfly_amd.ppo import MlpPolicy
+    _lib, lib = L()
+    dims = {"state": 13, "target": 3}
+    g = torch.Generator(device=DEV).manual_seed(B)
+    obs = {k: torch.randn((B, dims[k]), device=DEV, generator=g) for k in keys}
+    actions = torch.tanh(torch.randn((B, 4), device=DEV, generator=g)).contiguous()
+    old_lp, adv, ret = (torch.randn(B, device=DEV, generator=g) for _ in range(3))
+    out = {}
+    for fused in (True, False):
+        pol = MlpPolicy({k: dims[k] for k in keys}, {k: [128, 64] for k in keys}, [64, 64], [64, 64], DEV, seed=5)
+        pol.lazy_pack = True
+        n = pol.n_params
+        gbuf = torch.zeros(n + 16, device=DEV)
+        pol.grad = gbuf[:n]
+        stats, acc = gbuf[n:], torch.zeros(16, device=DEV)
+        scratch = torch.zeros(16 * 1024 + 4096, device=DEV)
+        m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        sync = torch.zeros(_lib.WGRAD_SYNC_WORDS, dtype=torch.int32, device=DEV)
+        trace = []
+        for step in range(1, 4):
+            cfg = _lib.PpoLossCfg(0.2, 0.01, 0.5, 1.0 / B, pol.grad.data_ptr() + 4 * pol.log_std_off, acc.data_ptr())
+            pmap, packed = pol.pack_map()
+            acfg = _lib.AdamCfg(1e-3, 0.9, 0.999, 1e-8, 1e-5, 0.05, step, 0, pmap.data_ptr(), packed.data_ptr(), None, 0, pol.log_std_off)
+            tail = _lib.WgradTail(pol.flat.data_ptr(), m.data_ptr(), v.data_ptr(), n, acfg, sync.data_ptr()) if fused else None
+            res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch, want_sumsq=True, tail=tail)
+            if fused:
+                assert res == "adam", pol.tail_reason
+            else:
+                sq, nb = res
+                acfg.sumsq_partials, acfg.n_sumsq_partials = sq.data_ptr(), nb
+                _lib.check(lib.vf_adam_step(pol.flat.data_ptr(), pol.grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, None, C.byref(acfg), st()))
+            pol.mark_updated(packed_current=True)
+            torch.cuda.synchronize()
+            trace.append([t.clone() for t in (pol.grad, stats, acc, pol._sq_part, pol.flat, m, v, pol._packed)])
+        assert int(sync.abs().sum()) == (3 if fused else 0)           # only the generation word moved: counters back at zero
+        out[fused] = trace
+    for a, b in zip(out[True], out[False]):
+        for name, x, y in zip(("grad", "stats", "stats_accum", "sq_part", "param", "exp_avg", "exp_avg_sq", "packed"), a, b):
+            assert torch.equal(x, y), name
+    assert not torch.equal(out[True][0][4], out[True][2][4]) and float(out[True][0][0].abs().max()) > 0
+
+
+def test_ppo_training_with_the_fused_tail_equals_the_separate_launches():
+    """PPO.learn with the optimiser step's tail inside the weight-gradient launch (default) ends at the same parameters, bit for bit, as
+    with fold and Adam as launches of their own; trailing partial minibatch, value clipping, entropy term"""
+    from visfly_amd.envs import NavigationEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    flats = []
+    for flag in (True, False):
+        env = NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64, tensor_output=True)
+        ppo = PPO(env, n_steps=16, batch_size=6000, n_epochs=3, learning_rate=3e-4, seed=3, clip_range_vf=0.3, ent_coef=0.01)
+        ppo.fused_tail = flag
+        ppo.learn(16 * 1024 * 3)
+        torch.cuda.synchronize()
+        assert (ppo._tail_launches > 0) == flag, ppo.policy.tail_reason
+        flats.append((ppo.policy.flat.clone(), ppo.exp_avg.clone(), ppo.exp_avg_sq.clone(), dict(ppo.logs)))
+        env.close()
+    assert torch.equal(flats[0][0], flats[1][0]) and torch.equal(flats[0][1], flats[1][1]) and torch.equal(flats[0][2], flats[1][2])
+    assert {k: v for k, v in flats[0][3].items() if k != "time/fps"} == {k: v for k, v in flats[1][3].items() if k != "time/fps"}
+
+
 def test_predict_is_deterministic_and_bounded():
     """SB3 ``predict(obs, deterministic=True)`` as evaluation harnesses call it (utils/evaluate.py:94): a = tanh(mean)"""
     from visfly_amd.envs import HoverEnv

@@ -3,7 +3,9 @@ train() (utils/algorithms/PPO.py:177-337) was run, unmodified, on its own Custom
 DictRolloutBuffer for 2 epochs x (3 full minibatches + a partial one); ``visfly_amd.ppo.PPO.train`` replays the same minibatches (the
 recorded permutations) from the same rollout and initial parameters and must reproduce, per optimiser step, the loss, the value loss, the
 flat gradient before clipping, its norm and the parameters after clip + Adam -- and per run the epoch / minibatch at which ``target_kl``
-stops the loop, the number of optimiser steps and the logged means.  Tolerances: those of the SHAC / BPTT loop fixtures (fp32 MFMA chains
+stops the loop, the number of optimiser steps and everything train() hands to its logger (equal-weight means over minibatches, the last
+minibatch's loss, explained variance, std, n_updates = epochs, learning rate and clip ranges).  Third case: learning_rate / clip_range /
+clip_range_vf are callables of SB3's progress_remaining, train() entered with 40 % of the run remaining.  Tolerances: those of the SHAC / BPTT loop fixtures (fp32 MFMA chains
 vs MKL sgemm: gradients 2e-5 of the block scale, Adam 2e-7 absolute)."""
 import os
 
@@ -11,7 +13,7 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["ppo_loop_nav", "ppo_loop_nav_kl"]
+CASES = ["ppo_loop_nav", "ppo_loop_nav_kl", "ppo_loop_nav_sched"]
 
 
 def load(name):
@@ -49,11 +51,15 @@ def test_train_replays_the_references_train(name):
     fx = load(name)
     T, N, bs = int(fx["T"]), int(fx["N"]), int(fx["batch_size"])
     opt = lambda k: None if float(fx[k]) < 0 else float(fx[k])
+    lr_arg, clip_arg, clip_vf_arg = float(fx["lr"]), float(fx["clip_range"]), opt("clip_range_vf")
+    if bool(fx["sched"]):        # the generator's schedules (oracle/gen_ppo_loop.py: sched_lr, sched_clip), passed as callables
+        lr_arg, clip_arg, clip_vf_arg = (lambda p, v=lr_arg: v * p), (lambda p, v=clip_arg: v * (0.5 + 0.5 * p)), (lambda p, v=clip_vf_arg: v * (0.5 + 0.5 * p))
     env = NavigationEnv(num_agent_per_scene=N, seed=1, dynamics_kwargs=dict(ENV_DYN), device=dev, max_episode_steps=64, tensor_output=True)
     ppo = PPO(env, n_steps=T, batch_size=bs, n_epochs=int(fx["n_epochs"]), gamma=float(fx["gamma"]), gae_lambda=float(fx["gae_lambda"]),
-              clip_range=float(fx["clip_range"]), ent_coef=float(fx["ent_coef"]), vf_coef=float(fx["vf_coef"]),
-              max_grad_norm=float(fx["max_grad_norm"]), learning_rate=float(fx["lr"]), weight_decay=float(fx["weight_decay"]),
-              adam_eps=float(fx["adam_eps"]), target_kl=opt("target_kl"), clip_range_vf=opt("clip_range_vf"), seed=0)
+              clip_range=clip_arg, ent_coef=float(fx["ent_coef"]), vf_coef=float(fx["vf_coef"]),
+              max_grad_norm=float(fx["max_grad_norm"]), learning_rate=lr_arg, weight_decay=float(fx["weight_decay"]),
+              adam_eps=float(fx["adam_eps"]), target_kl=opt("target_kl"), clip_range_vf=clip_vf_arg, seed=0)
+    ppo._current_progress_remaining = float(fx["progress_remaining"])          # what learn() sets before train() (PPO.py:150-152)
     pol = ppo.policy
     n = pol.n_params
     assert n == fx["params0"].size
@@ -106,7 +112,7 @@ def test_train_replays_the_references_train(name):
     # visible fraction of lr, whatever computes it -- so (a) the trainer's Adam is checked tightly against a float64 replay from the
     # trainer's OWN gradients, (b) against the reference's parameters the bulk must agree to the SHAC loop's 2e-7 per step and no
     # parameter may be off by more than 2 % of a full-size step
-    lr, wd, eps, b1, b2 = float(fx["lr"]), float(fx["weight_decay"]), float(fx["adam_eps"]), 0.9, 0.999
+    lr, wd, eps, b1, b2 = float(fx["log_learning_rate"]), float(fx["weight_decay"]), float(fx["adam_eps"]), 0.9, 0.999
     p, m, v = fx["params0"].astype(np.float64), np.zeros(n), np.zeros(n)
     for i in range(n_opt):
         g = rec["grad"][i].astype(np.float64)
@@ -116,8 +122,16 @@ def test_train_replays_the_references_train(name):
         assert np.abs(rec["params"][i] - p).max() <= 3e-7 * (i + 1), f"Adam step {i} vs a float64 replay of the trainer's own gradients"
         diff = np.abs(rec["params"][i] - fx["params"][i])
         assert np.quantile(diff, 0.99) <= 2e-7 * (i + 1) and diff.max() <= 0.02 * lr * (i + 1), (i, np.quantile(diff, 0.99), diff.max())
-    # the logged means: equal-weight means over minibatches in the reference, row-weighted here -- recomputed the reference's way
-    mb = fx["mb_rows"].astype(np.float64)
-    assert abs(np.average(rec["value_loss"], weights=mb) - ppo.logs["train/value_loss"]) <= 1e-5 * max(1.0, ppo.logs["train/value_loss"])
-    assert abs(np.mean(rec["value_loss"]) - float(fx["log_value_loss"])) <= 2e-5 * max(1.0, float(fx["log_value_loss"]))
+    # what train() logs (PPO.py:322-336): equal-weight means over the evaluated minibatches (approx_kl: those of the last epoch started),
+    # the last minibatch's loss, explained variance of the buffer, std, n_updates (+1 per epoch), the schedules' current values
+    lg = ppo.logs
+    for key, name, tol in (("train/value_loss", "log_value_loss", 2e-5), ("train/policy_gradient_loss", "log_policy_gradient_loss", 2e-5),
+                           ("train/entropy_loss", "log_entropy_loss", 2e-6), ("train/approx_kl", "log_approx_kl", 2e-5),
+                           ("train/clip_fraction", "log_clip_fraction", 1e-9), ("train/loss", "log_loss", 2e-5),
+                           ("train/explained_variance", "log_explained_variance", 1e-5), ("train/std", "log_std_mean", 1e-6),
+                           ("train/learning_rate", "log_learning_rate", 1e-12), ("train/clip_range", "log_clip_range", 1e-9)):
+        assert abs(lg[key] - float(fx[name])) <= tol * max(1.0, abs(float(fx[name]))), (key, lg[key], float(fx[name]))
+    assert lg["train/n_updates"] == int(fx["log_n_updates"]) == int(fx["n_updates"])
+    if float(fx["clip_range_vf"]) > 0:
+        assert abs(lg["train/clip_range_vf"] - float(fx["log_clip_range_vf"])) <= 1e-9
     env.close()

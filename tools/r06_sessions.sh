@@ -1,0 +1,37 @@
+#!/bin/bash
+# The gpurun sessions of round 6, one case per session:  gpurun -- 'bash tools/r06_sessions.sh <name>'
+# Output under gpurun_out/r06_<name>/ ; the summaries that are cited go to profiles/r06_*.
+S=$1; R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r06_$S; mkdir -p $O; cd $R
+export TMPDIR=/tmp
+prof() {   # prof <tag> <cmd...>: rocprofv3 kernel stats of a command -> $O/<tag>_stats.txt
+    local tag=$1; shift
+    (cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/prof_$tag -- "$@" > $O/prof_$tag.log 2>&1)
+    python $R/tools/prof_summary.py $(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1) $O/${tag}_stats.txt "$@" > /dev/null 2>&1
+    head -14 $O/${tag}_stats.txt
+}
+ppo_ab() {  # ppo_ab <tag> <env assignments...>: bench.py --workload ppo under the given environment
+    local tag=$1; shift
+    env "$@" timeout 600 python bench.py --workload ppo --no-cpu-baseline 2>&1 | tail -1 > $O/bench_ppo_$tag.json
+    python - <<PY
+import json
+try:
+    d = json.loads(open("$O/bench_ppo_$tag.json").read())
+    print("ppo $tag value %.4g  us/update %.2f  frac %.4f  train ms %.2f" % (d["value"], d["roofline"]["us_per_update"], d["roofline"]["frac"], d["split_ms"]["train"]))
+except Exception as e:
+    print("ppo $tag unparsed", e)
+PY
+}
+case $S in
+tail1)    # fused optimiser tail (vf_mlp_weight_grad_adam): parity with the separate launches, then A/B of the PPO loop and kernel stats
+    timeout 900 python -m pytest tests/test_ppo_gpu.py -x -q -m gpu -k "fused_optimiser_tail or fused_tail or bitwise or fold_partials" 2>&1 | tail -15 | tee $O/pytest.txt
+    timeout 900 python -m pytest tests/test_ppo_loop_gpu.py -x -q -m gpu 2>&1 | tail -15 | tee $O/pytest_loop.txt
+    for ft in 1 0; do ppo_ab tail$ft VISFLY_AMD_FUSED_TAIL=$ft | tee -a $O/ab.txt; done
+    for ft in 1 0; do
+        VISFLY_AMD_FUSED_TAIL=$ft prof ppo_tail$ft timeout 300 python bench.py --workload ppo --no-cpu-baseline --steps 256
+    done
+    ;;
+tests)    # the whole GPU suite
+    timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $O/pytest.txt
+    ;;
+*) echo "unknown session $S"; exit 2 ;;
+esac

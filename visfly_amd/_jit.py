@@ -191,8 +191,14 @@ def build(shape, verbose=False, rollout=None):
         with ThreadPoolExecutor(max_workers=4) as pool:
             objs = list(pool.map(part, range(4) if rollout is None else [4]))
         tmp = f"{out}.{os.getpid()}.tmp"       # private name, then rename: concurrent builders (ranks) never see a torn file
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
-        os.replace(tmp, out)
+        try:
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"linking the chain plugin for {name_of(shape)} failed:\n{r.stderr[-4000:]}")
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
         for old in [] if os.environ.get("VISFLY_AMD_JIT_FLAGS") else os.listdir(JIT_DIR):          # builds of this shape against older headers
             stem = old[:-20] if len(old) > 20 else old          # libvf_chain_<slug>_<16 hex>.so
             if stem == f"libvf_chain_{_slug(shape, rollout)}" and old.endswith(".so") and old != os.path.basename(out):
@@ -213,10 +219,11 @@ def ensure(shape):
         return True
     if shape not in _loaded:
         from . import _lib
+        _loaded[shape] = None                # (a failed build is not repeated by every policy of this shape: ~40 s of hipcc each time)
         path = build(shape)
         _lib.check(_lib.lib().vf_chain_plugin_load(path.encode()))
         _loaded[shape] = path
-    return True
+    return _loaded[shape] is not None
 
 
 def ensure_rollout(shape, cfg):
@@ -237,6 +244,7 @@ def prebuild(verbose=False):
     """compile the PREBUILD shapes (in parallel) -> paths"""
     jobs = ([(shape_of(*v), None) for v in list(PREBUILD.values()) + list(PREBUILD_SAC.values())] +
             [(shape_of(*PREBUILD[n]), cfg) for n, cfg in PREBUILD_ROLLOUT])
-    with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+    # every chain job runs four hipcc parts of fully unrolled kernels: bound the number in flight by the cores of the build box
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), (os.cpu_count() or 4) // 4))) as pool:
         paths = list(pool.map(lambda j: build(j[0], verbose, rollout=j[1]), jobs))
     return paths

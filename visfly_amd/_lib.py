@@ -71,7 +71,7 @@ class DynCfg(C.Structure):
 
 
 EUNSUPPORTED = -4         # VF_EUNSUPPORTED
-ABI_VERSION = 9          # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
+ABI_VERSION = 10         # VF_ABI_VERSION of include/visfly_amd.h this binding mirrors
 MAX_GATES, MAX_SPAWN = 8, 4
 
 
@@ -188,6 +188,15 @@ class AdamCfg(C.Structure):
                 ("n_sumsq_partials", C.c_int32), ("sumsq_tail_from", C.c_int32)]
 
 
+class WgradTail(C.Structure):
+    """mirror of vf_wgrad_tail"""
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                ("adam", AdamCfg), ("sync", C.c_void_p)]
+
+
+WGRAD_SYNC_WORDS, WGRAD_SYNC_ABORT = 32, 2
+
+
 class VisflyError(RuntimeError):
     pass
 
@@ -282,6 +291,7 @@ SIGNATURES = {
     "vf_mlp_weight_grad": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vf_mlp_weight_grad_fold_blocks": (C.c_int32, [C.POINTER(MlpBwdDesc)]),
     "vf_mlp_weight_grad_sumsq": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(StatsFold), _vp]),
+    "vf_mlp_weight_grad_adam": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, C.POINTER(StatsFold), C.POINTER(WgradTail), _vp]),
     "vf_head_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "vf_ppo_loss": (C.c_int, [_vp] * 10 + [C.c_int32, C.POINTER(PpoLossCfg), _vp, _vp]),
     "vf_gather_rows": (C.c_int, [C.POINTER(GatherFields), _vp, C.c_int64, _vp]),

@@ -175,6 +175,8 @@ def _hyper(trainer) -> dict:
             "lr", "weight_decay", "adam_eps", "betas", "normalize_advantage", "target_kl", "seed", "H", "num_timesteps", "_opt_step",
             "clip_range_vf")
     out = {k: getattr(trainer, k) for k in keys if hasattr(trainer, k)}
+    # schedules (callables of progress_remaining) are archived as their current value: an archive holds data, not code
+    out = {k: (trainer._now(v) if callable(v) else v) for k, v in out.items()}
     out["learning_rate"] = out.pop("lr", None)
     out["algorithm"], out["policy_spec"] = type(trainer).__name__, trainer.policy.spec
     out["obs_dims"] = trainer.policy.obs_dims

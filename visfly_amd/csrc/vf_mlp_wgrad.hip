@@ -10,6 +10,7 @@
 // proportional to the layer's tile count); each wave writes one partial [No][K] + [No], and a table-driven fold sums
 // the partials of a layer in a fixed order (deterministic).
 #include "vf_common.hpp"
+#include "vf_adam_device.hpp"
 
 namespace vf {
 
@@ -185,12 +186,290 @@ __device__ __forceinline__ void wgrad_slab_pick(const vf_mlp_bwd_layer& L, int r
     wgrad_slab<NT, KT, false, false, SMALL>(L, r0, r1, part);
 }
 
+// ---- fold order (shared by k_wgrad_fold and the fused tail) ------------------------------------------------------------------------
+// element e of the layer's gradient = sum over the layer's waves of partial[w][e], in 32 chains: chain (q, u), q = 0..3, u = 0..7, takes
+// the partial rows w = q + 4 u + 32 k in ascending k; a q's chains combine as ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)), the four
+// q's as ((r0 + r1) + r2) + r3.  In k_wgrad_fold q is the wave of the block (the four combine through LDS); in the fused tail one lane
+// walks all 32 chains with rows past the layer read as +0 (adding +0 to a chain that started at +0 changes no bit).
+__device__ __forceinline__ float fold_chains_q(const float* __restrict__ p, size_t tot, int waves, int q)
+{
+    float s4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int w = q;
+    for (; w + 28 < waves; w += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s4[u] += p[(size_t)(w + 4 * u) * tot];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (w + 4 * u < waves) s4[u] += p[(size_t)(w + 4 * u) * tot];
+    return ((s4[0] + s4[1]) + (s4[2] + s4[3])) + ((s4[4] + s4[5]) + (s4[6] + s4[7]));
+}
+
+// statistic k of the loss-statistic partial rows (vf_ppo_update's scratch): 64 lanes stride over the rows, shuffle tree; lane 0 holds the
+// sum -- the order of k_fold_stats.  ROWS16: the caller's rows already in registers (fused tail: all statistics loaded in one batch)
+__device__ __forceinline__ float stats_fold_tree(float s)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    return s;
+}
+__device__ __forceinline__ float stats_fold_one(const vf_stats_fold& ls, int k, int lane)
+{
+    float s = 0.0f;
+    if (k < 9) {
+        // rows are at most 1024 in the common case (vf_ppo_update at <= 32 768 rows): all of a lane's loads are issued before the first add
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int b = lane + 64 * i;
+            v[i] = b < ls.n_rows ? ls.part[(size_t)b * 16 + k] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += (lane + 64 * i < ls.n_rows) ? v[i] : 0.0f;
+        for (int b = lane + 1024; b < ls.n_rows; b += 64) s += ls.part[(size_t)b * 16 + k];
+    }
+    return stats_fold_tree(s);
+}
+
+// ---- fused tail: fold -> squared norm -> clip -> Adam -> packed-weight refresh inside the weight-gradient launch ----------------------
+// The four launches of an optimiser step (chain, weight gradients, fold, Adam) were 105 us of kernels in 112 us: the fold (9.4 us) and Adam
+// (5.3 us) are latency, and every launch boundary costs ~1.8 us behind the dirty lines of the one before.  A lone workgroup cannot fold (the
+// partials are 20 MB: one wave reads ~6 GB/s), so the fold stays chip-wide: the waves of a LAYER meet at a counter once their partials are
+// out (release / acquire at agent scope: L2 write-back and invalidate across the 8 XCDs), every wave then folds 64 elements of its own
+// layer (all of its up-to-160 loads in flight at once), writes the gradient and the block's fp64 sum of squares; all waves meet once more,
+// add up the per-block sums in k_adam's order and run Adam on the elements they still hold.  Same reduction orders as the separate launches:
+// the two paths agree to the bit.  The launch needs every wave co-resident (1 024 waves of 512 VGPRs = one per SIMD): the host checks the
+// plan against the occupancy of this kernel on this device and answers VF_EUNSUPPORTED otherwise; a wave that waits longer than `timeout`
+// ticks of the 100 MHz clock raises sync[2] and every waiter leaves (the caller then sees VF_WGRAD_SYNC_ABORT set: hard error, no hang).
+struct WgradTail {
+    float* grad;
+    float* param;
+    float* m;
+    float* v;
+    double* sq_part;          // [n_fold_blocks]
+    unsigned* sync;           // [0] arrivals of the grid meeting, [1] generation, [2] abort, [4 + l] arrivals of layer l's meeting
+    vf_adam_cfg adam;
+    float step, bc2_sqrt;
+    vf_stats_fold ls;
+    int n, accumulate, n_fold_blocks, has_ls;
+    long long timeout;
+};
+
+__device__ __forceinline__ unsigned tail_peek(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <typename Pred>
+__device__ __forceinline__ bool tail_wait(Pred done, unsigned* abort_word, long long timeout)
+{
+    const long long t0 = wall_clock64();
+    for (int it = 1; !done(); ++it) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((it & 31) == 0) {
+            if (tail_peek(abort_word)) return false;
+            if (wall_clock64() - t0 > timeout) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return tail_peek(abort_word) == 0;
+}
+
+constexpr int kTailBatch = 5;      // partial rows fetched per round of the in-kernel fold: 32 x 5 = 160 loads in flight per lane
+
+__device__ __forceinline__ float tail_fold_element(__amdgpu_buffer_rsrc_t rs, unsigned e, unsigned tot, int waves)
+{
+    float s[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[q][u] = 0.0f;
+    for (int k0 = 0; 32 * k0 < waves; k0 += kTailBatch) {
+        float v[kTailBatch][4][8];
+#pragma unroll
+        for (int k = 0; k < kTailBatch; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {       // rows past the layer's block: the descriptor's range check answers +0
+                    const unsigned w = 32u * (unsigned)(k0 + k) + 4u * u + q;
+                    v[k][q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((w * tot + e) * 4u), 0, 0));
+                }
+#pragma unroll
+        for (int k = 0; k < kTailBatch; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[q][u] += v[k][q][u];
+    }
+    float r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = ((s[q][0] + s[q][1]) + (s[q][2] + s[q][3])) + ((s[q][4] + s[q][5]) + (s[q][6] + s[q][7]));
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
+
+__device__ __forceinline__ double bcast_lane0(double x)
+{
+    const unsigned long long b = __double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void wgrad_tail(const vf_mlp_bwd_desc& d, const WgradTable& t, float* __restrict__ partials, const WgradTail& T,
+                                        int l, int lw)
+{
+    const int lane = threadIdx.x & 63;
+    const int W = t.first_wave[l + 1] - t.first_wave[l], total = t.first_wave[t.n_layers];
+    const bool tail_wave = (int)blockIdx.x == total - 1;         // folds the loss statistics, owns the parameters the layers do not cover
+    unsigned* const abort_word = T.sync + 2;
+    const unsigned gen0 = tail_peek(T.sync + 1);
+    // (1) this wave's partial is out: meet the layer's other waves
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_fetch_add(T.sync + 4 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tail_wave && T.has_ls) {          // while the others arrive: the loss statistics (rows written by the launch before this one)
+        float st[16];
+        if (T.ls.n_rows <= 1024) {
+            float4 v[16][3];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = lane + 64 * i;
+                const float4* row = reinterpret_cast<const float4*>(T.ls.part + (size_t)(b < T.ls.n_rows ? b : 0) * 16);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[i][c] = row[c];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float4 x = v[i][k >> 2];
+                    const float xv = (k & 3) == 0 ? x.x : (k & 3) == 1 ? x.y : (k & 3) == 2 ? x.z : x.w;
+                    s += (lane + 64 * i < T.ls.n_rows) ? xv : 0.0f;
+                }
+                st[k] = stats_fold_tree(s);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) st[k] = stats_fold_one(T.ls, k, lane);
+        }
+#pragma unroll
+        for (int k = 9; k < 16; ++k) st[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st[k])));
+            if (lane == 0) {
+                T.ls.stats[k] = s;
+                if (T.ls.d_log_std_out && k >= 5 && k < 9) T.ls.d_log_std_out[k - 5] = s;
+                if (T.ls.stats_accum) T.ls.stats_accum[k] += s;
+            }
+        }
+    }
+    if (!tail_wait([&] { return tail_peek(T.sync + 4 + l) >= (unsigned)W; }, abort_word, T.timeout)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (2) fold: block b of the layer = 64 consecutive elements of its partial row, as k_wgrad_fold's block
+    const vf_mlp_bwd_layer& L = d.layer[l];
+    const int tot = wgrad_partial_size(L), nb_l = (tot + 63) / 64;
+    int blk0 = 0;
+    for (int i = 0; i < l; ++i) blk0 += (wgrad_partial_size(d.layer[i]) + 63) / 64;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(partials + t.part_off[l], 0, (int)((size_t)W * tot * 4), 0x00020000);
+    const int nw = L.K * L.No;
+    float g0 = 0.0f, p0 = 0.0f, m0 = 0.0f, v0 = 0.0f;
+    long i0 = -1;
+    for (int b = lw; b < nb_l; b += W) {
+        const int e = b * 64 + lane;
+        const int prm = e < tot ? wgrad_param_of(L, e) : -1;
+        const long idx = prm < 0 ? -1 : prm < nw ? L.w_off + prm : L.b_off + (prm - nw);
+        float gold = 0.0f;
+        if (idx >= 0 && T.accumulate) gold = T.grad[idx];
+        if (b == lw && idx >= 0) { i0 = idx; p0 = T.param[idx]; m0 = T.m[idx]; v0 = T.v[idx]; }     // requested ahead of the fold's loads
+        const float vsum = tail_fold_element(rs, (unsigned)(e < tot ? e : 0), (unsigned)tot, W);
+        double sq = 0.0;
+        if (idx >= 0) {
+            const float nv = T.accumulate ? gold + vsum : vsum;
+            T.grad[idx] = nv;
+            sq = (double)nv * (double)nv;
+            if (b == lw) g0 = nv;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+        if (lane == 0) T.sq_part[blk0 + b] = sq;
+    }
+    // the uncovered parameters [sumsq_tail_from, n): their gradients are the loss statistics' d_log_std (folded above) or what the caller
+    // left in grad; the tail wave owns them
+    const int tail_from = T.adam.sumsq_tail_from;
+    // (3) all gradients and per-block sums are out: meet everybody
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) {
+        const unsigned old = __hip_atomic_fetch_add(T.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)total - 1u) {     // last arrival: every wave is past its layer's meeting -> reset the counters for the next launch
+            for (int i = 0; i < t.n_layers; ++i) __hip_atomic_store(T.sync + 4 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(T.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(T.sync + 1, gen0 + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!tail_wait([&] { return tail_peek(T.sync + 1) != gen0; }, abort_word, T.timeout)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (4) squared norm: k_adam's order -- "thread" 64 q + lane of its 256 sums the partials 64 q + lane + 256 j, then the uncovered tail
+    float coef = 1.0f;
+    if (T.adam.max_grad_norm > 0.0f) {
+        double a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 64 * q + lane + 256 * j;
+                x[j] = i < T.n_fold_blocks ? T.sq_part[i] : 0.0;
+            }
+            a[q] = ((0.0 + x[0]) + x[1]) + x[2];
+            a[q] += x[3];
+            for (int i = 64 * q + lane + 1024; i < T.n_fold_blocks; i += 256) a[q] += T.sq_part[i];
+            for (long i = tail_from + 64 * q + lane; i < T.n; i += 256) a[q] += (double)T.grad[i] * (double)T.grad[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o, 64);
+            a[q] = bcast_lane0(a[q]);
+        }
+        coef = adam_clip_coef((float)((a[0] + a[1]) + (a[2] + a[3])), T.adam.max_grad_norm);
+    }
+    // (5) Adam on the elements this wave folded (+ the uncovered tail on the tail wave)
+    if (i0 >= 0) {
+        const float pn = adam_param(p0, g0, m0, v0, coef, T.adam, T.step, T.bc2_sqrt);
+        T.m[i0] = m0;
+        T.v[i0] = v0;
+        T.param[i0] = pn;
+        if (T.adam.pack_map) adam_refresh_packed(T.adam, i0, pn);
+    }
+    for (int b = lw + W; b < nb_l; b += W) {
+        const int e = b * 64 + lane;
+        const int prm = e < tot ? wgrad_param_of(L, e) : -1;
+        if (prm < 0) continue;
+        const long idx = prm < nw ? L.w_off + prm : L.b_off + (prm - nw);
+        float mi = T.m[idx], vi = T.v[idx];
+        const float pn = adam_param(T.param[idx], T.grad[idx], mi, vi, coef, T.adam, T.step, T.bc2_sqrt);
+        T.m[idx] = mi;
+        T.v[idx] = vi;
+        T.param[idx] = pn;
+        if (T.adam.pack_map) adam_refresh_packed(T.adam, idx, pn);
+    }
+    if (tail_wave) {
+        for (long i = tail_from + lane; i < T.n; i += 64) {
+            float mi = T.m[i], vi = T.v[i];
+            const float pn = adam_param(T.param[i], T.grad[i], mi, vi, coef, T.adam, T.step, T.bc2_sqrt);
+            T.m[i] = mi;
+            T.v[i] = vi;
+            T.param[i] = pn;
+            if (T.adam.pack_map) adam_refresh_packed(T.adam, i, pn);
+        }
+    }
+}
+
 // SMALL: every layer of the table has at most 8 accumulator tiles (the reference-default policies: 128 -> 64 is the largest layer), so
 // a wave fits 256 VGPRs and TWO waves share a SIMD -- the launch streams X / dZ and is bound by how much of that is in flight
-template <bool SMALL>
-__global__ __launch_bounds__(64, SMALL ? 2 : 1) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const WgradTable t, float* __restrict__ partials, int M)
+// TAIL: the fold, the gradient norm, the clip and Adam happen in this launch (wgrad_tail)
+template <bool SMALL, bool TAIL>
+__global__ __launch_bounds__(64, SMALL ? 2 : 1) void k_mlp_wgrad(const vf_mlp_bwd_desc d, const WgradTable t, float* __restrict__ partials, int M,
+                                                                 const WgradTail tail)
 {
-    prefetch_kernarg<sizeof(vf_mlp_bwd_desc) + sizeof(WgradTable) + 16>();
+    prefetch_kernarg<sizeof(vf_mlp_bwd_desc) + sizeof(WgradTable) + 16 + (TAIL ? sizeof(WgradTail) : 0)>();
     const int w = blockIdx.x;
     int l = 0;
     while (l + 1 < t.n_layers && w >= t.first_wave[l + 1]) ++l;
@@ -201,32 +480,33 @@ __global__ __launch_bounds__(64, SMALL ? 2 : 1) void k_mlp_wgrad(const vf_mlp_bw
     const int NT = (L.No + 31) >> 5, KT = (L.K + 31) >> 5;
     if (r0 >= r1) {        // empty slab (rounding): the fold still reads this partial
         for (int i = threadIdx.x; i < wgrad_partial_size(L); i += 64) part[i] = 0.0f;
-        return;
-    }
-    switch (NT * 4 + KT - 5) {
-    case 0: wgrad_slab_pick<1, 1, SMALL>(L, r0, r1, part); break;
-    case 1: wgrad_slab_pick<1, 2, SMALL>(L, r0, r1, part); break;
-    case 2: wgrad_slab_pick<1, 3, SMALL>(L, r0, r1, part); break;
-    case 3: wgrad_slab_pick<1, 4, SMALL>(L, r0, r1, part); break;
-    case 4: wgrad_slab_pick<2, 1, SMALL>(L, r0, r1, part); break;
-    case 5: wgrad_slab_pick<2, 2, SMALL>(L, r0, r1, part); break;
-    case 6: wgrad_slab_pick<2, 3, SMALL>(L, r0, r1, part); break;
-    case 7: wgrad_slab_pick<2, 4, SMALL>(L, r0, r1, part); break;
-    case 8: wgrad_slab_pick<3, 1, SMALL>(L, r0, r1, part); break;
-    case 9: wgrad_slab_pick<3, 2, SMALL>(L, r0, r1, part); break;
-    case 12: wgrad_slab_pick<4, 1, SMALL>(L, r0, r1, part); break;
-    case 13: wgrad_slab_pick<4, 2, SMALL>(L, r0, r1, part); break;
-    default:
-        if constexpr (!SMALL) {
-            switch (NT * 4 + KT - 5) {
-            case 10: wgrad_slab_pick<3, 3, SMALL>(L, r0, r1, part); break;
-            case 11: wgrad_slab_pick<3, 4, SMALL>(L, r0, r1, part); break;
-            case 14: wgrad_slab_pick<4, 3, SMALL>(L, r0, r1, part); break;
-            default: wgrad_slab_pick<4, 4, SMALL>(L, r0, r1, part); break;
+    } else {
+        switch (NT * 4 + KT - 5) {
+        case 0: wgrad_slab_pick<1, 1, SMALL>(L, r0, r1, part); break;
+        case 1: wgrad_slab_pick<1, 2, SMALL>(L, r0, r1, part); break;
+        case 2: wgrad_slab_pick<1, 3, SMALL>(L, r0, r1, part); break;
+        case 3: wgrad_slab_pick<1, 4, SMALL>(L, r0, r1, part); break;
+        case 4: wgrad_slab_pick<2, 1, SMALL>(L, r0, r1, part); break;
+        case 5: wgrad_slab_pick<2, 2, SMALL>(L, r0, r1, part); break;
+        case 6: wgrad_slab_pick<2, 3, SMALL>(L, r0, r1, part); break;
+        case 7: wgrad_slab_pick<2, 4, SMALL>(L, r0, r1, part); break;
+        case 8: wgrad_slab_pick<3, 1, SMALL>(L, r0, r1, part); break;
+        case 9: wgrad_slab_pick<3, 2, SMALL>(L, r0, r1, part); break;
+        case 12: wgrad_slab_pick<4, 1, SMALL>(L, r0, r1, part); break;
+        case 13: wgrad_slab_pick<4, 2, SMALL>(L, r0, r1, part); break;
+        default:
+            if constexpr (!SMALL) {
+                switch (NT * 4 + KT - 5) {
+                case 10: wgrad_slab_pick<3, 3, SMALL>(L, r0, r1, part); break;
+                case 11: wgrad_slab_pick<3, 4, SMALL>(L, r0, r1, part); break;
+                case 14: wgrad_slab_pick<4, 3, SMALL>(L, r0, r1, part); break;
+                default: wgrad_slab_pick<4, 4, SMALL>(L, r0, r1, part); break;
+                }
             }
+            break;
         }
-        break;
     }
+    if constexpr (TAIL) wgrad_tail(d, t, partials, tail, l, lw);
 }
 
 // grad (+)= sum over the layer's waves of partial[wave][e]; 64 consecutive partial elements per block, the 4 waves of
@@ -239,22 +519,8 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, 
     __shared__ float red[4][64];
     if ((int)blockIdx.x >= n_param_blocks) {     // the extra block: loss-statistic partial rows (vf_ppo_update) -> stats
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        for (int k = w; k < 16; k += 4) {         // 64 lanes stride over the rows, shuffle tree: the order of k_fold_stats
-            float s = 0.0f;
-            if (k < 9) {
-                // rows are at most 1024 (vf_ppo_update's contract): all of a lane's loads are issued before the first add
-                float v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int b = lane + 64 * i;
-                    v[i] = b < ls.n_rows ? ls.part[(size_t)b * 16 + k] : 0.0f;
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s += (lane + 64 * i < ls.n_rows) ? v[i] : 0.0f;
-                for (int b = lane + 1024; b < ls.n_rows; b += 64) s += ls.part[(size_t)b * 16 + k];
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        for (int k = w; k < 16; k += 4) {
+            const float s = stats_fold_one(ls, k, lane);
             if (lane == 0) {
                 ls.stats[k] = s;
                 if (ls.d_log_std_out && k >= 5 && k < 9) ls.d_log_std_out[k - 5] = s;
@@ -275,17 +541,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_fold(const vf_mlp_bwd_desc d, 
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, e = b * 64 + lane;
     const int prm = e < tot ? wgrad_param_of(L, e) : -1;
     float s = 0.0f;
-    if (prm >= 0) {
-        const float* p = partials + t.part_off[l] + e;
-        float s4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int w = q;
-        for (; w + 28 < waves; w += 32) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s4[u] += p[(size_t)(w + 4 * u) * tot];
-        }
-        for (; w < waves; w += 4) s4[0] += p[(size_t)w * tot];
-        s = ((s4[0] + s4[1]) + (s4[2] + s4[3])) + ((s4[4] + s4[5]) + (s4[6] + s4[7]));
-    }
+    if (prm >= 0) s = fold_chains_q(partials + t.part_off[l] + e, (size_t)tot, waves, q);
     red[q][lane] = s;
     __syncthreads();
     double sq = 0.0;
@@ -319,7 +575,8 @@ bool wgrad_small(const vf_mlp_bwd_desc& d, int M)
     return true;
 }
 
-// waves per layer proportional to its MFMA count per row pair; -> total waves, partial floats
+// waves per layer proportional to its MFMA count per row pair; -> total waves, partial floats.  The total never exceeds the budget
+// (1 024 SIMDs x waves per SIMD): the fused tail needs every wave of the launch resident at once
 int64_t wgrad_plan(const vf_mlp_bwd_desc& d, int M, WgradTable& t, int* total_waves)
 {
     int tiles[VF_MLP_MAX_LAYERS], sum = 0;
@@ -327,26 +584,28 @@ int64_t wgrad_plan(const vf_mlp_bwd_desc& d, int M, WgradTable& t, int* total_wa
         tiles[l] = ((d.layer[l].No + 31) >> 5) * ((d.layer[l].K + 31) >> 5) + 2;   // + per-row-pair overhead (loads, guards) in MFMA units
         sum += tiles[l];
     }
-    const int budget = wgrad_small(d, M) ? 2048 : 1024;   // waves per SIMD x 1024 SIMDs
+    const int cap = wgrad_small(d, M) ? 2048 : 1024;   // waves per SIMD x 1024 SIMDs
     t.n_layers = d.n_layers;
-    int w = 0;
-    int64_t off = 0;
-    for (int l = 0; l < d.n_layers; ++l) {
-        int nw = (int)(((int64_t)budget * tiles[l] + sum / 2) / sum);
-        if (nw < 1) nw = 1;
-        int rows = (M + nw - 1) / nw;
-        rows = (rows + 1) & ~1;
-        if (rows < 2) rows = 2;
-        nw = (M + rows - 1) / rows;
-        t.first_wave[l] = w;
-        t.rows_per_wave[l] = rows;
-        t.part_off[l] = off;
-        w += nw;
-        off += (int64_t)nw * wgrad_partial_size(d.layer[l]);
+    for (int budget = cap;; budget -= 8) {
+        int w = 0;
+        int64_t off = 0;
+        for (int l = 0; l < d.n_layers; ++l) {
+            int nw = (int)(((int64_t)budget * tiles[l] + sum / 2) / sum);
+            if (nw < 1) nw = 1;
+            int rows = (M + nw - 1) / nw;
+            rows = (rows + 1) & ~1;
+            if (rows < 2) rows = 2;
+            nw = (M + rows - 1) / rows;
+            t.first_wave[l] = w;
+            t.rows_per_wave[l] = rows;
+            t.part_off[l] = off;
+            w += nw;
+            off += (int64_t)nw * wgrad_partial_size(d.layer[l]);
+        }
+        t.first_wave[d.n_layers] = w;
+        *total_waves = w;
+        if (w <= cap || budget <= 8) return off;
     }
-    t.first_wave[d.n_layers] = w;
-    *total_waves = w;
-    return off;
 }
 
 int64_t mlp_wgrad_partial_floats(const vf_mlp_bwd_desc* d, int M)
@@ -369,14 +628,68 @@ int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int
     WgradTable t;
     int waves = 0;
     wgrad_plan(*d, M, t, &waves);
-    if (wgrad_small(*d, M)) hipLaunchKernelGGL(k_mlp_wgrad<true>, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
-    else hipLaunchKernelGGL(k_mlp_wgrad<false>, dim3(waves), dim3(64), 0, st, *d, t, partials, M);
+    if (wgrad_small(*d, M)) hipLaunchKernelGGL((k_mlp_wgrad<true, false>), dim3(waves), dim3(64), 0, st, *d, t, partials, M, WgradTail{});
+    else hipLaunchKernelGGL((k_mlp_wgrad<false, false>), dim3(waves), dim3(64), 0, st, *d, t, partials, M, WgradTail{});
     const int nb = mlp_wgrad_fold_blocks(d);
     const vf_stats_fold ls = loss_stats ? *loss_stats : vf_stats_fold{};
     hipLaunchKernelGGL(k_wgrad_fold, dim3(nb + (loss_stats ? 1 : 0)), dim3(kBlock), 0, st, *d, t, (const float*)partials, grad, accumulate,
                        sq_part, ls, nb);
     VF_HIP(hipGetLastError());
     return VF_OK;
+}
+
+// waves of k_mlp_wgrad<false, true> the device holds at once (occupancy of THIS kernel x compute units), per device; 0: unknown
+static int wgrad_tail_capacity()
+{
+    static int cap[64];
+    static bool known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!known[dev]) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_mlp_wgrad<false, true>), 64, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            cap[dev] = per_cu * cus;
+        known[dev] = true;
+    }
+    return cap[dev];
+}
+
+// 1: launched (weight gradients + fold + norm + clip + Adam in ONE launch), 0: this layer table / row count / device cannot (the caller
+// runs mlp_wgrad_launch + k_adam), < 0: error
+int mlp_wgrad_adam_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, const vf_stats_fold* loss_stats,
+                          const vf_wgrad_tail* tl, hipStream_t st)
+{
+    static const int enabled = [] { const char* e = getenv("VISFLY_AMD_FUSED_TAIL"); return e ? atoi(e) : 1; }();
+    if (!enabled) return fail(0, "fused optimiser tail switched off (VISFLY_AMD_FUSED_TAIL=0)");
+    if (wgrad_small(*d, M)) return fail(0, "fused optimiser tail: streaming row counts (two waves per SIMD) use the separate fold");
+    WgradTable t;
+    int waves = 0;
+    wgrad_plan(*d, M, t, &waves);
+    const int cap = wgrad_tail_capacity();
+    if (waves > cap) return fail(0, "fused optimiser tail: %d waves do not fit the device at once (%d)", waves, cap);
+    WgradTail T{};
+    T.grad = grad;
+    T.param = tl->param;
+    T.m = tl->exp_avg;
+    T.v = tl->exp_avg_sq;
+    T.sq_part = const_cast<double*>(tl->adam.sumsq_partials);
+    T.sync = tl->sync;
+    T.adam = tl->adam;
+    float bc1, bc2s;
+    adam_bias(tl->adam, &bc1, &bc2s);
+    T.step = tl->adam.lr / bc1;
+    T.bc2_sqrt = bc2s;
+    if (loss_stats) T.ls = *loss_stats;
+    T.has_ls = loss_stats ? 1 : 0;
+    T.n = (int)tl->n;
+    T.accumulate = accumulate;
+    T.n_fold_blocks = mlp_wgrad_fold_blocks(d);
+    static const long long timeout = [] { const char* e = getenv("VISFLY_AMD_FUSED_TAIL_TIMEOUT_MS"); return (long long)(e ? atoi(e) : 2000) * 100000LL; }();
+    T.timeout = timeout;        // ticks of the 100 MHz wall clock
+    hipLaunchKernelGGL((k_mlp_wgrad<false, true>), dim3(waves), dim3(64), 0, st, *d, t, partials, M, T);
+    VF_HIP(hipGetLastError());
+    return 1;
 }
 
 }  // namespace vf

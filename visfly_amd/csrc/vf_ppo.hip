@@ -12,6 +12,7 @@
 #include <utility>
 
 #include "vf_common.hpp"
+#include "vf_adam_device.hpp"
 #include "vf_ppo_device.hpp"
 #include "vf_env_device.hpp"  // Philox
 
@@ -1349,28 +1350,16 @@ __global__ __launch_bounds__(kBlock) void k_adam(float* __restrict__ p, const fl
         } else {
             ss = *sumsq;
         }
-        const float total = sqrtf(ss);
-        coef = fminf(c.max_grad_norm / (total + 1e-6f), 1.0f);
+        coef = adam_clip_coef(ss, c.max_grad_norm);
     }
     const float step = c.lr / bc1;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
-        const float pi = p[i];
-        float gi = g[i] * coef;
-        gi = gi + c.weight_decay * pi;
-        const float mi = c.beta1 * m[i] + (1.0f - c.beta1) * gi;
-        const float vi = c.beta2 * v[i] + (1.0f - c.beta2) * gi * gi;
+        float mi = m[i], vi = v[i];
+        const float pn = adam_param(p[i], g[i], mi, vi, coef, c, step, bc2_sqrt);       // vf_adam_device.hpp
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
-        const float pn = pi - step * (mi / denom);
         p[i] = pn;
-        if (c.pack_map) {   // keep the packed MFMA images of the weights current (vf_mlp_pack_weights layout)
-            const int4 o = reinterpret_cast<const int4*>(c.pack_map)[i];
-            if (o.x >= 0) c.packed[o.x] = pn;
-            if (o.y >= 0) c.packed[o.y] = pn;
-            if (o.z >= 0) c.packed[o.z] = pn;
-            if (o.w >= 0) c.packed[o.w] = pn;
-        }
+        if (c.pack_map) adam_refresh_packed(c, i, pn);
     }
 }
 
@@ -1776,6 +1765,23 @@ int vf_mlp_weight_grad_sumsq(const vf_mlp_bwd_desc* desc, float* partials, float
     return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, sumsq_partials, loss_stats, vf::as_stream(stream));
 }
 
+int vf_mlp_weight_grad_adam(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
+                            const vf_stats_fold* loss_stats, const vf_wgrad_tail* tail, vf_stream_t stream)
+{
+    if (!partials || !grad || !tail || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_adam: bad argument");
+    if (!tail->param || !tail->exp_avg || !tail->exp_avg_sq || !tail->sync || !tail->adam.sumsq_partials || tail->n <= 0 ||
+        tail->adam.step <= 0 || tail->adam.sumsq_tail_from < 0 || tail->adam.sumsq_tail_from > tail->n)
+        return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_adam: bad tail");
+    if ((tail->adam.pack_map == nullptr) != (tail->adam.packed == nullptr))
+        return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_adam: pack_map and packed must be given together");
+    if (loss_stats && (!loss_stats->part || !loss_stats->stats || loss_stats->n_rows < 1 || (reinterpret_cast<uintptr_t>(loss_stats->part) & 15)))
+        return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_adam: bad loss_stats (part: 16-byte aligned rows)");
+    if (int rc = check_bwd_desc(desc, "vf_mlp_weight_grad_adam")) return rc;
+    const int rc = vf::mlp_wgrad_adam_launch(desc, partials, grad, M, accumulate, loss_stats, tail, vf::as_stream(stream));
+    if (rc < 0) return rc;
+    return rc == 1 ? VF_OK : VF_EUNSUPPORTED;      // the reason is in vf_last_error()
+}
+
 int vf_reparam_fwd(const float* mean, const float* log_std, const float* eps, float* action, int32_t N, vf_stream_t stream)
 {
     if (!mean || !log_std || !eps || !action || N <= 0) return vf::fail(VF_EINVAL, "vf_reparam_fwd: bad argument");
@@ -1967,10 +1973,10 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
         return vf::fail(VF_EINVAL, "vf_adam_step: bad argument");
     if ((cfg->pack_map == nullptr) != (cfg->packed == nullptr))
         return vf::fail(VF_EINVAL, "vf_adam_step: pack_map and packed must be given together");
-    const float bc1 = 1.0f - (float)pow((double)cfg->beta1, (double)cfg->step);
-    const float bc2 = 1.0f - (float)pow((double)cfg->beta2, (double)cfg->step);
+    float bc1, bc2_sqrt;
+    vf::adam_bias(*cfg, &bc1, &bc2_sqrt);
     hipLaunchKernelGGL(vf::k_adam, dim3(vf::grid_for(n, 1024)), dim3(vf::kBlock), 0, vf::as_stream(stream), param, grad, exp_avg,
-                       exp_avg_sq, (long)n, grad_sumsq, *cfg, bc1, sqrtf(bc2));
+                       exp_avg_sq, (long)n, grad_sumsq, *cfg, bc1, bc2_sqrt);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }

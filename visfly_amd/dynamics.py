@@ -280,6 +280,14 @@ class Dynamics:
             th.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x.pow(2) + y.pow(2))])])
 
     @property
+    def xz_axis(self):
+        """rows 0 and 2 of ``R`` as the reference's Quaternion.xz_axis returns them, (2, 3, N) (dynamics.py:824-826, maths.py:134-151)"""
+        w, x, y, z = self._gran(G_QUAT).T
+        return th.stack([
+            th.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)]),
+            th.stack([2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)])])
+
+    @property
     def velocity(self):
         return self._vec(G_VEL) + self._wind
 

@@ -162,6 +162,7 @@ class MlpPolicy:
         self._pack_map = None
         self._pi_only_ok = True
         self._fused_ppo = None             # None: untried, False: vf_ppo_update does not support this network
+        self._tail_ok, self.tail_reason = None, ""      # False: vf_mlp_weight_grad_adam declined (reason kept)
         self._fused_twin_q = None          # the same for vf_twin_q_update (a twin critic's fused update step)
         self._steps_ok, self._steps_out = None, {}      # vf_mlp_forward_steps (forward_steps)
         self._act_fused = None             # likewise for vf_mlp_forward_act
@@ -619,11 +620,14 @@ class MlpPolicy:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
         _lib.check(L.vf_mlp_weight_grad(C.byref(d), _ptr(self._scratch), _ptr(self.grad), n * M, 1 if accumulate else 0, self._stream()))
 
-    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch, want_sumsq=False, row_index=None):
+    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch, want_sumsq=False, row_index=None, tail=None):
         """forward + PPO loss + reverse chain in one launch, then the weight gradients into ``self.grad`` (vf_ppo_update +
         vf_mlp_weight_grad).  -> False when the network is not one of the register-chained classes (the caller then
         runs forward / vf_ppo_loss / backward).  ``want_sumsq``: -> (fp64 partials tensor, count) of the squared norm of the
         gradient the fold wrote, for vf_adam_cfg.sumsq_partials (no separate grad-norm launch).
+        ``tail`` (a ``_lib.WgradTail``: parameters, Adam moments and configuration, sync words): the weight-gradient launch also folds,
+        forms the gradient norm, clips and runs Adam (vf_mlp_weight_grad_adam: the optimiser step is TWO launches) -> "adam"; when the
+        library declines (VF_EUNSUPPORTED) the call continues as ``want_sumsq`` and the caller runs vf_adam_step.
         ``row_index`` (int64, M entries; vf_ppo_loss_cfg.row_index): obs / actions / old_lp / ret (and loss_cfg.old_value) are the
         WHOLE rollout buffer and row m of the minibatch is their row row_index[m] -- no shuffled copy; ``adv`` stays in minibatch order."""
         if self._fused_ppo is False or self._plan is None or not (self.fused and self.fused_backward):
@@ -673,6 +677,7 @@ class MlpPolicy:
         ins = [_ptr(whole[k] if row_index is not None else b["obs:" + k]) for k in self.obs_keys] + [None] * (2 - len(self.obs_keys))
         self._pack()
         # want_sumsq: the loss-statistic rows are folded by the weight-gradient fold launch (one launch less)
+        want_sumsq = want_sumsq or tail is not None
         rc = L.vf_ppo_update(C.byref(d), C.byref(bd), _ptr(self.flat), _ptr(self._packed), ins[0], ins[1], _ptr(self.log_std),
                              _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret), None if want_sumsq else _ptr(stats), M,
                              C.byref(loss_cfg), _ptr(loss_scratch), st)
@@ -690,6 +695,15 @@ class MlpPolicy:
             if self._sq_part is None or self._sq_part.numel() < nb:
                 self._sq_part = th.empty(nb, dtype=th.float64, device=self.device)
             ls = _lib.StatsFold(_ptr(loss_scratch), (M + 31) // 32, 0, _ptr(stats), loss_cfg.d_log_std_out, loss_cfg.stats_accum)
+            if tail is not None and self._tail_ok is not False:
+                tail.adam.sumsq_partials = self._sq_part.data_ptr()
+                rc = L.vf_mlp_weight_grad_adam(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, C.byref(ls), C.byref(tail), st)
+                if rc == 0:
+                    return "adam"
+                if rc != _lib.EUNSUPPORTED:
+                    _lib.check(rc)
+                self._tail_ok = False          # the library said why (vf_last_error); the separate fold + Adam launches from here on
+                self.tail_reason = L.vf_last_error().decode()
             _lib.check(L.vf_mlp_weight_grad_sumsq(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, self._sq_part.data_ptr(),
                                                   C.byref(ls), st))
             return self._sq_part, nb
@@ -869,11 +883,14 @@ class PPO:
         self.device = env.device
         self.n_envs = env.num_envs
         self.n_steps, self.batch_size, self.n_epochs = n_steps, batch_size, n_epochs
+        # learning_rate / clip_range / clip_range_vf: a float or, as SB3's get_schedule_fn accepts them, a callable of
+        # progress_remaining (1 at the start of learn(), 0 at its end; PPO.py:150-152,184-189) evaluated once per train() call
         self.gamma, self.gae_lambda, self.clip_range = gamma, gae_lambda, clip_range
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
-        self.lr, self.weight_decay, self.adam_eps, self.betas = learning_rate, weight_decay, adam_eps, betas
+        self.lr_schedule, self.weight_decay, self.adam_eps, self.betas = learning_rate, weight_decay, adam_eps, betas
         self.normalize_advantage, self.target_kl, self.seed = normalize_advantage, target_kl, seed
         self.clip_range_vf = clip_range_vf                          # PPO.py:237-243; None = no value clipping
+        self._current_progress_remaining = 1.0
         # TimeLimit bootstrap valued once per rollout (collect_rollouts) from the terminal rows the step kernel wrote; envs that
         # assemble their observation on the host (RacingEnv2: 16 gate-relative columns) have no such kernel rows -> valued per step
         self.defer_bootstrap, self._boot = not getattr(env, "_HOST_OBS", False), None
@@ -910,15 +927,33 @@ class PPO:
         self._sumsq = th.zeros(1, device=dev)
         self._sums = th.zeros(2, dtype=th.float64, device=dev)
         self._opt_step = 0
+        self._n_updates = 0            # SB3's counter: epochs (PPO.py:294), what train/n_updates logs
         self._sample_step = 0
         self.num_timesteps = 0
         self._last_starts = th.ones(self.n_envs, device=dev)
         self._shuf = None
+        # fold + gradient norm + clip + Adam inside the weight-gradient launch (vf_mlp_weight_grad_adam): single-GPU steps without a
+        # target_kl check between backward and optimizer.step(); VISFLY_AMD_FUSED_TAIL=0 switches it off in the library
+        self.fused_tail = True
+        self._tail_sync = th.zeros(_lib.WGRAD_SYNC_WORDS, dtype=th.int32, device=dev)
+        self._tail_launches = 0
         self.index_minibatches = False     # True: train() reads its minibatches through the permutation slice (vf_ppo_loss_cfg.row_index) instead of a shuffled copy -- measured 2 % slower, see train()
         self.logs: Dict[str, float] = {}
 
     def _stream(self):
         return _lib.current_stream(self.device)
+
+    def _now(self, v):
+        """a schedule's value at the current progress_remaining (floats are constant schedules)"""
+        return None if v is None else float(v(self._current_progress_remaining) if callable(v) else v)
+
+    @property
+    def lr(self):
+        return self._now(self.lr_schedule)
+
+    @lr.setter
+    def lr(self, v):
+        self.lr_schedule = v
 
     def _bootstrap_list(self):
         """compact list of the rollout's truncated rows (vf_rollout_post_collect): an agent is truncated at most once per
@@ -1063,18 +1098,29 @@ class PPO:
         # the loss launch also writes d(loss)/d(log_std) into the tail of the flat gradient and adds the minibatch
         # statistics to the epoch accumulator (no separate copy / add launches)
         vclip = self.clip_range_vf is not None
-        cfg = _lib.PpoLossCfg(self.clip_range, self.ent_coef, self.vf_coef, 1.0 / gB, _ptr(pol.grad, pol.log_std_off),
+        cfg = _lib.PpoLossCfg(self._now(self.clip_range), self.ent_coef, self.vf_coef, 1.0 / gB, _ptr(pol.grad, pol.log_std_off),
                               None if stats_acc is None else _ptr(stats_acc),
-                              _ptr(mb["old_v"]) if vclip else None, float(self.clip_range_vf) if vclip else 0.0, 0)
+                              _ptr(mb["old_v"]) if vclip else None, self._now(self.clip_range_vf) if vclip else 0.0, 0)
         # reference-default policy shapes: forward + loss + reverse chain are one launch (vf_ppo_update)
         # single GPU: the weight-gradient fold also leaves the squared gradient norm as partial sums, which Adam adds up itself
-        res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch, want_sumsq=self.world == 1, row_index=rows)
+        tail = None
+        if self.fused_tail and self.world == 1 and self.target_kl is None:
+            pmap, packed = pol.pack_map()
+            tail = _lib.WgradTail(_ptr(pol.flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params, self._adam_cfg(self._opt_step + 1, pmap, packed, None),
+                                  self._tail_sync.data_ptr())
+        res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch, want_sumsq=self.world == 1, row_index=rows, tail=tail)
+        if res == "adam":        # the optimiser step happened inside the weight-gradient launch
+            self._opt_step += 1
+            self._tail_launches += 1
+            pol.mark_updated(packed_current=pmap is not None)
+            return self._stats
         sq = res if isinstance(res, tuple) else None
         if res is False and rows is not None:       # no fused step for this network: materialise the minibatch (what the gather did)
             obs = {k: v.index_select(0, rows) for k, v in obs.items()}
             actions, old_lp, ret = actions.index_select(0, rows), old_lp.index_select(0, rows), ret.index_select(0, rows)
             if vclip:
-                cfg.old_value = _ptr(mb["old_v"].index_select(0, rows))
+                old_v_sel = mb["old_v"].index_select(0, rows)       # bound to a name: it must outlive vf_ppo_loss (cfg holds its raw pointer)
+                cfg.old_value = _ptr(old_v_sel)
             cfg.row_index, cfg.obs_copy0, cfg.obs_copy1 = None, None, None
         if res is False:
             mean, value = pol.forward(obs)
@@ -1096,14 +1142,25 @@ class PPO:
         if sq is None:
             _lib.check(L.vf_sumsq(_ptr(pol.grad), pol.n_params, _ptr(self._sumsq), _ptr(self._scratch), st))
         pmap, packed = pol.pack_map()          # Adam refreshes the packed MFMA weight images in the same launch
-        acfg = _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, self.weight_decay,
-                            self.max_grad_norm if self.max_grad_norm is not None else 0.0, self._opt_step, 0,
-                            _ptr(pmap), _ptr(packed), None if sq is None else sq[0].data_ptr(), 0 if sq is None else sq[1],
-                            pol.log_std_off)
+        acfg = self._adam_cfg(self._opt_step, pmap, packed, sq)
         _lib.check(L.vf_adam_step(_ptr(pol.flat), _ptr(pol.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params,
                                   _ptr(self._sumsq), C.byref(acfg), st))
         pol.mark_updated(packed_current=pmap is not None)
         return self._stats
+
+    def _adam_cfg(self, step, pmap, packed, sq):
+        return _lib.AdamCfg(self.lr, self.betas[0], self.betas[1], self.adam_eps, self.weight_decay,
+                            self.max_grad_norm if self.max_grad_norm is not None else 0.0, step, 0,
+                            _ptr(pmap), _ptr(packed), None if sq is None else sq[0].data_ptr(), 0 if sq is None else sq[1],
+                            self.policy.log_std_off)
+
+    def _check_tail(self):
+        """the fused optimiser tail's waves meet at device counters; one that waited past the time limit raised the abort word and the
+        update did not happen -- a hard error, reported at the trainer's next host synchronisation"""
+        if self._tail_launches and int(self._tail_sync[_lib.WGRAD_SYNC_ABORT].item()):
+            self._tail_sync.zero_()
+            raise _lib.VisflyError("the fused optimiser tail (vf_mlp_weight_grad_adam) timed out waiting for its waves to become "
+                                   "co-resident: another kernel holds part of the device; set VISFLY_AMD_FUSED_TAIL=0")
 
     def train(self, permutations=None):
         """PPO.train (PPO.py:177-337): n_epochs passes over random minibatches (SB3 RolloutBuffer.get: the trailing
@@ -1114,10 +1171,13 @@ class PPO:
         bs = min(self.batch_size, total)
         g = th.Generator(device=self.device)
         g.manual_seed(self.seed + 7919 * (self._opt_step + 1))
-        # loss statistics per epoch: the reference logs approx_kl of the LAST epoch it started (the list is reset per epoch,
-        # PPO.py:197) and everything else over all minibatches of the call
-        stats_epoch = th.zeros((self.n_epochs, 16), device=self.device)
-        rows_epoch = [0] * self.n_epochs
+        # loss statistics: one row per evaluated minibatch.  The reference appends every minibatch's MEAN to a list and logs np.mean of
+        # the lists -- equal weight per minibatch, whatever its row count (the trailing partial one counts like a full one); approx_kl's
+        # list is reset per epoch (PPO.py:197), so its log is the mean over the minibatches of the LAST epoch started, including the one
+        # that tripped target_kl (PPO.py:263-282: appended before the check)
+        n_mb = (total + bs - 1) // bs
+        stats_mb = th.zeros((self.n_epochs * n_mb, 16), device=self.device)
+        rows_mb, epoch_mb = [], []
         stop = False
         buf = self.buf
         flat = {"actions": buf.actions.view(-1, 4), "old_lp": buf.log_probs.view(-1), "adv": buf.advantages.view(-1),
@@ -1126,7 +1186,6 @@ class PPO:
             flat["old_v"] = buf.values.view(-1)
         flat.update({"obs:" + k: buf.obs[k].view(-1, buf.obs[k].shape[-1]) for k in self.obs_keys})
         for _epoch in range(self.n_epochs):
-            stats_acc = stats_epoch[_epoch]
             if permutations is not None:
                 perm = th.as_tensor(permutations[_epoch], dtype=th.int64, device=self.device).contiguous()
                 assert perm.numel() == total
@@ -1148,26 +1207,39 @@ class PPO:
                     mb = dict(flat, adv=shuf["adv"][s:e], rows=perm[s:e])
                 else:
                     mb = {k: v[s:e] for k, v in shuf.items()}
-                st = self._minibatch_update(mb, stats_acc)
-                rows_epoch[_epoch] += e - s
+                st = self._minibatch_update(mb, stats_mb[len(rows_mb)])
+                rows_mb.append(e - s)
+                epoch_mb.append(_epoch)
                 if st is None:
                     stop = True
                     break
+            self._n_updates += 1        # PPO.py:294: once per epoch started, the early-stopped one included
             if stop:
                 break
+        self._check_tail()
         if self.world > 1:
-            parallel.allreduce_sum_(stats_epoch)                     # log the global means, like a single-process run would
-        rows_done, last = sum(rows_epoch), max(e for e in range(self.n_epochs) if rows_epoch[e] > 0 or e == 0)
-        s = (stats_epoch.sum(0) / float(max(rows_done, 1) * self.world)).tolist()
-        s[3] = float(stats_epoch[last, 3].item()) / float(max(rows_epoch[last], 1) * self.world)      # approx_kl: the last epoch's
+            parallel.allreduce_sum_(stats_mb)                        # log the global means, like a single-process run would
+        n_eval = len(rows_mb)
+        means = stats_mb[:max(n_eval, 1)].double().cpu().numpy() / (np.asarray(rows_mb or [1], np.float64)[:, None] * self.world)
+        last = [i for i in range(n_eval) if epoch_mb[i] == epoch_mb[-1]] or [0]
         ep = parallel.allreduce_sum_(self._ep_stats.clone()).tolist()          # rollout statistics of this iteration (:398-414)
         self._ep_stats.zero_()
         if ep[0] > 0:
             self.logs.update({"rollout/ep_rew_mean": ep[1] / ep[0], "rollout/ep_len_mean": ep[2] / ep[0],
                               "rollout/ep_success_rate": ep[3] / ep[0], "rollout/episodes": ep[0]})
-        self.logs.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/entropy_loss": s[2],
-                          "train/approx_kl": s[3], "train/clip_fraction": s[4], "train/n_updates": self._opt_step,
-                          "train/early_stop": float(stop)})
+        # PPO.py:322-336
+        ret, val = buf.returns.view(-1).double(), buf.values.view(-1).double()
+        var_y = float(ret.var(unbiased=False))
+        self.logs.update({"train/policy_gradient_loss": float(means[:, 0].mean()), "train/value_loss": float(means[:, 1].mean()),
+                          "train/entropy_loss": float(means[:, 2].mean()), "train/approx_kl": float(means[last, 3].mean()),
+                          "train/clip_fraction": float(means[:, 4].mean()),
+                          "train/loss": float(means[-1, 0] + self.ent_coef * means[-1, 2] + self.vf_coef * means[-1, 1]),
+                          "train/explained_variance": float("nan") if var_y == 0 else 1.0 - float((ret - val).var(unbiased=False)) / var_y,
+                          "train/std": float(self.policy.log_std.exp().mean()),
+                          "train/n_updates": self._n_updates, "train/optimiser_steps": self._opt_step, "train/learning_rate": self.lr,
+                          "train/clip_range": self._now(self.clip_range), "train/early_stop": float(stop)})
+        if self.clip_range_vf is not None:
+            self.logs["train/clip_range_vf"] = self._now(self.clip_range_vf)
 
     def _prepare_epoch(self, flat, perm, bs, slot=0):
         """the epoch's shuffled copy of the rollout (buffer set `slot`), advantages normalised per minibatch"""
@@ -1225,6 +1297,8 @@ class PPO:
         it = 0
         while self.num_timesteps - start < total_timesteps:
             self.collect_rollouts()
+            # SB3 _update_current_progress_remaining (PPO.py:150-152): after the rollout, before train()
+            self._current_progress_remaining = 1.0 - float(self.num_timesteps - start) / float(total_timesteps)
             self.train()
             it += 1
             if log_interval and it % log_interval == 0:
