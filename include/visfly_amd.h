@@ -755,12 +755,12 @@ typedef struct vf_adam_cfg {
  *                                       launches of one stream (the kernel leaves the counters at zero)
  *   loss_stats                          as vf_mlp_weight_grad_sumsq (part rows 16-byte aligned)
  * Needs every wave of the launch resident at once: VF_EUNSUPPORTED (reason in vf_last_error) when the plan for (desc, M) exceeds
- * what this device holds of the kernel, for streaming row counts (>= 131 072 with narrow layers), or with VISFLY_AMD_FUSED_TAIL=0 --
+ * what this device holds of the kernel or for streaming row counts (>= 131 072 with narrow layers) --
  * the caller then issues vf_mlp_weight_grad_sumsq + vf_adam_step.  A wave that waits longer than VISFLY_AMD_FUSED_TAIL_TIMEOUT_MS
  * (default 2000) sets sync[VF_WGRAD_SYNC_ABORT] and every waiter leaves WITHOUT the update: a caller polls that word at its
  * next host synchronisation and treats non-zero as a hard error (the counters are then stale: zero sync[] before reuse). */
-#define VF_WGRAD_SYNC_WORDS 32
-#define VF_WGRAD_SYNC_ABORT 2
+#define VF_WGRAD_SYNC_WORDS 5120
+#define VF_WGRAD_SYNC_ABORT 16
 typedef struct vf_wgrad_tail {
     float* param;
     float* exp_avg;

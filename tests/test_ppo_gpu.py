@@ -729,7 +729,12 @@ def test_fused_optimiser_tail_equals_separate_launches(keys, B):
             pol.mark_updated(packed_current=True)
             torch.cuda.synchronize()
             trace.append([t.clone() for t in (pol.grad, stats, acc, pol._sq_part, pol.flat, m, v, pol._packed)])
-        assert int(sync.abs().sum()) == (3 if fused else 0)           # only the generation word moved: counters back at zero
+        slots = sync.view(-1, 16)[:, 0].tolist()                      # one word per 64-byte line (csrc/vf_mlp_wgrad.hip: tail_slot)
+        if fused:       # generation = launches; no abort; every arrival count back at zero; release words / group flags at the generation
+            counts = slots[2:11] + [slots[19 + 18 * l + k] for l in range(16) for k in (0, 2, 3, 4, 5, 6, 7, 8, 9)]
+            assert slots[0] == 3 and slots[1] == 0 and not any(counts) and set(slots) <= {0, 3}, slots[:40]
+        else:
+            assert not any(slots)
         out[fused] = trace
     for a, b in zip(out[True], out[False]):
         for name, x, y in zip(("grad", "stats", "stats_accum", "sq_part", "param", "exp_avg", "exp_avg_sq", "packed"), a, b):
@@ -738,14 +743,16 @@ def test_fused_optimiser_tail_equals_separate_launches(keys, B):
 
 
 def test_ppo_training_with_the_fused_tail_equals_the_separate_launches():
-    """PPO.learn with the optimiser step's tail inside the weight-gradient launch (default) ends at the same parameters, bit for bit, as
+    """PPO.learn with the optimiser step's tail inside the weight-gradient launch (opt-in) ends at the same parameters, bit for bit, as
     with fold and Adam as launches of their own; trailing partial minibatch, value clipping, entropy term"""
     from visfly_amd.envs import NavigationEnv
     from visfly_amd.ppo import PPO
     from _golden import ENV_DYN
     flats = []
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
     for flag in (True, False):
-        env = NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64, tensor_output=True)
+        env = NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64, tensor_output=True,
+                            random_kwargs=spawn)
         ppo = PPO(env, n_steps=16, batch_size=6000, n_epochs=3, learning_rate=3e-4, seed=3, clip_range_vf=0.3, ent_coef=0.01)
         ppo.fused_tail = flag
         ppo.learn(16 * 1024 * 3)
@@ -754,7 +761,8 @@ def test_ppo_training_with_the_fused_tail_equals_the_separate_launches():
         flats.append((ppo.policy.flat.clone(), ppo.exp_avg.clone(), ppo.exp_avg_sq.clone(), dict(ppo.logs)))
         env.close()
     assert torch.equal(flats[0][0], flats[1][0]) and torch.equal(flats[0][1], flats[1][1]) and torch.equal(flats[0][2], flats[1][2])
-    assert {k: v for k, v in flats[0][3].items() if k != "time/fps"} == {k: v for k, v in flats[1][3].items() if k != "time/fps"}
+    logs = [{k: v for k, v in f[3].items() if k != "time/fps"} for f in flats]
+    assert logs[0] == logs[1] and abs(logs[0]["train/explained_variance"]) < 10
 
 
 def test_predict_is_deterministic_and_bounded():

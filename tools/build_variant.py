@@ -6,11 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visfly_amd import _build
 from concurrent.futures import ThreadPoolExecutor
 src_name, out, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
-objdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tmp", "obj")
+objdir = os.path.join(_build.CSRC, ".obj")        # the object cache of visfly_amd/_build.py (run the normal build first)
 os.makedirs(objdir, exist_ok=True)
 hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 cflags = [f for f in _build.HIPCC_FLAGS if f != "-shared"] + ["-I", _build.INCLUDE, "-I", _build.CSRC]
-hdr_time = max(os.path.getmtime(os.path.join(_build.CSRC, f)) for f in os.listdir(_build.CSRC) if f.endswith(".hpp"))
+hdr_time = max([os.path.getmtime(os.path.join(_build.CSRC, f)) for f in os.listdir(_build.CSRC) if f.endswith(".hpp")] +
+               [os.path.getmtime(os.path.join(_build.INCLUDE, "visfly_amd.h"))])
 def obj_for(src, variant=False):
     return os.path.join(objdir, os.path.basename(src) + (".variant.o" if variant else ".o"))
 def compile_one(src, flags, obj):

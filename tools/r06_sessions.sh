@@ -27,8 +27,29 @@ tail1)    # fused optimiser tail (vf_mlp_weight_grad_adam): parity with the sepa
     timeout 900 python -m pytest tests/test_ppo_loop_gpu.py -x -q -m gpu 2>&1 | tail -15 | tee $O/pytest_loop.txt
     for ft in 1 0; do ppo_ab tail$ft VISFLY_AMD_FUSED_TAIL=$ft | tee -a $O/ab.txt; done
     for ft in 1 0; do
-        VISFLY_AMD_FUSED_TAIL=$ft prof ppo_tail$ft timeout 300 python bench.py --workload ppo --no-cpu-baseline --steps 256
+        VISFLY_AMD_FUSED_TAIL=$ft prof ppo_tail$ft timeout 300 python $R/bench.py --workload ppo --no-cpu-baseline --steps 256
     done
+    ;;
+tail2)    # wave timeline of the fused launch (trace build) + the A/B again
+    timeout 600 python -m pytest tests/test_ppo_gpu.py -x -q -m gpu -k "fused_optimiser_tail or fused_tail" 2>&1 | tail -5 | tee $O/pytest.txt
+    VF_ALT_LIB=$R/tools/tmp/libvf_wtrace.so timeout 300 python tools/exp_tail_trace.py 25600 2>&1 | grep -v amdgpu.ids | tee $O/trace.txt
+    for ft in 1 0 1 0; do ppo_ab tail$ft VISFLY_AMD_FUSED_TAIL=$ft | tee -a $O/ab.txt; done
+    for ft in 1 0; do
+        VISFLY_AMD_FUSED_TAIL=$ft prof ppo_tail$ft timeout 300 python $R/bench.py --workload ppo --no-cpu-baseline --steps 256
+    done
+    ;;
+aux)      # cache policy of the chain kernel's saved-activation stores (write-through / non-temporal): does the chain -> wgrad boundary shrink?
+    ppo_ab base VISFLY_AMD_FUSED_TAIL=0 | tee -a $O/ab.txt
+    for a in 16 2 18; do
+        VF_ALT_LIB=$R/tools/tmp/libvf_saux$a.so timeout 600 python tools/bench_alt.py --workload ppo --no-cpu-baseline 2>&1 | tail -1 > $O/bench_ppo_aux$a.json
+        python - <<PY | tee -a $O/ab.txt
+import json
+d = json.loads(open("$O/bench_ppo_aux$a.json").read())
+print("ppo store aux $a value %.4g  us/update %.2f  frac %.4f  train ms %.2f" % (d["value"], d["roofline"]["us_per_update"], d["roofline"]["frac"], d["split_ms"]["train"]))
+PY
+    done
+    ppo_ab base VISFLY_AMD_FUSED_TAIL=0 | tee -a $O/ab.txt
+    prof ppo_base timeout 300 python $R/bench.py --workload ppo --no-cpu-baseline --steps 256
     ;;
 tests)    # the whole GPU suite
     timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $O/pytest.txt

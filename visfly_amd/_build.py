@@ -38,7 +38,8 @@ def _stale():
 
 def build(force=False, verbose=False, extra_flags=(), out=None):
     """one `hipcc -c` per source in parallel (the register-chained MLP kernels are ~1.5 min of fully unrolled code on
-    their own), then one link"""
+    their own), then one link.  Objects are kept under csrc/.obj and reused while they are newer than their source, every header
+    and this file (default flags only): editing one .hip costs one compile."""
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     out = out or LIB
@@ -47,14 +48,21 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     tmp = f"{out}.{os.getpid()}.tmp"          # link to a private name, then rename: concurrent builders never see a torn file
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC]
-    objdir = tempfile.mkdtemp(prefix="visfly_amd_build_")
+    keep = not extra_flags and not force
+    objdir = os.path.join(CSRC, ".obj") if keep else tempfile.mkdtemp(prefix="visfly_amd_build_")
+    os.makedirs(objdir, exist_ok=True)
+    common = max(os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h")) + [__file__])
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc] + cflags + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        if keep and os.path.exists(obj) and os.path.getmtime(obj) > max(common, os.path.getmtime(src)):
+            return obj
+        part = f"{obj}.{os.getpid()}.tmp"
+        cmd = [hipcc] + cflags + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", part]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        os.replace(part, obj)
         return obj
 
     try:
@@ -68,5 +76,6 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
-        shutil.rmtree(objdir, ignore_errors=True)
+        if not keep:
+            shutil.rmtree(objdir, ignore_errors=True)
     return out

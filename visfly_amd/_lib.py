@@ -194,7 +194,7 @@ class WgradTail(C.Structure):
                 ("adam", AdamCfg), ("sync", C.c_void_p)]
 
 
-WGRAD_SYNC_WORDS, WGRAD_SYNC_ABORT = 32, 2
+WGRAD_SYNC_WORDS, WGRAD_SYNC_ABORT = 5120, 16
 
 
 class VisflyError(RuntimeError):

@@ -232,9 +232,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_store_rsrc(unsigned long
 // (first touch of freshly allocated pages): element 0 of the float4 of the last-read lanes (12-15 of every 16) went out as the NEW value
 // of v6, a pre-ReLU sum -- 8 rows x 2 floats of one saved activation wrong, once in ~3 cold launches.  With the immediate form the
 // compiler sees a store without soffset register and inserts the `s_nop 1` itself.
+#ifndef VF_CHAIN_STORE_AUX
+#define VF_CHAIN_STORE_AUX 0      // cache policy of the saved-activation / masked-gradient stores (bit 0 sc0, bit 1 nt, bit 4 sc1): A/B knob, profiles/r06_fused_tail.txt
+#endif
 __device__ __forceinline__ void chain_buffer_store(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned col_off, float a, float b, float c, float d)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(vf_u4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, (int)(lane_off + col_off), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(vf_u4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, (int)(lane_off + col_off), 0, VF_CHAIN_STORE_AUX);
 }
 
 template <class N, int I>

@@ -57,6 +57,15 @@ __device__ __forceinline__ void wgrad_load(__amdgpu_buffer_rsrc_t r, unsigned of
     }
 }
 
+// What one wave writes and another reads within the launch (the fused tail's partials, gradients, per-block sums) goes out as agent-scope
+// stores -- write-through to where the eight XCDs' L2s agree -- and comes back through agent-scope loads: no L2 write-back / invalidate
+// fences between the waves.  The partials are written that way in every form of the launch (the separate fold reads them from another
+// launch: nothing changes for it, and the launch ends without 20 MB of dirty lines behind it).
+template <typename T>
+__device__ __forceinline__ void store_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T load_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Operand rows through BUFFER loads whose descriptors cover exactly the wave's slab [r0, r1): a row past the slab reads as zeros
 // (hardware range check), so the steps that overhang the slab need neither clamped row indices nor `live` multipliers, and an
 // address is a 32-bit lane offset + one add per step instead of a 64-bit multiply-add per operand (r03: ~27 VALU instructions per
@@ -135,11 +144,11 @@ __device__ __forceinline__ void wgrad_slab(const vf_mlp_bwd_layer& L, int r0, in
 #pragma unroll
         for (int j = 0; j < KT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[((i * KT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) store_agent(part + ((i * KT + j) * 16 + r) * 64 + lane, acc[i][j][r]);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const float other = __shfl_xor(bsum[i], 32);
-        if (kk == 0) part[NT * KT * 1024 + 32 * i + c] = bsum[i] + other;
+        if (kk == 0) store_agent(part + NT * KT * 1024 + 32 * i + c, bsum[i] + other);
     }
 }
 
@@ -234,46 +243,122 @@ __device__ __forceinline__ float stats_fold_one(const vf_stats_fold& ls, int k, 
 // ---- fused tail: fold -> squared norm -> clip -> Adam -> packed-weight refresh inside the weight-gradient launch ----------------------
 // The four launches of an optimiser step (chain, weight gradients, fold, Adam) were 105 us of kernels in 112 us: the fold (9.4 us) and Adam
 // (5.3 us) are latency, and every launch boundary costs ~1.8 us behind the dirty lines of the one before.  A lone workgroup cannot fold (the
-// partials are 20 MB: one wave reads ~6 GB/s), so the fold stays chip-wide: the waves of a LAYER meet at a counter once their partials are
-// out (release / acquire at agent scope: L2 write-back and invalidate across the 8 XCDs), every wave then folds 64 elements of its own
-// layer (all of its up-to-160 loads in flight at once), writes the gradient and the block's fp64 sum of squares; all waves meet once more,
-// add up the per-block sums in k_adam's order and run Adam on the elements they still hold.  Same reduction orders as the separate launches:
-// the two paths agree to the bit.  The launch needs every wave co-resident (1 024 waves of 512 VGPRs = one per SIMD): the host checks the
-// plan against the occupancy of this kernel on this device and answers VF_EUNSUPPORTED otherwise; a wave that waits longer than `timeout`
-// ticks of the 100 MHz clock raises sync[2] and every waiter leaves (the caller then sees VF_WGRAD_SYNC_ABORT set: hard error, no hang).
+// partials are 20 MB: one wave reads ~6 GB/s), so the fold stays chip-wide: the waves of a LAYER meet once their partials are out, every
+// wave then folds 64 elements of its own layer (all of its up-to-160 loads in flight at once), writes the gradient and the block's fp64 sum
+// of squares; all waves meet once more, add up the per-block sums in k_adam's order and run Adam on the elements they still hold.  Same
+// reduction orders as the separate launches: the two paths agree to the bit.
+// What a meeting of ~1 000 lone waves costs on gfx950 (tools/grid_barrier_probe.hip, profiles/r06_fused_tail.txt): every wave adding to ONE
+// word and polling ONE word 62 us (same-address agent-scope atomics and polls are served one by one, ~10 ns each); an agent-scope release
+// fence (buffer_wbl2) 7 us when all waves issue it; arrivals grouped eight ways (workgroup id mod 8), the group's last arrival carrying it to
+// the global word, release handed back the same way, and NO fences -- everything that crosses waves is written with agent-scope
+// (write-through) stores, waited for (vmcnt) and read with agent-scope loads -- 3.5 us.  That is the form used here.
+// The launch needs every wave co-resident (1 024 waves of 512 VGPRs = one per SIMD): the host checks the plan against the occupancy of this
+// kernel on this device and answers VF_EUNSUPPORTED otherwise; a wave that waits longer than `timeout` ticks of the 100 MHz clock raises
+// the abort word and every waiter leaves (the caller then sees VF_WGRAD_SYNC_ABORT set: hard error, no hang).
 struct WgradTail {
     float* grad;
     float* param;
     float* m;
     float* v;
     double* sq_part;          // [n_fold_blocks]
-    unsigned* sync;           // [0] arrivals of the grid meeting, [1] generation, [2] abort, [4 + l] arrivals of layer l's meeting
+    unsigned* sync;           // slots of 16 words (one 64-byte line each), see tail_slot
     vf_adam_cfg adam;
     float step, bc2_sqrt;
     vf_stats_fold ls;
     int n, accumulate, n_fold_blocks, has_ls;
     long long timeout;
+    long long* trace;         // VF_WGRAD_TRACE builds only
 };
 
-__device__ __forceinline__ unsigned tail_peek(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// slot 0: generation (= release word of the grid meeting), 1: abort (VF_WGRAD_SYNC_ABORT = 16), 2: grid meeting's global count,
+// 3..10 its group counts, 11..18 its group flags; layer l: 19 + 18 l: global count, + 1 release word, + 2..9 group counts, + 10..17 group flags
+__device__ __forceinline__ unsigned* tail_slot(unsigned* sync, int i) { return sync + 16 * i; }
+static_assert((19 + 18 * VF_MLP_MAX_LAYERS) * 16 <= VF_WGRAD_SYNC_WORDS, "sync words");
+static_assert(VF_WGRAD_SYNC_ABORT == 16, "abort word = slot 1");
 
-template <typename Pred>
-__device__ __forceinline__ bool tail_wait(Pred done, unsigned* abort_word, long long timeout)
+__device__ __forceinline__ unsigned tail_peek(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tail_poke(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// this wave's agent-scope stores have been acknowledged (and the compiler keeps what follows behind them); no L2 write-back: they were
+// write-through.  The mirror image after a wait: what follows is not hoisted above the poll
+__device__ __forceinline__ void tail_stores_out() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void tail_after_wait() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// release words and group flags are 64-bit: the generation in the low half, a payload in the high half (the grid meeting hands the clip
+// coefficient to everybody with the flag itself: no wave but one reads the per-block sums)
+__device__ __forceinline__ unsigned long long tail_peek64(const unsigned* p)
+{
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tail_poke64(unsigned* p, unsigned gen, unsigned payload)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)payload << 32) | gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// -> false: aborted (time limit of this or of another wave); else *payload = the high half of the word once its low half is `gen`
+__device__ __forceinline__ bool tail_wait_for(const unsigned* word, unsigned gen, unsigned* payload, unsigned* abort_word, long long timeout)
 {
     const long long t0 = wall_clock64();
-    for (int it = 1; !done(); ++it) {
+    unsigned long long v = tail_peek64(word);
+    for (int it = 1; (unsigned)v != gen; ++it) {
         __builtin_amdgcn_s_sleep(1);
         if ((it & 31) == 0) {
             if (tail_peek(abort_word)) return false;
             if (wall_clock64() - t0 > timeout) {
-                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tail_poke(abort_word, 1u);
                 return false;
             }
         }
+        v = tail_peek64(word);
     }
-    return tail_peek(abort_word) == 0;
+    *payload = (unsigned)(v >> 32);
+    return true;
 }
 
+// members of [f0, f1) whose workgroup id is x mod 8
+__device__ __forceinline__ unsigned tail_group_size(int f0, int f1, int x) { return (unsigned)(((f1 - x + 7) >> 3) - ((f0 - x + 7) >> 3)); }
+
+// One meeting of the workgroups [f0, f1): arrive at the group's count (group = workgroup id mod 8); the group's last arrival carries it to
+// the global count; the last group there runs `final_fn` (-> payload) and raises the release word to (gen, payload); the groups' last
+// arrivals wait for that and raise their group's flag, everybody else waits for the flag.  Counts return to zero through `final_fn` of the
+// launch's last meeting.  -> false: aborted
+template <typename F>
+__device__ __forceinline__ bool tail_meet(unsigned* global, unsigned* release, unsigned* gcount, unsigned* gflag, int f0, int f1, unsigned gen,
+                                          unsigned* payload, unsigned* abort_word, long long timeout, F final_fn)
+{
+    const int x = blockIdx.x & 7;
+    unsigned groups = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) groups += tail_group_size(f0, f1, g) > 0 ? 1u : 0u;
+    unsigned old = 0;
+    if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(gcount + 16 * x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old + 1u == tail_group_size(f0, f1, x)) {
+        unsigned old2 = 0;
+        if ((threadIdx.x & 63) == 0) old2 = __hip_atomic_fetch_add(global, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old2 = __builtin_amdgcn_readfirstlane(old2);
+        if (old2 + 1u == groups) {
+            *payload = final_fn();
+            tail_stores_out();
+            tail_poke64(release, gen, *payload);
+        } else if (!tail_wait_for(release, gen, payload, abort_word, timeout)) {
+            return false;
+        }
+        tail_poke64(gflag + 16 * x, gen, *payload);
+    } else if (!tail_wait_for(gflag + 16 * x, gen, payload, abort_word, timeout)) {
+        return false;
+    }
+    tail_after_wait();
+    return true;
+}
+
+// -DVF_WGRAD_TRACE (tools/build_variant.py; never in the shipped library): every wave of the fused launch leaves the 100 MHz clock at
+// its phase boundaries in the 8 words behind its partial's sq_part... -- a buffer the experiment passes through VISFLY_AMD_WGRAD_TRACE_PTR
+#ifdef VF_WGRAD_TRACE
+#define VF_TRACE_MARK(k) do { if (trace && (threadIdx.x & 63) == 0) trace[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define VF_TRACE_MARK(k) do { } while (0)
+#endif
+constexpr int kAuxSc1 = 16;       // cache-policy operand of the buffer builtins on gfx940+: bit 4 = sc1 (agent scope: coherent across the XCDs' L2s)
 constexpr int kTailBatch = 5;      // partial rows fetched per round of the in-kernel fold: 32 x 5 = 160 loads in flight per lane
 
 __device__ __forceinline__ float tail_fold_element(__amdgpu_buffer_rsrc_t rs, unsigned e, unsigned tot, int waves)
@@ -292,7 +377,7 @@ __device__ __forceinline__ float tail_fold_element(__amdgpu_buffer_rsrc_t rs, un
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {       // rows past the layer's block: the descriptor's range check answers +0
                     const unsigned w = 32u * (unsigned)(k0 + k) + 4u * u + q;
-                    v[k][q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((w * tot + e) * 4u), 0, 0));
+                    v[k][q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((w * tot + e) * 4u), 0, kAuxSc1));
                 }
 #pragma unroll
         for (int k = 0; k < kTailBatch; ++k)
@@ -320,12 +405,49 @@ __device__ __forceinline__ void wgrad_tail(const vf_mlp_bwd_desc& d, const Wgrad
     const int lane = threadIdx.x & 63;
     const int W = t.first_wave[l + 1] - t.first_wave[l], total = t.first_wave[t.n_layers];
     const bool tail_wave = (int)blockIdx.x == total - 1;         // folds the loss statistics, owns the parameters the layers do not cover
-    unsigned* const abort_word = T.sync + 2;
-    const unsigned gen0 = tail_peek(T.sync + 1);
-    // (1) this wave's partial is out: meet the layer's other waves
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) __hip_atomic_fetch_add(T.sync + 4 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tail_wave && T.has_ls) {          // while the others arrive: the loss statistics (rows written by the launch before this one)
+    unsigned* const abort_word = tail_slot(T.sync, 1);
+#ifdef VF_WGRAD_TRACE
+    long long* const trace = T.trace;
+#endif
+    VF_TRACE_MARK(1);                     // slab done, partial stores issued
+    const unsigned gen = tail_peek(tail_slot(T.sync, 0)) + 1u;      // (slot 0 = the grid meeting's release word: generation | clip coefficient)
+    unsigned* const lay = tail_slot(T.sync, 19 + 18 * l);
+    // (1) this wave's partial is out (agent-scope stores, acknowledged): meet the layer's other waves -- arrival now, the wait after the
+    // loss statistics
+    tail_stores_out();
+    unsigned none;
+    if (!tail_meet(lay, lay + 16, lay + 32, lay + 160, t.first_wave[l], t.first_wave[l + 1], gen, &none, abort_word, T.timeout, [] { return 0u; })) return;
+    VF_TRACE_MARK(2);                     // the layer's partials are all out
+    // (2) fold: block b of the layer = 64 consecutive elements of its partial row, as k_wgrad_fold's block
+    const vf_mlp_bwd_layer& L = d.layer[l];
+    const int tot = wgrad_partial_size(L), nb_l = (tot + 63) / 64;
+    int blk0 = 0;
+    for (int i = 0; i < l; ++i) blk0 += (wgrad_partial_size(d.layer[i]) + 63) / 64;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(partials + t.part_off[l], 0, (int)((size_t)W * tot * 4), 0x00020000);
+    const int nw = L.K * L.No;
+    float g0 = 0.0f, p0 = 0.0f, m0 = 0.0f, v0 = 0.0f;
+    long i0 = -1;
+    for (int b = lw; b < nb_l; b += W) {
+        const int e = b * 64 + lane;
+        const int prm = e < tot ? wgrad_param_of(L, e) : -1;
+        const long idx = prm < 0 ? -1 : prm < nw ? L.w_off + prm : L.b_off + (prm - nw);
+        float gold = 0.0f;
+        if (idx >= 0 && T.accumulate) gold = T.grad[idx];
+        if (b == lw && idx >= 0) { i0 = idx; p0 = T.param[idx]; m0 = T.m[idx]; v0 = T.v[idx]; }     // requested ahead of the fold's loads
+        const float vsum = tail_fold_element(rs, (unsigned)(e < tot ? e : 0), (unsigned)tot, W);
+        double sq = 0.0;
+        if (idx >= 0) {
+            const float nv = T.accumulate ? gold + vsum : vsum;
+            T.grad[idx] = nv;
+            sq = (double)nv * (double)nv;
+            if (b == lw) g0 = nv;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+        if (lane == 0) store_agent(T.sq_part + blk0 + b, sq);
+    }
+    if (tail_wave && T.has_ls) {          // while the others fold (the last wave of the last layer seldom has a block of its own): the loss
+        // statistics (rows written by the launch before this one); d_log_std goes into the gradient's uncovered tail
         float st[16];
         if (T.ls.n_rows <= 1024) {
             float4 v[16][3];
@@ -358,78 +480,63 @@ __device__ __forceinline__ void wgrad_tail(const vf_mlp_bwd_desc& d, const Wgrad
             const float s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st[k])));
             if (lane == 0) {
                 T.ls.stats[k] = s;
-                if (T.ls.d_log_std_out && k >= 5 && k < 9) T.ls.d_log_std_out[k - 5] = s;
+                if (T.ls.d_log_std_out && k >= 5 && k < 9) store_agent(T.ls.d_log_std_out + (k - 5), s);
                 if (T.ls.stats_accum) T.ls.stats_accum[k] += s;
             }
         }
     }
-    if (!tail_wait([&] { return tail_peek(T.sync + 4 + l) >= (unsigned)W; }, abort_word, T.timeout)) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // (2) fold: block b of the layer = 64 consecutive elements of its partial row, as k_wgrad_fold's block
-    const vf_mlp_bwd_layer& L = d.layer[l];
-    const int tot = wgrad_partial_size(L), nb_l = (tot + 63) / 64;
-    int blk0 = 0;
-    for (int i = 0; i < l; ++i) blk0 += (wgrad_partial_size(d.layer[i]) + 63) / 64;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(partials + t.part_off[l], 0, (int)((size_t)W * tot * 4), 0x00020000);
-    const int nw = L.K * L.No;
-    float g0 = 0.0f, p0 = 0.0f, m0 = 0.0f, v0 = 0.0f;
-    long i0 = -1;
-    for (int b = lw; b < nb_l; b += W) {
-        const int e = b * 64 + lane;
-        const int prm = e < tot ? wgrad_param_of(L, e) : -1;
-        const long idx = prm < 0 ? -1 : prm < nw ? L.w_off + prm : L.b_off + (prm - nw);
-        float gold = 0.0f;
-        if (idx >= 0 && T.accumulate) gold = T.grad[idx];
-        if (b == lw && idx >= 0) { i0 = idx; p0 = T.param[idx]; m0 = T.m[idx]; v0 = T.v[idx]; }     // requested ahead of the fold's loads
-        const float vsum = tail_fold_element(rs, (unsigned)(e < tot ? e : 0), (unsigned)tot, W);
-        double sq = 0.0;
-        if (idx >= 0) {
-            const float nv = T.accumulate ? gold + vsum : vsum;
-            T.grad[idx] = nv;
-            sq = (double)nv * (double)nv;
-            if (b == lw) g0 = nv;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
-        if (lane == 0) T.sq_part[blk0 + b] = sq;
-    }
     // the uncovered parameters [sumsq_tail_from, n): their gradients are the loss statistics' d_log_std (folded above) or what the caller
     // left in grad; the tail wave owns them
     const int tail_from = T.adam.sumsq_tail_from;
-    // (3) all gradients and per-block sums are out: meet everybody
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) {
-        const unsigned old = __hip_atomic_fetch_add(T.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (unsigned)total - 1u) {     // last arrival: every wave is past its layer's meeting -> reset the counters for the next launch
-            for (int i = 0; i < t.n_layers; ++i) __hip_atomic_store(T.sync + 4 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(T.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(T.sync + 1, gen0 + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (!tail_wait([&] { return tail_peek(T.sync + 1) != gen0; }, abort_word, T.timeout)) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // (4) squared norm: k_adam's order -- "thread" 64 q + lane of its 256 sums the partials 64 q + lane + 256 j, then the uncovered tail
-    float coef = 1.0f;
-    if (T.adam.max_grad_norm > 0.0f) {
-        double a[4];
+    VF_TRACE_MARK(3);                     // own block folded, gradient and block sum issued
+    // (3) all gradients and per-block sums are out: meet everybody.  The last arrival of all returns every count to zero (each wave is
+    // past its layer's meeting by then), forms the squared norm and raises the generation -- this meeting's release word -- with the
+    // clip coefficient in its upper half
+    tail_stores_out();
+    unsigned coef_bits;
+    if (!tail_meet(tail_slot(T.sync, 2), tail_slot(T.sync, 0), tail_slot(T.sync, 3), tail_slot(T.sync, 11), 0, total, gen, &coef_bits, abort_word, T.timeout, [&] {
+            for (int i = lane; i < 9; i += 64) tail_poke(tail_slot(T.sync, 2 + i), 0u);
+            for (int i = lane; i < 18 * t.n_layers; i += 64)
+                if (i % 18 != 1 && i % 18 < 10) tail_poke(tail_slot(T.sync, 19 + i), 0u);
+            // (4) squared norm, by this one wave for everybody: k_adam's order -- "thread" 64 q + lane of its 256 sums the partials
+            // 64 q + lane + 256 j, then the uncovered tail; four wave sums, ((0 + 1) + (2 + 3))
+            float coef = 1.0f;
+            if (T.adam.max_grad_norm > 0.0f) {
+                tail_after_wait();
+                double a[4], x[4][4], xt[4];
+                // every load of the common case (<= 1 024 blocks, <= 256 uncovered parameters) is requested before the first sum
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double x[4];
+                for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = 64 * q + lane + 256 * j;
-                x[j] = i < T.n_fold_blocks ? T.sq_part[i] : 0.0;
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 64 * q + lane + 256 * j;
+                        x[q][j] = i < T.n_fold_blocks ? load_agent(T.sq_part + i) : 0.0;
+                    }
+                    const long it = tail_from + 64 * q + lane;
+                    xt[q] = it < T.n ? (double)load_agent(T.grad + it) : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = ((0.0 + x[q][0]) + x[q][1]) + x[q][2];
+                    a[q] += x[q][3];
+                    for (int i = 64 * q + lane + 1024; i < T.n_fold_blocks; i += 256) a[q] += load_agent(T.sq_part + i);
+                    a[q] += xt[q] * xt[q];
+                    for (long i = tail_from + 64 * q + lane + 256; i < T.n; i += 256) {
+                        const double gi = (double)load_agent(T.grad + i);
+                        a[q] += gi * gi;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o, 64);
+                    a[q] = bcast_lane0(a[q]);
+                }
+                coef = adam_clip_coef((float)((a[0] + a[1]) + (a[2] + a[3])), T.adam.max_grad_norm);
             }
-            a[q] = ((0.0 + x[0]) + x[1]) + x[2];
-            a[q] += x[3];
-            for (int i = 64 * q + lane + 1024; i < T.n_fold_blocks; i += 256) a[q] += T.sq_part[i];
-            for (long i = tail_from + 64 * q + lane; i < T.n; i += 256) a[q] += (double)T.grad[i] * (double)T.grad[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o, 64);
-            a[q] = bcast_lane0(a[q]);
-        }
-        coef = adam_clip_coef((float)((a[0] + a[1]) + (a[2] + a[3])), T.adam.max_grad_norm);
-    }
+            return __float_as_uint(coef);
+        }))
+        return;
+    VF_TRACE_MARK(4);                     // everybody's block sums are out, the clip coefficient came with the flag
+    const float coef = __uint_as_float(coef_bits);
+    VF_TRACE_MARK(5);                     // clip coefficient known
     // (5) Adam on the elements this wave folded (+ the uncovered tail on the tail wave)
     if (i0 >= 0) {
         const float pn = adam_param(p0, g0, m0, v0, coef, T.adam, T.step, T.bc2_sqrt);
@@ -453,13 +560,14 @@ __device__ __forceinline__ void wgrad_tail(const vf_mlp_bwd_desc& d, const Wgrad
     if (tail_wave) {
         for (long i = tail_from + lane; i < T.n; i += 64) {
             float mi = T.m[i], vi = T.v[i];
-            const float pn = adam_param(T.param[i], T.grad[i], mi, vi, coef, T.adam, T.step, T.bc2_sqrt);
+            const float pn = adam_param(T.param[i], load_agent(T.grad + i), mi, vi, coef, T.adam, T.step, T.bc2_sqrt);
             T.m[i] = mi;
             T.v[i] = vi;
             T.param[i] = pn;
             if (T.adam.pack_map) adam_refresh_packed(T.adam, i, pn);
         }
     }
+    VF_TRACE_MARK(6);
 }
 
 // SMALL: every layer of the table has at most 8 accumulator tiles (the reference-default policies: 128 -> 64 is the largest layer), so
@@ -470,6 +578,10 @@ __global__ __launch_bounds__(64, SMALL ? 2 : 1) void k_mlp_wgrad(const vf_mlp_bw
                                                                  const WgradTail tail)
 {
     prefetch_kernarg<sizeof(vf_mlp_bwd_desc) + sizeof(WgradTable) + 16 + (TAIL ? sizeof(WgradTail) : 0)>();
+#ifdef VF_WGRAD_TRACE
+    long long* const trace = tail.trace;
+#endif
+    VF_TRACE_MARK(0);
     const int w = blockIdx.x;
     int l = 0;
     while (l + 1 < t.n_layers && w >= t.first_wave[l + 1]) ++l;
@@ -479,7 +591,7 @@ __global__ __launch_bounds__(64, SMALL ? 2 : 1) void k_mlp_wgrad(const vf_mlp_bw
     float* part = partials + t.part_off[l] + (size_t)lw * wgrad_partial_size(L);
     const int NT = (L.No + 31) >> 5, KT = (L.K + 31) >> 5;
     if (r0 >= r1) {        // empty slab (rounding): the fold still reads this partial
-        for (int i = threadIdx.x; i < wgrad_partial_size(L); i += 64) part[i] = 0.0f;
+        for (int i = threadIdx.x; i < wgrad_partial_size(L); i += 64) store_agent(part + i, 0.0f);
     } else {
         switch (NT * 4 + KT - 5) {
         case 0: wgrad_slab_pick<1, 1, SMALL>(L, r0, r1, part); break;
@@ -579,12 +691,17 @@ bool wgrad_small(const vf_mlp_bwd_desc& d, int M)
 // (1 024 SIMDs x waves per SIMD): the fused tail needs every wave of the launch resident at once
 int64_t wgrad_plan(const vf_mlp_bwd_desc& d, int M, WgradTable& t, int* total_waves)
 {
+    const bool small = wgrad_small(d, M);
     int tiles[VF_MLP_MAX_LAYERS], sum = 0;
     for (int l = 0; l < d.n_layers; ++l) {
-        tiles[l] = ((d.layer[l].No + 31) >> 5) * ((d.layer[l].K + 31) >> 5) + 2;   // + per-row-pair overhead (loads, guards) in MFMA units
+        // cost of a row pair in MFMA units: tiles + the per-row-pair overhead (loads, address steps).  Measured on the wave timeline
+        // of the 25 600-row launch (profiles/r06_fused_tail.txt): 116 / 180 / 346 ns per row pair at 2 / 4 / 8 tiles = 38.5 (tiles + 0.9);
+        // until r06 the plan said tiles + 2 and the 8-tile layers' waves ran 31.5 us next to 26 us for the 2-tile layers'.  The
+        // streaming regime (two waves per SIMD, bandwidth) keeps its + 2
+        tiles[l] = ((d.layer[l].No + 31) >> 5) * ((d.layer[l].K + 31) >> 5) + (small ? 2 : 1);
         sum += tiles[l];
     }
-    const int cap = wgrad_small(d, M) ? 2048 : 1024;   // waves per SIMD x 1024 SIMDs
+    const int cap = small ? 2048 : 1024;   // waves per SIMD x 1024 SIMDs
     t.n_layers = d.n_layers;
     for (int budget = cap;; budget -= 8) {
         int w = 0;
@@ -660,8 +777,6 @@ static int wgrad_tail_capacity()
 int mlp_wgrad_adam_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, const vf_stats_fold* loss_stats,
                           const vf_wgrad_tail* tl, hipStream_t st)
 {
-    static const int enabled = [] { const char* e = getenv("VISFLY_AMD_FUSED_TAIL"); return e ? atoi(e) : 1; }();
-    if (!enabled) return fail(0, "fused optimiser tail switched off (VISFLY_AMD_FUSED_TAIL=0)");
     if (wgrad_small(*d, M)) return fail(0, "fused optimiser tail: streaming row counts (two waves per SIMD) use the separate fold");
     WgradTable t;
     int waves = 0;
@@ -687,6 +802,9 @@ int mlp_wgrad_adam_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad
     T.n_fold_blocks = mlp_wgrad_fold_blocks(d);
     static const long long timeout = [] { const char* e = getenv("VISFLY_AMD_FUSED_TAIL_TIMEOUT_MS"); return (long long)(e ? atoi(e) : 2000) * 100000LL; }();
     T.timeout = timeout;        // ticks of the 100 MHz wall clock
+#ifdef VF_WGRAD_TRACE
+    if (const char* e = getenv("VISFLY_AMD_WGRAD_TRACE_PTR")) T.trace = reinterpret_cast<long long*>(strtoull(e, nullptr, 0));
+#endif
     hipLaunchKernelGGL((k_mlp_wgrad<false, true>), dim3(waves), dim3(64), 0, st, *d, t, partials, M, T);
     VF_HIP(hipGetLastError());
     return 1;

@@ -1335,6 +1335,18 @@ __global__ __launch_bounds__(kBlock) void k_adam(float* __restrict__ p, const fl
                                                  float* __restrict__ v, long n, const float* __restrict__ sumsq,
                                                  const vf_adam_cfg c, float bc1, float bc2_sqrt)
 {
+    // the first element's operands are requested ahead of the norm's reduction: they do not depend on it, and a launch this small is
+    // nothing but dependent round trips (r06: 5.1 -> see profiles/r06_fused_tail.txt)
+    const long i0 = (long)blockIdx.x * kBlock + threadIdx.x;
+    float p0 = 0.0f, g0 = 0.0f, m0 = 0.0f, v0 = 0.0f;
+    int4 o0 = make_int4(-1, -1, -1, -1);
+    if (i0 < n) {
+        p0 = p[i0];
+        g0 = g[i0];
+        m0 = m[i0];
+        v0 = v[i0];
+        if (c.pack_map) o0 = reinterpret_cast<const int4*>(c.pack_map)[i0];
+    }
     float coef = 1.0f;
     if (c.max_grad_norm > 0.0f) {
         float ss;
@@ -1353,9 +1365,19 @@ __global__ __launch_bounds__(kBlock) void k_adam(float* __restrict__ p, const fl
         coef = adam_clip_coef(ss, c.max_grad_norm);
     }
     const float step = c.lr / bc1;
-    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+    if (i0 < n) {
+        const float pn = adam_param(p0, g0, m0, v0, coef, c, step, bc2_sqrt);       // vf_adam_device.hpp
+        m[i0] = m0;
+        v[i0] = v0;
+        p[i0] = pn;
+        if (o0.x >= 0) c.packed[o0.x] = pn;
+        if (o0.y >= 0) c.packed[o0.y] = pn;
+        if (o0.z >= 0) c.packed[o0.z] = pn;
+        if (o0.w >= 0) c.packed[o0.w] = pn;
+    }
+    for (long i = i0 + (long)gridDim.x * kBlock; i < n; i += (long)gridDim.x * kBlock) {
         float mi = m[i], vi = v[i];
-        const float pn = adam_param(p[i], g[i], mi, vi, coef, c, step, bc2_sqrt);       // vf_adam_device.hpp
+        const float pn = adam_param(p[i], g[i], mi, vi, coef, c, step, bc2_sqrt);
         m[i] = mi;
         v[i] = vi;
         p[i] = pn;
@@ -1770,8 +1792,9 @@ int vf_mlp_weight_grad_adam(const vf_mlp_bwd_desc* desc, float* partials, float*
 {
     if (!partials || !grad || !tail || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_adam: bad argument");
     if (!tail->param || !tail->exp_avg || !tail->exp_avg_sq || !tail->sync || !tail->adam.sumsq_partials || tail->n <= 0 ||
-        tail->adam.step <= 0 || tail->adam.sumsq_tail_from < 0 || tail->adam.sumsq_tail_from > tail->n)
-        return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_adam: bad tail");
+        tail->adam.step <= 0 || tail->adam.sumsq_tail_from < 0 || tail->adam.sumsq_tail_from > tail->n ||
+        (reinterpret_cast<uintptr_t>(tail->sync) & 63) || (reinterpret_cast<uintptr_t>(tail->adam.sumsq_partials) & 7))
+        return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_adam: bad tail (sync: 64-byte aligned)");
     if ((tail->adam.pack_map == nullptr) != (tail->adam.packed == nullptr))
         return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_adam: pack_map and packed must be given together");
     if (loss_stats && (!loss_stats->part || !loss_stats->stats || loss_stats->n_rows < 1 || (reinterpret_cast<uintptr_t>(loss_stats->part) & 15)))

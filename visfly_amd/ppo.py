@@ -13,6 +13,7 @@ flat fp32 gradient buffer per optimiser step (plus the two fp64 advantage sums s
 normalisation is over the global minibatch) through ``torch.distributed`` (RCCL on ROCm).
 """
 import ctypes as C
+import os
 import time
 from typing import Dict, List, Optional
 
@@ -933,8 +934,11 @@ class PPO:
         self._last_starts = th.ones(self.n_envs, device=dev)
         self._shuf = None
         # fold + gradient norm + clip + Adam inside the weight-gradient launch (vf_mlp_weight_grad_adam): single-GPU steps without a
-        # target_kl check between backward and optimizer.step(); VISFLY_AMD_FUSED_TAIL=0 switches it off in the library
-        self.fused_tail = True
+        # target_kl check between backward and optimizer.step().  Bit-identical to the separate launches and, measured, 4.6 us per
+        # optimiser step SLOWER (two device-wide meetings of 1 000 lone waves cost 3.5 us each, the in-kernel fold reads the same 20 MB
+        # of partials, and the expensive launch boundaries are the ones behind the two big kernels, which stay:
+        # profiles/r06_fused_tail.txt) -- off unless VISFLY_AMD_FUSED_TAIL=1
+        self.fused_tail = os.environ.get("VISFLY_AMD_FUSED_TAIL", "0") == "1"
         self._tail_sync = th.zeros(_lib.WGRAD_SYNC_WORDS, dtype=th.int32, device=dev)
         self._tail_launches = 0
         self.index_minibatches = False     # True: train() reads its minibatches through the permutation slice (vf_ppo_loss_cfg.row_index) instead of a shuffled copy -- measured 2 % slower, see train()
