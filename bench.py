@@ -154,7 +154,9 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
     spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
     env = NavigationEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dict(DYN_KW), random_kwargs=spawn,
                         device=dev, max_episode_steps=256)
-    kw = {}
+    # the networks of the reference's experiment YAMLs (exps/examples/alg_cfgs/*/PPO.yaml: activation_fn relu; the policy class's own
+    # default would be Tanh trunks, policies.py:108)
+    kw = dict(policy_kwargs=dict(activation_fn="relu"))
     if getattr(args, "net_arch", None):
         arch = {k: [int(x) for x in v.split(",")] for k, v in (p.split("=") for p in args.net_arch.split(":"))}
         kw = dict(policy_kwargs=dict(features_extractor_class="StateTargetExtractor", activation_fn="ReLU", net_arch=arch,

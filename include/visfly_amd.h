@@ -38,7 +38,9 @@ extern "C" {
                               7: mean_rows / log_std_rows / reward_rows / ep_flag_rows of vf_bptt_rollout, log_std_rows of vf_bptt_reverse (td_policies.Actor classes);
                               8: vf_twin_q_update (fused critic step of SHAC), vf_mlp_forward_steps, vf_shac_accumulate_horizon 
                               9: vf_ppo_loss_cfg.row_index / obs_copy0 / obs_copy1 (vf_ppo_update on an indexed minibatch), vf_chain_plugin_*
-                              10: vf_mlp_weight_grad_adam / vf_wgrad_tail (fold + norm + clip + Adam inside the weight-gradient launch) */
+                              10: vf_mlp_weight_grad_adam / vf_wgrad_tail (fold + norm + clip + Adam inside the weight-gradient launch);
+                                  VF_ACTIVATION_* (vf_mlp_layer.relu is the activation kind, vf_mlp_bwd_layer.act, `act` argument of
+                                  vf_linear_bwd_data / vf_linear_bwd_weight / _acc) */
 
 /* clamp interval of the state-dependent log_std head of the reference's Actor (utils/policies/td_policies.py:31-32,241-243) */
 #define VF_SAC_LOG_STD_MIN (-10.0f)
@@ -445,27 +447,39 @@ int vf_adv_normalize(const float* adv, float* out, int64_t n, int64_t count, dou
 int vf_adv_normalize_segments(const float* adv, float* out, int32_t n_seg, int64_t seg_len, int64_t count, double* sums,
                               int32_t phase, vf_stream_t stream);
 
-/* Y[M][No] (+)= act(X[M][K] @ W^T + b)   nn.Linear + ReLU (extractors.py:421-445)
- *   W [No][K], b [No] or NULL; ldx / ldy row strides in floats; relu: 0/1; K, No <= 128. */
+/* Activation of an MLP layer (ABI 10): create_mlp's `activation_fn` (utils/policies/extractors.py:376-449) with the aliases of
+ * CustomMultiInputActorCriticPolicy (utils/policies/policies.py:64-69: relu, tanh, elu, leaky_relu -- torch.nn defaults: ELU alpha 1,
+ * LeakyReLU slope 0.01).  The values 0 / 1 are the `relu` flag of ABI <= 9.  In all four the derivative is a function of the layer's
+ * OUTPUT, so the reverse sweep needs the saved output only: [y > 0] | 1 - y^2 | y > 0 ? 1 : y + 1 | y > 0 ? 1 : 0.01.
+ * The register-chained kernels built into the library are ReLU networks; other activations run on the block-tile kernels or on chain
+ * classes generated for them (visfly_amd/_jit.py). */
+#define VF_ACTIVATION_NONE 0
+#define VF_ACTIVATION_RELU 1
+#define VF_ACTIVATION_TANH 2
+#define VF_ACTIVATION_ELU 3
+#define VF_ACTIVATION_LEAKY_RELU 4
+
+/* Y[M][No] (+)= act(X[M][K] @ W^T + b)   nn.Linear + activation (extractors.py:421-445)
+ *   W [No][K], b [No] or NULL; ldx / ldy row strides in floats; relu: VF_ACTIVATION_*; K, No <= 128. */
 int vf_linear_fwd(const float* X, int32_t ldx, const float* W, const float* b, float* Y, int32_t ldy,
                   int32_t M, int32_t K, int32_t No, int32_t relu, vf_stream_t stream);
 
-/* dX[M][K] (+)= (dY * [Y > 0]) @ W ; Ymask = the layer's saved post-ReLU output or NULL (no ReLU);
- * accumulate != 0 adds into dX (a tensor consumed by two branches). */
+/* dX[M][K] (+)= (dY * act'(Y)) @ W ; Ymask = the layer's saved post-activation output or NULL (no activation), act = its
+ * VF_ACTIVATION_* (0 with a Ymask: ReLU); accumulate != 0 adds into dX (a tensor consumed by two branches). */
 int vf_linear_bwd_data(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* W,
-                       float* dX, int32_t lddx, int32_t M, int32_t K, int32_t No, int32_t accumulate,
+                       float* dX, int32_t lddx, int32_t M, int32_t K, int32_t No, int32_t accumulate, int32_t act,
                        vf_stream_t stream);
 
-/* dW[No][K] = (dY * [Y > 0])^T @ X, db[No] = column sums; deterministic two-stage reduction.
+/* dW[No][K] = (dY * act'(Y))^T @ X, db[No] = column sums; deterministic two-stage reduction.
  * scratch: vf_linear_bwd_scratch_floats(M, K, No) floats. */
 int64_t vf_linear_bwd_scratch_floats(int32_t M, int32_t K, int32_t No);
 int vf_linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X,
                          int32_t ldx, float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch,
-                         vf_stream_t stream);
+                         int32_t act, vf_stream_t stream);
 /* same, adding into dW / db (gradient accumulation over the steps of a BPTT horizon) */
 int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X,
                              int32_t ldx, float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch,
-                             vf_stream_t stream);
+                             int32_t act, vf_stream_t stream);
 
 /* Whole actor-critic MLP forward in ONE launch (policies.py:195-254: extract_features -> mlp_extractor ->
  * action_net / value_net).  A workgroup walks 64-row tiles; activations live in LDS between layers,
@@ -567,7 +581,7 @@ typedef struct vf_mlp_bwd_layer {
     int32_t ld_dy, ld_y, ld_x, ld_dx;
     int32_t wb_off;              /* packed data-gradient weights of this layer (vf_mlp_layer.wb_off) */
     int32_t wq_off;              /* reverse-chain image of this layer (vf_mlp_layer.wq_off) */
-    int32_t pad0;
+    int32_t act;                 /* ABI 10 (was pad0): VF_ACTIVATION_* of the layer whose output Y is; 0 with Y != NULL = ReLU */
     int64_t w_off, b_off;        /* offsets into the flat parameter buffer == into a partial row */
     const float* dY;
     const float* Y;

@@ -342,3 +342,42 @@ def test_bptt_with_the_reference_actor_on_a_non_default_shape_runs_on_chain_kern
     lib.vf_chain_plugin_set_enabled(1)
     scale = grads[1].abs().max().item()
     assert scale > 0 and (grads[0] - grads[1]).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+def test_cold_jit_compile_on_this_box(tmp_path, monkeypatch):
+    """"compiled on first use" where users hit it: a shape nobody pre-built, an EMPTY cache directory, this box's own hipcc (four parts in
+    parallel + link), the plugin registered and its forward checked against torch -- the seconds go to gpurun_out/ (profiles/r06_jit_cold.txt)"""
+    import shutil
+    import time
+    from visfly_amd import _jit, _lib
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this box: a non-default net_arch then runs on the block-tile kernels (MlpPolicy warns once)")
+    lib = _lib.lib()
+    dims, ext, pi, vf = {"state": 13}, {"state": [32]}, [32], [64]            # the smallest class there is: one 32-wide layer per part
+    sh = _jit.shape_of(dims, ext, pi, vf)
+    assert sh is not None and not _jit.is_builtin(sh) and sh not in [_jit.shape_of(*v) for v in _jit.PREBUILD.values()]
+    monkeypatch.setattr(_jit, "JIT_DIR", str(tmp_path / "jit"))
+    monkeypatch.delitem(_jit._loaded, sh, raising=False)
+    assert not os.path.exists(_jit.path_of(sh)) and _jit.path_of(sh).startswith(str(tmp_path))
+    t0 = time.time()
+    assert _jit.ensure(sh)
+    secs = time.time() - t0
+    assert os.path.exists(_jit.path_of(sh)) and _jit.name_of(sh).encode() in [lib.vf_chain_plugin_name(i) for i in range(lib.vf_chain_plugin_count())]
+    from visfly_amd.ppo import MlpPolicy
+    pol = MlpPolicy(dims, ext, pi, vf, DEV, seed=4)
+    assert pol.chain_jit
+    M = 1000
+    obs = {"state": torch.randn((M, 13), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))}
+    ref = pol.to_torch().double().to(DEV)
+    m0, v0 = ref({k: v.double() for k, v in obs.items()})
+    n0 = lib.vf_chain_plugin_launches()
+    mean, value = pol.forward(obs)
+    assert lib.vf_chain_plugin_launches() == n0 + 1, "the freshly compiled plugin served the forward"
+    sc = max(m0.abs().max().item(), v0.abs().max().item(), 1e-3)
+    assert (mean.double() - m0).abs().max().item() <= 2e-6 * sc and (value.view(-1).double() - v0.view(-1)).abs().max().item() <= 2e-6 * sc
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r06_jit_cold.txt"), "a") as f:
+            f.write(f"cold JIT of `{_jit.name_of(sh)}` on the GPU box: {secs:.1f} s (hipcc x 4 parts + link, {os.cpu_count()} cores)\n")
+    assert secs < 600

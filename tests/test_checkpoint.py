@@ -97,20 +97,26 @@ def test_reference_yaml_blocks(tmp_path):
     assert cfg["env"]["num_agent_per_scene"] == 48
     pk = checkpoint.policy_kwargs_from_reference(cfg["algorithm"]["policy_kwargs"], ["state", "target"])
     assert pk == dict(extractor={"state": [128, 64], "target": [96, 32]}, pi=[64, 48], vf=[64, 64], weight_decay=1e-5,
-                      ortho_init=False)            # the YAML sets ortho_init: false; the default (key absent) is the reference's True
+                      ortho_init=False, activation=1, extractor_activation=1)      # the YAML sets ortho_init: false (default: the reference's True) and relu
     no_ortho_key = {k: v for k, v in cfg["algorithm"]["policy_kwargs"].items() if k != "ortho_init"}
     assert checkpoint.policy_kwargs_from_reference(no_ortho_key, ["state", "target"])["ortho_init"] is True
-    for missing_or_bad in ({k: v for k, v in cfg["algorithm"]["policy_kwargs"].items() if k != "activation_fn"},   # reference default: Tanh
-                           dict(cfg["algorithm"]["policy_kwargs"], squash_output=False)):
-        with pytest.raises(NotImplementedError):
-            checkpoint.policy_kwargs_from_reference(missing_or_bad, ["state", "target"])
+    # r06: activation_fn absent = the reference policy's own default, Tanh trunks over ReLU extractor MLPs (policies.py:108, extractors.py:666)
+    no_act = checkpoint.policy_kwargs_from_reference({k: v for k, v in cfg["algorithm"]["policy_kwargs"].items() if k != "activation_fn"}, ["state", "target"])
+    assert (no_act["activation"], no_act["extractor_activation"]) == (2, 1)
+    assert checkpoint.policy_kwargs_from_reference(None, ["state"])["activation"] == 2
+    with pytest.raises(NotImplementedError):
+        checkpoint.policy_kwargs_from_reference(dict(cfg["algorithm"]["policy_kwargs"], squash_output=False), ["state", "target"])
     native = dict(extractor={"state": [32]}, pi=[16], vf=[16])
     assert checkpoint.policy_kwargs_from_reference(native, ["state"]) == native
     bad = dict(cfg["algorithm"]["policy_kwargs"], features_extractor_class="StateTargetImageExtractor")
     with pytest.raises(NotImplementedError):
         checkpoint.policy_kwargs_from_reference(bad, ["state", "target"])
+    with_act = checkpoint.policy_kwargs_from_reference(dict(cfg["algorithm"]["policy_kwargs"], activation_fn="leaky_relu",
+                                                            features_extractor_kwargs=dict(cfg["algorithm"]["policy_kwargs"]["features_extractor_kwargs"], activation_fn="elu")),
+                                                       ["state", "target"])
+    assert (with_act["activation"], with_act["extractor_activation"]) == (4, 3)
     with pytest.raises(NotImplementedError):
-        checkpoint.policy_kwargs_from_reference(dict(cfg["algorithm"]["policy_kwargs"], activation_fn="tanh"), ["state", "target"])
+        checkpoint.policy_kwargs_from_reference(dict(cfg["algorithm"]["policy_kwargs"], activation_fn="gelu"), ["state", "target"])
     with pytest.raises(ValueError):
         checkpoint.policy_kwargs_from_reference(cfg["algorithm"]["policy_kwargs"], ["state"])
 

@@ -93,7 +93,7 @@ def _ppo_iteration(seed):
     N = 32768
     env = NavigationEnv(num_agent_per_scene=N, seed=42, dynamics_kwargs=dict(DYN), random_kwargs=NAV_SPAWN, device="cuda:0",
                         max_episode_steps=256)
-    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=seed)
+    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=seed, policy_kwargs=dict(activation_fn="relu"))
     ppo.learn(256 * N)
     torch.cuda.synchronize()
     out = (ppo.policy.flat.clone(), dict(ppo.logs), ppo._opt_step, ppo.num_timesteps)

@@ -27,7 +27,7 @@ def _worker(rank, world, port, q, algo, backend="gloo"):
         from visfly_amd.ppo import PPO
         env = HoverEnv(num_agent_per_scene=1024, seed=10 + rank, dynamics_kwargs=dict(ENV_DYN), device=dev, max_episode_steps=64,
                        tensor_output=True)
-        tr = PPO(env, n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3 + 17 * rank)   # rank-dependent seed: the ctor broadcasts rank 0's weights
+        tr = PPO(env, n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3 + 17 * rank, policy_kwargs=dict(activation_fn="relu"))   # rank-dependent seed: the ctor broadcasts rank 0's weights
         tr.learn(16 * 1024 * world * 2)
     elif algo == "shac":
         from visfly_amd.envs import HoverEnv

@@ -90,20 +90,124 @@ def test_linear_layers_vs_torch(K, No, M):
     dYm = (dY * (Ypost > 0)).double()
     # data gradient with mask, then accumulate
     dX = torch.zeros((M, K), device=DEV)
-    _lib.check(lib.vf_linear_bwd_data(dY.data_ptr(), No, Ypost.data_ptr(), No, W.data_ptr(), dX.data_ptr(), K, M, K, No, 0, st()))
+    _lib.check(lib.vf_linear_bwd_data(dY.data_ptr(), No, Ypost.data_ptr(), No, W.data_ptr(), dX.data_ptr(), K, M, K, No, 0, 1, st()))
     ref = dYm @ W.double()
     assert torch.allclose(dX.double(), ref, rtol=1e-5, atol=1e-5 * np.sqrt(No))
-    _lib.check(lib.vf_linear_bwd_data(dY.data_ptr(), No, None, 0, W.data_ptr(), dX.data_ptr(), K, M, K, No, 1, st()))
+    _lib.check(lib.vf_linear_bwd_data(dY.data_ptr(), No, None, 0, W.data_ptr(), dX.data_ptr(), K, M, K, No, 1, 0, st()))
     assert torch.allclose(dX.double(), ref + dY.double() @ W.double(), rtol=1e-5, atol=2e-5 * np.sqrt(No))
     # weight / bias gradient
     need = int(lib.vf_linear_bwd_scratch_floats(M, K, No))
     scratch = torch.empty(need, device=DEV)
     dW, db = torch.empty((No, K), device=DEV), torch.empty(No, device=DEV)
     _lib.check(lib.vf_linear_bwd_weight(dY.data_ptr(), No, Ypost.data_ptr(), No, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(),
-                                        M, K, No, scratch.data_ptr(), st()))
+                                        M, K, No, scratch.data_ptr(), 1, st()))
     tol = 2e-5 * np.sqrt(M)
     assert torch.allclose(dW.double(), dYm.T @ X.double(), rtol=1e-5, atol=tol)
     assert torch.allclose(db.double(), dYm.sum(0), rtol=1e-5, atol=tol)
+
+
+ACTS = {"relu": (1, torch.nn.ReLU), "tanh": (2, torch.nn.Tanh), "elu": (3, torch.nn.ELU), "leaky_relu": (4, torch.nn.LeakyReLU)}
+
+
+@pytest.mark.parametrize("act", list(ACTS))
+@pytest.mark.parametrize("K,No,M", [(13, 128, 200), (128, 64, 25600), (64, 64, 63), (7, 33, 1)])
+def test_linear_layers_with_every_activation_vs_torch(K, No, M, act):
+    """create_mlp's activation_fn (extractors.py:376-449; aliases policies.py:64-69) in the per-layer kernels: forward act(z), data and
+    weight gradients through act'(y) formed from the saved OUTPUT, against torch fp64"""
+    _lib, lib = L()
+    kind, mod = ACTS[act]
+    g = torch.Generator(device=DEV).manual_seed(K * 1000 + No + M + kind)
+    X = torch.randn((M, K), device=DEV, generator=g)
+    W = (torch.randn((No, K), device=DEV, generator=g) / np.sqrt(K)).requires_grad_(False)
+    b = torch.randn(No, device=DEV, generator=g)
+    dY = torch.randn((M, No), device=DEV, generator=g)
+    Xr, Wr, br = X.double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    Yr = mod()(Xr @ Wr.T + br)
+    (Yr * dY.double()).sum().backward()
+    Y = torch.empty((M, No), device=DEV)
+    _lib.check(lib.vf_linear_fwd(X.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), No, M, K, No, kind, st()))
+    assert torch.allclose(Y.double(), Yr.detach(), rtol=2e-6, atol=2e-6 * np.sqrt(K))
+    dX = torch.zeros((M, K), device=DEV)
+    _lib.check(lib.vf_linear_bwd_data(dY.data_ptr(), No, Y.data_ptr(), No, W.data_ptr(), dX.data_ptr(), K, M, K, No, 0, kind, st()))
+    assert torch.allclose(dX.double(), Xr.grad, rtol=1e-5, atol=1e-5 * np.sqrt(No))
+    scratch = torch.empty(int(lib.vf_linear_bwd_scratch_floats(M, K, No)), device=DEV)
+    dW, db = torch.empty((No, K), device=DEV), torch.empty(No, device=DEV)
+    _lib.check(lib.vf_linear_bwd_weight(dY.data_ptr(), No, Y.data_ptr(), No, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), M, K, No,
+                                        scratch.data_ptr(), kind, st()))
+    tol = 2e-5 * np.sqrt(M)
+    assert torch.allclose(dW.double(), Wr.grad, rtol=1e-5, atol=tol) and torch.allclose(db.double(), br.grad, rtol=1e-5, atol=tol)
+
+
+@pytest.mark.parametrize("acts", [("tanh", "relu"), ("elu", "tanh"), ("leaky_relu", "leaky_relu"), ("tanh", "tanh")])
+@pytest.mark.parametrize("M", [33, 25600])
+def test_policy_with_other_activations_vs_torch(acts, M):
+    """the whole actor-critic with `activation_fn` = Tanh (the reference policy's DEFAULT, policies.py:108) / ELU / LeakyReLU in the trunks
+    and / or the extractor MLPs: one-launch forward and backward (block-tile kernels: the chain classes are ReLU networks) and the
+    layer-by-layer path against torch autograd in fp64 -- the bounds of the ReLU tests"""
+    import warnings
+    from visfly_amd.ppo import MlpPolicy
+    act, ext_act = acts
+    dims = {"state": 13, "target": 3}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pol = MlpPolicy(dims, {k: [128, 64] for k in dims}, [64, 64], [64, 64], DEV, seed=5, activation=act, extractor_activation=ext_act)
+    assert pol.chain_shape is None and pol.spec["activation"] == act and pol.spec["extractor_activation"] == ext_act
+    g = torch.Generator(device=DEV).manual_seed(M)
+    obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+    d_mean, d_value = torch.randn((M, 4), device=DEV, generator=g) / M, torch.randn(M, device=DEV, generator=g) / M
+    ref = pol.to_torch().double().to(DEV)
+    xs = {k: v.double().requires_grad_(True) for k, v in obs.items()}
+    m0, v0 = ref(xs)
+    ((m0 * d_mean.double()).sum() + (v0.view(-1) * d_value.double()).sum()).backward()
+    gref = ref.flat_grad().to(DEV)
+    sc = max(m0.abs().max().item(), v0.abs().max().item(), 1e-3)
+    grads = []
+    for fused in (True, False):
+        pol.fused = pol.fused_backward = fused
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mean, value = pol.forward(obs)
+            assert (mean.double() - m0).abs().max().item() <= 4e-6 * sc and (value.view(-1).double() - v0.view(-1)).abs().max().item() <= 4e-6 * sc
+            d_in = pol.backward(d_mean, d_value, None, need_input_grad=True)
+        n = pol.log_std_off
+        gs = gref[:n].abs().max().item()
+        assert (pol.grad[:n].double() - gref[:n]).abs().max().item() <= 2e-5 * gs, fused
+        for k in dims:
+            assert (d_in[k].double() - xs[k].grad).abs().max().item() <= 2e-5 * max(xs[k].grad.abs().max().item(), 1e-12), (fused, k)
+        grads.append(pol.grad.clone())
+    assert (grads[0] - grads[1]).abs().max().item() <= 2e-5 * gref.abs().max().item()
+
+
+def test_ppo_without_policy_kwargs_builds_the_references_default_network_and_trains():
+    """`PPO(env)` with no policy_kwargs: CustomMultiInputActorCriticPolicy's defaults -- Tanh trunks (policies.py:108), ReLU extractor MLPs
+    (extractors.py:666) -- until r06 this raised.  It trains (value loss falls), on the block-tile kernels with ONE warning that says so;
+    string / class spellings of activation_fn are accepted; an archive restores the activations"""
+    import warnings
+    from visfly_amd.envs import NavigationEnv
+    from visfly_amd.ppo import PPO
+    from _golden import ENV_DYN
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+    mk = lambda: NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64,
+                               tensor_output=True, random_kwargs=spawn)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ppo = PPO(mk(), n_steps=16, batch_size=4096, n_epochs=4, learning_rate=1e-3, seed=3)
+        pol = ppo.policy
+        assert [ly.relu for ly in pol.layers] == [1, 1, 1, 1, 2, 2, 0, 2, 2, 0]
+        ppo.learn(16 * 1024)
+        v0 = ppo.logs["train/value_loss"]
+        ppo.learn(16 * 1024 * 6)
+    torch.cuda.synchronize()
+    assert ppo.logs["train/value_loss"] < v0 and np.isfinite(ppo.logs["train/loss"]) and bool(torch.isfinite(pol.flat).all())
+    fb = [x for x in w if "register-chained" in str(x.message) or "not available" in str(x.message)]
+    assert 1 <= len(fb) <= 3, [str(x.message)[:80] for x in w]
+    for spelled in ("Tanh", torch.nn.Tanh, "tanh"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            p2 = PPO(mk(), n_steps=16, batch_size=4096, policy_kwargs=dict(activation_fn=spelled, features_extractor_kwargs=dict(activation_fn="elu")))
+        assert (p2.policy.act, p2.policy.ext_act) == (2, 3)
+    with pytest.raises(NotImplementedError):
+        PPO(mk(), policy_kwargs=dict(activation_fn="gelu"))
 
 
 def sb3_squashed_log_prob(mean, log_std, actions):
@@ -321,7 +425,7 @@ def test_ppo_learn_runs_and_improves_value_fit():
     from _golden import ENV_DYN
     env = HoverEnv(num_agent_per_scene=2048, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64,
                    tensor_output=True)
-    ppo = PPO(env, n_steps=32, batch_size=8192, n_epochs=4, learning_rate=3e-4, seed=3)
+    ppo = PPO(env, n_steps=32, batch_size=8192, n_epochs=4, learning_rate=3e-4, seed=3, policy_kwargs=dict(activation_fn="relu"))
     p0 = ppo.policy.flat.clone()
     ppo.learn(32 * 2048)
     v_first = ppo.logs["train/value_loss"]
@@ -351,7 +455,7 @@ def test_ppo_training_is_bitwise_reproducible():
     for _ in range(2):
         env = HoverEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64,
                        tensor_output=True)
-        ppo = PPO(env, n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3)
+        ppo = PPO(env, n_steps=16, batch_size=4096, n_epochs=2, learning_rate=3e-4, seed=3, policy_kwargs=dict(activation_fn="relu"))
         ppo.learn(16 * 1024 * 3)
         flats.append(ppo.policy.flat.clone())
     assert torch.equal(flats[0], flats[1])
@@ -680,7 +784,7 @@ def test_ppo_training_with_indexed_minibatches_equals_the_shuffled_copy():
     flats = []
     for flag in (True, False):
         env = NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64, tensor_output=True)
-        ppo = PPO(env, n_steps=16, batch_size=6000, n_epochs=3, learning_rate=3e-4, seed=3, clip_range_vf=0.3)
+        ppo = PPO(env, n_steps=16, batch_size=6000, n_epochs=3, learning_rate=3e-4, seed=3, clip_range_vf=0.3, policy_kwargs=dict(activation_fn="relu"))
         ppo.index_minibatches = flag
         ppo.learn(16 * 1024 * 3)
         torch.cuda.synchronize()
@@ -753,7 +857,7 @@ def test_ppo_training_with_the_fused_tail_equals_the_separate_launches():
     for flag in (True, False):
         env = NavigationEnv(num_agent_per_scene=1024, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=64, tensor_output=True,
                             random_kwargs=spawn)
-        ppo = PPO(env, n_steps=16, batch_size=6000, n_epochs=3, learning_rate=3e-4, seed=3, clip_range_vf=0.3, ent_coef=0.01)
+        ppo = PPO(env, n_steps=16, batch_size=6000, n_epochs=3, learning_rate=3e-4, seed=3, clip_range_vf=0.3, ent_coef=0.01, policy_kwargs=dict(activation_fn="relu"))
         ppo.fused_tail = flag
         ppo.learn(16 * 1024 * 3)
         torch.cuda.synchronize()
@@ -771,7 +875,7 @@ def test_predict_is_deterministic_and_bounded():
     from visfly_amd.ppo import PPO
     from _golden import ENV_DYN
     env = HoverEnv(num_agent_per_scene=256, seed=1, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=48, tensor_output=True)
-    ppo = PPO(env, n_steps=16, batch_size=2048, n_epochs=1, seed=3)
+    ppo = PPO(env, n_steps=16, batch_size=2048, n_epochs=1, seed=3, policy_kwargs=dict(activation_fn="relu"))
     a0, _ = ppo.predict(env.reset(), deterministic=True)
     a1, _ = ppo.predict(env.get_observation(), deterministic=True)
     assert torch.equal(a0, a1) and a0.shape == (256, 4) and float(a0.abs().max()) <= 1.0
@@ -875,7 +979,7 @@ def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
             kw["random_kwargs"] = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
         env = getattr(E, env_name)(num_agent_per_scene=3000, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=11,
                                    tensor_output=True, **kw)
-        ppo = PPO(env, n_steps=48, batch_size=4096, n_epochs=1, seed=2)
+        ppo = PPO(env, n_steps=48, batch_size=4096, n_epochs=1, seed=2, policy_kwargs=dict(activation_fn="relu"))
         ppo.defer_bootstrap = defer
         ppo.collect_rollouts()
         torch.cuda.synchronize()
@@ -944,7 +1048,7 @@ def _persistent_rollout_vs_loop(env_name, N, dyn, policy_kwargs=None):
         env = getattr(E, env_name)(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(dkw), device=DEV, max_episode_steps=7,
                                    tensor_output=True, **kw)
         ppo = PPO(env, n_steps=20, batch_size=N * 20 // (4 if N < 16000 else 20), n_epochs=1, seed=2,
-                  **({"policy_kwargs": policy_kwargs} if policy_kwargs else {}))
+                  policy_kwargs=policy_kwargs or dict(activation_fn="relu"))
         ppo.fused_rollout = fused
         out = {}
         for rnd in range(2):
@@ -986,7 +1090,7 @@ def test_persistent_rollout_shortest_horizons(n_steps):
     res = []
     for fused in (True, False):
         env = HoverEnv(num_agent_per_scene=777, seed=3, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=3, tensor_output=True)
-        ppo = PPO(env, n_steps=n_steps, batch_size=777 * n_steps, n_epochs=1, seed=2)
+        ppo = PPO(env, n_steps=n_steps, batch_size=777 * n_steps, n_epochs=1, seed=2, policy_kwargs=dict(activation_fn="relu"))
         ppo.fused_rollout = fused
         for _ in range(5):
             ppo.collect_rollouts()
@@ -1007,7 +1111,7 @@ def test_persistent_rollout_declines_what_it_has_no_kernel_for():
     from _golden import ENV_DYN
     env = HoverEnv(num_agent_per_scene=512, seed=3, dynamics_kwargs=dict(ENV_DYN, wind_settings=["0.3 - 0.05*x", "0.02*x*x", "0.5*y + 0.1", "0*x + 0.125", "-0.01*x", "0.25*y - 0.05"]), device=DEV,
                    max_episode_steps=5, tensor_output=True)
-    ppo = PPO(env, n_steps=8, batch_size=2048, n_epochs=1, seed=2)
+    ppo = PPO(env, n_steps=8, batch_size=2048, n_epochs=1, seed=2, policy_kwargs=dict(activation_fn="relu"))
     used = []
     inner = env.collect_policy
     env.collect_policy = lambda *a, **k: used.append(inner(*a, **k)) or used[-1]
@@ -1026,7 +1130,7 @@ def test_ppo_on_a_host_observation_env_values_its_own_terminal_rows():
     from visfly_amd.ppo import PPO
     from _golden import ENV_DYN
     env = RacingEnv2(num_agent_per_scene=512, seed=4, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=9, tensor_output=True)
-    ppo = PPO(env, n_steps=24, batch_size=2048, n_epochs=1, seed=1)
+    ppo = PPO(env, n_steps=24, batch_size=2048, n_epochs=1, seed=1, policy_kwargs=dict(activation_fn="relu"))
     assert ppo.policy.obs_dims["state"] == 16 and ppo.defer_bootstrap is False
     ppo.collect_rollouts()
     torch.cuda.synchronize()

@@ -58,7 +58,8 @@ def test_train_replays_the_references_train(name):
     ppo = PPO(env, n_steps=T, batch_size=bs, n_epochs=int(fx["n_epochs"]), gamma=float(fx["gamma"]), gae_lambda=float(fx["gae_lambda"]),
               clip_range=clip_arg, ent_coef=float(fx["ent_coef"]), vf_coef=float(fx["vf_coef"]),
               max_grad_norm=float(fx["max_grad_norm"]), learning_rate=lr_arg, weight_decay=float(fx["weight_decay"]),
-              adam_eps=float(fx["adam_eps"]), target_kl=opt("target_kl"), clip_range_vf=clip_vf_arg, seed=0)
+              adam_eps=float(fx["adam_eps"]), target_kl=opt("target_kl"), clip_range_vf=clip_vf_arg, seed=0,
+              policy_kwargs=dict(activation_fn="relu"))        # the fixture's networks (oracle/gen_ppo_loop.py: activation_fn=nn.ReLU in both places)
     ppo._current_progress_remaining = float(fx["progress_remaining"])          # what learn() sets before train() (PPO.py:150-152)
     pol = ppo.policy
     n = pol.n_params

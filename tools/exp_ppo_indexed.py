@@ -11,7 +11,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dev = "cuda:0"
 dyn = dict(action_type="bodyrate", ori_output_type="quaternion", dt=0.0025, ctrl_dt=0.02, integrator="euler", drag_random=0.0)
 env = NavigationEnv(num_agent_per_scene=25600, seed=1, device=dev, max_episode_steps=256, tensor_output=True, dynamics_kwargs=dict(dyn))
-ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=0)
+ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=0, policy_kwargs=dict(activation_fn="relu"))
 ppo.collect_rollouts()
 rows = []
 for rep in range(3):

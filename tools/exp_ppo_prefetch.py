@@ -44,7 +44,7 @@ dyn = dict(action_type="bodyrate", ori_output_type="quaternion", dt=0.0025, ctrl
 
 def make(n, **kw):
     env = NavigationEnv(num_agent_per_scene=n, seed=1, device=dev, max_episode_steps=256, tensor_output=True, dynamics_kwargs=dict(dyn))
-    return PPO(env, learning_rate=1e-4, seed=0, **kw)
+    return PPO(env, learning_rate=1e-4, seed=0, policy_kwargs=dict(activation_fn="relu"), **kw)
 
 
 if len(sys.argv) <= 2:

@@ -13,7 +13,7 @@ N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 256
 dyn = dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True)
 env = NavigationEnv(num_agent_per_scene=N, seed=1, dynamics_kwargs=dyn, device="cuda:0", max_episode_steps=256, tensor_output=True,
                     random_kwargs={"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}})
-ppo = PPO(env, n_steps=T, batch_size=25600, n_epochs=1, seed=2)
+ppo = PPO(env, n_steps=T, batch_size=25600, n_epochs=1, seed=2, policy_kwargs=dict(activation_fn="relu"))
 for _ in range(3):
     ev = [th.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()

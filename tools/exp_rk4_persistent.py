@@ -28,7 +28,7 @@ def med(fn, n=5):
 print("NavigationEnv 32 768 agents, RK4 + drag randomisation, PPO collect_rollouts (256 steps):")
 for fused in (True, False):
     env = NavigationEnv(num_agent_per_scene=32768, seed=42, dynamics_kwargs=dict(DYN), random_kwargs=SPAWN, device="cuda:0", max_episode_steps=256)
-    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=1, seed=0)
+    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=1, seed=0, policy_kwargs=dict(activation_fn="relu"))
     ppo.fused_rollout = fused
     ppo.collect_rollouts()
     ms = med(ppo.collect_rollouts)

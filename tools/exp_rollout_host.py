@@ -7,7 +7,7 @@ from visfly_amd.ppo import PPO
 spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1.0, 0.0, 1.5], "half": [0.0, 2.0, 1.0]}}]}}
 env = NavigationEnv(num_agent_per_scene=32768, seed=1, device="cuda:0", tensor_output=True, max_episode_steps=256, random_kwargs=spawn,
                     dynamics_kwargs=dict(action_type="bodyrate", integrator="euler", dt=0.0025, ctrl_dt=0.02, ctrl_delay=True))
-ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5)
+ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, policy_kwargs=dict(activation_fn="relu"))
 ppo.collect_rollouts()
 torch.cuda.synchronize()
 for _ in range(2):

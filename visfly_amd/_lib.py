@@ -162,7 +162,7 @@ class GatherFields(C.Structure):
 class MlpBwdLayer(C.Structure):
     """mirror of vf_mlp_bwd_layer"""
     _fields_ = [("K", C.c_int32), ("No", C.c_int32), ("need_dx", C.c_int32), ("ld_dy", C.c_int32), ("ld_y", C.c_int32),
-                ("ld_x", C.c_int32), ("ld_dx", C.c_int32), ("wb_off", C.c_int32), ("wq_off", C.c_int32), ("pad0", C.c_int32),
+                ("ld_x", C.c_int32), ("ld_dx", C.c_int32), ("wb_off", C.c_int32), ("wq_off", C.c_int32), ("act", C.c_int32),
                 ("w_off", C.c_int64), ("b_off", C.c_int64),
                 ("dY", C.c_void_p), ("Y", C.c_void_p), ("X", C.c_void_p), ("dX", C.c_void_p)]
 
@@ -256,17 +256,17 @@ SIGNATURES = {
     "vf_env_time_steps": (C.c_int, [_vp, _vp, C.POINTER(EnvOut), C.c_int32, C.c_int32, _vp, C.POINTER(C.c_float)]),
     "vf_env_step_bwd": (C.c_int, [_vp, C.POINTER(EnvBwdArgs), _vp]),
     "vf_linear_bwd_weight_acc": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
-                                           C.c_int32, _vp, _vp]),
+                                           C.c_int32, _vp, C.c_int32, _vp]),
     "vf_gae": (C.c_int, [_vp] * 7 + [C.c_int32, C.c_int32, C.c_double, C.c_double, _vp]),
     "vf_td_returns": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp]),
     "vf_adv_normalize": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp]),
     "vf_adv_normalize_segments": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int64, _vp, C.c_int32, _vp]),
     "vf_linear_fwd": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "vf_linear_bwd_data": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_int32,
-                                     C.c_int32, C.c_int32, _vp]),
+                                     C.c_int32, C.c_int32, C.c_int32, _vp]),
     "vf_linear_bwd_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "vf_linear_bwd_weight": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
-                                       C.c_int32, _vp, _vp]),
+                                       C.c_int32, _vp, C.c_int32, _vp]),
     "vf_episode_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_reparam_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "vf_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),

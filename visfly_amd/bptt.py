@@ -124,7 +124,9 @@ class BPTT:
         pk.pop("share_features_extractor", None)
         if any(k in pk for k in ("features_extractor_class", "net_arch", "features_extractor_kwargs", "activation_fn")):
             pk.setdefault("activation_fn", "relu")                    # MTDPolicy's default activation IS ReLU (td_policies.py:297)
+        pk.setdefault("activation_fn", "relu")
         pk = checkpoint.policy_kwargs_from_reference(pk, self.obs_keys)
+        self._relu_only(pk)
         self._extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
         self._ext_keys = list(self._extractor.keys())
         arch = list(pk.get("pi", [64, 64]))
@@ -138,6 +140,13 @@ class BPTT:
             pol.bias(b).copy_(pol.bias(a))
         return pol
 
+    @staticmethod
+    def _relu_only(pk):
+        """BPTT / SHAC run their horizons on the persistent chain launches, which are ReLU networks (td_policies' own default,
+        td_policies.py:297); Tanh / ELU / LeakyReLU policies: PPO"""
+        if (pk.get("activation", 1), pk.get("extractor_activation", 1)) != (1, 1):
+            raise NotImplementedError("BPTT / SHAC: activation_fn other than relu is not implemented (the horizon kernels are ReLU networks)")
+
     def _head_fwd(self, mu, log_std, eps, action):
         """action = tanh(mu + eps exp(clamp(log_std))) -- Actor.action_log_prob's sample (SB3 squashed Gaussian)"""
         _lib.check(_lib.lib().vf_shac_head_fwd(_ptr(mu), _ptr(log_std), _ptr(eps), _ptr(action), mu.shape[0], LOG_STD_MIN,
@@ -148,7 +157,10 @@ class BPTT:
         state-independent log_std"""
         if self.reference_actor:
             return self._make_reference_actor(obs, policy_kwargs, seed)
-        pk = checkpoint.policy_kwargs_from_reference(policy_kwargs, self.obs_keys)
+        pk = dict(policy_kwargs or {})
+        pk.setdefault("activation_fn", "relu")             # (this actor is not a reference class: its default stays what it was)
+        pk = checkpoint.policy_kwargs_from_reference(pk, self.obs_keys)
+        self._relu_only(pk)
         self.weight_decay = pk.get("weight_decay", self.weight_decay)
         return MlpPolicy({k: obs[k].shape[1] for k in self.obs_keys},
                          pk.get("extractor", {k: [128, 64] for k in self.obs_keys}), pk.get("pi", [64, 64]),
@@ -393,8 +405,10 @@ class BPTT:
             kwargs.setdefault("horizon", spec["horizon"])
             # the hyper-parameters the archive was trained with (a resumed run silently trained with the constructor's
             # defaults next to the restored Adam moments); an explicit keyword argument still wins
+            import inspect
+            accepted = set(inspect.signature(cls.__init__).parameters)     # (BPTT.load on an archive SHAC wrote: tau / gradient_steps / lamda are not BPTT's)
             for k in ("gamma", "learning_rate", "tau", "gradient_steps", "lamda"):
-                if k in spec:
+                if k in spec and k in accepted:
                     kwargs.setdefault(k, spec[k])
             if cls is BPTT:
                 kwargs.setdefault("policy", "MultiInputPolicy")

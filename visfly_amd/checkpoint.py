@@ -52,8 +52,7 @@ def policy_kwargs_from_reference(pk: Optional[dict], obs_keys: List[str]) -> dic
     """SB3-style policy_kwargs of the reference's YAMLs -> MlpPolicy arguments (`extractor`, `pi`, `vf`,
     `log_std_init`) plus `weight_decay` from optimizer_kwargs.  Already-native dicts pass through."""
     pk = dict(pk or {})
-    if "extractor" in pk or not any(k in pk for k in ("features_extractor_class", "net_arch", "features_extractor_kwargs",
-                                                      "activation_fn", "optimizer_kwargs", "ortho_init")):
+    if "extractor" in pk:       # already MlpPolicy arguments
         return pk
     out: Dict[str, object] = {}
     cls = pk.get("features_extractor_class", "StateTargetExtractor" if "target" in obs_keys else "StateExtractor")
@@ -72,15 +71,12 @@ def policy_kwargs_from_reference(pk: Optional[dict], obs_keys: List[str]) -> dic
             raise NotImplementedError("batch / layer norm in the extractor MLPs is not implemented")
         ext[k] = list(a.get("layer", []))
     out["extractor"] = ext
-    # the reference policy's default activation is Tanh (policies.py:108); its YAMLs set relu explicitly.  A missing key would
-    # silently build a different network than the reference does, so it is required here.
-    if "activation_fn" not in pk:
-        raise NotImplementedError("policy_kwargs without activation_fn: the reference would build Tanh networks "
-                                  "(policies.py:108); the fused MLP kernels implement ReLU -- set activation_fn: relu")
-    act = pk["activation_fn"]
-    act = act if isinstance(act, str) else act.__name__
-    if act.lower() != "relu":
-        raise NotImplementedError(f"activation_fn {act}: the fused MLP kernels implement ReLU")
+    # trunks: the policy's activation_fn -- the reference's default is Tanh (policies.py:108; its YAMLs set relu); extractor MLPs:
+    # features_extractor_kwargs.activation_fn -- default ReLU (extractors.py:560,583,666).  relu | tanh | elu | leaky_relu
+    # (policies.py:64-69) as strings or torch classes
+    from .ppo import activation_kind
+    out["activation"] = activation_kind(pk.get("activation_fn", "tanh"))
+    out["extractor_activation"] = activation_kind((pk.get("features_extractor_kwargs") or {}).get("activation_fn", "relu"))
     if pk.get("squash_output", True) is False:
         raise NotImplementedError("squash_output=False: the action head is the tanh-squashed Gaussian (policies.py:114,177-181)")
     if pk.get("use_sde"):
@@ -246,7 +242,8 @@ def ctor_kwargs_from_archive(path: str, overrides: Optional[dict] = None) -> dic
                 kw[k] = tuple(v) if k == "betas" else v
         spec = data.get("policy_spec")
         if isinstance(spec, dict) and "extractor" in spec:
-            kw["policy_kwargs"] = dict(extractor=spec["extractor"], pi=spec["pi"], vf=spec["vf"])
+            kw["policy_kwargs"] = dict(extractor=spec["extractor"], pi=spec["pi"], vf=spec["vf"], activation=spec.get("activation", "relu"),
+                                       extractor_activation=spec.get("extractor_activation", "relu"))
     kw.update(overrides or {})
     return kw
 

@@ -80,6 +80,31 @@ __device__ __forceinline__ U4 philox4x32_10(U4 ctr, unsigned k0, unsigned k1)
 
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f); }
 
+// ---- activations of the MLP layers (vf_mlp_layer.relu / vf_mlp_bwd_layer.act: VF_ACTIVATION_*) ----
+// create_mlp's `activation_fn` (utils/policies/extractors.py:376-449; the aliases of policies.py:64-69): ReLU, Tanh, ELU (alpha = 1),
+// LeakyReLU (slope 0.01) -- torch.nn defaults.  The derivative is a function of the OUTPUT in all four, so the reverse sweep needs
+// the saved layer output only (as for the ReLU mask): d/dz = [y > 0] | 1 - y^2 | y > 0 ? 1 : y + 1 | y > 0 ? 1 : 0.01
+__device__ __forceinline__ float act_fwd(float z, int kind)
+{
+    switch (kind) {
+    case VF_ACTIVATION_RELU: return z > 0.0f ? z : 0.0f;
+    case VF_ACTIVATION_TANH: return tanhf(z);
+    case VF_ACTIVATION_ELU: return z > 0.0f ? z : expm1f(z);
+    case VF_ACTIVATION_LEAKY_RELU: return z > 0.0f ? z : 0.01f * z;
+    default: return z;
+    }
+}
+// upstream gradient v through the activation whose output was y
+__device__ __forceinline__ float act_mul(float v, float y, int kind)
+{
+    switch (kind) {
+    case VF_ACTIVATION_TANH: return v * (1.0f - y * y);
+    case VF_ACTIVATION_ELU: return y > 0.0f ? v : v * (y + 1.0f);
+    case VF_ACTIVATION_LEAKY_RELU: return y > 0.0f ? v : 0.01f * v;
+    default: return y > 0.0f ? v : 0.0f;        // ReLU (kind 0 with a saved output = ReLU: tables written before ABI 10)
+    }
+}
+
 // Pull the whole kernel-argument block into the scalar cache with one batch of loads (24 lines per batch).  The chain kernels
 // take their layer tables by value (1.2 - 2.8 KB of kernel arguments at a fresh address every launch) and the compiler fetches a
 // field where it is first used: k_ppo_update_chain had 314 s_load / 216 s_waitcnt lgkmcnt in its body, ~44 of them first touches

@@ -357,7 +357,7 @@ bool chain_matches_gen(const vf_mlp_desc& d)
         const int b = Sh::branch_of(fl), p = Sh::producer(fl);
         const int K = p == -1 ? d.in_dim[b] : 32 * Sh::in_tiles(fl);
         const int No = fl == N::L_mean ? N::HM : fl == N::L_value ? N::HV : 32 * Sh::width(fl);
-        if (L.K != K || L.No != No || (L.relu != 0) == Sh::is_head(fl) || L.wr_off < 0 || (L.wr_off & 3)) return false;
+        if (L.K != K || L.No != No || L.relu != (Sh::is_head(fl) ? VF_ACTIVATION_NONE : VF_ACTIVATION_RELU) || L.wr_off < 0 || (L.wr_off & 3)) return false;
         if (p == -1) {
             if (L.src != b || L.src_col != 0) return false;
         } else if (p == -2) {
@@ -394,7 +394,7 @@ bool bwd_chain_matches_gen(const vf_mlp_bwd_desc& d, bool ig)
             if (E.K != 32 * Sh::in_tiles(fl) || E.need_dx == 0) return false;
         }
         const int No = fl == N::L_mean ? N::HM : fl == N::L_value ? N::HV : 32 * Sh::width(fl);
-        if (E.No != No || (E.Y != nullptr) != relu || E.wq_off < 0 || (E.wq_off & 3)) return false;
+        if (E.No != No || (E.Y != nullptr) != relu || E.act > VF_ACTIVATION_RELU || E.wq_off < 0 || (E.wq_off & 3)) return false;
         if (relu && (!al16(E.Y) || (E.ld_y & 3) || !al16(E.dY) || (E.ld_dy & 3))) return false;
         // wiring: the gradient this layer's weights produce is its producer's dY buffer (the feature gradient: the branch's columns)
         if (p >= 0 && E.dX != d.layer[P::entry(p)].dY) return false;

@@ -186,7 +186,7 @@ bool chain_matches(const vf_mlp_desc& d)
         if (d.in_dim[b] < 1 || d.in_dim[b] > N::kin(b)) return false;
     auto is = [&](int li, int K, int No, int relu) {
         const vf_mlp_layer& L = d.layer[li];
-        return L.K == K && L.No == No && (L.relu != 0) == (relu != 0) && L.wr_off >= 0 && (L.wr_off & 3) == 0;
+        return L.K == K && L.No == No && L.relu == (relu ? VF_ACTIVATION_RELU : VF_ACTIVATION_NONE) && L.wr_off >= 0 && (L.wr_off & 3) == 0;     // (the built-in classes are ReLU networks)
     };
     int feat = N::NB * N::E2 * 32;
     for (int b = 0; b < N::NB; ++b) {
@@ -263,7 +263,7 @@ bool bwd_chain_matches(const vf_mlp_bwd_desc& d)
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     auto is = [&](int fl, int K, int No, bool relu, bool first) {
         const vf_mlp_bwd_layer& E = d.layer[P::entry(fl)];
-        if (E.K != K || E.No != No || (E.Y != nullptr) != relu || E.wq_off < 0 || (E.wq_off & 3)) return false;
+        if (E.K != K || E.No != No || (E.Y != nullptr) != relu || E.act > VF_ACTIVATION_RELU || E.wq_off < 0 || (E.wq_off & 3)) return false;
         if (relu && (!al16(E.Y) || (E.ld_y & 3) || !al16(E.dY) || (E.ld_dy & 3))) return false;   // float4 mask loads / dZ stores
         if (first ? (E.need_dx != 0) != IG : E.need_dx == 0) return false;
         return true;

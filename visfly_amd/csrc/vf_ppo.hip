@@ -220,7 +220,7 @@ __device__ __forceinline__ void mfma_sweep2(const float* __restrict__ ap, const 
 template <bool MASK, int NT = kBlock>
 __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const float* __restrict__ A, int lda,
                                            const float* __restrict__ Ym, int ldym, int m0, int M, int red, int redp,
-                                           int nrows = kRows)
+                                           int nrows = kRows, int act = VF_ACTIVATION_RELU)
 {
     const int tid = threadIdx.x;
     const int c4 = red >> 2;
@@ -254,8 +254,8 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
                     const bool ok = r <= rmax;
                     float4 x = v[j];
                     if (mask) {
-                        x.x = y[j].x > 0.0f ? x.x : 0.0f; x.y = y[j].y > 0.0f ? x.y : 0.0f;
-                        x.z = y[j].z > 0.0f ? x.z : 0.0f; x.w = y[j].w > 0.0f ? x.w : 0.0f;
+                        x.x = act_mul(x.x, y[j].x, act); x.y = act_mul(x.y, y[j].y, act);
+                        x.z = act_mul(x.z, y[j].z, act); x.w = act_mul(x.w, y[j].w, act);
                     }
                     if (r < nrows) {
                         float* d = As + r * sa + col;
@@ -288,7 +288,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ As, int sa, const
                 if (idx < total) {
                     const int r = idx / redp, k = idx - r * redp;
                     float v = x[j];
-                    if (mask) v = y[j] > 0.0f ? v : 0.0f;
+                    if (mask) v = act_mul(v, y[j], act);
                     As[r * sa + k] = (r <= rmax && k < red) ? v : 0.0f;
                 }
             }
@@ -316,7 +316,7 @@ struct RowPrefetch {
         rstep = kBlock >> sh;          // rows covered per pass; 64 rows -> 64 / rstep <= 8 passes
     }
     __device__ __forceinline__ void load(const float* __restrict__ A, int lda, const float* __restrict__ Ym, int ldym, int m0,
-                                         int M)
+                                         int M, int act = VF_ACTIVATION_RELU)
     {
         const bool mask = MASK && Ym != nullptr;
         float4 y[8];
@@ -331,8 +331,8 @@ struct RowPrefetch {
             const bool ok = m0 + r0 + j * rstep < M;
             float4 x = v[j];
             if (mask) {
-                x.x = y[j].x > 0.0f ? x.x : 0.0f; x.y = y[j].y > 0.0f ? x.y : 0.0f;
-                x.z = y[j].z > 0.0f ? x.z : 0.0f; x.w = y[j].w > 0.0f ? x.w : 0.0f;
+                x.x = act_mul(x.x, y[j].x, act); x.y = act_mul(x.y, y[j].y, act);
+                x.z = act_mul(x.z, y[j].z, act); x.w = act_mul(x.w, y[j].w, act);
             }
             v[j] = make_float4(ok ? x.x : 0.0f, ok ? x.y : 0.0f, ok ? x.z : 0.0f, ok ? x.w : 0.0f);
         }
@@ -354,10 +354,10 @@ struct RowPrefetch {
 // BWD == true : C[m][k] = sum_n (A[m][n] * [Ymask[m][n] > 0]) * W[n][k]  (data grad; red = No, cols = K)
 // Weight-stationary: a block stages W once and walks 64-row tiles with stride gridDim.x; the next
 // tile's rows are fetched into registers while the MFMAs of the current one run.
-template <bool BWD, bool RELU>
+template <bool BWD>
 __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, int lda, const float* __restrict__ Ym,
                                                    int ldym, const float* __restrict__ W, const float* __restrict__ bias,
-                                                   float* __restrict__ C, int ldc, int M, int K, int No, int accumulate)
+                                                   float* __restrict__ C, int ldc, int M, int K, int No, int accumulate, int act)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int red = BWD ? No : K;         // reduction length
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
     RowPrefetch<BWD> pf;
     pf.setup(A, lda, Ym, ldym, red);
     int tile = blockIdx.x;
-    if (pf.vec && tile < ntiles) pf.load(A, lda, Ym, ldym, tile * kRows, M);   // in flight while W is staged
+    if (pf.vec && tile < ntiles) pf.load(A, lda, Ym, ldym, tile * kRows, M, act);   // in flight while W is staged
 
     // W image: Ws[n * sw + k] = W[n][k] for both directions (forward reads it column-major over the
     // reduction, the data gradient row-major); pads are zero.
@@ -398,9 +398,9 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
     for (; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * kRows;
         if (pf.vec) pf.store(As, sa);
-        else stage_rows<BWD>(As, sa, A, lda, Ym, ldym, m0, M, red, red);
+        else stage_rows<BWD>(As, sa, A, lda, Ym, ldym, m0, M, red, red, kRows, act);
         __syncthreads();
-        if (pf.vec && tile + gridDim.x < ntiles) pf.load(A, lda, Ym, ldym, (tile + gridDim.x) * kRows, M);
+        if (pf.vec && tile + gridDim.x < ntiles) pf.load(A, lda, Ym, ldym, (tile + gridDim.x) * kRows, M, act);
         f32x16 acc0 = {0}, acc1 = {0};
         if (nacc == 2) mfma_sweep2(ap, b0, b1, bs, red16, acc0, acc1);
         else if (nacc == 1) mfma_sweep1(ap, b0, bs, red16, acc0);
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void k_linear(const float* __restrict__ A, 
                 const int m = m0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
                 if (m >= M) continue;
                 float y = acc[reg] + bn;
-                if (RELU) y = y > 0.0f ? y : 0.0f;
+                if (!BWD) y = act_fwd(y, act);
                 float* dst = C + (size_t)m * ldc + n;
                 *dst = accumulate ? *dst + y : y;
             }
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mlp_forward(const vf_mlp_desc d, 
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     float y = acc[reg] + bn;
-                    if (L.relu) y = y > 0.0f ? y : 0.0f;
+                    y = act_fwd(y, L.relu);
                     acc[reg] = y;
                 }
                 if (L.dst < VF_MLP_OUT0) {
@@ -719,7 +719,8 @@ struct TilePf {
             v[0].x = t[0]; v[0].y = t[1];
         }
     }
-    __device__ __forceinline__ void park(int mode, float* __restrict__ As, int sa, int m0, int M, int w, int wpad, const TilePf* ym) const
+    __device__ __forceinline__ void park(int mode, float* __restrict__ As, int sa, int m0, int M, int w, int wpad, const TilePf* ym,
+                                         int act = VF_ACTIVATION_RELU) const
     {
         const int tid = threadIdx.x, rmax = M - 1 - m0;
         if (wpad > w) {                                        // pad columns hold stale words of another layer
@@ -739,8 +740,8 @@ struct TilePf {
                     float4 x = v[j];
                     if (ym) {
                         const float4 y = ym->v[j];
-                        x.x = y.x > 0.0f ? x.x : 0.0f; x.y = y.y > 0.0f ? x.y : 0.0f;
-                        x.z = y.z > 0.0f ? x.z : 0.0f; x.w = y.w > 0.0f ? x.w : 0.0f;
+                        x.x = act_mul(x.x, y.x, act); x.y = act_mul(x.y, y.y, act);
+                        x.z = act_mul(x.z, y.z, act); x.w = act_mul(x.w, y.w, act);
                     }
                     const bool ok = r <= rmax;
                     if (r < kRows) {
@@ -758,7 +759,7 @@ struct TilePf {
                 const int idx = tid + j * kBwdThreads;
                 if (idx < total) {
                     const int r = idx / w, k = idx - r * w;
-                    As[r * sa + k] = (r <= rmax && ty[j] > 0.0f) ? t[j] : 0.0f;
+                    As[r * sa + k] = r <= rmax ? (ym ? act_mul(t[j], ty[j], act) : t[j]) : 0.0f;
                 }
             }
         }
@@ -808,10 +809,10 @@ __global__ __launch_bounds__(kBwdThreads) void k_mlp_backward(const vf_mlp_bwd_d
             if (sx - 1 > L.K) pfX.park(0, Xs, sx, m0, M, L.K, sx - 1, nullptr);   // pads only
             stage_rows<false, kBwdThreads>(Xs, sx, L.X, L.ld_x, nullptr, 0, m0, M, L.K, L.K);
         }
-        if (md) pfD.park(md, Ds, sd, m0, M, L.No, sd - 1, L.Y ? &pfY : nullptr);
+        if (md) pfD.park(md, Ds, sd, m0, M, L.No, sd - 1, L.Y ? &pfY : nullptr, L.act);
         else {
             if (sd - 1 > L.No) pfD.park(0, Ds, sd, m0, M, L.No, sd - 1, nullptr);
-            stage_rows<true, kBwdThreads>(Ds, sd, L.dY, L.ld_dy, L.Y, L.ld_y, m0, M, L.No, L.No);
+            stage_rows<true, kBwdThreads>(Ds, sd, L.dY, L.ld_dy, L.Y, L.ld_y, m0, M, L.No, L.No, kRows, L.act);
         }
     };
     auto issue_item = [&](const vf_mlp_bwd_layer& L, int m0, bool with_dy) {
@@ -952,7 +953,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_mlp_backward(const vf_mlp_bwd_d
 // dW[n][k] = sum_m dYm[m][n] X[m][k]; block = one chunk of rows, partial written to part[blk][No*K + No]
 __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict__ dY, int lddy, const float* __restrict__ Ym,
                                                          int ldym, const float* __restrict__ X, int ldx,
-                                                         float* __restrict__ part, int M, int K, int No, int rows_per_block)
+                                                         float* __restrict__ part, int M, int K, int No, int rows_per_block, int act)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nt = (No + 31) >> 5, kt = (K + 31) >> 5;
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void k_linear_wgrad(const float* __restrict
     for (int idx = tid; idx < kRows * (sd + sx); idx += kBlock) lds[idx] = 0.0f;   // pad columns stay zero
     __syncthreads();
     for (int m0 = mb; m0 < me; m0 += kRows) {
-        stage_rows<true>(Ds, sd, dY, lddy, Ym, ldym, m0, me, No, nt * 32);
+        stage_rows<true>(Ds, sd, dY, lddy, Ym, ldym, m0, me, No, nt * 32, kRows, act);
         stage_rows<false>(Xs, sx, X, ldx, nullptr, 0, m0, me, K, kt * 32);
         __syncthreads();
         {   // bias gradient: every thread owns (column, row-slice); slices are combined at the end
@@ -1494,26 +1495,23 @@ int vf_linear_fwd(const float* X, int32_t ldx, const float* W, const float* b, f
     const size_t lds = linear_lds_bytes(false, K, No);
     const dim3 grid(linear_grid(M)), block(vf::kBlock);
     hipStream_t st = vf::as_stream(stream);
-    if (relu) {
-        if (int rc = allow_lds(vf::k_linear<false, true>, lds)) return rc;
-        hipLaunchKernelGGL((vf::k_linear<false, true>), grid, block, lds, st, X, ldx, (const float*)nullptr, 0, W, b, Y, ldy, M, K, No, 0);
-    } else {
-        if (int rc = allow_lds(vf::k_linear<false, false>, lds)) return rc;
-        hipLaunchKernelGGL((vf::k_linear<false, false>), grid, block, lds, st, X, ldx, (const float*)nullptr, 0, W, b, Y, ldy, M, K, No, 0);
-    }
+    if (relu < 0 || relu > VF_ACTIVATION_LEAKY_RELU) return vf::fail(VF_EINVAL, "vf_linear_fwd: activation kind %d", relu);
+    if (int rc = allow_lds(vf::k_linear<false>, lds)) return rc;
+    hipLaunchKernelGGL((vf::k_linear<false>), grid, block, lds, st, X, ldx, (const float*)nullptr, 0, W, b, Y, ldy, M, K, No, 0, relu);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
 
 int vf_linear_bwd_data(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* W, float* dX,
-                       int32_t lddx, int32_t M, int32_t K, int32_t No, int32_t accumulate, vf_stream_t stream)
+                       int32_t lddx, int32_t M, int32_t K, int32_t No, int32_t accumulate, int32_t act, vf_stream_t stream)
 {
-    if (!dY || !W || !dX || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128 || lddy < No || lddx < K)
+    if (!dY || !W || !dX || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128 || lddy < No || lddx < K || act < 0 ||
+        act > VF_ACTIVATION_LEAKY_RELU)
         return vf::fail(VF_EINVAL, "vf_linear_bwd_data: bad argument (K, No <= 128)");
     const size_t lds = linear_lds_bytes(true, K, No);
-    if (int rc = allow_lds(vf::k_linear<true, false>, lds)) return rc;
-    hipLaunchKernelGGL((vf::k_linear<true, false>), dim3(linear_grid(M)), dim3(vf::kBlock), lds,
-                       vf::as_stream(stream), dY, lddy, Ymask, ldym, W, (const float*)nullptr, dX, lddx, M, K, No, accumulate);
+    if (int rc = allow_lds(vf::k_linear<true>, lds)) return rc;
+    hipLaunchKernelGGL((vf::k_linear<true>), dim3(linear_grid(M)), dim3(vf::kBlock), lds,
+                       vf::as_stream(stream), dY, lddy, Ymask, ldym, W, (const float*)nullptr, dX, lddx, M, K, No, accumulate, act);
     VF_HIP(hipGetLastError());
     return VF_OK;
 }
@@ -1527,9 +1525,9 @@ int64_t vf_linear_bwd_scratch_floats(int32_t M, int32_t K, int32_t No)
 
 static int linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X, int32_t ldx,
                              float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream,
-                             int accumulate)
+                             int accumulate, int act)
 {
-    if (!dY || !X || !dW || !scratch || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128)
+    if (!dY || !X || !dW || !scratch || M <= 0 || K <= 0 || No <= 0 || K > 128 || No > 128 || act < 0 || act > VF_ACTIVATION_LEAKY_RELU)
         return vf::fail(VF_EINVAL, "vf_linear_bwd_weight: bad argument (K, No <= 128)");
     const int rpb = wgrad_rows_per_block(M);
     const int nblk = (M + rpb - 1) / rpb;
@@ -1538,7 +1536,7 @@ static int linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, 
     if (int rc = allow_lds(vf::k_linear_wgrad, lds)) return rc;
     hipStream_t st = vf::as_stream(stream);
     hipLaunchKernelGGL(vf::k_linear_wgrad, dim3(nblk), dim3(vf::kBlock), lds, st, dY, lddy, Ymask, ldym, X, ldx, scratch, M, K,
-                       No, rpb);
+                       No, rpb, act);
     const int n = No * K + No;
     hipLaunchKernelGGL(vf::k_fold_partials, dim3((n + 63) / 64), dim3(vf::kBlock), 0, st, scratch, nblk, n,
                        No * K, No, dW, db, accumulate);
@@ -1547,15 +1545,15 @@ static int linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, 
 }
 
 int vf_linear_bwd_weight(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X, int32_t ldx,
-                         float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream)
+                         float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, int32_t act, vf_stream_t stream)
 {
-    return linear_bwd_weight(dY, lddy, Ymask, ldym, X, ldx, dW, db, M, K, No, scratch, stream, 0);
+    return linear_bwd_weight(dY, lddy, Ymask, ldym, X, ldx, dW, db, M, K, No, scratch, stream, 0, act);
 }
 
 int vf_linear_bwd_weight_acc(const float* dY, int32_t lddy, const float* Ymask, int32_t ldym, const float* X, int32_t ldx,
-                             float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, vf_stream_t stream)
+                             float* dW, float* db, int32_t M, int32_t K, int32_t No, float* scratch, int32_t act, vf_stream_t stream)
 {
-    return linear_bwd_weight(dY, lddy, Ymask, ldym, X, ldx, dW, db, M, K, No, scratch, stream, 1);
+    return linear_bwd_weight(dY, lddy, Ymask, ldym, X, ldx, dW, db, M, K, No, scratch, stream, 1, act);
 }
 
 int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc)

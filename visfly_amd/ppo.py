@@ -27,8 +27,28 @@ def _ptr(t, off=0):
     return None if t is None else t.data_ptr() + 4 * off
 
 
+# create_mlp's activation_fn (utils/policies/extractors.py:376-449) under the aliases of CustomMultiInputActorCriticPolicy
+# (utils/policies/policies.py:64-69) -> VF_ACTIVATION_* of include/visfly_amd.h
+ACTIVATIONS = {"relu": 1, "tanh": 2, "elu": 3, "leaky_relu": 4}
+_TORCH_ACT = {1: "ReLU", 2: "Tanh", 3: "ELU", 4: "LeakyReLU"}
+
+
+def activation_kind(a) -> int:
+    """'relu' / 'Tanh' / nn.ELU / nn.LeakyReLU() ... -> VF_ACTIVATION_*"""
+    if isinstance(a, int):
+        if a in _TORCH_ACT:
+            return a
+        raise ValueError(f"activation kind {a}")
+    name = a if isinstance(a, str) else getattr(a, "__name__", type(a).__name__)
+    key = name.lower().replace("leakyrelu", "leaky_relu")
+    if key not in ACTIVATIONS:
+        raise NotImplementedError(f"activation_fn {name}: the MLP kernels implement {sorted(ACTIVATIONS)} (policies.py:64-69)")
+    return ACTIVATIONS[key]
+
+
 class _Linear:
-    """one nn.Linear (+ReLU) of the schedule: reads src[:, sc:sc+K], writes dst[:, dc:dc+No]"""
+    """one nn.Linear (+ activation) of the schedule: reads src[:, sc:sc+K], writes dst[:, dc:dc+No]; ``relu``: the activation kind
+    (VF_ACTIVATION_*: 0 none, 1 ReLU, 2 Tanh, 3 ELU, 4 LeakyReLU -- the name is the ABI's)"""
 
     def __init__(self, K, No, relu, src, sc, dst, dc, w_off, b_off, first):
         self.K, self.No, self.relu = K, No, relu
@@ -49,20 +69,28 @@ class MlpPolicy:
 
     def __init__(self, obs_dims: Dict[str, int], extractor: Dict[str, List[int]], pi: List[int], vf: List[int],
                  device, action_dim: int = 4, log_std_init: float = 0.0, seed: int = 0, ortho_init: bool = True,
-                 head_dims=None, passthrough=(), log_std_param: bool = True):
+                 head_dims=None, passthrough=(), log_std_param: bool = True, activation="relu", extractor_activation="relu"):
         """``head_dims`` (default (action_dim, 1)): widths of the two heads "mean" / "value" -- the SHAC actor of the reference
         has two 4-wide heads (mu and a state-dependent log_std, utils/policies/td_policies.py:230-243), its twin critic two
         1-wide ones.  ``passthrough``: input keys whose columns are appended to the features unchanged, after the extractor
         outputs -- ``th.cat([features, actions], dim=-1)`` of ContinuousCritic.forward (:137); realised as a frozen identity
         layer (W = I, b = 0: exact in fp32) whose parameters sit BEHIND the trainable ones in ``flat`` and never receive a
-        gradient.  ``log_std_param`` False: no state-independent log_std parameter."""
+        gradient.  ``log_std_param`` False: no state-independent log_std parameter.
+        ``activation`` / ``extractor_activation``: activation of the trunks' hidden layers (the policy's ``activation_fn``,
+        policies.py:108: the reference's default there is Tanh) and of the extractor MLPs (``features_extractor_kwargs.activation_fn``,
+        extractors.py:560,583: default ReLU): relu | tanh | elu | leaky_relu.  The register-chained kernels are ReLU networks; another
+        activation runs on the block-tile kernels (same arithmetic, 0.13-0.26 of the fp32-MFMA peak instead of 0.38-0.46)."""
         assert action_dim == 4, "the head kernels are written for the 4-d drone action"
         self.device = th.device(device)
         self.passthrough = [k for k in passthrough]
         self.obs_keys = list(extractor.keys()) + self.passthrough
         self.obs_dims = {k: int(obs_dims[k]) for k in self.obs_keys}
         self.head_dims = tuple(head_dims) if head_dims is not None else (action_dim, 1)
+        self.act, self.ext_act = activation_kind(activation), activation_kind(extractor_activation)
         self.spec = dict(extractor={k: list(v) for k, v in extractor.items()}, pi=list(pi), vf=list(vf))
+        if (self.act, self.ext_act) != (1, 1):        # (archives of ReLU networks keep the r05 spec)
+            self.spec.update(activation=_TORCH_ACT[self.act].lower().replace("leakyrelu", "leaky_relu"),
+                             extractor_activation=_TORCH_ACT[self.ext_act].lower().replace("leakyrelu", "leaky_relu"))
         # ---- activation buffers (name -> width) and the layer schedule ----
         self.widths: Dict[str, int] = {}
         self.layers: List[_Linear] = []
@@ -86,7 +114,7 @@ class MlpPolicy:
                 dc = col if last else 0
                 if not last:
                     self.widths[dst] = h
-                add(K, h, True, src, sc, dst, dc, first=(li == 0))
+                add(K, h, self.ext_act, src, sc, dst, dc, first=(li == 0))
                 src, sc, K = dst, dc, h
             col += hidden[-1]
         pass_cols = []
@@ -98,10 +126,10 @@ class MlpPolicy:
             for li, h in enumerate(hidden):
                 dst = f"{trunk}:{li}"
                 self.widths[dst] = h
-                add(K, h, True, src, sc, dst, 0)
+                add(K, h, self.act, src, sc, dst, 0)
                 src, sc, K = dst, 0, h
             self.widths[head] = head_dim
-            add(K, head_dim, False, src, sc, head, 0)
+            add(K, head_dim, 0, src, sc, head, 0)
         self.log_std_off = off
         self.n_params = off + (action_dim if log_std_param else 0)      # trainable parameters (what Adam / the all-reduce see)
         # frozen identity layers of the pass-through inputs: executed with the extractors, parameters behind the trainable ones
@@ -109,7 +137,7 @@ class MlpPolicy:
         n_ext = sum(len(v) for v in extractor.values())
         for j, (k, c) in enumerate(pass_cols):
             d = self.obs_dims[k]
-            ly = _Linear(d, d, False, "obs:" + k, 0, "feat", c, off, off + d * d, True)
+            ly = _Linear(d, d, 0, "obs:" + k, 0, "feat", c, off, off + d * d, True)
             ly.frozen = True
             self.layers.insert(n_ext + j, ly)
             off += d * d + d
@@ -147,7 +175,7 @@ class MlpPolicy:
         # chain kernels of a shape the library holds no instance of: compiled on first use (visfly_amd/_jit.py)
         # (heads (4, 1) with the log_std parameter: the PPO policies' actor-critic; (4, 4) without: the SAC-style Actor of BPTT / SHAC)
         self.chain_shape = (_jit.shape_of(self.obs_dims, extractor, pi, vf, self.head_dims, self.passthrough)
-                            if bool(log_std_param) == (self.head_dims == (4, 1)) else None)
+                            if bool(log_std_param) == (self.head_dims == (4, 1)) and (self.act, self.ext_act) == (1, 1) else None)
         self.chain_jit = False
         if self._plan is None:          # more activation buffers than a vf_mlp_desc names (VF_MLP_MAX_BUFS): layer-by-layer launches
             self.chain_shape = None
@@ -269,7 +297,7 @@ class MlpPolicy:
         d.lds_floats = p["total"]
         for li, ly in enumerate(self.layers):
             L = d.layer[li]
-            L.K, L.No, L.relu = ly.K, ly.No, 1 if ly.relu else 0
+            L.K, L.No, L.relu = ly.K, ly.No, int(ly.relu)
             L.src, L.src_col = p["ids"][ly.src], ly.sc
             L.dst = {"mean": _lib.MLP_OUT0, "value": _lib.MLP_OUT1}.get(ly.dst, p["ids"].get(ly.dst, 0))
             L.dst_col, L.w_off, L.b_off, L.wt_off, L.wb_off = ly.dc, ly.w_off, ly.b_off, p["wt_off"][li], p["wb_off"][li]
@@ -415,7 +443,7 @@ class MlpPolicy:
         for ly in self.layers:
             X, Y = b[ly.src], b[ly.dst]
             rc = L.vf_linear_fwd(_ptr(X, ly.sc), X.shape[1], _ptr(self.flat, ly.w_off), _ptr(self.flat, ly.b_off),
-                                 _ptr(Y, ly.dc), Y.shape[1], M, ly.K, ly.No, 1 if ly.relu else 0, st)
+                                 _ptr(Y, ly.dc), Y.shape[1], M, ly.K, ly.No, int(ly.relu), st)
             if rc:
                 _lib.check(rc)
         if out_value is not None:
@@ -454,7 +482,7 @@ class MlpPolicy:
             Y, X = b[ly.dst], b[ly.src]
             ym = _ptr(Y, ly.dc) if ly.relu else None
             rc = wgrad(_ptr(dY, ly.dc), dY.shape[1], ym, Y.shape[1], _ptr(X, ly.sc), X.shape[1],
-                       _ptr(self.grad, ly.w_off), _ptr(self.grad, ly.b_off), M, ly.K, ly.No, _ptr(self._scratch), st)
+                       _ptr(self.grad, ly.w_off), _ptr(self.grad, ly.b_off), M, ly.K, ly.No, _ptr(self._scratch), int(ly.relu), st)
             if rc:
                 _lib.check(rc)
             if ly.first and not need_input_grad:
@@ -465,7 +493,7 @@ class MlpPolicy:
                 dX = b["g:" + ly.src]
             key = (ly.src, ly.sc)
             rc = L.vf_linear_bwd_data(_ptr(dY, ly.dc), dY.shape[1], ym, Y.shape[1], _ptr(self.flat, ly.w_off),
-                                      _ptr(dX, ly.sc), dX.shape[1], M, ly.K, ly.No, 1 if key in touched else 0, st)
+                                      _ptr(dX, ly.sc), dX.shape[1], M, ly.K, ly.No, 1 if key in touched else 0, int(ly.relu), st)
             if rc:
                 _lib.check(rc)
             touched.add(key)
@@ -500,7 +528,7 @@ class MlpPolicy:
             li = self.layers.index(ly)
             e.wb_off, e.wq_off = self._plan["wb_off"][li], self._plan["wq_off"][li]
             e.dY, e.ld_dy = _ptr(dY, ly.dc), dY.shape[-1]
-            e.Y, e.ld_y = (_ptr(Y, ly.dc) if ly.relu else None), Y.shape[-1]
+            e.Y, e.ld_y, e.act = (_ptr(Y, ly.dc) if ly.relu else None), Y.shape[-1], int(ly.relu)
             e.X, e.ld_x = _ptr(X, ly.sc), X.shape[-1]
             e.need_dx = 0
             if ly.first and not need_input_grad:
@@ -831,7 +859,7 @@ class MlpPolicy:
                 for ly, m in zip(pol.layers, s.lin):
                     x = acts[ly.src][:, ly.sc:ly.sc + ly.K]
                     y = m(x)
-                    y = th.relu(y) if ly.relu else y
+                    y = getattr(nn, _TORCH_ACT[ly.relu])()(y) if ly.relu else y
                     if ly.dst == "feat":
                         if "feat" not in acts:
                             acts["feat"] = th.zeros((M, pol.widths["feat"]), dtype=y.dtype, device=y.device)
@@ -906,7 +934,8 @@ class PPO:
         self.weight_decay = pk.get("weight_decay", self.weight_decay)   # optimizer_kwargs.weight_decay of the YAMLs
         extractor = pk.get("extractor", {k: [128, 64] for k in self.obs_keys})
         self.policy = MlpPolicy(obs_dims, extractor, pk.get("pi", [64, 64]), pk.get("vf", [64, 64]), self.device,
-                                log_std_init=pk.get("log_std_init", 0.0), seed=seed, ortho_init=pk.get("ortho_init", True))
+                                log_std_init=pk.get("log_std_init", 0.0), seed=seed, ortho_init=pk.get("ortho_init", True),
+                                activation=pk.get("activation", "relu"), extractor_activation=pk.get("extractor_activation", "relu"))
         self.policy.lazy_pack = True        # this trainer calls mark_updated() after every optimiser step
         self.world, self.rank = parallel.world_size(), parallel.rank()
         # every rank must start from the SAME parameters (only gradients are exchanged afterwards) and draw DIFFERENT
