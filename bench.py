@@ -208,6 +208,25 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
                        "optimiser step: k_ppo_update_split (k_ppo_update_chain above 32 768 rows) + k_mlp_wgrad + fold + Adam"), "us_per_update": us_upd,
             "rows": rows, "note": "fp32 v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)"}
     exchange = exchange_block(ppo._gbuf, n_upd, el / iters, us_upd, world, dev)
+    # the two gradient-exchange modes side by side: one more train() pass in each, device events; N = 1 with
+    # VISFLY_AMD_GRAD_BUCKETS_FORCE=1 shows what the split of the weight-gradient launch costs by itself
+    if exchange is not None or os.environ.get("VISFLY_AMD_GRAD_BUCKETS_FORCE") == "1":
+        modes = {}
+        for nb in (1, 2, 1, 2):
+            ppo.grad_buckets = nb
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k0 = ppo._opt_step
+            parallel.barrier()
+            e0.record()
+            ppo.train()
+            e1.record()
+            torch.cuda.synchronize()
+            modes.setdefault(f"buckets_{nb}", []).append(e0.elapsed_time(e1) * 1e3 / max(1, ppo._opt_step - k0))
+        ab = {k: parallel.max_over_ranks(min(v), dev) for k, v in modes.items()}
+        ab["note"] = ("us per optimiser step, best of two train() passes each, max over ranks; buckets_2 = trunks' bucket all-reduced on a second "
+                      "stream under the extractors' weight-gradient launches (VISFLY_AMD_GRAD_BUCKETS=2)")
+        exchange = dict(exchange or {}, grad_bucket_modes=ab)
+        ppo.grad_buckets = int(os.environ.get("VISFLY_AMD_GRAD_BUCKETS", "1"))
     out = {"metric": "PPO env-steps/s (rollout + train, NavigationEnv, StateTarget MLP)",
            "value": 256 * N * world * iters / el, "unit": "agent-steps/s", "n_gpus": world,
            "iterations": iters, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic",

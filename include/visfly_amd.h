@@ -613,6 +613,12 @@ int vf_mlp_backward_data_supported(const vf_mlp_bwd_desc* desc);
 int vf_mlp_backward_data(const vf_mlp_bwd_desc* desc, const float* packed, int32_t M, vf_stream_t stream);
 int vf_mlp_weight_grad(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
                        vf_stream_t stream);
+/* ABI 10: vf_mlp_weight_grad for the layers whose bit is set in layer_mask (bit i = desc->layer[i]) only, on the row-slab plan of the WHOLE
+ * table (partials sized as for the whole table): the gradient of a layer has the same bits whether it was formed by this call or by
+ * vf_mlp_weight_grad -- two calls with complementary masks are the two buckets of a two-bucket gradient exchange (a data-parallel step
+ * all-reduces the first bucket while the second is being formed). */
+int vf_mlp_weight_grad_layers(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
+                              uint32_t layer_mask, vf_stream_t stream);
 /* same, and the fold also leaves sum(grad[i]^2) of the values it wrote as vf_mlp_weight_grad_fold_blocks(desc) fp64
  * partials in sumsq_partials (for vf_adam_cfg.sumsq_partials).  loss_stats (optional): one more block of the same fold
  * launch sums the loss-statistic partial rows a vf_ppo_update call with stats == NULL left in its scratch -- what

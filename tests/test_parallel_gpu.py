@@ -11,8 +11,9 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q, algo, backend="gloo"):
+def _worker(rank, world, port, q, algo, backend="gloo", buckets=1):
     import sys
+    os.environ["VISFLY_AMD_GRAD_BUCKETS"] = str(buckets)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     local = rank if backend == "nccl" else 0
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -52,7 +53,9 @@ def _worker(rank, world, port, q, algo, backend="gloo"):
     ok = bool(torch.isfinite(flat).all()) and all(torch.equal(both[0], b) for b in both)
     if backend == "nccl":
         ok = ok and parallel.native_comm() is not None          # the gradient went through vf_allreduce_grads
-    q.put((rank, ok, tr.num_timesteps))
+    import hashlib
+    digest = hashlib.sha256(flat.cpu().numpy().tobytes()).hexdigest()
+    q.put((rank, ok, tr.num_timesteps, digest, getattr(tr, "grad_buckets", 1)))
     dist.destroy_process_group()
 
 
@@ -73,6 +76,27 @@ def test_two_ranks_stay_in_lockstep(algo):
     assert res[0][2] == res[1][2] and res[0][2] > 0          # num_timesteps counts the global batch on every rank
 
 
+def test_two_bucket_gradient_exchange_equals_one_bucket():
+    """VISFLY_AMD_GRAD_BUCKETS=2 (trunks' gradients + log_std + statistics all-reduced on a second stream under the extractors'
+    weight-gradient launches, the extractors' bucket behind it, Adam behind both) ends at the parameters of the one-bucket exchange, bit
+    for bit: the same per-element sums, only issued as two collectives"""
+    ctx = mp.get_context("spawn")
+    digests = {}
+    for buckets in (1, 2):
+        q = ctx.Queue()
+        port = 29850 + os.getpid() % 100 + buckets
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "ppo", "gloo", buckets)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        res = sorted(q.get() for _ in range(2))
+        assert all(r[1] for r in res) and res[0][3] == res[1][3] and all(r[4] == buckets for r in res), res
+        digests[buckets] = res[0][3]
+    assert digests[1] == digests[2]
+
+
 @pytest.mark.parametrize("algo", ["ppo", "bptt"])
 def test_two_ranks_rccl(algo):
     """the same lock-step check over RCCL (backend "nccl", gradient through vf_allreduce_grads) -- needs two GPUs; the
@@ -82,7 +106,7 @@ def test_two_ranks_rccl(algo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29750 + os.getpid() % 100 + (0 if algo == "ppo" else 1)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo, "nccl")) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo, "nccl", 2 if algo == "ppo" else 1)) for r in range(2)]      # (PPO: the two-bucket exchange over RCCL)
     for p in procs:
         p.start()
     for p in procs:

@@ -51,6 +51,21 @@ PY
     ppo_ab base VISFLY_AMD_FUSED_TAIL=0 | tee -a $O/ab.txt
     prof ppo_base timeout 300 python $R/bench.py --workload ppo --no-cpu-baseline --steps 256
     ;;
+buckets)  # two-bucket gradient exchange: lockstep + equality tests (2 processes / 1 GPU over gloo), the N = 1 cost of the split launches
+    timeout 1200 python -m pytest tests/test_parallel_gpu.py -x -q -m gpu 2>&1 | tail -40 | tee $O/pytest.txt
+    VISFLY_AMD_GRAD_BUCKETS_FORCE=1 timeout 600 python bench.py --workload ppo --no-cpu-baseline 2>&1 | tail -1 > $O/bench_ppo_force.json
+    python - <<PY | tee $O/ab.txt
+import json
+d = json.loads(open("$O/bench_ppo_force.json").read())
+print("N = 1, split forced:", d["exchange"])
+PY
+    VISFLY_AMD_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --workload ppo --no-cpu-baseline --agents 8192 2>&1 | tail -1 > $O/bench_ppo_2ranks_gloo.json
+    python - <<PY | tee -a $O/ab.txt
+import json
+d = json.loads(open("$O/bench_ppo_2ranks_gloo.json").read())
+print("2 ranks on one GPU over gloo (control flow only):", d["value"], d["exchange"])
+PY
+    ;;
 tests)    # the whole GPU suite
     timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $O/pytest.txt
     ;;

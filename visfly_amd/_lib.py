@@ -289,6 +289,7 @@ SIGNATURES = {
     "vf_mlp_forward_act": (C.c_int, [C.POINTER(MlpDesc)] + [_vp] * 9 + [C.c_int32, _vp]),
     "vf_mlp_backward_data_act": (C.c_int, [C.POINTER(MlpBwdDesc)] + [_vp] * 6 + [C.c_int32, _vp]),
     "vf_mlp_weight_grad": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "vf_mlp_weight_grad_layers": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, C.c_uint32, _vp]),
     "vf_mlp_weight_grad_fold_blocks": (C.c_int32, [C.POINTER(MlpBwdDesc)]),
     "vf_mlp_weight_grad_sumsq": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(StatsFold), _vp]),
     "vf_mlp_weight_grad_adam": (C.c_int, [C.POINTER(MlpBwdDesc), _vp, _vp, C.c_int32, C.c_int32, C.POINTER(StatsFold), C.POINTER(WgradTail), _vp]),

@@ -207,6 +207,7 @@ int64_t mlp_wgrad_partial_floats(const vf_mlp_bwd_desc* d, int M);
 int mlp_wgrad_fold_blocks(const vf_mlp_bwd_desc* d);
 int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, double* sq_part,
                      const vf_stats_fold* loss_stats, hipStream_t st);
+int mlp_wgrad_launch_layers(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, unsigned layer_mask, hipStream_t st);
 // the same with fold, gradient norm, clip and Adam inside the weight-gradient launch: 1 launched, 0 not for this table / device, < 0 error
 int mlp_wgrad_adam_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, const vf_stats_fold* loss_stats,
                           const vf_wgrad_tail* tail, hipStream_t st);

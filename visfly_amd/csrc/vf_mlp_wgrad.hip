@@ -755,6 +755,38 @@ int mlp_wgrad_launch(const vf_mlp_bwd_desc* d, float* partials, float* grad, int
     return VF_OK;
 }
 
+// the launches of mlp_wgrad_launch for the layers whose bit is set in `layer_mask` only, on the row-slab plan of the WHOLE table: the same
+// slabs, partials and fold order per layer as the one launch over all layers -- a gradient formed in two such calls (the two buckets of
+// the two-bucket exchange) has the bits of the one formed in one
+int mlp_wgrad_launch_layers(const vf_mlp_bwd_desc* d, float* partials, float* grad, int M, int accumulate, unsigned layer_mask, hipStream_t st)
+{
+    WgradTable full;
+    int waves = 0;
+    wgrad_plan(*d, M, full, &waves);
+    vf_mlp_bwd_desc sd{};
+    WgradTable t{};
+    sd.n_fold = d->n_fold;
+    int w = 0;
+    for (int l = 0; l < d->n_layers; ++l) {
+        if (!((layer_mask >> l) & 1u)) continue;
+        const int k = sd.n_layers++;
+        sd.layer[k] = d->layer[l];
+        t.first_wave[k] = w;
+        t.rows_per_wave[k] = full.rows_per_wave[l];
+        t.part_off[k] = full.part_off[l];
+        w += full.first_wave[l + 1] - full.first_wave[l];
+    }
+    if (sd.n_layers == 0) return VF_OK;
+    t.n_layers = sd.n_layers;
+    t.first_wave[sd.n_layers] = w;
+    if (wgrad_small(*d, M)) hipLaunchKernelGGL((k_mlp_wgrad<true, false>), dim3(w), dim3(64), 0, st, sd, t, partials, M, WgradTail{});
+    else hipLaunchKernelGGL((k_mlp_wgrad<false, false>), dim3(w), dim3(64), 0, st, sd, t, partials, M, WgradTail{});
+    const int nb = mlp_wgrad_fold_blocks(&sd);
+    hipLaunchKernelGGL(k_wgrad_fold, dim3(nb), dim3(kBlock), 0, st, sd, t, (const float*)partials, grad, accumulate, (double*)nullptr, vf_stats_fold{}, nb);
+    VF_HIP(hipGetLastError());
+    return VF_OK;
+}
+
 // waves of k_mlp_wgrad<false, true> the device holds at once (occupancy of THIS kernel x compute units), per device; 0: unknown
 static int wgrad_tail_capacity()
 {

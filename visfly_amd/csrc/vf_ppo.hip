@@ -1785,6 +1785,14 @@ int vf_mlp_weight_grad_sumsq(const vf_mlp_bwd_desc* desc, float* partials, float
     return vf::mlp_wgrad_launch(desc, partials, grad, M, accumulate, sumsq_partials, loss_stats, vf::as_stream(stream));
 }
 
+int vf_mlp_weight_grad_layers(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate, uint32_t layer_mask,
+                              vf_stream_t stream)
+{
+    if (!partials || !grad || M <= 0) return vf::fail(VF_EINVAL, "vf_mlp_weight_grad_layers: bad argument");
+    if (int rc = check_bwd_desc(desc, "vf_mlp_weight_grad_layers")) return rc;
+    return vf::mlp_wgrad_launch_layers(desc, partials, grad, M, accumulate, layer_mask, vf::as_stream(stream));
+}
+
 int vf_mlp_weight_grad_adam(const vf_mlp_bwd_desc* desc, float* partials, float* grad, int32_t M, int32_t accumulate,
                             const vf_stats_fold* loss_stats, const vf_wgrad_tail* tail, vf_stream_t stream)
 {

@@ -200,9 +200,10 @@ def _destroy_native():
             pass
 
 
-def allreduce_sum_(t: th.Tensor) -> th.Tensor:
+def allreduce_sum_(t: th.Tensor, stream: th.cuda.Stream = None) -> th.Tensor:
     """in-place sum over the ranks.  fp32 / fp64 device tensors on the nccl backend: one ncclAllReduce enqueued from C on
-    torch's current stream (vf_allreduce_grads); anything else: torch.distributed"""
+    torch's current stream (vf_allreduce_grads); anything else: torch.distributed.  ``stream``: enqueue on that stream instead
+    (the two-bucket gradient exchange: the caller orders it against its own stream with events)"""
     if world_size() > 1:
         c = native_comm() if (t.is_cuda and t.is_contiguous() and t.dtype in (th.float32, th.float64)) else None
         if c is not None:
@@ -210,7 +211,10 @@ def allreduce_sum_(t: th.Tensor) -> th.Tensor:
             L = _lib.lib()
             fn = L.vf_allreduce_grads if t.dtype == th.float32 else L.vf_allreduce_f64
             with th.cuda.device(t.device):
-                _lib.check(fn(c, t.data_ptr(), t.numel(), _lib.current_stream(t.device)))
+                _lib.check(fn(c, t.data_ptr(), t.numel(), stream.cuda_stream if stream is not None else _lib.current_stream(t.device)))
+        elif stream is not None:
+            with th.cuda.stream(stream):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t

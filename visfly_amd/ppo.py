@@ -649,7 +649,13 @@ class MlpPolicy:
             self._scratch = th.empty(need, dtype=th.float32, device=self.device)
         _lib.check(L.vf_mlp_weight_grad(C.byref(d), _ptr(self._scratch), _ptr(self.grad), n * M, 1 if accumulate else 0, self._stream()))
 
-    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch, want_sumsq=False, row_index=None, tail=None):
+    def bucket_split(self):
+        """first flat-parameter offset of the trunks: [0, split) = the extractor MLPs' parameters, [split, n_params) = both trunks, the
+        heads and log_std -- the two gradient buckets of the two-bucket exchange (PPO.grad_buckets)"""
+        return min(ly.w_off for ly in self.layers if not ly.frozen and not (ly.first or ly.src.startswith("x:") or ly.dst == "feat"))
+
+    def ppo_update(self, obs, actions, old_lp, adv, ret, loss_cfg, stats, loss_scratch, want_sumsq=False, row_index=None, tail=None,
+                   between=None):
         """forward + PPO loss + reverse chain in one launch, then the weight gradients into ``self.grad`` (vf_ppo_update +
         vf_mlp_weight_grad).  -> False when the network is not one of the register-chained classes (the caller then
         runs forward / vf_ppo_loss / backward).  ``want_sumsq``: -> (fp64 partials tensor, count) of the squared norm of the
@@ -657,6 +663,8 @@ class MlpPolicy:
         ``tail`` (a ``_lib.WgradTail``: parameters, Adam moments and configuration, sync words): the weight-gradient launch also folds,
         forms the gradient norm, clips and runs Adam (vf_mlp_weight_grad_adam: the optimiser step is TWO launches) -> "adam"; when the
         library declines (VF_EUNSUPPORTED) the call continues as ``want_sumsq`` and the caller runs vf_adam_step.
+        ``between`` (callable): the weight gradients are formed in TWO launch pairs -- trunks + heads first, then the extractor MLPs -- and
+        ``between()`` runs after the first pair was enqueued (the trainer starts the first bucket's all-reduce there).
         ``row_index`` (int64, M entries; vf_ppo_loss_cfg.row_index): obs / actions / old_lp / ret (and loss_cfg.old_value) are the
         WHOLE rollout buffer and row m of the minibatch is their row row_index[m] -- no shuffled copy; ``adv`` stays in minibatch order."""
         if self._fused_ppo is False or self._plan is None or not (self.fused and self.fused_backward):
@@ -736,6 +744,13 @@ class MlpPolicy:
             _lib.check(L.vf_mlp_weight_grad_sumsq(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, self._sq_part.data_ptr(),
                                                   C.byref(ls), st))
             return self._sq_part, nb
+        if between is not None:        # two launch pairs on the plan of the whole table (same bits): trunk / head layers, then the extractors'
+            split = self.bucket_split()
+            first = sum(1 << i for i in range(bd.n_layers) if bd.layer[i].w_off >= split)
+            _lib.check(L.vf_mlp_weight_grad_layers(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, first, st))
+            between()
+            _lib.check(L.vf_mlp_weight_grad_layers(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, ((1 << bd.n_layers) - 1) & ~first, st))
+            return True
         _lib.check(L.vf_mlp_weight_grad(C.byref(bd), _ptr(self._scratch), _ptr(self.grad), M, 0, st))
         return True
 
@@ -968,6 +983,13 @@ class PPO:
         # of partials, and the expensive launch boundaries are the ones behind the two big kernels, which stay:
         # profiles/r06_fused_tail.txt) -- off unless VISFLY_AMD_FUSED_TAIL=1
         self.fused_tail = os.environ.get("VISFLY_AMD_FUSED_TAIL", "0") == "1"
+        # gradient exchange of a multi-GPU step.  1 (default): ONE all-reduce of [gradient | 16 loss statistics] between the fold and
+        # Adam.  2 (VISFLY_AMD_GRAD_BUCKETS=2): the weight gradients are formed in two launch pairs -- trunks + heads, then the extractor
+        # MLPs -- and the first bucket ([trunks | log_std | statistics]) is all-reduced on a second stream UNDER the second pair; the
+        # second bucket follows on that stream, Adam waits for both.  Same sums, same bits (tests/test_parallel_*); whether it pays is a
+        # question for real xGMI links: 176 KB is latency, not bandwidth (bench.py prints both modes for N > 1)
+        self.grad_buckets = int(os.environ.get("VISFLY_AMD_GRAD_BUCKETS", "1"))
+        self._xstream, self._xev = None, None
         self._tail_sync = th.zeros(_lib.WGRAD_SYNC_WORDS, dtype=th.int32, device=dev)
         self._tail_launches = 0
         self.index_minibatches = False     # True: train() reads its minibatches through the permutation slice (vf_ppo_loss_cfg.row_index) instead of a shuffled copy -- measured 2 % slower, see train()
@@ -1141,7 +1163,27 @@ class PPO:
             pmap, packed = pol.pack_map()
             tail = _lib.WgradTail(_ptr(pol.flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), pol.n_params, self._adam_cfg(self._opt_step + 1, pmap, packed, None),
                                   self._tail_sync.data_ptr())
-        res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch, want_sumsq=self.world == 1, row_index=rows, tail=tail)
+        two = self.grad_buckets == 2 and tail is None and (self.world > 1 or os.environ.get("VISFLY_AMD_GRAD_BUCKETS_FORCE") == "1")
+        between = None
+        if two:
+            if self._xstream is None:
+                self._xstream, self._xev = th.cuda.Stream(device=self.device), [th.cuda.Event() for _ in range(3)]
+            split, xs, ev = pol.bucket_split(), self._xstream, self._xev
+
+            def between():        # trunks' gradients, log_std's and the statistics are final: their all-reduce runs under the second launch pair
+                ev[0].record()
+                xs.wait_event(ev[0])
+                parallel.allreduce_sum_(self._gbuf[split:], stream=xs)
+        res = pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, self._stats, self._scratch, want_sumsq=self.world == 1 and not two,
+                             row_index=rows, tail=tail, between=between)
+        if two and res is True:
+            ev[1].record()
+            xs.wait_event(ev[1])
+            parallel.allreduce_sum_(self._gbuf[:split], stream=xs)
+            ev[2].record(xs)
+            th.cuda.current_stream(self.device).wait_event(ev[2])
+        elif two:       # no fused step for this network: one bucket after the layer-by-layer backward (below)
+            two = False
         if res == "adam":        # the optimiser step happened inside the weight-gradient launch
             self._opt_step += 1
             self._tail_launches += 1
@@ -1161,7 +1203,7 @@ class PPO:
             _lib.check(L.vf_ppo_loss(_ptr(mean), _ptr(value), _ptr(pol.log_std), _ptr(actions), _ptr(old_lp), _ptr(adv), _ptr(ret),
                                      _ptr(d_mean), _ptr(d_value), _ptr(self._stats), B, C.byref(cfg), _ptr(self._scratch), st))
             pol.backward(d_mean, d_value, None)
-        if self.world > 1:
+        if self.world > 1 and not two:
             # ONE collective per optimiser step: the flat gradient and the 16 loss statistics are one buffer
             # (sum over ranks: every gradient term is already / global batch, the statistics are per-rank sums)
             parallel.allreduce_sum_(self._gbuf)
