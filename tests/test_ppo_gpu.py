@@ -138,20 +138,25 @@ def test_linear_layers_with_every_activation_vs_torch(K, No, M, act):
     assert torch.allclose(dW.double(), Wr.grad, rtol=1e-5, atol=tol) and torch.allclose(db.double(), br.grad, rtol=1e-5, atol=tol)
 
 
-@pytest.mark.parametrize("acts", [("tanh", "relu"), ("elu", "tanh"), ("leaky_relu", "leaky_relu"), ("tanh", "tanh")])
+@pytest.mark.parametrize("acts", [("tanh", "relu"), ("elu", "leaky_relu"), ("leaky_relu", "leaky_relu"), ("tanh", "tanh")])
 @pytest.mark.parametrize("M", [33, 25600])
-def test_policy_with_other_activations_vs_torch(acts, M):
+def test_policy_with_other_activations_vs_torch(acts, M, monkeypatch):
     """the whole actor-critic with `activation_fn` = Tanh (the reference policy's DEFAULT, policies.py:108) / ELU / LeakyReLU in the trunks
-    and / or the extractor MLPs: one-launch forward and backward (block-tile kernels: the chain classes are ReLU networks) and the
-    layer-by-layer path against torch autograd in fp64 -- the bounds of the ReLU tests"""
+    and / or the extractor MLPs against torch autograd in fp64: (a) the generated chain class of the shape + activations (forward, reverse
+    chain + row-slab weight gradients; ("tanh", "relu") and ("elu", "leaky_relu") are pre-built, __graft_entry__.build), (b) the block-tile
+    kernels (one launch each way), (c) layer by layer"""
     import warnings
     from visfly_amd.ppo import MlpPolicy
+    _lib, lib = L()
     act, ext_act = acts
     dims = {"state": 13, "target": 3}
+    prebuilt = acts in (("tanh", "relu"), ("elu", "leaky_relu"))
+    if not prebuilt:
+        monkeypatch.setenv("VISFLY_AMD_JIT", "0")          # (the other two combinations: the general kernels only)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         pol = MlpPolicy(dims, {k: [128, 64] for k in dims}, [64, 64], [64, 64], DEV, seed=5, activation=act, extractor_activation=ext_act)
-    assert pol.chain_shape is None and pol.spec["activation"] == act and pol.spec["extractor_activation"] == ext_act
+    assert pol.chain_jit == prebuilt and pol.spec["activation"] == act and pol.spec["extractor_activation"] == ext_act
     g = torch.Generator(device=DEV).manual_seed(M)
     obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
     d_mean, d_value = torch.randn((M, 4), device=DEV, generator=g) / M, torch.randn(M, device=DEV, generator=g) / M
@@ -168,13 +173,18 @@ def test_policy_with_other_activations_vs_torch(acts, M):
     g32 = ref32.flat_grad().to(DEV).double()
     sc = max(m0.abs().max().item(), v0.abs().max().item(), 1e-3)
     grads = []
-    for fused in (True, False):
-        pol.fused = pol.fused_backward = fused
+    for fused in ((("chain", True), ("tile", True), ("layers", False)) if prebuilt else (("tile", True), ("layers", False))):
+        fused, on = fused
+        pol.fused = pol.fused_backward = on
+        lib.vf_chain_plugin_set_enabled(1 if fused == "chain" else 0)
+        n0 = lib.vf_chain_plugin_launches()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             mean, value = pol.forward(obs)
+            assert (lib.vf_chain_plugin_launches() > n0) == (fused == "chain"), fused
             assert (mean.double() - m0).abs().max().item() <= 4e-6 * sc and (value.view(-1).double() - v0.view(-1)).abs().max().item() <= 4e-6 * sc
             d_in = pol.backward(d_mean, d_value, None, need_input_grad=True)
+        lib.vf_chain_plugin_set_enabled(1)
         # Tanh's derivative from the saved output, 1 - y^2 in fp32 (torch's tanh_backward forms it the same way), cancels where the unit
         # saturates: ~6e-5 relative per term against the fp64 reference, which the other three activations do not have
         # -- and LeakyReLU / ELU pass a gradient through EVERY unit, so a block of 25 600-row sums cancels further below the magnitude of its
@@ -190,13 +200,57 @@ def test_policy_with_other_activations_vs_torch(acts, M):
             bound = max(tol * max(xs[k].grad.abs().max().item(), 1e-12), 3.0 * (x32[k].grad.double() - xs[k].grad).abs().max().item())
             assert (d_in[k].double() - xs[k].grad).abs().max().item() <= bound, (fused, k)
         grads.append(pol.grad.clone())
-    assert (grads[0] - grads[1]).abs().max().item() <= (3e-4 if "tanh" in acts else 2e-5) * gref.abs().max().item()
+    for gx in grads[1:]:
+        assert (grads[0] - gx).abs().max().item() <= (3e-4 if "tanh" in acts else 2e-5) * gref.abs().max().item()
 
 
-def test_ppo_without_policy_kwargs_builds_the_references_default_network_and_trains():
+@pytest.mark.parametrize("acts", [("tanh", "relu"), ("elu", "leaky_relu")])
+@pytest.mark.parametrize("B", [25600, 777])
+def test_fused_ppo_step_of_a_tanh_or_elu_class_equals_separate_launches(acts, B):
+    """vf_ppo_update on a generated class with Tanh / ELU / LeakyReLU layers (derivatives from the forward's own live tiles) + weight
+    gradients vs forward / vf_ppo_loss / backward on the block-tile kernels: as test_fused_ppo_update_equals_separate_launches"""
+    from visfly_amd.ppo import MlpPolicy
+    _lib, lib = L()
+    dims = {"state": 13, "target": 3}
+    pol = MlpPolicy(dims, {k: [128, 64] for k in dims}, [64, 64], [64, 64], DEV, seed=5, log_std_init=-0.3, activation=acts[0], extractor_activation=acts[1])
+    assert pol.chain_jit
+    g = torch.Generator(device=DEV).manual_seed(B)
+    obs = {k: torch.randn((B, d), device=DEV, generator=g) for k, d in dims.items()}
+    mean, value = pol.forward(obs)
+    actions = torch.tanh(mean + 0.7 * torch.randn((B, 4), device=DEV, generator=g)).contiguous()
+    old_lp = sb3_squashed_log_prob(mean, pol.log_std, actions) + 0.3 * torch.randn(B, device=DEV, generator=g)
+    adv, ret = torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g)
+    scratch = torch.zeros(16 * max(1024, (B + 31) // 32), device=DEV)
+    res = {}
+    for fused in (True, False):
+        stats = torch.zeros(16, device=DEV)
+        pol.grad.fill_(3.0)
+        cfg = _lib.PpoLossCfg(0.2, 0.01, 0.5, 1.0 / B, pol.grad.data_ptr() + 4 * pol.log_std_off, None)
+        if fused:
+            n0 = lib.vf_chain_plugin_launches()
+            assert pol.ppo_update(obs, actions, old_lp, adv, ret, cfg, stats, scratch) is True
+            assert lib.vf_chain_plugin_launches() == n0 + 1, "the generated class's fused step ran"
+        else:
+            lib.vf_chain_plugin_set_enabled(0)
+            m, v = pol.forward(obs)
+            d_mean, d_value = torch.empty((B, 4), device=DEV), torch.empty(B, device=DEV)
+            _lib.check(lib.vf_ppo_loss(m.data_ptr(), v.data_ptr(), pol.log_std.data_ptr(), actions.data_ptr(), old_lp.data_ptr(),
+                                       adv.data_ptr(), ret.data_ptr(), d_mean.data_ptr(), d_value.data_ptr(), stats.data_ptr(), B,
+                                       C.byref(cfg), scratch.data_ptr(), st()))
+            pol.backward(d_mean, d_value, None)
+            lib.vf_chain_plugin_set_enabled(1)
+        res[fused] = (pol.grad.clone(), stats.clone())
+    (g1, s1), (g0, s0) = res[True], res[False]
+    assert torch.allclose(s1[:9], s0[:9], rtol=2e-5, atol=1e-6 * max(1.0, s0[:9].abs().max().item())), (s1, s0)
+    scale = g0.abs().max().item()
+    assert (g1 - g0).abs().max().item() <= (1e-4 if "tanh" in acts else 5e-6) * scale, ((g1 - g0).abs().max().item(), scale)
+
+
+def test_ppo_without_policy_kwargs_builds_the_references_default_network_and_trains(monkeypatch):
     """`PPO(env)` with no policy_kwargs: CustomMultiInputActorCriticPolicy's defaults -- Tanh trunks (policies.py:108), ReLU extractor MLPs
-    (extractors.py:666) -- until r06 this raised.  It trains (value loss falls), on the block-tile kernels with ONE warning that says so;
-    string / class spellings of activation_fn are accepted; an archive restores the activations"""
+    (extractors.py:666) -- until r06 this raised.  It trains (value loss falls) on the generated chain class of that network (pre-built:
+    visfly_amd/_jit.py PREBUILD_ACT) -- fused step, persistent roll-out, no fallback warning; string / class spellings of activation_fn are
+    accepted"""
     import warnings
     from visfly_amd.envs import NavigationEnv
     from visfly_amd.ppo import PPO
@@ -215,7 +269,8 @@ def test_ppo_without_policy_kwargs_builds_the_references_default_network_and_tra
     torch.cuda.synchronize()
     assert ppo.logs["train/value_loss"] < v0 and np.isfinite(ppo.logs["train/loss"]) and bool(torch.isfinite(pol.flat).all())
     fb = [x for x in w if "register-chained" in str(x.message) or "not available" in str(x.message)]
-    assert 1 <= len(fb) <= 3, [str(x.message)[:80] for x in w]
+    assert not fb and pol.chain_jit and ppo.fused_rollout and pol._fused_ppo is not False, [str(x.message)[:120] for x in w]
+    monkeypatch.setenv("VISFLY_AMD_JIT", "0")          # (spellings only: no class is compiled for these)
     for spelled in ("Tanh", torch.nn.Tanh, "tanh"):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")

@@ -41,6 +41,13 @@ PREBUILD = {
     "wide": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [128, 128], [128, 128]),
 }
 # the SAC-style Actor (heads (4, 4); td_policies.Actor: `pi` = latent_pi, `vf` = log_latent_pi) on a non-default shape: (.., head_dims)
+# the reference policy's DEFAULT activations (Tanh trunks, policies.py:108; ReLU extractor MLPs, extractors.py:666) on the YAMLs' shapes:
+# (.., head_dims, (trunk, extractor) activations)
+PREBUILD_ACT = {
+    "tanh_nav": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64], (4, 1), (2, 1)),
+    "tanh_hover": ({"state": 13}, {"state": [128, 64]}, [64, 64], [64, 64], (4, 1), (2, 1)),
+    "elu_leaky_nav": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64], (4, 1), (3, 4)),
+}
 PREBUILD_SAC = {
     "sac_nav": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [64]}, [128, 64], [64], (4, 4)),
     "sac_hover": ({"state": 13}, {"state": [64, 64, 32]}, [32], [32], (4, 4)),      # (the Actor BPTT builds for pi=[32]: log_latent_pi mirrors latent_pi)
@@ -49,9 +56,10 @@ PREBUILD_SAC = {
 PREBUILD_ROLLOUT = [("verdict", (1, 1, 0, True)), ("one_layer_extractor", (0, 1, 1, False)), ("one_layer_extractor", (1, 1, 0, True))]
 
 
-def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=()):
-    """(KIN, extractor widths in tiles, pi tiles, vf tiles[, (4, 4)]) of a network the generated chain classes cover, else None.
-    Heads (4, 1): the actor-critic of the PPO policies; (4, 4): the SAC-style Actor of BPTT / SHAC (mu / log_std heads; fifth element)"""
+def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=(), acts=(1, 1)):
+    """(KIN, extractor widths in tiles, pi tiles, vf tiles[, (4, 4)][, ("act", trunks, extractor)]) of a network the generated chain classes
+    cover, else None.  Heads (4, 1): the actor-critic of the PPO policies; (4, 4): the SAC-style Actor of BPTT / SHAC (mu / log_std heads).
+    acts: VF_ACTIVATION_* of the trunks / the extractor MLPs -- (1, 1) = ReLU networks (no element: the keys of r05's shapes)"""
     if passthrough or tuple(head_dims) not in ((4, 1), (4, 4)) or not 1 <= len(extractor) <= 2:
         return None
     kin, ew = [], []
@@ -69,21 +77,35 @@ def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=()):
         return None
     tiles = lambda t: tuple(h // 32 for h in t)
     sh = tuple(kin), tuple(tiles(e) for e in ew), tiles(trunks[0]), tiles(trunks[1])
-    return sh if tuple(head_dims) == (4, 1) else sh + ((4, 4),)
+    sh = sh if tuple(head_dims) == (4, 1) else sh + ((4, 4),)
+    return sh if tuple(acts) == (1, 1) else sh + (("act", int(acts[0]), int(acts[1])),)
 
 
 def is_builtin(shape):
-    return shape in _BUILTIN
+    return shape in _BUILTIN          # (ReLU networks only: a shape with an ("act", ..) element is never one of these)
 
 
 def _heads(shape):
-    return shape[4] if len(shape) > 4 else (4, 1)
+    return (4, 4) if (4, 4) in shape[4:] else (4, 1)
+
+
+def _acts(shape):
+    """(trunk activation, extractor activation) as VF_ACTIVATION_*"""
+    for e in shape[4:]:
+        if e and e[0] == "act":
+            return e[1], e[2]
+    return 1, 1
+
+
+_ACT_NAME = {1: "relu", 2: "tanh", 3: "elu", 4: "leaky_relu"}
 
 
 def name_of(shape):
     kin, ew, pw, vw = shape[:4]
     f = lambda t: "[" + ",".join(str(32 * x) for x in t) + "]"
-    return " ".join(f"in{k}{f(e)}" for k, e in zip(kin, ew)) + f" pi{f(pw)} vf{f(vw)}" + (" heads 4/4" if _heads(shape) == (4, 4) else "")
+    a = _acts(shape)
+    return (" ".join(f"in{k}{f(e)}" for k, e in zip(kin, ew)) + f" pi{f(pw)} vf{f(vw)}" + (" heads 4/4" if _heads(shape) == (4, 4) else "") +
+            ("" if a == (1, 1) else f" act {_ACT_NAME[a[0]]}/{_ACT_NAME[a[1]]}"))
 
 
 def source(shape):
@@ -106,6 +128,7 @@ struct Spec {{
     static constexpr int VW[{MAX_DEPTH}] = {{{pad(vw)}}};
     static constexpr bool VF = true;
     static constexpr int HM = {_heads(shape)[0]}, HV = {_heads(shape)[1]};
+    static constexpr int ACT = {_acts(shape)[0]}, EACT = {_acts(shape)[1]};       // VF_ACTIVATION_* of the trunks / the extractor MLPs
 }};
 struct SpecPi : Spec {{
     static constexpr bool VF = false;
@@ -146,6 +169,8 @@ def _slug(shape, rollout=None):
     kin, ew, pw, vw = shape[:4]
     t = lambda x: "".join(str(v) for v in x)
     s = "e" + "_".join(f"{k}x{t(e)}" for k, e in zip(kin, ew)) + f"_p{t(pw)}_v{t(vw)}" + ("_h44" if _heads(shape) == (4, 4) else "")
+    if _acts(shape) != (1, 1):
+        s += "_a%d%d" % _acts(shape)
     return s if rollout is None else s + "_roll" + "".join(str(int(x)) for x in rollout)
 
 
@@ -242,8 +267,9 @@ def ensure_rollout(shape, cfg):
 
 def prebuild(verbose=False):
     """compile the PREBUILD shapes (in parallel) -> paths"""
-    jobs = ([(shape_of(*v), None) for v in list(PREBUILD.values()) + list(PREBUILD_SAC.values())] +
-            [(shape_of(*PREBUILD[n]), cfg) for n, cfg in PREBUILD_ROLLOUT])
+    act = [shape_of(*v[:5], acts=v[5]) for v in PREBUILD_ACT.values()]
+    jobs = ([(shape_of(*v), None) for v in list(PREBUILD.values()) + list(PREBUILD_SAC.values())] + [(sh, None) for sh in act] +
+            [(shape_of(*PREBUILD[n]), cfg) for n, cfg in PREBUILD_ROLLOUT] + [(act[0], (1, 1, 0, True))])        # + the Tanh policy's roll-out on NavigationEnv
     # every chain job runs four hipcc parts of fully unrolled kernels: bound the number in flight by the cores of the build box
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), (os.cpu_count() or 4) // 4))) as pool:
         paths = list(pool.map(lambda j: build(j[0], verbose, rollout=j[1]), jobs))

@@ -93,8 +93,11 @@ template <class Net0>
 int plugin_ppo_update(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowArgs* pr, int M, hipStream_t st)
 {
     // more forward tiles than stay live beside the reverse chain: the variant that keeps the ReLU masks as bits (vf_mlp_chain_gen.hpp)
-    using Net = std::conditional_t<(Net0::n_tiles > kGenLiveTiles), ChainNetG<typename Net0::Spec, true>, Net0>;
-    if constexpr (Net::HV != 1) {
+    // (a Tanh / ELU / LeakyReLU network needs the values: above the live-tile limit it has no fused step -- forward, loss and reverse chain
+    // then run as the chain launches of their own)
+    constexpr bool packable = Net0::all_relu;
+    using Net = std::conditional_t<(Net0::n_tiles > kGenLiveTiles && packable), ChainNetG<typename Net0::Spec, true>, Net0>;
+    if constexpr (Net::HV != 1 || (Net0::n_tiles > kGenLiveTiles && !packable)) {
         return 0;                 // (no PPO step on the SAC-style Actor: the kernel is not instantiated)
     } else {
         using PU = typename Net::template Bwd<true, true, false>;

@@ -105,6 +105,21 @@ __device__ __forceinline__ float act_mul(float v, float y, int kind)
     }
 }
 
+// the same with the kind a compile-time constant (the register-chained kernels: ChainLayer::relu); ReLU keeps the max instruction the
+// built-in classes have always used
+template <int KIND>
+__device__ __forceinline__ float act_fwd_c(float z)
+{
+    if constexpr (KIND == VF_ACTIVATION_RELU) return fmaxf(z, 0.0f);
+    else return act_fwd(z, KIND);
+}
+template <int KIND>
+__device__ __forceinline__ float act_mul_c(float v, float y)
+{
+    if constexpr (KIND <= VF_ACTIVATION_RELU) return y > 0.0f ? v : 0.0f;
+    else return act_mul(v, y, KIND);
+}
+
 // Pull the whole kernel-argument block into the scalar cache with one batch of loads (24 lines per batch).  The chain kernels
 // take their layer tables by value (1.2 - 2.8 KB of kernel arguments at a fresh address every launch) and the compiler fetches a
 // field where it is first used: k_ppo_update_chain had 314 s_load / 216 s_waitcnt lgkmcnt in its body, ~44 of them first touches

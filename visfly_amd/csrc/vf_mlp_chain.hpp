@@ -144,6 +144,7 @@ struct ChainNet {
         for (int i = 0; i < li; ++i) n += items(i);
         return n;
     }
+    static constexpr int act_of(int /*fl*/) { return VF_ACTIVATION_RELU; }     // activation of forward layer fl's output (the built-in classes: ReLU networks)
     static constexpr int mask_bits(int /*fl*/) { return -1; }     // first bit tile of forward layer fl's ReLU mask (ChainLayer::pk0), -1: the tiles stay
     static constexpr int n_mb = 8;              // words of ChainState::mb
     static constexpr bool pack_or = false;      // true: bit tiles are packed in any order into words the kernel zeroed (vf_mlp_chain_gen.hpp)
@@ -321,7 +322,7 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& g, ChainState<N>
                 y[4 * q + 0] += bq.x; y[4 * q + 1] += bq.y; y[4 * q + 2] += bq.z; y[4 * q + 3] += bq.w;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = fmaxf(y[r], 0.0f);
+            for (int r = 0; r < 16; ++r) y[r] = act_fwd_c<L.relu>(y[r]);
         }
     }
 }
@@ -677,8 +678,8 @@ __device__ __forceinline__ void chain16_epilogue(const ChainArgs& g, ChainState1
         for (int a = 0; a < Chain16<N>::nout(LI); ++a) {
             f32x4& y = st.t[2 * L.out0 + a];
             const float4 bq = st.bias[a];
-            y[0] = fmaxf(y[0] + bq.x, 0.0f); y[1] = fmaxf(y[1] + bq.y, 0.0f);
-            y[2] = fmaxf(y[2] + bq.z, 0.0f); y[3] = fmaxf(y[3] + bq.w, 0.0f);
+            y[0] = act_fwd_c<L.relu>(y[0] + bq.x); y[1] = act_fwd_c<L.relu>(y[1] + bq.y);
+            y[2] = act_fwd_c<L.relu>(y[2] + bq.z); y[3] = act_fwd_c<L.relu>(y[3] + bq.w);
         }
     }
 }

@@ -204,10 +204,11 @@ __device__ __forceinline__ void bwd_mask_fin(BwdState<P>& st, const FS& fs)
                         const f32x16& t = fs.t[P::Net::tile_of_layer(fin.fl) + fin.c0 + a];
                         y = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
                     }
-                    v[4 * q + 0] = y.x > 0.0f ? v[4 * q + 0] : 0.0f;
-                    v[4 * q + 1] = y.y > 0.0f ? v[4 * q + 1] : 0.0f;
-                    v[4 * q + 2] = y.z > 0.0f ? v[4 * q + 2] : 0.0f;
-                    v[4 * q + 3] = y.w > 0.0f ? v[4 * q + 3] : 0.0f;
+                    constexpr int kind = P::Net::act_of(fin.fl);      // d/dz from the layer's OUTPUT (vf_common.hpp: act_mul)
+                    v[4 * q + 0] = act_mul_c<kind>(v[4 * q + 0], y.x);
+                    v[4 * q + 1] = act_mul_c<kind>(v[4 * q + 1], y.y);
+                    v[4 * q + 2] = act_mul_c<kind>(v[4 * q + 2], y.z);
+                    v[4 * q + 3] = act_mul_c<kind>(v[4 * q + 3], y.w);
                 }
             }
         }
@@ -561,10 +562,11 @@ __device__ __forceinline__ void bwd16_finalize(const BwdArgsChain& g, BwdState16
         for (int a = 0; a < 2 * O.fin[f].nt; ++a) {
             f32x4& v = st.t[2 * O.fin[f].t0 + a];
             const float4 y = st.ym[m0 + (f == 0 ? 0 : 2 * O.fin[0].nt) + a];
-            v[0] = y.x > 0.0f ? v[0] : 0.0f;
-            v[1] = y.y > 0.0f ? v[1] : 0.0f;
-            v[2] = y.z > 0.0f ? v[2] : 0.0f;
-            v[3] = y.w > 0.0f ? v[3] : 0.0f;
+            const int kind = P::Net::act_of(O.fin[f].fl);      // (a constant once the loop over f is unrolled: the switch folds away)
+            v[0] = act_mul(v[0], y.x, kind);
+            v[1] = act_mul(v[1], y.y, kind);
+            v[2] = act_mul(v[2], y.z, kind);
+            v[3] = act_mul(v[3], y.w, kind);
         }
     if constexpr (O.obs >= 0) {        // dLoss/d observation: features 4 gq + r of this lane's row
         const vf_mlp_bwd_layer& E = g.d.layer[P::entry(O.fl)];

@@ -47,6 +47,9 @@ struct GenShape {
             if (fl >= ext(b, 0) && fl < ext(b, 0) + de(b)) return b;
         return -1;
     }
+    // VF_ACTIVATION_* of forward layer fl's output: the extractor MLPs' (features_extractor_kwargs.activation_fn), the trunks' (the
+    // policy's activation_fn), none on the heads
+    static constexpr int act_of(int fl) { return is_head(fl) ? VF_ACTIVATION_NONE : branch_of(fl) >= 0 ? S::EACT : S::ACT; }
     static constexpr int feat_off(int b)
     {
         int n = 0;
@@ -155,7 +158,7 @@ struct GenLayerTable {
             const int fl = Shape::exec_desc(i, VF);
             const int b = Shape::branch_of(fl);
             r.l[i] = ChainLayer{fl, Shape::producer(fl) == -1 ? b : -1, Shape::in_tile(fl), Shape::in_tiles(fl), Shape::tile_of_layer(fl),
-                                Shape::width(fl), Shape::is_head(fl) ? 0 : 1};
+                                Shape::width(fl), Shape::act_of(fl)};
             r.first[i + 1] = r.first[i] + (r.l[i].obs >= 0 ? r.l[i].nin : r.l[i].nin * 4) * r.l[i].nout;
         }
         if (PACK)
@@ -206,6 +209,9 @@ struct ChainNetG {
         return i;
     }
     static constexpr int first_item(int li) { return tab.first[li]; }
+    static constexpr int act_of(int fl) { return Shape::act_of(fl); }
+    static constexpr bool all_relu = S::ACT == VF_ACTIVATION_RELU && S::EACT == VF_ACTIVATION_RELU;
+    static_assert(!PACK || all_relu, "activations as bits: ReLU networks only");
     static constexpr int mask_bits(int fl) { return PACK && !Shape::is_head(fl) ? tab.tile_of[fl] : -1; }
 };
 
@@ -357,7 +363,7 @@ bool chain_matches_gen(const vf_mlp_desc& d)
         const int b = Sh::branch_of(fl), p = Sh::producer(fl);
         const int K = p == -1 ? d.in_dim[b] : 32 * Sh::in_tiles(fl);
         const int No = fl == N::L_mean ? N::HM : fl == N::L_value ? N::HV : 32 * Sh::width(fl);
-        if (L.K != K || L.No != No || L.relu != (Sh::is_head(fl) ? VF_ACTIVATION_NONE : VF_ACTIVATION_RELU) || L.wr_off < 0 || (L.wr_off & 3)) return false;
+        if (L.K != K || L.No != No || L.relu != Sh::act_of(fl) || L.wr_off < 0 || (L.wr_off & 3)) return false;
         if (p == -1) {
             if (L.src != b || L.src_col != 0) return false;
         } else if (p == -2) {
@@ -394,7 +400,8 @@ bool bwd_chain_matches_gen(const vf_mlp_bwd_desc& d, bool ig)
             if (E.K != 32 * Sh::in_tiles(fl) || E.need_dx == 0) return false;
         }
         const int No = fl == N::L_mean ? N::HM : fl == N::L_value ? N::HV : 32 * Sh::width(fl);
-        if (E.No != No || (E.Y != nullptr) != relu || E.act > VF_ACTIVATION_RELU || E.wq_off < 0 || (E.wq_off & 3)) return false;
+        if (E.No != No || (E.Y != nullptr) != relu || E.wq_off < 0 || (E.wq_off & 3)) return false;
+        if (relu && (E.act ? E.act : VF_ACTIVATION_RELU) != Sh::act_of(fl)) return false;
         if (relu && (!al16(E.Y) || (E.ld_y & 3) || !al16(E.dY) || (E.ld_dy & 3))) return false;
         // wiring: the gradient this layer's weights produce is its producer's dY buffer (the feature gradient: the branch's columns)
         if (p >= 0 && E.dX != d.layer[P::entry(p)].dY) return false;

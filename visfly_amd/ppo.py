@@ -78,8 +78,9 @@ class MlpPolicy:
         gradient.  ``log_std_param`` False: no state-independent log_std parameter.
         ``activation`` / ``extractor_activation``: activation of the trunks' hidden layers (the policy's ``activation_fn``,
         policies.py:108: the reference's default there is Tanh) and of the extractor MLPs (``features_extractor_kwargs.activation_fn``,
-        extractors.py:560,583: default ReLU): relu | tanh | elu | leaky_relu.  The register-chained kernels are ReLU networks; another
-        activation runs on the block-tile kernels (same arithmetic, 0.13-0.26 of the fp32-MFMA peak instead of 0.38-0.46)."""
+        extractors.py:560,583: default ReLU): relu | tanh | elu | leaky_relu.  The register-chained classes built into the library are
+        ReLU networks; for another activation the class is generated and compiled on first use like a non-default net_arch
+        (visfly_amd/_jit.py: the activation is part of the class), else the block-tile kernels run it."""
         assert action_dim == 4, "the head kernels are written for the 4-d drone action"
         self.device = th.device(device)
         self.passthrough = [k for k in passthrough]
@@ -174,8 +175,8 @@ class MlpPolicy:
         self._descs = {}
         # chain kernels of a shape the library holds no instance of: compiled on first use (visfly_amd/_jit.py)
         # (heads (4, 1) with the log_std parameter: the PPO policies' actor-critic; (4, 4) without: the SAC-style Actor of BPTT / SHAC)
-        self.chain_shape = (_jit.shape_of(self.obs_dims, extractor, pi, vf, self.head_dims, self.passthrough)
-                            if bool(log_std_param) == (self.head_dims == (4, 1)) and (self.act, self.ext_act) == (1, 1) else None)
+        self.chain_shape = (_jit.shape_of(self.obs_dims, extractor, pi, vf, self.head_dims, self.passthrough, acts=(self.act, self.ext_act))
+                            if bool(log_std_param) == (self.head_dims == (4, 1)) else None)
         self.chain_jit = False
         if self._plan is None:          # more activation buffers than a vf_mlp_desc names (VF_MLP_MAX_BUFS): layer-by-layer launches
             self.chain_shape = None
