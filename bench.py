@@ -156,10 +156,10 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
                         device=dev, max_episode_steps=256)
     # the networks of the reference's experiment YAMLs (exps/examples/alg_cfgs/*/PPO.yaml: activation_fn relu; the policy class's own
     # default would be Tanh trunks, policies.py:108)
-    kw = dict(policy_kwargs=dict(activation_fn="relu"))
+    kw = dict(policy_kwargs=dict(activation_fn=getattr(args, "activation", None) or "relu"))
     if getattr(args, "net_arch", None):
         arch = {k: [int(x) for x in v.split(",")] for k, v in (p.split("=") for p in args.net_arch.split(":"))}
-        kw = dict(policy_kwargs=dict(features_extractor_class="StateTargetExtractor", activation_fn="ReLU", net_arch=arch,
+        kw = dict(policy_kwargs=dict(features_extractor_class="StateTargetExtractor", activation_fn=getattr(args, "activation", None) or "ReLU", net_arch=arch,
                                      features_extractor_kwargs=dict(net_arch=dict(state=dict(layer=[128, 64]), target=dict(layer=[128, 64])))))
     ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=0, **kw)
     ppo.learn(256 * N * world)   # warm-up iteration
@@ -237,7 +237,8 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
                                                             "the optimiser steps (one all-reduce each)"},
            "exchange": exchange,
            "config": {"workload": f"NavigationEnv {N} agents/GPU, n_steps=256, batch 25600/GPU, 5 epochs "
-                                  "(BASELINE configs[3] shard)" + (f", net_arch {args.net_arch} (generated chain class)" if kw else ""),
+                                  "(BASELINE configs[3] shard)" + (f", net_arch {args.net_arch} (generated chain class)" if getattr(args, "net_arch", None) else "")
+                                  + (f", activation_fn {args.activation}" if getattr(args, "activation", None) else ""),
                       "logs": {k: float(v) for k, v in ppo.logs.items()}},
            "roofline": roof}
     if cpu_ref and rank == 0:
@@ -478,6 +479,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--net-arch", default=None, help="--workload ppo only: `pi=128,128:vf=32` -- a net_arch without a built-in chain class "
                                                      "(kernels compiled on first use, visfly_amd/_jit.py); the default is the reference's [64, 64] / [64, 64]")
+    ap.add_argument("--activation", default=None, help="--workload ppo only: the policy's activation_fn (relu | tanh | elu | leaky_relu; default relu = the "
+                                                        "reference's YAMLs; tanh = the policy class's own default): a generated chain class")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short PPO / BPTT runs embedded in the line")
     ap.add_argument("--workload", default="env", choices=["env", "ppo", "bptt", "shac", "nav_rk4_dr"],
                     help="env: fused HoverEnv.step (the BASELINE metric, default); ppo / bptt / shac / nav_rk4_dr (BASELINE configs[2]): that leg only")

@@ -66,6 +66,33 @@ d = json.loads(open("$O/bench_ppo_2ranks_gloo.json").read())
 print("2 ranks on one GPU over gloo (control flow only):", d["value"], d["exchange"])
 PY
     ;;
+acts)     # optimiser-step fraction per activation (generated chain classes), + where the suite's time goes
+    for a in relu tanh elu leaky_relu; do
+        timeout 900 python bench.py --workload ppo --no-cpu-baseline --activation $a 2>&1 | tail -1 > $O/bench_ppo_$a.json
+        python - <<PY | tee -a $O/acts.txt
+import json
+d = json.loads(open("$O/bench_ppo_$a.json").read())
+print("activation_fn %-10s PPO %.4g env-steps/s  optimiser step %.2f us  frac %.4f  rollout ms %s" % ("$a", d["value"], d["roofline"]["us_per_update"], d["roofline"]["frac"], d["split_ms"]["rollout_256_steps"]))
+PY
+    done
+    timeout 3000 python -m pytest tests -x -q -m gpu --durations=12 2>&1 | tail -30 | tee $O/pytest.txt
+    ;;
+bptt)     # (a) BPTT's weight-gradient launch per chunk of steps, cache-hot vs the one launch over the horizon; (b) why the driver's
+          # reference-actor figure fell 3.03e8 (r04) -> 2.93e8 (r05): the three trees' own bench.py --workload bptt on THIS box, interleaved
+    timeout 900 python tools/exp_bptt_wgrad_chunks.py 2>&1 | grep -v amdgpu.ids | tee $O/wgrad_chunks.txt
+    for rep in 1 2 3; do
+        for tree in tools/tmp/tree_13cc83c tools/tmp/tree_8743b9a .; do
+            (cd $R/$tree && timeout 600 python bench.py --workload bptt --no-cpu-baseline 2>/dev/null | tail -1) > $O/bptt_$(basename $tree)_$rep.json
+            python - <<PY | tee -a $O/ab.txt
+import json
+d = json.loads(open("$O/bptt_$(basename $tree)_$rep.json").read())
+ra = d.get("reference_actor", {}).get("value") or d["value"]
+mlp = d.get("mlp_policy_actor", {}).get("value") or (d["value"] if "reference_actor" in d else None)
+print("%-22s rep $rep  reference actor %.4g   MlpPolicy actor %s" % ("$(basename $tree)", ra, "%.4g" % mlp if mlp else "-"))
+PY
+        done
+    done
+    ;;
 tests)    # the whole GPU suite
     timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $O/pytest.txt
     ;;

@@ -635,14 +635,24 @@ class MlpPolicy:
         _lib.check(_lib.lib().vf_mlp_backward_data(C.byref(d), _ptr(self._packed), M, self._stream()))
         return d_in
 
-    def weight_grad_slots(self, M, n, d_mean_all, accumulate=False, d_value_all=None):
+    def weight_grad_slots(self, M, n, d_mean_all, accumulate=False, d_value_all=None, lo=0):
         """weight / bias gradients of the policy trunk (+ the second trunk when ``d_value_all`` is given) + extractors summed over
-        slots 0..n-1 (reserved with ``reserve_slots``; d_mean_all (n, M, 4) [d_value_all (n, M, w)] hold the head gradients the
-        ``backward_data`` calls were given)"""
+        slots lo..lo+n-1 (reserved with ``reserve_slots``; d_mean_all (n, M, 4) [d_value_all (n, M, w)] hold the head gradients the
+        ``backward_data`` calls were given for THOSE slots)"""
         nblk, blk = self._slot_blocks[M]
-        assert n <= nblk and d_mean_all.shape == (n, M, 4) and d_mean_all.is_contiguous()
+        assert lo + n <= nblk and d_mean_all.shape == (n, M, 4) and d_mean_all.is_contiguous()
         assert d_value_all is None or (d_value_all.shape == (n, M, self.head_dims[1]) and d_value_all.is_contiguous())
-        b = {name: t[:n].reshape(-1, t.shape[-1]) for name, t in blk.items()}
+        # one launch over 1 M rows runs at 67 TF/s, two over 512 K rows each at 76 (profiles/r06_bptt_wgrad_chunks.txt: not a cache effect --
+        # the rows are as fast cold as hot): a horizon above WGRAD_SPLIT_ROWS is reduced in equal runs of whole slots, in slot order
+        cap = int(os.environ.get("VISFLY_AMD_WGRAD_SPLIT_ROWS", "524288"))
+        if n > 1 and n * M > cap > 0:
+            per = max(1, min(n - 1, cap // M))
+            per = (n + ((n + per - 1) // per) - 1) // ((n + per - 1) // per)        # equal runs
+            for s0 in range(0, n, per):
+                k = min(per, n - s0)
+                self.weight_grad_slots(M, k, d_mean_all[s0:s0 + k], accumulate or s0 > 0, None if d_value_all is None else d_value_all[s0:s0 + k], lo + s0)
+            return
+        b = {name: t[lo:lo + n].reshape(-1, t.shape[-1]) for name, t in blk.items()}
         d, _ = self._bwd_desc(b, n * M, d_mean_all.view(-1, 4), None if d_value_all is None else d_value_all.view(n * M, -1), False)
         L = _lib.lib()
         need = int(L.vf_mlp_backward_partial_floats(C.byref(d), n * M))
