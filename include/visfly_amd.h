@@ -215,7 +215,7 @@ enum {
     VF_F_EPISODE_DONE = 1, VF_F_ONCE_COLLIDED = 2, VF_F_COLLISION = 4, VF_F_OUT_BOUNDS = 8,
     VF_F_SUCCESS = 16, VF_F_FAILURE = 32, VF_F_DONE = 64
 };
-enum { VF_OBS_STATE = 0, VF_OBS_HOVER2 = 1, VF_OBS_NAV2 = 2 };
+enum { VF_OBS_STATE = 0, VF_OBS_HOVER2 = 1, VF_OBS_NAV2 = 2, VF_OBS_RACE2 = 3 };
 enum { VF_REWARD_DEFAULT = 0, VF_REWARD_NAV2 = 1 };
 enum { VF_EP_SUCCESS = 1, VF_EP_TRUNCATED = 2, VF_EP_COLLIDED = 4, VF_EP_EPISODE_DONE = 8 };
 #define VF_MAX_GATES 8
@@ -245,10 +245,16 @@ typedef struct vf_env_cfg {
     vf_spawn_box spawn[VF_MAX_SPAWN];
     uint64_t seed;                /* Philox key of the on-device spawner                 */
     /* observation / reward variants */
-    int32_t obs_mode;             /* VF_OBS_*: raw state | HoverEnv2 (HoverEnv.py:136-152) | NavigationEnv2 (NavigationEnv.py:163-183) */
+    int32_t obs_mode;             /* VF_OBS_*: raw state | HoverEnv2 (HoverEnv.py:136-152) | NavigationEnv2 (NavigationEnv.py:163-183) |
+                                     RacingEnv2 (RacingEnv.py:218-267; r06): the 16-column gate-relative row [(gate - p) / sense_radius,
+                                     (next gate - p) / sense_radius, q, v / 10, w / 10] with the agent's CURRENT gate index.  The single-step
+                                     launches (vf_env_step) return the raw row in this mode too -- which index the rows step() returns
+                                     use is a batch-wide rule (vf_race_obs) --; the persistent launches (vf_bptt_rollout / vf_bptt_reverse
+                                     / vf_ppo_rollout), whose policy reads the current gates, form and differentiate the 16 columns
+                                     themselves: their observation slots, obs_final, terminal rows and g_obs are 16 wide then */
     int32_t reward_mode;          /* VF_REWARD_*: the kind's own reward | NavigationEnv2 reward + failure = is_collision (:155-224) */
     int32_t spawn_prefetch;       /* != 0: the next re-spawn state of every agent is kept ready in the slab (see "Prefetched re-spawn") */
-    int32_t pad1;
+    float sense_radius;           /* ABI 10 (was pad1): max_sense_radius of VF_OBS_RACE2 (droneGymEnv.py:69: 10) */
 } vf_env_cfg;
 
 /* Outputs of one env step; obs/reward/done are required, the rest may be NULL. */

@@ -257,7 +257,7 @@ FAST_SPAWN = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"
 
 
 @pytest.mark.parametrize("N,H,steps,spawn", [(2048, 16, 20, None), (1000, 8, 5, None), (7, 6, 4, None), (3000, 12, 30, FAST_SPAWN),
-                                             (1500, 8, 6, "NavigationEnv2"), (900, 8, 6, "HoverEnv2")])
+                                             (1500, 8, 6, "NavigationEnv2"), (900, 8, 6, "HoverEnv2"), (1200, 8, 6, "RacingEnv2")])
 def test_persistent_launches_equal_the_loop(N, H, steps, spawn):
     """SHAC's horizon on vf_bptt_rollout / vf_bptt_reverse (actor class (b)) + the next-action / target-critic terms evaluated over the
     recorded horizon, against the launch-by-launch loop: horizon buffer (observations, actions, rewards, done / episode_done, next
@@ -268,6 +268,7 @@ def test_persistent_launches_equal_the_loop(N, H, steps, spawn):
     from _golden import ENV_DYN
     # r05: the observation / reward variants (their adjoint is obs_variant_bwd + the NAV2 reward gradient) run SHAC on the persistent
     # launches too -- NavigationEnv2 = the Navigation env kind under the one-observation actor (vf_bptt_*_nav2.hip)
+    # r06: RacingEnv2 -- the 16 gate-relative columns inside the launches (kernel-side kind VF_ENV_RACING2)
     cls, spawn = (getattr(E, spawn), None) if isinstance(spawn, str) else (E.HoverEnv, spawn)
     res = []
     for fused in (True, False):

@@ -93,7 +93,7 @@ class EnvCfg(C.Structure):
         ("spawn", SpawnBox * MAX_SPAWN),
         ("seed", C.c_uint64),
         ("obs_mode", C.c_int32), ("reward_mode", C.c_int32),
-        ("spawn_prefetch", C.c_int32), ("pad1", C.c_int32),
+        ("spawn_prefetch", C.c_int32), ("sense_radius", C.c_float),
     ]
 
 

@@ -47,7 +47,10 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     const bool ckpt = substep_tape != nullptr && r16 && h->dyn.cfg.delay_steps <= vf::kRingRegs;
     if (reinterpret_cast<uintptr_t>(substep_tape) & 15) return vf::fail(VF_EINVAL, "vf_bptt_reverse: substep_tape must be 16-byte aligned");
     vf::RevKernel k = nullptr;
-    if ((net == 1 || net == 3) && h->cfg.kind == VF_ENV_NAV) k = vf::pick_rev_nav2(net, r16, h->dyn.cfg, ckpt);
+    const bool race2 = h->cfg.kind == VF_ENV_RACING && h->cfg.obs_mode == VF_OBS_RACE2;      // RacingEnv2: 16 gate-relative columns
+    const int OW = race2 ? 16 : 13;
+    if (race2) k = vf::pick_rev_race2(net, r16, h->dyn.cfg, ckpt);
+    else if ((net == 1 || net == 3) && h->cfg.kind == VF_ENV_NAV) k = vf::pick_rev_nav2(net, r16, h->dyn.cfg, ckpt);
     else if (!h->dyn.cfg.ctrl_delay) k = vf::pick_rev_nodelay(net, r16, h->cfg.kind, h->dyn.cfg, ckpt);
     else if (sac) k = r16 ? vf::pick_rev_sac(net, h->cfg.kind, h->dyn.cfg, ckpt) : vf::pick_rev_sac32(net, h->cfg.kind, h->dyn.cfg);
     else if (net == 1 && h->cfg.kind == VF_ENV_HOVER) k = r16 ? vf::pick_rev<vf::NetHover, 16, VF_ENV_HOVER>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetHover, 32, VF_ENV_HOVER>(h->dyn.cfg, ckpt);
@@ -55,8 +58,8 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     else if (net == 2 && h->cfg.kind == VF_ENV_NAV) k = r16 ? vf::pick_rev<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg, ckpt);
     if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: no persistent reverse sweep for this network class / env kind / dynamics configuration");
     bool found = false;        // g_obs must be the (rows, 13) buffer the "state" branch's first layer writes its data gradient to
-    for (int l = 0; l < desc->n_layers; ++l) found = found || (desc->layer[l].need_dx && desc->layer[l].dX == g_obs && desc->layer[l].ld_dx == 13);
-    if (!found) return vf::fail(VF_EINVAL, "vf_bptt_reverse: g_obs is not the (rows, 13) observation-gradient buffer of the layer table");
+    for (int l = 0; l < desc->n_layers; ++l) found = found || (desc->layer[l].need_dx && desc->layer[l].dX == g_obs && desc->layer[l].ld_dx == OW);
+    if (!found) return vf::fail(VF_EINVAL, "vf_bptt_reverse: g_obs is not the (rows, %d) observation-gradient buffer of the layer table", OW);
     vf::BwdArgsChain gb{*desc, packed, H * N, reinterpret_cast<const float4*>(d_action), reinterpret_cast<const float4*>(actions), log_std,
                         reinterpret_cast<const float4*>(eps), reinterpret_cast<float4*>(g_log_std), reinterpret_cast<const float4*>(log_std_rows),
                         VF_SAC_LOG_STD_MIN, VF_SAC_LOG_STD_MAX};

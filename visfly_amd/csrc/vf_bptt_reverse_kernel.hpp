@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void k_bptt_reverse(const vf_dyn_cfg* __restric
     }
     for (int t = r.H - 1; t >= 0; --t) {
         const BwdArgs g{r.N, r.G, r.g_drag, r.g_race, r.tape + (size_t)t * r.tape_stride, r.actions + (size_t)t * r.N,
-                        t + 1 < r.H ? r.g_obs + (size_t)(t + 1) * r.N * 13 : nullptr, r.d_reward + (size_t)t * r.N,
+                        t + 1 < r.H ? r.g_obs + (size_t)(t + 1) * r.N * obs_width(KIND) : nullptr, r.d_reward + (size_t)t * r.N,
                         r.done + (size_t)t * r.N, r.adj, r.d_action + (size_t)t * r.N};
         const int row = t * r.N + i;
         // the masks of this step's reverse chain (saved activations of slot t: written a forward sweep ago, HBM by now) are loaded
@@ -194,6 +194,8 @@ static RevKernel pick_rev(const vf_dyn_cfg& c, bool ckpt)
 
 // vf_bptt_reverse_nav2.hip: the one-observation classes (net 1, 3) over the Navigation env kind (NavigationEnv2); both forms of the interval
 RevKernel pick_rev_nav2(int net, bool r16, const vf_dyn_cfg& c, bool ckpt);
+// vf_bptt_reverse_race2.hip: the one-observation classes (net 1, 3) over RacingEnv2's 16-column rows (kernel-side kind VF_ENV_RACING2)
+RevKernel pick_rev_race2(int net, bool r16, const vf_dyn_cfg& c, bool ckpt);
 // vf_bptt_reverse_nodelay.hip: every class with ctrl_delay = false (net: bwd_chain_policy_class's 1 .. 4; r16: 16 rows per wave)
 RevKernel pick_rev_nodelay(int net, bool r16, int kind, const vf_dyn_cfg& c, bool ckpt);
 

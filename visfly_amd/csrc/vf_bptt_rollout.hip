@@ -35,7 +35,10 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if (reinterpret_cast<uintptr_t>(substep_tape) & 15) return vf::fail(VF_EINVAL, "vf_bptt_rollout: substep_tape must be 16-byte aligned");
     if ((int64_t)H * h->dyn.N * 128 * 4 >= (1ll << 32))      // the chain addresses its activation copies with 32-bit byte offsets
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: H x N rows of activation copies pass 4 GiB per buffer");
-    if (desc->in_dim[0] != 13) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the first observation must be the 13-wide state row");
+    const bool race2 = h->cfg.kind == VF_ENV_RACING && h->cfg.obs_mode == VF_OBS_RACE2;      // RacingEnv2: 16 gate-relative columns
+    const int OW = race2 ? 16 : 13;
+    if (desc->in_dim[0] != OW) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the first observation must be the %d-wide state row", OW);
+    // (RacingEnv2: out->obs / out->terminal_obs / obs_slots0 / obs_final rows are 16 wide)
     const int cls = vf::chain16_policy_class(desc, params);
     if (cls == 0)          // (before the per-class argument checks: a caller with another network -- a generated class -- steps launch by launch)
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the policy's layer table is not one of the built-in register-chained classes");
@@ -46,7 +49,8 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if ((reinterpret_cast<uintptr_t>(mean_rows) | reinterpret_cast<uintptr_t>(log_std_rows)) & 15)
         return vf::fail(VF_EINVAL, "vf_bptt_rollout: mean_rows / log_std_rows must be 16-byte aligned");
     vf::RollKernel k = nullptr;
-    if ((cls == 1 || cls == 3) && h->cfg.kind == VF_ENV_NAV) k = obs_slots1 ? nullptr : vf::pick_roll_nav2(cls, h->dyn.cfg);
+    if (race2) k = obs_slots1 ? nullptr : vf::pick_roll_race2(cls, h->dyn.cfg);
+    else if ((cls == 1 || cls == 3) && h->cfg.kind == VF_ENV_NAV) k = obs_slots1 ? nullptr : vf::pick_roll_nav2(cls, h->dyn.cfg);
     else if (!h->dyn.cfg.ctrl_delay) k = (cls == 2 || cls == 4) && !obs_slots1 ? nullptr : vf::pick_roll_nodelay(cls, h->cfg.kind, h->dyn.cfg);
     else if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_HOVER>(h->dyn.cfg);
     else if (cls == 1 && h->cfg.kind == VF_ENV_RACING) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_RACING>(h->dyn.cfg);
@@ -61,7 +65,7 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     ge.out.done = tape_done;
     ge.out.done_list = ge.out.done_count = nullptr;
     // slot t + 1's observation rows are what step t writes; slot 0 holds the current observation (caller)
-    ge.out.obs = H > 1 ? const_cast<float*>(obs_slots0) + (size_t)N * 13 : obs_final;
+    ge.out.obs = H > 1 ? const_cast<float*>(obs_slots0) + (size_t)N * OW : obs_final;
     // (the policy-only classes do not run the second trunk: log_std_rows is written by the two-headed classes only)
     vf::ChainArgs gc{*desc, params, packed, vf::ChainIo{{obs_slots0, obs_slots1}, mean_rows, sac ? log_std_rows : nullptr}, H * N, log_std,
                      reinterpret_cast<const float4*>(eps), reinterpret_cast<float4*>(actions), {nullptr, nullptr}, VF_SAC_LOG_STD_MIN,

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
     prefetch_kernarg<sizeof(EnvArgs) + sizeof(ChainArgs) + sizeof(RollArgs) + 16>();
     const vf_dyn_cfg& c = *cp;
     const vf_env_cfg& e = *ep;
+    constexpr int OW = obs_width(KIND);       // 13, or RacingEnv2's 16 gate-relative columns
     __shared__ __attribute__((aligned(16))) float tile[64 * 13];
     __shared__ float4 act_lds[16];      // the action rows of the step: chain lanes (m, gq = 0) -> the quad of agent slot m
     const int lane = threadIdx.x, m = lane & 15;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
                 const float* x = gct.io.in[b] + (size_t)rc * w;
                 // the state observation of step t > 0 is the row the env epilogue of step t - 1 left in the LDS tile (it also wrote it to
                 // slot t: the weight gradients' X); read back from the slot it would be an L2 round trip behind the store
-                const float* xl = tile + (lane_t & 15) * 13;
+                const float* xl = tile + (lane_t & 15) * OW;
                 const bool from_lds = b == 0 && t > 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         ck.inputs(s, head_pre, counter_pre, a);
         ck.drag(g.d.S, Gx, ic, g.d.g_drag);
         float gate_pre = 0.0f;
-        if constexpr (KIND == VF_ENV_RACING) gate_pre = granule(g.d.S, Gx, ic, g.g_race)->x;
+        if constexpr (kind_is_racing(KIND)) gate_pre = granule(g.d.S, Gx, ic, g.g_race)->x;
         control_interval_quad<ACT, INTEG, CTRL_DELAY>(c, ql, s, a, kl, kq, g.d.vstrided != 0, ck);
         asm volatile("" :: "v"(eps_touch.x), "v"(eps_touch.y), "v"(eps_touch.z), "v"(eps_touch.w));
         float reward = 0.0f;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(64) void k_bptt_rollout(const vf_dyn_cfg* __restric
         // ---- next step ----
         g.d.action += r.N;                               // float4 units
         g.out.done += r.N;
-        g.out.obs = t + 2 < r.H ? r.obs_slots + (size_t)(t + 2) * r.N * 13 : r.obs_final;   // the last one: the env's own buffer
+        g.out.obs = t + 2 < r.H ? r.obs_slots + (size_t)(t + 2) * r.N * OW : r.obs_final;   // the last one: the env's own buffer
         g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
     }
     store_agent(g.d.S, Gx, ic, s, sp);
@@ -248,6 +249,8 @@ RollKernel pick_roll_nodelay(int cls, int kind, const vf_dyn_cfg& c);
 // "state" row (envs/NavigationEnv.py:163-183); both forms of the interval
 RollKernel pick_roll_nav2(int cls, const vf_dyn_cfg& c);
 
+// vf_bptt_rollout_race2.hip: the one-observation classes (1, 3) over RacingEnv2's 16-column rows (kernel-side kind VF_ENV_RACING2)
+RollKernel pick_roll_race2(int cls, const vf_dyn_cfg& c);
 // vf_bptt_rollout_sac.hip: net = 3 NetSacHover (Hover / Racing env), 4 NetSacNav (Navigation env); nullptr: no instance
 RollKernel pick_roll_sac(int net, int kind, const vf_dyn_cfg& c);
 

@@ -160,7 +160,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
         }
         done_in = live && g.done != nullptr && g.done[i] != 0;
         if (live && g.d_reward) dr_in = g.d_reward[i];
-        if constexpr (KIND == VF_ENV_RACING) {
+        if constexpr (kind_is_racing(KIND)) {
             if (live) gate_bits = granule(T, g.G, i, g.g_race)->x;
         }
     }
@@ -268,6 +268,10 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
                 float4 d0, d1, d2, d3;
                 lds_read4_opaque<16>(d4, d0, d1, d2, d3);
                 float dd[13] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x};
+                if constexpr (KIND == VF_ENV_RACING2) {
+                    const float d16[16] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
+                    race2_obs_bwd(e, d16, dd);
+                }
                 obs_variant_bwd(e, dd);
                 lp[0] += dd[0]; lp[1] += dd[1]; lp[2] += dd[2];
                 lq.w += dd[3]; lq.x += dd[4]; lq.y += dd[5]; lq.z += dd[6];
@@ -286,10 +290,18 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
         lwm[0] = g4.x; lwm[1] = g4.y; lwm[2] = g4.z; lwm[3] = g4.w;
         laa[0] = g6.y; laa[1] = g6.z; laa[2] = g6.w;
         if (g.d_obs) {  // observation = [p, q, v + wind, w] of the post-step state (dynamics.py:779-786), in the env's obs_mode
-            const float* d = g.d_obs + 13 * (size_t)i;
             float dd[13];
+            if constexpr (KIND == VF_ENV_RACING2) {
+                const float* d = g.d_obs + 16 * (size_t)i;
+                float d16[16];
 #pragma unroll
-            for (int k = 0; k < 13; ++k) dd[k] = d[k];
+                for (int k = 0; k < 16; ++k) d16[k] = d[k];
+                race2_obs_bwd(e, d16, dd);
+            } else {
+                const float* d = g.d_obs + 13 * (size_t)i;
+#pragma unroll
+                for (int k = 0; k < 13; ++k) dd[k] = d[k];
+            }
             obs_variant_bwd(e, dd);
             lp[0] += dd[0]; lp[1] += dd[1]; lp[2] += dd[2];
             lq.w += dd[3]; lq.x += dd[4]; lq.y += dd[5]; lq.z += dd[6];
@@ -407,7 +419,7 @@ __device__ __forceinline__ void env_step_bwd_agent(const vf_dyn_cfg& c, const vf
     } else if (live && g.d_reward) {
         const float dr = dr_in;
         const float* tgt = e.target;
-        if constexpr (KIND == VF_ENV_RACING) {
+        if constexpr (kind_is_racing(KIND)) {
             int gate = __float_as_int(gate_bits);
             gate = (unsigned)gate < (unsigned)e.n_gates ? gate : 0;
             // CKPT (persistent sweep): a per-lane indexed load of the gate table would be a vector load queued behind the step's

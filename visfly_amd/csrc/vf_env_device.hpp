@@ -127,6 +127,43 @@ __device__ __forceinline__ void obs_variant(const vf_env_cfg& e, float* o)
     }
 }
 
+// RacingEnv2's observation inside the persistent launches (RacingEnv.py:254-262; the arithmetic of k_race_obs, vf_obs.hip): the kernels are
+// instantiated with the kernel-side env kind VF_ENV_RACING2 -- RacingEnv's step (dynamics, gates, reward, re-spawn) with 16-wide rows
+constexpr int VF_ENV_RACING2 = 3;
+constexpr bool kind_is_racing(int kind) { return kind == VF_ENV_RACING || kind == VF_ENV_RACING2; }
+constexpr int obs_width(int kind) { return kind == VF_ENV_RACING2 ? 16 : 13; }
+// o: the raw state row [p, q, v, w] (13) -> out (16) for gate index `gate`
+__device__ __forceinline__ void race2_obs(const vf_env_cfg& e, const float* o, int gate, float* out)
+{
+    const int g1 = gate + 1 == e.n_gates ? 0 : gate + 1;            // (gate + 1) % n_gates, gate < n_gates
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out[c] = (e.gates[gate][c] - o[c]) / e.sense_radius;
+        out[3 + c] = (e.gates[g1][c] - o[c]) / e.sense_radius;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[6 + c] = o[3 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out[10 + c] = o[7 + c] / 10.0f;
+        out[13 + c] = o[10 + c] / 10.0f;
+    }
+}
+// its adjoint (the gate index carries no gradient): d (16) -> the raw row's (13): dp = -(d[0:3] + d[3:6]) / R, dq = d[6:10],
+// dv = d[10:13] / 10, dw = d[13:16] / 10 (RacingEnv2.backward_step's arithmetic, visfly_amd/envs/tasks.py)
+__device__ __forceinline__ void race2_obs_bwd(const vf_env_cfg& e, const float* d, float* dd)
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dd[c] = -(d[c] + d[3 + c]) / e.sense_radius;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dd[3 + c] = d[6 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dd[7 + c] = d[10 + c] / 10.0f;
+        dd[10 + c] = d[13 + c] / 10.0f;
+    }
+}
+
 // ... and their adjoint: the gradient w.r.t. an observation row in the env's obs_mode -> the gradient w.r.t. the raw state row
 // (HoverEnv2 / NavigationEnv2 take requires_grad like every env of the reference: HoverEnv.py:105,125, NavigationEnv.py:109,137; r05)
 __device__ __forceinline__ void obs_variant_bwd(const vf_env_cfg& e, float* d)

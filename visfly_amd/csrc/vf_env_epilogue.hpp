@@ -228,14 +228,22 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
                 g.out.ep_flags[i] = (success ? VF_EP_SUCCESS : 0) | (truncated ? VF_EP_TRUNCATED : 0) |
                                     ((er.flags & VF_F_ONCE_COLLIDED) ? VF_EP_COLLIDED : 0) |
                                     (ep_done ? VF_EP_EPISODE_DONE : 0);
-            if constexpr (KIND == VF_ENV_RACING) {
+            if constexpr (kind_is_racing(KIND)) {
                 if (g.out.ep_past_gates) g.out.ep_past_gates[i] = passed;
                 if (g.out.terminal_gate) g.out.terminal_gate[i] = gate_pre;
             }
             if (g.out.terminal_obs) {
-                float* to = g.out.terminal_obs + 13 * (size_t)i;
+                if constexpr (KIND == VF_ENV_RACING2) {      // the terminal row with the gate index of the step's start (RacingEnv's rule)
+                    float ot[16];
+                    race2_obs(e, o, gate_pre, ot);
+                    float* to = g.out.terminal_obs + 16 * (size_t)i;
 #pragma unroll
-                for (int k = 0; k < 13; ++k) to[k] = o[k];
+                    for (int k = 0; k < 16; ++k) to[k] = ot[k];
+                } else {
+                    float* to = g.out.terminal_obs + 13 * (size_t)i;
+#pragma unroll
+                    for (int k = 0; k < 13; ++k) to[k] = o[k];
+                }
             }
         }
     }
@@ -248,7 +256,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     }
     if (done && g.auto_reset) {  // examine() -> reset_agent_by_id (:339-349,420-423)
         unsigned episode = ((unsigned)er.flags >> 8) + 1u;
-        if constexpr (KIND == VF_ENV_RACING) {
+        if constexpr (kind_is_racing(KIND)) {
             // RacingEnv.reset_agent_by_id (RacingEnv.py:150-163) picks the next gate BEFORE the base class
             // re-spawns the agent: the choice is made from the terminal position of the finished episode
             gate = racing_choose_gate(s.p);
@@ -282,7 +290,7 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
         obs_row(c, s, o);
         obs_variant(e, o);
     }
-    if constexpr (KIND == VF_ENV_RACING) {
+    if constexpr (kind_is_racing(KIND)) {
         race.x = __int_as_float(gate);
         race.y = __int_as_float(passed);
         *granule(g.d.S, g.d.G, i, g.g_race) = race;
@@ -292,7 +300,12 @@ __device__ __forceinline__ void env_epilogue(const vf_dyn_cfg& c, const vf_env_c
     VF_EPI_TR(9, sp.acc);                                                                // outputs written, re-spawn decided
     if constexpr (STORE_STATE) store_agent(g.d.S, g.d.G, i, s, sp);
     VF_EPI_TR(10, sp.acc);                                                               // state stores issued
-    if constexpr (LANES == 4) store_rows_quads<13>(g.out.obs, g.d.N, wave_first, o, tile);
+    if constexpr (KIND == VF_ENV_RACING2) {          // the row the policy reads next: the CURRENT gate (after a pass / a re-spawn)
+        float o16[16];
+        race2_obs(e, o, gate, o16);
+        if constexpr (LANES == 4) store_rows_quads<16>(g.out.obs, g.d.N, wave_first, o16, tile);
+        else store_rows_coalesced<16>(g.out.obs, g.d.N, wave_first, o16, tile);
+    } else if constexpr (LANES == 4) store_rows_quads<13>(g.out.obs, g.d.N, wave_first, o, tile);
     else store_rows_coalesced<13>(g.out.obs, g.d.N, wave_first, o, tile);
 }
 

@@ -209,6 +209,7 @@ class DroneEnvsBase:
 class DroneGymEnvsBase:
     KIND = HOVER
     OBS_MODE = 0        # VF_OBS_STATE
+    _OBS_W = 13         # columns of the "state" rows the kernels write (RacingEnv2's persistent launches: 16)
     REWARD_MODE = 0     # VF_REWARD_DEFAULT
     _STATIC_OBS_CONST = True   # _static_obs() returns the same tensor objects every step (the ring path caches the dict)
 
@@ -285,6 +286,7 @@ class DroneGymEnvsBase:
         e = _lib.EnvCfg()
         e.kind, e.max_episode_steps = self.KIND, self.max_episode_steps
         e.obs_mode, e.reward_mode = self.OBS_MODE, self.REWARD_MODE
+        e.sense_radius = 10.0                                                         # droneGymEnv.py:69 (max_sense_radius; VF_OBS_RACE2)
         e.is_collision_reset = int(bool(is_collision_reset))
         lo, hi = (-30., -30., 0.), (30., 30., 8.)                                     # droneEnv.py:129
         for d in range(3):
@@ -844,8 +846,9 @@ class DroneGymEnvsBase:
         every step in the slots' "mean" / "value" buffers.  -> False when the library has no roll-out kernel for this env / network
         / dynamics configuration (the caller then steps launch by launch).  ``reward_rows`` (H,N) / ``ep_flag_rows`` (H,N) uint8:
         optional per-step copies of the reward and of the episode flags (valid where done) -- SHAC's horizon buffer."""
+        W = self._OBS_W        # 13, or the 16 gate-relative columns the persistent launches form themselves for RacingEnv2 (VF_OBS_RACE2)
         if (self._tape is None or self.spawn_mode != "device" or self._imu_noise is not None or self._half_step
-                or self.envs.dynamics._wind_fn is not None or getattr(self, "_HOST_OBS", False) or not self.tensor_output
+                or self.envs.dynamics._wind_fn is not None or (getattr(self, "_HOST_OBS", False) and W == 13) or not self.tensor_output
                 or getattr(self, "obs_gate_exact", False)):
             return False
         H, N, dev = eps.shape[0], self.num_agent, self.device
@@ -868,10 +871,13 @@ class DroneGymEnvsBase:
             d = policy._descs[key] = policy._fused_desc(b0, True)
         policy._pack()
         if getattr(self, "_roll_out", None) is None:
-            self._roll_scratch = (th.empty((N, 13), dtype=th.float32, device=dev), th.empty(N, dtype=th.float32, device=dev),
+            self._roll_scratch = (th.empty((N, W), dtype=th.float32, device=dev), th.empty(N, dtype=th.float32, device=dev),
                                   th.empty(N, dtype=th.bool, device=dev))
             self._roll_out = self._out(*self._roll_scratch)
-        final = th.empty((N, 13), dtype=th.float32, device=dev)
+            if W != 13:         # the launch's terminal rows are W wide as well: a buffer of their own
+                self._terminal_rows_w = th.zeros((N, W), dtype=th.float32, device=dev)
+                self._roll_out.terminal_obs = _lib.ptr(self._terminal_rows_w)
+        final = th.empty((N, W), dtype=th.float32, device=dev)
         L = _lib.lib()
         # sub-step tape (include/visfly_amd.h, vf_bptt_rollout): what the reverse launch reads instead of replaying every interval;
         # one (S + 3 rows, waves of 16 agents, 64) float4 record block per tape row, allocated with the first persistent roll-out
@@ -907,9 +913,13 @@ class DroneGymEnvsBase:
         self._qcache = self._imu_cache = self._ext_col = None
         self._action = actions[H - 1]
         self._reward, self._done = self._roll_scratch[1], self._tape_done[t0 + H - 1]
+        self._after_persistent_launch()
         self._observations = self._full_obs(final)
         policy._last_M, policy._last_slot = N, H - 1
         return True
+
+    def _after_persistent_launch(self):
+        """host-side caches of per-step state that a persistent launch stepped past (overridden where an env keeps any)"""
 
     def collect_policy(self, policy, obs_keys, buf, boot, noise_key, sample_step, last_starts):
         """T = buf.actions.shape[0] rounds of PPO's collect_rollouts loop -- policy.forward (both heads), squashed-Gaussian

@@ -203,9 +203,13 @@ class RacingEnv2(RacingEnv):
     terminal rows) (NEXT tier; step_n() is refused).
     requires_grad=True (r05): the observation is linear in the raw state row for a given gate index (which carries no gradient), so
     its adjoint is four column operations in front of the step kernel's adjoint (``backward_step``); pinned by the gradient fixture
-    ``bptt_racing2_thrust`` (the reference's autograd over its own RacingEnv2.get_observation).  The trainers' persistent launches
-    do not cover a host-side observation: BPTT / SHAC on this env step launch by launch."""
-    _HOST_OBS = True
+    ``bptt_racing2_thrust`` (the reference's autograd over its own RacingEnv2.get_observation).
+    r06: the trainers' persistent launches (BPTT / SHAC: vf_bptt_rollout / vf_bptt_reverse) form and differentiate the 16 columns
+    themselves (vf_env_cfg.obs_mode = VF_OBS_RACE2: the row of the agent's CURRENT gate, which is what a trainer's policy reads --
+    ``obs_gate_exact`` False); step() keeps the launch behind the step kernel, whose gate index is the batch-wide rule."""
+    _HOST_OBS = True      # step() / step_n(): the rows are formed behind the step kernel
+    OBS_MODE = 3          # VF_OBS_RACE2: ... and inside the persistent launches
+    _OBS_W = 16
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -215,6 +219,15 @@ class RacingEnv2(RacingEnv):
         self._gates_host = (C.c_float * (3 * len(self.targets)))(*[float(x) for x in self.targets.cpu().reshape(-1).tolist()])
         self._gate_prev = th.zeros_like(self._gate)
         self.enable_done_list()        # vf_race_obs reads the step's done count (which gate index the returned rows use)
+
+    def _after_persistent_launch(self):
+        self._last_raw = None          # get_observation() re-reads the raw rows from the slab
+        self._g_obs = None
+
+    def get_observation(self, indices=None, predicted_obs=None):
+        if self._last_raw is None:
+            self._last_raw = self.envs.dynamics.state.detach()
+        return super().get_observation(indices, predicted_obs)
 
     def _race_rows(self, raw, gate, gate_prev=None, mode=0, gate_out=None):
         """vf_race_obs: the observation rows in one launch -> (N, 16) tensor (mode: include/visfly_amd.h)"""
@@ -264,7 +277,9 @@ class RacingEnv2(RacingEnv):
         dv = d[10:13] / 10, dw = d[13:16] / 10"""
         if d_obs is not None:
             d = d_obs.to(self.device, dtype=th.float32).reshape(self.num_agent, 16)
-            d_obs = th.cat([-(d[:, 0:3] + d[:, 3:6]) / float(self.max_sense_radius), d[:, 6:10], d[:, 10:13] / 10.0, d[:, 13:16] / 10.0], dim=1)
+            # divisors as device tensors: IEEE divisions like the persistent launch's race2_obs_bwd (a python scalar becomes x * (1 / s))
+            R, ten = th.full((1,), float(self.max_sense_radius), device=self.device), th.full((1,), 10.0, device=self.device)
+            d_obs = th.cat([-(d[:, 0:3] + d[:, 3:6]) / R, d[:, 6:10], d[:, 10:13] / ten, d[:, 13:16] / ten], dim=1)
         return super().backward_step(t, d_obs, d_reward)
 
     def _full_obs(self, state, raw=False):          # RacingEnv's rules for WHICH gate index the returned rows use apply unchanged
