@@ -1070,7 +1070,8 @@ def test_deferred_bootstrap_equals_per_step_bootstrap(env_name):
 @pytest.mark.parametrize("env_name,N,dyn", [("NavigationEnv", 3000, "euler"), ("HoverEnv", 1000, "euler"), ("NavigationEnv", 16500, "euler"),
                                             ("HoverEnv", 16401, "euler"), ("NavigationEnv", 3000, "rk4_drag"), ("HoverEnv", 16401, "rk4"),
                                             ("HoverEnv", 1000, "euler_nodelay"), ("NavigationEnv", 16500, "rk4_nodelay"),
-                                            ("HoverEnv2", 3000, "euler"), ("NavigationEnv2", 3000, "euler"), ("NavigationEnv2", 16500, "rk4")])
+                                            ("HoverEnv2", 3000, "euler"), ("NavigationEnv2", 3000, "euler"), ("NavigationEnv2", 16500, "rk4"),
+                                            ("RacingEnv", 3000, "euler"), ("RacingEnv2", 3000, "euler"), ("RacingEnv2", 16401, "rk4")])
 def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
     _persistent_rollout_vs_loop(env_name, N, dyn)
 
@@ -1140,7 +1141,8 @@ def _persistent_rollout_vs_loop(env_name, N, dyn, policy_kwargs=None):
             out[f"{rnd}:slab"] = sl.transpose(-3, -4).reshape(sl.shape[-3], -1, 4)[:, :N].clone()
             out[f"{rnd}:starts"] = ppo._last_starts.clone()
             out[f"{rnd}:ep"] = torch.stack([env._ep_return, env._ep_length.float(), env._ep_flags.float()]).clone()
-            out[f"{rnd}:terminal"] = env._terminal_obs.clone()
+            if env._OBS_W == 13:      # (RacingEnv2, r06: the launch's terminal rows are its own 16-column buffer; the truncated ones are compared as boot_rows)
+                out[f"{rnd}:terminal"] = env._terminal_obs.clone()
             if rnd == 0:
                 ppo.train()
         out["params"] = ppo.policy.flat.clone()
@@ -1201,7 +1203,8 @@ def test_ppo_on_a_host_observation_env_values_its_own_terminal_rows():
     from _golden import ENV_DYN
     env = RacingEnv2(num_agent_per_scene=512, seed=4, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=9, tensor_output=True)
     ppo = PPO(env, n_steps=24, batch_size=2048, n_epochs=1, seed=1, policy_kwargs=dict(activation_fn="relu"))
-    assert ppo.policy.obs_dims["state"] == 16 and ppo.defer_bootstrap is False
+    assert ppo.policy.obs_dims["state"] == 16
+    ppo.fused_rollout = False                 # (the launch-by-launch loop; the persistent roll-out forms its own 16-column terminal rows)
     ppo.collect_rollouts()
     torch.cuda.synchronize()
     rows = env._terminal_state_rows()

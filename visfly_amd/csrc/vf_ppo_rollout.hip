@@ -71,11 +71,20 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
         k = r16 ? pick_ppo_roll<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_ppo_roll<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg);
     else if ((cls & 15) == 1 && h->cfg.kind == VF_ENV_NAV && !a->obs_target)      // NavigationEnv2: the target is inside the "state" row
         k = r16 ? pick_ppo_roll<vf::NetHover, 16, VF_ENV_NAV>(h->dyn.cfg) : pick_ppo_roll<vf::NetHover, 32, VF_ENV_NAV>(h->dyn.cfg);
+    // r06: RacingEnv (the raw state row) and RacingEnv2 (obs_mode VF_OBS_RACE2: the 16 gate-relative columns of the agent's current gate,
+    // formed by the epilogue -- kernel-side kind VF_ENV_RACING2) under the one-observation class; the motor-lag form of the interval
+    const bool race2 = h->cfg.kind == VF_ENV_RACING && h->cfg.obs_mode == VF_OBS_RACE2;
+    const int OW = race2 ? 16 : 13;
+    if (desc->in_dim[0] != OW) k = nullptr;
+    else if ((cls & 15) == 1 && h->cfg.kind == VF_ENV_RACING && !a->obs_target && h->dyn.cfg.ctrl_delay) {
+        if (race2) k = r16 ? pick_ppo_roll2<vf::NetHover, 16, vf::VF_ENV_RACING2, true>(h->dyn.cfg) : pick_ppo_roll2<vf::NetHover, 32, vf::VF_ENV_RACING2, true>(h->dyn.cfg);
+        else k = r16 ? pick_ppo_roll2<vf::NetHover, 16, VF_ENV_RACING, true>(h->dyn.cfg) : pick_ppo_roll2<vf::NetHover, 32, VF_ENV_RACING, true>(h->dyn.cfg);
+    }
     const int rows = r16 ? 16 : 32;
     vf::EnvArgs ge{vf::DynArgs{N, h->dyn.G, h->dyn.g_drag, h->dyn.S, nullptr, nullptr, vf::ring_head(&h->dyn), nullptr, h->dyn.vel_strided},
                    *out, h->g_race, 1};
     ge.out.done_list = ge.out.done_count = nullptr;
-    ge.out.obs = T > 1 ? a->obs_state + (size_t)N * 13 : a->obs_final;
+    ge.out.obs = T > 1 ? a->obs_state + (size_t)N * OW : a->obs_final;
     vf::ChainArgs gc{*desc, params, packed, vf::ChainIo{{a->obs_state, a->obs_target}, a->means, a->values}, T * N, nullptr, nullptr, nullptr,
                      {nullptr, nullptr}};
     vf::PpoRollArgs r{T, N, reinterpret_cast<float4*>(a->actions), a->log_probs, a->rewards, a->episode_starts, a->last_starts,

@@ -19,7 +19,7 @@ struct PpoRollArgs {
     float* rewards;                 // [T][N]
     float* episode_starts;          // [T][N]; row 0 is filled by the caller
     float* last_starts;             // (N,): episode_starts of the step after the last one
-    float* obs_slots;               // [T][N][13] = RolloutBuffer.obs["state"]
+    float* obs_slots;               // [T][N][13] = RolloutBuffer.obs["state"] (RacingEnv2: 16 wide, like obs_final / rows0 / the terminal rows)
     float* obs_final;               // (N,13)
     const float* log_std;
     unsigned long long noise_key, sample_step;      // step t samples with Philox counter sample_step + 1 + t (k_head_sample)
@@ -36,7 +36,7 @@ struct PpoRollArgs {
 // one forward of rows `row` (lane & (ROWS - 1) of the wave): value -> g.io.value; -> the mean row, valid in the lanes < ROWS
 // (the accumulator lanes of group 0 hold heads of their own row: chain_epilogue / chain16_epilogue).  The "state" row comes from
 // the wave's LDS tile (13 floats per agent, where the env epilogue of the previous step left it), other branches from memory.
-template <class Net, int ROWS>
+template <class Net, int ROWS, int OW = 13>
 __device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int row, const float* tile)
 {
     const int m = lane & (ROWS - 1);
@@ -47,7 +47,7 @@ __device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int
 #pragma unroll
         for (int b = 0; b < Net::NB; ++b) {
             const int w = gc.d.in_dim[b];
-            const float* x = b == 0 ? tile + m * 13 : gc.io.in[b] + (size_t)row * w;
+            const float* x = b == 0 ? tile + m * OW : gc.io.in[b] + (size_t)row * w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * gq + j;
@@ -65,7 +65,7 @@ __device__ __forceinline__ float4 policy_rows(const ChainArgs& gc, int lane, int
 #pragma unroll
         for (int b = 0; b < Net::NB; ++b) {
             const int w = gc.d.in_dim[b];
-            const float* x = b == 0 ? tile + m * 13 : gc.io.in[b] + (size_t)row * w;
+            const float* x = b == 0 ? tile + m * OW : gc.io.in[b] + (size_t)row * w;
 #pragma unroll
             for (int s = 0; s < Net::kin(b) / 2; ++s) {
                 const int k = 2 * s + h;
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
     prefetch_kernarg<sizeof(EnvArgs) + sizeof(ChainArgs) + sizeof(PpoRollArgs) + 16>();
     const vf_dyn_cfg& c = *cp;
     const vf_env_cfg& e = *ep;
-    __shared__ __attribute__((aligned(16))) float tile[64 * 13];
+    constexpr int OW = obs_width(KIND);       // 13, or RacingEnv2's 16 gate-relative columns (vf_env_device.hpp: race2_obs)
+    __shared__ __attribute__((aligned(16))) float tile[64 * OW];
     const int lane = threadIdx.x, m = lane & (ROWS - 1);
     const int wave_first = blockIdx.x * ROWS;
     // lanes ROWS..63 and the lanes past the last agent are REPLICAS of a live lane (same index, loads, arithmetic, stores of the
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
     // the wave's observation tile: row l = the "state" observation of lane l's agent.  The env epilogue of step t leaves the rows
     // of step t + 1 there (store_rows_coalesced stages them through it on their way to RolloutBuffer.obs[t + 1]); step 0's come
     // from the caller's row 0.  One wave's LDS operations execute in order: no barrier.
-    for (int k = 0; k < 13; ++k) tile[lane * 13 + k] = r.obs_slots[(size_t)i * 13 + k];
+    for (int k = 0; k < OW; ++k) tile[lane * OW + k] = r.obs_slots[(size_t)i * OW + k];
     __builtin_amdgcn_wave_barrier();
 #ifdef VF_PPO_TRACE
     long long tr[5] = {0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
         ChainArgs gct = gc;
         gct.packed = gc.packed + zero_t;
         gct.params = gc.params + zero_t;
-        float4 mean = policy_rows<Net, ROWS>(gct, lane_t, row, tile);
+        float4 mean = policy_rows<Net, ROWS, OW>(gct, lane_t, row, tile);
         // lane m < ROWS holds the head of its own agent; the replica lanes take it from there
         mean.x = __shfl(mean.x, m); mean.y = __shfl(mean.y, m); mean.z = __shfl(mean.z, m); mean.w = __shfl(mean.w, m);
         VF_PT(0);
@@ -175,13 +176,13 @@ __global__ __launch_bounds__(64) void k_ppo_rollout(const vf_dyn_cfg* __restrict
                 const int slot = atomicAdd(r.cursor, 1);
                 if (slot < r.capacity) {
                     r.idx_list[slot] = row;
-                    const float* to = g.out.terminal_obs + 13 * (size_t)i;
-                    for (int k = 0; k < 13; ++k) r.rows0[(size_t)slot * 13 + k] = to[k];
+                    const float* to = g.out.terminal_obs + OW * (size_t)i;
+                    for (int k = 0; k < OW; ++k) r.rows0[(size_t)slot * OW + k] = to[k];
                     for (int k = 0; k < r.w1; ++k) r.rows1[(size_t)slot * r.w1 + k] = r.obs1[(size_t)i * r.w1 + k];
                 }
             }
         }
-        g.out.obs = t + 2 < r.T ? r.obs_slots + (size_t)(t + 2) * r.N * 13 : r.obs_final;
+        g.out.obs = t + 2 < r.T ? r.obs_slots + (size_t)(t + 2) * r.N * OW : r.obs_final;
         g.d.head = g.d.head + 1 == c.delay_steps ? 0 : g.d.head + 1;
         VF_PT(4);
     }

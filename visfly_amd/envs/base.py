@@ -927,12 +927,13 @@ class DroneGymEnvsBase:
         statistics -- in ONE persistent launch (vf_ppo_rollout).  buf.obs["state"][0] (and every row of buf.obs["target"])
         and buf.episode_starts[0] are the caller's.  -> the final observation TensorDict, or False when the library has no
         roll-out kernel for this env / network / dynamics configuration (the caller then steps launch by launch)."""
+        W = self._OBS_W        # 13, or RacingEnv2's 16 columns (formed inside the launch: VF_OBS_RACE2)
         if (self._tape is not None or self.spawn_mode != "device" or self._imu_noise is not None or self._half_step
-                or self.envs.dynamics._wind_fn is not None or getattr(self, "_HOST_OBS", False) or not self.tensor_output
+                or self.envs.dynamics._wind_fn is not None or (getattr(self, "_HOST_OBS", False) and W == 13) or not self.tensor_output
                 or getattr(self, "obs_gate_exact", False)
-                or self._terminal_state_rows() is not self._terminal_obs
+                or (W == 13 and self._terminal_state_rows() is not self._terminal_obs)
                 or any(k not in ("state", "target") for k in obs_keys) or policy._plan is None or not policy.fused
-                or policy.obs_dims.get("state") != 13 or buf.obs["state"].shape[-1] != 13):
+                or policy.obs_dims.get("state") != W or buf.obs["state"].shape[-1] != W):
             return False
         assert self._is_initial, "You should call reset() before step()"
         T, N, dev = buf.actions.shape[0], self.num_agent, self.device
@@ -946,9 +947,12 @@ class DroneGymEnvsBase:
         if sc is None:
             sc = self._collect_scratch = {"reward": th.empty(N, dtype=th.float32, device=dev),
                                           "done": th.empty(N, dtype=th.bool, device=dev),
-                                          "state": th.empty((N, 13), dtype=th.float32, device=dev)}
+                                          "state": th.empty((N, W), dtype=th.float32, device=dev)}
             sc["out"] = self._out(sc["state"], sc["reward"], sc["done"])
-        final = th.empty((N, 13), dtype=th.float32, device=dev)
+            if W != 13:         # the launch's terminal rows are W wide as well: a buffer of their own
+                sc["terminal"] = th.zeros((N, W), dtype=th.float32, device=dev)
+                sc["out"].terminal_obs = _lib.ptr(sc["terminal"])
+        final = th.empty((N, W), dtype=th.float32, device=dev)
         o1 = buf.obs["target"] if "target" in obs_keys else None
         a = _lib.PpoRolloutArgs()
         a.T, a.w1, a.capacity = T, 0 if o1 is None else o1.shape[-1], boot["cap"]
@@ -981,6 +985,7 @@ class DroneGymEnvsBase:
         self._qcache = self._imu_cache = self._ext_col = None
         self._action = buf.actions[T - 1]
         self._reward, self._done = sc["reward"], sc["done"]
+        self._after_persistent_launch()
         self._observations = obs = self._full_obs(final)
         return obs
 

@@ -948,7 +948,9 @@ class PPO:
         self._current_progress_remaining = 1.0
         # TimeLimit bootstrap valued once per rollout (collect_rollouts) from the terminal rows the step kernel wrote; envs that
         # assemble their observation on the host (RacingEnv2: 16 gate-relative columns) have no such kernel rows -> valued per step
-        self.defer_bootstrap, self._boot = not getattr(env, "_HOST_OBS", False), None
+        self.defer_bootstrap, self._boot = (not getattr(env, "_HOST_OBS", False)) or getattr(env, "_OBS_W", 13) != 13, None
+        if hasattr(env, "obs_gate_exact"):       # RacingEnv / RacingEnv2: this policy does not read "gate"; its "state" rows use the agent's
+            env.obs_gate_exact = False           # current gate (what the persistent roll-out forms), as under BPTT / SHAC
         self.fused_rollout = True           # collect_rollouts as one persistent launch where the library has the kernel (vf_ppo_rollout)
         self._last_obs = None
         if not getattr(env, "_is_initial", False):
