@@ -154,9 +154,9 @@ def test_bench_two_ranks_control_flow(launcher):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20", "--agents", "16384"]
-    if launcher == "torchrun":
+    if launcher == "torchrun":     # (the primary line only: the secondary legs' two-rank control flow is the plain launch's below)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(29900 + os.getpid() % 90)] + tail
+               "--master-port", str(29900 + os.getpid() % 90)] + tail + ["--no-secondary"]
     else:
         cmd = [sys.executable] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)

@@ -40,9 +40,8 @@ def test_fixture_is_a_run_of_the_references_train(name):
         assert not bool(fx["early_stop"]) and len(fx["value_loss"]) == n_opt == len(per_epoch) * int(fx["n_epochs"])
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", CASES)
-def test_train_replays_the_references_train(name):
+def _trainer_on_fixture(name):
+    """the trainer with the fixture's hyper-parameters, initial parameters and rollout buffer -> (env, ppo, fx, perms, device tensor maker)"""
     import torch
     from visfly_amd.envs import NavigationEnv
     from visfly_amd.ppo import PPO
@@ -75,6 +74,16 @@ def test_train_replays_the_references_train(name):
         dst.copy_(d(fx[key]))
     # the reference's rows are env-major (SB3 swap_and_flatten: row = env * T + step), the trainer's step-major
     perms = [(p % T) * N + (p // T) for p in fx["perms"].astype(np.int64)]
+    return env, ppo, fx, perms, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_train_replays_the_references_train(name):
+    import torch
+    env, ppo, fx, perms, d = _trainer_on_fixture(name)
+    pol = ppo.policy
+    n = pol.n_params
     rec = {"loss": [], "value_loss": [], "grad": [], "params": [], "stepped": []}
     real = ppo._minibatch_update
 
@@ -135,4 +144,56 @@ def test_train_replays_the_references_train(name):
     assert lg["train/n_updates"] == int(fx["log_n_updates"]) == int(fx["n_updates"])
     if float(fx["clip_range_vf"]) > 0:
         assert abs(lg["train/clip_range_vf"] - float(fx["log_clip_range_vf"])) <= 1e-9
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_every_optimiser_step_from_the_references_own_state(name):
+    """the replay above lets the two runs drift apart (its bounds grow with the step index: r05 verdict).  Here every optimiser step starts
+    from the REFERENCE's state -- its parameters after the previous step and the Adam moments a float64 replay of its recorded gradients
+    gives -- so that each step is held to the bounds of the first one: gradient 2e-5 of the block scale, norm 2e-5, parameters after clip +
+    Adam 99 % within 2e-7 and none off by more than 2 % of a full-size step"""
+    import torch
+    env, ppo, fx, perms, d = _trainer_on_fixture(name)
+    pol = ppo.policy
+    n = pol.n_params
+    lr, wd, eps, b1, b2, mx = float(fx["log_learning_rate"]), float(fx["weight_decay"]), float(fx["adam_eps"]), 0.9, 0.999, float(fx["max_grad_norm"])
+    n_opt = len(fx["loss"])
+    # the reference's optimiser state before step k, from its own gradients (float64)
+    m, v, states = np.zeros(n), np.zeros(n), []
+    for k in range(n_opt):
+        states.append((m.copy(), v.copy()))
+        p_before = (fx["params0"] if k == 0 else fx["params"][k - 1]).astype(np.float64)
+        g = fx["grad"][k].astype(np.float64)
+        g = g * min(1.0, mx / (np.linalg.norm(g) + 1e-6)) + wd * p_before
+        m, v = b1 * m + (1 - b1) * g, b2 * v + (1 - b2) * g * g
+    rec = {"grad": [], "params": []}
+    real = ppo._minibatch_update
+    offs = [(ly.w_off, ly.w_off + ly.K * ly.No) for ly in pol.layers] + [(ly.b_off, ly.b_off + ly.No) for ly in pol.layers] + [(pol.log_std_off, n)]
+
+    def spy(mb, stats_acc=None):
+        k = len(rec["grad"])
+        if 0 < k < n_opt:          # continue from where the REFERENCE stood
+            pol.flat[:n].copy_(d(fx["params"][k - 1]))
+            pol.mark_updated()
+            ppo.exp_avg[:n].copy_(d(states[k][0].astype(np.float32)))
+            ppo.exp_avg_sq[:n].copy_(d(states[k][1].astype(np.float32)))
+        r = real(mb, stats_acc)
+        if r is not None:
+            rec["grad"].append(pol.grad[:n].cpu().numpy().copy())
+            rec["params"].append(pol.flat[:n].cpu().numpy().copy())
+        return r
+    ppo._minibatch_update = spy
+    ppo.train(permutations=perms)
+    torch.cuda.synchronize()
+    assert len(rec["grad"]) == n_opt
+    for i in range(n_opt):
+        g, w = rec["grad"][i], fx["grad"][i]
+        for lo, hi in offs:
+            scale = max(np.abs(w[lo:hi]).max(), 1e-3 * np.abs(w).max())
+            assert np.abs(g[lo:hi] - w[lo:hi]).max() <= 2e-5 * scale, f"step {i}: gradient block [{lo}, {hi})"
+        assert abs(np.linalg.norm(g.astype(np.float64)) - fx["grad_norm"][i]) <= 2e-5 * fx["grad_norm"][i]
+        diff = np.abs(rec["params"][i] - fx["params"][i])
+        assert np.quantile(diff, 0.99) <= 2e-7 and diff.max() <= 0.02 * lr, (i, np.quantile(diff, 0.99), diff.max())
     env.close()
