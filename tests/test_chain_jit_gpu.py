@@ -28,6 +28,14 @@ def test_shape_rules_and_generated_source():
     assert _jit.shape_of(dims, ext, [48], [32]) is None and _jit.shape_of(dims, ext, [160], [32]) is None
     assert _jit.shape_of(dims, ext, [], [32]) is None and _jit.shape_of(dims, ext, [32] * 5, [32]) is None
     assert _jit.shape_of(dims, ext, pi, vf, head_dims=(1, 1)) is None and _jit.shape_of(dims, ext, pi, vf, passthrough=("action",)) is None
+    # the twin critic (r06): heads (1, 1) + ONE pass-through input of <= 4 columns behind ONE observation branch; the default widths built in
+    cd, ce = {"state": 13, "action": 4}, {"state": [64, 64, 32]}
+    csh = _jit.shape_of(cd, ce, [32], [96, 32], head_dims=(1, 1), passthrough=("action",))
+    assert csh == ((16,), ((2, 2, 1),), (1,), (3, 1), (1, 1)) and "heads 1/1" in _jit.name_of(csh) and "static constexpr int PASS = 1;" in _jit.source(csh)
+    assert "static constexpr int PASS = 0;" in _jit.source(sh) and _jit.path_of(csh) != _jit.path_of(csh[:4])
+    assert _jit.is_builtin(_jit.shape_of(cd, {"state": [128, 64]}, [64, 64], [64, 64], head_dims=(1, 1), passthrough=("action",)))
+    assert _jit.shape_of({**dims, "action": 4}, ext, pi, vf, head_dims=(1, 1), passthrough=("action",)) is None       # two branches: 132 columns
+    assert _jit.shape_of({"state": 13, "action": 6}, ce, [32], [32], head_dims=(1, 1), passthrough=("action",)) is None
     # the SAC-style Actor (two 4-wide heads): a class of its own, the default widths built in
     assert _jit.shape_of(dims, ext, pi, vf, head_dims=(4, 4)) == sh + ((4, 4),) and "heads 4/4" in _jit.name_of(sh + ((4, 4),))
     assert "static constexpr int HM = 4, HV = 4;" in _jit.source(sh + ((4, 4),)) and "static constexpr int HM = 4, HV = 1;" in _jit.source(sh)
@@ -312,6 +320,126 @@ def test_generated_sac_actor_vs_torch_and_block_tile_kernel(name, ig, M):
         want = xs[k].grad.float()
         bad = ((res[True][1][k] - want).abs() > 1e-4 * want.abs() + 1e-5 * want.abs().max()).any(dim=1)
         assert int(bad.sum()) <= (8 if M >= 16384 else 0), (k, int(bad.sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 33, 777, 16384, 40000])
+@pytest.mark.parametrize("name", ["critic_hover", "critic_wide"])
+def test_generated_twin_critic_vs_torch_and_block_tile_kernel(name, M):
+    """r06: the reference's twin ContinuousCritic (utils/policies/td_policies.py:82-143: own extractor, th.cat([features, actions]) -> qf0 / qf1
+    -> Q) on a NON-default shape: generated class with the pass-through action tile and two 1-wide heads (ChainNetG<Spec>, PASS = 1) -- forward
+    and reverse chain against an fp64 torch network on the same weights and against the block-tile kernels it ran on until r05
+    (test_twin_critic_chain_vs_torch_and_block_tile_kernel's checks for the built-in class); the saved feature rows carry the action columns"""
+    from visfly_amd import _jit, _lib
+    from visfly_amd.ppo import MlpPolicy
+    lib = _lib.lib()
+    dims, ext, pi, vf, heads, pas = _jit.PREBUILD_CRITIC[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        pol = MlpPolicy(dims, ext, pi, vf, DEV, seed=11, ortho_init=False, head_dims=heads, passthrough=pas, log_std_param=False)
+    assert pol.chain_jit
+    g = torch.Generator(device=DEV).manual_seed(M + 7)
+    obs = {k: torch.randn((M, d), device=DEV, generator=g) for k, d in dims.items()}
+    obs["action"] = torch.tanh(obs["action"])
+    d_q0 = torch.randn((M, 1), device=DEV, generator=g) / M
+    d_q1 = torch.randn((M, 1), device=DEV, generator=g) / M
+    ref = pol.to_torch().double().to(DEV)
+    q0r, q1r = ref({k: v.double() for k, v in obs.items()})
+    ((q0r * d_q0.double()).sum() + (q1r * d_q1.double()).sum()).backward()
+    gref = ref.flat_grad().to(DEV).float()[:pol.n_params]
+    n0 = lib.vf_chain_plugin_launches()
+    q0, q1 = pol.forward(obs)
+    assert lib.vf_chain_plugin_launches() == n0 + 1 and q0.shape == q1.shape == (M, 1)
+    sc = max(q0r.abs().max().item(), q1r.abs().max().item())
+    assert (q0 - q0r.float()).abs().max().item() <= 2e-6 * sc and (q1 - q1r.float()).abs().max().item() <= 2e-6 * sc
+    nfeat = ext["state"][-1]
+    assert torch.equal(pol._buffers(M, 0)["feat"][:, nfeat:], obs["action"])          # pass-through columns of the saved feature rows
+    b = pol._buffers(M, 0)
+    bd = pol._bwd_desc(b, M, d_q0, d_q1, False)[0]
+    assert lib.vf_mlp_backward_data_supported(C.byref(bd)) == 1                        # the generated class IS what runs
+    res = {}
+    for fused in (True, False, True):
+        pol.fused_backward = fused
+        pol.grad.fill_(0.0)
+        pol.forward(obs)
+        n1 = lib.vf_chain_plugin_launches()
+        pol.backward(d_q0, d_q1, None)
+        assert (lib.vf_chain_plugin_launches() > n1) == fused
+        if fused and fused in res:
+            assert torch.equal(res[True], pol.grad)
+        res[fused] = pol.grad.clone()
+    scale = gref.abs().max().item()
+    assert (res[True] - res[False]).abs().max().item() <= 5e-6 * scale
+    for fused in (True, False):                      # vs fp64: ReLU-mask flips at large M (test_sac_actor_chain_vs_torch_and_block_tile_kernel)
+        err = (res[fused] - gref).abs().max().item()
+        assert err <= (1e-3 if M >= 16384 else 2e-6) * scale, (fused, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1000, 4096 + 17, 40000])
+@pytest.mark.parametrize("name", ["critic_hover", "critic_wide"])
+def test_generated_fused_critic_step_equals_the_three_launch_step(name, M):
+    """vf_twin_q_update on a generated twin-critic class (forward + twin-Q loss + reverse chain in one launch of the plugin's
+    k_twin_q_update_chain) leaves the loss and the flat gradient of the forward / vf_twin_q_loss / backward path (same chain arithmetic;
+    the masks come from registers instead of the saved activations) -- test_fused_critic_step_equals_the_three_launch_step for the built-in class"""
+    from visfly_amd import _jit, _lib
+    from visfly_amd.ppo import MlpPolicy, _ptr
+    L = _lib.lib()
+    st = _lib.current_stream(torch.device(DEV))
+    dims, ext, pi, vf, heads, pas = _jit.PREBUILD_CRITIC[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        c = MlpPolicy(dims, ext, pi, vf, DEV, seed=3, ortho_init=False, head_dims=heads, passthrough=pas, log_std_param=False)
+        g = torch.Generator(device=DEV).manual_seed(M)
+        obs = {"state": torch.randn((M, 13), device=DEV, generator=g), "action": torch.tanh(torch.randn((M, 4), device=DEV, generator=g))}
+        target = torch.randn(M, device=DEV, generator=g)
+        out = {}
+        for fused in (False, True):
+            c.grad.fill_(0.0)
+            loss = torch.empty(1, device=DEV)
+            if fused:
+                n0 = L.vf_chain_plugin_launches()
+                assert c.twin_q_update(obs, target, loss, M), "the generated critic class must run on vf_twin_q_update"
+                assert L.vf_chain_plugin_launches() == n0 + 1 and c._fused_twin_q is not False
+            else:
+                q0, q1 = c.forward(obs, save_activations=True)
+                dq0, dq1 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+                scr = torch.empty(int(L.vf_twin_q_loss_scratch_doubles(M)), dtype=torch.float64, device=DEV)
+                _lib.check(L.vf_twin_q_loss(_ptr(q0.view(-1)), _ptr(q1.view(-1)), _ptr(target), _ptr(dq0), _ptr(dq1), _ptr(loss), scr.data_ptr(), M, M, st))
+                c.backward(dq0.view(M, 1), dq1.view(M, 1), None)
+            out[fused] = (float(loss), c.grad[:c.n_params].clone())
+    (l0, g0), (l1, g1) = out[False], out[True]
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0)), (l0, l1)
+    scale = g0.abs().max().item()
+    assert scale > 0 and (g1 - g0).abs().max().item() <= 2e-6 * scale, ((g1 - g0).abs().max().item(), scale)
+
+
+@pytest.mark.gpu
+def test_shac_with_a_non_default_net_arch_runs_its_critic_on_chain_kernels():
+    """SHAC(net_arch=dict(pi=[32], qf=[32])) over a [64, 64, 32] extractor: actor AND twin critic have generated chain classes -- the critic
+    updates are the plugin's fused step (no block-tile fallback warning from vf_twin_q_update), and the critic loss falls over an iteration"""
+    from visfly_amd import _lib
+    from visfly_amd.shac import SHAC
+    from visfly_amd.envs import HoverEnv2
+    from _golden import ENV_DYN
+    lib = _lib.lib()
+    pk = dict(features_extractor_class="StateExtractor", features_extractor_kwargs={"net_arch": {"state": {"layer": [64, 64, 32]}}},
+              net_arch=dict(pi=[32], qf=[32]), activation_fn="relu", share_features_extractor=False)
+    env = HoverEnv2(num_agent_per_scene=1024, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, tensor_output=True, max_episode_steps=64,
+                    requires_grad=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        algo = SHAC(env, policy="MultiInputPolicy", policy_kwargs=pk, horizon=8, learning_rate=1e-3, seed=1)
+        assert algo.critic.chain_jit and algo.policy.chain_jit
+        env.reset()
+        n0 = lib.vf_chain_plugin_launches()
+        algo.learn(2 * 8 * 1024)
+        torch.cuda.synchronize()
+    assert lib.vf_chain_plugin_launches() - n0 >= 2 * algo.gradient_steps
+    assert algo.critic._fused_twin_q is not False
+    bad = [str(x.message) for x in w if "vf_twin_q_update" in str(x.message) or "block-tile" in str(x.message)]
+    assert not bad, bad
+    env.close()
 
 
 @pytest.mark.gpu

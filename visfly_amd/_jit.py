@@ -9,7 +9,8 @@ flags) and registers it with the library (vf_chain_plugin_load).  ``__graft_entr
 the GPU box finds them in the snapshot.
 
 Shapes that qualify: 1-2 observation branches of <= 32 columns, 1-4 layers per branch / trunk, widths in multiples of 32 up to 128,
-the actor-critic heads (4, 1) or the SAC-style Actor's (4, 4), no pass-through input.  Everything else keeps running on the block-tile kernels (MlpPolicy warns once).
+the actor-critic heads (4, 1), the SAC-style Actor's (4, 4), or the twin critic's (1, 1) with its pass-through action input behind ONE
+observation branch.  Everything else keeps running on the block-tile kernels (MlpPolicy warns once).
 ``VISFLY_AMD_JIT=0`` switches the compilation off.
 """
 import hashlib
@@ -25,7 +26,8 @@ JIT_DIR = os.path.join(CSRC, "jit")
 MAX_DEPTH = 4
 # the shapes libvisfly_amd.so itself instantiates (NetHover / NetNav and their policy-only classes)
 _BUILTIN = {((16,), ((4, 2),), (2, 2), (2, 2)), ((16, 8), ((4, 2), (4, 2)), (2, 2), (2, 2)),
-            ((16,), ((4, 2),), (2, 2), (2, 2), (4, 4)), ((16, 8), ((4, 2), (4, 2)), (2, 2), (2, 2), (4, 4))}      # (.., (4, 4)): the SAC-style Actor
+            ((16,), ((4, 2),), (2, 2), (2, 2), (4, 4)), ((16, 8), ((4, 2), (4, 2)), (2, 2), (2, 2), (4, 4)),      # (.., (4, 4)): the SAC-style Actor
+            ((16,), ((4, 2),), (2, 2), (2, 2), (1, 1))}                                                            # (.., (1, 1)): its twin critic (NetCriticHover)
 _HEADERS = ("vf_mlp_chain.hpp", "vf_mlp_chain_bwd.hpp", "vf_mlp_chain_kernels.hpp", "vf_mlp_chain_gen.hpp", "vf_chain_plugin.hpp",
             "vf_common.hpp", "vf_ppo_device.hpp")
 _ROLLOUT_HEADERS = ("vf_ppo_rollout_kernel.hpp", "vf_env_epilogue.hpp", "vf_env_device.hpp", "vf_dyn_device.hpp", "vf_xmath.hpp",
@@ -48,6 +50,11 @@ PREBUILD_ACT = {
     "tanh_hover": ({"state": 13}, {"state": [128, 64]}, [64, 64], [64, 64], (4, 1), (2, 1)),
     "elu_leaky_nav": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [128, 64]}, [64, 64], [64, 64], (4, 1), (3, 4)),
 }
+# the twin critic (heads (1, 1) + pass-through action; td_policies.ContinuousCritic) on non-default shapes: (.., head_dims, passthrough)
+PREBUILD_CRITIC = {
+    "critic_hover": ({"state": 13, "action": 4}, {"state": [64, 64, 32]}, [32], [32], (1, 1), ("action",)),      # SHAC(net_arch pi=[32]) over features [64, 64, 32]
+    "critic_wide": ({"state": 13, "action": 4}, {"state": [128, 96]}, [128, 64], [128, 64], (1, 1), ("action",)),
+}
 PREBUILD_SAC = {
     "sac_nav": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [64]}, [128, 64], [64], (4, 4)),
     "sac_hover": ({"state": 13}, {"state": [64, 64, 32]}, [32], [32], (4, 4)),      # (the Actor BPTT builds for pi=[32]: log_latent_pi mirrors latent_pi)
@@ -60,7 +67,10 @@ def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=(), acts
     """(KIN, extractor widths in tiles, pi tiles, vf tiles[, (4, 4)][, ("act", trunks, extractor)]) of a network the generated chain classes
     cover, else None.  Heads (4, 1): the actor-critic of the PPO policies; (4, 4): the SAC-style Actor of BPTT / SHAC (mu / log_std heads).
     acts: VF_ACTIVATION_* of the trunks / the extractor MLPs -- (1, 1) = ReLU networks (no element: the keys of r05's shapes)"""
-    if passthrough or tuple(head_dims) not in ((4, 1), (4, 4)) or not 1 <= len(extractor) <= 2:
+    critic = tuple(head_dims) == (1, 1)      # td_policies.ContinuousCritic: th.cat([features, actions]) -> qf0 / qf1 (one pass-through input of <= 4 columns)
+    if critic != bool(passthrough) or tuple(head_dims) not in ((4, 1), (4, 4), (1, 1)) or not 1 <= len(extractor) <= 2:
+        return None
+    if critic and (len(passthrough) != 1 or len(extractor) != 1 or not 1 <= int(obs_dims[list(passthrough)[0]]) <= 4):
         return None
     kin, ew = [], []
     for k, hidden in extractor.items():
@@ -77,7 +87,7 @@ def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=(), acts
         return None
     tiles = lambda t: tuple(h // 32 for h in t)
     sh = tuple(kin), tuple(tiles(e) for e in ew), tiles(trunks[0]), tiles(trunks[1])
-    sh = sh if tuple(head_dims) == (4, 1) else sh + ((4, 4),)
+    sh = sh if tuple(head_dims) == (4, 1) else sh + (tuple(head_dims),)
     return sh if tuple(acts) == (1, 1) else sh + (("act", int(acts[0]), int(acts[1])),)
 
 
@@ -86,7 +96,7 @@ def is_builtin(shape):
 
 
 def _heads(shape):
-    return (4, 4) if (4, 4) in shape[4:] else (4, 1)
+    return (4, 4) if (4, 4) in shape[4:] else (1, 1) if (1, 1) in shape[4:] else (4, 1)
 
 
 def _acts(shape):
@@ -104,7 +114,7 @@ def name_of(shape):
     kin, ew, pw, vw = shape[:4]
     f = lambda t: "[" + ",".join(str(32 * x) for x in t) + "]"
     a = _acts(shape)
-    return (" ".join(f"in{k}{f(e)}" for k, e in zip(kin, ew)) + f" pi{f(pw)} vf{f(vw)}" + (" heads 4/4" if _heads(shape) == (4, 4) else "") +
+    return (" ".join(f"in{k}{f(e)}" for k, e in zip(kin, ew)) + f" pi{f(pw)} vf{f(vw)}" + {(4, 4): " heads 4/4", (1, 1): " (+) action, heads 1/1", (4, 1): ""}[_heads(shape)] +
             ("" if a == (1, 1) else f" act {_ACT_NAME[a[0]]}/{_ACT_NAME[a[1]]}"))
 
 
@@ -128,6 +138,7 @@ struct Spec {{
     static constexpr int VW[{MAX_DEPTH}] = {{{pad(vw)}}};
     static constexpr bool VF = true;
     static constexpr int HM = {_heads(shape)[0]}, HV = {_heads(shape)[1]};
+    static constexpr int PASS = {1 if _heads(shape) == (1, 1) else 0};
     static constexpr int ACT = {_acts(shape)[0]}, EACT = {_acts(shape)[1]};       // VF_ACTIVATION_* of the trunks / the extractor MLPs
 }};
 struct SpecPi : Spec {{
@@ -168,7 +179,7 @@ def _key(shape, rollout=None):
 def _slug(shape, rollout=None):
     kin, ew, pw, vw = shape[:4]
     t = lambda x: "".join(str(v) for v in x)
-    s = "e" + "_".join(f"{k}x{t(e)}" for k, e in zip(kin, ew)) + f"_p{t(pw)}_v{t(vw)}" + ("_h44" if _heads(shape) == (4, 4) else "")
+    s = "e" + "_".join(f"{k}x{t(e)}" for k, e in zip(kin, ew)) + f"_p{t(pw)}_v{t(vw)}" + {(4, 4): "_h44", (1, 1): "_h11", (4, 1): ""}[_heads(shape)]
     if _acts(shape) != (1, 1):
         s += "_a%d%d" % _acts(shape)
     return s if rollout is None else s + "_roll" + "".join(str(int(x)) for x in rollout)
@@ -268,7 +279,8 @@ def ensure_rollout(shape, cfg):
 def prebuild(verbose=False):
     """compile the PREBUILD shapes (in parallel) -> paths"""
     act = [shape_of(*v[:5], acts=v[5]) for v in PREBUILD_ACT.values()]
-    jobs = ([(shape_of(*v), None) for v in list(PREBUILD.values()) + list(PREBUILD_SAC.values())] + [(sh, None) for sh in act] +
+    jobs = ([(shape_of(*v), None) for v in list(PREBUILD.values()) + list(PREBUILD_SAC.values()) + list(PREBUILD_CRITIC.values())] +
+            [(sh, None) for sh in act] +
             [(shape_of(*PREBUILD[n]), cfg) for n, cfg in PREBUILD_ROLLOUT] + [(act[0], (1, 1, 0, True))])        # + the Tanh policy's roll-out on NavigationEnv
     # every chain job runs four hipcc parts of fully unrolled kernels: bound the number in flight by the cores of the build box
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), (os.cpu_count() or 4) // 4))) as pool:

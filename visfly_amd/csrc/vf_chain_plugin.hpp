@@ -12,7 +12,7 @@
 namespace vf {
 
 // layout stamp: both sides are compiled from the same headers; a plugin built against other struct layouts is refused
-constexpr unsigned kChainPluginAbi = 0x56460001u ^ (unsigned)(sizeof(vf_mlp_desc) * 31u + sizeof(vf_mlp_bwd_desc) * 17u + sizeof(ChainArgs) * 7u +
+constexpr unsigned kChainPluginAbi = 0x56460002u ^ (unsigned)(sizeof(vf_mlp_desc) * 31u + sizeof(vf_mlp_bwd_desc) * 17u + sizeof(ChainArgs) * 7u +
                                                             sizeof(BwdArgsChain) * 5u + sizeof(PpoRowArgs) * 3u + sizeof(ReparamFwd) + sizeof(ReparamBwd));
 
 struct ChainPlugin {
@@ -24,6 +24,8 @@ struct ChainPlugin {
     // packed == null: capability query
     int (*backward)(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp);
     int (*ppo_update)(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowArgs* pr, int M, hipStream_t st);
+    // the twin critic's classes (heads (1, 1), pass-through action tile): SHAC's fused critic step (k_twin_q_update_chain); null: not a critic
+    int (*twin_q_update)(const ChainArgs* g, const BwdArgsChain* gb, const float* target, double* part, float scale, int M, hipStream_t st);
     // a ROLL-OUT plugin (one more shared object per shape AND env kind / action type / integrator / ctrl_delay: the persistent
     // launch of vf_ppo_rollout.hip is a template over all of them) sets only this one; env_args / roll_args: vf::EnvArgs /
     // vf::PpoRollArgs (vf_ppo_rollout_kernel.hpp; rollout_abi stamps their layout), c: the host copy of the dynamics constants
@@ -48,12 +50,13 @@ template <class Net, class NetPi>
 int plugin_forward(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1, float* out0, float* out1, int M,
                    hipStream_t st, const ReparamFwd* rpp)
 {
-    if (Net::NB == 2 && !in1) return 0;
+    if (Net::NB + Net::PASS == 2 && !in1) return 0;
     const ReparamFwd rp = rpp ? *rpp : ReparamFwd{};
+    if (Net::PASS && (rpp || !out0 || !out1)) return 0;      // the twin critic: Q1 / Q2 (M,), no action head
     ChainArgs g{*d, params, packed, ChainIo{{in0, in1, nullptr}, out0, out1}, M, rp.log_std, reinterpret_cast<const float4*>(rp.eps),
                 reinterpret_cast<float4*>(rp.action), {rp.obs_copy[0], rp.obs_copy[1]}};
     if (!out1) {
-        if constexpr (Net::HV != 1) {
+        if constexpr (Net::HV != 1 || Net::HM != 4) {
             return 0;             // (the SAC-style Actor always runs both trunks)
         } else {
             if (!chain_matches_gen<NetPi>(*d)) return 0;
@@ -73,14 +76,15 @@ int plugin_backward(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStr
     using PU = typename Net::template Bwd<true, true, false>;      // PPO update / SHAC actor: both trunks, no observation gradient
     // with observation gradient: the policy trunk alone (first-order optimisation of an actor-critic's policy) or, for the SAC-style
     // Actor, both trunks (mu and log_std heads both carry gradient)
-    using PG = typename Net::template Bwd<true, Net::HV == 4, true>;
+    // (the twin critic has no such variant: PG = PU)
+    using PG = std::conditional_t<Net::PASS != 0, PU, typename Net::template Bwd<true, Net::HV == 4, true>>;
     const ReparamBwd rp = rpp ? *rpp : ReparamBwd{};
     BwdArgsChain g{*d, packed, M, reinterpret_cast<const float4*>(rp.d_action), reinterpret_cast<const float4*>(rp.action), rp.log_std,
                    reinterpret_cast<const float4*>(rp.eps), reinterpret_cast<float4*>(rp.g_log_std)};
     const dim3 grid((M + 31) / 32);
     if (bwd_chain_matches_gen<PU>(*d, false)) {
         if (packed) hipLaunchKernelGGL(k_mlp_backward_chain<PU>, grid, dim3(64), 0, st, g);
-    } else if (bwd_chain_matches_gen<PG>(*d, true)) {
+    } else if (!Net::PASS && bwd_chain_matches_gen<PG>(*d, true)) {
         if (packed) hipLaunchKernelGGL(k_mlp_backward_chain<PG>, grid, dim3(64), 0, st, g);
     } else {
         return 0;
@@ -97,8 +101,8 @@ int plugin_ppo_update(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowAr
     // then run as the chain launches of their own)
     constexpr bool packable = Net0::all_relu;
     using Net = std::conditional_t<(Net0::n_tiles > kGenLiveTiles && packable), ChainNetG<typename Net0::Spec, true>, Net0>;
-    if constexpr (Net::HV != 1 || (Net0::n_tiles > kGenLiveTiles && !packable)) {
-        return 0;                 // (no PPO step on the SAC-style Actor: the kernel is not instantiated)
+    if constexpr (Net::HV != 1 || Net::HM != 4 || (Net0::n_tiles > kGenLiveTiles && !packable)) {
+        return 0;                 // (no PPO step on the SAC-style Actor / the twin critic: the kernel is not instantiated)
     } else {
         using PU = typename Net::template Bwd<true, true, false>;
         if (Net::NB == 2 && !g->io.in[1]) return 0;
@@ -109,9 +113,27 @@ int plugin_ppo_update(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowAr
     }
 }
 
+// SHAC's fused critic step on a generated twin-critic class (vf_mlp_chain_sac.hip: twin_q_update_chain_try checked the save pointers / row counts)
+template <class Net0>
+int plugin_twin_q_update(const ChainArgs* g, const BwdArgsChain* gb, const float* target, double* part, float scale, int M, hipStream_t st)
+{
+    constexpr bool packable = Net0::all_relu;
+    using Net = std::conditional_t<(Net0::n_tiles > kGenLiveTiles && packable), ChainNetG<typename Net0::Spec, true>, Net0>;
+    if constexpr (!Net::PASS || (Net0::n_tiles > kGenLiveTiles && !packable)) {
+        return 0;
+    } else {
+        using PU = typename Net::template Bwd<true, true, false>;
+        if (!g->io.in[1] || !chain_matches_gen<Net>(g->d) || !bwd_chain_matches_gen<PU>(gb->d, false)) return 0;
+        hipLaunchKernelGGL(k_twin_q_update_chain<Net>, dim3((M + 31) / 32), dim3(64), 0, st, *g, *gb, target, part, scale);
+        VF_HIP(hipGetLastError());
+        return 1;
+    }
+}
+
 }  // namespace vf
 
 extern "C" {
+int vf_plugin_twin_q_update(const vf::ChainArgs*, const vf::BwdArgsChain*, const float*, double*, float, int, hipStream_t);
 int vf_plugin_forward(const vf_mlp_desc*, const float*, const float*, const float*, const float*, float*, float*, int, hipStream_t, const vf::ReparamFwd*);
 int vf_plugin_backward(const vf_mlp_bwd_desc*, const float*, int, hipStream_t, const vf::ReparamBwd*);
 int vf_plugin_ppo_update(const vf::ChainArgs*, const vf::BwdArgsChain*, const vf::PpoRowArgs*, int, hipStream_t);
@@ -131,7 +153,10 @@ const vf::ChainPlugin* vf_chain_plugin();
 #elif VF_CHAIN_PLUGIN_PART == 3
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
     extern "C" int vf_plugin_ppo_update(const vf::ChainArgs* g, const vf::BwdArgsChain* gb, const vf::PpoRowArgs* pr, int M, hipStream_t st) \
-    { return vf::plugin_ppo_update<Net>(g, gb, pr, M, st); }
+    { return vf::plugin_ppo_update<Net>(g, gb, pr, M, st); }                                                                                 \
+    extern "C" int vf_plugin_twin_q_update(const vf::ChainArgs* g, const vf::BwdArgsChain* gb, const float* target, double* part,            \
+                                           float scale, int M, hipStream_t st)                                                               \
+    { return vf::plugin_twin_q_update<Net>(g, gb, target, part, scale, M, st); }
 #elif VF_CHAIN_PLUGIN_PART == 4
 // the roll-out plugin: one translation unit, one kernel instance (vf_ppo_rollout_kernel.hpp defines VF_CHAIN_PLUGIN_ROLLOUT_DEFINE)
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)
@@ -139,7 +164,8 @@ const vf::ChainPlugin* vf_chain_plugin();
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
     extern "C" const vf::ChainPlugin* vf_chain_plugin()                                                                                      \
     {                                                                                                                                        \
-        static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, vf_plugin_forward, vf_plugin_backward, vf_plugin_ppo_update, 0u, nullptr}; \
+        static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, vf_plugin_forward, vf_plugin_backward, vf_plugin_ppo_update,               \
+                                       Net::PASS ? vf_plugin_twin_q_update : nullptr, 0u, nullptr};                                          \
         return &p;                                                                                                                           \
     }
 #endif

@@ -77,6 +77,7 @@ struct ChainNet {
     static_assert(PASS_ == 0 || PASS_ == 1, "at most one pass-through input");
     static constexpr int kin(int b) { return b == 0 ? KA_ : KB_; }
     static constexpr int base = 2 * NB + PASS;               // desc index of the first trunk layer
+    static constexpr int L_ident = 2 * NB;                   // (PASS) desc index of the frozen identity layer
     static constexpr int n_layers = base + 6;                // layers of the vf_mlp_desc this class matches
     static constexpr int n_exec = 2 * NB + (VF ? 6 : 3);     // layers the kernel runs (the identity layer is not one of them)
     static constexpr int L_mean = base + 2, L_value = base + 5;   // desc indices of the heads
@@ -498,7 +499,7 @@ __device__ __forceinline__ void chain_pass_tile(const ChainArgs& g, ChainState<N
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (h == 0 && k < pw) ? x[k < pw ? k : pw - 1] : 0.0f;
         t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
-        const vf_mlp_layer& D = g.d.layer[2 * N::NB];
+        const vf_mlp_layer& D = g.d.layer[N::L_ident];
         if (STORE && D.save && live && h == 0) {
             float* o = D.save + (size_t)row * D.save_ld + D.dst_col;
 #pragma unroll
@@ -696,7 +697,7 @@ __device__ __forceinline__ void chain16_pass_tile(const ChainArgs& g, ChainState
         for (int k = 0; k < 4; ++k) v[k] = (gq == 0 && k < pw) ? x[k < pw ? k : pw - 1] : 0.0f;
         st.t[2 * N::t_pass] = f32x4{v[0], v[1], v[2], v[3]};
         st.t[2 * N::t_pass + 1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const vf_mlp_layer& D = g.d.layer[2 * N::NB];
+        const vf_mlp_layer& D = g.d.layer[N::L_ident];
         if (D.save && live && gq == 0) {
             float* o = D.save + (size_t)row * D.save_ld + D.dst_col;
 #pragma unroll

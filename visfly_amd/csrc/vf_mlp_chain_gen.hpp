@@ -11,7 +11,12 @@
 //     DP, PW[j]     hidden layers of the policy trunk (>= 1), widths in tiles;   DV, VW[j]: the value trunk's
 //     VF            false: the class runs extractors + policy trunk only
 //     HM, HV        widths of the two heads: (4, 1) the PPO policies' action mean / value; (4, 4) the SAC-style Actor's mu / log_std
-//                   (utils/policies/td_policies.py:146-252: `pi` = latent_pi, `vf` = log_latent_pi)
+//                   (utils/policies/td_policies.py:146-252: `pi` = latent_pi, `vf` = log_latent_pi); (1, 1) its twin ContinuousCritic's
+//                   Q1 / Q2 (:82-143: `pi` = qf0, `vf` = qf1)
+//     PASS          1: one more input of <= 4 columns (the critic's action) is appended to the features unchanged -- th.cat([features,
+//                   actions]) (:137): one more input tile of the trunks' first layers (ChainNet::PASS); the layer table's frozen identity
+//                   layer between the extractor layers and the trunks is not executed.  Layer numbers `fl` below are MlpPolicy order
+//                   WITHOUT that layer (the numbering of the reverse chain); desc(fl) is the layer's index in the vf_mlp_desc
 // ChainNetG<Spec> / BwdProgG<..> derive from it the same layer / op tables that ChainNet / BwdProg spell out for the two-layer shapes;
 // the device code (vf_mlp_chain.hpp, vf_mlp_chain_bwd.hpp) is the same.
 #pragma once
@@ -24,7 +29,7 @@ constexpr int kGenMaxOps = 4 * kGenMaxDepth + 4;
 
 template <class S>
 struct GenShape {
-    static constexpr int NB = S::NB, DP = S::DP, DV = S::DV;
+    static constexpr int NB = S::NB, DP = S::DP, DV = S::DV, PASS = S::PASS;
     static constexpr int de(int b) { return S::DE[b]; }
     static constexpr int ew(int b, int l) { return S::EW[b][l]; }
     // forward layers in MlpPolicy order: extractor branches layer by layer, policy trunk + mean head, value trunk + value head
@@ -40,6 +45,7 @@ struct GenShape {
     static constexpr int L_vf(int j) { return L_mean() + 1 + j; }    // j == DV: the value head
     static constexpr int L_value() { return L_mean() + 1 + DV; }
     static constexpr int n_layers() { return L_value() + 1; }
+    static constexpr int desc(int fl) { return fl + (PASS && fl >= base() ? 1 : 0); }       // index in the layer table (the identity layer sits at base())
     static constexpr bool is_head(int fl) { return fl == L_mean() || fl == L_value(); }
     static constexpr int branch_of(int fl)      // -1: a trunk layer
     {
@@ -56,7 +62,9 @@ struct GenShape {
         for (int i = 0; i < b; ++i) n += ew(i, de(i) - 1);
         return n;
     }
-    static constexpr int n_feat() { return feat_off(NB); }
+    static constexpr int n_feat_b() { return feat_off(NB); }          // feature tiles the extractor branches produce
+    static constexpr int n_feat() { return feat_off(NB) + PASS; }     // input tiles of the trunks' first layers (+ the pass-through tile)
+    static constexpr int t_pass() { return t_feat() + n_feat_b(); }
     // output width of forward layer fl in tiles (heads: 1)
     static constexpr int width(int fl)
     {
@@ -65,7 +73,7 @@ struct GenShape {
         if (is_head(fl)) return 1;
         return fl < L_mean() ? S::PW[fl - base()] : S::VW[fl - L_vf(0)];
     }
-    // tiles: [extractor hidden outputs, branch by branch][feat = the branches' last outputs][pi hidden ..][mean][vf hidden ..][value]
+    // tiles: [extractor hidden outputs, branch by branch][feat = the branches' last outputs][pass][pi hidden ..][mean][vf hidden ..][value]
     static constexpr int t_feat()
     {
         int n = 0;
@@ -157,7 +165,7 @@ struct GenLayerTable {
         for (int i = 0; i < r.n; ++i) {
             const int fl = Shape::exec_desc(i, VF);
             const int b = Shape::branch_of(fl);
-            r.l[i] = ChainLayer{fl, Shape::producer(fl) == -1 ? b : -1, Shape::in_tile(fl), Shape::in_tiles(fl), Shape::tile_of_layer(fl),
+            r.l[i] = ChainLayer{Shape::desc(fl), Shape::producer(fl) == -1 ? b : -1, Shape::in_tile(fl), Shape::in_tiles(fl), Shape::tile_of_layer(fl),
                                 Shape::width(fl), Shape::act_of(fl)};
             r.first[i + 1] = r.first[i] + (r.l[i].obs >= 0 ? r.l[i].nin : r.l[i].nin * 4) * r.l[i].nout;
         }
@@ -180,18 +188,19 @@ struct ChainNetG {
     using Spec = S;
     template <bool PI, bool VF2, bool IG>
     using Bwd = BwdProgG<ChainNetG, PI, VF2, IG>;
-    static constexpr int NB = S::NB, HV = S::HV, HM = S::HM, PASS = 0;       // heads (4, 1): actor-critic; (4, 4): the SAC-style Actor (mu / log_std)
-    static_assert(HM == 4 && (HV == 1 || HV == 4), "heads");
+    static constexpr int NB = S::NB, HV = S::HV, HM = S::HM, PASS = S::PASS;   // heads (4, 1): actor-critic; (4, 4): the SAC-style Actor (mu / log_std); (1, 1) + PASS: its twin critic
+    static_assert((HM == 4 && (HV == 1 || HV == 4) && PASS == 0) || (HM == 1 && HV == 1 && PASS == 1), "heads");
     static constexpr bool VF = S::VF;
     static_assert(NB >= 1 && NB <= 2 && S::DP >= 1 && S::DV >= 1 && S::DP <= kGenMaxDepth && S::DV <= kGenMaxDepth, "shape");
     static constexpr int kin(int b) { return S::KIN[b]; }
-    static constexpr int base = Shape::base();
-    static constexpr int n_layers = Shape::n_layers();
-    static constexpr int L_mean = Shape::L_mean(), L_value = Shape::L_value();
-    static constexpr int n_exec = VF ? n_layers : L_mean + 1;
+    static constexpr int base = Shape::base() + PASS;            // layer-table index of the first trunk layer
+    static constexpr int n_layers = Shape::n_layers() + PASS;    // layers of the vf_mlp_desc this class matches
+    static constexpr int L_ident = Shape::base();                // (PASS) layer-table index of the frozen identity layer
+    static constexpr int L_mean = Shape::desc(Shape::L_mean()), L_value = Shape::desc(Shape::L_value());      // layer-table indices of the heads
+    static constexpr int n_exec = VF ? Shape::n_layers() : Shape::L_mean() + 1;     // layers the kernel runs
     static constexpr int t_feat = Shape::t_feat(), n_feat = Shape::n_feat();
-    static constexpr int t_pass = 0;
-    static constexpr int t_mean = Shape::tile_of_layer(L_mean), t_val = Shape::tile_of_layer(L_value);
+    static constexpr int t_pass = Shape::t_pass();
+    static constexpr int t_mean = Shape::tile_of_layer(Shape::L_mean()), t_val = Shape::tile_of_layer(Shape::L_value());
     static constexpr int n_tiles = Shape::n_tiles();
     static constexpr GenLayers tab = GenLayerTable<S, S::VF, PACK>::make();
     static constexpr bool pack_or = PACK;
@@ -250,7 +259,7 @@ struct BwdGenTable {
                 }
                 if (Sh::producer(fl) == -2) {           // a trunk's first layer: its data gradient is (part of) the feature gradient
                     o.out0 = Sh::t_feat();
-                    o.nout = Sh::n_feat();
+                    o.nout = Sh::n_feat_b();              // (the pass-through columns' gradient is not formed: a critic update does not need it)
                     o.accum = seen > 0 ? 1 : 0;
                     ++seen;
                     o.nfin = 0;
@@ -319,22 +328,22 @@ struct BwdProgG {
     static_assert(PI || VF, "a reverse chain needs a head gradient");
     static constexpr int NB = N::NB;
     static constexpr bool sac_head = PI && VF && N::HV == 4 && N::HM == 4;     // td_policies.Actor: both heads' gradients can come from d_action (BwdProg)
-    static constexpr int L_mean = N::L_mean, L_val = N::L_value;
+    static constexpr int L_mean = Sh::L_mean(), L_val = Sh::L_value();       // (MlpPolicy order without the identity layer)
     static constexpr int n_tiles = N::n_tiles + NB;
     static constexpr GenOps tab = Tab::make();
     static constexpr int n_ops = tab.n;
     static constexpr int n_ym = tab.n_ym;
-    static constexpr bool included(int l) { return l < N::base || (l <= N::L_mean ? PI : VF); }
+    static constexpr bool included(int l) { return l < Sh::base() || (l <= Sh::L_mean() ? PI : VF); }
     static constexpr int n_entries()
     {
         int e = 0;
-        for (int l = 0; l < N::n_layers; ++l) e += included(l) ? 1 : 0;
+        for (int l = 0; l < Sh::n_layers(); ++l) e += included(l) ? 1 : 0;
         return e;
     }
     static constexpr int entry(int fl)
     {
         int e = 0;
-        for (int l = fl + 1; l < N::n_layers; ++l) e += included(l) ? 1 : 0;
+        for (int l = fl + 1; l < Sh::n_layers(); ++l) e += included(l) ? 1 : 0;
         return e;
     }
     static constexpr BwdOp op(int i) { return tab.op[i]; }
@@ -354,28 +363,38 @@ template <class N>
 bool chain_matches_gen(const vf_mlp_desc& d)
 {
     using Sh = typename N::Shape;
-    if (d.n_layers != N::n_layers || d.n_inputs != N::NB || d.identity_mask) return false;
+    if (d.n_layers != N::n_layers || d.n_inputs != N::NB + N::PASS) return false;
     for (int b = 0; b < N::NB; ++b)
         if (d.in_dim[b] < 1 || ((d.in_dim[b] + 7) & ~7) != N::kin(b)) return false;
     const int fid = d.layer[Sh::ext(0, Sh::de(0) - 1)].dst;
-    for (int fl = 0; fl < N::n_layers; ++fl) {
-        const vf_mlp_layer& L = d.layer[fl];
+    int pw = 0;
+    if constexpr (N::PASS) {      // the frozen identity layer: input NB, <= 4 columns, appended to the features, declared in identity_mask (chain_matches)
+        const vf_mlp_layer& I = d.layer[N::L_ident];
+        pw = d.in_dim[N::NB];
+        if (pw < 1 || pw > 4 || I.K != pw || I.No != pw || I.relu || I.src != N::NB || I.src_col != 0 || I.dst != fid || I.dst_col != 32 * Sh::n_feat_b()) return false;
+        if (d.identity_mask != (1 << N::L_ident)) return false;
+        if (I.save && ((I.save_ld & 3) || (I.dst_col & 3))) return false;
+    } else if (d.identity_mask) {
+        return false;
+    }
+    for (int fl = 0; fl < Sh::n_layers(); ++fl) {
+        const vf_mlp_layer& L = d.layer[Sh::desc(fl)];
         const int b = Sh::branch_of(fl), p = Sh::producer(fl);
-        const int K = p == -1 ? d.in_dim[b] : 32 * Sh::in_tiles(fl);
-        const int No = fl == N::L_mean ? N::HM : fl == N::L_value ? N::HV : 32 * Sh::width(fl);
+        const int K = p == -1 ? d.in_dim[b] : p == -2 ? 32 * Sh::n_feat_b() + pw : 32 * Sh::in_tiles(fl);
+        const int No = fl == Sh::L_mean() ? N::HM : fl == Sh::L_value() ? N::HV : 32 * Sh::width(fl);
         if (L.K != K || L.No != No || L.relu != Sh::act_of(fl) || L.wr_off < 0 || (L.wr_off & 3)) return false;
         if (p == -1) {
             if (L.src != b || L.src_col != 0) return false;
         } else if (p == -2) {
             if (L.src != fid || L.src_col != 0) return false;
-        } else if (L.src != d.layer[p].dst || L.src_col != d.layer[p].dst_col) {
+        } else if (L.src != d.layer[Sh::desc(p)].dst || L.src_col != d.layer[Sh::desc(p)].dst_col) {
             return false;
         }
         if (b >= 0 && fl == Sh::ext(b, Sh::de(b) - 1) && (L.dst != fid || L.dst_col != 32 * Sh::feat_off(b))) return false;
         if (b >= 0 && fl != Sh::ext(b, Sh::de(b) - 1) && L.dst_col != 0) return false;
         if (b < 0 && !Sh::is_head(fl) && L.dst_col != 0) return false;
-        if (fl == N::L_mean && L.dst != VF_MLP_OUT0) return false;
-        if (fl == N::L_value && L.dst != VF_MLP_OUT1) return false;
+        if (fl == Sh::L_mean() && L.dst != VF_MLP_OUT0) return false;
+        if (fl == Sh::L_value() && L.dst != VF_MLP_OUT1) return false;
         if (L.save && ((L.save_ld & 3) || (L.dst_col & 3) || (reinterpret_cast<uintptr_t>(L.save) & 15))) return false;
     }
     return true;
@@ -388,7 +407,7 @@ bool bwd_chain_matches_gen(const vf_mlp_bwd_desc& d, bool ig)
     using Sh = typename N::Shape;
     if (d.n_layers != P::n_entries()) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    for (int fl = 0; fl < N::n_layers; ++fl) {
+    for (int fl = 0; fl < Sh::n_layers(); ++fl) {
         if (!P::included(fl)) continue;
         const vf_mlp_bwd_layer& E = d.layer[P::entry(fl)];
         const int b = Sh::branch_of(fl), p = Sh::producer(fl);
@@ -396,10 +415,12 @@ bool bwd_chain_matches_gen(const vf_mlp_bwd_desc& d, bool ig)
         if (p == -1) {
             if (E.K < 1 || ((E.K + 7) & ~7) != N::kin(b)) return false;
             if ((E.need_dx != 0) != ig) return false;
+        } else if (p == -2 && N::PASS) {      // features (+) pass-through columns: K = feat + pw, pw = 1 .. 4 (bwd_chain_matches)
+            if (E.K <= 32 * Sh::n_feat_b() || E.K > 32 * Sh::n_feat_b() + 4 || E.need_dx == 0) return false;
         } else {
             if (E.K != 32 * Sh::in_tiles(fl) || E.need_dx == 0) return false;
         }
-        const int No = fl == N::L_mean ? N::HM : fl == N::L_value ? N::HV : 32 * Sh::width(fl);
+        const int No = fl == Sh::L_mean() ? N::HM : fl == Sh::L_value() ? N::HV : 32 * Sh::width(fl);
         if (E.No != No || (E.Y != nullptr) != relu || E.wq_off < 0 || (E.wq_off & 3)) return false;
         if (relu && (E.act ? E.act : VF_ACTIVATION_RELU) != Sh::act_of(fl)) return false;
         if (relu && (!al16(E.Y) || (E.ld_y & 3) || !al16(E.dY) || (E.ld_dy & 3))) return false;

@@ -177,6 +177,69 @@ __global__ __launch_bounds__(64) void k_ppo_update_chain(const ChainArgs g, cons
     bwd_tail_store<P>(gb, bs, row, h, live);
 }
 
+// ------------------------------------------------------------------------------------------------
+// One critic update of SHAC (shac.py:267-270), everything that is per-row in ONE launch: forward chain of the twin critic ->
+// mse_loss(returns, min(Q1, Q2)) of the wave's 32 rows and its gradient w.r.t. the two heads (k_twin_q_loss's arithmetic; the head
+// outputs never leave the registers) -> reverse chain, whose ReLU masks are the forward's own accumulator tiles (still live), so the
+// saved activations are not read back: k_ppo_update_chain's scheme for the critic class.  Left in HBM for the weight-gradient launch:
+// the layer inputs X, the masked gradients dZ, dQ1 / dQ2; per wave one fp64 partial of the squared error (k_twin_q_fold).
+// ------------------------------------------------------------------------------------------------
+template <class N>
+__global__ __launch_bounds__(64) void k_twin_q_update_chain(const ChainArgs g, const BwdArgsChain gb, const float* __restrict__ target,
+                                                            double* __restrict__ part, float scale)
+{
+    using P = typename N::template Bwd<true, true, false>;
+    prefetch_kernarg<sizeof(ChainArgs) + sizeof(BwdArgsChain) + 24>();
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int row = blockIdx.x * 32 + m;
+    const bool live = row < g.M;
+    const int rc = live ? row : g.M - 1;
+    ChainState<N> fs;
+    if constexpr (N::pack_or) {
+#pragma unroll
+        for (int i = 0; i < N::n_mb; ++i) fs.mb[i] = 0u;
+    }
+    chain_prologue<N, 0>(g, fs, lane);
+#pragma unroll
+    for (int b = 0; b < N::NB; ++b) {
+        const int w = g.d.in_dim[b];
+        const float* x = g.io.in[b] + (size_t)rc * w;
+#pragma unroll
+        for (int s = 0; s < N::kin(b) / 2; ++s) {
+            const int k = 2 * s + h;
+            const float v = x[k < w ? k : w - 1];
+            fs.x[b][s] = k < w ? v : 0.0f;
+        }
+    }
+    chain_pass_tile<N>(g, fs, row, rc, h, live);
+    const float tgt = target[rc];                       // issued before the forward so that it has arrived when the forward ends
+    chain_items<N, 0>(g, fs, lane, row, live, rc);
+    BwdState<P> bs;
+    bwd_prologue<P, 0>(gb, bs, lane);                  // first weight blocks of the reverse chain: in flight during the loss arithmetic
+    // ---- loss of this lane's row (lane half 0 holds Q1 / Q2 in register 0 of the head tiles) ----
+    const float q0 = fs.t[N::t_mean][0], q1 = fs.t[N::t_val][0];
+    const bool first = q0 <= q1;                       // ties: the first, like torch.min over dim 1
+    const float diff = (first ? q0 : q1) - tgt;
+    const float gq = 2.0f * diff * scale;
+    // head gradients: lane half 0 of EVERY lane -- lanes past the last row are replicas of row M - 1 and stay replicas through the
+    // reverse chain, whose dZ stores are unguarded (k_ppo_update_chain); only the partial sum and the head rows exclude them
+    const float dq0 = h == 0 ? (first ? gq : 0.0f) : 0.0f, dq1 = h == 0 ? (first ? 0.0f : gq) : 0.0f;
+    double sq = (live && h == 0) ? (double)diff * (double)diff : 0.0;
+    if (live && h == 0) {                               // dZ of the head layers for the weight-gradient kernel
+        const vf_mlp_bwd_layer& E0 = gb.d.layer[P::entry(P::L_mean)];
+        const vf_mlp_bwd_layer& E1 = gb.d.layer[P::entry(P::L_val)];
+        const_cast<float*>(E0.dY)[(size_t)row * E0.ld_dy] = dq0;
+        const_cast<float*>(E1.dY)[(size_t)row * E1.ld_dy] = dq1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+    if (lane == 0) part[blockIdx.x] = sq;
+    bs.hin[0][0] = dq0; bs.hin[0][1] = 0.0f; bs.hin[0][2] = 0.0f; bs.hin[0][3] = 0.0f;
+    bs.hin[1][0] = dq1; bs.hin[1][1] = 0.0f; bs.hin[1][2] = 0.0f; bs.hin[1][3] = 0.0f;
+    bwd_items<P, ChainState<N>, 0>(gb, bs, fs, lane, row, rc, live);
+    bwd_tail_store<P>(gb, bs, row, h, live);
+}
+
 // does the layer table describe network class N (shapes, wiring, execution order of MlpPolicy)?
 template <class N>
 bool chain_matches(const vf_mlp_desc& d)

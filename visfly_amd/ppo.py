@@ -174,7 +174,8 @@ class MlpPolicy:
         self._plan = self._plan_fused()
         self._descs = {}
         # chain kernels of a shape the library holds no instance of: compiled on first use (visfly_amd/_jit.py)
-        # (heads (4, 1) with the log_std parameter: the PPO policies' actor-critic; (4, 4) without: the SAC-style Actor of BPTT / SHAC)
+        # (heads (4, 1) with the log_std parameter: the PPO policies' actor-critic; (4, 4) without: the SAC-style Actor of BPTT / SHAC;
+        # (1, 1) without, behind a pass-through action input: its twin critic)
         self.chain_shape = (_jit.shape_of(self.obs_dims, extractor, pi, vf, self.head_dims, self.passthrough, acts=(self.act, self.ext_act))
                             if bool(log_std_param) == (self.head_dims == (4, 1)) else None)
         self.chain_jit = False
