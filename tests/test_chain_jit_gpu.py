@@ -271,7 +271,7 @@ def test_saved_activations_of_cold_launches(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [1, 33, 777, 16384])
 @pytest.mark.parametrize("ig", [True, False])
-@pytest.mark.parametrize("name", ["sac_nav", "sac_hover"])
+@pytest.mark.parametrize("name", ["sac_nav", "sac_hover", "sac_nav_bptt"])
 def test_generated_sac_actor_vs_torch_and_block_tile_kernel(name, ig, M):
     """the reference's SAC-style Actor (utils/policies/td_policies.py:146-252: latent_pi -> mu, log_latent_pi -> log_std, two 4-wide heads; the
     actor of its BPTT and SHAC loops) on a NON-default shape: generated class, forward + reverse chain of both trunks with / without the
@@ -417,7 +417,7 @@ def test_generated_fused_critic_step_equals_the_three_launch_step(name, M):
 @pytest.mark.gpu
 def test_shac_with_a_non_default_net_arch_runs_its_critic_on_chain_kernels():
     """SHAC(net_arch=dict(pi=[32], qf=[32])) over a [64, 64, 32] extractor: actor AND twin critic have generated chain classes -- the critic
-    updates are the plugin's fused step (no block-tile fallback warning from vf_twin_q_update), and the critic loss falls over an iteration"""
+    updates are the plugin's fused step (no block-tile fallback warning from vf_twin_q_update), the horizons the actor class's persistent launches"""
     from visfly_amd import _lib
     from visfly_amd.shac import SHAC
     from visfly_amd.envs import HoverEnv2
@@ -437,16 +437,16 @@ def test_shac_with_a_non_default_net_arch_runs_its_critic_on_chain_kernels():
         torch.cuda.synchronize()
     assert lib.vf_chain_plugin_launches() - n0 >= 2 * algo.gradient_steps
     assert algo.critic._fused_twin_q is not False
-    bad = [str(x.message) for x in w if "vf_twin_q_update" in str(x.message) or "block-tile" in str(x.message)]
-    assert not bad, bad
+    bad = [str(x.message) for x in w if "vf_twin_q_update" in str(x.message) or "block-tile" in str(x.message) or "falling back" in str(x.message)]
+    assert not bad, bad           # (r06: the horizon too -- the actor's persistent launches come from its BPTT plugin)
     env.close()
 
 
 @pytest.mark.gpu
 def test_bptt_with_the_reference_actor_on_a_non_default_shape_runs_on_chain_kernels():
-    """BPTT(policy="MultiInputPolicy") -- the reference's own actor -- with a non-default `net_arch`: the per-step forward / reverse chains
-    come from the generated class (the persistent launches are built-in classes only: one warning says so), and one update's gradient
-    equals the block-tile kernels' (plugins switched off) to fp32 summation order"""
+    """BPTT(policy="MultiInputPolicy") -- the reference's own actor -- with a non-default `net_arch`: forward / reverse chains come from
+    the generated class (r06: inside the class's own persistent launches -- no fallback warning), and one update's gradient equals the
+    block-tile kernels' (plugins switched off: launch by launch) to fp32 summation order"""
     from visfly_amd import _lib
     from visfly_amd.bptt import BPTT
     from visfly_amd.envs import HoverEnv
@@ -459,17 +459,128 @@ def test_bptt_with_the_reference_actor_on_a_non_default_shape_runs_on_chain_kern
         lib.vf_chain_plugin_set_enabled(on)
         env = HoverEnv(num_agent_per_scene=2048, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, tensor_output=True, max_episode_steps=64)
         n0 = lib.vf_chain_plugin_launches()
-        with warnings.catch_warnings(record=True):
+        with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             algo = BPTT(env, policy="MultiInputPolicy", policy_kwargs=pk, horizon=8, learning_rate=1e-3, seed=1)
             algo._grad_reverse_sweep()
         torch.cuda.synchronize()
-        assert (lib.vf_chain_plugin_launches() - n0 >= 16) == bool(on), "8 forwards + 8 reverse chains from the plugin"
+        if on:
+            assert lib.vf_chain_plugin_launches() - n0 == 2, "one persistent roll-out + one persistent reverse sweep from the BPTT plugin"
+            assert not [str(x.message) for x in w if "falling back" in str(x.message)], [str(x.message) for x in w]
+        else:
+            assert lib.vf_chain_plugin_launches() == n0
         grads.append(algo.policy.grad.clone())
         env.close()
     lib.vf_chain_plugin_set_enabled(1)
     scale = grads[1].abs().max().item()
     assert scale > 0 and (grads[0] - grads[1]).abs().max().item() <= 2e-5 * scale
+
+
+def _bptt_env(kind, N):
+    import visfly_amd.envs as E
+    from _golden import ENV_DYN
+    spawn = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"mean": [1., 0., 1.5], "half": [0., 2., 1.]}}]}}
+    if kind == "nav":
+        return E.NavigationEnv(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=7, requires_grad=True,
+                               tensor_output=True, random_kwargs=spawn)
+    dkw = dict(ENV_DYN, action_type="thrust") if kind == "hover_thrust" else dict(ENV_DYN)
+    return E.HoverEnv(num_agent_per_scene=N, seed=5, dynamics_kwargs=dkw, device=DEV, max_episode_steps=7, requires_grad=True, tensor_output=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1000, 4096])
+@pytest.mark.parametrize("kind", ["hover", "nav"])
+def test_persistent_launches_of_a_generated_reference_actor_equal_the_loop(kind, N):
+    """r06: BPTT(policy="MultiInputPolicy", net_arch=non-default) on the persistent launches of its GENERATED actor
+    class (the BPTT plugin: k_bptt_rollout / k_bptt_reverse instances for ChainNetG<Spec>, 16 agents per wave) against the launch-by-launch
+    sweep on the same class (plugin forward / reverse chains with the same rows-per-wave choice): actions, both heads, every saved
+    activation and masked gradient of every slot, tape, done flags, adjoint slab, loss, flat gradient and the parameters after two updates
+    are bit-identical (test_persistent_launches_with_the_reference_actor_equal_the_loop for the built-in classes)"""
+    from visfly_amd import _jit, _lib
+    from visfly_amd.bptt import BPTT
+    lib = _lib.lib()
+    H = 10
+    name = "sac_nav_bptt" if kind == "nav" else "sac_hover"
+    dims, ext, pi, vf, heads = _jit.PREBUILD_SAC[name]
+    pk = dict(features_extractor_class="StateTargetExtractor" if kind == "nav" else "StateExtractor",
+              features_extractor_kwargs={"net_arch": {k: {"layer": list(v)} for k, v in ext.items()}},
+              net_arch=dict(pi=list(pi), qf=[64, 64]), activation_fn="relu", share_features_extractor=False)
+    res = []
+    for fused in (True, False):
+        env = _bptt_env(kind, N)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            algo = BPTT(env, policy="MultiInputPolicy", policy_kwargs=pk, horizon=H, learning_rate=1e-3, seed=9)
+            assert algo.reference_actor and tuple(algo.policy.head_dims) == (4, 4) and algo.policy.chain_jit
+            assert algo.policy.chain_shape == _jit.shape_of(dims, ext, pi, vf, heads)
+            algo.fused_rollout = algo.fused_reverse = fused
+            used, rev_used = [], []
+            orig, orig_rev = env.rollout_policy, env.reverse_policy
+            env.rollout_policy = lambda *a, **k: used.append(orig(*a, **k)) or used[-1]
+            env.reverse_policy = lambda *a, **k: rev_used.append(orig_rev(*a, **k)) or rev_used[-1]
+            out = {}
+            blk_names = None
+            for it in range(2):
+                n0 = lib.vf_chain_plugin_launches()
+                loss = algo._grad_reverse_sweep()
+                torch.cuda.synchronize()
+                assert lib.vf_chain_plugin_launches() - n0 == (2 if fused else 2 * H), "every policy pass came from the plugins"
+                out[f"loss{it}"] = loss.clone()
+                out[f"grad{it}"] = algo.policy.grad.clone()
+                out[f"action{it}"] = algo._last_rollout["action"].clone()
+                out[f"done{it}"] = algo._last_rollout["done"].clone().bool()
+                live = lambda x: x.transpose(-3, -4).reshape(*x.shape[:-4], x.shape[-3], -1, 4)[..., :N, :].clone()
+                out[f"tape{it}"] = live(env._tape[:H])
+                out[f"slab{it}"] = live(env._slab)
+                out[f"adj{it}"] = live(env._adj)
+                out[f"obs{it}"] = env.get_observation()["state"].clone()
+                blk = algo.policy._slot_blocks[N][1]
+                blk_names = [k for k, v in blk.items() if isinstance(v, torch.Tensor) and k.split(":")[0] in ("obs", "x", "feat", "pi", "vf", "mean", "value", "g")]
+                for k in blk_names:
+                    out[f"{k}{it}"] = blk[k][:H].clone()
+                algo._apply(loss)
+            out["flat"] = algo.policy.flat.clone()
+        assert used == ([True, True] if fused else []) and rev_used == used, (used, rev_used, [str(x.message) for x in w])
+        assert not [str(x.message) for x in w if "falling back" in str(x.message)], [str(x.message) for x in w]
+        assert any(k.startswith("g:") for k in blk_names) and any(k.startswith("pi:") for k in blk_names)
+        res.append(out)
+        env.close()
+    assert bool(res[0]["done0"].any()), "no episode ended inside the horizon"
+    assert float(res[0]["grad0"].abs().max()) > 0 and float(res[0]["value0"].abs().max()) > 0
+    for k in res[0]:
+        a, b = res[0][k], res[1][k]
+        same = torch.equal(a, b) if a.dtype == torch.bool else torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert same, f"{kind}: {k} differs (max abs {float((a.float() - b.float()).abs().max()):.3e})"
+
+
+@pytest.mark.gpu
+def test_persistent_launches_of_a_generated_mlp_policy_actor_equal_the_loop():
+    """... and BPTT's own MlpPolicy actor (state-independent log_std) on a non-default shape: the horizon steps the generated POLICY-ONLY
+    class with the action head (16 rows per wave), persistent launches from the BPTT plugin == the launch-by-launch loop, bit for bit"""
+    from visfly_amd import _jit, _lib
+    from visfly_amd.bptt import BPTT
+    lib = _lib.lib()
+    dims, ext, pi, vf = SHAPES["one_layer_extractor"]
+    N, H = 2000, 8
+    res = []
+    for fused in (True, False):
+        env = _bptt_env("hover_thrust", N)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            algo = BPTT(env, horizon=H, learning_rate=1e-3, seed=3,
+                        policy_kwargs=dict(features_extractor_kwargs={"net_arch": {"state": {"layer": list(ext["state"])}}},
+                                           net_arch=dict(pi=list(pi), vf=list(vf)), activation_fn="relu"))
+            assert not algo.reference_actor and algo.policy.chain_jit and algo.policy.chain_shape == _jit.shape_of(dims, ext, pi, vf)
+            algo.fused_rollout = algo.fused_reverse = fused
+            n0 = lib.vf_chain_plugin_launches()
+            algo.learn(3 * H * N)
+            torch.cuda.synchronize()
+            assert lib.vf_chain_plugin_launches() - n0 == 3 * (2 if fused else 2 * H)
+        assert not [str(x.message) for x in w if "falling back" in str(x.message)], [str(x.message) for x in w]
+        res.append((algo.policy.flat.clone(), algo.policy.grad.clone()))
+        env.close()
+    assert float(res[0][1].abs().max()) > 0
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
 @pytest.mark.gpu

@@ -32,6 +32,8 @@ _HEADERS = ("vf_mlp_chain.hpp", "vf_mlp_chain_bwd.hpp", "vf_mlp_chain_kernels.hp
             "vf_common.hpp", "vf_ppo_device.hpp")
 _ROLLOUT_HEADERS = ("vf_ppo_rollout_kernel.hpp", "vf_env_epilogue.hpp", "vf_env_device.hpp", "vf_dyn_device.hpp", "vf_xmath.hpp",
                     "vf_quad.hpp", "vf_handles.hpp")
+_BPTT_HEADERS = _ROLLOUT_HEADERS[1:] + ("vf_bptt_rollout_kernel.hpp", "vf_bptt_reverse_kernel.hpp", "vf_env_bwd_body.hpp", "vf_env_bwd_quad.hpp",
+                                        "vf_dyn_quad.hpp")
 _loaded = {}
 # shapes compiled ahead of time by __graft_entry__.build() (name -> observation widths, extractor layers, pi, vf): the ones the parity
 # tests run (tests/test_chain_jit_gpu.py), so that a GPU box without a warm cache finds them in the snapshot
@@ -58,8 +60,12 @@ PREBUILD_CRITIC = {
 PREBUILD_SAC = {
     "sac_nav": ({"state": 13, "target": 3}, {"state": [128, 64], "target": [64]}, [128, 64], [64], (4, 4)),
     "sac_hover": ({"state": 13}, {"state": [64, 64, 32]}, [32], [32], (4, 4)),      # (the Actor BPTT builds for pi=[32]: log_latent_pi mirrors latent_pi)
+    "sac_nav_bptt": ({"state": 13, "target": 3}, {"state": [64, 64], "target": [32]}, [64], [64], (4, 4)),      # ... over StateTargetExtractor, pi=[64]
 }
 # ... and their roll-out plugins for the configurations tests/test_ppo_gpu.py runs: (shape name, (VF_ENV_*, VF_ACT_*, VF_INT_*, ctrl_delay))
+# ... and the BPTT plugins (both persistent launches of a horizon) tests/test_chain_jit_gpu.py runs: (shape name in PREBUILD_SAC / PREBUILD,
+# (kernel-side env kind, VF_ACT_*, VF_INT_*, ctrl_delay))
+PREBUILD_BPTT = [("sac_hover", (0, 1, 0, True)), ("sac_nav_bptt", (1, 1, 0, True)), ("one_layer_extractor", (0, 0, 0, True))]
 PREBUILD_ROLLOUT = [("verdict", (1, 1, 0, True)), ("one_layer_extractor", (0, 1, 1, False)), ("one_layer_extractor", (1, 1, 0, True))]
 
 
@@ -160,17 +166,41 @@ VF_CHAIN_PLUGIN_ROLLOUT_DEFINE(Net, {int(kind)}, {int(act)}, {int(integ)}, {"tru
 """
 
 
+def bptt_source(shape, cfg):
+    """the BPTT plugin of `shape` (an actor class: the SAC-style Actor, or an actor-critic whose policy-only class the horizon steps) under
+    cfg = (KERNEL-side env kind, action type, integrator, ctrl_delay): ONE instance each of the two persistent launches of a horizon
+    (csrc/vf_bptt_rollout_kernel.hpp, csrc/vf_bptt_reverse_kernel.hpp), compiled as parts 5 / 6 (+ 7: the table)"""
+    kind, act, integ, delay = cfg
+    return source(shape) + f"""#if VF_CHAIN_PLUGIN_PART != 6
+#include "vf_bptt_rollout_kernel.hpp"
+#endif
+#if VF_CHAIN_PLUGIN_PART != 5
+#include "vf_bptt_reverse_kernel.hpp"
+#endif
+VF_CHAIN_PLUGIN_BPTT_DEFINE(Net, NetPi, {int(kind)}, {int(act)}, {int(integ)}, {"true" if delay else "false"}, "{name_of(shape)} BPTT horizon kind {int(kind)} act {int(act)} int {int(integ)} delay {int(bool(delay))}")
+"""
+
+
 def _flags():
     extra = os.environ.get("VISFLY_AMD_JIT_FLAGS", "").split()       # e.g. -DVF_GEN_LIVE_TILES=0 (A/B builds; part of the cache key)
     return [f for f in HIPCC_FLAGS if f not in ("-shared", "-Wall")] + ["-ftemplate-depth=4096", "-Wno-unused-const-variable"] + extra + [
         "-I", INCLUDE, "-I", CSRC]
 
 
+def _is_bptt(rollout):
+    return rollout is not None and rollout[0] == "bptt"
+
+
+def _source_of(shape, rollout):
+    """rollout: None (the chain plugin), (kind, act, integ, delay) (PPO's roll-out plugin) or ("bptt", kind, act, integ, delay)"""
+    return source(shape) if rollout is None else bptt_source(shape, rollout[1:]) if _is_bptt(rollout) else rollout_source(shape, rollout)
+
+
 def _key(shape, rollout=None):
     h = hashlib.sha256()
-    h.update((source(shape) if rollout is None else rollout_source(shape, rollout)).encode())
+    h.update(_source_of(shape, rollout).encode())
     h.update(" ".join(_flags()[:-4]).encode())
-    for n in _HEADERS + (() if rollout is None else _ROLLOUT_HEADERS) + (os.path.join(INCLUDE, "visfly_amd.h"),):
+    for n in _HEADERS + (() if rollout is None else _BPTT_HEADERS if _is_bptt(rollout) else _ROLLOUT_HEADERS) + (os.path.join(INCLUDE, "visfly_amd.h"),):
         with open(n if os.path.isabs(n) else os.path.join(CSRC, n), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -182,6 +212,8 @@ def _slug(shape, rollout=None):
     s = "e" + "_".join(f"{k}x{t(e)}" for k, e in zip(kin, ew)) + f"_p{t(pw)}_v{t(vw)}" + {(4, 4): "_h44", (1, 1): "_h11", (4, 1): ""}[_heads(shape)]
     if _acts(shape) != (1, 1):
         s += "_a%d%d" % _acts(shape)
+    if _is_bptt(rollout):
+        return s + "_bptt" + "".join(str(int(x)) for x in rollout[1:])
     return s if rollout is None else s + "_roll" + "".join(str(int(x)) for x in rollout)
 
 
@@ -212,7 +244,7 @@ def build(shape, verbose=False, rollout=None):
         tmpdir = tempfile.mkdtemp(prefix="visfly_amd_jit_")
         src = os.path.join(tmpdir, "plugin.hip")
         with open(src, "w") as f:
-            f.write(source(shape) if rollout is None else rollout_source(shape, rollout))
+            f.write(_source_of(shape, rollout))
 
         def part(p):
             obj = os.path.join(tmpdir, f"part{p}.o")
@@ -225,7 +257,7 @@ def build(shape, verbose=False, rollout=None):
             return obj
 
         with ThreadPoolExecutor(max_workers=4) as pool:
-            objs = list(pool.map(part, range(4) if rollout is None else [4]))
+            objs = list(pool.map(part, range(4) if rollout is None else [5, 6, 7] if _is_bptt(rollout) else [4]))
         tmp = f"{out}.{os.getpid()}.tmp"       # private name, then rename: concurrent builders (ranks) never see a torn file
         try:
             r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp], capture_output=True, text=True)
@@ -276,12 +308,28 @@ def ensure_rollout(shape, cfg):
     return _loaded[key] is not None
 
 
+def ensure_bptt(shape, cfg):
+    """the same for the BPTT plugin (the two persistent launches of a horizon) of an actor class `shape` under cfg = (KERNEL-side env kind,
+    action type, integrator, ctrl_delay); ~2 min of hipcc on first use"""
+    if shape is None or is_builtin(shape) or _heads(shape) == (1, 1) or os.environ.get("VISFLY_AMD_JIT", "1") == "0":
+        return False
+    key = (shape, ("bptt",) + tuple(int(x) for x in cfg))
+    if key not in _loaded:
+        from . import _lib
+        _loaded[key] = None
+        path = build(shape, rollout=key[1])
+        _lib.check(_lib.lib().vf_chain_plugin_load(path.encode()))
+        _loaded[key] = path
+    return _loaded[key] is not None
+
+
 def prebuild(verbose=False):
     """compile the PREBUILD shapes (in parallel) -> paths"""
     act = [shape_of(*v[:5], acts=v[5]) for v in PREBUILD_ACT.values()]
     jobs = ([(shape_of(*v), None) for v in list(PREBUILD.values()) + list(PREBUILD_SAC.values()) + list(PREBUILD_CRITIC.values())] +
             [(sh, None) for sh in act] +
-            [(shape_of(*PREBUILD[n]), cfg) for n, cfg in PREBUILD_ROLLOUT] + [(act[0], (1, 1, 0, True))])        # + the Tanh policy's roll-out on NavigationEnv
+            [(shape_of(*PREBUILD[n]), cfg) for n, cfg in PREBUILD_ROLLOUT] + [(act[0], (1, 1, 0, True))] +       # + the Tanh policy's roll-out on NavigationEnv
+            [(shape_of(*{**PREBUILD, **PREBUILD_SAC}[n]), ("bptt",) + cfg) for n, cfg in PREBUILD_BPTT])
     # every chain job runs four hipcc parts of fully unrolled kernels: bound the number in flight by the cores of the build box
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), (os.cpu_count() or 4) // 4))) as pool:
         paths = list(pool.map(lambda j: build(j[0], verbose, rollout=j[1]), jobs))

@@ -11,6 +11,7 @@
 //     the slot's dZ buffers for the horizon-wide weight-gradient launch, dLoss/d observation for the next adjoint step;
 // d_action and the observation gradient travel through per-step rows of scratch (the same wave reads what it wrote).
 // Bit-identical to the launch-by-launch sweep (tests/test_bptt_gpu.py).
+#include "vf_chain_plugin.hpp"
 #include "vf_bptt_reverse_kernel.hpp"
 
 extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const float* packed, const float* log_std, const float* eps,
@@ -35,9 +36,10 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
         return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: H x N rows of layer gradients pass 4 GiB per buffer");
     // rows per wave: the choice vf_mlp_backward_data makes for N rows, so that the sweep equals the launch-by-launch one to the bit
     const int cls = vf::bwd_chain_policy_class(desc, N), net = cls & 15;
-    if (net == 0) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: the policy's layer table is not one of the built-in register-chained classes");
-    const bool r16 = (cls & 16) != 0;
-    const bool sac = net >= 3;          // td_policies.Actor: both head gradients come from d_action and the saved log_std rows
+    // net == 0: not a built-in class -- a generated one runs from its BPTT plugin below (16 agents per wave with the sub-step tape only);
+    // its caller says which head form it has by the rows it passes
+    const bool r16 = net ? (cls & 16) != 0 : N <= 16384;
+    const bool sac = net ? net >= 3 : log_std_rows != nullptr;          // td_policies.Actor: both head gradients come from d_action and the saved log_std rows
     if (sac ? !log_std_rows : (!log_std || !g_log_std))
         return vf::fail(VF_EINVAL, sac ? "vf_bptt_reverse: log_std_rows (H N, 4) is required for the two-headed actor classes"
                                        : "vf_bptt_reverse: log_std / g_log_std are required for the state-independent-log_std classes");
@@ -49,14 +51,18 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
     vf::RevKernel k = nullptr;
     const bool race2 = h->cfg.kind == VF_ENV_RACING && h->cfg.obs_mode == VF_OBS_RACE2;      // RacingEnv2: 16 gate-relative columns
     const int OW = race2 ? 16 : 13;
-    if (race2) k = vf::pick_rev_race2(net, r16, h->dyn.cfg, ckpt);
+    if (net == 0) k = nullptr;
+    else if (race2) k = vf::pick_rev_race2(net, r16, h->dyn.cfg, ckpt);
     else if ((net == 1 || net == 3) && h->cfg.kind == VF_ENV_NAV) k = vf::pick_rev_nav2(net, r16, h->dyn.cfg, ckpt);
     else if (!h->dyn.cfg.ctrl_delay) k = vf::pick_rev_nodelay(net, r16, h->cfg.kind, h->dyn.cfg, ckpt);
     else if (sac) k = r16 ? vf::pick_rev_sac(net, h->cfg.kind, h->dyn.cfg, ckpt) : vf::pick_rev_sac32(net, h->cfg.kind, h->dyn.cfg);
     else if (net == 1 && h->cfg.kind == VF_ENV_HOVER) k = r16 ? vf::pick_rev<vf::NetHover, 16, VF_ENV_HOVER>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetHover, 32, VF_ENV_HOVER>(h->dyn.cfg, ckpt);
     else if (net == 1 && h->cfg.kind == VF_ENV_RACING) k = r16 ? vf::pick_rev<vf::NetHover, 16, VF_ENV_RACING>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetHover, 32, VF_ENV_RACING>(h->dyn.cfg, ckpt);
     else if (net == 2 && h->cfg.kind == VF_ENV_NAV) k = r16 ? vf::pick_rev<vf::NetNav, 16, VF_ENV_NAV>(h->dyn.cfg, ckpt) : vf::pick_rev<vf::NetNav, 32, VF_ENV_NAV>(h->dyn.cfg, ckpt);
-    if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: no persistent reverse sweep for this network class / env kind / dynamics configuration");
+    if (!k && net != 0) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: no persistent reverse sweep for this network class / env kind / dynamics configuration");
+    if (net == 0 && !ckpt)
+        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: a generated actor class sweeps 16 agents per wave from the sub-step tape only (N <= 16 384, "
+                                         "substep_tape of the forward launch, delay ring <= %d slots)", vf::kRingRegs);
     bool found = false;        // g_obs must be the (rows, 13) buffer the "state" branch's first layer writes its data gradient to
     for (int l = 0; l < desc->n_layers; ++l) found = found || (desc->layer[l].need_dx && desc->layer[l].dX == g_obs && desc->layer[l].ld_dx == OW);
     if (!found) return vf::fail(VF_EINVAL, "vf_bptt_reverse: g_obs is not the (rows, %d) observation-gradient buffer of the layer table", OW);
@@ -67,8 +73,23 @@ extern "C" int vf_bptt_reverse(vf_env* h, const vf_mlp_bwd_desc* desc, const flo
                   adj_slab, reinterpret_cast<float4*>(d_action), g_obs, reinterpret_cast<const float4*>(substep_tape)};
     const size_t lds = ckpt ? (size_t)2 * (S + 3) * 64 * sizeof(float4) + (64 + 256) * sizeof(float) : (size_t)S * vf::kSave * 64 * sizeof(float);
     const int rows = r16 ? 16 : 32;
-    hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, gb, r);
-    VF_HIP(hipGetLastError());
+    if (k) {
+        hipLaunchKernelGGL(k, dim3((N + rows - 1) / rows), dim3(64), lds, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, gb, r);
+        VF_HIP(hipGetLastError());
+        return VF_OK;
+    }
+    int rc = 0;
+    const int kkind = race2 ? vf::VF_ENV_RACING2 : h->cfg.kind;
+    for (int i = 0; i < vf::chain_plugin_count() && rc == 0; ++i) {
+        const vf::ChainPlugin* p = vf::chain_plugin(i);
+        if (p->bptt_reverse && p->bptt_rev_abi == vf::kBpttRevPluginAbi)
+            rc = p->bptt_reverse(desc, kkind, &h->dyn.cfg, h->dyn.d_cfg, h->d_cfg, &gb, &r, N, lds, vf::as_stream(stream));
+    }
+    if (rc <= -1000) return vf::fail(VF_EHIP, "vf_bptt_reverse (chain plugin) failed: %s", hipGetErrorString((hipError_t)(-rc - 1000)));
+    if (rc == 0)
+        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_reverse: the policy's layer table is not one of the built-in register-chained classes and no BPTT "
+                                         "plugin of a generated class serves it under this env kind / dynamics configuration");
+    vf::chain_plugin_count_launch();
     return VF_OK;
 }
 

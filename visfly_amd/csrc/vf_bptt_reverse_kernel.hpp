@@ -206,3 +206,57 @@ RevKernel pick_rev_sac32(int net, int kind, const vf_dyn_cfg& c);
 
 }  // namespace vf
 
+
+namespace vf {
+
+// layout stamp of what a BPTT plugin's reverse sweep is handed (vf_chain_plugin.hpp: ChainPlugin::bptt_rev_abi)
+constexpr unsigned kBpttRevPluginAbi = 0x42560001u ^ (unsigned)(sizeof(BwdArgsChain) * 31u + sizeof(RevArgs) * 17u + sizeof(vf_dyn_cfg) * 7u +
+                                                               sizeof(vf_env_cfg) * 5u);
+
+}  // namespace vf
+
+#if defined(VF_CHAIN_PLUGIN) && (VF_CHAIN_PLUGIN_PART == 6 || VF_CHAIN_PLUGIN_PART == 7)
+#include "vf_mlp_chain_gen.hpp"
+#include "vf_chain_plugin.hpp"
+extern "C" int vf_plugin_bptt_reverse(const vf_mlp_bwd_desc*, int, const vf_dyn_cfg*, const vf_dyn_cfg*, const vf_env_cfg*, const vf::BwdArgsChain*,
+                                      const void*, int, size_t, hipStream_t);
+#endif
+#if defined(VF_CHAIN_PLUGIN) && VF_CHAIN_PLUGIN_PART == 6
+namespace vf {
+
+// the reverse half for the same class: 16 agents per wave, the sub-step tape of the forward launch (CKPT); P = the reverse chain a BPTT
+// sweep runs per step (observation gradient; both trunks for the SAC-style Actor, the policy trunk for an actor-critic)
+template <class P, int KIND, int ACT, int INTEG, bool DELAY>
+int plugin_bptt_reverse(const vf_mlp_bwd_desc* d, int env_kind, const vf_dyn_cfg* c, const vf_dyn_cfg* d_dyn, const vf_env_cfg* d_env,
+                        const BwdArgsChain* gb, const void* rev_args, int N, size_t lds, hipStream_t st)
+{
+    if (env_kind != KIND || c->action_type != ACT || c->integrator != INTEG || (c->ctrl_delay != 0) != DELAY) return 0;
+    if (!bwd_chain_matches_gen<P>(*d, true) || !bwd16_ok_gen<P>(*d, N)) return 0;
+    if (P::sac_head ? !gb->rp_ls_rows : (!gb->rp_log_std || !gb->rp_g_log_std)) return 0;
+    hipLaunchKernelGGL((k_bptt_reverse<P, 16, KIND, ACT, INTEG, DELAY, true>), dim3((N + 15) / 16), dim3(64), lds, st, d_dyn, d_env, *gb,
+                       *static_cast<const RevArgs*>(rev_args));
+    VF_HIP(hipGetLastError());
+    return 1;
+}
+
+}  // namespace vf
+
+#define VF_CHAIN_PLUGIN_BPTT_DEFINE(Net, NetPi, KIND, ACT, INTEG, DELAY, NAME)                                                                  \
+    extern "C" int vf_plugin_bptt_reverse(const vf_mlp_bwd_desc* d, int env_kind, const vf_dyn_cfg* c, const vf_dyn_cfg* d_dyn,                 \
+                                          const vf_env_cfg* d_env, const vf::BwdArgsChain* gb, const void* ra, int N, size_t lds,               \
+                                          hipStream_t st)                                                                                       \
+    {                                                                                                                                           \
+        using P = typename Net::template Bwd<true, Net::HV == 4, true>;                                                                         \
+        return vf::plugin_bptt_reverse<P, KIND, ACT, INTEG, DELAY>(d, env_kind, c, d_dyn, d_env, gb, ra, N, lds, st);                           \
+    }
+#endif
+#if defined(VF_CHAIN_PLUGIN) && VF_CHAIN_PLUGIN_PART == 7
+#include "vf_bptt_rollout_kernel.hpp"
+#define VF_CHAIN_PLUGIN_BPTT_DEFINE(Net, NetPi, KIND, ACT, INTEG, DELAY, NAME)                                                                  \
+    extern "C" const vf::ChainPlugin* vf_chain_plugin()                                                                                         \
+    {                                                                                                                                           \
+        static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, nullptr, nullptr, nullptr, nullptr, 0u, nullptr,                              \
+                                       vf::kBpttRollPluginAbi, vf::kBpttRevPluginAbi, vf_plugin_bptt_rollout, vf_plugin_bptt_reverse};          \
+        return &p;                                                                                                                              \
+    }
+#endif

@@ -17,6 +17,7 @@
 //     discount recurrence in registers.
 // Everything the per-step path leaves behind -- saved activations of every slot, actions, tape rows, done flags, d_reward
 // rows, loss, episode outputs, final slab -- is bit-identical (tests/test_bptt_gpu.py), so the reverse sweep is unchanged.
+#include "vf_chain_plugin.hpp"
 #include "vf_bptt_rollout_kernel.hpp"
 
 extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* params, const float* packed, const float* obs_slots0,
@@ -40,24 +41,29 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
     if (desc->in_dim[0] != OW) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the first observation must be the %d-wide state row", OW);
     // (RacingEnv2: out->obs / out->terminal_obs / obs_slots0 / obs_final rows are 16 wide)
     const int cls = vf::chain16_policy_class(desc, params);
-    if (cls == 0)          // (before the per-class argument checks: a caller with another network -- a generated class -- steps launch by launch)
-        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the policy's layer table is not one of the built-in register-chained classes");
-    const bool sac = cls >= 3;          // td_policies.Actor: the second head is the state-dependent log_std
+    // td_policies.Actor: the second head is the state-dependent log_std.  cls == 0: not a built-in class -- a generated one runs from its
+    // BPTT plugin below (visfly_amd/_jit.py: ensure_bptt), told apart by the width of the table's second head
+    bool sac = cls >= 3;
+    if (cls == 0)
+        for (int l = 0; l < desc->n_layers; ++l)
+            if (desc->layer[l].dst == VF_MLP_OUT1) sac = desc->layer[l].No == 4;
     if (sac ? !log_std_rows : !log_std)
         return vf::fail(VF_EINVAL, sac ? "vf_bptt_rollout: log_std_rows (H N, 4) is required for the two-headed actor classes"
                                        : "vf_bptt_rollout: log_std is required for the state-independent-log_std classes");
     if ((reinterpret_cast<uintptr_t>(mean_rows) | reinterpret_cast<uintptr_t>(log_std_rows)) & 15)
         return vf::fail(VF_EINVAL, "vf_bptt_rollout: mean_rows / log_std_rows must be 16-byte aligned");
     vf::RollKernel k = nullptr;
-    if (race2) k = obs_slots1 ? nullptr : vf::pick_roll_race2(cls, h->dyn.cfg);
+    if (cls == 0) k = nullptr;
+    else if (race2) k = obs_slots1 ? nullptr : vf::pick_roll_race2(cls, h->dyn.cfg);
     else if ((cls == 1 || cls == 3) && h->cfg.kind == VF_ENV_NAV) k = obs_slots1 ? nullptr : vf::pick_roll_nav2(cls, h->dyn.cfg);
     else if (!h->dyn.cfg.ctrl_delay) k = (cls == 2 || cls == 4) && !obs_slots1 ? nullptr : vf::pick_roll_nodelay(cls, h->cfg.kind, h->dyn.cfg);
     else if (cls == 1 && h->cfg.kind == VF_ENV_HOVER) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_HOVER>(h->dyn.cfg);
     else if (cls == 1 && h->cfg.kind == VF_ENV_RACING) k = vf::pick_roll<vf::NetHoverPi, VF_ENV_RACING>(h->dyn.cfg);
     else if (cls == 2 && h->cfg.kind == VF_ENV_NAV && obs_slots1) k = vf::pick_roll<vf::NetNavPi, VF_ENV_NAV>(h->dyn.cfg);
     else if (sac && (cls == 3 || obs_slots1)) k = vf::pick_roll_sac(cls, h->cfg.kind, h->dyn.cfg);
-    if (!k) return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: no persistent roll-out for this network class / env kind / dynamics "
-                                             "configuration (policy trunk or td_policies.Actor over [128, 64] x [64, 64], thrust / bodyrate, Euler / RK4)");
+    if (!k && cls != 0)
+        return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: no persistent roll-out for this network class / env kind / dynamics "
+                                         "configuration (policy trunk or td_policies.Actor over [128, 64] x [64, 64], thrust / bodyrate, Euler / RK4)");
     const int N = h->dyn.N;
     vf::EnvArgs ge{vf::DynArgs{N, h->dyn.G, h->dyn.g_drag, h->dyn.S, reinterpret_cast<const float4*>(actions), nullptr,
                                vf::ring_head(&h->dyn), nullptr, h->dyn.vel_strided},
@@ -72,8 +78,24 @@ extern "C" int vf_bptt_rollout(vf_env* h, const vf_mlp_desc* desc, const float* 
                      VF_SAC_LOG_STD_MAX};
     vf::RollArgs r{H, N, tape, tape_stride, tape_done, d_reward, loss, disc, const_cast<float*>(obs_slots0), obs_final, gamma, scale, reinterpret_cast<float4*>(substep_tape), reward_rows,
                    ep_flag_rows};
-    hipLaunchKernelGGL(k, dim3((N + 15) / 16), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
-    VF_HIP(hipGetLastError());
+    if (k) {
+        hipLaunchKernelGGL(k, dim3((N + 15) / 16), dim3(64), 0, vf::as_stream(stream), h->dyn.d_cfg, h->d_cfg, ge, gc, r);
+        VF_HIP(hipGetLastError());
+    } else {
+        // a generated actor class: its BPTT plugin, compiled on first use for this env kind / dynamics configuration (visfly_amd/_jit.py)
+        int rc = 0;
+        const int kkind = race2 ? vf::VF_ENV_RACING2 : h->cfg.kind;
+        for (int i = 0; i < vf::chain_plugin_count() && rc == 0; ++i) {
+            const vf::ChainPlugin* p = vf::chain_plugin(i);
+            if (p->bptt_rollout && p->bptt_roll_abi == vf::kBpttRollPluginAbi)
+                rc = p->bptt_rollout(desc, params, kkind, &h->dyn.cfg, obs_slots1 != nullptr, h->dyn.d_cfg, h->d_cfg, &ge, &gc, &r, N, vf::as_stream(stream));
+        }
+        if (rc <= -1000) return vf::fail(VF_EHIP, "vf_bptt_rollout (chain plugin) failed: %s", hipGetErrorString((hipError_t)(-rc - 1000)));
+        if (rc == 0)
+            return vf::fail(VF_EUNSUPPORTED, "vf_bptt_rollout: the policy's layer table is not one of the built-in register-chained classes and no "
+                                             "BPTT plugin of a generated class serves it under this env kind / dynamics configuration");
+        vf::chain_plugin_count_launch();
+    }
     h->dyn.tick += H;
     h->stale_all = 1;       // agents re-spawned inside the launch: the prefetched copies' stale bits no longer cover them
     return VF_OK;

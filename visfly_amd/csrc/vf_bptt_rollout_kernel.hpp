@@ -256,3 +256,49 @@ RollKernel pick_roll_sac(int net, int kind, const vf_dyn_cfg& c);
 
 }  // namespace vf
 
+
+namespace vf {
+
+// layout stamp of what a BPTT plugin's roll-out is handed (vf_chain_plugin.hpp: ChainPlugin::bptt_roll_abi)
+constexpr unsigned kBpttRollPluginAbi = 0x42520001u ^ (unsigned)(sizeof(EnvArgs) * 31u + sizeof(RollArgs) * 17u + sizeof(vf_dyn_cfg) * 7u +
+                                                                sizeof(vf_env_cfg) * 5u + sizeof(ChainArgs) * 3u);
+
+}  // namespace vf
+
+#if defined(VF_CHAIN_PLUGIN) && (VF_CHAIN_PLUGIN_PART == 5 || VF_CHAIN_PLUGIN_PART == 7)
+#include "vf_mlp_chain_gen.hpp"
+#include "vf_chain_plugin.hpp"
+extern "C" int vf_plugin_bptt_rollout(const vf_mlp_desc*, const float*, int, const vf_dyn_cfg*, int, const vf_dyn_cfg*, const vf_env_cfg*, const void*,
+                                      const vf::ChainArgs*, const void*, int, hipStream_t);
+#endif
+#if defined(VF_CHAIN_PLUGIN) && VF_CHAIN_PLUGIN_PART == 5
+namespace vf {
+
+// the forward half of a horizon for ONE generated actor class under ONE env kind / action type / integrator / motor-lag setting.  NetR: the
+// class the horizon steps -- the SAC-style Actor (both trunks) or the policy-only class of an actor-critic; 16 agents per wave, the
+// rows-per-wave choice of the plugin's per-step forward for the row counts this launch serves (vf_chain_plugin.hpp: plugin_forward)
+template <class NetR, int KIND, int ACT, int INTEG, bool DELAY>
+int plugin_bptt_rollout(const vf_mlp_desc* d, const float* params, int env_kind, const vf_dyn_cfg* c, int has_target, const vf_dyn_cfg* d_dyn,
+                        const vf_env_cfg* d_env, const void* env_args, const ChainArgs* gc, const void* roll_args, int N, hipStream_t st)
+{
+    if (env_kind != KIND || c->action_type != ACT || c->integrator != INTEG || (c->ctrl_delay != 0) != DELAY) return 0;
+    if ((NetR::NB == 2) != (has_target != 0) || (NetR::NB == 2 && KIND != VF_ENV_NAV)) return 0;
+    if (!chain_matches_gen<NetR>(*d) || !chain16_ok<NetR>(*d, params, 1)) return 0;
+    if (NetR::HV == 4 ? (!gc->io.mean || !gc->io.value) : !gc->rp_log_std) return 0;
+    hipLaunchKernelGGL((k_bptt_rollout<NetR, KIND, ACT, INTEG, DELAY>), dim3((N + 15) / 16), dim3(64), 0, st, d_dyn, d_env,
+                       *static_cast<const EnvArgs*>(env_args), *gc, *static_cast<const RollArgs*>(roll_args));
+    VF_HIP(hipGetLastError());
+    return 1;
+}
+
+}  // namespace vf
+
+#define VF_CHAIN_PLUGIN_BPTT_DEFINE(Net, NetPi, KIND, ACT, INTEG, DELAY, NAME)                                                                  \
+    extern "C" int vf_plugin_bptt_rollout(const vf_mlp_desc* d, const float* params, int env_kind, const vf_dyn_cfg* c, int has_target,         \
+                                          const vf_dyn_cfg* d_dyn, const vf_env_cfg* d_env, const void* ea, const vf::ChainArgs* gc,            \
+                                          const void* ra, int N, hipStream_t st)                                                                \
+    {                                                                                                                                           \
+        using NetR = std::conditional_t<Net::HV == 4, Net, NetPi>;                                                                              \
+        return vf::plugin_bptt_rollout<NetR, KIND, ACT, INTEG, DELAY>(d, params, env_kind, c, has_target, d_dyn, d_env, ea, gc, ra, N, st);     \
+    }
+#endif

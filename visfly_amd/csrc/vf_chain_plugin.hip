@@ -56,7 +56,7 @@ extern "C" int vf_chain_plugin_load(const char* path)
     typedef const ChainPlugin* (*entry_t)();
     entry_t entry = reinterpret_cast<entry_t>(dlsym(h, "vf_chain_plugin"));
     const ChainPlugin* p = entry ? entry() : nullptr;
-    if (!p || p->abi != kChainPluginAbi || !((p->forward && p->backward && p->ppo_update) || p->ppo_rollout)) {
+    if (!p || p->abi != kChainPluginAbi || !((p->forward && p->backward && p->ppo_update) || p->ppo_rollout || (p->bptt_rollout && p->bptt_reverse))) {
         dlclose(h);
         return fail(VF_EINVAL, "vf_chain_plugin_load: %s is not a chain plugin of this library build (abi %08x, expected %08x)", path,
                     p ? p->abi : 0u, kChainPluginAbi);

@@ -12,15 +12,17 @@
 namespace vf {
 
 // layout stamp: both sides are compiled from the same headers; a plugin built against other struct layouts is refused
-constexpr unsigned kChainPluginAbi = 0x56460002u ^ (unsigned)(sizeof(vf_mlp_desc) * 31u + sizeof(vf_mlp_bwd_desc) * 17u + sizeof(ChainArgs) * 7u +
+constexpr unsigned kChainPluginAbi = 0x56460003u ^ (unsigned)(sizeof(vf_mlp_desc) * 31u + sizeof(vf_mlp_bwd_desc) * 17u + sizeof(ChainArgs) * 7u +
                                                             sizeof(BwdArgsChain) * 5u + sizeof(PpoRowArgs) * 3u + sizeof(ReparamFwd) + sizeof(ReparamBwd));
 
 struct ChainPlugin {
     unsigned abi;
     const char* name;      // the shape, for messages
-    // out1 == null: the policy-only class (no value trunk)
+    // out1 == null: the policy-only class (no value trunk).  M_choice > 0: the rows-per-wave choice is made for M_choice rows
+    // (vf_mlp_forward_steps).  The classes a BPTT / SHAC horizon steps -- the SAC-style Actor, the policy-only class -- run 16 rows per wave
+    // where the built-in classes do (chain16_ok), so that their persistent launches (16 agents per wave) equal the per-step path to the bit
     int (*forward)(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1, float* out0, float* out1,
-                   int M, hipStream_t st, const ReparamFwd* rp);
+                   int M, hipStream_t st, const ReparamFwd* rp, int M_choice);
     // packed == null: capability query
     int (*backward)(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const ReparamBwd* rp);
     int (*ppo_update)(const ChainArgs* g, const BwdArgsChain* gb, const PpoRowArgs* pr, int M, hipStream_t st);
@@ -32,6 +34,16 @@ struct ChainPlugin {
     unsigned rollout_abi;
     int (*ppo_rollout)(const vf_mlp_desc* d, int env_kind, const vf_dyn_cfg* c, int has_target, const vf_dyn_cfg* d_dyn, const vf_env_cfg* d_env,
                        const void* env_args, const ChainArgs* gc, const void* roll_args, int N, hipStream_t st);
+    // a BPTT plugin (r06; per shape AND env kind / action type / integrator / ctrl_delay like the roll-out plugin): the two persistent
+    // launches of a BPTT / SHAC horizon for a generated actor class, 16 agents per wave -- k_bptt_rollout (vf_bptt_rollout_kernel.hpp:
+    // env_args / roll_args = vf::EnvArgs / vf::RollArgs, stamped by bptt_roll_abi) and k_bptt_reverse with the sub-step tape
+    // (vf_bptt_reverse_kernel.hpp: rev_args = vf::RevArgs, bptt_rev_abi; lds = its dynamic LDS bytes).  env_kind: the KERNEL-side kind
+    // (VF_ENV_RACING2 for RacingEnv2's 16-column rows)
+    unsigned bptt_roll_abi, bptt_rev_abi;
+    int (*bptt_rollout)(const vf_mlp_desc* d, const float* params, int env_kind, const vf_dyn_cfg* c, int has_target, const vf_dyn_cfg* d_dyn,
+                        const vf_env_cfg* d_env, const void* env_args, const ChainArgs* gc, const void* roll_args, int N, hipStream_t st);
+    int (*bptt_reverse)(const vf_mlp_bwd_desc* d, int env_kind, const vf_dyn_cfg* c, const vf_dyn_cfg* d_dyn, const vf_env_cfg* d_env,
+                        const BwdArgsChain* gb, const void* rev_args, int N, size_t lds, hipStream_t st);
 };
 
 // the registry (vf_chain_plugin.hip)
@@ -48,7 +60,7 @@ namespace vf {
 
 template <class Net, class NetPi>
 int plugin_forward(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1, float* out0, float* out1, int M,
-                   hipStream_t st, const ReparamFwd* rpp)
+                   hipStream_t st, const ReparamFwd* rpp, int M_choice)
 {
     if (Net::NB + Net::PASS == 2 && !in1) return 0;
     const ReparamFwd rp = rpp ? *rpp : ReparamFwd{};
@@ -60,10 +72,23 @@ int plugin_forward(const vf_mlp_desc* d, const float* params, const float* packe
             return 0;             // (the SAC-style Actor always runs both trunks)
         } else {
             if (!chain_matches_gen<NetPi>(*d)) return 0;
-            hipLaunchKernelGGL(k_mlp_forward_chain<NetPi>, dim3((M + 31) / 32), dim3(64), 0, st, g);
+            // with the action head (vf_mlp_forward_act: what a BPTT horizon steps) 16 rows per wave for small row counts, like the
+            // persistent launch that replaces the loop (k_bptt_rollout); the plain policy-only forward keeps the full class's 32 rows,
+            // whose mean it reproduces bit for bit
+            if (rp.action && chain16_ok<NetPi>(*d, params, M_choice > 0 ? M_choice : M))
+                hipLaunchKernelGGL(k_mlp_forward_chain16<NetPi>, dim3((M + 15) / 16), dim3(64), 0, st, g);
+            else
+                hipLaunchKernelGGL(k_mlp_forward_chain<NetPi>, dim3((M + 31) / 32), dim3(64), 0, st, g);
         }
     } else {
         if (!chain_matches_gen<Net>(*d)) return 0;
+        if constexpr (Net::HV == 4) {      // the SAC-style Actor: 16 rows per wave for small row counts (chain_launch's rule)
+            if (chain16_ok<Net>(*d, params, M_choice > 0 ? M_choice : M)) {
+                hipLaunchKernelGGL(k_mlp_forward_chain16<Net>, dim3((M + 15) / 16), dim3(64), 0, st, g);
+                VF_HIP(hipGetLastError());
+                return 1;
+            }
+        }
         hipLaunchKernelGGL(k_mlp_forward_chain<Net>, dim3((M + 31) / 32), dim3(64), 0, st, g);
     }
     VF_HIP(hipGetLastError());
@@ -85,6 +110,13 @@ int plugin_backward(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStr
     if (bwd_chain_matches_gen<PU>(*d, false)) {
         if (packed) hipLaunchKernelGGL(k_mlp_backward_chain<PU>, grid, dim3(64), 0, st, g);
     } else if (!Net::PASS && bwd_chain_matches_gen<PG>(*d, true)) {
+        if constexpr (!Net::PASS) {        // what a BPTT sweep runs per step: 16 rows per wave for small row counts (bwd_chain_launch's rule)
+            if (packed && bwd16_ok_gen<PG>(*d, M)) {
+                hipLaunchKernelGGL((k_mlp_backward_chain<PG, 16>), dim3((M + 15) / 16), dim3(64), 0, st, g);
+                VF_HIP(hipGetLastError());
+                return 1;
+            }
+        }
         if (packed) hipLaunchKernelGGL(k_mlp_backward_chain<PG>, grid, dim3(64), 0, st, g);
     } else {
         return 0;
@@ -134,7 +166,7 @@ int plugin_twin_q_update(const ChainArgs* g, const BwdArgsChain* gb, const float
 
 extern "C" {
 int vf_plugin_twin_q_update(const vf::ChainArgs*, const vf::BwdArgsChain*, const float*, double*, float, int, hipStream_t);
-int vf_plugin_forward(const vf_mlp_desc*, const float*, const float*, const float*, const float*, float*, float*, int, hipStream_t, const vf::ReparamFwd*);
+int vf_plugin_forward(const vf_mlp_desc*, const float*, const float*, const float*, const float*, float*, float*, int, hipStream_t, const vf::ReparamFwd*, int);
 int vf_plugin_backward(const vf_mlp_bwd_desc*, const float*, int, hipStream_t, const vf::ReparamBwd*);
 int vf_plugin_ppo_update(const vf::ChainArgs*, const vf::BwdArgsChain*, const vf::PpoRowArgs*, int, hipStream_t);
 const vf::ChainPlugin* vf_chain_plugin();
@@ -144,8 +176,8 @@ const vf::ChainPlugin* vf_chain_plugin();
 #if VF_CHAIN_PLUGIN_PART == 1
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
     extern "C" int vf_plugin_forward(const vf_mlp_desc* d, const float* params, const float* packed, const float* in0, const float* in1,    \
-                                     float* out0, float* out1, int M, hipStream_t st, const vf::ReparamFwd* rp)                              \
-    { return vf::plugin_forward<Net, NetPi>(d, params, packed, in0, in1, out0, out1, M, st, rp); }
+                                     float* out0, float* out1, int M, hipStream_t st, const vf::ReparamFwd* rp, int M_choice)                \
+    { return vf::plugin_forward<Net, NetPi>(d, params, packed, in0, in1, out0, out1, M, st, rp, M_choice); }
 #elif VF_CHAIN_PLUGIN_PART == 2
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
     extern "C" int vf_plugin_backward(const vf_mlp_bwd_desc* d, const float* packed, int M, hipStream_t st, const vf::ReparamBwd* rp)        \
@@ -160,12 +192,16 @@ const vf::ChainPlugin* vf_chain_plugin();
 #elif VF_CHAIN_PLUGIN_PART == 4
 // the roll-out plugin: one translation unit, one kernel instance (vf_ppo_rollout_kernel.hpp defines VF_CHAIN_PLUGIN_ROLLOUT_DEFINE)
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)
+#elif VF_CHAIN_PLUGIN_PART >= 5
+// the BPTT plugin: parts 5 (k_bptt_rollout), 6 (k_bptt_reverse), 7 (the table): vf_bptt_rollout_kernel.hpp / vf_bptt_reverse_kernel.hpp
+// define VF_CHAIN_PLUGIN_BPTT_DEFINE
+#define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)
 #else
 #define VF_CHAIN_PLUGIN_DEFINE(Net, NetPi, NAME)                                                                                             \
     extern "C" const vf::ChainPlugin* vf_chain_plugin()                                                                                      \
     {                                                                                                                                        \
         static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, vf_plugin_forward, vf_plugin_backward, vf_plugin_ppo_update,               \
-                                       Net::PASS ? vf_plugin_twin_q_update : nullptr, 0u, nullptr};                                          \
+                                       Net::PASS ? vf_plugin_twin_q_update : nullptr, 0u, nullptr, 0u, 0u, nullptr, nullptr};                \
         return &p;                                                                                                                           \
     }
 #endif

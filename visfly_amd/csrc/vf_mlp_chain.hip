@@ -24,9 +24,9 @@
 namespace vf {
 
 // a plugin's return value in the library's terms (vf_chain_plugin.hpp)
-static int plugin_rc(int rc, const char* what)
+static int plugin_rc(int rc, const char* what, bool launched = true)
 {
-    if (rc == 1) chain_plugin_count_launch();
+    if (rc == 1 && launched) chain_plugin_count_launch();      // (a capability query is not a launch)
     if (rc <= -1000) return fail(VF_EHIP, "%s (chain plugin) failed: %s", what, hipGetErrorString((hipError_t)(-rc - 1000)));
     return rc;
 }
@@ -49,7 +49,7 @@ int mlp_backward_chain_try(const vf_mlp_bwd_desc* d, const float* packed, int M,
     if (bwd_chain_matches<NetHover, true, false, true>(*d)) return launch ? bwd_chain_launch<NetHover, true, false, true>(*d, packed, M, st, rp) : 1;
     for (int i = 0; i < chain_plugin_count(); ++i)      // shapes compiled on first use (vf_mlp_chain_gen.hpp)
         if (chain_plugin(i)->backward)
-            if (int rc = chain_plugin(i)->backward(d, launch ? packed : nullptr, M, st, rpp)) return plugin_rc(rc, "vf_mlp_backward_data");
+            if (int rc = chain_plugin(i)->backward(d, launch ? packed : nullptr, M, st, rpp)) return plugin_rc(rc, "vf_mlp_backward_data", launch);
     if (!rpp) return mlp_backward_chain_try_sac(d, packed, M, st);       // the SAC-style Actor's classes (vf_mlp_chain_sac.hip)
     return 0;
 }
@@ -104,15 +104,16 @@ int mlp_forward_chain_try(const vf_mlp_desc* d, const float* params, const float
     if (!out1) {      // no value requested: the value trunk is skipped
         if (chain_matches<NetNavPi>(*d) && in1) return chain_launch<NetNavPi>(*d, params, packed, in0, in1, out0, out1, M, st, rp, nullptr, M_choice);
         if (chain_matches<NetHoverPi>(*d)) return chain_launch<NetHoverPi>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp, nullptr, M_choice);
-        return 0;
+        // (a generated class: the plugin's policy-only class below -- r06: until then this branch ended here, the caller re-ran the full class)
+    } else {
+        if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp, nullptr, M_choice);
+        if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp, nullptr, M_choice);
     }
-    if (chain_matches<NetNav>(*d) && in1) return chain_launch<NetNav>(*d, params, packed, in0, in1, out0, out1, M, st, rp, nullptr, M_choice);
-    if (chain_matches<NetHover>(*d)) return chain_launch<NetHover>(*d, params, packed, in0, nullptr, out0, out1, M, st, rp, nullptr, M_choice);
     if (!in2)
-        for (int i = 0; i < chain_plugin_count(); ++i)      // shapes compiled on first use (vf_mlp_chain_gen.hpp); 32 rows per wave at every M
+        for (int i = 0; i < chain_plugin_count(); ++i)      // shapes compiled on first use (vf_mlp_chain_gen.hpp)
             if (chain_plugin(i)->forward)
-                if (int rc = chain_plugin(i)->forward(d, params, packed, in0, in1, out0, out1, M, st, rpp)) return plugin_rc(rc, "vf_mlp_forward");
-    if (!rpp) return mlp_forward_chain_try_sac(d, params, packed, in0, in1, in2, out0, out1, M, st, M_choice);    // SAC-style Actor / twin critic (vf_mlp_chain_sac.hip)
+                if (int rc = chain_plugin(i)->forward(d, params, packed, in0, in1, out0, out1, M, st, rpp, M_choice)) return plugin_rc(rc, "vf_mlp_forward");
+    if (!rpp && out1) return mlp_forward_chain_try_sac(d, params, packed, in0, in1, in2, out0, out1, M, st, M_choice);    // SAC-style Actor / twin critic (vf_mlp_chain_sac.hip)
     return 0;
 }
 

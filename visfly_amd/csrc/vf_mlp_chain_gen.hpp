@@ -436,4 +436,18 @@ bool bwd_chain_matches_gen(const vf_mlp_bwd_desc& d, bool ig)
     return true;
 }
 
+// 16 rows per wave for the reverse chain of a generated class?  bwd16_ok's rule (vf_mlp_chain_kernels.hpp)
+template <class P>
+bool bwd16_ok_gen(const vf_mlp_bwd_desc& d, int M)
+{
+    using Sh = typename P::Net::Shape;
+    static const int forced = [] { const char* e = getenv("VISFLY_AMD_MLP_CHAIN16"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || (forced < 0 && M > 16384)) return false;
+    for (int l = 0; l < d.n_layers; ++l)
+        if (d.layer[l].wb_off < 0) return false;
+    for (int b = 0; b < Sh::NB; ++b)
+        if (d.layer[P::entry(Sh::ext(b, 0))].K > 16) return false;
+    return true;
+}
+
 }  // namespace vf

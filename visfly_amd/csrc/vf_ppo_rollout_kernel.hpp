@@ -230,7 +230,7 @@ int plugin_ppo_rollout(const vf_mlp_desc* d, int env_kind, const vf_dyn_cfg* c, 
     { return vf::plugin_ppo_rollout<Net, KIND, ACT, INTEG, DELAY>(d, env_kind, c, has_target, d_dyn, d_env, ea, gc, ra, N, st); }             \
     extern "C" const vf::ChainPlugin* vf_chain_plugin()                                                                                      \
     {                                                                                                                                        \
-        static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, nullptr, nullptr, nullptr, nullptr, vf::kRolloutPluginAbi, vf_plugin_ppo_rollout};  \
+        static const vf::ChainPlugin p{vf::kChainPluginAbi, NAME, nullptr, nullptr, nullptr, nullptr, vf::kRolloutPluginAbi, vf_plugin_ppo_rollout, 0u, 0u, nullptr, nullptr};  \
         return &p;                                                                                                                           \
     }
 #endif

@@ -892,6 +892,7 @@ class DroneGymEnvsBase:
             sub = self._substep[t0]
         self._substep_range = None
         two_heads = tuple(policy.head_dims) == (4, 4) and policy.log_std.numel() == 0
+        self._ensure_bptt_plugin(policy)
         with th.cuda.device(dev):
             rc = L.vf_bptt_rollout(self._h, C.byref(d), _lib.ptr(policy.flat), _lib.ptr(policy._packed), _lib.ptr(blk["obs:state"]),
                                    _lib.ptr(o1), None if two_heads else _lib.ptr(policy.log_std), _lib.ptr(eps), _lib.ptr(actions),
@@ -917,6 +918,20 @@ class DroneGymEnvsBase:
         self._observations = self._full_obs(final)
         policy._last_M, policy._last_slot = N, H - 1
         return True
+
+    def _ensure_bptt_plugin(self, policy):
+        """a generated actor class: the two persistent launches of its horizons are one more plugin, per env kind / action type /
+        integrator / motor lag (visfly_amd/_jit.py: ensure_bptt; ~2 min of hipcc on first use, 16 agents per wave: N <= 16 384)"""
+        if not getattr(policy, "chain_jit", False) or self.num_agent > 16384:
+            return
+        try:
+            from .. import _jit
+            c = self.envs.dynamics.constants
+            kind = 3 if self._OBS_W == 16 else self.KIND       # kernel-side kind: VF_ENV_RACING2 forms RacingEnv2's 16 columns itself
+            _jit.ensure_bptt(policy.chain_shape, (kind, int(c["action_type"]), int(c["integrator"]), bool(c["ctrl_delay"])))
+        except Exception as e:          # no hipcc, ...: launch by launch, with the library's warning
+            import warnings
+            warnings.warn(f"visfly_amd: no BPTT plugin for this network ({e})")
 
     def _after_persistent_launch(self):
         """host-side caches of per-step state that a persistent launch stepped past (overridden where an env keeps any)"""
