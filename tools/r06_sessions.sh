@@ -93,6 +93,13 @@ PY
         done
     done
     ;;
+genhor)   # VERDICT r05 items 3b / 3c measured: generated twin-critic class + BPTT plugins on a non-default net_arch (one process per mode)
+    for w in 128,128 32; do
+        for m in all loop r05 blocktile; do
+            timeout 900 python tools/exp_generated_horizons.py $m $w 2>&1 | grep -v amdgpu.ids | tee -a $O/table.txt
+        done
+    done
+    ;;
 tests)    # the whole GPU suite
     timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $O/pytest.txt
     ;;
