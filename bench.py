@@ -249,6 +249,18 @@ def bench_ppo(args, rank, world, dev, iters=None, cpu_ref=False):
     return out
 
 
+def _actor_critic_arch(args):
+    """--net-arch pi=128,128[:qf=128,128] for the BPTT / SHAC legs: policy_kwargs of the reference's MTDPolicy over its StateExtractor with a
+    net_arch the library holds no built-in chain class of -- actor (and twin critic) classes are generated, the horizons run from the BPTT
+    plugin (visfly_amd/_jit.py; profiles/r06_generated_horizons.txt)"""
+    if not getattr(args, "net_arch", None):
+        return None
+    arch = {k: [int(x) for x in v.split(",")] for k, v in (p.split("=") for p in args.net_arch.split(":"))}
+    arch.setdefault("qf", list(arch["pi"]))
+    return dict(features_extractor_class="StateExtractor", features_extractor_kwargs=dict(net_arch=dict(state=dict(layer=[128, 64]))),
+                net_arch=dict(pi=arch["pi"], qf=arch["qf"]), activation_fn="relu", share_features_extractor=False)
+
+
 def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
     """BASELINE configs[4] shape: RacingEnv, thrust actions, BPTT H=64 through the adjoint kernel, 16 384 agents per GPU
     (131 072 / 8), agents sharded by rank, one all-reduce of the flat gradient per update.  The leg's `value` is the loop with the
@@ -265,7 +277,9 @@ def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
     def run(policy):
         env = RacingEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dkw, device=dev, max_episode_steps=256,
                         requires_grad=True, tensor_output=True)
-        algo = BPTT(env, horizon=64, gamma=0.99, learning_rate=1e-3, seed=0, **({"policy": policy} if policy else {}))
+        pk = _actor_critic_arch(args) if policy else None
+        algo = BPTT(env, horizon=64, gamma=0.99, learning_rate=1e-3, seed=0, **({"policy": policy} if policy else {}),
+                    **({"policy_kwargs": pk} if pk else {}))
         algo.learn(64 * N * world)     # warm-up update
         torch.cuda.synchronize()
         parallel.barrier()
@@ -304,7 +318,8 @@ def bench_bptt(args, rank, world, dev, iters=None, cpu_ref=False):
            "iterations": iters, "regions": regions, "s_per_iteration": el / iters, "dtype": "f32", "data": "synthetic", "roofline": roof,
            "policy": "td_policies.Actor (policy=\"MultiInputPolicy\"): extractor [128, 64], latent_pi / log_latent_pi [64, 64], mu / log_std heads",
            "exchange": exchange_block(algo.policy.grad, 1, el / iters, el / iters * 1e6, world, dev),     # one all-reduce of the flat gradient per update
-           "config": {"workload": f"RacingEnv {N} agents/GPU, thrust actions, horizon 64 (BASELINE configs[4] shard)",
+           "config": {"workload": f"RacingEnv {N} agents/GPU, thrust actions, horizon 64 (BASELINE configs[4] shard)" +
+                                  (f", net_arch {args.net_arch} (generated actor class, BPTT plugin)" if getattr(args, "net_arch", None) else ""),
                       "logs": {k: float(v) for k, v in algo.logs.items()}}}
     if cpu_ref and rank == 0:
         out["cpu_baseline"] = cpu_baseline_env(env.envs.dynamics.constants, "racing", 16384, seconds_target=3.0,
@@ -330,7 +345,8 @@ def bench_shac(args, rank, world, dev, iters=None, cpu_ref=False):
     N, H = (args.agents if args.agents != AGENTS_PER_GPU else 16384), 32
     env = HoverEnv(num_agent_per_scene=N, seed=42 + rank, dynamics_kwargs=dict(DYN_KW), device=dev, max_episode_steps=256,
                    requires_grad=True, tensor_output=True)
-    algo = SHAC(env, horizon=H, gamma=0.99, learning_rate=1e-3, gradient_steps=5, seed=0)
+    pk = _actor_critic_arch(args)
+    algo = SHAC(env, horizon=H, gamma=0.99, learning_rate=1e-3, gradient_steps=5, seed=0, **({"policy": "MultiInputPolicy", "policy_kwargs": pk} if pk else {}))
     algo.learn(H * N * world)       # warm-up iteration
     torch.cuda.synchronize()
     parallel.barrier()
@@ -356,7 +372,8 @@ def bench_shac(args, rank, world, dev, iters=None, cpu_ref=False):
                         "kernel": "whole iteration: actor chain forward / reverse + env step + adjoint, target critics, 5 critic updates",
                         "flops_per_agent_step": flops_row, "actor_params": int(wa), "critic_params": int(wc),
                         "note": "loop-level figure over the timed iterations (wall clock, not one kernel)"},
-           "config": {"workload": f"HoverEnv {N} agents/GPU, bodyrate, horizon {H}, 5 critic steps (SURVEY 8f-2; the reference's SHAC defaults)",
+           "config": {"workload": f"HoverEnv {N} agents/GPU, bodyrate, horizon {H}, 5 critic steps (SURVEY 8f-2; the reference's SHAC defaults)" +
+                                  (f", net_arch {args.net_arch} (generated actor / twin-critic classes, BPTT plugin)" if getattr(args, "net_arch", None) else ""),
                       "logs": {k: float(v) for k, v in algo.logs.items()}}}
     env.close()
     return out
@@ -477,7 +494,7 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=6.0, help="seconds of back-to-back stepping reported as `sustained` (the driver's "
                     "gpu_busy samples see the GPU working; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--net-arch", default=None, help="--workload ppo only: `pi=128,128:vf=32` -- a net_arch without a built-in chain class "
+    ap.add_argument("--net-arch", default=None, help="--workload ppo: `pi=128,128:vf=32`; --workload bptt / shac: `pi=128,128[:qf=128,128]` -- a net_arch without a built-in chain class "
                                                      "(kernels compiled on first use, visfly_amd/_jit.py); the default is the reference's [64, 64] / [64, 64]")
     ap.add_argument("--activation", default=None, help="--workload ppo only: the policy's activation_fn (relu | tanh | elu | leaky_relu; default relu = the "
                                                         "reference's YAMLs; tanh = the policy class's own default): a generated chain class")
@@ -721,7 +738,7 @@ def main():
         # HBM bytes per launch: NOT measured in this run -- read from the PMC pass committed under profiles/ (rocprofv3 --pmc in its
         # own run, as MI355X_MICROARCH.md prescribes; per-agent figure x N), and labelled as such (roofline.traffic_source)
         traffic, traffic_src = None, None
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = (pmc["fetch_bytes_per_agent"] + pmc["write_bytes_per_agent"]) * N

@@ -100,6 +100,35 @@ genhor)   # VERDICT r05 items 3b / 3c measured: generated twin-critic class + BP
         done
     done
     ;;
+evidence) # r06 evidence for profiles/: the driver's bench command, kernel stats of every bench workload, PMC passes (env traffic + SQ, MFMA of the trainers)
+    timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_default.json
+    timeout 900 python bench.py 2>/dev/null | tail -1 > $O/bench_2000steps.json
+    cd /tmp
+    RP="rocprofv3 --output-format csv"
+    timeout 600 $RP --kernel-trace --stats -d /tmp/ks_env -- python $R/bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline --no-reset-leg --sustain-s 1 > $O/log_ks_env.txt 2>&1
+    python $R/tools/prof_summary.py $(find /tmp/ks_env -name "*kernel_stats.csv" | head -1) $O/r06_env_step_kernel_stats.txt python bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline --no-reset-leg --sustain-s 1 > /dev/null
+    for w in ppo bptt shac nav_rk4_dr; do
+        steps=256; [ $w = bptt ] && steps=128; [ $w = nav_rk4_dr ] && steps=200
+        timeout 600 $RP --kernel-trace --stats -d /tmp/ks_$w -- python $R/bench.py --workload $w --steps $steps --no-cpu-baseline > $O/log_ks_$w.txt 2>&1
+        python $R/tools/prof_summary.py $(find /tmp/ks_$w -name "*kernel_stats.csv" | head -1) $O/r06_${w}_kernel_stats.txt python bench.py --workload $w --steps $steps > /dev/null
+    done
+    timeout 300 $RP --kernel-trace --pmc FETCH_SIZE -d /tmp/pm_f -- python $R/tools/exp_env_one.py 65536 12 > $O/log_f.txt 2>&1
+    timeout 300 $RP --kernel-trace --pmc WRITE_SIZE -d /tmp/pm_w -- python $R/tools/exp_env_one.py 65536 12 > $O/log_w.txt 2>&1
+    for p in f w; do python $R/tools/pmc_summary.py /tmp/pm_$p k_env_step >> $O/pmc_traffic.txt 2>&1; done
+    timeout 300 $RP --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d /tmp/pm_a -- python $R/tools/exp_env_one.py 65536 12 > $O/log_a.txt 2>&1
+    timeout 300 $RP --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS -d /tmp/pm_b -- python $R/tools/exp_env_one.py 65536 12 > $O/log_b.txt 2>&1
+    for p in a b; do python $R/tools/pmc_summary.py /tmp/pm_$p k_env_step >> $O/pmc_env_sq.txt 2>&1; done
+    for w in ppo bptt shac; do
+        steps=256; [ $w = bptt ] && steps=128
+        timeout 600 $RP --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d /tmp/pmm_$w -- python $R/bench.py --workload $w --steps $steps --no-cpu-baseline > $O/log_mfma_$w.txt 2>&1
+        for k in k_ppo_update_split k_ppo_update_chain k_ppo_rollout k_mlp_wgrad k_bptt_rollout k_bptt_reverse k_twin_q_update; do echo "== $k ($w)" >> $O/pmc_mfma.txt; python $R/tools/pmc_summary.py /tmp/pmm_$w $k >> $O/pmc_mfma.txt 2>&1; done
+    done
+    cat $O/pmc_traffic.txt $O/pmc_env_sq.txt; head -8 $O/r06_*_kernel_stats.txt
+    ;;
+functional) # end of the round: soak of the step kernels, PPO learning curve on the built-in class and on the reference's DEFAULT (Tanh) policy
+    timeout 1500 python tools/soak_envs.py 50000 2>&1 | grep -v amdgpu.ids | tee $O/soak.txt
+    timeout 900 python tools/exp_ppo_learn.py 40 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve.txt
+    ;;
 tests)    # the whole GPU suite
     timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $O/pytest.txt
     ;;
