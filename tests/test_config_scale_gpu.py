@@ -118,6 +118,83 @@ def test_config3_ppo_iteration_at_shard_scale():
     assert not torch.equal(flat, flat3)
 
 
+def test_config3_rollout_at_shard_scale_bit_identical_to_oracle():
+    """configs[3] at the shard's size against the ORACLE ("the oracle comparison is at N = 64 only"): the persistent
+    collect_rollouts launch at 32 768 agents leaves the actions it sampled in the buffer; the CPU oracle, started from the same spawn states
+    and handed those actions, reproduces the buffer's observation rows, rewards and episode starts bit for bit for every agent until its
+    first episode end (the device's Philox re-spawn is not the oracle's to draw), over the first 96 steps"""
+    import oracle
+    from visfly_amd.envs import NavigationEnv
+    from visfly_amd.ppo import PPO
+    N, T = 32768, 96
+    env = NavigationEnv(num_agent_per_scene=N, seed=42, dynamics_kwargs=dict(DYN), random_kwargs=NAV_SPAWN, device="cuda:0", max_episode_steps=256)
+    ppo = PPO(env, n_steps=256, batch_size=25600, n_epochs=5, learning_rate=1e-4, seed=0, policy_kwargs=dict(activation_fn="relu"))
+    ppo._last_obs = env.reset()
+    ppo._last_starts = torch.ones(N, device="cuda:0")
+    fs0 = env.full_state.cpu().numpy()
+    ppo.collect_rollouts()
+    torch.cuda.synchronize()
+    assert ppo.fused_rollout, "the shard's roll-out is ONE persistent launch"
+    buf = ppo.buf
+    ref = oracle.OracleEnv(env.envs.dynamics.constants, N, "nav", 256, target=[9., 0., 1.])
+    ref.reset_full_state(fs0)
+    obs, acts, rew, starts = (x[:T + 1].cpu().numpy() for x in (buf.obs["state"], buf.actions, buf.rewards, buf.episode_starts))
+    alive, compared = np.ones(N, bool), 0
+    assert_bits_equal(obs[0], fs0[:, :13], "row 0 of the buffer = the spawn states")
+    for t in range(T):
+        ro, rr, rd = ref.step(acts[t])
+        assert np.array_equal(starts[t + 1][alive] > 0, rd[alive] > 0), f"episode starts @ {t + 1}"
+        # (a truncated episode's buffer reward carries the TimeLimit bootstrap: compared for the agents that go on)
+        alive &= ~(rd > 0)
+        assert_bits_equal(rew[t][alive], rr[alive], f"reward @ {t}")
+        assert_bits_equal(obs[t + 1][alive], ro[alive], f"observation row @ {t + 1}")
+        compared += int(alive.sum())
+    assert compared > 0.5 * N * T, (compared, N * T)
+    env.close()
+
+
+def test_config4_horizon_at_shard_scale_bit_identical_to_oracle():
+    """configs[4] at the shard's size against the ORACLE: the persistent forward half of a BPTT horizon (RacingEnv, 16 384 agents, thrust,
+    the reference's actor) records its actions; the oracle reproduces rewards, done flags and the observation the policy saw at every step,
+    bit for bit, for every agent until its first episode end (max_episode_steps = 40: every first episode ends inside the 48 steps compared)"""
+    import oracle
+    from visfly_amd.bptt import BPTT
+    from visfly_amd.envs import RacingEnv
+    N, H, T = 16384, 64, 48
+    env = RacingEnv(num_agent_per_scene=N, seed=42, dynamics_kwargs=dict(DYN, action_type="thrust"), device="cuda:0", max_episode_steps=40,
+                    requires_grad=True, tensor_output=True)
+    algo = BPTT(env, policy="MultiInputPolicy", horizon=H, gamma=0.99, learning_rate=1e-3, seed=0)
+    fs0 = env.full_state.cpu().numpy()
+    used = []
+    orig = env.rollout_policy
+    env.rollout_policy = lambda *a, **k: used.append(orig(*a, **k)) or used[-1]
+    reward_rows = torch.empty((H, N), device="cuda:0")
+    pol = algo.policy
+    pol.reserve_slots(N, H)
+    eps = torch.randn((H, N, 4), device="cuda:0", generator=algo._gen)
+    acts, drews = torch.empty((H, N, 4), device="cuda:0"), torch.empty((H, N), device="cuda:0")
+    t0 = env._tape_t
+    assert env.rollout_policy(pol, algo.obs_keys, eps, acts, drews, torch.zeros(N, device="cuda:0"), torch.ones(N, device="cuda:0"), 0.99,
+                              1.0 / N, reward_rows=reward_rows), "the shard's horizon is ONE persistent launch"
+    torch.cuda.synchronize()
+    ref = oracle.OracleEnv(env.envs.dynamics.constants, N, "racing", 40, success_radius=float(env.success_radius),
+                           gates=[[4, 4, 1.], [8, 0, 2.], [5, -4, 1.], [1, -1, 1.]])          # RacingEnv.py:87-92 (test_full_size_batch_vs_oracle)
+    ref.reset_full_state(fs0)
+    obs = pol._slot_blocks[N][1]["obs:state"][:T + 1].cpu().numpy()
+    a, rew, done = acts[:T].cpu().numpy(), reward_rows[:T].cpu().numpy(), env._tape_done[t0:t0 + T].cpu().numpy()
+    alive, compared = np.ones(N, bool), 0
+    assert_bits_equal(obs[0], fs0[:, :13], "slot 0 = the spawn states")
+    for t in range(T):
+        ro, rr, rd = ref.step(a[t])
+        assert np.array_equal(done[t][alive] > 0, rd[alive] > 0), f"done @ {t}"
+        assert_bits_equal(rew[t][alive], rr[alive], f"reward @ {t}")
+        compared += int(alive.sum())
+        alive &= ~(rd > 0)
+        assert_bits_equal(obs[t + 1][alive], ro[alive], f"observation of slot {t + 1}")
+    assert not alive.any() and compared > 0.5 * N * 40, (int(alive.sum()), compared)
+    env.close()
+
+
 def test_config4_bptt_update_at_shard_scale_reverse_sweep_equals_autograd():
     from visfly_amd.bptt import BPTT
     from visfly_amd.envs import RacingEnv

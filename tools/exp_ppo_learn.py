@@ -10,7 +10,9 @@ env = NavigationEnv(num_agent_per_scene=N, seed=1, dynamics_kwargs=dict(action_t
                     ctrl_dt=0.02, ctrl_delay=True), random_kwargs=spawn, device="cuda:0", max_episode_steps=128, target=[4., 0., 1.5])
 # third argument "pi=128,128:vf=32": a net_arch without a built-in chain class (compiled on first use, visfly_amd/_jit.py)
 kw = dict(policy_kwargs=dict(activation_fn="relu"))
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2] == "default":       # PPO(env) exactly as the reference policy class defaults it: Tanh trunks (policies.py:108)
+    kw = {}
+elif len(sys.argv) > 2:
     arch = {k: [int(x) for x in v.split(",")] for k, v in (p.split("=") for p in sys.argv[2].split(":"))}
     kw = dict(policy_kwargs=dict(features_extractor_class="StateTargetExtractor", activation_fn="ReLU", net_arch=arch,
                                  features_extractor_kwargs=dict(net_arch=dict(state=dict(layer=[128, 64]), target=dict(layer=[128, 64])))))

@@ -128,6 +128,7 @@ evidence) # r06 evidence for profiles/: the driver's bench command, kernel stats
 functional) # end of the round: soak of the step kernels, PPO learning curve on the built-in class and on the reference's DEFAULT (Tanh) policy
     timeout 1500 python tools/soak_envs.py 50000 2>&1 | grep -v amdgpu.ids | tee $O/soak.txt
     timeout 900 python tools/exp_ppo_learn.py 40 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve.txt
+    timeout 900 python tools/exp_ppo_learn.py 40 default 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve_tanh.txt
     ;;
 tests)    # the whole GPU suite
     timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $O/pytest.txt
