@@ -130,6 +130,24 @@ functional) # end of the round: soak of the step kernels, PPO learning curve on 
     timeout 900 python tools/exp_ppo_learn.py 40 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve.txt
     timeout 900 python tools/exp_ppo_learn.py 40 default 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve_tanh.txt
     ;;
+fold)     # k_wgrad_fold with 8 / 16 / 32 / 64 partial rows in flight per lane (-DVF_FOLD_BATCH=1 / 2 / 4 / 8 builds): parity, A/B of the PPO step, kernel stats
+    timeout 900 python -m pytest tests/test_ppo_gpu.py -x -q -m gpu -k "fused_optimiser_tail or fused_tail or bitwise or fold_partials or weight_grad" 2>&1 | tail -5 | tee $O/pytest.txt
+    for rep in 1 2; do
+        for b in 1 2 4 8; do
+            lib=$R/tools/tmp/libvf_fold$b.so; [ $b = 4 ] && lib=$R/visfly_amd/csrc/libvisfly_amd.so
+            VF_ALT_LIB=$lib timeout 600 python tools/bench_alt.py --workload ppo --no-cpu-baseline 2>&1 | tail -1 > $O/bench_ppo_fold$b.json
+            python - <<PY | tee -a $O/ab.txt
+import json
+d = json.loads(open("$O/bench_ppo_fold$b.json").read())
+print("fold batch $b rep $rep: value %.4g  us/update %.2f  frac %.4f  train ms %.2f" % (d["value"], d["roofline"]["us_per_update"], d["roofline"]["frac"], d["split_ms"]["train"]))
+PY
+        done
+    done
+    for b in 1 4; do
+        lib=$R/tools/tmp/libvf_fold$b.so; [ $b = 4 ] && lib=$R/visfly_amd/csrc/libvisfly_amd.so
+        VF_ALT_LIB=$lib prof ppo_fold$b timeout 300 python $R/tools/bench_alt.py --workload ppo --no-cpu-baseline --steps 256
+    done
+    ;;
 tests)    # the whole GPU suite
     timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $O/pytest.txt
     ;;

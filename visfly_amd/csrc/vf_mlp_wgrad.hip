@@ -200,17 +200,31 @@ __device__ __forceinline__ void wgrad_slab_pick(const vf_mlp_bwd_layer& L, int r
 // the partial rows w = q + 4 u + 32 k in ascending k; a q's chains combine as ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)), the four
 // q's as ((r0 + r1) + r2) + r3.  In k_wgrad_fold q is the wave of the block (the four combine through LDS); in the fused tail one lane
 // walks all 32 chains with rows past the layer read as +0 (adding +0 to a chain that started at +0 changes no bit).
+#ifndef VF_FOLD_BATCH
+#define VF_FOLD_BATCH 1      // rounds of 8 partial rows fetched before the first add (A/B knob: 2 / 4 / 8 rounds = 16 / 32 / 64 loads in flight per lane
+                             // measured 118.8 / 119.6 / 122.3 us per optimiser step against 118.7 for 1 on the same box -- profiles/r06_fused_tail.txt, 7)
+#endif
 __device__ __forceinline__ float fold_chains_q(const float* __restrict__ p, size_t tot, int waves, int q)
 {
     float s4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int w = q;
-    for (; w + 28 < waves; w += 32) {
+    // VF_FOLD_BATCH rounds are fetched before their adds -- the same adds in the same order (chain u takes rows w + 4 u + 32 k in
+    // ascending k): same bits.  More loads in flight per lane do NOT shorten the fold (r06: 800 blocks x 4 waves already cover the latency)
+    // (rows past the layer's block are read as +0: a chain that started at +0 is never -0, so adding +0 changes no bit)
+    for (; w < waves; w += 32 * VF_FOLD_BATCH) {
+        float v[VF_FOLD_BATCH][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s4[u] += p[(size_t)(w + 4 * u) * tot];
+        for (int k = 0; k < VF_FOLD_BATCH; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = w + 32 * k + 4 * u;
+                v[k][u] = row < waves ? p[(size_t)row * tot] : 0.0f;
+            }
+#pragma unroll
+        for (int k = 0; k < VF_FOLD_BATCH; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s4[u] += v[k][u];
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-        if (w + 4 * u < waves) s4[u] += p[(size_t)(w + 4 * u) * tot];
     return ((s4[0] + s4[1]) + (s4[2] + s4[3])) + ((s4[4] + s4[5]) + (s4[6] + s4[7]));
 }
 
