@@ -146,6 +146,38 @@ def test_racing2_replay_matches_reference_run():
         env.step_n(torch.zeros((2, fx["fs_init"].shape[0], 4), device="cuda"))
 
 
+def test_racing2_without_done_list_and_with_reassigned_targets():
+    """RacingEnv2 after enable_done_list(False) steps on the torch expressions (same rows, bit for bit, as the one-launch
+    path that needs the step's done count), and assigning `targets` refreshes the host copy vf_race_obs reads: one-launch rows == torch rows"""
+    from visfly_amd.envs import RacingEnv2
+    N = 512
+    g = torch.Generator().manual_seed(3)
+    acts = [(torch.tensor([-0.8333] * 4) + (torch.rand((N, 4), generator=g) * 2 - 1) * 0.2).clamp(-1, 1).cuda() for _ in range(40)]
+    rows = []
+    for on in (True, False):
+        env = RacingEnv2(num_agent_per_scene=N, seed=4, dynamics_kwargs=dict(RACING_DYN), device="cuda:0", max_episode_steps=12, tensor_output=True)
+        if not on:
+            env.enable_done_list(False)
+        env.reset()
+        out = []
+        for a in acts:
+            obs, r, d, _ = env.step(a)
+            out.append((obs["state"].clone(), obs["gate"].clone(), r.clone(), d.clone()))
+        rows.append(out)
+        if on:      # new gates for the observation: the launch (N > 1 rows) and the torch expressions (row by row) read the same ones
+            env.targets = [[3., 3., 1.], [7., 1., 2.], [4., -3., 1.], [0., -2., 1.5]]
+            raw, gate = env.envs.dynamics.state.detach().contiguous(), env._gate
+            fast = env._race_state(raw, gate)
+            slow = torch.cat([env._race_state(raw[i:i + 1], gate[i:i + 1]) for i in range(8)])
+            assert torch.equal(fast[:8], slow)
+            assert torch.equal(fast[:, 0:3], (env.targets[gate.long() % 4] - raw[:, 0:3]) / torch.full((1,), 10.0, device="cuda:0"))
+        env.close()
+    assert any(bool(x[3].any()) for x in rows[0]), "episodes ended"
+    for k, (a, b) in enumerate(zip(*rows)):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), k
+
+
 def test_device_spawn_statistics_and_conventions():
     """device (Philox) spawn mode: one launch per step; spawn box respected, counters reset, reward/done
     are the pre-reset values, obs the post-reset ones, episode stats consistent."""

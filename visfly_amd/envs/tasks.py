@@ -216,9 +216,22 @@ class RacingEnv2(RacingEnv):
         self.max_sense_radius = 10                                                     # droneGymEnv.py:69
         g = kw.get("gates")
         self.targets = th.as_tensor(_RACING_GATES if g is None else g, dtype=th.float32, device=self.device)
-        self._gates_host = (C.c_float * (3 * len(self.targets)))(*[float(x) for x in self.targets.cpu().reshape(-1).tolist()])
         self._gate_prev = th.zeros_like(self._gate)
         self.enable_done_list()        # vf_race_obs reads the step's done count (which gate index the returned rows use)
+
+    # `targets` (the gates the observation is relative to) is what vf_race_obs reads through a host copy: assigning it refreshes the
+    # copy, so that the one-launch rows, the torch expressions (single / terminal rows) and the caller agree.  (The step
+    # kernel's own gates -- reward, passing, re-spawn -- are the constructor's `gates`, as in RacingEnv.)
+    @property
+    def targets(self):
+        return self._targets
+
+    @targets.setter
+    def targets(self, v):
+        self._targets = v
+        if v is not None:
+            self._targets = th.as_tensor(v, dtype=th.float32).to(getattr(self, "device", "cpu"))
+            self._gates_host = (C.c_float * (3 * len(self._targets)))(*[float(x) for x in self._targets.cpu().reshape(-1).tolist()])
 
     def _after_persistent_launch(self):
         self._last_raw = None          # get_observation() re-reads the raw rows from the slab
@@ -244,8 +257,8 @@ class RacingEnv2(RacingEnv):
     def _step_no_grad(self, _action, is_test=False, **kw):
         """RacingEnv's step with the returned rows formed by ONE launch behind the step kernel (vf_race_obs picks the gate index by
         RacingEnv's rule from the step's done count) instead of a clone, an any(), a where() and the dozen launches of _race_state"""
-        if not self.obs_gate_exact or not self.tensor_output:
-            return super()._step_no_grad(_action, is_test=is_test, **kw)
+        if not self.obs_gate_exact or not self.tensor_output or (getattr(self, "_done_list", None) is None and not is_test):
+            return super()._step_no_grad(_action, is_test=is_test, **kw)      # (enable_done_list(False): the torch path needs no done count)
         self._g_obs = None
         self._gate_prev.copy_(self._gate)
         self._defer_rows = True                    # the base step's own _full_obs call only records the raw rows
@@ -276,10 +289,14 @@ class RacingEnv2(RacingEnv):
         obs = [(g0 - p) / R, (g1 - p) / R, q, v / 10, w / 10] (RacingEnv.py:254-262): dp = -(d[0:3] + d[3:6]) / R, dq = d[6:10],
         dv = d[10:13] / 10, dw = d[13:16] / 10"""
         if d_obs is not None:
-            d = d_obs.to(self.device, dtype=th.float32).reshape(self.num_agent, 16)
+            n3 = 3 * self._next_target_num            # columns of the gate-relative block (6 for the reference's two gates)
+            d = d_obs.to(self.device, dtype=th.float32).reshape(self.num_agent, n3 + 10)
             # divisors as device tensors: IEEE divisions like the persistent launch's race2_obs_bwd (a python scalar becomes x * (1 / s))
             R, ten = th.full((1,), float(self.max_sense_radius), device=self.device), th.full((1,), 10.0, device=self.device)
-            d_obs = th.cat([-(d[:, 0:3] + d[:, 3:6]) / R, d[:, 6:10], d[:, 10:13] / ten, d[:, 13:16] / ten], dim=1)
+            dp = d[:, 0:3]
+            for j in range(1, self._next_target_num):
+                dp = dp + d[:, 3 * j:3 * j + 3]
+            d_obs = th.cat([-dp / R, d[:, n3:n3 + 4], d[:, n3 + 4:n3 + 7] / ten, d[:, n3 + 7:n3 + 10] / ten], dim=1)
         return super().backward_step(t, d_obs, d_reward)
 
     def _full_obs(self, state, raw=False):          # RacingEnv's rules for WHICH gate index the returned rows use apply unchanged
