@@ -267,7 +267,9 @@ def _flat(mods, grad=False):
     return np.concatenate(out)
 
 
-def gen_shac(name="shac_hover", N=64, H=8, seed=42, gradient_steps=3, lr=1e-3, tau=0.005):
+def gen_shac(name="shac_hover", N=64, H=8, seed=42, gradient_steps=3, lr=1e-3, tau=0.005, share=False):
+    """share: MTDPolicy(share_features_extractor=True) -- the critic runs the ACTOR's features extractor under no_grad and its optimiser
+    leaves it alone (SACPolicy._build; td_policies.py:127), the target keeps its own, Polyak-averaged copy (fixture shac_hover_shared)"""
     sp = _install_sb3()
     HoverEnvShim, _, _ = G.import_envs()
     G.use_cr_sqrt(True)
@@ -305,7 +307,7 @@ def gen_shac(name="shac_hover", N=64, H=8, seed=42, gradient_steps=3, lr=1e-3, t
     consts = G.extract_consts(env.envs.dynamics)
     policy_kwargs = dict(features_extractor_class=E.StateExtractor,
                          features_extractor_kwargs={"net_arch": {"state": {"layer": [128, 64]}}},
-                         net_arch=dict(pi=[64, 64], qf=[64, 64]), activation_fn=nn.ReLU, share_features_extractor=False)
+                         net_arch=dict(pi=[64, 64], qf=[64, 64]), activation_fn=nn.ReLU, share_features_extractor=bool(share))
     th.manual_seed(seed + 1)                                     # network initialisation (nn.Linear defaults)
     import copy as _copy
     real_deepcopy = _copy.deepcopy
@@ -315,6 +317,7 @@ def gen_shac(name="shac_hover", N=64, H=8, seed=42, gradient_steps=3, lr=1e-3, t
     algo._create_logger = lambda **kw: types.SimpleNamespace(record=lambda *a, **k: None, dump=lambda *a, **k: None)
     actor, critic, target = algo.policy.actor, algo.policy.critic, algo.policy.critic_target
     assert type(actor).__module__.endswith("td_policies") and type(critic).__module__.endswith("td_policies")
+    assert (critic.features_extractor is actor.features_extractor) == bool(share)
     # de-correlate the two actor trunks (log_latent_pi is a deepcopy of latent_pi) and the heads, so that a wiring mix-up shows
     with th.no_grad():
         g = th.Generator().manual_seed(seed + 2)
@@ -342,7 +345,8 @@ def gen_shac(name="shac_hover", N=64, H=8, seed=42, gradient_steps=3, lr=1e-3, t
 
     def clip_rec(params, max_norm, *a, **k):
         params = list(params)
-        which = "actor" if params[0] is next(actor.parameters()) else "critic"
+        q0 = next(critic.qf0.parameters())             # (with a shared extractor the critic's first parameter IS the actor's)
+        which = "critic" if any(p is q0 for p in params) else "actor"
         lin = a_lin if which == "actor" else c_lin
         rec["clip"].append((which, _flat(lin, grad=True), float(max_norm)))
         return real_clip(params, max_norm, *a, **k)
@@ -559,13 +563,15 @@ def gen_bptt_loop(name="bptt_loop_hover", N=64, H=8, seed=42, lr=1e-3):
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default=None, choices=[None, "shac_hover", "bptt_loop_hover"])
+    ap.add_argument("--only", default=None, choices=[None, "shac_hover", "shac_hover_shared", "bptt_loop_hover"])
     a = ap.parse_args()
     if a.only == "bptt_loop_hover":
         gen_bptt_loop()
     elif a.only == "shac_hover":
         gen_shac()
+    elif a.only == "shac_hover_shared":
+        gen_shac(name="shac_hover_shared", share=True)
     else:          # separate interpreters: both patch module-level state of the imported reference
         import subprocess
-        for n in ("shac_hover", "bptt_loop_hover"):
+        for n in ("shac_hover", "shac_hover_shared", "bptt_loop_hover"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--only", n])

@@ -130,3 +130,44 @@ def test_bptt_loop_loss_recurrence_and_adam_step():
     step = float(fx["lr"]) * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)
     assert np.abs(fx["actor_params0"] - step - fx["actor_params1"]).max() <= 2e-7
     assert fx["actor_params0"].size == 13 * 128 + 128 + 128 * 64 + 64 + 2 * (64 * 64 + 64) * 2 + 2 * (64 * 4 + 4)
+
+
+def test_shared_extractor_fixture_means_what_the_gpu_test_assumes():
+    """tests/golden/shac_hover_shared.npz (oracle/gen_shac.py --only shac_hover_shared: MTDPolicy(share_features_extractor=True)): the critic's
+    extractor block IS the actor's -- before and after the actor step, untouched by the critic steps --, the extractor block of the gradient
+    clip_grad_norm_(critic.parameters()) saw is the actor loss's gradient (x the clip coefficients applied so far), the q-network part is the
+    twin-Q gradient with the features detached, and the target's own extractor follows by Polyak averaging"""
+    fx = load("shac_hover_shared")
+    e = 13 * 128 + 128 + 128 * 64 + 64
+    assert np.array_equal(fx["critic_params0"][:e], fx["actor_params0"][:e])
+    steps = int(fx["gradient_steps"])
+    for i in range(steps):
+        assert np.array_equal(fx["critic_params"][i][:e], fx["actor_params1"][:e]), "the critic's optimiser never touches the shared extractor"
+    # stale extractor gradient: the actor's (clip coefficient 1 here: |g_actor| << 0.5), rescaled in place by every critic clip
+    na = float(np.linalg.norm(fx["actor_grad"].astype(np.float64)))
+    assert na < 0.5
+    stale = fx["actor_grad"][:e].astype(np.float64)
+    for i in range(steps):
+        assert np.abs(fx["critic_grad"][i][:e] - stale).max() <= 1e-7 * max(np.abs(stale).max(), 1e-30) + 1e-12
+        n = float(np.linalg.norm(fx["critic_grad"][i].astype(np.float64)))
+        stale = stale * min(1.0, 0.5 / (n + 1e-6))
+    # q-network gradient at the recorded parameters, features detached
+    H, N = fx["buf_reward"].shape
+    obs = torch.from_numpy(fx["buf_obs"].reshape(H * N, 13)).double()
+    act = torch.from_numpy(fx["buf_action"].reshape(H * N, 4)).double()
+    ret = torch.from_numpy(fx["buf_returns"].reshape(-1)).double()
+    prm = fx["critic_params0"].copy()
+    prm[:e] = fx["actor_params1"][:e]
+    p, qs = _critic(prm, obs, act)
+    loss = torch.nn.functional.mse_loss(ret, torch.minimum(qs[0], qs[1]).view(-1))
+    loss.backward()
+    assert abs(float(loss) - float(fx["critic_loss"][0])) <= 1e-6
+    g = p.grad.numpy()
+    assert np.abs(g[e:] - fx["critic_grad"][0][e:]).max() <= 2e-6 * np.abs(g[e:]).max()
+    # Polyak over ALL critic parameters, the shared extractor included (shac.py:277)
+    tau = float(fx["tau"])
+    t = fx["critic_params0"].astype(np.float64)
+    for i in range(steps):
+        t = (1 - tau) * t + tau * fx["critic_params"][i].astype(np.float64)
+        assert np.abs(t - fx["target_params"][i]).max() <= 2e-7
+    assert not np.array_equal(fx["target_params"][-1][:e], fx["critic_params"][-1][:e])

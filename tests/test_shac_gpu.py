@@ -26,7 +26,7 @@ PK = dict(features_extractor_class="StateExtractor", features_extractor_kwargs={
           net_arch=dict(pi=[64, 64], qf=[64, 64]), activation_fn="relu", share_features_extractor=False)
 
 
-def make(fx, **kw):
+def make(fx, share=False, **kw):
     from visfly_amd.envs import HoverEnv
     from visfly_amd.shac import SHAC
     N = fx["fs_init"].shape[0]
@@ -35,7 +35,7 @@ def make(fx, **kw):
                    random_kwargs=ast.literal_eval(str(fx["spawn"])), spawn="replay", replay_trig="cr", constants=consts_of(fx))
     env.reset()
     assert_bits_equal(env.full_state.cpu().numpy(), fx["fs_init"], "spawn states of the replayed stream")
-    algo = SHAC(env, policy_kwargs=dict(PK), horizon=int(fx["H"]), tau=float(fx["tau"]), gamma=float(fx["gamma"]),
+    algo = SHAC(env, policy_kwargs=dict(PK, share_features_extractor=share), horizon=int(fx["H"]), tau=float(fx["tau"]), gamma=float(fx["gamma"]),
                 gradient_steps=int(fx["gradient_steps"]), learning_rate=float(fx["lr"]), seed=int(fx["seed"]), **kw)
     a, c = algo.policy, algo.critic
     assert a.n_params == fx["actor_params0"].size == a.n_total and c.n_params == fx["critic_params0"].size == c.n_total - 20
@@ -144,6 +144,72 @@ def test_one_iteration_matches_the_reference_loop():
     assert float(np.linalg.norm(fx["critic_grad"][0])) > 0.5 > float(np.linalg.norm(fx["critic_grad"][-1]))   # both clip branches
     ident = n(tg.flat[c.n_params:]).reshape(-1)
     assert np.array_equal(ident[:16].reshape(4, 4), np.eye(4, dtype=np.float32)) and not ident[16:].any()   # the frozen block stays I
+    env.close()
+    env2.close()
+
+
+def test_one_iteration_with_a_shared_extractor_matches_the_reference_loop():
+    """r06: MTDPolicy(share_features_extractor=True) (td_policies.py:127; SB3 SACPolicy._build) -- tests/golden/shac_hover_shared.npz is ONE
+    iteration of the reference's learn() with that flag (oracle/gen_shac.py --only shac_hover_shared).  The critic runs the ACTOR's extractor
+    (its parameters follow the actor step, its optimiser leaves them alone, the gradient clip_grad_norm_ sees for them is the actor loss's,
+    still sitting in .grad), the target keeps its own Polyak-averaged extractor.  Stages and tolerances of
+    test_one_iteration_matches_the_reference_loop"""
+    fx = load("shac_hover_shared")
+    env, algo = make(fx, share=True)
+    H, N = int(fx["H"]), fx["fs_init"].shape[0]
+    a, c, tg = algo.policy, algo.critic, algo.critic_target
+    e = algo._ext_end
+    assert e == 13 * 128 + 128 + 128 * 64 + 64 and np.array_equal(fx["actor_params0"][:e], fx["critic_params0"][:e])
+    n = lambda t: t.cpu().numpy()
+    algo._eps_override = torch.from_numpy(fx["eps"]).to(DEV)
+    loss = algo._grad_reverse_sweep()
+    b = algo._buf
+    for got, want, what in ((b["obs"]["state"], fx["buf_obs"], "observations"), (b["action"], fx["buf_action"], "actions"),
+                            (b["reward"], fx["buf_reward"], "rewards"), (b["next_value"], fx["buf_next_value"], "next values")):
+        assert np.abs(n(got) - want).max() <= 1e-6, what
+    assert abs(float(loss) - float(fx["actor_loss"])) <= 2e-6
+    blocks_close(n(a.grad), fx["actor_grad"], a, 2e-5, 1e-3, "actor gradient")
+    # the actor step from the reference's own gradient, then what follows it in the shared mode
+    a.grad.copy_(torch.from_numpy(fx["actor_grad"]))
+    algo._apply(loss)
+    algo._after_actor_step()
+    assert np.abs(n(a.flat[:a.n_params]) - fx["actor_params1"]).max() <= 2e-7
+    assert torch.equal(c.flat[:e], a.flat[:e]), "the critic's extractor IS the actor's"
+    assert np.abs(n(c.flat[:e]) - fx["critic_params"][0][:e]).max() <= 2e-7
+    f = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    obs, act, target = {"state": f(fx["buf_obs"]).view(H * N, 13)}, f(fx["buf_action"]).view(H * N, 4), f(fx["buf_returns"]).view(-1)
+    stale0 = algo._stale_ext.clone()
+    for i in range(int(fx["gradient_steps"])):
+        # loss and gradient at the REFERENCE's parameters of this step (its extractor block = the actor's after its step)
+        prev = fx["critic_params0"] if i == 0 else fx["critic_params"][i - 1]
+        c.flat[e:c.n_params].copy_(torch.from_numpy(prev[e:]))
+        c.mark_updated()
+        tg.flat[:c.n_params].copy_(torch.from_numpy(fx["critic_params0"] if i == 0 else fx["target_params"][i - 1]))
+        algo._stale_ext.copy_(torch.from_numpy(fx["critic_grad"][i][:e]))        # (exactly what the reference's clip saw; checked against ours below)
+        loss_c = algo._critic_step_once(obs, act, target)
+        assert abs(float(loss_c) - float(fx["critic_loss"][i])) <= 1e-5 * max(1.0, abs(float(fx["critic_loss"][i])))
+        blocks_close(n(c.grad), fx["critic_grad"][i], c, 2e-5, 1e-3, f"critic gradient, step {i}")
+    # the extractor block of the gradient the reference's clip saw at step 0 = the actor loss's gradient x the actor's clip coefficient
+    assert np.abs(n(stale0) - fx["critic_grad"][0][:e]).max() <= 1e-6 * max(np.abs(fx["critic_grad"][0][:e]).max(), 1e-12) + 1e-12
+    # the optimiser trajectory from the reference's own gradients: clip + Adam on the q networks only, extractor untouched, Polyak over everything
+    env2, algo2 = make(fx, share=True)
+    a2, c2, tg2 = algo2.policy, algo2.critic, algo2.critic_target
+    a2.flat[:a2.n_params].copy_(torch.from_numpy(fx["actor_params1"]))
+    a2.mark_updated()
+    algo2._sync_shared_extractor()
+    for i in range(int(fx["gradient_steps"])):
+        algo2._stale_ext.copy_(torch.from_numpy(fx["critic_grad"][i][:e]))
+        algo2._critic_grad_override = torch.from_numpy(fx["critic_grad"][i]).to(DEV)
+        algo2._critic_step_once(obs, act, target)
+        assert np.abs(n(c2.flat[:c2.n_params]) - fx["critic_params"][i]).max() <= 2e-7, f"critic parameters after step {i}"
+        assert np.abs(n(tg2.flat[:c2.n_params]) - fx["target_params"][i]).max() <= 2e-7, f"target parameters after step {i}"
+        assert torch.equal(c2.flat[:e], a2.flat[:e]) and not algo2.c_exp_avg[:e].any() and not algo2.c_exp_avg_sq[:e].any()
+    assert not np.array_equal(fx["target_params"][-1][:e], fx["critic_params"][-1][:e]), "the target keeps its own extractor"
+    # ... and the loop as a whole runs in this mode
+    algo2._critic_grad_override = None
+    algo2._eps_override = None
+    algo2.learn(2 * H * N)
+    assert torch.equal(c2.flat[:e], a2.flat[:e]) and torch.isfinite(c2.flat).all() and torch.isfinite(a2.flat).all()
     env.close()
     env2.close()
 

@@ -119,9 +119,9 @@ class BPTT:
         if isinstance(na, dict) and "qf" in na:                       # SB3 get_actor_critic_arch: dict(pi=..., qf=...)
             self._critic_arch = list(na["qf"])
             pk["net_arch"] = dict(pi=list(na["pi"]), vf=list(na["pi"]))
-        if pk.get("share_features_extractor"):
-            raise NotImplementedError("share_features_extractor=True: the critic here owns its extractor (the reference default)")
-        pk.pop("share_features_extractor", None)
+        # share_features_extractor=True (td_policies.py:127, SACPolicy._build): the critic runs the ACTOR's extractor under no_grad.  BPTT has
+        # no critic (nothing changes); SHAC reads the flag (shac.py: _share_extractor)
+        self._share_extractor = bool(pk.pop("share_features_extractor", False))
         if any(k in pk for k in ("features_extractor_class", "net_arch", "features_extractor_kwargs", "activation_fn")):
             pk.setdefault("activation_fn", "relu")                    # MTDPolicy's default activation IS ReLU (td_policies.py:297)
         pk.setdefault("activation_fn", "relu")

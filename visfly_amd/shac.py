@@ -6,7 +6,8 @@ Restates ``TemporalDifferBase.learn`` of the reference (utils/algorithms/shac.py
 * **Actor** (:146-252): features extractor -> two trunks of identical shape, ``latent_pi -> mu`` (4) and ``log_latent_pi ->
   log_std`` (4, clamped to [-10, 2], :31-32,241-243); action = tanh(mu + eps * exp(log_std)) (SB3's squashed Gaussian).  One
   ``MlpPolicy`` layer table with two 4-wide heads; ``log_latent_pi`` starts as a copy of ``latent_pi`` (:205).
-* **Critic** (:82-143): its OWN features extractor (``share_features_extractor=False``, trained by the critic loss),
+* **Critic** (:82-143): its OWN features extractor (``share_features_extractor=False``, the reference's default: trained by the critic loss;
+  with ``True`` the critic runs the actor's extractor under no_grad and its optimiser leaves it alone -- r06, fixture ``shac_hover_shared``),
   ``th.cat([features, actions])`` -> two Q MLPs ``qf0`` / ``qf1`` -> 1.  One layer table: extractor branch + a frozen identity
   branch that appends the 4 action columns to the features, two trunks with 1-wide heads; a second instance is the target.
 
@@ -63,6 +64,16 @@ class SHAC(BPTT):
                                  ortho_init=False, head_dims=(1, 1), passthrough=("action",), log_std_param=False)
         self.critic, self.critic_target = mk(seed + 101), mk(seed + 101)
         parallel.broadcast_(self.critic.flat)
+        # share_features_extractor=True (td_policies.py:127; SB3 SACPolicy._build): critic.features_extractor IS the actor's -- run under
+        # no_grad, left alone by the critic's optimiser; the TARGET keeps its own copy (initialised from it, Polyak-averaged with the rest).
+        # Here: the critic's extractor block of `flat` mirrors the actor's (same layer order and offsets: extractor layers lead both tables)
+        self._share_extractor = bool(getattr(self, "_share_extractor", False))
+        self._ext_end = sum(ly.K * ly.No + ly.No for ly in self._ext_layers()) if self._share_extractor else 0
+        self._stale_ext = th.zeros(self._ext_end, device=dev) if self._share_extractor else None
+        if self._share_extractor:
+            assert [(ly.K, ly.No, ly.w_off) for ly in self.critic.layers[:len(self._ext_layers())]] == \
+                   [(ly.K, ly.No, ly.w_off) for ly in pol.layers[:len(self._ext_layers())]], "extractor blocks of actor and critic differ"
+            self._sync_shared_extractor()
         self.critic_target.flat.copy_(self.critic.flat)                              # critic_target.load_state_dict(critic.state_dict())
         for net in (self.critic, self.critic_target):
             net.lazy_pack = True
@@ -73,6 +84,23 @@ class SHAC(BPTT):
         self._critic_step = 0
         self._buf = None
         # _eps_override (tests): (2H, N, 4) noise feed, [2t] = action of step t, [2t+1] = next action
+
+    def _ext_layers(self):
+        return [ly for ly in self.critic.layers if not ly.frozen and (ly.dst == "feat" or ly.dst.startswith("x:"))]
+
+    def _sync_shared_extractor(self):
+        """share_features_extractor: the critic's extractor parameters ARE the actor's (after every actor step)"""
+        self.critic.flat[:self._ext_end].copy_(self.policy.flat[:self._ext_end])
+        self.critic.mark_updated()
+
+    def _after_actor_step(self):
+        """share_features_extractor: the shared extractor's .grad still holds the actor loss's gradient, scaled by the actor's clip
+        (clip_grad_norm_ works in place; the critic's optimizer.zero_grad() does not touch parameters it does not own), and
+        clip_grad_norm_(critic.parameters()) (shac.py:274) counts it; the critic sees the actor's NEW extractor"""
+        if self._share_extractor:
+            coef = th.clamp(self.max_grad_norm / (self._sumsq.sqrt() + 1e-6), max=1.0)
+            self._stale_ext.copy_(self.policy.grad[:self._ext_end] * coef)             # (policy.grad: summed over the ranks by _apply)
+            self._sync_shared_extractor()
 
     # ---- networks ---------------------------------------------------------------------------------------------------------
     # the Actor (extractor -> latent_pi -> mu | log_latent_pi -> log_std) and its action head are BPTT's reference-actor path
@@ -199,6 +227,7 @@ class SHAC(BPTT):
     def _update(self):
         loss = self._grad_reverse_sweep()
         out = self._apply(loss)                                                        # clip 0.5 + Adam + env.detach() :271-277
+        self._after_actor_step()
         b, N, H = self._buf, self.env.num_envs, self.H
         L, st = _lib.lib(), _lib.current_stream(self.device)
         returns = th.empty((H, N), device=self.device)
@@ -240,6 +269,10 @@ class SHAC(BPTT):
                                         M * self.world, st))
             c.backward(dq0.view(M, 1), dq1.view(M, 1), None)
         parallel.allreduce_sum_(c.grad)
+        if getattr(self, "_critic_grad_override", None) is not None:      # tests: the optimiser trajectory from recorded gradients
+            c.grad.copy_(self._critic_grad_override)
+        if self._share_extractor:          # no gradient reaches the shared extractor from the critic loss; what its .grad holds is the actor's (above)
+            c.grad[:self._ext_end].copy_(self._stale_ext)
         self._last_critic_grad = c.grad
         _lib.check(L.vf_sumsq(_ptr(c.grad), c.n_params, _ptr(self._c_sumsq), _ptr(self._scratch), st))
         self._critic_step += 1
@@ -249,6 +282,14 @@ class SHAC(BPTT):
         _lib.check(L.vf_adam_step(_ptr(c.flat), _ptr(c.grad), _ptr(self.c_exp_avg), _ptr(self.c_exp_avg_sq), c.n_params,
                                   _ptr(self._c_sumsq), C.byref(cfg), st))
         c.mark_updated(packed_current=pmap is not None)
+        if self._share_extractor:
+            # the critic's optimiser does not own the extractor: its parameters stay the actor's, its moments never existed; the clip
+            # rescaled the stale gradient in place
+            e = self._ext_end
+            self._stale_ext.mul_(th.clamp(self.max_grad_norm / (self._c_sumsq.sqrt() + 1e-6), max=1.0))
+            self.c_exp_avg[:e].zero_()
+            self.c_exp_avg_sq[:e].zero_()
+            self._sync_shared_extractor()
         tg = self.critic_target
         _lib.check(L.vf_polyak_update(_ptr(tg.flat), _ptr(c.flat), c.n_params, float(self.tau), st))    # trainable part only
         tg.mark_updated()
