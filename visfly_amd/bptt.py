@@ -367,7 +367,8 @@ class BPTT:
         return {"actor": self.policy.flat.cpu(), "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
                 "opt_step": int(self._opt_step), "num_timesteps": int(self.num_timesteps), "rng": self._gen.get_state().cpu(),
                 "spec": dict(extractor=self._extractor, pi=self.policy.spec["pi"], qf=self._critic_arch, horizon=self.H,
-                             gamma=self.gamma, learning_rate=self.lr, algo=type(self).__name__)}
+                             gamma=self.gamma, learning_rate=self.lr, algo=type(self).__name__,
+                             share_features_extractor=bool(getattr(self, "_share_extractor", False)))}
 
     def _load_state(self, d, load_optimizer=True):
         assert d["actor"].numel() == self.policy.flat.numel(), "actor: the archive holds a different network (pass the same policy_kwargs, or use load())"
@@ -395,7 +396,8 @@ class BPTT:
         """the stored network shapes as SB3-style policy_kwargs (what _make_reference_actor parses)"""
         return dict(features_extractor_class="StateTargetExtractor" if len(spec["extractor"]) > 1 else "StateExtractor",
                     features_extractor_kwargs={"net_arch": {k: {"layer": list(v)} for k, v in spec["extractor"].items()}},
-                    net_arch=dict(pi=list(spec["pi"]), qf=list(spec["qf"])), activation_fn="relu")
+                    net_arch=dict(pi=list(spec["pi"]), qf=list(spec["qf"])), activation_fn="relu",
+                    share_features_extractor=bool(spec.get("share_features_extractor", False)))
 
     @classmethod
     def load(cls, path: str, env, **kwargs):
