@@ -1077,7 +1077,9 @@ def test_persistent_rollout_equals_the_per_step_loop(env_name, N, dyn):
 
 
 @pytest.mark.parametrize("env_name,N,dyn,net", [("NavigationEnv", 3000, "euler", "verdict"), ("HoverEnv", 16401, "rk4_nodelay", "one_layer_extractor"),
-                                                ("NavigationEnv2", 3000, "euler", "one_layer_extractor")])      # (Nav2: the target is inside the one "state" row)
+                                                ("NavigationEnv2", 3000, "euler", "one_layer_extractor"),       # (Nav2: the target is inside the one "state" row)
+                                                ("RacingEnv", 3000, "euler", "one_layer_extractor"),
+                                                ("RacingEnv2", 3000, "euler", "one_layer_extractor")])          # (r06: 16 gate-relative columns: kernel-side kind VF_ENV_RACING2)
 def test_persistent_rollout_of_a_generated_class_equals_the_per_step_loop(env_name, N, dyn, net):
     """r05: a network shape without a built-in chain class gets its roll-out launch as one more plugin, compiled on first use for the env
     kind / action type / integrator / motor-lag setting (visfly_amd/_jit.py: ensure_rollout; csrc/vf_ppo_rollout_kernel.hpp) -- the same

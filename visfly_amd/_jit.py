@@ -66,7 +66,8 @@ PREBUILD_SAC = {
 # ... and the BPTT plugins (both persistent launches of a horizon) tests/test_chain_jit_gpu.py runs: (shape name in PREBUILD_SAC / PREBUILD,
 # (kernel-side env kind, VF_ACT_*, VF_INT_*, ctrl_delay))
 PREBUILD_BPTT = [("sac_hover", (0, 1, 0, True)), ("sac_nav_bptt", (1, 1, 0, True)), ("one_layer_extractor", (0, 0, 0, True))]
-PREBUILD_ROLLOUT = [("verdict", (1, 1, 0, True)), ("one_layer_extractor", (0, 1, 1, False)), ("one_layer_extractor", (1, 1, 0, True))]
+PREBUILD_ROLLOUT = [("verdict", (1, 1, 0, True)), ("one_layer_extractor", (0, 1, 1, False)), ("one_layer_extractor", (1, 1, 0, True)),
+                    ("one_layer_extractor", (2, 1, 0, True)), ("one_layer_extractor", (3, 1, 0, True))]      # RacingEnv / RacingEnv2 (kernel-side kind 3)
 
 
 def shape_of(obs_dims, extractor, pi, vf, head_dims=(4, 1), passthrough=(), acts=(1, 1)):

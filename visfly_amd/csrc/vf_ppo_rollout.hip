@@ -96,11 +96,12 @@ extern "C" int vf_ppo_rollout(vf_env* h, const vf_mlp_desc* desc, const float* p
     } else {
         // a generated class: its roll-out plugin, compiled on first use for this env kind / dynamics configuration (visfly_amd/_jit.py)
         int rc = 0;
-        for (int i = 0; i < vf::chain_plugin_count() && rc == 0; ++i) {
+        // (only for the observation width the env kind's epilogue forms: a class padded to the same 16 input columns matches 13- and 16-wide rows alike)
+        for (int i = 0; i < vf::chain_plugin_count() && rc == 0 && desc->in_dim[0] == OW; ++i) {
             const vf::ChainPlugin* p = vf::chain_plugin(i);
             if (p->ppo_rollout && p->rollout_abi == vf::kRolloutPluginAbi)
-                rc = p->ppo_rollout(desc, h->cfg.kind, &h->dyn.cfg, a->obs_target != nullptr, h->dyn.d_cfg, h->d_cfg, &ge, &gc, &r, N,
-                                    vf::as_stream(stream));
+                rc = p->ppo_rollout(desc, race2 ? vf::VF_ENV_RACING2 : h->cfg.kind, &h->dyn.cfg, a->obs_target != nullptr, h->dyn.d_cfg, h->d_cfg,
+                                    &ge, &gc, &r, N, vf::as_stream(stream));      // (the KERNEL-side kind: RacingEnv2's 16 columns are formed by the epilogue)
         }
         if (rc <= -1000) return vf::fail(VF_EHIP, "vf_ppo_rollout (chain plugin) failed: %s", hipGetErrorString((hipError_t)(-rc - 1000)));
         if (rc == 0)

@@ -986,7 +986,8 @@ class DroneGymEnvsBase:
             try:
                 from .. import _jit
                 c = self.envs.dynamics.constants
-                _jit.ensure_rollout(policy.chain_shape, (self.KIND, int(c["action_type"]), int(c["integrator"]), bool(c["ctrl_delay"])))
+                kind = 3 if W == 16 else self.KIND          # kernel-side kind: VF_ENV_RACING2 forms RacingEnv2's 16 columns itself
+                _jit.ensure_rollout(policy.chain_shape, (kind, int(c["action_type"]), int(c["integrator"]), bool(c["ctrl_delay"])))
             except Exception as e:          # no hipcc, ...: launch by launch, with the warning below
                 import warnings
                 warnings.warn(f"visfly_amd: no roll-out plugin for this network ({e})")
