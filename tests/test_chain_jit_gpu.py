@@ -483,13 +483,17 @@ def _bptt_env(kind, N):
     if kind == "nav":
         return E.NavigationEnv(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(ENV_DYN), device=DEV, max_episode_steps=7, requires_grad=True,
                                tensor_output=True, random_kwargs=spawn)
+    if kind == "racing2":          # 16 gate-relative columns, formed and differentiated inside the launches (kernel-side kind VF_ENV_RACING2)
+        from _golden import RACING_DYN
+        return E.RacingEnv2(num_agent_per_scene=N, seed=5, dynamics_kwargs=dict(RACING_DYN), device=DEV, max_episode_steps=7, requires_grad=True,
+                            tensor_output=True)
     dkw = dict(ENV_DYN, action_type="thrust") if kind == "hover_thrust" else dict(ENV_DYN)
     return E.HoverEnv(num_agent_per_scene=N, seed=5, dynamics_kwargs=dkw, device=DEV, max_episode_steps=7, requires_grad=True, tensor_output=True)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", [1000, 4096])
-@pytest.mark.parametrize("kind", ["hover", "nav"])
+@pytest.mark.parametrize("kind", ["hover", "nav", "racing2"])
 def test_persistent_launches_of_a_generated_reference_actor_equal_the_loop(kind, N):
     """r06: BPTT(policy="MultiInputPolicy", net_arch=non-default) on the persistent launches of its GENERATED actor
     class (the BPTT plugin: k_bptt_rollout / k_bptt_reverse instances for ChainNetG<Spec>, 16 agents per wave) against the launch-by-launch

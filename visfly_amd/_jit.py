@@ -65,7 +65,8 @@ PREBUILD_SAC = {
 # ... and their roll-out plugins for the configurations tests/test_ppo_gpu.py runs: (shape name, (VF_ENV_*, VF_ACT_*, VF_INT_*, ctrl_delay))
 # ... and the BPTT plugins (both persistent launches of a horizon) tests/test_chain_jit_gpu.py runs: (shape name in PREBUILD_SAC / PREBUILD,
 # (kernel-side env kind, VF_ACT_*, VF_INT_*, ctrl_delay))
-PREBUILD_BPTT = [("sac_hover", (0, 1, 0, True)), ("sac_nav_bptt", (1, 1, 0, True)), ("one_layer_extractor", (0, 0, 0, True))]
+PREBUILD_BPTT = [("sac_hover", (0, 1, 0, True)), ("sac_nav_bptt", (1, 1, 0, True)), ("one_layer_extractor", (0, 0, 0, True)),
+                 ("sac_hover", (3, 0, 0, True))]        # RacingEnv2: kernel-side kind VF_ENV_RACING2, thrust
 PREBUILD_ROLLOUT = [("verdict", (1, 1, 0, True)), ("one_layer_extractor", (0, 1, 1, False)), ("one_layer_extractor", (1, 1, 0, True)),
                     ("one_layer_extractor", (2, 1, 0, True)), ("one_layer_extractor", (3, 1, 0, True))]      # RacingEnv / RacingEnv2 (kernel-side kind 3)
 
