@@ -323,7 +323,8 @@ FAST_SPAWN = {"state_generator": {"class": "Uniform", "kwargs": [{"position": {"
 
 
 @pytest.mark.parametrize("N,H,steps,spawn", [(2048, 16, 20, None), (1000, 8, 5, None), (7, 6, 4, None), (3000, 12, 30, FAST_SPAWN),
-                                             (1500, 8, 6, "NavigationEnv2"), (900, 8, 6, "HoverEnv2"), (1200, 8, 6, "RacingEnv2")])
+                                             (1500, 8, 6, "NavigationEnv2"), (900, 8, 6, "HoverEnv2"), (1200, 8, 6, "RacingEnv2"),
+                                             (1100, 8, 6, "generated"), (700, 8, 6, "generated:HoverEnv2")])
 def test_persistent_launches_equal_the_loop(N, H, steps, spawn):
     """SHAC's horizon on vf_bptt_rollout / vf_bptt_reverse (actor class (b)) + the next-action / target-critic terms evaluated over the
     recorded horizon, against the launch-by-launch loop: horizon buffer (observations, actions, rewards, done / episode_done, next
@@ -335,12 +336,21 @@ def test_persistent_launches_equal_the_loop(N, H, steps, spawn):
     # r05: the observation / reward variants (their adjoint is obs_variant_bwd + the NAV2 reward gradient) run SHAC on the persistent
     # launches too -- NavigationEnv2 = the Navigation env kind under the one-observation actor (vf_bptt_*_nav2.hip)
     # r06: RacingEnv2 -- the 16 gate-relative columns inside the launches (kernel-side kind VF_ENV_RACING2)
+    # r06: "generated": a non-default net_arch -- actor AND twin critic are generated chain classes, the horizon runs from the actor
+    # class's BPTT plugin (visfly_amd/_jit.py: PREBUILD_SAC["sac_hover"] / PREBUILD_CRITIC["critic_hover"] / PREBUILD_BPTT)
+    pk = dict(PK)
+    if isinstance(spawn, str) and spawn.startswith("generated"):
+        pk = dict(features_extractor_class="StateExtractor", features_extractor_kwargs={"net_arch": {"state": {"layer": [64, 64, 32]}}},
+                  net_arch=dict(pi=[32], qf=[32]), activation_fn="relu", share_features_extractor=False)
+        spawn = spawn.partition(":")[2] or None
+    generated = pk != PK
     cls, spawn = (getattr(E, spawn), None) if isinstance(spawn, str) else (E.HoverEnv, spawn)
     res = []
     for fused in (True, False):
         env = cls(num_agent_per_scene=N, seed=3, dynamics_kwargs=dict(ENV_DYN), device=DEV, tensor_output=True, requires_grad=True,
                   max_episode_steps=steps, **({} if spawn is None else {"random_kwargs": spawn}))
-        algo = SHAC(env, policy_kwargs=dict(PK), horizon=H, gradient_steps=2, learning_rate=1e-3, seed=7)
+        algo = SHAC(env, policy_kwargs=dict(pk), horizon=H, gradient_steps=2, learning_rate=1e-3, seed=7)
+        assert algo.policy.chain_jit == generated and algo.critic.chain_jit == generated
         algo.fused_rollout = algo.fused_reverse = fused
         used = []
         orig = env.rollout_policy
