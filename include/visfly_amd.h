@@ -548,12 +548,17 @@ int64_t vf_mlp_packed_floats(const vf_mlp_desc* desc);
  * up to 128): the host side generates a translation unit that names the shape (csrc/vf_mlp_chain_gen.hpp), compiles it with hipcc on
  * first use into a shared object next to the library (visfly_amd/_jit.py) and registers it here.  vf_mlp_forward, vf_mlp_backward_data,
  * vf_ppo_update and their relatives then ask the loaded plugins after the built-in classes.  A plugin compiled against other struct
- * layouts is refused (VF_EINVAL).  Loading the same path twice is a no-op. */
+ * layouts is refused (VF_EINVAL).  Loading the same path twice is a no-op.
+ * r06 (no new entry point; ABI 10): a class carries its activations (VF_ACTIVATION_*); the twin critic (heads 1 / 1 behind a pass-through
+ * input, vf_mlp_desc.identity_mask) has generated classes too, served by vf_mlp_forward / vf_mlp_backward_data / vf_twin_q_update; and a
+ * generated ACTOR class gets one more plugin per env kind / action type / integrator / motor lag that holds its instances of the two
+ * persistent launches of a horizon: vf_bptt_rollout / vf_bptt_reverse then serve its layer table (16 agents per wave with the sub-step
+ * tape: N <= 16 384 per launch), as vf_ppo_rollout does from the roll-out plugin. */
 int vf_chain_plugin_load(const char* path);
 int vf_chain_plugin_count(void);
 const char* vf_chain_plugin_name(int32_t i);
 int vf_chain_plugin_set_enabled(int on); /* 0: the loaded plugins are not asked (A/B against the block-tile kernels); returns the previous setting */
-int64_t vf_chain_plugin_launches(void); /* launches (queries included) the plugins have served since the library was loaded */
+int64_t vf_chain_plugin_launches(void); /* launches the plugins have served since the library was loaded (capability queries are not counted) */
 int vf_mlp_pack_weights(const vf_mlp_desc* desc, const float* params, float* packed, vf_stream_t stream);
 /* out1 == NULL: the caller does not need the value head -- the register-chained kernel then skips the value trunk
  * (its saved activations are left untouched); layer tables that run on the LDS kernel return VF_EUNSUPPORTED. */
@@ -841,8 +846,9 @@ int vf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  *   out           episode outputs as for vf_env_step; out->reward = N floats of scratch; obs / done are ignored
  *   obs_final     (N,13) observation after the last step;  tape [H] rows of tape_stride floats;  tape_done [H][N]
  *   d_reward      [H][N] = -disc_t * scale;  loss / disc (N,) in/out as for vf_bptt_accumulate
- * VF_EUNSUPPORTED unless: policy-only network of the register-chained classes, Hover / Racing / Navigation env with the
- * raw-state observation, thrust / bodyrate actions, Euler or (repaired, utils/maths.py:353-386) RK4, ctrl_delay, constant wind;
+ * VF_EUNSUPPORTED unless: actor network of the built-in register-chained classes (or of a generated class whose BPTT plugin for this
+ * configuration is loaded: vf_chain_plugin_load), Hover / Racing / Navigation env (r05: the *2 observation variants; r06: RacingEnv2's
+ * 16 gate-relative columns), thrust / bodyrate actions, Euler or (repaired, utils/maths.py:353-386) RK4, with / without ctrl_delay, constant wind;
  * per-agent drag randomisation (dynamics.py:244-267) is carried in the slab's drag granules.
  *   substep_tape  optional (NULL: off), [H][S + 3][W][64] float4 with S = interval_steps and W = ceil(N / 16) waves: for every
  *                 (step, wave of 16 agents) S + 3 rows of 1 KiB.  Rows 0 .. S are component-major: the float4 at [k * 16 + m] of
@@ -963,8 +969,9 @@ int vf_twin_q_loss(const float* q0, const float* q1, const float* target, float*
  *                       / vf_mlp_backward_data (no input gradient); in0 = the extractor's observation rows, in1 = the action rows;
  *                       leaves the saved inputs X, the masked gradients dZ and dQ1 / dQ2 (the head entries' dY) for
  *                       vf_mlp_weight_grad, loss_out[0] as vf_twin_q_loss.  scratch: vf_twin_q_update_scratch_doubles(M) doubles.
- *                       VF_EUNSUPPORTED when the tables are not the instantiated class (td_policies.ContinuousCritic over a
- *                       StateExtractor): the caller then runs vf_mlp_forward / vf_twin_q_loss / vf_mlp_backward_data. */
+ *                       VF_EUNSUPPORTED when the tables are neither the built-in class (td_policies.ContinuousCritic over a
+ *                       StateExtractor [128, 64], qf [64, 64]) nor a loaded generated twin-critic class (r06): the caller then runs
+ *                       vf_mlp_forward / vf_twin_q_loss / vf_mlp_backward_data. */
 int64_t vf_twin_q_update_scratch_doubles(int32_t M);
 int vf_twin_q_update(const vf_mlp_desc* fwd, const vf_mlp_bwd_desc* bwd, const float* params, const float* packed, const float* in0,
                      const float* in1, const float* target, float* loss_out, double* scratch, int32_t M, int64_t M_global,

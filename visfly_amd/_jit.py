@@ -12,6 +12,11 @@ Shapes that qualify: 1-2 observation branches of <= 32 columns, 1-4 layers per b
 the actor-critic heads (4, 1), the SAC-style Actor's (4, 4), or the twin critic's (1, 1) with its pass-through action input behind ONE
 observation branch.  Everything else keeps running on the block-tile kernels (MlpPolicy warns once).
 ``VISFLY_AMD_JIT=0`` switches the compilation off.
+
+Two more plugin kinds hold ONE instance each of a persistent launch for a generated class under one env kind / action type / integrator /
+motor-lag setting, built when a trainer first needs them: the roll-out plugin (PPO's collect_rollouts: ``ensure_rollout``,
+csrc/vf_ppo_rollout_kernel.hpp) and, r06, the BPTT plugin (both halves of a BPTT / SHAC horizon for an actor class: ``ensure_bptt``,
+csrc/vf_bptt_rollout_kernel.hpp + csrc/vf_bptt_reverse_kernel.hpp).
 """
 import hashlib
 import os
