@@ -68,6 +68,27 @@ def test_plugin_builds_loads_and_is_checked(tmp_path):
     assert lib.vf_chain_plugin_count() == n1
 
 
+def test_bptt_and_critic_plugins_build_and_load():
+    """r06: the two further plugin kinds cross-compile without a GPU and register: a twin-critic class (PASS = 1, heads 1 / 1) and a BPTT
+    plugin (one instance each of k_bptt_rollout / k_bptt_reverse for a generated actor class under one env configuration); distinct cache
+    files per configuration"""
+    from visfly_amd import _jit, _lib
+    lib = _lib.lib()
+    csh = _jit.shape_of(*_jit.PREBUILD_CRITIC["critic_hover"])
+    ash = _jit.shape_of(*_jit.PREBUILD_SAC["sac_hover"])
+    cfg = ("bptt", 0, 1, 0, True)
+    src = _jit.bptt_source(ash, cfg[1:])
+    assert "VF_CHAIN_PLUGIN_BPTT_DEFINE(Net, NetPi, 0, 1, 0, true," in src and '#include "vf_bptt_reverse_kernel.hpp"' in src
+    assert _jit.path_of(ash, cfg) != _jit.path_of(ash, ("bptt", 1, 1, 0, True)) != _jit.path_of(ash) and "_bptt0101_" in _jit.path_of(ash, cfg)
+    for path in (_jit.build(csh), _jit.build(ash, rollout=cfg)):
+        assert os.path.exists(path)
+        _lib.check(lib.vf_chain_plugin_load(path.encode()))
+    names = [lib.vf_chain_plugin_name(i) for i in range(lib.vf_chain_plugin_count())]
+    assert _jit.name_of(csh).encode() in names and any(b"BPTT horizon kind 0 act 1 int 0 delay 1" in n for n in names)
+    # the BPTT plugin is for ACTOR classes: not for the critic's shape, not for a built-in one
+    assert _jit.ensure_bptt(csh, cfg[1:]) is False and _jit.ensure_bptt(_jit.shape_of({"state": 13}, {"state": [128, 64]}, [64, 64], [64, 64], (4, 4)), cfg[1:]) is False
+
+
 def make(name, **kw):
     from visfly_amd.ppo import MlpPolicy
     dims, ext, pi, vf = SHAPES[name]
