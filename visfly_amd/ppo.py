@@ -145,7 +145,10 @@ class MlpPolicy:
         self.n_total = off
         for ly in self.layers:
             if ly.K > 128 or ly.No > 128:
-                raise ValueError("layer widths up to 128 are supported by the MFMA linear kernels")
+                raise ValueError(f"layer widths up to 128 are supported by the MFMA linear kernels (layer {ly.src} -> {ly.dst} is {ly.K} -> {ly.No}"
+                                 + (f": the extractor outputs {feat_w - sum(self.obs_dims[k] for k in self.passthrough)} features (+) "
+                                    f"{sum(self.obs_dims[k] for k in self.passthrough)} pass-through columns -- narrow the extractors' last layers"
+                                    if self.passthrough and ly.K == feat_w else "") + ")")
         # ---- parameters, reproducible from `seed`.  ortho_init (the reference's default, policies.py:109): SB3's
         # ActorCriticPolicy._build -- orthogonal weights with gain sqrt(2) for the extractor and trunk layers, 0.01 for
         # action_net, 1 for value_net, zero biases; otherwise nn.Linear's default (kaiming-uniform) ----
