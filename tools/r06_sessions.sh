@@ -129,6 +129,10 @@ functional) # end of the round: soak of the step kernels, PPO learning curve on 
     timeout 1500 python tools/soak_envs.py 50000 2>&1 | grep -v amdgpu.ids | tee $O/soak.txt
     timeout 900 python tools/exp_ppo_learn.py 40 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve.txt
     timeout 900 python tools/exp_ppo_learn.py 40 default 2>&1 | grep -v amdgpu.ids | tee $O/ppo_learning_curve_tanh.txt
+    timeout 900 python tools/exp_td_learn.py 60 2>&1 | grep -v amdgpu.ids | tee $O/td_learning_curves.txt
+    ;;
+tdlearn)  # BPTT / SHAC learning curves only
+    timeout 900 python tools/exp_td_learn.py 60 2>&1 | grep -v amdgpu.ids | tee $O/td_learning_curves.txt
     ;;
 fold)     # k_wgrad_fold with 8 / 16 / 32 / 64 partial rows in flight per lane (-DVF_FOLD_BATCH=1 / 2 / 4 / 8 builds): parity, A/B of the PPO step, kernel stats
     timeout 900 python -m pytest tests/test_ppo_gpu.py -x -q -m gpu -k "fused_optimiser_tail or fused_tail or bitwise or fold_partials or weight_grad" 2>&1 | tail -5 | tee $O/pytest.txt
